@@ -1,0 +1,212 @@
+/*
+ * mgx.h — C-ABI of the MI355X-native sequence-to-graph aligner (libmgx.so).
+ *
+ * This is the drop-in boundary for MetaGraph's `DBGAligner` hot path.  Every entry point
+ * cites the reference interface it stands in for (paths are into ratschlab/metagraph,
+ * `metagraph/src/...`).  Plain C types only: pointers + sizes, no C++/torch types.
+ *
+ * Ownership: inputs are caller-owned and only read during the call.  Results live in a
+ * library-owned arena attached to the aligner handle and stay valid until the next
+ * mgx_align_batch() on the same handle or mgx_aligner_destroy().
+ * Threading: one in-flight batch per aligner handle; several handles may share one graph
+ * (graph is immutable after creation), mirroring `DBGAligner` instances sharing a
+ * `const DeBruijnGraph&` (graph/alignment/dbg_aligner.hpp:63-64).
+ * Errors: every function returns MGX_OK (0) or a negative code; mgx_last_error() gives text.
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with
+ * MGX_ERR_NO_DEVICE.
+ */
+#ifndef MGX_H_
+#define MGX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_ABI_VERSION 1
+
+enum {
+    MGX_OK = 0,
+    MGX_ERR_INVALID = -1,      /* bad argument / malformed BOSS view */
+    MGX_ERR_NO_DEVICE = -2,    /* no HIP device / HIP runtime failure */
+    MGX_ERR_UNSUPPORTED = -3,  /* config outside the implemented path */
+    MGX_ERR_CONFIG = -4,       /* check_config_scores() failed (aligner_config.cpp:39-66);
+                                  the reference throws std::runtime_error (dbg_aligner.cpp:55-56) */
+    MGX_ERR_CAPACITY = -5,     /* a per-read device arena overflowed; see mgx_limits */
+    MGX_ERR_OOM = -6
+};
+
+/* Graph modes (graph/representation/base/sequence_graph.hpp:160). */
+enum { MGX_MODE_BASIC = 0, MGX_MODE_CANONICAL = 1, MGX_MODE_PRIMARY = 2 };
+
+/* CIGAR operators, numeric values identical to Cigar::Operator
+ * (graph/alignment/aligner_cigar.hpp:18-25); printed with "SX=DIG" (:107). */
+enum { MGX_OP_CLIPPED = 0, MGX_OP_MISMATCH = 1, MGX_OP_MATCH = 2,
+       MGX_OP_DELETION = 3, MGX_OP_INSERTION = 4, MGX_OP_NODE_INSERTION = 5 };
+
+/*
+ * A read-only view of a BOSS table — what `boss::BOSS` holds after load
+ * (graph/representation/succinct/boss.hpp:28-631; fields W_, last_, F_, k_).
+ * Edge indices are 1..n_edges; slot 0 of W/last is the unused sentinel slot
+ * (boss.cpp:74-83).  A DBG node IS a BOSS edge index (dbg_succinct.cpp:43-45).
+ */
+typedef struct mgx_boss_view {
+    uint32_t k;              /* DBG k-mer length = BOSS node length + 1 (dbg_succinct.cpp:44) */
+    uint32_t sigma;          /* alphabet size incl. '$'; must be 5 ("$ACGT", kmer/alphabets.hpp:64) */
+    uint64_t n_edges;        /* W/last have n_edges+1 entries */
+    const uint8_t *W;        /* one byte per edge, values 0..2*sigma-1 (boss.cpp:62) */
+    const uint8_t *last;     /* one byte per edge, 0/1 */
+    const uint64_t *F;       /* sigma entries (boss.hpp:506-510) */
+    const uint8_t *valid;    /* optional node mask, one byte per edge (dbg_succinct.cpp:934-936);
+                                NULL = every edge is a node, as after reset_mask() (cli/align.cpp:337-339) */
+    uint32_t mode;           /* MGX_MODE_*; only BASIC is implemented */
+    uint32_t on_device;      /* 0: W/last/valid are host pointers; 1: device pointers (F always host) */
+} mgx_boss_view;
+
+/* Field-for-field mirror of DBGAlignerConfig (graph/alignment/aligner_config.hpp:18-94). */
+typedef struct mgx_config {
+    uint64_t num_alternative_paths;    /* :23 */
+    uint64_t min_seed_length;          /* :24  (0 -> k, dbg_aligner.cpp:37-38) */
+    uint64_t max_seed_length;          /* :25  (0 -> k, dbg_aligner.cpp:43-44) */
+    uint64_t max_num_seeds_per_locus;  /* :26 */
+    int32_t min_cell_score;            /* :34 */
+    int32_t min_path_score;            /* :35 */
+    int32_t xdrop;                     /* :36 */
+    int32_t _pad0;
+    double min_exact_match;            /* :38 */
+    double max_nodes_per_seq_char;     /* :39 */
+    double max_ram_per_alignment;      /* :40 */
+    double rel_score_cutoff;           /* :41 */
+    int8_t gap_opening_penalty;        /* :43 */
+    int8_t gap_extension_penalty;      /* :44 */
+    int8_t left_end_bonus;             /* :45 */
+    int8_t right_end_bonus;            /* :46 */
+    uint8_t forward_and_reverse_complement; /* :48 */
+    uint8_t chain_alignments;          /* :49 (must be 0) */
+    uint8_t post_chain_alignments;     /* :50 (must be 0) */
+    uint8_t global_xdrop;              /* :51 (must be 1) */
+    uint8_t allow_left_trim;           /* :52 */
+    uint8_t no_backtrack;              /* :53 (must be 0) */
+    uint8_t seed_complexity_filter;    /* :54 */
+    uint8_t _pad1[5];
+    int8_t score_matrix[128][128];     /* :61 ScoreMatrix, [graph char][query char] */
+} mgx_config;
+
+/* Fill `c` with DBGAlignerConfig{} defaults (aligner_config.hpp:23-54); score matrix zeroed. */
+void mgx_config_init_default(mgx_config *c);
+/* Fill `c` with the `metagraph align` CLI defaults (cli/config/config.hpp:114-145 through
+ * cli/align.cpp:33-69), for a graph with k-mer length k. */
+void mgx_config_init_cli(mgx_config *c, uint32_t k);
+/* DBGAlignerConfig::dna_scoring_matrix (aligner_config.cpp:164-183); penalties are negative. */
+void mgx_config_set_dna_matrix(mgx_config *c, int8_t match, int8_t mm_transition, int8_t mm_transversion);
+/* DBGAlignerConfig::unit_scoring_matrix over "ACGT" (aligner_config.cpp:185-204). */
+void mgx_config_set_unit_matrix(mgx_config *c, int8_t match);
+
+/* Per-read device arena limits (no reference counterpart; the reference uses the heap). */
+typedef struct mgx_limits {
+    uint32_t max_query_length;   /* longest read accepted in a batch */
+    uint32_t max_columns;        /* DP-table columns per extension  */
+    uint32_t max_seeds;          /* seeds per read and strand       */
+    uint64_t cell_arena_bytes;   /* S/E/F storage per in-flight read */
+} mgx_limits;
+void mgx_limits_init_default(mgx_limits *l, uint32_t max_query_length);
+
+typedef struct mgx_graph mgx_graph;
+typedef struct mgx_aligner mgx_aligner;
+
+/* One CIGAR run: Cigar::value_type (aligner_cigar.hpp:28). */
+typedef struct mgx_cigar_op { uint32_t len; uint8_t op; uint8_t _pad[3]; } mgx_cigar_op;
+
+/* One alignment: the observable state of `Alignment` (graph/alignment/alignment.hpp:132-331). */
+typedef struct mgx_alignment {
+    int32_t score;            /* get_score() */
+    uint32_t offset;          /* get_offset() */
+    uint32_t clipping;        /* get_clipping() */
+    uint32_t end_clipping;    /* get_end_clipping() */
+    uint32_t num_matches;     /* get_cigar().get_num_matches() */
+    uint32_t n_nodes;         /* size() */
+    uint32_t n_cigar;
+    uint32_t seq_len;         /* get_sequence().size() */
+    uint64_t nodes_begin;     /* index into mgx_results.nodes */
+    uint64_t cigar_begin;     /* index into mgx_results.cigar */
+    uint64_t seq_begin;       /* index into mgx_results.seqs  */
+    uint8_t orientation;      /* get_orientation(): 1 = reverse complement of the query matched */
+    uint8_t _pad[7];
+} mgx_alignment;
+
+/* Results of one batch: AlignmentResults per query (alignment.hpp:366-406), in batch order. */
+typedef struct mgx_results {
+    uint64_t n_queries;
+    const uint64_t *aln_begin;        /* n_queries+1 prefix offsets into `alignments` */
+    const mgx_alignment *alignments;
+    const uint64_t *nodes;
+    const mgx_cigar_op *cigar;
+    const char *seqs;
+    const int32_t *status;            /* per query: MGX_OK or MGX_ERR_CAPACITY */
+} mgx_results;
+
+/* Seeding-only output (DeBruijnGraph::map_to_nodes_sequentially for both strands). */
+typedef struct mgx_mapping {
+    uint64_t n_queries;
+    const uint64_t *node_begin;       /* n_queries+1 prefix offsets (per strand array) */
+    const uint64_t *nodes_fwd;        /* BOSS::map_to_edges of the query (boss.cpp:996-1045) */
+    const uint64_t *nodes_rc;         /* ... of its reverse complement (sequence_graph.cpp:563-573) */
+} mgx_mapping;
+
+/* Counters for roofline accounting: BOSS primitives actually executed. */
+typedef struct mgx_stats {
+    uint64_t n_reads;
+    uint64_t n_rank_lines;      /* 64-B block reads issued for rank_W / W / last        */
+    uint64_t n_select_lines;    /* 64-B block reads issued for select_last / select_W  */
+    uint64_t n_bit_lines;       /* side-table reads (MEM terminus bits, first chars)   */
+    uint64_t n_columns;         /* DP columns computed                                  */
+    uint64_t n_extensions;      /* DefaultColumnExtender::extend calls                  */
+    uint64_t n_seeds;
+    double seed_kernel_ms, align_kernel_ms;   /* HIP-event time of the two kernels, last batch */
+} mgx_stats;
+
+int mgx_device_count(void);                 /* number of visible HIP devices (0 without a GPU) */
+const char *mgx_last_error(void);
+uint32_t mgx_abi_version(void);
+
+/* Upload a BOSS table and build the device index.  Replaces BOSS::load + DBGSuccinct::load
+ * (boss.cpp:338-394, dbg_succinct.cpp:690-785) as the source of W/last/F.  `device` is the HIP ordinal. */
+int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out);
+void mgx_graph_destroy(mgx_graph *g);
+uint32_t mgx_graph_k(const mgx_graph *g);            /* DeBruijnGraph::get_k  (sequence_graph.hpp:176) */
+uint64_t mgx_graph_max_index(const mgx_graph *g);    /* DeBruijnGraph::max_index (dbg_succinct.cpp:686-688) */
+uint64_t mgx_graph_device_bytes(const mgx_graph *g);
+
+/* DBGAligner<>::DBGAligner(graph, config) (dbg_aligner.cpp:33-61): clamps seed lengths,
+ * validates scores.  `limits` may be NULL (defaults for 512-bp reads). */
+int mgx_aligner_create(const mgx_graph *g, const mgx_config *config,
+                       const mgx_limits *limits, mgx_aligner **out);
+void mgx_aligner_destroy(mgx_aligner *a);
+/* IDBGAligner::get_config() after clamping. */
+int mgx_aligner_get_config(const mgx_aligner *a, mgx_config *out);
+
+/* IDBGAligner::align_batch (dbg_aligner.hpp:32-33, dbg_aligner.cpp:251-355).
+ * `seqs` holds the concatenated raw query bytes, query i = seqs[offsets[i] .. offsets[i+1]).
+ * With seqs_on_device != 0, `seqs` and `offsets` are device pointers (reads already in HBM). */
+int mgx_align_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uint64_t n_queries,
+                    int seqs_on_device, mgx_results *out);
+
+/* Hot loop #1 only: map both strands to nodes (dbg_aligner.cpp:210,227-231). */
+int mgx_map_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uint64_t n_queries,
+                  int seqs_on_device, mgx_mapping *out);
+
+int mgx_aligner_stats(const mgx_aligner *a, mgx_stats *out);
+
+/* Format one query's results exactly like format_alignment() (cli/align.cpp:254-285):
+ * "header\tquery\t(+|-)\tpath\tscore\tnum_matches\tcigar\toffset\n", or the "*" line.
+ * Returns the number of bytes needed (excluding NUL); writes at most buf_len bytes. */
+size_t mgx_format_tsv(const mgx_results *res, uint64_t query_index, const char *header,
+                      const char *query, size_t query_len, int32_t min_path_score,
+                      char *buf, size_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H_ */

@@ -1,0 +1,196 @@
+"""ctypes mirror of include/mgx.h and the loader for libmgx.so (the HIP product library).
+
+PyTorch / Python are plumbing here: the product is the C-ABI library.  There is no CPU fallback;
+if libmgx.so is missing the import of `lib()` raises, and every compute call fails without a GPU.
+"""
+import ctypes as C
+import os
+
+MGX_OK = 0
+MGX_ERR_INVALID, MGX_ERR_NO_DEVICE, MGX_ERR_UNSUPPORTED, MGX_ERR_CONFIG, MGX_ERR_CAPACITY, MGX_ERR_OOM = -1, -2, -3, -4, -5, -6
+OP_CHARS = "SX=DIG"
+
+
+class BossView(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("sigma", C.c_uint32), ("n_edges", C.c_uint64),
+                ("W", C.c_void_p), ("last", C.c_void_p), ("F", C.POINTER(C.c_uint64)),
+                ("valid", C.c_void_p), ("mode", C.c_uint32), ("on_device", C.c_uint32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("num_alternative_paths", C.c_uint64), ("min_seed_length", C.c_uint64),
+                ("max_seed_length", C.c_uint64), ("max_num_seeds_per_locus", C.c_uint64),
+                ("min_cell_score", C.c_int32), ("min_path_score", C.c_int32), ("xdrop", C.c_int32),
+                ("_pad0", C.c_int32),
+                ("min_exact_match", C.c_double), ("max_nodes_per_seq_char", C.c_double),
+                ("max_ram_per_alignment", C.c_double), ("rel_score_cutoff", C.c_double),
+                ("gap_opening_penalty", C.c_int8), ("gap_extension_penalty", C.c_int8),
+                ("left_end_bonus", C.c_int8), ("right_end_bonus", C.c_int8),
+                ("forward_and_reverse_complement", C.c_uint8), ("chain_alignments", C.c_uint8),
+                ("post_chain_alignments", C.c_uint8), ("global_xdrop", C.c_uint8),
+                ("allow_left_trim", C.c_uint8), ("no_backtrack", C.c_uint8),
+                ("seed_complexity_filter", C.c_uint8), ("_pad1", C.c_uint8 * 5),
+                ("score_matrix", (C.c_int8 * 128) * 128)]
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_query_length", C.c_uint32), ("max_columns", C.c_uint32), ("max_seeds", C.c_uint32),
+                ("cell_arena_bytes", C.c_uint64)]
+
+
+class CigarOp(C.Structure):
+    _fields_ = [("len", C.c_uint32), ("op", C.c_uint8), ("_pad", C.c_uint8 * 3)]
+
+
+class Alignment(C.Structure):
+    _fields_ = [("score", C.c_int32), ("offset", C.c_uint32), ("clipping", C.c_uint32),
+                ("end_clipping", C.c_uint32), ("num_matches", C.c_uint32), ("n_nodes", C.c_uint32),
+                ("n_cigar", C.c_uint32), ("seq_len", C.c_uint32), ("nodes_begin", C.c_uint64),
+                ("cigar_begin", C.c_uint64), ("seq_begin", C.c_uint64), ("orientation", C.c_uint8),
+                ("_pad", C.c_uint8 * 7)]
+
+
+class Results(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("aln_begin", C.POINTER(C.c_uint64)),
+                ("alignments", C.POINTER(Alignment)), ("nodes", C.POINTER(C.c_uint64)),
+                ("cigar", C.POINTER(CigarOp)), ("seqs", C.POINTER(C.c_char)), ("status", C.POINTER(C.c_int32))]
+
+
+class Mapping(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("node_begin", C.POINTER(C.c_uint64)),
+                ("nodes_fwd", C.POINTER(C.c_uint64)), ("nodes_rc", C.POINTER(C.c_uint64))]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_rank_lines", C.c_uint64), ("n_select_lines", C.c_uint64),
+                ("n_bit_lines", C.c_uint64), ("n_columns", C.c_uint64), ("n_extensions", C.c_uint64),
+                ("n_seeds", C.c_uint64), ("seed_kernel_ms", C.c_double), ("align_kernel_ms", C.c_double)]
+
+
+def results_to_py(res):
+    """Decode an mgx_results view into a list (per query) of lists of dicts."""
+    out = []
+    for q in range(res.n_queries):
+        alns = []
+        for ai in range(res.aln_begin[q], res.aln_begin[q + 1]):
+            a = res.alignments[ai]
+            nodes = [res.nodes[a.nodes_begin + i] for i in range(a.n_nodes)]
+            cig = "".join("%d%s" % (res.cigar[a.cigar_begin + i].len, OP_CHARS[res.cigar[a.cigar_begin + i].op])
+                          for i in range(a.n_cigar))
+            seq = C.string_at(C.addressof(res.seqs.contents) + a.seq_begin, a.seq_len).decode() if a.seq_len else ""
+            alns.append({"score": a.score, "offset": a.offset, "clipping": a.clipping,
+                         "end_clipping": a.end_clipping, "num_matches": a.num_matches, "nodes": nodes,
+                         "cigar": cig, "sequence": seq, "orientation": int(a.orientation)})
+        out.append(alns)
+    return out
+
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_ROOT, "metagraph_amd", "_build", "libmgx.so")
+_lib = None
+
+
+def lib():
+    """Load libmgx.so (raises OSError if it has not been built — there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libmgx.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(needs hipcc); the aligner has no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.mgx_last_error.restype = C.c_char_p
+    L.mgx_abi_version.restype = C.c_uint32
+    L.mgx_device_count.restype = C.c_int
+    L.mgx_graph_create.argtypes = [C.POINTER(BossView), C.c_int, C.POINTER(C.c_void_p)]
+    L.mgx_graph_destroy.argtypes = [C.c_void_p]
+    L.mgx_graph_k.argtypes = [C.c_void_p]
+    L.mgx_graph_k.restype = C.c_uint32
+    L.mgx_graph_max_index.argtypes = [C.c_void_p]
+    L.mgx_graph_max_index.restype = C.c_uint64
+    L.mgx_graph_device_bytes.argtypes = [C.c_void_p]
+    L.mgx_graph_device_bytes.restype = C.c_uint64
+    L.mgx_aligner_create.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(Limits), C.POINTER(C.c_void_p)]
+    L.mgx_aligner_destroy.argtypes = [C.c_void_p]
+    L.mgx_aligner_get_config.argtypes = [C.c_void_p, C.POINTER(Config)]
+    L.mgx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Results)]
+    L.mgx_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Mapping)]
+    L.mgx_aligner_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.mgx_config_init_default.argtypes = [C.POINTER(Config)]
+    L.mgx_config_init_cli.argtypes = [C.POINTER(Config), C.c_uint32]
+    L.mgx_config_set_dna_matrix.argtypes = [C.POINTER(Config), C.c_int8, C.c_int8, C.c_int8]
+    L.mgx_config_set_unit_matrix.argtypes = [C.POINTER(Config), C.c_int8]
+    L.mgx_limits_init_default.argtypes = [C.POINTER(Limits), C.c_uint32]
+    L.mgx_format_tsv.argtypes = [C.POINTER(Results), C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t,
+                                 C.c_int32, C.c_char_p, C.c_size_t]
+    L.mgx_format_tsv.restype = C.c_size_t
+    _lib = L
+    return L
+
+
+# ---- host-side config helpers that do not need the library (same tables as mgx_config_init_*) ----
+INT32_MAX = 2**31 - 1
+NINF = -2**31 + 100
+UINT64_MAX = 2**64 - 1
+DBL_MAX = 1.7976931348623157e308
+
+
+def config_default():
+    """DBGAlignerConfig{} (graph/alignment/aligner_config.hpp:23-54)."""
+    c = Config()
+    c.num_alternative_paths = 1
+    c.max_num_seeds_per_locus = UINT64_MAX
+    c.min_cell_score = NINF
+    c.min_path_score = 0
+    c.xdrop = INT32_MAX
+    c.min_exact_match = 0.0
+    c.max_nodes_per_seq_char = DBL_MAX
+    c.max_ram_per_alignment = DBL_MAX
+    c.rel_score_cutoff = 0.0
+    c.gap_opening_penalty = -5
+    c.gap_extension_penalty = -2
+    c.forward_and_reverse_complement = 1
+    c.global_xdrop = 1
+    c.allow_left_trim = 1
+    c.seed_complexity_filter = 1
+    return c
+
+
+def set_dna_matrix(c, match, transition, transversion):
+    """DBGAlignerConfig::dna_scoring_matrix (aligner_config.cpp:164-183)."""
+    for i in range(128):
+        for j in range(128):
+            c.score_matrix[i][j] = transversion
+    for a, b in (("A", "G"), ("G", "A"), ("C", "T"), ("T", "C")):
+        c.score_matrix[ord(a)][ord(b)] = transition
+    for a in "ACGT":
+        c.score_matrix[ord(a)][ord(a)] = match
+
+
+def set_unit_matrix(c, match):
+    """DBGAlignerConfig::unit_scoring_matrix over "ACGT" (aligner_config.cpp:185-204)."""
+    for i in range(128):
+        for j in range(128):
+            c.score_matrix[i][j] = -match
+    for a in "ACGT":
+        c.score_matrix[ord(a)][ord(a)] = match
+
+
+def config_cli(k):
+    """`metagraph align` defaults (cli/config/config.hpp:114-145 via cli/align.cpp:33-69)."""
+    c = config_default()
+    c.min_seed_length = min(19, k)
+    c.max_seed_length = UINT64_MAX
+    c.max_num_seeds_per_locus = 1000
+    c.min_path_score = 0
+    c.xdrop = 27
+    c.min_exact_match = 0.7
+    c.max_nodes_per_seq_char = 5.0
+    c.max_ram_per_alignment = 200.0
+    c.rel_score_cutoff = 0.95
+    c.gap_opening_penalty = -6
+    c.gap_extension_penalty = -2
+    c.left_end_bonus = 5
+    c.right_end_bonus = 5
+    set_dna_matrix(c, 2, -3, -3)
+    return c

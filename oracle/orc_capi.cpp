@@ -1,0 +1,250 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  C API over the CPU restatement so that tests/ (ctypes) and
+// bench.py's cpu_baseline leg can drive it.  Result layout = include/mgx.h so that GPU and oracle
+// outputs can be compared field by field.  Never linked into libmgx.so.
+#include <atomic>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "orc_align.hpp"
+
+using namespace orc;
+
+namespace orc { extern uint64_t g_oob_reads_total(); }
+
+namespace {
+struct ResultStore {
+    std::vector<uint64_t> aln_begin;
+    std::vector<mgx_alignment> alignments;
+    std::vector<uint64_t> nodes;
+    std::vector<mgx_cigar_op> cigar;
+    std::string seqs;
+    std::vector<int32_t> status;
+    // mapping
+    std::vector<uint64_t> node_begin, nodes_fwd, nodes_rc;
+    // seeds, flattened: per query and strand
+    std::vector<uint64_t> seed_begin[2];           // n_queries + 1
+    std::vector<uint32_t> seed_meta[2];            // 4 per seed: clipping, length, offset, n_nodes
+    std::vector<uint64_t> seed_node_begin[2];      // per seed + 1
+    std::vector<uint64_t> seed_nodes[2];
+    std::vector<uint64_t> num_matches[2];
+    std::string tsv;
+    WorkCounters wc;
+    std::string error;
+};
+
+void flatten(const std::vector<AlignmentResults> &res, ResultStore *st, int32_t min_path_score) {
+    st->aln_begin.assign(1, 0);
+    st->node_begin.assign(1, 0);
+    for (int s = 0; s < 2; ++s) { st->seed_begin[s].assign(1, 0); st->seed_node_begin[s].assign(1, 0); }
+    for (const auto &r : res) {
+        for (const auto &a : r.alignments) {
+            mgx_alignment m;
+            std::memset(&m, 0, sizeof(m));
+            m.score = a.score; m.offset = a.offset; m.clipping = a.get_clipping();
+            m.end_clipping = a.get_end_clipping(); m.num_matches = a.cigar.get_num_matches();
+            m.n_nodes = a.nodes.size(); m.n_cigar = a.cigar.ops.size(); m.seq_len = a.sequence.size();
+            m.nodes_begin = st->nodes.size(); m.cigar_begin = st->cigar.size(); m.seq_begin = st->seqs.size();
+            m.orientation = a.orientation;
+            st->nodes.insert(st->nodes.end(), a.nodes.begin(), a.nodes.end());
+            for (auto &op : a.cigar.ops) { mgx_cigar_op o; std::memset(&o, 0, sizeof(o)); o.len = op.second; o.op = op.first; st->cigar.push_back(o); }
+            st->seqs += a.sequence;
+            st->alignments.push_back(m);
+        }
+        st->aln_begin.push_back(st->alignments.size());
+        st->status.push_back(MGX_OK);
+        // mapping: both strands padded to the same per-query count
+        size_t n = std::max(r.nodes_fwd.size(), r.nodes_rc.size());
+        for (size_t i = 0; i < n; ++i) {
+            st->nodes_fwd.push_back(i < r.nodes_fwd.size() ? r.nodes_fwd[i] : 0);
+            st->nodes_rc.push_back(i < r.nodes_rc.size() ? r.nodes_rc[i] : 0);
+        }
+        st->node_begin.push_back(st->nodes_fwd.size());
+        const std::vector<Seed> *seeds[2] = { &r.seeds_fwd, &r.seeds_rc };
+        for (int s = 0; s < 2; ++s) {
+            for (const auto &sd : *seeds[s]) {
+                st->seed_meta[s].push_back(sd.clipping);
+                st->seed_meta[s].push_back(sd.query_view.size());
+                st->seed_meta[s].push_back(sd.offset);
+                st->seed_meta[s].push_back(sd.nodes.size());
+                st->seed_nodes[s].insert(st->seed_nodes[s].end(), sd.nodes.begin(), sd.nodes.end());
+                st->seed_node_begin[s].push_back(st->seed_nodes[s].size());
+            }
+            st->seed_begin[s].push_back(st->seed_meta[s].size() / 4);
+        }
+        st->num_matches[0].push_back(r.num_matches_fwd);
+        st->num_matches[1].push_back(r.num_matches_rc);
+    }
+    (void)min_path_score;
+}
+} // namespace
+
+extern "C" {
+
+void *orc_graph_build(uint32_t k, uint32_t n_seqs, const char **seqs, uint32_t mode, int mask_dummy) {
+    try {
+        auto *g = new Graph();
+        std::vector<std::string> v(seqs, seqs + n_seqs);
+        g->boss = build_boss(k, v, (Mode)mode);
+        g->mode = (Mode)mode;
+        if (mask_dummy) g->mask_dummy_kmers();
+        return g;
+    } catch (...) { return nullptr; }
+}
+
+void *orc_graph_from_boss(const mgx_boss_view *view) {
+    auto *g = new Graph();
+    g->boss.k_ = view->k - 1;
+    g->boss.n = view->n_edges;
+    g->boss.W.assign(view->W, view->W + view->n_edges + 1);
+    g->boss.last.assign(view->last, view->last + view->n_edges + 1);
+    for (int c = 0; c < SIGMA; ++c) g->boss.F[c] = view->F[c];
+    if (view->valid) g->valid.assign(view->valid, view->valid + view->n_edges + 1);
+    g->mode = (Mode)view->mode;
+    g->boss.finalize();
+    return g;
+}
+
+void orc_graph_free(void *h) { delete static_cast<Graph *>(h); }
+uint64_t orc_graph_num_edges(void *h) { return static_cast<Graph *>(h)->boss.n; }
+uint32_t orc_graph_k(void *h) { return static_cast<Graph *>(h)->get_k(); }
+uint64_t orc_graph_num_nodes(void *h) { return static_cast<Graph *>(h)->num_nodes(); }
+int orc_graph_has_mask(void *h) { return !static_cast<Graph *>(h)->valid.empty(); }
+
+// copies W/last (n_edges + 1 bytes each), F (5), valid (n_edges + 1, only if the graph has a mask)
+void orc_graph_export(void *h, uint8_t *W, uint8_t *last, uint64_t *F, uint8_t *valid) {
+    auto *g = static_cast<Graph *>(h);
+    std::memcpy(W, g->boss.W.data(), g->boss.n + 1);
+    std::memcpy(last, g->boss.last.data(), g->boss.n + 1);
+    for (int c = 0; c < SIGMA; ++c) F[c] = g->boss.F[c];
+    if (valid && !g->valid.empty()) std::memcpy(valid, g->valid.data(), g->boss.n + 1);
+}
+
+// writes the node's k-mer into out (k bytes)
+void orc_graph_node_sequence(void *h, uint64_t node, char *out) {
+    std::string s = static_cast<Graph *>(h)->get_node_sequence(node);
+    std::memcpy(out, s.data(), s.size());
+}
+
+// primitives for parity tests of the device BOSS layer; out arrays sized by the caller
+uint64_t orc_boss_fwd(void *h, uint64_t i, uint32_t c) { return static_cast<Graph *>(h)->boss.fwd(i, c); }
+uint64_t orc_boss_bwd(void *h, uint64_t i) { return static_cast<Graph *>(h)->boss.bwd(i); }
+uint64_t orc_boss_rank_W(void *h, uint64_t i, uint32_t c) { return static_cast<Graph *>(h)->boss.rank_W(i, c); }
+uint64_t orc_boss_select_last(void *h, uint64_t r) { return static_cast<Graph *>(h)->boss.select_last(r); }
+uint64_t orc_boss_rank_last(void *h, uint64_t i) { return static_cast<Graph *>(h)->boss.rank_last(i); }
+int orc_graph_has_multiple_outgoing(void *h, uint64_t v) { return static_cast<Graph *>(h)->has_multiple_outgoing(v); }
+int orc_graph_has_single_incoming(void *h, uint64_t v) { return static_cast<Graph *>(h)->has_single_incoming(v); }
+// children (rc=0) or RC-graph children (rc=1): up to 8 (node, char) pairs; returns count
+uint32_t orc_graph_outgoing(void *h, uint64_t v, int rc, uint64_t *nodes, char *chars) {
+    GraphView view{ static_cast<Graph *>(h), rc != 0 };
+    uint32_t n = 0;
+    view.call_outgoing_kmers(v, [&](node_t nn, char c) { if (n < 8) { nodes[n] = nn; chars[n] = c; } ++n; });
+    return n;
+}
+// suffix matching; returns number of nodes (written up to cap), *match_len = matched length
+uint32_t orc_graph_suffix_match(void *h, const char *str, uint32_t len, uint32_t min_len, uint64_t max_matches,
+                                uint64_t *nodes, uint32_t cap, uint32_t *match_len) {
+    uint32_t n = 0;
+    *match_len = 0;
+    static_cast<Graph *>(h)->call_nodes_with_suffix_matching_longest_prefix(
+        std::string_view(str, len),
+        [&](node_t v, uint64_t l) { if (n < cap) nodes[n] = v; ++n; *match_len = l; },
+        min_len, max_matches ? max_matches : SIZE_MAX);
+    return n;
+}
+
+int orc_is_low_complexity(const char *s, uint32_t len) { return is_low_complexity(std::string_view(s, len)); }
+int orc_check_config(const mgx_config *c) { return check_config_scores(*c); }
+uint64_t orc_oob_reads() { return g_oob_reads_total(); }
+
+// Align a batch with `threads` worker threads (thread pool over sub-batches like cli/align.cpp:415-480).
+// validate != 0 additionally runs Alignment::is_valid on every result (alignment.cpp:1316-1345).
+void *orc_align_batch(void *h, const mgx_config *config, const char *seqs, const uint64_t *offsets,
+                      uint64_t n, uint32_t threads, int validate) {
+    auto *g = static_cast<Graph *>(h);
+    auto *st = new ResultStore();
+    try {
+        Aligner aligner(*g, *config);
+        std::vector<std::string> queries(n);
+        for (uint64_t i = 0; i < n; ++i) queries[i].assign(seqs + offsets[i], seqs + offsets[i + 1]);
+        std::vector<AlignmentResults> res(n);
+        if (threads <= 1) {
+            aligner.align_batch(queries, &res, &st->wc);
+        } else {
+            std::atomic<uint64_t> next{ 0 };
+            const uint64_t chunk = 256;
+            std::vector<std::thread> pool;
+            std::vector<WorkCounters> wcs(threads);
+            for (uint32_t t = 0; t < threads; ++t) {
+                pool.emplace_back([&, t]() {
+                    for (;;) {
+                        uint64_t b = next.fetch_add(chunk);
+                        if (b >= n) break;
+                        uint64_t e = std::min(n, b + chunk);
+                        std::vector<std::string> sub(queries.begin() + b, queries.begin() + e);
+                        std::vector<AlignmentResults> r;
+                        aligner.align_batch(sub, &r, &wcs[t]);
+                        for (uint64_t i = b; i < e; ++i) res[i] = std::move(r[i - b]);
+                    }
+                });
+            }
+            for (auto &th : pool) th.join();
+            for (auto &w : wcs) st->wc.add(w);
+        }
+        if (validate) {
+            GraphView view{ g, false };
+            const mgx_config &cfg = aligner.get_config();
+            for (uint64_t i = 0; i < n; ++i)
+                for (auto &a : res[i].alignments) {
+                    std::string why;
+                    if (!a.is_valid(view, &cfg, &why)) { st->error = "query " + std::to_string(i) + ": " + why; break; }
+                }
+        }
+        flatten(res, st, config->min_path_score);
+        for (uint64_t i = 0; i < n; ++i) st->tsv += format_alignment_tsv(std::to_string(i), res[i], config->min_path_score);
+    } catch (const std::exception &e) {
+        st->error = e.what();
+    }
+    return st;
+}
+
+const char *orc_results_error(void *r) { return static_cast<ResultStore *>(r)->error.c_str(); }
+void orc_results_view(void *r, mgx_results *out) {
+    auto *st = static_cast<ResultStore *>(r);
+    out->n_queries = st->status.size();
+    out->aln_begin = st->aln_begin.data();
+    out->alignments = st->alignments.data();
+    out->nodes = st->nodes.data();
+    out->cigar = st->cigar.data();
+    out->seqs = st->seqs.data();
+    out->status = st->status.data();
+}
+void orc_results_mapping(void *r, mgx_mapping *out) {
+    auto *st = static_cast<ResultStore *>(r);
+    out->n_queries = st->status.size();
+    out->node_begin = st->node_begin.data();
+    out->nodes_fwd = st->nodes_fwd.data();
+    out->nodes_rc = st->nodes_rc.data();
+}
+// seeds of one strand: begin[n+1], meta[4*n_seeds], node_begin[n_seeds+1], nodes[], num_matches[n]
+void orc_results_seeds(void *r, int strand, const uint64_t **begin, const uint32_t **meta,
+                       const uint64_t **node_begin, const uint64_t **nodes, const uint64_t **num_matches) {
+    auto *st = static_cast<ResultStore *>(r);
+    *begin = st->seed_begin[strand].data();
+    *meta = st->seed_meta[strand].data();
+    *node_begin = st->seed_node_begin[strand].data();
+    *nodes = st->seed_nodes[strand].data();
+    *num_matches = st->num_matches[strand].data();
+}
+const char *orc_results_tsv(void *r) { return static_cast<ResultStore *>(r)->tsv.c_str(); }
+// n_map_fwd, n_index_steps, n_terminus, n_expansions, n_columns, n_extensions, n_seeds
+void orc_results_counters(void *r, uint64_t *out7) {
+    auto &w = static_cast<ResultStore *>(r)->wc;
+    out7[0] = w.n_map_fwd; out7[1] = w.n_index_steps; out7[2] = w.n_terminus; out7[3] = w.n_expansions;
+    out7[4] = w.n_columns; out7[5] = w.n_extensions; out7[6] = w.n_seeds;
+}
+void orc_results_free(void *r) { delete static_cast<ResultStore *>(r); }
+
+} // extern "C"

@@ -1,0 +1,561 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see orc_graph.hpp header).
+#include "orc_graph.hpp"
+
+#include <algorithm>
+#include <cassert>
+#include <cstring>
+#include <map>
+#include <set>
+#include <stdexcept>
+
+namespace orc {
+
+// ---------------------------------------------------------------------------------------------
+// alphabet tables
+// ---------------------------------------------------------------------------------------------
+uint8_t encode_char(char ch) {
+    // kmer/alphabets.hpp:67-76; bytes < 0 -> table[0] (kmer_extractor.cpp:33-36)
+    int8_t s = static_cast<int8_t>(ch);
+    if (s < 0) return 5;
+    switch (s) {
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 3;
+        case 'T': case 't': case 'U': case 'u': return 4;
+        default: return 5;
+    }
+}
+
+std::vector<uint8_t> encode_seq(std::string_view s) {
+    std::vector<uint8_t> r(s.size());
+    for (size_t i = 0; i < s.size(); ++i) r[i] = encode_char(s[i]);
+    return r;
+}
+
+char complement_char(char c) {
+    // COMPL_TAB, common/seq_tools/reverse_complement.hpp:31-48 (seqtk table)
+    static const unsigned char up[26] = {
+        'T','V','G','H','E','F','C','D','I','J','M','L','K','N','O',
+        'P','Q','Y','S','A','A','B','W','X','R','Z' };
+    unsigned char u = static_cast<unsigned char>(c);
+    if (u >= 'A' && u <= 'Z') return up[u - 'A'];
+    if (u >= 'a' && u <= 'z') return up[u - 'a'] + ('a' - 'A');
+    if (u == 96) return 64;  // table quirk: entry 96 is 64
+    return c;
+}
+
+void reverse_complement_inplace(std::string &s) {
+    // reverse_complement.hpp:50-63
+    std::reverse(s.begin(), s.end());
+    for (char &c : s) c = complement_char(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Boss: support structures
+// ---------------------------------------------------------------------------------------------
+void Boss::finalize() {
+    assert(W.size() == n + 1 && last.size() == n + 1);
+    size_t nb = (n + 1 + 63) / 64;
+    w_cum.assign((nb + 1) * SIGMA, 0);
+    last_cum.assign(nb + 1, 0);
+    last_hint.clear();
+    for (int c = 0; c < SIGMA; ++c) w_hint[c].clear();
+    uint64_t cnt[SIGMA] = {0}, lc = 0;
+    for (size_t b = 0; b < nb; ++b) {
+        for (int c = 0; c < SIGMA; ++c) w_cum[b * SIGMA + c] = cnt[c];
+        last_cum[b] = lc;
+        size_t e = std::min<size_t>((b + 1) * 64, n + 1);
+        for (size_t i = b * 64; i < e; ++i) {
+            if (i == 0) continue;                        // slot 0 is not an edge
+            if (W[i] < SIGMA) {
+                if (cnt[W[i]] % 64 == 0) w_hint[W[i]].push_back(b);
+                ++cnt[W[i]];
+            }
+            if (last[i]) {
+                if (lc % 64 == 0) last_hint.push_back(b);
+                ++lc;
+            }
+        }
+    }
+    for (int c = 0; c < SIGMA; ++c) w_cum[nb * SIGMA + c] = cnt[c];
+    last_cum[nb] = lc;
+    for (int c = 0; c < SIGMA; ++c) NF[c] = rank_last(F[c]);     // boss.cpp:1095-1101
+}
+
+uint64_t Boss::rank_W(edge_t i, uint8_t c) const {
+    // boss.cpp:437-441: occurrences of c in W[1..i] (slot 0 excluded)
+    assert(c < SIGMA && i <= n);
+    size_t b = i / 64;
+    uint64_t r = w_cum[b * SIGMA + c];
+    for (size_t j = std::max<size_t>(b * 64, 1); j <= i; ++j) r += (W[j] == c);
+    return r;
+}
+
+uint64_t Boss::rank_last(edge_t i) const {
+    assert(i <= n);
+    size_t b = i / 64;
+    uint64_t r = last_cum[b];
+    for (size_t j = std::max<size_t>(b * 64, 1); j <= i; ++j) r += last[j];
+    return r;
+}
+
+edge_t Boss::select_last(uint64_t r) const {
+    if (r == 0) return 0;
+    size_t b = last_hint[(r - 1) / 64];
+    while (last_cum[b + 1] < r) ++b;
+    uint64_t c = last_cum[b];
+    for (size_t j = std::max<size_t>(b * 64, 1);; ++j) {
+        c += last[j];
+        if (c == r) return j;
+    }
+}
+
+edge_t Boss::select_W(uint8_t ch, uint64_t r) const {
+    assert(r >= 1);
+    size_t b = w_hint[ch][(r - 1) / 64];
+    while (w_cum[(b + 1) * SIGMA + ch] < r) ++b;
+    uint64_t c = w_cum[b * SIGMA + ch];
+    for (size_t j = std::max<size_t>(b * 64, 1);; ++j) {
+        c += (W[j] == ch);
+        if (c == r) return j;
+    }
+}
+
+edge_t Boss::pred_last(edge_t i) const {
+    // boss.cpp:598-607: last set bit in last[1..i], 0 if none
+    while (i && !last[i]) --i;
+    return i;
+}
+
+edge_t Boss::succ_last(edge_t i) const {
+    // boss.cpp:613-617: first set bit in last[i..]
+    while (i <= n && !last[i]) ++i;
+    return i;
+}
+
+std::pair<edge_t, uint8_t> Boss::succ_W(edge_t i, uint8_t a, uint8_t b) const {
+    // boss.cpp:515-570: first occurrence of a or b in W[i..n]; (n+1, 0) if none
+    for (; i <= n; ++i) {
+        if (W[i] == a) return { i, a };
+        if (W[i] == b) return { i, b };
+    }
+    return { n + 1, 0 };
+}
+
+uint8_t Boss::get_node_last_value(edge_t i) const {
+    // boss.cpp:679-690
+    if (i == 0) return 0;
+    for (uint8_t c = 0; c < SIGMA; ++c)
+        if (F[c] >= i) return c - 1;
+    return SIGMA - 1;
+}
+
+edge_t Boss::bwd(edge_t i) const {
+    // boss.cpp:623-636
+    uint64_t target_node = rank_last(i - 1) + 1;
+    if (target_node == 1) return 1;
+    uint8_t c = get_node_last_value(i);
+    return select_W(c, target_node - NF[c]);
+}
+
+edge_t Boss::fwd(edge_t i, uint8_t c) const {
+    // boss.cpp:642-652
+    return select_last(NF[c] + rank_W(i, c));
+}
+
+edge_t Boss::pick_edge(edge_t edge, uint8_t c) const {
+    // boss.cpp:710-722
+    do {
+        uint8_t w = W[edge];
+        if (w == c || w == c + SIGMA) return edge;
+    } while (--edge && !last[edge]);
+    return 0;
+}
+
+void Boss::call_incoming_to_target(edge_t edge, uint8_t d,
+                                   const std::function<void(edge_t)> &cb) const {
+    // boss.cpp:766-786
+    cb(edge);
+    uint8_t d_next;
+    while (++edge <= n) {
+        std::tie(edge, d_next) = succ_W(edge, d, d + SIGMA);
+        if (d_next != d + SIGMA) break;
+        cb(edge);
+    }
+}
+
+bool Boss::is_single_incoming(edge_t i, uint8_t w) const {
+    // boss.cpp:802-815
+    if (w > SIGMA) return false;
+    ++i;
+    return i == n + 1 || succ_W(i, w, w + SIGMA).second != w + SIGMA;
+}
+
+size_t Boss::num_incoming_to_target(edge_t x, uint8_t d) const {
+    // boss.cpp:821-838
+    if (x + 1 == n + 1) return 1;
+    size_t indeg = 0;
+    call_incoming_to_target(x, d, [&](edge_t) { ++indeg; });
+    return indeg;
+}
+
+bool Boss::tighten_range(edge_t *rl, edge_t *ru, uint8_t s) const {
+    // boss.hpp:682-693
+    uint64_t rk_rl = rank_W(*rl - 1, s) + 1;
+    uint64_t rk_ru = rank_W(*ru, s);
+    if (rk_rl > rk_ru) return false;
+    *rl = select_last(NF[s] + rk_rl - 1) + 1;
+    *ru = select_last(NF[s] + rk_ru);
+    return true;
+}
+
+static inline void initial_range(const Boss &b, uint8_t s, edge_t *rl, edge_t *ru) {
+    // boss.hpp:665-677 (no suffix-range index: it only changes speed)
+    *rl = b.F[s] + 1 < b.n + 1 ? b.F[s] + 1 : b.n + 1;
+    *ru = s + 1 < SIGMA ? b.F[s + 1] : b.n;
+}
+
+edge_t Boss::index(const uint8_t *begin, const uint8_t *end) const {
+    // boss.hpp:696-718
+    assert(begin + k_ == end);
+    if (std::find(begin, end, (uint8_t)SIGMA) != end) return 0;
+    edge_t rl, ru;
+    initial_range(*this, *begin, &rl, &ru);
+    if (rl > ru) return 0;
+    for (auto it = begin + 1; it != end; ++it)
+        if (!tighten_range(&rl, &ru, *it)) return 0;
+    return ru;
+}
+
+std::tuple<edge_t, edge_t, size_t> Boss::index_range(const uint8_t *begin, const uint8_t *end) const {
+    // boss.hpp:720-764
+    if (begin == end) return { 1, 1, 0 };
+    if (std::find(begin, end, (uint8_t)SIGMA) != end) return { 0, 0, 0 };
+    edge_t rl, ru;
+    initial_range(*this, *begin, &rl, &ru);
+    if (rl > ru) return { 0, 0, 0 };
+    auto it = begin + 1;
+    for (; it != end; ++it)
+        if (!tighten_range(&rl, &ru, *it)) return { succ_last(rl), ru, size_t(it - begin) };
+    return { succ_last(rl), ru, size_t(it - begin) };
+}
+
+edge_t Boss::map_to_edge(const uint8_t *begin, const uint8_t *end) const {
+    // boss.hpp:766-777
+    edge_t edge = index(begin, end - 1);
+    return edge && *(end - 1) < SIGMA ? pick_edge(edge, *(end - 1)) : 0;
+}
+
+std::vector<edge_t> Boss::map_to_edges(const std::vector<uint8_t> &seq) const {
+    // boss.cpp:1003-1045 (terminate/skip hooks are inert on the align path)
+    std::vector<edge_t> out;
+    if (seq.size() <= k_) return out;
+    // utils::drag_and_mark_segments(seq, alph_size, k_ + 1), common/algorithms.hpp:58-74
+    std::vector<bool> invalid(seq.size(), false);
+    {
+        size_t last_occ = std::find(seq.begin(), seq.end(), (uint8_t)SIGMA) - seq.begin();
+        for (size_t i = last_occ; i < seq.size(); ++i) {
+            if (seq[i] == SIGMA) last_occ = i;
+            if (i - last_occ < k_ + 1) invalid[i] = true;
+        }
+    }
+    for (size_t i = 0; i + k_ + 1 <= seq.size(); ++i) {
+        if (invalid[i + k_]) { out.push_back(0); continue; }
+        edge_t edge = map_to_edge(seq.data() + i, seq.data() + i + k_ + 1);
+        out.push_back(edge);
+        while (edge && ++i + k_ < seq.size()) {
+            if (invalid[i + k_]) { out.push_back(0); break; }
+            edge = fwd(edge, seq[i + k_ - 1]);
+            edge = pick_edge(edge, seq[i + k_]);
+            out.push_back(edge);
+        }
+    }
+    return out;
+}
+
+std::vector<uint8_t> Boss::get_node_seq(edge_t x) const {
+    // boss.cpp:940-973 without the suffix-range shortcut
+    std::vector<uint8_t> ret(k_);
+    size_t i = k_;
+    ret[--i] = get_node_last_value(x);
+    while (i > 0) {
+        x = bwd(x);
+        ret[--i] = get_node_last_value(x);
+    }
+    return ret;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Test-fixture BOSS builder
+// ---------------------------------------------------------------------------------------------
+namespace {
+// an edge = node (k_ codes) + label; BOSS order = co-lex on node, then label (kmer_boss.hpp:15-26,58-63)
+struct EdgeKey {
+    std::vector<uint8_t> node;   // codes 0..4
+    uint8_t label;
+};
+struct EdgeLess {
+    bool operator()(const EdgeKey &a, const EdgeKey &b) const {
+        for (size_t i = a.node.size(); i-- > 0;) {
+            if (a.node[i] != b.node[i]) return a.node[i] < b.node[i];
+        }
+        return a.label < b.label;
+    }
+};
+} // namespace
+
+Boss build_boss(size_t k, const std::vector<std::string> &sequences, Mode mode) {
+    if (k < 2) throw std::runtime_error("k must be at least 2");
+    const size_t kb = k - 1;  // BOSS node length
+    std::set<EdgeKey, EdgeLess> real;
+    auto add_kmers = [&](const std::string &s) {
+        auto enc = encode_seq(s);
+        for (size_t i = 0; i + k <= enc.size(); ++i) {
+            bool ok = true;
+            for (size_t j = 0; j < k; ++j) if (enc[i + j] >= SIGMA || enc[i + j] == 0) { ok = false; break; }
+            if (!ok) continue;
+            EdgeKey e{ std::vector<uint8_t>(enc.begin() + i, enc.begin() + i + kb), enc[i + kb] };
+            real.insert(std::move(e));
+        }
+    };
+    for (const auto &s : sequences) {
+        add_kmers(s);
+        if (mode == CANONICAL) {              // boss_chunk_construct.cpp:357-359
+            std::string rc(s);
+            reverse_complement_inplace(rc);
+            add_kmers(rc);
+        }
+    }
+
+    // index real edges by source node and by target node
+    std::set<std::vector<uint8_t>> real_sources;
+    std::set<std::pair<std::vector<uint8_t>, uint8_t>> node_tail_label;   // (node[1..], label)
+    for (const auto &e : real) {
+        real_sources.insert(e.node);
+        node_tail_label.insert({ std::vector<uint8_t>(e.node.begin() + 1, e.node.end()), e.label });
+    }
+
+    std::set<EdgeKey, EdgeLess> all(real.begin(), real.end());
+
+    // dummy sinks (boss_chunk_construct.cpp:57-101): target node without outgoing real edge
+    for (const auto &e : real) {
+        std::vector<uint8_t> target(e.node.begin() + 1, e.node.end());
+        target.push_back(e.label);
+        if (!real_sources.count(target)) all.insert(EdgeKey{ target, 0 });
+    }
+
+    // dummy sources with prefix length 1 (boss_chunk_construct.cpp:126-171)
+    std::set<EdgeKey, EdgeLess> level;
+    for (const auto &node : real_sources) {
+        // prev_kmer: node' = $ node[0..kb-2], label = node[kb-1]
+        std::vector<uint8_t> tail(node.begin(), node.end() - 1);     // a1..a_{kb-1}
+        uint8_t label = node.back();
+        // redundant iff some real edge  x a1..a_{kb-1} -> a_kb  exists
+        if (node_tail_label.count({ tail, label })) continue;
+        EdgeKey d;
+        d.node.reserve(kb);
+        d.node.push_back(0);
+        d.node.insert(d.node.end(), tail.begin(), tail.end());
+        d.label = label;
+        level.insert(std::move(d));
+    }
+    // prefix lengths 2..kb (boss_chunk_construct.cpp:380-397)
+    for (size_t c = 1; c <= kb; ++c) {
+        for (const auto &d : level) all.insert(d);
+        if (c == kb) break;
+        std::set<EdgeKey, EdgeLess> next;
+        for (const auto &d : level) {
+            EdgeKey p;
+            p.node.reserve(kb);
+            p.node.push_back(0);
+            p.node.insert(p.node.end(), d.node.begin(), d.node.end() - 1);
+            p.label = d.node.back();
+            next.insert(std::move(p));
+        }
+        level.swap(next);
+    }
+
+    // lay out (boss_chunk.cpp:32-125); the root edge $...$ -> $ comes first (boss_chunk_construct.cpp:404-409)
+    std::vector<EdgeKey> edges;
+    edges.push_back(EdgeKey{ std::vector<uint8_t>(kb, 0), 0 });
+    for (const auto &e : all) {
+        if (e.label == 0 && std::all_of(e.node.begin(), e.node.end(), [](uint8_t x) { return x == 0; }))
+            continue;
+        edges.push_back(e);
+    }
+    std::sort(edges.begin(), edges.end(), EdgeLess());
+
+    Boss b;
+    b.k_ = kb;
+    b.W.push_back(0);
+    b.last.push_back(0);
+    uint64_t curpos = 1;
+    uint8_t lastF = 0;
+    std::vector<const EdgeKey*> last_kmer(SIGMA, nullptr);
+    for (size_t idx = 0; idx < edges.size(); ++idx) {
+        const EdgeKey &e = edges[idx];
+        uint8_t curW = e.label;
+        uint8_t curF = e.node[kb - 1];
+        bool same_node_next = idx + 1 < edges.size() && edges[idx + 1].node == e.node;
+        if (same_node_next) {
+            if (curW == 0 && curF > 0) continue;         // redundant dummy sink (boss_chunk.cpp:83-85)
+            b.last.push_back(0);
+        } else {
+            b.last.push_back(1);
+        }
+        if (curW) {
+            const EdgeKey *lk = last_kmer[curW];
+            // same node except the first char -> not the first incoming edge (boss_chunk.cpp:92-101)
+            if (lk && std::equal(lk->node.begin() + 1, lk->node.end(), e.node.begin() + 1)) {
+                curW += SIGMA;
+            } else {
+                last_kmer[e.label] = &e;
+            }
+        }
+        b.W.push_back(curW);
+        while (curF > lastF && lastF + 1 < SIGMA) b.F[++lastF] = curpos - 1;
+        ++curpos;
+    }
+    while (++lastF < SIGMA) b.F[lastF] = curpos - 1;
+    b.n = curpos - 1;
+    b.finalize();
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Graph (DBGSuccinct)
+// ---------------------------------------------------------------------------------------------
+void Graph::mask_dummy_kmers() {
+    // dbg_succinct.cpp:924-932 -> BOSS::mark_all_dummy_edges (boss.cpp:1743-1775), flipped
+    valid.assign(boss.n + 1, 1);
+    valid[0] = 0;
+    for (edge_t i = 1; i <= boss.n; ++i) {
+        if (i > 1 && boss.W[i] == 0) { valid[i] = 0; continue; }
+        auto seq = boss.get_node_seq(i);
+        if (std::find(seq.begin(), seq.end(), 0) != seq.end()) valid[i] = 0;
+    }
+    valid[1] = 0;
+}
+
+uint64_t Graph::num_nodes() const {
+    if (valid.empty()) return boss.n;
+    uint64_t c = 0;
+    for (auto v : valid) c += v;
+    return c;
+}
+
+std::vector<node_t> Graph::map_to_nodes_sequentially(std::string_view seq) const {
+    // dbg_succinct.cpp:285-305 (no Bloom filter)
+    std::vector<node_t> nodes;
+    if (seq.size() < get_k()) return nodes;
+    auto edges = boss.map_to_edges(encode_seq(seq));
+    nodes.reserve(edges.size());
+    for (auto e : edges) nodes.push_back(validate_edge(e));
+    return nodes;
+}
+
+void Graph::call_outgoing_kmers(node_t v, const std::function<void(node_t, char)> &cb) const {
+    // dbg_succinct.cpp:110-139
+    uint8_t w = 0;
+    if (v > 1 && !(w = boss.get_W(v))) return;
+    edge_t lst = boss.fwd(v, w % SIGMA);
+    edge_t first = boss.pred_last(lst - 1) + 1;
+    for (edge_t i = std::max<edge_t>(2, first); i <= lst; ++i) {
+        if (in_graph(i)) cb(i, decode_code(boss.get_W(i) % SIGMA));
+    }
+}
+
+void Graph::call_incoming_kmers(node_t v, const std::function<void(node_t, char)> &cb) const {
+    // NodeFirstCache::call_incoming_kmers (graph_extensions/node_first_cache.cpp:27-52):
+    // first char = get_minus_k_value(edge, k_-1).first (boss.cpp:696-704)
+    boss.call_incoming_to_target(boss.bwd(v), boss.get_node_last_value(v), [&](edge_t prev) {
+        if (in_graph(prev)) {
+            auto seq = boss.get_node_seq(prev);
+            cb(prev, decode_code(seq[0]));
+        }
+    });
+}
+
+bool Graph::has_multiple_outgoing(node_t v) const {
+    // dbg_succinct.cpp:609-624
+    if (v == 1) return boss.succ_last(1) > 2;
+    uint8_t d = boss.get_W(v) % SIGMA;
+    if (!d) return false;
+    return !boss.get_last(boss.fwd(v, d) - 1);
+}
+
+bool Graph::has_single_incoming(node_t v) const {
+    // dbg_succinct.cpp:658-678
+    if (v == 1) return false;
+    edge_t x = boss.bwd(v);
+    uint8_t w = boss.get_node_last_value(v);
+    size_t first_valid = valid.empty() || valid[x];
+    if (x + 1 == boss.n + 1) return first_valid;
+    if (first_valid) return boss.is_single_incoming(x, w);
+    return boss.num_incoming_to_target(x, w) == 2;
+}
+
+std::string Graph::get_node_sequence(node_t v) const {
+    // dbg_succinct.cpp:272-279
+    auto seq = boss.get_node_seq(v);
+    std::string s;
+    for (auto c : seq) s += decode_code(c);
+    s += decode_code(boss.get_W(v) % SIGMA);
+    return s;
+}
+
+void Graph::call_nodes_with_suffix_matching_longest_prefix(
+        std::string_view str, const std::function<void(node_t, uint64_t)> &cb,
+        size_t min_match_length, size_t max_num_allowed_matches) const {
+    // dbg_succinct.cpp:307-393
+    if (!max_num_allowed_matches || str.size() < min_match_length) return;
+    auto encoded = encode_seq(str);
+    if (std::find(encoded.begin(), encoded.end(), (uint8_t)SIGMA) != encoded.end()) return;
+    const uint8_t *b = encoded.data();
+    const uint8_t *e = b + std::min(get_k() - 1, encoded.size());
+    auto [first, lst, match_size] = boss.index_range(b, e);
+
+    if (str.size() == get_k() && match_size + 1 == get_k()) {
+        edge_t edge = boss.pick_edge(lst, encoded.back());
+        if (edge && in_graph(edge)) { cb(edge, get_k()); return; }
+    }
+    if (match_size < min_match_length) return;
+
+    uint64_t rank_first = boss.rank_last(first);
+    uint64_t rank_lst = boss.rank_last(lst);
+    if (max_num_allowed_matches < SIZE_MAX) {
+        std::vector<node_t> nodes;
+        for (uint64_t i = rank_first; i <= rank_lst && nodes.size() <= max_num_allowed_matches; ++i) {
+            edge_t ed = boss.select_last(i);
+            boss.call_incoming_to_target(boss.bwd(ed), boss.get_node_last_value(ed), [&](edge_t inc) {
+                if (in_graph(inc)) nodes.push_back(inc);
+            });
+        }
+        if (nodes.size() > max_num_allowed_matches) return;
+        for (auto nd : nodes) cb(nd, match_size);
+    } else {
+        for (uint64_t i = rank_first; i <= rank_lst; ++i) {
+            edge_t ed = boss.select_last(i);
+            boss.call_incoming_to_target(boss.bwd(ed), boss.get_node_last_value(ed), [&](edge_t inc) {
+                if (in_graph(inc)) cb(inc, match_size);
+            });
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GraphView (RCDBG)
+// ---------------------------------------------------------------------------------------------
+void GraphView::call_outgoing_kmers(node_t v, const std::function<void(node_t, char)> &cb) const {
+    if (!rc) { g->call_outgoing_kmers(v, cb); return; }
+    // rc_dbg.hpp:88-99
+    g->call_incoming_kmers(v, [&](node_t prev, char c) { cb(prev, complement_char(c)); });
+}
+
+std::string GraphView::get_node_sequence(node_t v) const {
+    std::string s = g->get_node_sequence(v);
+    if (rc) reverse_complement_inplace(s);
+    return s;
+}
+
+} // namespace orc

@@ -1,0 +1,193 @@
+"""ctypes driver for the CPU oracle (oracle/_build/liborc.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+
+from metagraph_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_L = None
+
+
+def L():
+    global _L
+    if _L is None:
+        _L = C.CDLL(os.path.join(ROOT, "oracle", "_build", "liborc.so"))
+        _L.orc_graph_build.restype = C.c_void_p
+        _L.orc_graph_build.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_int]
+        _L.orc_graph_from_boss.restype = C.c_void_p
+        _L.orc_graph_from_boss.argtypes = [C.POINTER(capi.BossView)]
+        _L.orc_graph_free.argtypes = [C.c_void_p]
+        for f in ("orc_graph_num_edges", "orc_graph_num_nodes"):
+            getattr(_L, f).restype = C.c_uint64
+            getattr(_L, f).argtypes = [C.c_void_p]
+        _L.orc_graph_k.restype = C.c_uint32
+        _L.orc_graph_k.argtypes = [C.c_void_p]
+        _L.orc_graph_has_mask.argtypes = [C.c_void_p]
+        _L.orc_graph_export.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _L.orc_graph_node_sequence.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p]
+        for f in ("orc_boss_fwd", "orc_boss_rank_W"):
+            getattr(_L, f).restype = C.c_uint64
+            getattr(_L, f).argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        for f in ("orc_boss_bwd", "orc_boss_select_last", "orc_boss_rank_last"):
+            getattr(_L, f).restype = C.c_uint64
+            getattr(_L, f).argtypes = [C.c_void_p, C.c_uint64]
+        _L.orc_graph_has_multiple_outgoing.argtypes = [C.c_void_p, C.c_uint64]
+        _L.orc_graph_has_single_incoming.argtypes = [C.c_void_p, C.c_uint64]
+        _L.orc_graph_outgoing.restype = C.c_uint32
+        _L.orc_graph_outgoing.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_char_p]
+        _L.orc_graph_suffix_match.restype = C.c_uint32
+        _L.orc_graph_suffix_match.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64,
+                                              C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]
+        _L.orc_is_low_complexity.argtypes = [C.c_char_p, C.c_uint32]
+        _L.orc_check_config.argtypes = [C.POINTER(capi.Config)]
+        _L.orc_oob_reads.restype = C.c_uint64
+        _L.orc_align_batch.restype = C.c_void_p
+        _L.orc_align_batch.argtypes = [C.c_void_p, C.POINTER(capi.Config), C.c_char_p, C.POINTER(C.c_uint64),
+                                       C.c_uint64, C.c_uint32, C.c_int]
+        _L.orc_results_error.restype = C.c_char_p
+        _L.orc_results_error.argtypes = [C.c_void_p]
+        _L.orc_results_view.argtypes = [C.c_void_p, C.POINTER(capi.Results)]
+        _L.orc_results_mapping.argtypes = [C.c_void_p, C.POINTER(capi.Mapping)]
+        _L.orc_results_seeds.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.POINTER(C.c_uint64)),
+                                         C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(C.c_uint64)),
+                                         C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64))]
+        _L.orc_results_tsv.restype = C.c_char_p
+        _L.orc_results_tsv.argtypes = [C.c_void_p]
+        _L.orc_results_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _L.orc_results_free.argtypes = [C.c_void_p]
+    return _L
+
+
+class Graph:
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def build(cls, k, seqs, mode=0, mask_dummy=False):
+        arr = (C.c_char_p * max(1, len(seqs)))(*[s.encode() for s in seqs])
+        h = L().orc_graph_build(k, len(seqs), arr, mode, int(mask_dummy))
+        assert h, "oracle graph build failed"
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L().orc_graph_free(self.h)
+            self.h = None
+
+    @property
+    def n_edges(self):
+        return L().orc_graph_num_edges(self.h)
+
+    @property
+    def k(self):
+        return L().orc_graph_k(self.h)
+
+    @property
+    def num_nodes(self):
+        return L().orc_graph_num_nodes(self.h)
+
+    def export(self):
+        """-> (W bytes, last bytes, F list, valid bytes or None) as numpy arrays"""
+        import numpy as np
+        n = self.n_edges
+        W = np.zeros(n + 1, dtype=np.uint8)
+        last = np.zeros(n + 1, dtype=np.uint8)
+        F = np.zeros(5, dtype=np.uint64)
+        valid = np.zeros(n + 1, dtype=np.uint8) if L().orc_graph_has_mask(self.h) else None
+        L().orc_graph_export(self.h, W.ctypes.data, last.ctypes.data, F.ctypes.data,
+                             valid.ctypes.data if valid is not None else None)
+        return W, last, F, valid
+
+    def node_sequence(self, node):
+        buf = C.create_string_buffer(self.k)
+        L().orc_graph_node_sequence(self.h, node, buf)
+        return buf.raw.decode()
+
+    def outgoing(self, v, rc=False):
+        nodes = (C.c_uint64 * 8)()
+        chars = C.create_string_buffer(8)
+        n = L().orc_graph_outgoing(self.h, v, int(rc), nodes, chars)
+        return [(nodes[i], chars.raw[i:i + 1].decode()) for i in range(n)]
+
+    def suffix_match(self, s, min_len, max_matches=0, cap=4096):
+        nodes = (C.c_uint64 * cap)()
+        ml = C.c_uint32()
+        n = L().orc_graph_suffix_match(self.h, s.encode(), len(s), min_len, max_matches, nodes, cap, C.byref(ml))
+        return [nodes[i] for i in range(min(n, cap))], ml.value
+
+
+def pack_queries(queries):
+    import numpy as np
+    offs = np.zeros(len(queries) + 1, dtype=np.uint64)
+    bs = [q if isinstance(q, bytes) else q.encode("latin-1") for q in queries]
+    for i, b in enumerate(bs):
+        offs[i + 1] = offs[i] + len(b)
+    return b"".join(bs), offs
+
+
+class AlignRun:
+    """Result of one oracle batch; keeps the native store alive."""
+
+    def __init__(self, graph, config, queries, threads=1, validate=True):
+        blob, offs = pack_queries(queries)
+        self._keep = (blob, offs)
+        self.r = L().orc_align_batch(graph.h, C.byref(config), blob, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                     len(queries), threads, int(validate))
+        self.error = L().orc_results_error(self.r).decode()
+        self.n = len(queries)
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            L().orc_results_free(self.r)
+            self.r = None
+
+    def results(self):
+        v = capi.Results()
+        L().orc_results_view(self.r, C.byref(v))
+        return capi.results_to_py(v)
+
+    def mapping(self):
+        m = capi.Mapping()
+        L().orc_results_mapping(self.r, C.byref(m))
+        out = []
+        for q in range(self.n):
+            b, e = m.node_begin[q], m.node_begin[q + 1]
+            out.append(([m.nodes_fwd[i] for i in range(b, e)], [m.nodes_rc[i] for i in range(b, e)]))
+        return out
+
+    def seeds(self, strand):
+        begin = C.POINTER(C.c_uint64)()
+        meta = C.POINTER(C.c_uint32)()
+        nb = C.POINTER(C.c_uint64)()
+        nodes = C.POINTER(C.c_uint64)()
+        nm = C.POINTER(C.c_uint64)()
+        L().orc_results_seeds(self.r, strand, C.byref(begin), C.byref(meta), C.byref(nb), C.byref(nodes), C.byref(nm))
+        out = []
+        for q in range(self.n):
+            ss = []
+            for s in range(begin[q], begin[q + 1]):
+                ss.append({"clipping": meta[4 * s], "length": meta[4 * s + 1], "offset": meta[4 * s + 2],
+                           "nodes": [nodes[i] for i in range(nb[s], nb[s + 1])]})
+            out.append((ss, nm[q]))
+        return out
+
+    def tsv_lines(self):
+        return L().orc_results_tsv(self.r).decode().split("\n")[:-1]
+
+    def counters(self):
+        a = (C.c_uint64 * 7)()
+        L().orc_results_counters(self.r, a)
+        return dict(zip(["n_map_fwd", "n_index_steps", "n_terminus", "n_expansions", "n_columns", "n_extensions",
+                         "n_seeds"], list(a)))
+
+
+def make_config(case_cfg, matrix, base=None):
+    """Build an mgx_config from a KAT case (DBGAlignerConfig{} defaults + overrides)."""
+    c = base if base is not None else capi.config_default()
+    if matrix[0] == "dna":
+        capi.set_dna_matrix(c, *matrix[1:])
+    else:
+        capi.set_unit_matrix(c, matrix[1])
+    for key, val in case_cfg.items():
+        setattr(c, key, val)
+    return c

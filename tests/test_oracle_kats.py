@@ -1,0 +1,143 @@
+"""The oracle against the reference's own known-answer tests (tests/golden/aligner_kats.json,
+transcribed from metagraph/tests/graph/test_aligner.cpp and integration_tests/test_align.py)."""
+import copy
+import json
+import os
+
+import pytest
+
+import orc
+from metagraph_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "aligner_kats.json")))
+
+
+def check_path(case, path, e):
+    for key in ("score", "offset", "clipping", "end_clipping", "cigar", "sequence", "orientation"):
+        if key in e and e[key] is not None:
+            assert path[key] == e[key], (case["name"], key, path)
+    if e.get("num_matches") is not None:
+        assert path["num_matches"] == e["num_matches"], (case["name"], path)
+    if "n_nodes" in e:
+        assert len(path["nodes"]) == e["n_nodes"], (case["name"], path)
+    if "cigar_any" in e:
+        assert path["cigar"] in e["cigar_any"], (case["name"], path)
+    if "sequence_any" in e:
+        assert path["sequence"] in e["sequence_any"], (case["name"], path)
+    if "by_orientation" in e:
+        sub = e["by_orientation"][str(path["orientation"])]
+        assert path["sequence"] == sub["sequence"] and path["cigar"] == sub["cigar"], (case["name"], path)
+
+
+def run_case(case, extend=False):
+    g = orc.Graph.build(case["k"], case["graph"], 0, case["mask_dummy"])
+    cfg = orc.make_config(case["config"], case["matrix"])
+    if extend:      # get_extend(): max_seed_length = inf (tests/graph/test_aligner_helpers.hpp:57-66)
+        cfg.max_seed_length = capi.UINT64_MAX
+    run = orc.AlignRun(g, cfg, [case["query"]])
+    return run
+
+
+@pytest.mark.parametrize("case", KATS["unit"], ids=lambda c: c["name"])
+def test_unit_kat(case):
+    e = case["expect"]
+    run = run_case(case)
+    if e.get("throws"):
+        assert "min_cell_score" in run.error
+        return
+    assert run.error == "", run.error
+    paths = run.results()[0]
+    if "n_paths" in e:
+        assert len(paths) == e["n_paths"], (case["name"], paths)
+    if "n_paths_min" in e:
+        assert len(paths) >= e["n_paths_min"], (case["name"], paths)
+    if paths and e.get("n_paths", 1) == 1:
+        check_path(case, paths[0], e)
+    if "first" in e:
+        check_path(case, paths[0], e["first"])
+    if case.get("extend_same_expect"):
+        ext = run_case(case, extend=True)
+        assert ext.error == ""
+        p2 = ext.results()[0]
+        assert len(p2) == 1
+        check_path(case, p2[0], e)
+    if case["check_extend"]:
+        # check_extend(): the MEM-seeded run must give identical alignments (test_aligner_helpers.hpp:68-90)
+        ext = run_case(case, extend=True)
+        assert ext.error == "", ext.error
+        assert ext.results()[0] == paths, (case["name"], paths, ext.results()[0])
+
+
+def read_fasta(path):
+    seqs, cur = [], []
+    for line in open(path):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur:
+                seqs.append("".join(cur))
+            cur = []
+        elif line:
+            cur.append(line)
+    if cur:
+        seqs.append("".join(cur))
+    return seqs
+
+
+def read_fastq(path):
+    lines = [l.rstrip("\n") for l in open(path)]
+    return [(lines[i][1:].split()[0], lines[i + 1]) for i in range(0, len(lines) - 3, 4)]
+
+
+@pytest.fixture(scope="module")
+def mt_graph():
+    cli = KATS["cli"]
+    seqs = read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"]))
+    g = orc.Graph.build(cli["k"], seqs, 0, False)     # CLI path: reset_mask() -> no mask (cli/align.cpp:337-339)
+    return g
+
+
+def test_cli_builder_kmer_count(mt_graph):
+    cli = KATS["cli"]
+    seqs = read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"]))
+    gm = orc.Graph.build(cli["k"], seqs, 0, True)
+    assert gm.num_nodes == cli["expected_num_real_kmers"]
+
+
+@pytest.mark.parametrize("run_i", [0, 1])
+def test_cli_goldens(mt_graph, run_i):
+    cli = KATS["cli"]
+    spec = cli["runs"][run_i]
+    reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
+    assert len(reads) == spec["n_lines"]
+    cfg = capi.config_cli(cli["k"])
+    for key, val in spec["flags"].items():
+        setattr(cfg, key, val)
+    run = orc.AlignRun(mt_graph, cfg, [r[1] for r in reads])
+    assert run.error == "", run.error
+    lines = run.tsv_lines()
+    # the oracle labels lines by index; swap in the read names
+    lines = [reads[i][0] + l[l.index("\t"):] for i, l in enumerate(lines)]
+    for idx, want in spec["lines"].items():
+        assert lines[int(idx)] == want, (idx, lines[int(idx)])
+    for idx, fields in spec["fields"].items():
+        got = lines[int(idx)].split("\t")
+        for fi, fv in fields.items():
+            assert got[int(fi)] == fv, (idx, fi, got)
+
+
+def test_cli_map_counts(mt_graph):
+    cli = KATS["cli"]
+    reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
+    cfg = capi.config_cli(cli["k"])
+    run = orc.AlignRun(mt_graph, cfg, [r[1] for r in reads])
+    # --map --count-kmers runs on the masked graph? No: align.cpp resets the mask before mapping too;
+    # source-dummy k-mers cannot match a full k-mer of ACGT, so counts are mask-independent.
+    for (fwd, _), want in zip(run.mapping(), cli["map_counts"]["counts"]):
+        matched = sum(1 for v in fwd if v)
+        w = want.split("/")
+        assert matched == int(w[0]) and len(fwd) == int(w[1]), (matched, len(fwd), want)
+
+
+def test_no_undefined_reads():
+    assert orc.L().orc_oob_reads() == 0
