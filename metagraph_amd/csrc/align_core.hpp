@@ -1,0 +1,1775 @@
+// align_core.hpp — the per-read wave program: seeding bookkeeping, seed extension (x-drop affine
+// DP over graph neighbours), backtracking, strand handling and best-alignment selection.
+//
+// One wavefront owns one read.  Control flow is wave-uniform; DP columns, scans, table searches
+// and array copies are lane-parallel (FOR_LANES).  All per-read state lives in a per-wave slice
+// of an HBM arena (AlignParams::arena) that stays L2-hot; the only graph traffic is the 64-byte
+// blocks of dev_graph.hpp.
+//
+// Reference being restated (A/ = M/src/graph/alignment/):
+//   seeding      A/aligner_seeder_methods.cpp:49-93,153-424   (SuffixSeeder<UniMEMSeeder>)
+//   extension    A/aligner_extender_methods.cpp:66-1034       (DefaultColumnExtender)
+//   driver       A/dbg_aligner.cpp:193-384,531-758            (DBGAligner<>, BASIC graphs)
+//   aggregator   A/aligner_aggregator.hpp:68-202              (num_alternative_paths == 1)
+// Integer results are bit-exact; the four double comparisons and the one fma are kept as in the
+// reference (see DESIGN.md "floating point").
+#pragma once
+#include "align_types.hpp"
+
+namespace mgx {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+MGX_DEV uint32_t encode_char(uint8_t ch) {           // kmer/alphabets.hpp:67-76 (+ kmer_extractor.cpp:33-36)
+    if (ch & 0x80) return 5;
+    switch (ch) {
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 3;
+        case 'T': case 't': case 'U': case 'u': return 4;
+        default: return 5;
+    }
+}
+
+MGX_DEV uint8_t decode_code(uint32_t c) {            // "$ACGT"
+    return c == 0 ? '$' : c == 1 ? 'A' : c == 2 ? 'C' : c == 3 ? 'G' : 'T';
+}
+
+MGX_DEV uint8_t complement_char(uint8_t c) {         // COMPL_TAB, common/seq_tools/reverse_complement.hpp:31-48
+    const char *up = "TVGHEFCDIJMLKNOPQYSAABWXRZ";
+    if (c >= 'A' && c <= 'Z') return (uint8_t)up[c - 'A'];
+    if (c >= 'a' && c <= 'z') return (uint8_t)(up[c - 'a'] + ('a' - 'A'));
+    if (c == 96) return 64;
+    return c;
+}
+
+MGX_DEV uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+MGX_DEV uint8_t char_to_op(uint8_t a, uint8_t b) {   // initialize_opt_table (A/aligner_cigar.cpp:10-51)
+    uint8_t ua = to_upper(a), ub = to_upper(b);
+    bool valid = (ua == 'A' || ua == 'C' || ua == 'G' || ua == 'T');
+    return (valid && ua == ub) ? OP_MATCH : OP_MISMATCH;
+}
+
+template <class T>
+MGX_DEV T imin(T a, T b) { return a < b ? a : b; }
+template <class T>
+MGX_DEV T imax(T a, T b) { return a > b ? a : b; }
+MGX_DEV int32_t iabs(int32_t a) { return a < 0 ? -a : a; }
+
+// ------------------------------------------------------------------------------------------------
+// per-wave arena
+// ------------------------------------------------------------------------------------------------
+struct ColMeta {                 // DPTColumn minus the vectors (aligner_extender_methods.hpp:129-147)
+    uint32_t node;
+    int32_t parent;
+    int32_t offset, max_pos, trim, size;
+    int32_t score;               // edge score
+    uint32_t cells;              // word offset of cell 0 in the cell arena (S,E,F interleaved)
+    uint32_t c;                  // path character
+    uint32_t cap3;               // S.capacity()+E.capacity()+F.capacity() of the reference's vectors
+};
+
+struct BtIndex { int32_t score, neg_off_diag, neg_i, pos; };
+
+struct ConvSlot { uint32_t gen, idx; };
+struct ConvEntry { uint64_t key; int32_t start, len; };
+
+struct ConvChecker {             // SeedFilteringExtender::conv_checker_ (extender hpp:75-76)
+    ConvSlot *slots;
+    ConvEntry *entries;
+    int32_t *vecs;               // entry e covers query positions [start, start + len) at vecs[e * L + pos]
+    uint32_t n_entries;
+    uint32_t gen;
+};
+
+struct DevAln {                  // Alignment (alignment.hpp:132-331)
+    uint32_t *nodes;
+    uint32_t *cigar;             // len << 3 | op
+    uint8_t *seq;
+    int32_t n_nodes, n_cigar, seq_len;
+    int32_t score, offset;
+    int32_t qbegin, qlen;        // query_view within the strand's query
+    int32_t orientation;         // strand of the query this alignment is on
+    int32_t extra_score;
+};
+
+MGX_DEV int32_t aln_clipping(const DevAln &a) {
+    return a.n_cigar && (a.cigar[0] & 7) == OP_CLIPPED ? (int32_t)(a.cigar[0] >> 3) : 0;
+}
+MGX_DEV int32_t aln_end_clipping(const DevAln &a) {
+    return a.n_cigar && (a.cigar[a.n_cigar - 1] & 7) == OP_CLIPPED ? (int32_t)(a.cigar[a.n_cigar - 1] >> 3) : 0;
+}
+
+// what the extender needs to know about its seed (a Seed-derived or a reversed Alignment)
+struct SeedRef {
+    const uint32_t *nodes;
+    const uint8_t *seq;
+    int32_t n_nodes, seq_len;
+    int32_t clipping, end_clipping, qlen, offset, score;
+    int32_t orientation;
+};
+
+struct ExtenderState {           // one per strand (Extender object in dbg_aligner.cpp:287,292)
+    const uint8_t *q;            // normalized query of this strand
+    const int32_t *psum;         // partial_sums_ (aligner_extender_methods.cpp:26-36)
+    ConvChecker conv;
+    uint32_t table_cap;          // capacity of the reference's std::vector<DPTColumn>
+    int32_t rc_view;             // 1 while this extender runs on the RCDBG view
+};
+
+struct Wave {
+    const AlignParams *P;
+    int32_t L;                   // query length
+    uint8_t *q[2];
+    int32_t *psum[2];
+    const uint32_t *nodes[2];
+    int32_t n_kmers;
+    DevSeed *seeds[2];
+    uint8_t *alive[2];
+    int32_t n_seeds[2];
+    uint32_t num_matching[2];
+    // sub-k scratch
+    uint16_t *msl, *pos_cnt, *ml;
+    uint8_t *pos_full;
+    uint32_t *pos_start, *rfirst, *rlast, *alt;
+    // extension scratch
+    int32_t *cells;
+    ColMeta *cols;
+    uint64_t *queue, *next_nodes;
+    uint32_t *tips, *prev_starts;
+    BtIndex *indices;
+    uint32_t *rev_ops, *rev_nodes;
+    uint8_t *rev_seq;
+    int32_t *sd;                 // sdust scratch
+    ExtenderState ext[2];
+    DevAln aln[4];               // 0: extension result, 1: reversed seed for the backward pass,
+                                 // 2: backward extension result, 3: best (aggregator)
+    int32_t have_best;
+    LineCtr ctr;                 // wave-uniform code
+    LV<LineCtr> lctr;            // lane-parallel regions
+    uint32_t n_columns, n_extensions;
+    int32_t status;
+};
+
+MGX_HD uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
+
+// byte size of one wave's arena slice
+MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
+    uint64_t L = lim.Lmax, Lp = align8(L + 8);
+    uint64_t ent = (uint64_t)lim.max_columns + lim.max_path;
+    uint64_t b = 0;
+    b += 2 * Lp;                                        // q
+    b += 2 * align8((L + 1) * 4);                       // psum
+    b += 2 * align8((uint64_t)lim.max_seeds * sizeof(DevSeed));
+    b += 2 * align8(lim.max_seeds);                     // alive
+    b += 3 * align8((L + 1) * 2);                       // msl, pos_cnt, ml
+    b += align8(L + 1);                                 // pos_full
+    b += 3 * align8((L + 1) * 4);                       // pos_start, rfirst, rlast
+    b += align8((uint64_t)lim.max_alt * 4);             // alt
+    b += align8((uint64_t)lim.cell_words * 4);          // cells
+    b += align8((uint64_t)lim.max_columns * sizeof(ColMeta));
+    b += 2 * align8((uint64_t)lim.max_columns * 8);     // queue, next_nodes
+    b += align8((uint64_t)lim.max_columns * 4);         // tips
+    b += align8(((uint64_t)lim.max_columns + 31) / 32 * 4);   // prev_starts
+    b += align8((uint64_t)lim.max_columns * 2 * sizeof(BtIndex));
+    b += 2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path);   // rev_*
+    b += align8(2048 * 4);                              // sdust
+    b += 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8(ent * sizeof(ConvEntry)) + align8(ent * L * 4));
+    b += 4 * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
+    return align8(b);
+}
+
+MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base) {
+    const DevLimits &lim = P.lim;
+    uint64_t L = lim.Lmax, Lp = align8(L + 8);
+    uint64_t ent = (uint64_t)lim.max_columns + lim.max_path;
+    uint8_t *p = base;
+    auto take = [&](uint64_t bytes) { uint8_t *r = p; p += align8(bytes); return r; };
+    for (int s = 0; s < 2; ++s) w.q[s] = take(Lp);
+    for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take((L + 1) * 4);
+    for (int s = 0; s < 2; ++s) w.seeds[s] = (DevSeed *)take((uint64_t)lim.max_seeds * sizeof(DevSeed));
+    for (int s = 0; s < 2; ++s) w.alive[s] = take(lim.max_seeds);
+    w.msl = (uint16_t *)take((L + 1) * 2);
+    w.pos_cnt = (uint16_t *)take((L + 1) * 2);
+    w.ml = (uint16_t *)take((L + 1) * 2);
+    w.pos_full = take(L + 1);
+    w.pos_start = (uint32_t *)take((L + 1) * 4);
+    w.rfirst = (uint32_t *)take((L + 1) * 4);
+    w.rlast = (uint32_t *)take((L + 1) * 4);
+    w.alt = (uint32_t *)take((uint64_t)lim.max_alt * 4);
+    w.cells = (int32_t *)take((uint64_t)lim.cell_words * 4);
+    w.cols = (ColMeta *)take((uint64_t)lim.max_columns * sizeof(ColMeta));
+    w.queue = (uint64_t *)take((uint64_t)lim.max_columns * 8);
+    w.next_nodes = (uint64_t *)take((uint64_t)lim.max_columns * 8);
+    w.tips = (uint32_t *)take((uint64_t)lim.max_columns * 4);
+    w.prev_starts = (uint32_t *)take(((uint64_t)lim.max_columns + 31) / 32 * 4);
+    w.indices = (BtIndex *)take((uint64_t)lim.max_columns * 2 * sizeof(BtIndex));
+    w.rev_ops = (uint32_t *)take((uint64_t)lim.max_path * 4);
+    w.rev_nodes = (uint32_t *)take((uint64_t)lim.max_path * 4);
+    w.rev_seq = take(lim.max_path);
+    w.sd = (int32_t *)take(2048 * 4);
+    for (int s = 0; s < 2; ++s) {
+        w.ext[s].conv.slots = (ConvSlot *)take((uint64_t)lim.hash_size * sizeof(ConvSlot));
+        w.ext[s].conv.entries = (ConvEntry *)take(ent * sizeof(ConvEntry));
+        w.ext[s].conv.vecs = (int32_t *)take(ent * L * 4);
+    }
+    for (int a = 0; a < 4; ++a) {
+        w.aln[a].nodes = (uint32_t *)take((uint64_t)lim.max_path * 4);
+        w.aln[a].cigar = (uint32_t *)take((uint64_t)lim.max_path * 4);
+        w.aln[a].seq = take(lim.max_path);
+    }
+}
+
+MGX_DEV int32_t score_of(const AlignParams &P, uint8_t graph_char, uint8_t query_char) {
+    return P.score_matrix[(uint32_t)(graph_char & 127) * 128 + (query_char & 127)];
+}
+
+// profile_score_[encode(c)][start + trim + j] (aligner_extender_methods.cpp:38-59): column char vs
+// the query character one before absolute window position; 0 in the first cell and the padding
+MGX_DEV int32_t profile_at(const AlignParams &P, const uint8_t *q, int32_t L, uint8_t c, int32_t abs_pos) {
+    if (abs_pos < 1 || abs_pos > L) return 0;
+    uint32_t code = encode_char(c);
+    uint8_t row = code != 5 ? decode_code(code) : 0;
+    return score_of(P, row, q[abs_pos - 1]);
+}
+
+MGX_DEV uint8_t profile_op_at(const uint8_t *q, int32_t L, uint8_t c, int32_t abs_pos) {
+    if (abs_pos < 1 || abs_pos > L) return OP_CLIPPED;
+    uint32_t code = encode_char(c);
+    uint8_t row = code != 5 ? decode_code(code) : 0;
+    return char_to_op(row, q[abs_pos - 1]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sdust — lh3's symmetric DUST restated (github.com/lh3/sdust, sdust.c; called at
+// A/aligner_seeder_methods.cpp:22-29 with T = 20, W = 64).  Wave-uniform scalar code; `sd` is a
+// 2048-word scratch area.  Returns whether any interval is masked.
+// ------------------------------------------------------------------------------------------------
+MGX_DEV bool is_low_complexity(const uint8_t *s, int32_t l_seq, int32_t *sd) {
+    constexpr int T = 20, W = 64, WLEN = 3, WTOT = 64, WMSK = 63;
+    int32_t *cv = sd, *cw = sd + 64, *c2 = sd + 128;
+    int32_t *wq = sd + 192;                   // window deque, ring of 64
+    int32_t *Ps = sd + 256, *Pf = sd + 512, *Pr = sd + 768, *Pl = sd + 1024;   // perfect intervals (<= 256)
+    for (int i = 0; i < WTOT; ++i) { cv[i] = 0; cw[i] = 0; }
+    int wfront = 0, wcount = 0;
+    int Pn = 0;
+    bool have_res = false;
+    int res_f = 0;
+    int rv = 0, rw = 0, Lw = 0;
+    int l = 0;
+    uint32_t t = 0;
+    auto wat = [&](int idx) { return wq[(wfront + idx) & 63]; };
+    auto save_masked = [&](int start) {
+        if (Pn == 0 || Ps[Pn - 1] >= start) return;
+        int ps = Ps[Pn - 1], pf = Pf[Pn - 1];
+        bool saved = false;
+        if (have_res) {
+            if (ps <= res_f) { saved = true; res_f = res_f > pf ? res_f : pf; }
+        }
+        if (!saved) { have_res = true; res_f = pf; }
+        int i;
+        for (i = Pn - 1; i >= 0 && Ps[i] < start; --i) {}
+        Pn = i + 1;
+    };
+    for (int i = 0; i <= l_seq; ++i) {
+        int b = 4;
+        if (i < l_seq) {
+            uint32_t code = encode_char(s[i]);
+            b = code >= 1 && code <= 4 ? (int)code - 1 : 4;
+        }
+        if (b < 4) {
+            ++l;
+            t = (t << 2 | (uint32_t)b) & WMSK;
+            if (l >= WLEN) {
+                int start = (l - W > 0 ? l - W : 0) + (i + 1 - l);
+                save_masked(start);
+                // shift_window
+                if (wcount >= W - WLEN + 1) {
+                    int sv = wq[wfront & 63];
+                    wfront = (wfront + 1) & 63;
+                    --wcount;
+                    rw -= --cw[sv];
+                    if (Lw > wcount) { --Lw; rv -= --cv[sv]; }
+                }
+                wq[(wfront + wcount) & 63] = (int32_t)t;
+                ++wcount;
+                ++Lw;
+                rw += cw[t]++;
+                rv += cv[t]++;
+                if (cv[t] * 10 > T << 1) {
+                    int sv;
+                    do {
+                        sv = wat(wcount - Lw);
+                        rv -= --cv[sv];
+                        --Lw;
+                    } while (sv != (int)t);
+                }
+                if (rw * 10 > Lw * T) {
+                    // find_perfect
+                    for (int x = 0; x < WTOT; ++x) c2[x] = cv[x];
+                    int r = rv, max_r = 0, max_l = 0;
+                    for (int ii = wcount - Lw - 1; ii >= 0; --ii) {
+                        int tt = wat(ii);
+                        r += c2[tt]++;
+                        int new_r = r, new_l = wcount - ii - 1;
+                        if (new_r * 10 > T * new_l) {
+                            int j;
+                            for (j = 0; j < Pn && Ps[j] >= ii + start; ++j) {
+                                if (max_r == 0 || Pr[j] * max_l > max_r * Pl[j]) { max_r = Pr[j]; max_l = Pl[j]; }
+                            }
+                            if (max_r == 0 || new_r * max_l >= max_r * new_l) {
+                                max_r = new_r; max_l = new_l;
+                                if (Pn < 255) {
+                                    for (int m = Pn; m > j; --m) { Ps[m] = Ps[m - 1]; Pf[m] = Pf[m - 1]; Pr[m] = Pr[m - 1]; Pl[m] = Pl[m - 1]; }
+                                    ++Pn;
+                                    Ps[j] = ii + start; Pf[j] = wcount + (WLEN - 1) + start; Pr[j] = new_r; Pl[j] = new_l;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            int start = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);
+            while (Pn) save_masked(start++);
+            l = 0; t = 0;
+        }
+    }
+    return have_res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// query preparation: AlignmentResults ctor (A/alignment.cpp:1348-1372) + partial sums
+// ------------------------------------------------------------------------------------------------
+MGX_DEV void prepare_query(Wave &w, const char *raw) {
+    const AlignParams &P = *w.P;
+    const int32_t L = w.L;
+    for (int32_t base = 0; base < L; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            if (j < L) {
+                uint8_t c = (uint8_t)raw[j];
+                uint8_t f = (c & 0x80) ? 127 : to_upper(c);
+                w.q[0][j] = f;
+                w.q[1][L - 1 - j] = complement_char(f);
+            }
+        }
+    }
+    wave_sync();
+    // partial_sums_[i] = sum_{j >= i} score(q[j], q[j]); partial_sums_[L] = 0
+    for (int s = 0; s < 2; ++s) {
+        int32_t carry = 0;
+        int32_t nchunks = (L + WAVE - 1) / WAVE;
+        for (int32_t ch = nchunks - 1; ch >= 0; --ch) {
+            // process positions [ch*64, ch*64+64) from high to low: lane l handles position top - l
+            int32_t top = imin(L, (ch + 1) * WAVE) - 1;
+            LV<int32_t> x;
+            FOR_LANES(l) {
+                int32_t j = top - l;
+                x[l] = (j >= ch * WAVE) ? score_of(P, w.q[s][j], w.q[s][j]) : 0;
+            }
+            LV<int32_t> ex = wave_prefix_sum_excl(x);
+            FOR_LANES(l) {
+                int32_t j = top - l;
+                if (j >= ch * WAVE) w.psum[s][j] = carry + ex[l] + x[l];
+            }
+            carry += wave_sum(x);
+        }
+        FOR_LANES(l) { if (l == 0) w.psum[s][L] = 0; }
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// seeding
+// ------------------------------------------------------------------------------------------------
+MGX_DEV uint32_t num_exact_matching(const uint32_t *nodes, int32_t n, int32_t k) {
+    // A/aligner_seeder_methods.cpp:49-65
+    uint32_t num_matching = 0, last_match_count = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        if (nodes[i]) {
+            int32_t j = i + 1;
+            while (j < n && nodes[j]) ++j;
+            num_matching += k + (j - i) - 1 - last_match_count;
+            last_match_count = k;
+            i = j - 1;
+        } else if (last_match_count) {
+            --last_match_count;
+        }
+    }
+    return num_matching;
+}
+
+MGX_DEV bool push_seed(Wave &w, int s, int32_t clip, int32_t len, int32_t offset, int32_t n_nodes, uint32_t node) {
+    if (w.n_seeds[s] >= (int32_t)w.P->lim.max_seeds) { w.status = ST_CAPACITY; return false; }
+    DevSeed sd;
+    sd.clipping = (uint16_t)clip; sd.length = (uint16_t)len; sd.offset = (uint16_t)offset;
+    sd.n_nodes = (uint16_t)n_nodes; sd.node = node;
+    w.seeds[s][w.n_seeds[s]] = sd;
+    w.alive[s][w.n_seeds[s]] = 1;
+    ++w.n_seeds[s];
+    return true;
+}
+
+// MEMSeeder::get_seeds / ExactSeeder::get_seeds into w.seeds[s] (A/aligner_seeder_methods.cpp:67-93,360-424)
+MGX_DEV void base_seeds(Wave &w, int s) {
+    const AlignParams &P = *w.P;
+    const DevConfig &cfg = P.cfg;
+    const int32_t k = (int32_t)P.g.k, L = w.L, n = w.n_kmers;
+    const uint32_t *nodes = w.nodes[s];
+    w.n_seeds[s] = 0;
+    if ((double)w.num_matching[s] < cfg.min_exact_match * (double)L) return;
+    if ((uint32_t)k >= cfg.max_seed_length) {
+        // ExactSeeder::get_seeds
+        if (cfg.max_seed_length < (uint32_t)k) return;
+        for (int32_t i = 0; i < n; ++i) {
+            if (nodes[i]) {
+                if (!cfg.seed_complexity_filter || !is_low_complexity(w.q[s] + i, k, w.sd))
+                    if (!push_seed(w, s, i, k, 0, 1, nodes[i])) return;
+            }
+        }
+        return;
+    }
+    // flags: bit 1 = matched, bit 0 = MEM terminus (UniMEMSeeder, seeder hpp:116-135)
+    uint8_t *flags = w.pos_full;          // scratch, n <= L
+    for (int32_t base = 0; base < n; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t i = base + l;
+            if (i < n) {
+                uint8_t f = 0;
+                uint32_t v = nodes[i];
+                if (v) {
+                    bool term = (i + 1 == n) || nodes[i + 1] == 0;
+                    if (!term) term = (P.g.terminus[v >> 6] >> (v & 63)) & 1;
+                    f = 2 | (term ? 1 : 0);
+                }
+                flags[i] = f;
+            }
+        }
+    }
+    w.ctr.bit_lines += (uint32_t)n;
+    wave_sync();
+    int32_t it = 0;
+    while (it < n) {
+        while (it < n && !(flags[it] & 2)) ++it;
+        if (it >= n) break;
+        int32_t next = it;
+        while (next < n && !((flags[next] & 1) == 1 || (flags[next] & 2) == 0)) ++next;
+        if (next < n && (flags[next] & 2)) ++next;
+        int32_t mem_length = (next - it) + k - 1;
+        if ((uint32_t)mem_length >= cfg.min_seed_length)
+            if (!push_seed(w, s, it, mem_length, 0, next - it, 0)) return;
+        it = next;
+    }
+}
+
+// BOSS::index_range (boss.hpp:720-764) for one lane: codes q[i .. i + len); returns matched length,
+// *first = succ_last(rl), *last = ru
+MGX_DEV int32_t index_range_lane(const DevGraph &g, const uint8_t *q, int32_t len, uint64_t *first, uint64_t *last, LineCtr &ctr) {
+    *first = 0; *last = 0;
+    if (len == 0) { *first = 1; *last = 1; return 0; }
+    for (int32_t j = 0; j < len; ++j) if (encode_char(q[j]) == 5) return 0;
+    uint64_t rl, ru;
+    initial_range(g, encode_char(q[0]), &rl, &ru);
+    if (rl > ru) return 0;
+    int32_t it = 1;
+    for (; it < len; ++it)
+        if (!tighten_range(g, &rl, &ru, encode_char(q[it]), ctr)) break;
+    *first = succ_last(g, rl, ctr);
+    *last = ru;
+    return it;
+}
+
+// SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358, non-canonical)
+MGX_DEV void make_seeder(Wave &w, int s) {
+    const AlignParams &P = *w.P;
+    const DevConfig &cfg = P.cfg;
+    const DevGraph &g = P.g;
+    const int32_t k = (int32_t)g.k, L = w.L;
+    w.num_matching[s] = num_exact_matching(w.nodes[s], w.n_kmers, k);
+    w.n_seeds[s] = 0;
+    if ((uint32_t)L < cfg.min_seed_length) return;
+    if (cfg.min_seed_length >= (uint32_t)k) { base_seeds(w, s); return; }
+
+    const int32_t msl0 = (int32_t)cfg.min_seed_length;
+    const int32_t nslots = L - msl0 + 1;
+    base_seeds(w, s);
+    if (w.status != ST_OK) return;
+    const int32_t n_base = w.n_seeds[s];
+    // min_seed_length[] and per-position seed lists
+    for (int32_t base = 0; base < nslots; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t i = base + l;
+            if (i < nslots) { w.msl[i] = (uint16_t)msl0; w.pos_cnt[i] = 0; w.pos_full[i] = 0; w.pos_start[i] = 0; }
+        }
+    }
+    wave_sync();
+    for (int32_t b = 0; b < n_base; ++b) {
+        DevSeed sd = w.seeds[s][b];
+        int32_t i = sd.clipping;
+        for (int32_t j = 0; j < sd.n_nodes; ++j) w.msl[i + j] = (uint16_t)k;
+        if (i + sd.n_nodes < nslots) w.msl[i + sd.n_nodes] = (uint16_t)k;
+        w.pos_full[i] = 1;            // suffix_seeds[i] holds exactly this full seed
+        w.pos_cnt[i] = 1;
+        w.pos_start[i] = (uint32_t)b; // index of the full seed among the base seeds
+    }
+    wave_sync();
+    // lane-parallel longest-prefix lookups for every position that can report a seed
+    for (int32_t base = 0; base < nslots; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t i = base + l;
+            if (i < nslots) {
+                int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
+                uint16_t mlen = 0;
+                uint32_t rf = 0, rl_ = 0;
+                if (max_len >= (int32_t)w.msl[i]) {
+                    uint64_t first, last;
+                    int32_t m = index_range_lane(g, w.q[s] + i, max_len, &first, &last, w.lctr[l]);
+                    if (m >= msl0 && first && first <= g.n) {
+                        mlen = (uint16_t)m;
+                        rf = rank_last(g, first, w.lctr[l]);
+                        rl_ = rank_last(g, last, w.lctr[l]);
+                    }
+                }
+                w.ml[i] = mlen; w.rfirst[i] = rf; w.rlast[i] = rl_;
+            }
+        }
+    }
+    wave_sync();
+    // sequential bookkeeping (:195-249)
+    uint32_t alt_n = 0;
+    const int32_t last_full_id = L >= k ? L - k + 1 : nslots;
+    for (int32_t i = 0; i < nslots; ++i) {
+        int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
+        int32_t cur_msl = w.msl[i];
+        if (max_len < cur_msl) continue;                       // lookup returns immediately (dbg_succinct.cpp:314)
+        if (cfg.seed_complexity_filter && is_low_complexity(w.q[s] + i, cur_msl, w.sd)) continue;
+        int32_t seed_length = w.ml[i];
+        if (seed_length < cur_msl) continue;                   // match_size < min_match_length
+        // enumerate nodes whose suffix matches (dbg_succinct.cpp:349-392)
+        uint32_t first_alt = alt_n;
+        uint32_t cnt = 0;
+        for (uint32_t r = w.rfirst[i]; r <= w.rlast[i]; ++r) {
+            uint64_t e = select_last(g, r, w.ctr);
+            uint64_t inc[5];
+            uint32_t fc[5];
+            // call_incoming_to_target(bwd(e), node_last_value(e)) == parents of the node whose last edge is e
+            int ni = incoming(g, e, inc, fc, w.ctr);
+            for (int t = 0; t < ni; ++t) {
+                if (alt_n >= w.P->lim.max_alt) { w.status = ST_CAPACITY; return; }
+                w.alt[alt_n++] = (uint32_t)inc[t];
+                ++cnt;
+            }
+        }
+        if (i >= last_full_id && cnt == 1 && w.msl[last_full_id - 1] == k && w.pos_full[last_full_id - 1]
+                && w.pos_cnt[last_full_id - 1] == 1) {
+            DevSeed fs = w.seeds[s][w.pos_start[last_full_id - 1]];
+            uint32_t first_node = w.nodes[s][fs.clipping];
+            if (w.alt[first_alt] == first_node) { alt_n = first_alt; continue; }
+        }
+        // append_suffix_seed for every alt node (:195-213)
+        for (uint32_t a = 0; a < cnt; ++a) {
+            int32_t ii = i;
+            int32_t sl = seed_length;
+            if (sl > (int32_t)w.msl[ii]) { w.pos_cnt[ii] = 0; w.pos_full[ii] = 0; }
+            w.msl[ii] = (uint16_t)sl;
+            if (w.pos_cnt[ii] == 0) { w.pos_start[ii] = first_alt + a; w.pos_full[ii] = 0; }
+            ++w.pos_cnt[ii];
+            for (++ii; ii < nslots && sl > (int32_t)w.msl[ii]; ++ii) {
+                w.msl[ii] = (uint16_t)sl--;
+                w.pos_cnt[ii] = 0;
+                w.pos_full[ii] = 0;
+            }
+        }
+    }
+    // aggregate (:316-357): rebuild the seed list in position order
+    // full seeds are already stored at [0, n_base); copy them out of the way first
+    DevSeed *tmp = (DevSeed *)w.indices;         // scratch big enough for n_base <= L seeds
+    for (int32_t b = 0; b < n_base; ++b) tmp[b] = w.seeds[s][b];
+    w.n_seeds[s] = 0;
+    uint32_t num_matching = 0;
+    int32_t last_end = 0;
+    for (int32_t i = 0; i < nslots; ++i) {
+        int32_t cnt = w.pos_cnt[i];
+        if (!cnt) continue;
+        bool full = w.pos_full[i];
+        bool emitted = false;
+        int32_t begin = i, end = 0;
+        if (full) {
+            DevSeed fs = tmp[w.pos_start[i]];
+            if (!push_seed(w, s, fs.clipping, fs.length, 0, fs.n_nodes, fs.node)) return;
+            end = begin + fs.length;
+            emitted = true;
+        } else if ((uint32_t)cnt <= cfg.max_num_seeds_per_locus) {
+            int32_t sl = w.msl[i];
+            for (int32_t a = 0; a < cnt; ++a)
+                if (!push_seed(w, s, i, sl, k - sl, 1, w.alt[w.pos_start[i] + a])) return;
+            end = begin + sl;
+            emitted = true;
+        }
+        if (emitted) {
+            if (begin < last_end) num_matching += end - begin - (last_end - begin);
+            else num_matching += end - begin;
+            last_end = end;
+        }
+    }
+    w.num_matching[s] = num_matching;
+}
+
+// ------------------------------------------------------------------------------------------------
+// convergence checker (SeedFilteringExtender, A/aligner_extender_methods.cpp:66-207)
+// ------------------------------------------------------------------------------------------------
+MGX_DEV void conv_clear(ConvChecker &c) { ++c.gen; c.n_entries = 0; }
+
+MGX_DEV uint32_t conv_hash(uint64_t key, uint32_t mask) {
+    key ^= key >> 33; key *= 0xff51afd7ed558ccdULL; key ^= key >> 33;
+    return (uint32_t)key & mask;
+}
+
+// returns entry index or -1; *slot_out = slot where the key would be inserted
+MGX_DEV int32_t conv_find(const ConvChecker &c, uint32_t mask, uint64_t key, uint32_t *slot_out) {
+    uint32_t h = conv_hash(key, mask);
+    for (;;) {
+        ConvSlot sl = c.slots[h];
+        if (sl.gen != c.gen) { *slot_out = h; return -1; }
+        if (c.entries[sl.idx].key == key) { *slot_out = h; return (int32_t)sl.idx; }
+        h = (h + 1) & mask;
+    }
+}
+
+MGX_DEV int32_t conv_insert(Wave &w, ConvChecker &c, uint32_t slot, uint64_t key, int32_t start, int32_t len) {
+    uint32_t cap = w.P->lim.max_columns + w.P->lim.max_path;
+    if (c.n_entries >= cap || c.n_entries * 2 >= w.P->lim.hash_size) { w.status = ST_CAPACITY; return -1; }
+    uint32_t idx = c.n_entries++;
+    ConvEntry e; e.key = key; e.start = start; e.len = len;
+    c.entries[idx] = e;
+    ConvSlot sl; sl.gen = c.gen; sl.idx = idx;
+    c.slots[slot] = sl;
+    return (int32_t)idx;
+}
+
+// fill vec positions [a, b) with `val`
+MGX_DEV void fill_range(int32_t *vec, int32_t a, int32_t b, int32_t val) {
+    for (int32_t base = a; base < b; base += WAVE) {
+        FOR_LANES(l) { int32_t j = base + l; if (j < b) vec[j] = val; }
+    }
+}
+
+// update_seed_filter (:100-156).  s = cells of the column (S at stride 3), size cells starting at
+// query position query_start.  Returns converged score (NINF = nothing improved).
+MGX_DEV int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start,
+                                   const int32_t *s_cells, int32_t size) {
+    const AlignParams &P = *w.P;
+    auto column_max = [&]() {
+        int32_t m = INT32_MIN;
+        for (int32_t base = 0; base < size; base += WAVE) {
+            LV<int32_t> x;
+            FOR_LANES(l) { int32_t j = base + l; x[l] = j < size ? s_cells[3 * j] : INT32_MIN; }
+            m = imax(m, wave_max(x));
+        }
+        return m;
+    };
+    if (node == 0) return column_max();
+    uint64_t key = (uint64_t)node + (E.rc_view ? P.g.n : 0);
+    uint32_t mask = P.lim.hash_size - 1, slot;
+    int32_t idx = conv_find(E.conv, mask, key, &slot);
+    const int32_t Lq = (int32_t)P.lim.Lmax;
+    if (idx < 0) {
+        idx = conv_insert(w, E.conv, slot, key, query_start, size);
+        if (idx < 0) return NINF;
+        int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
+        for (int32_t base = 0; base < size; base += WAVE) {
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[3 * j]; }
+        }
+        wave_sync();
+        return column_max();
+    }
+    ConvEntry e = E.conv.entries[idx];
+    int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
+    int32_t start = e.start, len = e.len;
+    if (query_start + size <= start) {
+        fill_range(vec, query_start + size, start, NINF);
+        for (int32_t base = 0; base < size; base += WAVE) {
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[3 * j]; }
+        }
+        e.len = start + len - query_start; e.start = query_start;
+        E.conv.entries[idx] = e;
+        wave_sync();
+        return column_max();
+    }
+    if (query_start >= start + len) {
+        fill_range(vec, start + len, query_start, NINF);
+        for (int32_t base = 0; base < size; base += WAVE) {
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[3 * j]; }
+        }
+        e.len = query_start + size - start;
+        E.conv.entries[idx] = e;
+        wave_sync();
+        return column_max();
+    }
+    if (query_start < start) { fill_range(vec, query_start, start, NINF); len += start - query_start; start = query_start; }
+    if (query_start + size > start + len) { fill_range(vec, start + len, query_start + size, NINF); len = query_start + size - start; }
+    e.start = start; e.len = len;
+    E.conv.entries[idx] = e;
+    wave_sync();
+    int32_t max_changed = NINF;
+    const double rel = P.cfg.rel_score_cutoff;
+    for (int32_t base = 0; base < size; base += WAVE) {
+        LV<int32_t> x;
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            x[l] = NINF;
+            if (j < size) {
+                int32_t sv = s_cells[3 * j];
+                int32_t vv = vec[query_start + j];
+                if ((double)sv > (double)vv * rel) {
+                    vv = imax(vv, sv);
+                    vec[query_start + j] = vv;
+                    x[l] = vv;
+                }
+            }
+        }
+        max_changed = imax(max_changed, wave_max(x));
+    }
+    wave_sync();
+    return max_changed;
+}
+
+// check_seed (:66-88): true when the seed is still worth extending
+MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int32_t qlen, int32_t clipping, int32_t score) {
+    const AlignParams &P = *w.P;
+    uint64_t key = (uint64_t)last_node + (E.rc_view ? P.g.n : 0);
+    uint32_t slot;
+    int32_t idx = conv_find(E.conv, P.lim.hash_size - 1, key, &slot);
+    if (idx < 0) return true;
+    ConvEntry e = E.conv.entries[idx];
+    int32_t pos = qlen + clipping - 1;
+    if (pos < e.start || pos - e.start >= e.len) return true;
+    return E.conv.vecs[(uint64_t)idx * P.lim.Lmax + pos] < score;
+}
+
+// filter_nodes (:158-207); the key is the raw node id (no RCDBG offset), as in the reference
+MGX_DEV void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start, int32_t query_end) {
+    const AlignParams &P = *w.P;
+    const int32_t mscore = -NINF;
+    int32_t size = query_end - query_start;
+    uint32_t slot;
+    int32_t idx = conv_find(E.conv, P.lim.hash_size - 1, (uint64_t)node, &slot);
+    const int32_t Lq = (int32_t)P.lim.Lmax;
+    if (idx < 0) {
+        idx = conv_insert(w, E.conv, slot, (uint64_t)node, query_start, size);
+        if (idx < 0) return;
+        fill_range(E.conv.vecs + (uint64_t)idx * Lq, query_start, query_end, mscore);
+        wave_sync();
+        return;
+    }
+    ConvEntry e = E.conv.entries[idx];
+    int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
+    int32_t start = e.start, len = e.len;
+    if (query_start + size <= start) {
+        fill_range(vec, query_start + size, start, NINF);
+        fill_range(vec, query_start, query_start + size, mscore);
+        e.len = start + len - query_start; e.start = query_start;
+    } else if (query_start >= start + len) {
+        fill_range(vec, start + len, query_start, NINF);
+        fill_range(vec, query_start, query_end, mscore);
+        e.len = query_start + size - start;
+    } else {
+        if (query_start < start) { fill_range(vec, query_start, start, NINF); len += start - query_start; start = query_start; }
+        if (query_start + size > start + len) { fill_range(vec, start + len, query_start + size, NINF); len = query_start + size - start; }
+        fill_range(vec, query_start, query_end, mscore);      // mscore is the maximum, so max(v, mscore) == mscore
+        e.start = start; e.len = len;
+    }
+    E.conv.entries[idx] = e;
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// extension (DefaultColumnExtender::extend, A/aligner_extender_methods.cpp:412-772)
+// ------------------------------------------------------------------------------------------------
+MGX_DEV int32_t cell_S(const Wave &w, const ColMeta &c, int32_t j) {
+    return (j >= 0 && j < c.size + 5) ? w.cells[c.cells + 3 * j] : NINF;   // outside: undefined in the reference
+}
+MGX_DEV int32_t cell_E(const Wave &w, const ColMeta &c, int32_t j) { return (j >= 0 && j < c.size + 5) ? w.cells[c.cells + 3 * j + 1] : NINF; }
+MGX_DEV int32_t cell_F(const Wave &w, const ColMeta &c, int32_t j) { return (j >= 0 && j < c.size + 5) ? w.cells[c.cells + 3 * j + 2] : NINF; }
+
+// capacity of a reference vector created with `size0` elements (+5 reserved) after `pushes` push_backs
+// followed by reserve(size + 5) (DPTColumn::create :389-410, extend_ins_end :293-328; libstdc++ growth)
+MGX_DEV uint32_t ref_capacity(uint32_t size0, uint32_t pushes) {
+    uint32_t cap = size0 + 5, sz = size0;
+    if (!pushes) return cap;
+    // pushes happen one at a time; capacity doubles when full
+    uint32_t target = size0 + pushes;
+    while (cap < target) cap = imax<uint32_t>(1u, 2 * cap);
+    (void)sz;
+    return imax(cap, target + 5);
+}
+
+MGX_DEV uint64_t queue_key(int32_t score, int32_t neg_off_diag, uint32_t idx) {
+    // orders like std::tuple<score, -|off diag|, table idx, ...> (:477-480); idx is unique.
+    // 24 bits of score (|score| < 2^23), 16 bits of off-diagonal distance, 24 bits of table index.
+    return ((uint64_t)(uint32_t)(score + (1 << 23)) << 40) | ((uint64_t)(uint32_t)(neg_off_diag + 32768) << 24) | idx;
+}
+MGX_DEV int32_t key_score(uint64_t key) { return (int32_t)(uint32_t)(key >> 40) - (1 << 23); }
+MGX_DEV uint32_t key_idx(uint64_t key) { return (uint32_t)(key & 0xFFFFFF); }
+
+// index of the maximum key among queue[0..n), -1 if none satisfies score == want (want_any: any)
+MGX_DEV int32_t queue_argmax(const uint64_t *queue, int32_t n, bool restrict_score, int32_t want) {
+    uint64_t best = 0;
+    int32_t best_i = -1;
+    for (int32_t base = 0; base < n; base += WAVE) {
+        LV<uint64_t> x;
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            uint64_t kx = 0;
+            if (j < n) {
+                uint64_t key = queue[j];
+                if (!restrict_score || key_score(key) == want) kx = key;
+            }
+            x[l] = kx;
+        }
+        uint64_t m = wave_max_u64(x);
+        if (m > best) {
+            best = m;
+            LV<bool> hit;
+            FOR_LANES(l) { hit[l] = x[l] == m; }
+            best_i = base + ctz64(wave_ballot(hit));
+        }
+    }
+    return best_i;
+}
+
+// Compute one DP column into freshly reserved cells (update_column :209-290 + extend_ins_end :293-328).
+// Returns the final size (cells) and the number of pushes in *pushes.
+MGX_DEV int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta &prev, int32_t prev_end, int32_t begin,
+                               int32_t size, uint32_t cells_off, uint8_t c, int32_t init_score, int32_t offset,
+                               int32_t start, int32_t window_size, int32_t xdrop_cutoff, int32_t *pushes) {
+    const AlignParams &P = *w.P;
+    const int32_t go = P.cfg.gap_open, ge = P.cfg.gap_ext;
+    const int32_t L = w.L;
+    int32_t *cells = w.cells + cells_off;
+    const int32_t trim = begin;
+    const int32_t max_size = window_size + 1 - trim;
+    // DPTColumn::create: size + 5 cells of ninf (we initialise everything the column may grow into)
+    const int32_t init_n = imin(max_size, size) + 8;
+    for (int32_t base = 0; base < 3 * init_n; base += WAVE) {
+        FOR_LANES(l) { int32_t j = base + l; if (j < 3 * init_n) cells[j] = NINF; }
+    }
+    wave_sync();
+    const int32_t n_prev = prev_end - trim;                 // update_column's prev_end
+    const int32_t n_loop = (n_prev + 3) & ~3;               // lanes computed in blocks of 4
+    const int32_t dp = trim - prev.trim;                    // S_prev_v = S_prev.data() + trim - trim_prev
+    int32_t e_carry = NINF;                                 // E_v[base], E_v[0] = ninf
+    int32_t tmax_carry = INT32_MIN;
+    for (int32_t base = 0; base < n_loop; base += WAVE) {
+        LV<int32_t> m, tval;
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            int32_t mm = NINF;
+            if (j < n_loop) {
+                int32_t match = NINF;
+                if (j) match = cell_S(w, prev, dp + j - 1) + profile_at(P, E.q, L, c, start + trim + j) + init_score;
+                int32_t del = NINF;
+                if (offset > 1) del = imax(cell_S(w, prev, dp + j) + go, cell_F(w, prev, dp + j) + ge) + init_score;
+                cells[3 * j + 2] = del;                     // F_v[j]
+                mm = imax(match, del);
+            }
+            m[l] = mm;
+            // E[j + 1] = max(E[j] + ge, m[j] + go)  ==  max_i<=j (m[i] + go + (j - i) ge)  or the E[0] chain
+            tval[l] = j < n_loop ? mm + go - j * ge : INT32_MIN;
+        }
+        LV<int32_t> pm = wave_prefix_max(tval);
+        LV<int32_t> enext;                                  // E[j + 1]
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            int32_t t = imax(pm[l], tmax_carry);
+            int32_t from_open = t + j * ge;
+            int64_t fe0 = (int64_t)NINF + (int64_t)(j + 1) * ge;     // E[0] = ninf extended j + 1 times
+            int32_t from_e0 = fe0 < (int64_t)INT32_MIN ? INT32_MIN : (int32_t)fe0;
+            enext[l] = j < n_loop ? imax(from_open, from_e0) : NINF;
+        }
+        LV<int32_t> ecur = wave_shift_up1(enext, e_carry);  // E[j]
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            if (j < n_loop) {
+                cells[3 * (j + 1) + 1] = enext[l];          // E_v[j + 1]
+                int32_t sv = imax(m[l], ecur[l]);
+                cells[3 * j] = sv > xdrop_cutoff - 1 ? sv : NINF;
+            }
+        }
+        int32_t last_lane = imin(WAVE, n_loop - base) - 1;
+        e_carry = wave_bcast(enext, last_lane);
+        tmax_carry = imax(tmax_carry, wave_max(tval));
+    }
+    wave_sync();
+    if (size > imax(1, n_prev)) {                            // scalar tail (:284-289)
+        int32_t j = size - 1;
+        int32_t match = imax(cell_S(w, prev, dp + j - 1) + init_score + profile_at(P, E.q, L, c, start + trim + j),
+                             cells[3 * j + 1]);
+        if (match >= xdrop_cutoff) {
+            FOR_LANES(l) { if (l == 0) cells[3 * j] = match; }
+        }
+    }
+    wave_sync();
+    // extend_ins_end
+    *pushes = 0;
+    if (size < max_size) {
+        int32_t ins_score = imax(cells[3 * (size - 1)] + go, cells[3 * (size - 1) + 1] + ge);
+        if (ins_score >= xdrop_cutoff) {
+            int32_t n_push = 1;
+            // further pushes while E.back() + ge >= cutoff && E.size() < max_size
+            int32_t room = max_size - (size + 1);
+            if (ge == 0) {
+                n_push += room;
+            } else {
+                int32_t v = ins_score;
+                while (n_push - 1 < room && v + ge >= xdrop_cutoff) { v += ge; ++n_push; }
+            }
+            for (int32_t base = 0; base < n_push; base += WAVE) {
+                FOR_LANES(l) {
+                    int32_t t = base + l;
+                    if (t < n_push) {
+                        int32_t v = ins_score + t * ge;
+                        cells[3 * (size + t)] = v;
+                        cells[3 * (size + t) + 1] = v;
+                        cells[3 * (size + t) + 2] = NINF;
+                    }
+                }
+            }
+            // padding after the new end is ninf
+            FOR_LANES(l) {
+                if (l < 5) {
+                    int32_t j = size + n_push + l;
+                    cells[3 * j] = NINF; cells[3 * j + 1] = NINF; cells[3 * j + 2] = NINF;
+                }
+            }
+            *pushes = n_push;
+            size += n_push;
+        }
+    }
+    wave_sync();
+    return size;
+}
+
+struct ExtendResult { int32_t n_tips; int32_t min_cell_score; int32_t table_size; };
+
+// children of table[i] (DefaultColumnExtender::call_outgoing :330-387, non-canonical graphs)
+MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
+                          uint32_t *nodes, uint8_t *chars, int32_t *scores) {
+    const AlignParams &P = *w.P;
+    const int32_t k = (int32_t)P.g.k;
+    int32_t next_offset = col.offset + 1;
+    int32_t seed_pos = next_offset - seed.offset;
+    bool in_seed = seed_pos >= 0 && seed_pos < seed.seq_len;
+    if (in_seed && next_offset < k) {
+        nodes[0] = seed.nodes[0]; chars[0] = seed.seq[seed_pos]; scores[0] = 0;
+        return 1;
+    }
+    if (in_seed && force_fixed_seed) {
+        int32_t node_i = next_offset - k + 1;
+        uint32_t next_node = seed.nodes[node_i];
+        nodes[0] = next_node; chars[0] = seed.seq[seed_pos];
+        scores[0] = next_node ? 0 : (!col.node ? P.cfg.gap_ext : P.cfg.gap_open);
+        return 1;
+    }
+    uint64_t nn[5];
+    uint32_t cc[5];
+    int n;
+    if (!E.rc_view) {
+        n = outgoing(P.g, col.node, nn, cc, w.ctr);
+        for (int t = 0; t < n; ++t) { nodes[t] = (uint32_t)nn[t]; chars[t] = decode_code(cc[t]); scores[t] = 0; }
+        return n;
+    }
+    // RCDBG::call_outgoing_kmers (rc_dbg.hpp:88-99): parents with the complemented first character
+    n = incoming(P.g, col.node, nn, cc, w.ctr);
+    int m = 0;
+    for (int t = 0; t < n; ++t) {
+        if (cc[t] == 0) continue;                             // complement('$') == '$' is dropped (:381-384)
+        nodes[m] = (uint32_t)nn[t]; chars[m] = complement_char(decode_code(cc[t])); scores[m] = 0;
+        ++m;
+    }
+    return m;
+}
+
+MGX_DEV void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed, ExtendResult *res) {
+    const AlignParams &P = *w.P;
+    const DevConfig &cfg = P.cfg;
+    const DevLimits &lim = P.lim;
+    ++w.n_extensions;
+    // table.clear(); prev_starts.clear()
+    for (uint32_t base = 0; base < (lim.max_columns + 31) / 32; base += WAVE) {
+        FOR_LANES(l) { uint32_t j = base + l; if (j < (lim.max_columns + 31) / 32) w.prev_starts[j] = 0; }
+    }
+    const int32_t xdrop = cfg.xdrop;                          // added_xdrop == 0
+    int32_t xdrop_cutoff = imax(-xdrop, NINF + 1);
+    const int32_t start = seed.clipping;
+    const int32_t window_size = w.L - start;                  // trim_query_suffix == 0
+    const int32_t partial_sum_offset = E.psum[start + window_size];
+    const int32_t seed_offset = seed.offset - 1;
+    uint32_t cell_top = 0;
+    int32_t tsize = 0;
+    uint64_t table_size_bytes = 0;
+    // root column
+    {
+        ColMeta r;
+        r.node = seed.nodes[0]; r.parent = -1; r.c = 0; r.offset = seed_offset; r.max_pos = 0; r.trim = 0;
+        r.score = 0; r.cells = cell_top; r.size = 1;
+        int32_t *cells = w.cells;
+        int32_t max_size = window_size + 1;
+        int32_t init_n = 8;
+        FOR_LANES(l) { if (l < 3 * init_n) cells[l] = NINF; }
+        wave_sync();
+        int32_t s0 = (cfg.left_end_bonus && !seed.clipping) ? cfg.left_end_bonus : 0;
+        FOR_LANES(l) { if (l == 0) cells[0] = s0; }
+        wave_sync();
+        int32_t pushes = 0;
+        if (1 < max_size) {
+            int32_t ins_score = imax(s0 + cfg.gap_open, NINF + cfg.gap_ext);
+            if (ins_score >= xdrop_cutoff) {
+                int32_t n_push = 1, room = max_size - 2;
+                if (cfg.gap_ext == 0) n_push += room;
+                else { int32_t v = ins_score; while (n_push - 1 < room && v + cfg.gap_ext >= xdrop_cutoff) { v += cfg.gap_ext; ++n_push; } }
+                if ((uint64_t)3 * (1 + n_push + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
+                for (int32_t base = 0; base < n_push + 5; base += WAVE) {
+                    FOR_LANES(l) {
+                        int32_t t = base + l;
+                        if (t < n_push) {
+                            int32_t v = ins_score + t * cfg.gap_ext;
+                            cells[3 * (1 + t)] = v; cells[3 * (1 + t) + 1] = v; cells[3 * (1 + t) + 2] = NINF;
+                        } else if (t < n_push + 5) {
+                            cells[3 * (1 + t)] = NINF; cells[3 * (1 + t) + 1] = NINF; cells[3 * (1 + t) + 2] = NINF;
+                        }
+                    }
+                }
+                pushes = n_push;
+            }
+        }
+        r.size = 1 + pushes;
+        r.cap3 = 3 * ref_capacity(1, (uint32_t)pushes);
+        cell_top += 3 * (uint32_t)(r.size + 5);
+        if (E.table_cap < 1) E.table_cap = 1;                 // emplace_back on an empty vector
+        w.cols[0] = r;
+        tsize = 1;
+        table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)r.cap3 * 4;
+        wave_sync();
+    }
+    int32_t min_cell_score = 0;
+    int32_t best_score = 0;
+    int32_t qn = 0, nn = 0, n_tips = 0;
+    w.queue[qn++] = queue_key(0, 0, 0);
+    wave_sync();
+    const int32_t k = (int32_t)P.g.k;
+
+    while (qn) {
+        // pop every entry that shares the top score, in descending tuple order (:491-500)
+        {
+            int32_t bi = queue_argmax(w.queue, qn, false, 0);
+            int32_t top_score = key_score(w.queue[bi]);
+            nn = 0;
+            while (bi >= 0) {
+                uint64_t key = w.queue[bi];
+                w.next_nodes[nn++] = key;
+                w.queue[bi] = w.queue[qn - 1];
+                --qn;
+                wave_sync();
+                bi = qn ? queue_argmax(w.queue, qn, true, top_score) : -1;
+            }
+        }
+        while (nn) {
+            const uint64_t batch_first_key = w.next_nodes[0];
+            int32_t i = (int32_t)key_idx(w.next_nodes[nn - 1]);
+            --nn;
+            const ColMeta col = w.cols[i];
+            const int32_t next_offset = col.offset + 1;
+            const int32_t prev_xdrop_cutoff = xdrop_cutoff;       // global_xdrop: one shared cutoff
+            const bool in_seed = (next_offset - seed.offset) >= 0 && (next_offset - seed.offset) < seed.seq_len;
+            // early cut-offs when off the optimal path (:521-547)
+            if (cell_S(w, col, col.max_pos - col.trim) < best_score) {
+                double node_counter = (double)tsize;
+                if (node_counter / (double)window_size >= cfg.max_nodes_per_seq_char) { qn = 0; nn = 0; continue; }
+                if ((double)table_size_bytes / 1000000.0 > cfg.max_ram_per_alignment) { qn = 0; nn = 0; continue; }
+            }
+            // band within the x-drop cutoff (:549-560)
+            int32_t b = col.size, e = 0;
+            for (int32_t base = 0; base < col.size; base += WAVE) {
+                LV<bool> inr;
+                FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && w.cells[col.cells + 3 * j] >= prev_xdrop_cutoff; }
+                uint64_t mk = wave_ballot(inr);
+                if (mk) {
+                    if (b == col.size) b = base + ctz64(mk);
+                    e = base + 64 - clz64(mk);
+                }
+            }
+            int32_t begin = b + col.trim, prev_end = e + col.trim;
+            if (prev_end <= begin) continue;
+
+            uint32_t out_nodes[5];
+            uint8_t out_chars[5];
+            int32_t out_scores[5];
+            int n_out = call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores);
+            if (n_out == 0) {
+                if (n_tips < (int32_t)lim.max_columns) w.tips[n_tips++] = (uint32_t)i;
+                continue;
+            }
+            const int32_t end = imin(prev_end, window_size) + 1;
+            for (int oi = 0; oi < n_out; ++oi) {
+                const uint32_t next = out_nodes[oi];
+                const uint8_t c = to_upper(out_chars[oi]);
+                const int32_t score = out_scores[oi];
+                if (tsize >= (int32_t)lim.max_columns - 1) { w.status = ST_CAPACITY; res->table_size = 0; return; }
+                int32_t size0 = end - begin;
+                uint32_t need = 3 * (uint32_t)(window_size + 1 - begin + 8);     // the column may grow to the window end
+                if ((uint64_t)cell_top + need > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
+                uint32_t table_cap_before = E.table_cap;
+                if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
+                ++w.n_columns;
+                int32_t pushes = 0;
+                int32_t size = compute_column(w, E, col, prev_end, begin, size0, cell_top, c, score, next_offset,
+                                              start, window_size, xdrop_cutoff, &pushes);
+                ColMeta cur;
+                cur.node = next; cur.parent = i; cur.c = c; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
+                cur.score = score; cur.cells = cell_top; cur.size = size;
+                cur.cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
+                const int32_t *cc = w.cells + cell_top;
+                // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
+                const int32_t diag_i = next_offset - seed_offset;
+                bool has_extension = in_seed;
+                const int32_t extension_cutoff =
+                    (int32_t)fma_f64((double)best_score, cfg.rel_score_cutoff, (double)partial_sum_offset);
+                uint64_t best_key = 0;
+                for (int32_t base = 0; base < size; base += WAVE) {
+                    LV<int32_t> mn;
+                    LV<uint64_t> key;
+                    LV<bool> ext;
+                    FOR_LANES(l) {
+                        int32_t j = base + l;
+                        int32_t sv = j < size ? cc[3 * j] : NINF;
+                        mn[l] = (j < size && sv != NINF) ? sv : INT32_MAX;
+                        // lexicographic (S desc, |pos - diag| asc, j asc)
+                        uint32_t dist = (uint32_t)iabs(j + begin - diag_i);
+                        key[l] = j < size ? (((uint64_t)((uint32_t)sv ^ 0x80000000u) << 32) | ((uint64_t)(0xFFFFu - imin<uint32_t>(dist, 0xFFFFu)) << 16)
+                                             | (uint64_t)(0xFFFFu - (uint32_t)j)) : 0;
+                        ext[l] = j < size && sv + E.psum[start + begin + j] >= extension_cutoff;
+                    }
+                    min_cell_score = imin(min_cell_score, wave_min(mn));
+                    best_key = imax(best_key, wave_max_u64(key));
+                    if (wave_ballot(ext)) has_extension = true;
+                }
+                cur.max_pos = (int32_t)(0xFFFFu - (uint32_t)(best_key & 0xFFFF)) + begin;
+                const int32_t max_val = cc[3 * (cur.max_pos - begin)];
+                if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) {
+                    // pop(table.size() - 1): the vector keeps its (possibly grown) capacity
+                    continue;
+                }
+                uint32_t table_sizediff = E.table_cap - table_cap_before;
+                table_size_bytes += (uint64_t)136 * table_sizediff + (uint64_t)cur.cap3 * 4;
+                if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
+                best_score = imax(best_score, max_val);
+                // commit the column
+                w.cols[tsize] = cur;
+                cell_top += 3 * (uint32_t)(size + 5);
+                const int32_t my_idx = tsize;
+                ++tsize;
+                wave_sync();
+                const int32_t vec_offset = start + begin - (begin ? 1 : 0);
+                const int32_t skip = begin ? 0 : 1;
+                int32_t converged = update_seed_filter(w, E, next, vec_offset, cc + 3 * skip, size - skip);
+                if (w.status != ST_OK) { res->table_size = 0; return; }
+                if (converged != NINF) {
+                    uint64_t key = queue_key(converged, -iabs(cur.max_pos - diag_i), (uint32_t)my_idx);
+                    // next_nodes[0] is the first element popped into this batch (still there unless the
+                    // batch has been fully consumed, in which case next_nodes.size() == 0)
+                    if (nn && converged == key_score(w.next_nodes[0])) {
+                        w.next_nodes[nn++] = key;
+                    } else {
+                        w.queue[qn++] = key;
+                    }
+                    wave_sync();
+                }
+                (void)batch_first_key;
+            }
+        }
+    }
+    res->n_tips = n_tips;
+    res->min_cell_score = min_cell_score;
+    res->table_size = tsize;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backtracking (DefaultColumnExtender::backtrack + construct_alignment, :774-1034), target_node == npos
+// Writes at most one alignment into `out`; returns whether one was produced.
+// ------------------------------------------------------------------------------------------------
+MGX_DEV bool prev_start_test_and_set(Wave &w, int32_t j) {
+    uint32_t word = w.prev_starts[j >> 5];
+    bool was = (word >> (j & 31)) & 1;
+    if (!was) { w.prev_starts[j >> 5] = word | (1u << (j & 31)); }
+    return !was;       // true when newly inserted (emplace(...).second)
+}
+
+MGX_DEV void cigar_append(uint32_t *ops, int32_t *n, uint32_t op, uint32_t num, int32_t cap, int32_t *status) {
+    if (!num) return;
+    if (*n == 0 || (ops[*n - 1] & 7) != op) {
+        if (*n >= cap) { *status = ST_CAPACITY; return; }
+        ops[(*n)++] = (num << 3) | op;
+    } else {
+        ops[*n - 1] += num << 3;
+    }
+}
+
+MGX_DEV void seed_as_alignment(Wave &w, const SeedRef &seed, DevAln &out);
+
+MGX_DEV void copy_aln(DevAln &dst, const DevAln &src);
+
+// seed_aln: the Alignment the seed was made from (backward pass) or nullptr for Seed-derived seeds
+MGX_DEV bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, const DevAln *seed_aln,
+                       const ExtendResult &er, int32_t min_path_score, DevAln &out) {
+    const AlignParams &P = *w.P;
+    const DevConfig &cfg = P.cfg;
+    const int32_t k = (int32_t)P.g.k;
+    const int32_t seed_clipping = seed.clipping;
+    const int32_t seed_offset = seed.offset - 1;
+    const int32_t k_minus_1 = k - 1;
+    const int32_t window_size = w.L - seed.clipping;
+    const int32_t last_pos = window_size;
+    const int32_t seed_dist = imax(k, seed.seq_len) - 1;
+    const int32_t min_start_score = min_path_score;
+    const int32_t min_trace_length = k - seed.offset;
+    const int32_t right_end_bonus = cfg.right_end_bonus;
+    const int32_t cap = (int32_t)P.lim.max_path;
+    const int32_t tsize = er.table_size;
+    // sort tips (std::sort :758); n_tips is small: insertion sort
+    for (int32_t a = 1; a < er.n_tips; ++a) {
+        uint32_t v = w.tips[a];
+        int32_t b = a - 1;
+        while (b >= 0 && w.tips[b] > v) { w.tips[b + 1] = w.tips[b]; --b; }
+        w.tips[b + 1] = v;
+    }
+    // candidate start cells (:815-867)
+    int32_t n_idx = 0;
+    {
+        int32_t it = 0;
+        for (int32_t i = 1; i < tsize; ++i) {
+            while (it < er.n_tips && (uint32_t)i > w.tips[it]) ++it;
+            const ColMeta col = w.cols[i];
+            if (col.offset < seed_dist) continue;
+            const ColMeta par = w.cols[col.parent];
+            bool is_tip = it < er.n_tips && (uint32_t)i == w.tips[it];
+            for (int pass = 0; pass < 2; ++pass) {
+                int32_t start_pos;
+                if (pass == 0) start_pos = col.max_pos;
+                else {
+                    if (!(col.size + col.trim == window_size + 1 && col.max_pos != last_pos)) break;
+                    start_pos = last_pos;
+                }
+                if (start_pos < par.trim + 1) continue;
+                int32_t pos = start_pos - col.trim, pos_p = start_pos - par.trim - 1;
+                int32_t sv = cell_S(w, col, pos), sp = cell_S(w, par, pos_p);
+                if (sv == NINF || sp == NINF) continue;
+                int32_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
+                if (sv + end_bonus >= min_start_score) {
+                    bool is_match = sv == sp + col.score + profile_at(P, E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos)
+                        && profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos) == OP_MATCH;
+                    if (is_match || start_pos == last_pos || is_tip) {
+                        BtIndex bx;
+                        bx.score = sv + end_bonus; bx.neg_off_diag = -iabs(start_pos - col.offset + seed_offset);
+                        bx.neg_i = -i; bx.pos = start_pos;
+                        w.indices[n_idx++] = bx;
+                    }
+                }
+            }
+        }
+    }
+    wave_sync();
+    bool produced = false;
+    int32_t best_score = INT32_MIN;
+    int32_t remaining = n_idx;
+    while (remaining > 0 && !produced) {        // terminate_backtrack_start: num_alternative_paths == 1
+        // pop the lexicographic maximum (score, -off_diag, -i, pos) (:873-879)
+        int32_t bi = 0;
+        for (int32_t x = 1; x < remaining; ++x) {
+            BtIndex a = w.indices[x], b = w.indices[bi];
+            bool gt = a.score != b.score ? a.score > b.score
+                    : a.neg_off_diag != b.neg_off_diag ? a.neg_off_diag > b.neg_off_diag
+                    : a.neg_i != b.neg_i ? a.neg_i > b.neg_i : a.pos > b.pos;
+            if (gt) bi = x;
+        }
+        BtIndex cur = w.indices[bi];
+        w.indices[bi] = w.indices[remaining - 1];
+        --remaining;
+        int32_t j = -cur.neg_i;
+        if (!prev_start_test_and_set(w, j)) continue;       // skip_backtrack_start
+        int32_t score = cur.score;
+        if (score - er.min_cell_score < best_score) break;
+
+        int32_t n_ops = 0, n_path = 0, n_seq = 0, n_trace = 0;
+        int32_t dummy_counter = 0;
+        int32_t pos = cur.pos;
+        const int32_t end_pos = pos;
+        int32_t align_offset = seed.offset;
+        int32_t extra_score = 0;
+        uint32_t last_path_node = 0;
+        auto append_node = [&](uint32_t node, uint8_t c, int32_t offset, uint32_t op) {
+            if (n_seq >= cap) { w.status = ST_CAPACITY; return; }
+            w.rev_seq[n_seq++] = c;
+            cigar_append(w.rev_ops, &n_ops, op, 1, cap, &w.status);
+            if (offset >= k_minus_1) {
+                if (n_path >= cap) { w.status = ST_CAPACITY; return; }
+                w.rev_nodes[n_path++] = node;
+                last_path_node = node;
+                if (!node) {
+                    ++dummy_counter;
+                } else if (dummy_counter) {
+                    cigar_append(w.rev_ops, &n_ops, OP_NODE_INSERTION, (uint32_t)dummy_counter, cap, &w.status);
+                    extra_score -= cfg.gap_open + (dummy_counter - 1) * cfg.gap_ext;
+                    dummy_counter = 0;
+                }
+            }
+        };
+        while (j) {
+            const ColMeta col = w.cols[j];
+            const ColMeta par = w.cols[col.parent];
+            const int32_t trim = col.trim, trim_p = par.trim;
+            align_offset = imin(col.offset, k_minus_1);
+            if (pos == col.max_pos) prev_start_test_and_set(w, j);
+            const int32_t sv = cell_S(w, col, pos - trim);
+            const uint32_t last_op = n_ops ? (w.rev_ops[n_ops - 1] & 7) : 99u;
+            if (sv == NINF) {
+                j = 0;
+            } else if (pos && sv == cell_E(w, col, pos - trim) && (n_ops == 0 || last_op != OP_DELETION)) {
+                uint32_t lop = OP_INSERTION;
+                while (lop == OP_INSERTION) {
+                    cigar_append(w.rev_ops, &n_ops, lop, 1, cap, &w.status);
+                    lop = cell_E(w, col, pos - trim) == cell_E(w, col, pos - trim - 1) + cfg.gap_ext ? OP_INSERTION : OP_MATCH;
+                    --pos;
+                    if (w.status != ST_OK) return false;
+                }
+            } else if (pos && pos >= trim_p + 1
+                       && sv == cell_S(w, par, pos - trim_p - 1) + col.score
+                              + profile_at(P, E.q, w.L, (uint8_t)col.c, seed_clipping + pos)) {
+                ++n_trace;
+                extra_score += col.score;
+                append_node(col.node, (uint8_t)col.c, col.offset, profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + pos));
+                --pos;
+                j = col.parent;
+            } else if (sv == cell_F(w, col, pos - trim) && (n_ops == 0 || last_op != OP_INSERTION)) {
+                uint32_t lop = OP_DELETION;
+                while (lop == OP_DELETION && j) {
+                    const ColMeta c2 = w.cols[j];
+                    const ColMeta p2 = w.cols[c2.parent];
+                    align_offset = imin(c2.offset, k_minus_1);
+                    lop = cell_F(w, c2, pos - c2.trim) == cell_F(w, p2, pos - p2.trim) + c2.score + cfg.gap_ext
+                        ? OP_DELETION : OP_MATCH;
+                    ++n_trace;
+                    extra_score += c2.score;
+                    append_node(c2.node, (uint8_t)c2.c, c2.offset, OP_DELETION);
+                    j = c2.parent;
+                    if (w.status != ST_OK) return false;
+                }
+            } else {
+                break;
+            }
+            if (w.status != ST_OK) return false;
+        }
+        if (n_trace >= min_trace_length && n_path && last_path_node) {
+            const ColMeta cj = w.cols[j];
+            int32_t cur_cell_score = cell_S(w, cj, pos - cj.trim);
+            best_score = imax(best_score, score - cur_cell_score);
+            if (score - er.min_cell_score < best_score) break;
+            if (score >= min_start_score && (!pos || cur_cell_score == 0)
+                    && (pos || cur_cell_score == w.cells[w.cols[0].cells])
+                    && (cfg.allow_left_trim || !j)) {
+                // construct_alignment (:774-798): clipping = pos, window = [pos, end_pos)
+                int32_t nc = 0;
+                uint32_t clip_total = (uint32_t)(seed_clipping + pos);      // cigar clip + extend_query_begin
+                if (clip_total) out.cigar[nc++] = (clip_total << 3) | OP_CLIPPED;
+                // reversed ops; the clipping appended last becomes the first run
+                for (int32_t x = n_ops - 1; x >= 0; --x) {
+                    uint32_t op = w.rev_ops[x];
+                    if (nc && (out.cigar[nc - 1] & 7) == (op & 7)) out.cigar[nc - 1] += (op >> 3) << 3;
+                    else { if (nc >= cap) { w.status = ST_CAPACITY; return false; } out.cigar[nc++] = op; }
+                }
+                uint32_t end_clip = (uint32_t)(w.L - (seed_clipping + end_pos));   // extend_query_end
+                if (end_clip) {
+                    if (nc && (out.cigar[nc - 1] & 7) == OP_CLIPPED) out.cigar[nc - 1] += end_clip << 3;
+                    else { if (nc >= cap) { w.status = ST_CAPACITY; return false; } out.cigar[nc++] = (end_clip << 3) | OP_CLIPPED; }
+                }
+                wave_sync();
+                for (int32_t base = 0; base < imax(n_path, n_seq); base += WAVE) {
+                    FOR_LANES(l) {
+                        int32_t x = base + l;
+                        if (x < n_path) out.nodes[x] = w.rev_nodes[n_path - 1 - x];
+                        if (x < n_seq) out.seq[x] = w.rev_seq[n_seq - 1 - x];
+                    }
+                }
+                out.n_cigar = nc; out.n_nodes = n_path; out.seq_len = n_seq;
+                out.score = score; out.offset = align_offset;
+                out.qbegin = seed_clipping + pos; out.qlen = end_pos - pos;
+                out.orientation = seed.orientation; out.extra_score = extra_score;
+                wave_sync();
+                produced = true;
+            }
+        }
+    }
+    if (!produced && seed.score >= min_path_score) {       // extensions.emplace_back(*seed_) (:1030-1031)
+        if (seed_aln) copy_aln(out, *seed_aln);
+        else seed_as_alignment(w, seed, out);
+        produced = true;
+    }
+    if (produced) {
+        // extension.trim_offset() (alignment.cpp:177-190)
+        if (out.offset && out.n_nodes > 1) {
+            int32_t first_dummy = out.n_nodes;      // no npos nodes can occur on this path
+            for (int32_t x = 0; x < out.n_nodes; ++x) if (!out.nodes[x]) { first_dummy = x; break; }
+            int32_t trim = imin(imin(out.offset, out.n_nodes - 1), first_dummy - 1);
+            if (trim > 0) {
+                // erase the first `trim` nodes (wave-uniform in-place shift)
+                for (int32_t x = 0; x + trim < out.n_nodes; ++x) out.nodes[x] = out.nodes[x + trim];
+                out.n_nodes -= trim;
+                out.offset -= trim;
+            }
+        }
+        wave_sync();
+    }
+    return produced;
+}
+
+// Alignment(const Seed&, config) or a copy of an Alignment used as seed
+MGX_DEV void seed_as_alignment(Wave &w, const SeedRef &seed, DevAln &out) {
+    int32_t nc = 0;
+    if (seed.clipping) out.cigar[nc++] = ((uint32_t)seed.clipping << 3) | OP_CLIPPED;
+    // Seed-derived seeds are exact matches: cigar "cS m= eS" (alignment.hpp:162-164)
+    out.cigar[nc++] = ((uint32_t)seed.qlen << 3) | OP_MATCH;
+    if (seed.end_clipping) out.cigar[nc++] = ((uint32_t)seed.end_clipping << 3) | OP_CLIPPED;
+    for (int32_t base = 0; base < imax(seed.n_nodes, seed.seq_len); base += WAVE) {
+        FOR_LANES(l) {
+            int32_t x = base + l;
+            if (x < seed.n_nodes) out.nodes[x] = seed.nodes[x];
+            if (x < seed.seq_len) out.seq[x] = seed.seq[x];
+        }
+    }
+    out.n_cigar = nc; out.n_nodes = seed.n_nodes; out.seq_len = seed.seq_len;
+    out.score = seed.score; out.offset = seed.offset;
+    out.qbegin = seed.clipping; out.qlen = seed.qlen; out.orientation = seed.orientation; out.extra_score = 0;
+    wave_sync();
+}
+
+MGX_DEV void copy_aln(DevAln &dst, const DevAln &src) {
+    int32_t n = imax(imax(src.n_nodes, src.n_cigar), src.seq_len);
+    for (int32_t base = 0; base < n; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t x = base + l;
+            if (x < src.n_nodes) dst.nodes[x] = src.nodes[x];
+            if (x < src.n_cigar) dst.cigar[x] = src.cigar[x];
+            if (x < src.seq_len) dst.seq[x] = src.seq[x];
+        }
+    }
+    dst.n_nodes = src.n_nodes; dst.n_cigar = src.n_cigar; dst.seq_len = src.seq_len;
+    dst.score = src.score; dst.offset = src.offset; dst.qbegin = src.qbegin; dst.qlen = src.qlen;
+    dst.orientation = src.orientation; dst.extra_score = src.extra_score;
+    wave_sync();
+}
+
+// Alignment::reverse_complement for RCDBG views (alignment.cpp:547-561); false = alignment became empty
+MGX_DEV bool reverse_complement_aln(Wave &w, DevAln &a) {
+    if (a.offset) { a.n_nodes = 0; return false; }        // trim_offset() left a non-zero offset
+    int32_t n = imax(imax(a.n_nodes, a.n_cigar), a.seq_len);
+    for (int32_t base = 0; base < (n + 1) / 2; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t x = base + l;
+            if (x < a.n_nodes / 2) { uint32_t t = a.nodes[x]; a.nodes[x] = a.nodes[a.n_nodes - 1 - x]; a.nodes[a.n_nodes - 1 - x] = t; }
+            if (x < a.n_cigar / 2) { uint32_t t = a.cigar[x]; a.cigar[x] = a.cigar[a.n_cigar - 1 - x]; a.cigar[a.n_cigar - 1 - x] = t; }
+            if (x < (a.seq_len + 1) / 2) {
+                uint8_t t0 = complement_char(a.seq[x]), t1 = complement_char(a.seq[a.seq_len - 1 - x]);
+                a.seq[x] = t1; a.seq[a.seq_len - 1 - x] = t0;
+            }
+        }
+    }
+    wave_sync();
+    a.orientation = !a.orientation;
+    int32_t clip = aln_clipping(a), eclip = aln_end_clipping(a);
+    a.qbegin = clip;
+    a.qlen = w.L - clip - eclip;
+    return true;
+}
+
+MGX_DEV SeedRef seedref_from_aln(const DevAln &a) {
+    SeedRef s;
+    s.nodes = a.nodes; s.seq = a.seq; s.n_nodes = a.n_nodes; s.seq_len = a.seq_len;
+    s.clipping = aln_clipping(a); s.end_clipping = aln_end_clipping(a); s.qlen = a.qlen;
+    s.offset = a.offset; s.score = a.score; s.orientation = a.orientation;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// aggregator (AlignmentAggregator, num_alternative_paths == 1, unlabeled; A/aligner_aggregator.hpp)
+// ------------------------------------------------------------------------------------------------
+MGX_DEV int32_t global_cutoff(const Wave &w) {              // :141-149
+    if (!w.have_best) return NINF;
+    int32_t cur_max = w.aln[3].score;
+    return cur_max > 0 ? (int32_t)((double)cur_max * w.P->cfg.rel_score_cutoff) : cur_max;
+}
+
+MGX_DEV bool aln_equal(const Wave &w, const DevAln &a, const DevAln &b) {     // Alignment::operator== (alignment.hpp:261-269)
+    if (a.orientation != b.orientation || a.offset != b.offset || a.score != b.score || a.qlen != b.qlen
+            || a.seq_len != b.seq_len || a.n_cigar != b.n_cigar || a.n_nodes != b.n_nodes) return false;
+    const uint8_t *qa = w.q[a.orientation] + a.qbegin, *qb = w.q[b.orientation] + b.qbegin;
+    for (int32_t x = 0; x < a.qlen; ++x) if (qa[x] != qb[x]) return false;
+    for (int32_t x = 0; x < a.seq_len; ++x) if (a.seq[x] != b.seq[x]) return false;
+    for (int32_t x = 0; x < a.n_cigar; ++x) if (a.cigar[x] != b.cigar[x]) return false;
+    for (int32_t x = 0; x < a.n_nodes; ++x) if (a.nodes[x] != b.nodes[x]) return false;
+    return true;
+}
+
+// LocalAlignmentLess (alignment.hpp:337-348): a < b
+MGX_DEV bool aln_less(const DevAln &a, const DevAln &b) {
+    int32_t ca = aln_clipping(a), cb = aln_clipping(b);
+    if (b.score != a.score) return b.score > a.score;
+    if (a.qlen != b.qlen) return a.qlen > b.qlen;
+    if (a.orientation != b.orientation) return a.orientation > b.orientation;
+    return ca > cb;
+}
+
+MGX_DEV void add_alignment(Wave &w, const DevAln &a) {       // :68-138
+    if (!w.have_best) { copy_aln(w.aln[3], a); w.have_best = 1; return; }
+    if (a.score < global_cutoff(w)) return;
+    if (aln_equal(w, a, w.aln[3])) return;
+    if (aln_less(a, w.aln[3])) return;
+    copy_aln(w.aln[3], a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// driver (DBGAligner<>::align_batch for one query, A/dbg_aligner.cpp:263-355,360-384,531-758)
+// ------------------------------------------------------------------------------------------------
+MGX_DEV SeedRef seedref_from_seed(const Wave &w, int s, int32_t idx, int32_t *sub_node_slot) {
+    const DevConfig &cfg = w.P->cfg;
+    DevSeed sd = w.seeds[s][idx];
+    SeedRef r;
+    r.clipping = sd.clipping; r.qlen = sd.length; r.offset = sd.offset; r.n_nodes = sd.n_nodes;
+    r.end_clipping = w.L - sd.clipping - sd.length;
+    r.seq = w.q[s] + sd.clipping; r.seq_len = sd.length;
+    r.nodes = (sd.offset == 0 && sd.n_nodes >= 1) ? w.nodes[s] + sd.clipping : &w.seeds[s][idx].node;
+    if (sd.offset == 0 && sd.n_nodes == 1) r.nodes = w.nodes[s] + sd.clipping;
+    r.orientation = s;
+    // Alignment(const Seed&, config) score (alignment.hpp:160-161)
+    int32_t ms = w.psum[s][sd.clipping] - w.psum[s][sd.clipping + sd.length];
+    r.score = ms + (!sd.clipping ? cfg.left_end_bonus : 0) + (!r.end_clipping ? cfg.right_end_bonus : 0);
+    (void)sub_node_slot;
+    return r;
+}
+
+MGX_DEV int32_t min_path_score_now(const Wave &w) {          // get_min_path_score (:277-282)
+    return imax(w.P->cfg.min_path_score, global_cutoff(w));
+}
+
+// aln_both (:657-736): seeds of strand s; fwd extender = ext[s] on the graph, bwd extender = ext[1 - s] on RCDBG
+MGX_DEV void aln_both(Wave &w, int s) {
+    const AlignParams &P = *w.P;
+    ExtenderState &F = w.ext[s];
+    ExtenderState &B = w.ext[1 - s];
+    F.rc_view = 0;
+    B.rc_view = 1;
+    const int32_t n = w.n_seeds[s];
+    for (int32_t i = 0; i < n; ++i) {
+        if (!w.alive[s][i]) continue;
+        SeedRef seed = seedref_from_seed(w, s, i, nullptr);
+        conv_clear(F.conv);                                   // set_seed (:90-98)
+        ExtendResult er;
+        extend(w, F, seed, false, &er);
+        if (w.status != ST_OK) return;
+        int32_t mps = imax(0, P.cfg.min_cell_score);          // extend(): min_path_score = max(0, min_cell_score)
+        bool have = backtrack(w, F, seed, nullptr, er, mps, w.aln[0]);
+        if (w.status != ST_OK) return;
+        if (have) {
+            DevAln &path = w.aln[0];
+            if (path.score >= min_path_score_now(w)) add_alignment(w, path);
+            if (aln_clipping(path) && !path.offset) {
+                copy_aln(w.aln[1], path);
+                if (reverse_complement_aln(w, w.aln[1])) {
+                    // align_core(ManualSeeder{rc path}, bwd_extender, ..., force_fixed_seed = true) (:708-729)
+                    SeedRef rseed = seedref_from_aln(w.aln[1]);
+                    int32_t mps2 = imax(0, min_path_score_now(w));
+                    conv_clear(B.conv);
+                    ExtendResult er2;
+                    extend(w, B, rseed, true, &er2);
+                    if (w.status != ST_OK) return;
+                    bool have2 = backtrack(w, B, rseed, &w.aln[1], er2, mps2, w.aln[2]);
+                    if (w.status != ST_OK) return;
+                    if (have2) {
+                        DevAln &p2 = w.aln[2];
+                        if (reverse_complement_aln(w, p2)) {
+                            int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
+                            for (int32_t x = 0; x < p2.n_nodes; ++x)
+                                filter_nodes(w, F, p2.nodes[x], clip, w.L - eclip);
+                            if (w.status != ST_OK) return;
+                            add_alignment(w, p2);
+                        }
+                    }
+                }
+            }
+        }
+        for (int32_t j = i + 1; j < n; ++j) {
+            if (!w.alive[s][j]) continue;
+            DevSeed sj = w.seeds[s][j];
+            uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
+            SeedRef rj = seedref_from_seed(w, s, j, nullptr);
+            if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[s][j] = 0;   // filter_seed (:105-108)
+        }
+        wave_sync();
+    }
+}
+
+// align_core (:360-384) with the seeds of strand 0, forward only
+MGX_DEV void align_core_fwd(Wave &w) {
+    const AlignParams &P = *w.P;
+    ExtenderState &F = w.ext[0];
+    F.rc_view = 0;
+    const int32_t n = w.n_seeds[0];
+    for (int32_t i = 0; i < n; ++i) {
+        if (!w.alive[0][i]) continue;
+        SeedRef seed = seedref_from_seed(w, 0, i, nullptr);
+        int32_t mps = imax(0, min_path_score_now(w));
+        conv_clear(F.conv);
+        ExtendResult er;
+        extend(w, F, seed, false, &er);
+        if (w.status != ST_OK) return;
+        if (backtrack(w, F, seed, nullptr, er, mps, w.aln[0])) add_alignment(w, w.aln[0]);
+        if (w.status != ST_OK) return;
+        for (int32_t j = i + 1; j < n; ++j) {
+            if (!w.alive[0][j]) continue;
+            DevSeed sj = w.seeds[0][j];
+            uint32_t last_node = sj.offset == 0 ? w.nodes[0][sj.clipping + sj.n_nodes - 1] : sj.node;
+            SeedRef rj = seedref_from_seed(w, 0, j, nullptr);
+            if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[0][j] = 0;
+        }
+        wave_sync();
+        (void)P;
+    }
+}
+
+// the whole per-read program; `slot` selects the arena slice
+MGX_DEV void align_read(const AlignParams &P, uint64_t read, uint32_t slot, KernelStats *stats_accum) {
+    Wave w;
+    w.P = &P;
+    carve(w, P, P.arena + (uint64_t)slot * P.arena_stride);
+    const uint64_t off = P.offsets[read];
+    w.L = (int32_t)(P.offsets[read + 1] - off);
+    w.status = ST_OK;
+    w.have_best = 0;
+    w.ctr.rank_lines = w.ctr.select_lines = w.ctr.bit_lines = 0;
+    FOR_LANES(l) { w.lctr[l].rank_lines = 0; w.lctr[l].select_lines = 0; w.lctr[l].bit_lines = 0; }
+    w.n_columns = w.n_extensions = 0;
+    const int32_t k = (int32_t)P.g.k;
+    const uint64_t nb = P.node_begin[read];
+    w.n_kmers = (int32_t)(P.node_begin[read + 1] - nb);
+    w.nodes[0] = P.nodes_fwd + nb;
+    w.nodes[1] = P.nodes_rc + nb;
+    ReadResult rr;
+    rr.status = ST_OK; rr.n_alignments = 0; rr.score = 0; rr.offset = 0; rr.n_nodes = rr.n_cigar = rr.seq_len = 0;
+    rr.orientation = 0; rr.stream_off = 0;
+    rr.num_matches_fwd = rr.num_matches_rc = rr.n_seeds_fwd = rr.n_seeds_rc = 0; rr.n_extensions = rr.n_columns = 0;
+
+    if (w.L > (int32_t)P.lim.Lmax) {
+        w.status = ST_CAPACITY;
+    } else {
+        prepare_query(w, P.seqs + off);
+        for (int s = 0; s < 2; ++s) {
+            w.ext[s].q = w.q[s];
+            w.ext[s].psum = w.psum[s];
+            w.ext[s].table_cap = 0;
+            w.ext[s].rc_view = 0;
+            w.ext[s].conv.n_entries = 0;
+        }
+        // generation tags make clearing the hash tables O(1); the counters persist in the arena
+        // slice (last words of the sdust scratch area) across the reads a wave slot processes
+        uint32_t *gen_store = (uint32_t *)(w.sd + 2040);
+        for (int s = 0; s < 2; ++s) w.ext[s].conv.gen = gen_store[s];
+        const bool have_rc = P.cfg.fwd_and_rc != 0;
+        // build_seeders (:193-248)
+        make_seeder(w, 0);
+        if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[0]) { w.n_seeds[0] = 0; w.num_matching[0] = 0; }
+        if (have_rc && w.status == ST_OK) {
+            make_seeder(w, 1);
+            if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[1]) { w.n_seeds[1] = 0; w.num_matching[1] = 0; }
+        } else {
+            w.n_seeds[1] = 0; w.num_matching[1] = 0;
+        }
+        rr.num_matches_fwd = w.num_matching[0]; rr.num_matches_rc = w.num_matching[1];
+        rr.n_seeds_fwd = (uint32_t)w.n_seeds[0]; rr.n_seeds_rc = (uint32_t)w.n_seeds[1];
+        if (P.dbg_seeds && w.status == ST_OK) {
+            for (int s = 0; s < 2; ++s)
+                for (int32_t i = 0; i < w.n_seeds[s]; ++i)
+                    P.dbg_seeds[((uint64_t)read * 2 + s) * P.lim.max_seeds + i] = w.seeds[s][i];
+        }
+        wave_sync();
+        if (w.status == ST_OK) {
+            if (have_rc) {
+                // align_both_directions (:738-755)
+                uint32_t fm = w.num_matching[0], bm = w.num_matching[1];
+                if (fm >= bm) {
+                    aln_both(w, 0);
+                    if (w.status == ST_OK && (double)bm >= (double)fm * P.cfg.rel_score_cutoff) aln_both(w, 1);
+                } else {
+                    aln_both(w, 1);
+                    if (w.status == ST_OK && (double)fm >= (double)bm * P.cfg.rel_score_cutoff) aln_both(w, 0);
+                }
+            } else {
+                align_core_fwd(w);
+            }
+        }
+        for (int s = 0; s < 2; ++s) gen_store[s] = w.ext[s].conv.gen;
+        wave_sync();
+    }
+
+    rr.status = w.status;
+    rr.n_extensions = w.n_extensions; rr.n_columns = w.n_columns;
+    if (w.status == ST_OK && w.have_best && w.aln[3].n_nodes) {
+        const DevAln &a = w.aln[3];
+        uint32_t words = (uint32_t)a.n_nodes + (uint32_t)a.n_cigar + ((uint32_t)a.seq_len + 3) / 4;
+        LV<uint64_t> offv;
+        FOR_LANES(l) {
+            offv[l] = 0;
+            if (l == 0) {
+#if MGX_WAVE_EMU
+                offv[l] = *P.out_cursor; *P.out_cursor += words;
+#else
+                offv[l] = atomicAdd(P.out_cursor, (unsigned long long)words);
+#endif
+            }
+        }
+        uint64_t so = wave_bcast(offv, 0);
+        if (so + words > P.out_capacity) {
+            rr.status = ST_CAPACITY;
+        } else {
+            uint32_t *dst = P.out_stream + so;
+            uint8_t *dseq = (uint8_t *)(dst + a.n_nodes + a.n_cigar);
+            int32_t n = imax(imax(a.n_nodes, a.n_cigar), a.seq_len);
+            for (int32_t base = 0; base < n; base += WAVE) {
+                FOR_LANES(l) {
+                    int32_t x = base + l;
+                    if (x < a.n_nodes) dst[x] = a.nodes[x];
+                    if (x < a.n_cigar) dst[a.n_nodes + x] = a.cigar[x];
+                    if (x < a.seq_len) dseq[x] = a.seq[x];
+                }
+            }
+            rr.n_alignments = 1; rr.score = a.score; rr.offset = (uint32_t)a.offset;
+            rr.n_nodes = (uint32_t)a.n_nodes; rr.n_cigar = (uint32_t)a.n_cigar; rr.seq_len = (uint32_t)a.seq_len;
+            rr.orientation = (uint32_t)a.orientation; rr.stream_off = so;
+        }
+    }
+    FOR_LANES(l) { if (l == 0) P.results[read] = rr; }
+    {
+        LV<int32_t> a, b, c;
+        FOR_LANES(l) { a[l] = (int32_t)w.lctr[l].rank_lines; b[l] = (int32_t)w.lctr[l].select_lines; c[l] = (int32_t)w.lctr[l].bit_lines; }
+        stats_accum->rank_lines += w.ctr.rank_lines + (uint32_t)wave_sum(a);
+        stats_accum->select_lines += w.ctr.select_lines + (uint32_t)wave_sum(b);
+        stats_accum->bit_lines += w.ctr.bit_lines + (uint32_t)wave_sum(c);
+    }
+    stats_accum->columns += w.n_columns;
+    stats_accum->extensions += w.n_extensions;
+    stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
+    stats_accum->capacity_errors += rr.status != ST_OK;
+}
+
+} // namespace mgx

@@ -1,0 +1,79 @@
+// align_types.hpp — plain-data structures shared by the host launcher and the kernels.
+#pragma once
+#include "dev_graph.hpp"
+
+namespace mgx {
+
+constexpr int32_t NINF = INT32_MIN + 100;            // DBGAlignerConfig::ninf (aligner_config.hpp:31)
+constexpr uint32_t INF_LEN = 0xFFFFFFFFu;            // "unbounded" size_t config values
+
+enum { OP_CLIPPED = 0, OP_MISMATCH = 1, OP_MATCH = 2, OP_DELETION = 3, OP_INSERTION = 4, OP_NODE_INSERTION = 5 };
+
+enum { ST_OK = 0, ST_CAPACITY = -5 };
+
+// DBGAlignerConfig after the DBGAligner ctor clamps (dbg_aligner.cpp:33-61), narrowed for the device
+struct DevConfig {
+    uint32_t min_seed_length, max_seed_length;       // INF_LEN = unbounded
+    uint32_t max_num_seeds_per_locus;                // INF_LEN = unbounded
+    int32_t min_cell_score, min_path_score, xdrop;
+    double min_exact_match, max_nodes_per_seq_char, max_ram_per_alignment, rel_score_cutoff;
+    int32_t gap_open, gap_ext, left_end_bonus, right_end_bonus;
+    uint32_t fwd_and_rc, allow_left_trim, seed_complexity_filter;
+};
+
+struct DevLimits {
+    uint32_t Lmax;           // longest query in the batch
+    uint32_t max_columns;    // DP columns per extension
+    uint32_t max_seeds;      // seeds per strand
+    uint32_t max_path;       // nodes / cigar runs / path characters per alignment
+    uint32_t max_alt;        // alternative sub-k nodes kept per read and strand
+    uint32_t cell_words;     // int32 words of S/E/F storage per wave
+    uint32_t hash_size;      // power of two
+};
+
+// per-read result header; variable-length parts live in the output stream
+struct ReadResult {
+    int32_t status;          // ST_OK / ST_CAPACITY
+    int32_t n_alignments;    // 0 or 1
+    int32_t score;
+    uint32_t offset;
+    uint32_t n_nodes, n_cigar, seq_len;
+    uint32_t orientation;
+    uint64_t stream_off;     // word offset into the output stream: nodes[n_nodes] (u32),
+                             // cigar[n_cigar] (u32: len << 3 | op), seq bytes (padded to words)
+    // intermediate products for parity tests
+    uint32_t num_matches_fwd, num_matches_rc, n_seeds_fwd, n_seeds_rc;
+    uint32_t n_extensions, n_columns;
+};
+
+struct DevSeed {             // Seed (alignment.hpp:32-98); full seeds reference the strand's node array
+    uint16_t clipping, length, offset, n_nodes;
+    uint32_t node;           // the single node of a sub-k seed
+};
+
+struct KernelStats {
+    unsigned long long rank_lines, select_lines, bit_lines, columns, extensions, seeds, capacity_errors;
+};
+
+struct AlignParams {
+    DevGraph g;
+    DevConfig cfg;
+    DevLimits lim;
+    const int8_t *score_matrix;          // 128 x 128, [graph char][query char]
+    const char *seqs;
+    const uint64_t *offsets;             // n_reads + 1
+    const uint64_t *node_begin;          // n_reads + 1, k-mer slots per read
+    const uint32_t *nodes_fwd, *nodes_rc;
+    uint64_t n_reads;
+    uint8_t *arena;                      // per-wave workspace
+    uint64_t arena_stride;
+    ReadResult *results;
+    uint32_t *out_stream;
+    uint64_t out_capacity;               // words
+    unsigned long long *out_cursor;
+    unsigned long long *read_cursor;
+    KernelStats *stats;
+    DevSeed *dbg_seeds;                  // optional: seeds dump [n_reads][2][max_seeds]
+};
+
+} // namespace mgx

@@ -1,0 +1,125 @@
+// graph_build.hpp — per-index building blocks for turning a BOSS view (W, last, F) into the device
+// layout of dev_graph.hpp, and the lane-per-chain k-mer mapping routine.  Each function is pure
+// per-thread code: the HIP kernels in kernels.hip call them with one thread per index.
+#pragma once
+#include "align_core.hpp"
+
+namespace mgx {
+
+// pass 1: bit-planes, last bits and per-block counts (counts[6*b + c]: c = 0..4 unflagged labels, 5 = last)
+MGX_DEV void build_block_pass1(uint32_t b, const uint8_t *W, const uint8_t *last, uint64_t n, Block *blocks, uint32_t *counts) {
+    Block blk;
+    blk.cum[0] = blk.cum[1] = blk.cum[2] = blk.cum[3] = 0;
+    blk.last_cum = 0; blk.cum0 = 0;
+    uint64_t p0 = 0, p1 = 0, p2 = 0, pf = 0, lb = 0;
+    uint32_t cnt[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int j = 0; j < 64; ++j) {
+        uint64_t i = ((uint64_t)b << 6) + (uint32_t)j;
+        if (i > n) break;
+        uint32_t w = W[i];
+        uint32_t c = w % SIGMA;
+        bool flagged = w >= SIGMA;
+        if (c & 1) p0 |= 1ull << j;
+        if (c & 2) p1 |= 1ull << j;
+        if (c & 4) p2 |= 1ull << j;
+        if (flagged) pf |= 1ull << j;
+        if (i >= 1) {
+            if (!flagged) ++cnt[c];
+            if (last[i]) { lb |= 1ull << j; ++cnt[5]; }
+        }
+    }
+    blk.p0 = p0; blk.p1 = p1; blk.p2 = p2; blk.pf = pf; blk.last_bits = lb;
+    blocks[b] = blk;
+    for (int c = 0; c < 6; ++c) counts[6 * (uint64_t)b + c] = cnt[c];
+}
+
+// pass 2: cum[6*b + c] holds exclusive prefix sums of the counts; fills cumulative fields and hints
+MGX_DEV void build_block_pass2(uint32_t b, Block *blocks, const uint32_t *cum, uint32_t *last_hint,
+                               uint32_t *const *w_hint) {
+    Block blk = blocks[b];
+    const uint32_t *cb = cum + 6 * (uint64_t)b;
+    blk.cum0 = cb[0];
+    for (int c = 1; c < SIGMA; ++c) blk.cum[c - 1] = cb[c];
+    blk.last_cum = cb[5];
+    blocks[b] = blk;
+    // hint[(r - 1) / 64] = block of the r-th occurrence for every r with (r - 1) % 64 == 0
+    {
+        uint32_t cnt = (uint32_t)popc64(blk.last_bits);
+        uint32_t first_r = cb[5] + 1, last_r = cb[5] + cnt;
+        for (uint32_t h = (first_r - 1 + 63) / 64; cnt && h * 64 + 1 <= last_r; ++h) last_hint[h] = b;
+    }
+    for (uint32_t c = 1; c < SIGMA; ++c) {
+        uint64_t m = code_mask(blk, c) & ~blk.pf;
+        if (b == 0) m &= ~1ull;
+        uint32_t cnt = (uint32_t)popc64(m);
+        uint32_t first_r = cb[c] + 1, last_r = cb[c] + cnt;
+        for (uint32_t h = (first_r - 1 + 63) / 64; cnt && h * 64 + 1 <= last_r; ++h) w_hint[c - 1][h] = b;
+    }
+}
+
+// parent pointer used to propagate first characters: P[e] = bwd(e) (boss.cpp:623-636)
+MGX_DEV uint32_t build_parent(const DevGraph &g, uint64_t e) {
+    if (e == 0) return 0;
+    LineCtr ctr = { 0, 0, 0 };
+    return (uint32_t)bwd(g, e, ctr);
+}
+
+// MEM terminus bit: has_multiple_outgoing(v) || !has_single_incoming(v) (aligner_seeder_methods.hpp:121-125)
+MGX_DEV bool build_terminus(const DevGraph &g, uint64_t v) {
+    if (v == 0 || v > g.n) return false;
+    LineCtr ctr = { 0, 0, 0 };
+    return has_multiple_outgoing(g, v, ctr) || !has_single_incoming(g, v, ctr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BOSS::map_to_edges for one (read, strand) chain (boss.cpp:996-1045 via dbg_succinct.cpp:285-305).
+// strand 1 maps the reverse complement (sequence_graph.cpp:563-573).  out has L - k + 1 slots.
+// ------------------------------------------------------------------------------------------------
+MGX_DEV uint32_t strand_code(const char *seq, int32_t L, int strand, int32_t pos) {
+    if (!strand) return encode_char((uint8_t)seq[pos]);
+    uint32_t c = encode_char((uint8_t)seq[L - 1 - pos]);
+    return c == 5 ? 5u : 5u - c;                 // complement: A<->T, C<->G (kBOSSComplementMapDNA)
+}
+
+MGX_DEV void map_chain(const DevGraph &g, const char *seq, int32_t L, int strand, uint32_t *out, LineCtr &ctr) {
+    const int32_t k = (int32_t)g.k;
+    const int32_t n_kmers = L - k + 1;
+    if (n_kmers <= 0) return;
+    int32_t last_invalid = -1;                   // position of the most recent invalid code seen
+    int32_t scanned = 0;                         // codes [0, scanned) have been inspected
+    uint64_t edge = 0;                           // BOSS edge of the previous k-mer (0 = must re-index)
+    Block blk;                                   // block of `edge`
+    for (int32_t i = 0; i < n_kmers; ++i) {
+        for (; scanned < i + k; ++scanned)
+            if (strand_code(seq, L, strand, scanned) == 5) last_invalid = scanned;
+        if (last_invalid >= i) { out[i] = 0; edge = 0; continue; }
+        if (edge) {
+            // edge = fwd(edge, seq[i + k - 2]); edge = pick_edge(edge, seq[i + k - 1])
+            uint32_t c_prev = strand_code(seq, L, strand, i + k - 2);
+            Block tgt;
+            uint64_t lst = fwd_from(g, edge, blk, c_prev, tgt, ctr);
+            blk = tgt;
+            edge = lst ? pick_edge_from(g, lst, blk, strand_code(seq, L, strand, i + k - 1), ctr) : 0;
+        } else {
+            // map_to_edge: index(k - 1 codes) then pick_edge (boss.hpp:696-718,766-777)
+            uint64_t rl, ru;
+            initial_range(g, strand_code(seq, L, strand, i), &rl, &ru);
+            bool ok = rl <= ru;
+            for (int32_t t = 1; ok && t < k - 1; ++t)
+                ok = tighten_range(g, &rl, &ru, strand_code(seq, L, strand, i + t), ctr);
+            if (ok) {
+                ++ctr.rank_lines;
+                blk = load_block(g, (uint32_t)(ru >> 6));
+                edge = pick_edge_from(g, ru, blk, strand_code(seq, L, strand, i + k - 1), ctr);
+            } else {
+                edge = 0;
+            }
+        }
+        out[i] = in_graph(g, edge) ? (uint32_t)edge : 0;          // validate_edge (dbg_succinct.cpp:937-939)
+        if (edge && ((edge >> 6) != 0 || true)) {
+            // keep blk == block of edge (pick_edge_from leaves it there)
+        }
+    }
+}
+
+} // namespace mgx

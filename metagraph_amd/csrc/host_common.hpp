@@ -1,0 +1,138 @@
+// host_common.hpp — host-side logic of the C-ABI that does not touch the HIP runtime: config
+// validation/clamping (DBGAligner ctor), arena limits, and decoding of the device result stream.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mgx.h"
+#include "align_types.hpp"
+
+namespace mgx {
+
+inline bool check_config_scores(const mgx_config &c) {
+    // aligner_config.cpp:39-66
+    int8_t min_penalty = INT8_MAX;
+    for (int i = 0; i < 128; ++i)
+        for (int j = 0; j < 128; ++j) min_penalty = std::min(min_penalty, c.score_matrix[i][j]);
+    if (c.gap_opening_penalty * 2 >= min_penalty) return false;
+    min_penalty = std::min({ min_penalty, c.gap_opening_penalty, c.gap_extension_penalty });
+    return (int64_t)c.min_cell_score >= (int64_t)INT32_MIN - min_penalty;
+}
+
+// DBGAligner<>::DBGAligner (dbg_aligner.cpp:33-61) + what this build implements.  Returns MGX_OK or
+// an error code with a message in *err.
+inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, DevConfig *d, std::string *err) {
+    *out = in;
+    mgx_config &c = *out;
+    if (!c.min_seed_length) c.min_seed_length = k;
+    if (!c.max_seed_length) c.max_seed_length = k;
+    uint64_t lo = std::min(c.min_seed_length, c.max_seed_length), hi = std::max(c.min_seed_length, c.max_seed_length);
+    c.min_seed_length = lo;
+    c.max_seed_length = hi;
+    if (!check_config_scores(c)) { *err = "Error: sum of min_cell_score and lowest penalty too low."; return MGX_ERR_CONFIG; }
+    if (c.chain_alignments || c.post_chain_alignments) { *err = "seed/alignment chaining is not implemented"; return MGX_ERR_UNSUPPORTED; }
+    if (!c.global_xdrop) { *err = "per-branch xdrop (labeled+coordinates mode) is not implemented"; return MGX_ERR_UNSUPPORTED; }
+    if (c.no_backtrack) { *err = "no_backtrack is not implemented"; return MGX_ERR_UNSUPPORTED; }
+    if (c.num_alternative_paths != 1) { *err = "num_alternative_paths != 1 is not implemented on the device"; return MGX_ERR_UNSUPPORTED; }
+    if (c.xdrop <= 0) { *err = "xdrop must be positive"; return MGX_ERR_INVALID; }
+    auto sat = [](uint64_t v) { return v >= INF_LEN ? INF_LEN : (uint32_t)v; };
+    d->min_seed_length = sat(c.min_seed_length);
+    d->max_seed_length = sat(c.max_seed_length);
+    d->max_num_seeds_per_locus = sat(c.max_num_seeds_per_locus);
+    d->min_cell_score = c.min_cell_score; d->min_path_score = c.min_path_score; d->xdrop = c.xdrop;
+    d->min_exact_match = c.min_exact_match; d->max_nodes_per_seq_char = c.max_nodes_per_seq_char;
+    d->max_ram_per_alignment = c.max_ram_per_alignment; d->rel_score_cutoff = c.rel_score_cutoff;
+    d->gap_open = c.gap_opening_penalty; d->gap_ext = c.gap_extension_penalty;
+    d->left_end_bonus = c.left_end_bonus; d->right_end_bonus = c.right_end_bonus;
+    d->fwd_and_rc = c.forward_and_reverse_complement; d->allow_left_trim = c.allow_left_trim;
+    d->seed_complexity_filter = c.seed_complexity_filter;
+    return MGX_OK;
+}
+
+inline uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lmax, DevLimits *lim, std::string *err) {
+    DevLimits &l = *lim;
+    if (u && u->max_query_length && Lmax > u->max_query_length) {
+        *err = "a query of length " + std::to_string(Lmax) + " exceeds mgx_limits.max_query_length = " + std::to_string(u->max_query_length);
+        return MGX_ERR_CAPACITY;
+    }
+    l.Lmax = std::max<uint32_t>(8, (Lmax + 7) & ~7u);
+    uint32_t mc;
+    if (u && u->max_columns) mc = u->max_columns;
+    else if (cfg.max_nodes_per_seq_char < 1e6) mc = (uint32_t)(cfg.max_nodes_per_seq_char * l.Lmax) * 2 + 64;
+    else mc = 16 * l.Lmax + 256;
+    l.max_columns = std::min<uint32_t>((1u << 24) - 2, std::max<uint32_t>(64, mc));   // 24-bit table index in the queue key
+    l.max_seeds = (u && u->max_seeds) ? u->max_seeds : 2 * l.Lmax + 64;
+    l.max_path = 2 * l.Lmax + 64;
+    l.max_alt = std::max<uint32_t>(4096, l.max_seeds);
+    uint64_t cw;
+    if (u && u->cell_arena_bytes) cw = u->cell_arena_bytes / 4;
+    else {
+        uint64_t band = cfg.xdrop < 1000 ? std::min<uint64_t>(l.Lmax + 8, 96) : (l.Lmax + 8);
+        cw = (uint64_t)l.max_columns * 3 * band + 3 * (l.Lmax + 16);
+    }
+    l.cell_words = (uint32_t)std::min<uint64_t>(cw, 0xFFFFFF00ull);
+    l.hash_size = next_pow2(2ull * ((uint64_t)l.max_columns + l.max_path) + 2);
+    return MGX_OK;
+}
+
+// host copy of one batch's results in the layout of mgx_results
+struct HostResults {
+    std::vector<uint64_t> aln_begin, nodes;
+    std::vector<mgx_alignment> alns;
+    std::vector<mgx_cigar_op> cigar;
+    std::vector<char> seqs;
+    std::vector<int32_t> status;
+
+    void decode(const ReadResult *rr, uint64_t n, const uint32_t *stream) {
+        aln_begin.assign(1, 0);
+        alns.clear(); nodes.clear(); cigar.clear(); seqs.clear(); status.clear();
+        for (uint64_t i = 0; i < n; ++i) {
+            const ReadResult &r = rr[i];
+            status.push_back(r.status);
+            if (r.status == ST_OK && r.n_alignments) {
+                mgx_alignment m;
+                memset(&m, 0, sizeof(m));
+                const uint32_t *p = stream + r.stream_off;
+                m.score = r.score; m.offset = r.offset; m.n_nodes = r.n_nodes; m.n_cigar = r.n_cigar; m.seq_len = r.seq_len;
+                m.orientation = (uint8_t)r.orientation;
+                m.nodes_begin = nodes.size(); m.cigar_begin = cigar.size(); m.seq_begin = seqs.size();
+                for (uint32_t x = 0; x < r.n_nodes; ++x) nodes.push_back(p[x]);
+                uint32_t nm = 0;
+                for (uint32_t x = 0; x < r.n_cigar; ++x) {
+                    mgx_cigar_op op;
+                    memset(&op, 0, sizeof(op));
+                    op.len = p[r.n_nodes + x] >> 3;
+                    op.op = (uint8_t)(p[r.n_nodes + x] & 7);
+                    if (op.op == MGX_OP_MATCH) nm += op.len;
+                    cigar.push_back(op);
+                }
+                m.num_matches = nm;
+                if (r.n_cigar) {
+                    const mgx_cigar_op &f = cigar[m.cigar_begin], &b = cigar.back();
+                    m.clipping = f.op == MGX_OP_CLIPPED ? f.len : 0;
+                    m.end_clipping = b.op == MGX_OP_CLIPPED ? b.len : 0;
+                }
+                const char *sq = reinterpret_cast<const char *>(p + r.n_nodes + r.n_cigar);
+                seqs.insert(seqs.end(), sq, sq + r.seq_len);
+                alns.push_back(m);
+            }
+            aln_begin.push_back(alns.size());
+        }
+    }
+
+    void view(mgx_results *out) const {
+        out->n_queries = status.size();
+        out->aln_begin = aln_begin.data();
+        out->alignments = alns.data();
+        out->nodes = nodes.data();
+        out->cigar = cigar.data();
+        out->seqs = seqs.data();
+        out->status = status.data();
+    }
+};
+
+} // namespace mgx

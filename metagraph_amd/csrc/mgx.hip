@@ -1,0 +1,674 @@
+// mgx.hip — libmgx.so: gfx950 kernels and the C-ABI of include/mgx.h.
+// Host side is plain C++ around the HIP runtime; there is no CPU execution path for the aligner.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mgx.h"
+#include "graph_build.hpp"
+#include "host_common.hpp"
+
+using namespace mgx;
+
+// =================================================================================================
+// kernels
+// =================================================================================================
+__global__ void k_build_pass1(const uint8_t *W, const uint8_t *last, uint64_t n, Block *blocks, uint32_t *counts, uint32_t n_blocks) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_blocks) build_block_pass1(b, W, last, n, blocks, counts);
+}
+
+struct HintPtrs { uint32_t *last_hint; uint32_t *w_hint[4]; };
+
+__global__ void k_build_pass2(Block *blocks, const uint32_t *cum, HintPtrs hp, uint32_t n_blocks) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_blocks) build_block_pass2(b, blocks, cum, hp.last_hint, hp.w_hint);
+}
+
+__global__ void k_parent(DevGraph g, uint32_t *P, uint8_t *D) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e <= g.n) { P[e] = build_parent(g, e); D[e] = (uint8_t)node_last_value(g, e); }
+}
+
+__global__ void k_gather(const uint32_t *P, const uint8_t *Din, uint8_t *Dout, uint64_t n) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e <= n) Dout[e] = Din[P[e]];
+}
+
+__global__ void k_pack_firstc(const uint8_t *D, uint32_t *firstc, uint64_t n) {
+    uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi * 8 <= n) {
+        uint32_t v = 0;
+        for (int j = 0; j < 8; ++j) {
+            uint64_t e = wi * 8 + j;
+            if (e <= n) v |= (uint32_t)(D[e] & 0xF) << (4 * j);
+        }
+        firstc[wi] = v;
+    }
+}
+
+__global__ void k_pack_valid(const uint8_t *valid, uint64_t *bits, uint64_t n) {
+    uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi * 64 <= n) {
+        uint64_t v = 0;
+        for (int j = 0; j < 64; ++j) {
+            uint64_t e = wi * 64 + j;
+            if (e <= n && valid[e]) v |= 1ull << j;
+        }
+        bits[wi] = v;
+    }
+}
+
+__global__ void k_terminus(DevGraph g, uint64_t *bits) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // blockDim multiple of 64
+    bool t = v <= g.n && in_graph(g, v) && build_terminus(g, v);
+    uint64_t m = __ballot(t);
+    if ((threadIdx.x & 63) == 0 && (v >> 6) < ((g.n + 64) >> 6)) bits[v >> 6] = m;
+}
+
+__global__ void k_kmer_counts(const uint64_t *offsets, uint64_t n_reads, uint32_t k, uint64_t *counts, unsigned long long *lmax) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_reads) {
+        uint64_t L = offsets[i + 1] - offsets[i];
+        counts[i] = L >= k ? L - k + 1 : 0;
+        atomicMax(lmax, (unsigned long long)L);
+    }
+    if (i == n_reads) counts[i] = 0;
+}
+
+// one lane per (read, strand) chain
+__global__ void __launch_bounds__(256) k_map(DevGraph g, const char *seqs, const uint64_t *offsets, const uint64_t *node_begin,
+                                             uint32_t *nodes_fwd, uint32_t *nodes_rc, uint64_t n_reads, int do_rc,
+                                             KernelStats *stats) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t read = t >> 1;
+    int strand = (int)(t & 1);
+    LineCtr ctr = { 0, 0, 0 };
+    if (read < n_reads && (strand == 0 || do_rc)) {
+        uint64_t off = offsets[read];
+        int32_t L = (int32_t)(offsets[read + 1] - off);
+        uint32_t *out = (strand ? nodes_rc : nodes_fwd) + node_begin[read];
+        map_chain(g, seqs + off, L, strand, out, ctr);
+    }
+    // per-wave reduction of the line counters
+    uint32_t r = ctr.rank_lines, s = ctr.select_lines;
+    for (int d = 32; d >= 1; d >>= 1) { r += __shfl_xor(r, d, 64); s += __shfl_xor(s, d, 64); }
+    if ((threadIdx.x & 63) == 0 && (r | s)) {
+        atomicAdd(&stats->rank_lines, (unsigned long long)r);
+        atomicAdd(&stats->select_lines, (unsigned long long)s);
+    }
+}
+
+// one wave per read, persistent over the batch; each wave owns one arena slice
+__global__ void __launch_bounds__(64) k_align(AlignParams P) {
+    const uint32_t slot = blockIdx.x;
+    KernelStats acc;
+    memset(&acc, 0, sizeof(acc));
+    for (;;) {
+        LV<uint64_t> rv;
+        rv.v = 0;
+        if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
+        uint64_t read = wave_bcast(rv, 0);
+        if (read >= P.n_reads) break;
+        align_read(P, read, slot, &acc);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(&P.stats->rank_lines, acc.rank_lines);
+        atomicAdd(&P.stats->select_lines, acc.select_lines);
+        atomicAdd(&P.stats->bit_lines, acc.bit_lines);
+        atomicAdd(&P.stats->columns, acc.columns);
+        atomicAdd(&P.stats->extensions, acc.extensions);
+        atomicAdd(&P.stats->seeds, acc.seeds);
+        atomicAdd(&P.stats->capacity_errors, acc.capacity_errors);
+    }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? MGX_ERR_OOM : MGX_ERR_NO_DEVICE, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                                \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int ensure(size_t n) {
+        if (n <= bytes) return MGX_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t want = n + n / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return fail(MGX_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+        bytes = want;
+        return MGX_OK;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct mgx_graph {
+    int device = 0;
+    DevGraph g;
+    DevBuf blocks, last_hint, w_hint[4], firstc, terminus, valid;
+    uint64_t bytes = 0;
+};
+
+struct mgx_aligner {
+    const mgx_graph *graph = nullptr;
+    mgx_config cfg;
+    DevConfig dcfg;
+    mgx_limits user_lim;
+    bool have_user_lim = false;
+    DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, scan_tmp, dbg_seeds;
+    DevLimits lim;
+    uint64_t n_reads = 0, total_kmers = 0;
+    uint32_t n_slots = 0;
+    bool keep_seeds = false;
+    // host copies
+    std::vector<ReadResult> h_results;
+    std::vector<uint32_t> h_stream;
+    HostResults host;
+    std::vector<uint64_t> m_node_begin, m_fwd, m_rc;
+    mgx_stats hstats;
+    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+};
+
+extern "C" {
+
+int mgx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+const char *mgx_last_error(void) { return g_err.c_str(); }
+uint32_t mgx_abi_version(void) { return MGX_ABI_VERSION; }
+
+void mgx_config_init_default(mgx_config *c) {
+    memset(c, 0, sizeof(*c));
+    c->num_alternative_paths = 1;
+    c->max_num_seeds_per_locus = UINT64_MAX;
+    c->min_cell_score = INT32_MIN + 100;
+    c->min_path_score = 0;
+    c->xdrop = INT32_MAX;
+    c->max_nodes_per_seq_char = 1.7976931348623157e308;
+    c->max_ram_per_alignment = 1.7976931348623157e308;
+    c->gap_opening_penalty = -5;
+    c->gap_extension_penalty = -2;
+    c->forward_and_reverse_complement = 1;
+    c->global_xdrop = 1;
+    c->allow_left_trim = 1;
+    c->seed_complexity_filter = 1;
+}
+
+void mgx_config_set_dna_matrix(mgx_config *c, int8_t match, int8_t mm_transition, int8_t mm_transversion) {
+    for (int i = 0; i < 128; ++i)
+        for (int j = 0; j < 128; ++j) c->score_matrix[i][j] = mm_transversion;
+    c->score_matrix['A']['G'] = c->score_matrix['G']['A'] = mm_transition;
+    c->score_matrix['C']['T'] = c->score_matrix['T']['C'] = mm_transition;
+    c->score_matrix['A']['A'] = c->score_matrix['C']['C'] = c->score_matrix['G']['G'] = c->score_matrix['T']['T'] = match;
+}
+
+void mgx_config_set_unit_matrix(mgx_config *c, int8_t match) {
+    for (int i = 0; i < 128; ++i)
+        for (int j = 0; j < 128; ++j) c->score_matrix[i][j] = (int8_t)-match;
+    c->score_matrix['A']['A'] = c->score_matrix['C']['C'] = c->score_matrix['G']['G'] = c->score_matrix['T']['T'] = match;
+}
+
+void mgx_config_init_cli(mgx_config *c, uint32_t k) {
+    mgx_config_init_default(c);
+    c->min_seed_length = std::min<uint64_t>(19, k);
+    c->max_seed_length = UINT64_MAX;
+    c->max_num_seeds_per_locus = 1000;
+    c->xdrop = 27;
+    c->min_exact_match = 0.7;
+    c->max_nodes_per_seq_char = 5.0;
+    c->max_ram_per_alignment = 200.0;
+    c->rel_score_cutoff = 0.95;
+    c->gap_opening_penalty = -6;
+    c->gap_extension_penalty = -2;
+    c->left_end_bonus = 5;
+    c->right_end_bonus = 5;
+    mgx_config_set_dna_matrix(c, 2, -3, -3);
+}
+
+void mgx_limits_init_default(mgx_limits *l, uint32_t max_query_length) {
+    memset(l, 0, sizeof(*l));
+    l->max_query_length = max_query_length;      // the rest: 0 = derive from the config at batch time
+}
+
+// ------------------------------------------------------------------------------------------------
+// graph
+// ------------------------------------------------------------------------------------------------
+int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
+    if (!view || !out || !view->W || !view->last || !view->F) return fail(MGX_ERR_INVALID, "null BOSS view");
+    if (view->sigma != SIGMA) return fail(MGX_ERR_UNSUPPORTED, "only the DNA alphabet $ACGT (sigma = 5) is implemented");
+    if (view->mode != MGX_MODE_BASIC) return fail(MGX_ERR_UNSUPPORTED, "only BASIC-mode graphs are implemented (canonical/primary are next)");
+    if (view->k < 2 || view->k > 255) return fail(MGX_ERR_INVALID, "k out of range");
+    if (view->n_edges == 0 || view->n_edges >= 0xFFFFFFF0ull) return fail(MGX_ERR_UNSUPPORTED, "edge count must fit 32 bits");
+    if (mgx_device_count() <= device) return fail(MGX_ERR_NO_DEVICE, "HIP device %d not available", device);
+    HIP_TRY(hipSetDevice(device));
+    auto *G = new mgx_graph();
+    std::unique_ptr<mgx_graph> guard(G);
+    G->device = device;
+    const uint64_t n = view->n_edges;
+    const uint32_t n_blocks = (uint32_t)((n + 1 + 63) / 64);
+    DevBuf dW, dLast, dValid, counts, cum;
+    const uint8_t *W = view->W, *last = view->last;
+    if (!view->on_device) {
+        if (int rc = dW.ensure(n + 1)) return rc;
+        if (int rc = dLast.ensure(n + 1)) return rc;
+        HIP_TRY(hipMemcpy(dW.p, view->W, n + 1, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dLast.p, view->last, n + 1, hipMemcpyHostToDevice));
+        W = dW.as<uint8_t>();
+        last = dLast.as<uint8_t>();
+    }
+    if (int rc = G->blocks.ensure((size_t)n_blocks * sizeof(Block))) return rc;
+    if (int rc = counts.ensure((size_t)n_blocks * 6 * 4)) return rc;
+    k_build_pass1<<<(n_blocks + 255) / 256, 256>>>(W, last, n, G->blocks.as<Block>(), counts.as<uint32_t>(), n_blocks);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> hc((size_t)n_blocks * 6);
+    HIP_TRY(hipMemcpy(hc.data(), counts.p, hc.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t tot[6] = { 0, 0, 0, 0, 0, 0 };
+    for (uint32_t b = 0; b < n_blocks; ++b)
+        for (int c = 0; c < 6; ++c) { uint32_t v = hc[(size_t)b * 6 + c]; hc[(size_t)b * 6 + c] = (uint32_t)tot[c]; tot[c] += v; }
+    if (int rc = cum.ensure(hc.size() * 4)) return rc;
+    HIP_TRY(hipMemcpy(cum.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+    HintPtrs hp;
+    if (int rc = G->last_hint.ensure((tot[5] / 64 + 2) * 4)) return rc;
+    hp.last_hint = G->last_hint.as<uint32_t>();
+    for (int c = 0; c < 4; ++c) {
+        if (int rc = G->w_hint[c].ensure((tot[c + 1] / 64 + 2) * 4)) return rc;
+        hp.w_hint[c] = G->w_hint[c].as<uint32_t>();
+    }
+    k_build_pass2<<<(n_blocks + 255) / 256, 256>>>(G->blocks.as<Block>(), cum.as<uint32_t>(), hp, n_blocks);
+    HIP_TRY(hipGetLastError());
+
+    DevGraph &g = G->g;
+    memset(&g, 0, sizeof(g));
+    g.blocks = G->blocks.as<Block>();
+    g.last_hint = hp.last_hint;
+    for (int c = 0; c < 4; ++c) g.w_hint[c] = hp.w_hint[c];
+    g.n = n;
+    g.n_blocks = n_blocks;
+    g.k = view->k;
+    for (int c = 0; c < SIGMA; ++c) {
+        if (view->F[c] > n) return fail(MGX_ERR_INVALID, "F[%d] out of range", c);
+        g.F[c] = (uint32_t)view->F[c];
+    }
+    // NF[c] = rank_last(F[c]) (boss.cpp:1095-1101)
+    {
+        std::vector<Block> hb(1);
+        for (int c = 0; c < SIGMA; ++c) {
+            uint64_t i = g.F[c];
+            if (i == 0) { g.NF[c] = 0; continue; }
+            HIP_TRY(hipMemcpy(hb.data(), g.blocks + (i >> 6), sizeof(Block), hipMemcpyDeviceToHost));
+            uint64_t m = hb[0].last_bits & ((i & 63) == 63 ? ~0ull : ((1ull << ((i & 63) + 1)) - 1));
+            g.NF[c] = hb[0].last_cum + (uint32_t)__builtin_popcountll(m);
+        }
+    }
+    // node mask
+    if (view->valid) {
+        const uint8_t *valid = view->valid;
+        if (!view->on_device) {
+            if (int rc = dValid.ensure(n + 1)) return rc;
+            HIP_TRY(hipMemcpy(dValid.p, view->valid, n + 1, hipMemcpyHostToDevice));
+            valid = dValid.as<uint8_t>();
+        }
+        if (int rc = G->valid.ensure((size_t)n_blocks * 8)) return rc;
+        k_pack_valid<<<(n_blocks + 255) / 256, 256>>>(valid, G->valid.as<uint64_t>(), n);
+        HIP_TRY(hipGetLastError());
+        g.valid = G->valid.as<uint64_t>();
+    }
+    // first characters: k - 2 rounds of D[e] <- D[bwd(e)]
+    {
+        DevBuf P, D0, D1;
+        if (int rc = P.ensure((n + 1) * 4)) return rc;
+        if (int rc = D0.ensure(n + 1)) return rc;
+        if (int rc = D1.ensure(n + 1)) return rc;
+        uint32_t nb = (uint32_t)((n + 1 + 255) / 256);
+        k_parent<<<nb, 256>>>(g, P.as<uint32_t>(), D0.as<uint8_t>());
+        HIP_TRY(hipGetLastError());
+        uint8_t *din = D0.as<uint8_t>(), *dout = D1.as<uint8_t>();
+        for (uint32_t r = 0; r + 2 < g.k; ++r) {
+            k_gather<<<nb, 256>>>(P.as<uint32_t>(), din, dout, n);
+            std::swap(din, dout);
+        }
+        HIP_TRY(hipGetLastError());
+        if (int rc = G->firstc.ensure(((n + 1 + 7) / 8) * 4 + 4)) return rc;
+        k_pack_firstc<<<(uint32_t)(((n + 8) / 8 + 255) / 256), 256>>>(din, G->firstc.as<uint32_t>(), n);
+        HIP_TRY(hipGetLastError());
+        g.firstc = G->firstc.as<uint32_t>();
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    // MEM terminus bits
+    if (int rc = G->terminus.ensure((size_t)n_blocks * 8)) return rc;
+    g.terminus = G->terminus.as<uint64_t>();
+    k_terminus<<<n_blocks, 64>>>(g, G->terminus.as<uint64_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    G->bytes = G->blocks.bytes + G->last_hint.bytes + G->firstc.bytes + G->terminus.bytes + G->valid.bytes;
+    for (int c = 0; c < 4; ++c) G->bytes += G->w_hint[c].bytes;
+    *out = guard.release();
+    return MGX_OK;
+}
+
+void mgx_graph_destroy(mgx_graph *g) { delete g; }
+uint32_t mgx_graph_k(const mgx_graph *g) { return g->g.k; }
+uint64_t mgx_graph_max_index(const mgx_graph *g) { return g->g.n; }
+uint64_t mgx_graph_device_bytes(const mgx_graph *g) { return g->bytes; }
+
+// ------------------------------------------------------------------------------------------------
+// aligner
+// ------------------------------------------------------------------------------------------------
+int mgx_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_limits *limits, mgx_aligner **out) {
+    if (!g || !config || !out) return fail(MGX_ERR_INVALID, "null argument");
+    auto *A = new mgx_aligner();
+    std::unique_ptr<mgx_aligner> guard(A);
+    A->graph = g;
+    {
+        std::string err;
+        int rc = prepare_config(*config, g->g.k, &A->cfg, &A->dcfg, &err);
+        if (rc) return fail(rc, "%s", err.c_str());
+    }
+    mgx_config &c = A->cfg;
+    if (limits) { A->user_lim = *limits; A->have_user_lim = true; }
+    HIP_TRY(hipSetDevice(g->device));
+    if (int rc = A->score_matrix.ensure(128 * 128)) return rc;
+    HIP_TRY(hipMemcpy(A->score_matrix.p, c.score_matrix, 128 * 128, hipMemcpyHostToDevice));
+    if (int rc = A->cursors.ensure(64)) return rc;
+    if (int rc = A->d_stats.ensure(sizeof(KernelStats))) return rc;
+    for (auto &e : A->ev) HIP_TRY(hipEventCreate(&e));
+    memset(&A->hstats, 0, sizeof(A->hstats));
+    memset(&A->lim, 0, sizeof(A->lim));
+    *out = guard.release();
+    return MGX_OK;
+}
+
+void mgx_aligner_destroy(mgx_aligner *a) {
+    if (!a) return;
+    for (auto &e : a->ev) if (e) (void)hipEventDestroy(e);
+    delete a;
+}
+
+int mgx_aligner_get_config(const mgx_aligner *a, mgx_config *out) { *out = a->cfg; return MGX_OK; }
+
+// stage inputs, compute k-mer slot offsets and Lmax on the device
+static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device,
+                       const char **d_seqs, const uint64_t **d_offsets, uint32_t *Lmax_out) {
+    const uint32_t k = A->graph->g.k;
+    if (on_device) {
+        *d_seqs = seqs;
+        *d_offsets = offsets;
+    } else {
+        uint64_t total = offsets[n];
+        if (int rc = A->seqs.ensure(total + 16)) return rc;
+        if (int rc = A->offsets.ensure((n + 1) * 8)) return rc;
+        HIP_TRY(hipMemcpyAsync(A->seqs.p, seqs, total, hipMemcpyHostToDevice, 0));
+        HIP_TRY(hipMemcpyAsync(A->offsets.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, 0));
+        *d_seqs = A->seqs.as<char>();
+        *d_offsets = A->offsets.as<uint64_t>();
+    }
+    if (int rc = A->counts.ensure((n + 2) * 8)) return rc;
+    if (int rc = A->node_begin.ensure((n + 2) * 8)) return rc;
+    unsigned long long *cur = A->cursors.as<unsigned long long>();
+    HIP_TRY(hipMemsetAsync(cur, 0, 64, 0));
+    k_kmer_counts<<<(uint32_t)((n + 1 + 255) / 256), 256>>>(*d_offsets, n, k, A->counts.as<uint64_t>(), cur + 2);
+    HIP_TRY(hipGetLastError());
+    size_t tmp_bytes = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, A->counts.as<uint64_t>(), A->node_begin.as<uint64_t>(), (int)(n + 1)));
+    if (int rc = A->scan_tmp.ensure(tmp_bytes + 16)) return rc;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(A->scan_tmp.p, tmp_bytes, A->counts.as<uint64_t>(), A->node_begin.as<uint64_t>(), (int)(n + 1)));
+    uint64_t total_kmers = 0;
+    unsigned long long lmax = 0;
+    HIP_TRY(hipMemcpy(&total_kmers, A->node_begin.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&lmax, cur + 2, 8, hipMemcpyDeviceToHost));
+    A->total_kmers = total_kmers;
+    A->n_reads = n;
+    *Lmax_out = (uint32_t)lmax;
+    if (int rc = A->nodes_fwd.ensure((total_kmers + 1) * 4)) return rc;
+    if (int rc = A->nodes_rc.ensure((total_kmers + 1) * 4)) return rc;
+    return MGX_OK;
+}
+
+static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, bool do_rc, bool mapped) {
+    HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), 0));
+    if (!mapped) {
+        // max_seed_length < k: nodes are not mapped (dbg_aligner.cpp:209-213)
+        HIP_TRY(hipMemsetAsync(A->nodes_fwd.p, 0, (A->total_kmers + 1) * 4, 0));
+        HIP_TRY(hipMemsetAsync(A->nodes_rc.p, 0, (A->total_kmers + 1) * 4, 0));
+        return MGX_OK;
+    }
+    HIP_TRY(hipEventRecord(A->ev[0], 0));
+    uint64_t threads = 2 * n;
+    k_map<<<(uint32_t)((threads + 255) / 256), 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
+                                                        A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(), n, do_rc ? 1 : 0,
+                                                        A->d_stats.as<KernelStats>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(A->ev[1], 0));
+    return MGX_OK;
+}
+
+static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, uint32_t Lmax) {
+    {
+        std::string err;
+        int rc = derive_limits(A->cfg, A->have_user_lim ? &A->user_lim : nullptr, Lmax, &A->lim, &err);
+        if (rc) return fail(rc, "%s", err.c_str());
+    }
+    const DevLimits &l = A->lim;
+    const uint64_t stride = arena_bytes(l);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, A->graph->device));
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t want_slots = (uint64_t)prop.multiProcessorCount * 16;
+    uint64_t budget = free_b / 2;
+    uint64_t slots = std::min<uint64_t>(std::min<uint64_t>(want_slots, n), std::max<uint64_t>(1, budget / stride));
+    if (slots == 0) slots = 1;
+    if (A->arena.bytes < slots * stride) {
+        if (int rc = A->arena.ensure(slots * stride)) return rc;
+        HIP_TRY(hipMemsetAsync(A->arena.p, 0, A->arena.bytes, 0));     // generation counters start at 0
+    } else {
+        HIP_TRY(hipMemsetAsync(A->arena.p, 0, A->arena.bytes, 0));
+    }
+    A->n_slots = (uint32_t)slots;
+    if (int rc = A->results.ensure(n * sizeof(ReadResult))) return rc;
+    uint64_t words_per_read = (uint64_t)l.Lmax + l.Lmax / 4 + 40;
+    uint64_t out_words = n * words_per_read + 1024;
+    if (int rc = A->stream.ensure(out_words * 4)) return rc;
+    if (A->keep_seeds) {
+        if (int rc = A->dbg_seeds.ensure(n * 2 * (uint64_t)l.max_seeds * sizeof(DevSeed))) return rc;
+        HIP_TRY(hipMemsetAsync(A->dbg_seeds.p, 0, n * 2 * (uint64_t)l.max_seeds * sizeof(DevSeed), 0));
+    }
+    unsigned long long *cur = A->cursors.as<unsigned long long>();
+    HIP_TRY(hipMemsetAsync(cur, 0, 16, 0));
+    AlignParams P;
+    memset(&P, 0, sizeof(P));
+    P.g = A->graph->g;
+    P.cfg = A->dcfg;
+    P.lim = l;
+    P.score_matrix = A->score_matrix.as<int8_t>();
+    P.seqs = d_seqs;
+    P.offsets = d_offsets;
+    P.node_begin = A->node_begin.as<uint64_t>();
+    P.nodes_fwd = A->nodes_fwd.as<uint32_t>();
+    P.nodes_rc = A->nodes_rc.as<uint32_t>();
+    P.n_reads = n;
+    P.arena = A->arena.as<uint8_t>();
+    P.arena_stride = stride;
+    P.results = A->results.as<ReadResult>();
+    P.out_stream = A->stream.as<uint32_t>();
+    P.out_capacity = out_words;
+    P.out_cursor = cur;
+    P.read_cursor = cur + 1;
+    P.stats = A->d_stats.as<KernelStats>();
+    P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
+    HIP_TRY(hipEventRecord(A->ev[2], 0));
+    k_align<<<(uint32_t)slots, 64>>>(P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(A->ev[3], 0));
+    return MGX_OK;
+}
+
+static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
+    HIP_TRY(hipDeviceSynchronize());
+    KernelStats ks;
+    HIP_TRY(hipMemcpy(&ks, A->d_stats.p, sizeof(ks), hipMemcpyDeviceToHost));
+    mgx_stats &s = A->hstats;
+    memset(&s, 0, sizeof(s));
+    s.n_reads = A->n_reads;
+    s.n_rank_lines = ks.rank_lines; s.n_select_lines = ks.select_lines; s.n_bit_lines = ks.bit_lines;
+    s.n_columns = ks.columns; s.n_extensions = ks.extensions; s.n_seeds = ks.seeds;
+    float ms = 0;
+    if (mapped) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[0], A->ev[1])); s.seed_kernel_ms = ms; }
+    if (aligned) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[2], A->ev[3])); s.align_kernel_ms = ms; }
+    return MGX_OK;
+}
+
+int mgx_map_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_mapping *out) {
+    if (!A || !seqs || !offsets || !out) return fail(MGX_ERR_INVALID, "null argument");
+    if (mgx_device_count() <= A->graph->device) return fail(MGX_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(A->graph->device));
+    const char *d_seqs; const uint64_t *d_offsets; uint32_t Lmax;
+    if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc;
+    if (int rc = run_map(A, d_seqs, d_offsets, n, true, true)) return rc;
+    if (int rc = collect_stats(A, true, false)) return rc;
+    A->m_node_begin.resize(n + 1);
+    HIP_TRY(hipMemcpy(A->m_node_begin.data(), A->node_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> f(A->total_kmers), r(A->total_kmers);
+    if (A->total_kmers) {
+        HIP_TRY(hipMemcpy(f.data(), A->nodes_fwd.p, A->total_kmers * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(r.data(), A->nodes_rc.p, A->total_kmers * 4, hipMemcpyDeviceToHost));
+    }
+    A->m_fwd.assign(f.begin(), f.end());
+    A->m_rc.assign(r.begin(), r.end());
+    out->n_queries = n;
+    out->node_begin = A->m_node_begin.data();
+    out->nodes_fwd = A->m_fwd.data();
+    out->nodes_rc = A->m_rc.data();
+    return MGX_OK;
+}
+
+// kernels only; results stay in HBM
+int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device) {
+    if (!A || !seqs || !offsets) return fail(MGX_ERR_INVALID, "null argument");
+    if (mgx_device_count() <= A->graph->device) return fail(MGX_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(A->graph->device));
+    const char *d_seqs; const uint64_t *d_offsets; uint32_t Lmax;
+    if (n == 0) { A->n_reads = 0; return MGX_OK; }
+    if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc;
+    bool mapped = A->cfg.max_seed_length >= A->graph->g.k;
+    if (int rc = run_map(A, d_seqs, d_offsets, n, A->cfg.forward_and_reverse_complement != 0, mapped)) return rc;
+    if (int rc = run_align(A, d_seqs, d_offsets, n, Lmax)) return rc;
+    return collect_stats(A, mapped, true);
+}
+
+int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
+    const uint64_t n = A->n_reads;
+    HIP_TRY(hipSetDevice(A->graph->device));
+    A->h_results.resize(n);
+    unsigned long long used = 0;
+    if (n) {
+        HIP_TRY(hipMemcpy(A->h_results.data(), A->results.p, n * sizeof(ReadResult), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&used, A->cursors.p, 8, hipMemcpyDeviceToHost));
+    }
+    A->h_stream.resize(used);
+    if (used) HIP_TRY(hipMemcpy(A->h_stream.data(), A->stream.p, used * 4, hipMemcpyDeviceToHost));
+    A->host.decode(A->h_results.data(), n, A->h_stream.data());
+    A->host.view(out);
+    return MGX_OK;
+}
+
+int mgx_align_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_results *out) {
+    if (!out) return fail(MGX_ERR_INVALID, "null argument");
+    if (int rc = mgx_align_batch_device(A, seqs, offsets, n, on_device)) return rc;
+    return mgx_fetch_results(A, out);
+}
+
+// test hook: keep the per-read seed lists of the next batches (device -> mgx_fetch_seeds)
+void mgx_aligner_keep_seeds(mgx_aligner *A, int keep) { A->keep_seeds = keep != 0; }
+
+// per read: num_matches fwd/rc, n_seeds fwd/rc, n_extensions, n_columns (6 x u32), and optionally the seeds
+int mgx_fetch_seed_info(mgx_aligner *A, uint32_t *info6, uint32_t *seeds /* [n][2][max_seeds][4] or NULL */, uint32_t *max_seeds_out) {
+    const uint64_t n = A->n_reads;
+    if (A->h_results.size() != n) {
+        A->h_results.resize(n);
+        if (n) HIP_TRY(hipMemcpy(A->h_results.data(), A->results.p, n * sizeof(ReadResult), hipMemcpyDeviceToHost));
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        const ReadResult &r = A->h_results[i];
+        uint32_t *o = info6 + 6 * i;
+        o[0] = r.num_matches_fwd; o[1] = r.num_matches_rc; o[2] = r.n_seeds_fwd; o[3] = r.n_seeds_rc;
+        o[4] = r.n_extensions; o[5] = r.n_columns;
+    }
+    if (max_seeds_out) *max_seeds_out = A->lim.max_seeds;
+    if (seeds && A->keep_seeds && n) {
+        std::vector<DevSeed> h(n * 2 * (uint64_t)A->lim.max_seeds);
+        HIP_TRY(hipMemcpy(h.data(), A->dbg_seeds.p, h.size() * sizeof(DevSeed), hipMemcpyDeviceToHost));
+        for (size_t x = 0; x < h.size(); ++x) {
+            seeds[4 * x] = h[x].clipping; seeds[4 * x + 1] = h[x].length; seeds[4 * x + 2] = h[x].offset;
+            seeds[4 * x + 3] = h[x].offset ? h[x].node : h[x].n_nodes;
+        }
+    }
+    return MGX_OK;
+}
+
+int mgx_aligner_stats(const mgx_aligner *A, mgx_stats *out) { *out = A->hstats; return MGX_OK; }
+
+size_t mgx_format_tsv(const mgx_results *res, uint64_t qi, const char *header, const char *query, size_t query_len,
+                      int32_t min_path_score, char *buf, size_t buf_len) {
+    // cli/align.cpp:262-285 + alignment.hpp:426-433; the query is printed normalised (AlignmentResults ctor)
+    std::string s(header);
+    s += '\t';
+    for (size_t i = 0; i < query_len; ++i) {
+        int8_t c = (int8_t)query[i];
+        s += c >= 0 ? (char)toupper(c) : (char)127;
+    }
+    if (res->aln_begin[qi] == res->aln_begin[qi + 1]) {
+        s += "\t*\t*\t" + std::to_string(min_path_score) + "\t*\t*\t*\n";
+    } else {
+        static const char ops[] = "SX=DIG";
+        for (uint64_t ai = res->aln_begin[qi]; ai < res->aln_begin[qi + 1]; ++ai) {
+            const mgx_alignment &a = res->alignments[ai];
+            s += a.orientation ? "\t-\t" : "\t+\t";
+            s.append(res->seqs + a.seq_begin, a.seq_len);
+            s += '\t' + std::to_string(a.score) + '\t' + std::to_string(a.num_matches) + '\t';
+            for (uint32_t x = 0; x < a.n_cigar; ++x) {
+                const mgx_cigar_op &op = res->cigar[a.cigar_begin + x];
+                s += std::to_string(op.len) + ops[op.op];
+            }
+            s += '\t' + std::to_string(a.offset);
+        }
+        s += '\n';
+    }
+    if (buf && buf_len) {
+        size_t nc = std::min(buf_len - 1, s.size());
+        memcpy(buf, s.data(), nc);
+        buf[nc] = 0;
+    }
+    return s.size();
+}
+
+} // extern "C"

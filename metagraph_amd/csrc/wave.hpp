@@ -1,0 +1,147 @@
+// wave.hpp — the only place kernels touch gfx950 wave intrinsics.
+//
+// Kernel bodies are written as "wave programs": uniform (wave-scalar) control flow, with
+// lane-parallel regions spelled FOR_LANES(l) { ... } over per-lane values LV<T>, and cross-lane
+// traffic only through the wave_* functions below.  On gfx950 a wave is 64 lanes; LV<T> is one
+// register per lane and FOR_LANES runs its body once on every lane.
+//
+// (tests/emu/wave.hpp is a lock-step host model of exactly this interface used by the CPU-only
+// unit tests to check kernel logic against the oracle.  It is never part of libmgx.so.)
+#ifndef MGX_WAVE_HPP_
+#define MGX_WAVE_HPP_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MGX_DEV __device__ __forceinline__
+#define MGX_DEV_NOINLINE __device__ __noinline__
+#define MGX_HD __host__ __device__ __forceinline__
+#define MGX_WAVE_EMU 0
+
+namespace mgx {
+
+constexpr int WAVE = 64;
+
+MGX_DEV int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// one value per lane
+template <class T>
+struct LV {
+    T v;
+    MGX_DEV T &operator[](int) { return v; }
+    MGX_DEV const T &operator[](int) const { return v; }
+};
+
+#define FOR_LANES(l) for (int l = ::mgx::lane_id(), l##_once = 1; l##_once; l##_once = 0)
+
+MGX_DEV uint64_t wave_ballot(const LV<bool> &p) { return __ballot(p.v); }
+
+MGX_DEV int32_t shfl_i32(int32_t v, int src) { return __shfl(v, src, WAVE); }
+
+template <class T>
+MGX_DEV T wave_bcast(const LV<T> &x, int src) {
+    if constexpr (sizeof(T) == 8) {
+        uint64_t u = (uint64_t)x.v;
+        uint32_t lo = (uint32_t)shfl_i32((int32_t)(uint32_t)u, src);
+        uint32_t hi = (uint32_t)shfl_i32((int32_t)(uint32_t)(u >> 32), src);
+        return (T)(((uint64_t)hi << 32) | lo);
+    } else {
+        return (T)shfl_i32((int32_t)x.v, src);
+    }
+}
+
+// value of lane (l - 1); lane 0 receives `fill`
+MGX_DEV LV<int32_t> wave_shift_up1(const LV<int32_t> &x, int32_t fill) {
+    LV<int32_t> r;
+    int32_t t = __shfl_up(x.v, 1, WAVE);
+    r.v = lane_id() == 0 ? fill : t;
+    return r;
+}
+
+// inclusive prefix max over lanes
+MGX_DEV LV<int32_t> wave_prefix_max(const LV<int32_t> &x) {
+    int32_t v = x.v;
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int32_t t = __shfl_up(v, d, WAVE);
+        if (l >= d) v = t > v ? t : v;
+    }
+    LV<int32_t> r;
+    r.v = v;
+    return r;
+}
+
+MGX_DEV int32_t wave_max(const LV<int32_t> &x) {
+    int32_t v = x.v;
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) {
+        int32_t t = __shfl_xor(v, d, WAVE);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+MGX_DEV int32_t wave_min(const LV<int32_t> &x) {
+    int32_t v = x.v;
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) {
+        int32_t t = __shfl_xor(v, d, WAVE);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+MGX_DEV uint64_t wave_max_u64(const LV<uint64_t> &x) {
+    uint64_t v = x.v;
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int32_t)(uint32_t)v, d, WAVE);
+        uint32_t hi = (uint32_t)__shfl_xor((int32_t)(uint32_t)(v >> 32), d, WAVE);
+        uint64_t t = ((uint64_t)hi << 32) | lo;
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+MGX_DEV int32_t wave_sum(const LV<int32_t> &x) {
+    int32_t v = x.v;
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+// exclusive prefix sum over lanes
+MGX_DEV LV<int32_t> wave_prefix_sum_excl(const LV<int32_t> &x) {
+    int32_t v = x.v;
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int32_t t = __shfl_up(v, d, WAVE);
+        if (l >= d) v += t;
+    }
+    LV<int32_t> r;
+    r.v = v - x.v;
+    return r;
+}
+
+// Make this wave's earlier memory writes visible to its later reads made by other lanes.
+MGX_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// wave-uniform value -> scalar register (all lanes must hold the same value)
+MGX_DEV int32_t uni(int32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+MGX_DEV uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)x); }
+MGX_DEV uint64_t uni(uint64_t x) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)x);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+MGX_DEV int64_t uni(int64_t x) { return (int64_t)uni((uint64_t)x); }
+MGX_DEV bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int32_t)x) != 0; }
+
+MGX_DEV int popc64(uint64_t x) { return __popcll(x); }
+MGX_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }           // x != 0
+MGX_DEV int clz64(uint64_t x) { return __clzll((long long)x); }                // x != 0
+MGX_DEV double fma_f64(double a, double b, double c) { return __fma_rn(a, b, c); }
+
+} // namespace mgx
+#endif  // MGX_WAVE_HPP_

@@ -1,0 +1,192 @@
+// tests/emu/emu_driver.cpp — TEST INFRASTRUCTURE ONLY.
+// Runs the kernels' wave programs (metagraph_amd/csrc/{dev_graph,graph_build,align_core}.hpp, the
+// same sources the HIP build compiles) under the lock-step host model tests/emu/wave.hpp, one
+// "wave" at a time, so that CPU-only CI can compare kernel logic with the oracle.  Built into
+// tests/emu/_build/libmgxemu.so; never linked into or loaded by the product.
+#include "wave.hpp"              // tests/emu/wave.hpp (shadows the gfx950 header)
+
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "graph_build.hpp"
+#include "host_common.hpp"
+
+using namespace mgx;
+
+namespace {
+struct EmuGraph {
+    DevGraph g;
+    std::vector<Block> blocks;
+    std::vector<uint32_t> last_hint, w_hint[4], firstc;
+    std::vector<uint64_t> terminus, valid;
+};
+
+struct EmuRun {
+    std::string error;
+    std::vector<ReadResult> results;
+    std::vector<uint32_t> stream;
+    HostResults host;
+    std::vector<uint64_t> node_begin, m_fwd, m_rc;
+    std::vector<DevSeed> seeds;
+    DevLimits lim;
+    KernelStats stats;
+};
+} // namespace
+
+extern "C" {
+
+void *emu_graph_create(const mgx_boss_view *view) {
+    auto *G = new EmuGraph();
+    const uint64_t n = view->n_edges;
+    const uint32_t n_blocks = (uint32_t)((n + 1 + 63) / 64);
+    G->blocks.resize(n_blocks);
+    std::vector<uint32_t> counts((size_t)n_blocks * 6);
+    for (uint32_t b = 0; b < n_blocks; ++b) build_block_pass1(b, view->W, view->last, n, G->blocks.data(), counts.data());
+    uint64_t tot[6] = { 0, 0, 0, 0, 0, 0 };
+    for (uint32_t b = 0; b < n_blocks; ++b)
+        for (int c = 0; c < 6; ++c) { uint32_t v = counts[(size_t)b * 6 + c]; counts[(size_t)b * 6 + c] = (uint32_t)tot[c]; tot[c] += v; }
+    G->last_hint.assign(tot[5] / 64 + 2, 0);
+    uint32_t *wh[4];
+    for (int c = 0; c < 4; ++c) { G->w_hint[c].assign(tot[c + 1] / 64 + 2, 0); wh[c] = G->w_hint[c].data(); }
+    for (uint32_t b = 0; b < n_blocks; ++b) build_block_pass2(b, G->blocks.data(), counts.data(), G->last_hint.data(), wh);
+    DevGraph &g = G->g;
+    memset(&g, 0, sizeof(g));
+    g.blocks = G->blocks.data();
+    g.last_hint = G->last_hint.data();
+    for (int c = 0; c < 4; ++c) g.w_hint[c] = G->w_hint[c].data();
+    g.n = n; g.n_blocks = n_blocks; g.k = view->k;
+    LineCtr ctr = { 0, 0, 0 };
+    for (int c = 0; c < SIGMA; ++c) { g.F[c] = (uint32_t)view->F[c]; }
+    for (int c = 0; c < SIGMA; ++c) g.NF[c] = rank_last(g, g.F[c], ctr);
+    if (view->valid) {
+        G->valid.assign(n_blocks, 0);
+        for (uint64_t e = 0; e <= n; ++e) if (view->valid[e]) G->valid[e >> 6] |= 1ull << (e & 63);
+        g.valid = G->valid.data();
+    }
+    std::vector<uint32_t> P(n + 1);
+    std::vector<uint8_t> D0(n + 1), D1(n + 1);
+    for (uint64_t e = 0; e <= n; ++e) { P[e] = build_parent(g, e); D0[e] = (uint8_t)node_last_value(g, e); }
+    for (uint32_t r = 0; r + 2 < g.k; ++r) {
+        for (uint64_t e = 0; e <= n; ++e) D1[e] = D0[P[e]];
+        D0.swap(D1);
+    }
+    G->firstc.assign((n + 1 + 7) / 8 + 1, 0);
+    for (uint64_t e = 0; e <= n; ++e) G->firstc[e >> 3] |= (uint32_t)(D0[e] & 0xF) << (4 * (e & 7));
+    g.firstc = G->firstc.data();
+    G->terminus.assign(n_blocks, 0);
+    g.terminus = G->terminus.data();
+    for (uint64_t v = 1; v <= n; ++v)
+        if (in_graph(g, v) && build_terminus(g, v)) G->terminus[v >> 6] |= 1ull << (v & 63);
+    return G;
+}
+
+void emu_graph_free(void *h) { delete static_cast<EmuGraph *>(h); }
+
+// graph primitives for layer tests
+uint64_t emu_fwd(void *h, uint64_t i, uint32_t c) { LineCtr ctr = { 0, 0, 0 }; return fwd(static_cast<EmuGraph *>(h)->g, i, c, ctr); }
+uint64_t emu_bwd(void *h, uint64_t i) { LineCtr ctr = { 0, 0, 0 }; return bwd(static_cast<EmuGraph *>(h)->g, i, ctr); }
+uint32_t emu_first_char(void *h, uint64_t e) { LineCtr ctr = { 0, 0, 0 }; return first_char(static_cast<EmuGraph *>(h)->g, e, ctr); }
+int emu_terminus(void *h, uint64_t v) { auto &g = static_cast<EmuGraph *>(h)->g; return (g.terminus[v >> 6] >> (v & 63)) & 1; }
+uint32_t emu_outgoing(void *h, uint64_t v, int rc, uint64_t *nodes, char *chars) {
+    auto &g = static_cast<EmuGraph *>(h)->g;
+    LineCtr ctr = { 0, 0, 0 };
+    uint64_t nn[5]; uint32_t cc[5];
+    int n = rc ? incoming(g, v, nn, cc, ctr) : outgoing(g, v, nn, cc, ctr);
+    for (int t = 0; t < n; ++t) { nodes[t] = nn[t]; chars[t] = rc ? (char)complement_char(decode_code(cc[t])) : (char)decode_code(cc[t]); }
+    return (uint32_t)n;
+}
+int emu_is_low_complexity(const char *s, uint32_t len) {
+    std::vector<int32_t> sd(2048);
+    return is_low_complexity((const uint8_t *)s, (int32_t)len, sd.data());
+}
+
+void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, const char *seqs, const uint64_t *offsets,
+                uint64_t n, int map_only) {
+    auto *G = static_cast<EmuGraph *>(gh);
+    auto *R = new EmuRun();
+    mgx_config cfg;
+    DevConfig dcfg;
+    int rc = prepare_config(*config, G->g.k, &cfg, &dcfg, &R->error);
+    if (rc) return R;
+    const uint32_t k = G->g.k;
+    uint32_t Lmax = 0;
+    R->node_begin.assign(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t L = offsets[i + 1] - offsets[i];
+        Lmax = std::max<uint32_t>(Lmax, (uint32_t)L);
+        R->node_begin[i + 1] = R->node_begin[i] + (L >= k ? L - k + 1 : 0);
+    }
+    std::vector<uint32_t> nf(R->node_begin[n] + 1, 0), nr(R->node_begin[n] + 1, 0);
+    bool mapped = cfg.max_seed_length >= k;
+    memset(&R->stats, 0, sizeof(R->stats));
+    if (mapped) {
+        for (uint64_t i = 0; i < n; ++i) {
+            LineCtr ctr = { 0, 0, 0 };
+            int32_t L = (int32_t)(offsets[i + 1] - offsets[i]);
+            map_chain(G->g, seqs + offsets[i], L, 0, nf.data() + R->node_begin[i], ctr);
+            if (map_only || cfg.forward_and_reverse_complement) map_chain(G->g, seqs + offsets[i], L, 1, nr.data() + R->node_begin[i], ctr);
+            R->stats.rank_lines += ctr.rank_lines; R->stats.select_lines += ctr.select_lines;
+        }
+    }
+    R->m_fwd.assign(nf.begin(), nf.end());
+    R->m_rc.assign(nr.begin(), nr.end());
+    if (map_only) return R;
+    rc = derive_limits(cfg, limits, Lmax, &R->lim, &R->error);
+    if (rc) return R;
+    const uint64_t stride = arena_bytes(R->lim);
+    std::vector<uint8_t> arena(stride, 0);
+    std::vector<int8_t> sm(128 * 128);
+    memcpy(sm.data(), cfg.score_matrix, 128 * 128);
+    R->results.resize(n);
+    uint64_t out_words = n * ((uint64_t)R->lim.Lmax * 3 + 64) + 1024;
+    R->stream.assign(out_words, 0);
+    R->seeds.assign(n * 2 * (uint64_t)R->lim.max_seeds, DevSeed{ 0, 0, 0, 0, 0 });
+    unsigned long long cursors[2] = { 0, 0 };
+    AlignParams P;
+    memset(&P, 0, sizeof(P));
+    P.g = G->g; P.cfg = dcfg; P.lim = R->lim; P.score_matrix = sm.data();
+    P.seqs = seqs; P.offsets = offsets; P.node_begin = R->node_begin.data();
+    P.nodes_fwd = nf.data(); P.nodes_rc = nr.data(); P.n_reads = n;
+    P.arena = arena.data(); P.arena_stride = stride;
+    P.results = R->results.data(); P.out_stream = R->stream.data(); P.out_capacity = out_words;
+    P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();
+    for (uint64_t i = 0; i < n; ++i) align_read(P, i, 0, &R->stats);
+    R->host.decode(R->results.data(), n, R->stream.data());
+    return R;
+}
+
+const char *emu_error(void *r) { return static_cast<EmuRun *>(r)->error.c_str(); }
+void emu_results(void *r, mgx_results *out) { static_cast<EmuRun *>(r)->host.view(out); }
+void emu_mapping(void *r, mgx_mapping *out) {
+    auto *R = static_cast<EmuRun *>(r);
+    out->n_queries = R->node_begin.size() - 1;
+    out->node_begin = R->node_begin.data();
+    out->nodes_fwd = R->m_fwd.data();
+    out->nodes_rc = R->m_rc.data();
+}
+// info6 per read + seeds [n][2][max_seeds][4]
+uint32_t emu_seed_info(void *r, uint32_t *info6, uint32_t *seeds) {
+    auto *R = static_cast<EmuRun *>(r);
+    for (size_t i = 0; i < R->results.size(); ++i) {
+        const ReadResult &x = R->results[i];
+        uint32_t *o = info6 + 6 * i;
+        o[0] = x.num_matches_fwd; o[1] = x.num_matches_rc; o[2] = x.n_seeds_fwd; o[3] = x.n_seeds_rc;
+        o[4] = x.n_extensions; o[5] = x.n_columns;
+    }
+    if (seeds)
+        for (size_t x = 0; x < R->seeds.size(); ++x) {
+            seeds[4 * x] = R->seeds[x].clipping; seeds[4 * x + 1] = R->seeds[x].length; seeds[4 * x + 2] = R->seeds[x].offset;
+            seeds[4 * x + 3] = R->seeds[x].offset ? R->seeds[x].node : R->seeds[x].n_nodes;
+        }
+    return R->lim.max_seeds;
+}
+void emu_stats(void *r, uint64_t *out7) {
+    auto &s = static_cast<EmuRun *>(r)->stats;
+    out7[0] = s.rank_lines; out7[1] = s.select_lines; out7[2] = s.bit_lines; out7[3] = s.columns;
+    out7[4] = s.extensions; out7[5] = s.seeds; out7[6] = s.capacity_errors;
+}
+void emu_free(void *r) { delete static_cast<EmuRun *>(r); }
+
+} // extern "C"

@@ -1,0 +1,108 @@
+// tests/emu/wave.hpp — TEST INFRASTRUCTURE ONLY.
+// Lock-step host model of metagraph_amd/csrc/wave.hpp: a "wave" is 64 lanes evaluated one after the
+// other inside every FOR_LANES region, LV<T> is a 64-entry array, and the wave_* functions are
+// plain loops.  It lets the CPU-only unit tests run the kernels' wave programs (the very same
+// source files as the HIP build) against the oracle.  It is put first on the include path by
+// tests/emu/Makefile so that it shadows the gfx950 header; nothing here is ever compiled into
+// libmgx.so and the product has no CPU execution path.
+// Shares the include guard of metagraph_amd/csrc/wave.hpp: the test driver includes this file first,
+// which turns the gfx950 header into a no-op for that translation unit only.
+#ifndef MGX_WAVE_HPP_
+#define MGX_WAVE_HPP_
+#include <stdint.h>
+#include <cmath>
+#include <cstring>
+
+#define MGX_DEV inline
+#define MGX_DEV_NOINLINE
+#define MGX_HD inline
+#define MGX_WAVE_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+struct uint4 { uint32_t x, y, z, w; };
+
+namespace mgx {
+
+constexpr int WAVE = 64;
+
+inline int lane_id() { return 0; }
+
+template <class T>
+struct LV {
+    T v[WAVE];
+    T &operator[](int l) { return v[l]; }
+    const T &operator[](int l) const { return v[l]; }
+};
+
+#define FOR_LANES(l) for (int l = 0; l < ::mgx::WAVE; ++l)
+
+inline uint64_t wave_ballot(const LV<bool> &p) {
+    uint64_t m = 0;
+    for (int l = 0; l < WAVE; ++l) m |= (uint64_t)(p[l] ? 1 : 0) << l;
+    return m;
+}
+
+template <class T>
+inline T wave_bcast(const LV<T> &x, int src) { return x[src]; }
+
+inline LV<int32_t> wave_shift_up1(const LV<int32_t> &x, int32_t fill) {
+    LV<int32_t> r;
+    r[0] = fill;
+    for (int l = 1; l < WAVE; ++l) r[l] = x[l - 1];
+    return r;
+}
+
+inline LV<int32_t> wave_prefix_max(const LV<int32_t> &x) {
+    LV<int32_t> r;
+    int32_t m = x[0];
+    for (int l = 0; l < WAVE; ++l) { m = x[l] > m ? x[l] : m; r[l] = m; }
+    return r;
+}
+
+inline int32_t wave_max(const LV<int32_t> &x) {
+    int32_t m = x[0];
+    for (int l = 1; l < WAVE; ++l) m = x[l] > m ? x[l] : m;
+    return m;
+}
+
+inline int32_t wave_min(const LV<int32_t> &x) {
+    int32_t m = x[0];
+    for (int l = 1; l < WAVE; ++l) m = x[l] < m ? x[l] : m;
+    return m;
+}
+
+inline uint64_t wave_max_u64(const LV<uint64_t> &x) {
+    uint64_t m = x[0];
+    for (int l = 1; l < WAVE; ++l) m = x[l] > m ? x[l] : m;
+    return m;
+}
+
+inline int32_t wave_sum(const LV<int32_t> &x) {
+    int32_t s = 0;
+    for (int l = 0; l < WAVE; ++l) s += x[l];
+    return s;
+}
+
+inline LV<int32_t> wave_prefix_sum_excl(const LV<int32_t> &x) {
+    LV<int32_t> r;
+    int32_t s = 0;
+    for (int l = 0; l < WAVE; ++l) { r[l] = s; s += x[l]; }
+    return r;
+}
+
+inline void wave_sync() {}
+
+inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
+inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+inline int clz64(uint64_t x) { return __builtin_clzll(x); }
+inline double fma_f64(double a, double b, double c) { return std::fma(a, b, c); }
+
+template <class T>
+inline T uni(T x) { return x; }
+
+} // namespace mgx
+#endif  // MGX_WAVE_HPP_

@@ -1,0 +1,141 @@
+"""ctypes driver for tests/emu/_build/libmgxemu.so — the host model of the kernels' wave programs.
+TEST INFRASTRUCTURE ONLY (CPU-only CI); the product path is libmgx.so on a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from metagraph_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_L = None
+
+
+def L():
+    global _L
+    if _L is None:
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")], check=True)
+        _L = C.CDLL(os.path.join(ROOT, "tests", "emu", "_build", "libmgxemu.so"))
+        _L.emu_graph_create.restype = C.c_void_p
+        _L.emu_graph_create.argtypes = [C.POINTER(capi.BossView)]
+        _L.emu_graph_free.argtypes = [C.c_void_p]
+        _L.emu_fwd.restype = C.c_uint64
+        _L.emu_fwd.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        _L.emu_bwd.restype = C.c_uint64
+        _L.emu_bwd.argtypes = [C.c_void_p, C.c_uint64]
+        _L.emu_first_char.restype = C.c_uint32
+        _L.emu_first_char.argtypes = [C.c_void_p, C.c_uint64]
+        _L.emu_terminus.argtypes = [C.c_void_p, C.c_uint64]
+        _L.emu_outgoing.restype = C.c_uint32
+        _L.emu_outgoing.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_char_p]
+        _L.emu_is_low_complexity.argtypes = [C.c_char_p, C.c_uint32]
+        _L.emu_align.restype = C.c_void_p
+        _L.emu_align.argtypes = [C.c_void_p, C.POINTER(capi.Config), C.POINTER(capi.Limits), C.c_char_p,
+                                 C.POINTER(C.c_uint64), C.c_uint64, C.c_int]
+        _L.emu_error.restype = C.c_char_p
+        _L.emu_error.argtypes = [C.c_void_p]
+        _L.emu_results.argtypes = [C.c_void_p, C.POINTER(capi.Results)]
+        _L.emu_mapping.argtypes = [C.c_void_p, C.POINTER(capi.Mapping)]
+        _L.emu_seed_info.restype = C.c_uint32
+        _L.emu_seed_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _L.emu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        _L.emu_free.argtypes = [C.c_void_p]
+    return _L
+
+
+def boss_view(k, W, last, F, valid=None, on_device=0):
+    """numpy arrays -> (BossView, keepalive)"""
+    v = capi.BossView()
+    v.k = k
+    v.sigma = 5
+    v.n_edges = len(W) - 1
+    v.W = W.ctypes.data
+    v.last = last.ctypes.data
+    Fc = (C.c_uint64 * 5)(*[int(x) for x in F])
+    v.F = C.cast(Fc, C.POINTER(C.c_uint64))
+    v.valid = valid.ctypes.data if valid is not None else None
+    v.mode = 0
+    v.on_device = on_device
+    return v, (W, last, Fc, valid)
+
+
+class EmuGraph:
+    def __init__(self, orc_graph):
+        W, last, F, valid = orc_graph.export()
+        self.view, self._keep = boss_view(orc_graph.k, W, last, F, valid)
+        self.h = L().emu_graph_create(C.byref(self.view))
+        self.k = orc_graph.k
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L().emu_graph_free(self.h)
+            self.h = None
+
+    def outgoing(self, v, rc=False):
+        nodes = (C.c_uint64 * 8)()
+        chars = C.create_string_buffer(8)
+        n = L().emu_outgoing(self.h, v, int(rc), nodes, chars)
+        return [(nodes[i], chars.raw[i:i + 1].decode()) for i in range(n)]
+
+
+class EmuRun:
+    def __init__(self, graph, config, queries, limits=None, map_only=False):
+        from orc import pack_queries
+        blob, offs = pack_queries(queries)
+        self._keep = (blob, offs)
+        self.n = len(queries)
+        self.r = L().emu_align(graph.h, C.byref(config), C.byref(limits) if limits is not None else None, blob,
+                               offs.ctypes.data_as(C.POINTER(C.c_uint64)), self.n, int(map_only))
+        self.error = L().emu_error(self.r).decode()
+
+    def __del__(self):
+        if getattr(self, "r", None):
+            L().emu_free(self.r)
+            self.r = None
+
+    def results(self):
+        v = capi.Results()
+        L().emu_results(self.r, C.byref(v))
+        return capi.results_to_py(v), [v.status[i] for i in range(self.n)]
+
+    def mapping(self):
+        m = capi.Mapping()
+        L().emu_mapping(self.r, C.byref(m))
+        out = []
+        for q in range(self.n):
+            b, e = m.node_begin[q], m.node_begin[q + 1]
+            out.append(([m.nodes_fwd[i] for i in range(b, e)], [m.nodes_rc[i] for i in range(b, e)]))
+        return out
+
+    def seed_info(self):
+        info = (C.c_uint32 * (6 * self.n))()
+        ms = L().emu_seed_info(self.r, info, None)
+        seeds = (C.c_uint32 * (self.n * 2 * ms * 4))()
+        L().emu_seed_info(self.r, info, seeds)
+        return decode_seed_info(self.n, ms, info, seeds)
+
+    def stats(self):
+        a = (C.c_uint64 * 7)()
+        L().emu_stats(self.r, a)
+        return dict(zip(["rank_lines", "select_lines", "bit_lines", "columns", "extensions", "seeds", "capacity_errors"], list(a)))
+
+
+def decode_seed_info(n, ms, info, seeds):
+    """-> per read: {'num_matches': (f, r), 'seeds': (list_f, list_r), 'n_extensions', 'n_columns'};
+    a seed = (clipping, length, offset, n_nodes or the sub-k node)"""
+    out = []
+    arr = np.ctypeslib.as_array(seeds).reshape(n, 2, ms, 4) if n else None
+    for i in range(n):
+        nf, nr = info[6 * i + 2], info[6 * i + 3]
+        sl = []
+        for s, cnt in ((0, nf), (1, nr)):
+            sl.append([tuple(int(x) for x in arr[i, s, j]) for j in range(cnt)])
+        out.append({"num_matches": (info[6 * i], info[6 * i + 1]), "seeds": tuple(sl),
+                    "n_extensions": info[6 * i + 4], "n_columns": info[6 * i + 5]})
+    return out
+
+
+def oracle_seeds_as_tuples(seed_list):
+    """orc.AlignRun.seeds(strand)[q][0] -> same tuple form as decode_seed_info"""
+    return [(s["clipping"], s["length"], s["offset"], s["nodes"][0] if s["offset"] else len(s["nodes"])) for s in seed_list]

@@ -1,0 +1,184 @@
+"""Kernel logic (wave programs under the host model) against the oracle.  CPU only."""
+import json
+import os
+import random
+
+import pytest
+
+import emu_drv
+import orc
+from metagraph_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "aligner_kats.json")))
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice("ACGT") for _ in range(n))
+
+
+def mutate(rng, s, sub=0.03, ins=0.005, dele=0.005):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < dele:
+            continue
+        if r < dele + sub:
+            out.append(rng.choice([c for c in "ACGT" if c != ch]))
+        else:
+            out.append(ch)
+        if rng.random() < ins:
+            out.append(rng.choice("ACGT"))
+    return "".join(out)
+
+
+def rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def make_world(seed, k, genome_len=3000, n_reads=40, read_len=100, mask=False, n_variants=10):
+    rng = random.Random(seed)
+    genome = rand_seq(rng, genome_len)
+    seqs = [genome]
+    for _ in range(n_variants):
+        p = rng.randrange(k, genome_len - k)
+        alt = rng.choice([c for c in "ACGT" if c != genome[p]])
+        seqs.append(genome[p - k + 1:p] + alt + genome[p + 1:p + k])
+    g = orc.Graph.build(k, seqs, 0, mask)
+    reads = []
+    for i in range(n_reads):
+        if i % 10 == 9:
+            reads.append(rand_seq(rng, read_len))
+            continue
+        p = rng.randrange(0, genome_len - read_len)
+        r = mutate(rng, genome[p:p + read_len])
+        if rng.random() < 0.5:
+            r = rc(r)
+        if i % 7 == 3:
+            r = r[:len(r) // 2] + "N" + r[len(r) // 2 + 1:]
+        reads.append(r)
+    return g, reads
+
+
+def test_graph_primitives():
+    g, _ = make_world(1, 9, genome_len=600, n_reads=0)
+    eg = emu_drv.EmuGraph(g)
+    Lo, Le = orc.L(), emu_drv.L()
+    W, last, F, _ = g.export()
+    n = g.n_edges
+    for v in range(1, n + 1):
+        assert Le.emu_bwd(eg.h, v) == Lo.orc_boss_bwd(g.h, v), v
+        c = int(W[v]) % 5
+        if c or v == 1:
+            assert Le.emu_fwd(eg.h, v, c) == Lo.orc_boss_fwd(g.h, v, c), v
+        assert eg.outgoing(v) == [(a, b) for a, b in g.outgoing(v) if b != "$"], v
+        want_in = [(a, b) for a, b in g.outgoing(v, rc=True)]
+        got_in = eg.outgoing(v, rc=True)
+        assert got_in == want_in, (v, got_in, want_in)
+        seq = g.node_sequence(v)
+        assert "$ACGT"[Le.emu_first_char(eg.h, v)] == seq[0], (v, seq)
+        term = bool(Lo.orc_graph_has_multiple_outgoing(g.h, v)) or not bool(Lo.orc_graph_has_single_incoming(g.h, v))
+        assert bool(Le.emu_terminus(eg.h, v)) == term, v
+
+
+def test_graph_primitives_masked():
+    g, _ = make_world(2, 7, genome_len=400, n_reads=0, mask=True)
+    eg = emu_drv.EmuGraph(g)
+    Lo, Le = orc.L(), emu_drv.L()
+    W, last, F, valid = g.export()
+    for v in range(1, g.n_edges + 1):
+        if not valid[v]:
+            continue
+        assert eg.outgoing(v) == [(a, b) for a, b in g.outgoing(v) if b != "$"], v
+        assert eg.outgoing(v, rc=True) == g.outgoing(v, rc=True), v
+        term = bool(Lo.orc_graph_has_multiple_outgoing(g.h, v)) or not bool(Lo.orc_graph_has_single_incoming(g.h, v))
+        assert bool(Le.emu_terminus(eg.h, v)) == term, v
+
+
+def test_sdust_matches_oracle():
+    rng = random.Random(5)
+    Lo, Le = orc.L(), emu_drv.L()
+    for _ in range(400):
+        n = rng.randrange(3, 64)
+        mode = rng.random()
+        if mode < 0.3:
+            s = rand_seq(rng, n)
+        elif mode < 0.6:
+            unit = rand_seq(rng, rng.randrange(1, 4))
+            s = (unit * 40)[:n]
+        else:
+            s = "".join(rng.choice("AAAT") for _ in range(n))
+        if rng.random() < 0.2:
+            s = s[:n // 2] + "N" + s[n // 2 + 1:]
+        b = s.encode()
+        assert bool(Le.emu_is_low_complexity(b, len(b))) == bool(Lo.orc_is_low_complexity(b, len(b))), s
+
+
+@pytest.mark.parametrize("k,mask", [(11, False), (11, True), (31, False), (5, False)])
+def test_mapping(k, mask):
+    g, reads = make_world(10 + k, k, mask=mask)
+    eg = emu_drv.EmuGraph(g)
+    cfg = capi.config_cli(k)
+    want = orc.AlignRun(g, cfg, reads).mapping()
+    got = emu_drv.EmuRun(eg, cfg, reads, map_only=True).mapping()
+    assert got == want
+
+
+def compare_full(g, eg, cfg, reads, limits=None):
+    o = orc.AlignRun(g, cfg, reads)
+    assert o.error == "", o.error
+    e = emu_drv.EmuRun(eg, cfg, reads, limits=limits)
+    assert e.error == "", e.error
+    got, status = e.results()
+    assert all(s == 0 for s in status), status
+    info = e.seed_info()
+    for strand in (0, 1):
+        for q, (ss, nm) in enumerate(o.seeds(strand)):
+            assert info[q]["num_matches"][strand] == nm, (q, strand, "num_matches")
+            assert info[q]["seeds"][strand] == emu_drv.oracle_seeds_as_tuples(ss), (q, strand, reads[q])
+    want = o.results()
+    for q in range(len(reads)):
+        assert got[q] == want[q], (q, reads[q], got[q], want[q])
+    return e
+
+
+@pytest.mark.parametrize("k,mask,seed", [(11, False, 1), (19, False, 2), (31, False, 3), (11, True, 4), (31, True, 5)])
+def test_align_cli_config(k, mask, seed):
+    g, reads = make_world(100 + seed, k, mask=mask)
+    eg = emu_drv.EmuGraph(g)
+    cfg = capi.config_cli(k)
+    compare_full(g, eg, cfg, reads)
+
+
+def test_align_cli_config_no_min_exact_match():
+    g, reads = make_world(200, 15, n_reads=60)
+    eg = emu_drv.EmuGraph(g)
+    cfg = capi.config_cli(15)
+    cfg.min_exact_match = 0.0
+    compare_full(g, eg, cfg, reads)
+
+
+def test_align_forward_only():
+    g, reads = make_world(201, 13, n_reads=40)
+    eg = emu_drv.EmuGraph(g)
+    cfg = capi.config_cli(13)
+    cfg.forward_and_reverse_complement = 0
+    cfg.min_exact_match = 0.0
+    compare_full(g, eg, cfg, reads)
+
+
+BIG = capi.Limits()
+BIG.max_columns = 250000
+BIG.max_seeds = 2048
+
+
+@pytest.mark.parametrize("case", [c for c in KATS["unit"] if not c["expect"].get("throws")
+                                  and c["config"].get("num_alternative_paths", 1) == 1], ids=lambda c: c["name"])
+def test_unit_kats_through_kernels(case):
+    g = orc.Graph.build(case["k"], case["graph"], 0, case["mask_dummy"])
+    eg = emu_drv.EmuGraph(g)
+    for extend in (False, True):
+        cfg = orc.make_config(case["config"], case["matrix"])
+        if extend:
+            cfg.max_seed_length = capi.UINT64_MAX
+        compare_full(g, eg, cfg, [case["query"]], limits=BIG)
