@@ -1,0 +1,138 @@
+"""Thin Python plumbing over libmgx.so (ctypes).  Mirrors the reference's operator surface for the
+alignment path: `Graph` ~ DBGSuccinct (BOSS view upload), `Aligner.align_batch` ~
+IDBGAligner::align_batch (graph/alignment/dbg_aligner.hpp:20-39).  No compute happens in Python and
+there is no CPU fallback: every call below fails loudly without the HIP library / a GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class MgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mgx error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _check(rc):
+    if rc != capi.MGX_OK:
+        raise MgxError(rc, capi.lib().mgx_last_error().decode())
+
+
+def pack_queries(queries):
+    offs = np.zeros(len(queries) + 1, dtype=np.uint64)
+    bs = [q if isinstance(q, bytes) else q.encode("latin-1") for q in queries]
+    for i, b in enumerate(bs):
+        offs[i + 1] = offs[i] + len(b)
+    return b"".join(bs), offs
+
+
+class Graph:
+    """A BOSS table on the GPU.  W/last: uint8 arrays of n_edges + 1 entries (slot 0 unused)."""
+
+    def __init__(self, k, W, last, F, valid=None, device=0, on_device=False, mode=0):
+        L = capi.lib()
+        v = capi.BossView()
+        v.k = k
+        v.sigma = 5
+        if on_device:      # (ptr, n_entries) pairs for W / last / valid
+            v.n_edges = W[1] - 1
+            v.W, v.last = W[0], last[0]
+            v.valid = valid[0] if valid is not None else None
+        else:
+            W = np.ascontiguousarray(W, dtype=np.uint8)
+            last = np.ascontiguousarray(last, dtype=np.uint8)
+            v.n_edges = len(W) - 1
+            v.W, v.last = W.ctypes.data, last.ctypes.data
+            if valid is not None:
+                valid = np.ascontiguousarray(valid, dtype=np.uint8)
+                v.valid = valid.ctypes.data
+        Fc = (C.c_uint64 * 5)(*[int(x) for x in F])
+        v.F = C.cast(Fc, C.POINTER(C.c_uint64))
+        v.mode = mode
+        v.on_device = 1 if on_device else 0
+        self.h = C.c_void_p()
+        _check(L.mgx_graph_create(C.byref(v), device, C.byref(self.h)))
+        self.k = k
+        self.n_edges = v.n_edges
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().mgx_graph_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def device_bytes(self):
+        return capi.lib().mgx_graph_device_bytes(self.h)
+
+
+class Aligner:
+    """DBGAligner<> on the GPU (default seeder/extender, BASIC graphs)."""
+
+    def __init__(self, graph, config, limits=None):
+        self.graph = graph
+        self.h = C.c_void_p()
+        _check(capi.lib().mgx_aligner_create(graph.h, C.byref(config), C.byref(limits) if limits is not None else None,
+                                             C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib().mgx_aligner_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def get_config(self):
+        c = capi.Config()
+        _check(capi.lib().mgx_aligner_get_config(self.h, C.byref(c)))
+        return c
+
+    def align_batch(self, queries):
+        """-> (list per query of alignment dicts, list of status codes)"""
+        blob, offs = pack_queries(queries)
+        res = capi.Results()
+        _check(capi.lib().mgx_align_batch(self.h, blob, offs.ctypes.data, len(queries), 0, C.byref(res)))
+        return capi.results_to_py(res), [res.status[i] for i in range(len(queries))]
+
+    def align_device(self, seqs_ptr, offsets_ptr, n):
+        """Reads already in HBM (device pointers); results stay on the device until fetch()."""
+        _check(capi.lib().mgx_align_batch_device(self.h, seqs_ptr, offsets_ptr, n, 1))
+
+    def fetch(self):
+        res = capi.Results()
+        _check(capi.lib().mgx_fetch_results(self.h, C.byref(res)))
+        return res
+
+    def map_batch(self, queries):
+        blob, offs = pack_queries(queries)
+        m = capi.Mapping()
+        _check(capi.lib().mgx_map_batch(self.h, blob, offs.ctypes.data, len(queries), 0, C.byref(m)))
+        out = []
+        for q in range(len(queries)):
+            b, e = m.node_begin[q], m.node_begin[q + 1]
+            out.append(([m.nodes_fwd[i] for i in range(b, e)], [m.nodes_rc[i] for i in range(b, e)]))
+        return out
+
+    def keep_seeds(self, keep=True):
+        capi.lib().mgx_aligner_keep_seeds(self.h, int(keep))
+
+    def seed_info(self, n):
+        from . import _seedinfo
+        return _seedinfo.fetch(self, n)
+
+    def stats(self):
+        s = capi.Stats()
+        _check(capi.lib().mgx_aligner_stats(self.h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in capi.Stats._fields_}
+
+    def format_tsv(self, res, qi, header, query):
+        q = query if isinstance(query, bytes) else query.encode("latin-1")
+        cfg = self.get_config()
+        n = capi.lib().mgx_format_tsv(C.byref(res), qi, header.encode(), q, len(q), cfg.min_path_score, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        capi.lib().mgx_format_tsv(C.byref(res), qi, header.encode(), q, len(q), cfg.min_path_score, buf, n + 1)
+        return buf.value.decode("latin-1")

@@ -114,6 +114,9 @@ def lib():
     L.mgx_aligner_destroy.argtypes = [C.c_void_p]
     L.mgx_aligner_get_config.argtypes = [C.c_void_p, C.POINTER(Config)]
     L.mgx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Results)]
+    L.mgx_align_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
+    L.mgx_fetch_results.argtypes = [C.c_void_p, C.POINTER(Results)]
+    L.mgx_aligner_keep_seeds.argtypes = [C.c_void_p, C.c_int]
     L.mgx_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Mapping)]
     L.mgx_aligner_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.mgx_config_init_default.argtypes = [C.POINTER(Config)]

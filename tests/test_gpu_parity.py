@@ -1,0 +1,135 @@
+"""GPU parity: libmgx.so (HIP kernels through the C-ABI) against the oracle.  Needs a real MI355X."""
+import json
+import os
+import random
+
+import pytest
+
+import orc
+from metagraph_amd import aligner, capi
+from test_emu_vs_oracle import make_world, mutate, KATS
+from emu_drv import oracle_seeds_as_tuples
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_graph(g):
+    W, last, F, valid = g.export()
+    return aligner.Graph(g.k, W, last, F, valid)
+
+
+def compare_gpu(g, G, cfg, reads, limits=None, check_seeds=True):
+    o = orc.AlignRun(g, cfg, reads)
+    assert o.error == "", o.error
+    A = aligner.Aligner(G, cfg, limits)
+    A.keep_seeds(check_seeds)
+    got, status = A.align_batch(reads)
+    assert all(s == 0 for s in status), status
+    if check_seeds:
+        info = A.seed_info(len(reads))
+        for strand in (0, 1):
+            for q, (ss, nm) in enumerate(o.seeds(strand)):
+                assert info[q]["num_matches"][strand] == nm, (q, strand)
+                assert info[q]["seeds"][strand] == oracle_seeds_as_tuples(ss), (q, strand, reads[q])
+    want = o.results()
+    for q in range(len(reads)):
+        assert got[q] == want[q], (q, reads[q], got[q], want[q])
+    return A
+
+
+def test_library_sees_gpu():
+    assert capi.lib().mgx_device_count() >= 1
+
+
+@pytest.mark.parametrize("k,mask", [(11, False), (11, True), (31, False), (5, False)])
+def test_mapping(k, mask):
+    g, reads = make_world(10 + k, k, mask=mask)
+    G = gpu_graph(g)
+    cfg = capi.config_cli(k)
+    want = orc.AlignRun(g, cfg, reads).mapping()
+    got = aligner.Aligner(G, cfg).map_batch(reads)
+    assert got == want
+
+
+@pytest.mark.parametrize("k,mask,seed", [(11, False, 1), (19, False, 2), (31, False, 3), (11, True, 4), (31, True, 5)])
+def test_align_cli_config(k, mask, seed):
+    g, reads = make_world(100 + seed, k, mask=mask)
+    compare_gpu(g, gpu_graph(g), capi.config_cli(k), reads)
+
+
+def test_align_forward_only_and_no_min_exact_match():
+    g, reads = make_world(201, 13, n_reads=40)
+    cfg = capi.config_cli(13)
+    cfg.forward_and_reverse_complement = 0
+    cfg.min_exact_match = 0.0
+    compare_gpu(g, gpu_graph(g), cfg, reads)
+
+
+def test_align_many_reads_k31():
+    rng = random.Random(77)
+    g, reads = make_world(1001, 31, genome_len=50000, n_reads=3000, read_len=150, n_variants=200)
+    reads = [mutate(rng, r, sub=0.04, ins=0.01, dele=0.01) if i % 3 == 0 else r for i, r in enumerate(reads)]
+    reads += ["", "ACGT", "N" * 150, "A" * 150, reads[0][:40]]          # empty / short / invalid / low complexity
+    A = compare_gpu(g, gpu_graph(g), capi.config_cli(31), reads, check_seeds=False)
+    st = A.stats()
+    assert st["n_reads"] == len(reads) and st["n_columns"] > 0
+
+
+BIG = capi.Limits()
+BIG.max_columns = 250000
+BIG.max_seeds = 2048
+
+
+@pytest.mark.parametrize("case", [c for c in KATS["unit"] if not c["expect"].get("throws")
+                                  and c["config"].get("num_alternative_paths", 1) == 1], ids=lambda c: c["name"])
+def test_reference_kats_on_gpu(case):
+    g = orc.Graph.build(case["k"], case["graph"], 0, case["mask_dummy"])
+    G = gpu_graph(g)
+    for extend in (False, True):
+        cfg = orc.make_config(case["config"], case["matrix"])
+        if extend:
+            cfg.max_seed_length = capi.UINT64_MAX
+        compare_gpu(g, G, cfg, [case["query"]], limits=BIG)
+
+
+def test_cli_goldens_on_gpu():
+    """metagraph align goldens (integration_tests/test_align.py) byte-for-byte through mgx_format_tsv."""
+    from test_oracle_kats import read_fasta, read_fastq, HERE
+    cli = KATS["cli"]
+    seqs = read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"]))
+    g = orc.Graph.build(cli["k"], seqs, 0, False)
+    G = gpu_graph(g)
+    reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
+    for spec in cli["runs"]:
+        cfg = capi.config_cli(cli["k"])
+        for key, val in spec["flags"].items():
+            setattr(cfg, key, val)
+        A = aligner.Aligner(G, cfg)
+        blob, offs = aligner.pack_queries([r[1] for r in reads])
+        import ctypes as C
+        res = capi.Results()
+        rc = capi.lib().mgx_align_batch(A.h, blob, offs.ctypes.data, len(reads), 0, C.byref(res))
+        assert rc == 0
+        lines = [A.format_tsv(res, i, reads[i][0], reads[i][1]).rstrip("\n") for i in range(len(reads))]
+        for idx, want in spec["lines"].items():
+            assert lines[int(idx)] == want
+        for idx, fields in spec["fields"].items():
+            got = lines[int(idx)].split("\t")
+            for fi, fv in fields.items():
+                assert got[int(fi)] == fv
+
+
+def test_unsupported_and_bad_config_fail_loudly():
+    g, _ = make_world(3, 9, genome_len=300, n_reads=0)
+    G = gpu_graph(g)
+    cfg = capi.config_cli(9)
+    cfg.num_alternative_paths = 2
+    with pytest.raises(aligner.MgxError) as e:
+        aligner.Aligner(G, cfg)
+    assert e.value.code == capi.MGX_ERR_UNSUPPORTED
+    cfg = capi.config_default()
+    capi.set_dna_matrix(cfg, 2, -1, -2)
+    cfg.min_cell_score = -2**31
+    with pytest.raises(aligner.MgxError) as e:
+        aligner.Aligner(G, cfg)
+    assert e.value.code == capi.MGX_ERR_CONFIG      # the reference throws std::runtime_error (dbg_aligner.cpp:55-56)
