@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — aligned reads/s of the DBGAligner hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (k-mer mapping + seeding + extension, `mgx_align_batch_device`)
+over one batch of synthetic reads already resident in HBM.  Workload (BASELINE.json configs[1]):
+10 M x 150 bp reads against a ~100 M-node k = 31 graph per GPU; with N > 1 every rank owns a replica
+of the graph and its own read shard (weak scaling) and the per-read result records are gathered to
+rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line (rank 0).  PyTorch is plumbing only (device tensors, streams, torch.distributed).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=int(os.environ.get("MGX_BENCH_READS", 10_000_000)))
+    ap.add_argument("--genome", type=int, default=int(os.environ.get("MGX_BENCH_GENOME", 98_000_000)))
+    ap.add_argument("--snps", type=int, default=int(os.environ.get("MGX_BENCH_SNPS", 200_000)))
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MGX_BENCH_CPU_SAMPLE", 20000)))
+    ap.add_argument("--parity-sample", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist:
+        dist.barrier()
+    from metagraph_amd import aligner, capi, synth
+    lib = capi.lib()
+    assert lib.mgx_device_count() > local_rank, "libmgx.so sees no HIP device (no CPU fallback exists)"
+
+    # ---------------- workload (identical graph on every rank; reads differ per rank) ----------------
+    t0 = time.time()
+    genome = synth.random_genome(args.genome, 20240501, dev)
+    tensors = [genome[None, :]]
+    if args.snps:
+        tensors.append(synth.snp_windows(genome, args.snps, args.k, 20240502))
+    boss = synth.build_boss(tensors, args.k)
+    del tensors
+    torch.cuda.synchronize()
+    n_edges = boss["n_edges"]
+    W, last = boss["W"].contiguous(), boss["last"].contiguous()
+    G = aligner.Graph(args.k, (W.data_ptr(), n_edges + 1), (last.data_ptr(), n_edges + 1), boss["F"],
+                      device=local_rank, on_device=True)
+    t_graph = time.time() - t0
+    reads = synth.sample_reads(genome, args.reads, args.read_len, 20240503 + rank).contiguous()
+    offsets = (torch.arange(args.reads + 1, device=dev, dtype=torch.int64) * args.read_len).contiguous()
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("graph: %d edges, device index %.1f MB, built in %.1fs; reads %d x %d" %
+            (n_edges, G.device_bytes / 1e6, t_graph, args.reads, args.read_len))
+    cfg = capi.config_cli(args.k)            # `metagraph align` defaults (cli/config/config.hpp:114-145)
+    A = aligner.Aligner(G, cfg)
+
+    hdr_bytes = None
+
+    def step():
+        A.align_device(reads.data_ptr(), offsets.data_ptr(), args.reads)
+        if dist:
+            # gather the fixed-size per-read result records to rank 0 over RCCL/xGMI
+            hp, hb, nq, sp, sw = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+            rc = lib.mgx_device_results(A.h, C.byref(hp), C.byref(hb), C.byref(nq), C.byref(sp), C.byref(sw))
+            assert rc == 0
+            n_bytes = hb.value * nq.value
+
+            class _Ptr:
+                __cuda_array_interface__ = {"shape": (n_bytes,), "typestr": "|u1", "data": (hp.value, True), "version": 2}
+            hdr = torch.as_tensor(_Ptr(), device=dev)
+            gl = [torch.empty_like(hdr) for _ in range(world)] if rank == 0 else None
+            dist.gather(hdr, gl, dst=0)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t1 = time.time()
+    align_ms, map_ms = [], []
+    for _ in range(args.steps):
+        step()
+        st = A.stats()
+        align_ms.append(st["align_kernel_ms"])
+        map_ms.append(st["seed_kernel_ms"])
+    sync()
+    elapsed = time.time() - t1
+    if dist:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    st = A.stats()
+    ms_per_step = 1000.0 * elapsed / max(1, args.steps)
+    total_reads = args.reads * world
+    value = total_reads / (elapsed / max(1, args.steps))
+
+    if rank != 0:
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---------------- roofline of the dominant kernel (HIP events inside libmgx, per launch) ----------
+    k_align = float(np.mean(align_ms))
+    k_map = float(np.mean(map_ms))
+    lines_total = st["n_rank_lines"] + st["n_select_lines"] + st["n_bit_lines"]
+    lines_map = st["n_map_lines"]
+    lines_align = lines_total - lines_map
+    n_kmers = max(0, args.read_len - args.k + 1)
+    # algorithmic bytes: B_read = L + R_out + 64 B x N_lines; the align kernel also reads the
+    # two node arrays written by the map kernel
+    bytes_align = 64.0 * lines_align + args.reads * (args.read_len + 96 + 2 * 4 * n_kmers)
+    bytes_map = 64.0 * lines_map + args.reads * (2 * args.read_len + 2 * 4 * n_kmers)
+    dom = "k_align" if k_align >= k_map else "k_map"
+    dom_ms, dom_bytes = (k_align, bytes_align) if dom == "k_align" else (k_map, bytes_map)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "kernel_ms": {"k_align": round(k_align, 3), "k_map": round(k_map, 3)},
+                "lines_per_read": {"k_align": round(lines_align / args.reads, 1), "k_map": round(lines_map / args.reads, 1)},
+                "columns_per_read": round(st["n_columns"] / args.reads, 2)}
+
+    # ---------------- parity spot check + CPU baseline (oracle = checker, never the thing measured) -----
+    import orc
+    W_h, last_h = W.cpu().numpy(), last.cpu().numpy()
+    view = capi.BossView()
+    view.k, view.sigma, view.n_edges, view.mode, view.on_device = args.k, 5, n_edges, 0, 0
+    view.W, view.last = W_h.ctypes.data, last_h.ctypes.data
+    Fc = (C.c_uint64 * 5)(*[int(x) for x in boss["F"]])
+    view.F = C.cast(Fc, C.POINTER(C.c_uint64))
+    og = orc.Graph(orc.L().orc_graph_from_boss(C.byref(view)))
+    ns = min(args.parity_sample, args.reads)
+    sample = [bytes(r) for r in reads[:ns].cpu().numpy()]
+    got, status = A.align_batch(sample)
+    orun = orc.AlignRun(og, cfg, sample, threads=os.cpu_count() or 1, validate=False)
+    want = orun.results()
+    mism = sum(1 for a, b in zip(got, want) if a != b)
+    parity = {"sample": ns, "mismatches": mism, "capacity_errors": int(st["n_capacity_errors"])}
+    cpu = None
+    if not args.no_cpu_baseline:
+        nc = min(args.cpu_sample, args.reads)
+        csample = [bytes(r) for r in reads[:nc].cpu().numpy()]
+        threads = os.cpu_count() or 1
+        tc = time.time()
+        orc.AlignRun(og, cfg, csample, threads=threads, validate=False)
+        dt = time.time() - tc
+        cpu = {"value": round(nc / dt, 1), "unit": "reads/s", "cores": threads, "kind": "port",
+               "sample": "first %d reads of the same workload, same graph, %d threads, %.1fs" % (nc, threads, dt)}
+
+    out = {"metric": "aligned reads/sec (150 bp, k=31)", "value": round(value, 1), "unit": "reads/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "%d synthetic %d bp reads per GPU vs %d-edge k=%d BOSS graph (%.0f Mbp iid genome + %d SNP windows), CLI-default scoring" %
+                      (args.reads, args.read_len, n_edges, args.k, args.genome / 1e6, args.snps),
+                      "reads_per_gpu": args.reads, "graph_edges": n_edges, "k": args.k, "parallelism": "reads sharded x%d, graph replicated" % world},
+           "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
+    print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,8 @@ typedef struct mgx_stats {
     uint64_t n_columns;         /* DP columns computed                                  */
     uint64_t n_extensions;      /* DefaultColumnExtender::extend calls                  */
     uint64_t n_seeds;
+    uint64_t n_map_lines;       /* part of n_rank_lines + n_select_lines issued by the k-mer mapping kernel */
+    uint64_t n_capacity_errors; /* reads whose status is MGX_ERR_CAPACITY */
     double seed_kernel_ms, align_kernel_ms;   /* HIP-event time of the two kernels, last batch */
 } mgx_stats;
 
@@ -192,6 +194,21 @@ int mgx_aligner_get_config(const mgx_aligner *a, mgx_config *out);
  * With seqs_on_device != 0, `seqs` and `offsets` are device pointers (reads already in HBM). */
 int mgx_align_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uint64_t n_queries,
                     int seqs_on_device, mgx_results *out);
+
+/* The two halves of mgx_align_batch: run the kernels and leave the results in HBM / copy them out.
+ * mgx_align_batch(a, ...) == mgx_align_batch_device(a, ...) followed by mgx_fetch_results(a, out). */
+int mgx_align_batch_device(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uint64_t n_queries,
+                           int seqs_on_device);
+int mgx_fetch_results(mgx_aligner *a, mgx_results *out);
+/* Device-resident results of the last batch, for gathering over RCCL without a host round trip:
+ * `headers` = n_queries fixed-size records of `header_bytes` bytes each (status, n_alignments, score,
+ * offset, n_nodes, n_cigar, seq_len, orientation, stream offset, ...), `stream` = `stream_words`
+ * 32-bit words holding nodes / packed CIGAR runs (len << 3 | op) / path characters. */
+int mgx_device_results(mgx_aligner *a, const void **headers, uint64_t *header_bytes, uint64_t *n_queries,
+                       const void **stream, uint64_t *stream_words);
+/* Test hooks: keep and fetch the per-read seed lists (DBGAligner::build_seeders products). */
+void mgx_aligner_keep_seeds(mgx_aligner *a, int keep);
+int mgx_fetch_seed_info(mgx_aligner *a, uint32_t *info6, uint32_t *seeds, uint32_t *max_seeds_out);
 
 /* Hot loop #1 only: map both strands to nodes (dbg_aligner.cpp:210,227-231). */
 int mgx_map_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uint64_t n_queries,

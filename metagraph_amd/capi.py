@@ -64,7 +64,8 @@ class Mapping(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_rank_lines", C.c_uint64), ("n_select_lines", C.c_uint64),
                 ("n_bit_lines", C.c_uint64), ("n_columns", C.c_uint64), ("n_extensions", C.c_uint64),
-                ("n_seeds", C.c_uint64), ("seed_kernel_ms", C.c_double), ("align_kernel_ms", C.c_double)]
+                ("n_seeds", C.c_uint64), ("n_map_lines", C.c_uint64), ("n_capacity_errors", C.c_uint64),
+                ("seed_kernel_ms", C.c_double), ("align_kernel_ms", C.c_double)]
 
 
 def results_to_py(res):
@@ -117,6 +118,8 @@ def lib():
     L.mgx_align_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.mgx_fetch_results.argtypes = [C.c_void_p, C.POINTER(Results)]
     L.mgx_aligner_keep_seeds.argtypes = [C.c_void_p, C.c_int]
+    L.mgx_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.mgx_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Mapping)]
     L.mgx_aligner_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.mgx_config_init_default.argtypes = [C.POINTER(Config)]

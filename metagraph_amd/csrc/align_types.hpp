@@ -52,7 +52,7 @@ struct DevSeed {             // Seed (alignment.hpp:32-98); full seeds reference
 };
 
 struct KernelStats {
-    unsigned long long rank_lines, select_lines, bit_lines, columns, extensions, seeds, capacity_errors;
+    unsigned long long rank_lines, select_lines, bit_lines, columns, extensions, seeds, capacity_errors, map_lines;
 };
 
 struct AlignParams {

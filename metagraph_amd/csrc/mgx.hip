@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(256) k_map(DevGraph g, const char *seqs, const
     if ((threadIdx.x & 63) == 0 && (r | s)) {
         atomicAdd(&stats->rank_lines, (unsigned long long)r);
         atomicAdd(&stats->select_lines, (unsigned long long)s);
+        atomicAdd(&stats->map_lines, (unsigned long long)r + s);
     }
 }
 
@@ -541,6 +542,7 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     s.n_reads = A->n_reads;
     s.n_rank_lines = ks.rank_lines; s.n_select_lines = ks.select_lines; s.n_bit_lines = ks.bit_lines;
     s.n_columns = ks.columns; s.n_extensions = ks.extensions; s.n_seeds = ks.seeds;
+    s.n_map_lines = ks.map_lines; s.n_capacity_errors = ks.capacity_errors;
     float ms = 0;
     if (mapped) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[0], A->ev[1])); s.seed_kernel_ms = ms; }
     if (aligned) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[2], A->ev[3])); s.align_kernel_ms = ms; }
@@ -598,6 +600,16 @@ int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
     if (used) HIP_TRY(hipMemcpy(A->h_stream.data(), A->stream.p, used * 4, hipMemcpyDeviceToHost));
     A->host.decode(A->h_results.data(), n, A->h_stream.data());
     A->host.view(out);
+    return MGX_OK;
+}
+
+int mgx_device_results(mgx_aligner *A, const void **headers, uint64_t *header_bytes, uint64_t *n_queries,
+                       const void **stream, uint64_t *stream_words) {
+    if (!A) return fail(MGX_ERR_INVALID, "null argument");
+    unsigned long long used = 0;
+    if (A->n_reads) HIP_TRY(hipMemcpy(&used, A->cursors.p, 8, hipMemcpyDeviceToHost));
+    *headers = A->results.p; *header_bytes = sizeof(ReadResult); *n_queries = A->n_reads;
+    *stream = A->stream.p; *stream_words = used;
     return MGX_OK;
 }
 
