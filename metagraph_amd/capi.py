@@ -87,7 +87,7 @@ def results_to_py(res):
 
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_ROOT, "metagraph_amd", "_build", "libmgx.so")
+LIB_PATH = os.environ.get("MGX_LIB_PATH") or os.path.join(_ROOT, "metagraph_amd", "_build", "libmgx.so")   # override: A/B builds
 _lib = None
 
 

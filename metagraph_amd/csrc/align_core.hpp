@@ -16,6 +16,36 @@
 #pragma once
 #include "align_types.hpp"
 
+// per-group inlining control (register pressure vs. call overhead)
+#ifndef MGX_NI_MASK
+#define MGX_NI_MASK 15   // depth-3 call chains fault on gfx950 (ROCm 7.2); keep at most two noinline levels
+#endif
+#if MGX_NI_MASK & 1
+#define MGX_NI_G1 MGX_DEV_NOINLINE
+#else
+#define MGX_NI_G1 MGX_DEV
+#endif
+#if MGX_NI_MASK & 2
+#define MGX_NI_G2 MGX_DEV_NOINLINE
+#else
+#define MGX_NI_G2 MGX_DEV
+#endif
+#if MGX_NI_MASK & 4
+#define MGX_NI_G3 MGX_DEV_NOINLINE
+#else
+#define MGX_NI_G3 MGX_DEV
+#endif
+#if MGX_NI_MASK & 16
+#define MGX_NI_G5 MGX_DEV_NOINLINE
+#else
+#define MGX_NI_G5 MGX_DEV
+#endif
+#if MGX_NI_MASK & 8
+#define MGX_NI_G4 MGX_DEV_NOINLINE
+#else
+#define MGX_NI_G4 MGX_DEV
+#endif
+
 namespace mgx {
 
 // ------------------------------------------------------------------------------------------------
@@ -84,6 +114,12 @@ struct ConvChecker {             // SeedFilteringExtender::conv_checker_ (extend
     uint32_t gen;
 };
 
+struct SdustScratch {            // working set of is_low_complexity(); lives in LDS on the device
+    int16_t cv[64], cw[64], c2[64];
+    int16_t Ps[64], Pf[64], Pr[64], Pl[64];   // perfect intervals (at most one per window position)
+    uint8_t wq[64];                           // window deque (ring)
+};
+
 struct DevAln {                  // Alignment (alignment.hpp:132-331)
     uint32_t *nodes;
     uint32_t *cigar;             // len << 3 | op
@@ -119,6 +155,8 @@ struct ExtenderState {           // one per strand (Extender object in dbg_align
     int32_t rc_view;             // 1 while this extender runs on the RCDBG view
 };
 
+struct ExtendResult { int32_t n_tips; int32_t min_cell_score; int32_t table_size; };
+
 struct Wave {
     const AlignParams *P;
     int32_t L;                   // query length
@@ -142,13 +180,15 @@ struct Wave {
     BtIndex *indices;
     uint32_t *rev_ops, *rev_nodes;
     uint8_t *rev_seq;
-    int32_t *sd;                 // sdust scratch
+    SdustScratch *sd;            // sdust scratch (LDS)
+    uint32_t *gen_store;         // conv-checker generation counters, persistent per arena slice
     ExtenderState ext[2];
     DevAln aln[4];               // 0: extension result, 1: reversed seed for the backward pass,
                                  // 2: backward extension result, 3: best (aggregator)
     int32_t have_best;
-    LineCtr ctr;                 // wave-uniform code
-    LV<LineCtr> lctr;            // lane-parallel regions
+    LineCtr ctr;                 // BOSS block loads (lane-parallel regions add their wave sums)
+    ExtendResult er;             // result of the last extend(); noinline callees must not write through
+    int32_t tmp_pushes;          // pointers into the caller's private frame, so outputs live here
     uint32_t n_columns, n_extensions;
     int32_t status;
 };
@@ -175,29 +215,40 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += align8(((uint64_t)lim.max_columns + 31) / 32 * 4);   // prev_starts
     b += align8((uint64_t)lim.max_columns * 2 * sizeof(BtIndex));
     b += 2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path);   // rev_*
-    b += align8(2048 * 4);                              // sdust
+    b += 16;                                            // gen_store
     b += 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8(ent * sizeof(ConvEntry)) + align8(ent * L * 4));
     b += 4 * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
     return align8(b);
 }
 
-MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base) {
+// Carve the wave's workspace.  Small, latency-critical scalar arrays go to LDS (`lds`, `lds_bytes`)
+// when they fit; everything else lives in the wave's HBM arena slice.
+MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, uint32_t lds_bytes) {
     const DevLimits &lim = P.lim;
     uint64_t L = lim.Lmax, Lp = align8(L + 8);
     uint64_t ent = (uint64_t)lim.max_columns + lim.max_path;
     uint8_t *p = base;
+    uint8_t *lp = lds;
+    uint32_t lleft = lds_bytes;
     auto take = [&](uint64_t bytes) { uint8_t *r = p; p += align8(bytes); return r; };
-    for (int s = 0; s < 2; ++s) w.q[s] = take(Lp);
-    for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take((L + 1) * 4);
+    auto take_fast = [&](uint64_t bytes) {
+        uint64_t b8 = align8(bytes);
+        uint8_t *r = p;
+        p += b8;                                   // the arena slot is reserved either way (layout is static)
+        if (b8 <= lleft) { r = lp; lp += b8; lleft -= (uint32_t)b8; }
+        return r;
+    };
+    for (int s = 0; s < 2; ++s) w.q[s] = take_fast(Lp);
+    w.msl = (uint16_t *)take_fast((L + 1) * 2);
+    w.pos_cnt = (uint16_t *)take_fast((L + 1) * 2);
+    w.ml = (uint16_t *)take_fast((L + 1) * 2);
+    w.pos_full = take_fast(L + 1);
+    w.pos_start = (uint32_t *)take_fast((L + 1) * 4);
+    w.rfirst = (uint32_t *)take_fast((L + 1) * 4);
+    w.rlast = (uint32_t *)take_fast((L + 1) * 4);
+    for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take_fast((L + 1) * 4);
     for (int s = 0; s < 2; ++s) w.seeds[s] = (DevSeed *)take((uint64_t)lim.max_seeds * sizeof(DevSeed));
     for (int s = 0; s < 2; ++s) w.alive[s] = take(lim.max_seeds);
-    w.msl = (uint16_t *)take((L + 1) * 2);
-    w.pos_cnt = (uint16_t *)take((L + 1) * 2);
-    w.ml = (uint16_t *)take((L + 1) * 2);
-    w.pos_full = take(L + 1);
-    w.pos_start = (uint32_t *)take((L + 1) * 4);
-    w.rfirst = (uint32_t *)take((L + 1) * 4);
-    w.rlast = (uint32_t *)take((L + 1) * 4);
     w.alt = (uint32_t *)take((uint64_t)lim.max_alt * 4);
     w.cells = (int32_t *)take((uint64_t)lim.cell_words * 4);
     w.cols = (ColMeta *)take((uint64_t)lim.max_columns * sizeof(ColMeta));
@@ -209,7 +260,7 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base) {
     w.rev_ops = (uint32_t *)take((uint64_t)lim.max_path * 4);
     w.rev_nodes = (uint32_t *)take((uint64_t)lim.max_path * 4);
     w.rev_seq = take(lim.max_path);
-    w.sd = (int32_t *)take(2048 * 4);
+    w.gen_store = (uint32_t *)take(16);
     for (int s = 0; s < 2; ++s) {
         w.ext[s].conv.slots = (ConvSlot *)take((uint64_t)lim.hash_size * sizeof(ConvSlot));
         w.ext[s].conv.entries = (ConvEntry *)take(ent * sizeof(ConvEntry));
@@ -220,6 +271,12 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base) {
         w.aln[a].cigar = (uint32_t *)take((uint64_t)lim.max_path * 4);
         w.aln[a].seq = take(lim.max_path);
     }
+}
+
+// LDS bytes that hold every "fast" array of carve() for a given Lmax
+MGX_HD uint32_t fast_lds_bytes(uint32_t Lmax) {
+    uint64_t L = Lmax, Lp = align8(L + 8);
+    return (uint32_t)(2 * Lp + 3 * align8((L + 1) * 2) + align8(L + 1) + 3 * align8((L + 1) * 4) + 2 * align8((L + 1) * 4));
 }
 
 MGX_DEV int32_t score_of(const AlignParams &P, uint8_t graph_char, uint8_t query_char) {
@@ -247,11 +304,11 @@ MGX_DEV uint8_t profile_op_at(const uint8_t *q, int32_t L, uint8_t c, int32_t ab
 // A/aligner_seeder_methods.cpp:22-29 with T = 20, W = 64).  Wave-uniform scalar code; `sd` is a
 // 2048-word scratch area.  Returns whether any interval is masked.
 // ------------------------------------------------------------------------------------------------
-MGX_DEV bool is_low_complexity(const uint8_t *s, int32_t l_seq, int32_t *sd) {
+MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *sd) {
     constexpr int T = 20, W = 64, WLEN = 3, WTOT = 64, WMSK = 63;
-    int32_t *cv = sd, *cw = sd + 64, *c2 = sd + 128;
-    int32_t *wq = sd + 192;                   // window deque, ring of 64
-    int32_t *Ps = sd + 256, *Pf = sd + 512, *Pr = sd + 768, *Pl = sd + 1024;   // perfect intervals (<= 256)
+    int16_t *cv = sd->cv, *cw = sd->cw, *c2 = sd->c2;
+    uint8_t *wq = sd->wq;                     // window deque, ring of 64
+    int16_t *Ps = sd->Ps, *Pf = sd->Pf, *Pr = sd->Pr, *Pl = sd->Pl;
     for (int i = 0; i < WTOT; ++i) { cv[i] = 0; cw[i] = 0; }
     int wfront = 0, wcount = 0;
     int Pn = 0;
@@ -293,7 +350,7 @@ MGX_DEV bool is_low_complexity(const uint8_t *s, int32_t l_seq, int32_t *sd) {
                     rw -= --cw[sv];
                     if (Lw > wcount) { --Lw; rv -= --cv[sv]; }
                 }
-                wq[(wfront + wcount) & 63] = (int32_t)t;
+                wq[(wfront + wcount) & 63] = (uint8_t)t;
                 ++wcount;
                 ++Lw;
                 rw += cw[t]++;
@@ -321,10 +378,11 @@ MGX_DEV bool is_low_complexity(const uint8_t *s, int32_t l_seq, int32_t *sd) {
                             }
                             if (max_r == 0 || new_r * max_l >= max_r * new_l) {
                                 max_r = new_r; max_l = new_l;
-                                if (Pn < 255) {
+                                if (Pn < 63) {
                                     for (int m = Pn; m > j; --m) { Ps[m] = Ps[m - 1]; Pf[m] = Pf[m - 1]; Pr[m] = Pr[m - 1]; Pl[m] = Pl[m - 1]; }
                                     ++Pn;
-                                    Ps[j] = ii + start; Pf[j] = wcount + (WLEN - 1) + start; Pr[j] = new_r; Pl[j] = new_l;
+                                    Ps[j] = (int16_t)(ii + start); Pf[j] = (int16_t)(wcount + (WLEN - 1) + start);
+                                    Pr[j] = (int16_t)new_r; Pl[j] = (int16_t)new_l;
                                 }
                             }
                         }
@@ -343,7 +401,7 @@ MGX_DEV bool is_low_complexity(const uint8_t *s, int32_t l_seq, int32_t *sd) {
 // ------------------------------------------------------------------------------------------------
 // query preparation: AlignmentResults ctor (A/alignment.cpp:1348-1372) + partial sums
 // ------------------------------------------------------------------------------------------------
-MGX_DEV void prepare_query(Wave &w, const char *raw) {
+MGX_NI_G1 void prepare_query(Wave &w, const char *raw) {
     const AlignParams &P = *w.P;
     const int32_t L = w.L;
     for (int32_t base = 0; base < L; base += WAVE) {
@@ -414,7 +472,7 @@ MGX_DEV bool push_seed(Wave &w, int s, int32_t clip, int32_t len, int32_t offset
 }
 
 // MEMSeeder::get_seeds / ExactSeeder::get_seeds into w.seeds[s] (A/aligner_seeder_methods.cpp:67-93,360-424)
-MGX_DEV void base_seeds(Wave &w, int s) {
+MGX_NI_G2 void base_seeds(Wave &w, int s) {
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const int32_t k = (int32_t)P.g.k, L = w.L, n = w.n_kmers;
@@ -483,7 +541,7 @@ MGX_DEV int32_t index_range_lane(const DevGraph &g, const uint8_t *q, int32_t le
 }
 
 // SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358, non-canonical)
-MGX_DEV void make_seeder(Wave &w, int s) {
+MGX_NI_G2 void make_seeder(Wave &w, int s) {
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const DevGraph &g = P.g;
@@ -518,7 +576,9 @@ MGX_DEV void make_seeder(Wave &w, int s) {
     wave_sync();
     // lane-parallel longest-prefix lookups for every position that can report a seed
     for (int32_t base = 0; base < nslots; base += WAVE) {
+        LV<int32_t> nr, ns;
         FOR_LANES(l) {
+            LineCtr lc = { 0, 0, 0 };
             int32_t i = base + l;
             if (i < nslots) {
                 int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
@@ -526,16 +586,19 @@ MGX_DEV void make_seeder(Wave &w, int s) {
                 uint32_t rf = 0, rl_ = 0;
                 if (max_len >= (int32_t)w.msl[i]) {
                     uint64_t first, last;
-                    int32_t m = index_range_lane(g, w.q[s] + i, max_len, &first, &last, w.lctr[l]);
+                    int32_t m = index_range_lane(g, w.q[s] + i, max_len, &first, &last, lc);
                     if (m >= msl0 && first && first <= g.n) {
                         mlen = (uint16_t)m;
-                        rf = rank_last(g, first, w.lctr[l]);
-                        rl_ = rank_last(g, last, w.lctr[l]);
+                        rf = rank_last(g, first, lc);
+                        rl_ = rank_last(g, last, lc);
                     }
                 }
                 w.ml[i] = mlen; w.rfirst[i] = rf; w.rlast[i] = rl_;
             }
+            nr[l] = (int32_t)lc.rank_lines; ns[l] = (int32_t)lc.select_lines;
         }
+        w.ctr.rank_lines += (uint32_t)wave_sum(nr);
+        w.ctr.select_lines += (uint32_t)wave_sum(ns);
     }
     wave_sync();
     // sequential bookkeeping (:195-249)
@@ -545,9 +608,11 @@ MGX_DEV void make_seeder(Wave &w, int s) {
         int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
         int32_t cur_msl = w.msl[i];
         if (max_len < cur_msl) continue;                       // lookup returns immediately (dbg_succinct.cpp:314)
-        if (cfg.seed_complexity_filter && is_low_complexity(w.q[s] + i, cur_msl, w.sd)) continue;
         int32_t seed_length = w.ml[i];
-        if (seed_length < cur_msl) continue;                   // match_size < min_match_length
+        if (seed_length < cur_msl) continue;                   // match_size < min_match_length: no callback
+        // the complexity filter is evaluated first in the reference (:226-229); it has no side effects, so
+        // testing it only for positions that would report a seed is equivalent
+        if (cfg.seed_complexity_filter && is_low_complexity(w.q[s] + i, cur_msl, w.sd)) continue;
         // enumerate nodes whose suffix matches (dbg_succinct.cpp:349-392)
         uint32_t first_alt = alt_n;
         uint32_t cnt = 0;
@@ -659,7 +724,7 @@ MGX_DEV void fill_range(int32_t *vec, int32_t a, int32_t b, int32_t val) {
 
 // update_seed_filter (:100-156).  s = cells of the column (S at stride 3), size cells starting at
 // query position query_start.  Returns converged score (NINF = nothing improved).
-MGX_DEV int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start,
+MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start,
                                    const int32_t *s_cells, int32_t size) {
     const AlignParams &P = *w.P;
     auto column_max = [&]() {
@@ -751,7 +816,7 @@ MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int
 }
 
 // filter_nodes (:158-207); the key is the raw node id (no RCDBG offset), as in the reference
-MGX_DEV void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start, int32_t query_end) {
+MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start, int32_t query_end) {
     const AlignParams &P = *w.P;
     const int32_t mscore = -NINF;
     int32_t size = query_end - query_start;
@@ -843,9 +908,9 @@ MGX_DEV int32_t queue_argmax(const uint64_t *queue, int32_t n, bool restrict_sco
 
 // Compute one DP column into freshly reserved cells (update_column :209-290 + extend_ins_end :293-328).
 // Returns the final size (cells) and the number of pushes in *pushes.
-MGX_DEV int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta &prev, int32_t prev_end, int32_t begin,
+MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta &prev, int32_t prev_end, int32_t begin,
                                int32_t size, uint32_t cells_off, uint8_t c, int32_t init_score, int32_t offset,
-                               int32_t start, int32_t window_size, int32_t xdrop_cutoff, int32_t *pushes) {
+                               int32_t start, int32_t window_size, int32_t xdrop_cutoff) {
     const AlignParams &P = *w.P;
     const int32_t go = P.cfg.gap_open, ge = P.cfg.gap_ext;
     const int32_t L = w.L;
@@ -914,7 +979,7 @@ MGX_DEV int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta &p
     }
     wave_sync();
     // extend_ins_end
-    *pushes = 0;
+    w.tmp_pushes = 0;
     if (size < max_size) {
         int32_t ins_score = imax(cells[3 * (size - 1)] + go, cells[3 * (size - 1) + 1] + ge);
         if (ins_score >= xdrop_cutoff) {
@@ -945,15 +1010,13 @@ MGX_DEV int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta &p
                     cells[3 * j] = NINF; cells[3 * j + 1] = NINF; cells[3 * j + 2] = NINF;
                 }
             }
-            *pushes = n_push;
+            w.tmp_pushes = n_push;
             size += n_push;
         }
     }
     wave_sync();
     return size;
 }
-
-struct ExtendResult { int32_t n_tips; int32_t min_cell_score; int32_t table_size; };
 
 // children of table[i] (DefaultColumnExtender::call_outgoing :330-387, non-canonical graphs)
 MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
@@ -993,7 +1056,8 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
     return m;
 }
 
-MGX_DEV void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed, ExtendResult *res) {
+MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
+    ExtendResult *res = &w.er;
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const DevLimits &lim = P.lim;
@@ -1125,9 +1189,9 @@ MGX_DEV void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_f
                 uint32_t table_cap_before = E.table_cap;
                 if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
                 ++w.n_columns;
-                int32_t pushes = 0;
                 int32_t size = compute_column(w, E, col, prev_end, begin, size0, cell_top, c, score, next_offset,
-                                              start, window_size, xdrop_cutoff, &pushes);
+                                              start, window_size, xdrop_cutoff);
+                const int32_t pushes = w.tmp_pushes;
                 ColMeta cur;
                 cur.node = next; cur.parent = i; cur.c = c; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
                 cur.score = score; cur.cells = cell_top; cur.size = size;
@@ -1220,10 +1284,10 @@ MGX_DEV void cigar_append(uint32_t *ops, int32_t *n, uint32_t op, uint32_t num, 
 
 MGX_DEV void seed_as_alignment(Wave &w, const SeedRef &seed, DevAln &out);
 
-MGX_DEV void copy_aln(DevAln &dst, const DevAln &src);
+MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src);
 
 // seed_aln: the Alignment the seed was made from (backward pass) or nullptr for Seed-derived seeds
-MGX_DEV bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, const DevAln *seed_aln,
+MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, const DevAln *seed_aln,
                        const ExtendResult &er, int32_t min_path_score, DevAln &out) {
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
@@ -1455,7 +1519,7 @@ MGX_DEV void seed_as_alignment(Wave &w, const SeedRef &seed, DevAln &out) {
     wave_sync();
 }
 
-MGX_DEV void copy_aln(DevAln &dst, const DevAln &src) {
+MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src) {
     int32_t n = imax(imax(src.n_nodes, src.n_cigar), src.seq_len);
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
@@ -1472,7 +1536,7 @@ MGX_DEV void copy_aln(DevAln &dst, const DevAln &src) {
 }
 
 // Alignment::reverse_complement for RCDBG views (alignment.cpp:547-561); false = alignment became empty
-MGX_DEV bool reverse_complement_aln(Wave &w, DevAln &a) {
+MGX_NI_G4 bool reverse_complement_aln(Wave &w, DevAln &a) {
     if (a.offset) { a.n_nodes = 0; return false; }        // trim_offset() left a non-zero offset
     int32_t n = imax(imax(a.n_nodes, a.n_cigar), a.seq_len);
     for (int32_t base = 0; base < (n + 1) / 2; base += WAVE) {
@@ -1531,7 +1595,7 @@ MGX_DEV bool aln_less(const DevAln &a, const DevAln &b) {
     return ca > cb;
 }
 
-MGX_DEV void add_alignment(Wave &w, const DevAln &a) {       // :68-138
+MGX_NI_G4 void add_alignment(Wave &w, const DevAln &a) {       // :68-138
     if (!w.have_best) { copy_aln(w.aln[3], a); w.have_best = 1; return; }
     if (a.score < global_cutoff(w)) return;
     if (aln_equal(w, a, w.aln[3])) return;
@@ -1564,7 +1628,7 @@ MGX_DEV int32_t min_path_score_now(const Wave &w) {          // get_min_path_sco
 }
 
 // aln_both (:657-736): seeds of strand s; fwd extender = ext[s] on the graph, bwd extender = ext[1 - s] on RCDBG
-MGX_DEV void aln_both(Wave &w, int s) {
+MGX_NI_G4 void aln_both(Wave &w, int s) {
     const AlignParams &P = *w.P;
     ExtenderState &F = w.ext[s];
     ExtenderState &B = w.ext[1 - s];
@@ -1575,8 +1639,8 @@ MGX_DEV void aln_both(Wave &w, int s) {
         if (!w.alive[s][i]) continue;
         SeedRef seed = seedref_from_seed(w, s, i, nullptr);
         conv_clear(F.conv);                                   // set_seed (:90-98)
-        ExtendResult er;
-        extend(w, F, seed, false, &er);
+        extend(w, F, seed, false);
+        const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
         int32_t mps = imax(0, P.cfg.min_cell_score);          // extend(): min_path_score = max(0, min_cell_score)
         bool have = backtrack(w, F, seed, nullptr, er, mps, w.aln[0]);
@@ -1591,8 +1655,8 @@ MGX_DEV void aln_both(Wave &w, int s) {
                     SeedRef rseed = seedref_from_aln(w.aln[1]);
                     int32_t mps2 = imax(0, min_path_score_now(w));
                     conv_clear(B.conv);
-                    ExtendResult er2;
-                    extend(w, B, rseed, true, &er2);
+                    extend(w, B, rseed, true);
+                    const ExtendResult er2 = w.er;
                     if (w.status != ST_OK) return;
                     bool have2 = backtrack(w, B, rseed, &w.aln[1], er2, mps2, w.aln[2]);
                     if (w.status != ST_OK) return;
@@ -1621,7 +1685,7 @@ MGX_DEV void aln_both(Wave &w, int s) {
 }
 
 // align_core (:360-384) with the seeds of strand 0, forward only
-MGX_DEV void align_core_fwd(Wave &w) {
+MGX_NI_G4 void align_core_fwd(Wave &w) {
     const AlignParams &P = *w.P;
     ExtenderState &F = w.ext[0];
     F.rc_view = 0;
@@ -1631,8 +1695,8 @@ MGX_DEV void align_core_fwd(Wave &w) {
         SeedRef seed = seedref_from_seed(w, 0, i, nullptr);
         int32_t mps = imax(0, min_path_score_now(w));
         conv_clear(F.conv);
-        ExtendResult er;
-        extend(w, F, seed, false, &er);
+        extend(w, F, seed, false);
+        const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
         if (backtrack(w, F, seed, nullptr, er, mps, w.aln[0])) add_alignment(w, w.aln[0]);
         if (w.status != ST_OK) return;
@@ -1649,16 +1713,16 @@ MGX_DEV void align_core_fwd(Wave &w) {
 }
 
 // the whole per-read program; `slot` selects the arena slice
-MGX_DEV void align_read(const AlignParams &P, uint64_t read, uint32_t slot, KernelStats *stats_accum) {
-    Wave w;
+MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t slot, KernelStats *stats_accum,
+                        SdustScratch *sd, uint8_t *lds, uint32_t lds_bytes) {
     w.P = &P;
-    carve(w, P, P.arena + (uint64_t)slot * P.arena_stride);
+    carve(w, P, P.arena + (uint64_t)slot * P.arena_stride, lds, lds_bytes);
+    w.sd = sd;
     const uint64_t off = P.offsets[read];
     w.L = (int32_t)(P.offsets[read + 1] - off);
     w.status = ST_OK;
     w.have_best = 0;
     w.ctr.rank_lines = w.ctr.select_lines = w.ctr.bit_lines = 0;
-    FOR_LANES(l) { w.lctr[l].rank_lines = 0; w.lctr[l].select_lines = 0; w.lctr[l].bit_lines = 0; }
     w.n_columns = w.n_extensions = 0;
     const int32_t k = (int32_t)P.g.k;
     const uint64_t nb = P.node_begin[read];
@@ -1682,9 +1746,8 @@ MGX_DEV void align_read(const AlignParams &P, uint64_t read, uint32_t slot, Kern
             w.ext[s].conv.n_entries = 0;
         }
         // generation tags make clearing the hash tables O(1); the counters persist in the arena
-        // slice (last words of the sdust scratch area) across the reads a wave slot processes
-        uint32_t *gen_store = (uint32_t *)(w.sd + 2040);
-        for (int s = 0; s < 2; ++s) w.ext[s].conv.gen = gen_store[s];
+        // slice across the reads a wave slot processes
+        for (int s = 0; s < 2; ++s) w.ext[s].conv.gen = w.gen_store[s];
         const bool have_rc = P.cfg.fwd_and_rc != 0;
         // build_seeders (:193-248)
         make_seeder(w, 0);
@@ -1718,7 +1781,7 @@ MGX_DEV void align_read(const AlignParams &P, uint64_t read, uint32_t slot, Kern
                 align_core_fwd(w);
             }
         }
-        for (int s = 0; s < 2; ++s) gen_store[s] = w.ext[s].conv.gen;
+        for (int s = 0; s < 2; ++s) w.gen_store[s] = w.ext[s].conv.gen;
         wave_sync();
     }
 
@@ -1759,13 +1822,9 @@ MGX_DEV void align_read(const AlignParams &P, uint64_t read, uint32_t slot, Kern
         }
     }
     FOR_LANES(l) { if (l == 0) P.results[read] = rr; }
-    {
-        LV<int32_t> a, b, c;
-        FOR_LANES(l) { a[l] = (int32_t)w.lctr[l].rank_lines; b[l] = (int32_t)w.lctr[l].select_lines; c[l] = (int32_t)w.lctr[l].bit_lines; }
-        stats_accum->rank_lines += w.ctr.rank_lines + (uint32_t)wave_sum(a);
-        stats_accum->select_lines += w.ctr.select_lines + (uint32_t)wave_sum(b);
-        stats_accum->bit_lines += w.ctr.bit_lines + (uint32_t)wave_sum(c);
-    }
+    stats_accum->rank_lines += w.ctr.rank_lines;
+    stats_accum->select_lines += w.ctr.select_lines;
+    stats_accum->bit_lines += w.ctr.bit_lines;
     stats_accum->columns += w.n_columns;
     stats_accum->extensions += w.n_extensions;
     stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);

@@ -108,8 +108,21 @@ __global__ void __launch_bounds__(256) k_map(DevGraph g, const char *seqs, const
 }
 
 // one wave per read, persistent over the batch; each wave owns one arena slice
-__global__ void __launch_bounds__(64) k_align(AlignParams P) {
+#ifndef MGX_ALIGN_WAVES_PER_SIMD
+#define MGX_ALIGN_WAVES_PER_SIMD 4
+#endif
+__global__ void __launch_bounds__(64, MGX_ALIGN_WAVES_PER_SIMD) k_align(AlignParams P, uint32_t lds_bytes) {
     const uint32_t slot = blockIdx.x;
+#ifndef MGX_WAVE_IN_LDS
+#define MGX_WAVE_IN_LDS 1
+#endif
+#if MGX_WAVE_IN_LDS
+    __shared__ Wave w;                // the wave's scalar state lives in LDS, not in registers
+#else
+    Wave w;
+#endif
+    __shared__ SdustScratch sd;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     KernelStats acc;
     memset(&acc, 0, sizeof(acc));
     for (;;) {
@@ -118,7 +131,7 @@ __global__ void __launch_bounds__(64) k_align(AlignParams P) {
         if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
         uint64_t read = wave_bcast(rv, 0);
         if (read >= P.n_reads) break;
-        align_read(P, read, slot, &acc);
+        align_read(w, P, read, slot, &acc, &sd, dyn_lds, lds_bytes);
     }
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);
@@ -484,7 +497,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     HIP_TRY(hipGetDeviceProperties(&prop, A->graph->device));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    uint64_t want_slots = (uint64_t)prop.multiProcessorCount * 16;
+    uint64_t want_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;
     uint64_t budget = free_b / 2;
     uint64_t slots = std::min<uint64_t>(std::min<uint64_t>(want_slots, n), std::max<uint64_t>(1, budget / stride));
     if (slots == 0) slots = 1;
@@ -527,7 +540,10 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.stats = A->d_stats.as<KernelStats>();
     P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
     HIP_TRY(hipEventRecord(A->ev[2], 0));
-    k_align<<<(uint32_t)slots, 64>>>(P);
+    // latency-critical scalar arrays go to LDS when they fit next to the other resident waves of the CU
+    uint32_t lds_budget = (160u * 1024u) / (4 * MGX_ALIGN_WAVES_PER_SIMD) - 2048u;
+    uint32_t lds_bytes = std::min<uint32_t>(fast_lds_bytes(l.Lmax), lds_budget) & ~15u;
+    k_align<<<(uint32_t)slots, 64, lds_bytes>>>(P, lds_bytes);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(A->ev[3], 0));
     return MGX_OK;

@@ -13,7 +13,14 @@
 #include <stdint.h>
 
 #define MGX_DEV __device__ __forceinline__
+#ifndef MGX_NOINLINE
+#define MGX_NOINLINE 1
+#endif
+#if MGX_NOINLINE
 #define MGX_DEV_NOINLINE __device__ __noinline__
+#else
+#define MGX_DEV_NOINLINE __device__ __forceinline__
+#endif
 #define MGX_HD __host__ __device__ __forceinline__
 #define MGX_WAVE_EMU 0
 

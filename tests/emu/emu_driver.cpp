@@ -98,8 +98,8 @@ uint32_t emu_outgoing(void *h, uint64_t v, int rc, uint64_t *nodes, char *chars)
     return (uint32_t)n;
 }
 int emu_is_low_complexity(const char *s, uint32_t len) {
-    std::vector<int32_t> sd(2048);
-    return is_low_complexity((const uint8_t *)s, (int32_t)len, sd.data());
+    SdustScratch sd;
+    return is_low_complexity((const uint8_t *)s, (int32_t)len, &sd);
 }
 
 void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, const char *seqs, const uint64_t *offsets,
@@ -152,7 +152,11 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     P.arena = arena.data(); P.arena_stride = stride;
     P.results = R->results.data(); P.out_stream = R->stream.data(); P.out_capacity = out_words;
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();
-    for (uint64_t i = 0; i < n; ++i) align_read(P, i, 0, &R->stats);
+    auto w = std::make_unique<Wave>();
+    SdustScratch sd;
+    // model a small LDS so that both placements (LDS / arena) of the fast arrays are exercised
+    std::vector<uint8_t> lds(2048);
+    for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, lds.data(), (uint32_t)lds.size());
     R->host.decode(R->results.data(), n, R->stream.data());
     return R;
 }
