@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--snps", type=int, default=int(os.environ.get("MGX_BENCH_SNPS", 200_000)))
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MGX_BENCH_CPU_SAMPLE", 20000)))
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MGX_BENCH_CPU_SAMPLE", 200000)))
     ap.add_argument("--parity-sample", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

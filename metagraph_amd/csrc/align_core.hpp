@@ -1124,7 +1124,6 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     int32_t qn = 0, nn = 0, n_tips = 0;
     w.queue[qn++] = queue_key(0, 0, 0);
     wave_sync();
-    const int32_t k = (int32_t)P.g.k;
 
     while (qn) {
         // pop every entry that shares the top score, in descending tuple order (:491-500)
@@ -1724,7 +1723,6 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     w.have_best = 0;
     w.ctr.rank_lines = w.ctr.select_lines = w.ctr.bit_lines = 0;
     w.n_columns = w.n_extensions = 0;
-    const int32_t k = (int32_t)P.g.k;
     const uint64_t nb = P.node_begin[read];
     w.n_kmers = (int32_t)(P.node_begin[read + 1] - nb);
     w.nodes[0] = P.nodes_fwd + nb;

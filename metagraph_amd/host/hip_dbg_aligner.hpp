@@ -1,0 +1,217 @@
+// hip_dbg_aligner.hpp — C++ host adapter: MetaGraph's aligner operator surface over the C-ABI.
+//
+// Mirrors, name for name, what `metagraph align` consumes from graph/alignment:
+//   IDBGAligner::align_batch / align / get_config      (dbg_aligner.hpp:20-39, dbg_aligner.cpp:22-31)
+//   Query, AlignmentCallback                            (dbg_aligner.hpp:22-24)
+//   AlignmentResults (normalised query + RC + alignments, alignment.hpp:366-406; ctor alignment.cpp:1348-1372)
+//   Alignment getters + Cigar::to_string                (alignment.hpp:132-331, aligner_cigar.cpp:86-96)
+//   format_alignment TSV                                (cli/align.cpp:254-285)
+// Header-only; links against libmgx.so only (include/mgx.h).  Callbacks are invoked once per query, in
+// batch order, on the calling thread, like DBGAligner::align_batch (dbg_aligner.cpp:263,353).
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "../../include/mgx.h"
+
+namespace mgx {
+namespace host {
+
+typedef mgx_config DBGAlignerConfig;      // field-for-field mirror (aligner_config.hpp:18-94)
+typedef uint64_t node_index;
+
+class Cigar {
+  public:
+    typedef std::pair<uint8_t, uint32_t> value_type;
+    const std::vector<value_type> &data() const { return cigar_; }
+    std::vector<value_type> &data() { return cigar_; }
+    std::string to_string() const {
+        static const char op_str[] = "SX=DIG";
+        std::string s;
+        for (const auto &p : cigar_) s += std::to_string(p.second) + op_str[p.first];
+        return s;
+    }
+    size_t get_num_matches() const {
+        size_t n = 0;
+        for (const auto &p : cigar_) n += (p.first == MGX_OP_MATCH) * p.second;
+        return n;
+    }
+    uint32_t get_clipping() const { return cigar_.size() && cigar_.front().first == MGX_OP_CLIPPED ? cigar_.front().second : 0; }
+    uint32_t get_end_clipping() const { return cigar_.size() && cigar_.back().first == MGX_OP_CLIPPED ? cigar_.back().second : 0; }
+  private:
+    std::vector<value_type> cigar_;
+};
+
+class Alignment {
+  public:
+    std::string_view get_query_view() const { return query_view_; }
+    const std::vector<node_index> &get_nodes() const { return nodes_; }
+    std::string_view get_sequence() const { return sequence_; }
+    size_t get_offset() const { return offset_; }
+    size_t size() const { return nodes_.size(); }
+    bool empty() const { return nodes_.empty(); }
+    bool get_orientation() const { return orientation_; }
+    int32_t get_score() const { return score_; }
+    const Cigar &get_cigar() const { return cigar_; }
+    uint32_t get_clipping() const { return cigar_.get_clipping(); }
+    uint32_t get_end_clipping() const { return cigar_.get_end_clipping(); }
+    // fmt formatter of the reference (alignment.hpp:426-433)
+    std::string to_tsv_fields() const {
+        return std::string(orientation_ ? "-" : "+") + "\t" + sequence_ + "\t" + std::to_string(score_) + "\t"
+            + std::to_string(cigar_.get_num_matches()) + "\t" + cigar_.to_string() + "\t" + std::to_string(offset_);
+    }
+  private:
+    friend class HipDBGAligner;
+    std::string_view query_view_;
+    std::vector<node_index> nodes_;
+    bool orientation_ = false;
+    size_t offset_ = 0;
+    std::string sequence_;
+    int32_t score_ = 0;
+    Cigar cigar_;
+};
+
+class AlignmentResults {
+  public:
+    explicit AlignmentResults(std::string_view query = {}) {
+        // alignment.cpp:1348-1372: upper-case, bytes < 0 -> 127, SSO disabled, reverse complement
+        query_.reserve(std::max<size_t>(query.size(), 32) + 8);
+        for (char ch : query) {
+            int8_t c = (int8_t)ch;
+            query_.push_back(c >= 0 ? (char)toupper(c) : (char)127);
+        }
+        query_rc_.reserve(query_.capacity());
+        query_rc_.assign(query_.rbegin(), query_.rend());
+        for (char &c : query_rc_) c = complement(c);
+    }
+    AlignmentResults(const AlignmentResults &) = delete;
+    AlignmentResults &operator=(const AlignmentResults &) = delete;
+    AlignmentResults(AlignmentResults &&) = default;
+    AlignmentResults &operator=(AlignmentResults &&) = default;
+    const std::string &get_query(bool reverse_complement = false) const { return reverse_complement ? query_rc_ : query_; }
+    size_t size() const { return alignments_.size(); }
+    bool empty() const { return alignments_.empty(); }
+    const Alignment &operator[](size_t i) const { return alignments_[i]; }
+    auto begin() const { return alignments_.begin(); }
+    auto end() const { return alignments_.end(); }
+  private:
+    friend class HipDBGAligner;
+    static char complement(char c) {      // COMPL_TAB (common/seq_tools/reverse_complement.hpp:31-48)
+        static const char up[] = "TVGHEFCDIJMLKNOPQYSAABWXRZ";
+        unsigned char u = (unsigned char)c;
+        if (u >= 'A' && u <= 'Z') return up[u - 'A'];
+        if (u >= 'a' && u <= 'z') return (char)(up[u - 'a'] + 32);
+        if (u == 96) return 64;
+        return c;
+    }
+    std::string query_, query_rc_;
+    std::vector<Alignment> alignments_;
+};
+
+// The graph handle the aligner holds a reference to (DBGSuccinct's role for this path)
+class HipBOSSGraph {
+  public:
+    // W/last: one byte per edge, n_edges + 1 entries; valid may be null (reset_mask(), cli/align.cpp:337-339)
+    HipBOSSGraph(uint32_t k, uint64_t n_edges, const uint8_t *W, const uint8_t *last, const uint64_t F[5],
+                 const uint8_t *valid = nullptr, int device = 0) {
+        mgx_boss_view v{};
+        v.k = k; v.sigma = 5; v.n_edges = n_edges; v.W = W; v.last = last; v.F = F; v.valid = valid;
+        v.mode = MGX_MODE_BASIC; v.on_device = 0;
+        if (int rc = mgx_graph_create(&v, device, &g_)) throw std::runtime_error(std::string("mgx_graph_create: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
+    }
+    ~HipBOSSGraph() { mgx_graph_destroy(g_); }
+    HipBOSSGraph(const HipBOSSGraph &) = delete;
+    size_t get_k() const { return mgx_graph_k(g_); }
+    uint64_t max_index() const { return mgx_graph_max_index(g_); }
+    mgx_graph *handle() const { return g_; }
+  private:
+    mgx_graph *g_ = nullptr;
+};
+
+class IDBGAligner {
+  public:
+    typedef std::pair<std::string /* header */, std::string /* seq */> Query;
+    typedef std::function<void(const std::string & /* header */, AlignmentResults && /* alignments */)> AlignmentCallback;
+    virtual ~IDBGAligner() {}
+    virtual const HipBOSSGraph &get_graph() const = 0;
+    virtual const DBGAlignerConfig &get_config() const = 0;
+    virtual void align_batch(const std::vector<Query> &seq_batch, const AlignmentCallback &callback) const = 0;
+    AlignmentResults align(std::string_view query) const {          // dbg_aligner.cpp:22-31
+        AlignmentResults result;
+        align_batch({ Query{ std::string{}, std::string(query) } },
+                    [&](const std::string &, AlignmentResults &&alignment) { std::swap(result, alignment); });
+        return result;
+    }
+    virtual bool has_coordinates() const = 0;
+};
+
+class HipDBGAligner : public IDBGAligner {
+  public:
+    // throws std::runtime_error like the reference when check_config_scores() fails (dbg_aligner.cpp:55-56)
+    HipDBGAligner(const HipBOSSGraph &graph, const DBGAlignerConfig &config, const mgx_limits *limits = nullptr)
+          : graph_(graph) {
+        if (int rc = mgx_aligner_create(graph.handle(), &config, limits, &a_))
+            throw std::runtime_error(std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")");
+        mgx_aligner_get_config(a_, &config_);
+    }
+    ~HipDBGAligner() override { mgx_aligner_destroy(a_); }
+    const HipBOSSGraph &get_graph() const override { return graph_; }
+    const DBGAlignerConfig &get_config() const override { return config_; }
+    bool has_coordinates() const override { return false; }
+
+    void align_batch(const std::vector<Query> &seq_batch, const AlignmentCallback &callback) const override {
+        std::string blob;
+        std::vector<uint64_t> offsets(seq_batch.size() + 1, 0);
+        for (size_t i = 0; i < seq_batch.size(); ++i) {
+            blob += seq_batch[i].second;
+            offsets[i + 1] = blob.size();
+        }
+        mgx_results res{};
+        if (int rc = mgx_align_batch(a_, blob.data(), offsets.data(), seq_batch.size(), 0, &res))
+            throw std::runtime_error(std::string("mgx_align_batch: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
+        for (size_t i = 0; i < seq_batch.size(); ++i) {
+            if (res.status[i] != MGX_OK)
+                throw std::runtime_error("query " + std::to_string(i) + ": device arena overflow (raise mgx_limits)");
+            AlignmentResults paths(seq_batch[i].second);
+            for (uint64_t ai = res.aln_begin[i]; ai < res.aln_begin[i + 1]; ++ai) {
+                const mgx_alignment &m = res.alignments[ai];
+                Alignment a;
+                a.orientation_ = m.orientation;
+                a.offset_ = m.offset;
+                a.score_ = m.score;
+                a.sequence_.assign(res.seqs + m.seq_begin, m.seq_len);
+                a.nodes_.assign(res.nodes + m.nodes_begin, res.nodes + m.nodes_begin + m.n_nodes);
+                for (uint32_t x = 0; x < m.n_cigar; ++x)
+                    a.cigar_.data().emplace_back(res.cigar[m.cigar_begin + x].op, res.cigar[m.cigar_begin + x].len);
+                const std::string &q = paths.get_query(m.orientation);
+                a.query_view_ = std::string_view(q).substr(m.clipping, q.size() - m.clipping - m.end_clipping);
+                paths.alignments_.push_back(std::move(a));
+            }
+            callback(seq_batch[i].first, std::move(paths));
+        }
+    }
+
+  private:
+    const HipBOSSGraph &graph_;
+    DBGAlignerConfig config_;
+    mgx_aligner *a_ = nullptr;
+};
+
+// format_alignment (cli/align.cpp:254-285), TSV branch
+inline std::string format_alignment(const std::string &header, const AlignmentResults &paths, int32_t min_path_score) {
+    std::string s = header + "\t" + paths.get_query();
+    if (paths.empty()) {
+        s += "\t*\t*\t" + std::to_string(min_path_score) + "\t*\t*\t*\n";
+    } else {
+        for (const auto &p : paths) s += "\t" + p.to_tsv_fields();
+        s += "\n";
+    }
+    return s;
+}
+
+} // namespace host
+} // namespace mgx

@@ -1,0 +1,41 @@
+"""The C++ host adapter (IDBGAligner shape) + mgx_align driver reproduce the reference's CLI goldens."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import orc
+from test_oracle_kats import read_fasta, HERE, KATS
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(HERE)
+
+
+def test_mgx_align_driver_goldens(tmp_path):
+    cli = KATS["cli"]
+    g = orc.Graph.build(cli["k"], read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"])), 0, False)
+    W, last, F, _ = g.export()
+    dump = tmp_path / "mt.boss"
+    with open(dump, "wb") as f:
+        f.write(struct.pack("<7Q", g.k, g.n_edges, *[int(x) for x in F]))
+        f.write(W.tobytes())
+        f.write(last.tobytes())
+    exe = os.path.join(ROOT, "metagraph_amd", "_build", "mgx_align")
+    reads = os.path.join(HERE, "golden", cli["reads_fastq"])
+    for spec in cli["runs"]:
+        args = [exe, str(dump), reads, "--align-min-exact-match", "0.0"]
+        if not spec["flags"]["forward_and_reverse_complement"]:
+            args.append("--align-only-forwards")
+        r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.rstrip("\n").split("\n")
+        assert len(lines) == spec["n_lines"]
+        for idx, want in spec["lines"].items():
+            assert lines[int(idx)] == want
+        for idx, fields in spec["fields"].items():
+            got = lines[int(idx)].split("\t")
+            for fi, fv in fields.items():
+                assert got[int(fi)] == fv
