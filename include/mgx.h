@@ -166,6 +166,9 @@ typedef struct mgx_stats {
     uint64_t n_seeds;
     uint64_t n_map_lines;       /* part of n_rank_lines + n_select_lines issued by the k-mer mapping kernel */
     uint64_t n_capacity_errors; /* reads whose status is MGX_ERR_CAPACITY */
+    uint64_t phase_cycles[8];   /* k_align shader cycles summed over waves: query prep, seeding, extend,
+                                   backtrack, driver rest, output (profiling aid) */
+    uint64_t extend_cycles[8];  /* extend() breakdown: pop, stage+band, outgoing, column, scan, commit, conv, push */
     double seed_kernel_ms, align_kernel_ms;   /* HIP-event time of the two kernels, last batch */
 } mgx_stats;
 

@@ -127,7 +127,10 @@ class Aligner:
     def stats(self):
         s = capi.Stats()
         _check(capi.lib().mgx_aligner_stats(self.h, C.byref(s)))
-        return {f[0]: getattr(s, f[0]) for f in capi.Stats._fields_}
+        d = {f[0]: getattr(s, f[0]) for f in capi.Stats._fields_}
+        d["phase_cycles"] = list(s.phase_cycles)
+        d["extend_cycles"] = list(s.extend_cycles)
+        return d
 
     def format_tsv(self, res, qi, header, query):
         q = query if isinstance(query, bytes) else query.encode("latin-1")

@@ -157,6 +157,11 @@ struct ExtenderState {           // one per strand (Extender object in dbg_align
 
 struct ExtendResult { int32_t n_tips; int32_t min_cell_score; int32_t table_size; };
 
+// One DP column staged on chip (S, E, F incl. the 5-cell padding): the column being computed and its
+// parent live in LDS so that the hot path of an extension never waits on the HBM arena.
+struct Staging { int32_t *S, *E, *F; int32_t col; };
+constexpr int32_t LQ_CAP = 32;       // frontier entries kept in LDS; the rest spill to the arena
+
 struct Wave {
     const AlignParams *P;
     int32_t L;                   // query length
@@ -175,12 +180,19 @@ struct Wave {
     // extension scratch
     int32_t *cells;
     ColMeta *cols;
-    uint64_t *queue, *next_nodes;
+    uint64_t *queue, *next_nodes;         // arena tiers of the frontier / current batch
+    uint64_t *lq, *lnn;                   // LDS tiers (first LQ_CAP entries)
+    Staging st[2];
+    ColMeta hot;                          // metadata of the most recently committed column
+    int32_t hot_idx;
+    Block blk_cache;                      // target block of the last graph expansion (children live in it)
+    uint32_t blk_cache_idx;
     uint32_t *tips, *prev_starts;
     BtIndex *indices;
     uint32_t *rev_ops, *rev_nodes;
     uint8_t *rev_seq;
     SdustScratch *sd;            // sdust scratch (LDS)
+    const int8_t *sm_rows;       // score-matrix rows of the 6 possible path characters ($ACGT\\0) x 128, in LDS
     uint32_t *gen_store;         // conv-checker generation counters, persistent per arena slice
     ExtenderState ext[2];
     DevAln aln[4];               // 0: extension result, 1: reversed seed for the backward pass,
@@ -188,7 +200,9 @@ struct Wave {
     int32_t have_best;
     LineCtr ctr;                 // BOSS block loads (lane-parallel regions add their wave sums)
     ExtendResult er;             // result of the last extend(); noinline callees must not write through
-    int32_t tmp_pushes;          // pointers into the caller's private frame, so outputs live here
+    int32_t tmp_pushes;
+    uint64_t cyc[8];             // phase timers (shader cycles)
+    uint64_t xcyc[8];            // extend() breakdown: pop, stage+band, outgoing, column, scan, commit, conv, push          // pointers into the caller's private frame, so outputs live here
     uint32_t n_columns, n_extensions;
     int32_t status;
 };
@@ -216,6 +230,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += align8((uint64_t)lim.max_columns * 2 * sizeof(BtIndex));
     b += 2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path);   // rev_*
     b += 16;                                            // gen_store
+    b += 6 * align8((L + 16) * 4) + 2 * align8(32 * 8); // staging + LDS-tier fallbacks
     b += 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8(ent * sizeof(ConvEntry)) + align8(ent * L * 4));
     b += 4 * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
     return align8(b);
@@ -238,7 +253,14 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
         if (b8 <= lleft) { r = lp; lp += b8; lleft -= (uint32_t)b8; }
         return r;
     };
+    // persistent fast arrays
     for (int s = 0; s < 2; ++s) w.q[s] = take_fast(Lp);
+    for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take_fast((L + 1) * 4);
+    w.lq = (uint64_t *)take_fast(LQ_CAP * 8);
+    w.lnn = (uint64_t *)take_fast(LQ_CAP * 8);
+    // overlay: the seeding tables and the extension's column staging are never live at the same time
+    uint8_t *lp_mark = lp;
+    uint32_t lleft_mark = lleft;
     w.msl = (uint16_t *)take_fast((L + 1) * 2);
     w.pos_cnt = (uint16_t *)take_fast((L + 1) * 2);
     w.ml = (uint16_t *)take_fast((L + 1) * 2);
@@ -246,7 +268,14 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.pos_start = (uint32_t *)take_fast((L + 1) * 4);
     w.rfirst = (uint32_t *)take_fast((L + 1) * 4);
     w.rlast = (uint32_t *)take_fast((L + 1) * 4);
-    for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take_fast((L + 1) * 4);
+    lp = lp_mark;
+    lleft = lleft_mark;
+    for (int b = 0; b < 2; ++b) {
+        w.st[b].S = (int32_t *)take_fast((L + 16) * 4);
+        w.st[b].E = (int32_t *)take_fast((L + 16) * 4);
+        w.st[b].F = (int32_t *)take_fast((L + 16) * 4);
+        w.st[b].col = -1;
+    }
     for (int s = 0; s < 2; ++s) w.seeds[s] = (DevSeed *)take((uint64_t)lim.max_seeds * sizeof(DevSeed));
     for (int s = 0; s < 2; ++s) w.alive[s] = take(lim.max_seeds);
     w.alt = (uint32_t *)take((uint64_t)lim.max_alt * 4);
@@ -276,20 +305,36 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
 // LDS bytes that hold every "fast" array of carve() for a given Lmax
 MGX_HD uint32_t fast_lds_bytes(uint32_t Lmax) {
     uint64_t L = Lmax, Lp = align8(L + 8);
-    return (uint32_t)(2 * Lp + 3 * align8((L + 1) * 2) + align8(L + 1) + 3 * align8((L + 1) * 4) + 2 * align8((L + 1) * 4));
+    uint64_t persistent = 2 * Lp + 2 * align8((L + 1) * 4) + 2 * 32 * 8;
+    uint64_t seeding = 3 * align8((L + 1) * 2) + align8(L + 1) + 3 * align8((L + 1) * 4);
+    uint64_t staging = 6 * align8((L + 16) * 4);
+    return (uint32_t)(persistent + (seeding > staging ? seeding : staging));
 }
 
 MGX_DEV int32_t score_of(const AlignParams &P, uint8_t graph_char, uint8_t query_char) {
     return P.score_matrix[(uint32_t)(graph_char & 127) * 128 + (query_char & 127)];
 }
 
+// fill the 6 x 128 score rows ($, A, C, G, T, '\\0'); dst may be LDS
+MGX_DEV void load_score_rows(const AlignParams &P, int8_t *dst) {
+    for (int32_t base = 0; base < 6 * 128; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t x = base + l;
+            if (x < 6 * 128) {
+                uint32_t code = (uint32_t)(x >> 7);
+                uint8_t row = code != 5 ? decode_code(code) : 0;
+                dst[x] = P.score_matrix[(uint32_t)(row & 127) * 128 + (x & 127)];
+            }
+        }
+    }
+    wave_sync();
+}
+
 // profile_score_[encode(c)][start + trim + j] (aligner_extender_methods.cpp:38-59): column char vs
 // the query character one before absolute window position; 0 in the first cell and the padding
-MGX_DEV int32_t profile_at(const AlignParams &P, const uint8_t *q, int32_t L, uint8_t c, int32_t abs_pos) {
+MGX_DEV int32_t profile_at(const Wave &w, const uint8_t *q, int32_t L, uint8_t c, int32_t abs_pos) {
     if (abs_pos < 1 || abs_pos > L) return 0;
-    uint32_t code = encode_char(c);
-    uint8_t row = code != 5 ? decode_code(code) : 0;
-    return score_of(P, row, q[abs_pos - 1]);
+    return w.sm_rows[encode_char(c) * 128 + (q[abs_pos - 1] & 127)];      // row 5 = score_matrix['\0']
 }
 
 MGX_DEV uint8_t profile_op_at(const uint8_t *q, int32_t L, uint8_t c, int32_t abs_pos) {
@@ -525,14 +570,28 @@ MGX_NI_G2 void base_seeds(Wave &w, int s) {
 
 // BOSS::index_range (boss.hpp:720-764) for one lane: codes q[i .. i + len); returns matched length,
 // *first = succ_last(rl), *last = ru
-MGX_DEV int32_t index_range_lane(const DevGraph &g, const uint8_t *q, int32_t len, uint64_t *first, uint64_t *last, LineCtr &ctr) {
+MGX_DEV int32_t index_range_lane(const DevGraph &g, const uint8_t *q, int32_t len, int32_t min_len,
+                                 uint64_t *first, uint64_t *last, LineCtr &ctr) {
     *first = 0; *last = 0;
     if (len == 0) { *first = 1; *last = 1; return 0; }
     for (int32_t j = 0; j < len; ++j) if (encode_char(q[j]) == 5) return 0;
-    uint64_t rl, ru;
-    initial_range(g, encode_char(q[0]), &rl, &ru);
-    if (rl > ru) return 0;
+    uint64_t rl = 1, ru = 0;
     int32_t it = 1;
+    bool have = false;
+    if (g.prefix_len && (int32_t)g.prefix_len <= len) {
+        // get_initial_range via the suffix-range table (boss.hpp:645-663)
+        uint32_t key = 0;
+        for (uint32_t j = 0; j < g.prefix_len; ++j) key |= (encode_char(q[j]) - 1) << (2 * j);
+        prefix_range(g, key, &rl, &ru, ctr);
+        if (rl <= ru) { have = true; it = (int32_t)g.prefix_len; }
+        else if (min_len > (int32_t)g.prefix_len) return 0;      // the match is shorter than prefix_len < min_len:
+                                                                 // the caller discards it (dbg_succinct.cpp:346-347)
+    }
+    if (!have) {                                                 // "start search from scratch" (boss.hpp:739-754)
+        initial_range(g, encode_char(q[0]), &rl, &ru);
+        if (rl > ru) return 0;
+        it = 1;
+    }
     for (; it < len; ++it)
         if (!tighten_range(g, &rl, &ru, encode_char(q[it]), ctr)) break;
     *first = succ_last(g, rl, ctr);
@@ -586,7 +645,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                 uint32_t rf = 0, rl_ = 0;
                 if (max_len >= (int32_t)w.msl[i]) {
                     uint64_t first, last;
-                    int32_t m = index_range_lane(g, w.q[s] + i, max_len, &first, &last, lc);
+                    int32_t m = index_range_lane(g, w.q[s] + i, max_len, msl0, &first, &last, lc);
                     if (m >= msl0 && first && first <= g.n) {
                         mlen = (uint16_t)m;
                         rf = rank_last(g, first, lc);
@@ -726,12 +785,13 @@ MGX_DEV void fill_range(int32_t *vec, int32_t a, int32_t b, int32_t val) {
 // query position query_start.  Returns converged score (NINF = nothing improved).
 MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start,
                                    const int32_t *s_cells, int32_t size) {
+    // s_cells: S values of the column (contiguous, from the staging buffer)
     const AlignParams &P = *w.P;
     auto column_max = [&]() {
         int32_t m = INT32_MIN;
         for (int32_t base = 0; base < size; base += WAVE) {
             LV<int32_t> x;
-            FOR_LANES(l) { int32_t j = base + l; x[l] = j < size ? s_cells[3 * j] : INT32_MIN; }
+            FOR_LANES(l) { int32_t j = base + l; x[l] = j < size ? s_cells[j] : INT32_MIN; }
             m = imax(m, wave_max(x));
         }
         return m;
@@ -746,7 +806,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         if (idx < 0) return NINF;
         int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[3 * j]; }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[j]; }
         }
         wave_sync();
         return column_max();
@@ -757,7 +817,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
     if (query_start + size <= start) {
         fill_range(vec, query_start + size, start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[3 * j]; }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[j]; }
         }
         e.len = start + len - query_start; e.start = query_start;
         E.conv.entries[idx] = e;
@@ -767,7 +827,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
     if (query_start >= start + len) {
         fill_range(vec, start + len, query_start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[3 * j]; }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[j]; }
         }
         e.len = query_start + size - start;
         E.conv.entries[idx] = e;
@@ -787,7 +847,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
             int32_t j = base + l;
             x[l] = NINF;
             if (j < size) {
-                int32_t sv = s_cells[3 * j];
+                int32_t sv = s_cells[j];
                 int32_t vv = vec[query_start + j];
                 if ((double)sv > (double)vv * rel) {
                     vv = imax(vv, sv);
@@ -863,12 +923,10 @@ MGX_DEV int32_t cell_F(const Wave &w, const ColMeta &c, int32_t j) { return (j >
 // capacity of a reference vector created with `size0` elements (+5 reserved) after `pushes` push_backs
 // followed by reserve(size + 5) (DPTColumn::create :389-410, extend_ins_end :293-328; libstdc++ growth)
 MGX_DEV uint32_t ref_capacity(uint32_t size0, uint32_t pushes) {
-    uint32_t cap = size0 + 5, sz = size0;
+    uint32_t cap = size0 + 5;
     if (!pushes) return cap;
-    // pushes happen one at a time; capacity doubles when full
     uint32_t target = size0 + pushes;
     while (cap < target) cap = imax<uint32_t>(1u, 2 * cap);
-    (void)sz;
     return imax(cap, target + 5);
 }
 
@@ -880,52 +938,91 @@ MGX_DEV uint64_t queue_key(int32_t score, int32_t neg_off_diag, uint32_t idx) {
 MGX_DEV int32_t key_score(uint64_t key) { return (int32_t)(uint32_t)(key >> 40) - (1 << 23); }
 MGX_DEV uint32_t key_idx(uint64_t key) { return (uint32_t)(key & 0xFFFFFF); }
 
-// index of the maximum key among queue[0..n), -1 if none satisfies score == want (want_any: any)
-MGX_DEV int32_t queue_argmax(const uint64_t *queue, int32_t n, bool restrict_score, int32_t want) {
-    uint64_t best = 0;
-    int32_t best_i = -1;
-    for (int32_t base = 0; base < n; base += WAVE) {
-        LV<uint64_t> x;
-        FOR_LANES(l) {
-            int32_t j = base + l;
-            uint64_t kx = 0;
-            if (j < n) {
-                uint64_t key = queue[j];
-                if (!restrict_score || key_score(key) == want) kx = key;
-            }
-            x[l] = kx;
-        }
-        uint64_t m = wave_max_u64(x);
-        if (m > best) {
-            best = m;
-            LV<bool> hit;
-            FOR_LANES(l) { hit[l] = x[l] == m; }
-            best_i = base + ctz64(wave_ballot(hit));
-        }
+// two-tier arrays: the first LQ_CAP entries in LDS, the rest in the arena
+MGX_DEV uint64_t tier_get(const uint64_t *lds, const uint64_t *arena, int32_t i) { return i < LQ_CAP ? lds[i] : arena[i - LQ_CAP]; }
+MGX_DEV void tier_set(uint64_t *lds, uint64_t *arena, int32_t i, uint64_t v) { if (i < LQ_CAP) lds[i] = v; else arena[i - LQ_CAP] = v; }
+
+// The frontier (std::priority_queue<TableIt>, :477-487) is kept as an ascending sorted array (keys are
+// unique), so the maximum is at the back.  Insert = lane-parallel rank + shift.
+MGX_DEV void frontier_insert(Wave &w, int32_t &qn, uint64_t key) {
+    int32_t pos = 0;
+    for (int32_t base = 0; base < qn; base += WAVE) {
+        LV<bool> lt;
+        FOR_LANES(l) { int32_t j = base + l; lt[l] = j < qn && tier_get(w.lq, w.queue, j) < key; }
+        pos += popc64(wave_ballot(lt));
     }
-    return best_i;
+    // shift [pos, qn) up by one, highest chunk first
+    for (int32_t top = qn; top > pos; top -= WAVE) {
+        int32_t lo = imax(pos, top - WAVE);
+        LV<uint64_t> v;
+        FOR_LANES(l) { int32_t j = lo + l; v[l] = j < top ? tier_get(w.lq, w.queue, j) : 0; }
+        wave_sync();
+        FOR_LANES(l) { int32_t j = lo + l; if (j < top) tier_set(w.lq, w.queue, j + 1, v[l]); }
+        wave_sync();
+    }
+    tier_set(w.lq, w.queue, pos, key);
+    ++qn;
+    wave_sync();
 }
 
-// Compute one DP column into freshly reserved cells (update_column :209-290 + extend_ins_end :293-328).
-// Returns the final size (cells) and the number of pushes in *pushes.
-MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta &prev, int32_t prev_end, int32_t begin,
-                               int32_t size, uint32_t cells_off, uint8_t c, int32_t init_score, int32_t offset,
-                               int32_t start, int32_t window_size, int32_t xdrop_cutoff) {
+MGX_DEV int32_t st_S(const Staging &s, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? s.S[j] : NINF; }
+MGX_DEV int32_t st_F(const Staging &s, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? s.F[j] : NINF; }
+
+// make column `idx` resident in a staging buffer; returns the buffer index
+MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
+    if (w.st[0].col == idx) return 0;
+    if (w.st[1].col == idx) return 1;
+    const int b = 0;
+    Staging &s = w.st[b];
+    const int32_t n = c.size + 5;
+    const int32_t *cells = w.cells + c.cells;
+    for (int32_t base = 0; base < n; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            if (j < n) { s.S[j] = cells[3 * j]; s.E[j] = cells[3 * j + 1]; s.F[j] = cells[3 * j + 2]; }
+        }
+    }
+    s.col = idx;
+    wave_sync();
+    return b;
+}
+
+// write a staged column (size + 5 cells) to the arena, S/E/F interleaved; nothing waits on these stores
+MGX_DEV void flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t size) {
+    int32_t *cells = w.cells + cells_off;
+    const int32_t n = size + 5;
+    for (int32_t base = 0; base < n; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            if (j < n) { cells[3 * j] = s.S[j]; cells[3 * j + 1] = s.E[j]; cells[3 * j + 2] = s.F[j]; }
+        }
+    }
+}
+
+// Compute one DP column into staging buffer `cb` from its parent in buffer `pb`
+// (update_column :209-290 + extend_ins_end :293-328).  Returns the final size; pushes in w.tmp_pushes.
+MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_size, int32_t prev_trim, int pb, int cb,
+                               int32_t prev_end, int32_t begin, int32_t size, uint8_t c, int32_t init_score,
+                               int32_t offset, int32_t start, int32_t window_size, int32_t xdrop_cutoff) {
     const AlignParams &P = *w.P;
     const int32_t go = P.cfg.gap_open, ge = P.cfg.gap_ext;
     const int32_t L = w.L;
-    int32_t *cells = w.cells + cells_off;
+    const Staging &par = w.st[pb];
+    Staging &cur = w.st[cb];
     const int32_t trim = begin;
     const int32_t max_size = window_size + 1 - trim;
-    // DPTColumn::create: size + 5 cells of ninf (we initialise everything the column may grow into)
+    const int8_t *row = w.sm_rows + encode_char(c) * 128;     // profile_score_[encode(c)] (:38-59)
+    const uint8_t *qq = E.q;
+    // DPTColumn::create: size + 5 cells of ninf (we initialise everything update_column may touch)
     const int32_t init_n = imin(max_size, size) + 8;
-    for (int32_t base = 0; base < 3 * init_n; base += WAVE) {
-        FOR_LANES(l) { int32_t j = base + l; if (j < 3 * init_n) cells[j] = NINF; }
+    for (int32_t base = 0; base < init_n; base += WAVE) {
+        FOR_LANES(l) { int32_t j = base + l; if (j < init_n) { cur.S[j] = NINF; cur.E[j] = NINF; cur.F[j] = NINF; } }
     }
+    cur.col = -1;
     wave_sync();
     const int32_t n_prev = prev_end - trim;                 // update_column's prev_end
     const int32_t n_loop = (n_prev + 3) & ~3;               // lanes computed in blocks of 4
-    const int32_t dp = trim - prev.trim;                    // S_prev_v = S_prev.data() + trim - trim_prev
+    const int32_t dp = trim - prev_trim;                    // S_prev_v = S_prev.data() + trim - trim_prev
     int32_t e_carry = NINF;                                 // E_v[base], E_v[0] = ninf
     int32_t tmax_carry = INT32_MIN;
     for (int32_t base = 0; base < n_loop; base += WAVE) {
@@ -935,10 +1032,14 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta 
             int32_t mm = NINF;
             if (j < n_loop) {
                 int32_t match = NINF;
-                if (j) match = cell_S(w, prev, dp + j - 1) + profile_at(P, E.q, L, c, start + trim + j) + init_score;
+                if (j) {
+                    int32_t ap = start + trim + j;
+                    int32_t prof = (ap >= 1 && ap <= L) ? (int32_t)row[qq[ap - 1] & 127] : 0;
+                    match = st_S(par, prev_size, dp + j - 1) + prof + init_score;
+                }
                 int32_t del = NINF;
-                if (offset > 1) del = imax(cell_S(w, prev, dp + j) + go, cell_F(w, prev, dp + j) + ge) + init_score;
-                cells[3 * j + 2] = del;                     // F_v[j]
+                if (offset > 1) del = imax(st_S(par, prev_size, dp + j) + go, st_F(par, prev_size, dp + j) + ge) + init_score;
+                cur.F[j] = del;                             // F_v[j]
                 mm = imax(match, del);
             }
             m[l] = mm;
@@ -959,9 +1060,9 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta 
         FOR_LANES(l) {
             int32_t j = base + l;
             if (j < n_loop) {
-                cells[3 * (j + 1) + 1] = enext[l];          // E_v[j + 1]
+                cur.E[j + 1] = enext[l];                    // E_v[j + 1]
                 int32_t sv = imax(m[l], ecur[l]);
-                cells[3 * j] = sv > xdrop_cutoff - 1 ? sv : NINF;
+                cur.S[j] = sv > xdrop_cutoff - 1 ? sv : NINF;
             }
         }
         int32_t last_lane = imin(WAVE, n_loop - base) - 1;
@@ -971,20 +1072,16 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta 
     wave_sync();
     if (size > imax(1, n_prev)) {                            // scalar tail (:284-289)
         int32_t j = size - 1;
-        int32_t match = imax(cell_S(w, prev, dp + j - 1) + init_score + profile_at(P, E.q, L, c, start + trim + j),
-                             cells[3 * j + 1]);
-        if (match >= xdrop_cutoff) {
-            FOR_LANES(l) { if (l == 0) cells[3 * j] = match; }
-        }
+        int32_t match = imax(st_S(par, prev_size, dp + j - 1) + init_score + profile_at(w, E.q, L, c, start + trim + j), cur.E[j]);
+        if (match >= xdrop_cutoff) cur.S[j] = match;
     }
     wave_sync();
     // extend_ins_end
     w.tmp_pushes = 0;
     if (size < max_size) {
-        int32_t ins_score = imax(cells[3 * (size - 1)] + go, cells[3 * (size - 1) + 1] + ge);
+        int32_t ins_score = imax(cur.S[size - 1] + go, cur.E[size - 1] + ge);
         if (ins_score >= xdrop_cutoff) {
             int32_t n_push = 1;
-            // further pushes while E.back() + ge >= cutoff && E.size() < max_size
             int32_t room = max_size - (size + 1);
             if (ge == 0) {
                 n_push += room;
@@ -992,22 +1089,15 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta 
                 int32_t v = ins_score;
                 while (n_push - 1 < room && v + ge >= xdrop_cutoff) { v += ge; ++n_push; }
             }
-            for (int32_t base = 0; base < n_push; base += WAVE) {
+            for (int32_t base = 0; base < n_push + 5; base += WAVE) {
                 FOR_LANES(l) {
                     int32_t t = base + l;
                     if (t < n_push) {
                         int32_t v = ins_score + t * ge;
-                        cells[3 * (size + t)] = v;
-                        cells[3 * (size + t) + 1] = v;
-                        cells[3 * (size + t) + 2] = NINF;
+                        cur.S[size + t] = v; cur.E[size + t] = v; cur.F[size + t] = NINF;
+                    } else if (t < n_push + 5) {             // padding after the new end is ninf
+                        cur.S[size + t] = NINF; cur.E[size + t] = NINF; cur.F[size + t] = NINF;
                     }
-                }
-            }
-            // padding after the new end is ninf
-            FOR_LANES(l) {
-                if (l < 5) {
-                    int32_t j = size + n_push + l;
-                    cells[3 * j] = NINF; cells[3 * j + 1] = NINF; cells[3 * j + 2] = NINF;
                 }
             }
             w.tmp_pushes = n_push;
@@ -1018,7 +1108,7 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, const ColMeta 
     return size;
 }
 
-// children of table[i] (DefaultColumnExtender::call_outgoing :330-387, non-canonical graphs)
+// children of a column (DefaultColumnExtender::call_outgoing :330-387, non-canonical graphs)
 MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
                           uint32_t *nodes, uint8_t *chars, int32_t *scores) {
     const AlignParams &P = *w.P;
@@ -1041,9 +1131,30 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
     uint32_t cc[5];
     int n;
     if (!E.rc_view) {
-        n = outgoing(P.g, col.node, nn, cc, w.ctr);
-        for (int t = 0; t < n; ++t) { nodes[t] = (uint32_t)nn[t]; chars[t] = decode_code(cc[t]); scores[t] = 0; }
-        return n;
+        // DBGSuccinct::call_outgoing_kmers (dbg_succinct.cpp:110-139); the node's own block is usually the
+        // target block of the expansion that created it
+        const DevGraph &g = P.g;
+        const uint64_t v = col.node;
+        Block cur;
+        if ((uint32_t)(v >> 6) == w.blk_cache_idx) cur = w.blk_cache;
+        else { ++w.ctr.rank_lines; cur = load_block(g, (uint32_t)(v >> 6)); }
+        uint32_t wv = block_W(cur, (int)(v & 63));
+        if (v > 1 && wv == 0) return 0;
+        Block tgt;
+        uint64_t lst = fwd_from(g, v, cur, wv % SIGMA, tgt, w.ctr);
+        w.blk_cache = tgt;
+        w.blk_cache_idx = (uint32_t)(lst >> 6);
+        uint64_t first = pred_last_from(g, lst - 1, ((lst - 1) >> 6) == (lst >> 6) ? tgt : load_block(g, (uint32_t)((lst - 1) >> 6)), w.ctr) + 1;
+        if (first < 2) first = 2;
+        n = 0;
+        Block b = tgt;
+        uint32_t bi = (uint32_t)(lst >> 6);
+        for (uint64_t i = first; i <= lst; ++i) {
+            if ((uint32_t)(i >> 6) != bi) { bi = (uint32_t)(i >> 6); ++w.ctr.rank_lines; b = load_block(g, bi); }
+            uint32_t c = block_W(b, (int)(i & 63)) % SIGMA;
+            if (c != 0 && in_graph(g, i)) { if (n < 4) { nodes[n] = (uint32_t)i; chars[n] = decode_code(c); scores[n] = 0; } ++n; }
+        }
+        return n < 4 ? n : 4;
     }
     // RCDBG::call_outgoing_kmers (rc_dbg.hpp:88-99): parents with the complemented first character
     n = incoming(P.g, col.node, nn, cc, w.ctr);
@@ -1075,35 +1186,36 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     uint32_t cell_top = 0;
     int32_t tsize = 0;
     uint64_t table_size_bytes = 0;
-    // root column
+    w.st[0].col = -1; w.st[1].col = -1;
+    w.hot_idx = -1;
+    w.blk_cache_idx = 0xFFFFFFFFu;
+    // root column (:455-470)
     {
         ColMeta r;
         r.node = seed.nodes[0]; r.parent = -1; r.c = 0; r.offset = seed_offset; r.max_pos = 0; r.trim = 0;
         r.score = 0; r.cells = cell_top; r.size = 1;
-        int32_t *cells = w.cells;
+        Staging &s0 = w.st[0];
+        FOR_LANES(l) { if (l < 8) { s0.S[l] = NINF; s0.E[l] = NINF; s0.F[l] = NINF; } }
+        wave_sync();
+        int32_t sroot = (cfg.left_end_bonus && !seed.clipping) ? cfg.left_end_bonus : 0;
+        s0.S[0] = sroot;
+        wave_sync();
         int32_t max_size = window_size + 1;
-        int32_t init_n = 8;
-        FOR_LANES(l) { if (l < 3 * init_n) cells[l] = NINF; }
-        wave_sync();
-        int32_t s0 = (cfg.left_end_bonus && !seed.clipping) ? cfg.left_end_bonus : 0;
-        FOR_LANES(l) { if (l == 0) cells[0] = s0; }
-        wave_sync();
         int32_t pushes = 0;
         if (1 < max_size) {
-            int32_t ins_score = imax(s0 + cfg.gap_open, NINF + cfg.gap_ext);
+            int32_t ins_score = imax(sroot + cfg.gap_open, NINF + cfg.gap_ext);
             if (ins_score >= xdrop_cutoff) {
                 int32_t n_push = 1, room = max_size - 2;
                 if (cfg.gap_ext == 0) n_push += room;
                 else { int32_t v = ins_score; while (n_push - 1 < room && v + cfg.gap_ext >= xdrop_cutoff) { v += cfg.gap_ext; ++n_push; } }
-                if ((uint64_t)3 * (1 + n_push + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
                 for (int32_t base = 0; base < n_push + 5; base += WAVE) {
                     FOR_LANES(l) {
                         int32_t t = base + l;
                         if (t < n_push) {
                             int32_t v = ins_score + t * cfg.gap_ext;
-                            cells[3 * (1 + t)] = v; cells[3 * (1 + t) + 1] = v; cells[3 * (1 + t) + 2] = NINF;
+                            s0.S[1 + t] = v; s0.E[1 + t] = v; s0.F[1 + t] = NINF;
                         } else if (t < n_push + 5) {
-                            cells[3 * (1 + t)] = NINF; cells[3 * (1 + t) + 1] = NINF; cells[3 * (1 + t) + 2] = NINF;
+                            s0.S[1 + t] = NINF; s0.E[1 + t] = NINF; s0.F[1 + t] = NINF;
                         }
                     }
                 }
@@ -1111,45 +1223,51 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             }
         }
         r.size = 1 + pushes;
+        if ((uint64_t)3 * (r.size + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
         r.cap3 = 3 * ref_capacity(1, (uint32_t)pushes);
+        wave_sync();
+        flush_column(w, s0, cell_top, r.size);
+        s0.col = 0;
         cell_top += 3 * (uint32_t)(r.size + 5);
         if (E.table_cap < 1) E.table_cap = 1;                 // emplace_back on an empty vector
         w.cols[0] = r;
+        w.hot = r;
+        w.hot_idx = 0;
         tsize = 1;
         table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)r.cap3 * 4;
-        wave_sync();
     }
+    const int32_t root_S0 = w.st[0].S[0];
+    (void)root_S0;
     int32_t min_cell_score = 0;
     int32_t best_score = 0;
     int32_t qn = 0, nn = 0, n_tips = 0;
-    w.queue[qn++] = queue_key(0, 0, 0);
-    wave_sync();
+    frontier_insert(w, qn, queue_key(0, 0, 0));
 
     while (qn) {
+        uint64_t tx0 = cycle_clock();
         // pop every entry that shares the top score, in descending tuple order (:491-500)
         {
-            int32_t bi = queue_argmax(w.queue, qn, false, 0);
-            int32_t top_score = key_score(w.queue[bi]);
+            const int32_t top_score = key_score(tier_get(w.lq, w.queue, qn - 1));
             nn = 0;
-            while (bi >= 0) {
-                uint64_t key = w.queue[bi];
-                w.next_nodes[nn++] = key;
-                w.queue[bi] = w.queue[qn - 1];
+            while (qn && key_score(tier_get(w.lq, w.queue, qn - 1)) == top_score) {
+                tier_set(w.lnn, w.next_nodes, nn++, tier_get(w.lq, w.queue, qn - 1));
                 --qn;
-                wave_sync();
-                bi = qn ? queue_argmax(w.queue, qn, true, top_score) : -1;
             }
+            wave_sync();
         }
+        w.xcyc[0] += cycle_clock() - tx0;
         while (nn) {
-            const uint64_t batch_first_key = w.next_nodes[0];
-            int32_t i = (int32_t)key_idx(w.next_nodes[nn - 1]);
+            uint64_t tx1 = cycle_clock();
+            int32_t i = (int32_t)key_idx(tier_get(w.lnn, w.next_nodes, nn - 1));
             --nn;
-            const ColMeta col = w.cols[i];
+            const ColMeta col = (i == w.hot_idx) ? w.hot : w.cols[i];
+            const int pb = stage_column(w, i, col);
+            const Staging &par = w.st[pb];
             const int32_t next_offset = col.offset + 1;
             const int32_t prev_xdrop_cutoff = xdrop_cutoff;       // global_xdrop: one shared cutoff
             const bool in_seed = (next_offset - seed.offset) >= 0 && (next_offset - seed.offset) < seed.seq_len;
             // early cut-offs when off the optimal path (:521-547)
-            if (cell_S(w, col, col.max_pos - col.trim) < best_score) {
+            if (st_S(par, col.size, col.max_pos - col.trim) < best_score) {
                 double node_counter = (double)tsize;
                 if (node_counter / (double)window_size >= cfg.max_nodes_per_seq_char) { qn = 0; nn = 0; continue; }
                 if ((double)table_size_bytes / 1000000.0 > cfg.max_ram_per_alignment) { qn = 0; nn = 0; continue; }
@@ -1158,7 +1276,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             int32_t b = col.size, e = 0;
             for (int32_t base = 0; base < col.size; base += WAVE) {
                 LV<bool> inr;
-                FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && w.cells[col.cells + 3 * j] >= prev_xdrop_cutoff; }
+                FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && par.S[j] >= prev_xdrop_cutoff; }
                 uint64_t mk = wave_ballot(inr);
                 if (mk) {
                     if (b == col.size) b = base + ctz64(mk);
@@ -1167,6 +1285,8 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             }
             int32_t begin = b + col.trim, prev_end = e + col.trim;
             if (prev_end <= begin) continue;
+            uint64_t tx2 = cycle_clock();
+            w.xcyc[1] += tx2 - tx1;
 
             uint32_t out_nodes[5];
             uint8_t out_chars[5];
@@ -1176,7 +1296,9 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 if (n_tips < (int32_t)lim.max_columns) w.tips[n_tips++] = (uint32_t)i;
                 continue;
             }
+            w.xcyc[2] += cycle_clock() - tx2;
             const int32_t end = imin(prev_end, window_size) + 1;
+            const int cb = 1 - pb;
             for (int oi = 0; oi < n_out; ++oi) {
                 const uint32_t next = out_nodes[oi];
                 const uint8_t c = to_upper(out_chars[oi]);
@@ -1188,40 +1310,48 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 uint32_t table_cap_before = E.table_cap;
                 if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
                 ++w.n_columns;
-                int32_t size = compute_column(w, E, col, prev_end, begin, size0, cell_top, c, score, next_offset,
+                uint64_t tx3 = cycle_clock();
+                int32_t size = compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
                                               start, window_size, xdrop_cutoff);
                 const int32_t pushes = w.tmp_pushes;
+                uint64_t tx4 = cycle_clock();
+                w.xcyc[3] += tx4 - tx3;
                 ColMeta cur;
                 cur.node = next; cur.parent = i; cur.c = c; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
                 cur.score = score; cur.cells = cell_top; cur.size = size;
                 cur.cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
-                const int32_t *cc = w.cells + cell_top;
+                const int32_t *cS = w.st[cb].S;
                 // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
                 const int32_t diag_i = next_offset - seed_offset;
                 bool has_extension = in_seed;
                 const int32_t extension_cutoff =
                     (int32_t)fma_f64((double)best_score, cfg.rel_score_cutoff, (double)partial_sum_offset);
-                uint64_t best_key = 0;
+                int32_t best_s = INT32_MIN, best_d = INT32_MAX, best_j = 0;
                 for (int32_t base = 0; base < size; base += WAVE) {
-                    LV<int32_t> mn;
-                    LV<uint64_t> key;
+                    LV<int32_t> sv, mn, dd;
                     LV<bool> ext;
                     FOR_LANES(l) {
                         int32_t j = base + l;
-                        int32_t sv = j < size ? cc[3 * j] : NINF;
-                        mn[l] = (j < size && sv != NINF) ? sv : INT32_MAX;
-                        // lexicographic (S desc, |pos - diag| asc, j asc)
-                        uint32_t dist = (uint32_t)iabs(j + begin - diag_i);
-                        key[l] = j < size ? (((uint64_t)((uint32_t)sv ^ 0x80000000u) << 32) | ((uint64_t)(0xFFFFu - imin<uint32_t>(dist, 0xFFFFu)) << 16)
-                                             | (uint64_t)(0xFFFFu - (uint32_t)j)) : 0;
-                        ext[l] = j < size && sv + E.psum[start + begin + j] >= extension_cutoff;
+                        int32_t v = j < size ? cS[j] : INT32_MIN;
+                        sv[l] = v;
+                        mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
+                        ext[l] = j < size && v + E.psum[start + begin + j] >= extension_cutoff;
                     }
                     min_cell_score = imin(min_cell_score, wave_min(mn));
-                    best_key = imax(best_key, wave_max_u64(key));
                     if (wave_ballot(ext)) has_extension = true;
+                    // arg max in the order (S desc, |pos - diag| asc, j asc) (:647-650)
+                    const int32_t cm = wave_max(sv);
+                    FOR_LANES(l) { int32_t j = base + l; dd[l] = (j < size && sv[l] == cm) ? iabs(j + begin - diag_i) : INT32_MAX; }
+                    const int32_t cd = wave_min(dd);
+                    LV<bool> hit;
+                    FOR_LANES(l) { hit[l] = dd[l] == cd; }
+                    const int32_t cj = base + ctz64(wave_ballot(hit));
+                    if (cm > best_s || (cm == best_s && cd < best_d)) { best_s = cm; best_d = cd; best_j = cj; }
                 }
-                cur.max_pos = (int32_t)(0xFFFFu - (uint32_t)(best_key & 0xFFFF)) + begin;
-                const int32_t max_val = cc[3 * (cur.max_pos - begin)];
+                cur.max_pos = best_j + begin;
+                const int32_t max_val = cS[cur.max_pos - begin];
+                uint64_t tx5 = cycle_clock();
+                w.xcyc[4] += tx5 - tx4;
                 if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) {
                     // pop(table.size() - 1): the vector keeps its (possibly grown) capacity
                     continue;
@@ -1230,31 +1360,39 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 table_size_bytes += (uint64_t)136 * table_sizediff + (uint64_t)cur.cap3 * 4;
                 if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
                 best_score = imax(best_score, max_val);
-                // commit the column
+                // commit the column: metadata + cells go to the arena (nothing waits on them)
                 w.cols[tsize] = cur;
+                w.hot = cur;
+                w.hot_idx = tsize;
+                flush_column(w, w.st[cb], cell_top, size);
+                w.st[cb].col = tsize;
                 cell_top += 3 * (uint32_t)(size + 5);
                 const int32_t my_idx = tsize;
                 ++tsize;
-                wave_sync();
                 const int32_t vec_offset = start + begin - (begin ? 1 : 0);
                 const int32_t skip = begin ? 0 : 1;
-                int32_t converged = update_seed_filter(w, E, next, vec_offset, cc + 3 * skip, size - skip);
+                uint64_t tx6 = cycle_clock();
+                w.xcyc[5] += tx6 - tx5;
+                int32_t converged = update_seed_filter(w, E, next, vec_offset, cS + skip, size - skip);
+                uint64_t tx7 = cycle_clock();
+                w.xcyc[6] += tx7 - tx6;
                 if (w.status != ST_OK) { res->table_size = 0; return; }
                 if (converged != NINF) {
                     uint64_t key = queue_key(converged, -iabs(cur.max_pos - diag_i), (uint32_t)my_idx);
-                    // next_nodes[0] is the first element popped into this batch (still there unless the
-                    // batch has been fully consumed, in which case next_nodes.size() == 0)
-                    if (nn && converged == key_score(w.next_nodes[0])) {
-                        w.next_nodes[nn++] = key;
+                    // next_nodes[0] is the first element popped into this batch (still there unless the batch
+                    // has been fully consumed, in which case next_nodes.size() == 0)
+                    if (nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
+                        tier_set(w.lnn, w.next_nodes, nn++, key);
+                        wave_sync();
                     } else {
-                        w.queue[qn++] = key;
+                        frontier_insert(w, qn, key);
                     }
-                    wave_sync();
                 }
-                (void)batch_first_key;
+                w.xcyc[7] += cycle_clock() - tx7;
             }
         }
     }
+    wave_sync();
     res->n_tips = n_tips;
     res->min_cell_score = min_cell_score;
     res->table_size = tsize;
@@ -1332,7 +1470,7 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                 if (sv == NINF || sp == NINF) continue;
                 int32_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
                 if (sv + end_bonus >= min_start_score) {
-                    bool is_match = sv == sp + col.score + profile_at(P, E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos)
+                    bool is_match = sv == sp + col.score + profile_at(w, E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos)
                         && profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos) == OP_MATCH;
                     if (is_match || start_pos == last_pos || is_tip) {
                         BtIndex bx;
@@ -1410,7 +1548,7 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                 }
             } else if (pos && pos >= trim_p + 1
                        && sv == cell_S(w, par, pos - trim_p - 1) + col.score
-                              + profile_at(P, E.q, w.L, (uint8_t)col.c, seed_clipping + pos)) {
+                              + profile_at(w, E.q, w.L, (uint8_t)col.c, seed_clipping + pos)) {
                 ++n_trace;
                 extra_score += col.score;
                 append_node(col.node, (uint8_t)col.c, col.offset, profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + pos));
@@ -1638,11 +1776,15 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         if (!w.alive[s][i]) continue;
         SeedRef seed = seedref_from_seed(w, s, i, nullptr);
         conv_clear(F.conv);                                   // set_seed (:90-98)
+        uint64_t t0 = cycle_clock();
         extend(w, F, seed, false);
+        uint64_t t1 = cycle_clock();
+        w.cyc[2] += t1 - t0;
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
         int32_t mps = imax(0, P.cfg.min_cell_score);          // extend(): min_path_score = max(0, min_cell_score)
         bool have = backtrack(w, F, seed, nullptr, er, mps, w.aln[0]);
+        w.cyc[3] += cycle_clock() - t1;
         if (w.status != ST_OK) return;
         if (have) {
             DevAln &path = w.aln[0];
@@ -1654,10 +1796,14 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
                     SeedRef rseed = seedref_from_aln(w.aln[1]);
                     int32_t mps2 = imax(0, min_path_score_now(w));
                     conv_clear(B.conv);
+                    uint64_t t2 = cycle_clock();
                     extend(w, B, rseed, true);
+                    uint64_t t3 = cycle_clock();
+                    w.cyc[2] += t3 - t2;
                     const ExtendResult er2 = w.er;
                     if (w.status != ST_OK) return;
                     bool have2 = backtrack(w, B, rseed, &w.aln[1], er2, mps2, w.aln[2]);
+                    w.cyc[3] += cycle_clock() - t3;
                     if (w.status != ST_OK) return;
                     if (have2) {
                         DevAln &p2 = w.aln[2];
@@ -1713,8 +1859,9 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
 
 // the whole per-read program; `slot` selects the arena slice
 MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t slot, KernelStats *stats_accum,
-                        SdustScratch *sd, uint8_t *lds, uint32_t lds_bytes) {
+                        SdustScratch *sd, const int8_t *sm_rows, uint8_t *lds, uint32_t lds_bytes) {
     w.P = &P;
+    w.sm_rows = sm_rows;
     carve(w, P, P.arena + (uint64_t)slot * P.arena_stride, lds, lds_bytes);
     w.sd = sd;
     const uint64_t off = P.offsets[read];
@@ -1732,10 +1879,13 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     rr.orientation = 0; rr.stream_off = 0;
     rr.num_matches_fwd = rr.num_matches_rc = rr.n_seeds_fwd = rr.n_seeds_rc = 0; rr.n_extensions = rr.n_columns = 0;
 
+    for (int x = 0; x < 8; ++x) { w.cyc[x] = 0; w.xcyc[x] = 0; }
+    const uint64_t tstart = cycle_clock();
     if (w.L > (int32_t)P.lim.Lmax) {
         w.status = ST_CAPACITY;
     } else {
         prepare_query(w, P.seqs + off);
+        w.cyc[0] = cycle_clock() - tstart;
         for (int s = 0; s < 2; ++s) {
             w.ext[s].q = w.q[s];
             w.ext[s].psum = w.psum[s];
@@ -1748,6 +1898,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         for (int s = 0; s < 2; ++s) w.ext[s].conv.gen = w.gen_store[s];
         const bool have_rc = P.cfg.fwd_and_rc != 0;
         // build_seeders (:193-248)
+        const uint64_t tseed = cycle_clock();
         make_seeder(w, 0);
         if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[0]) { w.n_seeds[0] = 0; w.num_matching[0] = 0; }
         if (have_rc && w.status == ST_OK) {
@@ -1764,6 +1915,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
                     P.dbg_seeds[((uint64_t)read * 2 + s) * P.lim.max_seeds + i] = w.seeds[s][i];
         }
         wave_sync();
+        w.cyc[1] = cycle_clock() - tseed;
+        const uint64_t tdrv = cycle_clock();
         if (w.status == ST_OK) {
             if (have_rc) {
                 // align_both_directions (:738-755)
@@ -1781,7 +1934,9 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         }
         for (int s = 0; s < 2; ++s) w.gen_store[s] = w.ext[s].conv.gen;
         wave_sync();
+        w.cyc[4] = cycle_clock() - tdrv - w.cyc[2] - w.cyc[3];
     }
+    const uint64_t tout = cycle_clock();
 
     rr.status = w.status;
     rr.n_extensions = w.n_extensions; rr.n_columns = w.n_columns;
@@ -1827,6 +1982,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     stats_accum->extensions += w.n_extensions;
     stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
     stats_accum->capacity_errors += rr.status != ST_OK;
+    w.cyc[5] = cycle_clock() - tout;
+    for (int x = 0; x < 8; ++x) { stats_accum->cyc[x] += w.cyc[x]; stats_accum->xcyc[x] += w.xcyc[x]; }
 }
 
 } // namespace mgx

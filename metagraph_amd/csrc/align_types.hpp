@@ -53,6 +53,8 @@ struct DevSeed {             // Seed (alignment.hpp:32-98); full seeds reference
 
 struct KernelStats {
     unsigned long long rank_lines, select_lines, bit_lines, columns, extensions, seeds, capacity_errors, map_lines;
+    unsigned long long xcyc[8];     // extend() breakdown
+    unsigned long long cyc[8];      // shader cycles per phase: prepare, seeding, extend, backtrack, driver rest, output
 };
 
 struct AlignParams {

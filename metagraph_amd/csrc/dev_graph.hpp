@@ -33,6 +33,9 @@ struct DevGraph {
     const uint32_t *firstc;        // first character code of every edge's k-mer, 8 nibbles per word
     const uint64_t *terminus;      // MEM-terminus bit per node (aligner_seeder_methods.hpp:121-125)
     const uint64_t *valid;         // node mask or nullptr (dbg_succinct.cpp:934-936)
+    const uint2 *prefix_tbl;       // [4^prefix_len] edge range (rl, ru) of nodes whose suffix spells the key;
+                                   // the device form of BOSS's suffix-range index (boss.hpp:645-663, boss.cpp:3177-3219)
+    uint32_t prefix_len;           // 0 = no table
     uint64_t n;                    // number of edges
     uint32_t n_blocks;
     uint32_t k;                    // DBG k
@@ -250,6 +253,14 @@ MGX_DEV bool tighten_range(const DevGraph &g, uint64_t *rl, uint64_t *ru, uint32
     *rl = select_last(g, g.NF[s] + rk_rl - 1, ctr) + 1;
     *ru = select_last(g, g.NF[s] + rk_ru, ctr);
     return true;
+}
+
+// get_initial_range through the suffix-range table (boss.hpp:645-663): codes[0..prefix_len) must all be
+// in 1..4.  Key = first char least significant, exactly the reference's co-lex index.
+MGX_DEV void prefix_range(const DevGraph &g, uint32_t key, uint64_t *rl, uint64_t *ru, LineCtr &ctr) {
+    ++ctr.bit_lines;
+    uint2 r = g.prefix_tbl[key];
+    *rl = r.x; *ru = r.y;
 }
 
 MGX_DEV void initial_range(const DevGraph &g, uint32_t s, uint64_t *rl, uint64_t *ru) {   // boss.hpp:665-677

@@ -64,6 +64,29 @@ MGX_DEV uint32_t build_parent(const DevGraph &g, uint64_t e) {
     return (uint32_t)bwd(g, e, ctr);
 }
 
+// Suffix keys for the prefix table: after round r, D[e] is the node character r positions from the end.
+// key[e] accumulates (D - 1) << 2 * (m - 1 - r); bit 31 marks a '$' inside the last m characters.
+MGX_DEV uint32_t build_key_step(uint32_t key, uint32_t d, uint32_t m, uint32_t r) {
+    if (d == 0) return key | 0x80000000u;
+    return key | ((d - 1) << (2 * (m - 1 - r)));
+}
+
+// table boundaries: edges with equal keys are contiguous (co-lex order)
+MGX_DEV void build_prefix_entry(const uint32_t *key, uint64_t e, uint64_t n, uint2 *tbl) {
+    uint32_t k0 = key[e];
+    if (k0 & 0x80000000u) return;
+    if (e == 1 || key[e - 1] != k0) tbl[k0].x = (uint32_t)e;
+    if (e == n || key[e + 1] != k0) tbl[k0].y = (uint32_t)e;
+}
+
+MGX_HD uint32_t choose_prefix_len(uint64_t n_edges, uint32_t k) {
+    // ~log4(n) + 1 characters resolve a range to O(1) nodes; cap at 12 (134 MB) like the reference's default
+    uint32_t m = 2;
+    while (m < 12 && (1ull << (2 * (m - 1))) < n_edges) ++m;
+    if (m > k - 1) m = k - 1;
+    return m;
+}
+
 // MEM terminus bit: has_multiple_outgoing(v) || !has_single_incoming(v) (aligner_seeder_methods.hpp:121-125)
 MGX_DEV bool build_terminus(const DevGraph &g, uint64_t v) {
     if (v == 0 || v > g.n) return false;
@@ -103,9 +126,17 @@ MGX_DEV void map_chain(const DevGraph &g, const char *seq, int32_t L, int strand
         } else {
             // map_to_edge: index(k - 1 codes) then pick_edge (boss.hpp:696-718,766-777)
             uint64_t rl, ru;
-            initial_range(g, strand_code(seq, L, strand, i), &rl, &ru);
+            int32_t t0 = 1;
+            if (g.prefix_len && (int32_t)g.prefix_len <= k - 1) {
+                uint32_t key = 0;
+                for (uint32_t j = 0; j < g.prefix_len; ++j) key |= (strand_code(seq, L, strand, i + (int32_t)j) - 1) << (2 * j);
+                prefix_range(g, key, &rl, &ru, ctr);
+                t0 = (int32_t)g.prefix_len;
+            } else {
+                initial_range(g, strand_code(seq, L, strand, i), &rl, &ru);
+            }
             bool ok = rl <= ru;
-            for (int32_t t = 1; ok && t < k - 1; ++t)
+            for (int32_t t = t0; ok && t < k - 1; ++t)
                 ok = tighten_range(g, &rl, &ru, strand_code(seq, L, strand, i + t), ctr);
             if (ok) {
                 ++ctr.rank_lines;

@@ -42,6 +42,21 @@ __global__ void k_gather(const uint32_t *P, const uint8_t *Din, uint8_t *Dout, u
     if (e <= n) Dout[e] = Din[P[e]];
 }
 
+__global__ void k_key_step(const uint8_t *D, uint32_t *key, uint64_t n, uint32_t m, uint32_t r) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e <= n) key[e] = build_key_step(r ? key[e] : 0u, D[e], m, r);
+}
+
+__global__ void k_prefix_init(uint2 *tbl, uint64_t entries) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < entries) tbl[i] = make_uint2(1u, 0u);        // empty range (rl > ru)
+}
+
+__global__ void k_prefix_fill(const uint32_t *key, uint64_t n, uint2 *tbl) {
+    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 1 && e <= n) build_prefix_entry(key, e, n, tbl);
+}
+
 __global__ void k_pack_firstc(const uint8_t *D, uint32_t *firstc, uint64_t n) {
     uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi * 8 <= n) {
@@ -122,16 +137,18 @@ __global__ void __launch_bounds__(64, MGX_ALIGN_WAVES_PER_SIMD) k_align(AlignPar
     Wave w;
 #endif
     __shared__ SdustScratch sd;
+    __shared__ int8_t sm_rows[6 * 128];
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     KernelStats acc;
     memset(&acc, 0, sizeof(acc));
+    load_score_rows(P, sm_rows);
     for (;;) {
         LV<uint64_t> rv;
         rv.v = 0;
         if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
         uint64_t read = wave_bcast(rv, 0);
         if (read >= P.n_reads) break;
-        align_read(w, P, read, slot, &acc, &sd, dyn_lds, lds_bytes);
+        align_read(w, P, read, slot, &acc, &sd, sm_rows, dyn_lds, lds_bytes);
     }
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);
@@ -141,6 +158,7 @@ __global__ void __launch_bounds__(64, MGX_ALIGN_WAVES_PER_SIMD) k_align(AlignPar
         atomicAdd(&P.stats->extensions, acc.extensions);
         atomicAdd(&P.stats->seeds, acc.seeds);
         atomicAdd(&P.stats->capacity_errors, acc.capacity_errors);
+        for (int x = 0; x < 8; ++x) { atomicAdd(&P.stats->cyc[x], acc.cyc[x]); atomicAdd(&P.stats->xcyc[x], acc.xcyc[x]); }
     }
 }
 
@@ -186,7 +204,7 @@ struct DevBuf {
 struct mgx_graph {
     int device = 0;
     DevGraph g;
-    DevBuf blocks, last_hint, w_hint[4], firstc, terminus, valid;
+    DevBuf blocks, last_hint, w_hint[4], firstc, terminus, valid, prefix_tbl;
     uint64_t bytes = 0;
 };
 
@@ -366,11 +384,24 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
         k_parent<<<nb, 256>>>(g, P.as<uint32_t>(), D0.as<uint8_t>());
         HIP_TRY(hipGetLastError());
         uint8_t *din = D0.as<uint8_t>(), *dout = D1.as<uint8_t>();
+        // suffix-range table over the last m node characters, accumulated during the same rounds
+        const uint32_t m = choose_prefix_len(n, g.k);
+        DevBuf key;
+        if (int rc = key.ensure((n + 1) * 4)) return rc;
+        const uint64_t entries = 1ull << (2 * m);
+        if (int rc = G->prefix_tbl.ensure(entries * sizeof(uint2))) return rc;
+        k_prefix_init<<<(uint32_t)((entries + 255) / 256), 256>>>(G->prefix_tbl.as<uint2>(), entries);
+        k_key_step<<<nb, 256>>>(din, key.as<uint32_t>(), n, m, 0);
         for (uint32_t r = 0; r + 2 < g.k; ++r) {
             k_gather<<<nb, 256>>>(P.as<uint32_t>(), din, dout, n);
             std::swap(din, dout);
+            if (r + 1 < m) k_key_step<<<nb, 256>>>(din, key.as<uint32_t>(), n, m, r + 1);
         }
         HIP_TRY(hipGetLastError());
+        k_prefix_fill<<<nb, 256>>>(key.as<uint32_t>(), n, G->prefix_tbl.as<uint2>());
+        HIP_TRY(hipGetLastError());
+        g.prefix_tbl = G->prefix_tbl.as<uint2>();
+        g.prefix_len = m;
         if (int rc = G->firstc.ensure(((n + 1 + 7) / 8) * 4 + 4)) return rc;
         k_pack_firstc<<<(uint32_t)(((n + 8) / 8 + 255) / 256), 256>>>(din, G->firstc.as<uint32_t>(), n);
         HIP_TRY(hipGetLastError());
@@ -383,7 +414,7 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
     k_terminus<<<n_blocks, 64>>>(g, G->terminus.as<uint64_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    G->bytes = G->blocks.bytes + G->last_hint.bytes + G->firstc.bytes + G->terminus.bytes + G->valid.bytes;
+    G->bytes = G->blocks.bytes + G->last_hint.bytes + G->firstc.bytes + G->terminus.bytes + G->valid.bytes + G->prefix_tbl.bytes;
     for (int c = 0; c < 4; ++c) G->bytes += G->w_hint[c].bytes;
     *out = guard.release();
     return MGX_OK;
@@ -541,7 +572,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
     HIP_TRY(hipEventRecord(A->ev[2], 0));
     // latency-critical scalar arrays go to LDS when they fit next to the other resident waves of the CU
-    uint32_t lds_budget = (160u * 1024u) / (4 * MGX_ALIGN_WAVES_PER_SIMD) - 2048u;
+    uint32_t lds_budget = (160u * 1024u) / (4 * MGX_ALIGN_WAVES_PER_SIMD) - 3072u;   // minus static LDS (Wave, sdust, score rows)
     uint32_t lds_bytes = std::min<uint32_t>(fast_lds_bytes(l.Lmax), lds_budget) & ~15u;
     k_align<<<(uint32_t)slots, 64, lds_bytes>>>(P, lds_bytes);
     HIP_TRY(hipGetLastError());
@@ -559,6 +590,7 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     s.n_rank_lines = ks.rank_lines; s.n_select_lines = ks.select_lines; s.n_bit_lines = ks.bit_lines;
     s.n_columns = ks.columns; s.n_extensions = ks.extensions; s.n_seeds = ks.seeds;
     s.n_map_lines = ks.map_lines; s.n_capacity_errors = ks.capacity_errors;
+    for (int x = 0; x < 8; ++x) { s.phase_cycles[x] = ks.cyc[x]; s.extend_cycles[x] = ks.xcyc[x]; }
     float ms = 0;
     if (mapped) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[0], A->ev[1])); s.seed_kernel_ms = ms; }
     if (aligned) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[2], A->ev[3])); s.align_kernel_ms = ms; }

@@ -42,7 +42,7 @@ struct LV {
 
 MGX_DEV uint64_t wave_ballot(const LV<bool> &p) { return __ballot(p.v); }
 
-MGX_DEV int32_t shfl_i32(int32_t v, int src) { return __shfl(v, src, WAVE); }
+MGX_DEV int32_t shfl_i32(int32_t v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
 
 template <class T>
 MGX_DEV T wave_bcast(const LV<T> &x, int src) {
@@ -59,43 +59,37 @@ MGX_DEV T wave_bcast(const LV<T> &x, int src) {
 // value of lane (l - 1); lane 0 receives `fill`
 MGX_DEV LV<int32_t> wave_shift_up1(const LV<int32_t> &x, int32_t fill) {
     LV<int32_t> r;
-    int32_t t = __shfl_up(x.v, 1, WAVE);
-    r.v = lane_id() == 0 ? fill : t;
+    r.v = __builtin_amdgcn_update_dpp(fill, x.v, 0x138, 0xF, 0xF, false);     // wave_shr:1, lane 0 keeps `fill`
     return r;
 }
 
-// inclusive prefix max over lanes
+// inclusive prefix max over lanes: 4 row-shift DPP steps inside each row of 16, then row_bcast:15 and
+// row_bcast:31 carry the row totals across rows (the classic GCN/CDNA wave64 scan; no LDS traffic)
+#define MGX_DPP_MAX(v, ctrl, rmask, bmask)                                                          \
+    { int32_t t_ = __builtin_amdgcn_update_dpp(INT32_MIN, v, ctrl, rmask, bmask, false); v = t_ > v ? t_ : v; }
 MGX_DEV LV<int32_t> wave_prefix_max(const LV<int32_t> &x) {
     int32_t v = x.v;
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int32_t t = __shfl_up(v, d, WAVE);
-        if (l >= d) v = t > v ? t : v;
-    }
+    MGX_DPP_MAX(v, 0x111, 0xF, 0xF)      // row_shr:1
+    MGX_DPP_MAX(v, 0x112, 0xF, 0xF)      // row_shr:2
+    MGX_DPP_MAX(v, 0x114, 0xF, 0xF)      // row_shr:4
+    MGX_DPP_MAX(v, 0x118, 0xF, 0xF)      // row_shr:8
+    MGX_DPP_MAX(v, 0x142, 0xA, 0xF)      // row_bcast:15 -> rows 1 and 3
+    MGX_DPP_MAX(v, 0x143, 0xC, 0xF)      // row_bcast:31 -> rows 2 and 3
     LV<int32_t> r;
     r.v = v;
     return r;
 }
 
 MGX_DEV int32_t wave_max(const LV<int32_t> &x) {
-    int32_t v = x.v;
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) {
-        int32_t t = __shfl_xor(v, d, WAVE);
-        v = t > v ? t : v;
-    }
-    return v;
+    LV<int32_t> p = wave_prefix_max(x);
+    return __builtin_amdgcn_readlane(p.v, 63);
 }
 
 MGX_DEV int32_t wave_min(const LV<int32_t> &x) {
-    int32_t v = x.v;
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) {
-        int32_t t = __shfl_xor(v, d, WAVE);
-        v = t < v ? t : v;
-    }
-    return v;
+    LV<int32_t> n;
+    n.v = ~x.v;                              // min(x) == ~max(~x) in two's complement
+    LV<int32_t> p = wave_prefix_max(n);
+    return ~__builtin_amdgcn_readlane(p.v, 63);
 }
 
 MGX_DEV uint64_t wave_max_u64(const LV<uint64_t> &x) {
@@ -145,6 +139,7 @@ MGX_DEV uint64_t uni(uint64_t x) {
 MGX_DEV int64_t uni(int64_t x) { return (int64_t)uni((uint64_t)x); }
 MGX_DEV bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int32_t)x) != 0; }
 
+MGX_DEV uint64_t cycle_clock() { return __builtin_readcyclecounter(); }
 MGX_DEV int popc64(uint64_t x) { return __popcll(x); }
 MGX_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }           // x != 0
 MGX_DEV int clz64(uint64_t x) { return __clzll((long long)x); }                // x != 0

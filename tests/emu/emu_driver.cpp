@@ -21,6 +21,7 @@ struct EmuGraph {
     std::vector<Block> blocks;
     std::vector<uint32_t> last_hint, w_hint[4], firstc;
     std::vector<uint64_t> terminus, valid;
+    std::vector<uint2> prefix_tbl;
 };
 
 struct EmuRun {
@@ -68,10 +69,18 @@ void *emu_graph_create(const mgx_boss_view *view) {
     std::vector<uint32_t> P(n + 1);
     std::vector<uint8_t> D0(n + 1), D1(n + 1);
     for (uint64_t e = 0; e <= n; ++e) { P[e] = build_parent(g, e); D0[e] = (uint8_t)node_last_value(g, e); }
+    const uint32_t m = choose_prefix_len(n, g.k);
+    std::vector<uint32_t> key(n + 1, 0);
+    G->prefix_tbl.assign(1ull << (2 * m), uint2{ 1u, 0u });
+    for (uint64_t e = 0; e <= n; ++e) key[e] = build_key_step(0u, D0[e], m, 0);
     for (uint32_t r = 0; r + 2 < g.k; ++r) {
         for (uint64_t e = 0; e <= n; ++e) D1[e] = D0[P[e]];
         D0.swap(D1);
+        if (r + 1 < m) for (uint64_t e = 0; e <= n; ++e) key[e] = build_key_step(key[e], D0[e], m, r + 1);
     }
+    for (uint64_t e = 1; e <= n; ++e) build_prefix_entry(key.data(), e, n, G->prefix_tbl.data());
+    g.prefix_tbl = G->prefix_tbl.data();
+    g.prefix_len = m;
     G->firstc.assign((n + 1 + 7) / 8 + 1, 0);
     for (uint64_t e = 0; e <= n; ++e) G->firstc[e >> 3] |= (uint32_t)(D0[e] & 0xF) << (4 * (e & 7));
     g.firstc = G->firstc.data();
@@ -156,7 +165,9 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     SdustScratch sd;
     // model a small LDS so that both placements (LDS / arena) of the fast arrays are exercised
     std::vector<uint8_t> lds(2048);
-    for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, lds.data(), (uint32_t)lds.size());
+    std::vector<int8_t> rows(6 * 128);
+    load_score_rows(P, rows.data());
+    for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)lds.size());
     R->host.decode(R->results.data(), n, R->stream.data());
     return R;
 }

@@ -24,6 +24,7 @@
 #define __launch_bounds__(...)
 
 struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
 
 namespace mgx {
 
@@ -96,6 +97,7 @@ inline LV<int32_t> wave_prefix_sum_excl(const LV<int32_t> &x) {
 
 inline void wave_sync() {}
 
+inline uint64_t cycle_clock() { return 0; }
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 inline int clz64(uint64_t x) { return __builtin_clzll(x); }
