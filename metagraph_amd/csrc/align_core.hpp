@@ -172,6 +172,7 @@ struct Wave {
     DevSeed *seeds[2];
     uint8_t *alive[2];
     int32_t n_seeds[2];
+    int32_t lc_any[2];           // whole-strand sdust verdict: 0 = no maskable interval anywhere, 1 = some, -1 = unknown
     uint32_t num_matching[2];
     // sub-k scratch
     uint16_t *msl, *pos_cnt, *ml;
@@ -443,6 +444,15 @@ MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *
     return have_res;
 }
 
+// Window test with an exact shortcut.  A window is flagged iff it contains an interval (<= 64 words) whose
+// DUST score exceeds T; any such interval also exists in the whole strand, so if sdust on the whole strand
+// masks nothing, no window can be flagged.  Only strands with a masked region pay the per-window runs.
+MGX_DEV bool window_low_complexity(Wave &w, int s, int32_t begin, int32_t len) {
+    if (w.lc_any[s] < 0) w.lc_any[s] = is_low_complexity(w.q[s], w.L, w.sd) ? 1 : 0;
+    if (!w.lc_any[s]) return false;
+    return is_low_complexity(w.q[s] + begin, len, w.sd);
+}
+
 // ------------------------------------------------------------------------------------------------
 // query preparation: AlignmentResults ctor (A/alignment.cpp:1348-1372) + partial sums
 // ------------------------------------------------------------------------------------------------
@@ -529,7 +539,7 @@ MGX_NI_G2 void base_seeds(Wave &w, int s) {
         if (cfg.max_seed_length < (uint32_t)k) return;
         for (int32_t i = 0; i < n; ++i) {
             if (nodes[i]) {
-                if (!cfg.seed_complexity_filter || !is_low_complexity(w.q[s] + i, k, w.sd))
+                if (!cfg.seed_complexity_filter || !window_low_complexity(w, s, i, k))
                     if (!push_seed(w, s, i, k, 0, 1, nodes[i])) return;
             }
         }
@@ -671,16 +681,16 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         if (seed_length < cur_msl) continue;                   // match_size < min_match_length: no callback
         // the complexity filter is evaluated first in the reference (:226-229); it has no side effects, so
         // testing it only for positions that would report a seed is equivalent
-        if (cfg.seed_complexity_filter && is_low_complexity(w.q[s] + i, cur_msl, w.sd)) continue;
+        if (cfg.seed_complexity_filter && window_low_complexity(w, s, i, cur_msl)) continue;
         // enumerate nodes whose suffix matches (dbg_succinct.cpp:349-392)
         uint32_t first_alt = alt_n;
         uint32_t cnt = 0;
         for (uint32_t r = w.rfirst[i]; r <= w.rlast[i]; ++r) {
-            uint64_t e = select_last(g, r, w.ctr);
+            uint64_t e = select_last<true>(g, r, w.ctr);
             uint64_t inc[5];
             uint32_t fc[5];
             // call_incoming_to_target(bwd(e), node_last_value(e)) == parents of the node whose last edge is e
-            int ni = incoming(g, e, inc, fc, w.ctr);
+            int ni = incoming<true>(g, e, inc, fc, w.ctr);
             for (int t = 0; t < ni; ++t) {
                 if (alt_n >= w.P->lim.max_alt) { w.status = ST_CAPACITY; return; }
                 w.alt[alt_n++] = (uint32_t)inc[t];
@@ -1137,27 +1147,27 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
         const uint64_t v = col.node;
         Block cur;
         if ((uint32_t)(v >> 6) == w.blk_cache_idx) cur = w.blk_cache;
-        else { ++w.ctr.rank_lines; cur = load_block(g, (uint32_t)(v >> 6)); }
+        else { ++w.ctr.rank_lines; cur = load_block_uniform(g, uni((uint32_t)(v >> 6))); }
         uint32_t wv = block_W(cur, (int)(v & 63));
         if (v > 1 && wv == 0) return 0;
         Block tgt;
-        uint64_t lst = fwd_from(g, v, cur, wv % SIGMA, tgt, w.ctr);
+        uint64_t lst = fwd_from<true>(g, v, cur, wv % SIGMA, tgt, w.ctr);
         w.blk_cache = tgt;
         w.blk_cache_idx = (uint32_t)(lst >> 6);
-        uint64_t first = pred_last_from(g, lst - 1, ((lst - 1) >> 6) == (lst >> 6) ? tgt : load_block(g, (uint32_t)((lst - 1) >> 6)), w.ctr) + 1;
+        uint64_t first = pred_last_from<true>(g, lst - 1, ((lst - 1) >> 6) == (lst >> 6) ? tgt : load_block_uniform(g, uni((uint32_t)((lst - 1) >> 6))), w.ctr) + 1;
         if (first < 2) first = 2;
         n = 0;
         Block b = tgt;
         uint32_t bi = (uint32_t)(lst >> 6);
         for (uint64_t i = first; i <= lst; ++i) {
-            if ((uint32_t)(i >> 6) != bi) { bi = (uint32_t)(i >> 6); ++w.ctr.rank_lines; b = load_block(g, bi); }
+            if ((uint32_t)(i >> 6) != bi) { bi = (uint32_t)(i >> 6); ++w.ctr.rank_lines; b = load_block_uniform(g, uni(bi)); }
             uint32_t c = block_W(b, (int)(i & 63)) % SIGMA;
             if (c != 0 && in_graph(g, i)) { if (n < 4) { nodes[n] = (uint32_t)i; chars[n] = decode_code(c); scores[n] = 0; } ++n; }
         }
         return n < 4 ? n : 4;
     }
     // RCDBG::call_outgoing_kmers (rc_dbg.hpp:88-99): parents with the complemented first character
-    n = incoming(P.g, col.node, nn, cc, w.ctr);
+    n = incoming<true>(P.g, col.node, nn, cc, w.ctr);
     int m = 0;
     for (int t = 0; t < n; ++t) {
         if (cc[t] == 0) continue;                             // complement('$') == '$' is dropped (:381-384)
@@ -1440,61 +1450,99 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
     const int32_t right_end_bonus = cfg.right_end_bonus;
     const int32_t cap = (int32_t)P.lim.max_path;
     const int32_t tsize = er.table_size;
-    // sort tips (std::sort :758); n_tips is small: insertion sort
-    for (int32_t a = 1; a < er.n_tips; ++a) {
-        uint32_t v = w.tips[a];
-        int32_t b = a - 1;
-        while (b >= 0 && w.tips[b] > v) { w.tips[b + 1] = w.tips[b]; --b; }
-        w.tips[b + 1] = v;
-    }
-    // candidate start cells (:815-867)
+    // candidate start cells (:815-867), one table column per lane; the order of `indices` is irrelevant
+    // because the heap pops by the full (unique) tuple
+    // tips as a bitset (prev_starts is cleared per extension and only used from here on; use a second region)
     int32_t n_idx = 0;
-    {
-        int32_t it = 0;
-        for (int32_t i = 1; i < tsize; ++i) {
-            while (it < er.n_tips && (uint32_t)i > w.tips[it]) ++it;
-            const ColMeta col = w.cols[i];
-            if (col.offset < seed_dist) continue;
-            const ColMeta par = w.cols[col.parent];
-            bool is_tip = it < er.n_tips && (uint32_t)i == w.tips[it];
-            for (int pass = 0; pass < 2; ++pass) {
-                int32_t start_pos;
-                if (pass == 0) start_pos = col.max_pos;
-                else {
-                    if (!(col.size + col.trim == window_size + 1 && col.max_pos != last_pos)) break;
-                    start_pos = last_pos;
-                }
-                if (start_pos < par.trim + 1) continue;
-                int32_t pos = start_pos - col.trim, pos_p = start_pos - par.trim - 1;
-                int32_t sv = cell_S(w, col, pos), sp = cell_S(w, par, pos_p);
-                if (sv == NINF || sp == NINF) continue;
-                int32_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
-                if (sv + end_bonus >= min_start_score) {
-                    bool is_match = sv == sp + col.score + profile_at(w, E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos)
-                        && profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos) == OP_MATCH;
-                    if (is_match || start_pos == last_pos || is_tip) {
-                        BtIndex bx;
-                        bx.score = sv + end_bonus; bx.neg_off_diag = -iabs(start_pos - col.offset + seed_offset);
-                        bx.neg_i = -i; bx.pos = start_pos;
-                        w.indices[n_idx++] = bx;
+    for (int32_t base = 1; base < tsize; base += WAVE) {
+        LV<int32_t> cnt;
+        LV<BtIndex> c0, c1;
+        FOR_LANES(l) {
+            int32_t i = base + l;
+            int32_t n = 0;
+            BtIndex b0 = { 0, 0, 0, 0 }, b1 = { 0, 0, 0, 0 };
+            if (i < tsize) {
+                const ColMeta col = w.cols[i];
+                if (col.offset >= seed_dist) {
+                    const ColMeta par = w.cols[col.parent];
+                    bool is_tip = false;
+                    for (int32_t t = 0; t < er.n_tips; ++t) is_tip |= w.tips[t] == (uint32_t)i;
+                    for (int pass = 0; pass < 2; ++pass) {
+                        int32_t start_pos;
+                        if (pass == 0) start_pos = col.max_pos;
+                        else {
+                            if (!(col.size + col.trim == window_size + 1 && col.max_pos != last_pos)) break;
+                            start_pos = last_pos;
+                        }
+                        if (start_pos < par.trim + 1) continue;
+                        int32_t pos = start_pos - col.trim, pos_p = start_pos - par.trim - 1;
+                        int32_t sv = cell_S(w, col, pos), sp = cell_S(w, par, pos_p);
+                        if (sv == NINF || sp == NINF) continue;
+                        int32_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
+                        if (sv + end_bonus >= min_start_score) {
+                            bool is_match = sv == sp + col.score + profile_at(w, E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos)
+                                && profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos) == OP_MATCH;
+                            if (is_match || start_pos == last_pos || is_tip) {
+                                BtIndex bx;
+                                bx.score = sv + end_bonus; bx.neg_off_diag = -iabs(start_pos - col.offset + seed_offset);
+                                bx.neg_i = -i; bx.pos = start_pos;
+                                if (n == 0) b0 = bx; else b1 = bx;
+                                ++n;
+                            }
+                        }
                     }
                 }
             }
+            cnt[l] = n; c0[l] = b0; c1[l] = b1;
         }
+        LV<int32_t> off = wave_prefix_sum_excl(cnt);
+        FOR_LANES(l) {
+            if (cnt[l] > 0) w.indices[n_idx + off[l]] = c0[l];
+            if (cnt[l] > 1) w.indices[n_idx + off[l] + 1] = c1[l];
+        }
+        n_idx += wave_sum(cnt);
     }
     wave_sync();
     bool produced = false;
     int32_t best_score = INT32_MIN;
     int32_t remaining = n_idx;
     while (remaining > 0 && !produced) {        // terminate_backtrack_start: num_alternative_paths == 1
-        // pop the lexicographic maximum (score, -off_diag, -i, pos) (:873-879)
+        // pop the lexicographic maximum (score, -off_diag, -i, pos) (:873-879): four lane-parallel passes
         int32_t bi = 0;
-        for (int32_t x = 1; x < remaining; ++x) {
-            BtIndex a = w.indices[x], b = w.indices[bi];
-            bool gt = a.score != b.score ? a.score > b.score
-                    : a.neg_off_diag != b.neg_off_diag ? a.neg_off_diag > b.neg_off_diag
-                    : a.neg_i != b.neg_i ? a.neg_i > b.neg_i : a.pos > b.pos;
-            if (gt) bi = x;
+        {
+            int32_t m_score = INT32_MIN, m_off = INT32_MIN, m_i = INT32_MIN, m_pos = INT32_MIN;
+            for (int pass = 0; pass < 4; ++pass) {
+                int32_t best = INT32_MIN;
+                for (int32_t base = 0; base < remaining; base += WAVE) {
+                    LV<int32_t> v;
+                    FOR_LANES(l) {
+                        int32_t x = base + l;
+                        int32_t val = INT32_MIN;
+                        if (x < remaining) {
+                            BtIndex a = w.indices[x];
+                            bool ok = (pass < 1 || a.score == m_score) && (pass < 2 || a.neg_off_diag == m_off) && (pass < 3 || a.neg_i == m_i);
+                            if (ok) val = pass == 0 ? a.score : pass == 1 ? a.neg_off_diag : pass == 2 ? a.neg_i : a.pos;
+                        }
+                        v[l] = val;
+                    }
+                    best = imax(best, wave_max(v));
+                }
+                if (pass == 0) m_score = best; else if (pass == 1) m_off = best; else if (pass == 2) m_i = best; else m_pos = best;
+            }
+            for (int32_t base = 0; base < remaining; base += WAVE) {
+                LV<bool> hit;
+                FOR_LANES(l) {
+                    int32_t x = base + l;
+                    bool h = false;
+                    if (x < remaining) {
+                        BtIndex a = w.indices[x];
+                        h = a.score == m_score && a.neg_off_diag == m_off && a.neg_i == m_i && a.pos == m_pos;
+                    }
+                    hit[l] = h;
+                }
+                uint64_t mk = wave_ballot(hit);
+                if (mk) { bi = base + ctz64(mk); break; }
+            }
         }
         BtIndex cur = w.indices[bi];
         w.indices[bi] = w.indices[remaining - 1];
@@ -1885,6 +1933,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         w.status = ST_CAPACITY;
     } else {
         prepare_query(w, P.seqs + off);
+        w.lc_any[0] = w.lc_any[1] = -1;
         w.cyc[0] = cycle_clock() - tstart;
         for (int s = 0; s < 2; ++s) {
             w.ext[s].q = w.q[s];

@@ -45,6 +45,10 @@ struct DevGraph {
 
 struct LineCtr { uint32_t rank_lines, select_lines, bit_lines; };
 
+// U = true: the address is wave-uniform -> scalar load (SMEM), the block lands in SGPRs
+template <bool U>
+MGX_DEV Block load_block_t(const DevGraph &g, uint32_t b);
+
 MGX_DEV Block load_block(const DevGraph &g, uint32_t b) {
     const uint4 *p = reinterpret_cast<const uint4 *>(g.blocks + b);
     uint4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
@@ -58,6 +62,22 @@ MGX_DEV Block load_block(const DevGraph &g, uint32_t b) {
     r.pf = ((uint64_t)a3.w << 32) | a3.z;
     return r;
 }
+
+MGX_DEV Block load_block_uniform(const DevGraph &g, uint32_t b) {
+    u32x16 v = sload_x16(g.blocks + b);
+    Block r;
+    r.cum[0] = v[0]; r.cum[1] = v[1]; r.cum[2] = v[2]; r.cum[3] = v[3];
+    r.last_cum = v[4]; r.cum0 = v[5];
+    r.last_bits = ((uint64_t)v[7] << 32) | v[6];
+    r.p0 = ((uint64_t)v[9] << 32) | v[8];
+    r.p1 = ((uint64_t)v[11] << 32) | v[10];
+    r.p2 = ((uint64_t)v[13] << 32) | v[12];
+    r.pf = ((uint64_t)v[15] << 32) | v[14];
+    return r;
+}
+template <> MGX_DEV Block load_block_t<false>(const DevGraph &g, uint32_t b) { return load_block(g, b); }
+template <> MGX_DEV Block load_block_t<true>(const DevGraph &g, uint32_t b) { return load_block_uniform(g, b); }
+template <bool U> MGX_DEV uint32_t load_hint(const uint32_t *p) { if constexpr (U) return sload_u32(p); else return *p; }
 
 // bits j <= pos
 MGX_DEV uint64_t mask_upto(int pos) { return pos >= 63 ? ~0ull : ((1ull << (pos + 1)) - 1); }
@@ -102,9 +122,10 @@ MGX_DEV bool in_graph(const DevGraph &g, uint64_t v) {              // dbg_succi
     return !g.valid || ((g.valid[v >> 6] >> (v & 63)) & 1);
 }
 
+template <bool U = false>
 MGX_DEV uint32_t get_W(const DevGraph &g, uint64_t i, LineCtr &ctr) {
     ++ctr.rank_lines;
-    Block b = load_block(g, (uint32_t)(i >> 6));
+    Block b = load_block_t<U>(g, (uint32_t)(i >> 6));
     return block_W(b, (int)(i & 63));
 }
 
@@ -115,26 +136,29 @@ MGX_DEV uint32_t block_rank_W(const Block &b, int j, uint32_t c, bool first_bloc
     return (c ? b.cum[c - 1] : b.cum0) + (uint32_t)popc64(m);
 }
 
+template <bool U = false>
 MGX_DEV uint32_t rank_W(const DevGraph &g, uint64_t i, uint32_t c, LineCtr &ctr) {
     if (i == 0) return 0;
     ++ctr.rank_lines;
-    Block b = load_block(g, (uint32_t)(i >> 6));
+    Block b = load_block_t<U>(g, (uint32_t)(i >> 6));
     return block_rank_W(b, (int)(i & 63), c, (i >> 6) == 0);
 }
 
+template <bool U = false>
 MGX_DEV uint32_t rank_last(const DevGraph &g, uint64_t i, LineCtr &ctr) {       // boss.cpp:577-581
     if (i == 0) return 0;
     ++ctr.rank_lines;
-    Block b = load_block(g, (uint32_t)(i >> 6));
+    Block b = load_block_t<U>(g, (uint32_t)(i >> 6));
     return b.last_cum + (uint32_t)popc64(b.last_bits & mask_upto((int)(i & 63)));
 }
 
 // select_last (boss.cpp:588-592): also returns the block that holds the answer
+template <bool U = false>
 MGX_DEV uint64_t select_last_blk(const DevGraph &g, uint32_t r, Block &b, LineCtr &ctr) {
-    uint32_t bi = g.last_hint[(r - 1) >> 6];
+    uint32_t bi = load_hint<U>(g.last_hint + ((r - 1) >> 6));
     for (;;) {
         ++ctr.select_lines;
-        b = load_block(g, bi);
+        b = load_block_t<U>(g, bi);
         uint32_t c = (uint32_t)popc64(b.last_bits);
         if (b.last_cum + c >= r) break;
         ++bi;
@@ -142,18 +166,20 @@ MGX_DEV uint64_t select_last_blk(const DevGraph &g, uint32_t r, Block &b, LineCt
     return ((uint64_t)bi << 6) + (uint32_t)select64(b.last_bits, (int)(r - b.last_cum));
 }
 
+template <bool U = false>
 MGX_DEV uint64_t select_last(const DevGraph &g, uint32_t r, LineCtr &ctr) {
     if (r == 0) return 0;
     Block b;
-    return select_last_blk(g, r, b, ctr);
+    return select_last_blk<U>(g, r, b, ctr);
 }
 
 // position of the r-th unflagged c in W (wavelet_tree::select as used by boss.cpp:635); c in 1..4
+template <bool U = false>
 MGX_DEV uint64_t select_W(const DevGraph &g, uint32_t c, uint32_t r, LineCtr &ctr) {
-    uint32_t bi = g.w_hint[c - 1][(r - 1) >> 6];
+    uint32_t bi = load_hint<U>(g.w_hint[c - 1] + ((r - 1) >> 6));
     for (;;) {
         ++ctr.select_lines;
-        Block b = load_block(g, bi);
+        Block b = load_block_t<U>(g, bi);
         uint64_t m = code_mask(b, c) & ~b.pf;
         uint32_t cnt = (uint32_t)popc64(m);
         if (b.cum[c - 1] + cnt >= r)
@@ -163,6 +189,7 @@ MGX_DEV uint64_t select_W(const DevGraph &g, uint32_t c, uint32_t r, LineCtr &ct
 }
 
 // last set bit of `last` in [1..i], 0 if none (boss.cpp:598-607); blk = loaded block of i
+template <bool U = false>
 MGX_DEV uint64_t pred_last_from(const DevGraph &g, uint64_t i, const Block &blk, LineCtr &ctr) {
     if (i == 0) return 0;
     uint64_t m = blk.last_bits & mask_upto((int)(i & 63));
@@ -172,7 +199,7 @@ MGX_DEV uint64_t pred_last_from(const DevGraph &g, uint64_t i, const Block &blk,
         if (bi == 0) return 0;
         --bi;
         ++ctr.rank_lines;
-        b = load_block(g, bi);
+        b = load_block_t<U>(g, bi);
         m = b.last_bits;
     }
     return ((uint64_t)bi << 6) + (uint32_t)(63 - clz64(m));
@@ -210,10 +237,11 @@ MGX_DEV uint32_t node_last_value(const DevGraph &g, uint64_t i) {       // boss.
 
 // fwd(i, c) = select_last(NF[c] + rank_W(i, c)) (boss.cpp:642-652); cur = loaded block of i.
 // Returns the target's last edge and its block.
+template <bool U = false>
 MGX_DEV uint64_t fwd_from(const DevGraph &g, uint64_t i, const Block &cur, uint32_t c, Block &tgt, LineCtr &ctr) {
     uint32_t r = g.NF[c] + block_rank_W(cur, (int)(i & 63), c, (i >> 6) == 0);
     if (r == 0) { tgt = cur; return 0; }
-    return select_last_blk(g, r, tgt, ctr);
+    return select_last_blk<U>(g, r, tgt, ctr);
 }
 
 MGX_DEV uint64_t fwd(const DevGraph &g, uint64_t i, uint32_t c, LineCtr &ctr) {
@@ -238,11 +266,12 @@ MGX_DEV uint64_t pick_edge_from(const DevGraph &g, uint64_t edge, Block &blk, ui
 }
 
 // bwd (boss.cpp:623-636)
+template <bool U = false>
 MGX_DEV uint64_t bwd(const DevGraph &g, uint64_t i, LineCtr &ctr) {
-    uint32_t target_node = rank_last(g, i - 1, ctr) + 1;
+    uint32_t target_node = rank_last<U>(g, i - 1, ctr) + 1;
     if (target_node == 1) return 1;
     uint32_t c = node_last_value(g, i);
-    return select_W(g, c, target_node - g.NF[c], ctr);
+    return select_W<U>(g, c, target_node - g.NF[c], ctr);
 }
 
 // tighten_range (boss.hpp:682-693)
@@ -299,8 +328,9 @@ MGX_DEV uint32_t first_char(const DevGraph &g, uint64_t e, LineCtr &ctr) {
 // Parents of v with the first character of each parent k-mer, in the order of
 // BOSS::call_incoming_to_target (boss.cpp:766-786) as used by NodeFirstCache::call_incoming_kmers
 // (graph_extensions/node_first_cache.cpp:38-52).  Up to 5 parents ($ACGT first chars).
+template <bool U = false>
 MGX_DEV int incoming(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *first_codes, LineCtr &ctr) {
-    uint64_t x = bwd(g, v, ctr);
+    uint64_t x = bwd<U>(g, v, ctr);
     uint32_t d = node_last_value(g, v);
     int n = 0;
     if (in_graph(g, x)) { nodes[n] = x; first_codes[n] = first_char(g, x, ctr); ++n; }
@@ -309,7 +339,7 @@ MGX_DEV int incoming(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *f
     uint32_t bi = (uint32_t)(pos >> 6);
     while (pos <= g.n) {
         ++ctr.rank_lines;
-        Block b = load_block(g, bi);
+        Block b = load_block_t<U>(g, bi);
         uint64_t from = ~(mask_upto((int)(pos & 63)) >> 1);          // bits >= pos & 63
         uint64_t cm = code_mask(b, d) & from;
         if (bi == g.n_blocks - 1 && ((g.n + 1) & 63)) cm &= mask_upto((int)(g.n & 63));

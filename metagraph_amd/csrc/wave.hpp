@@ -139,6 +139,29 @@ MGX_DEV uint64_t uni(uint64_t x) {
 MGX_DEV int64_t uni(int64_t x) { return (int64_t)uni((uint64_t)x); }
 MGX_DEV bool uni(bool x) { return __builtin_amdgcn_readfirstlane((int32_t)x) != 0; }
 
+// Wave-uniform loads through the scalar data cache: one SMEM instruction, result in SGPRs, so that all
+// arithmetic on it is issued by the scalar unit instead of 64 redundant vector lanes.  Only for
+// read-only data (the graph) at wave-uniform addresses.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+MGX_DEV uint64_t sgpr_addr(const void *p) {
+    uint64_t a = (uint64_t)p;
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)a);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)(uint32_t)(a >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+MGX_DEV u32x16 sload_x16(const void *p) {
+    u32x16 v;
+    uint64_t a = sgpr_addr(p);
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(a) : "memory");
+    return v;
+}
+MGX_DEV uint32_t sload_u32(const uint32_t *p) {
+    uint32_t v;
+    uint64_t a = sgpr_addr(p);
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(a) : "memory");
+    return v;
+}
+
 MGX_DEV uint64_t cycle_clock() { return __builtin_readcyclecounter(); }
 MGX_DEV int popc64(uint64_t x) { return __popcll(x); }
 MGX_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }           // x != 0

@@ -97,6 +97,9 @@ inline LV<int32_t> wave_prefix_sum_excl(const LV<int32_t> &x) {
 
 inline void wave_sync() {}
 
+typedef struct { uint32_t v[16]; uint32_t operator[](int i) const { return v[i]; } } u32x16;
+inline u32x16 sload_x16(const void *p) { u32x16 r; memcpy(r.v, p, 64); return r; }
+inline uint32_t sload_u32(const uint32_t *p) { return *p; }
 inline uint64_t cycle_clock() { return 0; }
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }

@@ -182,3 +182,32 @@ def test_unit_kats_through_kernels(case):
         if extend:
             cfg.max_seed_length = capi.UINT64_MAX
         compare_full(g, eg, cfg, [case["query"]], limits=BIG)
+
+
+def test_sdust_whole_read_shortcut_is_sound():
+    """window_low_complexity() skips per-window sdust when the whole strand masks nothing: check the
+    implication (whole clean => every window clean) on the oracle's sdust over many repeat-rich strings."""
+    rng = random.Random(11)
+    Lo = orc.L()
+    n_clean = 0
+    for t in range(600):
+        mode = rng.random()
+        if mode < 0.4:
+            s = rand_seq(rng, 150)
+        elif mode < 0.7:      # short tandem repeats embedded in random sequence
+            unit = rand_seq(rng, rng.randrange(1, 7))
+            rep = (unit * 30)[:rng.randrange(6, 26)]
+            p = rng.randrange(0, 120)
+            s = rand_seq(rng, p) + rep + rand_seq(rng, 150 - p - len(rep))
+        else:                 # biased composition
+            s = "".join(rng.choice("AAAAACGT") for _ in range(150))
+        if rng.random() < 0.2:
+            s = s[:70] + "N" + s[71:]
+        b = s.encode()
+        if Lo.orc_is_low_complexity(b, len(b)):
+            continue
+        n_clean += 1
+        for wl in (19, 25, 31):
+            for i in range(0, len(s) - wl + 1):
+                assert not Lo.orc_is_low_complexity(b[i:i + wl], wl), (s, i, wl)
+    assert n_clean > 100
