@@ -174,6 +174,7 @@ def main():
     Fc = (C.c_uint64 * 5)(*[int(x) for x in boss["F"]])
     view.F = C.cast(Fc, C.POINTER(C.c_uint64))
     og = orc.Graph(orc.L().orc_graph_from_boss(C.byref(view)))
+    orc.L().orc_graph_build_first_chars(og.h, os.cpu_count() or 1)      # NodeFirstCache stand-in (one-off, untimed)
     ns = min(args.parity_sample, args.reads)
     sample = [bytes(r) for r in reads[:ns].cpu().numpy()]
     got, status = A.align_batch(sample)

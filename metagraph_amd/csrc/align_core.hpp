@@ -101,6 +101,16 @@ struct ColMeta {                 // DPTColumn minus the vectors (aligner_extende
     uint32_t cap3;               // S.capacity()+E.capacity()+F.capacity() of the reference's vectors
 };
 
+// all lanes hold the same metadata; moving it to scalar registers makes every dependent branch and
+// address computation scalar
+MGX_DEV ColMeta uni_col(const ColMeta &c) {
+    ColMeta r;
+    r.node = uni(c.node); r.parent = uni(c.parent); r.offset = uni(c.offset); r.max_pos = uni(c.max_pos);
+    r.trim = uni(c.trim); r.size = uni(c.size); r.score = uni(c.score); r.cells = uni(c.cells);
+    r.c = uni(c.c); r.cap3 = uni(c.cap3);
+    return r;
+}
+
 struct BtIndex { int32_t score, neg_off_diag, neg_i, pos; };
 
 struct ConvSlot { uint32_t gen, idx; };
@@ -764,19 +774,27 @@ MGX_DEV uint32_t conv_hash(uint64_t key, uint32_t mask) {
 
 // returns entry index or -1; *slot_out = slot where the key would be inserted
 MGX_DEV int32_t conv_find(const ConvChecker &c, uint32_t mask, uint64_t key, uint32_t *slot_out) {
+    key = uni(key);
+    mask = uni(mask);
+    const ConvSlot *slots = (const ConvSlot *)uni((uint64_t)c.slots);
+    const ConvEntry *entries = (const ConvEntry *)uni((uint64_t)c.entries);
+    const uint32_t gen = uni(c.gen);
     uint32_t h = conv_hash(key, mask);
     for (;;) {
-        ConvSlot sl = c.slots[h];
-        if (sl.gen != c.gen) { *slot_out = h; return -1; }
-        if (c.entries[sl.idx].key == key) { *slot_out = h; return (int32_t)sl.idx; }
+        ConvSlot sl = slots[h];
+        if (uni(sl.gen) != gen) { *slot_out = h; return -1; }
+        const uint32_t idx = uni(sl.idx);
+        if (uni(entries[idx].key) == key) { *slot_out = h; return (int32_t)idx; }
         h = (h + 1) & mask;
     }
 }
 
 MGX_DEV int32_t conv_insert(Wave &w, ConvChecker &c, uint32_t slot, uint64_t key, int32_t start, int32_t len) {
-    uint32_t cap = w.P->lim.max_columns + w.P->lim.max_path;
-    if (c.n_entries >= cap || c.n_entries * 2 >= w.P->lim.hash_size) { w.status = ST_CAPACITY; return -1; }
-    uint32_t idx = c.n_entries++;
+    uint32_t cap = uni(w.P->lim.max_columns + w.P->lim.max_path);
+    const uint32_t ne = uni(c.n_entries);
+    if (ne >= cap || ne * 2 >= uni(w.P->lim.hash_size)) { w.status = ST_CAPACITY; return -1; }
+    uint32_t idx = ne;
+    c.n_entries = ne + 1;
     ConvEntry e; e.key = key; e.start = start; e.len = len;
     c.entries[idx] = e;
     ConvSlot sl; sl.gen = c.gen; sl.idx = idx;
@@ -807,14 +825,17 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         return m;
     };
     if (node == 0) return column_max();
-    uint64_t key = (uint64_t)node + (E.rc_view ? P.g.n : 0);
-    uint32_t mask = P.lim.hash_size - 1, slot;
-    int32_t idx = conv_find(E.conv, mask, key, &slot);
-    const int32_t Lq = (int32_t)P.lim.Lmax;
+    node = uni(node); query_start = uni(query_start); size = uni(size);
+    s_cells = (const int32_t *)uni((uint64_t)s_cells);
+    uint64_t key = (uint64_t)node + (uni(E.rc_view) ? uni(P.g.n) : 0);
+    uint32_t mask = uni(P.lim.hash_size) - 1, slot;
+    int32_t idx = uni(conv_find(E.conv, mask, key, &slot));
+    slot = uni(slot);
+    const int32_t Lq = (int32_t)uni(P.lim.Lmax);
     if (idx < 0) {
-        idx = conv_insert(w, E.conv, slot, key, query_start, size);
+        idx = uni(conv_insert(w, E.conv, slot, key, query_start, size));
         if (idx < 0) return NINF;
-        int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
+        int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
         for (int32_t base = 0; base < size; base += WAVE) {
             FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[j]; }
         }
@@ -822,8 +843,8 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         return column_max();
     }
     ConvEntry e = E.conv.entries[idx];
-    int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
-    int32_t start = e.start, len = e.len;
+    int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
+    int32_t start = uni(e.start), len = uni(e.len);
     if (query_start + size <= start) {
         fill_range(vec, query_start + size, start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
@@ -955,6 +976,8 @@ MGX_DEV void tier_set(uint64_t *lds, uint64_t *arena, int32_t i, uint64_t v) { i
 // The frontier (std::priority_queue<TableIt>, :477-487) is kept as an ascending sorted array (keys are
 // unique), so the maximum is at the back.  Insert = lane-parallel rank + shift.
 MGX_DEV void frontier_insert(Wave &w, int32_t &qn, uint64_t key) {
+    key = uni(key);
+    qn = uni(qn);
     int32_t pos = 0;
     for (int32_t base = 0; base < qn; base += WAVE) {
         LV<bool> lt;
@@ -998,9 +1021,11 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
 }
 
 // write a staged column (size + 5 cells) to the arena, S/E/F interleaved; nothing waits on these stores
-MGX_DEV void flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t size) {
-    int32_t *cells = w.cells + cells_off;
-    const int32_t n = size + 5;
+MGX_DEV void flush_column(Wave &w, const Staging &s_, uint32_t cells_off, int32_t size) {
+    int32_t *cells = (int32_t *)uni((uint64_t)(w.cells + cells_off));
+    Staging s;
+    s.S = (int32_t *)uni((uint64_t)s_.S); s.E = (int32_t *)uni((uint64_t)s_.E); s.F = (int32_t *)uni((uint64_t)s_.F); s.col = 0;
+    const int32_t n = uni(size) + 5;
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
@@ -1015,20 +1040,25 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
                                int32_t prev_end, int32_t begin, int32_t size, uint8_t c, int32_t init_score,
                                int32_t offset, int32_t start, int32_t window_size, int32_t xdrop_cutoff) {
     const AlignParams &P = *w.P;
-    const int32_t go = P.cfg.gap_open, ge = P.cfg.gap_ext;
-    const int32_t L = w.L;
-    const Staging &par = w.st[pb];
-    Staging &cur = w.st[cb];
+    const int32_t go = uni(P.cfg.gap_open), ge = uni(P.cfg.gap_ext);
+    const int32_t L = uni(w.L);
+    prev_size = uni(prev_size); prev_trim = uni(prev_trim); prev_end = uni(prev_end); begin = uni(begin);
+    size = uni(size); init_score = uni(init_score); offset = uni(offset); start = uni(start);
+    window_size = uni(window_size); xdrop_cutoff = uni(xdrop_cutoff);
+    Staging par, cur;
+    par.S = (int32_t *)uni((uint64_t)w.st[pb].S); par.E = nullptr; par.F = (int32_t *)uni((uint64_t)w.st[pb].F); par.col = 0;
+    cur.S = (int32_t *)uni((uint64_t)w.st[cb].S); cur.E = (int32_t *)uni((uint64_t)w.st[cb].E);
+    cur.F = (int32_t *)uni((uint64_t)w.st[cb].F); cur.col = 0;
     const int32_t trim = begin;
     const int32_t max_size = window_size + 1 - trim;
-    const int8_t *row = w.sm_rows + encode_char(c) * 128;     // profile_score_[encode(c)] (:38-59)
-    const uint8_t *qq = E.q;
+    const int8_t *row = (const int8_t *)uni((uint64_t)(w.sm_rows + encode_char(c) * 128));   // profile_score_[encode(c)] (:38-59)
+    const uint8_t *qq = (const uint8_t *)uni((uint64_t)E.q);
     // DPTColumn::create: size + 5 cells of ninf (we initialise everything update_column may touch)
     const int32_t init_n = imin(max_size, size) + 8;
     for (int32_t base = 0; base < init_n; base += WAVE) {
         FOR_LANES(l) { int32_t j = base + l; if (j < init_n) { cur.S[j] = NINF; cur.E[j] = NINF; cur.F[j] = NINF; } }
     }
-    cur.col = -1;
+    w.st[cb].col = -1;
     wave_sync();
     const int32_t n_prev = prev_end - trim;                 // update_column's prev_end
     const int32_t n_loop = (n_prev + 3) & ~3;               // lanes computed in blocks of 4
@@ -1082,14 +1112,16 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
     wave_sync();
     if (size > imax(1, n_prev)) {                            // scalar tail (:284-289)
         int32_t j = size - 1;
-        int32_t match = imax(st_S(par, prev_size, dp + j - 1) + init_score + profile_at(w, E.q, L, c, start + trim + j), cur.E[j]);
+        int32_t ap = start + trim + j;
+        int32_t prof = (ap >= 1 && ap <= L) ? (int32_t)row[qq[ap - 1] & 127] : 0;
+        int32_t match = uni(imax(st_S(par, prev_size, dp + j - 1) + init_score + prof, cur.E[j]));
         if (match >= xdrop_cutoff) cur.S[j] = match;
     }
     wave_sync();
     // extend_ins_end
     w.tmp_pushes = 0;
     if (size < max_size) {
-        int32_t ins_score = imax(cur.S[size - 1] + go, cur.E[size - 1] + ge);
+        const int32_t ins_score = uni(imax(cur.S[size - 1] + go, cur.E[size - 1] + ge));
         if (ins_score >= xdrop_cutoff) {
             int32_t n_push = 1;
             int32_t room = max_size - (size + 1);
@@ -1122,10 +1154,10 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
 MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
                           uint32_t *nodes, uint8_t *chars, int32_t *scores) {
     const AlignParams &P = *w.P;
-    const int32_t k = (int32_t)P.g.k;
-    int32_t next_offset = col.offset + 1;
-    int32_t seed_pos = next_offset - seed.offset;
-    bool in_seed = seed_pos >= 0 && seed_pos < seed.seq_len;
+    const int32_t k = (int32_t)uni(P.g.k);
+    const int32_t next_offset = col.offset + 1;
+    const int32_t seed_pos = next_offset - uni(seed.offset);
+    const bool in_seed = seed_pos >= 0 && seed_pos < uni(seed.seq_len);
     if (in_seed && next_offset < k) {
         nodes[0] = seed.nodes[0]; chars[0] = seed.seq[seed_pos]; scores[0] = 0;
         return 1;
@@ -1146,12 +1178,12 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
         const DevGraph &g = P.g;
         const uint64_t v = col.node;
         Block cur;
-        if ((uint32_t)(v >> 6) == w.blk_cache_idx) cur = w.blk_cache;
+        if ((uint32_t)(v >> 6) == uni(w.blk_cache_idx)) cur = uni_block(w.blk_cache);
         else { ++w.ctr.rank_lines; cur = load_block_uniform(g, uni((uint32_t)(v >> 6))); }
         uint32_t wv = block_W(cur, (int)(v & 63));
         if (v > 1 && wv == 0) return 0;
         Block tgt;
-        uint64_t lst = fwd_from<true>(g, v, cur, wv % SIGMA, tgt, w.ctr);
+        const uint64_t lst = uni(fwd_from<true>(g, v, cur, wv % SIGMA, tgt, w.ctr));
         w.blk_cache = tgt;
         w.blk_cache_idx = (uint32_t)(lst >> 6);
         uint64_t first = pred_last_from<true>(g, lst - 1, ((lst - 1) >> 6) == (lst >> 6) ? tgt : load_block_uniform(g, uni((uint32_t)((lst - 1) >> 6))), w.ctr) + 1;
@@ -1182,17 +1214,22 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const DevLimits &lim = P.lim;
+    const int32_t max_columns = (int32_t)uni(lim.max_columns);
+    const uint32_t cell_words = uni(lim.cell_words);
+    const double rel_cutoff = cfg.rel_score_cutoff, max_nodes_per_char = cfg.max_nodes_per_seq_char, max_ram = cfg.max_ram_per_alignment;
     ++w.n_extensions;
     // table.clear(); prev_starts.clear()
     for (uint32_t base = 0; base < (lim.max_columns + 31) / 32; base += WAVE) {
         FOR_LANES(l) { uint32_t j = base + l; if (j < (lim.max_columns + 31) / 32) w.prev_starts[j] = 0; }
     }
-    const int32_t xdrop = cfg.xdrop;                          // added_xdrop == 0
+    const int32_t xdrop = uni(cfg.xdrop);                     // added_xdrop == 0
     int32_t xdrop_cutoff = imax(-xdrop, NINF + 1);
-    const int32_t start = seed.clipping;
-    const int32_t window_size = w.L - start;                  // trim_query_suffix == 0
-    const int32_t partial_sum_offset = E.psum[start + window_size];
-    const int32_t seed_offset = seed.offset - 1;
+    const int32_t start = uni(seed.clipping);
+    const int32_t window_size = uni(w.L) - start;             // trim_query_suffix == 0
+    const int32_t *psum = (const int32_t *)uni((uint64_t)E.psum);
+    const int32_t partial_sum_offset = uni(psum[start + window_size]);
+    const int32_t seed_offset = uni(seed.offset) - 1;
+    const int32_t seed_off = uni(seed.offset), seed_seq_len = uni(seed.seq_len);
     uint32_t cell_top = 0;
     int32_t tsize = 0;
     uint64_t table_size_bytes = 0;
@@ -1268,19 +1305,20 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         w.xcyc[0] += cycle_clock() - tx0;
         while (nn) {
             uint64_t tx1 = cycle_clock();
-            int32_t i = (int32_t)key_idx(tier_get(w.lnn, w.next_nodes, nn - 1));
+            const int32_t i = (int32_t)uni(key_idx(tier_get(w.lnn, w.next_nodes, nn - 1)));
             --nn;
-            const ColMeta col = (i == w.hot_idx) ? w.hot : w.cols[i];
-            const int pb = stage_column(w, i, col);
-            const Staging &par = w.st[pb];
+            const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : w.cols[i]);
+            const int pb = uni(stage_column(w, i, col));
+            Staging par;
+            par.S = (int32_t *)uni((uint64_t)w.st[pb].S); par.E = nullptr; par.F = nullptr; par.col = 0;
             const int32_t next_offset = col.offset + 1;
             const int32_t prev_xdrop_cutoff = xdrop_cutoff;       // global_xdrop: one shared cutoff
-            const bool in_seed = (next_offset - seed.offset) >= 0 && (next_offset - seed.offset) < seed.seq_len;
+            const bool in_seed = (next_offset - seed_off) >= 0 && (next_offset - seed_off) < seed_seq_len;
             // early cut-offs when off the optimal path (:521-547)
-            if (st_S(par, col.size, col.max_pos - col.trim) < best_score) {
+            if (uni(st_S(par, col.size, col.max_pos - col.trim)) < best_score) {
                 double node_counter = (double)tsize;
-                if (node_counter / (double)window_size >= cfg.max_nodes_per_seq_char) { qn = 0; nn = 0; continue; }
-                if ((double)table_size_bytes / 1000000.0 > cfg.max_ram_per_alignment) { qn = 0; nn = 0; continue; }
+                if (node_counter / (double)window_size >= max_nodes_per_char) { qn = 0; nn = 0; continue; }
+                if ((double)table_size_bytes / 1000000.0 > max_ram) { qn = 0; nn = 0; continue; }
             }
             // band within the x-drop cutoff (:549-560)
             int32_t b = col.size, e = 0;
@@ -1301,41 +1339,41 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             uint32_t out_nodes[5];
             uint8_t out_chars[5];
             int32_t out_scores[5];
-            int n_out = call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores);
+            const int n_out = uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
             if (n_out == 0) {
-                if (n_tips < (int32_t)lim.max_columns) w.tips[n_tips++] = (uint32_t)i;
+                if (n_tips < max_columns) w.tips[n_tips++] = (uint32_t)i;
                 continue;
             }
             w.xcyc[2] += cycle_clock() - tx2;
             const int32_t end = imin(prev_end, window_size) + 1;
             const int cb = 1 - pb;
             for (int oi = 0; oi < n_out; ++oi) {
-                const uint32_t next = out_nodes[oi];
-                const uint8_t c = to_upper(out_chars[oi]);
-                const int32_t score = out_scores[oi];
-                if (tsize >= (int32_t)lim.max_columns - 1) { w.status = ST_CAPACITY; res->table_size = 0; return; }
+                const uint32_t next = uni(out_nodes[oi]);
+                const uint8_t c = (uint8_t)uni((uint32_t)to_upper(out_chars[oi]));
+                const int32_t score = uni(out_scores[oi]);
+                if (tsize >= max_columns - 1) { w.status = ST_CAPACITY; res->table_size = 0; return; }
                 int32_t size0 = end - begin;
                 uint32_t need = 3 * (uint32_t)(window_size + 1 - begin + 8);     // the column may grow to the window end
-                if ((uint64_t)cell_top + need > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
+                if ((uint64_t)cell_top + need > cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
                 uint32_t table_cap_before = E.table_cap;
                 if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
                 ++w.n_columns;
                 uint64_t tx3 = cycle_clock();
-                int32_t size = compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
-                                              start, window_size, xdrop_cutoff);
-                const int32_t pushes = w.tmp_pushes;
+                const int32_t size = uni(compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
+                                                        start, window_size, xdrop_cutoff));
+                const int32_t pushes = uni(w.tmp_pushes);
                 uint64_t tx4 = cycle_clock();
                 w.xcyc[3] += tx4 - tx3;
                 ColMeta cur;
                 cur.node = next; cur.parent = i; cur.c = c; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
                 cur.score = score; cur.cells = cell_top; cur.size = size;
                 cur.cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
-                const int32_t *cS = w.st[cb].S;
+                const int32_t *cS = (const int32_t *)uni((uint64_t)w.st[cb].S);
                 // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
                 const int32_t diag_i = next_offset - seed_offset;
                 bool has_extension = in_seed;
                 const int32_t extension_cutoff =
-                    (int32_t)fma_f64((double)best_score, cfg.rel_score_cutoff, (double)partial_sum_offset);
+                    uni((int32_t)fma_f64((double)best_score, rel_cutoff, (double)partial_sum_offset));
                 int32_t best_s = INT32_MIN, best_d = INT32_MAX, best_j = 0;
                 for (int32_t base = 0; base < size; base += WAVE) {
                     LV<int32_t> sv, mn, dd;
@@ -1345,7 +1383,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                         int32_t v = j < size ? cS[j] : INT32_MIN;
                         sv[l] = v;
                         mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
-                        ext[l] = j < size && v + E.psum[start + begin + j] >= extension_cutoff;
+                        ext[l] = j < size && v + psum[start + begin + j] >= extension_cutoff;
                     }
                     min_cell_score = imin(min_cell_score, wave_min(mn));
                     if (wave_ballot(ext)) has_extension = true;
@@ -1359,7 +1397,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                     if (cm > best_s || (cm == best_s && cd < best_d)) { best_s = cm; best_d = cd; best_j = cj; }
                 }
                 cur.max_pos = best_j + begin;
-                const int32_t max_val = cS[cur.max_pos - begin];
+                const int32_t max_val = best_s;
                 uint64_t tx5 = cycle_clock();
                 w.xcyc[4] += tx5 - tx4;
                 if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) {

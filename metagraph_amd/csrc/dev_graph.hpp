@@ -75,6 +75,13 @@ MGX_DEV Block load_block_uniform(const DevGraph &g, uint32_t b) {
     r.pf = ((uint64_t)v[15] << 32) | v[14];
     return r;
 }
+MGX_DEV Block uni_block(const Block &b) {
+    Block r;
+    for (int i = 0; i < 4; ++i) r.cum[i] = uni(b.cum[i]);
+    r.last_cum = uni(b.last_cum); r.cum0 = uni(b.cum0);
+    r.last_bits = uni(b.last_bits); r.p0 = uni(b.p0); r.p1 = uni(b.p1); r.p2 = uni(b.p2); r.pf = uni(b.pf);
+    return r;
+}
 template <> MGX_DEV Block load_block_t<false>(const DevGraph &g, uint32_t b) { return load_block(g, b); }
 template <> MGX_DEV Block load_block_t<true>(const DevGraph &g, uint32_t b) { return load_block_uniform(g, b); }
 template <bool U> MGX_DEV uint32_t load_hint(const uint32_t *p) { if constexpr (U) return sload_u32(p); else return *p; }

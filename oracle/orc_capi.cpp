@@ -107,6 +107,9 @@ void *orc_graph_from_boss(const mgx_boss_view *view) {
     return g;
 }
 
+// precompute the first-character table (what NodeFirstCache amortises in the reference)
+void orc_graph_build_first_chars(void *h, uint32_t threads) { static_cast<Graph *>(h)->build_first_chars(threads); }
+
 void orc_graph_free(void *h) { delete static_cast<Graph *>(h); }
 uint64_t orc_graph_num_edges(void *h) { return static_cast<Graph *>(h)->boss.n; }
 uint32_t orc_graph_k(void *h) { return static_cast<Graph *>(h)->get_k(); }

@@ -7,6 +7,7 @@
 #include <map>
 #include <set>
 #include <stdexcept>
+#include <thread>
 
 namespace orc {
 
@@ -465,7 +466,39 @@ void Graph::call_outgoing_kmers(node_t v, const std::function<void(node_t, char)
     }
 }
 
+void Graph::build_first_chars(unsigned threads) {
+    // D_0[e] = last character of e's source node; D_{r+1}[e] = D_r[bwd(e)]; after k - 2 rounds D[e] is the
+    // first character (get_minus_k_value(e, k_ - 1), boss.cpp:696-704)
+    const uint64_t n = boss.n;
+    threads = std::max(1u, threads);
+    std::vector<uint32_t> P(n + 1, 0);
+    std::vector<uint8_t> D0(n + 1, 0), D1(n + 1, 0);
+    auto par = [&](const std::function<void(uint64_t, uint64_t)> &f) {
+        std::vector<std::thread> pool;
+        uint64_t chunk = (n + 1 + threads - 1) / threads;
+        for (unsigned t = 0; t < threads; ++t) {
+            uint64_t b = t * chunk, e = std::min<uint64_t>(n + 1, b + chunk);
+            if (b < e) pool.emplace_back(f, b, e);
+        }
+        for (auto &th : pool) th.join();
+    };
+    par([&](uint64_t b, uint64_t e) {
+        for (uint64_t i = std::max<uint64_t>(b, 1); i < e; ++i) { P[i] = (uint32_t)boss.bwd(i); D0[i] = boss.get_node_last_value(i); }
+    });
+    for (size_t r = 0; r + 1 < boss.k_; ++r) {
+        par([&](uint64_t b, uint64_t e) { for (uint64_t i = b; i < e; ++i) D1[i] = D0[P[i]]; });
+        D0.swap(D1);
+    }
+    first_char = std::move(D0);
+}
+
 void Graph::call_incoming_kmers(node_t v, const std::function<void(node_t, char)> &cb) const {
+    if (!first_char.empty()) {
+        boss.call_incoming_to_target(boss.bwd(v), boss.get_node_last_value(v), [&](edge_t prev) {
+            if (in_graph(prev)) cb(prev, decode_code(first_char[prev]));
+        });
+        return;
+    }
     // NodeFirstCache::call_incoming_kmers (graph_extensions/node_first_cache.cpp:27-52):
     // first char = get_minus_k_value(edge, k_-1).first (boss.cpp:696-704)
     boss.call_incoming_to_target(boss.bwd(v), boss.get_node_last_value(v), [&](edge_t prev) {

@@ -91,6 +91,9 @@ struct Graph {
     Boss boss;
     Mode mode = BASIC;
     std::vector<uint8_t> valid;          // empty = no mask (cli/align.cpp:337-339 reset_mask)
+    std::vector<uint8_t> first_char;     // optional: first character code of every edge's k-mer; stands in for
+                                         // NodeFirstCache (graph_extensions/node_first_cache.cpp:9-118), results identical
+    void build_first_chars(unsigned threads);
 
     size_t get_k() const { return boss.k_ + 1; }             // dbg_succinct.cpp:43-45
     uint64_t max_index() const { return boss.n; }            // dbg_succinct.cpp:686-688

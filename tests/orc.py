@@ -17,6 +17,7 @@ def L():
         _L.orc_graph_from_boss.restype = C.c_void_p
         _L.orc_graph_from_boss.argtypes = [C.POINTER(capi.BossView)]
         _L.orc_graph_free.argtypes = [C.c_void_p]
+        _L.orc_graph_build_first_chars.argtypes = [C.c_void_p, C.c_uint32]
         for f in ("orc_graph_num_edges", "orc_graph_num_nodes"):
             getattr(_L, f).restype = C.c_uint64
             getattr(_L, f).argtypes = [C.c_void_p]
