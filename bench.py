@@ -161,7 +161,7 @@ def main():
                 "lines_per_read": {"k_align": round(lines_align / args.reads, 1), "k_map": round(lines_map / args.reads, 1)},
                 "columns_per_read": round(st["n_columns"] / args.reads, 2),
                 "k_align_phase_share": dict(zip(["prepare", "seeding", "extend", "backtrack", "driver", "output"],
-                                                [round(c / max(1, sum(st["phase_cycles"])), 3) for c in st["phase_cycles"][:6]])),
+                                                [round(c / max(1, sum(st["phase_cycles"][:6])), 3) for c in st["phase_cycles"][:6]])),
                 "extend_share": dict(zip(["pop", "stage_band", "outgoing", "column", "scan", "commit", "conv", "push"],
                                          [round(c / max(1, sum(st["extend_cycles"])), 3) for c in st["extend_cycles"]]))}
 

@@ -59,7 +59,7 @@ class Graph:
         self.n_edges = v.n_edges
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and capi is not None:      # capi is None during interpreter shutdown
             capi.lib().mgx_graph_destroy(self.h)
             self.h = None
 
@@ -80,7 +80,7 @@ class Aligner:
                                              C.byref(self.h)))
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and capi is not None:
             capi.lib().mgx_aligner_destroy(self.h)
             self.h = None
 

@@ -203,6 +203,10 @@ struct Wave {
     uint32_t *rev_ops, *rev_nodes;
     uint8_t *rev_seq;
     SdustScratch *sd;            // sdust scratch (LDS)
+    uint32_t *pk[2];             // 2-bit packed strands (16 codes per word, first char least significant)
+    uint64_t *bm[4];             // position bitmasks of the seeder: matched k-mers, MEM stops, lookup hits, seed slots
+    int32_t inv_any[2];          // strand holds a character outside ACGT
+    SdustScratch *sd_own;        // carve()'s own scratch in the seeding overlay (used when the kernel passes none)
     const int8_t *sm_rows;       // score-matrix rows of the 6 possible path characters ($ACGT\\0) x 128, in LDS
     uint32_t *gen_store;         // conv-checker generation counters, persistent per arena slice
     ExtenderState ext[2];
@@ -232,6 +236,8 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 3 * align8((L + 1) * 2);                       // msl, pos_cnt, ml
     b += align8(L + 1);                                 // pos_full
     b += 3 * align8((L + 1) * 4);                       // pos_start, rfirst, rlast
+    b += align8(sizeof(SdustScratch));
+    b += 2 * align8(((L + 15) / 16 + 2) * 4) + 4 * align8(((L + 63) / 64 + 1) * 8);   // pk, bm
     b += align8((uint64_t)lim.max_alt * 4);             // alt
     b += align8((uint64_t)lim.cell_words * 4);          // cells
     b += align8((uint64_t)lim.max_columns * sizeof(ColMeta));
@@ -266,9 +272,9 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     };
     // persistent fast arrays
     for (int s = 0; s < 2; ++s) w.q[s] = take_fast(Lp);
-    for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take_fast((L + 1) * 4);
     w.lq = (uint64_t *)take_fast(LQ_CAP * 8);
     w.lnn = (uint64_t *)take_fast(LQ_CAP * 8);
+    for (int s = 0; s < 2; ++s) w.pk[s] = (uint32_t *)take_fast(((L + 15) / 16 + 2) * 4);
     // overlay: the seeding tables and the extension's column staging are never live at the same time
     uint8_t *lp_mark = lp;
     uint32_t lleft_mark = lleft;
@@ -279,6 +285,10 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.pos_start = (uint32_t *)take_fast((L + 1) * 4);
     w.rfirst = (uint32_t *)take_fast((L + 1) * 4);
     w.rlast = (uint32_t *)take_fast((L + 1) * 4);
+    w.sd_own = (SdustScratch *)take_fast(sizeof(SdustScratch));
+    for (int b = 0; b < 4; ++b) w.bm[b] = (uint64_t *)take_fast(((L + 63) / 64 + 1) * 8);
+    uint8_t *lp_seed_end = lp;
+    uint32_t lleft_seed_end = lleft;
     lp = lp_mark;
     lleft = lleft_mark;
     for (int b = 0; b < 2; ++b) {
@@ -287,6 +297,8 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
         w.st[b].F = (int32_t *)take_fast((L + 16) * 4);
         w.st[b].col = -1;
     }
+    if (lleft_seed_end < lleft) { lp = lp_seed_end; lleft = lleft_seed_end; }     // past the larger side of the overlay
+    for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take_fast((L + 1) * 4);
     for (int s = 0; s < 2; ++s) w.seeds[s] = (DevSeed *)take((uint64_t)lim.max_seeds * sizeof(DevSeed));
     for (int s = 0; s < 2; ++s) w.alive[s] = take(lim.max_seeds);
     w.alt = (uint32_t *)take((uint64_t)lim.max_alt * 4);
@@ -316,8 +328,9 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
 // LDS bytes that hold every "fast" array of carve() for a given Lmax
 MGX_HD uint32_t fast_lds_bytes(uint32_t Lmax) {
     uint64_t L = Lmax, Lp = align8(L + 8);
-    uint64_t persistent = 2 * Lp + 2 * align8((L + 1) * 4) + 2 * 32 * 8;
-    uint64_t seeding = 3 * align8((L + 1) * 2) + align8(L + 1) + 3 * align8((L + 1) * 4);
+    uint64_t persistent = 2 * Lp + 2 * align8((L + 1) * 4) + 2 * 32 * 8 + 2 * align8(((L + 15) / 16 + 2) * 4);
+    uint64_t seeding = 3 * align8((L + 1) * 2) + align8(L + 1) + 3 * align8((L + 1) * 4) + align8(sizeof(SdustScratch))
+                       + 4 * align8(((L + 63) / 64 + 1) * 8);
     uint64_t staging = 6 * align8((L + 16) * 4);
     return (uint32_t)(persistent + (seeding > staging ? seeding : staging));
 }
@@ -502,24 +515,98 @@ MGX_NI_G1 void prepare_query(Wave &w, const char *raw) {
         }
         FOR_LANES(l) { if (l == 0) w.psum[s][L] = 0; }
     }
+    // 2-bit packed strands for the suffix-range table keys
+    for (int s = 0; s < 2; ++s) {
+        const int32_t nw = (L + 15) / 16 + 1;
+        uint64_t bad_any = 0;
+        for (int32_t base = 0; base < nw; base += WAVE) {
+            LV<bool> bad;
+            FOR_LANES(l) {
+                int32_t wi = base + l;
+                bad[l] = false;
+                if (wi < nw) {
+                    uint32_t v = 0;
+                    for (int32_t j = 0; j < 16; ++j) {
+                        int32_t p = wi * 16 + j;
+                        if (p < L) {
+                            uint32_t code = encode_char(w.q[s][p]);
+                            if (code < 1 || code > 4) bad[l] = true;
+                            else v |= (code - 1) << (2 * j);
+                        }
+                    }
+                    w.pk[s][wi] = v;
+                }
+            }
+            bad_any |= wave_ballot(bad);
+        }
+        w.inv_any[s] = bad_any ? 1 : 0;
+    }
     wave_sync();
 }
+
+// first position >= from whose bit equals `val` in a bitmask over [0, n); n if none
+MGX_DEV int32_t bits_next(const uint64_t *wds, int32_t n, int32_t from, bool val) {
+    while (from < n) {
+        uint64_t x = wds[from >> 6];
+        if (!val) x = ~x;
+        x >>= (from & 63);
+        if (x) { int32_t p = from + ctz64(x); return p < n ? p : n; }
+        from = (from | 63) + 1;
+    }
+    return n;
+}
+MGX_DEV bool bits_test(const uint64_t *wds, int32_t i) { return (wds[i >> 6] >> (i & 63)) & 1; }
 
 // ------------------------------------------------------------------------------------------------
 // seeding
 // ------------------------------------------------------------------------------------------------
-MGX_DEV uint32_t num_exact_matching(const uint32_t *nodes, int32_t n, int32_t k) {
-    // A/aligner_seeder_methods.cpp:49-65
+// bitmasks of the strand's k-mer positions: bm[0] = matched (node != 0), bm[1] = MEM stop (terminus of a
+// matched k-mer, or unmatched); one coalesced pass over nodes[] instead of per-position scalar loads
+MGX_DEV void kmer_masks(Wave &w, int s) {
+    const AlignParams &P = *w.P;
+    const int32_t n = w.n_kmers;
+    const uint32_t *nodes = w.nodes[s];
+    const int32_t nwords = (imax(n, 0) + 63) / 64 + 1;
+    FOR_LANES(l) { if (l == 0) for (int32_t x = 0; x < nwords; ++x) { w.bm[0][x] = 0; w.bm[1][x] = 0; } }
+    wave_sync();
+    for (int32_t base = 0; base < n; base += WAVE) {
+        LV<bool> mt, st;
+        FOR_LANES(l) {
+            int32_t i = base + l;
+            mt[l] = false; st[l] = false;
+            if (i < n) {
+                uint32_t v = nodes[i];
+                if (v) {
+                    bool term = (i + 1 == n) || nodes[i + 1] == 0;
+                    if (!term) term = (P.g.terminus[v >> 6] >> (v & 63)) & 1;
+                    mt[l] = true; st[l] = term;
+                } else {
+                    st[l] = true;
+                }
+            }
+        }
+        const uint64_t bm = wave_ballot(mt), bs = wave_ballot(st);
+        FOR_LANES(l) { if (l == 0) { w.bm[0][base >> 6] |= bm << (base & 63); w.bm[1][base >> 6] |= bs << (base & 63); } }
+        wave_sync();
+    }
+    w.ctr.bit_lines += (uint32_t)imax(n, 0);
+}
+
+MGX_DEV uint32_t num_exact_matching(const uint64_t *matched, int32_t n, int32_t k) {
+    // A/aligner_seeder_methods.cpp:49-65, run by run over the matched-k-mer mask
     uint32_t num_matching = 0, last_match_count = 0;
-    for (int32_t i = 0; i < n; ++i) {
-        if (nodes[i]) {
-            int32_t j = i + 1;
-            while (j < n && nodes[j]) ++j;
-            num_matching += k + (j - i) - 1 - last_match_count;
-            last_match_count = k;
-            i = j - 1;
-        } else if (last_match_count) {
-            --last_match_count;
+    int32_t i = 0;
+    while (i < n) {
+        if (bits_test(matched, i)) {
+            int32_t j = bits_next(matched, n, i + 1, false);
+            num_matching += (uint32_t)k + (uint32_t)(j - i) - 1 - last_match_count;
+            last_match_count = (uint32_t)k;
+            i = j;
+        } else {
+            int32_t j = bits_next(matched, n, i + 1, true);
+            uint32_t zeros = (uint32_t)(j - i);
+            last_match_count = last_match_count > zeros ? last_match_count - zeros : 0;
+            i = j;
         }
     }
     return num_matching;
@@ -555,32 +642,15 @@ MGX_NI_G2 void base_seeds(Wave &w, int s) {
         }
         return;
     }
-    // flags: bit 1 = matched, bit 0 = MEM terminus (UniMEMSeeder, seeder hpp:116-135)
-    uint8_t *flags = w.pos_full;          // scratch, n <= L
-    for (int32_t base = 0; base < n; base += WAVE) {
-        FOR_LANES(l) {
-            int32_t i = base + l;
-            if (i < n) {
-                uint8_t f = 0;
-                uint32_t v = nodes[i];
-                if (v) {
-                    bool term = (i + 1 == n) || nodes[i + 1] == 0;
-                    if (!term) term = (P.g.terminus[v >> 6] >> (v & 63)) & 1;
-                    f = 2 | (term ? 1 : 0);
-                }
-                flags[i] = f;
-            }
-        }
-    }
-    w.ctr.bit_lines += (uint32_t)n;
-    wave_sync();
+    // UniMEMSeeder (seeder hpp:116-135) over the masks of kmer_masks(): a MEM runs from a matched k-mer to the
+    // first stop position (terminus of a matched k-mer, inclusive, or an unmatched k-mer, exclusive)
+    const uint64_t *matched = w.bm[0], *stop = w.bm[1];
     int32_t it = 0;
     while (it < n) {
-        while (it < n && !(flags[it] & 2)) ++it;
+        it = bits_next(matched, n, it, true);
         if (it >= n) break;
-        int32_t next = it;
-        while (next < n && !((flags[next] & 1) == 1 || (flags[next] & 2) == 0)) ++next;
-        if (next < n && (flags[next] & 2)) ++next;
+        int32_t next = bits_next(stop, n, it, true);
+        if (next < n && bits_test(matched, next)) ++next;
         int32_t mem_length = (next - it) + k - 1;
         if ((uint32_t)mem_length >= cfg.min_seed_length)
             if (!push_seed(w, s, it, mem_length, 0, next - it, 0)) return;
@@ -590,18 +660,29 @@ MGX_NI_G2 void base_seeds(Wave &w, int s) {
 
 // BOSS::index_range (boss.hpp:720-764) for one lane: codes q[i .. i + len); returns matched length,
 // *first = succ_last(rl), *last = ru
-MGX_DEV int32_t index_range_lane(const DevGraph &g, const uint8_t *q, int32_t len, int32_t min_len,
+MGX_DEV int32_t index_range_lane(const Wave &w, int s, int32_t i, int32_t len, int32_t min_len,
                                  uint64_t *first, uint64_t *last, LineCtr &ctr) {
+    const DevGraph &g = w.P->g;
+    const uint8_t *q = w.q[s] + i;
     *first = 0; *last = 0;
     if (len == 0) { *first = 1; *last = 1; return 0; }
-    for (int32_t j = 0; j < len; ++j) if (encode_char(q[j]) == 5) return 0;
+    const bool clean = !w.inv_any[s];                            // whole strand is ACGT: no per-window check
+    if (!clean)
+        for (int32_t j = 0; j < len; ++j) if (encode_char(q[j]) == 5) return 0;
     uint64_t rl = 1, ru = 0;
     int32_t it = 1;
     bool have = false;
     if (g.prefix_len && (int32_t)g.prefix_len <= len) {
         // get_initial_range via the suffix-range table (boss.hpp:645-663)
         uint32_t key = 0;
-        for (uint32_t j = 0; j < g.prefix_len; ++j) key |= (encode_char(q[j]) - 1) << (2 * j);
+        if (clean) {
+            const uint32_t *pk = w.pk[s];
+            const uint32_t wi = (uint32_t)i >> 4, sh = 2 * ((uint32_t)i & 15);
+            const uint64_t two = ((uint64_t)pk[wi + 1] << 32) | pk[wi];
+            key = (uint32_t)(two >> sh) & ((1u << (2 * g.prefix_len)) - 1);
+        } else {
+            for (uint32_t j = 0; j < g.prefix_len; ++j) key |= (encode_char(q[j]) - 1) << (2 * j);
+        }
         prefix_range(g, key, &rl, &ru, ctr);
         if (rl <= ru) { have = true; it = (int32_t)g.prefix_len; }
         else if (min_len > (int32_t)g.prefix_len) return 0;      // the match is shorter than prefix_len < min_len:
@@ -619,13 +700,23 @@ MGX_DEV int32_t index_range_lane(const DevGraph &g, const uint8_t *q, int32_t le
     return it;
 }
 
+#ifdef MGX_SEED_PROBE
+#define SEED_T(slot, t0) { uint64_t t_ = cycle_clock(); w.xcyc[slot] += t_ - t0; t0 = t_; }
+#else
+#define SEED_T(slot, t0)
+#endif
 // SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358, non-canonical)
 MGX_NI_G2 void make_seeder(Wave &w, int s) {
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const DevGraph &g = P.g;
     const int32_t k = (int32_t)g.k, L = w.L;
-    w.num_matching[s] = num_exact_matching(w.nodes[s], w.n_kmers, k);
+#ifdef MGX_SEED_PROBE
+    uint64_t tp = cycle_clock();
+#endif
+    kmer_masks(w, s);
+    w.num_matching[s] = num_exact_matching(w.bm[0], w.n_kmers, k);
+    SEED_T(0, tp)
     w.n_seeds[s] = 0;
     if ((uint32_t)L < cfg.min_seed_length) return;
     if (cfg.min_seed_length >= (uint32_t)k) { base_seeds(w, s); return; }
@@ -633,6 +724,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     const int32_t msl0 = (int32_t)cfg.min_seed_length;
     const int32_t nslots = L - msl0 + 1;
     base_seeds(w, s);
+    SEED_T(1, tp)
     if (w.status != ST_OK) return;
     const int32_t n_base = w.n_seeds[s];
     // min_seed_length[] and per-position seed lists
@@ -642,10 +734,15 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             if (i < nslots) { w.msl[i] = (uint16_t)msl0; w.pos_cnt[i] = 0; w.pos_full[i] = 0; w.pos_start[i] = 0; }
         }
     }
+    {
+        const int32_t nwords = (nslots + 63) / 64 + 1;
+        FOR_LANES(l) { if (l == 0) for (int32_t x = 0; x < nwords; ++x) { w.bm[2][x] = 0; w.bm[3][x] = 0; } }
+    }
     wave_sync();
     for (int32_t b = 0; b < n_base; ++b) {
         DevSeed sd = w.seeds[s][b];
         int32_t i = sd.clipping;
+        w.bm[3][i >> 6] |= 1ull << (i & 63);
         for (int32_t j = 0; j < sd.n_nodes; ++j) w.msl[i + j] = (uint16_t)k;
         if (i + sd.n_nodes < nslots) w.msl[i + sd.n_nodes] = (uint16_t)k;
         w.pos_full[i] = 1;            // suffix_seeds[i] holds exactly this full seed
@@ -653,19 +750,22 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         w.pos_start[i] = (uint32_t)b; // index of the full seed among the base seeds
     }
     wave_sync();
+    SEED_T(2, tp)
     // lane-parallel longest-prefix lookups for every position that can report a seed
     for (int32_t base = 0; base < nslots; base += WAVE) {
         LV<int32_t> nr, ns;
+        LV<bool> hit;
         FOR_LANES(l) {
             LineCtr lc = { 0, 0, 0 };
             int32_t i = base + l;
+            hit[l] = false;
             if (i < nslots) {
                 int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
                 uint16_t mlen = 0;
                 uint32_t rf = 0, rl_ = 0;
                 if (max_len >= (int32_t)w.msl[i]) {
                     uint64_t first, last;
-                    int32_t m = index_range_lane(g, w.q[s] + i, max_len, msl0, &first, &last, lc);
+                    int32_t m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
                     if (m >= msl0 && first && first <= g.n) {
                         mlen = (uint16_t)m;
                         rf = rank_last(g, first, lc);
@@ -673,17 +773,23 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                     }
                 }
                 w.ml[i] = mlen; w.rfirst[i] = rf; w.rlast[i] = rl_;
+                hit[l] = mlen != 0;
             }
             nr[l] = (int32_t)lc.rank_lines; ns[l] = (int32_t)lc.select_lines;
         }
         w.ctr.rank_lines += (uint32_t)wave_sum(nr);
         w.ctr.select_lines += (uint32_t)wave_sum(ns);
+        const uint64_t hb = wave_ballot(hit);
+        FOR_LANES(l) { if (l == 0) { w.bm[2][base >> 6] |= hb << (base & 63); w.bm[3][base >> 6] |= hb << (base & 63); } }
     }
     wave_sync();
+    SEED_T(3, tp)
     // sequential bookkeeping (:195-249)
     uint32_t alt_n = 0;
     const int32_t last_full_id = L >= k ? L - k + 1 : nslots;
-    for (int32_t i = 0; i < nslots; ++i) {
+    // only positions whose lookup matched >= min_seed_length characters can report (every other position takes
+    // one of the two `continue`s below: msl[i] never drops under min_seed_length)
+    for (int32_t i = bits_next(w.bm[2], nslots, 0, true); i < nslots; i = bits_next(w.bm[2], nslots, i + 1, true)) {
         int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
         int32_t cur_msl = w.msl[i];
         if (max_len < cur_msl) continue;                       // lookup returns immediately (dbg_succinct.cpp:314)
@@ -691,7 +797,14 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         if (seed_length < cur_msl) continue;                   // match_size < min_match_length: no callback
         // the complexity filter is evaluated first in the reference (:226-229); it has no side effects, so
         // testing it only for positions that would report a seed is equivalent
+#ifdef MGX_SEED_PROBE
+        uint64_t tq = cycle_clock();
+        bool lowc = cfg.seed_complexity_filter && window_low_complexity(w, s, i, cur_msl);
+        SEED_T(6, tq)
+        if (lowc) continue;
+#else
         if (cfg.seed_complexity_filter && window_low_complexity(w, s, i, cur_msl)) continue;
+#endif
         // enumerate nodes whose suffix matches (dbg_succinct.cpp:349-392)
         uint32_t first_alt = alt_n;
         uint32_t cnt = 0;
@@ -707,6 +820,9 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                 ++cnt;
             }
         }
+#ifdef MGX_SEED_PROBE
+        SEED_T(7, tq)
+#endif
         if (i >= last_full_id && cnt == 1 && w.msl[last_full_id - 1] == k && w.pos_full[last_full_id - 1]
                 && w.pos_cnt[last_full_id - 1] == 1) {
             DevSeed fs = w.seeds[s][w.pos_start[last_full_id - 1]];
@@ -728,6 +844,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             }
         }
     }
+    SEED_T(4, tp)
     // aggregate (:316-357): rebuild the seed list in position order
     // full seeds are already stored at [0, n_base); copy them out of the way first
     DevSeed *tmp = (DevSeed *)w.indices;         // scratch big enough for n_base <= L seeds
@@ -735,7 +852,8 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     w.n_seeds[s] = 0;
     uint32_t num_matching = 0;
     int32_t last_end = 0;
-    for (int32_t i = 0; i < nslots; ++i) {
+    // slots that can hold seeds: positions of base seeds and of lookup hits (pos_cnt is only ever raised there)
+    for (int32_t i = bits_next(w.bm[3], nslots, 0, true); i < nslots; i = bits_next(w.bm[3], nslots, i + 1, true)) {
         int32_t cnt = w.pos_cnt[i];
         if (!cnt) continue;
         bool full = w.pos_full[i];
@@ -760,6 +878,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         }
     }
     w.num_matching[s] = num_matching;
+    SEED_T(5, tp)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1860,9 +1979,11 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
     const int32_t n = w.n_seeds[s];
     for (int32_t i = 0; i < n; ++i) {
         if (!w.alive[s][i]) continue;
+        const uint64_t tp0 = cycle_clock();
         SeedRef seed = seedref_from_seed(w, s, i, nullptr);
         conv_clear(F.conv);                                   // set_seed (:90-98)
         uint64_t t0 = cycle_clock();
+        w.cyc[6] += t0 - tp0;
         extend(w, F, seed, false);
         uint64_t t1 = cycle_clock();
         w.cyc[2] += t1 - t0;
@@ -1874,10 +1995,16 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         if (w.status != ST_OK) return;
         if (have) {
             DevAln &path = w.aln[0];
+            const uint64_t tm0 = cycle_clock();
             if (path.score >= min_path_score_now(w)) add_alignment(w, path);
+            bool go_back = false;
             if (aln_clipping(path) && !path.offset) {
                 copy_aln(w.aln[1], path);
-                if (reverse_complement_aln(w, w.aln[1])) {
+                go_back = reverse_complement_aln(w, w.aln[1]);
+            }
+            w.cyc[7] += cycle_clock() - tm0;
+            if (aln_clipping(path) && !path.offset) {
+                if (go_back) {
                     // align_core(ManualSeeder{rc path}, bwd_extender, ..., force_fixed_seed = true) (:708-729)
                     SeedRef rseed = seedref_from_aln(w.aln[1]);
                     int32_t mps2 = imax(0, min_path_score_now(w));
@@ -1949,7 +2076,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     w.P = &P;
     w.sm_rows = sm_rows;
     carve(w, P, P.arena + (uint64_t)slot * P.arena_stride, lds, lds_bytes);
-    w.sd = sd;
+    w.sd = sd ? sd : w.sd_own;
     const uint64_t off = P.offsets[read];
     w.L = (int32_t)(P.offsets[read + 1] - off);
     w.status = ST_OK;
@@ -2004,17 +2131,19 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         wave_sync();
         w.cyc[1] = cycle_clock() - tseed;
         const uint64_t tdrv = cycle_clock();
+#ifdef MGX_SEED_ONLY
+        if (false) {
+#else
         if (w.status == ST_OK) {
+#endif
             if (have_rc) {
                 // align_both_directions (:738-755)
                 uint32_t fm = w.num_matching[0], bm = w.num_matching[1];
-                if (fm >= bm) {
-                    aln_both(w, 0);
-                    if (w.status == ST_OK && (double)bm >= (double)fm * P.cfg.rel_score_cutoff) aln_both(w, 1);
-                } else {
-                    aln_both(w, 1);
-                    if (w.status == ST_OK && (double)fm >= (double)bm * P.cfg.rel_score_cutoff) aln_both(w, 0);
-                }
+                // one call site for both orders: groups of a wavefront that start on different strands stay converged
+                const int first = fm >= bm ? 0 : 1;
+                const uint32_t m_first = first ? bm : fm, m_second = first ? fm : bm;
+                aln_both(w, first);
+                if (w.status == ST_OK && (double)m_second >= (double)m_first * P.cfg.rel_score_cutoff) aln_both(w, 1 - first);
             } else {
                 align_core_fwd(w);
             }

@@ -281,13 +281,31 @@ MGX_DEV uint64_t bwd(const DevGraph &g, uint64_t i, LineCtr &ctr) {
     return select_W<U>(g, c, target_node - g.NF[c], ctr);
 }
 
-// tighten_range (boss.hpp:682-693)
+// tighten_range (boss.hpp:682-693).  Narrow ranges are the common case, so the two ranks share one block
+// load when rl - 1 and ru fall into the same block, and the two selects share the block of the upper one.
 MGX_DEV bool tighten_range(const DevGraph &g, uint64_t *rl, uint64_t *ru, uint32_t s, LineCtr &ctr) {
-    uint32_t rk_rl = rank_W(g, *rl - 1, s, ctr) + 1;
-    uint32_t rk_ru = rank_W(g, *ru, s, ctr);
+    const uint64_t lo = *rl - 1, hi = *ru;
+    ++ctr.rank_lines;
+    Block bh = load_block(g, (uint32_t)(hi >> 6));
+    uint32_t rk_ru = hi ? block_rank_W(bh, (int)(hi & 63), s, (hi >> 6) == 0) : 0;
+    uint32_t rk_rl;
+    if (lo == 0) {
+        rk_rl = 1;
+    } else if ((lo >> 6) == (hi >> 6)) {
+        rk_rl = block_rank_W(bh, (int)(lo & 63), s, (lo >> 6) == 0) + 1;
+    } else {
+        ++ctr.rank_lines;
+        Block bl = load_block(g, (uint32_t)(lo >> 6));
+        rk_rl = block_rank_W(bl, (int)(lo & 63), s, (lo >> 6) == 0) + 1;
+    }
     if (rk_rl > rk_ru) return false;
-    *rl = select_last(g, g.NF[s] + rk_rl - 1, ctr) + 1;
-    *ru = select_last(g, g.NF[s] + rk_ru, ctr);
+    const uint32_t r_hi = g.NF[s] + rk_ru, r_lo = g.NF[s] + rk_rl - 1;
+    Block sb;
+    const uint64_t pos_hi = select_last_blk(g, r_hi, sb, ctr);
+    *ru = pos_hi;
+    if (r_lo == 0) *rl = 1;
+    else if (r_lo > sb.last_cum) *rl = ((pos_hi >> 6) << 6) + (uint32_t)select64(sb.last_bits, (int)(r_lo - sb.last_cum)) + 1;
+    else *rl = select_last(g, r_lo, ctr) + 1;
     return true;
 }
 

@@ -208,6 +208,28 @@ struct mgx_graph {
     uint64_t bytes = 0;
 };
 
+extern "C" int mgx_launch_align_lane(const void *params, uint32_t n_slots, void *stream);   // mgx_lane.hip
+extern "C" int mgx_launch_align_grp16(const void *params, uint32_t n_groups, uint32_t lds_bytes, void *stream);   // mgx_grp.hip, MGX_GROUP=16
+extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, void *stream);    // mgx_grp.hip, MGX_GROUP=8
+extern "C" int mgx_grp_waves_per_simd16(void);
+extern "C" int mgx_grp_waves_per_simd8(void);
+extern "C" unsigned mgx_grp_static_lds16(void);
+extern "C" unsigned mgx_grp_static_lds8(void);
+
+// which instantiation of the aligner's wave program run_align launches
+enum AlignMode { MODE_WAVE = 0, MODE_GRP16 = 1, MODE_GRP8 = 2, MODE_LANE = 3 };
+static AlignMode align_mode() {
+    static const AlignMode m = [] {
+        const char *e = getenv("MGX_ALIGN_MODE");
+        if (!e) return MODE_WAVE;
+        if (!strcmp(e, "g16")) return MODE_GRP16;
+        if (!strcmp(e, "g8")) return MODE_GRP8;
+        if (!strcmp(e, "lane")) return MODE_LANE;
+        return MODE_WAVE;
+    }();
+    return m;
+}
+
 struct mgx_aligner {
     const mgx_graph *graph = nullptr;
     mgx_config cfg;
@@ -528,7 +550,11 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     HIP_TRY(hipGetDeviceProperties(&prop, A->graph->device));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const AlignMode mode = align_mode();
     uint64_t want_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;
+    if (mode == MODE_LANE) want_slots = (uint64_t)prop.multiProcessorCount * 4 * 64;
+    if (mode == MODE_GRP16) want_slots = (uint64_t)prop.multiProcessorCount * 4 * 4 * (uint64_t)mgx_grp_waves_per_simd16();
+    if (mode == MODE_GRP8) want_slots = (uint64_t)prop.multiProcessorCount * 4 * 8 * (uint64_t)mgx_grp_waves_per_simd8();
     uint64_t budget = free_b / 2;
     uint64_t slots = std::min<uint64_t>(std::min<uint64_t>(want_slots, n), std::max<uint64_t>(1, budget / stride));
     if (slots == 0) slots = 1;
@@ -574,8 +600,21 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     // latency-critical scalar arrays go to LDS when they fit next to the other resident waves of the CU
     uint32_t lds_budget = (160u * 1024u) / (4 * MGX_ALIGN_WAVES_PER_SIMD) - 3072u;   // minus static LDS (Wave, sdust, score rows)
     uint32_t lds_bytes = std::min<uint32_t>(fast_lds_bytes(l.Lmax), lds_budget) & ~15u;
-    k_align<<<(uint32_t)slots, 64, lds_bytes>>>(P, lds_bytes);
-    HIP_TRY(hipGetLastError());
+    if (mode == MODE_LANE) {
+        HIP_TRY((hipError_t)mgx_launch_align_lane(&P, (uint32_t)slots, nullptr));
+    } else if (mode == MODE_GRP16 || mode == MODE_GRP8) {
+        const bool g16 = mode == MODE_GRP16;
+        const uint32_t groups = g16 ? 4 : 8;
+        const uint32_t waves_cu = 4u * (uint32_t)(g16 ? mgx_grp_waves_per_simd16() : mgx_grp_waves_per_simd8());
+        const uint32_t static_lds = g16 ? mgx_grp_static_lds16() : mgx_grp_static_lds8();
+        uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 256u;
+        uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
+        HIP_TRY((hipError_t)(g16 ? mgx_launch_align_grp16(&P, (uint32_t)slots, per_group, nullptr)
+                                 : mgx_launch_align_grp8(&P, (uint32_t)slots, per_group, nullptr)));
+    } else {
+        k_align<<<(uint32_t)slots, 64, lds_bytes>>>(P, lds_bytes);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(A->ev[3], 0));
     return MGX_OK;
 }

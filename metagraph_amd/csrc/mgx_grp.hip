@@ -1,0 +1,68 @@
+// mgx_grp.hip — the sub-wave-group instantiation of the aligner's wave program (see wave_group.hpp):
+// every hardware wavefront aligns 64 / MGX_GROUP reads at once, one per group of MGX_GROUP lanes.
+// Same sources as the wave-per-read kernel (dev_graph.hpp, align_core.hpp); symbols live in their own
+// namespace so that all instantiations coexist in libmgx.so.
+#ifndef MGX_GROUP
+#define MGX_GROUP 16
+#endif
+#define MGX_CAT2(a, b) a##b
+#define MGX_CAT(a, b) MGX_CAT2(a, b)
+#define mgx MGX_CAT(mgx_grp, MGX_GROUP)
+#include "wave_group.hpp"
+#include "align_core.hpp"
+
+using namespace mgx;
+
+#ifndef MGX_GRP_WAVES_PER_SIMD
+#define MGX_GRP_WAVES_PER_SIMD 2
+#endif
+
+// each group owns one read at a time, one arena slice and one slice of the dynamic LDS
+__global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_grp, MGX_GROUP)(AlignParams P, uint32_t lds_bytes) {
+    const int g = group_id();
+    const uint32_t slot = blockIdx.x * GROUPS_PER_WAVEFRONT + (uint32_t)g;
+    __shared__ Wave ws[GROUPS_PER_WAVEFRONT];
+    __shared__ int8_t sm_rows[6 * 128];
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+    for (int x = threadIdx.x; x < 6 * 128; x += 64) {
+        uint32_t code = (uint32_t)(x >> 7);
+        uint8_t row = code != 5 ? decode_code(code) : 0;
+        sm_rows[x] = P.score_matrix[(uint32_t)(row & 127) * 128 + (x & 127)];
+    }
+    __syncthreads();
+    Wave &w = ws[g];
+    uint8_t *lds = dyn_lds + (uint32_t)g * lds_bytes;
+    KernelStats acc;
+    memset(&acc, 0, sizeof(acc));
+    for (;;) {
+        LV<uint64_t> rv;
+        rv.v = 0;
+        if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
+        uint64_t read = wave_bcast(rv, 0);
+        if (read >= P.n_reads) break;
+        align_read(w, P, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(&P.stats->rank_lines, acc.rank_lines);
+        atomicAdd(&P.stats->select_lines, acc.select_lines);
+        atomicAdd(&P.stats->bit_lines, acc.bit_lines);
+        atomicAdd(&P.stats->columns, acc.columns);
+        atomicAdd(&P.stats->extensions, acc.extensions);
+        atomicAdd(&P.stats->seeds, acc.seeds);
+        atomicAdd(&P.stats->capacity_errors, acc.capacity_errors);
+        for (int x = 0; x < 8; ++x) {
+            atomicAdd(&P.stats->cyc[x], acc.cyc[x]);
+            atomicAdd(&P.stats->xcyc[x], acc.xcyc[x]);
+        }
+    }
+}
+
+// n_groups = arena slices; lds_bytes = dynamic LDS per group
+extern "C" int MGX_CAT(mgx_launch_align_grp, MGX_GROUP)(const void *params, uint32_t n_groups, uint32_t lds_bytes, void *stream) {
+    const AlignParams &P = *static_cast<const AlignParams *>(params);
+    uint32_t blocks = (n_groups + GROUPS_PER_WAVEFRONT - 1) / GROUPS_PER_WAVEFRONT;
+    MGX_CAT(k_align_grp, MGX_GROUP)<<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes);
+    return (int)hipGetLastError();
+}
+extern "C" int MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP)(void) { return MGX_GRP_WAVES_PER_SIMD; }
+extern "C" unsigned MGX_CAT(mgx_grp_static_lds, MGX_GROUP)(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + 6 * 128); }

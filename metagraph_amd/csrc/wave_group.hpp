@@ -1,0 +1,161 @@
+// wave_group.hpp — the wave interface of wave.hpp for SUB-WAVE GROUPS: a hardware wavefront is split into
+// 64 / MGX_GROUP independent groups of MGX_GROUP lanes (16 = one DPP row, or 8), and every group runs its
+// own wave program (its own read).  All cross-lane operations are scoped to the group: DPP row shifts never
+// leave a 16-lane row, ballots are cut to the group's bits, broadcasts go through ds_bpermute.  Control flow
+// that is "uniform" inside a wave program is uniform per GROUP here and may diverge between the groups of a
+// wavefront; the hardware's EXEC masking serialises such paths, everything else is issued once for all
+// groups — which is the point: the scalar bookkeeping of the aligner is shared by 4 (8) reads per issue slot.
+#ifndef MGX_WAVE_HPP_
+#define MGX_WAVE_HPP_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef MGX_GROUP
+#define MGX_GROUP 16
+#endif
+static_assert(MGX_GROUP == 16 || MGX_GROUP == 8 || MGX_GROUP == 4, "group = 4, 8 or 16 lanes");
+
+#define MGX_DEV __device__ __forceinline__
+#ifndef MGX_NOINLINE
+#define MGX_NOINLINE 1
+#endif
+#if MGX_NOINLINE
+#define MGX_DEV_NOINLINE __device__ __noinline__
+#else
+#define MGX_DEV_NOINLINE __device__ __forceinline__
+#endif
+#define MGX_HD __host__ __device__ __forceinline__
+#define MGX_WAVE_EMU 0
+#define MGX_GROUP_MODE 1
+
+namespace mgx {
+
+constexpr int WAVE = MGX_GROUP;
+constexpr int GROUPS_PER_WAVEFRONT = 64 / MGX_GROUP;
+
+MGX_DEV int hw_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+MGX_DEV int lane_id() { return hw_lane() & (WAVE - 1); }
+MGX_DEV int group_id() { return hw_lane() / WAVE; }
+MGX_DEV int group_base() { return hw_lane() & ~(WAVE - 1); }
+
+template <class T>
+struct LV {
+    T v;
+    MGX_DEV T &operator[](int) { return v; }
+    MGX_DEV const T &operator[](int) const { return v; }
+};
+
+#define FOR_LANES(l) for (int l = ::mgx::lane_id(), l##_once = 1; l##_once; l##_once = 0)
+
+MGX_DEV uint64_t wave_ballot(const LV<bool> &p) {
+    uint64_t m = __ballot(p.v);
+    return (m >> group_base()) & ((1ull << WAVE) - 1);
+}
+
+MGX_DEV int32_t grp_shfl(int32_t v, int src) { return __builtin_amdgcn_ds_bpermute((group_base() + src) << 2, v); }
+
+template <class T>
+MGX_DEV T wave_bcast(const LV<T> &x, int src) {
+    if constexpr (sizeof(T) == 8) {
+        uint64_t u = (uint64_t)x.v;
+        uint32_t lo = (uint32_t)grp_shfl((int32_t)(uint32_t)u, src);
+        uint32_t hi = (uint32_t)grp_shfl((int32_t)(uint32_t)(u >> 32), src);
+        return (T)(((uint64_t)hi << 32) | lo);
+    } else {
+        return (T)grp_shfl((int32_t)x.v, src);
+    }
+}
+
+// value of lane (l - 1) of the group; lane 0 receives `fill`
+MGX_DEV LV<int32_t> wave_shift_up1(const LV<int32_t> &x, int32_t fill) {
+    LV<int32_t> r;
+    int32_t t = __builtin_amdgcn_update_dpp(fill, x.v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    r.v = lane_id() == 0 ? fill : t;
+    return r;
+}
+
+// inclusive prefix max inside the group: log2(group) row-shift DPP steps
+MGX_DEV LV<int32_t> wave_prefix_max(const LV<int32_t> &x) {
+    int32_t v = x.v;
+    const int l = lane_id();
+#define MGX_GRP_MAX(ctrl, d)                                                                       \
+    if (WAVE > d) { int32_t t_ = __builtin_amdgcn_update_dpp(INT32_MIN, v, ctrl, 0xF, 0xF, false);  \
+                    t_ = (WAVE == 16 || l >= d) ? t_ : INT32_MIN; v = t_ > v ? t_ : v; }
+    MGX_GRP_MAX(0x111, 1)
+    MGX_GRP_MAX(0x112, 2)
+    MGX_GRP_MAX(0x114, 4)
+    MGX_GRP_MAX(0x118, 8)
+#undef MGX_GRP_MAX
+    LV<int32_t> r;
+    r.v = v;
+    return r;
+}
+
+MGX_DEV int32_t wave_max(const LV<int32_t> &x) {
+    LV<int32_t> p = wave_prefix_max(x);
+    return grp_shfl(p.v, WAVE - 1);
+}
+
+MGX_DEV int32_t wave_min(const LV<int32_t> &x) {
+    LV<int32_t> n;
+    n.v = ~x.v;
+    LV<int32_t> p = wave_prefix_max(n);
+    return ~grp_shfl(p.v, WAVE - 1);
+}
+
+MGX_DEV uint64_t wave_max_u64(const LV<uint64_t> &x) {
+    uint64_t v = x.v;
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int32_t)(uint32_t)v, d, WAVE);
+        uint32_t hi = (uint32_t)__shfl_xor((int32_t)(uint32_t)(v >> 32), d, WAVE);
+        uint64_t t = ((uint64_t)hi << 32) | lo;
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+MGX_DEV int32_t wave_sum(const LV<int32_t> &x) {
+    int32_t v = x.v;
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+MGX_DEV LV<int32_t> wave_prefix_sum_excl(const LV<int32_t> &x) {
+    int32_t v = x.v;
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int32_t t = __shfl_up(v, d, WAVE);
+        if (l >= d) v += t;
+    }
+    LV<int32_t> r;
+    r.v = v - x.v;
+    return r;
+}
+
+MGX_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// group-uniform values stay in vector registers (they differ between the groups of a wavefront)
+template <class T> MGX_DEV T uni(T x) { return x; }
+
+struct u32x16 { uint32_t v[16]; MGX_DEV uint32_t operator[](int i) const { return v[i]; } };
+MGX_DEV u32x16 sload_x16(const void *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    u32x16 r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w; r.v[12] = d.x; r.v[13] = d.y; r.v[14] = d.z; r.v[15] = d.w;
+    return r;
+}
+MGX_DEV uint32_t sload_u32(const uint32_t *p) { return *p; }
+
+MGX_DEV uint64_t cycle_clock() { return __builtin_readcyclecounter(); }
+MGX_DEV int popc64(uint64_t x) { return __popcll(x); }
+MGX_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
+MGX_DEV int clz64(uint64_t x) { return __clzll((long long)x); }
+MGX_DEV double fma_f64(double a, double b, double c) { return __fma_rn(a, b, c); }
+
+} // namespace mgx
+#endif  // MGX_WAVE_HPP_
