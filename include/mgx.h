@@ -169,7 +169,11 @@ typedef struct mgx_stats {
     uint64_t phase_cycles[8];   /* k_align shader cycles summed over waves: query prep, seeding, extend,
                                    backtrack, driver rest, output (profiling aid) */
     uint64_t extend_cycles[8];  /* extend() breakdown: pop, stage+band, outgoing, column, scan, commit, conv, push */
-    double seed_kernel_ms, align_kernel_ms;   /* HIP-event time of the two kernels, last batch */
+    double seed_kernel_ms, align_kernel_ms;   /* HIP-event time of the k-mer mapping kernel and of the whole
+                                                 alignment stage (seeding + sort + extension), last batch */
+    double seeding_ms, sort_ms, extend_ms;    /* split pipeline only (0 otherwise): seeding kernel, work sort,
+                                                 extension kernel */
+    uint64_t n_seed_lines;      /* split pipeline: part of the line counters issued by the seeding kernel */
 } mgx_stats;
 
 int mgx_device_count(void);                 /* number of visible HIP devices (0 without a GPU) */
@@ -218,6 +222,13 @@ int mgx_map_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uin
                   int seqs_on_device, mgx_mapping *out);
 
 int mgx_aligner_stats(const mgx_aligner *a, mgx_stats *out);
+
+/* Tuning / test hook: which instantiation of the per-read program the aligner launches.  Results are
+ * identical for all of them.  "split8" (default): seeding kernel with one wavefront per read, radix sort of
+ * the reads by predicted extension work, extension kernel with 8 lanes per read; "split16": 16 lanes per read;
+ * "splitw": both kernels one wavefront per read; "wave" / "g8" / "g16" / "lane": one fused kernel with 64 / 8 /
+ * 16 / 1 lanes per read.  The environment variable MGX_ALIGN_MODE sets the default.  Unknown name: MGX_ERR_INVALID. */
+int mgx_aligner_set_pipeline(mgx_aligner *a, const char *name);
 
 /* Format one query's results exactly like format_alignment() (cli/align.cpp:254-285):
  * "header\tquery\t(+|-)\tpath\tscore\tnum_matches\tcigar\toffset\n", or the "*" line.

@@ -117,6 +117,12 @@ class Aligner:
             out.append(([m.nodes_fwd[i] for i in range(b, e)], [m.nodes_rc[i] for i in range(b, e)]))
         return out
 
+    def set_pipeline(self, name):
+        """Tuning/test hook: 'split8' (default), 'split16', 'splitw', 'wave', 'g8', 'g16', 'lane'."""
+        L = capi.lib()
+        L.mgx_aligner_set_pipeline.argtypes = [C.c_void_p, C.c_char_p]
+        _check(L.mgx_aligner_set_pipeline(self.h, name.encode()))
+
     def keep_seeds(self, keep=True):
         capi.lib().mgx_aligner_keep_seeds(self.h, int(keep))
 

@@ -2070,7 +2070,22 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
     }
 }
 
-// the whole per-read program; `slot` selects the arena slice
+// Predicted extension work of a read from its seeds: (number of extensions, columns), the sort key that
+// lets the sub-wave groups of one wavefront work on similar reads.  Any value is correct; a better
+// prediction only means less idling.
+MGX_DEV uint32_t predicted_work(const Wave &w) {
+    const int first = w.num_matching[0] >= w.num_matching[1] ? 0 : 1;
+    if (!w.n_seeds[first]) return 0;
+    const DevSeed sd = w.seeds[first][0];
+    const int32_t end = sd.clipping + sd.length;
+    const uint32_t n_ext = (sd.clipping > 0 ? 1u : 0u) + (end < w.L ? 1u : 0u);
+    const uint32_t cols = (uint32_t)imin(1023, w.L - (int32_t)sd.length);
+    return 1 + ((n_ext << 10) | cols);
+}
+
+// The whole per-read program; `slot` selects the arena slice.  PHASE splits it for the two-kernel
+// pipeline: PH_SEED stops after build_seeders and publishes the seeds, PH_EXTEND picks them up.
+template <int PHASE = PH_BOTH>
 MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t slot, KernelStats *stats_accum,
                         SdustScratch *sd, const int8_t *sm_rows, uint8_t *lds, uint32_t lds_bytes) {
     w.P = &P;
@@ -2113,13 +2128,69 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         const bool have_rc = P.cfg.fwd_and_rc != 0;
         // build_seeders (:193-248)
         const uint64_t tseed = cycle_clock();
-        make_seeder(w, 0);
-        if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[0]) { w.n_seeds[0] = 0; w.num_matching[0] = 0; }
-        if (have_rc && w.status == ST_OK) {
-            make_seeder(w, 1);
-            if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[1]) { w.n_seeds[1] = 0; w.num_matching[1] = 0; }
+        if constexpr (PHASE & PH_SEED) {
+            make_seeder(w, 0);
+            if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[0]) { w.n_seeds[0] = 0; w.num_matching[0] = 0; }
+            if (have_rc && w.status == ST_OK) {
+                make_seeder(w, 1);
+                if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[1]) { w.n_seeds[1] = 0; w.num_matching[1] = 0; }
+            } else {
+                w.n_seeds[1] = 0; w.num_matching[1] = 0;
+            }
         } else {
-            w.n_seeds[1] = 0; w.num_matching[1] = 0;
+            // seeds of the seeding kernel
+            const SeedHdr h = P.seed_hdr[read];
+            w.status = h.status;
+            for (int s = 0; s < 2; ++s) { w.n_seeds[s] = h.n_seeds[s]; w.num_matching[s] = h.num_matching[s]; }
+            if (w.status == ST_OK) {
+                const DevSeed *src = P.seed_stream + h.off;
+                for (int s = 0; s < 2; ++s) {
+                    const int32_t n = w.n_seeds[s];
+                    for (int32_t base = 0; base < n; base += WAVE) {
+                        FOR_LANES(l) {
+                            int32_t x = base + l;
+                            if (x < n) { w.seeds[s][x] = src[x]; w.alive[s][x] = 1; }
+                        }
+                    }
+                    src += n;
+                }
+            }
+            wave_sync();
+        }
+        if constexpr (PHASE == PH_SEED) {
+            // publish: header, seeds, work key; the extension kernel writes the read's result record
+            SeedHdr h;
+            h.status = w.status; h.pad = 0; h.off = 0;
+            for (int s = 0; s < 2; ++s) { h.n_seeds[s] = (uint16_t)w.n_seeds[s]; h.num_matching[s] = w.num_matching[s]; }
+            const uint32_t total = (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
+            if (w.status == ST_OK && total) {
+                LV<uint64_t> offv;
+                FOR_LANES(l) {
+                    offv[l] = 0;
+                    if (l == 0) {
+#if MGX_WAVE_EMU
+                        offv[l] = *P.seed_cursor; *P.seed_cursor += total;
+#else
+                        offv[l] = atomicAdd(P.seed_cursor, (unsigned long long)total);
+#endif
+                    }
+                }
+                h.off = wave_bcast(offv, 0);
+                if (h.off + total > P.seed_capacity) {
+                    h.status = ST_CAPACITY;
+                } else {
+                    DevSeed *dst = P.seed_stream + h.off;
+                    for (int s = 0; s < 2; ++s) {
+                        const int32_t n = w.n_seeds[s];
+                        for (int32_t base = 0; base < n; base += WAVE) {
+                            FOR_LANES(l) { int32_t x = base + l; if (x < n) dst[x] = w.seeds[s][x]; }
+                        }
+                        dst += n;
+                    }
+                }
+            }
+            const uint32_t key = h.status == ST_OK ? predicted_work(w) : 0;
+            FOR_LANES(l) { if (l == 0) { P.seed_hdr[read] = h; P.work_key[read] = key; } }
         }
         rr.num_matches_fwd = w.num_matching[0]; rr.num_matches_rc = w.num_matching[1];
         rr.n_seeds_fwd = (uint32_t)w.n_seeds[0]; rr.n_seeds_rc = (uint32_t)w.n_seeds[1];
@@ -2134,7 +2205,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
 #ifdef MGX_SEED_ONLY
         if (false) {
 #else
-        if (w.status == ST_OK) {
+        if ((PHASE & PH_EXTEND) && w.status == ST_OK) {
 #endif
             if (have_rc) {
                 // align_both_directions (:738-755)
@@ -2151,6 +2222,21 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         for (int s = 0; s < 2; ++s) w.gen_store[s] = w.ext[s].conv.gen;
         wave_sync();
         w.cyc[4] = cycle_clock() - tdrv - w.cyc[2] - w.cyc[3];
+    }
+    if constexpr (PHASE == PH_SEED) {
+        if (w.L > (int32_t)P.lim.Lmax) {
+            SeedHdr h;
+            h.off = 0; h.status = ST_CAPACITY; h.pad = 0;
+            h.n_seeds[0] = h.n_seeds[1] = 0; h.num_matching[0] = h.num_matching[1] = 0;
+            FOR_LANES(l) { if (l == 0) { P.seed_hdr[read] = h; P.work_key[read] = 0; } }
+        }
+        stats_accum->rank_lines += w.ctr.rank_lines;
+        stats_accum->select_lines += w.ctr.select_lines;
+        stats_accum->bit_lines += w.ctr.bit_lines;
+        stats_accum->seed_lines += w.ctr.rank_lines + w.ctr.select_lines + w.ctr.bit_lines;
+        stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
+        for (int x = 0; x < 2; ++x) stats_accum->cyc[x] += w.cyc[x];
+        return;
     }
     const uint64_t tout = cycle_clock();
 
@@ -2196,7 +2282,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     stats_accum->bit_lines += w.ctr.bit_lines;
     stats_accum->columns += w.n_columns;
     stats_accum->extensions += w.n_extensions;
-    stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
+    if (PHASE & PH_SEED) stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
     stats_accum->capacity_errors += rr.status != ST_OK;
     w.cyc[5] = cycle_clock() - tout;
     for (int x = 0; x < 8; ++x) { stats_accum->cyc[x] += w.cyc[x]; stats_accum->xcyc[x] += w.xcyc[x]; }

@@ -51,8 +51,20 @@ struct DevSeed {             // Seed (alignment.hpp:32-98); full seeds reference
     uint32_t node;           // the single node of a sub-k seed
 };
 
+// what the seeding kernel hands to the extension kernel (split pipeline): the seeds live in seed_stream
+struct SeedHdr {
+    uint64_t off;            // first seed of strand 0 in the seed stream; strand 1 follows
+    uint32_t num_matching[2];
+    uint16_t n_seeds[2];
+    int32_t status;
+    uint32_t pad;
+};
+
+enum { PH_SEED = 1, PH_EXTEND = 2, PH_BOTH = 3 };
+
 struct KernelStats {
     unsigned long long rank_lines, select_lines, bit_lines, columns, extensions, seeds, capacity_errors, map_lines;
+    unsigned long long seed_lines;  // part of the three line counters issued by the seeding phase (split pipeline)
     unsigned long long xcyc[8];     // extend() breakdown
     unsigned long long cyc[8];      // shader cycles per phase: prepare, seeding, extend, backtrack, driver rest, output
 };
@@ -76,6 +88,13 @@ struct AlignParams {
     unsigned long long *read_cursor;
     KernelStats *stats;
     DevSeed *dbg_seeds;                  // optional: seeds dump [n_reads][2][max_seeds]
+    // split pipeline (seeding kernel -> sort by predicted extension work -> extension kernel)
+    SeedHdr *seed_hdr;                   // [n_reads]
+    DevSeed *seed_stream;
+    uint64_t seed_capacity;              // seeds
+    unsigned long long *seed_cursor;
+    uint32_t *work_key;                  // [n_reads], written by the seeding phase
+    const uint32_t *order;               // optional: the extension phase processes read order[i] as its i-th item
 };
 
 } // namespace mgx

@@ -126,16 +126,10 @@ __global__ void __launch_bounds__(256) k_map(DevGraph g, const char *seqs, const
 #ifndef MGX_ALIGN_WAVES_PER_SIMD
 #define MGX_ALIGN_WAVES_PER_SIMD 4
 #endif
+template <int PHASE>
 __global__ void __launch_bounds__(64, MGX_ALIGN_WAVES_PER_SIMD) k_align(AlignParams P, uint32_t lds_bytes) {
     const uint32_t slot = blockIdx.x;
-#ifndef MGX_WAVE_IN_LDS
-#define MGX_WAVE_IN_LDS 1
-#endif
-#if MGX_WAVE_IN_LDS
     __shared__ Wave w;                // the wave's scalar state lives in LDS, not in registers
-#else
-    Wave w;
-#endif
     __shared__ SdustScratch sd;
     __shared__ int8_t sm_rows[6 * 128];
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -146,9 +140,10 @@ __global__ void __launch_bounds__(64, MGX_ALIGN_WAVES_PER_SIMD) k_align(AlignPar
         LV<uint64_t> rv;
         rv.v = 0;
         if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
-        uint64_t read = wave_bcast(rv, 0);
-        if (read >= P.n_reads) break;
-        align_read(w, P, read, slot, &acc, &sd, sm_rows, dyn_lds, lds_bytes);
+        uint64_t item = wave_bcast(rv, 0);
+        if (item >= P.n_reads) break;
+        const uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
+        align_read<PHASE>(w, P, read, slot, &acc, &sd, sm_rows, dyn_lds, lds_bytes);
     }
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);
@@ -158,8 +153,14 @@ __global__ void __launch_bounds__(64, MGX_ALIGN_WAVES_PER_SIMD) k_align(AlignPar
         atomicAdd(&P.stats->extensions, acc.extensions);
         atomicAdd(&P.stats->seeds, acc.seeds);
         atomicAdd(&P.stats->capacity_errors, acc.capacity_errors);
+        if (acc.seed_lines) atomicAdd(&P.stats->seed_lines, acc.seed_lines);
         for (int x = 0; x < 8; ++x) { atomicAdd(&P.stats->cyc[x], acc.cyc[x]); atomicAdd(&P.stats->xcyc[x], acc.xcyc[x]); }
     }
+}
+
+__global__ void k_iota(uint32_t *v, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
 }
 
 // =================================================================================================
@@ -209,25 +210,31 @@ struct mgx_graph {
 };
 
 extern "C" int mgx_launch_align_lane(const void *params, uint32_t n_slots, void *stream);   // mgx_lane.hip
-extern "C" int mgx_launch_align_grp16(const void *params, uint32_t n_groups, uint32_t lds_bytes, void *stream);   // mgx_grp.hip, MGX_GROUP=16
-extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, void *stream);    // mgx_grp.hip, MGX_GROUP=8
+extern "C" int mgx_launch_align_grp16(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);   // mgx_grp.hip, MGX_GROUP=16
+extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);    // mgx_grp.hip, MGX_GROUP=8
 extern "C" int mgx_grp_waves_per_simd16(void);
 extern "C" int mgx_grp_waves_per_simd8(void);
 extern "C" unsigned mgx_grp_static_lds16(void);
 extern "C" unsigned mgx_grp_static_lds8(void);
 
-// which instantiation of the aligner's wave program run_align launches
-enum AlignMode { MODE_WAVE = 0, MODE_GRP16 = 1, MODE_GRP8 = 2, MODE_LANE = 3 };
-static AlignMode align_mode() {
-    static const AlignMode m = [] {
-        const char *e = getenv("MGX_ALIGN_MODE");
-        if (!e) return MODE_WAVE;
-        if (!strcmp(e, "g16")) return MODE_GRP16;
-        if (!strcmp(e, "g8")) return MODE_GRP8;
-        if (!strcmp(e, "lane")) return MODE_LANE;
-        return MODE_WAVE;
-    }();
-    return m;
+// Which instantiation of the aligner's wave program run_align launches.  The default is the split pipeline:
+// seeding by one wavefront per read, a radix sort of the reads by predicted extension work, extension by
+// 8-lane groups (8 reads per wavefront).  MGX_ALIGN_MODE selects the others for A/B measurements.
+enum AlignMode { MODE_WAVE = 0, MODE_GRP16 = 1, MODE_GRP8 = 2, MODE_LANE = 3, MODE_SPLIT8 = 4, MODE_SPLIT16 = 5, MODE_SPLITW = 6, MODE_BAD = -1 };
+static AlignMode parse_mode(const char *e) {
+    if (!e) return MODE_BAD;
+    if (!strcmp(e, "split8")) return MODE_SPLIT8;
+    if (!strcmp(e, "split16")) return MODE_SPLIT16;
+    if (!strcmp(e, "splitw")) return MODE_SPLITW;
+    if (!strcmp(e, "wave")) return MODE_WAVE;
+    if (!strcmp(e, "g16")) return MODE_GRP16;
+    if (!strcmp(e, "g8")) return MODE_GRP8;
+    if (!strcmp(e, "lane")) return MODE_LANE;
+    return MODE_BAD;
+}
+static AlignMode default_mode() {
+    AlignMode m = parse_mode(getenv("MGX_ALIGN_MODE"));
+    return m == MODE_BAD ? MODE_SPLIT8 : m;
 }
 
 struct mgx_aligner {
@@ -237,6 +244,7 @@ struct mgx_aligner {
     mgx_limits user_lim;
     bool have_user_lim = false;
     DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, scan_tmp, dbg_seeds;
+    DevBuf seed_hdr, seed_stream, work_key, work_key_sorted, order_in, order, sort_tmp;    // split pipeline
     DevLimits lim;
     uint64_t n_reads = 0, total_kmers = 0;
     uint32_t n_slots = 0;
@@ -247,7 +255,10 @@ struct mgx_aligner {
     HostResults host;
     std::vector<uint64_t> m_node_begin, m_fwd, m_rc;
     mgx_stats hstats;
-    hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    bool split_ran = false;
+    AlignMode mode = default_mode();
+    uint64_t arena_stride = 0;
 };
 
 extern "C" {
@@ -550,19 +561,26 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     HIP_TRY(hipGetDeviceProperties(&prop, A->graph->device));
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const AlignMode mode = align_mode();
-    uint64_t want_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;
+    const AlignMode mode = A->mode;
+    const bool split = mode == MODE_SPLIT8 || mode == MODE_SPLIT16 || mode == MODE_SPLITW;
+    const bool ext_g16 = mode == MODE_GRP16 || mode == MODE_SPLIT16, ext_g8 = mode == MODE_GRP8 || mode == MODE_SPLIT8;
+    const uint64_t wave_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;
+    uint64_t want_slots = wave_slots;            // wave-per-read kernels (fused, seeding, splitw extension)
     if (mode == MODE_LANE) want_slots = (uint64_t)prop.multiProcessorCount * 4 * 64;
-    if (mode == MODE_GRP16) want_slots = (uint64_t)prop.multiProcessorCount * 4 * 4 * (uint64_t)mgx_grp_waves_per_simd16();
-    if (mode == MODE_GRP8) want_slots = (uint64_t)prop.multiProcessorCount * 4 * 8 * (uint64_t)mgx_grp_waves_per_simd8();
+    if (ext_g16) want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 4 * (uint64_t)mgx_grp_waves_per_simd16());
+    if (ext_g8) want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * (uint64_t)mgx_grp_waves_per_simd8());
     uint64_t budget = free_b / 2;
-    uint64_t slots = std::min<uint64_t>(std::min<uint64_t>(want_slots, n), std::max<uint64_t>(1, budget / stride));
+    uint64_t slots = std::min<uint64_t>(std::min<uint64_t>(want_slots, std::max<uint64_t>(n, 1)), std::max<uint64_t>(1, budget / stride));
     if (slots == 0) slots = 1;
-    if (A->arena.bytes < slots * stride) {
+    {
+        // The hash tables of the convergence checker are cleared by generation tags that persist in each slice,
+        // so a slice only needs zeroing when its layout (stride) changes or the buffer is new.
+        const size_t before = A->arena.bytes;
         if (int rc = A->arena.ensure(slots * stride)) return rc;
-        HIP_TRY(hipMemsetAsync(A->arena.p, 0, A->arena.bytes, 0));     // generation counters start at 0
-    } else {
-        HIP_TRY(hipMemsetAsync(A->arena.p, 0, A->arena.bytes, 0));
+        if (A->arena.bytes != before || A->arena_stride != stride) {
+            HIP_TRY(hipMemsetAsync(A->arena.p, 0, A->arena.bytes, 0));
+            A->arena_stride = stride;
+        }
     }
     A->n_slots = (uint32_t)slots;
     if (int rc = A->results.ensure(n * sizeof(ReadResult))) return rc;
@@ -574,7 +592,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         HIP_TRY(hipMemsetAsync(A->dbg_seeds.p, 0, n * 2 * (uint64_t)l.max_seeds * sizeof(DevSeed), 0));
     }
     unsigned long long *cur = A->cursors.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(cur, 0, 16, 0));
+    HIP_TRY(hipMemsetAsync(cur, 0, 32, 0));
     AlignParams P;
     memset(&P, 0, sizeof(P));
     P.g = A->graph->g;
@@ -596,23 +614,62 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.read_cursor = cur + 1;
     P.stats = A->d_stats.as<KernelStats>();
     P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
+    size_t sort_tmp_bytes = 0;
+    if (split) {
+        // seeds travel from the seeding kernel to the extension kernel through a compact stream
+        const uint64_t seed_cap = std::min<uint64_t>(n * 2 * (uint64_t)l.max_seeds, n * 24 + 4096);
+        if (int rc = A->seed_hdr.ensure(n * sizeof(SeedHdr))) return rc;
+        if (int rc = A->seed_stream.ensure(seed_cap * sizeof(DevSeed))) return rc;
+        if (int rc = A->work_key.ensure(n * 4)) return rc;
+        if (int rc = A->work_key_sorted.ensure(n * 4)) return rc;
+        if (int rc = A->order_in.ensure(n * 4)) return rc;
+        if (int rc = A->order.ensure(n * 4)) return rc;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes, A->work_key.as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
+                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, 12, (hipStream_t)0));
+        if (int rc = A->sort_tmp.ensure(sort_tmp_bytes)) return rc;
+        P.seed_hdr = A->seed_hdr.as<SeedHdr>();
+        P.seed_stream = A->seed_stream.as<DevSeed>();
+        P.seed_capacity = seed_cap;
+        P.seed_cursor = cur + 2;
+        P.work_key = A->work_key.as<uint32_t>();
+    }
     HIP_TRY(hipEventRecord(A->ev[2], 0));
     // latency-critical scalar arrays go to LDS when they fit next to the other resident waves of the CU
     uint32_t lds_budget = (160u * 1024u) / (4 * MGX_ALIGN_WAVES_PER_SIMD) - 3072u;   // minus static LDS (Wave, sdust, score rows)
     uint32_t lds_bytes = std::min<uint32_t>(fast_lds_bytes(l.Lmax), lds_budget) & ~15u;
-    if (mode == MODE_LANE) {
-        HIP_TRY((hipError_t)mgx_launch_align_lane(&P, (uint32_t)slots, nullptr));
-    } else if (mode == MODE_GRP16 || mode == MODE_GRP8) {
-        const bool g16 = mode == MODE_GRP16;
-        const uint32_t groups = g16 ? 4 : 8;
-        const uint32_t waves_cu = 4u * (uint32_t)(g16 ? mgx_grp_waves_per_simd16() : mgx_grp_waves_per_simd8());
-        const uint32_t static_lds = g16 ? mgx_grp_static_lds16() : mgx_grp_static_lds8();
+    const uint32_t w_slots = (uint32_t)std::min<uint64_t>(slots, wave_slots);
+    auto launch_groups = [&](int phase) -> int {
+        const uint32_t groups = ext_g16 ? 4 : 8;
+        const uint32_t waves_cu = 4u * (uint32_t)(ext_g16 ? mgx_grp_waves_per_simd16() : mgx_grp_waves_per_simd8());
+        const uint32_t static_lds = ext_g16 ? mgx_grp_static_lds16() : mgx_grp_static_lds8();
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 256u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
-        HIP_TRY((hipError_t)(g16 ? mgx_launch_align_grp16(&P, (uint32_t)slots, per_group, nullptr)
-                                 : mgx_launch_align_grp8(&P, (uint32_t)slots, per_group, nullptr)));
+        return ext_g16 ? mgx_launch_align_grp16(&P, (uint32_t)slots, per_group, phase, nullptr)
+                       : mgx_launch_align_grp8(&P, (uint32_t)slots, per_group, phase, nullptr);
+    };
+    A->split_ran = split;
+    if (split) {
+        k_align<PH_SEED><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(A->ev[4], 0));
+        k_iota<<<(uint32_t)((n + 255) / 256), 256>>>(A->order_in.as<uint32_t>(), n);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, sort_tmp_bytes, A->work_key.as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
+                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, 12, (hipStream_t)0));
+        HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));                      // rewind the read cursor
+        P.order = A->order.as<uint32_t>();
+        HIP_TRY(hipEventRecord(A->ev[5], 0));
+        if (mode == MODE_SPLITW) {
+            k_align<PH_EXTEND><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
+            HIP_TRY(hipGetLastError());
+        } else {
+            HIP_TRY((hipError_t)launch_groups(PH_EXTEND));
+        }
+    } else if (mode == MODE_LANE) {
+        HIP_TRY((hipError_t)mgx_launch_align_lane(&P, (uint32_t)slots, nullptr));
+    } else if (ext_g16 || ext_g8) {
+        HIP_TRY((hipError_t)launch_groups(PH_BOTH));
     } else {
-        k_align<<<(uint32_t)slots, 64, lds_bytes>>>(P, lds_bytes);
+        k_align<PH_BOTH><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(A->ev[3], 0));
@@ -628,11 +685,16 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     s.n_reads = A->n_reads;
     s.n_rank_lines = ks.rank_lines; s.n_select_lines = ks.select_lines; s.n_bit_lines = ks.bit_lines;
     s.n_columns = ks.columns; s.n_extensions = ks.extensions; s.n_seeds = ks.seeds;
-    s.n_map_lines = ks.map_lines; s.n_capacity_errors = ks.capacity_errors;
+    s.n_map_lines = ks.map_lines; s.n_capacity_errors = ks.capacity_errors; s.n_seed_lines = ks.seed_lines;
     for (int x = 0; x < 8; ++x) { s.phase_cycles[x] = ks.cyc[x]; s.extend_cycles[x] = ks.xcyc[x]; }
     float ms = 0;
     if (mapped) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[0], A->ev[1])); s.seed_kernel_ms = ms; }
     if (aligned) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[2], A->ev[3])); s.align_kernel_ms = ms; }
+    if (aligned && A->split_ran) {
+        HIP_TRY(hipEventElapsedTime(&ms, A->ev[2], A->ev[4])); s.seeding_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, A->ev[4], A->ev[5])); s.sort_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, A->ev[5], A->ev[3])); s.extend_ms = ms;
+    }
     return MGX_OK;
 }
 
@@ -657,6 +719,14 @@ int mgx_map_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uin
     out->node_begin = A->m_node_begin.data();
     out->nodes_fwd = A->m_fwd.data();
     out->nodes_rc = A->m_rc.data();
+    return MGX_OK;
+}
+
+int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
+    if (!A) return fail(MGX_ERR_INVALID, "null argument");
+    AlignMode m = parse_mode(name);
+    if (m == MODE_BAD) return fail(MGX_ERR_INVALID, "unknown pipeline '%s'", name ? name : "(null)");
+    A->mode = m;
     return MGX_OK;
 }
 

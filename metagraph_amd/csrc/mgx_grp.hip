@@ -18,7 +18,8 @@ using namespace mgx;
 #endif
 
 // each group owns one read at a time, one arena slice and one slice of the dynamic LDS
-__global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_grp, MGX_GROUP)(AlignParams P, uint32_t lds_bytes) {
+template <int PHASE>
+__global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_grp, MGX_GROUP)(AlignParams P, uint32_t lds_bytes, uint32_t n_groups) {
     const int g = group_id();
     const uint32_t slot = blockIdx.x * GROUPS_PER_WAVEFRONT + (uint32_t)g;
     __shared__ Wave ws[GROUPS_PER_WAVEFRONT];
@@ -30,6 +31,7 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
         sm_rows[x] = P.score_matrix[(uint32_t)(row & 127) * 128 + (x & 127)];
     }
     __syncthreads();
+    if (slot >= n_groups) return;                      // the last wavefront may hold fewer groups than arena slices exist
     Wave &w = ws[g];
     uint8_t *lds = dyn_lds + (uint32_t)g * lds_bytes;
     KernelStats acc;
@@ -38,9 +40,10 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
         LV<uint64_t> rv;
         rv.v = 0;
         if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
-        uint64_t read = wave_bcast(rv, 0);
-        if (read >= P.n_reads) break;
-        align_read(w, P, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
+        uint64_t item = wave_bcast(rv, 0);
+        if (item >= P.n_reads) break;
+        const uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
+        align_read<PHASE>(w, P, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
     }
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);
@@ -50,6 +53,7 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
         atomicAdd(&P.stats->extensions, acc.extensions);
         atomicAdd(&P.stats->seeds, acc.seeds);
         atomicAdd(&P.stats->capacity_errors, acc.capacity_errors);
+        if (acc.seed_lines) atomicAdd(&P.stats->seed_lines, acc.seed_lines);
         for (int x = 0; x < 8; ++x) {
             atomicAdd(&P.stats->cyc[x], acc.cyc[x]);
             atomicAdd(&P.stats->xcyc[x], acc.xcyc[x]);
@@ -58,10 +62,14 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
 }
 
 // n_groups = arena slices; lds_bytes = dynamic LDS per group
-extern "C" int MGX_CAT(mgx_launch_align_grp, MGX_GROUP)(const void *params, uint32_t n_groups, uint32_t lds_bytes, void *stream) {
+// phase = PH_BOTH (fused) or PH_EXTEND (after the seeding kernel)
+extern "C" int MGX_CAT(mgx_launch_align_grp, MGX_GROUP)(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream) {
     const AlignParams &P = *static_cast<const AlignParams *>(params);
     uint32_t blocks = (n_groups + GROUPS_PER_WAVEFRONT - 1) / GROUPS_PER_WAVEFRONT;
-    MGX_CAT(k_align_grp, MGX_GROUP)<<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes);
+    if (phase == PH_EXTEND)
+        MGX_CAT(k_align_grp, MGX_GROUP)<PH_EXTEND><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
+    else
+        MGX_CAT(k_align_grp, MGX_GROUP)<PH_BOTH><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
     return (int)hipGetLastError();
 }
 extern "C" int MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP)(void) { return MGX_GRP_WAVES_PER_SIMD; }

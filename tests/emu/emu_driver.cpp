@@ -6,6 +6,7 @@
 #include "wave.hpp"              // tests/emu/wave.hpp (shadows the gfx950 header)
 
 #include <cstdio>
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -167,7 +168,25 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     std::vector<uint8_t> lds(2048);
     std::vector<int8_t> rows(6 * 128);
     load_score_rows(P, rows.data());
-    for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)lds.size());
+    const char *split = getenv("MGX_EMU_SPLIT");
+    if (split && *split == '1') {
+        // the two-kernel pipeline: seeding phase for every read, stable sort by predicted work, extension phase
+        std::vector<SeedHdr> hdr(n);
+        std::vector<DevSeed> sstream(n * 2 * (uint64_t)R->lim.max_seeds + 16);
+        std::vector<uint32_t> key(n), order(n);
+        unsigned long long seed_cursor = 0;
+        P.seed_hdr = hdr.data(); P.seed_stream = sstream.data(); P.seed_capacity = sstream.size();
+        P.seed_cursor = &seed_cursor; P.work_key = key.data();
+        for (uint64_t i = 0; i < n; ++i)
+            align_read<PH_SEED>(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)lds.size());
+        for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        P.order = order.data();
+        for (uint64_t i = 0; i < n; ++i)
+            align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)lds.size());
+    } else {
+        for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)lds.size());
+    }
     R->host.decode(R->results.data(), n, R->stream.data());
     return R;
 }

@@ -28,7 +28,10 @@ struct uint2 { uint32_t x, y; };
 
 namespace mgx {
 
-constexpr int WAVE = 64;
+#ifndef MGX_EMU_WAVE
+#define MGX_EMU_WAVE 64
+#endif
+constexpr int WAVE = MGX_EMU_WAVE;      // 64 = a wavefront; 16 / 8 / 1 model the sub-wave-group and thread-per-read kernels
 
 inline int lane_id() { return 0; }
 

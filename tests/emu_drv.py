@@ -16,7 +16,9 @@ def L():
     global _L
     if _L is None:
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")], check=True)
-        _L = C.CDLL(os.path.join(ROOT, "tests", "emu", "_build", "libmgxemu.so"))
+        # MGX_EMU_WAVE=16 / 8 selects the model of the sub-wave-group kernels (default: one 64-lane wavefront)
+        suffix = {"16": "_w16", "8": "_w8"}.get(os.environ.get("MGX_EMU_WAVE", ""), "")
+        _L = C.CDLL(os.path.join(ROOT, "tests", "emu", "_build", "libmgxemu%s.so" % suffix))
         _L.emu_graph_create.restype = C.c_void_p
         _L.emu_graph_create.argtypes = [C.POINTER(capi.BossView)]
         _L.emu_graph_free.argtypes = [C.c_void_p]

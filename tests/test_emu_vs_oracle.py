@@ -150,6 +150,43 @@ def test_align_cli_config(k, mask, seed):
     compare_full(g, eg, cfg, reads)
 
 
+@pytest.mark.parametrize("k,mask,seed", [(11, False, 21), (31, False, 22), (19, True, 23)])
+def test_split_pipeline(k, mask, seed, monkeypatch):
+    """Seeding kernel -> sort by predicted work -> extension kernel (the product's default pipeline) gives
+    the results of the fused per-read program: seeds survive the hand-over and the processing order is free."""
+    monkeypatch.setenv("MGX_EMU_SPLIT", "1")
+    g, reads = make_world(300 + seed, k, mask=mask, n_reads=50)
+    eg = emu_drv.EmuGraph(g)
+    cfg = capi.config_cli(k)
+    compare_full(g, eg, cfg, reads)
+
+
+def test_split_pipeline_unit_kats(monkeypatch):
+    monkeypatch.setenv("MGX_EMU_SPLIT", "1")
+    for case in KATS["unit"]:
+        if case["expect"].get("throws") or case["config"].get("num_alternative_paths", 1) != 1:
+            continue
+        g = orc.Graph.build(case["k"], case["graph"], 0, case["mask_dummy"])
+        eg = emu_drv.EmuGraph(g)
+        cfg = orc.make_config(case["config"], case["matrix"])
+        compare_full(g, eg, cfg, [case["query"]], limits=BIG)
+
+
+@pytest.mark.parametrize("lanes", ["16", "8"])
+def test_group_sizes_in_emulation(lanes):
+    """The wave programs do not depend on the lane count: the same sources modelled with 16 and 8 lanes per read
+    (the sub-wave-group kernels) pass the alignment and split-pipeline checks.  Runs in a subprocess because the
+    model's lane count is a compile-time constant of the loaded library."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MGX_EMU_WAVE=lanes)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k",
+                        "test_align_cli_config or test_split_pipeline or test_align_forward_only",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_align_cli_config_no_min_exact_match():
     g, reads = make_world(200, 15, n_reads=60)
     eg = emu_drv.EmuGraph(g)

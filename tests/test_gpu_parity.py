@@ -18,10 +18,12 @@ def gpu_graph(g):
     return aligner.Graph(g.k, W, last, F, valid)
 
 
-def compare_gpu(g, G, cfg, reads, limits=None, check_seeds=True):
+def compare_gpu(g, G, cfg, reads, limits=None, check_seeds=True, pipeline=None):
     o = orc.AlignRun(g, cfg, reads)
     assert o.error == "", o.error
     A = aligner.Aligner(G, cfg, limits)
+    if pipeline:
+        A.set_pipeline(pipeline)
     A.keep_seeds(check_seeds)
     got, status = A.align_batch(reads)
     assert all(s == 0 for s in status), status
@@ -55,6 +57,32 @@ def test_mapping(k, mask):
 def test_align_cli_config(k, mask, seed):
     g, reads = make_world(100 + seed, k, mask=mask)
     compare_gpu(g, gpu_graph(g), capi.config_cli(k), reads)
+
+
+PIPELINES = ["split8", "split16", "splitw", "wave", "g8", "g16", "lane"]
+
+
+@pytest.mark.parametrize("pipeline", PIPELINES)
+def test_every_pipeline_matches_the_oracle(pipeline):
+    """All instantiations of the per-read program (64 / 16 / 8 / 1 lanes per read, fused or split into a
+    seeding and an extension kernel with a work sort between them) give the oracle's results."""
+    g, reads = make_world(500, 31, genome_len=6000, n_reads=150, read_len=150, n_variants=30)
+    G = gpu_graph(g)
+    compare_gpu(g, G, capi.config_cli(31), reads, pipeline=pipeline)
+    # ragged batch, fewer reads than lanes, forward only
+    g, reads = make_world(501, 13, n_reads=7)
+    cfg = capi.config_cli(13)
+    cfg.forward_and_reverse_complement = 0
+    cfg.min_exact_match = 0.0
+    compare_gpu(g, gpu_graph(g), cfg, reads + [reads[0][:40], "ACGT", ""], pipeline=pipeline)
+
+
+def test_unknown_pipeline_is_an_error():
+    g, _ = make_world(3, 9, genome_len=300, n_reads=0)
+    A = aligner.Aligner(gpu_graph(g), capi.config_cli(9))
+    with pytest.raises(aligner.MgxError) as e:
+        A.set_pipeline("warp32")
+    assert e.value.code == capi.MGX_ERR_INVALID
 
 
 def test_align_forward_only_and_no_min_exact_match():
