@@ -181,32 +181,34 @@ def main():
                                          [round(c / max(1, sum(st["extend_cycles"])), 3) for c in st["extend_cycles"]]))}
 
     # ---------------- parity spot check + CPU baseline (oracle = checker, never the thing measured) -----
-    import orc
-    W_h, last_h = W.cpu().numpy(), last.cpu().numpy()
-    view = capi.BossView()
-    view.k, view.sigma, view.n_edges, view.mode, view.on_device = args.k, 5, n_edges, 0, 0
-    view.W, view.last = W_h.ctypes.data, last_h.ctypes.data
-    Fc = (C.c_uint64 * 5)(*[int(x) for x in boss["F"]])
-    view.F = C.cast(Fc, C.POINTER(C.c_uint64))
-    og = orc.Graph(orc.L().orc_graph_from_boss(C.byref(view)))
-    orc.L().orc_graph_build_first_chars(og.h, os.cpu_count() or 1)      # NodeFirstCache stand-in (one-off, untimed)
-    ns = min(args.parity_sample, args.reads)
-    sample = [bytes(r) for r in reads[:ns].cpu().numpy()]
-    got, status = A.align_batch(sample)
-    orun = orc.AlignRun(og, cfg, sample, threads=os.cpu_count() or 1, validate=False)
-    want = orun.results()
-    mism = sum(1 for a, b in zip(got, want) if a != b)
-    parity = {"sample": ns, "mismatches": mism, "capacity_errors": int(st["n_capacity_errors"])}
-    cpu = None
-    if not args.no_cpu_baseline:
-        nc = min(args.cpu_sample, args.reads)
-        csample = [bytes(r) for r in reads[:nc].cpu().numpy()]
-        threads = os.cpu_count() or 1
-        tc = time.time()
-        orc.AlignRun(og, cfg, csample, threads=threads, validate=False)
-        dt = time.time() - tc
-        cpu = {"value": round(nc / dt, 1), "unit": "reads/s", "cores": threads, "kind": "port",
-               "sample": "first %d reads of the same workload, same graph, %d threads, %.1fs" % (nc, threads, dt)}
+    parity, cpu = None, None
+    if args.parity_sample > 0 or not args.no_cpu_baseline:
+        import orc
+        W_h, last_h = W.cpu().numpy(), last.cpu().numpy()
+        view = capi.BossView()
+        view.k, view.sigma, view.n_edges, view.mode, view.on_device = args.k, 5, n_edges, 0, 0
+        view.W, view.last = W_h.ctypes.data, last_h.ctypes.data
+        Fc = (C.c_uint64 * 5)(*[int(x) for x in boss["F"]])
+        view.F = C.cast(Fc, C.POINTER(C.c_uint64))
+        og = orc.Graph(orc.L().orc_graph_from_boss(C.byref(view)))
+        orc.L().orc_graph_build_first_chars(og.h, os.cpu_count() or 1)      # NodeFirstCache stand-in (one-off, untimed)
+        ns = min(args.parity_sample, args.reads)
+        if ns:
+            sample = [bytes(r) for r in reads[:ns].cpu().numpy()]
+            got, status = A.align_batch(sample)
+            orun = orc.AlignRun(og, cfg, sample, threads=os.cpu_count() or 1, validate=False)
+            want = orun.results()
+            mism = sum(1 for a, b in zip(got, want) if a != b)
+            parity = {"sample": ns, "mismatches": mism, "capacity_errors": int(st["n_capacity_errors"])}
+        if not args.no_cpu_baseline:
+            nc = min(args.cpu_sample, args.reads)
+            csample = [bytes(r) for r in reads[:nc].cpu().numpy()]
+            threads = os.cpu_count() or 1
+            tc = time.time()
+            orc.AlignRun(og, cfg, csample, threads=threads, validate=False)
+            dt = time.time() - tc
+            cpu = {"value": round(nc / dt, 1), "unit": "reads/s", "cores": threads, "kind": "port",
+                   "sample": "first %d reads of the same workload, same graph, %d threads, %.1fs" % (nc, threads, dt)}
 
     out = {"metric": "aligned reads/sec (150 bp, k=31)", "value": round(value, 1), "unit": "reads/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

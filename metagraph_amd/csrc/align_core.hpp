@@ -169,7 +169,10 @@ struct ExtendResult { int32_t n_tips; int32_t min_cell_score; int32_t table_size
 
 // One DP column staged on chip (S, E, F incl. the 5-cell padding): the column being computed and its
 // parent live in LDS so that the hot path of an extension never waits on the HBM arena.
-struct Staging { int32_t *S, *E, *F; int32_t col; };
+#ifndef MGX_WPTR
+#define MGX_WPTR
+#endif
+struct Staging { int32_t * MGX_WPTR S, * MGX_WPTR E, * MGX_WPTR F; int32_t col; };
 constexpr int32_t LQ_CAP = 32;       // frontier entries kept in LDS; the rest spill to the arena
 
 struct Wave {
@@ -189,10 +192,10 @@ struct Wave {
     uint8_t *pos_full;
     uint32_t *pos_start, *rfirst, *rlast, *alt;
     // extension scratch
-    int32_t *cells;
-    ColMeta *cols;
-    uint64_t *queue, *next_nodes;         // arena tiers of the frontier / current batch
-    uint64_t *lq, *lnn;                   // LDS tiers (first LQ_CAP entries)
+    int32_t * MGX_WPTR cells;
+    ColMeta * MGX_WPTR cols;
+    uint64_t * MGX_WPTR queue, * MGX_WPTR next_nodes;         // arena tiers of the frontier / current batch
+    uint64_t * MGX_WPTR lq, * MGX_WPTR lnn;                   // LDS tiers (first LQ_CAP entries)
     Staging st[2];
     ColMeta hot;                          // metadata of the most recently committed column
     int32_t hot_idx;
@@ -291,10 +294,15 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     uint32_t lleft_seed_end = lleft;
     lp = lp_mark;
     lleft = lleft_mark;
+#ifdef MGX_ST_CAP_HACK
+    const uint64_t stc = MGX_ST_CAP_HACK;
+#else
+    const uint64_t stc = L + 16;
+#endif
     for (int b = 0; b < 2; ++b) {
-        w.st[b].S = (int32_t *)take_fast((L + 16) * 4);
-        w.st[b].E = (int32_t *)take_fast((L + 16) * 4);
-        w.st[b].F = (int32_t *)take_fast((L + 16) * 4);
+        w.st[b].S = (int32_t *)take_fast(stc * 4);
+        w.st[b].E = (int32_t *)take_fast(stc * 4);
+        w.st[b].F = (int32_t *)take_fast(stc * 4);
         w.st[b].col = -1;
     }
     if (lleft_seed_end < lleft) { lp = lp_seed_end; lleft = lleft_seed_end; }     // past the larger side of the overlay
@@ -698,6 +706,19 @@ MGX_DEV int32_t index_range_lane(const Wave &w, int s, int32_t i, int32_t len, i
     *first = succ_last(g, rl, ctr);
     *last = ru;
     return it;
+}
+
+// per-column timers of extend() (mgx_stats.extend_cycles): a profiling aid that costs an s_memtime + lgkmcnt
+// drain per reading, measured to be free on gfx950 (769 vs 773 ms per 2 M reads); -DMGX_XTIMERS=0 removes them
+#ifndef MGX_XTIMERS
+#define MGX_XTIMERS 1
+#endif
+MGX_DEV uint64_t xclock() {
+#if MGX_XTIMERS
+    return cycle_clock();
+#else
+    return 0;
+#endif
 }
 
 #ifdef MGX_SEED_PROBE
@@ -1410,7 +1431,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     frontier_insert(w, qn, queue_key(0, 0, 0));
 
     while (qn) {
-        uint64_t tx0 = cycle_clock();
+        uint64_t tx0 = xclock();
         // pop every entry that shares the top score, in descending tuple order (:491-500)
         {
             const int32_t top_score = key_score(tier_get(w.lq, w.queue, qn - 1));
@@ -1421,9 +1442,9 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             }
             wave_sync();
         }
-        w.xcyc[0] += cycle_clock() - tx0;
+        w.xcyc[0] += xclock() - tx0;
         while (nn) {
-            uint64_t tx1 = cycle_clock();
+            uint64_t tx1 = xclock();
             const int32_t i = (int32_t)uni(key_idx(tier_get(w.lnn, w.next_nodes, nn - 1)));
             --nn;
             const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : w.cols[i]);
@@ -1452,7 +1473,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             }
             int32_t begin = b + col.trim, prev_end = e + col.trim;
             if (prev_end <= begin) continue;
-            uint64_t tx2 = cycle_clock();
+            uint64_t tx2 = xclock();
             w.xcyc[1] += tx2 - tx1;
 
             uint32_t out_nodes[5];
@@ -1463,7 +1484,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 if (n_tips < max_columns) w.tips[n_tips++] = (uint32_t)i;
                 continue;
             }
-            w.xcyc[2] += cycle_clock() - tx2;
+            w.xcyc[2] += xclock() - tx2;
             const int32_t end = imin(prev_end, window_size) + 1;
             const int cb = 1 - pb;
             for (int oi = 0; oi < n_out; ++oi) {
@@ -1477,11 +1498,11 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 uint32_t table_cap_before = E.table_cap;
                 if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
                 ++w.n_columns;
-                uint64_t tx3 = cycle_clock();
+                uint64_t tx3 = xclock();
                 const int32_t size = uni(compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
                                                         start, window_size, xdrop_cutoff));
                 const int32_t pushes = uni(w.tmp_pushes);
-                uint64_t tx4 = cycle_clock();
+                uint64_t tx4 = xclock();
                 w.xcyc[3] += tx4 - tx3;
                 ColMeta cur;
                 cur.node = next; cur.parent = i; cur.c = c; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
@@ -1517,7 +1538,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 }
                 cur.max_pos = best_j + begin;
                 const int32_t max_val = best_s;
-                uint64_t tx5 = cycle_clock();
+                uint64_t tx5 = xclock();
                 w.xcyc[4] += tx5 - tx4;
                 if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) {
                     // pop(table.size() - 1): the vector keeps its (possibly grown) capacity
@@ -1538,10 +1559,10 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 ++tsize;
                 const int32_t vec_offset = start + begin - (begin ? 1 : 0);
                 const int32_t skip = begin ? 0 : 1;
-                uint64_t tx6 = cycle_clock();
+                uint64_t tx6 = xclock();
                 w.xcyc[5] += tx6 - tx5;
                 int32_t converged = update_seed_filter(w, E, next, vec_offset, cS + skip, size - skip);
-                uint64_t tx7 = cycle_clock();
+                uint64_t tx7 = xclock();
                 w.xcyc[6] += tx7 - tx6;
                 if (w.status != ST_OK) { res->table_size = 0; return; }
                 if (converged != NINF) {
@@ -1555,7 +1576,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                         frontier_insert(w, qn, key);
                     }
                 }
-                w.xcyc[7] += cycle_clock() - tx7;
+                w.xcyc[7] += xclock() - tx7;
             }
         }
     }
@@ -2076,11 +2097,12 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
 MGX_DEV uint32_t predicted_work(const Wave &w) {
     const int first = w.num_matching[0] >= w.num_matching[1] ? 0 : 1;
     if (!w.n_seeds[first]) return 0;
-    const DevSeed sd = w.seeds[first][0];
-    const int32_t end = sd.clipping + sd.length;
-    const uint32_t n_ext = (sd.clipping > 0 ? 1u : 0u) + (end < w.L ? 1u : 0u);
-    const uint32_t cols = (uint32_t)imin(1023, w.L - (int32_t)sd.length);
-    return 1 + ((n_ext << 10) | cols);
+    // The forward extension starts at the first seed's first node and replays the seed, so it computes about
+    // L - clipping columns; a clipped start adds the backward pass, which replays the whole forward alignment
+    // before it reaches the clipped prefix (about L more columns).
+    const int32_t clip = w.seeds[first][0].clipping;
+    const int32_t cols = (w.L - clip) + (clip > 0 ? w.L : 0);
+    return 1u + (uint32_t)imin(4094, cols);
 }
 
 // The whole per-read program; `slot` selects the arena slice.  PHASE splits it for the two-kernel

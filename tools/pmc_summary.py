@@ -1,0 +1,41 @@
+"""Aggregate the rocprofv3 --pmc CSVs of tools/pmc_passes.sh into profiles/<round>_pmc_summary.json:
+per kernel the summed counter values over its dispatches, bytes per read, and the SQ ratios."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+out_name = sys.argv[2] if len(sys.argv) > 2 else "r01_pmc_summary.json"
+KERNELS = {"k_map": "k_map(", "k_seed": "k_align<1>", "k_extend": "k_align_grp8<2>", "k_align_fused": "k_align<3>"}
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(set)
+for path in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(path)):
+        for short, pat in KERNELS.items():
+            if pat in r["Kernel_Name"]:
+                agg[short][r["Counter_Name"]] += float(r["Counter_Value"])
+                disp[short].add((path, r["Dispatch_Id"]))
+summary = {"reads_per_launch": reads, "note": "bench.py --reads %d --steps 1 --warmup 0: one launch of each kernel; "
+           "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE tallies 128-B requests as "
+           "64 B (MI355X_MICROARCH.md, HBM section), so fetch bytes = 2 x FETCH_SIZE x 1024; Infinity-Cache hits are "
+           "included in these fabric-side counters" % reads, "kernels": {}}
+for k, c in agg.items():
+    d = {"counters": dict(c), "dispatches": len(disp[k])}
+    if "FETCH_SIZE" in c:
+        d["fetch_bytes_corrected"] = 2 * c["FETCH_SIZE"] * 1024
+    if "WRITE_SIZE" in c:
+        d["write_bytes"] = c["WRITE_SIZE"] * 1024
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        d["traffic_bytes_per_read"] = (d["fetch_bytes_corrected"] + d["write_bytes"]) / reads
+    if c.get("SQ_WAVE_CYCLES"):
+        wc = c["SQ_WAVE_CYCLES"]
+        d["sq"] = {"active_inst_frac": c.get("SQ_ACTIVE_INST_ANY", 0) / wc, "wait_any_frac": c.get("SQ_WAIT_ANY", 0) / wc,
+                   "wait_inst_frac": c.get("SQ_WAIT_INST_ANY", 0) / wc,
+                   "insts_per_read": {n[9:]: c[n] / reads for n in c if n.startswith("SQ_INSTS_")}}
+    summary["kernels"][k] = d
+json.dump(summary, open(os.path.join(ROOT, "profiles", out_name), "w"), indent=1, sort_keys=True)
+print(json.dumps(summary, indent=1, sort_keys=True)[:3000])
