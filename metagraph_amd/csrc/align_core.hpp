@@ -169,10 +169,7 @@ struct ExtendResult { int32_t n_tips; int32_t min_cell_score; int32_t table_size
 
 // One DP column staged on chip (S, E, F incl. the 5-cell padding): the column being computed and its
 // parent live in LDS so that the hot path of an extension never waits on the HBM arena.
-#ifndef MGX_WPTR
-#define MGX_WPTR
-#endif
-struct Staging { int32_t * MGX_WPTR S, * MGX_WPTR E, * MGX_WPTR F; int32_t col; };
+struct Staging { int32_t *S, *E, *F; int32_t col; };
 constexpr int32_t LQ_CAP = 32;       // frontier entries kept in LDS; the rest spill to the arena
 
 struct Wave {
@@ -192,10 +189,10 @@ struct Wave {
     uint8_t *pos_full;
     uint32_t *pos_start, *rfirst, *rlast, *alt;
     // extension scratch
-    int32_t * MGX_WPTR cells;
-    ColMeta * MGX_WPTR cols;
-    uint64_t * MGX_WPTR queue, * MGX_WPTR next_nodes;         // arena tiers of the frontier / current batch
-    uint64_t * MGX_WPTR lq, * MGX_WPTR lnn;                   // LDS tiers (first LQ_CAP entries)
+    int32_t *cells;
+    ColMeta *cols;
+    uint64_t *queue, *next_nodes;         // arena tiers of the frontier / current batch
+    uint64_t *lq, *lnn;                   // LDS tiers (first LQ_CAP entries)
     Staging st[2];
     ColMeta hot;                          // metadata of the most recently committed column
     int32_t hot_idx;
