@@ -127,7 +127,7 @@ struct ConvChecker {             // SeedFilteringExtender::conv_checker_ (extend
 struct SdustScratch {            // working set of is_low_complexity(); lives in LDS on the device
     int16_t cv[64], cw[64], c2[64];
     int16_t Ps[64], Pf[64], Pr[64], Pl[64];   // perfect intervals (at most one per window position)
-    uint8_t wq[64];                           // window deque (ring)
+    int16_t wqw[64];                          // window deque (ring)
 };
 
 struct DevAln {                  // Alignment (alignment.hpp:132-331)
@@ -178,6 +178,7 @@ struct Wave {
     uint8_t *q[2];
     int32_t *psum[2];
     const uint32_t *nodes[2];
+    const uint8_t *mlen[2];      // k_map's index() match lengths per position (may be null)
     int32_t n_kmers;
     DevSeed *seeds[2];
     uint8_t *alive[2];
@@ -378,12 +379,24 @@ MGX_DEV uint8_t profile_op_at(const uint8_t *q, int32_t L, uint8_t c, int32_t ab
 // A/aligner_seeder_methods.cpp:22-29 with T = 20, W = 64).  Wave-uniform scalar code; `sd` is a
 // 2048-word scratch area.  Returns whether any interval is masked.
 // ------------------------------------------------------------------------------------------------
-MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *sd) {
-    constexpr int T = 20, W = 64, WLEN = 3, WTOT = 64, WMSK = 63;
-    int16_t *cv = sd->cv, *cw = sd->cw, *c2 = sd->c2;
-    uint8_t *wq = sd->wq;                     // window deque, ring of 64
+// 64-entry tables of sdust in memory (any lane count) ...
+struct MemTab64 {
+    int16_t *p;
+    MGX_DEV int32_t get(int i) const { return p[i]; }
+    MGX_DEV void add(int i, int32_t d) { p[i] = (int16_t)(p[i] + d); }
+    MGX_DEV void set(int i, int32_t x) { p[i] = (int16_t)x; }
+    MGX_DEV void fill(int32_t x) { for (int i = 0; i < 64; ++i) p[i] = (int16_t)x; }
+};
+// ... or, for a 64-lane wave, one entry per lane in a register (RegTab64 of wave.hpp)
+MGX_DEV void tab_copy(MemTab64 &dst, const MemTab64 &src) { for (int i = 0; i < 64; ++i) dst.p[i] = src.p[i]; }
+#if MGX_HAS_REGTAB
+MGX_DEV void tab_copy(RegTab64 &dst, const RegTab64 &src) { dst = src; }
+#endif
+template <class Tab>
+MGX_DEV bool sdust_core(const uint8_t *s, int32_t l_seq, SdustScratch *sd, Tab cv, Tab cw, Tab c2, Tab wq) {
+    constexpr int T = 20, W = 64, WLEN = 3, WMSK = 63;
     int16_t *Ps = sd->Ps, *Pf = sd->Pf, *Pr = sd->Pr, *Pl = sd->Pl;
-    for (int i = 0; i < WTOT; ++i) { cv[i] = 0; cw[i] = 0; }
+    cv.fill(0); cw.fill(0);
     int wfront = 0, wcount = 0;
     int Pn = 0;
     bool have_res = false;
@@ -391,7 +404,7 @@ MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *
     int rv = 0, rw = 0, Lw = 0;
     int l = 0;
     uint32_t t = 0;
-    auto wat = [&](int idx) { return wq[(wfront + idx) & 63]; };
+    auto wat = [&](int idx) { return wq.get((wfront + idx) & 63); };
     auto save_masked = [&](int start) {
         if (Pn == 0 || Ps[Pn - 1] >= start) return;
         int ps = Ps[Pn - 1], pf = Pf[Pn - 1];
@@ -418,32 +431,32 @@ MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *
                 save_masked(start);
                 // shift_window
                 if (wcount >= W - WLEN + 1) {
-                    int sv = wq[wfront & 63];
+                    int sv = wq.get(wfront & 63);
                     wfront = (wfront + 1) & 63;
                     --wcount;
-                    rw -= --cw[sv];
-                    if (Lw > wcount) { --Lw; rv -= --cv[sv]; }
+                    cw.add(sv, -1); rw -= cw.get(sv);
+                    if (Lw > wcount) { --Lw; cv.add(sv, -1); rv -= cv.get(sv); }
                 }
-                wq[(wfront + wcount) & 63] = (uint8_t)t;
+                wq.set((wfront + wcount) & 63, (int32_t)t);
                 ++wcount;
                 ++Lw;
-                rw += cw[t]++;
-                rv += cv[t]++;
-                if (cv[t] * 10 > T << 1) {
+                rw += cw.get((int)t); cw.add((int)t, 1);
+                rv += cv.get((int)t); cv.add((int)t, 1);
+                if (cv.get((int)t) * 10 > T << 1) {
                     int sv;
                     do {
                         sv = wat(wcount - Lw);
-                        rv -= --cv[sv];
+                        cv.add(sv, -1); rv -= cv.get(sv);
                         --Lw;
                     } while (sv != (int)t);
                 }
                 if (rw * 10 > Lw * T) {
                     // find_perfect
-                    for (int x = 0; x < WTOT; ++x) c2[x] = cv[x];
+                    tab_copy(c2, cv);
                     int r = rv, max_r = 0, max_l = 0;
                     for (int ii = wcount - Lw - 1; ii >= 0; --ii) {
                         int tt = wat(ii);
-                        r += c2[tt]++;
+                        r += c2.get(tt); c2.add(tt, 1);
                         int new_r = r, new_l = wcount - ii - 1;
                         if (new_r * 10 > T * new_l) {
                             int j;
@@ -470,6 +483,17 @@ MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *
         }
     }
     return have_res;
+}
+
+MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *sd) {
+#if MGX_HAS_REGTAB
+    RegTab64 cv, cw, c2, wq;
+    wq.fill(0); c2.fill(0);
+    return sdust_core(s, l_seq, sd, cv, cw, c2, wq);
+#else
+    MemTab64 cv = { sd->cv }, cw = { sd->cw }, c2 = { sd->c2 }, wq = { sd->wqw };
+    return sdust_core(s, l_seq, sd, cv, cw, c2, wq);
+#endif
 }
 
 // Window test with an exact shortcut.  A window is flagged iff it contains an interval (<= 64 words) whose
@@ -781,7 +805,14 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                 int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
                 uint16_t mlen = 0;
                 uint32_t rf = 0, rl_ = 0;
-                if (max_len >= (int32_t)w.msl[i]) {
+                bool need = max_len >= (int32_t)w.msl[i];
+                if (need && w.mlen[s] && i < w.n_kmers && max_len == k - 1) {
+                    // k_map's index() walked this very chain: skip lookups that cannot reach min_seed_length
+                    const uint32_t ml = w.mlen[s][i];
+                    if (ml == 254) need = msl0 <= (int32_t)g.prefix_len;
+                    else if (ml < 254) need = (int32_t)ml >= msl0;
+                }
+                if (need) {
                     uint64_t first, last;
                     int32_t m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
                     if (m >= msl0 && first && first <= g.n) {
@@ -2121,6 +2152,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     w.n_kmers = (int32_t)(P.node_begin[read + 1] - nb);
     w.nodes[0] = P.nodes_fwd + nb;
     w.nodes[1] = P.nodes_rc + nb;
+    w.mlen[0] = P.mlen_fwd ? P.mlen_fwd + nb : nullptr;
+    w.mlen[1] = P.mlen_rc ? P.mlen_rc + nb : nullptr;
     ReadResult rr;
     rr.status = ST_OK; rr.n_alignments = 0; rr.score = 0; rr.offset = 0; rr.n_nodes = rr.n_cigar = rr.seq_len = 0;
     rr.orientation = 0; rr.stream_off = 0;

@@ -78,6 +78,7 @@ struct AlignParams {
     const uint64_t *offsets;             // n_reads + 1
     const uint64_t *node_begin;          // n_reads + 1, k-mer slots per read
     const uint32_t *nodes_fwd, *nodes_rc;
+    const uint8_t *mlen_fwd, *mlen_rc;   // optional: per k-mer position, what index() matched (graph_build.hpp MLEN_*)
     uint64_t n_reads;
     uint8_t *arena;                      // per-wave workspace
     uint64_t arena_stride;

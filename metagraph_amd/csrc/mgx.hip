@@ -98,27 +98,39 @@ __global__ void k_kmer_counts(const uint64_t *offsets, uint64_t n_reads, uint32_
     if (i == n_reads) counts[i] = 0;
 }
 
-// one lane per (read, strand) chain
+#ifndef MGX_MAP_BLOCKS_PER_CU
+#define MGX_MAP_BLOCKS_PER_CU 8          // 256-thread blocks resident per CU (8 = 32 waves: full occupancy if registers allow)
+#endif
+// persistent lanes, one (read, strand) chain at a time (map_lane_step)
 __global__ void __launch_bounds__(256) k_map(DevGraph g, const char *seqs, const uint64_t *offsets, const uint64_t *node_begin,
-                                             uint32_t *nodes_fwd, uint32_t *nodes_rc, uint64_t n_reads, int do_rc,
-                                             KernelStats *stats) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t read = t >> 1;
-    int strand = (int)(t & 1);
+                                             uint32_t *nodes_fwd, uint32_t *nodes_rc, uint8_t *mlen_fwd, uint8_t *mlen_rc,
+                                             uint64_t n_reads, int do_rc, unsigned long long *cursor, KernelStats *stats) {
     LineCtr ctr = { 0, 0, 0 };
-    if (read < n_reads && (strand == 0 || do_rc)) {
+    MapLane m;
+    m.state = 0;
+    const uint64_t n_chains = do_rc ? 2 * n_reads : n_reads;
+    auto fetch = [&](MapLane &ml) -> bool {
+        uint64_t c = atomicAdd(cursor, 1ull);
+        if (c >= n_chains) return false;
+        uint64_t read = do_rc ? (c >> 1) : c;
+        ml.strand = do_rc ? (int)(c & 1) : 0;
         uint64_t off = offsets[read];
-        int32_t L = (int32_t)(offsets[read + 1] - off);
-        uint32_t *out = (strand ? nodes_rc : nodes_fwd) + node_begin[read];
-        map_chain(g, seqs + off, L, strand, out, ctr);
-    }
+        ml.L = (int32_t)(offsets[read + 1] - off);
+        ml.seq = seqs + off;
+        ml.out = (ml.strand ? nodes_rc : nodes_fwd) + node_begin[read];
+        ml.out_len = (ml.strand ? mlen_rc : mlen_fwd) + node_begin[read];
+        ml.n_kmers = ml.L - (int32_t)g.k + 1;
+        return true;
+    };
+    while (m.state != 3) map_lane_step(g, m, ctr, fetch);
     // per-wave reduction of the line counters
-    uint32_t r = ctr.rank_lines, s = ctr.select_lines;
-    for (int d = 32; d >= 1; d >>= 1) { r += __shfl_xor(r, d, 64); s += __shfl_xor(s, d, 64); }
-    if ((threadIdx.x & 63) == 0 && (r | s)) {
+    uint32_t r = ctr.rank_lines, s = ctr.select_lines, b = ctr.bit_lines;
+    for (int d = 32; d >= 1; d >>= 1) { r += __shfl_xor(r, d, 64); s += __shfl_xor(s, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0 && (r | s | b)) {
         atomicAdd(&stats->rank_lines, (unsigned long long)r);
         atomicAdd(&stats->select_lines, (unsigned long long)s);
-        atomicAdd(&stats->map_lines, (unsigned long long)r + s);
+        atomicAdd(&stats->bit_lines, (unsigned long long)b);
+        atomicAdd(&stats->map_lines, (unsigned long long)r + s + b);
     }
 }
 
@@ -243,6 +255,7 @@ struct mgx_aligner {
     DevConfig dcfg;
     mgx_limits user_lim;
     bool have_user_lim = false;
+    DevBuf mlen_fwd, mlen_rc;     // k_map's index() match lengths, one byte per k-mer position
     DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, scan_tmp, dbg_seeds;
     DevBuf seed_hdr, seed_stream, work_key, work_key_sorted, order_in, order, sort_tmp;    // split pipeline
     DevLimits lim;
@@ -528,6 +541,8 @@ static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets
     *Lmax_out = (uint32_t)lmax;
     if (int rc = A->nodes_fwd.ensure((total_kmers + 1) * 4)) return rc;
     if (int rc = A->nodes_rc.ensure((total_kmers + 1) * 4)) return rc;
+    if (int rc = A->mlen_fwd.ensure(total_kmers + 1)) return rc;
+    if (int rc = A->mlen_rc.ensure(total_kmers + 1)) return rc;
     return MGX_OK;
 }
 
@@ -537,13 +552,27 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
         // max_seed_length < k: nodes are not mapped (dbg_aligner.cpp:209-213)
         HIP_TRY(hipMemsetAsync(A->nodes_fwd.p, 0, (A->total_kmers + 1) * 4, 0));
         HIP_TRY(hipMemsetAsync(A->nodes_rc.p, 0, (A->total_kmers + 1) * 4, 0));
+        HIP_TRY(hipMemsetAsync(A->mlen_fwd.p, 0xFF, A->total_kmers + 1, 0));
+        HIP_TRY(hipMemsetAsync(A->mlen_rc.p, 0xFF, A->total_kmers + 1, 0));
         return MGX_OK;
     }
+    unsigned long long *map_cursor = A->cursors.as<unsigned long long>() + 4;
+    HIP_TRY(hipMemsetAsync(map_cursor, 0, 8, 0));
+    HIP_TRY(hipMemsetAsync(A->mlen_fwd.p, 0xFF, A->total_kmers + 1, 0));       // MLEN_UNKNOWN
+    if (do_rc) HIP_TRY(hipMemsetAsync(A->mlen_rc.p, 0xFF, A->total_kmers + 1, 0));
     HIP_TRY(hipEventRecord(A->ev[0], 0));
-    uint64_t threads = 2 * n;
-    k_map<<<(uint32_t)((threads + 255) / 256), 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
-                                                        A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(), n, do_rc ? 1 : 0,
-                                                        A->d_stats.as<KernelStats>());
+    {
+        // persistent lanes: enough wavefronts to fill the device, never more lanes than chains
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, A->graph->device));
+        const uint64_t chains = (do_rc ? 2 : 1) * n;
+        uint64_t blocks = std::min<uint64_t>((uint64_t)prop.multiProcessorCount * MGX_MAP_BLOCKS_PER_CU, (chains + 255) / 256);
+        if (blocks == 0) blocks = 1;
+        k_map<<<(uint32_t)blocks, 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
+                                         A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(),
+                                         A->mlen_fwd.as<uint8_t>(), A->mlen_rc.as<uint8_t>(), n, do_rc ? 1 : 0,
+                                         map_cursor, A->d_stats.as<KernelStats>());
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(A->ev[1], 0));
     return MGX_OK;
@@ -604,6 +633,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.node_begin = A->node_begin.as<uint64_t>();
     P.nodes_fwd = A->nodes_fwd.as<uint32_t>();
     P.nodes_rc = A->nodes_rc.as<uint32_t>();
+    P.mlen_fwd = A->mlen_fwd.as<uint8_t>();
+    P.mlen_rc = A->mlen_rc.as<uint8_t>();
     P.n_reads = n;
     P.arena = A->arena.as<uint8_t>();
     P.arena_stride = stride;

@@ -162,6 +162,17 @@ MGX_DEV uint32_t sload_u32(const uint32_t *p) {
     return v;
 }
 
+// A 64-entry table of small integers held one entry per lane in a VGPR (wave-uniform index): reads are one
+// v_readlane, updates one predicated add; no memory traffic.  Used by sdust for its triplet counters and window.
+#define MGX_HAS_REGTAB 1
+struct RegTab64 {
+    int32_t v;
+    MGX_DEV int32_t get(int i) const { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(i)); }
+    MGX_DEV void add(int i, int32_t d) { if (lane_id() == i) v += d; }
+    MGX_DEV void set(int i, int32_t x) { if (lane_id() == i) v = x; }
+    MGX_DEV void fill(int32_t x) { v = x; }
+};
+
 MGX_DEV uint64_t cycle_clock() { return __builtin_readcyclecounter(); }
 MGX_DEV int popc64(uint64_t x) { return __popcll(x); }
 MGX_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }           // x != 0

@@ -60,6 +60,8 @@ MGX_DEV u32x16 sload_x16(const void *p) {
 }
 MGX_DEV uint32_t sload_u32(const uint32_t *p) { return *p; }
 
+#define MGX_HAS_REGTAB 0          // fewer than 64 lanes per read: sdust keeps its tables in memory
+
 MGX_DEV uint64_t cycle_clock() { return __builtin_readcyclecounter(); }
 MGX_DEV int popc64(uint64_t x) { return __popcll(x); }
 MGX_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }

@@ -129,16 +129,31 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         R->node_begin[i + 1] = R->node_begin[i] + (L >= k ? L - k + 1 : 0);
     }
     std::vector<uint32_t> nf(R->node_begin[n] + 1, 0), nr(R->node_begin[n] + 1, 0);
+    std::vector<uint8_t> lf(R->node_begin[n] + 1, MLEN_UNKNOWN), lr(R->node_begin[n] + 1, MLEN_UNKNOWN);
     bool mapped = cfg.max_seed_length >= k;
     memset(&R->stats, 0, sizeof(R->stats));
     if (mapped) {
-        for (uint64_t i = 0; i < n; ++i) {
-            LineCtr ctr = { 0, 0, 0 };
-            int32_t L = (int32_t)(offsets[i + 1] - offsets[i]);
-            map_chain(G->g, seqs + offsets[i], L, 0, nf.data() + R->node_begin[i], ctr);
-            if (map_only || cfg.forward_and_reverse_complement) map_chain(G->g, seqs + offsets[i], L, 1, nr.data() + R->node_begin[i], ctr);
-            R->stats.rank_lines += ctr.rank_lines; R->stats.select_lines += ctr.select_lines;
-        }
+        // the product's k_map: persistent lanes stepping the per-lane state machine (here: one lane)
+        const bool do_rc = map_only || cfg.forward_and_reverse_complement;
+        const uint64_t n_chains = do_rc ? 2 * n : n;
+        uint64_t cursor = 0;
+        LineCtr ctr = { 0, 0, 0 };
+        MapLane m;
+        m.state = 0;
+        auto fetch = [&](MapLane &ml) -> bool {
+            uint64_t c = cursor++;
+            if (c >= n_chains) return false;
+            uint64_t read = do_rc ? (c >> 1) : c;
+            ml.strand = do_rc ? (int)(c & 1) : 0;
+            ml.L = (int32_t)(offsets[read + 1] - offsets[read]);
+            ml.seq = seqs + offsets[read];
+            ml.out = (ml.strand ? nr.data() : nf.data()) + R->node_begin[read];
+            ml.out_len = (ml.strand ? lr.data() : lf.data()) + R->node_begin[read];
+            ml.n_kmers = ml.L - (int32_t)k + 1;
+            return true;
+        };
+        while (m.state != 3) map_lane_step(G->g, m, ctr, fetch);
+        R->stats.rank_lines += ctr.rank_lines; R->stats.select_lines += ctr.select_lines;
     }
     R->m_fwd.assign(nf.begin(), nf.end());
     R->m_rc.assign(nr.begin(), nr.end());
@@ -159,6 +174,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     P.g = G->g; P.cfg = dcfg; P.lim = R->lim; P.score_matrix = sm.data();
     P.seqs = seqs; P.offsets = offsets; P.node_begin = R->node_begin.data();
     P.nodes_fwd = nf.data(); P.nodes_rc = nr.data(); P.n_reads = n;
+    P.mlen_fwd = lf.data(); P.mlen_rc = lr.data();
     P.arena = arena.data(); P.arena_stride = stride;
     P.results = R->results.data(); P.out_stream = R->stream.data(); P.out_capacity = out_words;
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();

@@ -103,6 +103,20 @@ inline void wave_sync() {}
 typedef struct { uint32_t v[16]; uint32_t operator[](int i) const { return v[i]; } } u32x16;
 inline u32x16 sload_x16(const void *p) { u32x16 r; memcpy(r.v, p, 64); return r; }
 inline uint32_t sload_u32(const uint32_t *p) { return *p; }
+// host model of wave.hpp's register-resident 64-entry table (only meaningful for a 64-lane wave)
+#if MGX_EMU_WAVE == 64
+#define MGX_HAS_REGTAB 1
+struct RegTab64 {
+    int32_t v[64];
+    int32_t get(int i) const { return v[i & 63]; }
+    void add(int i, int32_t d) { v[i & 63] += d; }
+    void set(int i, int32_t x) { v[i & 63] = x; }
+    void fill(int32_t x) { for (int i = 0; i < 64; ++i) v[i] = x; }
+};
+#else
+#define MGX_HAS_REGTAB 0
+#endif
+
 inline uint64_t cycle_clock() { return 0; }
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
