@@ -179,6 +179,7 @@ struct Wave {
     int32_t *psum[2];
     const uint32_t *nodes[2];
     const uint8_t *mlen[2];      // k_map's index() match lengths per position (may be null)
+    const uint2 *rng[2];         // and the (rl, ru) ranges of matches >= min_seed_length (may be null)
     int32_t n_kmers;
     DevSeed *seeds[2];
     uint8_t *alive[2];
@@ -687,6 +688,8 @@ MGX_NI_G2 void base_seeds(Wave &w, int s) {
     }
 }
 
+constexpr uint32_t DEFERRED_RANGE = 0xFFFFFFFFu;     // rfirst[] marker: match length known, range not fetched yet
+
 // BOSS::index_range (boss.hpp:720-764) for one lane: codes q[i .. i + len); returns matched length,
 // *first = succ_last(rl), *last = ru
 MGX_DEV int32_t index_range_lane(const Wave &w, int s, int32_t i, int32_t len, int32_t min_len,
@@ -793,6 +796,10 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     }
     wave_sync();
     SEED_T(2, tp)
+    // Read tail (positions with fewer than k characters left): if the last k-mer is a node, its target node's
+    // label ends with q[i..L) for every such i, so index_range matches all L - i characters.  The length is all
+    // the replacement rules need for dominated positions; the range is fetched only if a position reports.
+    const bool tail_known = w.n_kmers > 0 && w.nodes[s][w.n_kmers - 1] != 0 && !w.inv_any[s];
     // lane-parallel longest-prefix lookups for every position that can report a seed
     for (int32_t base = 0; base < nslots; base += WAVE) {
         LV<int32_t> nr, ns;
@@ -806,15 +813,34 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                 uint16_t mlen = 0;
                 uint32_t rf = 0, rl_ = 0;
                 bool need = max_len >= (int32_t)w.msl[i];
+                int32_t known = -1;                              // match length with a stored range, if any
                 if (need && w.mlen[s] && i < w.n_kmers && max_len == k - 1) {
-                    // k_map's index() walked this very chain: skip lookups that cannot reach min_seed_length
+                    // k_map's index() walked this very chain (BOSS::index_range == index() up to the failing
+                    // character): skip lookups that cannot reach min_seed_length, reuse the range of those that do
                     const uint32_t ml = w.mlen[s][i];
                     if (ml == 254) need = msl0 <= (int32_t)g.prefix_len;
-                    else if (ml < 254) need = (int32_t)ml >= msl0;
+                    else if (ml < 254) {
+                        need = (int32_t)ml >= msl0;
+                        if (need && w.rng[s]) known = (int32_t)ml;
+                    }
+                }
+                if (need && tail_known && i >= w.n_kmers && max_len == L - i && max_len >= msl0) {
+                    mlen = (uint16_t)max_len;
+                    rf = DEFERRED_RANGE;
+                    need = false;
                 }
                 if (need) {
                     uint64_t first, last;
-                    int32_t m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
+                    int32_t m;
+                    if (known >= 0) {
+                        const uint2 r = w.rng[s][i];
+                        ++lc.bit_lines;
+                        first = succ_last(g, r.x, lc);           // index_range's return (boss.hpp:756-763)
+                        last = r.y;
+                        m = known;
+                    } else {
+                        m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
+                    }
                     if (m >= msl0 && first && first <= g.n) {
                         mlen = (uint16_t)m;
                         rf = rank_last(g, first, lc);
@@ -824,7 +850,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                 w.ml[i] = mlen; w.rfirst[i] = rf; w.rlast[i] = rl_;
                 hit[l] = mlen != 0;
             }
-            nr[l] = (int32_t)lc.rank_lines; ns[l] = (int32_t)lc.select_lines;
+            nr[l] = (int32_t)(lc.rank_lines + lc.bit_lines); ns[l] = (int32_t)lc.select_lines;
         }
         w.ctr.rank_lines += (uint32_t)wave_sum(nr);
         w.ctr.select_lines += (uint32_t)wave_sum(ns);
@@ -854,6 +880,20 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
 #else
         if (cfg.seed_complexity_filter && window_low_complexity(w, s, i, cur_msl)) continue;
 #endif
+        if (w.rfirst[i] == DEFERRED_RANGE) {
+            // deferred tail lookup: this position does report, so its node range is needed after all
+            uint64_t first, last;
+            LineCtr lc = { 0, 0, 0 };
+            const int32_t m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
+            const bool ok = m >= msl0 && first && first <= g.n;
+            uint32_t rf = 0, rl_ = 0;
+            if (ok) { rf = rank_last(g, first, lc); rl_ = rank_last(g, last, lc); }
+            w.ctr.rank_lines += lc.rank_lines; w.ctr.select_lines += lc.select_lines; w.ctr.bit_lines += lc.bit_lines;
+            wave_sync();
+            FOR_LANES(l) { if (l == 0) { w.rfirst[i] = rf; w.rlast[i] = rl_; } }
+            wave_sync();
+            if (!ok) continue;                                 // the eager path would not have listed it as a hit
+        }
         // enumerate nodes whose suffix matches (dbg_succinct.cpp:349-392)
         uint32_t first_alt = alt_n;
         uint32_t cnt = 0;
@@ -2154,6 +2194,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     w.nodes[1] = P.nodes_rc + nb;
     w.mlen[0] = P.mlen_fwd ? P.mlen_fwd + nb : nullptr;
     w.mlen[1] = P.mlen_rc ? P.mlen_rc + nb : nullptr;
+    w.rng[0] = P.rng_fwd ? P.rng_fwd + nb : nullptr;
+    w.rng[1] = P.rng_rc ? P.rng_rc + nb : nullptr;
     ReadResult rr;
     rr.status = ST_OK; rr.n_alignments = 0; rr.score = 0; rr.offset = 0; rr.n_nodes = rr.n_cigar = rr.seq_len = 0;
     rr.orientation = 0; rr.stream_off = 0;
@@ -2288,6 +2330,9 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         stats_accum->seed_lines += w.ctr.rank_lines + w.ctr.select_lines + w.ctr.bit_lines;
         stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
         for (int x = 0; x < 2; ++x) stats_accum->cyc[x] += w.cyc[x];
+#ifdef MGX_SEED_PROBE
+        for (int x = 0; x < 8; ++x) stats_accum->xcyc[x] += w.xcyc[x];
+#endif
         return;
     }
     const uint64_t tout = cycle_clock();

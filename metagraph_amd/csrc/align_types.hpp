@@ -79,6 +79,7 @@ struct AlignParams {
     const uint64_t *node_begin;          // n_reads + 1, k-mer slots per read
     const uint32_t *nodes_fwd, *nodes_rc;
     const uint8_t *mlen_fwd, *mlen_rc;   // optional: per k-mer position, what index() matched (graph_build.hpp MLEN_*)
+    const uint2 *rng_fwd, *rng_rc;       // optional: (rl, ru) of that match where it has >= min_seed_length characters
     uint64_t n_reads;
     uint8_t *arena;                      // per-wave workspace
     uint64_t arena_stride;

@@ -171,6 +171,8 @@ struct MapLane {
     const char *seq;
     uint32_t *out;
     uint8_t *out_len;         // may be null; pre-set to MLEN_UNKNOWN by the caller, written only where index() failed
+    uint2 *out_rng;           // may be null; (rl, ru) of the matched prefix where it has >= min_rng_len characters
+    int32_t min_rng_len;
     int32_t L, n_kmers, strand;
     int32_t i;                // next k-mer position
     int32_t scanned, last_invalid;
@@ -229,7 +231,10 @@ MGX_DEV void map_lane_step(const DevGraph &g, MapLane &m, LineCtr &ctr, FetchCha
     const int32_t i = m.i;
     if (m.t < k - 1) {
         if (!tighten_range(g, &m.rl, &m.ru, strand_code(m.seq, m.L, m.strand, i + m.t), ctr)) {
-            if (m.out_len && k - 1 < MLEN_LT_PREFIX) m.out_len[i] = (uint8_t)m.t;
+            if (m.out_len && k - 1 < MLEN_LT_PREFIX) {
+                m.out_len[i] = (uint8_t)m.t;
+                if (m.out_rng && m.t >= m.min_rng_len) m.out_rng[i] = make_uint2((uint32_t)m.rl, (uint32_t)m.ru);
+            }
             m.out[i] = 0; m.edge = 0; ++m.i; m.state = 1;
             return;
         }
@@ -240,7 +245,10 @@ MGX_DEV void map_lane_step(const DevGraph &g, MapLane &m, LineCtr &ctr, FetchCha
     m.blk = load_block(g, (uint32_t)(m.ru >> 6));
     m.edge = pick_edge_from(g, m.ru, m.blk, strand_code(m.seq, m.L, m.strand, i + k - 1), ctr);
     m.out[i] = in_graph(g, m.edge) ? (uint32_t)m.edge : 0;
-    if (!m.edge && m.out_len && k - 1 < MLEN_LT_PREFIX) m.out_len[i] = (uint8_t)(k - 1);
+    if (!m.edge && m.out_len && k - 1 < MLEN_LT_PREFIX) {
+        m.out_len[i] = (uint8_t)(k - 1);
+        if (m.out_rng && k - 1 >= m.min_rng_len) m.out_rng[i] = make_uint2((uint32_t)m.rl, (uint32_t)m.ru);
+    }
     ++m.i;
     m.state = 1;
 }

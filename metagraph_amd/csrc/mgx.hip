@@ -104,6 +104,7 @@ __global__ void k_kmer_counts(const uint64_t *offsets, uint64_t n_reads, uint32_
 // persistent lanes, one (read, strand) chain at a time (map_lane_step)
 __global__ void __launch_bounds__(256) k_map(DevGraph g, const char *seqs, const uint64_t *offsets, const uint64_t *node_begin,
                                              uint32_t *nodes_fwd, uint32_t *nodes_rc, uint8_t *mlen_fwd, uint8_t *mlen_rc,
+                                             uint2 *rng_fwd, uint2 *rng_rc, int min_rng_len,
                                              uint64_t n_reads, int do_rc, unsigned long long *cursor, KernelStats *stats) {
     LineCtr ctr = { 0, 0, 0 };
     MapLane m;
@@ -119,6 +120,9 @@ __global__ void __launch_bounds__(256) k_map(DevGraph g, const char *seqs, const
         ml.seq = seqs + off;
         ml.out = (ml.strand ? nodes_rc : nodes_fwd) + node_begin[read];
         ml.out_len = (ml.strand ? mlen_rc : mlen_fwd) + node_begin[read];
+        uint2 *rg = ml.strand ? rng_rc : rng_fwd;
+        ml.out_rng = rg ? rg + node_begin[read] : nullptr;
+        ml.min_rng_len = min_rng_len;
         ml.n_kmers = ml.L - (int32_t)g.k + 1;
         return true;
     };
@@ -256,6 +260,8 @@ struct mgx_aligner {
     mgx_limits user_lim;
     bool have_user_lim = false;
     DevBuf mlen_fwd, mlen_rc;     // k_map's index() match lengths, one byte per k-mer position
+    DevBuf rng_fwd, rng_rc;       // and the (rl, ru) of matches >= min_seed_length (8 B per position; optional)
+    bool have_rng = false;
     DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, scan_tmp, dbg_seeds;
     DevBuf seed_hdr, seed_stream, work_key, work_key_sorted, order_in, order, sort_tmp;    // split pipeline
     DevLimits lim;
@@ -543,6 +549,17 @@ static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets
     if (int rc = A->nodes_rc.ensure((total_kmers + 1) * 4)) return rc;
     if (int rc = A->mlen_fwd.ensure(total_kmers + 1)) return rc;
     if (int rc = A->mlen_rc.ensure(total_kmers + 1)) return rc;
+    {
+        // the range arrays are an optimisation: only when they fit comfortably next to everything else
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const size_t need = 2 * (total_kmers + 1) * sizeof(uint2);
+        A->have_rng = need <= A->rng_fwd.bytes + A->rng_rc.bytes || need < free_b / 4;
+        if (A->have_rng) {
+            if (int rc = A->rng_fwd.ensure((total_kmers + 1) * sizeof(uint2))) return rc;
+            if (int rc = A->rng_rc.ensure((total_kmers + 1) * sizeof(uint2))) return rc;
+        }
+    }
     return MGX_OK;
 }
 
@@ -570,7 +587,9 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
         if (blocks == 0) blocks = 1;
         k_map<<<(uint32_t)blocks, 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
                                          A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(),
-                                         A->mlen_fwd.as<uint8_t>(), A->mlen_rc.as<uint8_t>(), n, do_rc ? 1 : 0,
+                                         A->mlen_fwd.as<uint8_t>(), A->mlen_rc.as<uint8_t>(),
+                                         A->have_rng ? A->rng_fwd.as<uint2>() : nullptr, A->have_rng ? A->rng_rc.as<uint2>() : nullptr,
+                                         (int)std::min<uint64_t>(A->cfg.min_seed_length, 1u << 20), n, do_rc ? 1 : 0,
                                          map_cursor, A->d_stats.as<KernelStats>());
     }
     HIP_TRY(hipGetLastError());
@@ -635,6 +654,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.nodes_rc = A->nodes_rc.as<uint32_t>();
     P.mlen_fwd = A->mlen_fwd.as<uint8_t>();
     P.mlen_rc = A->mlen_rc.as<uint8_t>();
+    P.rng_fwd = A->have_rng ? A->rng_fwd.as<uint2>() : nullptr;
+    P.rng_rc = A->have_rng ? A->rng_rc.as<uint2>() : nullptr;
     P.n_reads = n;
     P.arena = A->arena.as<uint8_t>();
     P.arena_stride = stride;

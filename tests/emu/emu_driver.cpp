@@ -130,6 +130,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     }
     std::vector<uint32_t> nf(R->node_begin[n] + 1, 0), nr(R->node_begin[n] + 1, 0);
     std::vector<uint8_t> lf(R->node_begin[n] + 1, MLEN_UNKNOWN), lr(R->node_begin[n] + 1, MLEN_UNKNOWN);
+    std::vector<uint2> gf(R->node_begin[n] + 1), gr(R->node_begin[n] + 1);
     bool mapped = cfg.max_seed_length >= k;
     memset(&R->stats, 0, sizeof(R->stats));
     if (mapped) {
@@ -149,6 +150,8 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
             ml.seq = seqs + offsets[read];
             ml.out = (ml.strand ? nr.data() : nf.data()) + R->node_begin[read];
             ml.out_len = (ml.strand ? lr.data() : lf.data()) + R->node_begin[read];
+            ml.out_rng = (ml.strand ? gr.data() : gf.data()) + R->node_begin[read];
+            ml.min_rng_len = (int32_t)std::min<uint64_t>(cfg.min_seed_length, 1u << 20);
             ml.n_kmers = ml.L - (int32_t)k + 1;
             return true;
         };
@@ -175,6 +178,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     P.seqs = seqs; P.offsets = offsets; P.node_begin = R->node_begin.data();
     P.nodes_fwd = nf.data(); P.nodes_rc = nr.data(); P.n_reads = n;
     P.mlen_fwd = lf.data(); P.mlen_rc = lr.data();
+    P.rng_fwd = gf.data(); P.rng_rc = gr.data();
     P.arena = arena.data(); P.arena_stride = stride;
     P.results = R->results.data(); P.out_stream = R->stream.data(); P.out_capacity = out_words;
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();

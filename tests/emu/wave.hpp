@@ -25,6 +25,7 @@
 
 struct uint4 { uint32_t x, y, z, w; };
 struct uint2 { uint32_t x, y; };
+inline uint2 make_uint2(uint32_t x, uint32_t y) { uint2 r; r.x = x; r.y = y; return r; }
 
 namespace mgx {
 

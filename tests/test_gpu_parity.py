@@ -77,6 +77,25 @@ def test_every_pipeline_matches_the_oracle(pipeline):
     compare_gpu(g, gpu_graph(g), cfg, reads + [reads[0][:40], "ACGT", ""], pipeline=pipeline)
 
 
+@pytest.mark.parametrize("pipeline", ["split8", "wave"])
+def test_aligner_reuse_across_batches_of_different_shape(pipeline):
+    """One aligner handle, several batches whose longest read differs (the per-slot arena layout changes and is
+    re-zeroed only then), interleaved with same-shape batches that reuse the generation-tagged tables."""
+    g, reads = make_world(600, 21, genome_len=5000, n_reads=120, read_len=150, n_variants=20)
+    G = gpu_graph(g)
+    cfg = capi.config_cli(21)
+    A = aligner.Aligner(G, cfg)
+    A.set_pipeline(pipeline)
+    rng = random.Random(5)
+    batches = [reads[:40], [r[:90] for r in reads[40:80]], reads[80:120], [r[:60] for r in reads[:30]] + [reads[3]], reads[:40]]
+    for b in batches:
+        want = orc.AlignRun(g, cfg, b).results()
+        got, status = A.align_batch(b)
+        assert all(s == 0 for s in status)
+        assert got == want
+    assert rng is not None
+
+
 def test_unknown_pipeline_is_an_error():
     g, _ = make_world(3, 9, genome_len=300, n_reads=0)
     A = aligner.Aligner(gpu_graph(g), capi.config_cli(9))
