@@ -141,3 +141,78 @@ def test_cli_map_counts(mt_graph):
 
 def test_no_undefined_reads():
     assert orc.L().orc_oob_reads() == 0
+
+
+def test_fixture_builder_against_a_reference_built_graph_file():
+    """examples/data/graphs/test_DNA_graph.dbg was written by the reference (BOSS::serialize, boss.cpp:286-336;
+    DBGSuccinct::serialize) from examples/data/test_DNA_sequences.fa.  Its W/last vectors are stored in the SMALL
+    state (rrr-compressed wavelet tree), which is not decoded here; the uncompressed header pins what our fixture
+    builder must reproduce: k, the number of edges, F, the number of distinct W symbols, and the total length of
+    the Huffman-shaped wavelet tree (= sum over symbols of count x code length, which any optimal code shares)."""
+    import heapq
+    import struct
+    d = open(os.path.join(HERE, "golden", "test_DNA_graph.dbg"), "rb").read()
+    be = lambda o: struct.unpack(">Q", d[o:o + 8])[0]      # serialize_number: big endian (serialization.cpp:30-41)
+    le = lambda o: struct.unpack("<Q", d[o:o + 8])[0]      # sdsl members: raw little endian
+    n = be(0)
+    F = [be(8 + 8 * i) for i in range(n)]
+    o = 8 + 8 * n
+    boss_k, state = be(o), be(o + 8)
+    o += 16
+    wt_size, wt_sigma, wt_bits = le(o), le(o + 8), le(o + 16)
+    assert n == 5 and state == 1                              # BOSS::State::SMALL (boss.hpp:325)
+    seqs = read_fasta(os.path.join(HERE, "golden", "test_DNA_sequences.fa"))
+    g = orc.Graph.build(boss_k + 1, seqs, 0, False)
+    W, last, Fo, _ = g.export()
+    assert len(W) == wt_size                                   # n_edges + 1 (slot 0)
+    assert [int(x) for x in Fo] == F
+    counts = {}
+    for w in W:
+        counts[int(w)] = counts.get(int(w), 0) + 1
+    assert len(counts) == wt_sigma
+    heap = [(c, i) for i, c in enumerate(counts.values())]
+    heapq.heapify(heap)
+    total, nxt = 0, len(heap)
+    while len(heap) > 1:
+        a, b = heapq.heappop(heap), heapq.heappop(heap)
+        total += a[0] + b[0]
+        heapq.heappush(heap, (a[0] + b[0], nxt))
+        nxt += 1
+    assert total == wt_bits
+
+
+def json_golden():
+    """genome_MT1.align.json (M/tests/data): `metagraph align --json --align-min-exact-match 0.0` on the k = 11
+    genome.MT graph (integration_tests/test_align.py:330-356).  Unlike the TSV goldens it carries the NODE IDS of
+    every alignment (Alignment::to_json, alignment.cpp:883-963), i.e. it pins the BOSS edge numbering of the
+    fixture builder and the node paths the aligner reports."""
+    import json
+    out = []
+    for line in open(os.path.join(HERE, "golden", "genome_MT1.align.json")):
+        if line.strip():
+            js = json.loads(line)
+            out.append({"name": js["name"], "score": js["score"], "cigar": js["annotation"]["cigar"],
+                        "sequence": js["annotation"]["ref_sequence"], "query": js["sequence"],
+                        "orientation": 1 if js.get("read_on_reverse_strand") else 0,
+                        "nodes": [int(m["position"]["node_id"]) for m in js["path"]["mapping"]]})
+    return out
+
+
+def check_against_json_golden(results, reads):
+    gold = json_golden()
+    assert len(gold) == 5
+    for i, want in enumerate(gold):
+        assert reads[i][0].lstrip("@").split()[0] == want["name"]
+        got = results[i][0]
+        assert list(got["nodes"]) == want["nodes"], i
+        assert (got["score"], got["cigar"], got["sequence"], got["orientation"]) == \
+               (want["score"], want["cigar"], want["sequence"], want["orientation"]), i
+
+
+def test_cli_json_golden_node_ids():
+    cli = KATS["cli"]
+    g = orc.Graph.build(cli["k"], read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"])), 0, False)
+    reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
+    cfg = capi.config_cli(cli["k"])
+    cfg.min_exact_match = 0.0
+    check_against_json_golden(orc.AlignRun(g, cfg, [r[1] for r in reads]).results(), reads)
