@@ -166,17 +166,18 @@ def test_cli_goldens_on_gpu():
                 assert got[int(fi)] == fv
 
 
-def test_cli_json_golden_node_ids_on_gpu():
-    """The reference's JSON golden (node ids of every alignment) straight against the HIP path."""
-    from test_oracle_kats import read_fasta, read_fastq, HERE, check_against_json_golden
+@pytest.mark.parametrize("edit_distance,name", [(False, "genome_MT1.align.json"), (True, "genome_MT1.align.edit.json")])
+def test_cli_json_golden_node_ids_on_gpu(edit_distance, name):
+    """The reference's JSON goldens (node ids of every alignment; default and edit-distance scoring) straight
+    against the HIP path."""
+    from test_oracle_kats import read_fasta, read_fastq, HERE, check_against_json_golden, json_golden_config
     cli = KATS["cli"]
     g = orc.Graph.build(cli["k"], read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"])), 0, False)
     reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
-    cfg = capi.config_cli(cli["k"])
-    cfg.min_exact_match = 0.0
+    cfg = json_golden_config(cli["k"], edit_distance)
     got, status = aligner.Aligner(gpu_graph(g), cfg).align_batch([r[1] for r in reads])
     assert all(s == 0 for s in status)
-    check_against_json_golden(got, reads)
+    check_against_json_golden(got, reads, name)
 
 
 def test_unsupported_and_bad_config_fail_loudly():

@@ -181,14 +181,14 @@ def test_fixture_builder_against_a_reference_built_graph_file():
     assert total == wt_bits
 
 
-def json_golden():
+def json_golden(name="genome_MT1.align.json"):
     """genome_MT1.align.json (M/tests/data): `metagraph align --json --align-min-exact-match 0.0` on the k = 11
     genome.MT graph (integration_tests/test_align.py:330-356).  Unlike the TSV goldens it carries the NODE IDS of
     every alignment (Alignment::to_json, alignment.cpp:883-963), i.e. it pins the BOSS edge numbering of the
     fixture builder and the node paths the aligner reports."""
     import json
     out = []
-    for line in open(os.path.join(HERE, "golden", "genome_MT1.align.json")):
+    for line in open(os.path.join(HERE, "golden", name)):
         if line.strip():
             js = json.loads(line)
             out.append({"name": js["name"], "score": js["score"], "cigar": js["annotation"]["cigar"],
@@ -198,8 +198,8 @@ def json_golden():
     return out
 
 
-def check_against_json_golden(results, reads):
-    gold = json_golden()
+def check_against_json_golden(results, reads, name="genome_MT1.align.json"):
+    gold = json_golden(name)
     assert len(gold) == 5
     for i, want in enumerate(gold):
         assert reads[i][0].lstrip("@").split()[0] == want["name"]
@@ -209,10 +209,21 @@ def check_against_json_golden(results, reads):
                (want["score"], want["cigar"], want["sequence"], want["orientation"]), i
 
 
-def test_cli_json_golden_node_ids():
+def json_golden_config(k, edit_distance):
+    cfg = capi.config_cli(k)
+    cfg.min_exact_match = 0.0
+    if edit_distance:
+        # --align-edit-distance: unit costs, no end bonuses (DBGAlignerConfig::set_scoring_matrix, aligner_config.cpp:128-147)
+        capi.set_unit_matrix(cfg, 1)
+        cfg.left_end_bonus = 0
+        cfg.right_end_bonus = 0
+    return cfg
+
+
+@pytest.mark.parametrize("edit_distance,name", [(False, "genome_MT1.align.json"), (True, "genome_MT1.align.edit.json")])
+def test_cli_json_golden_node_ids(edit_distance, name):
     cli = KATS["cli"]
     g = orc.Graph.build(cli["k"], read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"])), 0, False)
     reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
-    cfg = capi.config_cli(cli["k"])
-    cfg.min_exact_match = 0.0
-    check_against_json_golden(orc.AlignRun(g, cfg, [r[1] for r in reads]).results(), reads)
+    cfg = json_golden_config(cli["k"], edit_distance)
+    check_against_json_golden(orc.AlignRun(g, cfg, [r[1] for r in reads]).results(), reads, name)
