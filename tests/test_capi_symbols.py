@@ -50,3 +50,34 @@ def test_no_device_is_an_error_not_a_fallback():
     rc = L.mgx_graph_create(C.byref(v), 0, C.byref(h))
     assert rc == capi.MGX_ERR_NO_DEVICE
     assert b"not available" in L.mgx_last_error()
+
+
+def test_score_matrices_like_the_reference():
+    """check_score_matrix_dna / check_score_matrix_dna_unit (M/tests/graph/test_aligner.cpp:28-72) on the C-ABI's
+    matrix builders (DBGAlignerConfig::dna_scoring_matrix / unit_scoring_matrix, aligner_config.cpp:164-204)."""
+    L = capi.lib()
+    L.mgx_config_set_dna_matrix.argtypes = [C.c_void_p, C.c_int8, C.c_int8, C.c_int8]
+    L.mgx_config_set_unit_matrix.argtypes = [C.c_void_p, C.c_int8]
+    alphabet = "ACGTN"                                   # kAlphabetDNA5
+    for build in ("dna", "unit"):
+        c = capi.Config()
+        L.mgx_config_init_default(C.byref(c))
+        if build == "dna":
+            L.mgx_config_set_dna_matrix(C.byref(c), 2, -1, -2)
+        else:
+            L.mgx_config_set_unit_matrix(C.byref(c), 1)
+        m = lambda a, b: c.score_matrix[ord(a)][ord(b)]
+        for i, a in enumerate(alphabet):
+            if i + 1 != len(alphabet):
+                assert m(a, a) > 0
+            for b in alphabet:
+                if i + 1 != len(alphabet):
+                    assert m(a, a) >= m(a, b)
+                assert m(a, b) == m(b, a)
+        # and the Python mirrors used by the tests build the same bytes
+        ref = capi.config_default()
+        if build == "dna":
+            capi.set_dna_matrix(ref, 2, -1, -2)
+        else:
+            capi.set_unit_matrix(ref, 1)
+        assert bytes(c.score_matrix) == bytes(ref.score_matrix)
