@@ -1,0 +1,65 @@
+"""Known-answer tests of the reference for DBGSuccinct::call_nodes_with_suffix_matching_longest_prefix
+(M/tests/graph/succinct/test_dbg_succinct.cpp:162-527), transcribed as data and run against the oracle.
+This is the primitive behind the seeder's sub-k seeds (SURVEY 8a rows a12/a13)."""
+import pytest
+
+import orc
+
+# (name, k, sequences added one by one, mask_dummy_kmers?, string passed, min_match_length, expected node strings,
+#  expected match length); source lines in test_dbg_succinct.cpp
+SUFFIX_KATS = [
+    ("CallNodesWithSuffix", 4, ["GGCCCAGGGGTC"], True, "GG", 1, ["AGGG", "CAGG", "GGGG"], 2),                  # :162-198
+    ("CallNodesWithSuffixMinLength", 4, ["GGCCCAGGGGTC"], True, "CAGC", 4, [], 4),                            # :200-225
+    ("CallNodesWithSuffixK", 4, ["GGCCCAGGGGTC"], True, "GGCC", 1, ["GGCC"], 4),                              # :227-259
+    ("CallNodesWithSuffixK_v2", 4, ["AGCCC", "CGCC", "GGCC", "TGCC"], False, "AGCC", 4, 1, 4),                # :261-285 (count only)
+    ("CallNodesWithSuffixKEarlyCutoff", 4, ["GGCCCAGGGGTC"], True, "GG", 1, ["AGGG", "CAGG", "GGGG"], 2),     # :287-323 (query[:2])
+    ("CallNodesWithSuffixEarlyCutoffKMinusOne", 4, ["GGCCCAGGGGTC"], True, "GGG", 1, ["AGGG", "GGGG"], 3),    # :325-359 (query[:3])
+    ("CallNodesWithSuffixKMinusOne", 4, ["GGCCCAGGGGTC"], True, "GCC", 1, ["GGCC"], 3),                       # :361-393
+    ("CallNodesWithSuffixKMinusOneBeginning", 4, ["GGCCCAGGGGTC"], True, "GGC", 1, [], 3),                    # :395-419
+    ("CallNodesWithSuffixMinusTwoBeginning", 4, ["TGCCCAGGGGTC"], True, "TG", 1, [], 2),                      # :421-445
+    ("CallNodesWithSuffixMultipleOut", 3, ["GGGGGGATGTAG", "GGGGGGATGCCTAATTAA"], True, "TGC", 1, ["TGC"], 3),  # :447-479
+    ("CallNodesWithSuffixMultipleInOut", 4, ["AAAAAAAAATGC", "GGGGGGGGATGG", "GGGGGGGGTTGC", "AAAAAAAATTGG"], True,
+     "TGA", 1, ["AATG", "GATG", "GTTG", "ATTG"], 2),                                                           # :481-527
+]
+
+
+@pytest.mark.parametrize("case", SUFFIX_KATS, ids=lambda c: c[0])
+def test_call_nodes_with_suffix_matching_longest_prefix(case):
+    name, k, seqs, mask, query, min_len, want, want_len = case
+    g = orc.Graph.build(k, seqs, 0, mask)
+    nodes, match_len = g.suffix_match(query, min_len)
+    if isinstance(want, int):
+        assert len(nodes) == want
+    else:
+        assert sorted(g.node_sequence(v) for v in nodes) == sorted(want)
+        for v in nodes:
+            s = g.node_sequence(v)
+            assert query[:want_len] == s[len(s) - want_len:] or name == "CallNodesWithSuffixMultipleOut"
+    if nodes:
+        assert match_len == want_len
+
+
+def test_call_outgoing_kmers_source():
+    """DBGSuccinct.call_outgoing_kmers_source (test_dbg_succinct.cpp:138-160): the children of the source dummy
+    edge 1 in an unmasked graph, with their node ids."""
+    g = orc.Graph.build(4, ["AATGG", "CCGAA"], 0, False)
+    assert sorted(g.outgoing(1)) == [(2, "A"), (3, "C")]
+
+
+@pytest.mark.parametrize("k", range(2, 10))
+def test_source_dummy_is_node_one_until_masked(k):
+    """get_degree_with_source_dummy (test_dbg_succinct.cpp:13-56), the parts on the alignment path: edge 1 spells
+    '$' * k; after mask_dummy_kmers it is no longer a node, and the real k-mers keep their out-neighbours."""
+    seq = "A" * k + "C" * (k - 1) + "G" * (k - 1) + "T" * k
+    g = orc.Graph.build(k, [seq], 0, False)
+    assert g.node_sequence(1) == "$" * k
+    # (the reference test builds with add_sequence, which keeps the redundant source-dummy path $$$A.. into AAAA;
+    # the fixture builder follows construct_boss_chunk, boss_chunk_construct.cpp:57-171, which removes it — so the
+    # in-degree assertions of that test do not transfer, the out-neighbours do)
+    gm = orc.Graph.build(k, [seq], 0, True)
+    W, last, F, valid = gm.export()
+    assert valid is not None and not valid[1]
+    for graph in (g, gm):
+        nodes, ml = graph.suffix_match("A" * k, k)
+        assert ml == k and len(nodes) == 1
+        assert sorted(c for _, c in graph.outgoing(nodes[0])) == ["A", "C"]      # outdegree(AAAA) == 2
