@@ -63,3 +63,18 @@ def test_source_dummy_is_node_one_until_masked(k):
         nodes, ml = graph.suffix_match("A" * k, k)
         assert ml == k and len(nodes) == 1
         assert sorted(c for _, c in graph.outgoing(nodes[0])) == ["A", "C"]      # outdegree(AAAA) == 2
+
+
+@pytest.mark.parametrize("kb", range(1, 10))
+def test_boss_map_to_edges(kb):
+    """BOSS.map_to_edges (M/tests/graph/succinct/test_boss.cpp:2317-2345).  The reference builds this graph with
+    add_sequence, which keeps the kb redundant source-dummy edges $..$A.. in front of A^(kb+1); the fixture builder
+    follows construct_boss_chunk and removes them (A^(kb+1) has a real predecessor), so every edge index is lower by
+    exactly kb.  Positions, npos entries and the restart/walk pattern are the reference's."""
+    from metagraph_amd import capi
+    k = kb + 1
+    g = orc.Graph.build(k, ["A" * 100 + "C" * 100], 0, False)
+    seq = "T" * 2 + "A" * (kb + 3) + "C" * (2 * kb)
+    expected = [0, 0, kb + 2, kb + 2, kb + 2] + [kb + 2 + i for i in range(1, kb + 1)] + [kb + 2 + kb + 1] * kb
+    got = orc.AlignRun(g, capi.config_cli(k), [seq]).mapping()[0][0]
+    assert got == [e - kb if e else 0 for e in expected]
