@@ -5,7 +5,9 @@
 //
 // Parity status: the reference cannot be compiled here (all third-party submodules are
 // absent).  rank/select are mathematically specified, so this restatement is
-// pinned by the reference's own known-answer tests transcribed under tests/golden/.
+// pinned by the reference's own known-answer tests transcribed under tests/golden/ — incl. the JSON goldens
+// genome_MT1.align{,.edit}.json whose node ids fix the BOSS edge numbering of build_boss(), the header of a
+// reference-written .dbg file, and the suffix-matching / map_to_edges vectors of test_dbg_succinct.cpp / test_boss.cpp.
 //
 // Citations are into /root/reference/metagraph/src (M/src).
 #pragma once
