@@ -103,7 +103,7 @@ def main():
             n_bytes = hb.value * nq.value
 
             class _Ptr:
-                __cuda_array_interface__ = {"shape": (n_bytes,), "typestr": "|u1", "data": (hp.value, True), "version": 2}
+                __cuda_array_interface__ = {"shape": (n_bytes,), "typestr": "|u1", "data": (hp.value, False), "version": 2}
             hdr = torch.as_tensor(_Ptr(), device=dev)
             gl = [torch.empty_like(hdr) for _ in range(world)] if rank == 0 else None
             dist.gather(hdr, gl, dst=0)

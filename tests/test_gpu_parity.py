@@ -96,6 +96,32 @@ def test_aligner_reuse_across_batches_of_different_shape(pipeline):
     assert rng is not None
 
 
+def test_device_results_wrap_as_a_torch_tensor():
+    """bench.py's N > 1 path gathers the fixed-size result records over RCCL straight from the aligner's HBM buffer
+    (mgx_device_results): the buffer must wrap as a CUDA tensor and hold the same records the host fetch decodes."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    g, reads = make_world(700, 21, genome_len=4000, n_reads=64, read_len=120)
+    G = gpu_graph(g)
+    A = aligner.Aligner(G, capi.config_cli(21))
+    got, status = A.align_batch(reads)
+    hp, hb, nq, sp, sw = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+    assert capi.lib().mgx_device_results(A.h, C.byref(hp), C.byref(hb), C.byref(nq), C.byref(sp), C.byref(sw)) == 0
+    assert nq.value == len(reads) and hb.value >= 48
+
+    class _Ptr:
+        __cuda_array_interface__ = {"shape": (hb.value * nq.value,), "typestr": "|u1", "data": (hp.value, False), "version": 2}
+    t = torch.as_tensor(_Ptr(), device=torch.device("cuda", 0))
+    rec = t.cpu().numpy().reshape(nq.value, hb.value)
+    scores = rec[:, 8:12].copy().view(np.int32).ravel()            # ReadResult: status, n_alignments, score, ...
+    n_aln = rec[:, 4:8].copy().view(np.int32).ravel()
+    for q in range(len(reads)):
+        assert n_aln[q] == len(got[q])
+        if got[q]:
+            assert scores[q] == got[q][0]["score"]
+
+
 def test_unknown_pipeline_is_an_error():
     g, _ = make_world(3, 9, genome_len=300, n_reads=0)
     A = aligner.Aligner(gpu_graph(g), capi.config_cli(9))
