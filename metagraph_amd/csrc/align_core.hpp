@@ -169,7 +169,12 @@ struct ExtendResult { int32_t n_tips; int32_t min_cell_score; int32_t table_size
 
 // One DP column staged on chip (S, E, F incl. the 5-cell padding): the column being computed and its
 // parent live in LDS so that the hot path of an extension never waits on the HBM arena.
-struct Staging { int32_t *S, *E, *F; int32_t col; };
+// A staged array is two-tiered: the first `st_cap` cells in LDS (lo), the rest in the arena (hi, indexed by the
+// same j): x-drop bands are narrow, so at 8 reads per wavefront the common columns live entirely in LDS while
+// any width stays correct.  The parent column needs S and F only; E exists once, for the column being computed.
+struct Tier { int32_t *lo, *hi; };
+MGX_DEV int32_t &tref(const Tier &t, int32_t cap, int32_t j) { return j < cap ? t.lo[j] : t.hi[j]; }
+struct Staging { Tier S, F; int32_t col; };
 constexpr int32_t LQ_CAP = 32;       // frontier entries kept in LDS; the rest spill to the arena
 
 struct Wave {
@@ -196,6 +201,8 @@ struct Wave {
     uint64_t *queue, *next_nodes;         // arena tiers of the frontier / current batch
     uint64_t *lq, *lnn;                   // LDS tiers (first LQ_CAP entries)
     Staging st[2];
+    Tier stE;                             // E of the column being computed
+    int32_t st_cap;                       // cells of every staged array that live in LDS
     ColMeta hot;                          // metadata of the most recently committed column
     int32_t hot_idx;
     Block blk_cache;                      // target block of the last graph expansion (children live in it)
@@ -276,7 +283,6 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     for (int s = 0; s < 2; ++s) w.q[s] = take_fast(Lp);
     w.lq = (uint64_t *)take_fast(LQ_CAP * 8);
     w.lnn = (uint64_t *)take_fast(LQ_CAP * 8);
-    for (int s = 0; s < 2; ++s) w.pk[s] = (uint32_t *)take_fast(((L + 15) / 16 + 2) * 4);
     // overlay: the seeding tables and the extension's column staging are never live at the same time
     uint8_t *lp_mark = lp;
     uint32_t lleft_mark = lleft;
@@ -293,18 +299,24 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     uint32_t lleft_seed_end = lleft;
     lp = lp_mark;
     lleft = lleft_mark;
-#ifdef MGX_ST_CAP_HACK
-    const uint64_t stc = MGX_ST_CAP_HACK;
-#else
-    const uint64_t stc = L + 16;
-#endif
-    for (int b = 0; b < 2; ++b) {
-        w.st[b].S = (int32_t *)take_fast(stc * 4);
-        w.st[b].E = (int32_t *)take_fast(stc * 4);
-        w.st[b].F = (int32_t *)take_fast(stc * 4);
-        w.st[b].col = -1;
+    {
+        // staging: 5 arrays (S, F of two slots + E); the arena holds them at full size, LDS the first st_cap cells
+        const uint64_t full = L + 16;
+        uint64_t cap = (lleft / 20) & ~3ull;
+        if (cap > full) cap = full;
+        if (cap < 16) cap = 0;
+        w.st_cap = (int32_t)cap;
+        int32_t *hi[6];
+        for (int a = 0; a < 6; ++a) hi[a] = (int32_t *)take(full * 4);          // (6th slot kept for layout stability)
+        int32_t *lo[5];
+        for (int a = 0; a < 5; ++a) { lo[a] = (int32_t *)lp; lp += cap * 4; lleft -= (uint32_t)(cap * 4); }
+        w.st[0].S = { lo[0], hi[0] }; w.st[0].F = { lo[1], hi[1] };
+        w.st[1].S = { lo[2], hi[2] }; w.st[1].F = { lo[3], hi[3] };
+        w.stE = { lo[4], hi[4] };
+        w.st[0].col = -1; w.st[1].col = -1;
     }
     if (lleft_seed_end < lleft) { lp = lp_seed_end; lleft = lleft_seed_end; }     // past the larger side of the overlay
+    for (int s = 0; s < 2; ++s) w.pk[s] = (uint32_t *)take_fast(((L + 15) / 16 + 2) * 4);
     for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take_fast((L + 1) * 4);
     for (int s = 0; s < 2; ++s) w.seeds[s] = (DevSeed *)take((uint64_t)lim.max_seeds * sizeof(DevSeed));
     for (int s = 0; s < 2; ++s) w.alive[s] = take(lim.max_seeds);
@@ -1020,21 +1032,23 @@ MGX_DEV void fill_range(int32_t *vec, int32_t a, int32_t b, int32_t val) {
 // update_seed_filter (:100-156).  s = cells of the column (S at stride 3), size cells starting at
 // query position query_start.  Returns converged score (NINF = nothing improved).
 MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start,
-                                   const int32_t *s_cells, int32_t size) {
-    // s_cells: S values of the column (contiguous, from the staging buffer)
+                                   const Tier s_tier, int32_t s_skip, int32_t size) {
+    // S values of the column: cells s_skip .. s_skip + size of the staged (two-tier) S array
     const AlignParams &P = *w.P;
+    const int32_t s_cap = uni(w.st_cap);
+    s_skip = uni(s_skip);
+#define s_cells(j) tref(s_tier, s_cap, s_skip + (j))
     auto column_max = [&]() {
         int32_t m = INT32_MIN;
         for (int32_t base = 0; base < size; base += WAVE) {
             LV<int32_t> x;
-            FOR_LANES(l) { int32_t j = base + l; x[l] = j < size ? s_cells[j] : INT32_MIN; }
+            FOR_LANES(l) { int32_t j = base + l; x[l] = j < size ? s_cells(j) : INT32_MIN; }
             m = imax(m, wave_max(x));
         }
         return m;
     };
     if (node == 0) return column_max();
     node = uni(node); query_start = uni(query_start); size = uni(size);
-    s_cells = (const int32_t *)uni((uint64_t)s_cells);
     uint64_t key = (uint64_t)node + (uni(E.rc_view) ? uni(P.g.n) : 0);
     uint32_t mask = uni(P.lim.hash_size) - 1, slot;
     int32_t idx = uni(conv_find(E.conv, mask, key, &slot));
@@ -1045,7 +1059,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         if (idx < 0) return NINF;
         int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[j]; }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells(j); }
         }
         wave_sync();
         return column_max();
@@ -1056,7 +1070,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
     if (query_start + size <= start) {
         fill_range(vec, query_start + size, start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[j]; }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells(j); }
         }
         e.len = start + len - query_start; e.start = query_start;
         E.conv.entries[idx] = e;
@@ -1066,7 +1080,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
     if (query_start >= start + len) {
         fill_range(vec, start + len, query_start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells[j]; }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells(j); }
         }
         e.len = query_start + size - start;
         E.conv.entries[idx] = e;
@@ -1086,7 +1100,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
             int32_t j = base + l;
             x[l] = NINF;
             if (j < size) {
-                int32_t sv = s_cells[j];
+                int32_t sv = s_cells(j);
                 int32_t vv = vec[query_start + j];
                 if ((double)sv > (double)vv * rel) {
                     vv = imax(vv, sv);
@@ -1100,6 +1114,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
     wave_sync();
     return max_changed;
 }
+#undef s_cells
 
 // check_seed (:66-88): true when the seed is still worth extending
 MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int32_t qlen, int32_t clipping, int32_t score) {
@@ -1206,8 +1221,8 @@ MGX_DEV void frontier_insert(Wave &w, int32_t &qn, uint64_t key) {
     wave_sync();
 }
 
-MGX_DEV int32_t st_S(const Staging &s, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? s.S[j] : NINF; }
-MGX_DEV int32_t st_F(const Staging &s, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? s.F[j] : NINF; }
+MGX_DEV int32_t st_S(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tref(s.S, cap, j) : NINF; }
+MGX_DEV int32_t st_F(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tref(s.F, cap, j) : NINF; }
 
 // make column `idx` resident in a staging buffer; returns the buffer index
 MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
@@ -1216,11 +1231,12 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
     const int b = 0;
     Staging &s = w.st[b];
     const int32_t n = c.size + 5;
+    const int32_t cap = w.st_cap;
     const int32_t *cells = w.cells + c.cells;
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
-            if (j < n) { s.S[j] = cells[3 * j]; s.E[j] = cells[3 * j + 1]; s.F[j] = cells[3 * j + 2]; }
+            if (j < n) { tref(s.S, cap, j) = cells[3 * j]; tref(s.F, cap, j) = cells[3 * j + 2]; }      // a parent's E is never read
         }
     }
     s.col = idx;
@@ -1229,15 +1245,15 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
 }
 
 // write a staged column (size + 5 cells) to the arena, S/E/F interleaved; nothing waits on these stores
-MGX_DEV void flush_column(Wave &w, const Staging &s_, uint32_t cells_off, int32_t size) {
+MGX_DEV void flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t size) {
     int32_t *cells = (int32_t *)uni((uint64_t)(w.cells + cells_off));
-    Staging s;
-    s.S = (int32_t *)uni((uint64_t)s_.S); s.E = (int32_t *)uni((uint64_t)s_.E); s.F = (int32_t *)uni((uint64_t)s_.F); s.col = 0;
+    const int32_t cap = uni(w.st_cap);
+    const Tier tS = s.S, tF = s.F, tE = w.stE;
     const int32_t n = uni(size) + 5;
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
-            if (j < n) { cells[3 * j] = s.S[j]; cells[3 * j + 1] = s.E[j]; cells[3 * j + 2] = s.F[j]; }
+            if (j < n) { cells[3 * j] = tref(tS, cap, j); cells[3 * j + 1] = tref(tE, cap, j); cells[3 * j + 2] = tref(tF, cap, j); }
         }
     }
 }
@@ -1253,10 +1269,12 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
     prev_size = uni(prev_size); prev_trim = uni(prev_trim); prev_end = uni(prev_end); begin = uni(begin);
     size = uni(size); init_score = uni(init_score); offset = uni(offset); start = uni(start);
     window_size = uni(window_size); xdrop_cutoff = uni(xdrop_cutoff);
-    Staging par, cur;
-    par.S = (int32_t *)uni((uint64_t)w.st[pb].S); par.E = nullptr; par.F = (int32_t *)uni((uint64_t)w.st[pb].F); par.col = 0;
-    cur.S = (int32_t *)uni((uint64_t)w.st[cb].S); cur.E = (int32_t *)uni((uint64_t)w.st[cb].E);
-    cur.F = (int32_t *)uni((uint64_t)w.st[cb].F); cur.col = 0;
+    const Staging par = w.st[pb];
+    const Tier cS = w.st[cb].S, cF = w.st[cb].F, cE = w.stE;
+    const int32_t cap = uni(w.st_cap);
+#define CS(j) tref(cS, cap, (j))
+#define CE(j) tref(cE, cap, (j))
+#define CF(j) tref(cF, cap, (j))
     const int32_t trim = begin;
     const int32_t max_size = window_size + 1 - trim;
     const int8_t *row = (const int8_t *)uni((uint64_t)(w.sm_rows + encode_char(c) * 128));   // profile_score_[encode(c)] (:38-59)
@@ -1264,7 +1282,7 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
     // DPTColumn::create: size + 5 cells of ninf (we initialise everything update_column may touch)
     const int32_t init_n = imin(max_size, size) + 8;
     for (int32_t base = 0; base < init_n; base += WAVE) {
-        FOR_LANES(l) { int32_t j = base + l; if (j < init_n) { cur.S[j] = NINF; cur.E[j] = NINF; cur.F[j] = NINF; } }
+        FOR_LANES(l) { int32_t j = base + l; if (j < init_n) { CS(j) = NINF; CE(j) = NINF; CF(j) = NINF; } }
     }
     w.st[cb].col = -1;
     wave_sync();
@@ -1283,11 +1301,11 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
                 if (j) {
                     int32_t ap = start + trim + j;
                     int32_t prof = (ap >= 1 && ap <= L) ? (int32_t)row[qq[ap - 1] & 127] : 0;
-                    match = st_S(par, prev_size, dp + j - 1) + prof + init_score;
+                    match = st_S(par, cap, prev_size, dp + j - 1) + prof + init_score;
                 }
                 int32_t del = NINF;
-                if (offset > 1) del = imax(st_S(par, prev_size, dp + j) + go, st_F(par, prev_size, dp + j) + ge) + init_score;
-                cur.F[j] = del;                             // F_v[j]
+                if (offset > 1) del = imax(st_S(par, cap, prev_size, dp + j) + go, st_F(par, cap, prev_size, dp + j) + ge) + init_score;
+                CF(j) = del;                             // F_v[j]
                 mm = imax(match, del);
             }
             m[l] = mm;
@@ -1308,9 +1326,9 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
         FOR_LANES(l) {
             int32_t j = base + l;
             if (j < n_loop) {
-                cur.E[j + 1] = enext[l];                    // E_v[j + 1]
+                CE(j + 1) = enext[l];                    // E_v[j + 1]
                 int32_t sv = imax(m[l], ecur[l]);
-                cur.S[j] = sv > xdrop_cutoff - 1 ? sv : NINF;
+                CS(j) = sv > xdrop_cutoff - 1 ? sv : NINF;
             }
         }
         int32_t last_lane = imin(WAVE, n_loop - base) - 1;
@@ -1322,14 +1340,14 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
         int32_t j = size - 1;
         int32_t ap = start + trim + j;
         int32_t prof = (ap >= 1 && ap <= L) ? (int32_t)row[qq[ap - 1] & 127] : 0;
-        int32_t match = uni(imax(st_S(par, prev_size, dp + j - 1) + init_score + prof, cur.E[j]));
-        if (match >= xdrop_cutoff) cur.S[j] = match;
+        int32_t match = uni(imax(st_S(par, cap, prev_size, dp + j - 1) + init_score + prof, CE(j)));
+        if (match >= xdrop_cutoff) CS(j) = match;
     }
     wave_sync();
     // extend_ins_end
     w.tmp_pushes = 0;
     if (size < max_size) {
-        const int32_t ins_score = uni(imax(cur.S[size - 1] + go, cur.E[size - 1] + ge));
+        const int32_t ins_score = uni(imax(CS(size - 1) + go, CE(size - 1) + ge));
         if (ins_score >= xdrop_cutoff) {
             int32_t n_push = 1;
             int32_t room = max_size - (size + 1);
@@ -1344,9 +1362,9 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
                     int32_t t = base + l;
                     if (t < n_push) {
                         int32_t v = ins_score + t * ge;
-                        cur.S[size + t] = v; cur.E[size + t] = v; cur.F[size + t] = NINF;
+                        CS(size + t) = v; CE(size + t) = v; CF(size + t) = NINF;
                     } else if (t < n_push + 5) {             // padding after the new end is ninf
-                        cur.S[size + t] = NINF; cur.E[size + t] = NINF; cur.F[size + t] = NINF;
+                        CS(size + t) = NINF; CE(size + t) = NINF; CF(size + t) = NINF;
                     }
                 }
             }
@@ -1359,6 +1377,10 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
 }
 
 // children of a column (DefaultColumnExtender::call_outgoing :330-387, non-canonical graphs)
+#undef CS
+#undef CE
+#undef CF
+
 MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
                           uint32_t *nodes, uint8_t *chars, int32_t *scores) {
     const AlignParams &P = *w.P;
@@ -1450,10 +1472,13 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         r.node = seed.nodes[0]; r.parent = -1; r.c = 0; r.offset = seed_offset; r.max_pos = 0; r.trim = 0;
         r.score = 0; r.cells = cell_top; r.size = 1;
         Staging &s0 = w.st[0];
-        FOR_LANES(l) { if (l < 8) { s0.S[l] = NINF; s0.E[l] = NINF; s0.F[l] = NINF; } }
+        const int32_t cap = w.st_cap;
+        for (int32_t base = 0; base < 8; base += WAVE) {
+            FOR_LANES(l) { int32_t j = base + l; if (j < 8) { tref(s0.S, cap, j) = NINF; tref(w.stE, cap, j) = NINF; tref(s0.F, cap, j) = NINF; } }
+        }
         wave_sync();
         int32_t sroot = (cfg.left_end_bonus && !seed.clipping) ? cfg.left_end_bonus : 0;
-        s0.S[0] = sroot;
+        FOR_LANES(l) { if (l == 0) tref(s0.S, cap, 0) = sroot; }
         wave_sync();
         int32_t max_size = window_size + 1;
         int32_t pushes = 0;
@@ -1468,9 +1493,9 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                         int32_t t = base + l;
                         if (t < n_push) {
                             int32_t v = ins_score + t * cfg.gap_ext;
-                            s0.S[1 + t] = v; s0.E[1 + t] = v; s0.F[1 + t] = NINF;
+                            tref(s0.S, cap, 1 + t) = v; tref(w.stE, cap, 1 + t) = v; tref(s0.F, cap, 1 + t) = NINF;
                         } else if (t < n_push + 5) {
-                            s0.S[1 + t] = NINF; s0.E[1 + t] = NINF; s0.F[1 + t] = NINF;
+                            tref(s0.S, cap, 1 + t) = NINF; tref(w.stE, cap, 1 + t) = NINF; tref(s0.F, cap, 1 + t) = NINF;
                         }
                     }
                 }
@@ -1491,8 +1516,6 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         tsize = 1;
         table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)r.cap3 * 4;
     }
-    const int32_t root_S0 = w.st[0].S[0];
-    (void)root_S0;
     int32_t min_cell_score = 0;
     int32_t best_score = 0;
     int32_t qn = 0, nn = 0, n_tips = 0;
@@ -1517,13 +1540,13 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             --nn;
             const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : w.cols[i]);
             const int pb = uni(stage_column(w, i, col));
-            Staging par;
-            par.S = (int32_t *)uni((uint64_t)w.st[pb].S); par.E = nullptr; par.F = nullptr; par.col = 0;
+            const Staging par = w.st[pb];
+            const int32_t cap = uni(w.st_cap);
             const int32_t next_offset = col.offset + 1;
             const int32_t prev_xdrop_cutoff = xdrop_cutoff;       // global_xdrop: one shared cutoff
             const bool in_seed = (next_offset - seed_off) >= 0 && (next_offset - seed_off) < seed_seq_len;
             // early cut-offs when off the optimal path (:521-547)
-            if (uni(st_S(par, col.size, col.max_pos - col.trim)) < best_score) {
+            if (uni(st_S(par, cap, col.size, col.max_pos - col.trim)) < best_score) {
                 double node_counter = (double)tsize;
                 if (node_counter / (double)window_size >= max_nodes_per_char) { qn = 0; nn = 0; continue; }
                 if ((double)table_size_bytes / 1000000.0 > max_ram) { qn = 0; nn = 0; continue; }
@@ -1532,7 +1555,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             int32_t b = col.size, e = 0;
             for (int32_t base = 0; base < col.size; base += WAVE) {
                 LV<bool> inr;
-                FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && par.S[j] >= prev_xdrop_cutoff; }
+                FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && tref(par.S, cap, j) >= prev_xdrop_cutoff; }
                 uint64_t mk = wave_ballot(inr);
                 if (mk) {
                     if (b == col.size) b = base + ctz64(mk);
@@ -1576,7 +1599,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 cur.node = next; cur.parent = i; cur.c = c; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
                 cur.score = score; cur.cells = cell_top; cur.size = size;
                 cur.cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
-                const int32_t *cS = (const int32_t *)uni((uint64_t)w.st[cb].S);
+                const Tier cS = w.st[cb].S;
                 // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
                 const int32_t diag_i = next_offset - seed_offset;
                 bool has_extension = in_seed;
@@ -1588,7 +1611,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                     LV<bool> ext;
                     FOR_LANES(l) {
                         int32_t j = base + l;
-                        int32_t v = j < size ? cS[j] : INT32_MIN;
+                        int32_t v = j < size ? tref(cS, cap, j) : INT32_MIN;
                         sv[l] = v;
                         mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
                         ext[l] = j < size && v + psum[start + begin + j] >= extension_cutoff;
@@ -1629,7 +1652,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 const int32_t skip = begin ? 0 : 1;
                 uint64_t tx6 = xclock();
                 w.xcyc[5] += tx6 - tx5;
-                int32_t converged = update_seed_filter(w, E, next, vec_offset, cS + skip, size - skip);
+                int32_t converged = update_seed_filter(w, E, next, vec_offset, cS, skip, size - skip);
                 uint64_t tx7 = xclock();
                 w.xcyc[6] += tx7 - tx6;
                 if (w.status != ST_OK) { res->table_size = 0; return; }

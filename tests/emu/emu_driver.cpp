@@ -185,7 +185,8 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     auto w = std::make_unique<Wave>();
     SdustScratch sd;
     // model a small LDS so that both placements (LDS / arena) of the fast arrays are exercised
-    std::vector<uint8_t> lds(2048);
+    const char *lds_env = getenv("MGX_EMU_LDS");                 // tests vary the modelled LDS size (0 = everything in the arena)
+    std::vector<uint8_t> lds(lds_env ? (size_t)atoi(lds_env) + 16 : 2048);
     std::vector<int8_t> rows(6 * 128);
     load_score_rows(P, rows.data());
     const char *split = getenv("MGX_EMU_SPLIT");
@@ -198,14 +199,14 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         P.seed_hdr = hdr.data(); P.seed_stream = sstream.data(); P.seed_capacity = sstream.size();
         P.seed_cursor = &seed_cursor; P.work_key = key.data();
         for (uint64_t i = 0; i < n; ++i)
-            align_read<PH_SEED>(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)lds.size());
+            align_read<PH_SEED>(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
         for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         P.order = order.data();
         for (uint64_t i = 0; i < n; ++i)
-            align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)lds.size());
+            align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
     } else {
-        for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)lds.size());
+        for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
     }
     R->host.decode(R->results.data(), n, R->stream.data());
     return R;

@@ -172,6 +172,18 @@ def test_split_pipeline_unit_kats(monkeypatch):
         compare_full(g, eg, cfg, [case["query"]], limits=BIG)
 
 
+@pytest.mark.parametrize("lds_bytes", ["0", "700", "1400", "16384"])
+def test_lds_placements(lds_bytes, monkeypatch):
+    """carve() puts the latency-critical arrays LDS-first and the two-tier staging columns keep their first st_cap
+    cells there: every split between LDS and the arena (none, partial tiers, everything) gives the same results."""
+    monkeypatch.setenv("MGX_EMU_LDS", lds_bytes)
+    g, reads = make_world(410, 15, n_reads=40)
+    compare_full(g, emu_drv.EmuGraph(g), capi.config_cli(15), reads)
+    cfg = capi.config_default()                       # x-drop off: full-width columns reach far into the arena tier
+    capi.set_dna_matrix(cfg, 2, -1, -2)
+    compare_full(g, emu_drv.EmuGraph(g), cfg, reads[:6], limits=BIG)
+
+
 @pytest.mark.parametrize("lanes", ["16", "8"])
 def test_group_sizes_in_emulation(lanes):
     """The wave programs do not depend on the lane count: the same sources modelled with 16 and 8 lanes per read
