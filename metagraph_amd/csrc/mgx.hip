@@ -437,7 +437,15 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
         HIP_TRY(hipGetLastError());
         uint8_t *din = D0.as<uint8_t>(), *dout = D1.as<uint8_t>();
         // suffix-range table over the last m node characters, accumulated during the same rounds
-        const uint32_t m = choose_prefix_len(n, g.k);
+        // the longest table whose 8 B x 4^m fit a sixteenth of the free HBM (m = 15: 8.6 GB, 14: 2.1 GB, 13: 0.5 GB)
+        uint32_t cap_m = 12;
+        {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            while (cap_m < 15 && (8ull << (2 * (cap_m + 1))) <= free_b / 16) ++cap_m;
+        }
+        if (const char *e = getenv("MGX_PREFIX_LEN_MAX")) cap_m = (uint32_t)std::min(15, std::max(2, atoi(e)));
+        const uint32_t m = choose_prefix_len(n, g.k, cap_m);
         DevBuf key;
         if (int rc = key.ensure((n + 1) * 4)) return rc;
         const uint64_t entries = 1ull << (2 * m);
