@@ -168,8 +168,21 @@ def main():
     dom = max(kernels, key=lambda n: kernels[n][0])
     dom_ms, dom_bytes = kernels[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # HBM traffic per launch of the dominant kernel from the committed PMC passes (tools/pmc_passes.sh: FETCH_SIZE and
+    # WRITE_SIZE in separate rocprofv3 --pmc runs of this command at 1 M reads, corrected as MI355X_MICROARCH.md
+    # prescribes): bytes per read x the reads of this launch.  null when the summary is absent.
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")))
+        per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read")
+        if per_read:
+            traffic = round(per_read * args.reads)
+            traffic_src = "profiles/r01_pmc_summary.json (%d-read PMC run, scaled per read)" % pmc["reads_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes": round(dom_bytes),
                 "kernel_ms": kernel_ms,
                 "algorithmic_GBps": {n: round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0 for n, (ms, b) in kernels.items()},
                 "lines_per_read": {"k_map": round(lines_map / args.reads, 1), "k_seed": round(lines_seed / args.reads, 1),
