@@ -136,11 +136,20 @@ MGX_DEV uint32_t get_W(const DevGraph &g, uint64_t i, LineCtr &ctr) {
     return block_W(b, (int)(i & 63));
 }
 
+// cumulative count of label c before the block; selects instead of a dynamically indexed array so that a Block
+// held in registers stays there (a runtime index would force the whole struct into scratch memory)
+MGX_DEV uint32_t block_cum(const Block &b, uint32_t c) {
+    uint32_t lo = (c & 1) ? b.cum[0] : b.cum0;            // c = 1 : 0
+    uint32_t mid = (c & 1) ? b.cum[2] : b.cum[1];         // c = 3 : 2
+    uint32_t r = (c & 2) ? mid : lo;
+    return c >= 4 ? b.cum[3] : r;
+}
+
 // rank of unflagged c in W[1..i] within a loaded block (boss.cpp:437-441); c in 0..4
 MGX_DEV uint32_t block_rank_W(const Block &b, int j, uint32_t c, bool first_block) {
     uint64_t m = code_mask(b, c) & ~b.pf & mask_upto(j);
     if (c == 0 && first_block) m &= ~1ull;          // slot 0 is not an edge ("- (c == 0)")
-    return (c ? b.cum[c - 1] : b.cum0) + (uint32_t)popc64(m);
+    return block_cum(b, c) + (uint32_t)popc64(m);
 }
 
 template <bool U = false>
@@ -189,8 +198,8 @@ MGX_DEV uint64_t select_W(const DevGraph &g, uint32_t c, uint32_t r, LineCtr &ct
         Block b = load_block_t<U>(g, bi);
         uint64_t m = code_mask(b, c) & ~b.pf;
         uint32_t cnt = (uint32_t)popc64(m);
-        if (b.cum[c - 1] + cnt >= r)
-            return ((uint64_t)bi << 6) + (uint32_t)select64(m, (int)(r - b.cum[c - 1]));
+        if (block_cum(b, c) + cnt >= r)
+            return ((uint64_t)bi << 6) + (uint32_t)select64(m, (int)(r - block_cum(b, c)));
         ++bi;
     }
 }
