@@ -225,6 +225,9 @@ struct Wave {
     LineCtr ctr;                 // BOSS block loads (lane-parallel regions add their wave sums)
     ExtendResult er;             // result of the last extend(); noinline callees must not write through
     int32_t tmp_pushes;
+    uint32_t out_nodes[5];       // children of the column being expanded (call_outgoing)
+    int32_t out_scores[5];
+    uint8_t out_chars[8];
     uint64_t cyc[8];             // phase timers (shader cycles)
     uint64_t xcyc[8];            // extend() breakdown: pop, stage+band, outgoing, column, scan, commit, conv, push          // pointers into the caller's private frame, so outputs live here
     uint32_t n_columns, n_extensions;
@@ -1567,10 +1570,12 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             uint64_t tx2 = xclock();
             w.xcyc[1] += tx2 - tx1;
 
-            uint32_t out_nodes[5];
-            uint8_t out_chars[5];
-            int32_t out_scores[5];
+            // the children list lives in the LDS control block: a private array indexed at run time would sit in scratch
+            uint32_t *out_nodes = w.out_nodes;
+            uint8_t *out_chars = w.out_chars;
+            int32_t *out_scores = w.out_scores;
             const int n_out = uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
+            wave_sync();
             if (n_out == 0) {
                 if (n_tips < max_columns) w.tips[n_tips++] = (uint32_t)i;
                 continue;
