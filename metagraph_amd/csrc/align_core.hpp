@@ -173,7 +173,11 @@ struct ExtendResult { int32_t n_tips; int32_t min_cell_score; int32_t table_size
 // same j): x-drop bands are narrow, so at 8 reads per wavefront the common columns live entirely in LDS while
 // any width stays correct.  The parent column needs S and F only; E exists once, for the column being computed.
 struct Tier { int32_t *lo, *hi; };
-MGX_DEV int32_t &tref(const Tier &t, int32_t cap, int32_t j) { return j < cap ? t.lo[j] : t.hi[j]; }
+// One FLAT access through the selected pointer.  (Measured alternative: separate ds_/global_ paths behind a branch
+// on j < cap, with an LDS address-space hint for `lo` — 2 % slower, the extra branches cost more than decoupling
+// the LDS tier from vmcnt gains.)
+MGX_DEV int32_t tget(const Tier &t, int32_t cap, int32_t j) { return *(j < cap ? t.lo + j : t.hi + j); }
+MGX_DEV void tset(const Tier &t, int32_t cap, int32_t j, int32_t v) { *(j < cap ? t.lo + j : t.hi + j) = v; }
 struct Staging { Tier S, F; int32_t col; };
 constexpr int32_t LQ_CAP = 32;       // frontier entries kept in LDS; the rest spill to the arena
 
@@ -525,6 +529,7 @@ MGX_DEV bool window_low_complexity(Wave &w, int s, int32_t begin, int32_t len) {
 // query preparation: AlignmentResults ctor (A/alignment.cpp:1348-1372) + partial sums
 // ------------------------------------------------------------------------------------------------
 MGX_NI_G1 void prepare_query(Wave &w, const char *raw) {
+    MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     const int32_t L = w.L;
     for (int32_t base = 0; base < L; base += WAVE) {
@@ -670,6 +675,7 @@ MGX_DEV bool push_seed(Wave &w, int s, int32_t clip, int32_t len, int32_t offset
 
 // MEMSeeder::get_seeds / ExactSeeder::get_seeds into w.seeds[s] (A/aligner_seeder_methods.cpp:67-93,360-424)
 MGX_NI_G2 void base_seeds(Wave &w, int s) {
+    MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const int32_t k = (int32_t)P.g.k, L = w.L, n = w.n_kmers;
@@ -767,6 +773,7 @@ MGX_DEV uint64_t xclock() {
 #endif
 // SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358, non-canonical)
 MGX_NI_G2 void make_seeder(Wave &w, int s) {
+    MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const DevGraph &g = P.g;
@@ -1036,11 +1043,13 @@ MGX_DEV void fill_range(int32_t *vec, int32_t a, int32_t b, int32_t val) {
 // query position query_start.  Returns converged score (NINF = nothing improved).
 MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start,
                                    const Tier s_tier, int32_t s_skip, int32_t size) {
+    MGX_ASSUME_LDS(&w);
+    MGX_ASSUME_LDS(&E);
     // S values of the column: cells s_skip .. s_skip + size of the staged (two-tier) S array
     const AlignParams &P = *w.P;
     const int32_t s_cap = uni(w.st_cap);
     s_skip = uni(s_skip);
-#define s_cells(j) tref(s_tier, s_cap, s_skip + (j))
+#define s_cells(j) tget(s_tier, s_cap, s_skip + (j))
     auto column_max = [&]() {
         int32_t m = INT32_MIN;
         for (int32_t base = 0; base < size; base += WAVE) {
@@ -1134,6 +1143,8 @@ MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int
 
 // filter_nodes (:158-207); the key is the raw node id (no RCDBG offset), as in the reference
 MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start, int32_t query_end) {
+    MGX_ASSUME_LDS(&w);
+    MGX_ASSUME_LDS(&E);
     const AlignParams &P = *w.P;
     const int32_t mscore = -NINF;
     int32_t size = query_end - query_start;
@@ -1224,8 +1235,8 @@ MGX_DEV void frontier_insert(Wave &w, int32_t &qn, uint64_t key) {
     wave_sync();
 }
 
-MGX_DEV int32_t st_S(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tref(s.S, cap, j) : NINF; }
-MGX_DEV int32_t st_F(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tref(s.F, cap, j) : NINF; }
+MGX_DEV int32_t st_S(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tget(s.S, cap, j) : NINF; }
+MGX_DEV int32_t st_F(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tget(s.F, cap, j) : NINF; }
 
 // make column `idx` resident in a staging buffer; returns the buffer index
 MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
@@ -1239,7 +1250,7 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
-            if (j < n) { tref(s.S, cap, j) = cells[3 * j]; tref(s.F, cap, j) = cells[3 * j + 2]; }      // a parent's E is never read
+            if (j < n) { tset(s.S, cap, j, cells[3 * j]); tset(s.F, cap, j, cells[3 * j + 2]); }      // a parent's E is never read
         }
     }
     s.col = idx;
@@ -1256,7 +1267,7 @@ MGX_DEV void flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
-            if (j < n) { cells[3 * j] = tref(tS, cap, j); cells[3 * j + 1] = tref(tE, cap, j); cells[3 * j + 2] = tref(tF, cap, j); }
+            if (j < n) { cells[3 * j] = tget(tS, cap, j); cells[3 * j + 1] = tget(tE, cap, j); cells[3 * j + 2] = tget(tF, cap, j); }
         }
     }
 }
@@ -1266,6 +1277,7 @@ MGX_DEV void flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t
 MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_size, int32_t prev_trim, int pb, int cb,
                                int32_t prev_end, int32_t begin, int32_t size, uint8_t c, int32_t init_score,
                                int32_t offset, int32_t start, int32_t window_size, int32_t xdrop_cutoff) {
+    MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     const int32_t go = uni(P.cfg.gap_open), ge = uni(P.cfg.gap_ext);
     const int32_t L = uni(w.L);
@@ -1275,17 +1287,21 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
     const Staging par = w.st[pb];
     const Tier cS = w.st[cb].S, cF = w.st[cb].F, cE = w.stE;
     const int32_t cap = uni(w.st_cap);
-#define CS(j) tref(cS, cap, (j))
-#define CE(j) tref(cE, cap, (j))
-#define CF(j) tref(cF, cap, (j))
+#define CS(j) tget(cS, cap, (j))
+#define CS_SET(j, v) tset(cS, cap, (j), (v))
+#define CE(j) tget(cE, cap, (j))
+#define CE_SET(j, v) tset(cE, cap, (j), (v))
+#define CF(j) tget(cF, cap, (j))
+#define CF_SET(j, v) tset(cF, cap, (j), (v))
     const int32_t trim = begin;
     const int32_t max_size = window_size + 1 - trim;
-    const int8_t *row = (const int8_t *)uni((uint64_t)(w.sm_rows + encode_char(c) * 128));   // profile_score_[encode(c)] (:38-59)
+    MGX_ASSUME_LDS(w.sm_rows);                               // the score rows are a __shared__ array of the kernel
+    const int8_t *row = w.sm_rows + encode_char(c) * 128;    // profile_score_[encode(c)] (:38-59)
     const uint8_t *qq = (const uint8_t *)uni((uint64_t)E.q);
     // DPTColumn::create: size + 5 cells of ninf (we initialise everything update_column may touch)
     const int32_t init_n = imin(max_size, size) + 8;
     for (int32_t base = 0; base < init_n; base += WAVE) {
-        FOR_LANES(l) { int32_t j = base + l; if (j < init_n) { CS(j) = NINF; CE(j) = NINF; CF(j) = NINF; } }
+        FOR_LANES(l) { int32_t j = base + l; if (j < init_n) { CS_SET(j, NINF); CE_SET(j, NINF); CF_SET(j, NINF); } }
     }
     w.st[cb].col = -1;
     wave_sync();
@@ -1308,7 +1324,7 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
                 }
                 int32_t del = NINF;
                 if (offset > 1) del = imax(st_S(par, cap, prev_size, dp + j) + go, st_F(par, cap, prev_size, dp + j) + ge) + init_score;
-                CF(j) = del;                             // F_v[j]
+                CF_SET(j, del);                             // F_v[j]
                 mm = imax(match, del);
             }
             m[l] = mm;
@@ -1329,9 +1345,9 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
         FOR_LANES(l) {
             int32_t j = base + l;
             if (j < n_loop) {
-                CE(j + 1) = enext[l];                    // E_v[j + 1]
+                CE_SET(j + 1, enext[l]);                    // E_v[j + 1]
                 int32_t sv = imax(m[l], ecur[l]);
-                CS(j) = sv > xdrop_cutoff - 1 ? sv : NINF;
+                CS_SET(j, sv > xdrop_cutoff - 1 ? sv : NINF);
             }
         }
         int32_t last_lane = imin(WAVE, n_loop - base) - 1;
@@ -1344,7 +1360,7 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
         int32_t ap = start + trim + j;
         int32_t prof = (ap >= 1 && ap <= L) ? (int32_t)row[qq[ap - 1] & 127] : 0;
         int32_t match = uni(imax(st_S(par, cap, prev_size, dp + j - 1) + init_score + prof, CE(j)));
-        if (match >= xdrop_cutoff) CS(j) = match;
+        if (match >= xdrop_cutoff) CS_SET(j, match);
     }
     wave_sync();
     // extend_ins_end
@@ -1365,9 +1381,9 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
                     int32_t t = base + l;
                     if (t < n_push) {
                         int32_t v = ins_score + t * ge;
-                        CS(size + t) = v; CE(size + t) = v; CF(size + t) = NINF;
+                        CS_SET(size + t, v); CE_SET(size + t, v); CF_SET(size + t, NINF);
                     } else if (t < n_push + 5) {             // padding after the new end is ninf
-                        CS(size + t) = NINF; CE(size + t) = NINF; CF(size + t) = NINF;
+                        CS_SET(size + t, NINF); CE_SET(size + t, NINF); CF_SET(size + t, NINF);
                     }
                 }
             }
@@ -1383,6 +1399,9 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
 #undef CS
 #undef CE
 #undef CF
+#undef CS_SET
+#undef CE_SET
+#undef CF_SET
 
 MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
                           uint32_t *nodes, uint8_t *chars, int32_t *scores) {
@@ -1443,6 +1462,8 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
 }
 
 MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
+    MGX_ASSUME_LDS(&w);
+    MGX_ASSUME_LDS(&E);
     ExtendResult *res = &w.er;
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
@@ -1477,11 +1498,11 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         Staging &s0 = w.st[0];
         const int32_t cap = w.st_cap;
         for (int32_t base = 0; base < 8; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < 8) { tref(s0.S, cap, j) = NINF; tref(w.stE, cap, j) = NINF; tref(s0.F, cap, j) = NINF; } }
+            FOR_LANES(l) { int32_t j = base + l; if (j < 8) { tset(s0.S, cap, j, NINF); tset(w.stE, cap, j, NINF); tset(s0.F, cap, j, NINF); } }
         }
         wave_sync();
         int32_t sroot = (cfg.left_end_bonus && !seed.clipping) ? cfg.left_end_bonus : 0;
-        FOR_LANES(l) { if (l == 0) tref(s0.S, cap, 0) = sroot; }
+        FOR_LANES(l) { if (l == 0) tset(s0.S, cap, 0, sroot); }
         wave_sync();
         int32_t max_size = window_size + 1;
         int32_t pushes = 0;
@@ -1496,9 +1517,9 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                         int32_t t = base + l;
                         if (t < n_push) {
                             int32_t v = ins_score + t * cfg.gap_ext;
-                            tref(s0.S, cap, 1 + t) = v; tref(w.stE, cap, 1 + t) = v; tref(s0.F, cap, 1 + t) = NINF;
+                            tset(s0.S, cap, 1 + t, v); tset(w.stE, cap, 1 + t, v); tset(s0.F, cap, 1 + t, NINF);
                         } else if (t < n_push + 5) {
-                            tref(s0.S, cap, 1 + t) = NINF; tref(w.stE, cap, 1 + t) = NINF; tref(s0.F, cap, 1 + t) = NINF;
+                            tset(s0.S, cap, 1 + t, NINF); tset(w.stE, cap, 1 + t, NINF); tset(s0.F, cap, 1 + t, NINF);
                         }
                     }
                 }
@@ -1558,7 +1579,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             int32_t b = col.size, e = 0;
             for (int32_t base = 0; base < col.size; base += WAVE) {
                 LV<bool> inr;
-                FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && tref(par.S, cap, j) >= prev_xdrop_cutoff; }
+                FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && tget(par.S, cap, j) >= prev_xdrop_cutoff; }
                 uint64_t mk = wave_ballot(inr);
                 if (mk) {
                     if (b == col.size) b = base + ctz64(mk);
@@ -1616,7 +1637,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                     LV<bool> ext;
                     FOR_LANES(l) {
                         int32_t j = base + l;
-                        int32_t v = j < size ? tref(cS, cap, j) : INT32_MIN;
+                        int32_t v = j < size ? tget(cS, cap, j) : INT32_MIN;
                         sv[l] = v;
                         mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
                         ext[l] = j < size && v + psum[start + begin + j] >= extension_cutoff;
@@ -1710,6 +1731,7 @@ MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src);
 // seed_aln: the Alignment the seed was made from (backward pass) or nullptr for Seed-derived seeds
 MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, const DevAln *seed_aln,
                        const ExtendResult &er, int32_t min_path_score, DevAln &out) {
+    MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const int32_t k = (int32_t)P.g.k;
@@ -1996,6 +2018,7 @@ MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src) {
 
 // Alignment::reverse_complement for RCDBG views (alignment.cpp:547-561); false = alignment became empty
 MGX_NI_G4 bool reverse_complement_aln(Wave &w, DevAln &a) {
+    MGX_ASSUME_LDS(&w);
     if (a.offset) { a.n_nodes = 0; return false; }        // trim_offset() left a non-zero offset
     int32_t n = imax(imax(a.n_nodes, a.n_cigar), a.seq_len);
     for (int32_t base = 0; base < (n + 1) / 2; base += WAVE) {
@@ -2054,7 +2077,8 @@ MGX_DEV bool aln_less(const DevAln &a, const DevAln &b) {
     return ca > cb;
 }
 
-MGX_NI_G4 void add_alignment(Wave &w, const DevAln &a) {       // :68-138
+MGX_NI_G4 void add_alignment(Wave &w, const DevAln &a) {
+    MGX_ASSUME_LDS(&w);       // :68-138
     if (!w.have_best) { copy_aln(w.aln[3], a); w.have_best = 1; return; }
     if (a.score < global_cutoff(w)) return;
     if (aln_equal(w, a, w.aln[3])) return;
@@ -2088,6 +2112,7 @@ MGX_DEV int32_t min_path_score_now(const Wave &w) {          // get_min_path_sco
 
 // aln_both (:657-736): seeds of strand s; fwd extender = ext[s] on the graph, bwd extender = ext[1 - s] on RCDBG
 MGX_NI_G4 void aln_both(Wave &w, int s) {
+    MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     ExtenderState &F = w.ext[s];
     ExtenderState &B = w.ext[1 - s];
@@ -2161,6 +2186,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
 
 // align_core (:360-384) with the seeds of strand 0, forward only
 MGX_NI_G4 void align_core_fwd(Wave &w) {
+    MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     ExtenderState &F = w.ext[0];
     F.rc_view = 0;

@@ -22,6 +22,13 @@
 #define MGX_DEV_NOINLINE __device__ __forceinline__
 #endif
 #define MGX_HD __host__ __device__ __forceinline__
+// the control block of a wave program lives in LDS: tell the compiler, so that accesses through a `Wave &` that
+// crossed a noinline call boundary become ds_read/ds_write instead of FLAT instructions (which also wait on vmcnt)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGX_ASSUME_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const void *)(p)))
+#else
+#define MGX_ASSUME_LDS(p) ((void)0)
+#endif
 #define MGX_WAVE_EMU 0
 
 namespace mgx {

@@ -18,6 +18,9 @@
 #define MGX_DEV_NOINLINE __device__ __forceinline__
 #endif
 #define MGX_HD __host__ __device__ __forceinline__
+// the control block of a wave program lives in LDS: tell the compiler, so that accesses through a `Wave &` that
+// crossed a noinline call boundary become ds_read/ds_write instead of FLAT instructions (which also wait on vmcnt)
+#define MGX_ASSUME_LDS(p) ((void)0)
 #define MGX_WAVE_EMU 0
 #define MGX_LANE_MODE 1
 

@@ -16,6 +16,9 @@
 #define MGX_DEV inline
 #define MGX_DEV_NOINLINE
 #define MGX_HD inline
+// the control block of a wave program lives in LDS: tell the compiler, so that accesses through a `Wave &` that
+// crossed a noinline call boundary become ds_read/ds_write instead of FLAT instructions (which also wait on vmcnt)
+#define MGX_ASSUME_LDS(p) ((void)0)
 #define MGX_WAVE_EMU 1
 #define __global__
 #define __device__
