@@ -1011,10 +1011,10 @@ MGX_DEV int32_t conv_find(const ConvChecker &c, uint32_t mask, uint64_t key, uin
     const uint32_t gen = uni(c.gen);
     uint32_t h = conv_hash(key, mask);
     for (;;) {
-        ConvSlot sl = slots[h];
+        ConvSlot sl = gld(slots + h);
         if (uni(sl.gen) != gen) { *slot_out = h; return -1; }
         const uint32_t idx = uni(sl.idx);
-        if (uni(entries[idx].key) == key) { *slot_out = h; return (int32_t)idx; }
+        if (uni(gld(&entries[idx].key)) == key) { *slot_out = h; return (int32_t)idx; }
         h = (h + 1) & mask;
     }
 }
@@ -1026,16 +1026,16 @@ MGX_DEV int32_t conv_insert(Wave &w, ConvChecker &c, uint32_t slot, uint64_t key
     uint32_t idx = ne;
     c.n_entries = ne + 1;
     ConvEntry e; e.key = key; e.start = start; e.len = len;
-    c.entries[idx] = e;
+    gst(c.entries + idx, e);
     ConvSlot sl; sl.gen = c.gen; sl.idx = idx;
-    c.slots[slot] = sl;
+    gst(c.slots + slot, sl);
     return (int32_t)idx;
 }
 
 // fill vec positions [a, b) with `val`
 MGX_DEV void fill_range(int32_t *vec, int32_t a, int32_t b, int32_t val) {
     for (int32_t base = a; base < b; base += WAVE) {
-        FOR_LANES(l) { int32_t j = base + l; if (j < b) vec[j] = val; }
+        FOR_LANES(l) { int32_t j = base + l; if (j < b) gst(vec + j, val); }
     }
 }
 
@@ -1071,38 +1071,38 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         if (idx < 0) return NINF;
         int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells(j); }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
         }
         wave_sync();
         return column_max();
     }
-    ConvEntry e = E.conv.entries[idx];
+    ConvEntry e = gld(E.conv.entries + idx);
     int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
     int32_t start = uni(e.start), len = uni(e.len);
     if (query_start + size <= start) {
         fill_range(vec, query_start + size, start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells(j); }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
         }
         e.len = start + len - query_start; e.start = query_start;
-        E.conv.entries[idx] = e;
+        gst(E.conv.entries + idx, e);
         wave_sync();
         return column_max();
     }
     if (query_start >= start + len) {
         fill_range(vec, start + len, query_start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) vec[query_start + j] = s_cells(j); }
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
         }
         e.len = query_start + size - start;
-        E.conv.entries[idx] = e;
+        gst(E.conv.entries + idx, e);
         wave_sync();
         return column_max();
     }
     if (query_start < start) { fill_range(vec, query_start, start, NINF); len += start - query_start; start = query_start; }
     if (query_start + size > start + len) { fill_range(vec, start + len, query_start + size, NINF); len = query_start + size - start; }
     e.start = start; e.len = len;
-    E.conv.entries[idx] = e;
+    gst(E.conv.entries + idx, e);
     wave_sync();
     int32_t max_changed = NINF;
     const double rel = P.cfg.rel_score_cutoff;
@@ -1113,10 +1113,10 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
             x[l] = NINF;
             if (j < size) {
                 int32_t sv = s_cells(j);
-                int32_t vv = vec[query_start + j];
+                int32_t vv = gld(vec + query_start + j);
                 if ((double)sv > (double)vv * rel) {
                     vv = imax(vv, sv);
-                    vec[query_start + j] = vv;
+                    gst(vec + query_start + j, vv);
                     x[l] = vv;
                 }
             }
@@ -1207,8 +1207,8 @@ MGX_DEV int32_t key_score(uint64_t key) { return (int32_t)(uint32_t)(key >> 40) 
 MGX_DEV uint32_t key_idx(uint64_t key) { return (uint32_t)(key & 0xFFFFFF); }
 
 // two-tier arrays: the first LQ_CAP entries in LDS, the rest in the arena
-MGX_DEV uint64_t tier_get(const uint64_t *lds, const uint64_t *arena, int32_t i) { return i < LQ_CAP ? lds[i] : arena[i - LQ_CAP]; }
-MGX_DEV void tier_set(uint64_t *lds, uint64_t *arena, int32_t i, uint64_t v) { if (i < LQ_CAP) lds[i] = v; else arena[i - LQ_CAP] = v; }
+MGX_DEV uint64_t tier_get(const uint64_t *lds, const uint64_t *arena, int32_t i) { return i < LQ_CAP ? lds[i] : gld(arena + (i - LQ_CAP)); }
+MGX_DEV void tier_set(uint64_t *lds, uint64_t *arena, int32_t i, uint64_t v) { if (i < LQ_CAP) lds[i] = v; else gst(arena + (i - LQ_CAP), v); }
 
 // The frontier (std::priority_queue<TableIt>, :477-487) is kept as an ascending sorted array (keys are
 // unique), so the maximum is at the back.  Insert = lane-parallel rank + shift.
@@ -1250,7 +1250,7 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
-            if (j < n) { tset(s.S, cap, j, cells[3 * j]); tset(s.F, cap, j, cells[3 * j + 2]); }      // a parent's E is never read
+            if (j < n) { tset(s.S, cap, j, gld(cells + 3 * j)); tset(s.F, cap, j, gld(cells + 3 * j + 2)); }      // a parent's E is never read
         }
     }
     s.col = idx;
@@ -1267,7 +1267,7 @@ MGX_DEV void flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
-            if (j < n) { cells[3 * j] = tget(tS, cap, j); cells[3 * j + 1] = tget(tE, cap, j); cells[3 * j + 2] = tget(tF, cap, j); }
+            if (j < n) { gst(cells + 3 * j, tget(tS, cap, j)); gst(cells + 3 * j + 1, tget(tE, cap, j)); gst(cells + 3 * j + 2, tget(tF, cap, j)); }
         }
     }
 }
@@ -1534,7 +1534,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         s0.col = 0;
         cell_top += 3 * (uint32_t)(r.size + 5);
         if (E.table_cap < 1) E.table_cap = 1;                 // emplace_back on an empty vector
-        w.cols[0] = r;
+        gst(w.cols + 0, r);
         w.hot = r;
         w.hot_idx = 0;
         tsize = 1;
@@ -1562,7 +1562,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             uint64_t tx1 = xclock();
             const int32_t i = (int32_t)uni(key_idx(tier_get(w.lnn, w.next_nodes, nn - 1)));
             --nn;
-            const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : w.cols[i]);
+            const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : gld(w.cols + i));
             const int pb = uni(stage_column(w, i, col));
             const Staging par = w.st[pb];
             const int32_t cap = uni(w.st_cap);
@@ -1598,7 +1598,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             const int n_out = uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
             wave_sync();
             if (n_out == 0) {
-                if (n_tips < max_columns) w.tips[n_tips++] = (uint32_t)i;
+                if (n_tips < max_columns) gst(w.tips + n_tips++, (uint32_t)i);
                 continue;
             }
             w.xcyc[2] += xclock() - tx2;
@@ -1666,7 +1666,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
                 best_score = imax(best_score, max_val);
                 // commit the column: metadata + cells go to the arena (nothing waits on them)
-                w.cols[tsize] = cur;
+                gst(w.cols + tsize, cur);
                 w.hot = cur;
                 w.hot_idx = tsize;
                 flush_column(w, w.st[cb], cell_top, size);

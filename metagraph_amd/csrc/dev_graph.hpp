@@ -51,7 +51,7 @@ MGX_DEV Block load_block_t(const DevGraph &g, uint32_t b);
 
 MGX_DEV Block load_block(const DevGraph &g, uint32_t b) {
     const uint4 *p = reinterpret_cast<const uint4 *>(g.blocks + b);
-    uint4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+    uint4 a0 = gld(p), a1 = gld(p + 1), a2 = gld(p + 2), a3 = gld(p + 3);
     Block r;
     r.cum[0] = a0.x; r.cum[1] = a0.y; r.cum[2] = a0.z; r.cum[3] = a0.w;
     r.last_cum = a1.x; r.cum0 = a1.y;
@@ -84,7 +84,7 @@ MGX_DEV Block uni_block(const Block &b) {
 }
 template <> MGX_DEV Block load_block_t<false>(const DevGraph &g, uint32_t b) { return load_block(g, b); }
 template <> MGX_DEV Block load_block_t<true>(const DevGraph &g, uint32_t b) { return load_block_uniform(g, b); }
-template <bool U> MGX_DEV uint32_t load_hint(const uint32_t *p) { if constexpr (U) return sload_u32(p); else return *p; }
+template <bool U> MGX_DEV uint32_t load_hint(const uint32_t *p) { if constexpr (U) return sload_u32(p); else return gld(p); }
 
 // bits j <= pos
 MGX_DEV uint64_t mask_upto(int pos) { return pos >= 63 ? ~0ull : ((1ull << (pos + 1)) - 1); }

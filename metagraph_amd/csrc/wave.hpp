@@ -180,6 +180,16 @@ struct RegTab64 {
     MGX_DEV void fill(int32_t x) { v = x; }
 };
 
+// Loads / stores that are known to target global memory (graph, arena): global_* instead of FLAT instructions, so
+// that they do not bump lgkmcnt and LDS traffic never waits for them.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGX_AS_GLOBAL(T, p) ((__attribute__((address_space(1))) T *)(p))
+#else
+#define MGX_AS_GLOBAL(T, p) (p)
+#endif
+template <class T> MGX_DEV T gld(const T *p) { return *MGX_AS_GLOBAL(const T, p); }
+template <class T, class V> MGX_DEV void gst(T *p, V v) { *MGX_AS_GLOBAL(T, p) = (T)v; }
+
 MGX_DEV uint64_t cycle_clock() { return __builtin_readcyclecounter(); }
 MGX_DEV int popc64(uint64_t x) { return __popcll(x); }
 MGX_DEV int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }           // x != 0

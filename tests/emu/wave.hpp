@@ -121,6 +121,10 @@ struct RegTab64 {
 #define MGX_HAS_REGTAB 0
 #endif
 
+// host model of wave.hpp's global-memory accessors
+template <class T> inline T gld(const T *p) { return *p; }
+template <class T, class V> inline void gst(T *p, V v) { *p = (T)v; }
+
 inline uint64_t cycle_clock() { return 0; }
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
 inline int ctz64(uint64_t x) { return __builtin_ctzll(x); }
