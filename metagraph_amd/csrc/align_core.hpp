@@ -528,7 +528,7 @@ MGX_DEV bool window_low_complexity(Wave &w, int s, int32_t begin, int32_t len) {
 // ------------------------------------------------------------------------------------------------
 // query preparation: AlignmentResults ctor (A/alignment.cpp:1348-1372) + partial sums
 // ------------------------------------------------------------------------------------------------
-MGX_NI_G1 void prepare_query(Wave &w, const char *raw) {
+MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     const int32_t L = w.L;
@@ -565,8 +565,8 @@ MGX_NI_G1 void prepare_query(Wave &w, const char *raw) {
         }
         FOR_LANES(l) { if (l == 0) w.psum[s][L] = 0; }
     }
-    // 2-bit packed strands for the suffix-range table keys
-    for (int s = 0; s < 2; ++s) {
+    // 2-bit packed strands for the suffix-range table keys (the seeder's lookups only)
+    for (int s = 0; for_seeding && s < 2; ++s) {
         const int32_t nw = (L + 15) / 16 + 1;
         uint64_t bad_any = 0;
         for (int32_t base = 0; base < nw; base += WAVE) {
@@ -1183,10 +1183,10 @@ MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t qu
 // extension (DefaultColumnExtender::extend, A/aligner_extender_methods.cpp:412-772)
 // ------------------------------------------------------------------------------------------------
 MGX_DEV int32_t cell_S(const Wave &w, const ColMeta &c, int32_t j) {
-    return (j >= 0 && j < c.size + 5) ? w.cells[c.cells + 3 * j] : NINF;   // outside: undefined in the reference
+    return (j >= 0 && j < c.size + 5) ? gld(w.cells + c.cells + 3 * j) : NINF;   // outside: undefined in the reference
 }
-MGX_DEV int32_t cell_E(const Wave &w, const ColMeta &c, int32_t j) { return (j >= 0 && j < c.size + 5) ? w.cells[c.cells + 3 * j + 1] : NINF; }
-MGX_DEV int32_t cell_F(const Wave &w, const ColMeta &c, int32_t j) { return (j >= 0 && j < c.size + 5) ? w.cells[c.cells + 3 * j + 2] : NINF; }
+MGX_DEV int32_t cell_E(const Wave &w, const ColMeta &c, int32_t j) { return (j >= 0 && j < c.size + 5) ? gld(w.cells + c.cells + 3 * j + 1) : NINF; }
+MGX_DEV int32_t cell_F(const Wave &w, const ColMeta &c, int32_t j) { return (j >= 0 && j < c.size + 5) ? gld(w.cells + c.cells + 3 * j + 2) : NINF; }
 
 // capacity of a reference vector created with `size0` elements (+5 reserved) after `pushes` push_backs
 // followed by reserve(size + 5) (DPTColumn::create :389-410, extend_ins_end :293-328; libstdc++ growth)
@@ -1872,9 +1872,13 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                 }
             }
         };
+        // The column chain is walked parent by parent.  Metadata is fetched one step ahead (the grandparent's with
+        // this step's cell loads), so that every step costs one arena round trip instead of three dependent ones.
+        ColMeta col = gld(w.cols + j), par = col;
+        if (j) par = gld(w.cols + col.parent);
         while (j) {
-            const ColMeta col = w.cols[j];
-            const ColMeta par = w.cols[col.parent];
+            ColMeta gp = par;
+            if (col.parent > 0) gp = gld(w.cols + par.parent);          // par is not the root
             const int32_t trim = col.trim, trim_p = par.trim;
             align_offset = imin(col.offset, k_minus_1);
             if (pos == col.max_pos) prev_start_test_and_set(w, j);
@@ -1898,6 +1902,7 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                 append_node(col.node, (uint8_t)col.c, col.offset, profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + pos));
                 --pos;
                 j = col.parent;
+                col = par; par = gp;
             } else if (sv == cell_F(w, col, pos - trim) && (n_ops == 0 || last_op != OP_INSERTION)) {
                 uint32_t lop = OP_DELETION;
                 while (lop == OP_DELETION && j) {
@@ -1912,6 +1917,7 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                     j = c2.parent;
                     if (w.status != ST_OK) return false;
                 }
+                if (j) { col = gld(w.cols + j); par = gld(w.cols + col.parent); }
             } else {
                 break;
             }
@@ -2260,7 +2266,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     if (w.L > (int32_t)P.lim.Lmax) {
         w.status = ST_CAPACITY;
     } else {
-        prepare_query(w, P.seqs + off);
+        prepare_query(w, P.seqs + off, (PHASE & PH_SEED) != 0);
         w.lc_any[0] = w.lc_any[1] = -1;
         w.cyc[0] = cycle_clock() - tstart;
         for (int s = 0; s < 2; ++s) {
