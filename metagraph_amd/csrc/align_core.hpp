@@ -226,6 +226,7 @@ struct Wave {
     DevAln aln[4];               // 0: extension result, 1: reversed seed for the backward pass,
                                  // 2: backward extension result, 3: best (aggregator)
     int32_t have_best;
+    int32_t seeds_done;          // seeds whose extension ran for this read (two-pass extension)
     LineCtr ctr;                 // BOSS block loads (lane-parallel regions add their wave sums)
     ExtendResult er;             // result of the last extend(); noinline callees must not write through
     int32_t tmp_pushes;
@@ -2127,6 +2128,8 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
     const int32_t n = w.n_seeds[s];
     for (int32_t i = 0; i < n; ++i) {
         if (!w.alive[s][i]) continue;
+        if (P.seed_limit && w.seeds_done >= (int32_t)P.seed_limit) { w.status = ST_RETRY; return; }
+        ++w.seeds_done;
         const uint64_t tp0 = cycle_clock();
         SeedRef seed = seedref_from_seed(w, s, i, nullptr);
         conv_clear(F.conv);                                   // set_seed (:90-98)
@@ -2199,6 +2202,8 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
     const int32_t n = w.n_seeds[0];
     for (int32_t i = 0; i < n; ++i) {
         if (!w.alive[0][i]) continue;
+        if (P.seed_limit && w.seeds_done >= (int32_t)P.seed_limit) { w.status = ST_RETRY; return; }
+        ++w.seeds_done;
         SeedRef seed = seedref_from_seed(w, 0, i, nullptr);
         int32_t mps = imax(0, min_path_score_now(w));
         conv_clear(F.conv);
@@ -2246,6 +2251,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     w.L = (int32_t)(P.offsets[read + 1] - off);
     w.status = ST_OK;
     w.have_best = 0;
+    w.seeds_done = 0;
     w.ctr.rank_lines = w.ctr.select_lines = w.ctr.bit_lines = 0;
     w.n_columns = w.n_extensions = 0;
     const uint64_t nb = P.node_begin[read];
@@ -2393,6 +2399,23 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
 #ifdef MGX_SEED_PROBE
         for (int x = 0; x < 8; ++x) stats_accum->xcyc[x] += w.xcyc[x];
 #endif
+        return;
+    }
+    if (w.status == ST_RETRY) {
+        // pass 1 of the two-pass extension: this read goes on to another seed; hand it to pass 2 untouched
+        FOR_LANES(l) {
+            if (l == 0) {
+#if MGX_WAVE_EMU
+                P.retry_list[(*P.retry_count)++] = (uint32_t)read;
+#else
+                P.retry_list[atomicAdd(P.retry_count, 1ull)] = (uint32_t)read;
+#endif
+            }
+        }
+        stats_accum->rank_lines += w.ctr.rank_lines;
+        stats_accum->select_lines += w.ctr.select_lines;
+        stats_accum->bit_lines += w.ctr.bit_lines;
+        for (int x = 0; x < 8; ++x) { stats_accum->cyc[x] += w.cyc[x]; stats_accum->xcyc[x] += w.xcyc[x]; }
         return;
     }
     const uint64_t tout = cycle_clock();

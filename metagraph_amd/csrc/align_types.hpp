@@ -9,7 +9,7 @@ constexpr uint32_t INF_LEN = 0xFFFFFFFFu;            // "unbounded" size_t confi
 
 enum { OP_CLIPPED = 0, OP_MISMATCH = 1, OP_MATCH = 2, OP_DELETION = 3, OP_INSERTION = 4, OP_NODE_INSERTION = 5 };
 
-enum { ST_OK = 0, ST_CAPACITY = -5 };
+enum { ST_OK = 0, ST_CAPACITY = -5, ST_RETRY = -100 };      // ST_RETRY is internal to the two-pass extension (never reported)
 
 // DBGAlignerConfig after the DBGAligner ctor clamps (dbg_aligner.cpp:33-61), narrowed for the device
 struct DevConfig {
@@ -97,6 +97,14 @@ struct AlignParams {
     unsigned long long *seed_cursor;
     uint32_t *work_key;                  // [n_reads], written by the seeding phase
     const uint32_t *order;               // optional: the extension phase processes read order[i] as its i-th item
+    // two-pass extension: pass 1 stops a read that would extend a second seed (seed_limit = 1) and lists it in
+    // retry_list; pass 2 re-runs the listed reads from scratch without a limit (order = retry_list, item count read
+    // from *n_items_ptr on the device).  Keeps the rare multi-seed reads from stalling the 7 other reads of their
+    // wavefront.
+    uint32_t seed_limit;                 // 0 = unlimited
+    uint32_t *retry_list;
+    unsigned long long *retry_count;
+    const unsigned long long *n_items_ptr;   // null: n_reads items
 };
 
 } // namespace mgx

@@ -36,12 +36,13 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
     uint8_t *lds = dyn_lds + (uint32_t)g * lds_bytes;
     KernelStats acc;
     memset(&acc, 0, sizeof(acc));
+    const uint64_t n_items = P.n_items_ptr ? *P.n_items_ptr : P.n_reads;
     for (;;) {
         LV<uint64_t> rv;
         rv.v = 0;
         if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
         uint64_t item = wave_bcast(rv, 0);
-        if (item >= P.n_reads) break;
+        if (item >= n_items) break;
         const uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
         align_read<PHASE>(w, P, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
     }

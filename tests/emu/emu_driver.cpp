@@ -34,6 +34,7 @@ struct EmuRun {
     std::vector<DevSeed> seeds;
     DevLimits lim;
     KernelStats stats;
+    uint64_t retried = 0;         // reads handed to pass 2 of the two-pass extension
 };
 } // namespace
 
@@ -203,8 +204,16 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         P.order = order.data();
+        // two-pass extension: at most one seed per read first, then the reads that go on, from scratch
+        std::vector<uint32_t> retry(n + 1);
+        unsigned long long retry_count = 0;
+        P.seed_limit = 1; P.retry_list = retry.data(); P.retry_count = &retry_count;
         for (uint64_t i = 0; i < n; ++i)
             align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
+        P.seed_limit = 0; P.order = retry.data();
+        for (uint64_t i = 0; i < retry_count; ++i)
+            align_read<PH_EXTEND>(*w, P, retry[i], 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
+        R->retried = retry_count;
     } else {
         for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
     }
@@ -212,6 +221,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     return R;
 }
 
+uint64_t emu_retried(void *r) { return static_cast<EmuRun *>(r)->retried; }
 const char *emu_error(void *r) { return static_cast<EmuRun *>(r)->error.c_str(); }
 void emu_results(void *r, mgx_results *out) { static_cast<EmuRun *>(r)->host.view(out); }
 void emu_mapping(void *r, mgx_mapping *out) {

@@ -96,6 +96,12 @@ class EmuRun:
             L().emu_free(self.r)
             self.r = None
 
+    def retried(self):
+        """reads that pass 1 of the two-pass extension handed to pass 2 (split pipeline only)"""
+        L().emu_retried.restype = C.c_uint64
+        L().emu_retried.argtypes = [C.c_void_p]
+        return L().emu_retried(self.r)
+
     def results(self):
         v = capi.Results()
         L().emu_results(self.r, C.byref(v))

@@ -161,6 +161,22 @@ def test_split_pipeline(k, mask, seed, monkeypatch):
     compare_full(g, eg, cfg, reads)
 
 
+def test_two_pass_extension_retries_multi_seed_reads(monkeypatch):
+    """Pass 1 of the split pipeline extends at most one seed per read; reads that go on to another seed are re-run
+    from scratch in pass 2.  A world with chimeric reads (two distant genome pieces glued together) makes sure the
+    second pass is actually taken, and the results still equal the oracle's."""
+    monkeypatch.setenv("MGX_EMU_SPLIT", "1")
+    g, reads = make_world(333, 15, genome_len=4000, n_reads=30, read_len=100)
+    rng = random.Random(9)
+    chim = [reads[i][:50] + reads[i + 1][40:90] for i in range(0, 20, 2)]
+    eg = emu_drv.EmuGraph(g)
+    cfg = capi.config_cli(15)
+    cfg.min_exact_match = 0.0
+    e = compare_full(g, eg, cfg, reads + chim)
+    assert e.retried() > 0
+    assert rng is not None
+
+
 def test_split_pipeline_unit_kats(monkeypatch):
     monkeypatch.setenv("MGX_EMU_SPLIT", "1")
     for case in KATS["unit"]:
