@@ -277,6 +277,7 @@ struct mgx_aligner {
     mgx_stats hstats;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     bool split_ran = false;
+    uint64_t seed_scale = 1, seed_cap = 0;
     AlignMode mode = default_mode();
     uint64_t arena_stride = 0;
 };
@@ -678,7 +679,12 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     size_t sort_tmp_bytes = 0;
     if (split) {
         // seeds travel from the seeding kernel to the extension kernel through a compact stream
-        const uint64_t seed_cap = std::min<uint64_t>(n * 2 * (uint64_t)l.max_seeds, n * 24 + 4096);
+        // typical reads carry a handful of seeds; long or repetitive ones scale with their k-mer count.  The stream is
+        // sized by a heuristic times A->seed_scale; mgx_align_batch_device re-runs the stage with a larger scale if the
+        // seeding kernel ran out of room (the cursor keeps counting), so the size is never a correctness limit.
+        const uint64_t seed_cap = std::min<uint64_t>(n * 2 * (uint64_t)l.max_seeds,
+                                                     (n * 24 + A->total_kmers / 8 + 4096) * A->seed_scale);
+        A->seed_cap = seed_cap;
         if (int rc = A->seed_hdr.ensure(n * sizeof(SeedHdr))) return rc;
         if (int rc = A->seed_stream.ensure(seed_cap * sizeof(DevSeed))) return rc;
         if (int rc = A->work_key.ensure(n * 4)) return rc;
@@ -818,8 +824,17 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
     if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc;
     bool mapped = A->cfg.max_seed_length >= A->graph->g.k;
     if (int rc = run_map(A, d_seqs, d_offsets, n, A->cfg.forward_and_reverse_complement != 0, mapped)) return rc;
-    if (int rc = run_align(A, d_seqs, d_offsets, n, Lmax)) return rc;
-    return collect_stats(A, mapped, true);
+    for (;;) {
+        if (int rc = run_align(A, d_seqs, d_offsets, n, Lmax)) return rc;
+        if (int rc = collect_stats(A, mapped, true)) return rc;
+        if (!A->split_ran) break;
+        unsigned long long seeds_wanted = 0;
+        HIP_TRY(hipMemcpy(&seeds_wanted, A->cursors.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost));
+        if (seeds_wanted <= A->seed_cap) break;
+        // the seed stream overflowed: reads past its end were given a capacity status; redo the stage with room
+        A->seed_scale = seeds_wanted / std::max<uint64_t>(1, A->seed_cap / A->seed_scale) + 2;
+    }
+    return MGX_OK;
 }
 
 int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {

@@ -122,6 +122,24 @@ def test_device_results_wrap_as_a_torch_tensor():
             assert scores[q] == got[q][0]["score"]
 
 
+@pytest.mark.parametrize("pipeline", ["split8", "wave"])
+def test_baseline_config0_transcripts_k12(pipeline):
+    """BASELINE.json configs[0] in small: `metagraph align` of the transcripts against their own k = 12 graph
+    (tests/data/transcripts_100.fa: 100 queries of 68 .. 5603 bp, every one an exact path).  Long queries put the
+    per-read arenas (O(columns x length) convergence vectors) and the ragged-batch handling under load."""
+    from test_oracle_kats import read_fasta, HERE
+    seqs = read_fasta(os.path.join(HERE, "golden", "transcripts_100.fa"))
+    g = orc.Graph.build(12, seqs, 0, False)
+    cfg = capi.config_cli(12)
+    want = orc.AlignRun(g, cfg, seqs, threads=8).results()
+    A = aligner.Aligner(gpu_graph(g), cfg)
+    A.set_pipeline(pipeline)
+    got, status = A.align_batch(seqs)
+    assert all(s == 0 for s in status), status
+    assert got == want
+    assert sum(1 for r, q in zip(got, seqs) if r and r[0]["cigar"] == "%d=" % len(q)) >= 95
+
+
 def test_unknown_pipeline_is_an_error():
     g, _ = make_world(3, 9, genome_len=300, n_reads=0)
     A = aligner.Aligner(gpu_graph(g), capi.config_cli(9))
