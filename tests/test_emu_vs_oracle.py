@@ -215,6 +215,25 @@ def test_group_sizes_in_emulation(lanes):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("min_seed,per_locus", [(15, 1000), (13, 2), (9, 1)])
+def test_sub_k_seeding_variants(min_seed, per_locus):
+    """BASELINE configs[4] flavour: `--align-min-seed-length 15` (and shorter), with the per-locus seed cap
+    (aligner_seeder_methods.cpp:340) biting on a repetitive genome where suffix ranges hold several nodes."""
+    rng = random.Random(77)
+    unit = rand_seq(rng, 40)
+    genome = rand_seq(rng, 600) + unit + rand_seq(rng, 300) + unit[:30] + rand_seq(rng, 5) + unit[10:] + rand_seq(rng, 600)
+    g = orc.Graph.build(31, [genome], 0, False)
+    reads = []
+    for _ in range(30):
+        p = rng.randrange(0, len(genome) - 120)
+        reads.append(mutate(rng, genome[p:p + 120], 0.03))
+    cfg = capi.config_cli(31)
+    cfg.min_seed_length = min_seed
+    cfg.max_num_seeds_per_locus = per_locus
+    cfg.min_exact_match = 0.0
+    compare_full(g, emu_drv.EmuGraph(g), cfg, reads)
+
+
 def test_align_cli_config_no_min_exact_match():
     g, reads = make_world(200, 15, n_reads=60)
     eg = emu_drv.EmuGraph(g)

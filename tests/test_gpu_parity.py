@@ -140,6 +140,26 @@ def test_baseline_config0_transcripts_k12(pipeline):
     assert sum(1 for r, q in zip(got, seqs) if r and r[0]["cigar"] == "%d=" % len(q)) >= 95
 
 
+@pytest.mark.parametrize("min_seed,per_locus", [(15, 1000), (13, 2), (9, 1)])
+def test_sub_k_seeding_variants_on_gpu(min_seed, per_locus):
+    """BASELINE configs[4] flavour (`--align-min-seed-length 15` and shorter, per-locus seed cap) on a repetitive
+    genome; same construction as the CPU-model test."""
+    from test_emu_vs_oracle import rand_seq
+    rng = random.Random(77)
+    unit = rand_seq(rng, 40)
+    genome = rand_seq(rng, 600) + unit + rand_seq(rng, 300) + unit[:30] + rand_seq(rng, 5) + unit[10:] + rand_seq(rng, 600)
+    g = orc.Graph.build(31, [genome], 0, False)
+    reads = []
+    for _ in range(30):
+        p = rng.randrange(0, len(genome) - 120)
+        reads.append(mutate(rng, genome[p:p + 120], 0.03))
+    cfg = capi.config_cli(31)
+    cfg.min_seed_length = min_seed
+    cfg.max_num_seeds_per_locus = per_locus
+    cfg.min_exact_match = 0.0
+    compare_gpu(g, gpu_graph(g), cfg, reads)
+
+
 def test_unknown_pipeline_is_an_error():
     g, _ = make_world(3, 9, genome_len=300, n_reads=0)
     A = aligner.Aligner(gpu_graph(g), capi.config_cli(9))
