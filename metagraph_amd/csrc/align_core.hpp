@@ -220,6 +220,8 @@ struct Wave {
     uint64_t *bm[4];             // position bitmasks of the seeder: matched k-mers, MEM stops, lookup hits, seed slots
     int32_t inv_any[2];          // strand holds a character outside ACGT
     SdustScratch *sd_own;        // carve()'s own scratch in the seeding overlay (used when the kernel passes none)
+    uint8_t *dust_t;             // triplet code per position (maybe_low_complexity)
+    uint64_t *dust_eq;           // per position: which of the next 61 positions hold the same triplet
     const int8_t *sm_rows;       // score-matrix rows of the 6 possible path characters ($ACGT\\0) x 128, in LDS
     uint32_t *gen_store;         // conv-checker generation counters, persistent per arena slice
     ExtenderState ext[2];
@@ -255,6 +257,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 3 * align8((L + 1) * 4);                       // pos_start, rfirst, rlast
     b += align8(sizeof(SdustScratch));
     b += 2 * align8(((L + 15) / 16 + 2) * 4) + 4 * align8(((L + 63) / 64 + 1) * 8);   // pk, bm
+    b += align8((L + 8) * 8) + align8(L + 8);           // dust_eq, dust_t
     b += align8((uint64_t)lim.max_alt * 4);             // alt
     b += align8((uint64_t)lim.cell_words * 4);          // cells
     b += align8((uint64_t)lim.max_columns * sizeof(ColMeta));
@@ -303,6 +306,8 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.rlast = (uint32_t *)take_fast((L + 1) * 4);
     w.sd_own = (SdustScratch *)take_fast(sizeof(SdustScratch));
     for (int b = 0; b < 4; ++b) w.bm[b] = (uint64_t *)take_fast(((L + 63) / 64 + 1) * 8);
+    w.dust_eq = (uint64_t *)take_fast((L + 8) * 8);
+    w.dust_t = take_fast(L + 8);
     uint8_t *lp_seed_end = lp;
     uint32_t lleft_seed_end = lleft;
     lp = lp_mark;
@@ -357,7 +362,7 @@ MGX_HD uint32_t fast_lds_bytes(uint32_t Lmax) {
     uint64_t L = Lmax, Lp = align8(L + 8);
     uint64_t persistent = 2 * Lp + 2 * align8((L + 1) * 4) + 2 * 32 * 8 + 2 * align8(((L + 15) / 16 + 2) * 4);
     uint64_t seeding = 3 * align8((L + 1) * 2) + align8(L + 1) + 3 * align8((L + 1) * 4) + align8(sizeof(SdustScratch))
-                       + 4 * align8(((L + 63) / 64 + 1) * 8);
+                       + 4 * align8(((L + 63) / 64 + 1) * 8) + align8((L + 8) * 8) + align8(L + 8);
     uint64_t staging = 6 * align8((L + 16) * 4);
     return (uint32_t)(persistent + (seeding > staging ? seeding : staging));
 }
@@ -517,11 +522,82 @@ MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *
 #endif
 }
 
+// Lane-parallel, conservative companion of is_low_complexity(): returns false only if NO interval of at most 62
+// consecutive triplets anywhere in the strand reaches a DUST score above T (sum over triplets of c(c-1)/2 pairs,
+// times 10, greater than T times (number of triplets - 1): the test find_perfect applies, sdust.c).  Every interval
+// sdust can mask — on the whole strand or on any window of it — is such an interval, so `false` proves that no
+// window is low-complexity; `true` only means "run the exact algorithm".  One lane per end position instead of
+// sdust's serial state machine: per position a 61-bit mask of the following positions with the same triplet, then
+// r(start, end) accumulates popcounts while the start walks back.  Strands with a non-ACGT character are not judged
+// here (`true`).
+MGX_DEV bool maybe_low_complexity(Wave &w, int s) {
+    constexpr int32_t T = 20, SPAN = 61;
+    const int32_t L = w.L;
+    const uint8_t *q = w.q[s];
+    uint8_t *tc = w.dust_t;
+    uint64_t *eq = w.dust_eq;
+    uint64_t invalid = 0;
+    for (int32_t base = 0; base < L; base += WAVE) {
+        LV<bool> bad;
+        FOR_LANES(l) {
+            int32_t i = base + l;
+            bad[l] = false;
+            if (i < L) {
+                uint8_t t = 255;
+                if (i >= 2) {
+                    uint32_t a = encode_char(q[i - 2]), b = encode_char(q[i - 1]), c = encode_char(q[i]);
+                    if (a >= 1 && a <= 4 && b >= 1 && b <= 4 && c >= 1 && c <= 4) t = (uint8_t)(((a - 1) << 4) | ((b - 1) << 2) | (c - 1));
+                    else bad[l] = true;
+                }
+                tc[i] = t;
+            }
+        }
+        invalid |= wave_ballot(bad);
+    }
+    wave_sync();
+    // sdust keeps its triplet window across an invalid character (only the run length restarts), so intervals can
+    // span it with fewer triplets than positions: leave such strands to the exact algorithm
+    if (invalid) return true;
+    for (int32_t base = 0; base < L; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t p = base + l;
+            if (p < L) {
+                uint64_t m = 0;
+                const uint8_t t = tc[p];
+                if (t != 255)
+                    for (int32_t d = 1; d <= SPAN && p + d < L; ++d)
+                        if (tc[p + d] == t) m |= 1ull << (d - 1);
+                eq[p] = m;
+            }
+        }
+    }
+    wave_sync();
+    uint64_t any = 0;
+    for (int32_t base = 0; base < L; base += WAVE) {
+        LV<bool> hit;
+        FOR_LANES(l) {
+            int32_t e = base + l;
+            bool h = false;
+            if (e < L && tc[e] != 255) {
+                int32_t r = 0;
+                for (int32_t d = 1; d <= SPAN && e - d >= 0; ++d) {
+                    r += popc64(eq[e - d] & ((1ull << d) - 1));       // pairs (e - d, y) with y in (e - d, e]
+                    if (r * 10 > T * d) { h = true; break; }
+                }
+            }
+            hit[l] = h;
+        }
+        any |= wave_ballot(hit);
+    }
+    wave_sync();
+    return any != 0;
+}
+
 // Window test with an exact shortcut.  A window is flagged iff it contains an interval (<= 64 words) whose
 // DUST score exceeds T; any such interval also exists in the whole strand, so if sdust on the whole strand
 // masks nothing, no window can be flagged.  Only strands with a masked region pay the per-window runs.
 MGX_DEV bool window_low_complexity(Wave &w, int s, int32_t begin, int32_t len) {
-    if (w.lc_any[s] < 0) w.lc_any[s] = is_low_complexity(w.q[s], w.L, w.sd) ? 1 : 0;
+    if (w.lc_any[s] < 0) w.lc_any[s] = (maybe_low_complexity(w, s) && is_low_complexity(w.q[s], w.L, w.sd)) ? 1 : 0;
     if (!w.lc_any[s]) return false;
     return is_low_complexity(w.q[s] + begin, len, w.sd);
 }

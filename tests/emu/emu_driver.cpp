@@ -108,6 +108,18 @@ uint32_t emu_outgoing(void *h, uint64_t v, int rc, uint64_t *nodes, char *chars)
     for (int t = 0; t < n; ++t) { nodes[t] = nn[t]; chars[t] = rc ? (char)complement_char(decode_code(cc[t])) : (char)decode_code(cc[t]); }
     return (uint32_t)n;
 }
+// the lane-parallel conservative filter on a bare string (a Wave with just the fields it reads)
+int emu_maybe_low_complexity(const char *s, uint32_t len) {
+    auto w = std::make_unique<Wave>();
+    std::vector<uint8_t> q(len + 16, 0), tc(len + 16);
+    std::vector<uint64_t> eq(len + 16);
+    memcpy(q.data(), s, len);
+    w->L = (int32_t)len;
+    w->q[0] = q.data();
+    w->dust_t = tc.data();
+    w->dust_eq = eq.data();
+    return maybe_low_complexity(*w, 0);
+}
 int emu_is_low_complexity(const char *s, uint32_t len) {
     SdustScratch sd;
     return is_low_complexity((const uint8_t *)s, (int32_t)len, &sd);

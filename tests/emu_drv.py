@@ -32,6 +32,7 @@ def L():
         _L.emu_outgoing.restype = C.c_uint32
         _L.emu_outgoing.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_char_p]
         _L.emu_is_low_complexity.argtypes = [C.c_char_p, C.c_uint32]
+        _L.emu_maybe_low_complexity.argtypes = [C.c_char_p, C.c_uint32]
         _L.emu_align.restype = C.c_void_p
         _L.emu_align.argtypes = [C.c_void_p, C.POINTER(capi.Config), C.POINTER(capi.Limits), C.c_char_p,
                                  C.POINTER(C.c_uint64), C.c_uint64, C.c_int]

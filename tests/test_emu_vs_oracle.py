@@ -295,3 +295,43 @@ def test_sdust_whole_read_shortcut_is_sound():
             for i in range(0, len(s) - wl + 1):
                 assert not Lo.orc_is_low_complexity(b[i:i + wl], wl), (s, i, wl)
     assert n_clean > 100
+
+
+def test_lane_parallel_dust_filter_is_conservative():
+    """maybe_low_complexity() must never say "clean" for a strand in which sdust masks anything — on the whole strand or
+    on any window the seeder may test.  Checked against the oracle's sdust on random, repeat-rich, biased and
+    N-containing strings; the filter should also be tight (it rarely fires when sdust finds nothing)."""
+    rng = random.Random(23)
+    Lo, Le = orc.L(), emu_drv.L()
+    fired = exact = loose = 0
+    for t in range(1500):
+        mode = rng.random()
+        n = rng.choice([30, 64, 100, 150, 151, 250])
+        if mode < 0.35:
+            s = rand_seq(rng, n)
+        elif mode < 0.7:
+            unit = rand_seq(rng, rng.randrange(1, 9))
+            rep = (unit * 40)[:rng.randrange(5, 40)]
+            p = rng.randrange(0, max(1, n - len(rep)))
+            s = (rand_seq(rng, p) + rep + rand_seq(rng, n))[:n]
+        elif mode < 0.85:
+            s = "".join(rng.choice("AAAAACGT") for _ in range(n))
+        else:
+            s = "".join(rng.choice("ACACACGT") for _ in range(n))
+        if rng.random() < 0.25:
+            p = rng.randrange(0, n)
+            s = s[:p] + "N" + s[p + 1:]
+        b = s.encode()
+        maybe = bool(Le.emu_maybe_low_complexity(b, len(b)))
+        whole = bool(Lo.orc_is_low_complexity(b, len(b)))
+        fired += maybe
+        exact += whole
+        if "N" not in s:
+            loose += maybe and not whole           # (strands with N are always handed to the exact algorithm)
+        if not maybe:
+            assert not whole, s
+            for wl in (12, 19, 31):
+                for i in range(0, len(s) - wl + 1, 3):
+                    assert not Lo.orc_is_low_complexity(b[i:i + wl], wl), (s, i, wl)
+    assert exact > 100 and fired < 1400
+    assert loose <= 25, (fired, exact, loose)
