@@ -605,7 +605,7 @@ MGX_DEV bool window_low_complexity(Wave &w, int s, int32_t begin, int32_t len) {
 // ------------------------------------------------------------------------------------------------
 // query preparation: AlignmentResults ctor (A/alignment.cpp:1348-1372) + partial sums
 // ------------------------------------------------------------------------------------------------
-MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding) {
+MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding, bool for_extension) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     const int32_t L = w.L;
@@ -621,8 +621,8 @@ MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding) {
         }
     }
     wave_sync();
-    // partial_sums_[i] = sum_{j >= i} score(q[j], q[j]); partial_sums_[L] = 0
-    for (int s = 0; s < 2; ++s) {
+    // partial_sums_[i] = sum_{j >= i} score(q[j], q[j]); partial_sums_[L] = 0 (seed scores and the extender only)
+    for (int s = 0; for_extension && s < 2; ++s) {
         int32_t carry = 0;
         int32_t nchunks = (L + WAVE - 1) / WAVE;
         for (int32_t ch = nchunks - 1; ch >= 0; --ch) {
@@ -2348,7 +2348,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     if (w.L > (int32_t)P.lim.Lmax) {
         w.status = ST_CAPACITY;
     } else {
-        prepare_query(w, P.seqs + off, (PHASE & PH_SEED) != 0);
+        prepare_query(w, P.seqs + off, (PHASE & PH_SEED) != 0, (PHASE & PH_EXTEND) != 0);
         w.lc_any[0] = w.lc_any[1] = -1;
         w.cyc[0] = cycle_clock() - tstart;
         for (int s = 0; s < 2; ++s) {
