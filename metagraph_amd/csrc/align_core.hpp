@@ -179,7 +179,10 @@ struct Tier { int32_t *lo, *hi; };
 MGX_DEV int32_t tget(const Tier &t, int32_t cap, int32_t j) { return *(j < cap ? t.lo + j : t.hi + j); }
 MGX_DEV void tset(const Tier &t, int32_t cap, int32_t j, int32_t v) { *(j < cap ? t.lo + j : t.hi + j) = v; }
 struct Staging { Tier S, F; int32_t col; };
-constexpr int32_t LQ_CAP = 32;       // frontier entries kept in LDS; the rest spill to the arena
+#ifndef MGX_LQ_CAP
+#define MGX_LQ_CAP 8        // measured on the 8-lane extension kernel: 32 -> 8 frees LDS for the staging tier (st_cap 44 -> 64), -12 %
+#endif
+constexpr int32_t LQ_CAP = MGX_LQ_CAP;       // frontier entries kept in LDS; the rest spill to the arena
 
 struct Wave {
     const AlignParams *P;
