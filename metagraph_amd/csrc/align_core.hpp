@@ -160,6 +160,7 @@ struct SeedRef {
 struct ExtenderState {           // one per strand (Extender object in dbg_aligner.cpp:287,292)
     const uint8_t *q;            // normalized query of this strand
     const int32_t *psum;         // partial_sums_ (aligner_extender_methods.cpp:26-36)
+    int32_t psum_lin;            // > 0: the strand is pure ACGT with one self-score m, so psum[x] == (L - x) * m exactly; else 0
     ConvChecker conv;
     uint32_t table_cap;          // capacity of the reference's std::vector<DPTColumn>
     int32_t rc_view;             // 1 while this extender runs on the RCDBG view
@@ -222,6 +223,7 @@ struct Wave {
     uint32_t *pk[2];             // 2-bit packed strands (16 codes per word, first char least significant)
     uint64_t *bm[4];             // position bitmasks of the seeder: matched k-mers, MEM stops, lookup hits, seed slots
     int32_t inv_any[2];          // strand holds a character outside ACGT
+    int32_t psum_lin[2];         // see ExtenderState::psum_lin
     SdustScratch *sd_own;        // carve()'s own scratch in the seeding overlay (used when the kernel passes none)
     uint8_t *dust_t;             // triplet code per position (maybe_low_complexity)
     uint64_t *dust_eq;           // per position: which of the next 61 positions hold the same triplet
@@ -608,6 +610,28 @@ MGX_DEV bool window_low_complexity(Wave &w, int s, int32_t begin, int32_t len) {
 // ------------------------------------------------------------------------------------------------
 // query preparation: AlignmentResults ctor (A/alignment.cpp:1348-1372) + partial sums
 // ------------------------------------------------------------------------------------------------
+// Linear partial sums: if every character of a strand is in ACGT and score(A,A) == score(C,C) == score(G,G) ==
+// score(T,T) == m > 0, then partial_sums_[x] == (L - x) * m exactly and the extender's per-cell test needs no table.
+MGX_DEV void detect_linear_psum(Wave &w) {
+    const AlignParams &P = *w.P;
+    const int32_t L = w.L;
+    const int32_t mA = score_of(P, 'A', 'A');
+    const bool same = mA > 0 && score_of(P, 'C', 'C') == mA && score_of(P, 'G', 'G') == mA && score_of(P, 'T', 'T') == mA;
+    for (int s = 0; s < 2; ++s) {
+        uint64_t other = 0;
+        for (int32_t base = 0; same && base < L; base += WAVE) {
+            LV<bool> bad;
+            FOR_LANES(l) {
+                int32_t j = base + l;
+                bad[l] = false;
+                if (j < L) { uint8_t c = w.q[s][j]; bad[l] = !(c == 'A' || c == 'C' || c == 'G' || c == 'T'); }
+            }
+            other |= wave_ballot(bad);
+        }
+        w.psum_lin[s] = (same && !other) ? mA : 0;
+    }
+}
+
 MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding, bool for_extension) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
@@ -1561,6 +1585,8 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     const int32_t start = uni(seed.clipping);
     const int32_t window_size = uni(w.L) - start;             // trim_query_suffix == 0
     const int32_t *psum = (const int32_t *)uni((uint64_t)E.psum);
+    const int32_t psum_lin = uni(E.psum_lin);
+    const int32_t qlen = uni(w.L);
     const int32_t partial_sum_offset = uni(psum[start + window_size]);
     const int32_t seed_offset = uni(seed.offset) - 1;
     const int32_t seed_off = uni(seed.offset), seed_seq_len = uni(seed.seq_len);
@@ -1720,7 +1746,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                         int32_t v = j < size ? tget(cS, cap, j) : INT32_MIN;
                         sv[l] = v;
                         mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
-                        ext[l] = j < size && v + psum[start + begin + j] >= extension_cutoff;
+                        ext[l] = j < size && v + (psum_lin ? (qlen - (start + begin + j)) * psum_lin : psum[start + begin + j]) >= extension_cutoff;
                     }
                     min_cell_score = imin(min_cell_score, wave_min(mn));
                     if (wave_ballot(ext)) has_extension = true;
@@ -2352,11 +2378,13 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         w.status = ST_CAPACITY;
     } else {
         prepare_query(w, P.seqs + off, (PHASE & PH_SEED) != 0, (PHASE & PH_EXTEND) != 0);
+        if constexpr (PHASE & PH_EXTEND) detect_linear_psum(w);
         w.lc_any[0] = w.lc_any[1] = -1;
         w.cyc[0] = cycle_clock() - tstart;
         for (int s = 0; s < 2; ++s) {
             w.ext[s].q = w.q[s];
             w.ext[s].psum = w.psum[s];
+            w.ext[s].psum_lin = (PHASE & PH_EXTEND) ? w.psum_lin[s] : 0;
             w.ext[s].table_cap = 0;
             w.ext[s].rc_view = 0;
             w.ext[s].conv.n_entries = 0;
