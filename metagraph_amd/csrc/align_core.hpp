@@ -1856,6 +1856,17 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
     // because the heap pops by the full (unique) tuple
     // tips as a bitset (prev_starts is cleared per extension and only used from here on; use a second region)
     int32_t n_idx = 0;
+    // every lane also keeps the lexicographic maximum (score, -off_diag, -i, pos) of the candidates it wrote and where it
+    // wrote it: the first pop of the heap — usually the only one — then needs no pass over the list in memory
+    LV<BtIndex> lbest;
+    LV<int32_t> lbest_at;
+    FOR_LANES(l) { lbest[l] = BtIndex{ INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN }; lbest_at[l] = -1; }
+    auto bt_greater = [](const BtIndex &a, const BtIndex &b) {
+        if (a.score != b.score) return a.score > b.score;
+        if (a.neg_off_diag != b.neg_off_diag) return a.neg_off_diag > b.neg_off_diag;
+        if (a.neg_i != b.neg_i) return a.neg_i > b.neg_i;
+        return a.pos > b.pos;
+    };
     for (int32_t base = 1; base < tsize; base += WAVE) {
         LV<int32_t> cnt;
         LV<BtIndex> c0, c1;
@@ -1899,10 +1910,36 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
         }
         LV<int32_t> off = wave_prefix_sum_excl(cnt);
         FOR_LANES(l) {
-            if (cnt[l] > 0) w.indices[n_idx + off[l]] = c0[l];
-            if (cnt[l] > 1) w.indices[n_idx + off[l] + 1] = c1[l];
+            if (cnt[l] > 0) {
+                w.indices[n_idx + off[l]] = c0[l];
+                if (lbest_at[l] < 0 || bt_greater(c0[l], lbest[l])) { lbest[l] = c0[l]; lbest_at[l] = n_idx + off[l]; }
+            }
+            if (cnt[l] > 1) {
+                w.indices[n_idx + off[l] + 1] = c1[l];
+                if (bt_greater(c1[l], lbest[l])) { lbest[l] = c1[l]; lbest_at[l] = n_idx + off[l] + 1; }
+            }
         }
         n_idx += wave_sum(cnt);
+    }
+    // wave-level maximum of the lanes' maxima (registers only)
+    int32_t first_bi = -1;
+    if (n_idx > 0) {
+        LV<int32_t> v;
+        FOR_LANES(l) { v[l] = lbest_at[l] >= 0 ? lbest[l].score : INT32_MIN; }
+        const int32_t m_score = wave_max(v);
+        FOR_LANES(l) { v[l] = (lbest_at[l] >= 0 && lbest[l].score == m_score) ? lbest[l].neg_off_diag : INT32_MIN; }
+        const int32_t m_off = wave_max(v);
+        FOR_LANES(l) { v[l] = (lbest_at[l] >= 0 && lbest[l].score == m_score && lbest[l].neg_off_diag == m_off) ? lbest[l].neg_i : INT32_MIN; }
+        const int32_t m_i = wave_max(v);
+        FOR_LANES(l) {
+            v[l] = (lbest_at[l] >= 0 && lbest[l].score == m_score && lbest[l].neg_off_diag == m_off && lbest[l].neg_i == m_i) ? lbest[l].pos : INT32_MIN;
+        }
+        const int32_t m_pos = wave_max(v);
+        LV<bool> hit;
+        FOR_LANES(l) {
+            hit[l] = lbest_at[l] >= 0 && lbest[l].score == m_score && lbest[l].neg_off_diag == m_off && lbest[l].neg_i == m_i && lbest[l].pos == m_pos;
+        }
+        first_bi = wave_bcast(lbest_at, ctz64(wave_ballot(hit)));
     }
     wave_sync();
     bool produced = false;
@@ -1911,7 +1948,10 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
     while (remaining > 0 && !produced) {        // terminate_backtrack_start: num_alternative_paths == 1
         // pop the lexicographic maximum (score, -off_diag, -i, pos) (:873-879): four lane-parallel passes
         int32_t bi = 0;
-        {
+        if (first_bi >= 0) {
+            bi = first_bi;
+            first_bi = -1;
+        } else {
             int32_t m_score = INT32_MIN, m_off = INT32_MIN, m_i = INT32_MIN, m_pos = INT32_MIN;
             for (int pass = 0; pass < 4; ++pass) {
                 int32_t best = INT32_MIN;
