@@ -648,8 +648,10 @@ MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding, bool fo
         }
     }
     wave_sync();
+    if (for_extension) detect_linear_psum(w); else { w.psum_lin[0] = w.psum_lin[1] = 0; }
     // partial_sums_[i] = sum_{j >= i} score(q[j], q[j]); partial_sums_[L] = 0 (seed scores and the extender only)
     for (int s = 0; for_extension && s < 2; ++s) {
+        if (w.psum_lin[s]) continue;                       // (L - x) * m: no table needed
         int32_t carry = 0;
         int32_t nchunks = (L + WAVE - 1) / WAVE;
         for (int32_t ch = nchunks - 1; ch >= 0; --ch) {
@@ -1587,7 +1589,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     const int32_t *psum = (const int32_t *)uni((uint64_t)E.psum);
     const int32_t psum_lin = uni(E.psum_lin);
     const int32_t qlen = uni(w.L);
-    const int32_t partial_sum_offset = uni(psum[start + window_size]);
+    const int32_t partial_sum_offset = psum_lin ? (qlen - (start + window_size)) * psum_lin : uni(psum[start + window_size]);
     const int32_t seed_offset = uni(seed.offset) - 1;
     const int32_t seed_off = uni(seed.offset), seed_seq_len = uni(seed.seq_len);
     uint32_t cell_top = 0;
@@ -2252,7 +2254,8 @@ MGX_DEV SeedRef seedref_from_seed(const Wave &w, int s, int32_t idx, int32_t *su
     if (sd.offset == 0 && sd.n_nodes == 1) r.nodes = w.nodes[s] + sd.clipping;
     r.orientation = s;
     // Alignment(const Seed&, config) score (alignment.hpp:160-161)
-    int32_t ms = w.psum[s][sd.clipping] - w.psum[s][sd.clipping + sd.length];
+    int32_t ms = w.psum_lin[s] ? (int32_t)sd.length * w.psum_lin[s]
+                               : w.psum[s][sd.clipping] - w.psum[s][sd.clipping + sd.length];
     r.score = ms + (!sd.clipping ? cfg.left_end_bonus : 0) + (!r.end_clipping ? cfg.right_end_bonus : 0);
     (void)sub_node_slot;
     return r;
@@ -2418,7 +2421,6 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         w.status = ST_CAPACITY;
     } else {
         prepare_query(w, P.seqs + off, (PHASE & PH_SEED) != 0, (PHASE & PH_EXTEND) != 0);
-        if constexpr (PHASE & PH_EXTEND) detect_linear_psum(w);
         w.lc_any[0] = w.lc_any[1] = -1;
         w.cyc[0] = cycle_clock() - tstart;
         for (int s = 0; s < 2; ++s) {
