@@ -234,6 +234,31 @@ def test_sub_k_seeding_variants(min_seed, per_locus):
     compare_full(g, emu_drv.EmuGraph(g), cfg, reads)
 
 
+def noisy_reads(seed, g_reads):
+    """reads with N's, lower case and a few non-nucleotide bytes sprinkled in (AlignmentResults upper-cases and keeps
+    the rest; KmerExtractorBOSS::encode maps everything else to the invalid code)"""
+    rng = random.Random(seed)
+    out = []
+    for r in g_reads:
+        r = list(r)
+        for _ in range(rng.randrange(0, 4)):
+            r[rng.randrange(len(r))] = rng.choice("NNNnXx-")
+        if rng.random() < 0.5:
+            a = rng.randrange(len(r))
+            b = min(len(r), a + rng.randrange(1, 30))
+            r[a:b] = [c.lower() for c in r[a:b]]
+        out.append("".join(r))
+    return out
+
+
+@pytest.mark.parametrize("k", [15, 31])
+def test_reads_with_invalid_and_lower_case_characters(k):
+    g, reads = make_world(520 + k, k, n_reads=40, read_len=120)
+    cfg = capi.config_cli(k)
+    cfg.min_exact_match = 0.0
+    compare_full(g, emu_drv.EmuGraph(g), cfg, noisy_reads(5, reads))
+
+
 def test_align_cli_config_no_min_exact_match():
     g, reads = make_world(200, 15, n_reads=60)
     eg = emu_drv.EmuGraph(g)

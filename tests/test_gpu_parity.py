@@ -160,6 +160,15 @@ def test_sub_k_seeding_variants_on_gpu(min_seed, per_locus):
     compare_gpu(g, gpu_graph(g), cfg, reads)
 
 
+@pytest.mark.parametrize("k", [15, 31])
+def test_reads_with_invalid_and_lower_case_characters_on_gpu(k):
+    from test_emu_vs_oracle import noisy_reads
+    g, reads = make_world(520 + k, k, n_reads=40, read_len=120)
+    cfg = capi.config_cli(k)
+    cfg.min_exact_match = 0.0
+    compare_gpu(g, gpu_graph(g), cfg, noisy_reads(5, reads))
+
+
 def test_unknown_pipeline_is_an_error():
     g, _ = make_world(3, 9, genome_len=300, n_reads=0)
     A = aligner.Aligner(gpu_graph(g), capi.config_cli(9))
