@@ -322,8 +322,9 @@ MGX_DEV bool tighten_range(const DevGraph &g, uint64_t *rl, uint64_t *ru, uint32
 // in 1..4.  Key = first char least significant, exactly the reference's co-lex index.
 MGX_DEV void prefix_range(const DevGraph &g, uint32_t key, uint64_t *rl, uint64_t *ru, LineCtr &ctr) {
     ++ctr.bit_lines;
-    uint2 r = g.prefix_tbl[key];
-    *rl = r.x; *ru = r.y;
+    // the table is far larger than any cache and every entry is read once per lookup: stream it past the caches
+    const uint64_t r = gld_stream_u64(g.prefix_tbl + key);
+    *rl = (uint32_t)r; *ru = (uint32_t)(r >> 32);
 }
 
 MGX_DEV void initial_range(const DevGraph &g, uint32_t s, uint64_t *rl, uint64_t *ru) {   // boss.hpp:665-677

@@ -197,7 +197,7 @@ MGX_DEV void map_lane_step(const DevGraph &g, MapLane &m, LineCtr &ctr, FetchCha
         const int32_t i = m.i;
         for (; m.scanned < i + k; ++m.scanned)
             if (strand_code(m.seq, m.L, m.strand, m.scanned) == 5) m.last_invalid = m.scanned;
-        if (m.last_invalid >= i) { m.out[i] = 0; m.edge = 0; ++m.i; return; }
+        if (m.last_invalid >= i) { gst_stream(m.out + i, 0); m.edge = 0; ++m.i; return; }
         if (m.edge) {
             // edge = fwd(edge, seq[i + k - 2]); edge = pick_edge(edge, seq[i + k - 1])
             uint32_t c_prev = strand_code(m.seq, m.L, m.strand, i + k - 2);
@@ -205,7 +205,7 @@ MGX_DEV void map_lane_step(const DevGraph &g, MapLane &m, LineCtr &ctr, FetchCha
             uint64_t lst = fwd_from(g, m.edge, m.blk, c_prev, tgt, ctr);
             m.blk = tgt;
             m.edge = lst ? pick_edge_from(g, lst, m.blk, strand_code(m.seq, m.L, m.strand, i + k - 1), ctr) : 0;
-            m.out[i] = in_graph(g, m.edge) ? (uint32_t)m.edge : 0;
+            gst_stream(m.out + i, in_graph(g, m.edge) ? (uint32_t)m.edge : 0);
             ++m.i;
             return;
         }
@@ -220,8 +220,8 @@ MGX_DEV void map_lane_step(const DevGraph &g, MapLane &m, LineCtr &ctr, FetchCha
             initial_range(g, strand_code(m.seq, m.L, m.strand, i), &m.rl, &m.ru);
         }
         if (m.rl > m.ru) {
-            if (m.out_len && t0 > 1 && k - 1 < MLEN_LT_PREFIX) m.out_len[i] = MLEN_LT_PREFIX;
-            m.out[i] = 0; m.edge = 0; ++m.i;
+            if (m.out_len && t0 > 1 && k - 1 < MLEN_LT_PREFIX) gst_stream(m.out_len + i, MLEN_LT_PREFIX);
+            gst_stream(m.out + i, 0); m.edge = 0; ++m.i;
             return;
         }
         m.t = t0;
@@ -233,10 +233,10 @@ MGX_DEV void map_lane_step(const DevGraph &g, MapLane &m, LineCtr &ctr, FetchCha
     if (m.t < k - 1) {
         if (!tighten_range(g, &m.rl, &m.ru, strand_code(m.seq, m.L, m.strand, i + m.t), ctr)) {
             if (m.out_len && k - 1 < MLEN_LT_PREFIX) {
-                m.out_len[i] = (uint8_t)m.t;
+                gst_stream(m.out_len + i, (uint8_t)m.t);
                 if (m.out_rng && m.t >= m.min_rng_len) m.out_rng[i] = make_uint2((uint32_t)m.rl, (uint32_t)m.ru);
             }
-            m.out[i] = 0; m.edge = 0; ++m.i; m.state = 1;
+            gst_stream(m.out + i, 0); m.edge = 0; ++m.i; m.state = 1;
             return;
         }
         ++m.t;
@@ -245,9 +245,9 @@ MGX_DEV void map_lane_step(const DevGraph &g, MapLane &m, LineCtr &ctr, FetchCha
     ++ctr.rank_lines;
     m.blk = load_block(g, (uint32_t)(m.ru >> 6));
     m.edge = pick_edge_from(g, m.ru, m.blk, strand_code(m.seq, m.L, m.strand, i + k - 1), ctr);
-    m.out[i] = in_graph(g, m.edge) ? (uint32_t)m.edge : 0;
+    gst_stream(m.out + i, in_graph(g, m.edge) ? (uint32_t)m.edge : 0);
     if (!m.edge && m.out_len && k - 1 < MLEN_LT_PREFIX) {
-        m.out_len[i] = (uint8_t)(k - 1);
+        gst_stream(m.out_len + i, (uint8_t)(k - 1));
         if (m.out_rng && k - 1 >= m.min_rng_len) m.out_rng[i] = make_uint2((uint32_t)m.rl, (uint32_t)m.ru);
     }
     ++m.i;

@@ -189,6 +189,29 @@ struct RegTab64 {
 #endif
 template <class T> MGX_DEV T gld(const T *p) { return *MGX_AS_GLOBAL(const T, p); }
 template <class T, class V> MGX_DEV void gst(T *p, V v) { *MGX_AS_GLOBAL(T, p) = (T)v; }
+// one-shot 8-byte load that should not displace reusable lines (graph blocks, hints) from L2 / Infinity Cache
+// write-once / read-once scalars of the batch streams (node ids, match lengths, ranges): nontemporal
+template <class T, class V> MGX_DEV void gst_stream(T *p, V v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store((T)v, (__attribute__((address_space(1))) T *)p);
+#else
+    *p = (T)v;
+#endif
+}
+template <class T> MGX_DEV T gld_stream(const T *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) T *)p);
+#else
+    return *p;
+#endif
+}
+MGX_DEV uint64_t gld_stream_u64(const void *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load((const __attribute__((address_space(1))) unsigned long long *)p);
+#else
+    return *(const unsigned long long *)p;
+#endif
+}
 
 MGX_DEV uint64_t cycle_clock() { return __builtin_readcyclecounter(); }
 MGX_DEV int popc64(uint64_t x) { return __popcll(x); }

@@ -124,6 +124,9 @@ struct RegTab64 {
 // host model of wave.hpp's global-memory accessors
 template <class T> inline T gld(const T *p) { return *p; }
 template <class T, class V> inline void gst(T *p, V v) { *p = (T)v; }
+template <class T, class V> inline void gst_stream(T *p, V v) { *p = (T)v; }
+template <class T> inline T gld_stream(const T *p) { return *p; }
+inline uint64_t gld_stream_u64(const void *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
 inline uint64_t cycle_clock() { return 0; }
 inline int popc64(uint64_t x) { return __builtin_popcountll(x); }
