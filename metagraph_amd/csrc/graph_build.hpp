@@ -106,61 +106,13 @@ MGX_DEV uint32_t strand_code(const char *seq, int32_t L, int strand, int32_t pos
     return c == 5 ? 5u : 5u - c;                 // complement: A<->T, C<->G (kBOSSComplementMapDNA)
 }
 
-MGX_DEV void map_chain(const DevGraph &g, const char *seq, int32_t L, int strand, uint32_t *out, LineCtr &ctr) {
-    const int32_t k = (int32_t)g.k;
-    const int32_t n_kmers = L - k + 1;
-    if (n_kmers <= 0) return;
-    int32_t last_invalid = -1;                   // position of the most recent invalid code seen
-    int32_t scanned = 0;                         // codes [0, scanned) have been inspected
-    uint64_t edge = 0;                           // BOSS edge of the previous k-mer (0 = must re-index)
-    Block blk;                                   // block of `edge`
-    for (int32_t i = 0; i < n_kmers; ++i) {
-        for (; scanned < i + k; ++scanned)
-            if (strand_code(seq, L, strand, scanned) == 5) last_invalid = scanned;
-        if (last_invalid >= i) { out[i] = 0; edge = 0; continue; }
-        if (edge) {
-            // edge = fwd(edge, seq[i + k - 2]); edge = pick_edge(edge, seq[i + k - 1])
-            uint32_t c_prev = strand_code(seq, L, strand, i + k - 2);
-            Block tgt;
-            uint64_t lst = fwd_from(g, edge, blk, c_prev, tgt, ctr);
-            blk = tgt;
-            edge = lst ? pick_edge_from(g, lst, blk, strand_code(seq, L, strand, i + k - 1), ctr) : 0;
-        } else {
-            // map_to_edge: index(k - 1 codes) then pick_edge (boss.hpp:696-718,766-777)
-            uint64_t rl, ru;
-            int32_t t0 = 1;
-            if (g.prefix_len && (int32_t)g.prefix_len <= k - 1) {
-                uint32_t key = 0;
-                for (uint32_t j = 0; j < g.prefix_len; ++j) key |= (strand_code(seq, L, strand, i + (int32_t)j) - 1) << (2 * j);
-                prefix_range(g, key, &rl, &ru, ctr);
-                t0 = (int32_t)g.prefix_len;
-            } else {
-                initial_range(g, strand_code(seq, L, strand, i), &rl, &ru);
-            }
-            bool ok = rl <= ru;
-            for (int32_t t = t0; ok && t < k - 1; ++t)
-                ok = tighten_range(g, &rl, &ru, strand_code(seq, L, strand, i + t), ctr);
-            if (ok) {
-                ++ctr.rank_lines;
-                blk = load_block(g, (uint32_t)(ru >> 6));
-                edge = pick_edge_from(g, ru, blk, strand_code(seq, L, strand, i + k - 1), ctr);
-            } else {
-                edge = 0;
-            }
-        }
-        out[i] = in_graph(g, edge) ? (uint32_t)edge : 0;          // validate_edge (dbg_succinct.cpp:937-939)
-        if (edge && ((edge >> 6) != 0 || true)) {
-            // keep blk == block of edge (pick_edge_from leaves it there)
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// map_chain as a per-lane state machine.  A lane owns one (read, strand) chain at a time and fetches the next
+// BOSS::map_to_edges as a per-lane state machine.  A lane owns one (read, strand) chain at a time and fetches the next
 // one from `cursor` as soon as its chain ends; every loop iteration performs at most ONE memory-dependent step
 // (a walk step fwd+pick_edge, the suffix-range table lookup, or one tighten_range), so lanes whose chain
 // fails early (the non-matching strand) do not idle while their neighbours walk 120 k-mers.
-// Results are identical to map_chain (same primitives in the same order per chain).
+// Per chain the primitives run in the reference's order: index() (table + tighten_range) at a start or after a miss,
+// then fwd + pick_edge per base (boss.cpp:996-1045).
 // ------------------------------------------------------------------------------------------------
 // what index() learned at a position where it found no node: 0..k-1 = characters matched before tighten_range
 // failed (k-1: only pick_edge failed), MLEN_LT_PREFIX = the suffix-range table had no entry (match shorter than
