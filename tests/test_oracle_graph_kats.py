@@ -78,3 +78,57 @@ def test_boss_map_to_edges(kb):
     expected = [0, 0, kb + 2, kb + 2, kb + 2] + [kb + 2 + i for i in range(1, kb + 1)] + [kb + 2 + kb + 1] * kb
     got = orc.AlignRun(g, capi.config_cli(k), [seq]).mapping()[0][0]
     assert got == [e - kb if e else 0 for e in expected]
+
+
+# ---- node degrees (M/tests/graph/all/test_dbg_node_degree.cpp, DBGSuccinct instantiation: build_graph masks the
+# dummy k-mers, test_dbg_helpers.cpp:379).  outdegree / indegree are counted through the traversal functions the
+# aligner uses (call_outgoing_kmers, RCDBG's call_outgoing_kmers == incoming), and has_multiple_outgoing /
+# has_single_incoming — the UniMEM terminus test of the seeder — must agree with them (check_degree_functions :48-80).
+def _node(g, kmer):
+    nodes, ml = g.suffix_match(kmer, len(kmer))
+    assert ml == len(kmer) and len(nodes) == 1, kmer
+    return nodes[0]
+
+
+def _degrees(g, v):
+    return len(g.outgoing(v)), len(g.outgoing(v, rc=True))
+
+
+def _check_degree_functions(g):
+    W, last, F, valid = g.export()
+    for v in range(1, len(W)):
+        if valid is not None and not valid[v]:
+            continue
+        outd, ind = _degrees(g, v)
+        assert bool(orc.L().orc_graph_has_multiple_outgoing(g.h, v)) == (outd > 1), v
+        assert bool(orc.L().orc_graph_has_single_incoming(g.h, v)) == (ind == 1), v
+
+
+@pytest.mark.parametrize("k", range(2, 10))
+def test_node_degree_kats(k):
+    g = orc.Graph.build(k, ["A" * (k - 1) + "C"], 0, True)                      # get_outdegree/indegree_single_node :18-24,105-114
+    assert g.num_nodes == 1 and _degrees(g, _node(g, "A" * (k - 1) + "C")) == (0, 0)
+    _check_degree_functions(g)
+    g = orc.Graph.build(k, ["A" * (k - 1) + c for c in "ACGT"], 0, True)        # get_maximum_outdegree :26-46
+    assert g.num_nodes == 4
+    for c in "ACGT":
+        assert _degrees(g, _node(g, "A" * (k - 1) + c))[0] == (4 if c == "A" else 0)
+    g = orc.Graph.build(k, [c + "A" * (k - 1) for c in "ACGT"], 0, True)        # get_maximum_indegree :116-138
+    assert g.num_nodes == 4
+    for c in "ACGT":
+        assert _degrees(g, _node(g, c + "A" * (k - 1)))[1] == (4 if c == "A" else 0)
+    _check_degree_functions(g)
+    g = orc.Graph.build(k, ["A" * k + "C" * (k - 1) + "G" * (k - 1) + "T" * k], 0, True)        # get_degree1 :179-201
+    assert _degrees(g, _node(g, "A" * k)) == (2, 1) and _degrees(g, _node(g, "T" * k)) == (1, 2)
+    _check_degree_functions(g)
+    g = orc.Graph.build(k, ["A" * k + "C" * (k - 1) + "G" * (k - 1) + "T" * (k - 1)], 0, True)  # get_degree2 :203-225
+    assert _degrees(g, _node(g, "A" * k)) == (2, 1) and _degrees(g, _node(g, "G" + "T" * (k - 1))) == (0, 1)
+    _check_degree_functions(g)
+
+
+def test_node_degree_indegree1():
+    g = orc.Graph.build(3, ["ACTAAGCCC", "AAAGC", "TAAGCA"], 0, True)           # indegree1 :164-177
+    assert g.num_nodes == 9
+    assert _degrees(g, _node(g, "CCC")) == (1, 2)
+    assert _degrees(g, _node(g, "AAA")) == (2, 2)
+    _check_degree_functions(g)
