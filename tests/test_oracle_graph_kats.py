@@ -132,3 +132,48 @@ def test_node_degree_indegree1():
     assert _degrees(g, _node(g, "CCC")) == (1, 2)
     assert _degrees(g, _node(g, "AAA")) == (2, 2)
     _check_degree_functions(g)
+
+
+# ---- call_outgoing_kmers / call_incoming_kmers (M/tests/graph/all/test_dbg_traverse.cpp:106-298): the characters
+# reported for each node, and that the reported neighbour spells node[1:] + c (resp. c + node[:-1]).  The incoming side
+# is read through the RC view the aligner uses (rc_dbg.hpp:88-99 complements the first character).
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def _out_chars(g, v):
+    seq = g.node_sequence(v)
+    res = g.outgoing(v)
+    for n, c in res:
+        assert g.node_sequence(n) == seq[1:] + c
+    return sorted(c for _, c in res)
+
+
+def _in_chars(g, v):
+    seq = g.node_sequence(v)
+    res = [(n, COMP[c]) for n, c in g.outgoing(v, rc=True)]
+    for n, c in res:
+        assert g.node_sequence(n) == c + seq[:-1]
+    return sorted(c for _, c in res)
+
+
+@pytest.mark.parametrize("k", range(3, 11))
+def test_call_outgoing_edges(k):
+    g = orc.Graph.build(k, ["A" * 100 + "C" * 100 + "G" * (k - 1)], 0, True)
+    assert _out_chars(g, _node(g, "A" * k)) == ["A", "C"]
+    assert _out_chars(g, _node(g, "A" * (k - 1) + "C")) == ["C"]
+    assert _out_chars(g, _node(g, "C" * k)) == ["C", "G"]
+    assert _out_chars(g, _node(g, "C" * (k - 1) + "G")) == ["G"]
+    assert _out_chars(g, _node(g, "C" + "G" * (k - 1))) == []
+    assert g.suffix_match("G" * k, k)[0] == []                       # GGG does not exist
+
+
+@pytest.mark.parametrize("k", range(3, 11))
+def test_call_incoming_edges(k):
+    g = orc.Graph.build(k, ["A" * (k - 1) + "C" * 100 + "G" * (k - 1)], 0, True)
+    assert g.suffix_match("G" * k, k)[0] == []
+    assert _in_chars(g, _node(g, "C" + "G" * (k - 1))) == ["C"]
+    assert _in_chars(g, _node(g, "C" * (k - 1) + "G")) == ["A", "C"]
+    assert _in_chars(g, _node(g, "C" * k)) == ["A", "C"]
+    assert _in_chars(g, _node(g, "A" + "C" * (k - 1))) == ["A"]
+    assert _in_chars(g, _node(g, "A" * (k - 1) + "C")) == []
+    assert g.suffix_match("A" * k, k)[0] == []
