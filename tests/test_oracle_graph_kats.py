@@ -177,3 +177,19 @@ def test_call_incoming_edges(k):
     assert _in_chars(g, _node(g, "A" + "C" * (k - 1))) == ["A"]
     assert _in_chars(g, _node(g, "A" * (k - 1) + "C")) == []
     assert g.suffix_match("A" * k, k)[0] == []
+
+
+@pytest.mark.parametrize("k", range(2, 11))
+def test_map_to_nodes_whole_sequence_equals_per_kmer(k):
+    """DeBruijnGraphTest.map_to_nodes (M/tests/graph/all/test_dbg_search.cpp:101-133): mapping a sequence with misses at
+    its start equals mapping every k-mer on its own (the incremental fwd + pick_edge walk and the re-index after a miss
+    agree with index() from scratch)."""
+    from metagraph_amd import capi
+    g = orc.Graph.build(k, ["A" * 100 + "C" * 100], 0, True)
+    seq = "T" * 2 + "A" * (k + 2) + "C" * (2 * (k - 1))
+    cfg = capi.config_cli(k)
+    whole = orc.AlignRun(g, cfg, [seq]).mapping()[0][0]
+    kmers = [seq[i:i + k] for i in range(len(seq) - k + 1)]
+    single = [m[0][0] for m in orc.AlignRun(g, cfg, kmers).mapping()]
+    assert whole == single
+    assert whole[0] == 0 and whole[1] == 0 and all(v != 0 for v in whole[2:])
