@@ -143,8 +143,11 @@ __global__ void __launch_bounds__(256, 6) k_map(DevGraph g, const char *seqs, co
 #ifndef MGX_ALIGN_WAVES_PER_SIMD
 #define MGX_ALIGN_WAVES_PER_SIMD 4
 #endif
-template <int PHASE>
-__global__ void __launch_bounds__(64, MGX_ALIGN_WAVES_PER_SIMD) k_align(AlignParams P, uint32_t lds_bytes) {
+// WPS = waves per SIMD the register allocation targets: 4 for the kernels that extend; the seeding-only instantiation of
+// short-read batches runs at 8 (64 VGPRs, seeding tables mostly in the arena) — a gather kernel gains more from the extra
+// wavefronts than it loses to spills (measured 112 vs 117 ms per 2 M reads)
+template <int PHASE, int WPS = MGX_ALIGN_WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WPS) k_align(AlignParams P, uint32_t lds_bytes) {
     const uint32_t slot = blockIdx.x;
     __shared__ Wave w;                // the wave's scalar state lives in LDS, not in registers
     __shared__ SdustScratch sd;
@@ -721,7 +724,13 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     };
     A->split_ran = split;
     if (split) {
-        k_align<PH_SEED><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
+        if (l.Lmax <= 192 && slots >= (uint64_t)prop.multiProcessorCount * 4 * 8) {
+            const uint32_t budget8 = (160u * 1024u) / (4 * 8) - static_lds - 64u;
+            const uint32_t lds8 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), budget8) & ~15u;
+            k_align<PH_SEED, 8><<<(uint32_t)prop.multiProcessorCount * 4 * 8, 64, lds8>>>(P, lds8);
+        } else {
+            k_align<PH_SEED><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(A->ev[4], 0));
         k_iota<<<(uint32_t)((n + 255) / 256), 256>>>(A->order_in.as<uint32_t>(), n);
