@@ -4,8 +4,12 @@
 A "step" is one pass of the hot path (k-mer mapping + seeding + extension, `mgx_align_batch_device`)
 over one batch of synthetic reads already resident in HBM.  Workload (BASELINE.json configs[1]):
 10 M x 150 bp reads against a ~100 M-node k = 31 graph per GPU; with N > 1 every rank owns a replica
-of the graph and its own read shard (weak scaling) and the per-read result records are gathered to
-rank 0 over RCCL inside the timed region.
+of the graph and its own read shard (weak scaling) and the complete alignments (result headers AND the
+variable-length node / CIGAR / path-spelling stream) are gathered to rank 0 over RCCL inside the timed region.
+
+`value` is the device-resident rate (reads and results in HBM, as the bench contract prescribes);
+`value_host_inclusive` is SURVEY 8(d)'s variant of the same step with the read H2D and the result D2H (pinned
+host buffers) inside the timed region.
 
 Prints ONE JSON line (rank 0).  PyTorch is plumbing only (device tensors, streams, torch.distributed).
 """
@@ -43,12 +47,14 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MGX_BENCH_CPU_SAMPLE", 200000)))
     ap.add_argument("--parity-sample", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-steps", type=int, default=2, help="steps of the PCIe-inclusive variant (0 = skip)")
+    ap.add_argument("--cpu-1t-sample", type=int, default=1500, help="reads of the single-thread CPU leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("MGX_BENCH_FORCE_DIST") == "1":     # the latter: single-rank RCCL run of the N > 1 code path
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -91,22 +97,13 @@ def main():
     cfg = capi.config_cli(args.k)            # `metagraph align` defaults (cli/config/config.hpp:114-145)
     A = aligner.Aligner(G, cfg)
 
-    hdr_bytes = None
+    from metagraph_amd import gather as mg
 
     def step():
         A.align_device(reads.data_ptr(), offsets.data_ptr(), args.reads)
         if dist:
-            # gather the fixed-size per-read result records to rank 0 over RCCL/xGMI
-            hp, hb, nq, sp, sw = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_void_p(), C.c_uint64()
-            rc = lib.mgx_device_results(A.h, C.byref(hp), C.byref(hb), C.byref(nq), C.byref(sp), C.byref(sw))
-            assert rc == 0
-            n_bytes = hb.value * nq.value
-
-            class _Ptr:
-                __cuda_array_interface__ = {"shape": (n_bytes,), "typestr": "|u1", "data": (hp.value, False), "version": 2}
-            hdr = torch.as_tensor(_Ptr(), device=dev)
-            gl = [torch.empty_like(hdr) for _ in range(world)] if rank == 0 else None
-            dist.gather(hdr, gl, dst=0)
+            # every alignment travels to rank 0 over RCCL/xGMI: fixed-size headers + the variable-length stream
+            mg.gather_device_results(A, dist, rank, world, dev)
 
     def sync():
         torch.cuda.synchronize()
@@ -134,6 +131,40 @@ def main():
     ms_per_step = 1000.0 * elapsed / max(1, args.steps)
     total_reads = args.reads * world
     value = total_reads / (elapsed / max(1, args.steps))
+
+    # ---------------- SURVEY 8(d) variant: read H2D and result D2H inside the timed region ----------------
+    # pinned host buffers; reads go up, the complete results (headers + used part of the stream) come down
+    host_value, host_ms = None, None
+    if args.host_steps > 0:
+        reads_h = reads.cpu().pin_memory()
+        offsets_h = offsets.cpu().pin_memory()
+        hdr_d, stream_d, used = mg.device_result_tensors(A, dev)
+        hdr_h = torch.empty(hdr_d.numel(), dtype=torch.uint8).pin_memory()
+        stream_h = torch.empty(stream_d.numel(), dtype=torch.uint8).pin_memory()
+
+        def host_step():
+            reads.copy_(reads_h, non_blocking=True)
+            offsets.copy_(offsets_h, non_blocking=True)
+            A.align_device(reads.data_ptr(), offsets.data_ptr(), args.reads)
+            hd, sd, u = mg.device_result_tensors(A, dev)
+            hdr_h.copy_(hd, non_blocking=True)
+            stream_h[:4 * u].copy_(sd[:4 * u], non_blocking=True)
+            if dist:
+                mg.gather_device_results(A, dist, rank, world, dev)
+        host_step()
+        sync()
+        th = time.time()
+        for _ in range(args.host_steps):
+            host_step()
+        sync()
+        eh = time.time() - th
+        if dist:
+            tmax = torch.tensor([eh], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            eh = float(tmax.item())
+        host_ms = 1000.0 * eh / args.host_steps
+        host_value = total_reads / (eh / args.host_steps)
+        del reads_h, offsets_h, hdr_h, stream_h
 
     if rank != 0:
         if dist:
@@ -173,11 +204,11 @@ def main():
     # prescribes): bytes per read x the reads of this launch.  null when the summary is absent.
     traffic, traffic_src = None, None
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")))
         per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read")
         if per_read:
             traffic = round(per_read * args.reads)
-            traffic_src = "profiles/r01_pmc_summary.json (%d-read PMC run, scaled per read)" % pmc["reads_per_launch"]
+            traffic_src = "profiles/r02_pmc_summary.json (%d-read PMC run, scaled per read)" % pmc["reads_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -193,10 +224,14 @@ def main():
                 "extend_share": dict(zip(["pop", "stage_band", "outgoing", "column", "scan", "commit", "conv", "push"],
                                          [round(c / max(1, sum(st["extend_cycles"])), 3) for c in st["extend_cycles"]]))}
 
-    # ---------------- parity spot check + CPU baseline (oracle = checker, never the thing measured) -----
+    # ---------------- parity + CPU baseline (oracle = checker, never the thing measured) -----------------
+    # The timed CPU leg is the restated reference path built -O3 -march=native -DNDEBUG on this host
+    # (oracle/Makefile `fast`), parallelised like cli/align.cpp:415-480 (thread pool over read batches, shared
+    # read-only graph).  Every read of its sample is also compared with the GPU's result for the same read.
     parity, cpu = None, None
     if args.parity_sample > 0 or not args.no_cpu_baseline:
         import orc
+        orc.use_library(orc.build_fast())
         W_h, last_h = W.cpu().numpy(), last.cpu().numpy()
         view = capi.BossView()
         view.k, view.sigma, view.n_edges, view.mode, view.on_device = args.k, 5, n_edges, 0, 0
@@ -204,26 +239,47 @@ def main():
         Fc = (C.c_uint64 * 5)(*[int(x) for x in boss["F"]])
         view.F = C.cast(Fc, C.POINTER(C.c_uint64))
         og = orc.Graph(orc.L().orc_graph_from_boss(C.byref(view)))
-        orc.L().orc_graph_build_first_chars(og.h, os.cpu_count() or 1)      # NodeFirstCache stand-in (one-off, untimed)
-        ns = min(args.parity_sample, args.reads)
-        if ns:
-            sample = [bytes(r) for r in reads[:ns].cpu().numpy()]
-            got, status = A.align_batch(sample)
-            orun = orc.AlignRun(og, cfg, sample, threads=os.cpu_count() or 1, validate=False)
-            want = orun.results()
-            mism = sum(1 for a, b in zip(got, want) if a != b)
-            parity = {"sample": ns, "mismatches": mism, "capacity_errors": int(st["n_capacity_errors"])}
+        threads = os.cpu_count() or 1
+        orc.L().orc_graph_build_first_chars(og.h, threads)      # NodeFirstCache stand-in (one-off, untimed)
+        nc = min(args.parity_sample if args.no_cpu_baseline else max(args.cpu_sample, args.parity_sample), args.reads)
+        csample = [bytes(r) for r in reads[:nc].cpu().numpy()]
+        tc = time.time()
+        orun = orc.AlignRun(og, cfg, csample, threads=threads, validate=False)
+        dt = time.time() - tc
+        # GPU results of the same reads through the C-ABI with host buffers, compared field by field
+        blob, offs = aligner.pack_queries(csample)
+        gres = capi.Results()
+        rc = lib.mgx_align_batch(A.h, blob, offs.ctypes.data, nc, 0, C.byref(gres))
+        assert rc == 0, lib.mgx_last_error()
+        ores = capi.Results()
+        orc.L().orc_results_view(orun.r, C.byref(ores))
+        mism = capi.count_result_mismatches(gres, ores)
+        cap_err = int(sum(1 for i in range(nc) if gres.status[i] != 0))
+        parity = {"sample": nc, "mismatches": int(mism), "capacity_errors": cap_err,
+                  "full_batch_capacity_errors": int(st["n_capacity_errors"])}
         if not args.no_cpu_baseline:
-            nc = min(args.cpu_sample, args.reads)
-            csample = [bytes(r) for r in reads[:nc].cpu().numpy()]
-            threads = os.cpu_count() or 1
-            tc = time.time()
-            orc.AlignRun(og, cfg, csample, threads=threads, validate=False)
-            dt = time.time() - tc
+            n1 = min(args.cpu_1t_sample, nc)
+            t1s = time.time()
+            orc.AlignRun(og, cfg, csample[:n1], threads=1, validate=False)
+            d1 = time.time() - t1s
+            model = "unknown"
+            try:
+                for line in open("/proc/cpuinfo"):
+                    if line.startswith("model name"):
+                        model = line.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
+            one = n1 / d1
             cpu = {"value": round(nc / dt, 1), "unit": "reads/s", "cores": threads, "kind": "port",
-                   "sample": "first %d reads of the same workload, same graph, %d threads, %.1fs" % (nc, threads, dt)}
+                   "sample": "first %d reads of the same workload, same graph, %d threads, %.1fs" % (nc, threads, dt),
+                   "build": "-O3 -march=native -DNDEBUG", "cpu_model": model,
+                   "single_thread": {"value": round(one, 1), "sample": "%d reads, %.1fs" % (n1, d1)},
+                   "thread_scaling_efficiency": round((nc / dt) / (one * threads), 3)}
 
     out = {"metric": "aligned reads/sec (150 bp, k=31)", "value": round(value, 1), "unit": "reads/s",
+           "value_host_inclusive": round(host_value, 1) if host_value else None,
+           "ms_per_step_host_inclusive": round(host_ms, 3) if host_ms else None,
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
            "config": {"workload": "%d synthetic %d bp reads per GPU vs %d-edge k=%d BOSS graph (%.0f Mbp iid genome + %d SNP windows), CLI-default scoring" %

@@ -104,9 +104,13 @@ void mgx_config_set_dna_matrix(mgx_config *c, int8_t match, int8_t mm_transition
 /* DBGAlignerConfig::unit_scoring_matrix over "ACGT" (aligner_config.cpp:185-204). */
 void mgx_config_set_unit_matrix(mgx_config *c, int8_t match);
 
+/* Longest query the device path accepts (seed coordinates are 16-bit on the device; per-strand seed lists hold up to
+ * 2 L + 64 entries).  Longer queries: MGX_ERR_UNSUPPORTED for the batch.  The reference has no such limit. */
+#define MGX_MAX_QUERY_LENGTH 32704u
+
 /* Per-read device arena limits (no reference counterpart; the reference uses the heap). */
 typedef struct mgx_limits {
-    uint32_t max_query_length;   /* longest read accepted in a batch */
+    uint32_t max_query_length;   /* longest read accepted in a batch (<= MGX_MAX_QUERY_LENGTH) */
     uint32_t max_columns;        /* DP-table columns per extension  */
     uint32_t max_seeds;          /* seeds per read and strand       */
     uint64_t cell_arena_bytes;   /* S/E/F storage per in-flight read */
@@ -213,6 +217,16 @@ int mgx_fetch_results(mgx_aligner *a, mgx_results *out);
  * 32-bit words holding nodes / packed CIGAR runs (len << 3 | op) / path characters. */
 int mgx_device_results(mgx_aligner *a, const void **headers, uint64_t *header_bytes, uint64_t *n_queries,
                        const void **stream, uint64_t *stream_words);
+/* Capacity (32-bit words) of the device stream buffer behind mgx_device_results: a function of the batch shape only,
+ * so equal on all ranks that run equally shaped batches — the padded RCCL gather relies on it. */
+uint64_t mgx_device_stream_capacity(const mgx_aligner *a);
+/* Host-only decode of raw result records (one rank's `headers` / `stream` as mgx_device_results exposes them, e.g.
+ * after an RCCL gather on the root) into the mgx_results view that mgx_format_tsv prints from — the root's side of
+ * cli/align.cpp:469-473.  Needs no GPU.  `*store` owns the memory behind `out`; release with mgx_raw_store_free. */
+typedef struct mgx_raw_store mgx_raw_store;
+int mgx_results_from_raw(const void *headers, uint64_t n_queries, const uint32_t *stream, uint64_t stream_words,
+                         mgx_raw_store **store, mgx_results *out);
+void mgx_raw_store_free(mgx_raw_store *store);
 /* Test hooks: keep and fetch the per-read seed lists (DBGAligner::build_seeders products). */
 void mgx_aligner_keep_seeds(mgx_aligner *a, int keep);
 int mgx_fetch_seed_info(mgx_aligner *a, uint32_t *info6, uint32_t *seeds, uint32_t *max_seeds_out);
@@ -224,10 +238,10 @@ int mgx_map_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uin
 int mgx_aligner_stats(const mgx_aligner *a, mgx_stats *out);
 
 /* Tuning / test hook: which instantiation of the per-read program the aligner launches.  Results are
- * identical for all of them.  "split8" (default): seeding kernel with one wavefront per read, radix sort of
- * the reads by predicted extension work, extension kernel with 8 lanes per read; "split16": 16 lanes per read;
- * "splitw": both kernels one wavefront per read; "wave" / "g8" / "g16" / "lane": one fused kernel with 64 / 8 /
- * 16 / 1 lanes per read.  The environment variable MGX_ALIGN_MODE sets the default.  Unknown name: MGX_ERR_INVALID. */
+ * identical for both.  "split8" (default, the product): seeding kernel with one wavefront per read, radix sort of
+ * the reads by predicted extension work, extension kernel with 8 lanes per read; "g8": the fused reference
+ * instantiation (seeding + extension of a read in one 8-lane group).  The environment variable MGX_ALIGN_MODE sets
+ * the default.  Unknown name: MGX_ERR_INVALID. */
 int mgx_aligner_set_pipeline(mgx_aligner *a, const char *name);
 
 /* Format one query's results exactly like format_alignment() (cli/align.cpp:254-285):

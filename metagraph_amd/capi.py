@@ -87,6 +87,52 @@ def results_to_py(res):
     return out
 
 
+def results_arrays(res):
+    """numpy views of an mgx_results (valid while the owner keeps the batch alive)"""
+    import numpy as np
+    n = int(res.n_queries)
+
+    def arr(ptr, count, dtype):
+        if not count:
+            return np.zeros(0, dtype=dtype)
+        nbytes = count * np.dtype(dtype).itemsize
+        return np.frombuffer((C.c_char * nbytes).from_address(C.addressof(ptr.contents)), dtype=dtype, count=count)
+
+    aln_begin = arr(res.aln_begin, n + 1, np.uint64)
+    na = int(aln_begin[-1]) if n else 0
+    aln_dt = np.dtype([("score", "<i4"), ("offset", "<u4"), ("clipping", "<u4"), ("end_clipping", "<u4"),
+                       ("num_matches", "<u4"), ("n_nodes", "<u4"), ("n_cigar", "<u4"), ("seq_len", "<u4"),
+                       ("nodes_begin", "<u8"), ("cigar_begin", "<u8"), ("seq_begin", "<u8"), ("orientation", "u1"),
+                       ("_pad", "u1", (7,))])
+    assert aln_dt.itemsize == C.sizeof(Alignment)
+    alns = arr(res.alignments, na, aln_dt)
+    tn = int(alns["n_nodes"].sum()) if na else 0
+    tc = int(alns["n_cigar"].sum()) if na else 0
+    ts = int(alns["seq_len"].sum()) if na else 0
+    cig_dt = np.dtype([("len", "<u4"), ("op", "u1"), ("_pad", "u1", (3,))])
+    return {"n": n, "aln_begin": aln_begin, "alns": alns, "nodes": arr(res.nodes, tn, np.uint64),
+            "cigar": arr(res.cigar, tc, cig_dt), "seqs": arr(res.seqs, ts, np.uint8),
+            "status": arr(res.status, n, np.int32)}
+
+
+def count_result_mismatches(res_a, res_b):
+    """Number of queries whose alignment lists differ between two mgx_results of the same batch (every field of every
+    alignment: score, offset, clippings, matches, orientation, node ids, CIGAR runs, path spelling).  Whole-array
+    comparison first; the per-query walk only runs when something differs."""
+    import numpy as np
+    a, b = results_arrays(res_a), results_arrays(res_b)
+    assert a["n"] == b["n"]
+    fields = ["score", "offset", "clipping", "end_clipping", "num_matches", "n_nodes", "n_cigar", "seq_len", "orientation"]
+    same = np.array_equal(a["aln_begin"], b["aln_begin"]) and len(a["alns"]) == len(b["alns"]) \
+        and all(np.array_equal(a["alns"][f], b["alns"][f]) for f in fields) \
+        and np.array_equal(a["nodes"], b["nodes"]) and np.array_equal(a["cigar"]["len"], b["cigar"]["len"]) \
+        and np.array_equal(a["cigar"]["op"], b["cigar"]["op"]) and np.array_equal(a["seqs"], b["seqs"])
+    if same:
+        return 0
+    pa, pb = results_to_py(res_a), results_to_py(res_b)
+    return sum(1 for x, y in zip(pa, pb) if x != y)
+
+
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("MGX_LIB_PATH") or os.path.join(_ROOT, "metagraph_amd", "_build", "libmgx.so")   # override: A/B builds
 _lib = None
@@ -121,6 +167,10 @@ def lib():
     L.mgx_aligner_keep_seeds.argtypes = [C.c_void_p, C.c_int]
     L.mgx_device_results.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.mgx_device_stream_capacity.argtypes = [C.c_void_p]
+    L.mgx_device_stream_capacity.restype = C.c_uint64
+    L.mgx_results_from_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(Results)]
+    L.mgx_raw_store_free.argtypes = [C.c_void_p]
     L.mgx_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Mapping)]
     L.mgx_aligner_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.mgx_config_init_default.argtypes = [C.POINTER(Config)]

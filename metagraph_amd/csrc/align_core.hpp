@@ -1098,6 +1098,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     SEED_T(5, tp)
 }
 
+#ifndef MGX_NO_EXTEND    // translation units that only seed (mgx.hip: k_map, k_seed) skip the extension half
 // ------------------------------------------------------------------------------------------------
 // convergence checker (SeedFilteringExtender, A/aligner_extender_methods.cpp:66-207)
 // ------------------------------------------------------------------------------------------------
@@ -2372,6 +2373,8 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
     }
 }
 
+#endif  // MGX_NO_EXTEND
+
 // Predicted extension work of a read from its seeds: (number of extensions, columns), the sort key that
 // lets the sub-wave groups of one wavefront work on similar reads.  Any value is correct; a better
 // prediction only means less idling.
@@ -2511,11 +2514,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         wave_sync();
         w.cyc[1] = cycle_clock() - tseed;
         const uint64_t tdrv = cycle_clock();
-#ifdef MGX_SEED_ONLY
-        if (false) {
-#else
+#ifndef MGX_NO_EXTEND
         if ((PHASE & PH_EXTEND) && w.status == ST_OK) {
-#endif
             if (have_rc) {
                 // align_both_directions (:738-755)
                 uint32_t fm = w.num_matching[0], bm = w.num_matching[1];
@@ -2528,6 +2528,9 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
                 align_core_fwd(w);
             }
         }
+#else
+        static_assert(PHASE == PH_SEED, "this translation unit was built without the extension half");
+#endif
         for (int s = 0; s < 2; ++s) w.gen_store[s] = w.ext[s].conv.gen;
         wave_sync();
         w.cyc[4] = cycle_clock() - tdrv - w.cyc[2] - w.cyc[3];

@@ -60,12 +60,19 @@ inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lm
         return MGX_ERR_CAPACITY;
     }
     l.Lmax = std::max<uint32_t>(8, (Lmax + 7) & ~7u);
+    // seed coordinates and per-strand seed counts are 16-bit on the device (DevSeed, SeedHdr): a longer query would wrap
+    // them silently, so it is refused here (the reference has no such limit; documented in mgx.h)
+    if (l.Lmax > MGX_MAX_QUERY_LENGTH) {
+        *err = "a query of length " + std::to_string(Lmax) + " exceeds the device limit of " + std::to_string(MGX_MAX_QUERY_LENGTH) + " bp";
+        return MGX_ERR_UNSUPPORTED;
+    }
     uint32_t mc;
     if (u && u->max_columns) mc = u->max_columns;
     else if (cfg.max_nodes_per_seq_char < 1e6) mc = (uint32_t)(cfg.max_nodes_per_seq_char * l.Lmax) * 2 + 64;
     else mc = 16 * l.Lmax + 256;
     l.max_columns = std::min<uint32_t>((1u << 24) - 2, std::max<uint32_t>(64, mc));   // 24-bit table index in the queue key
     l.max_seeds = (u && u->max_seeds) ? u->max_seeds : 2 * l.Lmax + 64;
+    if (l.max_seeds > 65535) { *err = "mgx_limits.max_seeds must not exceed 65535 (16-bit seed counts on the device)"; return MGX_ERR_UNSUPPORTED; }
     l.max_path = 2 * l.Lmax + 64;
     l.max_alt = std::max<uint32_t>(4096, l.max_seeds);
     uint64_t cw;

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/mgx.h"
+#define MGX_NO_EXTEND 1      // this unit holds k_map and the seeding kernel; the extension lives in mgx_grp.hip
 #include "graph_build.hpp"
 #include "host_common.hpp"
 
@@ -230,27 +231,19 @@ struct mgx_graph {
     uint64_t bytes = 0;
 };
 
-extern "C" int mgx_launch_align_lane(const void *params, uint32_t n_slots, void *stream);   // mgx_lane.hip
-extern "C" int mgx_launch_align_grp16(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);   // mgx_grp.hip, MGX_GROUP=16
 extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);    // mgx_grp.hip, MGX_GROUP=8
-extern "C" int mgx_grp_waves_per_simd16(void);
 extern "C" int mgx_grp_waves_per_simd8(void);
-extern "C" unsigned mgx_grp_static_lds16(void);
 extern "C" unsigned mgx_grp_static_lds8(void);
 
-// Which instantiation of the aligner's wave program run_align launches.  The default is the split pipeline:
+// Which instantiation of the aligner's wave program run_align launches.  The product is the split pipeline:
 // seeding by one wavefront per read, a radix sort of the reads by predicted extension work, extension by
-// 8-lane groups (8 reads per wavefront).  MGX_ALIGN_MODE selects the others for A/B measurements.
-enum AlignMode { MODE_WAVE = 0, MODE_GRP16 = 1, MODE_GRP8 = 2, MODE_LANE = 3, MODE_SPLIT8 = 4, MODE_SPLIT16 = 5, MODE_SPLITW = 6, MODE_BAD = -1 };
+// 8-lane groups (8 reads per wavefront).  "g8" is the fused reference instantiation (seeding and extension of a read
+// in one 8-lane group, no hand-over, no sort) kept for A/B parity tests.
+enum AlignMode { MODE_GRP8 = 2, MODE_SPLIT8 = 4, MODE_BAD = -1 };
 static AlignMode parse_mode(const char *e) {
     if (!e) return MODE_BAD;
     if (!strcmp(e, "split8")) return MODE_SPLIT8;
-    if (!strcmp(e, "split16")) return MODE_SPLIT16;
-    if (!strcmp(e, "splitw")) return MODE_SPLITW;
-    if (!strcmp(e, "wave")) return MODE_WAVE;
-    if (!strcmp(e, "g16")) return MODE_GRP16;
     if (!strcmp(e, "g8")) return MODE_GRP8;
-    if (!strcmp(e, "lane")) return MODE_LANE;
     return MODE_BAD;
 }
 static AlignMode default_mode() {
@@ -267,7 +260,7 @@ struct mgx_aligner {
     DevBuf mlen_fwd, mlen_rc;     // k_map's index() match lengths, one byte per k-mer position
     DevBuf rng_fwd, rng_rc;       // and the (rl, ru) of matches >= min_seed_length (8 B per position; optional)
     bool have_rng = false;
-    DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, scan_tmp, dbg_seeds;
+    DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, d_stats_map, scan_tmp, dbg_seeds;
     DevBuf seed_hdr, seed_stream, work_key, work_key_sorted, order_in, order, sort_tmp, retry_list;    // split pipeline
     DevLimits lim;
     uint64_t n_reads = 0, total_kmers = 0;
@@ -284,6 +277,8 @@ struct mgx_aligner {
     uint64_t seed_scale = 1, seed_cap = 0;
     AlignMode mode = default_mode();
     uint64_t arena_stride = 0;
+    uint64_t out_words = 0;       // capacity of `stream` for the current batch shape
+    uint64_t out_min_words = 0;   // raised when a batch overflowed the heuristic size
 };
 
 extern "C" {
@@ -511,6 +506,7 @@ int mgx_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_l
     HIP_TRY(hipMemcpy(A->score_matrix.p, c.score_matrix, 128 * 128, hipMemcpyHostToDevice));
     if (int rc = A->cursors.ensure(64)) return rc;
     if (int rc = A->d_stats.ensure(sizeof(KernelStats))) return rc;
+    if (int rc = A->d_stats_map.ensure(sizeof(KernelStats))) return rc;
     for (auto &e : A->ev) HIP_TRY(hipEventCreate(&e));
     memset(&A->hstats, 0, sizeof(A->hstats));
     memset(&A->lim, 0, sizeof(A->lim));
@@ -578,6 +574,8 @@ static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets
 }
 
 static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, bool do_rc, bool mapped) {
+    // k_map's counters live in their own block: a re-run of the alignment stage (stream overflow) resets only its own
+    HIP_TRY(hipMemsetAsync(A->d_stats_map.p, 0, sizeof(KernelStats), 0));
     HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), 0));
     if (!mapped) {
         // max_seed_length < k: nodes are not mapped (dbg_aligner.cpp:209-213)
@@ -604,7 +602,7 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
                                          A->mlen_fwd.as<uint8_t>(), A->mlen_rc.as<uint8_t>(),
                                          A->have_rng ? A->rng_fwd.as<uint2>() : nullptr, A->have_rng ? A->rng_rc.as<uint2>() : nullptr,
                                          (int)std::min<uint64_t>(A->cfg.min_seed_length, 1u << 20), n, do_rc ? 1 : 0,
-                                         map_cursor, A->d_stats.as<KernelStats>());
+                                         map_cursor, A->d_stats_map.as<KernelStats>());
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(A->ev[1], 0));
@@ -624,13 +622,9 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const AlignMode mode = A->mode;
-    const bool split = mode == MODE_SPLIT8 || mode == MODE_SPLIT16 || mode == MODE_SPLITW;
-    const bool ext_g16 = mode == MODE_GRP16 || mode == MODE_SPLIT16, ext_g8 = mode == MODE_GRP8 || mode == MODE_SPLIT8;
-    const uint64_t wave_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;
-    uint64_t want_slots = wave_slots;            // wave-per-read kernels (fused, seeding, splitw extension)
-    if (mode == MODE_LANE) want_slots = (uint64_t)prop.multiProcessorCount * 4 * 64;
-    if (ext_g16) want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 4 * (uint64_t)mgx_grp_waves_per_simd16());
-    if (ext_g8) want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * (uint64_t)mgx_grp_waves_per_simd8());
+    const bool split = mode == MODE_SPLIT8;
+    const uint64_t wave_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;   // seeding kernel: one wavefront per read
+    const uint64_t want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * (uint64_t)mgx_grp_waves_per_simd8());
     uint64_t budget = free_b / 2;
     uint64_t slots = std::min<uint64_t>(std::min<uint64_t>(want_slots, std::max<uint64_t>(n, 1)), std::max<uint64_t>(1, budget / stride));
     if (slots == 0) slots = 1;
@@ -647,14 +641,18 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     A->n_slots = (uint32_t)slots;
     if (int rc = A->results.ensure(n * sizeof(ReadResult))) return rc;
     uint64_t words_per_read = (uint64_t)l.Lmax + l.Lmax / 4 + 40;
-    uint64_t out_words = n * words_per_read + 1024;
+    // heuristic size (one alignment per read: nodes + CIGAR runs + path characters); a batch that needs more is re-run
+    // with what it asked for (mgx_align_batch_device), so the size is never a correctness limit
+    uint64_t out_words = std::max<uint64_t>(n * words_per_read + 1024, A->out_min_words);
     if (int rc = A->stream.ensure(out_words * 4)) return rc;
+    A->out_words = out_words;
     if (A->keep_seeds) {
         if (int rc = A->dbg_seeds.ensure(n * 2 * (uint64_t)l.max_seeds * sizeof(DevSeed))) return rc;
         HIP_TRY(hipMemsetAsync(A->dbg_seeds.p, 0, n * 2 * (uint64_t)l.max_seeds * sizeof(DevSeed), 0));
     }
     unsigned long long *cur = A->cursors.as<unsigned long long>();
     HIP_TRY(hipMemsetAsync(cur, 0, 32, 0));
+    HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), 0));     // counters of this run of the stage only
     AlignParams P;
     memset(&P, 0, sizeof(P));
     P.g = A->graph->g;
@@ -714,13 +712,12 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     uint32_t lds_bytes = std::min<uint32_t>(fast_lds_bytes(l.Lmax), lds_budget) & ~15u;
     const uint32_t w_slots = (uint32_t)std::min<uint64_t>(slots, wave_slots);
     auto launch_groups = [&](int phase) -> int {
-        const uint32_t groups = ext_g16 ? 4 : 8;
-        const uint32_t waves_cu = 4u * (uint32_t)(ext_g16 ? mgx_grp_waves_per_simd16() : mgx_grp_waves_per_simd8());
-        const uint32_t static_lds = ext_g16 ? mgx_grp_static_lds16() : mgx_grp_static_lds8();
+        const uint32_t groups = 8;
+        const uint32_t waves_cu = 4u * (uint32_t)mgx_grp_waves_per_simd8();
+        const uint32_t static_lds = mgx_grp_static_lds8();
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 256u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
-        return ext_g16 ? mgx_launch_align_grp16(&P, (uint32_t)slots, per_group, phase, nullptr)
-                       : mgx_launch_align_grp8(&P, (uint32_t)slots, per_group, phase, nullptr);
+        return mgx_launch_align_grp8(&P, (uint32_t)slots, per_group, phase, nullptr);
     };
     A->split_ran = split;
     if (split) {
@@ -754,20 +751,10 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                 P.order = A->retry_list.as<uint32_t>();
                 P.n_items_ptr = cur + 3;
             }
-            if (mode == MODE_SPLITW) {
-                k_align<PH_EXTEND><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
-                HIP_TRY(hipGetLastError());
-            } else {
-                HIP_TRY((hipError_t)launch_groups(PH_EXTEND));
-            }
+            HIP_TRY((hipError_t)launch_groups(PH_EXTEND));
         }
-    } else if (mode == MODE_LANE) {
-        HIP_TRY((hipError_t)mgx_launch_align_lane(&P, (uint32_t)slots, nullptr));
-    } else if (ext_g16 || ext_g8) {
-        HIP_TRY((hipError_t)launch_groups(PH_BOTH));
     } else {
-        k_align<PH_BOTH><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY((hipError_t)launch_groups(PH_BOTH));
     }
     HIP_TRY(hipEventRecord(A->ev[3], 0));
     return MGX_OK;
@@ -775,8 +762,10 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
 
 static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     HIP_TRY(hipDeviceSynchronize());
-    KernelStats ks;
+    KernelStats ks, km;
     HIP_TRY(hipMemcpy(&ks, A->d_stats.p, sizeof(ks), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&km, A->d_stats_map.p, sizeof(km), hipMemcpyDeviceToHost));
+    ks.rank_lines += km.rank_lines; ks.select_lines += km.select_lines; ks.bit_lines += km.bit_lines; ks.map_lines += km.map_lines;
     mgx_stats &s = A->hstats;
     memset(&s, 0, sizeof(s));
     s.n_reads = A->n_reads;
@@ -840,13 +829,22 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
     for (;;) {
         if (int rc = run_align(A, d_seqs, d_offsets, n, Lmax)) return rc;
         if (int rc = collect_stats(A, mapped, true)) return rc;
-        if (!A->split_ran) break;
-        unsigned long long seeds_wanted = 0;
-        HIP_TRY(hipMemcpy(&seeds_wanted, A->cursors.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost));
-        if (seeds_wanted <= A->seed_cap) break;
-        // the seed stream overflowed: reads past its end were given a capacity status; redo the stage with room
-        A->seed_scale = seeds_wanted / std::max<uint64_t>(1, A->seed_cap / A->seed_scale) + 2;
+        // both streams keep counting past their capacity: reads that found no room got a capacity status and the
+        // stage is redone with what it asked for
+        unsigned long long out_wanted = 0, seeds_wanted = 0;
+        HIP_TRY(hipMemcpy(&out_wanted, A->cursors.as<unsigned long long>(), 8, hipMemcpyDeviceToHost));
+        bool again = false;
+        if (out_wanted > A->out_words) { A->out_min_words = out_wanted + out_wanted / 8 + 1024; again = true; }
+        if (A->split_ran) {
+            HIP_TRY(hipMemcpy(&seeds_wanted, A->cursors.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost));
+            if (seeds_wanted > A->seed_cap) {
+                A->seed_scale = seeds_wanted / std::max<uint64_t>(1, A->seed_cap / A->seed_scale) + 2;
+                again = true;
+            }
+        }
+        if (!again) break;
     }
+    A->h_results.clear();          // host copies of an earlier batch must not be mistaken for this one's
     return MGX_OK;
 }
 
@@ -858,6 +856,7 @@ int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
     if (n) {
         HIP_TRY(hipMemcpy(A->h_results.data(), A->results.p, n * sizeof(ReadResult), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(&used, A->cursors.p, 8, hipMemcpyDeviceToHost));
+        used = std::min<unsigned long long>(used, A->out_words);
     }
     A->h_stream.resize(used);
     if (used) HIP_TRY(hipMemcpy(A->h_stream.data(), A->stream.p, used * 4, hipMemcpyDeviceToHost));
@@ -871,10 +870,36 @@ int mgx_device_results(mgx_aligner *A, const void **headers, uint64_t *header_by
     if (!A) return fail(MGX_ERR_INVALID, "null argument");
     unsigned long long used = 0;
     if (A->n_reads) HIP_TRY(hipMemcpy(&used, A->cursors.p, 8, hipMemcpyDeviceToHost));
+    used = std::min<unsigned long long>(used, A->out_words);
     *headers = A->results.p; *header_bytes = sizeof(ReadResult); *n_queries = A->n_reads;
     *stream = A->stream.p; *stream_words = used;
     return MGX_OK;
 }
+
+uint64_t mgx_device_stream_capacity(const mgx_aligner *A) { return A ? A->out_words : 0; }
+
+struct mgx_raw_store { HostResults host; };
+
+int mgx_results_from_raw(const void *headers, uint64_t n, const uint32_t *stream, uint64_t stream_words,
+                         mgx_raw_store **store, mgx_results *out) {
+    if ((!headers && n) || !store || !out || (!stream && stream_words)) return fail(MGX_ERR_INVALID, "null argument");
+    const ReadResult *rr = static_cast<const ReadResult *>(headers);
+    for (uint64_t i = 0; i < n; ++i) {
+        const ReadResult &r = rr[i];
+        if (r.status != ST_OK || !r.n_alignments) continue;
+        const uint64_t words = (uint64_t)r.n_nodes + r.n_cigar + ((uint64_t)r.seq_len + 3) / 4;
+        if (r.stream_off > stream_words || words > stream_words - r.stream_off)
+            return fail(MGX_ERR_INVALID, "record %llu points outside the stream (%llu + %llu > %llu words)",
+                        (unsigned long long)i, (unsigned long long)r.stream_off, (unsigned long long)words, (unsigned long long)stream_words);
+    }
+    auto *S = new mgx_raw_store();
+    S->host.decode(rr, n, stream);
+    S->host.view(out);
+    *store = S;
+    return MGX_OK;
+}
+
+void mgx_raw_store_free(mgx_raw_store *store) { delete store; }
 
 int mgx_align_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_results *out) {
     if (!out) return fail(MGX_ERR_INVALID, "null argument");
@@ -888,7 +913,7 @@ void mgx_aligner_keep_seeds(mgx_aligner *A, int keep) { A->keep_seeds = keep != 
 // per read: num_matches fwd/rc, n_seeds fwd/rc, n_extensions, n_columns (6 x u32), and optionally the seeds
 int mgx_fetch_seed_info(mgx_aligner *A, uint32_t *info6, uint32_t *seeds /* [n][2][max_seeds][4] or NULL */, uint32_t *max_seeds_out) {
     const uint64_t n = A->n_reads;
-    if (A->h_results.size() != n) {
+    if (A->h_results.size() != n || n == 0) {
         A->h_results.resize(n);
         if (n) HIP_TRY(hipMemcpy(A->h_results.data(), A->results.p, n * sizeof(ReadResult), hipMemcpyDeviceToHost));
     }

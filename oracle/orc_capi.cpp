@@ -177,9 +177,12 @@ void *orc_align_batch(void *h, const mgx_config *config, const char *seqs, const
             aligner.align_batch(queries, &res, &st->wc);
         } else {
             std::atomic<uint64_t> next{ 0 };
-            const uint64_t chunk = 256;
+            // small tasks keep the tail short when threads >> tasks; counters are padded to their own cache lines
+            // (adjacent 56-byte counter blocks bumped once per BOSS step would ping-pong between cores)
+            const uint64_t chunk = std::max<uint64_t>(8, std::min<uint64_t>(256, n / (8ull * threads) + 1));
             std::vector<std::thread> pool;
-            std::vector<WorkCounters> wcs(threads);
+            struct alignas(128) PaddedWC { WorkCounters w; };
+            std::vector<PaddedWC> wcs(threads);
             for (uint32_t t = 0; t < threads; ++t) {
                 pool.emplace_back([&, t]() {
                     for (;;) {
@@ -188,13 +191,13 @@ void *orc_align_batch(void *h, const mgx_config *config, const char *seqs, const
                         uint64_t e = std::min(n, b + chunk);
                         std::vector<std::string> sub(queries.begin() + b, queries.begin() + e);
                         std::vector<AlignmentResults> r;
-                        aligner.align_batch(sub, &r, &wcs[t]);
+                        aligner.align_batch(sub, &r, &wcs[t].w);
                         for (uint64_t i = b; i < e; ++i) res[i] = std::move(r[i - b]);
                     }
                 });
             }
             for (auto &th : pool) th.join();
-            for (auto &w : wcs) st->wc.add(w);
+            for (auto &w : wcs) st->wc.add(w.w);
         }
         if (validate) {
             GraphView view{ g, false };

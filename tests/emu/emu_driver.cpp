@@ -35,6 +35,7 @@ struct EmuRun {
     DevLimits lim;
     KernelStats stats;
     uint64_t retried = 0;         // reads handed to pass 2 of the two-pass extension
+    uint64_t out_used = 0;        // words of `stream` in use
 };
 } // namespace
 
@@ -229,10 +230,17 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     } else {
         for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
     }
+    R->out_used = std::min<uint64_t>(cursors[0], out_words);
     R->host.decode(R->results.data(), n, R->stream.data());
     return R;
 }
 
+// raw device-layout records of the run (what mgx_device_results exposes on the GPU): headers + used stream words
+void emu_raw(void *r, const void **headers, uint64_t *n, const uint32_t **stream, uint64_t *words) {
+    auto *R = static_cast<EmuRun *>(r);
+    *headers = R->results.data(); *n = R->results.size();
+    *stream = R->stream.data(); *words = R->out_used;
+}
 uint64_t emu_retried(void *r) { return static_cast<EmuRun *>(r)->retried; }
 const char *emu_error(void *r) { return static_cast<EmuRun *>(r)->error.c_str(); }
 void emu_results(void *r, mgx_results *out) { static_cast<EmuRun *>(r)->host.view(out); }

@@ -103,6 +103,13 @@ class EmuRun:
         L().emu_retried.argtypes = [C.c_void_p]
         return L().emu_retried(self.r)
 
+    def raw(self):
+        """-> (headers bytes, stream bytes): the device-layout records mgx_device_results exposes on the GPU"""
+        hp, n, sp, w = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+        L().emu_raw.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+        L().emu_raw(self.r, C.byref(hp), C.byref(n), C.byref(sp), C.byref(w))
+        return C.string_at(hp.value, 64 * n.value) if n.value else b"", C.string_at(sp.value, 4 * w.value) if w.value else b""
+
     def results(self):
         v = capi.Results()
         L().emu_results(self.r, C.byref(v))

@@ -6,12 +6,36 @@ from metagraph_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _L = None
+_LIB_PATH = os.path.join(ROOT, "oracle", "_build", "liborc.so")
+
+
+def use_library(path):
+    """Load another build of the same oracle sources from now on (bench.py: the -O3 -march=native -DNDEBUG build)."""
+    global _L, _LIB_PATH
+    _L, _LIB_PATH = None, path
+
+
+def build_fast():
+    """make the optimised build on THIS host (it is -march=native) and return its path"""
+    import hashlib
+    import subprocess
+    flags = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                flags = line
+                break
+    except OSError:
+        pass
+    out = os.path.join(ROOT, "oracle", "_build", "fast-" + hashlib.sha1(flags.encode()).hexdigest()[:12])
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "fast", "FAST_OUT=" + out], check=True)
+    return os.path.join(out, "liborc_fast.so")
 
 
 def L():
     global _L
     if _L is None:
-        _L = C.CDLL(os.path.join(ROOT, "oracle", "_build", "liborc.so"))
+        _L = C.CDLL(_LIB_PATH)
         _L.orc_graph_build.restype = C.c_void_p
         _L.orc_graph_build.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, C.c_int]
         _L.orc_graph_from_boss.restype = C.c_void_p

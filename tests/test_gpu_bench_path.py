@@ -1,0 +1,28 @@
+"""bench.py end to end at reduced size on one GPU, launched the way the driver launches N > 1 (torch.distributed.run,
+backend nccl = RCCL): the synthetic workload generator (metagraph_amd/synth.py), the device-resident step, the
+complete-alignment gather through RCCL (world size 1 executes mgx_device_results -> all_gather / gather), the
+host-inclusive variant, and the oracle comparison of every read of the CPU sample."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_step_under_torchrun_nccl_single_rank():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MGX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--reads", "30000", "--genome", "300000", "--snps", "600", "--cpu-sample", "30000", "--cpu-1t-sample", "300",
+           "--host-steps", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["value_host_inclusive"] > 0
+    assert out["parity"]["sample"] == 30000 and out["parity"]["mismatches"] == 0 and out["parity"]["capacity_errors"] == 0
+    assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["single_thread"]["value"] > 0
