@@ -271,11 +271,19 @@ def main():
             except OSError:
                 pass
             one = n1 / d1
+            scan = None
+            if os.environ.get("MGX_BENCH_THREAD_SCAN"):
+                scan = {}
+                for th in [int(x) for x in os.environ["MGX_BENCH_THREAD_SCAN"].split(",")]:
+                    ns = min(nc, max(2000, 400 * th))
+                    ts = time.time()
+                    orc.AlignRun(og, cfg, csample[:ns], threads=th, validate=False)
+                    scan[str(th)] = round(ns / (time.time() - ts), 1)
             cpu = {"value": round(nc / dt, 1), "unit": "reads/s", "cores": threads, "kind": "port",
                    "sample": "first %d reads of the same workload, same graph, %d threads, %.1fs" % (nc, threads, dt),
                    "build": "-O3 -march=native -DNDEBUG", "cpu_model": model,
                    "single_thread": {"value": round(one, 1), "sample": "%d reads, %.1fs" % (n1, d1)},
-                   "thread_scaling_efficiency": round((nc / dt) / (one * threads), 3)}
+                   "thread_scaling_efficiency": round((nc / dt) / (one * threads), 3), "thread_scan": scan}
 
     out = {"metric": "aligned reads/sec (150 bp, k=31)", "value": round(value, 1), "unit": "reads/s",
            "value_host_inclusive": round(host_value, 1) if host_value else None,

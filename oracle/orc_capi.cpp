@@ -2,6 +2,7 @@
 // bench.py's cpu_baseline leg can drive it.  Result layout = include/mgx.h so that GPU and oracle
 // outputs can be compared field by field.  Never linked into libmgx.so.
 #include <atomic>
+#include <malloc.h>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -173,6 +174,14 @@ void *orc_align_batch(void *h, const mgx_config *config, const char *seqs, const
         std::vector<std::string> queries(n);
         for (uint64_t i = 0; i < n; ++i) queries[i].assign(seqs + offsets[i], seqs + offsets[i + 1]);
         std::vector<AlignmentResults> res(n);
+        if (threads > 1) {
+            // glibc malloc under hundreds of threads: keep the per-thread arenas from returning memory to the kernel
+            // between reads (trim / mmap-threshold churn serialises on the process's mmap lock).  The reference links
+            // jemalloc for the same reason (M/CMakeLists.txt:515-518).
+            mallopt(M_MMAP_THRESHOLD, 1 << 30);
+            mallopt(M_TRIM_THRESHOLD, 1 << 30);
+            mallopt(M_TOP_PAD, 64 << 20);
+        }
         if (threads <= 1) {
             aligner.align_batch(queries, &res, &st->wc);
         } else {
