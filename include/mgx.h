@@ -178,6 +178,7 @@ typedef struct mgx_stats {
     double seeding_ms, sort_ms, extend_ms;    /* split pipeline only (0 otherwise): seeding kernel, work sort,
                                                  extension kernel */
     uint64_t n_seed_lines;      /* split pipeline: part of the line counters issued by the seeding kernel */
+    uint64_t n_fast_columns;    /* part of n_columns computed by the register-resident chain path */
 } mgx_stats;
 
 int mgx_device_count(void);                 /* number of visible HIP devices (0 without a GPU) */
@@ -241,7 +242,9 @@ int mgx_aligner_stats(const mgx_aligner *a, mgx_stats *out);
  * identical for both.  "split8" (default, the product): seeding kernel with one wavefront per read, radix sort of
  * the reads by predicted extension work, extension kernel with 8 lanes per read; "g8": the fused reference
  * instantiation (seeding + extension of a read in one 8-lane group).  The environment variable MGX_ALIGN_MODE sets
- * the default.  Unknown name: MGX_ERR_INVALID. */
+ * the default.  Two further names switch the extension kernel's register-resident chain path off / on without
+ * changing the pipeline: "general" (every DP column through the staging-buffer path) and "chain" (default).
+ * Unknown name: MGX_ERR_INVALID. */
 int mgx_aligner_set_pipeline(mgx_aligner *a, const char *name);
 
 /* Format one query's results exactly like format_alignment() (cli/align.cpp:254-285):

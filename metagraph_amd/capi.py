@@ -66,7 +66,8 @@ class Stats(C.Structure):
                 ("n_bit_lines", C.c_uint64), ("n_columns", C.c_uint64), ("n_extensions", C.c_uint64),
                 ("n_seeds", C.c_uint64), ("n_map_lines", C.c_uint64), ("n_capacity_errors", C.c_uint64), ("phase_cycles", C.c_uint64 * 8), ("extend_cycles", C.c_uint64 * 8),
                 ("seed_kernel_ms", C.c_double), ("align_kernel_ms", C.c_double),
-                ("seeding_ms", C.c_double), ("sort_ms", C.c_double), ("extend_ms", C.c_double), ("n_seed_lines", C.c_uint64)]
+                ("seeding_ms", C.c_double), ("sort_ms", C.c_double), ("extend_ms", C.c_double), ("n_seed_lines", C.c_uint64),
+                ("n_fast_columns", C.c_uint64)]
 
 
 def results_to_py(res):

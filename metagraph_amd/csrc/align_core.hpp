@@ -96,10 +96,19 @@ struct ColMeta {                 // DPTColumn minus the vectors (aligner_extende
     int32_t parent;
     int32_t offset, max_pos, trim, size;
     int32_t score;               // edge score
-    uint32_t cells;              // word offset of cell 0 in the cell arena (S,E,F interleaved)
-    uint32_t c;                  // path character
-    uint32_t cap3;               // S.capacity()+E.capacity()+F.capacity() of the reference's vectors
+    uint32_t cells;              // word offset of the column's cell record in the cell arena (see rec_words)
+    uint32_t cw;                 // path character (bits 0-7) | cells per array of the record (bits 8-31)
+    int32_t org;                 // window position of record cell 0 (org <= trim)
 };
+MGX_DEV uint8_t col_char(const ColMeta &c) { return (uint8_t)(c.cw & 0xFF); }
+MGX_DEV int32_t col_wc(const ColMeta &c) { return (int32_t)(c.cw >> 8); }
+
+// A column's cell record: S[wc], F[wc] (int32) and two bits per cell packed four cells to a byte — bit 0: S == E,
+// bit 1: E[j] == E[j - 1] + gap_extension (E[-1] = ninf).  These are the only facts about E that anything after the
+// column's own computation consumes (backtrack :943-958), so E itself is never stored.  Record cell x holds window
+// position org + x; positions outside [trim, trim + size + 5) or outside the record read as ninf / 0, exactly what the
+// reference's vectors hold there (never-written padding).  wc is a multiple of 4; records are 16-byte aligned.
+MGX_HD uint32_t rec_words(uint32_t wc) { return (2 * wc + (wc + 15) / 16 + 3) & ~3u; }
 
 // all lanes hold the same metadata; moving it to scalar registers makes every dependent branch and
 // address computation scalar
@@ -107,7 +116,7 @@ MGX_DEV ColMeta uni_col(const ColMeta &c) {
     ColMeta r;
     r.node = uni(c.node); r.parent = uni(c.parent); r.offset = uni(c.offset); r.max_pos = uni(c.max_pos);
     r.trim = uni(c.trim); r.size = uni(c.size); r.score = uni(c.score); r.cells = uni(c.cells);
-    r.c = uni(c.c); r.cap3 = uni(c.cap3);
+    r.cw = uni(c.cw); r.org = uni(c.org);
     return r;
 }
 
@@ -242,7 +251,7 @@ struct Wave {
     uint8_t out_chars[8];
     uint64_t cyc[8];             // phase timers (shader cycles)
     uint64_t xcyc[8];            // extend() breakdown: pop, stage+band, outgoing, column, scan, commit, conv, push          // pointers into the caller's private frame, so outputs live here
-    uint32_t n_columns, n_extensions;
+    uint32_t n_columns, n_extensions, n_fast_columns;
     int32_t status;
 };
 
@@ -1289,11 +1298,29 @@ MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t qu
 // ------------------------------------------------------------------------------------------------
 // extension (DefaultColumnExtender::extend, A/aligner_extender_methods.cpp:412-772)
 // ------------------------------------------------------------------------------------------------
-MGX_DEV int32_t cell_S(const Wave &w, const ColMeta &c, int32_t j) {
-    return (j >= 0 && j < c.size + 5) ? gld(w.cells + c.cells + 3 * j) : NINF;   // outside: undefined in the reference
+// cell of column c at window position pos (absolute, like DPTColumn's trim + index); ninf outside what the reference's
+// vectors hold (index < 0 or >= size + 5: undefined there, defined as ninf here and in the oracle)
+MGX_DEV bool cell_idx(const ColMeta &c, int32_t pos, int32_t &x) {
+    const int32_t j = pos - c.trim;
+    x = pos - c.org;
+    return j >= 0 && j < c.size + 5 && x < col_wc(c);
 }
-MGX_DEV int32_t cell_E(const Wave &w, const ColMeta &c, int32_t j) { return (j >= 0 && j < c.size + 5) ? gld(w.cells + c.cells + 3 * j + 1) : NINF; }
-MGX_DEV int32_t cell_F(const Wave &w, const ColMeta &c, int32_t j) { return (j >= 0 && j < c.size + 5) ? gld(w.cells + c.cells + 3 * j + 2) : NINF; }
+MGX_DEV int32_t cell_S(const Wave &w, const ColMeta &c, int32_t pos) {
+    int32_t x;
+    return cell_idx(c, pos, x) ? gld(w.cells + c.cells + x) : NINF;
+}
+MGX_DEV int32_t cell_F(const Wave &w, const ColMeta &c, int32_t pos) {
+    int32_t x;
+    return cell_idx(c, pos, x) ? gld(w.cells + c.cells + col_wc(c) + x) : NINF;
+}
+MGX_DEV uint32_t cell_ebits(const Wave &w, const ColMeta &c, int32_t pos) {
+    int32_t x;
+    if (!cell_idx(c, pos, x)) return 0;
+    const uint8_t *eb = (const uint8_t *)(w.cells + c.cells + 2 * col_wc(c));
+    return ((uint32_t)gld(eb + (x >> 2)) >> ((x & 3) * 2)) & 3u;
+}
+MGX_DEV bool cell_S_is_E(const Wave &w, const ColMeta &c, int32_t pos) { return cell_ebits(w, c, pos) & 1u; }      // S[pos] == E[pos]
+MGX_DEV bool cell_E_extends(const Wave &w, const ColMeta &c, int32_t pos) { return cell_ebits(w, c, pos) & 2u; }   // E[pos] == E[pos - 1] + ge
 
 // capacity of a reference vector created with `size0` elements (+5 reserved) after `pushes` push_backs
 // followed by reserve(size + 5) (DPTColumn::create :389-410, extend_ins_end :293-328; libstdc++ growth)
@@ -1353,11 +1380,16 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
     Staging &s = w.st[b];
     const int32_t n = c.size + 5;
     const int32_t cap = w.st_cap;
-    const int32_t *cells = w.cells + c.cells;
+    const int32_t wc = col_wc(c), shift = c.trim - c.org;
+    const int32_t *recS = w.cells + c.cells, *recF = recS + wc;
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
-            if (j < n) { tset(s.S, cap, j, gld(cells + 3 * j)); tset(s.F, cap, j, gld(cells + 3 * j + 2)); }      // a parent's E is never read
+            if (j < n) {                                  // a parent's E is never read
+                const int32_t x = j + shift;
+                tset(s.S, cap, j, x < wc ? gld(recS + x) : NINF);
+                tset(s.F, cap, j, x < wc ? gld(recF + x) : NINF);
+            }
         }
     }
     s.col = idx;
@@ -1365,18 +1397,42 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
     return b;
 }
 
-// write a staged column (size + 5 cells) to the arena, S/E/F interleaved; nothing waits on these stores
-MGX_DEV void flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t size) {
-    int32_t *cells = (int32_t *)uni((uint64_t)(w.cells + cells_off));
+// write a staged column (size + 5 cells: S, F and the two E bits) to the arena as a record with org == trim;
+// nothing waits on these stores.  Returns the record's cells per array.
+MGX_DEV int32_t flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t size, int32_t ge) {
+    int32_t *rec = (int32_t *)uni((uint64_t)(w.cells + cells_off));
     const int32_t cap = uni(w.st_cap);
     const Tier tS = s.S, tF = s.F, tE = w.stE;
     const int32_t n = uni(size) + 5;
-    for (int32_t base = 0; base < n; base += WAVE) {
+    const int32_t wc = (n + 3) & ~3;
+    uint8_t *eb = (uint8_t *)(rec + 2 * wc);
+    for (int32_t base = 0; base < wc; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
-            if (j < n) { gst(cells + 3 * j, tget(tS, cap, j)); gst(cells + 3 * j + 1, tget(tE, cap, j)); gst(cells + 3 * j + 2, tget(tF, cap, j)); }
+            if (j < wc) {
+                gst(rec + j, j < n ? tget(tS, cap, j) : NINF);
+                gst(rec + wc + j, j < n ? tget(tF, cap, j) : NINF);
+            }
         }
     }
+    for (int32_t base = 0; base < wc / 4; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t q = base + l;
+            if (q < wc / 4) {
+                uint32_t bits = 0;
+                for (int t = 0; t < 4; ++t) {
+                    const int32_t j = 4 * q + t;
+                    if (j < n) {
+                        const int32_t e = tget(tE, cap, j), ep = j ? tget(tE, cap, j - 1) : NINF;
+                        bits |= (uint32_t)(tget(tS, cap, j) == e) << (2 * t);
+                        bits |= (uint32_t)(e == ep + ge) << (2 * t + 1);
+                    }
+                }
+                gst(eb + q, (uint8_t)bits);
+            }
+        }
+    }
+    return wc;
 }
 
 // Compute one DP column into staging buffer `cb` from its parent in buffer `pb`
@@ -1568,6 +1624,189 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
     return m;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-resident column chains.
+//
+// Almost every column of an extension is the only child of the column computed just before it (the seed replay —
+// call_outgoing :344-348 — and every non-branching stretch of the graph), and the frontier hands it straight back
+// (:491-504: it is the unique top of the queue).  For such chains the column never leaves the registers: a window of
+// FW = 4 x WAVE cells, four consecutive window positions per lane starting at `org` (a multiple of 4, org <= trim),
+// holds S and F of the parent; the child is computed from it in one pass (update_column :209-290 lane-exactly incl.
+// the 4-wide overshoot, the scalar tail and extend_ins_end), scanned, committed (one record store per array) and
+// entered into the convergence table without touching the staging buffers or the frontier arrays.  Everything that
+// does not fit the pattern — several children, an equal-score batch, a band wider than the window — goes through the
+// general code below with the parent spilled to the staging buffer; results are identical by construction (the same
+// arithmetic on the same values in the same order) and the CPU/GPU parity tests run both with the chain path on
+// and off (AlignParams::no_fast).
+// ------------------------------------------------------------------------------------------------
+constexpr int32_t FW = 4 * WAVE;
+
+struct RegCol {                 // a column whose S / F live in registers
+    LV<int32_t> S[4], F[4];
+    int32_t idx, offset, trim, size, max_pos, max_val, org;
+    uint32_t node;
+};
+
+// lane l takes the value of lane l + n of its wave program (n >= 0); lanes past the end get `fill`
+MGX_DEV LV<int32_t> lanes_down(const LV<int32_t> &x, int32_t n, int32_t fill) { return wave_shift_down(x, n, fill); }
+
+MGX_DEV bool fast_fits(const ColMeta &c) { return (c.trim & 3) + c.size + 3 <= FW; }
+
+// select one of four per-lane values by a (group-uniform) slot number
+MGX_DEV int32_t pick4(int32_t a, int32_t b, int32_t c, int32_t d, int32_t s) { return s == 0 ? a : s == 1 ? b : s == 2 ? c : d; }
+
+// value of window position `pos` of a register column (must lie inside the window)
+MGX_DEV int32_t reg_at(const LV<int32_t> *A, int32_t org, int32_t pos) {
+    const int32_t x = pos - org;
+    LV<int32_t> t;
+    FOR_LANES(l) { t[l] = pick4(A[0][l], A[1][l], A[2][l], A[3][l], x & 3); }
+    return wave_bcast(t, x >> 2);
+}
+
+// load column `idx` (metadata c) into registers from its staging buffer or its arena record
+MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx, RegCol &P) {
+    P.idx = idx; P.node = c.node; P.offset = c.offset; P.trim = c.trim; P.size = c.size; P.max_pos = c.max_pos;
+    P.org = c.trim & ~3;
+    const int32_t n = c.size + 5;
+    const int sb = (w.st[0].col == idx) ? 0 : (w.st[1].col == idx) ? 1 : -1;
+    if (sb >= 0) {
+        const Staging st = w.st[sb];
+        const int32_t cap = w.st_cap;
+        FOR_LANES(l) {
+            for (int s = 0; s < 4; ++s) {
+                const int32_t j = P.org + 4 * l + s - c.trim;
+                const bool in = j >= 0 && j < n;
+                P.S[s][l] = in ? tget(st.S, cap, j) : NINF;
+                P.F[s][l] = in ? tget(st.F, cap, j) : NINF;
+            }
+        }
+    } else {
+        const int32_t wc = col_wc(c);
+        const int32_t *recS = w.cells + c.cells, *recF = recS + wc;
+        FOR_LANES(l) {
+            for (int s = 0; s < 4; ++s) {
+                const int32_t a = P.org + 4 * l + s, j = a - c.trim, x = a - c.org;
+                const bool in = j >= 0 && j < n && x < wc;
+                P.S[s][l] = in ? gld(recS + x) : NINF;
+                P.F[s][l] = in ? gld(recF + x) : NINF;
+            }
+        }
+    }
+    P.max_val = reg_at(P.S, P.org, c.max_pos);
+}
+
+// the parent goes back to staging buffer 0 in the general layout (cell j = window position trim + j)
+MGX_DEV void fast_spill(Wave &w, const RegCol &P) {
+    Staging &st = w.st[0];
+    const int32_t cap = w.st_cap;
+    const int32_t n = P.size + 5;
+    FOR_LANES(l) {
+        for (int s = 0; s < 4; ++s) {
+            const int32_t j = P.org + 4 * l + s - P.trim;
+            if (j >= 0 && j < n) { tset(st.S, cap, j, P.S[s][l]); tset(st.F, cap, j, P.F[s][l]); }
+        }
+    }
+    // cells the window does not hold: past its end, or below an origin that moved up with the band (all under the
+    // cut-off, or they would have kept the origin down): ninf
+    for (int32_t base = FW - (P.trim - P.org); base < n; base += WAVE) {
+        FOR_LANES(l) { int32_t j = base + l; if (j < n) { tset(st.S, cap, j, NINF); tset(st.F, cap, j, NINF); } }
+    }
+    for (int32_t base = 0; base < P.org - P.trim; base += WAVE) {
+        FOR_LANES(l) { int32_t j = base + l; if (j < P.org - P.trim && j < n) { tset(st.S, cap, j, NINF); tset(st.F, cap, j, NINF); } }
+    }
+    st.col = P.idx;
+    if (w.st[1].col == P.idx) w.st[1].col = -1;
+    wave_sync();
+}
+
+// update_seed_filter (:100-156) for a register column: cell at window position a (j = a - begin in [skip, size)) is
+// query position start + a - 1 of the node's vector.  Returns the converged score (NINF = nothing improved).
+MGX_DEV int32_t conv_update_regs(Wave &w, ExtenderState &E, uint32_t node, int32_t start, int32_t org, int32_t begin,
+                                 int32_t size, const LV<int32_t> *S) {
+    const AlignParams &P = *w.P;
+    const int32_t skip = begin ? 0 : 1;
+    const int32_t n = size - skip;                           // cells entered
+    const int32_t query_start = start + begin - (begin ? 1 : 0);
+    LV<int32_t> cm;
+    FOR_LANES(l) {
+        int32_t m = INT32_MIN;
+        for (int s = 0; s < 4; ++s) {
+            const int32_t j = org + 4 * l + s - begin;
+            if (j >= skip && j < size) m = imax(m, S[s][l]);
+        }
+        cm[l] = m;
+    }
+    if (node == 0) return wave_max(cm);
+    const uint64_t key = (uint64_t)node + (E.rc_view ? P.g.n : 0);
+    const uint32_t mask = P.lim.hash_size - 1;
+    uint32_t slot;
+    int32_t idx = conv_find(E.conv, mask, key, &slot);
+    const int32_t Lq = (int32_t)P.lim.Lmax;
+    auto store_cells = [&](int32_t *vec) {
+        FOR_LANES(l) {
+            for (int s = 0; s < 4; ++s) {
+                const int32_t a = org + 4 * l + s, j = a - begin;
+                if (j >= skip && j < size) gst(vec + start + a - 1, S[s][l]);
+            }
+        }
+    };
+    if (idx < 0) {
+        idx = conv_insert(w, E.conv, slot, key, query_start, n);
+        if (idx < 0) return NINF;
+        store_cells(E.conv.vecs + (uint64_t)idx * Lq);
+        wave_sync();
+        return wave_max(cm);
+    }
+    ConvEntry e = gld(E.conv.entries + idx);
+    int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
+    int32_t vstart = e.start, vlen = e.len;
+    if (query_start + n <= vstart) {
+        fill_range(vec, query_start + n, vstart, NINF);
+        store_cells(vec);
+        e.len = vstart + vlen - query_start; e.start = query_start;
+        gst(E.conv.entries + idx, e);
+        wave_sync();
+        return wave_max(cm);
+    }
+    if (query_start >= vstart + vlen) {
+        fill_range(vec, vstart + vlen, query_start, NINF);
+        store_cells(vec);
+        e.len = query_start + n - vstart;
+        gst(E.conv.entries + idx, e);
+        wave_sync();
+        return wave_max(cm);
+    }
+    if (query_start < vstart) { fill_range(vec, query_start, vstart, NINF); vlen += vstart - query_start; vstart = query_start; }
+    if (query_start + n > vstart + vlen) { fill_range(vec, vstart + vlen, query_start + n, NINF); vlen = query_start + n - vstart; }
+    e.start = vstart; e.len = vlen;
+    gst(E.conv.entries + idx, e);
+    wave_sync();
+    const double rel = P.cfg.rel_score_cutoff;
+    LV<int32_t> x;
+    FOR_LANES(l) {
+        int32_t m = NINF;
+        for (int s = 0; s < 4; ++s) {
+            const int32_t a = org + 4 * l + s, j = a - begin;
+            if (j >= skip && j < size) {
+                const int32_t sv = S[s][l];
+                int32_t vv = gld(vec + start + a - 1);
+                if ((double)sv > (double)vv * rel) {
+                    vv = imax(vv, sv);
+                    gst(vec + start + a - 1, vv);
+                    m = imax(m, vv);
+                }
+            }
+        }
+        x[l] = m;
+    }
+    const int32_t r = wave_max(x);
+    wave_sync();
+    return r;
+}
+
+enum { XM_POP = 0, XM_FAST = 1 };
+enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 2, FR_FALLBACK_CHILDREN = 3, FR_STOP = 4, FR_ERROR = 5 };
+
 MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
@@ -1593,6 +1832,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     const int32_t partial_sum_offset = psum_lin ? (qlen - (start + window_size)) * psum_lin : uni(psum[start + window_size]);
     const int32_t seed_offset = uni(seed.offset) - 1;
     const int32_t seed_off = uni(seed.offset), seed_seq_len = uni(seed.seq_len);
+    const int32_t go = uni(cfg.gap_open), ge = uni(cfg.gap_ext);
     uint32_t cell_top = 0;
     int32_t tsize = 0;
     uint64_t table_size_bytes = 0;
@@ -1602,7 +1842,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     // root column (:455-470)
     {
         ColMeta r;
-        r.node = seed.nodes[0]; r.parent = -1; r.c = 0; r.offset = seed_offset; r.max_pos = 0; r.trim = 0;
+        r.node = seed.nodes[0]; r.parent = -1; r.cw = 0; r.org = 0; r.offset = seed_offset; r.max_pos = 0; r.trim = 0;
         r.score = 0; r.cells = cell_top; r.size = 1;
         Staging &s0 = w.st[0];
         const int32_t cap = w.st_cap;
@@ -1636,55 +1876,44 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             }
         }
         r.size = 1 + pushes;
-        if ((uint64_t)3 * (r.size + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
-        r.cap3 = 3 * ref_capacity(1, (uint32_t)pushes);
+        if ((uint64_t)rec_words((uint32_t)r.size + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
+        const uint32_t root_cap3 = 3 * ref_capacity(1, (uint32_t)pushes);
         wave_sync();
-        flush_column(w, s0, cell_top, r.size);
+        const int32_t root_wc = flush_column(w, s0, cell_top, r.size, cfg.gap_ext);
+        r.cw = (uint32_t)root_wc << 8;
         s0.col = 0;
-        cell_top += 3 * (uint32_t)(r.size + 5);
+        cell_top += rec_words((uint32_t)root_wc);
         if (E.table_cap < 1) E.table_cap = 1;                 // emplace_back on an empty vector
         gst(w.cols + 0, r);
         w.hot = r;
         w.hot_idx = 0;
         tsize = 1;
-        table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)r.cap3 * 4;
+        table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)root_cap3 * 4;
     }
     int32_t min_cell_score = 0;
     int32_t best_score = 0;
     int32_t qn = 0, nn = 0, n_tips = 0;
     frontier_insert(w, qn, queue_key(0, 0, 0));
 
-    while (qn) {
-        uint64_t tx0 = xclock();
-        // pop every entry that shares the top score, in descending tuple order (:491-500)
-        {
-            const int32_t top_score = key_score(tier_get(w.lq, w.queue, qn - 1));
-            nn = 0;
-            while (qn && key_score(tier_get(w.lq, w.queue, qn - 1)) == top_score) {
-                tier_set(w.lnn, w.next_nodes, nn++, tier_get(w.lq, w.queue, qn - 1));
-                --qn;
-            }
-            wave_sync();
+    // ---- general path: one popped column `i` with all its children (staging buffers, frontier arrays) ----
+    // returns 0, or 1 = the extension is over (cut-off or capacity error; w.status says which)
+    auto general = [&](const int32_t i, const ColMeta col, const bool children_ready, int n_out_ready) -> int {
+        uint64_t tx1 = xclock();
+        const int pb = uni(stage_column(w, i, col));
+        const Staging par = w.st[pb];
+        const int32_t cap = uni(w.st_cap);
+        const int32_t next_offset = col.offset + 1;
+        const int32_t prev_xdrop_cutoff = xdrop_cutoff;       // global_xdrop: one shared cutoff
+        const bool in_seed = (next_offset - seed_off) >= 0 && (next_offset - seed_off) < seed_seq_len;
+        int32_t begin, prev_end;
+        // early cut-offs when off the optimal path (:521-547)
+        if (!children_ready && uni(st_S(par, cap, col.size, col.max_pos - col.trim)) < best_score) {
+            double node_counter = (double)tsize;
+            if (node_counter / (double)window_size >= max_nodes_per_char) { qn = 0; nn = 0; return 0; }
+            if ((double)table_size_bytes / 1000000.0 > max_ram) { qn = 0; nn = 0; return 0; }
         }
-        w.xcyc[0] += xclock() - tx0;
-        while (nn) {
-            uint64_t tx1 = xclock();
-            const int32_t i = (int32_t)uni(key_idx(tier_get(w.lnn, w.next_nodes, nn - 1)));
-            --nn;
-            const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : gld(w.cols + i));
-            const int pb = uni(stage_column(w, i, col));
-            const Staging par = w.st[pb];
-            const int32_t cap = uni(w.st_cap);
-            const int32_t next_offset = col.offset + 1;
-            const int32_t prev_xdrop_cutoff = xdrop_cutoff;       // global_xdrop: one shared cutoff
-            const bool in_seed = (next_offset - seed_off) >= 0 && (next_offset - seed_off) < seed_seq_len;
-            // early cut-offs when off the optimal path (:521-547)
-            if (uni(st_S(par, cap, col.size, col.max_pos - col.trim)) < best_score) {
-                double node_counter = (double)tsize;
-                if (node_counter / (double)window_size >= max_nodes_per_char) { qn = 0; nn = 0; continue; }
-                if ((double)table_size_bytes / 1000000.0 > max_ram) { qn = 0; nn = 0; continue; }
-            }
-            // band within the x-drop cutoff (:549-560)
+        // band within the x-drop cutoff (:549-560)
+        {
             int32_t b = col.size, e = 0;
             for (int32_t base = 0; base < col.size; base += WAVE) {
                 LV<bool> inr;
@@ -1695,116 +1924,416 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                     e = base + 64 - clz64(mk);
                 }
             }
-            int32_t begin = b + col.trim, prev_end = e + col.trim;
-            if (prev_end <= begin) continue;
-            uint64_t tx2 = xclock();
-            w.xcyc[1] += tx2 - tx1;
-
-            // the children list lives in the LDS control block: a private array indexed at run time would sit in scratch
-            uint32_t *out_nodes = w.out_nodes;
-            uint8_t *out_chars = w.out_chars;
-            int32_t *out_scores = w.out_scores;
-            const int n_out = uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
-            wave_sync();
-            if (n_out == 0) {
-                if (n_tips < max_columns) gst(w.tips + n_tips++, (uint32_t)i);
+            begin = b + col.trim; prev_end = e + col.trim;
+        }
+        if (prev_end <= begin) return 0;
+        uint64_t tx2 = xclock();
+        w.xcyc[1] += tx2 - tx1;
+        // the children list lives in the LDS control block: a private array indexed at run time would sit in scratch
+        uint32_t *out_nodes = w.out_nodes;
+        uint8_t *out_chars = w.out_chars;
+        int32_t *out_scores = w.out_scores;
+        const int n_out = children_ready ? n_out_ready : uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
+        wave_sync();
+        if (n_out == 0) {
+            if (n_tips < max_columns) gst(w.tips + n_tips++, (uint32_t)i);
+            return 0;
+        }
+        w.xcyc[2] += xclock() - tx2;
+        const int32_t end = imin(prev_end, window_size) + 1;
+        const int cb = 1 - pb;
+        for (int oi = 0; oi < n_out; ++oi) {
+            const uint32_t next = uni(out_nodes[oi]);
+            const uint8_t c = (uint8_t)uni((uint32_t)to_upper(out_chars[oi]));
+            const int32_t score = uni(out_scores[oi]);
+            if (tsize >= max_columns - 1) { w.status = ST_CAPACITY; return 1; }
+            int32_t size0 = end - begin;
+            uint32_t need = rec_words((uint32_t)(window_size + 1 - begin + 8));     // the column may grow to the window end
+            if ((uint64_t)cell_top + need > cell_words) { w.status = ST_CAPACITY; return 1; }
+            uint32_t table_cap_before = E.table_cap;
+            if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
+            ++w.n_columns;
+            uint64_t tx3 = xclock();
+            const int32_t size = uni(compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
+                                                    start, window_size, xdrop_cutoff));
+            const int32_t pushes = uni(w.tmp_pushes);
+            uint64_t tx4 = xclock();
+            w.xcyc[3] += tx4 - tx3;
+            ColMeta cur;
+            cur.node = next; cur.parent = i; cur.cw = c; cur.org = begin; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
+            cur.score = score; cur.cells = cell_top; cur.size = size;
+            const uint32_t cur_cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
+            const Tier cS = w.st[cb].S;
+            // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
+            const int32_t diag_i = next_offset - seed_offset;
+            bool has_extension = in_seed;
+            const int32_t extension_cutoff =
+                uni((int32_t)fma_f64((double)best_score, rel_cutoff, (double)partial_sum_offset));
+            int32_t best_s = INT32_MIN, best_d = INT32_MAX, best_j = 0;
+            for (int32_t base = 0; base < size; base += WAVE) {
+                LV<int32_t> sv, mn, dd;
+                LV<bool> ext;
+                FOR_LANES(l) {
+                    int32_t j = base + l;
+                    int32_t v = j < size ? tget(cS, cap, j) : INT32_MIN;
+                    sv[l] = v;
+                    mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
+                    ext[l] = j < size && v + (psum_lin ? (qlen - (start + begin + j)) * psum_lin : psum[start + begin + j]) >= extension_cutoff;
+                }
+                min_cell_score = imin(min_cell_score, wave_min(mn));
+                if (wave_ballot(ext)) has_extension = true;
+                // arg max in the order (S desc, |pos - diag| asc, j asc) (:647-650)
+                const int32_t cm = wave_max(sv);
+                FOR_LANES(l) { int32_t j = base + l; dd[l] = (j < size && sv[l] == cm) ? iabs(j + begin - diag_i) : INT32_MAX; }
+                const int32_t cd = wave_min(dd);
+                LV<bool> hit;
+                FOR_LANES(l) { hit[l] = dd[l] == cd; }
+                const int32_t cj = base + ctz64(wave_ballot(hit));
+                if (cm > best_s || (cm == best_s && cd < best_d)) { best_s = cm; best_d = cd; best_j = cj; }
+            }
+            cur.max_pos = best_j + begin;
+            const int32_t max_val = best_s;
+            uint64_t tx5 = xclock();
+            w.xcyc[4] += tx5 - tx4;
+            if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) {
+                // pop(table.size() - 1): the vector keeps its (possibly grown) capacity
                 continue;
             }
-            w.xcyc[2] += xclock() - tx2;
-            const int32_t end = imin(prev_end, window_size) + 1;
-            const int cb = 1 - pb;
-            for (int oi = 0; oi < n_out; ++oi) {
-                const uint32_t next = uni(out_nodes[oi]);
-                const uint8_t c = (uint8_t)uni((uint32_t)to_upper(out_chars[oi]));
-                const int32_t score = uni(out_scores[oi]);
-                if (tsize >= max_columns - 1) { w.status = ST_CAPACITY; res->table_size = 0; return; }
-                int32_t size0 = end - begin;
-                uint32_t need = 3 * (uint32_t)(window_size + 1 - begin + 8);     // the column may grow to the window end
-                if ((uint64_t)cell_top + need > cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
-                uint32_t table_cap_before = E.table_cap;
-                if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
-                ++w.n_columns;
-                uint64_t tx3 = xclock();
-                const int32_t size = uni(compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
-                                                        start, window_size, xdrop_cutoff));
-                const int32_t pushes = uni(w.tmp_pushes);
-                uint64_t tx4 = xclock();
-                w.xcyc[3] += tx4 - tx3;
-                ColMeta cur;
-                cur.node = next; cur.parent = i; cur.c = c; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
-                cur.score = score; cur.cells = cell_top; cur.size = size;
-                cur.cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
-                const Tier cS = w.st[cb].S;
-                // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
-                const int32_t diag_i = next_offset - seed_offset;
-                bool has_extension = in_seed;
-                const int32_t extension_cutoff =
-                    uni((int32_t)fma_f64((double)best_score, rel_cutoff, (double)partial_sum_offset));
-                int32_t best_s = INT32_MIN, best_d = INT32_MAX, best_j = 0;
-                for (int32_t base = 0; base < size; base += WAVE) {
-                    LV<int32_t> sv, mn, dd;
-                    LV<bool> ext;
-                    FOR_LANES(l) {
-                        int32_t j = base + l;
-                        int32_t v = j < size ? tget(cS, cap, j) : INT32_MIN;
-                        sv[l] = v;
-                        mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
-                        ext[l] = j < size && v + (psum_lin ? (qlen - (start + begin + j)) * psum_lin : psum[start + begin + j]) >= extension_cutoff;
-                    }
-                    min_cell_score = imin(min_cell_score, wave_min(mn));
-                    if (wave_ballot(ext)) has_extension = true;
-                    // arg max in the order (S desc, |pos - diag| asc, j asc) (:647-650)
-                    const int32_t cm = wave_max(sv);
-                    FOR_LANES(l) { int32_t j = base + l; dd[l] = (j < size && sv[l] == cm) ? iabs(j + begin - diag_i) : INT32_MAX; }
-                    const int32_t cd = wave_min(dd);
-                    LV<bool> hit;
-                    FOR_LANES(l) { hit[l] = dd[l] == cd; }
-                    const int32_t cj = base + ctz64(wave_ballot(hit));
-                    if (cm > best_s || (cm == best_s && cd < best_d)) { best_s = cm; best_d = cd; best_j = cj; }
+            uint32_t table_sizediff = E.table_cap - table_cap_before;
+            table_size_bytes += (uint64_t)136 * table_sizediff + (uint64_t)cur_cap3 * 4;
+            if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
+            best_score = imax(best_score, max_val);
+            // commit the column: metadata + cells go to the arena (nothing waits on them)
+            const int32_t cur_wc = flush_column(w, w.st[cb], cell_top, size, ge);
+            cur.cw |= (uint32_t)cur_wc << 8;
+            gst(w.cols + tsize, cur);
+            w.hot = cur;
+            w.hot_idx = tsize;
+            w.st[cb].col = tsize;
+            cell_top += rec_words((uint32_t)cur_wc);
+            const int32_t my_idx = tsize;
+            ++tsize;
+            const int32_t vec_offset = start + begin - (begin ? 1 : 0);
+            const int32_t skip = begin ? 0 : 1;
+            uint64_t tx6 = xclock();
+            w.xcyc[5] += tx6 - tx5;
+            int32_t converged = update_seed_filter(w, E, next, vec_offset, cS, skip, size - skip);
+            uint64_t tx7 = xclock();
+            w.xcyc[6] += tx7 - tx6;
+            if (w.status != ST_OK) return 1;
+            if (converged != NINF) {
+                uint64_t key = queue_key(converged, -iabs(cur.max_pos - diag_i), (uint32_t)my_idx);
+                // next_nodes[0] is the first element popped into this batch (still there unless the batch
+                // has been fully consumed, in which case next_nodes.size() == 0)
+                if (nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
+                    tier_set(w.lnn, w.next_nodes, nn++, key);
+                    wave_sync();
+                } else {
+                    frontier_insert(w, qn, key);
                 }
-                cur.max_pos = best_j + begin;
-                const int32_t max_val = best_s;
-                uint64_t tx5 = xclock();
-                w.xcyc[4] += tx5 - tx4;
-                if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) {
-                    // pop(table.size() - 1): the vector keeps its (possibly grown) capacity
-                    continue;
+            }
+            w.xcyc[7] += xclock() - tx7;
+        }
+        return 0;
+    };
+
+    // ---- chain path: the child of the register column Pc, computed, judged and committed in registers ----
+    RegCol Pc;
+    FOR_LANES(l) { for (int s = 0; s < 4; ++s) { Pc.S[s][l] = NINF; Pc.F[s][l] = NINF; } }
+    Pc.idx = 0; Pc.offset = 0; Pc.trim = 0; Pc.size = 0; Pc.max_pos = 0; Pc.max_val = 0; Pc.org = 0; Pc.node = 0;
+    int fast_n_out = 0;
+    const uint8_t *qq = E.q;
+    MGX_ASSUME_LDS(w.sm_rows);
+    auto fast_step = [&]() -> int {
+        uint64_t tx1 = xclock();
+        // early cut-offs when off the optimal path (:521-547)
+        if (Pc.max_val < best_score) {
+            double node_counter = (double)tsize;
+            if (node_counter / (double)window_size >= max_nodes_per_char) return FR_STOP;
+            if ((double)table_size_bytes / 1000000.0 > max_ram) return FR_STOP;
+        }
+        // band within the x-drop cutoff (:549-560)
+        int32_t begin, prev_end;
+        {
+            LV<int32_t> lo, hi;
+            FOR_LANES(l) {
+                int32_t a0 = INT32_MAX, a1 = INT32_MIN;
+                for (int s = 0; s < 4; ++s) {
+                    const int32_t a = Pc.org + 4 * l + s, j = a - Pc.trim;
+                    if (j >= 0 && j < Pc.size && Pc.S[s][l] >= xdrop_cutoff) { a0 = imin(a0, a); a1 = imax(a1, a + 1); }
                 }
-                uint32_t table_sizediff = E.table_cap - table_cap_before;
-                table_size_bytes += (uint64_t)136 * table_sizediff + (uint64_t)cur.cap3 * 4;
-                if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
-                best_score = imax(best_score, max_val);
-                // commit the column: metadata + cells go to the arena (nothing waits on them)
-                gst(w.cols + tsize, cur);
-                w.hot = cur;
-                w.hot_idx = tsize;
-                flush_column(w, w.st[cb], cell_top, size);
-                w.st[cb].col = tsize;
-                cell_top += 3 * (uint32_t)(size + 5);
-                const int32_t my_idx = tsize;
-                ++tsize;
-                const int32_t vec_offset = start + begin - (begin ? 1 : 0);
-                const int32_t skip = begin ? 0 : 1;
-                uint64_t tx6 = xclock();
-                w.xcyc[5] += tx6 - tx5;
-                int32_t converged = update_seed_filter(w, E, next, vec_offset, cS, skip, size - skip);
-                uint64_t tx7 = xclock();
-                w.xcyc[6] += tx7 - tx6;
-                if (w.status != ST_OK) { res->table_size = 0; return; }
-                if (converged != NINF) {
-                    uint64_t key = queue_key(converged, -iabs(cur.max_pos - diag_i), (uint32_t)my_idx);
-                    // next_nodes[0] is the first element popped into this batch (still there unless the batch
-                    // has been fully consumed, in which case next_nodes.size() == 0)
-                    if (nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
-                        tier_set(w.lnn, w.next_nodes, nn++, key);
-                        wave_sync();
-                    } else {
-                        frontier_insert(w, qn, key);
-                    }
-                }
-                w.xcyc[7] += xclock() - tx7;
+                lo[l] = a0; hi[l] = a1;
+            }
+            begin = wave_min(lo); prev_end = wave_max(hi);
+        }
+        if (prev_end == INT32_MIN || prev_end <= begin) return FR_END;
+        uint64_t tx2 = xclock();
+        w.xcyc[1] += tx2 - tx1;
+        const int32_t next_offset = Pc.offset + 1;
+        const bool in_seed = (next_offset - seed_off) >= 0 && (next_offset - seed_off) < seed_seq_len;
+        ColMeta pc;
+        pc.node = Pc.node; pc.offset = Pc.offset; pc.parent = 0; pc.max_pos = Pc.max_pos; pc.trim = Pc.trim; pc.size = Pc.size;
+        pc.score = 0; pc.cells = 0; pc.cw = 0; pc.org = Pc.org;
+        const int n_out = call_outgoing(w, E, seed, pc, force_fixed_seed, w.out_nodes, w.out_chars, w.out_scores);
+        wave_sync();
+        w.xcyc[2] += xclock() - tx2;
+        if (n_out == 0) {
+            if (n_tips < max_columns) gst(w.tips + n_tips++, (uint32_t)Pc.idx);
+            return FR_END;
+        }
+        if (n_out != 1) { fast_n_out = n_out; return FR_FALLBACK_CHILDREN; }
+        uint64_t tx3 = xclock();
+        const uint32_t next = w.out_nodes[0];
+        const uint8_t c = to_upper(w.out_chars[0]);
+        const int32_t score = w.out_scores[0];
+        const int32_t end = imin(prev_end, window_size) + 1;
+        const int32_t size0 = end - begin;
+        const int32_t max_size = window_size + 1 - begin;
+        const int32_t n_prev = prev_end - begin, n_loop = (n_prev + 3) & ~3;
+        const int32_t org = begin & ~3;
+        if ((begin - org) + imax(n_loop, size0) > FW) { fast_n_out = 1; return FR_FALLBACK_CHILDREN; }
+        if (tsize >= max_columns - 1) { w.status = ST_CAPACITY; return FR_ERROR; }
+        if ((uint64_t)cell_top + rec_words((uint32_t)(window_size + 1 - begin + 8)) > cell_words) { w.status = ST_CAPACITY; return FR_ERROR; }
+        // move the parent window to the child's origin (whole lanes)
+        if (org != Pc.org) {
+            const int32_t sh = (org - Pc.org) >> 2;
+            for (int s = 0; s < 4; ++s) { Pc.S[s] = lanes_down(Pc.S[s], sh, NINF); Pc.F[s] = lanes_down(Pc.F[s], sh, NINF); }
+            Pc.org = org;
+        }
+        // update_column (:209-290): cell j = a - begin; j in [0, n_loop) is computed in blocks of four lanes
+        const int8_t *row = w.sm_rows + encode_char(c) * 128;
+        const LV<int32_t> Sm1_0 = wave_shift_up1(Pc.S[3], NINF);        // parent at a - 1 for slot 0
+        LV<int32_t> cS[4], cF[4], cE[4], mraw[4], tv[4], mm[4];
+        FOR_LANES(l) {
+            for (int s = 0; s < 4; ++s) {
+                const int32_t a = org + 4 * l + s, j = a - begin;
+                const int32_t ap = start + a;
+                const int32_t prof = (ap >= 1 && ap <= qlen) ? (int32_t)row[qq[ap - 1] & 127] : 0;
+                const int32_t sm1 = s == 0 ? Sm1_0[l] : Pc.S[s - 1][l];
+                mraw[s][l] = sm1 + prof + score;                            // S_prev[j - 1] + profile + init_score
+                const bool in = j >= 0 && j < n_loop;
+                int32_t del = NINF;
+                if (next_offset > 1) del = imax(Pc.S[s][l] + go, Pc.F[s][l] + ge) + score;
+                const int32_t match = j >= 1 ? mraw[s][l] : NINF;
+                const int32_t m = imax(match, del);
+                cF[s][l] = in ? del : NINF;
+                mm[s][l] = m;
+                tv[s][l] = in ? m + go - j * ge : INT32_MIN;
             }
         }
+        // E[j + 1] = max(E[j] + ge, m[j] + go) == max_{i <= j}(m[i] + go + (j - i) ge) or the E[0] = ninf chain
+        LV<int32_t> tot;
+        FOR_LANES(l) {
+            tv[1][l] = imax(tv[1][l], tv[0][l]); tv[2][l] = imax(tv[2][l], tv[1][l]); tv[3][l] = imax(tv[3][l], tv[2][l]);
+            tot[l] = tv[3][l];
+        }
+        const LV<int32_t> pm = wave_prefix_max(tot);
+        const LV<int32_t> ex = wave_shift_up1(pm, INT32_MIN);             // everything in earlier lanes
+        LV<int32_t> en[4];                                                // E[j + 1] per cell j
+        FOR_LANES(l) {
+            for (int s = 0; s < 4; ++s) {
+                const int32_t a = org + 4 * l + s, j = a - begin;
+                const int32_t t = imax(tv[s][l], ex[l]);
+                const int32_t from_open = t + j * ge;
+                const int64_t fe0 = (int64_t)NINF + (int64_t)(j + 1) * ge;
+                const int32_t from_e0 = fe0 < (int64_t)INT32_MIN ? INT32_MIN : (int32_t)fe0;
+                en[s][l] = (j >= 0 && j < n_loop) ? imax(from_open, from_e0) : NINF;
+            }
+        }
+        const LV<int32_t> en_up = wave_shift_up1(en[3], NINF);
+        FOR_LANES(l) {
+            for (int s = 0; s < 4; ++s) {
+                const int32_t a = org + 4 * l + s, j = a - begin;
+                const int32_t ecur = s == 0 ? en_up[l] : en[s - 1][l];    // E[j] (ninf at j == 0 and wherever nothing was computed)
+                cE[s][l] = (j >= 0 && j <= n_loop) ? ecur : NINF;
+                int32_t sv = NINF;
+                if (j >= 0 && j < n_loop) { sv = imax(mm[s][l], ecur); if (!(sv > xdrop_cutoff - 1)) sv = NINF; }
+                cS[s][l] = sv;
+            }
+        }
+        // scalar tail (:284-289)
+        if (size0 > imax(1, n_prev)) {
+            FOR_LANES(l) {
+                for (int s = 0; s < 4; ++s) {
+                    const int32_t j = org + 4 * l + s - begin;
+                    if (j == size0 - 1) {
+                        const int32_t match = imax(mraw[s][l], cE[s][l]);
+                        if (match >= xdrop_cutoff) cS[s][l] = match;
+                    }
+                }
+            }
+        }
+        // extend_ins_end (:293-328)
+        int32_t size = size0, pushes = 0;
+        if (size0 < max_size) {
+            const int32_t lastS = reg_at(cS, org, begin + size0 - 1), lastE = reg_at(cE, org, begin + size0 - 1);
+            const int32_t ins_score = imax(lastS + go, lastE + ge);
+            if (ins_score >= xdrop_cutoff) {
+                int32_t n_push = 1;
+                const int32_t room = max_size - (size0 + 1);
+                if (ge == 0) {
+                    n_push += room;
+                } else {
+                    int32_t v = ins_score;
+                    while (n_push - 1 < room && v + ge >= xdrop_cutoff) { v += ge; ++n_push; }
+                }
+                if ((begin - org) + size0 + n_push > FW) { fast_n_out = 1; return FR_FALLBACK_CHILDREN; }
+                FOR_LANES(l) {
+                    for (int s = 0; s < 4; ++s) {
+                        const int32_t t = org + 4 * l + s - begin - size0;
+                        if (t >= 0 && t < n_push) { const int32_t v = ins_score + t * ge; cS[s][l] = v; cE[s][l] = v; cF[s][l] = NINF; }
+                        else if (t >= n_push) { cS[s][l] = NINF; cE[s][l] = NINF; cF[s][l] = NINF; }      // padding after the new end
+                    }
+                }
+                pushes = n_push;
+                size += n_push;
+            }
+        }
+        uint32_t table_cap_before = E.table_cap;
+        if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
+        ++w.n_columns;
+        ++w.n_fast_columns;
+        uint64_t tx4 = xclock();
+        w.xcyc[3] += tx4 - tx3;
+        // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
+        const int32_t diag_i = next_offset - seed_offset;
+        const int32_t extension_cutoff = (int32_t)fma_f64((double)best_score, rel_cutoff, (double)partial_sum_offset);
+        LV<int32_t> lmax, lmin;
+        LV<bool> lext;
+        FOR_LANES(l) {
+            int32_t mx = INT32_MIN, mn = INT32_MAX;
+            bool ext = false;
+            for (int s = 0; s < 4; ++s) {
+                const int32_t a = org + 4 * l + s, j = a - begin;
+                if (j >= 0 && j < size) {
+                    const int32_t v = cS[s][l];
+                    mx = imax(mx, v);
+                    if (v != NINF) mn = imin(mn, v);
+                    ext |= v + (psum_lin ? (qlen - (start + a)) * psum_lin : psum[start + a]) >= extension_cutoff;
+                }
+            }
+            lmax[l] = mx; lmin[l] = mn; lext[l] = ext;
+        }
+        min_cell_score = imin(min_cell_score, wave_min(lmin));
+        const bool has_extension = in_seed || wave_ballot(lext) != 0;
+        const int32_t max_val = wave_max(lmax);
+        // arg max in the order (S desc, |pos - diag| asc, j asc) (:647-650): one reduction over (distance, position)
+        LV<int32_t> lkey;
+        FOR_LANES(l) {
+            int32_t kk = INT32_MAX;
+            for (int s = 0; s < 4; ++s) {
+                const int32_t a = org + 4 * l + s, j = a - begin;
+                if (j >= 0 && j < size && cS[s][l] == max_val) kk = imin(kk, (iabs(a - diag_i) << 12) | j);
+            }
+            lkey[l] = kk;
+        }
+        int32_t max_pos;
+        if (size < 4096 && window_size < (1 << 18)) {
+            max_pos = begin + (wave_min(lkey) & 4095);
+        } else {
+            // (never taken with a register window; kept so that the packing above cannot silently overflow)
+            fast_n_out = 1; return FR_FALLBACK_CHILDREN;
+        }
+        uint64_t tx5 = xclock();
+        w.xcyc[4] += tx5 - tx4;
+        if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) return FR_END;      // pop(table.size() - 1)
+        const uint32_t cur_cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
+        uint32_t table_sizediff = E.table_cap - table_cap_before;
+        table_size_bytes += (uint64_t)136 * table_sizediff + (uint64_t)cur_cap3 * 4;
+        if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
+        best_score = imax(best_score, max_val);
+        // commit: metadata + one record (S, F, E bits) in window layout
+        ColMeta cur;
+        cur.node = next; cur.parent = Pc.idx; cur.cw = (uint32_t)c | ((uint32_t)FW << 8); cur.org = org; cur.offset = next_offset;
+        cur.max_pos = max_pos; cur.trim = begin; cur.score = score; cur.cells = cell_top; cur.size = size;
+        {
+            int32_t *rec = w.cells + cell_top;
+            uint8_t *eb = (uint8_t *)(rec + 2 * FW);
+            const LV<int32_t> e_up = wave_shift_up1(cE[3], NINF);
+            FOR_LANES(l) {
+                uint32_t bits = 0;
+                for (int s = 0; s < 4; ++s) {
+                    const int32_t j = org + 4 * l + s - begin;
+                    gst(rec + 4 * l + s, cS[s][l]);
+                    gst(rec + FW + 4 * l + s, cF[s][l]);
+                    const int32_t ep = j <= 0 ? NINF : (s == 0 ? e_up[l] : cE[s - 1][l]);
+                    bits |= (uint32_t)(cS[s][l] == cE[s][l]) << (2 * s);
+                    bits |= (uint32_t)(cE[s][l] == ep + ge) << (2 * s + 1);
+                }
+                gst(eb + l, (uint8_t)bits);
+            }
+        }
+        gst(w.cols + tsize, cur);
+        const int32_t my_idx = tsize;
+        ++tsize;
+        cell_top += rec_words((uint32_t)FW);
+        uint64_t tx6 = xclock();
+        w.xcyc[5] += tx6 - tx5;
+        const int32_t converged = conv_update_regs(w, E, next, start, org, begin, size, cS);
+        uint64_t tx7 = xclock();
+        w.xcyc[6] += tx7 - tx6;
+        if (w.status != ST_OK) return FR_ERROR;
+        if (converged == NINF) return FR_END;
+        // the frontier would hand this column straight back iff it is the unique maximum (:491-504)
+        if (nn == 0 && (qn == 0 || converged > key_score(tier_get(w.lq, w.queue, qn - 1))) && fast_fits(cur)) {
+            for (int s = 0; s < 4; ++s) { Pc.S[s] = cS[s]; Pc.F[s] = cF[s]; }
+            Pc.idx = my_idx; Pc.node = next; Pc.offset = next_offset; Pc.trim = begin; Pc.size = size; Pc.max_pos = max_pos;
+            Pc.max_val = max_val; Pc.org = org;
+            w.xcyc[7] += xclock() - tx7;
+            return FR_CONT;
+        }
+        {
+            uint64_t key = queue_key(converged, -iabs(max_pos - diag_i), (uint32_t)my_idx);
+            if (nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
+                tier_set(w.lnn, w.next_nodes, nn++, key);
+                wave_sync();
+            } else {
+                frontier_insert(w, qn, key);
+            }
+            w.hot = cur;
+            w.hot_idx = my_idx;
+        }
+        w.xcyc[7] += xclock() - tx7;
+        return FR_END;
+    };
+
+    const bool use_fast = !P.no_fast;
+    int mode = XM_POP;
+    for (;;) {
+        if (mode == XM_POP) {
+            if (nn == 0) {
+                if (qn == 0) break;
+                uint64_t tx0 = xclock();
+                // pop every entry that shares the top score, in descending tuple order (:491-500)
+                const int32_t top_score = key_score(tier_get(w.lq, w.queue, qn - 1));
+                while (qn && key_score(tier_get(w.lq, w.queue, qn - 1)) == top_score) {
+                    tier_set(w.lnn, w.next_nodes, nn++, tier_get(w.lq, w.queue, qn - 1));
+                    --qn;
+                }
+                wave_sync();
+                w.xcyc[0] += xclock() - tx0;
+            }
+            const int32_t i = (int32_t)uni(key_idx(tier_get(w.lnn, w.next_nodes, nn - 1)));
+            --nn;
+            const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : gld(w.cols + i));
+            if (use_fast && nn == 0 && fast_fits(col)) {
+                fast_load(w, col, i, Pc);
+                mode = XM_FAST;
+            } else {
+                if (general(i, col, false, 0)) { res->table_size = 0; return; }
+                continue;
+            }
+        }
+        const int r = fast_step();
+        if (r == FR_CONT) continue;
+        mode = XM_POP;
+        if (r == FR_END) continue;
+        if (r == FR_STOP) { qn = 0; nn = 0; continue; }
+        if (r == FR_ERROR) { res->table_size = 0; return; }
+        // the parent goes through the general code (children already enumerated)
+        fast_spill(w, Pc);
+        ColMeta col = uni_col(gld(w.cols + Pc.idx));
+        if (general(Pc.idx, col, true, fast_n_out)) { res->table_size = 0; return; }
     }
     wave_sync();
     res->n_tips = n_tips;
@@ -1891,13 +2420,12 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                             start_pos = last_pos;
                         }
                         if (start_pos < par.trim + 1) continue;
-                        int32_t pos = start_pos - col.trim, pos_p = start_pos - par.trim - 1;
-                        int32_t sv = cell_S(w, col, pos), sp = cell_S(w, par, pos_p);
+                        int32_t sv = cell_S(w, col, start_pos), sp = cell_S(w, par, start_pos - 1);
                         if (sv == NINF || sp == NINF) continue;
                         int32_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
                         if (sv + end_bonus >= min_start_score) {
-                            bool is_match = sv == sp + col.score + profile_at(w, E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos)
-                                && profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + start_pos) == OP_MATCH;
+                            bool is_match = sv == sp + col.score + profile_at(w, E.q, w.L, col_char(col), seed_clipping + start_pos)
+                                && profile_op_at(E.q, w.L, col_char(col), seed_clipping + start_pos) == OP_MATCH;
                             if (is_match || start_pos == last_pos || is_tip) {
                                 BtIndex bx;
                                 bx.score = sv + end_bonus; bx.neg_off_diag = -iabs(start_pos - col.offset + seed_offset);
@@ -2028,41 +2556,41 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
         while (j) {
             ColMeta gp = par;
             if (col.parent > 0) gp = gld(w.cols + par.parent);          // par is not the root
-            const int32_t trim = col.trim, trim_p = par.trim;
+            const int32_t trim_p = par.trim;
             align_offset = imin(col.offset, k_minus_1);
             if (pos == col.max_pos) prev_start_test_and_set(w, j);
-            const int32_t sv = cell_S(w, col, pos - trim);
+            const int32_t sv = cell_S(w, col, pos);
             const uint32_t last_op = n_ops ? (w.rev_ops[n_ops - 1] & 7) : 99u;
             if (sv == NINF) {
                 j = 0;
-            } else if (pos && sv == cell_E(w, col, pos - trim) && (n_ops == 0 || last_op != OP_DELETION)) {
+            } else if (pos && cell_S_is_E(w, col, pos) && (n_ops == 0 || last_op != OP_DELETION)) {
                 uint32_t lop = OP_INSERTION;
                 while (lop == OP_INSERTION) {
                     cigar_append(w.rev_ops, &n_ops, lop, 1, cap, &w.status);
-                    lop = cell_E(w, col, pos - trim) == cell_E(w, col, pos - trim - 1) + cfg.gap_ext ? OP_INSERTION : OP_MATCH;
+                    lop = cell_E_extends(w, col, pos) ? OP_INSERTION : OP_MATCH;
                     --pos;
                     if (w.status != ST_OK) return false;
                 }
             } else if (pos && pos >= trim_p + 1
-                       && sv == cell_S(w, par, pos - trim_p - 1) + col.score
-                              + profile_at(w, E.q, w.L, (uint8_t)col.c, seed_clipping + pos)) {
+                       && sv == cell_S(w, par, pos - 1) + col.score
+                              + profile_at(w, E.q, w.L, col_char(col), seed_clipping + pos)) {
                 ++n_trace;
                 extra_score += col.score;
-                append_node(col.node, (uint8_t)col.c, col.offset, profile_op_at(E.q, w.L, (uint8_t)col.c, seed_clipping + pos));
+                append_node(col.node, col_char(col), col.offset, profile_op_at(E.q, w.L, col_char(col), seed_clipping + pos));
                 --pos;
                 j = col.parent;
                 col = par; par = gp;
-            } else if (sv == cell_F(w, col, pos - trim) && (n_ops == 0 || last_op != OP_INSERTION)) {
+            } else if (sv == cell_F(w, col, pos) && (n_ops == 0 || last_op != OP_INSERTION)) {
                 uint32_t lop = OP_DELETION;
                 while (lop == OP_DELETION && j) {
                     const ColMeta c2 = w.cols[j];
                     const ColMeta p2 = w.cols[c2.parent];
                     align_offset = imin(c2.offset, k_minus_1);
-                    lop = cell_F(w, c2, pos - c2.trim) == cell_F(w, p2, pos - p2.trim) + c2.score + cfg.gap_ext
+                    lop = cell_F(w, c2, pos) == cell_F(w, p2, pos) + c2.score + cfg.gap_ext
                         ? OP_DELETION : OP_MATCH;
                     ++n_trace;
                     extra_score += c2.score;
-                    append_node(c2.node, (uint8_t)c2.c, c2.offset, OP_DELETION);
+                    append_node(c2.node, col_char(c2), c2.offset, OP_DELETION);
                     j = c2.parent;
                     if (w.status != ST_OK) return false;
                 }
@@ -2074,7 +2602,7 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
         }
         if (n_trace >= min_trace_length && n_path && last_path_node) {
             const ColMeta cj = w.cols[j];
-            int32_t cur_cell_score = cell_S(w, cj, pos - cj.trim);
+            int32_t cur_cell_score = cell_S(w, cj, pos);
             best_score = imax(best_score, score - cur_cell_score);
             if (score - er.min_cell_score < best_score) break;
             if (score >= min_start_score && (!pos || cur_cell_score == 0)
@@ -2404,7 +2932,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     w.have_best = 0;
     w.seeds_done = 0;
     w.ctr.rank_lines = w.ctr.select_lines = w.ctr.bit_lines = 0;
-    w.n_columns = w.n_extensions = 0;
+    w.n_columns = w.n_extensions = w.n_fast_columns = 0;
     const uint64_t nb = P.node_begin[read];
     w.n_kmers = (int32_t)(P.node_begin[read + 1] - nb);
     w.nodes[0] = P.nodes_fwd + nb;
@@ -2613,6 +3141,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     stats_accum->select_lines += w.ctr.select_lines;
     stats_accum->bit_lines += w.ctr.bit_lines;
     stats_accum->columns += w.n_columns;
+    stats_accum->fast_columns += w.n_fast_columns;
     stats_accum->extensions += w.n_extensions;
     if (PHASE & PH_SEED) stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
     stats_accum->capacity_errors += rr.status != ST_OK;

@@ -67,6 +67,7 @@ struct KernelStats {
     unsigned long long seed_lines;  // part of the three line counters issued by the seeding phase (split pipeline)
     unsigned long long xcyc[8];     // extend() breakdown
     unsigned long long cyc[8];      // shader cycles per phase: prepare, seeding, extend, backtrack, driver rest, output
+    unsigned long long fast_columns; // DP columns computed by the register-resident chain path (part of `columns`)
 };
 
 struct AlignParams {
@@ -105,6 +106,7 @@ struct AlignParams {
     uint32_t *retry_list;
     unsigned long long *retry_count;
     const unsigned long long *n_items_ptr;   // null: n_reads items
+    uint32_t no_fast;                    // A/B and test switch: every column through the general (staging buffer) path
 };
 
 } // namespace mgx

@@ -279,6 +279,7 @@ struct mgx_aligner {
     uint64_t arena_stride = 0;
     uint64_t out_words = 0;       // capacity of `stream` for the current batch shape
     uint64_t out_min_words = 0;   // raised when a batch overflowed the heuristic size
+    bool no_fast = false;         // test hook: extension through the general path only
 };
 
 extern "C" {
@@ -678,6 +679,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.read_cursor = cur + 1;
     P.stats = A->d_stats.as<KernelStats>();
     P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
+    static const bool no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;      // A/B switch: general path only
+    P.no_fast = no_fast || A->no_fast;
     size_t sort_tmp_bytes = 0;
     if (split) {
         // seeds travel from the seeding kernel to the extension kernel through a compact stream
@@ -772,6 +775,7 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     s.n_rank_lines = ks.rank_lines; s.n_select_lines = ks.select_lines; s.n_bit_lines = ks.bit_lines;
     s.n_columns = ks.columns; s.n_extensions = ks.extensions; s.n_seeds = ks.seeds;
     s.n_map_lines = ks.map_lines; s.n_capacity_errors = ks.capacity_errors; s.n_seed_lines = ks.seed_lines;
+    s.n_fast_columns = ks.fast_columns;
     for (int x = 0; x < 8; ++x) { s.phase_cycles[x] = ks.cyc[x]; s.extend_cycles[x] = ks.xcyc[x]; }
     float ms = 0;
     if (mapped) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[0], A->ev[1])); s.seed_kernel_ms = ms; }
@@ -811,6 +815,9 @@ int mgx_map_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uin
 int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
     if (!A) return fail(MGX_ERR_INVALID, "null argument");
     AlignMode m = parse_mode(name);
+    // "+general" / "+chain" suffix-free test switches: the extension's register-resident chain path off / on
+    if (name && !strcmp(name, "general")) { A->no_fast = true; return MGX_OK; }
+    if (name && !strcmp(name, "chain")) { A->no_fast = false; return MGX_OK; }
     if (m == MODE_BAD) return fail(MGX_ERR_INVALID, "unknown pipeline '%s'", name ? name : "(null)");
     A->mode = m;
     return MGX_OK;

@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
         atomicAdd(&P.stats->select_lines, acc.select_lines);
         atomicAdd(&P.stats->bit_lines, acc.bit_lines);
         atomicAdd(&P.stats->columns, acc.columns);
+        atomicAdd(&P.stats->fast_columns, acc.fast_columns);
         atomicAdd(&P.stats->extensions, acc.extensions);
         atomicAdd(&P.stats->seeds, acc.seeds);
         atomicAdd(&P.stats->capacity_errors, acc.capacity_errors);

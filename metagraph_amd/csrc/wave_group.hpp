@@ -81,6 +81,15 @@ MGX_DEV LV<int32_t> wave_shift_up1(const LV<int32_t> &x, int32_t fill) {
     return r;
 }
 
+// value of lane (l + n) of the group (n >= 0, group-uniform); lanes past the group's end receive `fill`
+MGX_DEV LV<int32_t> wave_shift_down(const LV<int32_t> &x, int32_t n, int32_t fill) {
+    LV<int32_t> r;
+    const int src = lane_id() + n;
+    const int32_t t = __builtin_amdgcn_ds_bpermute((group_base() + (src & (WAVE - 1))) << 2, x.v);
+    r.v = src < WAVE ? t : fill;
+    return r;
+}
+
 // inclusive prefix max inside the group: log2(group) row-shift DPP steps
 MGX_DEV LV<int32_t> wave_prefix_max(const LV<int32_t> &x) {
     int32_t v = x.v;

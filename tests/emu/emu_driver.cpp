@@ -196,6 +196,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     P.arena = arena.data(); P.arena_stride = stride;
     P.results = R->results.data(); P.out_stream = R->stream.data(); P.out_capacity = out_words;
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();
+    P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
     auto w = std::make_unique<Wave>();
     SdustScratch sd;
     // model a small LDS so that both placements (LDS / arena) of the fast arrays are exercised
@@ -267,10 +268,10 @@ uint32_t emu_seed_info(void *r, uint32_t *info6, uint32_t *seeds) {
         }
     return R->lim.max_seeds;
 }
-void emu_stats(void *r, uint64_t *out7) {
+void emu_stats(void *r, uint64_t *out8) {
     auto &s = static_cast<EmuRun *>(r)->stats;
-    out7[0] = s.rank_lines; out7[1] = s.select_lines; out7[2] = s.bit_lines; out7[3] = s.columns;
-    out7[4] = s.extensions; out7[5] = s.seeds; out7[6] = s.capacity_errors;
+    out8[0] = s.rank_lines; out8[1] = s.select_lines; out8[2] = s.bit_lines; out8[3] = s.columns;
+    out8[4] = s.extensions; out8[5] = s.seeds; out8[6] = s.capacity_errors; out8[7] = s.fast_columns;
 }
 void emu_free(void *r) { delete static_cast<EmuRun *>(r); }
 

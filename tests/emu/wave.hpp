@@ -64,6 +64,12 @@ inline LV<int32_t> wave_shift_up1(const LV<int32_t> &x, int32_t fill) {
     return r;
 }
 
+inline LV<int32_t> wave_shift_down(const LV<int32_t> &x, int32_t n, int32_t fill) {
+    LV<int32_t> r;
+    for (int l = 0; l < WAVE; ++l) r[l] = l + n < WAVE ? x[l + n] : fill;
+    return r;
+}
+
 inline LV<int32_t> wave_prefix_max(const LV<int32_t> &x) {
     LV<int32_t> r;
     int32_t m = x[0];

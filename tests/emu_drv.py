@@ -132,9 +132,10 @@ class EmuRun:
         return decode_seed_info(self.n, ms, info, seeds)
 
     def stats(self):
-        a = (C.c_uint64 * 7)()
+        a = (C.c_uint64 * 8)()
         L().emu_stats(self.r, a)
-        return dict(zip(["rank_lines", "select_lines", "bit_lines", "columns", "extensions", "seeds", "capacity_errors"], list(a)))
+        return dict(zip(["rank_lines", "select_lines", "bit_lines", "columns", "extensions", "seeds", "capacity_errors",
+                         "fast_columns"], list(a)))
 
 
 def decode_seed_info(n, ms, info, seeds):

@@ -23,7 +23,8 @@ def compare_gpu(g, G, cfg, reads, limits=None, check_seeds=True, pipeline=None):
     assert o.error == "", o.error
     A = aligner.Aligner(G, cfg, limits)
     if pipeline:
-        A.set_pipeline(pipeline)
+        for name in pipeline.split("+"):
+            A.set_pipeline(name)
     A.keep_seeds(check_seeds)
     got, status = A.align_batch(reads)
     assert all(s == 0 for s in status), status
@@ -59,7 +60,7 @@ def test_align_cli_config(k, mask, seed):
     compare_gpu(g, gpu_graph(g), capi.config_cli(k), reads)
 
 
-PIPELINES = ["split8", "g8"]
+PIPELINES = ["split8", "g8", "split8+general"]     # "+general": the extension's register-resident chain path off
 
 
 @pytest.mark.parametrize("pipeline", PIPELINES)
@@ -68,7 +69,12 @@ def test_every_pipeline_matches_the_oracle(pipeline):
     the fused 8-lane reference) give the oracle's results."""
     g, reads = make_world(500, 31, genome_len=6000, n_reads=150, read_len=150, n_variants=30)
     G = gpu_graph(g)
-    compare_gpu(g, G, capi.config_cli(31), reads, pipeline=pipeline)
+    A = compare_gpu(g, G, capi.config_cli(31), reads, pipeline=pipeline)
+    st = A.stats()
+    if pipeline.endswith("general"):
+        assert st["n_fast_columns"] == 0
+    else:
+        assert st["n_fast_columns"] > 0.9 * st["n_columns"], st      # the chain path must be the one that runs
     # ragged batch, fewer reads than lanes, forward only
     g, reads = make_world(501, 13, n_reads=7)
     cfg = capi.config_cli(13)
