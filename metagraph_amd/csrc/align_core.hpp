@@ -46,6 +46,13 @@
 #define MGX_NI_G4 MGX_DEV
 #endif
 
+// kernels that keep AlignParams in LDS (mgx_grp.hip) say so; elsewhere it is a kernel argument
+#if defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS
+#define MGX_ASSUME_PARAMS(p) MGX_ASSUME_LDS(p)
+#else
+#define MGX_ASSUME_PARAMS(p) ((void)0)
+#endif
+
 namespace mgx {
 
 // ------------------------------------------------------------------------------------------------
@@ -122,12 +129,12 @@ MGX_DEV ColMeta uni_col(const ColMeta &c) {
 
 struct BtIndex { int32_t score, neg_off_diag, neg_i, pos; };
 
-struct ConvSlot { uint32_t gen, idx; };
-struct ConvEntry { uint64_t key; int32_t start, len; };
+// One hash slot holds everything a lookup needs (key, generation tag, the entry's vector number and the query range
+// its vector covers): a probe is ONE 32-byte access instead of slot -> entry -> range.
+struct alignas(32) ConvSlot { uint64_t key; uint32_t gen, idx; int32_t start, len; uint32_t pad0, pad1; };
 
 struct ConvChecker {             // SeedFilteringExtender::conv_checker_ (extender hpp:75-76)
     ConvSlot *slots;
-    ConvEntry *entries;
     int32_t *vecs;               // entry e covers query positions [start, start + len) at vecs[e * L + pos]
     uint32_t n_entries;
     uint32_t gen;
@@ -194,6 +201,33 @@ struct Staging { Tier S, F; int32_t col; };
 #endif
 constexpr int32_t LQ_CAP = MGX_LQ_CAP;       // frontier entries kept in LDS; the rest spill to the arena
 
+// Loop-carried state of one extension (DefaultColumnExtender::extend): lives in LDS next to the control block so that
+// the step functions of the flat extension loop are separate small functions.  fS / fF: S and F of the chain path's
+// current column, four consecutive window positions per lane starting at f_org.
+#ifndef MGX_NO_EXTEND
+constexpr int32_t FW = 4 * WAVE;
+#else
+constexpr int32_t FW = 4;                 // seeding-only translation units never touch the window
+#endif
+struct XState {
+    int32_t xdrop_cutoff, best_score, tsize, min_cell_score, qn, nn, n_tips;
+    uint32_t cell_top;
+    uint64_t table_size_bytes;
+    int32_t start, window_size, qlen, partial_sum_offset, seed_off, seed_seq_len, psum_lin, force_fixed;
+    int32_t f_idx, f_offset, f_trim, f_size, f_max_pos, f_max_val, f_org, f_n_out;
+    uint32_t f_node, pad_;
+    // copies of what the chain step reads every column (the seed lives in its caller's private frame and the
+    // parameter block behind a generic pointer: both would be FLAT loads there)
+    const uint32_t *seed_nodes;
+    const uint8_t *seed_seq;
+    uint64_t rc_key_add;                  // RCDBG views key the convergence table by node + max_index (:74-75,107-108)
+    double rel_cutoff, max_nodes_per_char, max_ram;
+    int32_t go, ge, xdrop, k, Lq, max_columns, seq_lds, pad2_;
+    uint32_t hash_mask, cell_words;
+    alignas(16) int32_t fS[FW];
+    alignas(16) int32_t fF[FW];
+};
+
 struct Wave {
     const AlignParams *P;
     int32_t L;                   // query length
@@ -253,6 +287,8 @@ struct Wave {
     uint64_t xcyc[8];            // extend() breakdown: pop, stage+band, outgoing, column, scan, commit, conv, push          // pointers into the caller's private frame, so outputs live here
     uint32_t n_columns, n_extensions, n_fast_columns;
     int32_t status;
+    int32_t q_lds;               // the strands q[0], q[1] live in LDS (carve)
+    XState x;
 };
 
 MGX_HD uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
@@ -273,7 +309,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 2 * align8(((L + 15) / 16 + 2) * 4) + 4 * align8(((L + 63) / 64 + 1) * 8);   // pk, bm
     b += align8((L + 8) * 8) + align8(L + 8);           // dust_eq, dust_t
     b += align8((uint64_t)lim.max_alt * 4);             // alt
-    b += align8((uint64_t)lim.cell_words * 4);          // cells
+    b += 16 + align8((uint64_t)lim.cell_words * 4);     // cells
     b += align8((uint64_t)lim.max_columns * sizeof(ColMeta));
     b += 2 * align8((uint64_t)lim.max_columns * 8);     // queue, next_nodes
     b += align8((uint64_t)lim.max_columns * 4);         // tips
@@ -282,9 +318,9 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path);   // rev_*
     b += 16;                                            // gen_store
     b += 6 * align8((L + 16) * 4) + 2 * align8(32 * 8); // staging + LDS-tier fallbacks
-    b += 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8(ent * sizeof(ConvEntry)) + align8(ent * L * 4));
+    b += 32 + 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8(ent * L * 4));
     b += 4 * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
-    return align8(b);
+    return (b + 63) & ~63ull;          // slices keep the 32-byte alignment of the hash slots and the 16-byte one of the cell records
 }
 
 // Carve the wave's workspace.  Small, latency-critical scalar arrays go to LDS (`lds`, `lds_bytes`)
@@ -305,6 +341,7 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
         return r;
     };
     // persistent fast arrays
+    w.q_lds = 2 * Lp <= lleft ? 1 : 0;
     for (int s = 0; s < 2; ++s) w.q[s] = take_fast(Lp);
     w.lq = (uint64_t *)take_fast(LQ_CAP * 8);
     w.lnn = (uint64_t *)take_fast(LQ_CAP * 8);
@@ -348,6 +385,7 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     for (int s = 0; s < 2; ++s) w.seeds[s] = (DevSeed *)take((uint64_t)lim.max_seeds * sizeof(DevSeed));
     for (int s = 0; s < 2; ++s) w.alive[s] = take(lim.max_seeds);
     w.alt = (uint32_t *)take((uint64_t)lim.max_alt * 4);
+    p = (uint8_t *)(((uint64_t)p + 15) & ~15ull);                // cell records are written with 16-byte stores
     w.cells = (int32_t *)take((uint64_t)lim.cell_words * 4);
     w.cols = (ColMeta *)take((uint64_t)lim.max_columns * sizeof(ColMeta));
     w.queue = (uint64_t *)take((uint64_t)lim.max_columns * 8);
@@ -360,8 +398,8 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.rev_seq = take(lim.max_path);
     w.gen_store = (uint32_t *)take(16);
     for (int s = 0; s < 2; ++s) {
+        p = (uint8_t *)(((uint64_t)p + 31) & ~31ull);
         w.ext[s].conv.slots = (ConvSlot *)take((uint64_t)lim.hash_size * sizeof(ConvSlot));
-        w.ext[s].conv.entries = (ConvEntry *)take(ent * sizeof(ConvEntry));
         w.ext[s].conv.vecs = (int32_t *)take(ent * L * 4);
     }
     for (int a = 0; a < 4; ++a) {
@@ -1118,34 +1156,61 @@ MGX_DEV uint32_t conv_hash(uint64_t key, uint32_t mask) {
     return (uint32_t)key & mask;
 }
 
-// returns entry index or -1; *slot_out = slot where the key would be inserted
-MGX_DEV int32_t conv_find(const ConvChecker &c, uint32_t mask, uint64_t key, uint32_t *slot_out) {
-    key = uni(key);
-    mask = uni(mask);
-    const ConvSlot *slots = (const ConvSlot *)uni((uint64_t)c.slots);
-    const ConvEntry *entries = (const ConvEntry *)uni((uint64_t)c.entries);
-    const uint32_t gen = uni(c.gen);
-    uint32_t h = conv_hash(key, mask);
+MGX_DEV ConvSlot conv_load_slot(const ConvSlot *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = gld(q), b = gld(q + 1);
+    ConvSlot sl;
+    sl.key = ((uint64_t)a.y << 32) | a.x; sl.gen = a.z; sl.idx = a.w;
+    sl.start = (int32_t)b.x; sl.len = (int32_t)b.y; sl.pad0 = sl.pad1 = 0;
+    return sl;
+}
+MGX_DEV void conv_store_slot(ConvSlot *p, const ConvSlot &sl) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    uint4 a, b;
+    a.x = (uint32_t)sl.key; a.y = (uint32_t)(sl.key >> 32); a.z = sl.gen; a.w = sl.idx;
+    b.x = (uint32_t)sl.start; b.y = (uint32_t)sl.len; b.z = 0; b.w = 0;
+    gst(q, a); gst(q + 1, b);
+}
+// the range half of a slot only (key / generation / vector number unchanged)
+MGX_DEV void conv_store_range(ConvSlot *p, int32_t start, int32_t len) {
+    uint2 r; r.x = (uint32_t)start; r.y = (uint32_t)len;
+    gst(reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(p) + 1), r);
+}
+
+// Linear probing from `h`: returns the slot of `key` (found = true, sl = its content) or the free slot where it would
+// be inserted.  `first` may carry the content of slot h loaded earlier (the chain path issues that load before the DP).
+MGX_DEV uint32_t conv_probe_from(const ConvChecker &c, uint32_t mask, uint64_t key, uint32_t h, ConvSlot sl, bool &found) {
+    const ConvSlot *slots = c.slots;
+    const uint32_t gen = c.gen;
     for (;;) {
-        ConvSlot sl = gld(slots + h);
-        if (uni(sl.gen) != gen) { *slot_out = h; return -1; }
-        const uint32_t idx = uni(sl.idx);
-        if (uni(gld(&entries[idx].key)) == key) { *slot_out = h; return (int32_t)idx; }
+        if (sl.gen != gen) { found = false; return h; }
+        if (sl.key == key) { found = true; return h; }
         h = (h + 1) & mask;
+        sl = conv_load_slot(slots + h);
+    }
+}
+MGX_DEV uint32_t conv_probe(const ConvChecker &c, uint32_t mask, uint64_t key, ConvSlot &out, bool &found) {
+    uint32_t h = conv_hash(key, mask);
+    ConvSlot sl = conv_load_slot(c.slots + h);
+    const ConvSlot *slots = c.slots;
+    const uint32_t gen = c.gen;
+    for (;;) {
+        if (sl.gen != gen) { found = false; out = sl; return h; }
+        if (sl.key == key) { found = true; out = sl; return h; }
+        h = (h + 1) & mask;
+        sl = conv_load_slot(slots + h);
     }
 }
 
+// claim free slot `slot` for a new key; returns its vector number or -1 (capacity)
 MGX_DEV int32_t conv_insert(Wave &w, ConvChecker &c, uint32_t slot, uint64_t key, int32_t start, int32_t len) {
     uint32_t cap = uni(w.P->lim.max_columns + w.P->lim.max_path);
     const uint32_t ne = uni(c.n_entries);
     if (ne >= cap || ne * 2 >= uni(w.P->lim.hash_size)) { w.status = ST_CAPACITY; return -1; }
-    uint32_t idx = ne;
     c.n_entries = ne + 1;
-    ConvEntry e; e.key = key; e.start = start; e.len = len;
-    gst(c.entries + idx, e);
-    ConvSlot sl; sl.gen = c.gen; sl.idx = idx;
-    gst(c.slots + slot, sl);
-    return (int32_t)idx;
+    ConvSlot sl; sl.key = key; sl.gen = c.gen; sl.idx = ne; sl.start = start; sl.len = len; sl.pad0 = sl.pad1 = 0;
+    conv_store_slot(c.slots + slot, sl);
+    return (int32_t)ne;
 }
 
 // fill vec positions [a, b) with `val`
@@ -1178,12 +1243,13 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
     if (node == 0) return column_max();
     node = uni(node); query_start = uni(query_start); size = uni(size);
     uint64_t key = (uint64_t)node + (uni(E.rc_view) ? uni(P.g.n) : 0);
-    uint32_t mask = uni(P.lim.hash_size) - 1, slot;
-    int32_t idx = uni(conv_find(E.conv, mask, key, &slot));
-    slot = uni(slot);
+    uint32_t mask = uni(P.lim.hash_size) - 1;
+    ConvSlot e;
+    bool found;
+    const uint32_t slot = conv_probe(E.conv, mask, key, e, found);
     const int32_t Lq = (int32_t)uni(P.lim.Lmax);
-    if (idx < 0) {
-        idx = uni(conv_insert(w, E.conv, slot, key, query_start, size));
+    if (!found) {
+        const int32_t idx = uni(conv_insert(w, E.conv, slot, key, query_start, size));
         if (idx < 0) return NINF;
         int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
         for (int32_t base = 0; base < size; base += WAVE) {
@@ -1192,7 +1258,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         wave_sync();
         return column_max();
     }
-    ConvEntry e = gld(E.conv.entries + idx);
+    const int32_t idx = (int32_t)e.idx;
     int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
     int32_t start = uni(e.start), len = uni(e.len);
     if (query_start + size <= start) {
@@ -1200,8 +1266,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         for (int32_t base = 0; base < size; base += WAVE) {
             FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
         }
-        e.len = start + len - query_start; e.start = query_start;
-        gst(E.conv.entries + idx, e);
+        conv_store_range(E.conv.slots + slot, query_start, start + len - query_start);
         wave_sync();
         return column_max();
     }
@@ -1210,15 +1275,13 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         for (int32_t base = 0; base < size; base += WAVE) {
             FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
         }
-        e.len = query_start + size - start;
-        gst(E.conv.entries + idx, e);
+        conv_store_range(E.conv.slots + slot, start, query_start + size - start);
         wave_sync();
         return column_max();
     }
     if (query_start < start) { fill_range(vec, query_start, start, NINF); len += start - query_start; start = query_start; }
     if (query_start + size > start + len) { fill_range(vec, start + len, query_start + size, NINF); len = query_start + size - start; }
-    e.start = start; e.len = len;
-    gst(E.conv.entries + idx, e);
+    conv_store_range(E.conv.slots + slot, start, len);
     wave_sync();
     int32_t max_changed = NINF;
     const double rel = P.cfg.rel_score_cutoff;
@@ -1248,13 +1311,13 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
 MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int32_t qlen, int32_t clipping, int32_t score) {
     const AlignParams &P = *w.P;
     uint64_t key = (uint64_t)last_node + (E.rc_view ? P.g.n : 0);
-    uint32_t slot;
-    int32_t idx = conv_find(E.conv, P.lim.hash_size - 1, key, &slot);
-    if (idx < 0) return true;
-    ConvEntry e = E.conv.entries[idx];
+    ConvSlot e;
+    bool found;
+    conv_probe(E.conv, P.lim.hash_size - 1, key, e, found);
+    if (!found) return true;
     int32_t pos = qlen + clipping - 1;
     if (pos < e.start || pos - e.start >= e.len) return true;
-    return E.conv.vecs[(uint64_t)idx * P.lim.Lmax + pos] < score;
+    return gld(E.conv.vecs + (uint64_t)e.idx * P.lim.Lmax + pos) < score;
 }
 
 // filter_nodes (:158-207); the key is the raw node id (no RCDBG offset), as in the reference
@@ -1264,34 +1327,33 @@ MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t qu
     const AlignParams &P = *w.P;
     const int32_t mscore = -NINF;
     int32_t size = query_end - query_start;
-    uint32_t slot;
-    int32_t idx = conv_find(E.conv, P.lim.hash_size - 1, (uint64_t)node, &slot);
+    ConvSlot e;
+    bool found;
+    const uint32_t slot = conv_probe(E.conv, P.lim.hash_size - 1, (uint64_t)node, e, found);
     const int32_t Lq = (int32_t)P.lim.Lmax;
-    if (idx < 0) {
-        idx = conv_insert(w, E.conv, slot, (uint64_t)node, query_start, size);
+    if (!found) {
+        const int32_t idx = conv_insert(w, E.conv, slot, (uint64_t)node, query_start, size);
         if (idx < 0) return;
         fill_range(E.conv.vecs + (uint64_t)idx * Lq, query_start, query_end, mscore);
         wave_sync();
         return;
     }
-    ConvEntry e = E.conv.entries[idx];
-    int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
+    int32_t *vec = E.conv.vecs + (uint64_t)e.idx * Lq;
     int32_t start = e.start, len = e.len;
     if (query_start + size <= start) {
         fill_range(vec, query_start + size, start, NINF);
         fill_range(vec, query_start, query_start + size, mscore);
-        e.len = start + len - query_start; e.start = query_start;
+        len = start + len - query_start; start = query_start;
     } else if (query_start >= start + len) {
         fill_range(vec, start + len, query_start, NINF);
         fill_range(vec, query_start, query_end, mscore);
-        e.len = query_start + size - start;
+        len = query_start + size - start;
     } else {
         if (query_start < start) { fill_range(vec, query_start, start, NINF); len += start - query_start; start = query_start; }
         if (query_start + size > start + len) { fill_range(vec, start + len, query_start + size, NINF); len = query_start + size - start; }
         fill_range(vec, query_start, query_end, mscore);      // mscore is the maximum, so max(v, mscore) == mscore
-        e.start = start; e.len = len;
     }
-    E.conv.entries[idx] = e;
+    conv_store_range(E.conv.slots + slot, start, len);
     wave_sync();
 }
 
@@ -1566,24 +1628,9 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
 #undef CE_SET
 #undef CF_SET
 
-MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
-                          uint32_t *nodes, uint8_t *chars, int32_t *scores) {
+// children of `node` in the graph the extender runs on (the graph itself, or its RCDBG view)
+MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node, uint32_t *nodes, uint8_t *chars, int32_t *scores) {
     const AlignParams &P = *w.P;
-    const int32_t k = (int32_t)uni(P.g.k);
-    const int32_t next_offset = col.offset + 1;
-    const int32_t seed_pos = next_offset - uni(seed.offset);
-    const bool in_seed = seed_pos >= 0 && seed_pos < uni(seed.seq_len);
-    if (in_seed && next_offset < k) {
-        nodes[0] = seed.nodes[0]; chars[0] = seed.seq[seed_pos]; scores[0] = 0;
-        return 1;
-    }
-    if (in_seed && force_fixed_seed) {
-        int32_t node_i = next_offset - k + 1;
-        uint32_t next_node = seed.nodes[node_i];
-        nodes[0] = next_node; chars[0] = seed.seq[seed_pos];
-        scores[0] = next_node ? 0 : (!col.node ? P.cfg.gap_ext : P.cfg.gap_open);
-        return 1;
-    }
     uint64_t nn[5];
     uint32_t cc[5];
     int n;
@@ -1591,7 +1638,7 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
         // DBGSuccinct::call_outgoing_kmers (dbg_succinct.cpp:110-139); the node's own block is usually the
         // target block of the expansion that created it
         const DevGraph &g = P.g;
-        const uint64_t v = col.node;
+        const uint64_t v = node;
         Block cur;
         if ((uint32_t)(v >> 6) == uni(w.blk_cache_idx)) cur = uni_block(w.blk_cache);
         else { ++w.ctr.rank_lines; cur = load_block_uniform(g, uni((uint32_t)(v >> 6))); }
@@ -1614,7 +1661,7 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
         return n < 4 ? n : 4;
     }
     // RCDBG::call_outgoing_kmers (rc_dbg.hpp:88-99): parents with the complemented first character
-    n = incoming<true>(P.g, col.node, nn, cc, w.ctr);
+    n = incoming<true>(P.g, node, nn, cc, w.ctr);
     int m = 0;
     for (int t = 0; t < n; ++t) {
         if (cc[t] == 0) continue;                             // complement('$') == '$' is dropped (:381-384)
@@ -1624,60 +1671,78 @@ MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, 
     return m;
 }
 
+
+MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
+                          uint32_t *nodes, uint8_t *chars, int32_t *scores) {
+    const AlignParams &P = *w.P;
+    const int32_t k = (int32_t)uni(P.g.k);
+    const int32_t next_offset = col.offset + 1;
+    const int32_t seed_pos = next_offset - uni(seed.offset);
+    const bool in_seed = seed_pos >= 0 && seed_pos < uni(seed.seq_len);
+    if (in_seed && next_offset < k) {
+        nodes[0] = seed.nodes[0]; chars[0] = seed.seq[seed_pos]; scores[0] = 0;
+        return 1;
+    }
+    if (in_seed && force_fixed_seed) {
+        int32_t node_i = next_offset - k + 1;
+        uint32_t next_node = seed.nodes[node_i];
+        nodes[0] = next_node; chars[0] = seed.seq[seed_pos];
+        scores[0] = next_node ? 0 : (!col.node ? P.cfg.gap_ext : P.cfg.gap_open);
+        return 1;
+    }
+    return graph_children(w, E, col.node, nodes, chars, scores);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Register-resident column chains.
 //
 // Almost every column of an extension is the only child of the column computed just before it (the seed replay —
 // call_outgoing :344-348 — and every non-branching stretch of the graph), and the frontier hands it straight back
-// (:491-504: it is the unique top of the queue).  For such chains the column never leaves the registers: a window of
-// FW = 4 x WAVE cells, four consecutive window positions per lane starting at `org` (a multiple of 4, org <= trim),
-// holds S and F of the parent; the child is computed from it in one pass (update_column :209-290 lane-exactly incl.
-// the 4-wide overshoot, the scalar tail and extend_ins_end), scanned, committed (one record store per array) and
-// entered into the convergence table without touching the staging buffers or the frontier arrays.  Everything that
-// does not fit the pattern — several children, an equal-score batch, a band wider than the window — goes through the
-// general code below with the parent spilled to the staging buffer; results are identical by construction (the same
-// arithmetic on the same values in the same order) and the CPU/GPU parity tests run both with the chain path on
-// and off (AlignParams::no_fast).
+// (:491-504: it is the unique top of the queue).  For such chains the column never touches the staging buffers or the
+// frontier arrays: a window of FW = 4 x WAVE cells, four consecutive window positions per lane starting at `org` (a
+// multiple of 4, org <= trim), holds S and F of the parent; chain_step() computes the child from it in registers
+// (update_column :209-290 lane-exactly incl. the 4-wide overshoot, the scalar tail and extend_ins_end), scans it,
+// commits it (one record store per array) and enters it into the convergence table.  Everything that does not fit
+// the pattern — several children, an equal-score batch, a band wider than the window — goes through general_step()
+// with the parent spilled to a staging buffer; results are identical by construction (the same arithmetic on the same
+// values in the same order) and the CPU/GPU parity tests run with the chain path on and off (AlignParams::no_fast).
+//
+// extend() is a FLAT loop over single steps (pop / chain step / general step): the sub-wave groups of a wavefront
+// work on different reads, and a loop nest would make a group that leaves a chain wait for every other group's
+// chain to end.  All loop-carried state lives in XState (LDS), so each step is a small noinline function with its own
+// register allocation instead of one huge function spilling to scratch.
 // ------------------------------------------------------------------------------------------------
-constexpr int32_t FW = 4 * WAVE;
-
-struct RegCol {                 // a column whose S / F live in registers
-    LV<int32_t> S[4], F[4];
-    int32_t idx, offset, trim, size, max_pos, max_val, org;
-    uint32_t node;
-};
-
-// lane l takes the value of lane l + n of its wave program (n >= 0); lanes past the end get `fill`
-MGX_DEV LV<int32_t> lanes_down(const LV<int32_t> &x, int32_t n, int32_t fill) { return wave_shift_down(x, n, fill); }
-
-MGX_DEV bool fast_fits(const ColMeta &c) { return (c.trim & 3) + c.size + 3 <= FW; }
-
 // select one of four per-lane values by a (group-uniform) slot number
 MGX_DEV int32_t pick4(int32_t a, int32_t b, int32_t c, int32_t d, int32_t s) { return s == 0 ? a : s == 1 ? b : s == 2 ? c : d; }
 
 // value of window position `pos` of a register column (must lie inside the window)
-MGX_DEV int32_t reg_at(const LV<int32_t> *A, int32_t org, int32_t pos) {
+MGX_DEV int32_t reg_at(const LV<int32_t> &A0, const LV<int32_t> &A1, const LV<int32_t> &A2, const LV<int32_t> &A3, int32_t org, int32_t pos) {
     const int32_t x = pos - org;
     LV<int32_t> t;
-    FOR_LANES(l) { t[l] = pick4(A[0][l], A[1][l], A[2][l], A[3][l], x & 3); }
+    FOR_LANES(l) { t[l] = pick4(A0[l], A1[l], A2[l], A3[l], x & 3); }
     return wave_bcast(t, x >> 2);
 }
 
-// load column `idx` (metadata c) into registers from its staging buffer or its arena record
-MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx, RegCol &P) {
-    P.idx = idx; P.node = c.node; P.offset = c.offset; P.trim = c.trim; P.size = c.size; P.max_pos = c.max_pos;
-    P.org = c.trim & ~3;
+MGX_DEV bool fast_fits(const ColMeta &c) { return (c.trim & 3) + c.size + 3 <= FW; }
+
+// load column `idx` (metadata c) into the chain window from its staging buffer or its arena record
+MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx) {
+    XState &x = w.x;
+    x.f_idx = idx; x.f_node = c.node; x.f_offset = c.offset; x.f_trim = c.trim; x.f_size = c.size; x.f_max_pos = c.max_pos;
+    const int32_t org = c.trim & ~3;
+    x.f_org = org;
     const int32_t n = c.size + 5;
     const int sb = (w.st[0].col == idx) ? 0 : (w.st[1].col == idx) ? 1 : -1;
+    LV<int32_t> S[4];
     if (sb >= 0) {
         const Staging st = w.st[sb];
         const int32_t cap = w.st_cap;
         FOR_LANES(l) {
             for (int s = 0; s < 4; ++s) {
-                const int32_t j = P.org + 4 * l + s - c.trim;
+                const int32_t j = org + 4 * l + s - c.trim;
                 const bool in = j >= 0 && j < n;
-                P.S[s][l] = in ? tget(st.S, cap, j) : NINF;
-                P.F[s][l] = in ? tget(st.F, cap, j) : NINF;
+                S[s][l] = in ? tget(st.S, cap, j) : NINF;
+                x.fF[4 * l + s] = in ? tget(st.F, cap, j) : NINF;
             }
         }
     } else {
@@ -1685,165 +1750,625 @@ MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx, RegCol &P) {
         const int32_t *recS = w.cells + c.cells, *recF = recS + wc;
         FOR_LANES(l) {
             for (int s = 0; s < 4; ++s) {
-                const int32_t a = P.org + 4 * l + s, j = a - c.trim, x = a - c.org;
-                const bool in = j >= 0 && j < n && x < wc;
-                P.S[s][l] = in ? gld(recS + x) : NINF;
-                P.F[s][l] = in ? gld(recF + x) : NINF;
+                const int32_t a = org + 4 * l + s, j = a - c.trim, rx = a - c.org;
+                const bool in = j >= 0 && j < n && rx < wc;
+                S[s][l] = in ? gld(recS + rx) : NINF;
+                x.fF[4 * l + s] = in ? gld(recF + rx) : NINF;
             }
         }
     }
-    P.max_val = reg_at(P.S, P.org, c.max_pos);
+    FOR_LANES(l) { for (int s = 0; s < 4; ++s) x.fS[4 * l + s] = S[s][l]; }
+    x.f_max_val = reg_at(S[0], S[1], S[2], S[3], org, c.max_pos);
+    wave_sync();
 }
 
-// the parent goes back to staging buffer 0 in the general layout (cell j = window position trim + j)
-MGX_DEV void fast_spill(Wave &w, const RegCol &P) {
+// the chain's parent goes back to staging buffer 0 in the general layout (cell j = window position trim + j)
+MGX_DEV void fast_spill(Wave &w) {
+    XState &x = w.x;
     Staging &st = w.st[0];
     const int32_t cap = w.st_cap;
-    const int32_t n = P.size + 5;
+    const int32_t n = x.f_size + 5;
     FOR_LANES(l) {
         for (int s = 0; s < 4; ++s) {
-            const int32_t j = P.org + 4 * l + s - P.trim;
-            if (j >= 0 && j < n) { tset(st.S, cap, j, P.S[s][l]); tset(st.F, cap, j, P.F[s][l]); }
+            const int32_t j = x.f_org + 4 * l + s - x.f_trim;
+            if (j >= 0 && j < n) { tset(st.S, cap, j, x.fS[4 * l + s]); tset(st.F, cap, j, x.fF[4 * l + s]); }
         }
     }
     // cells the window does not hold: past its end, or below an origin that moved up with the band (all under the
     // cut-off, or they would have kept the origin down): ninf
-    for (int32_t base = FW - (P.trim - P.org); base < n; base += WAVE) {
+    for (int32_t base = FW - (x.f_trim - x.f_org); base < n; base += WAVE) {
         FOR_LANES(l) { int32_t j = base + l; if (j < n) { tset(st.S, cap, j, NINF); tset(st.F, cap, j, NINF); } }
     }
-    for (int32_t base = 0; base < P.org - P.trim; base += WAVE) {
-        FOR_LANES(l) { int32_t j = base + l; if (j < P.org - P.trim && j < n) { tset(st.S, cap, j, NINF); tset(st.F, cap, j, NINF); } }
+    for (int32_t base = 0; base < x.f_org - x.f_trim; base += WAVE) {
+        FOR_LANES(l) { int32_t j = base + l; if (j < x.f_org - x.f_trim && j < n) { tset(st.S, cap, j, NINF); tset(st.F, cap, j, NINF); } }
     }
-    st.col = P.idx;
-    if (w.st[1].col == P.idx) w.st[1].col = -1;
+    st.col = x.f_idx;
+    if (w.st[1].col == x.f_idx) w.st[1].col = -1;
     wave_sync();
-}
-
-// update_seed_filter (:100-156) for a register column: cell at window position a (j = a - begin in [skip, size)) is
-// query position start + a - 1 of the node's vector.  Returns the converged score (NINF = nothing improved).
-MGX_DEV int32_t conv_update_regs(Wave &w, ExtenderState &E, uint32_t node, int32_t start, int32_t org, int32_t begin,
-                                 int32_t size, const LV<int32_t> *S) {
-    const AlignParams &P = *w.P;
-    const int32_t skip = begin ? 0 : 1;
-    const int32_t n = size - skip;                           // cells entered
-    const int32_t query_start = start + begin - (begin ? 1 : 0);
-    LV<int32_t> cm;
-    FOR_LANES(l) {
-        int32_t m = INT32_MIN;
-        for (int s = 0; s < 4; ++s) {
-            const int32_t j = org + 4 * l + s - begin;
-            if (j >= skip && j < size) m = imax(m, S[s][l]);
-        }
-        cm[l] = m;
-    }
-    if (node == 0) return wave_max(cm);
-    const uint64_t key = (uint64_t)node + (E.rc_view ? P.g.n : 0);
-    const uint32_t mask = P.lim.hash_size - 1;
-    uint32_t slot;
-    int32_t idx = conv_find(E.conv, mask, key, &slot);
-    const int32_t Lq = (int32_t)P.lim.Lmax;
-    auto store_cells = [&](int32_t *vec) {
-        FOR_LANES(l) {
-            for (int s = 0; s < 4; ++s) {
-                const int32_t a = org + 4 * l + s, j = a - begin;
-                if (j >= skip && j < size) gst(vec + start + a - 1, S[s][l]);
-            }
-        }
-    };
-    if (idx < 0) {
-        idx = conv_insert(w, E.conv, slot, key, query_start, n);
-        if (idx < 0) return NINF;
-        store_cells(E.conv.vecs + (uint64_t)idx * Lq);
-        wave_sync();
-        return wave_max(cm);
-    }
-    ConvEntry e = gld(E.conv.entries + idx);
-    int32_t *vec = E.conv.vecs + (uint64_t)idx * Lq;
-    int32_t vstart = e.start, vlen = e.len;
-    if (query_start + n <= vstart) {
-        fill_range(vec, query_start + n, vstart, NINF);
-        store_cells(vec);
-        e.len = vstart + vlen - query_start; e.start = query_start;
-        gst(E.conv.entries + idx, e);
-        wave_sync();
-        return wave_max(cm);
-    }
-    if (query_start >= vstart + vlen) {
-        fill_range(vec, vstart + vlen, query_start, NINF);
-        store_cells(vec);
-        e.len = query_start + n - vstart;
-        gst(E.conv.entries + idx, e);
-        wave_sync();
-        return wave_max(cm);
-    }
-    if (query_start < vstart) { fill_range(vec, query_start, vstart, NINF); vlen += vstart - query_start; vstart = query_start; }
-    if (query_start + n > vstart + vlen) { fill_range(vec, vstart + vlen, query_start + n, NINF); vlen = query_start + n - vstart; }
-    e.start = vstart; e.len = vlen;
-    gst(E.conv.entries + idx, e);
-    wave_sync();
-    const double rel = P.cfg.rel_score_cutoff;
-    LV<int32_t> x;
-    FOR_LANES(l) {
-        int32_t m = NINF;
-        for (int s = 0; s < 4; ++s) {
-            const int32_t a = org + 4 * l + s, j = a - begin;
-            if (j >= skip && j < size) {
-                const int32_t sv = S[s][l];
-                int32_t vv = gld(vec + start + a - 1);
-                if ((double)sv > (double)vv * rel) {
-                    vv = imax(vv, sv);
-                    gst(vec + start + a - 1, vv);
-                    m = imax(m, vv);
-                }
-            }
-        }
-        x[l] = m;
-    }
-    const int32_t r = wave_max(x);
-    wave_sync();
-    return r;
 }
 
 enum { XM_POP = 0, XM_FAST = 1 };
-enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 2, FR_FALLBACK_CHILDREN = 3, FR_STOP = 4, FR_ERROR = 5 };
+enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 3, FR_STOP = 4, FR_ERROR = 5 };
 
-MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
+// ---- general path: one popped column `i` with all its children (staging buffers, frontier arrays) ----
+// returns 0, or 1 = the extension is over (capacity error; w.status says which)
+MGX_NI_G3 int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const int32_t i, const bool children_ready) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
+    MGX_ASSUME_PARAMS(w.P);
+    XState &x = w.x;
+    const AlignParams &P = *w.P;
+    const DevConfig &cfg = P.cfg;
+    const DevLimits &lim = P.lim;
+    const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : gld(w.cols + i));
+    const int32_t max_columns = (int32_t)uni(lim.max_columns);
+    const uint32_t cell_words = uni(lim.cell_words);
+    const double rel_cutoff = cfg.rel_score_cutoff, max_nodes_per_char = cfg.max_nodes_per_seq_char, max_ram = cfg.max_ram_per_alignment;
+    const int32_t xdrop = uni(cfg.xdrop);
+    const int32_t start = x.start, window_size = x.window_size, qlen = x.qlen, psum_lin = x.psum_lin;
+    const int32_t *psum = E.psum;
+    const int32_t seed_off = x.seed_off, seed_seq_len = x.seed_seq_len, seed_offset = x.seed_off - 1;
+    const bool force_fixed_seed = x.force_fixed != 0;
+    uint64_t tx1 = xclock();
+    const int pb = uni(stage_column(w, i, col));
+    const Staging par = w.st[pb];
+    const int32_t cap = uni(w.st_cap);
+    const int32_t next_offset = col.offset + 1;
+    const int32_t prev_xdrop_cutoff = x.xdrop_cutoff;       // global_xdrop: one shared cutoff
+    const bool in_seed = (next_offset - seed_off) >= 0 && (next_offset - seed_off) < seed_seq_len;
+    // early cut-offs when off the optimal path (:521-547)
+    if (!children_ready && uni(st_S(par, cap, col.size, col.max_pos - col.trim)) < x.best_score) {
+        double node_counter = (double)x.tsize;
+        if (node_counter / (double)window_size >= max_nodes_per_char) { x.qn = 0; x.nn = 0; return 0; }
+        if ((double)x.table_size_bytes / 1000000.0 > max_ram) { x.qn = 0; x.nn = 0; return 0; }
+    }
+    // band within the x-drop cutoff (:549-560)
+    int32_t begin, prev_end;
+    {
+        int32_t b = col.size, e = 0;
+        for (int32_t base = 0; base < col.size; base += WAVE) {
+            LV<bool> inr;
+            FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && tget(par.S, cap, j) >= prev_xdrop_cutoff; }
+            uint64_t mk = wave_ballot(inr);
+            if (mk) {
+                if (b == col.size) b = base + ctz64(mk);
+                e = base + 64 - clz64(mk);
+            }
+        }
+        begin = b + col.trim; prev_end = e + col.trim;
+    }
+    if (prev_end <= begin) return 0;
+    uint64_t tx2 = xclock();
+    w.xcyc[1] += tx2 - tx1;
+    // the children list lives in the LDS control block: a private array indexed at run time would sit in scratch
+    uint32_t *out_nodes = w.out_nodes;
+    uint8_t *out_chars = w.out_chars;
+    int32_t *out_scores = w.out_scores;
+    const int n_out = children_ready ? x.f_n_out : uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
+    wave_sync();
+    if (n_out == 0) {
+        if (x.n_tips < max_columns) gst(w.tips + x.n_tips++, (uint32_t)i);
+        return 0;
+    }
+    w.xcyc[2] += xclock() - tx2;
+    const int32_t end = imin(prev_end, window_size) + 1;
+    const int cb = 1 - pb;
+    for (int oi = 0; oi < n_out; ++oi) {
+        const uint32_t next = uni(out_nodes[oi]);
+        const uint8_t c = (uint8_t)uni((uint32_t)to_upper(out_chars[oi]));
+        const int32_t score = uni(out_scores[oi]);
+        if (x.tsize >= max_columns - 1) { w.status = ST_CAPACITY; return 1; }
+        int32_t size0 = end - begin;
+        uint32_t need = rec_words((uint32_t)(window_size + 1 - begin + 8));     // the column may grow to the window end
+        if ((uint64_t)x.cell_top + need > cell_words) { w.status = ST_CAPACITY; return 1; }
+        uint32_t table_cap_before = E.table_cap;
+        if ((uint32_t)x.tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
+        ++w.n_columns;
+        uint64_t tx3 = xclock();
+        const int32_t size = uni(compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
+                                                start, window_size, x.xdrop_cutoff));
+        const int32_t pushes = uni(w.tmp_pushes);
+        uint64_t tx4 = xclock();
+        w.xcyc[3] += tx4 - tx3;
+        ColMeta cur;
+        cur.node = next; cur.parent = i; cur.cw = c; cur.org = begin; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
+        cur.score = score; cur.cells = x.cell_top; cur.size = size;
+        const uint32_t cur_cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
+        const Tier cS = w.st[cb].S;
+        // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
+        const int32_t diag_i = next_offset - seed_offset;
+        bool has_extension = in_seed;
+        const int32_t extension_cutoff =
+            uni((int32_t)fma_f64((double)x.best_score, rel_cutoff, (double)x.partial_sum_offset));
+        int32_t best_s = INT32_MIN, best_d = INT32_MAX, best_j = 0;
+        int32_t min_cell_score = x.min_cell_score;
+        for (int32_t base = 0; base < size; base += WAVE) {
+            LV<int32_t> sv, mn, dd;
+            LV<bool> ext;
+            FOR_LANES(l) {
+                int32_t j = base + l;
+                int32_t v = j < size ? tget(cS, cap, j) : INT32_MIN;
+                sv[l] = v;
+                mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
+                ext[l] = j < size && v + (psum_lin ? (qlen - (start + begin + j)) * psum_lin : psum[start + begin + j]) >= extension_cutoff;
+            }
+            min_cell_score = imin(min_cell_score, wave_min(mn));
+            if (wave_ballot(ext)) has_extension = true;
+            // arg max in the order (S desc, |pos - diag| asc, j asc) (:647-650)
+            const int32_t cm = wave_max(sv);
+            FOR_LANES(l) { int32_t j = base + l; dd[l] = (j < size && sv[l] == cm) ? iabs(j + begin - diag_i) : INT32_MAX; }
+            const int32_t cd = wave_min(dd);
+            LV<bool> hit;
+            FOR_LANES(l) { hit[l] = dd[l] == cd; }
+            const int32_t cj = base + ctz64(wave_ballot(hit));
+            if (cm > best_s || (cm == best_s && cd < best_d)) { best_s = cm; best_d = cd; best_j = cj; }
+        }
+        x.min_cell_score = min_cell_score;
+        cur.max_pos = best_j + begin;
+        const int32_t max_val = best_s;
+        uint64_t tx5 = xclock();
+        w.xcyc[4] += tx5 - tx4;
+        if ((!in_seed && max_val < x.xdrop_cutoff) || (!in_seed && !has_extension)) {
+            // pop(table.size() - 1): the vector keeps its (possibly grown) capacity
+            continue;
+        }
+        uint32_t table_sizediff = E.table_cap - table_cap_before;
+        x.table_size_bytes += (uint64_t)136 * table_sizediff + (uint64_t)cur_cap3 * 4;
+        if ((int32_t)((uint32_t)max_val - (uint32_t)x.xdrop_cutoff) > xdrop) x.xdrop_cutoff = max_val - xdrop;
+        x.best_score = imax(x.best_score, max_val);
+        // commit the column: metadata + cells go to the arena (nothing waits on them)
+        const int32_t cur_wc = flush_column(w, w.st[cb], x.cell_top, size, uni(cfg.gap_ext));
+        cur.cw |= (uint32_t)cur_wc << 8;
+        const int32_t my_idx = x.tsize;
+        gst(w.cols + my_idx, cur);
+        w.hot = cur;
+        w.hot_idx = my_idx;
+        w.st[cb].col = my_idx;
+        x.cell_top += rec_words((uint32_t)cur_wc);
+        x.tsize = my_idx + 1;
+        const int32_t vec_offset = start + begin - (begin ? 1 : 0);
+        const int32_t skip = begin ? 0 : 1;
+        uint64_t tx6 = xclock();
+        w.xcyc[5] += tx6 - tx5;
+        int32_t converged = update_seed_filter(w, E, next, vec_offset, cS, skip, size - skip);
+        uint64_t tx7 = xclock();
+        w.xcyc[6] += tx7 - tx6;
+        if (w.status != ST_OK) return 1;
+        if (converged != NINF) {
+            uint64_t key = queue_key(converged, -iabs(cur.max_pos - diag_i), (uint32_t)my_idx);
+            // next_nodes[0] is the first element popped into this batch (still there unless the batch
+            // has been fully consumed, in which case next_nodes.size() == 0)
+            if (x.nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
+                tier_set(w.lnn, w.next_nodes, x.nn++, key);
+                wave_sync();
+            } else {
+                int32_t qn = x.qn;
+                frontier_insert(w, qn, key);
+                x.qn = qn;
+            }
+        }
+        w.xcyc[7] += xclock() - tx7;
+    }
+    return 0;
+}
+
+// ---- chain path: the only child of the window column, computed, judged and committed in registers ----
+MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
+    MGX_ASSUME_LDS(&w);
+    MGX_ASSUME_LDS(&E);
+    XState &x = w.x;
+    const int32_t xdrop_cutoff = x.xdrop_cutoff;
+    const int32_t start = x.start, window_size = x.window_size, qlen = x.qlen;
+    const int32_t go = x.go, ge = x.ge;
+    uint64_t tx1 = xclock();
+    // early cut-offs when off the optimal path (:521-547)
+    if (x.f_max_val < x.best_score) {
+        double node_counter = (double)x.tsize;
+        if (node_counter / (double)window_size >= x.max_nodes_per_char) return FR_STOP;
+        if ((double)x.table_size_bytes / 1000000.0 > x.max_ram) return FR_STOP;
+    }
+    LV<int32_t> pS[4], pF[4];
+    FOR_LANES(l) { for (int s = 0; s < 4; ++s) { pS[s][l] = x.fS[4 * l + s]; pF[s][l] = x.fF[4 * l + s]; } }
+    int32_t p_org = x.f_org;
+    // band within the x-drop cutoff (:549-560)
+    int32_t begin, prev_end;
+    {
+        LV<int32_t> lo, hi;
+        FOR_LANES(l) {
+            int32_t a0 = INT32_MAX, a1 = INT32_MIN;
+            for (int s = 0; s < 4; ++s) {
+                const int32_t a = p_org + 4 * l + s, j = a - x.f_trim;
+                if (j >= 0 && j < x.f_size && pS[s][l] >= xdrop_cutoff) { a0 = imin(a0, a); a1 = imax(a1, a + 1); }
+            }
+            lo[l] = a0; hi[l] = a1;
+        }
+        begin = wave_min(lo); prev_end = wave_max(hi);
+    }
+    if (prev_end <= begin) return FR_END;
+    // the child (call_outgoing :330-387)
+    const int32_t next_offset = x.f_offset + 1;
+    const int32_t seed_pos = next_offset - x.seed_off;
+    const bool in_seed = seed_pos >= 0 && seed_pos < x.seed_seq_len;
+    const int32_t k = x.k;
+    uint32_t next;
+    uint8_t c;
+    int32_t score;
+    if (in_seed && (next_offset < k || x.force_fixed)) {
+        // the seed replay (:344-372): the node sequence and spelling of the seed, no graph access
+        next = gld(x.seed_nodes + (next_offset < k ? 0 : next_offset - k + 1));
+        c = x.seq_lds ? lds_u8(x.seed_seq + seed_pos) : gld(x.seed_seq + seed_pos);
+        score = (next_offset < k || next) ? 0 : (!x.f_node ? ge : go);
+    } else {
+        const int n_out = graph_children(w, E, x.f_node, w.out_nodes, w.out_chars, w.out_scores);
+        wave_sync();
+        if (n_out == 0) {
+            if (x.n_tips < x.max_columns) gst(w.tips + x.n_tips++, (uint32_t)x.f_idx);
+            return FR_END;
+        }
+        x.f_n_out = n_out;
+        if (n_out != 1) return FR_FALLBACK;
+        next = w.out_nodes[0]; c = w.out_chars[0]; score = w.out_scores[0];
+    }
+    c = to_upper(c);
+    // the convergence table's slot for the child's node: issued now, consumed after the column is computed
+    const uint64_t ckey = (uint64_t)next + x.rc_key_add;
+    const uint32_t cmask = x.hash_mask;
+    const uint32_t chash = conv_hash(ckey, cmask);
+    ConvSlot csl;
+    csl.key = 0; csl.gen = 0; csl.idx = 0; csl.start = 0; csl.len = 0; csl.pad0 = csl.pad1 = 0;
+    if (next) csl = conv_load_slot(E.conv.slots + chash);
+    uint64_t tx3 = xclock();
+    w.xcyc[2] += tx3 - tx1;
+    const int32_t end = imin(prev_end, window_size) + 1;
+    const int32_t size0 = end - begin;
+    const int32_t max_size = window_size + 1 - begin;
+    const int32_t n_prev = prev_end - begin, n_loop = (n_prev + 3) & ~3;
+    const int32_t org = begin & ~3;
+    // from here on a fallback hands the one child over through the children list (general_step reads it from there)
+    x.f_n_out = 1;
+    w.out_nodes[0] = next; w.out_chars[0] = c; w.out_scores[0] = score;
+    if ((begin - org) + imax(n_loop, size0) > FW) { wave_sync(); return FR_FALLBACK; }
+    if (x.tsize >= x.max_columns - 1) { w.status = ST_CAPACITY; return FR_ERROR; }
+    if ((uint64_t)x.cell_top + rec_words((uint32_t)(window_size + 1 - begin + 8)) > x.cell_words) { w.status = ST_CAPACITY; return FR_ERROR; }
+    // move the parent window to the child's origin (whole lanes)
+    if (org != p_org) {
+        const int32_t sh = (org - p_org) >> 2;
+        for (int s = 0; s < 4; ++s) { pS[s] = wave_shift_down(pS[s], sh, NINF); pF[s] = wave_shift_down(pF[s], sh, NINF); }
+        p_org = org;
+    }
+    // update_column (:209-290): cell j = a - begin; j in [0, n_loop) is computed in blocks of four lanes
+    const int8_t *row = w.sm_rows + encode_char(c) * 128;      // a __shared__ array of the kernel
+    const uint8_t *qq = E.q;
+    const bool q_lds = w.q_lds != 0;
+    const LV<int32_t> Sm1_0 = wave_shift_up1(pS[3], NINF);        // parent at a - 1 for slot 0
+    LV<int32_t> cS[4], cF[4], cE[4], mraw[4], tv[4], mm[4];
+    FOR_LANES(l) {
+        for (int s = 0; s < 4; ++s) {
+            const int32_t a = org + 4 * l + s, j = a - begin;
+            const int32_t ap = start + a;
+            int32_t prof = 0;
+            if (ap >= 1 && ap <= qlen) {
+                const uint8_t qc = q_lds ? lds_u8(qq + ap - 1) : gld(qq + ap - 1);
+                prof = (int32_t)lds_i8(row + (qc & 127));
+            }
+            const int32_t sm1 = s == 0 ? Sm1_0[l] : pS[s - 1][l];
+            mraw[s][l] = sm1 + prof + score;                            // S_prev[j - 1] + profile + init_score
+            const bool in = j >= 0 && j < n_loop;
+            int32_t del = NINF;
+            if (next_offset > 1) del = imax(pS[s][l] + go, pF[s][l] + ge) + score;
+            const int32_t match = j >= 1 ? mraw[s][l] : NINF;
+            const int32_t m = imax(match, del);
+            cF[s][l] = in ? del : NINF;
+            mm[s][l] = m;
+            tv[s][l] = in ? m + go - j * ge : INT32_MIN;
+        }
+    }
+    // E[j + 1] = max(E[j] + ge, m[j] + go) == max_{i <= j}(m[i] + go + (j - i) ge) or the E[0] = ninf chain
+    LV<int32_t> tot;
+    FOR_LANES(l) {
+        tv[1][l] = imax(tv[1][l], tv[0][l]); tv[2][l] = imax(tv[2][l], tv[1][l]); tv[3][l] = imax(tv[3][l], tv[2][l]);
+        tot[l] = tv[3][l];
+    }
+    const LV<int32_t> pm = wave_prefix_max(tot);
+    const LV<int32_t> ex = wave_shift_up1(pm, INT32_MIN);             // everything in earlier lanes
+    LV<int32_t> en[4];                                                // E[j + 1] per cell j
+    FOR_LANES(l) {
+        for (int s = 0; s < 4; ++s) {
+            const int32_t a = org + 4 * l + s, j = a - begin;
+            const int32_t t = imax(tv[s][l], ex[l]);
+            const int32_t from_open = t + j * ge;
+            const int64_t fe0 = (int64_t)NINF + (int64_t)(j + 1) * ge;
+            const int32_t from_e0 = fe0 < (int64_t)INT32_MIN ? INT32_MIN : (int32_t)fe0;
+            en[s][l] = (j >= 0 && j < n_loop) ? imax(from_open, from_e0) : NINF;
+        }
+    }
+    const LV<int32_t> en_up = wave_shift_up1(en[3], NINF);
+    FOR_LANES(l) {
+        for (int s = 0; s < 4; ++s) {
+            const int32_t a = org + 4 * l + s, j = a - begin;
+            const int32_t ecur = s == 0 ? en_up[l] : en[s - 1][l];    // E[j] (ninf at j == 0 and wherever nothing was computed)
+            cE[s][l] = (j >= 0 && j <= n_loop) ? ecur : NINF;
+            int32_t sv = NINF;
+            if (j >= 0 && j < n_loop) { sv = imax(mm[s][l], ecur); if (!(sv > xdrop_cutoff - 1)) sv = NINF; }
+            cS[s][l] = sv;
+        }
+    }
+    // scalar tail (:284-289)
+    if (size0 > imax(1, n_prev)) {
+        FOR_LANES(l) {
+            for (int s = 0; s < 4; ++s) {
+                const int32_t j = org + 4 * l + s - begin;
+                if (j == size0 - 1) {
+                    const int32_t match = imax(mraw[s][l], cE[s][l]);
+                    if (match >= xdrop_cutoff) cS[s][l] = match;
+                }
+            }
+        }
+    }
+    // extend_ins_end (:293-328)
+    int32_t size = size0, pushes = 0;
+    if (size0 < max_size) {
+        const int32_t lastS = reg_at(cS[0], cS[1], cS[2], cS[3], org, begin + size0 - 1);
+        const int32_t lastE = reg_at(cE[0], cE[1], cE[2], cE[3], org, begin + size0 - 1);
+        const int32_t ins_score = imax(lastS + go, lastE + ge);
+        if (ins_score >= xdrop_cutoff) {
+            int32_t n_push = 1;
+            const int32_t room = max_size - (size0 + 1);
+            if (ge == 0) {
+                n_push += room;
+            } else {
+                int32_t v = ins_score;
+                while (n_push - 1 < room && v + ge >= xdrop_cutoff) { v += ge; ++n_push; }
+            }
+            if ((begin - org) + size0 + n_push > FW) {
+                // the parent window has moved: keep it consistent for the spill
+                FOR_LANES(l) { for (int s = 0; s < 4; ++s) { x.fS[4 * l + s] = pS[s][l]; x.fF[4 * l + s] = pF[s][l]; } }
+                x.f_org = p_org;
+                wave_sync();
+                return FR_FALLBACK;
+            }
+            FOR_LANES(l) {
+                for (int s = 0; s < 4; ++s) {
+                    const int32_t t = org + 4 * l + s - begin - size0;
+                    if (t >= 0 && t < n_push) { const int32_t v = ins_score + t * ge; cS[s][l] = v; cE[s][l] = v; cF[s][l] = NINF; }
+                    else if (t >= n_push) { cS[s][l] = NINF; cE[s][l] = NINF; cF[s][l] = NINF; }      // padding after the new end
+                }
+            }
+            pushes = n_push;
+            size += n_push;
+        }
+    }
+    uint32_t table_cap_before = E.table_cap;
+    if ((uint32_t)x.tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
+    ++w.n_columns;
+    ++w.n_fast_columns;
+    uint64_t tx4 = xclock();
+    w.xcyc[3] += tx4 - tx3;
+    // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
+    const int32_t psum_lin = x.psum_lin;
+    const int32_t *psum = E.psum;
+    const int32_t diag_i = next_offset - (x.seed_off - 1);
+    const int32_t extension_cutoff = (int32_t)fma_f64((double)x.best_score, x.rel_cutoff, (double)x.partial_sum_offset);
+    LV<int32_t> lmax, lmin;
+    LV<bool> lext;
+    FOR_LANES(l) {
+        int32_t mx = INT32_MIN, mn = INT32_MAX;
+        bool ext = false;
+        for (int s = 0; s < 4; ++s) {
+            const int32_t a = org + 4 * l + s, j = a - begin;
+            if (j >= 0 && j < size) {
+                const int32_t v = cS[s][l];
+                mx = imax(mx, v);
+                if (v != NINF) mn = imin(mn, v);
+                ext |= v + (psum_lin ? (qlen - (start + a)) * psum_lin : psum[start + a]) >= extension_cutoff;
+            }
+        }
+        lmax[l] = mx; lmin[l] = mn; lext[l] = ext;
+    }
+    x.min_cell_score = imin(x.min_cell_score, wave_min(lmin));
+    const bool has_extension = in_seed || wave_ballot(lext) != 0;
+    const int32_t max_val = wave_max(lmax);
+    // arg max in the order (S desc, |pos - diag| asc, j asc) (:647-650): one reduction over (distance, position)
+    LV<int32_t> lkey;
+    FOR_LANES(l) {
+        int32_t kk = INT32_MAX;
+        for (int s = 0; s < 4; ++s) {
+            const int32_t a = org + 4 * l + s, j = a - begin;
+            if (j >= 0 && j < size && cS[s][l] == max_val) kk = imin(kk, (iabs(a - diag_i) << 12) | j);
+        }
+        lkey[l] = kk;
+    }
+    const int32_t max_pos = begin + (wave_min(lkey) & 4095);          // j < FW <= 256, distance < 2^19 (Lmax <= 32704)
+    uint64_t tx5 = xclock();
+    w.xcyc[4] += tx5 - tx4;
+    if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) return FR_END;      // pop(table.size() - 1)
+    const uint32_t cur_cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
+    x.table_size_bytes += (uint64_t)136 * (E.table_cap - table_cap_before) + (uint64_t)cur_cap3 * 4;
+    if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > x.xdrop) x.xdrop_cutoff = max_val - x.xdrop;
+    x.best_score = imax(x.best_score, max_val);
+    // commit: metadata + one record (S, F, E bits) in window layout
+    const int32_t my_idx = x.tsize;
+    ColMeta cur;
+    cur.node = next; cur.parent = x.f_idx; cur.cw = (uint32_t)c | ((uint32_t)FW << 8); cur.org = org; cur.offset = next_offset;
+    cur.max_pos = max_pos; cur.trim = begin; cur.score = score; cur.cells = x.cell_top; cur.size = size;
+    {
+        int32_t *rec = w.cells + x.cell_top;
+        uint8_t *eb = (uint8_t *)(rec + 2 * FW);
+        const LV<int32_t> e_up = wave_shift_up1(cE[3], NINF);
+        FOR_LANES(l) {
+            uint32_t bits = 0;
+            for (int s = 0; s < 4; ++s) {
+                const int32_t j = org + 4 * l + s - begin;
+                const int32_t ep = j <= 0 ? NINF : (s == 0 ? e_up[l] : cE[s - 1][l]);
+                bits |= (uint32_t)(cS[s][l] == cE[s][l]) << (2 * s);
+                bits |= (uint32_t)(cE[s][l] == ep + ge) << (2 * s + 1);
+            }
+            gst4(rec + 4 * l, cS[0][l], cS[1][l], cS[2][l], cS[3][l]);
+            gst4(rec + FW + 4 * l, cF[0][l], cF[1][l], cF[2][l], cF[3][l]);
+            gst(eb + l, (uint8_t)bits);
+        }
+    }
+    FOR_LANES(l) { if (l == 0) gst(w.cols + my_idx, cur); }
+    x.tsize = my_idx + 1;
+    x.cell_top += rec_words((uint32_t)FW);
+    uint64_t tx6 = xclock();
+    w.xcyc[5] += tx6 - tx5;
+    // update_seed_filter (:100-156): cell at window position a (j in [skip, size)) is query position start + a - 1 of the
+    // node's vector.  A position outside the vector's old range holds ninf by definition, so nothing is read back
+    // that this step wrote and no store is ever waited for.
+    int32_t converged;
+    {
+        const int32_t skip = begin ? 0 : 1;
+        const int32_t n = size - skip;
+        const int32_t query_start = start + begin - (begin ? 1 : 0);
+        LV<int32_t> cm;
+        FOR_LANES(l) {
+            int32_t m = INT32_MIN;
+            for (int s = 0; s < 4; ++s) {
+                const int32_t j = org + 4 * l + s - begin;
+                if (j >= skip && j < size) m = imax(m, cS[s][l]);
+            }
+            cm[l] = m;
+        }
+        if (next == 0) {
+            converged = wave_max(cm);
+        } else {
+            bool found;
+            const uint32_t slot = conv_probe_from(E.conv, cmask, ckey, chash, csl, found);
+            const int32_t Lq = x.Lq;
+            if (!found) {
+                const int32_t vi = conv_insert(w, E.conv, slot, ckey, query_start, n);
+                if (vi < 0) return FR_ERROR;
+                int32_t *vec = E.conv.vecs + (uint64_t)vi * Lq;
+                FOR_LANES(l) {
+                    for (int s = 0; s < 4; ++s) {
+                        const int32_t a = org + 4 * l + s, j = a - begin;
+                        if (j >= skip && j < size) gst(vec + start + a - 1, cS[s][l]);
+                    }
+                }
+                converged = wave_max(cm);
+            } else {
+                // re-read the slot found by a later probe step
+                if (slot != chash) csl = conv_load_slot(E.conv.slots + slot);
+                int32_t *vec = E.conv.vecs + (uint64_t)csl.idx * Lq;
+                const int32_t vstart = csl.start, vlen = csl.len;
+                if (query_start + n <= vstart || query_start >= vstart + vlen) {
+                    // disjoint: the gap is filled with ninf, the column is stored as it is
+                    if (query_start + n <= vstart) {
+                        fill_range(vec, query_start + n, vstart, NINF);
+                        conv_store_range(E.conv.slots + slot, query_start, vstart + vlen - query_start);
+                    } else {
+                        fill_range(vec, vstart + vlen, query_start, NINF);
+                        conv_store_range(E.conv.slots + slot, vstart, query_start + n - vstart);
+                    }
+                    FOR_LANES(l) {
+                        for (int s = 0; s < 4; ++s) {
+                            const int32_t a = org + 4 * l + s, j = a - begin;
+                            if (j >= skip && j < size) gst(vec + start + a - 1, cS[s][l]);
+                        }
+                    }
+                    converged = wave_max(cm);
+                } else {
+                    const int32_t nstart = imin(vstart, query_start);
+                    const int32_t nend = imax(vstart + vlen, query_start + n);
+                    if (nstart != vstart || nend != vstart + vlen) conv_store_range(E.conv.slots + slot, nstart, nend - nstart);
+                    const double rel = x.rel_cutoff;
+                    LV<int32_t> xm;
+                    FOR_LANES(l) {
+                        int32_t m = NINF;
+                        for (int s = 0; s < 4; ++s) {
+                            const int32_t a = org + 4 * l + s, j = a - begin;
+                            if (j >= skip && j < size) {
+                                const int32_t pos = start + a - 1;
+                                const bool old = pos >= vstart && pos < vstart + vlen;
+                                const int32_t sv = cS[s][l];
+                                int32_t vv = old ? gld(vec + pos) : NINF;
+                                if ((double)sv > (double)vv * rel) {
+                                    vv = imax(vv, sv);
+                                    gst(vec + pos, vv);
+                                    m = imax(m, vv);
+                                } else if (!old) {
+                                    gst(vec + pos, NINF);
+                                }
+                            }
+                        }
+                        xm[l] = m;
+                    }
+                    converged = wave_max(xm);
+                }
+            }
+        }
+    }
+    uint64_t tx7 = xclock();
+    w.xcyc[6] += tx7 - tx6;
+    if (w.status != ST_OK) return FR_ERROR;
+    if (converged == NINF) return FR_END;
+    // the frontier would hand this column straight back iff it is the unique maximum (:491-504)
+    if (x.nn == 0 && (x.qn == 0 || converged > key_score(tier_get(w.lq, w.queue, x.qn - 1))) && fast_fits(cur)) {
+        FOR_LANES(l) { for (int s = 0; s < 4; ++s) { x.fS[4 * l + s] = cS[s][l]; x.fF[4 * l + s] = cF[s][l]; } }
+        x.f_idx = my_idx; x.f_node = next; x.f_offset = next_offset; x.f_trim = begin; x.f_size = size; x.f_max_pos = max_pos;
+        x.f_max_val = max_val; x.f_org = org;
+        wave_sync();
+        w.xcyc[7] += xclock() - tx7;
+        return FR_CONT;
+    }
+    {
+        uint64_t key = queue_key(converged, -iabs(max_pos - diag_i), (uint32_t)my_idx);
+        if (x.nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
+            tier_set(w.lnn, w.next_nodes, x.nn++, key);
+            wave_sync();
+        } else {
+            int32_t qn = x.qn;
+            frontier_insert(w, qn, key);
+            x.qn = qn;
+        }
+        w.hot = cur;
+        w.hot_idx = my_idx;
+    }
+    w.xcyc[7] += xclock() - tx7;
+    return FR_END;
+}
+
+MGX_DEV void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
     ExtendResult *res = &w.er;
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const DevLimits &lim = P.lim;
-    const int32_t max_columns = (int32_t)uni(lim.max_columns);
-    const uint32_t cell_words = uni(lim.cell_words);
-    const double rel_cutoff = cfg.rel_score_cutoff, max_nodes_per_char = cfg.max_nodes_per_seq_char, max_ram = cfg.max_ram_per_alignment;
+    XState &x = w.x;
     ++w.n_extensions;
     // table.clear(); prev_starts.clear()
     for (uint32_t base = 0; base < (lim.max_columns + 31) / 32; base += WAVE) {
         FOR_LANES(l) { uint32_t j = base + l; if (j < (lim.max_columns + 31) / 32) w.prev_starts[j] = 0; }
     }
     const int32_t xdrop = uni(cfg.xdrop);                     // added_xdrop == 0
-    int32_t xdrop_cutoff = imax(-xdrop, NINF + 1);
-    const int32_t start = uni(seed.clipping);
-    const int32_t window_size = uni(w.L) - start;             // trim_query_suffix == 0
-    const int32_t *psum = (const int32_t *)uni((uint64_t)E.psum);
-    const int32_t psum_lin = uni(E.psum_lin);
-    const int32_t qlen = uni(w.L);
-    const int32_t partial_sum_offset = psum_lin ? (qlen - (start + window_size)) * psum_lin : uni(psum[start + window_size]);
-    const int32_t seed_offset = uni(seed.offset) - 1;
-    const int32_t seed_off = uni(seed.offset), seed_seq_len = uni(seed.seq_len);
-    const int32_t go = uni(cfg.gap_open), ge = uni(cfg.gap_ext);
-    uint32_t cell_top = 0;
-    int32_t tsize = 0;
-    uint64_t table_size_bytes = 0;
+    x.xdrop_cutoff = imax(-xdrop, NINF + 1);
+    x.start = uni(seed.clipping);
+    x.window_size = uni(w.L) - x.start;                       // trim_query_suffix == 0
+    x.qlen = uni(w.L);
+    x.psum_lin = uni(E.psum_lin);
+    x.partial_sum_offset = x.psum_lin ? (x.qlen - (x.start + x.window_size)) * x.psum_lin : uni(E.psum[x.start + x.window_size]);
+    x.seed_off = uni(seed.offset);
+    x.seed_seq_len = uni(seed.seq_len);
+    x.force_fixed = force_fixed_seed ? 1 : 0;
+    x.seed_nodes = seed.nodes;
+    x.seed_seq = seed.seq;
+    x.seq_lds = (w.q_lds && seed.seq >= w.q[seed.orientation] && seed.seq < w.q[seed.orientation] + w.L) ? 1 : 0;
+    x.rc_key_add = E.rc_view ? P.g.n : 0;
+    x.rel_cutoff = cfg.rel_score_cutoff; x.max_nodes_per_char = cfg.max_nodes_per_seq_char; x.max_ram = cfg.max_ram_per_alignment;
+    x.go = cfg.gap_open; x.ge = cfg.gap_ext; x.xdrop = cfg.xdrop; x.k = (int32_t)P.g.k; x.Lq = (int32_t)lim.Lmax;
+    x.max_columns = (int32_t)lim.max_columns; x.hash_mask = lim.hash_size - 1; x.cell_words = lim.cell_words;
+    x.cell_top = 0;
+    x.tsize = 0;
+    x.table_size_bytes = 0;
+    x.f_n_out = 0;
     w.st[0].col = -1; w.st[1].col = -1;
     w.hot_idx = -1;
     w.blk_cache_idx = 0xFFFFFFFFu;
     // root column (:455-470)
     {
         ColMeta r;
-        r.node = seed.nodes[0]; r.parent = -1; r.cw = 0; r.org = 0; r.offset = seed_offset; r.max_pos = 0; r.trim = 0;
-        r.score = 0; r.cells = cell_top; r.size = 1;
+        r.node = seed.nodes[0]; r.parent = -1; r.cw = 0; r.org = 0; r.offset = x.seed_off - 1; r.max_pos = 0; r.trim = 0;
+        r.score = 0; r.cells = 0; r.size = 1;
         Staging &s0 = w.st[0];
         const int32_t cap = w.st_cap;
         for (int32_t base = 0; base < 8; base += WAVE) {
@@ -1853,14 +2378,14 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         int32_t sroot = (cfg.left_end_bonus && !seed.clipping) ? cfg.left_end_bonus : 0;
         FOR_LANES(l) { if (l == 0) tset(s0.S, cap, 0, sroot); }
         wave_sync();
-        int32_t max_size = window_size + 1;
+        int32_t max_size = x.window_size + 1;
         int32_t pushes = 0;
         if (1 < max_size) {
             int32_t ins_score = imax(sroot + cfg.gap_open, NINF + cfg.gap_ext);
-            if (ins_score >= xdrop_cutoff) {
+            if (ins_score >= x.xdrop_cutoff) {
                 int32_t n_push = 1, room = max_size - 2;
                 if (cfg.gap_ext == 0) n_push += room;
-                else { int32_t v = ins_score; while (n_push - 1 < room && v + cfg.gap_ext >= xdrop_cutoff) { v += cfg.gap_ext; ++n_push; } }
+                else { int32_t v = ins_score; while (n_push - 1 < room && v + cfg.gap_ext >= x.xdrop_cutoff) { v += cfg.gap_ext; ++n_push; } }
                 for (int32_t base = 0; base < n_push + 5; base += WAVE) {
                     FOR_LANES(l) {
                         int32_t t = base + l;
@@ -1879,466 +2404,73 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         if ((uint64_t)rec_words((uint32_t)r.size + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
         const uint32_t root_cap3 = 3 * ref_capacity(1, (uint32_t)pushes);
         wave_sync();
-        const int32_t root_wc = flush_column(w, s0, cell_top, r.size, cfg.gap_ext);
+        const int32_t root_wc = flush_column(w, s0, 0, r.size, cfg.gap_ext);
         r.cw = (uint32_t)root_wc << 8;
         s0.col = 0;
-        cell_top += rec_words((uint32_t)root_wc);
+        x.cell_top = rec_words((uint32_t)root_wc);
         if (E.table_cap < 1) E.table_cap = 1;                 // emplace_back on an empty vector
         gst(w.cols + 0, r);
         w.hot = r;
         w.hot_idx = 0;
-        tsize = 1;
-        table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)root_cap3 * 4;
+        x.tsize = 1;
+        x.table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)root_cap3 * 4;
     }
-    int32_t min_cell_score = 0;
-    int32_t best_score = 0;
-    int32_t qn = 0, nn = 0, n_tips = 0;
-    frontier_insert(w, qn, queue_key(0, 0, 0));
-
-    // ---- general path: one popped column `i` with all its children (staging buffers, frontier arrays) ----
-    // returns 0, or 1 = the extension is over (cut-off or capacity error; w.status says which)
-    auto general = [&](const int32_t i, const ColMeta col, const bool children_ready, int n_out_ready) -> int {
-        uint64_t tx1 = xclock();
-        const int pb = uni(stage_column(w, i, col));
-        const Staging par = w.st[pb];
-        const int32_t cap = uni(w.st_cap);
-        const int32_t next_offset = col.offset + 1;
-        const int32_t prev_xdrop_cutoff = xdrop_cutoff;       // global_xdrop: one shared cutoff
-        const bool in_seed = (next_offset - seed_off) >= 0 && (next_offset - seed_off) < seed_seq_len;
-        int32_t begin, prev_end;
-        // early cut-offs when off the optimal path (:521-547)
-        if (!children_ready && uni(st_S(par, cap, col.size, col.max_pos - col.trim)) < best_score) {
-            double node_counter = (double)tsize;
-            if (node_counter / (double)window_size >= max_nodes_per_char) { qn = 0; nn = 0; return 0; }
-            if ((double)table_size_bytes / 1000000.0 > max_ram) { qn = 0; nn = 0; return 0; }
-        }
-        // band within the x-drop cutoff (:549-560)
-        {
-            int32_t b = col.size, e = 0;
-            for (int32_t base = 0; base < col.size; base += WAVE) {
-                LV<bool> inr;
-                FOR_LANES(l) { int32_t j = base + l; inr[l] = j < col.size && tget(par.S, cap, j) >= prev_xdrop_cutoff; }
-                uint64_t mk = wave_ballot(inr);
-                if (mk) {
-                    if (b == col.size) b = base + ctz64(mk);
-                    e = base + 64 - clz64(mk);
-                }
-            }
-            begin = b + col.trim; prev_end = e + col.trim;
-        }
-        if (prev_end <= begin) return 0;
-        uint64_t tx2 = xclock();
-        w.xcyc[1] += tx2 - tx1;
-        // the children list lives in the LDS control block: a private array indexed at run time would sit in scratch
-        uint32_t *out_nodes = w.out_nodes;
-        uint8_t *out_chars = w.out_chars;
-        int32_t *out_scores = w.out_scores;
-        const int n_out = children_ready ? n_out_ready : uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
-        wave_sync();
-        if (n_out == 0) {
-            if (n_tips < max_columns) gst(w.tips + n_tips++, (uint32_t)i);
-            return 0;
-        }
-        w.xcyc[2] += xclock() - tx2;
-        const int32_t end = imin(prev_end, window_size) + 1;
-        const int cb = 1 - pb;
-        for (int oi = 0; oi < n_out; ++oi) {
-            const uint32_t next = uni(out_nodes[oi]);
-            const uint8_t c = (uint8_t)uni((uint32_t)to_upper(out_chars[oi]));
-            const int32_t score = uni(out_scores[oi]);
-            if (tsize >= max_columns - 1) { w.status = ST_CAPACITY; return 1; }
-            int32_t size0 = end - begin;
-            uint32_t need = rec_words((uint32_t)(window_size + 1 - begin + 8));     // the column may grow to the window end
-            if ((uint64_t)cell_top + need > cell_words) { w.status = ST_CAPACITY; return 1; }
-            uint32_t table_cap_before = E.table_cap;
-            if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
-            ++w.n_columns;
-            uint64_t tx3 = xclock();
-            const int32_t size = uni(compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
-                                                    start, window_size, xdrop_cutoff));
-            const int32_t pushes = uni(w.tmp_pushes);
-            uint64_t tx4 = xclock();
-            w.xcyc[3] += tx4 - tx3;
-            ColMeta cur;
-            cur.node = next; cur.parent = i; cur.cw = c; cur.org = begin; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
-            cur.score = score; cur.cells = cell_top; cur.size = size;
-            const uint32_t cur_cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
-            const Tier cS = w.st[cb].S;
-            // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
-            const int32_t diag_i = next_offset - seed_offset;
-            bool has_extension = in_seed;
-            const int32_t extension_cutoff =
-                uni((int32_t)fma_f64((double)best_score, rel_cutoff, (double)partial_sum_offset));
-            int32_t best_s = INT32_MIN, best_d = INT32_MAX, best_j = 0;
-            for (int32_t base = 0; base < size; base += WAVE) {
-                LV<int32_t> sv, mn, dd;
-                LV<bool> ext;
-                FOR_LANES(l) {
-                    int32_t j = base + l;
-                    int32_t v = j < size ? tget(cS, cap, j) : INT32_MIN;
-                    sv[l] = v;
-                    mn[l] = (j < size && v != NINF) ? v : INT32_MAX;
-                    ext[l] = j < size && v + (psum_lin ? (qlen - (start + begin + j)) * psum_lin : psum[start + begin + j]) >= extension_cutoff;
-                }
-                min_cell_score = imin(min_cell_score, wave_min(mn));
-                if (wave_ballot(ext)) has_extension = true;
-                // arg max in the order (S desc, |pos - diag| asc, j asc) (:647-650)
-                const int32_t cm = wave_max(sv);
-                FOR_LANES(l) { int32_t j = base + l; dd[l] = (j < size && sv[l] == cm) ? iabs(j + begin - diag_i) : INT32_MAX; }
-                const int32_t cd = wave_min(dd);
-                LV<bool> hit;
-                FOR_LANES(l) { hit[l] = dd[l] == cd; }
-                const int32_t cj = base + ctz64(wave_ballot(hit));
-                if (cm > best_s || (cm == best_s && cd < best_d)) { best_s = cm; best_d = cd; best_j = cj; }
-            }
-            cur.max_pos = best_j + begin;
-            const int32_t max_val = best_s;
-            uint64_t tx5 = xclock();
-            w.xcyc[4] += tx5 - tx4;
-            if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) {
-                // pop(table.size() - 1): the vector keeps its (possibly grown) capacity
-                continue;
-            }
-            uint32_t table_sizediff = E.table_cap - table_cap_before;
-            table_size_bytes += (uint64_t)136 * table_sizediff + (uint64_t)cur_cap3 * 4;
-            if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
-            best_score = imax(best_score, max_val);
-            // commit the column: metadata + cells go to the arena (nothing waits on them)
-            const int32_t cur_wc = flush_column(w, w.st[cb], cell_top, size, ge);
-            cur.cw |= (uint32_t)cur_wc << 8;
-            gst(w.cols + tsize, cur);
-            w.hot = cur;
-            w.hot_idx = tsize;
-            w.st[cb].col = tsize;
-            cell_top += rec_words((uint32_t)cur_wc);
-            const int32_t my_idx = tsize;
-            ++tsize;
-            const int32_t vec_offset = start + begin - (begin ? 1 : 0);
-            const int32_t skip = begin ? 0 : 1;
-            uint64_t tx6 = xclock();
-            w.xcyc[5] += tx6 - tx5;
-            int32_t converged = update_seed_filter(w, E, next, vec_offset, cS, skip, size - skip);
-            uint64_t tx7 = xclock();
-            w.xcyc[6] += tx7 - tx6;
-            if (w.status != ST_OK) return 1;
-            if (converged != NINF) {
-                uint64_t key = queue_key(converged, -iabs(cur.max_pos - diag_i), (uint32_t)my_idx);
-                // next_nodes[0] is the first element popped into this batch (still there unless the batch
-                // has been fully consumed, in which case next_nodes.size() == 0)
-                if (nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
-                    tier_set(w.lnn, w.next_nodes, nn++, key);
-                    wave_sync();
-                } else {
-                    frontier_insert(w, qn, key);
-                }
-            }
-            w.xcyc[7] += xclock() - tx7;
-        }
-        return 0;
-    };
-
-    // ---- chain path: the child of the register column Pc, computed, judged and committed in registers ----
-    RegCol Pc;
-    FOR_LANES(l) { for (int s = 0; s < 4; ++s) { Pc.S[s][l] = NINF; Pc.F[s][l] = NINF; } }
-    Pc.idx = 0; Pc.offset = 0; Pc.trim = 0; Pc.size = 0; Pc.max_pos = 0; Pc.max_val = 0; Pc.org = 0; Pc.node = 0;
-    int fast_n_out = 0;
-    const uint8_t *qq = E.q;
-    MGX_ASSUME_LDS(w.sm_rows);
-    auto fast_step = [&]() -> int {
-        uint64_t tx1 = xclock();
-        // early cut-offs when off the optimal path (:521-547)
-        if (Pc.max_val < best_score) {
-            double node_counter = (double)tsize;
-            if (node_counter / (double)window_size >= max_nodes_per_char) return FR_STOP;
-            if ((double)table_size_bytes / 1000000.0 > max_ram) return FR_STOP;
-        }
-        // band within the x-drop cutoff (:549-560)
-        int32_t begin, prev_end;
-        {
-            LV<int32_t> lo, hi;
-            FOR_LANES(l) {
-                int32_t a0 = INT32_MAX, a1 = INT32_MIN;
-                for (int s = 0; s < 4; ++s) {
-                    const int32_t a = Pc.org + 4 * l + s, j = a - Pc.trim;
-                    if (j >= 0 && j < Pc.size && Pc.S[s][l] >= xdrop_cutoff) { a0 = imin(a0, a); a1 = imax(a1, a + 1); }
-                }
-                lo[l] = a0; hi[l] = a1;
-            }
-            begin = wave_min(lo); prev_end = wave_max(hi);
-        }
-        if (prev_end == INT32_MIN || prev_end <= begin) return FR_END;
-        uint64_t tx2 = xclock();
-        w.xcyc[1] += tx2 - tx1;
-        const int32_t next_offset = Pc.offset + 1;
-        const bool in_seed = (next_offset - seed_off) >= 0 && (next_offset - seed_off) < seed_seq_len;
-        ColMeta pc;
-        pc.node = Pc.node; pc.offset = Pc.offset; pc.parent = 0; pc.max_pos = Pc.max_pos; pc.trim = Pc.trim; pc.size = Pc.size;
-        pc.score = 0; pc.cells = 0; pc.cw = 0; pc.org = Pc.org;
-        const int n_out = call_outgoing(w, E, seed, pc, force_fixed_seed, w.out_nodes, w.out_chars, w.out_scores);
-        wave_sync();
-        w.xcyc[2] += xclock() - tx2;
-        if (n_out == 0) {
-            if (n_tips < max_columns) gst(w.tips + n_tips++, (uint32_t)Pc.idx);
-            return FR_END;
-        }
-        if (n_out != 1) { fast_n_out = n_out; return FR_FALLBACK_CHILDREN; }
-        uint64_t tx3 = xclock();
-        const uint32_t next = w.out_nodes[0];
-        const uint8_t c = to_upper(w.out_chars[0]);
-        const int32_t score = w.out_scores[0];
-        const int32_t end = imin(prev_end, window_size) + 1;
-        const int32_t size0 = end - begin;
-        const int32_t max_size = window_size + 1 - begin;
-        const int32_t n_prev = prev_end - begin, n_loop = (n_prev + 3) & ~3;
-        const int32_t org = begin & ~3;
-        if ((begin - org) + imax(n_loop, size0) > FW) { fast_n_out = 1; return FR_FALLBACK_CHILDREN; }
-        if (tsize >= max_columns - 1) { w.status = ST_CAPACITY; return FR_ERROR; }
-        if ((uint64_t)cell_top + rec_words((uint32_t)(window_size + 1 - begin + 8)) > cell_words) { w.status = ST_CAPACITY; return FR_ERROR; }
-        // move the parent window to the child's origin (whole lanes)
-        if (org != Pc.org) {
-            const int32_t sh = (org - Pc.org) >> 2;
-            for (int s = 0; s < 4; ++s) { Pc.S[s] = lanes_down(Pc.S[s], sh, NINF); Pc.F[s] = lanes_down(Pc.F[s], sh, NINF); }
-            Pc.org = org;
-        }
-        // update_column (:209-290): cell j = a - begin; j in [0, n_loop) is computed in blocks of four lanes
-        const int8_t *row = w.sm_rows + encode_char(c) * 128;
-        const LV<int32_t> Sm1_0 = wave_shift_up1(Pc.S[3], NINF);        // parent at a - 1 for slot 0
-        LV<int32_t> cS[4], cF[4], cE[4], mraw[4], tv[4], mm[4];
-        FOR_LANES(l) {
-            for (int s = 0; s < 4; ++s) {
-                const int32_t a = org + 4 * l + s, j = a - begin;
-                const int32_t ap = start + a;
-                const int32_t prof = (ap >= 1 && ap <= qlen) ? (int32_t)row[qq[ap - 1] & 127] : 0;
-                const int32_t sm1 = s == 0 ? Sm1_0[l] : Pc.S[s - 1][l];
-                mraw[s][l] = sm1 + prof + score;                            // S_prev[j - 1] + profile + init_score
-                const bool in = j >= 0 && j < n_loop;
-                int32_t del = NINF;
-                if (next_offset > 1) del = imax(Pc.S[s][l] + go, Pc.F[s][l] + ge) + score;
-                const int32_t match = j >= 1 ? mraw[s][l] : NINF;
-                const int32_t m = imax(match, del);
-                cF[s][l] = in ? del : NINF;
-                mm[s][l] = m;
-                tv[s][l] = in ? m + go - j * ge : INT32_MIN;
-            }
-        }
-        // E[j + 1] = max(E[j] + ge, m[j] + go) == max_{i <= j}(m[i] + go + (j - i) ge) or the E[0] = ninf chain
-        LV<int32_t> tot;
-        FOR_LANES(l) {
-            tv[1][l] = imax(tv[1][l], tv[0][l]); tv[2][l] = imax(tv[2][l], tv[1][l]); tv[3][l] = imax(tv[3][l], tv[2][l]);
-            tot[l] = tv[3][l];
-        }
-        const LV<int32_t> pm = wave_prefix_max(tot);
-        const LV<int32_t> ex = wave_shift_up1(pm, INT32_MIN);             // everything in earlier lanes
-        LV<int32_t> en[4];                                                // E[j + 1] per cell j
-        FOR_LANES(l) {
-            for (int s = 0; s < 4; ++s) {
-                const int32_t a = org + 4 * l + s, j = a - begin;
-                const int32_t t = imax(tv[s][l], ex[l]);
-                const int32_t from_open = t + j * ge;
-                const int64_t fe0 = (int64_t)NINF + (int64_t)(j + 1) * ge;
-                const int32_t from_e0 = fe0 < (int64_t)INT32_MIN ? INT32_MIN : (int32_t)fe0;
-                en[s][l] = (j >= 0 && j < n_loop) ? imax(from_open, from_e0) : NINF;
-            }
-        }
-        const LV<int32_t> en_up = wave_shift_up1(en[3], NINF);
-        FOR_LANES(l) {
-            for (int s = 0; s < 4; ++s) {
-                const int32_t a = org + 4 * l + s, j = a - begin;
-                const int32_t ecur = s == 0 ? en_up[l] : en[s - 1][l];    // E[j] (ninf at j == 0 and wherever nothing was computed)
-                cE[s][l] = (j >= 0 && j <= n_loop) ? ecur : NINF;
-                int32_t sv = NINF;
-                if (j >= 0 && j < n_loop) { sv = imax(mm[s][l], ecur); if (!(sv > xdrop_cutoff - 1)) sv = NINF; }
-                cS[s][l] = sv;
-            }
-        }
-        // scalar tail (:284-289)
-        if (size0 > imax(1, n_prev)) {
-            FOR_LANES(l) {
-                for (int s = 0; s < 4; ++s) {
-                    const int32_t j = org + 4 * l + s - begin;
-                    if (j == size0 - 1) {
-                        const int32_t match = imax(mraw[s][l], cE[s][l]);
-                        if (match >= xdrop_cutoff) cS[s][l] = match;
-                    }
-                }
-            }
-        }
-        // extend_ins_end (:293-328)
-        int32_t size = size0, pushes = 0;
-        if (size0 < max_size) {
-            const int32_t lastS = reg_at(cS, org, begin + size0 - 1), lastE = reg_at(cE, org, begin + size0 - 1);
-            const int32_t ins_score = imax(lastS + go, lastE + ge);
-            if (ins_score >= xdrop_cutoff) {
-                int32_t n_push = 1;
-                const int32_t room = max_size - (size0 + 1);
-                if (ge == 0) {
-                    n_push += room;
-                } else {
-                    int32_t v = ins_score;
-                    while (n_push - 1 < room && v + ge >= xdrop_cutoff) { v += ge; ++n_push; }
-                }
-                if ((begin - org) + size0 + n_push > FW) { fast_n_out = 1; return FR_FALLBACK_CHILDREN; }
-                FOR_LANES(l) {
-                    for (int s = 0; s < 4; ++s) {
-                        const int32_t t = org + 4 * l + s - begin - size0;
-                        if (t >= 0 && t < n_push) { const int32_t v = ins_score + t * ge; cS[s][l] = v; cE[s][l] = v; cF[s][l] = NINF; }
-                        else if (t >= n_push) { cS[s][l] = NINF; cE[s][l] = NINF; cF[s][l] = NINF; }      // padding after the new end
-                    }
-                }
-                pushes = n_push;
-                size += n_push;
-            }
-        }
-        uint32_t table_cap_before = E.table_cap;
-        if ((uint32_t)tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
-        ++w.n_columns;
-        ++w.n_fast_columns;
-        uint64_t tx4 = xclock();
-        w.xcyc[3] += tx4 - tx3;
-        // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
-        const int32_t diag_i = next_offset - seed_offset;
-        const int32_t extension_cutoff = (int32_t)fma_f64((double)best_score, rel_cutoff, (double)partial_sum_offset);
-        LV<int32_t> lmax, lmin;
-        LV<bool> lext;
-        FOR_LANES(l) {
-            int32_t mx = INT32_MIN, mn = INT32_MAX;
-            bool ext = false;
-            for (int s = 0; s < 4; ++s) {
-                const int32_t a = org + 4 * l + s, j = a - begin;
-                if (j >= 0 && j < size) {
-                    const int32_t v = cS[s][l];
-                    mx = imax(mx, v);
-                    if (v != NINF) mn = imin(mn, v);
-                    ext |= v + (psum_lin ? (qlen - (start + a)) * psum_lin : psum[start + a]) >= extension_cutoff;
-                }
-            }
-            lmax[l] = mx; lmin[l] = mn; lext[l] = ext;
-        }
-        min_cell_score = imin(min_cell_score, wave_min(lmin));
-        const bool has_extension = in_seed || wave_ballot(lext) != 0;
-        const int32_t max_val = wave_max(lmax);
-        // arg max in the order (S desc, |pos - diag| asc, j asc) (:647-650): one reduction over (distance, position)
-        LV<int32_t> lkey;
-        FOR_LANES(l) {
-            int32_t kk = INT32_MAX;
-            for (int s = 0; s < 4; ++s) {
-                const int32_t a = org + 4 * l + s, j = a - begin;
-                if (j >= 0 && j < size && cS[s][l] == max_val) kk = imin(kk, (iabs(a - diag_i) << 12) | j);
-            }
-            lkey[l] = kk;
-        }
-        int32_t max_pos;
-        if (size < 4096 && window_size < (1 << 18)) {
-            max_pos = begin + (wave_min(lkey) & 4095);
-        } else {
-            // (never taken with a register window; kept so that the packing above cannot silently overflow)
-            fast_n_out = 1; return FR_FALLBACK_CHILDREN;
-        }
-        uint64_t tx5 = xclock();
-        w.xcyc[4] += tx5 - tx4;
-        if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) return FR_END;      // pop(table.size() - 1)
-        const uint32_t cur_cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
-        uint32_t table_sizediff = E.table_cap - table_cap_before;
-        table_size_bytes += (uint64_t)136 * table_sizediff + (uint64_t)cur_cap3 * 4;
-        if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
-        best_score = imax(best_score, max_val);
-        // commit: metadata + one record (S, F, E bits) in window layout
-        ColMeta cur;
-        cur.node = next; cur.parent = Pc.idx; cur.cw = (uint32_t)c | ((uint32_t)FW << 8); cur.org = org; cur.offset = next_offset;
-        cur.max_pos = max_pos; cur.trim = begin; cur.score = score; cur.cells = cell_top; cur.size = size;
-        {
-            int32_t *rec = w.cells + cell_top;
-            uint8_t *eb = (uint8_t *)(rec + 2 * FW);
-            const LV<int32_t> e_up = wave_shift_up1(cE[3], NINF);
-            FOR_LANES(l) {
-                uint32_t bits = 0;
-                for (int s = 0; s < 4; ++s) {
-                    const int32_t j = org + 4 * l + s - begin;
-                    gst(rec + 4 * l + s, cS[s][l]);
-                    gst(rec + FW + 4 * l + s, cF[s][l]);
-                    const int32_t ep = j <= 0 ? NINF : (s == 0 ? e_up[l] : cE[s - 1][l]);
-                    bits |= (uint32_t)(cS[s][l] == cE[s][l]) << (2 * s);
-                    bits |= (uint32_t)(cE[s][l] == ep + ge) << (2 * s + 1);
-                }
-                gst(eb + l, (uint8_t)bits);
-            }
-        }
-        gst(w.cols + tsize, cur);
-        const int32_t my_idx = tsize;
-        ++tsize;
-        cell_top += rec_words((uint32_t)FW);
-        uint64_t tx6 = xclock();
-        w.xcyc[5] += tx6 - tx5;
-        const int32_t converged = conv_update_regs(w, E, next, start, org, begin, size, cS);
-        uint64_t tx7 = xclock();
-        w.xcyc[6] += tx7 - tx6;
-        if (w.status != ST_OK) return FR_ERROR;
-        if (converged == NINF) return FR_END;
-        // the frontier would hand this column straight back iff it is the unique maximum (:491-504)
-        if (nn == 0 && (qn == 0 || converged > key_score(tier_get(w.lq, w.queue, qn - 1))) && fast_fits(cur)) {
-            for (int s = 0; s < 4; ++s) { Pc.S[s] = cS[s]; Pc.F[s] = cF[s]; }
-            Pc.idx = my_idx; Pc.node = next; Pc.offset = next_offset; Pc.trim = begin; Pc.size = size; Pc.max_pos = max_pos;
-            Pc.max_val = max_val; Pc.org = org;
-            w.xcyc[7] += xclock() - tx7;
-            return FR_CONT;
-        }
-        {
-            uint64_t key = queue_key(converged, -iabs(max_pos - diag_i), (uint32_t)my_idx);
-            if (nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
-                tier_set(w.lnn, w.next_nodes, nn++, key);
-                wave_sync();
-            } else {
-                frontier_insert(w, qn, key);
-            }
-            w.hot = cur;
-            w.hot_idx = my_idx;
-        }
-        w.xcyc[7] += xclock() - tx7;
-        return FR_END;
-    };
-
+    x.min_cell_score = 0;
+    x.best_score = 0;
+    x.qn = 0; x.nn = 0; x.n_tips = 0;
+    {
+        int32_t qn = 0;
+        frontier_insert(w, qn, queue_key(0, 0, 0));
+        x.qn = qn;
+    }
     const bool use_fast = !P.no_fast;
     int mode = XM_POP;
     for (;;) {
+        int32_t gi = -1;                 // column for the general step of this iteration
+        bool children_ready = false;
         if (mode == XM_POP) {
-            if (nn == 0) {
-                if (qn == 0) break;
+            if (x.nn == 0) {
+                if (x.qn == 0) break;
                 uint64_t tx0 = xclock();
                 // pop every entry that shares the top score, in descending tuple order (:491-500)
+                int32_t qn = x.qn, nn = 0;
                 const int32_t top_score = key_score(tier_get(w.lq, w.queue, qn - 1));
                 while (qn && key_score(tier_get(w.lq, w.queue, qn - 1)) == top_score) {
                     tier_set(w.lnn, w.next_nodes, nn++, tier_get(w.lq, w.queue, qn - 1));
                     --qn;
                 }
+                x.qn = qn; x.nn = nn;
                 wave_sync();
                 w.xcyc[0] += xclock() - tx0;
             }
-            const int32_t i = (int32_t)uni(key_idx(tier_get(w.lnn, w.next_nodes, nn - 1)));
-            --nn;
+            const int32_t i = (int32_t)uni(key_idx(tier_get(w.lnn, w.next_nodes, x.nn - 1)));
+            --x.nn;
             const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : gld(w.cols + i));
-            if (use_fast && nn == 0 && fast_fits(col)) {
-                fast_load(w, col, i, Pc);
+            if (use_fast && x.nn == 0 && fast_fits(col)) {
+                fast_load(w, col, i);
                 mode = XM_FAST;
             } else {
-                if (general(i, col, false, 0)) { res->table_size = 0; return; }
-                continue;
+                gi = i;
             }
         }
-        const int r = fast_step();
-        if (r == FR_CONT) continue;
-        mode = XM_POP;
-        if (r == FR_END) continue;
-        if (r == FR_STOP) { qn = 0; nn = 0; continue; }
-        if (r == FR_ERROR) { res->table_size = 0; return; }
-        // the parent goes through the general code (children already enumerated)
-        fast_spill(w, Pc);
-        ColMeta col = uni_col(gld(w.cols + Pc.idx));
-        if (general(Pc.idx, col, true, fast_n_out)) { res->table_size = 0; return; }
+        if (mode == XM_FAST) {
+            const int r = chain_step(w, E);
+            if (r == FR_CONT) continue;
+            mode = XM_POP;
+            if (r == FR_END) continue;
+            if (r == FR_STOP) { x.qn = 0; x.nn = 0; continue; }
+            if (r == FR_ERROR) { res->table_size = 0; return; }
+            // FR_FALLBACK: the parent goes through the general code (children already enumerated)
+            fast_spill(w);
+            gi = x.f_idx;
+            children_ready = true;
+        }
+        if (gi >= 0 && general_step(w, E, seed, gi, children_ready)) { res->table_size = 0; return; }
     }
     wave_sync();
-    res->n_tips = n_tips;
-    res->min_cell_score = min_cell_score;
-    res->table_size = tsize;
+    res->n_tips = x.n_tips;
+    res->min_cell_score = x.min_cell_score;
+    res->table_size = x.tsize;
 }
 
 // ------------------------------------------------------------------------------------------------

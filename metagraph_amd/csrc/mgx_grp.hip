@@ -8,6 +8,7 @@
 #define MGX_CAT2(a, b) a##b
 #define MGX_CAT(a, b) MGX_CAT2(a, b)
 #define mgx MGX_CAT(mgx_grp, MGX_GROUP)
+#define MGX_PARAMS_IN_LDS 1     // the kernel keeps one copy of AlignParams in LDS; the per-read program reads it with ds_ loads
 #include "wave_group.hpp"
 #include "align_core.hpp"
 
@@ -23,7 +24,13 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
     const int g = group_id();
     const uint32_t slot = blockIdx.x * GROUPS_PER_WAVEFRONT + (uint32_t)g;
     __shared__ Wave ws[GROUPS_PER_WAVEFRONT];
+    __shared__ AlignParams sP;                         // a kernel argument whose address is taken would live in scratch
     __shared__ int8_t sm_rows[6 * 128];
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&P);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&sP);
+        for (uint32_t x = threadIdx.x; x < sizeof(AlignParams) / 4; x += 64) dst[x] = src[x];
+    }
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     for (int x = threadIdx.x; x < 6 * 128; x += 64) {
         uint32_t code = (uint32_t)(x >> 7);
@@ -44,7 +51,7 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
         uint64_t item = wave_bcast(rv, 0);
         if (item >= n_items) break;
         const uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
-        align_read<PHASE>(w, P, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
+        align_read<PHASE>(w, sP, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
     }
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);
@@ -75,4 +82,4 @@ extern "C" int MGX_CAT(mgx_launch_align_grp, MGX_GROUP)(const void *params, uint
     return (int)hipGetLastError();
 }
 extern "C" int MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP)(void) { return MGX_GRP_WAVES_PER_SIMD; }
-extern "C" unsigned MGX_CAT(mgx_grp_static_lds, MGX_GROUP)(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + 6 * 128); }
+extern "C" unsigned MGX_CAT(mgx_grp_static_lds, MGX_GROUP)(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + sizeof(AlignParams) + 6 * 128 + 64); }

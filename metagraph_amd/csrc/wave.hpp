@@ -189,6 +189,24 @@ struct RegTab64 {
 #endif
 template <class T> MGX_DEV T gld(const T *p) { return *MGX_AS_GLOBAL(const T, p); }
 template <class T, class V> MGX_DEV void gst(T *p, V v) { *MGX_AS_GLOBAL(T, p) = (T)v; }
+// loads through pointers that are KNOWN to point into LDS (generic -> local is a truncation on gfx9): ds_read instead of
+// FLAT, which would wait on the vector-memory counter as well
+#if defined(__HIP_DEVICE_COMPILE__)
+MGX_DEV uint8_t lds_u8(const void *p) { return *(const __attribute__((address_space(3))) uint8_t *)(uint32_t)(uint64_t)p; }
+MGX_DEV int8_t lds_i8(const void *p) { return *(const __attribute__((address_space(3))) int8_t *)(uint32_t)(uint64_t)p; }
+#else
+MGX_DEV uint8_t lds_u8(const void *p) { return *(const uint8_t *)p; }
+MGX_DEV int8_t lds_i8(const void *p) { return *(const int8_t *)p; }
+#endif
+// four consecutive int32 as one 16-byte store (p must be 16-byte aligned)
+MGX_DEV void gst4(int32_t *p, int32_t a, int32_t b, int32_t c, int32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+    *MGX_AS_GLOBAL(int4, p) = v;
+#else
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+#endif
+}
 // one-shot 8-byte load that should not displace reusable lines (graph blocks, hints) from L2 / Infinity Cache
 // write-once / read-once scalars of the batch streams (node ids, match lengths, ranges): nontemporal
 template <class T, class V> MGX_DEV void gst_stream(T *p, V v) {

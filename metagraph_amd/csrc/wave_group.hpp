@@ -157,15 +157,21 @@ MGX_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 template <class T> MGX_DEV T uni(T x) { return x; }
 
 struct u32x16 { uint32_t v[16]; MGX_DEV uint32_t operator[](int i) const { return v[i]; } };
+// "uniform" loads of graph data: per-group uniform here, so plain vector loads — but explicitly GLOBAL ones (the graph
+// never lives in LDS; a generic pointer would make them FLAT instructions that also wait on the LDS counter)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MGX_AS_GLOBAL_EARLY(T, p) ((const __attribute__((address_space(1))) T *)(p))
+#else
+#define MGX_AS_GLOBAL_EARLY(T, p) ((const T *)(p))
+#endif
 MGX_DEV u32x16 sload_x16(const void *p) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    const uint4 a = MGX_AS_GLOBAL_EARLY(uint4, p)[0], b = MGX_AS_GLOBAL_EARLY(uint4, p)[1], c = MGX_AS_GLOBAL_EARLY(uint4, p)[2], d = MGX_AS_GLOBAL_EARLY(uint4, p)[3];
     u32x16 r;
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
     r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w; r.v[12] = d.x; r.v[13] = d.y; r.v[14] = d.z; r.v[15] = d.w;
     return r;
 }
-MGX_DEV uint32_t sload_u32(const uint32_t *p) { return *p; }
+MGX_DEV uint32_t sload_u32(const uint32_t *p) { return *MGX_AS_GLOBAL_EARLY(uint32_t, p); }
 
 #define MGX_HAS_REGTAB 0          // fewer than 64 lanes per read: sdust keeps its tables in memory
 
@@ -178,6 +184,24 @@ MGX_DEV uint32_t sload_u32(const uint32_t *p) { return *p; }
 #endif
 template <class T> MGX_DEV T gld(const T *p) { return *MGX_AS_GLOBAL(const T, p); }
 template <class T, class V> MGX_DEV void gst(T *p, V v) { *MGX_AS_GLOBAL(T, p) = (T)v; }
+// loads through pointers that are KNOWN to point into LDS (generic -> local is a truncation on gfx9): ds_read instead of
+// FLAT, which would wait on the vector-memory counter as well
+#if defined(__HIP_DEVICE_COMPILE__)
+MGX_DEV uint8_t lds_u8(const void *p) { return *(const __attribute__((address_space(3))) uint8_t *)(uint32_t)(uint64_t)p; }
+MGX_DEV int8_t lds_i8(const void *p) { return *(const __attribute__((address_space(3))) int8_t *)(uint32_t)(uint64_t)p; }
+#else
+MGX_DEV uint8_t lds_u8(const void *p) { return *(const uint8_t *)p; }
+MGX_DEV int8_t lds_i8(const void *p) { return *(const int8_t *)p; }
+#endif
+// four consecutive int32 as one 16-byte store (p must be 16-byte aligned)
+MGX_DEV void gst4(int32_t *p, int32_t a, int32_t b, int32_t c, int32_t d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int4 v; v.x = a; v.y = b; v.z = c; v.w = d;
+    *MGX_AS_GLOBAL(int4, p) = v;
+#else
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+#endif
+}
 // one-shot 8-byte load that should not displace reusable lines (graph blocks, hints) from L2 / Infinity Cache
 // write-once / read-once scalars of the batch streams (node ids, match lengths, ranges): nontemporal
 template <class T, class V> MGX_DEV void gst_stream(T *p, V v) {

@@ -130,6 +130,9 @@ struct RegTab64 {
 // host model of wave.hpp's global-memory accessors
 template <class T> inline T gld(const T *p) { return *p; }
 template <class T, class V> inline void gst(T *p, V v) { *p = (T)v; }
+inline uint8_t lds_u8(const void *p) { return *(const uint8_t *)p; }
+inline int8_t lds_i8(const void *p) { return *(const int8_t *)p; }
+inline void gst4(int32_t *p, int32_t a, int32_t b, int32_t c, int32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 template <class T, class V> inline void gst_stream(T *p, V v) { *p = (T)v; }
 template <class T> inline T gld_stream(const T *p) { return *p; }
 inline uint64_t gld_stream_u64(const void *p) { uint64_t v; memcpy(&v, p, 8); return v; }
