@@ -222,7 +222,8 @@ struct XState {
     const uint8_t *seed_seq;
     uint64_t rc_key_add;                  // RCDBG views key the convergence table by node + max_index (:74-75,107-108)
     double rel_cutoff, max_nodes_per_char, max_ram;
-    int32_t go, ge, xdrop, k, Lq, max_columns, seq_lds, pad2_;
+    int32_t go, ge, xdrop, k, Lq, max_columns, seq_lds, rc;
+    int32_t n_valid, n_for, n_count, pad3_;   // children of column n_for enumerated ahead of time into Wave::out_* (chain path)
     uint32_t hash_mask, cell_words;
     alignas(16) int32_t fS[FW];
     alignas(16) int32_t fF[FW];
@@ -1152,8 +1153,10 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
 MGX_DEV void conv_clear(ConvChecker &c) { ++c.gen; c.n_entries = 0; }
 
 MGX_DEV uint32_t conv_hash(uint64_t key, uint32_t mask) {
-    key ^= key >> 33; key *= 0xff51afd7ed558ccdULL; key ^= key >> 33;
-    return (uint32_t)key & mask;
+    // any mixing works (results do not depend on it): node ids of one extension are near-consecutive BOSS indices
+    uint32_t h = ((uint32_t)key ^ (uint32_t)(key >> 32) * 0x9E3779B9u) * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    return h & mask;
 }
 
 MGX_DEV ConvSlot conv_load_slot(const ConvSlot *p) {
@@ -1630,6 +1633,7 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
 
 // children of `node` in the graph the extender runs on (the graph itself, or its RCDBG view)
 MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node, uint32_t *nodes, uint8_t *chars, int32_t *scores) {
+    MGX_ASSUME_PARAMS(w.P);
     const AlignParams &P = *w.P;
     uint64_t nn[5];
     uint32_t cc[5];
@@ -1844,6 +1848,7 @@ MGX_NI_G3 int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const
     uint32_t *out_nodes = w.out_nodes;
     uint8_t *out_chars = w.out_chars;
     int32_t *out_scores = w.out_scores;
+    if (!children_ready) x.n_valid = 0;                       // the children list is about to be overwritten
     const int n_out = children_ready ? x.f_n_out : uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
     wave_sync();
     if (n_out == 0) {
@@ -1960,7 +1965,7 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
     const int32_t xdrop_cutoff = x.xdrop_cutoff;
     const int32_t start = x.start, window_size = x.window_size, qlen = x.qlen;
     const int32_t go = x.go, ge = x.ge;
-    uint64_t tx1 = xclock();
+    const uint64_t tx1 = xclock();
     // early cut-offs when off the optimal path (:521-547)
     if (x.f_max_val < x.best_score) {
         double node_counter = (double)x.tsize;
@@ -1999,8 +2004,14 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
         c = x.seq_lds ? lds_u8(x.seed_seq + seed_pos) : gld(x.seed_seq + seed_pos);
         score = (next_offset < k || next) ? 0 : (!x.f_node ? ge : go);
     } else {
-        const int n_out = graph_children(w, E, x.f_node, w.out_nodes, w.out_chars, w.out_scores);
-        wave_sync();
+        int n_out;
+        if (x.n_valid && x.n_for == x.f_idx) {
+            n_out = x.n_count;                                    // enumerated during the previous step
+        } else {
+            n_out = graph_children(w, E, x.f_node, w.out_nodes, w.out_chars, w.out_scores);
+            wave_sync();
+        }
+        x.n_valid = 0;
         if (n_out == 0) {
             if (x.n_tips < x.max_columns) gst(w.tips + x.n_tips++, (uint32_t)x.f_idx);
             return FR_END;
@@ -2017,8 +2028,29 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
     ConvSlot csl;
     csl.key = 0; csl.gen = 0; csl.idx = 0; csl.start = 0; csl.len = 0; csl.pad0 = csl.pad1 = 0;
     if (next) csl = conv_load_slot(E.conv.slots + chash);
-    uint64_t tx3 = xclock();
-    w.xcyc[2] += tx3 - tx1;
+    // Expansion of the child's own node one column ahead (forward graph only): if this child continues the chain and
+    // its successor comes from the graph, the two dependent loads of fwd() (select hint, target block) travel while
+    // this column is computed.  Same primitives, same results; a speculation that does not pan out is simply dropped.
+    bool pf = false;
+    uint32_t pf_r = 0;
+    uint32_t pf_hint = 0;
+    int pf_zero = 0;
+    {
+        const int32_t no2 = next_offset + 1, sp2 = no2 - x.seed_off;
+        const bool replay2 = sp2 >= 0 && sp2 < x.seed_seq_len && (no2 < k || x.force_fixed);
+        if (!x.rc && next > 1 && !replay2 && (next >> 6) == w.blk_cache_idx) {
+            MGX_ASSUME_PARAMS(w.P);
+            const DevGraph &g = w.P->g;
+            const Block cur = w.blk_cache;
+            const uint32_t wv = block_W(cur, (int)(next & 63));
+            if (wv == 0) {
+                pf = true; pf_zero = 1;                          // sink dummy: no children (dbg_succinct.cpp:113)
+            } else {
+                pf_r = g.NF[wv % SIGMA] + block_rank_W(cur, (int)(next & 63), wv % SIGMA, (next >> 6) == 0);
+                if (pf_r) { pf = true; pf_hint = gld(g.last_hint + ((pf_r - 1) >> 6)); }
+            }
+        }
+    }
     const int32_t end = imin(prev_end, window_size) + 1;
     const int32_t size0 = end - begin;
     const int32_t max_size = window_size + 1 - begin;
@@ -2077,8 +2109,9 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
             const int32_t a = org + 4 * l + s, j = a - begin;
             const int32_t t = imax(tv[s][l], ex[l]);
             const int32_t from_open = t + j * ge;
-            const int64_t fe0 = (int64_t)NINF + (int64_t)(j + 1) * ge;
-            const int32_t from_e0 = fe0 < (int64_t)INT32_MIN ? INT32_MIN : (int32_t)fe0;
+            // E[0] = ninf extended j + 1 times, saturating at INT32_MIN (NINF = INT32_MIN + 100; |(j + 1) ge| < 2^16 here)
+            const int32_t dec = (j + 1) * ge;
+            const int32_t from_e0 = dec < -100 ? INT32_MIN : NINF + dec;
             en[s][l] = (j >= 0 && j < n_loop) ? imax(from_open, from_e0) : NINF;
         }
     }
@@ -2112,14 +2145,10 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
         const int32_t lastE = reg_at(cE[0], cE[1], cE[2], cE[3], org, begin + size0 - 1);
         const int32_t ins_score = imax(lastS + go, lastE + ge);
         if (ins_score >= xdrop_cutoff) {
-            int32_t n_push = 1;
+            // while (v + ge >= cutoff) { v += ge; ++n_push; } bounded by the window end, in closed form (ge < 0)
             const int32_t room = max_size - (size0 + 1);
-            if (ge == 0) {
-                n_push += room;
-            } else {
-                int32_t v = ins_score;
-                while (n_push - 1 < room && v + ge >= xdrop_cutoff) { v += ge; ++n_push; }
-            }
+            int32_t n_push = 1 + room;
+            if (ge != 0) n_push = 1 + imin(room, (int32_t)(((int64_t)ins_score - (int64_t)xdrop_cutoff) / (int64_t)(-ge)));
             if ((begin - org) + size0 + n_push > FW) {
                 // the parent window has moved: keep it consistent for the spill
                 FOR_LANES(l) { for (int s = 0; s < 4; ++s) { x.fS[4 * l + s] = pS[s][l]; x.fF[4 * l + s] = pF[s][l]; } }
@@ -2142,8 +2171,10 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
     if ((uint32_t)x.tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
     ++w.n_columns;
     ++w.n_fast_columns;
-    uint64_t tx4 = xclock();
-    w.xcyc[3] += tx4 - tx3;
+    Block pf_blk;
+    pf_blk.cum[0] = pf_blk.cum[1] = pf_blk.cum[2] = pf_blk.cum[3] = 0; pf_blk.last_cum = 0; pf_blk.cum0 = 0;
+    pf_blk.last_bits = 0; pf_blk.p0 = pf_blk.p1 = pf_blk.p2 = pf_blk.pf = 0;
+    if (pf && !pf_zero) pf_blk = load_block_uniform(w.P->g, pf_hint);
     // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
     const int32_t psum_lin = x.psum_lin;
     const int32_t *psum = E.psum;
@@ -2179,8 +2210,6 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
         lkey[l] = kk;
     }
     const int32_t max_pos = begin + (wave_min(lkey) & 4095);          // j < FW <= 256, distance < 2^19 (Lmax <= 32704)
-    uint64_t tx5 = xclock();
-    w.xcyc[4] += tx5 - tx4;
     if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) return FR_END;      // pop(table.size() - 1)
     const uint32_t cur_cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
     x.table_size_bytes += (uint64_t)136 * (E.table_cap - table_cap_before) + (uint64_t)cur_cap3 * 4;
@@ -2211,8 +2240,6 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
     FOR_LANES(l) { if (l == 0) gst(w.cols + my_idx, cur); }
     x.tsize = my_idx + 1;
     x.cell_top += rec_words((uint32_t)FW);
-    uint64_t tx6 = xclock();
-    w.xcyc[5] += tx6 - tx5;
     // update_seed_filter (:100-156): cell at window position a (j in [skip, size)) is query position start + a - 1 of the
     // node's vector.  A position outside the vector's old range holds ninf by definition, so nothing is read back
     // that this step wrote and no store is ever waited for.
@@ -2299,8 +2326,6 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
             }
         }
     }
-    uint64_t tx7 = xclock();
-    w.xcyc[6] += tx7 - tx6;
     if (w.status != ST_OK) return FR_ERROR;
     if (converged == NINF) return FR_END;
     // the frontier would hand this column straight back iff it is the unique maximum (:491-504)
@@ -2308,8 +2333,36 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
         FOR_LANES(l) { for (int s = 0; s < 4; ++s) { x.fS[4 * l + s] = cS[s][l]; x.fF[4 * l + s] = cF[s][l]; } }
         x.f_idx = my_idx; x.f_node = next; x.f_offset = next_offset; x.f_trim = begin; x.f_size = size; x.f_max_pos = max_pos;
         x.f_max_val = max_val; x.f_org = org;
+        if (pf) {
+            int n = -1;
+            if (pf_zero) {
+                n = 0;
+            } else if (pf_blk.last_cum < pf_r && pf_blk.last_cum + (uint32_t)popc64(pf_blk.last_bits) >= pf_r) {
+                const DevGraph &g = w.P->g;
+                const int lj = select64(pf_blk.last_bits, (int)(pf_r - pf_blk.last_cum));     // fwd(): last edge of the target node
+                const uint64_t m = lj > 0 ? (pf_blk.last_bits & mask_upto(lj - 1)) : 0;       // pred_last(lst - 1) inside this block
+                if (m) {
+                    const uint64_t base = (uint64_t)pf_hint << 6;
+                    int fj = 63 - clz64(m) + 1;
+                    if (base + fj < 2) fj = (int)(2 - base);
+                    n = 0;
+                    for (int j = fj; j <= lj; ++j) {
+                        const uint32_t cc = block_W(pf_blk, j) % SIGMA;
+                        if (cc != 0 && in_graph(g, base + j)) {
+                            if (n < 4) { w.out_nodes[n] = (uint32_t)(base + j); w.out_chars[n] = decode_code(cc); w.out_scores[n] = 0; }
+                            ++n;
+                        }
+                    }
+                    if (n > 4) n = 4;
+                    w.blk_cache = pf_blk;
+                    w.blk_cache_idx = pf_hint;
+                    ++w.ctr.select_lines;
+                }
+            }
+            if (n >= 0) { x.n_valid = 1; x.n_for = my_idx; x.n_count = n; }
+        }
         wave_sync();
-        w.xcyc[7] += xclock() - tx7;
+        w.xcyc[3] += xclock() - tx1;
         return FR_CONT;
     }
     {
@@ -2325,7 +2378,7 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
         w.hot = cur;
         w.hot_idx = my_idx;
     }
-    w.xcyc[7] += xclock() - tx7;
+    w.xcyc[3] += xclock() - tx1;
     return FR_END;
 }
 
@@ -2354,6 +2407,8 @@ MGX_DEV void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_f
     x.seed_seq = seed.seq;
     x.seq_lds = (w.q_lds && seed.seq >= w.q[seed.orientation] && seed.seq < w.q[seed.orientation] + w.L) ? 1 : 0;
     x.rc_key_add = E.rc_view ? P.g.n : 0;
+    x.rc = E.rc_view ? 1 : 0;
+    x.n_valid = 0; x.n_for = -1; x.n_count = 0;
     x.rel_cutoff = cfg.rel_score_cutoff; x.max_nodes_per_char = cfg.max_nodes_per_seq_char; x.max_ram = cfg.max_ram_per_alignment;
     x.go = cfg.gap_open; x.ge = cfg.gap_ext; x.xdrop = cfg.xdrop; x.k = (int32_t)P.g.k; x.Lq = (int32_t)lim.Lmax;
     x.max_columns = (int32_t)lim.max_columns; x.hash_mask = lim.hash_size - 1; x.cell_words = lim.cell_words;
