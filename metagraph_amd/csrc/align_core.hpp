@@ -1796,7 +1796,7 @@ enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 3, FR_STOP = 4, FR_ERROR = 5 };
 
 // ---- general path: one popped column `i` with all its children (staging buffers, frontier arrays) ----
 // returns 0, or 1 = the extension is over (capacity error; w.status says which)
-MGX_NI_G3 int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const int32_t i, const bool children_ready) {
+MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const int32_t i, const bool children_ready) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
     MGX_ASSUME_PARAMS(w.P);
@@ -1958,7 +1958,7 @@ MGX_NI_G3 int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const
 }
 
 // ---- chain path: the only child of the window column, computed, judged and committed in registers ----
-MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
+MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
     XState &x = w.x;
@@ -2215,8 +2215,109 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
     x.table_size_bytes += (uint64_t)136 * (E.table_cap - table_cap_before) + (uint64_t)cur_cap3 * 4;
     if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > x.xdrop) x.xdrop_cutoff = max_val - x.xdrop;
     x.best_score = imax(x.best_score, max_val);
-    // commit: metadata + one record (S, F, E bits) in window layout
+    // --- everything that LOADS comes first (a wait on a load also waits for every store issued before it) ---
+    // update_seed_filter (:100-156), resolution: cell at window position a (j in [skip, size)) is query position
+    // start + a - 1 of the node's vector.  A position outside the vector's old range holds ninf by definition, so
+    // nothing is read back that this step writes.
     const int32_t my_idx = x.tsize;
+    const int32_t skip = begin ? 0 : 1;
+    const int32_t cn = size - skip;
+    const int32_t query_start = start + begin - (begin ? 1 : 0);
+    enum { CV_NONE = 0, CV_INSERT = 1, CV_BELOW = 2, CV_ABOVE = 3, CV_MERGE = 4 };
+    int cv_mode = CV_NONE;
+    uint32_t cv_slot = 0;
+    int32_t cv_vstart = 0, cv_vlen = 0;
+    int32_t *cv_vec = nullptr;
+    LV<int32_t> mv[4];                         // CV_MERGE: value to store per cell ...
+    LV<uint32_t> mdo;                          // ... and which cells are stored at all
+    int32_t converged;
+    {
+        LV<int32_t> cm;
+        FOR_LANES(l) {
+            int32_t m = INT32_MIN;
+            for (int s = 0; s < 4; ++s) {
+                const int32_t j = org + 4 * l + s - begin;
+                if (j >= skip && j < size) m = imax(m, cS[s][l]);
+                mv[s][l] = cS[s][l];
+            }
+            cm[l] = m;
+            mdo[l] = 0;
+        }
+        converged = wave_max(cm);
+        if (next != 0) {
+            bool found;
+            cv_slot = conv_probe_from(E.conv, cmask, ckey, chash, csl, found);
+            if (!found) {
+                cv_mode = CV_INSERT;
+            } else {
+                if (cv_slot != chash) csl = conv_load_slot(E.conv.slots + cv_slot);      // found by a later probe step
+                cv_vec = E.conv.vecs + (uint64_t)csl.idx * x.Lq;
+                cv_vstart = csl.start; cv_vlen = csl.len;
+                if (query_start + cn <= cv_vstart) cv_mode = CV_BELOW;
+                else if (query_start >= cv_vstart + cv_vlen) cv_mode = CV_ABOVE;
+                else {
+                    cv_mode = CV_MERGE;
+                    const double rel = x.rel_cutoff;
+                    LV<int32_t> xm;
+                    FOR_LANES(l) {
+                        int32_t m = NINF;
+                        uint32_t dm = 0;
+                        for (int s = 0; s < 4; ++s) {
+                            const int32_t a = org + 4 * l + s, j = a - begin;
+                            if (j >= skip && j < size) {
+                                const int32_t pos = start + a - 1;
+                                const bool old = pos >= cv_vstart && pos < cv_vstart + cv_vlen;
+                                const int32_t sv = cS[s][l];
+                                int32_t vv = old ? gld(cv_vec + pos) : NINF;
+                                if ((double)sv > (double)vv * rel) {
+                                    vv = imax(vv, sv);
+                                    mv[s][l] = vv;
+                                    dm |= 1u << s;
+                                    m = imax(m, vv);
+                                } else if (!old) {
+                                    mv[s][l] = NINF;
+                                    dm |= 1u << s;
+                                }
+                            }
+                        }
+                        xm[l] = m;
+                        mdo[l] = dm;
+                    }
+                    converged = wave_max(xm);
+                }
+            }
+        }
+    }
+    // the children of this column's node, enumerated ahead (see above): consume the target block now
+    int pf_n = -1;
+    if (pf) {
+        if (pf_zero) {
+            pf_n = 0;
+        } else if (pf_blk.last_cum < pf_r && pf_blk.last_cum + (uint32_t)popc64(pf_blk.last_bits) >= pf_r) {
+            const DevGraph &g = w.P->g;
+            const int lj = select64(pf_blk.last_bits, (int)(pf_r - pf_blk.last_cum));     // fwd(): last edge of the target node
+            const uint64_t m = lj > 0 ? (pf_blk.last_bits & mask_upto(lj - 1)) : 0;       // pred_last(lst - 1) inside this block
+            if (m) {
+                const uint64_t base = (uint64_t)pf_hint << 6;
+                int fj = 63 - clz64(m) + 1;
+                if (base + fj < 2) fj = (int)(2 - base);
+                pf_n = 0;
+                for (int j = fj; j <= lj; ++j) {
+                    const uint32_t cc = block_W(pf_blk, j) % SIGMA;
+                    if (cc != 0 && in_graph(g, base + j)) {
+                        if (pf_n < 4) { w.out_nodes[pf_n] = (uint32_t)(base + j); w.out_chars[pf_n] = decode_code(cc); w.out_scores[pf_n] = 0; }
+                        ++pf_n;
+                    }
+                }
+                if (pf_n > 4) pf_n = 4;
+                w.blk_cache = pf_blk;
+                w.blk_cache_idx = pf_hint;
+                ++w.ctr.select_lines;
+            }
+        }
+    }
+    // --- stores only from here on ---
+    // commit: metadata + one record (S, F, E bits) in window layout
     ColMeta cur;
     cur.node = next; cur.parent = x.f_idx; cur.cw = (uint32_t)c | ((uint32_t)FW << 8); cur.org = org; cur.offset = next_offset;
     cur.max_pos = max_pos; cur.trim = begin; cur.score = score; cur.cells = x.cell_top; cur.size = size;
@@ -2240,89 +2341,28 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
     FOR_LANES(l) { if (l == 0) gst(w.cols + my_idx, cur); }
     x.tsize = my_idx + 1;
     x.cell_top += rec_words((uint32_t)FW);
-    // update_seed_filter (:100-156): cell at window position a (j in [skip, size)) is query position start + a - 1 of the
-    // node's vector.  A position outside the vector's old range holds ninf by definition, so nothing is read back
-    // that this step wrote and no store is ever waited for.
-    int32_t converged;
-    {
-        const int32_t skip = begin ? 0 : 1;
-        const int32_t n = size - skip;
-        const int32_t query_start = start + begin - (begin ? 1 : 0);
-        LV<int32_t> cm;
+    // update_seed_filter, the stores
+    if (cv_mode == CV_INSERT) {
+        const int32_t vi = conv_insert(w, E.conv, cv_slot, ckey, query_start, cn);
+        if (vi < 0) return FR_ERROR;
+        cv_vec = E.conv.vecs + (uint64_t)vi * x.Lq;
+    } else if (cv_mode == CV_BELOW) {
+        fill_range(cv_vec, query_start + cn, cv_vstart, NINF);
+        conv_store_range(E.conv.slots + cv_slot, query_start, cv_vstart + cv_vlen - query_start);
+    } else if (cv_mode == CV_ABOVE) {
+        fill_range(cv_vec, cv_vstart + cv_vlen, query_start, NINF);
+        conv_store_range(E.conv.slots + cv_slot, cv_vstart, query_start + cn - cv_vstart);
+    } else if (cv_mode == CV_MERGE) {
+        const int32_t nstart = imin(cv_vstart, query_start);
+        const int32_t nend = imax(cv_vstart + cv_vlen, query_start + cn);
+        if (nstart != cv_vstart || nend != cv_vstart + cv_vlen) conv_store_range(E.conv.slots + cv_slot, nstart, nend - nstart);
+    }
+    if (cv_mode != CV_NONE) {
+        const bool all = cv_mode != CV_MERGE;              // a new or disjoint range takes the column as it is
         FOR_LANES(l) {
-            int32_t m = INT32_MIN;
             for (int s = 0; s < 4; ++s) {
-                const int32_t j = org + 4 * l + s - begin;
-                if (j >= skip && j < size) m = imax(m, cS[s][l]);
-            }
-            cm[l] = m;
-        }
-        if (next == 0) {
-            converged = wave_max(cm);
-        } else {
-            bool found;
-            const uint32_t slot = conv_probe_from(E.conv, cmask, ckey, chash, csl, found);
-            const int32_t Lq = x.Lq;
-            if (!found) {
-                const int32_t vi = conv_insert(w, E.conv, slot, ckey, query_start, n);
-                if (vi < 0) return FR_ERROR;
-                int32_t *vec = E.conv.vecs + (uint64_t)vi * Lq;
-                FOR_LANES(l) {
-                    for (int s = 0; s < 4; ++s) {
-                        const int32_t a = org + 4 * l + s, j = a - begin;
-                        if (j >= skip && j < size) gst(vec + start + a - 1, cS[s][l]);
-                    }
-                }
-                converged = wave_max(cm);
-            } else {
-                // re-read the slot found by a later probe step
-                if (slot != chash) csl = conv_load_slot(E.conv.slots + slot);
-                int32_t *vec = E.conv.vecs + (uint64_t)csl.idx * Lq;
-                const int32_t vstart = csl.start, vlen = csl.len;
-                if (query_start + n <= vstart || query_start >= vstart + vlen) {
-                    // disjoint: the gap is filled with ninf, the column is stored as it is
-                    if (query_start + n <= vstart) {
-                        fill_range(vec, query_start + n, vstart, NINF);
-                        conv_store_range(E.conv.slots + slot, query_start, vstart + vlen - query_start);
-                    } else {
-                        fill_range(vec, vstart + vlen, query_start, NINF);
-                        conv_store_range(E.conv.slots + slot, vstart, query_start + n - vstart);
-                    }
-                    FOR_LANES(l) {
-                        for (int s = 0; s < 4; ++s) {
-                            const int32_t a = org + 4 * l + s, j = a - begin;
-                            if (j >= skip && j < size) gst(vec + start + a - 1, cS[s][l]);
-                        }
-                    }
-                    converged = wave_max(cm);
-                } else {
-                    const int32_t nstart = imin(vstart, query_start);
-                    const int32_t nend = imax(vstart + vlen, query_start + n);
-                    if (nstart != vstart || nend != vstart + vlen) conv_store_range(E.conv.slots + slot, nstart, nend - nstart);
-                    const double rel = x.rel_cutoff;
-                    LV<int32_t> xm;
-                    FOR_LANES(l) {
-                        int32_t m = NINF;
-                        for (int s = 0; s < 4; ++s) {
-                            const int32_t a = org + 4 * l + s, j = a - begin;
-                            if (j >= skip && j < size) {
-                                const int32_t pos = start + a - 1;
-                                const bool old = pos >= vstart && pos < vstart + vlen;
-                                const int32_t sv = cS[s][l];
-                                int32_t vv = old ? gld(vec + pos) : NINF;
-                                if ((double)sv > (double)vv * rel) {
-                                    vv = imax(vv, sv);
-                                    gst(vec + pos, vv);
-                                    m = imax(m, vv);
-                                } else if (!old) {
-                                    gst(vec + pos, NINF);
-                                }
-                            }
-                        }
-                        xm[l] = m;
-                    }
-                    converged = wave_max(xm);
-                }
+                const int32_t a = org + 4 * l + s, j = a - begin;
+                if (j >= skip && j < size && (all || ((mdo[l] >> s) & 1u))) gst(cv_vec + start + a - 1, mv[s][l]);
             }
         }
     }
@@ -2333,34 +2373,7 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
         FOR_LANES(l) { for (int s = 0; s < 4; ++s) { x.fS[4 * l + s] = cS[s][l]; x.fF[4 * l + s] = cF[s][l]; } }
         x.f_idx = my_idx; x.f_node = next; x.f_offset = next_offset; x.f_trim = begin; x.f_size = size; x.f_max_pos = max_pos;
         x.f_max_val = max_val; x.f_org = org;
-        if (pf) {
-            int n = -1;
-            if (pf_zero) {
-                n = 0;
-            } else if (pf_blk.last_cum < pf_r && pf_blk.last_cum + (uint32_t)popc64(pf_blk.last_bits) >= pf_r) {
-                const DevGraph &g = w.P->g;
-                const int lj = select64(pf_blk.last_bits, (int)(pf_r - pf_blk.last_cum));     // fwd(): last edge of the target node
-                const uint64_t m = lj > 0 ? (pf_blk.last_bits & mask_upto(lj - 1)) : 0;       // pred_last(lst - 1) inside this block
-                if (m) {
-                    const uint64_t base = (uint64_t)pf_hint << 6;
-                    int fj = 63 - clz64(m) + 1;
-                    if (base + fj < 2) fj = (int)(2 - base);
-                    n = 0;
-                    for (int j = fj; j <= lj; ++j) {
-                        const uint32_t cc = block_W(pf_blk, j) % SIGMA;
-                        if (cc != 0 && in_graph(g, base + j)) {
-                            if (n < 4) { w.out_nodes[n] = (uint32_t)(base + j); w.out_chars[n] = decode_code(cc); w.out_scores[n] = 0; }
-                            ++n;
-                        }
-                    }
-                    if (n > 4) n = 4;
-                    w.blk_cache = pf_blk;
-                    w.blk_cache_idx = pf_hint;
-                    ++w.ctr.select_lines;
-                }
-            }
-            if (n >= 0) { x.n_valid = 1; x.n_for = my_idx; x.n_count = n; }
-        }
+        if (pf_n >= 0) { x.n_valid = 1; x.n_for = my_idx; x.n_count = pf_n; }
         wave_sync();
         w.xcyc[3] += xclock() - tx1;
         return FR_CONT;
@@ -2382,7 +2395,12 @@ MGX_NI_G3 int chain_step(Wave &w, ExtenderState &E) {
     return FR_END;
 }
 
-MGX_DEV void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
+// One function for the whole loop: a call boundary makes the callee wait for every store it issued (s_waitcnt before
+// s_setpc), which would drain each column's record stores at the end of each step.
+MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
+    MGX_ASSUME_LDS(&w);
+    MGX_ASSUME_LDS(&E);
+    MGX_ASSUME_PARAMS(w.P);
     ExtendResult *res = &w.er;
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
