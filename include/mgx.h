@@ -238,13 +238,10 @@ int mgx_map_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uin
 
 int mgx_aligner_stats(const mgx_aligner *a, mgx_stats *out);
 
-/* Tuning / test hook: which instantiation of the per-read program the aligner launches.  Results are
- * identical for both.  "split8" (default, the product): seeding kernel with one wavefront per read, radix sort of
- * the reads by predicted extension work, extension kernel with 8 lanes per read; "g8": the fused reference
- * instantiation (seeding + extension of a read in one 8-lane group).  The environment variable MGX_ALIGN_MODE sets
- * the default.  Two further names switch the extension kernel's register-resident chain path off / on without
- * changing the pipeline: "general" (every DP column through the staging-buffer path) and "chain" (default).
- * Unknown name: MGX_ERR_INVALID. */
+/* Test hook.  "split8" names the (only) pipeline: seeding kernel with one wavefront per read, radix sort of the reads
+ * by predicted extension work, extension kernel with 8 lanes per read.  "general" / "chain" switch the extension
+ * kernel's register-resident chain path off / on (results are identical; parity tests run both).  Unknown name:
+ * MGX_ERR_INVALID. */
 int mgx_aligner_set_pipeline(mgx_aligner *a, const char *name);
 
 /* Format one query's results exactly like format_alignment() (cli/align.cpp:254-285):

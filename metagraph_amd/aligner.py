@@ -118,7 +118,7 @@ class Aligner:
         return out
 
     def set_pipeline(self, name):
-        """Tuning/test hook: 'split8' (the product) or 'g8' (fused 8-lane reference instantiation)."""
+        """Tuning/test hook: 'split8' (the pipeline), 'general' / 'chain' (extension chain path off / on)."""
         L = capi.lib()
         L.mgx_aligner_set_pipeline.argtypes = [C.c_void_p, C.c_char_p]
         _check(L.mgx_aligner_set_pipeline(self.h, name.encode()))

@@ -2074,17 +2074,31 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
     const bool q_lds = w.q_lds != 0;
     const LV<int32_t> Sm1_0 = wave_shift_up1(pS[3], NINF);        // parent at a - 1 for slot 0
     LV<int32_t> cS[4], cF[4], cE[4], mraw[4], tv[4], mm[4];
+    // profile_score_[c][start + a] (:38-59): the query character before window position a against the column's
+    // character; 0 outside the query.  All loads are issued back to back at clamped addresses (no per-cell branches:
+    // a branch around a load costs a wait each) and masked afterwards.
+    LV<int32_t> prof[4];
+    {
+        LV<uint32_t> qc[4];
+        const int32_t hi = qlen - 1;
+        if (q_lds) {
+            FOR_LANES(l) { for (int s = 0; s < 4; ++s) qc[s][l] = lds_u8(qq + imax(0, imin(hi, start + org + 4 * l + s - 1))); }
+        } else {
+            FOR_LANES(l) { for (int s = 0; s < 4; ++s) qc[s][l] = gld(qq + imax(0, imin(hi, start + org + 4 * l + s - 1))); }
+        }
+        FOR_LANES(l) { for (int s = 0; s < 4; ++s) prof[s][l] = (int32_t)lds_i8(row + (qc[s][l] & 127)); }
+        FOR_LANES(l) {
+            for (int s = 0; s < 4; ++s) {
+                const int32_t ap = start + org + 4 * l + s;
+                prof[s][l] = (ap >= 1 && ap <= qlen) ? prof[s][l] : 0;
+            }
+        }
+    }
     FOR_LANES(l) {
         for (int s = 0; s < 4; ++s) {
             const int32_t a = org + 4 * l + s, j = a - begin;
-            const int32_t ap = start + a;
-            int32_t prof = 0;
-            if (ap >= 1 && ap <= qlen) {
-                const uint8_t qc = q_lds ? lds_u8(qq + ap - 1) : gld(qq + ap - 1);
-                prof = (int32_t)lds_i8(row + (qc & 127));
-            }
             const int32_t sm1 = s == 0 ? Sm1_0[l] : pS[s - 1][l];
-            mraw[s][l] = sm1 + prof + score;                            // S_prev[j - 1] + profile + init_score
+            mraw[s][l] = sm1 + prof[s][l] + score;                      // S_prev[j - 1] + profile + init_score
             const bool in = j >= 0 && j < n_loop;
             int32_t del = NINF;
             if (next_offset > 1) del = imax(pS[s][l] + go, pF[s][l] + ge) + score;
@@ -2258,27 +2272,24 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
                 else {
                     cv_mode = CV_MERGE;
                     const double rel = x.rel_cutoff;
-                    LV<int32_t> xm;
+                    LV<int32_t> xm, vold[4];
+                    const int32_t vlast = cv_vstart + cv_vlen - 1;
+                    FOR_LANES(l) { for (int s = 0; s < 4; ++s) vold[s][l] = gld(cv_vec + imax(cv_vstart, imin(vlast, start + org + 4 * l + s - 1))); }
                     FOR_LANES(l) {
                         int32_t m = NINF;
                         uint32_t dm = 0;
                         for (int s = 0; s < 4; ++s) {
                             const int32_t a = org + 4 * l + s, j = a - begin;
-                            if (j >= skip && j < size) {
-                                const int32_t pos = start + a - 1;
-                                const bool old = pos >= cv_vstart && pos < cv_vstart + cv_vlen;
-                                const int32_t sv = cS[s][l];
-                                int32_t vv = old ? gld(cv_vec + pos) : NINF;
-                                if ((double)sv > (double)vv * rel) {
-                                    vv = imax(vv, sv);
-                                    mv[s][l] = vv;
-                                    dm |= 1u << s;
-                                    m = imax(m, vv);
-                                } else if (!old) {
-                                    mv[s][l] = NINF;
-                                    dm |= 1u << s;
-                                }
-                            }
+                            const int32_t pos = start + a - 1;
+                            const bool cell = j >= skip && j < size;
+                            const bool old = pos >= cv_vstart && pos <= vlast;
+                            const int32_t sv = cS[s][l];
+                            const int32_t vv = old ? vold[s][l] : NINF;
+                            const bool up = (double)sv > (double)vv * rel;
+                            const int32_t nv = up ? imax(vv, sv) : NINF;
+                            mv[s][l] = nv;
+                            if (cell && (up || !old)) dm |= 1u << s;
+                            if (cell && up) m = imax(m, nv);
                         }
                         xm[l] = m;
                         mdo[l] = dm;

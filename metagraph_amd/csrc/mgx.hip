@@ -235,21 +235,16 @@ extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint
 extern "C" int mgx_grp_waves_per_simd8(void);
 extern "C" unsigned mgx_grp_static_lds8(void);
 
-// Which instantiation of the aligner's wave program run_align launches.  The product is the split pipeline:
-// seeding by one wavefront per read, a radix sort of the reads by predicted extension work, extension by
-// 8-lane groups (8 reads per wavefront).  "g8" is the fused reference instantiation (seeding and extension of a read
-// in one 8-lane group, no hand-over, no sort) kept for A/B parity tests.
-enum AlignMode { MODE_GRP8 = 2, MODE_SPLIT8 = 4, MODE_BAD = -1 };
+// The pipeline run_align launches: seeding by one wavefront per read (k_align<PH_SEED>), a radix sort of the reads by
+// predicted extension work, extension by 8-lane groups (8 reads per wavefront, mgx_grp.hip).  (Round 1 also carried
+// fused and 16- / 64- / 1-lane instantiations for A/B measurements; they are gone.)
+enum AlignMode { MODE_SPLIT8 = 4, MODE_BAD = -1 };
 static AlignMode parse_mode(const char *e) {
     if (!e) return MODE_BAD;
     if (!strcmp(e, "split8")) return MODE_SPLIT8;
-    if (!strcmp(e, "g8")) return MODE_GRP8;
     return MODE_BAD;
 }
-static AlignMode default_mode() {
-    AlignMode m = parse_mode(getenv("MGX_ALIGN_MODE"));
-    return m == MODE_BAD ? MODE_SPLIT8 : m;
-}
+static AlignMode default_mode() { return MODE_SPLIT8; }
 
 struct mgx_aligner {
     const mgx_graph *graph = nullptr;
@@ -623,7 +618,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const AlignMode mode = A->mode;
-    const bool split = mode == MODE_SPLIT8;
+    const bool split = mode == MODE_SPLIT8;      // always
     const uint64_t wave_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;   // seeding kernel: one wavefront per read
     const uint64_t want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * (uint64_t)mgx_grp_waves_per_simd8());
     uint64_t budget = free_b / 2;
@@ -756,8 +751,6 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             }
             HIP_TRY((hipError_t)launch_groups(PH_EXTEND));
         }
-    } else {
-        HIP_TRY((hipError_t)launch_groups(PH_BOTH));
     }
     HIP_TRY(hipEventRecord(A->ev[3], 0));
     return MGX_OK;

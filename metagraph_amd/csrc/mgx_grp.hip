@@ -75,10 +75,8 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
 extern "C" int MGX_CAT(mgx_launch_align_grp, MGX_GROUP)(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream) {
     const AlignParams &P = *static_cast<const AlignParams *>(params);
     uint32_t blocks = (n_groups + GROUPS_PER_WAVEFRONT - 1) / GROUPS_PER_WAVEFRONT;
-    if (phase == PH_EXTEND)
-        MGX_CAT(k_align_grp, MGX_GROUP)<PH_EXTEND><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
-    else
-        MGX_CAT(k_align_grp, MGX_GROUP)<PH_BOTH><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
+    if (phase != PH_EXTEND) return (int)hipErrorInvalidValue;      // only the extension half is instantiated for sub-wave groups
+    MGX_CAT(k_align_grp, MGX_GROUP)<PH_EXTEND><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
     return (int)hipGetLastError();
 }
 extern "C" int MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP)(void) { return MGX_GRP_WAVES_PER_SIMD; }

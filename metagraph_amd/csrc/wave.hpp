@@ -11,6 +11,7 @@
 #define MGX_WAVE_HPP_
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mem_access.hpp"
 
 #define MGX_DEV __device__ __forceinline__
 #ifndef MGX_NOINLINE
@@ -181,14 +182,15 @@ struct RegTab64 {
 };
 
 // Loads / stores that are known to target global memory (graph, arena): global_* instead of FLAT instructions, so
-// that they do not bump lgkmcnt and LDS traffic never waits for them.
+// that they do not bump lgkmcnt and LDS traffic never waits for them (see mem_access.hpp for why they are spelled
+// through native vectors).  Objects must be naturally aligned for their size class (16 / 8 / 4 / 2 / 1 bytes).
 #if defined(__HIP_DEVICE_COMPILE__)
-#define MGX_AS_GLOBAL(T, p) ((__attribute__((address_space(1))) T *)(p))
+template <class T> MGX_DEV T gld(const T *p) { T t; mgx_mem::load_bytes<(int)sizeof(T)>(p, &t); return t; }
+template <class T, class V> MGX_DEV void gst(T *p, V v) { const T t = (T)v; mgx_mem::store_bytes<(int)sizeof(T)>(p, &t); }
 #else
-#define MGX_AS_GLOBAL(T, p) (p)
+template <class T> MGX_DEV T gld(const T *p) { return *p; }
+template <class T, class V> MGX_DEV void gst(T *p, V v) { *p = (T)v; }
 #endif
-template <class T> MGX_DEV T gld(const T *p) { return *MGX_AS_GLOBAL(const T, p); }
-template <class T, class V> MGX_DEV void gst(T *p, V v) { *MGX_AS_GLOBAL(T, p) = (T)v; }
 // loads through pointers that are KNOWN to point into LDS (generic -> local is a truncation on gfx9): ds_read instead of
 // FLAT, which would wait on the vector-memory counter as well
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -201,8 +203,8 @@ MGX_DEV int8_t lds_i8(const void *p) { return *(const int8_t *)p; }
 // four consecutive int32 as one 16-byte store (p must be 16-byte aligned)
 MGX_DEV void gst4(int32_t *p, int32_t a, int32_t b, int32_t c, int32_t d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    int4 v; v.x = a; v.y = b; v.z = c; v.w = d;
-    *MGX_AS_GLOBAL(int4, p) = v;
+    mgx_mem::u32x4 v = { (uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d };
+    *MGX_GPTR(mgx_mem::u32x4, p) = v;
 #else
     p[0] = a; p[1] = b; p[2] = c; p[3] = d;
 #endif

@@ -9,6 +9,7 @@
 #define MGX_WAVE_HPP_
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mem_access.hpp"
 
 #ifndef MGX_GROUP
 #define MGX_GROUP 16
@@ -156,6 +157,7 @@ MGX_DEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 // group-uniform values stay in vector registers (they differ between the groups of a wavefront)
 template <class T> MGX_DEV T uni(T x) { return x; }
 
+template <class T> MGX_DEV T gld(const T *p);
 struct u32x16 { uint32_t v[16]; MGX_DEV uint32_t operator[](int i) const { return v[i]; } };
 // "uniform" loads of graph data: per-group uniform here, so plain vector loads — but explicitly GLOBAL ones (the graph
 // never lives in LDS; a generic pointer would make them FLAT instructions that also wait on the LDS counter)
@@ -165,25 +167,28 @@ struct u32x16 { uint32_t v[16]; MGX_DEV uint32_t operator[](int i) const { retur
 #define MGX_AS_GLOBAL_EARLY(T, p) ((const T *)(p))
 #endif
 MGX_DEV u32x16 sload_x16(const void *p) {
-    const uint4 a = MGX_AS_GLOBAL_EARLY(uint4, p)[0], b = MGX_AS_GLOBAL_EARLY(uint4, p)[1], c = MGX_AS_GLOBAL_EARLY(uint4, p)[2], d = MGX_AS_GLOBAL_EARLY(uint4, p)[3];
     u32x16 r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    r.v[8] = c.x; r.v[9] = c.y; r.v[10] = c.z; r.v[11] = c.w; r.v[12] = d.x; r.v[13] = d.y; r.v[14] = d.z; r.v[15] = d.w;
+#if defined(__HIP_DEVICE_COMPILE__)
+    mgx_mem::load_bytes<64>(p, r.v);
+#else
+    __builtin_memcpy(r.v, p, 64);
+#endif
     return r;
 }
-MGX_DEV uint32_t sload_u32(const uint32_t *p) { return *MGX_AS_GLOBAL_EARLY(uint32_t, p); }
+MGX_DEV uint32_t sload_u32(const uint32_t *p) { return gld(p); }
 
 #define MGX_HAS_REGTAB 0          // fewer than 64 lanes per read: sdust keeps its tables in memory
 
 // Loads / stores that are known to target global memory (graph, arena): global_* instead of FLAT instructions, so
-// that they do not bump lgkmcnt and LDS traffic never waits for them.
+// that they do not bump lgkmcnt and LDS traffic never waits for them (see mem_access.hpp for why they are spelled
+// through native vectors).  Objects must be naturally aligned for their size class (16 / 8 / 4 / 2 / 1 bytes).
 #if defined(__HIP_DEVICE_COMPILE__)
-#define MGX_AS_GLOBAL(T, p) ((__attribute__((address_space(1))) T *)(p))
+template <class T> MGX_DEV T gld(const T *p) { T t; mgx_mem::load_bytes<(int)sizeof(T)>(p, &t); return t; }
+template <class T, class V> MGX_DEV void gst(T *p, V v) { const T t = (T)v; mgx_mem::store_bytes<(int)sizeof(T)>(p, &t); }
 #else
-#define MGX_AS_GLOBAL(T, p) (p)
+template <class T> MGX_DEV T gld(const T *p) { return *p; }
+template <class T, class V> MGX_DEV void gst(T *p, V v) { *p = (T)v; }
 #endif
-template <class T> MGX_DEV T gld(const T *p) { return *MGX_AS_GLOBAL(const T, p); }
-template <class T, class V> MGX_DEV void gst(T *p, V v) { *MGX_AS_GLOBAL(T, p) = (T)v; }
 // loads through pointers that are KNOWN to point into LDS (generic -> local is a truncation on gfx9): ds_read instead of
 // FLAT, which would wait on the vector-memory counter as well
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -196,8 +201,8 @@ MGX_DEV int8_t lds_i8(const void *p) { return *(const int8_t *)p; }
 // four consecutive int32 as one 16-byte store (p must be 16-byte aligned)
 MGX_DEV void gst4(int32_t *p, int32_t a, int32_t b, int32_t c, int32_t d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    int4 v; v.x = a; v.y = b; v.z = c; v.w = d;
-    *MGX_AS_GLOBAL(int4, p) = v;
+    mgx_mem::u32x4 v = { (uint32_t)a, (uint32_t)b, (uint32_t)c, (uint32_t)d };
+    *MGX_GPTR(mgx_mem::u32x4, p) = v;
 #else
     p[0] = a; p[1] = b; p[2] = c; p[3] = d;
 #endif

@@ -60,13 +60,13 @@ def test_align_cli_config(k, mask, seed):
     compare_gpu(g, gpu_graph(g), capi.config_cli(k), reads)
 
 
-PIPELINES = ["split8", "g8", "split8+general"]     # "+general": the extension's register-resident chain path off
+PIPELINES = ["split8", "split8+general"]     # "+general": the extension's register-resident chain path off
 
 
 @pytest.mark.parametrize("pipeline", PIPELINES)
 def test_every_pipeline_matches_the_oracle(pipeline):
-    """Both instantiations of the per-read program (the product: seeding kernel, work sort, 8-lane extension kernel;
-    the fused 8-lane reference) give the oracle's results."""
+    """The product pipeline (seeding kernel, work sort, 8-lane extension kernel) gives the oracle's results with the
+    extension's register-resident chain path on and off."""
     g, reads = make_world(500, 31, genome_len=6000, n_reads=150, read_len=150, n_variants=30)
     G = gpu_graph(g)
     A = compare_gpu(g, G, capi.config_cli(31), reads, pipeline=pipeline)
@@ -83,7 +83,7 @@ def test_every_pipeline_matches_the_oracle(pipeline):
     compare_gpu(g, gpu_graph(g), cfg, reads + [reads[0][:40], "ACGT", ""], pipeline=pipeline)
 
 
-@pytest.mark.parametrize("pipeline", ["split8", "g8"])
+@pytest.mark.parametrize("pipeline", ["split8", "split8+general"])
 def test_aligner_reuse_across_batches_of_different_shape(pipeline):
     """One aligner handle, several batches whose longest read differs (the per-slot arena layout changes and is
     re-zeroed only then), interleaved with same-shape batches that reuse the generation-tagged tables."""
@@ -128,7 +128,7 @@ def test_device_results_wrap_as_a_torch_tensor():
             assert scores[q] == got[q][0]["score"]
 
 
-@pytest.mark.parametrize("pipeline", ["split8", "g8"])
+@pytest.mark.parametrize("pipeline", ["split8", "split8+general"])
 def test_baseline_config0_transcripts_k12(pipeline):
     """BASELINE.json configs[0] in small: `metagraph align` of the transcripts against their own k = 12 graph
     (tests/data/transcripts_100.fa: 100 queries of 68 .. 5603 bp, every one an exact path).  Long queries put the
