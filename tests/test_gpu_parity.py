@@ -91,7 +91,8 @@ def test_aligner_reuse_across_batches_of_different_shape(pipeline):
     G = gpu_graph(g)
     cfg = capi.config_cli(21)
     A = aligner.Aligner(G, cfg)
-    A.set_pipeline(pipeline)
+    for name in pipeline.split("+"):
+        A.set_pipeline(name)
     rng = random.Random(5)
     batches = [reads[:40], [r[:90] for r in reads[40:80]], reads[80:120], [r[:60] for r in reads[:30]] + [reads[3]], reads[:40]]
     for b in batches:
@@ -139,7 +140,8 @@ def test_baseline_config0_transcripts_k12(pipeline):
     cfg = capi.config_cli(12)
     want = orc.AlignRun(g, cfg, seqs, threads=8).results()
     A = aligner.Aligner(gpu_graph(g), cfg)
-    A.set_pipeline(pipeline)
+    for name in pipeline.split("+"):
+        A.set_pipeline(name)
     got, status = A.align_batch(seqs)
     assert all(s == 0 for s in status), status
     assert got == want
