@@ -196,21 +196,15 @@ struct Tier { int32_t *lo, *hi; };
 MGX_DEV int32_t tget(const Tier &t, int32_t cap, int32_t j) { return *(j < cap ? t.lo + j : t.hi + j); }
 MGX_DEV void tset(const Tier &t, int32_t cap, int32_t j, int32_t v) { *(j < cap ? t.lo + j : t.hi + j) = v; }
 struct Staging { Tier S, F; int32_t col; };
-#ifndef MGX_LQ_CAP
-#define MGX_LQ_CAP 8        // measured on the 8-lane extension kernel: 32 -> 8 frees LDS for the staging tier (st_cap 44 -> 64), -12 %
-#endif
-constexpr int32_t LQ_CAP = MGX_LQ_CAP;       // frontier entries kept in LDS; the rest spill to the arena
 
 // Loop-carried state of one extension (DefaultColumnExtender::extend): lives in LDS next to the control block so that
 // the step functions of the flat extension loop are separate small functions.  fS / fF: S and F of the chain path's
 // current column, four consecutive window positions per lane starting at f_org.
 #ifndef MGX_NO_EXTEND
 constexpr int32_t FW = 4 * WAVE;
-#else
-constexpr int32_t FW = 4;                 // seeding-only translation units never touch the window
-#endif
 struct XState {
     int32_t xdrop_cutoff, best_score, tsize, min_cell_score, qn, nn, n_tips;
+    int32_t q_top;                        // score of the frontier's top entry (INT32_MIN when empty)
     uint32_t cell_top;
     uint64_t table_size_bytes;
     int32_t start, window_size, qlen, partial_sum_offset, seed_off, seed_seq_len, psum_lin, force_fixed;
@@ -225,52 +219,62 @@ struct XState {
     int32_t go, ge, xdrop, k, Lq, max_columns, seq_lds, rc;
     int32_t n_valid, n_for, n_count, pad3_;   // children of column n_for enumerated ahead of time into Wave::out_* (chain path)
     uint32_t hash_mask, cell_words;
-    alignas(16) int32_t fS[FW];
-    alignas(16) int32_t fF[FW];
 };
+#else
+struct XState { int32_t unused_; };       // seeding-only translation units (k_seed) carry no extension state in LDS
+#endif
 
+#ifdef MGX_SEED_PROBE
+constexpr int XCYC_N = 8;
+#else
+constexpr int XCYC_N = 4;
+#endif
 struct Wave {
     const AlignParams *P;
     int32_t L;                   // query length
+    int32_t q_lds;               // the strands q[0], q[1] live in LDS (carve)
     uint8_t *q[2];
     int32_t *psum[2];
     const uint32_t *nodes[2];
-    const uint8_t *mlen[2];      // k_map's index() match lengths per position (may be null)
-    const uint2 *rng[2];         // and the (rl, ru) ranges of matches >= min_seed_length (may be null)
-    int32_t n_kmers;
     DevSeed *seeds[2];
     uint8_t *alive[2];
     int32_t n_seeds[2];
-    int32_t lc_any[2];           // whole-strand sdust verdict: 0 = no maskable interval anywhere, 1 = some, -1 = unknown
     uint32_t num_matching[2];
-    // sub-k scratch
-    uint16_t *msl, *pos_cnt, *ml;
-    uint8_t *pos_full;
-    uint32_t *pos_start, *rfirst, *rlast, *alt;
+    int32_t psum_lin[2];         // see ExtenderState::psum_lin
+    // The seeding half's scratch pointers and the extension's loop state are never live at the same time (build_seeders
+    // finishes before the first extend()), so they share their LDS bytes.
+    union {
+        struct {
+            const uint8_t *mlen[2];      // k_map's index() match lengths per position (may be null)
+            const uint2 *rng[2];         // and the (rl, ru) ranges of matches >= min_seed_length (may be null)
+            uint16_t *msl, *pos_cnt, *ml;    // sub-k scratch
+            uint8_t *pos_full;
+            uint32_t *pos_start, *rfirst, *rlast, *alt;
+            SdustScratch *sd;            // sdust scratch (LDS)
+            SdustScratch *sd_own;        // carve()'s own scratch in the seeding overlay (used when the kernel passes none)
+            uint32_t *pk[2];             // 2-bit packed strands (16 codes per word, first char least significant)
+            uint64_t *bm[4];             // position bitmasks of the seeder: matched k-mers, MEM stops, lookup hits, seed slots
+            uint8_t *dust_t;             // triplet code per position (maybe_low_complexity)
+            uint64_t *dust_eq;           // per position: which of the next 61 positions hold the same triplet
+            int32_t lc_any[2];           // whole-strand sdust verdict: 0 = no maskable interval anywhere, 1 = some, -1 = unknown
+            int32_t inv_any[2];          // strand holds a character outside ACGT
+            int32_t n_kmers;
+        };
+        XState x;
+    };
     // extension scratch
     int32_t *cells;
     ColMeta *cols;
-    uint64_t *queue, *next_nodes;         // arena tiers of the frontier / current batch
-    uint64_t *lq, *lnn;                   // LDS tiers (first LQ_CAP entries)
+    uint64_t *queue, *next_nodes;         // frontier / current batch (arena; the chain path rarely touches them)
     Staging st[2];
     Tier stE;                             // E of the column being computed
     int32_t st_cap;                       // cells of every staged array that live in LDS
-    ColMeta hot;                          // metadata of the most recently committed column
-    int32_t hot_idx;
-    Block blk_cache;                      // target block of the last graph expansion (children live in it)
+    uint32_t blk_cache_w[16];             // target block of the last graph expansion (children live in it), as plain words
     uint32_t blk_cache_idx;
     uint32_t *tips, *prev_starts;
     BtIndex *indices;
     uint32_t *rev_ops, *rev_nodes;
     uint8_t *rev_seq;
-    SdustScratch *sd;            // sdust scratch (LDS)
-    uint32_t *pk[2];             // 2-bit packed strands (16 codes per word, first char least significant)
-    uint64_t *bm[4];             // position bitmasks of the seeder: matched k-mers, MEM stops, lookup hits, seed slots
-    int32_t inv_any[2];          // strand holds a character outside ACGT
-    int32_t psum_lin[2];         // see ExtenderState::psum_lin
-    SdustScratch *sd_own;        // carve()'s own scratch in the seeding overlay (used when the kernel passes none)
-    uint8_t *dust_t;             // triplet code per position (maybe_low_complexity)
-    uint64_t *dust_eq;           // per position: which of the next 61 positions hold the same triplet
     const int8_t *sm_rows;       // score-matrix rows of the 6 possible path characters ($ACGT\\0) x 128, in LDS
     uint32_t *gen_store;         // conv-checker generation counters, persistent per arena slice
     ExtenderState ext[2];
@@ -280,17 +284,37 @@ struct Wave {
     int32_t seeds_done;          // seeds whose extension ran for this read (two-pass extension)
     LineCtr ctr;                 // BOSS block loads (lane-parallel regions add their wave sums)
     ExtendResult er;             // result of the last extend(); noinline callees must not write through
+                                 // pointers into the caller's private frame, so outputs live here
     int32_t tmp_pushes;
     uint32_t out_nodes[5];       // children of the column being expanded (call_outgoing)
     int32_t out_scores[5];
     uint8_t out_chars[8];
     uint64_t cyc[8];             // phase timers (shader cycles)
-    uint64_t xcyc[8];            // extend() breakdown: pop, stage+band, outgoing, column, scan, commit, conv, push          // pointers into the caller's private frame, so outputs live here
+#ifdef MGX_SEED_PROBE
+    uint64_t xcyc[8];            // seeding probe build: per-stage timers of make_seeder
+#else
+    uint64_t xcyc[4];            // extend() breakdown: pop, general steps, chain steps
+#endif
     uint32_t n_columns, n_extensions, n_fast_columns;
     int32_t status;
-    int32_t q_lds;               // the strands q[0], q[1] live in LDS (carve)
-    XState x;
 };
+
+MGX_DEV Block wave_blk_cache(const Wave &w) {
+    Block b;
+    const uint32_t *v = w.blk_cache_w;
+    b.cum[0] = v[0]; b.cum[1] = v[1]; b.cum[2] = v[2]; b.cum[3] = v[3]; b.last_cum = v[4]; b.cum0 = v[5];
+    b.last_bits = ((uint64_t)v[7] << 32) | v[6]; b.p0 = ((uint64_t)v[9] << 32) | v[8]; b.p1 = ((uint64_t)v[11] << 32) | v[10];
+    b.p2 = ((uint64_t)v[13] << 32) | v[12]; b.pf = ((uint64_t)v[15] << 32) | v[14];
+    return b;
+}
+MGX_DEV void wave_set_blk_cache(Wave &w, const Block &b, uint32_t idx) {
+    uint32_t *v = w.blk_cache_w;
+    v[0] = b.cum[0]; v[1] = b.cum[1]; v[2] = b.cum[2]; v[3] = b.cum[3]; v[4] = b.last_cum; v[5] = b.cum0;
+    v[6] = (uint32_t)b.last_bits; v[7] = (uint32_t)(b.last_bits >> 32); v[8] = (uint32_t)b.p0; v[9] = (uint32_t)(b.p0 >> 32);
+    v[10] = (uint32_t)b.p1; v[11] = (uint32_t)(b.p1 >> 32); v[12] = (uint32_t)b.p2; v[13] = (uint32_t)(b.p2 >> 32);
+    v[14] = (uint32_t)b.pf; v[15] = (uint32_t)(b.pf >> 32);
+    w.blk_cache_idx = idx;
+}
 
 MGX_HD uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
 
@@ -318,7 +342,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += align8((uint64_t)lim.max_columns * 2 * sizeof(BtIndex));
     b += 2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path);   // rev_*
     b += 16;                                            // gen_store
-    b += 6 * align8((L + 16) * 4) + 2 * align8(32 * 8); // staging + LDS-tier fallbacks
+    b += 6 * align8((L + 16) * 4);                      // staging
     b += 32 + 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8(ent * L * 4));
     b += 4 * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
     return (b + 63) & ~63ull;          // slices keep the 32-byte alignment of the hash slots and the 16-byte one of the cell records
@@ -344,8 +368,6 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     // persistent fast arrays
     w.q_lds = 2 * Lp <= lleft ? 1 : 0;
     for (int s = 0; s < 2; ++s) w.q[s] = take_fast(Lp);
-    w.lq = (uint64_t *)take_fast(LQ_CAP * 8);
-    w.lnn = (uint64_t *)take_fast(LQ_CAP * 8);
     // overlay: the seeding tables and the extension's column staging are never live at the same time
     uint8_t *lp_mark = lp;
     uint32_t lleft_mark = lleft;
@@ -413,7 +435,7 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
 // LDS bytes that hold every "fast" array of carve() for a given Lmax
 MGX_HD uint32_t fast_lds_bytes(uint32_t Lmax) {
     uint64_t L = Lmax, Lp = align8(L + 8);
-    uint64_t persistent = 2 * Lp + 2 * align8((L + 1) * 4) + 2 * 32 * 8 + 2 * align8(((L + 15) / 16 + 2) * 4);
+    uint64_t persistent = 2 * Lp + 2 * align8((L + 1) * 4) + 2 * align8(((L + 15) / 16 + 2) * 4);
     uint64_t seeding = 3 * align8((L + 1) * 2) + align8(L + 1) + 3 * align8((L + 1) * 4) + align8(sizeof(SdustScratch))
                        + 4 * align8(((L + 63) / 64 + 1) * 8) + align8((L + 8) * 8) + align8(L + 8);
     uint64_t staging = 6 * align8((L + 16) * 4);
@@ -1405,9 +1427,8 @@ MGX_DEV uint64_t queue_key(int32_t score, int32_t neg_off_diag, uint32_t idx) {
 MGX_DEV int32_t key_score(uint64_t key) { return (int32_t)(uint32_t)(key >> 40) - (1 << 23); }
 MGX_DEV uint32_t key_idx(uint64_t key) { return (uint32_t)(key & 0xFFFFFF); }
 
-// two-tier arrays: the first LQ_CAP entries in LDS, the rest in the arena
-MGX_DEV uint64_t tier_get(const uint64_t *lds, const uint64_t *arena, int32_t i) { return i < LQ_CAP ? lds[i] : gld(arena + (i - LQ_CAP)); }
-MGX_DEV void tier_set(uint64_t *lds, uint64_t *arena, int32_t i, uint64_t v) { if (i < LQ_CAP) lds[i] = v; else gst(arena + (i - LQ_CAP), v); }
+MGX_DEV uint64_t qget(const uint64_t *arena, int32_t i) { return gld(arena + i); }
+MGX_DEV void qset(uint64_t *arena, int32_t i, uint64_t v) { gst(arena + i, v); }
 
 // The frontier (std::priority_queue<TableIt>, :477-487) is kept as an ascending sorted array (keys are
 // unique), so the maximum is at the back.  Insert = lane-parallel rank + shift.
@@ -1417,22 +1438,33 @@ MGX_DEV void frontier_insert(Wave &w, int32_t &qn, uint64_t key) {
     int32_t pos = 0;
     for (int32_t base = 0; base < qn; base += WAVE) {
         LV<bool> lt;
-        FOR_LANES(l) { int32_t j = base + l; lt[l] = j < qn && tier_get(w.lq, w.queue, j) < key; }
+        FOR_LANES(l) { int32_t j = base + l; lt[l] = j < qn && qget(w.queue, j) < key; }
         pos += popc64(wave_ballot(lt));
     }
     // shift [pos, qn) up by one, highest chunk first
     for (int32_t top = qn; top > pos; top -= WAVE) {
         int32_t lo = imax(pos, top - WAVE);
         LV<uint64_t> v;
-        FOR_LANES(l) { int32_t j = lo + l; v[l] = j < top ? tier_get(w.lq, w.queue, j) : 0; }
+        FOR_LANES(l) { int32_t j = lo + l; v[l] = j < top ? qget(w.queue, j) : 0; }
         wave_sync();
-        FOR_LANES(l) { int32_t j = lo + l; if (j < top) tier_set(w.lq, w.queue, j + 1, v[l]); }
+        FOR_LANES(l) { int32_t j = lo + l; if (j < top) qset(w.queue, j + 1, v[l]); }
         wave_sync();
     }
-    tier_set(w.lq, w.queue, pos, key);
+    qset(w.queue, pos, key);
     ++qn;
     wave_sync();
 }
+
+#ifndef MGX_NO_EXTEND
+// frontier_insert on the extension's loop state (keeps the cached top score current)
+MGX_DEV void frontier_push(Wave &w, uint64_t key) {
+    XState &x = w.x;
+    int32_t qn = x.qn;
+    x.q_top = qn ? imax(x.q_top, key_score(key)) : key_score(key);
+    frontier_insert(w, qn, key);
+    x.qn = qn;
+}
+#endif
 
 MGX_DEV int32_t st_S(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tget(s.S, cap, j) : NINF; }
 MGX_DEV int32_t st_F(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tget(s.F, cap, j) : NINF; }
@@ -1644,14 +1676,13 @@ MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node,
         const DevGraph &g = P.g;
         const uint64_t v = node;
         Block cur;
-        if ((uint32_t)(v >> 6) == uni(w.blk_cache_idx)) cur = uni_block(w.blk_cache);
+        if ((uint32_t)(v >> 6) == uni(w.blk_cache_idx)) cur = uni_block(wave_blk_cache(w));
         else { ++w.ctr.rank_lines; cur = load_block_uniform(g, uni((uint32_t)(v >> 6))); }
         uint32_t wv = block_W(cur, (int)(v & 63));
         if (v > 1 && wv == 0) return 0;
         Block tgt;
         const uint64_t lst = uni(fwd_from<true>(g, v, cur, wv % SIGMA, tgt, w.ctr));
-        w.blk_cache = tgt;
-        w.blk_cache_idx = (uint32_t)(lst >> 6);
+        wave_set_blk_cache(w, tgt, (uint32_t)(lst >> 6));
         uint64_t first = pred_last_from<true>(g, lst - 1, ((lst - 1) >> 6) == (lst >> 6) ? tgt : load_block_uniform(g, uni((uint32_t)((lst - 1) >> 6))), w.ctr) + 1;
         if (first < 2) first = 2;
         n = 0;
@@ -1730,14 +1761,13 @@ MGX_DEV int32_t reg_at(const LV<int32_t> &A0, const LV<int32_t> &A1, const LV<in
 MGX_DEV bool fast_fits(const ColMeta &c) { return (c.trim & 3) + c.size + 3 <= FW; }
 
 // load column `idx` (metadata c) into the chain window from its staging buffer or its arena record
-MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx) {
+MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx, LV<int32_t> *S, LV<int32_t> *F) {
     XState &x = w.x;
     x.f_idx = idx; x.f_node = c.node; x.f_offset = c.offset; x.f_trim = c.trim; x.f_size = c.size; x.f_max_pos = c.max_pos;
     const int32_t org = c.trim & ~3;
     x.f_org = org;
     const int32_t n = c.size + 5;
     const int sb = (w.st[0].col == idx) ? 0 : (w.st[1].col == idx) ? 1 : -1;
-    LV<int32_t> S[4];
     if (sb >= 0) {
         const Staging st = w.st[sb];
         const int32_t cap = w.st_cap;
@@ -1746,7 +1776,7 @@ MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx) {
                 const int32_t j = org + 4 * l + s - c.trim;
                 const bool in = j >= 0 && j < n;
                 S[s][l] = in ? tget(st.S, cap, j) : NINF;
-                x.fF[4 * l + s] = in ? tget(st.F, cap, j) : NINF;
+                F[s][l] = in ? tget(st.F, cap, j) : NINF;
             }
         }
     } else {
@@ -1757,17 +1787,16 @@ MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx) {
                 const int32_t a = org + 4 * l + s, j = a - c.trim, rx = a - c.org;
                 const bool in = j >= 0 && j < n && rx < wc;
                 S[s][l] = in ? gld(recS + rx) : NINF;
-                x.fF[4 * l + s] = in ? gld(recF + rx) : NINF;
+                F[s][l] = in ? gld(recF + rx) : NINF;
             }
         }
     }
-    FOR_LANES(l) { for (int s = 0; s < 4; ++s) x.fS[4 * l + s] = S[s][l]; }
     x.f_max_val = reg_at(S[0], S[1], S[2], S[3], org, c.max_pos);
     wave_sync();
 }
 
 // the chain's parent goes back to staging buffer 0 in the general layout (cell j = window position trim + j)
-MGX_DEV void fast_spill(Wave &w) {
+MGX_DEV void fast_spill(Wave &w, const LV<int32_t> *S, const LV<int32_t> *F) {
     XState &x = w.x;
     Staging &st = w.st[0];
     const int32_t cap = w.st_cap;
@@ -1775,7 +1804,7 @@ MGX_DEV void fast_spill(Wave &w) {
     FOR_LANES(l) {
         for (int s = 0; s < 4; ++s) {
             const int32_t j = x.f_org + 4 * l + s - x.f_trim;
-            if (j >= 0 && j < n) { tset(st.S, cap, j, x.fS[4 * l + s]); tset(st.F, cap, j, x.fF[4 * l + s]); }
+            if (j >= 0 && j < n) { tset(st.S, cap, j, S[s][l]); tset(st.F, cap, j, F[s][l]); }
         }
     }
     // cells the window does not hold: past its end, or below an origin that moved up with the band (all under the
@@ -1804,7 +1833,7 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const DevLimits &lim = P.lim;
-    const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : gld(w.cols + i));
+    const ColMeta col = uni_col(gld(w.cols + i));
     const int32_t max_columns = (int32_t)uni(lim.max_columns);
     const uint32_t cell_words = uni(lim.cell_words);
     const double rel_cutoff = cfg.rel_score_cutoff, max_nodes_per_char = cfg.max_nodes_per_seq_char, max_ram = cfg.max_ram_per_alignment;
@@ -1813,7 +1842,6 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
     const int32_t *psum = E.psum;
     const int32_t seed_off = x.seed_off, seed_seq_len = x.seed_seq_len, seed_offset = x.seed_off - 1;
     const bool force_fixed_seed = x.force_fixed != 0;
-    uint64_t tx1 = xclock();
     const int pb = uni(stage_column(w, i, col));
     const Staging par = w.st[pb];
     const int32_t cap = uni(w.st_cap);
@@ -1842,8 +1870,6 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
         begin = b + col.trim; prev_end = e + col.trim;
     }
     if (prev_end <= begin) return 0;
-    uint64_t tx2 = xclock();
-    w.xcyc[1] += tx2 - tx1;
     // the children list lives in the LDS control block: a private array indexed at run time would sit in scratch
     uint32_t *out_nodes = w.out_nodes;
     uint8_t *out_chars = w.out_chars;
@@ -1855,7 +1881,6 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
         if (x.n_tips < max_columns) gst(w.tips + x.n_tips++, (uint32_t)i);
         return 0;
     }
-    w.xcyc[2] += xclock() - tx2;
     const int32_t end = imin(prev_end, window_size) + 1;
     const int cb = 1 - pb;
     for (int oi = 0; oi < n_out; ++oi) {
@@ -1869,12 +1894,9 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
         uint32_t table_cap_before = E.table_cap;
         if ((uint32_t)x.tsize == E.table_cap) E.table_cap = imax<uint32_t>(1u, 2 * E.table_cap);
         ++w.n_columns;
-        uint64_t tx3 = xclock();
         const int32_t size = uni(compute_column(w, E, col.size, col.trim, pb, cb, prev_end, begin, size0, c, score, next_offset,
                                                 start, window_size, x.xdrop_cutoff));
         const int32_t pushes = uni(w.tmp_pushes);
-        uint64_t tx4 = xclock();
-        w.xcyc[3] += tx4 - tx3;
         ColMeta cur;
         cur.node = next; cur.parent = i; cur.cw = c; cur.org = begin; cur.offset = next_offset; cur.max_pos = begin; cur.trim = begin;
         cur.score = score; cur.cells = x.cell_top; cur.size = size;
@@ -1911,8 +1933,6 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
         x.min_cell_score = min_cell_score;
         cur.max_pos = best_j + begin;
         const int32_t max_val = best_s;
-        uint64_t tx5 = xclock();
-        w.xcyc[4] += tx5 - tx4;
         if ((!in_seed && max_val < x.xdrop_cutoff) || (!in_seed && !has_extension)) {
             // pop(table.size() - 1): the vector keeps its (possibly grown) capacity
             continue;
@@ -1926,39 +1946,31 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
         cur.cw |= (uint32_t)cur_wc << 8;
         const int32_t my_idx = x.tsize;
         gst(w.cols + my_idx, cur);
-        w.hot = cur;
-        w.hot_idx = my_idx;
         w.st[cb].col = my_idx;
         x.cell_top += rec_words((uint32_t)cur_wc);
         x.tsize = my_idx + 1;
         const int32_t vec_offset = start + begin - (begin ? 1 : 0);
         const int32_t skip = begin ? 0 : 1;
-        uint64_t tx6 = xclock();
-        w.xcyc[5] += tx6 - tx5;
         int32_t converged = update_seed_filter(w, E, next, vec_offset, cS, skip, size - skip);
-        uint64_t tx7 = xclock();
-        w.xcyc[6] += tx7 - tx6;
         if (w.status != ST_OK) return 1;
         if (converged != NINF) {
             uint64_t key = queue_key(converged, -iabs(cur.max_pos - diag_i), (uint32_t)my_idx);
             // next_nodes[0] is the first element popped into this batch (still there unless the batch
             // has been fully consumed, in which case next_nodes.size() == 0)
-            if (x.nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
-                tier_set(w.lnn, w.next_nodes, x.nn++, key);
+            if (x.nn && converged == key_score(qget(w.next_nodes, 0))) {
+                qset(w.next_nodes, x.nn++, key);
                 wave_sync();
             } else {
-                int32_t qn = x.qn;
-                frontier_insert(w, qn, key);
-                x.qn = qn;
+                frontier_push(w, key);
             }
         }
-        w.xcyc[7] += xclock() - tx7;
     }
     return 0;
 }
 
 // ---- chain path: the only child of the window column, computed, judged and committed in registers ----
-MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
+// pS / pF: the window column (S and F of the chain's current parent), loop-carried registers of extend()
+MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *pF) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
     XState &x = w.x;
@@ -1972,8 +1984,6 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
         if (node_counter / (double)window_size >= x.max_nodes_per_char) return FR_STOP;
         if ((double)x.table_size_bytes / 1000000.0 > x.max_ram) return FR_STOP;
     }
-    LV<int32_t> pS[4], pF[4];
-    FOR_LANES(l) { for (int s = 0; s < 4; ++s) { pS[s][l] = x.fS[4 * l + s]; pF[s][l] = x.fF[4 * l + s]; } }
     int32_t p_org = x.f_org;
     // band within the x-drop cutoff (:549-560)
     int32_t begin, prev_end;
@@ -2041,7 +2051,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
         if (!x.rc && next > 1 && !replay2 && (next >> 6) == w.blk_cache_idx) {
             MGX_ASSUME_PARAMS(w.P);
             const DevGraph &g = w.P->g;
-            const Block cur = w.blk_cache;
+            const Block cur = wave_blk_cache(w);
             const uint32_t wv = block_W(cur, (int)(next & 63));
             if (wv == 0) {
                 pf = true; pf_zero = 1;                          // sink dummy: no children (dbg_succinct.cpp:113)
@@ -2165,9 +2175,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
             if (ge != 0) n_push = 1 + imin(room, (int32_t)(((int64_t)ins_score - (int64_t)xdrop_cutoff) / (int64_t)(-ge)));
             if ((begin - org) + size0 + n_push > FW) {
                 // the parent window has moved: keep it consistent for the spill
-                FOR_LANES(l) { for (int s = 0; s < 4; ++s) { x.fS[4 * l + s] = pS[s][l]; x.fF[4 * l + s] = pF[s][l]; } }
                 x.f_org = p_org;
-                wave_sync();
                 return FR_FALLBACK;
             }
             FOR_LANES(l) {
@@ -2321,8 +2329,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
                     }
                 }
                 if (pf_n > 4) pf_n = 4;
-                w.blk_cache = pf_blk;
-                w.blk_cache_idx = pf_hint;
+                wave_set_blk_cache(w, pf_blk, pf_hint);
                 ++w.ctr.select_lines;
             }
         }
@@ -2380,29 +2387,25 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E) {
     if (w.status != ST_OK) return FR_ERROR;
     if (converged == NINF) return FR_END;
     // the frontier would hand this column straight back iff it is the unique maximum (:491-504)
-    if (x.nn == 0 && (x.qn == 0 || converged > key_score(tier_get(w.lq, w.queue, x.qn - 1))) && fast_fits(cur)) {
-        FOR_LANES(l) { for (int s = 0; s < 4; ++s) { x.fS[4 * l + s] = cS[s][l]; x.fF[4 * l + s] = cF[s][l]; } }
+    if (x.nn == 0 && (x.qn == 0 || converged > x.q_top) && fast_fits(cur)) {
+        for (int s = 0; s < 4; ++s) { pS[s] = cS[s]; pF[s] = cF[s]; }
         x.f_idx = my_idx; x.f_node = next; x.f_offset = next_offset; x.f_trim = begin; x.f_size = size; x.f_max_pos = max_pos;
         x.f_max_val = max_val; x.f_org = org;
         if (pf_n >= 0) { x.n_valid = 1; x.n_for = my_idx; x.n_count = pf_n; }
         wave_sync();
-        w.xcyc[3] += xclock() - tx1;
+        w.xcyc[2] += xclock() - tx1;
         return FR_CONT;
     }
     {
         uint64_t key = queue_key(converged, -iabs(max_pos - diag_i), (uint32_t)my_idx);
-        if (x.nn && converged == key_score(tier_get(w.lnn, w.next_nodes, 0))) {
-            tier_set(w.lnn, w.next_nodes, x.nn++, key);
+        if (x.nn && converged == key_score(qget(w.next_nodes, 0))) {
+            qset(w.next_nodes, x.nn++, key);
             wave_sync();
         } else {
-            int32_t qn = x.qn;
-            frontier_insert(w, qn, key);
-            x.qn = qn;
+            frontier_push(w, key);
         }
-        w.hot = cur;
-        w.hot_idx = my_idx;
     }
-    w.xcyc[3] += xclock() - tx1;
+    w.xcyc[2] += xclock() - tx1;
     return FR_END;
 }
 
@@ -2446,7 +2449,6 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     x.table_size_bytes = 0;
     x.f_n_out = 0;
     w.st[0].col = -1; w.st[1].col = -1;
-    w.hot_idx = -1;
     w.blk_cache_idx = 0xFFFFFFFFu;
     // root column (:455-470)
     {
@@ -2494,21 +2496,17 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         x.cell_top = rec_words((uint32_t)root_wc);
         if (E.table_cap < 1) E.table_cap = 1;                 // emplace_back on an empty vector
         gst(w.cols + 0, r);
-        w.hot = r;
-        w.hot_idx = 0;
         x.tsize = 1;
         x.table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)root_cap3 * 4;
     }
     x.min_cell_score = 0;
     x.best_score = 0;
     x.qn = 0; x.nn = 0; x.n_tips = 0;
-    {
-        int32_t qn = 0;
-        frontier_insert(w, qn, queue_key(0, 0, 0));
-        x.qn = qn;
-    }
+    frontier_push(w, queue_key(0, 0, 0));
     const bool use_fast = !P.no_fast;
     int mode = XM_POP;
+    LV<int32_t> pS[4], pF[4];            // the chain window: S and F of the chain's current column, 4 cells per lane
+    FOR_LANES(l) { for (int s = 0; s < 4; ++s) { pS[s][l] = NINF; pF[s][l] = NINF; } }
     for (;;) {
         int32_t gi = -1;                 // column for the general step of this iteration
         bool children_ready = false;
@@ -2518,38 +2516,44 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 uint64_t tx0 = xclock();
                 // pop every entry that shares the top score, in descending tuple order (:491-500)
                 int32_t qn = x.qn, nn = 0;
-                const int32_t top_score = key_score(tier_get(w.lq, w.queue, qn - 1));
-                while (qn && key_score(tier_get(w.lq, w.queue, qn - 1)) == top_score) {
-                    tier_set(w.lnn, w.next_nodes, nn++, tier_get(w.lq, w.queue, qn - 1));
+                const int32_t top_score = key_score(qget(w.queue, qn - 1));
+                while (qn && key_score(qget(w.queue, qn - 1)) == top_score) {
+                    qset(w.next_nodes, nn++, qget(w.queue, qn - 1));
                     --qn;
                 }
                 x.qn = qn; x.nn = nn;
+                x.q_top = qn ? key_score(qget(w.queue, qn - 1)) : INT32_MIN;
                 wave_sync();
                 w.xcyc[0] += xclock() - tx0;
             }
-            const int32_t i = (int32_t)uni(key_idx(tier_get(w.lnn, w.next_nodes, x.nn - 1)));
+            const int32_t i = (int32_t)uni(key_idx(qget(w.next_nodes, x.nn - 1)));
             --x.nn;
-            const ColMeta col = uni_col((i == uni(w.hot_idx)) ? w.hot : gld(w.cols + i));
+            const ColMeta col = uni_col(gld(w.cols + i));
             if (use_fast && x.nn == 0 && fast_fits(col)) {
-                fast_load(w, col, i);
+                fast_load(w, col, i, pS, pF);
                 mode = XM_FAST;
             } else {
                 gi = i;
             }
         }
         if (mode == XM_FAST) {
-            const int r = chain_step(w, E);
+            const int r = chain_step(w, E, pS, pF);
             if (r == FR_CONT) continue;
             mode = XM_POP;
             if (r == FR_END) continue;
             if (r == FR_STOP) { x.qn = 0; x.nn = 0; continue; }
             if (r == FR_ERROR) { res->table_size = 0; return; }
             // FR_FALLBACK: the parent goes through the general code (children already enumerated)
-            fast_spill(w);
+            fast_spill(w, pS, pF);
             gi = x.f_idx;
             children_ready = true;
         }
-        if (gi >= 0 && general_step(w, E, seed, gi, children_ready)) { res->table_size = 0; return; }
+        if (gi >= 0) {
+            const uint64_t tg = xclock();
+            const int bad = general_step(w, E, seed, gi, children_ready);
+            w.xcyc[1] += xclock() - tg;
+            if (bad) { res->table_size = 0; return; }
+        }
     }
     wave_sync();
     res->n_tips = x.n_tips;
@@ -3162,7 +3166,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     rr.orientation = 0; rr.stream_off = 0;
     rr.num_matches_fwd = rr.num_matches_rc = rr.n_seeds_fwd = rr.n_seeds_rc = 0; rr.n_extensions = rr.n_columns = 0;
 
-    for (int x = 0; x < 8; ++x) { w.cyc[x] = 0; w.xcyc[x] = 0; }
+    for (int x = 0; x < 8; ++x) w.cyc[x] = 0;
+    for (int x = 0; x < XCYC_N; ++x) w.xcyc[x] = 0;
     const uint64_t tstart = cycle_clock();
     if (w.L > (int32_t)P.lim.Lmax) {
         w.status = ST_CAPACITY;
@@ -3293,7 +3298,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
         for (int x = 0; x < 2; ++x) stats_accum->cyc[x] += w.cyc[x];
 #ifdef MGX_SEED_PROBE
-        for (int x = 0; x < 8; ++x) stats_accum->xcyc[x] += w.xcyc[x];
+        for (int x = 0; x < XCYC_N; ++x) stats_accum->xcyc[x] += w.xcyc[x];
 #endif
         return;
     }
@@ -3311,7 +3316,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         stats_accum->rank_lines += w.ctr.rank_lines;
         stats_accum->select_lines += w.ctr.select_lines;
         stats_accum->bit_lines += w.ctr.bit_lines;
-        for (int x = 0; x < 8; ++x) { stats_accum->cyc[x] += w.cyc[x]; stats_accum->xcyc[x] += w.xcyc[x]; }
+        for (int x = 0; x < 8; ++x) stats_accum->cyc[x] += w.cyc[x];
+    for (int x = 0; x < XCYC_N; ++x) stats_accum->xcyc[x] += w.xcyc[x];
         return;
     }
     const uint64_t tout = cycle_clock();
@@ -3362,7 +3368,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     if (PHASE & PH_SEED) stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
     stats_accum->capacity_errors += rr.status != ST_OK;
     w.cyc[5] = cycle_clock() - tout;
-    for (int x = 0; x < 8; ++x) { stats_accum->cyc[x] += w.cyc[x]; stats_accum->xcyc[x] += w.xcyc[x]; }
+    for (int x = 0; x < 8; ++x) stats_accum->cyc[x] += w.cyc[x];
+    for (int x = 0; x < XCYC_N; ++x) stats_accum->xcyc[x] += w.xcyc[x];
 }
 
 } // namespace mgx

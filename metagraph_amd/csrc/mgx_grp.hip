@@ -14,8 +14,11 @@
 
 using namespace mgx;
 
+// 3 waves per SIMD: the kernel is bound by dependent memory round trips (halving the resident groups costs 1.77x), so
+// the control block was slimmed until 12 wavefronts' worth of it (+ both strands of a 150-bp read each) fit a CU's LDS;
+// 168 VGPRs hold the extension loop with a handful of spills
 #ifndef MGX_GRP_WAVES_PER_SIMD
-#define MGX_GRP_WAVES_PER_SIMD 2
+#define MGX_GRP_WAVES_PER_SIMD 3
 #endif
 
 // each group owns one read at a time, one arena slice and one slice of the dynamic LDS
@@ -80,4 +83,4 @@ extern "C" int MGX_CAT(mgx_launch_align_grp, MGX_GROUP)(const void *params, uint
     return (int)hipGetLastError();
 }
 extern "C" int MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP)(void) { return MGX_GRP_WAVES_PER_SIMD; }
-extern "C" unsigned MGX_CAT(mgx_grp_static_lds, MGX_GROUP)(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + sizeof(AlignParams) + 6 * 128 + 64); }
+extern "C" unsigned MGX_CAT(mgx_grp_static_lds, MGX_GROUP)(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + sizeof(AlignParams) + 6 * 128); }
