@@ -107,6 +107,8 @@ struct AlignParams {
     unsigned long long *retry_count;
     const unsigned long long *n_items_ptr;   // null: n_reads items
     uint32_t no_fast;                    // A/B and test switch: every column through the general (staging buffer) path
+    uint32_t ablate;                     // timing probes only (results become WRONG): bit 0 = no convergence table in the chain
+                                         // step, bit 1 = no cell records / column metadata stores, bit 2 = no backtrack
 };
 
 } // namespace mgx

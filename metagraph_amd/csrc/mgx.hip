@@ -676,6 +676,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
     static const bool no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;      // A/B switch: general path only
     P.no_fast = no_fast || A->no_fast;
+    P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results
     size_t sort_tmp_bytes = 0;
     if (split) {
         // seeds travel from the seeding kernel to the extension kernel through a compact stream
@@ -710,14 +711,15 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     uint32_t lds_bytes = std::min<uint32_t>(fast_lds_bytes(l.Lmax), lds_budget) & ~15u;
     const uint32_t w_slots = (uint32_t)std::min<uint64_t>(slots, wave_slots);
     auto launch_groups = [&](int phase) -> int {
-        // tuning probe: MGX_EXT_GROUPS_DIV=2 launches half the resident groups (occupancy experiments)
-        static const uint32_t div = getenv("MGX_EXT_GROUPS_DIV") ? (uint32_t)std::max(1, atoi(getenv("MGX_EXT_GROUPS_DIV"))) : 1u;
+        // tuning probe: MGX_EXT_GROUPS_PCT=50 launches half the resident groups (occupancy experiments)
+        static const uint32_t pct = getenv("MGX_EXT_GROUPS_PCT") ? (uint32_t)std::min(100, std::max(1, atoi(getenv("MGX_EXT_GROUPS_PCT")))) : 100u;
         const uint32_t groups = 8;
         const uint32_t waves_cu = 4u * (uint32_t)mgx_grp_waves_per_simd8();
         const uint32_t static_lds = mgx_grp_static_lds8();
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 64u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
-        return mgx_launch_align_grp8(&P, (uint32_t)std::max<uint64_t>(8, slots / div), per_group, phase, nullptr);
+        if (const char *e = getenv("MGX_EXT_LDS_CAP")) per_group = std::min<uint32_t>(per_group, (uint32_t)atoi(e)) & ~15u;   // tuning probe
+        return mgx_launch_align_grp8(&P, (uint32_t)std::max<uint64_t>(8, slots * pct / 100), per_group, phase, nullptr);
     };
     A->split_ran = split;
     if (split) {

@@ -14,11 +14,12 @@
 
 using namespace mgx;
 
-// 3 waves per SIMD: the kernel is bound by dependent memory round trips (halving the resident groups costs 1.77x), so
-// the control block was slimmed until 12 wavefronts' worth of it (+ both strands of a 150-bp read each) fit a CU's LDS;
-// 168 VGPRs hold the extension loop with a handful of spills
+// 2 waves per SIMD.  The kernel is bound by dependent round trips (halving the resident groups costs 1.77x) and its control
+// block is small enough for 3 (12 wavefronts per CU with both strands of a 150-bp read in LDS), but the 168-VGPR budget
+// that goes with 3 makes the code itself 1.7x slower at equal occupancy (measured: 1273 vs 734 ms per 4 M reads at 2
+// waves' worth of groups, 927 ms with all 3) — so the register allocation, not LDS, sets the occupancy here.
 #ifndef MGX_GRP_WAVES_PER_SIMD
-#define MGX_GRP_WAVES_PER_SIMD 3
+#define MGX_GRP_WAVES_PER_SIMD 2
 #endif
 
 // each group owns one read at a time, one arena slice and one slice of the dynamic LDS
