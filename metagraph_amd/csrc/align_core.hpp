@@ -205,9 +205,6 @@ constexpr int32_t FW = 4 * WAVE;
 struct XState {
     int32_t xdrop_cutoff, best_score, tsize, min_cell_score, qn, nn, n_tips;
     int32_t q_top;                        // score of the frontier's top entry (INT32_MIN when empty)
-    // backtracking start cells (:815-867) are collected while the columns are committed
-    int32_t min_start_score, seed_dist, n_idx, bt_best_at;
-    BtIndex bt_best;
     uint32_t cell_top;
     uint64_t table_size_bytes;
     int32_t start, window_size, qlen, partial_sum_offset, seed_off, seed_seq_len, psum_lin, force_fixed;
@@ -1826,53 +1823,6 @@ MGX_DEV void fast_spill(Wave &w, const LV<int32_t> *S, const LV<int32_t> *F) {
 enum { XM_POP = 0, XM_FAST = 1 };
 enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 3, FR_STOP = 4, FR_ERROR = 5 };
 
-// ---- backtracking start cells, collected as columns are committed (instead of a scan over the table afterwards) ----
-MGX_DEV bool bt_greater(const BtIndex &a, const BtIndex &b) {
-    if (a.score != b.score) return a.score > b.score;
-    if (a.neg_off_diag != b.neg_off_diag) return a.neg_off_diag > b.neg_off_diag;
-    if (a.neg_i != b.neg_i) return a.neg_i > b.neg_i;
-    return a.pos > b.pos;
-}
-// one candidate (:843-851); the list's order is irrelevant (the heap pops by the full, unique tuple) and the running
-// lexicographic maximum is what the first pop — usually the only one — takes
-MGX_DEV void bt_push(Wave &w, int32_t score, int32_t start_pos, int32_t col_offset, int32_t i) {
-    XState &x = w.x;
-    BtIndex bx;
-    bx.score = score; bx.neg_off_diag = -iabs(start_pos - col_offset + (x.seed_off - 1)); bx.neg_i = -i; bx.pos = start_pos;
-    const int32_t at = x.n_idx;
-    FOR_LANES(l) { if (l == 0) gst(w.indices + at, bx); }
-    if (x.bt_best_at < 0 || bt_greater(bx, x.bt_best)) { x.bt_best = bx; x.bt_best_at = at; }
-    x.n_idx = at + 1;
-}
-// the candidates of committed column i from its arena record (general path, tips, rare chain cases).
-// tip_only: i has just turned out to be a tip — add what qualifies only because of that (the rest is in already).
-MGX_DEV void bt_candidates(Wave &w, const ExtenderState &E, int32_t i, bool is_tip, bool tip_only) {
-    XState &x = w.x;
-    if (i <= 0) return;
-    const ColMeta col = gld(w.cols + i);
-    if (col.offset < x.seed_dist) return;
-    const ColMeta par = gld(w.cols + col.parent);
-    const int32_t last_pos = x.window_size;
-    for (int pass = 0; pass < 2; ++pass) {
-        int32_t start_pos;
-        if (pass == 0) start_pos = col.max_pos;
-        else {
-            if (!(col.size + col.trim == x.window_size + 1 && col.max_pos != last_pos)) break;
-            start_pos = last_pos;
-        }
-        if (start_pos < par.trim + 1) continue;
-        const int32_t sv = cell_S(w, col, start_pos), sp = cell_S(w, par, start_pos - 1);
-        if (sv == NINF || sp == NINF) continue;
-        const int32_t end_bonus = start_pos == last_pos ? w.P->cfg.right_end_bonus : 0;
-        if (sv + end_bonus >= x.min_start_score) {
-            const bool is_match = sv == sp + col.score + profile_at(w, E.q, w.L, col_char(col), x.start + start_pos)
-                && profile_op_at(E.q, w.L, col_char(col), x.start + start_pos) == OP_MATCH;
-            const bool plain = is_match || start_pos == last_pos;
-            if (tip_only ? (is_tip && !plain) : (plain || is_tip)) bt_push(w, sv + end_bonus, start_pos, col.offset, i);
-        }
-    }
-}
-
 // ---- general path: one popped column `i` with all its children (staging buffers, frontier arrays) ----
 // returns 0, or 1 = the extension is over (capacity error; w.status says which)
 MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const int32_t i, const bool children_ready) {
@@ -1928,7 +1878,7 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
     const int n_out = children_ready ? x.f_n_out : uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
     wave_sync();
     if (n_out == 0) {
-        if (x.n_tips < max_columns) { gst(w.tips + x.n_tips++, (uint32_t)i); wave_sync(); bt_candidates(w, E, i, true, true); }
+        if (x.n_tips < max_columns) gst(w.tips + x.n_tips++, (uint32_t)i);
         return 0;
     }
     const int32_t end = imin(prev_end, window_size) + 1;
@@ -1999,8 +1949,6 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
         w.st[cb].col = my_idx;
         x.cell_top += rec_words((uint32_t)cur_wc);
         x.tsize = my_idx + 1;
-        wave_sync();
-        bt_candidates(w, E, my_idx, false, false);
         const int32_t vec_offset = start + begin - (begin ? 1 : 0);
         const int32_t skip = begin ? 0 : 1;
         int32_t converged = update_seed_filter(w, E, next, vec_offset, cS, skip, size - skip);
@@ -2075,7 +2023,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         }
         x.n_valid = 0;
         if (n_out == 0) {
-            if (x.n_tips < x.max_columns) { gst(w.tips + x.n_tips++, (uint32_t)x.f_idx); bt_candidates(w, E, x.f_idx, true, true); }
+            if (x.n_tips < x.max_columns) gst(w.tips + x.n_tips++, (uint32_t)x.f_idx);
             return FR_END;
         }
         x.f_n_out = n_out;
@@ -2289,28 +2237,6 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     x.table_size_bytes += (uint64_t)136 * (E.table_cap - table_cap_before) + (uint64_t)cur_cap3 * 4;
     if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > x.xdrop) x.xdrop_cutoff = max_val - x.xdrop;
     x.best_score = imax(x.best_score, max_val);
-    // backtracking start cells of this column (:815-867) while it and its parent are in registers
-    bool bt_from_arena = false;
-    if (next_offset >= x.seed_dist) {
-        const int32_t last_pos = window_size;
-        const bool second = size + begin == window_size + 1 && max_pos != last_pos;
-        // a parent cell that left the window when its origin moved up with the band (rare): whole column from the arena
-        bt_from_arena = (max_pos >= x.f_trim + 1 && max_pos - 1 < org) || (second && last_pos >= x.f_trim + 1 && last_pos - 1 < org);
-        for (int pass = 0; pass < 2 && !bt_from_arena; ++pass) {
-            if (pass == 1 && !second) break;
-            const int32_t start_pos = pass == 0 ? max_pos : last_pos;
-            if (start_pos < x.f_trim + 1) continue;
-            const int32_t sv = pass == 0 ? max_val : reg_at(cS[0], cS[1], cS[2], cS[3], org, start_pos);
-            const int32_t sp = reg_at(pS[0], pS[1], pS[2], pS[3], org, start_pos - 1);
-            if (sv == NINF || sp == NINF) continue;
-            const int32_t end_bonus = start_pos == last_pos ? w.P->cfg.right_end_bonus : 0;
-            if (sv + end_bonus >= x.min_start_score) {
-                const bool is_match = sv == sp + score + profile_at(w, E.q, w.L, c, start + start_pos)
-                    && profile_op_at(E.q, w.L, c, start + start_pos) == OP_MATCH;
-                if (is_match || start_pos == last_pos) bt_push(w, sv + end_bonus, start_pos, next_offset, x.tsize);
-            }
-        }
-    }
     // --- everything that LOADS comes first (a wait on a load also waits for every store issued before it) ---
     // update_seed_filter (:100-156), resolution: cell at window position a (j in [skip, size)) is query position
     // start + a - 1 of the node's vector.  A position outside the vector's old range holds ninf by definition, so
@@ -2435,7 +2361,6 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     if (!(w.P->ablate & 2u)) { FOR_LANES(l) { if (l == 0) gst(w.cols + my_idx, cur); } }
     x.tsize = my_idx + 1;
     x.cell_top += rec_words((uint32_t)FW);
-    if (bt_from_arena) { wave_sync(); bt_candidates(w, E, my_idx, false, false); }
     // update_seed_filter, the stores
     if (cv_mode == CV_INSERT) {
         const int32_t vi = conv_insert(w, E.conv, cv_slot, ckey, query_start, cn);
@@ -2488,7 +2413,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
 
 // One function for the whole loop: a call boundary makes the callee wait for every store it issued (s_waitcnt before
 // s_setpc), which would drain each column's record stores at the end of each step.
-MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed, int32_t min_path_score) {
+MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
     MGX_ASSUME_PARAMS(w.P);
@@ -2518,9 +2443,6 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     x.rc_key_add = E.rc_view ? P.g.n : 0;
     x.rc = E.rc_view ? 1 : 0;
     x.n_valid = 0; x.n_for = -1; x.n_count = 0;
-    x.min_start_score = min_path_score;
-    x.seed_dist = imax((int32_t)P.g.k, (int32_t)seed.seq_len) - 1;
-    x.n_idx = 0; x.bt_best_at = -1;
     x.rel_cutoff = cfg.rel_score_cutoff; x.max_nodes_per_char = cfg.max_nodes_per_seq_char; x.max_ram = cfg.max_ram_per_alignment;
     x.go = cfg.gap_open; x.ge = cfg.gap_ext; x.xdrop = cfg.xdrop; x.k = (int32_t)P.g.k; x.Lq = (int32_t)lim.Lmax;
     x.max_columns = (int32_t)lim.max_columns; x.hash_mask = lim.hash_size - 1; x.cell_words = lim.cell_words;
@@ -2683,11 +2605,95 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
     const int32_t min_trace_length = k - seed.offset;
     const int32_t right_end_bonus = cfg.right_end_bonus;
     const int32_t cap = (int32_t)P.lim.max_path;
-    // candidate start cells (:815-867): collected by extend() as the columns were committed (bt_push), together with
-    // their lexicographic maximum — the first pop of the heap, usually the only one
-    const int32_t n_idx = w.x.n_idx;
-    int32_t first_bi = n_idx > 0 ? w.x.bt_best_at : -1;
-    (void)seed_dist; (void)min_start_score; (void)right_end_bonus; (void)last_pos;
+    const int32_t tsize = er.table_size;
+    // candidate start cells (:815-867), one table column per lane; the order of `indices` is irrelevant
+    // because the heap pops by the full (unique) tuple
+    // tips as a bitset (prev_starts is cleared per extension and only used from here on; use a second region)
+    int32_t n_idx = 0;
+    // every lane also keeps the lexicographic maximum (score, -off_diag, -i, pos) of the candidates it wrote and where it
+    // wrote it: the first pop of the heap — usually the only one — then needs no pass over the list in memory
+    LV<BtIndex> lbest;
+    LV<int32_t> lbest_at;
+    FOR_LANES(l) { lbest[l] = BtIndex{ INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN }; lbest_at[l] = -1; }
+    auto bt_greater = [](const BtIndex &a, const BtIndex &b) {
+        if (a.score != b.score) return a.score > b.score;
+        if (a.neg_off_diag != b.neg_off_diag) return a.neg_off_diag > b.neg_off_diag;
+        if (a.neg_i != b.neg_i) return a.neg_i > b.neg_i;
+        return a.pos > b.pos;
+    };
+    for (int32_t base = 1; base < tsize; base += WAVE) {
+        LV<int32_t> cnt;
+        LV<BtIndex> c0, c1;
+        FOR_LANES(l) {
+            int32_t i = base + l;
+            int32_t n = 0;
+            BtIndex b0 = { 0, 0, 0, 0 }, b1 = { 0, 0, 0, 0 };
+            if (i < tsize) {
+                const ColMeta col = w.cols[i];
+                if (col.offset >= seed_dist) {
+                    const ColMeta par = w.cols[col.parent];
+                    bool is_tip = false;
+                    for (int32_t t = 0; t < er.n_tips; ++t) is_tip |= w.tips[t] == (uint32_t)i;
+                    for (int pass = 0; pass < 2; ++pass) {
+                        int32_t start_pos;
+                        if (pass == 0) start_pos = col.max_pos;
+                        else {
+                            if (!(col.size + col.trim == window_size + 1 && col.max_pos != last_pos)) break;
+                            start_pos = last_pos;
+                        }
+                        if (start_pos < par.trim + 1) continue;
+                        int32_t sv = cell_S(w, col, start_pos), sp = cell_S(w, par, start_pos - 1);
+                        if (sv == NINF || sp == NINF) continue;
+                        int32_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
+                        if (sv + end_bonus >= min_start_score) {
+                            bool is_match = sv == sp + col.score + profile_at(w, E.q, w.L, col_char(col), seed_clipping + start_pos)
+                                && profile_op_at(E.q, w.L, col_char(col), seed_clipping + start_pos) == OP_MATCH;
+                            if (is_match || start_pos == last_pos || is_tip) {
+                                BtIndex bx;
+                                bx.score = sv + end_bonus; bx.neg_off_diag = -iabs(start_pos - col.offset + seed_offset);
+                                bx.neg_i = -i; bx.pos = start_pos;
+                                if (n == 0) b0 = bx; else b1 = bx;
+                                ++n;
+                            }
+                        }
+                    }
+                }
+            }
+            cnt[l] = n; c0[l] = b0; c1[l] = b1;
+        }
+        LV<int32_t> off = wave_prefix_sum_excl(cnt);
+        FOR_LANES(l) {
+            if (cnt[l] > 0) {
+                w.indices[n_idx + off[l]] = c0[l];
+                if (lbest_at[l] < 0 || bt_greater(c0[l], lbest[l])) { lbest[l] = c0[l]; lbest_at[l] = n_idx + off[l]; }
+            }
+            if (cnt[l] > 1) {
+                w.indices[n_idx + off[l] + 1] = c1[l];
+                if (bt_greater(c1[l], lbest[l])) { lbest[l] = c1[l]; lbest_at[l] = n_idx + off[l] + 1; }
+            }
+        }
+        n_idx += wave_sum(cnt);
+    }
+    // wave-level maximum of the lanes' maxima (registers only)
+    int32_t first_bi = -1;
+    if (n_idx > 0) {
+        LV<int32_t> v;
+        FOR_LANES(l) { v[l] = lbest_at[l] >= 0 ? lbest[l].score : INT32_MIN; }
+        const int32_t m_score = wave_max(v);
+        FOR_LANES(l) { v[l] = (lbest_at[l] >= 0 && lbest[l].score == m_score) ? lbest[l].neg_off_diag : INT32_MIN; }
+        const int32_t m_off = wave_max(v);
+        FOR_LANES(l) { v[l] = (lbest_at[l] >= 0 && lbest[l].score == m_score && lbest[l].neg_off_diag == m_off) ? lbest[l].neg_i : INT32_MIN; }
+        const int32_t m_i = wave_max(v);
+        FOR_LANES(l) {
+            v[l] = (lbest_at[l] >= 0 && lbest[l].score == m_score && lbest[l].neg_off_diag == m_off && lbest[l].neg_i == m_i) ? lbest[l].pos : INT32_MIN;
+        }
+        const int32_t m_pos = wave_max(v);
+        LV<bool> hit;
+        FOR_LANES(l) {
+            hit[l] = lbest_at[l] >= 0 && lbest[l].score == m_score && lbest[l].neg_off_diag == m_off && lbest[l].neg_i == m_i && lbest[l].pos == m_pos;
+        }
+        first_bi = wave_bcast(lbest_at, ctz64(wave_ballot(hit)));
+    }
     wave_sync();
     bool produced = false;
     int32_t best_score = INT32_MIN;
@@ -3028,12 +3034,12 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         conv_clear(F.conv);                                   // set_seed (:90-98)
         uint64_t t0 = cycle_clock();
         w.cyc[6] += t0 - tp0;
-        const int32_t mps = imax(0, P.cfg.min_cell_score);    // extend(): min_path_score = max(0, min_cell_score)
-        extend(w, F, seed, false, mps);
+        extend(w, F, seed, false);
         uint64_t t1 = cycle_clock();
         w.cyc[2] += t1 - t0;
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
+        int32_t mps = imax(0, P.cfg.min_cell_score);          // extend(): min_path_score = max(0, min_cell_score)
         bool have;
         if (P.ablate & 4u) { seed_as_alignment(w, seed, w.aln[0]); have = true; }       // timing probe only
         else have = backtrack(w, F, seed, nullptr, er, mps, w.aln[0]);
@@ -3056,7 +3062,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
                     int32_t mps2 = imax(0, min_path_score_now(w));
                     conv_clear(B.conv);
                     uint64_t t2 = cycle_clock();
-                    extend(w, B, rseed, true, mps2);
+                    extend(w, B, rseed, true);
                     uint64_t t3 = cycle_clock();
                     w.cyc[2] += t3 - t2;
                     const ExtendResult er2 = w.er;
@@ -3104,7 +3110,7 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
         SeedRef seed = seedref_from_seed(w, 0, i, nullptr);
         int32_t mps = imax(0, min_path_score_now(w));
         conv_clear(F.conv);
-        extend(w, F, seed, false, mps);
+        extend(w, F, seed, false);
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
         if (backtrack(w, F, seed, nullptr, er, mps, w.aln[0])) add_alignment(w, w.aln[0]);
