@@ -98,24 +98,58 @@ MGX_DEV int32_t iabs(int32_t a) { return a < 0 ? -a : a; }
 // ------------------------------------------------------------------------------------------------
 // per-wave arena
 // ------------------------------------------------------------------------------------------------
-struct ColMeta {                 // DPTColumn minus the vectors (aligner_extender_methods.hpp:129-147)
+// Lanes per read of the extension kernel, which fixes the width of the chain path's register window and with it the
+// layout of the column slots in the arena.  The HIP build runs the extension with 8-lane groups only (mgx_grp.hip); the
+// host translation unit (mgx.hip, 64-lane seeding kernel) must compute the same arena layout, hence a constant that does
+// not depend on the translation unit's own WAVE.  The host model runs every lane count.
+#if MGX_WAVE_EMU
+constexpr int32_t EXT_LANES = WAVE;
+#else
+constexpr int32_t EXT_LANES = 8;
+#endif
+constexpr int32_t FWS = 4 * EXT_LANES;          // cells of a chain-format column slot
+
+struct ColMeta {                 // DPTColumn minus the vectors (aligner_extender_methods.hpp:129-147), in registers
     uint32_t node;
     int32_t parent;
     int32_t offset, max_pos, trim, size;
     int32_t score;               // edge score
-    uint32_t cells;              // word offset of the column's cell record in the cell arena (see rec_words)
-    uint32_t cw;                 // path character (bits 0-7) | cells per array of the record (bits 8-31)
-    int32_t org;                 // window position of record cell 0 (org <= trim)
+    uint32_t cells;              // word offset of the column's S / F record in the cell arena (see rec_words); NO_CELLS: none
+    uint32_t cw;                 // path character (bits 0-7) | cells per array of the record (bits 8-30) | bit 31: chain format
+    int32_t org;                 // window position of record / slot cell 0 (org <= trim)
+    int32_t base;                // chain format: S = base + s16
+    int32_t self;                // the column's own table index (not stored)
 };
+constexpr uint32_t NO_CELLS = 0xFFFFFFFFu;
+constexpr uint32_t CW_CHAIN = 0x80000000u;
 MGX_DEV uint8_t col_char(const ColMeta &c) { return (uint8_t)(c.cw & 0xFF); }
-MGX_DEV int32_t col_wc(const ColMeta &c) { return (int32_t)(c.cw >> 8); }
+MGX_DEV int32_t col_wc(const ColMeta &c) { return (int32_t)((c.cw & ~CW_CHAIN) >> 8); }
+MGX_DEV bool col_chain(const ColMeta &c) { return (c.cw & CW_CHAIN) != 0; }
 
-// A column's cell record: S[wc], F[wc] (int32) and two bits per cell packed four cells to a byte — bit 0: S == E,
-// bit 1: E[j] == E[j - 1] + gap_extension (E[-1] = ninf).  These are the only facts about E that anything after the
-// column's own computation consumes (backtrack :943-958), so E itself is never stored.  Record cell x holds window
-// position org + x; positions outside [trim, trim + size + 5) or outside the record read as ninf / 0, exactly what the
-// reference's vectors hold there (never-written padding).  wc is a multiple of 4; records are 16-byte aligned.
-MGX_HD uint32_t rec_words(uint32_t wc) { return (2 * wc + (wc + 15) / 16 + 3) & ~3u; }
+// What a column leaves in HBM.  Every column owns one slot of the table (`Wave::cols`): 32 bytes of metadata, one FLAG
+// byte per cell of the chain window and the window's S values as 16-bit offsets from `base` — one or two 64-byte lines
+// that the chain path writes once and backtracking reads back (a 64-byte line costs the same DRAM access whether 4 or 64
+// of its bytes are used, and the kernel is bound by the number of such accesses).  The flags are every fact about a cell
+// that backtrack (:800-1034) tests, computed while the column and its parent are in registers / staging:
+//   bit 0  S != ninf                     bit 1  S == E                    bit 2  E[j] == E[j - 1] + gap_ext  (E[-1] = ninf)
+//   bit 3  S == S_parent[pos - 1] + edge score + profile   (and pos - 1 inside the parent column: the match test :963-975)
+//   bit 4  S == F                        bit 5  F == F_parent[pos] + edge score + gap_ext  (deletion run :985-1003)
+//   bit 6  S_parent[pos - 1] != ninf     (start-cell filter :846-853)
+// Columns of the general path (any width) keep S and F as int32 arrays plus their flag bytes in a record of the cell
+// arena (`cells`); a chain-format column gets such a record (S, F of its window) only when it stays behind in the
+// frontier, i.e. when something may have to reload it as a parent.
+struct alignas(16) ColSlot {
+    uint32_t m[8];
+    uint8_t flags[FWS];
+    int16_t s16[FWS];
+};
+enum { CF_REAL = 1, CF_S_IS_E = 2, CF_E_EXT = 4, CF_MATCH = 8, CF_S_IS_F = 16, CF_F_EXT = 32, CF_SP_REAL = 64 };
+constexpr int16_t S16_NINF = INT16_MIN;
+
+// S / F record of a column in the cell arena: S[wc], F[wc] (int32) and wc flag bytes; record cell x holds window position
+// org + x; positions outside [trim, trim + size + 5) or outside the record read as ninf / 0, exactly what the reference's
+// vectors hold there (never-written padding).  wc is a multiple of 4; records are 16-byte aligned.
+MGX_HD uint32_t rec_words(uint32_t wc) { return (2 * wc + wc / 4 + 3) & ~3u; }
 
 // all lanes hold the same metadata; moving it to scalar registers makes every dependent branch and
 // address computation scalar
@@ -123,7 +157,7 @@ MGX_DEV ColMeta uni_col(const ColMeta &c) {
     ColMeta r;
     r.node = uni(c.node); r.parent = uni(c.parent); r.offset = uni(c.offset); r.max_pos = uni(c.max_pos);
     r.trim = uni(c.trim); r.size = uni(c.size); r.score = uni(c.score); r.cells = uni(c.cells);
-    r.cw = uni(c.cw); r.org = uni(c.org);
+    r.cw = uni(c.cw); r.org = uni(c.org); r.base = uni(c.base); r.self = uni(c.self);
     return r;
 }
 
@@ -264,7 +298,7 @@ struct Wave {
     };
     // extension scratch
     int32_t *cells;
-    ColMeta *cols;
+    ColSlot *cols;                        // the column table: one slot per column (metadata, flags, 16-bit S of chain columns)
     uint64_t *queue, *next_nodes;         // frontier / current batch (arena; the chain path rarely touches them)
     Staging st[2];
     Tier stE;                             // E of the column being computed
@@ -335,7 +369,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += align8((L + 8) * 8) + align8(L + 8);           // dust_eq, dust_t
     b += align8((uint64_t)lim.max_alt * 4);             // alt
     b += 16 + align8((uint64_t)lim.cell_words * 4);     // cells
-    b += align8((uint64_t)lim.max_columns * sizeof(ColMeta));
+    b += 64 + align8((uint64_t)lim.max_columns * sizeof(ColSlot));
     b += 2 * align8((uint64_t)lim.max_columns * 8);     // queue, next_nodes
     b += align8((uint64_t)lim.max_columns * 4);         // tips
     b += align8(((uint64_t)lim.max_columns + 31) / 32 * 4);   // prev_starts
@@ -410,7 +444,8 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.alt = (uint32_t *)take((uint64_t)lim.max_alt * 4);
     p = (uint8_t *)(((uint64_t)p + 15) & ~15ull);                // cell records are written with 16-byte stores
     w.cells = (int32_t *)take((uint64_t)lim.cell_words * 4);
-    w.cols = (ColMeta *)take((uint64_t)lim.max_columns * sizeof(ColMeta));
+    p = (uint8_t *)(((uint64_t)p + 63) & ~63ull);                // a chain-format slot is exactly two 64-byte lines
+    w.cols = (ColSlot *)take((uint64_t)lim.max_columns * sizeof(ColSlot));
     w.queue = (uint64_t *)take((uint64_t)lim.max_columns * 8);
     w.next_nodes = (uint64_t *)take((uint64_t)lim.max_columns * 8);
     w.tips = (uint32_t *)take((uint64_t)lim.max_columns * 4);
@@ -1385,6 +1420,46 @@ MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t qu
 // ------------------------------------------------------------------------------------------------
 // extension (DefaultColumnExtender::extend, A/aligner_extender_methods.cpp:412-772)
 // ------------------------------------------------------------------------------------------------
+// metadata of column i <-> its slot (positions and sizes fit 16 bits: Lmax <= MGX_MAX_QUERY_LENGTH; gap scores are int8)
+MGX_DEV ColMeta col_load(const Wave &w, int32_t i) {
+    const ColSlot *sl = w.cols + i;
+    uint32_t m[8];
+#if MGX_WAVE_EMU
+    for (int t = 0; t < 8; ++t) m[t] = sl->m[t];
+#else
+    mgx_mem::load_bytes<32>(sl->m, m);
+#endif
+    ColMeta c;
+    c.node = m[0]; c.parent = (int32_t)m[1]; c.offset = (int32_t)m[2]; c.base = (int32_t)m[3]; c.cells = m[4];
+    c.max_pos = (int32_t)(m[5] & 0xFFFF); c.trim = (int32_t)(m[5] >> 16);
+    c.size = (int32_t)(m[6] & 0xFFFF); c.org = (int32_t)(m[6] >> 16);
+    c.score = (int32_t)(int8_t)((m[7] >> 8) & 0xFF);
+    c.cw = (m[7] & 0xFF) | (((m[7] >> 16) & 0x7FFF) << 8) | (m[7] & CW_CHAIN);
+    c.self = i;
+    return c;
+}
+MGX_DEV void col_pack(const ColMeta &c, uint32_t *m) {
+    m[0] = c.node; m[1] = (uint32_t)c.parent; m[2] = (uint32_t)c.offset; m[3] = (uint32_t)c.base; m[4] = c.cells;
+    m[5] = ((uint32_t)c.max_pos & 0xFFFF) | ((uint32_t)c.trim << 16);
+    m[6] = ((uint32_t)c.size & 0xFFFF) | ((uint32_t)c.org << 16);
+    m[7] = (c.cw & 0xFF) | (((uint32_t)c.score & 0xFF) << 8) | ((uint32_t)col_wc(c) << 16) | (c.cw & CW_CHAIN);
+}
+// store by one lane of the wave program
+MGX_DEV void col_store(Wave &w, int32_t i, const ColMeta &c) {
+    uint32_t m[8];
+    col_pack(c, m);
+    ColSlot *sl = w.cols + i;
+    FOR_LANES(l) {
+        if (l == 0) {
+#if MGX_WAVE_EMU
+            for (int t = 0; t < 8; ++t) sl->m[t] = m[t];
+#else
+            mgx_mem::store_bytes<32>(sl->m, m);
+#endif
+        }
+    }
+}
+
 // cell of column c at window position pos (absolute, like DPTColumn's trim + index); ninf outside what the reference's
 // vectors hold (index < 0 or >= size + 5: undefined there, defined as ninf here and in the oracle)
 MGX_DEV bool cell_idx(const ColMeta &c, int32_t pos, int32_t &x) {
@@ -1394,20 +1469,19 @@ MGX_DEV bool cell_idx(const ColMeta &c, int32_t pos, int32_t &x) {
 }
 MGX_DEV int32_t cell_S(const Wave &w, const ColMeta &c, int32_t pos) {
     int32_t x;
-    return cell_idx(c, pos, x) ? gld(w.cells + c.cells + x) : NINF;
+    if (!cell_idx(c, pos, x)) return NINF;
+    if (col_chain(c)) {
+        const int32_t v = (int32_t)gld(w.cols[c.self].s16 + x);
+        return v == (int32_t)S16_NINF ? NINF : c.base + v;
+    }
+    return gld(w.cells + c.cells + x);
 }
-MGX_DEV int32_t cell_F(const Wave &w, const ColMeta &c, int32_t pos) {
-    int32_t x;
-    return cell_idx(c, pos, x) ? gld(w.cells + c.cells + col_wc(c) + x) : NINF;
-}
-MGX_DEV uint32_t cell_ebits(const Wave &w, const ColMeta &c, int32_t pos) {
+MGX_DEV uint32_t cell_flags(const Wave &w, const ColMeta &c, int32_t pos) {
     int32_t x;
     if (!cell_idx(c, pos, x)) return 0;
-    const uint8_t *eb = (const uint8_t *)(w.cells + c.cells + 2 * col_wc(c));
-    return ((uint32_t)gld(eb + (x >> 2)) >> ((x & 3) * 2)) & 3u;
+    if (col_chain(c)) return gld(w.cols[c.self].flags + x);
+    return gld((const uint8_t *)(w.cells + c.cells + 2 * col_wc(c)) + x);
 }
-MGX_DEV bool cell_S_is_E(const Wave &w, const ColMeta &c, int32_t pos) { return cell_ebits(w, c, pos) & 1u; }      // S[pos] == E[pos]
-MGX_DEV bool cell_E_extends(const Wave &w, const ColMeta &c, int32_t pos) { return cell_ebits(w, c, pos) & 2u; }   // E[pos] == E[pos - 1] + ge
 
 // capacity of a reference vector created with `size0` elements (+5 reserved) after `pushes` push_backs
 // followed by reserve(size + 5) (DPTColumn::create :389-410, extend_ins_end :293-328; libstdc++ growth)
@@ -1469,7 +1543,8 @@ MGX_DEV void frontier_push(Wave &w, uint64_t key) {
 MGX_DEV int32_t st_S(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tget(s.S, cap, j) : NINF; }
 MGX_DEV int32_t st_F(const Staging &s, int32_t cap, int32_t size, int32_t j) { return (j >= 0 && j < size + 5) ? tget(s.F, cap, j) : NINF; }
 
-// make column `idx` resident in a staging buffer; returns the buffer index
+// make column `idx` resident in a staging buffer; returns the buffer index (the column must have an S / F record:
+// every column that can be popped from the frontier has one)
 MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
     if (w.st[0].col == idx) return 0;
     if (w.st[1].col == idx) return 1;
@@ -1479,6 +1554,7 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
     const int32_t cap = w.st_cap;
     const int32_t wc = col_wc(c), shift = c.trim - c.org;
     const int32_t *recS = w.cells + c.cells, *recF = recS + wc;
+    if (c.cells == NO_CELLS) { w.status = ST_CAPACITY; return b; }          // cannot happen (see above); fail loudly if it does
     for (int32_t base = 0; base < n; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
@@ -1494,38 +1570,41 @@ MGX_DEV int stage_column(Wave &w, int32_t idx, const ColMeta &c) {
     return b;
 }
 
-// write a staged column (size + 5 cells: S, F and the two E bits) to the arena as a record with org == trim;
-// nothing waits on these stores.  Returns the record's cells per array.
-MGX_DEV int32_t flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t size, int32_t ge) {
+// write a staged column (size + 5 cells: S, F and the flag byte per cell) to the arena as a record with org == trim;
+// nothing waits on these stores.  The flags relate the column to its parent (staged in `par`, nullptr for the root):
+// parent cell of window position trim + j is par cell j + dp.  Returns the record's cells per array.
+MGX_DEV int32_t flush_column(Wave &w, const Staging &s, uint32_t cells_off, int32_t size, int32_t ge, const Staging *par,
+                             int32_t par_size, int32_t dp, int32_t edge_score, uint8_t c, int32_t abs0, const uint8_t *q) {
     int32_t *rec = (int32_t *)uni((uint64_t)(w.cells + cells_off));
     const int32_t cap = uni(w.st_cap);
     const Tier tS = s.S, tF = s.F, tE = w.stE;
     const int32_t n = uni(size) + 5;
     const int32_t wc = (n + 3) & ~3;
-    uint8_t *eb = (uint8_t *)(rec + 2 * wc);
+    uint8_t *fb = (uint8_t *)(rec + 2 * wc);
     for (int32_t base = 0; base < wc; base += WAVE) {
         FOR_LANES(l) {
             int32_t j = base + l;
             if (j < wc) {
-                gst(rec + j, j < n ? tget(tS, cap, j) : NINF);
-                gst(rec + wc + j, j < n ? tget(tF, cap, j) : NINF);
-            }
-        }
-    }
-    for (int32_t base = 0; base < wc / 4; base += WAVE) {
-        FOR_LANES(l) {
-            int32_t q = base + l;
-            if (q < wc / 4) {
-                uint32_t bits = 0;
-                for (int t = 0; t < 4; ++t) {
-                    const int32_t j = 4 * q + t;
-                    if (j < n) {
-                        const int32_t e = tget(tE, cap, j), ep = j ? tget(tE, cap, j - 1) : NINF;
-                        bits |= (uint32_t)(tget(tS, cap, j) == e) << (2 * t);
-                        bits |= (uint32_t)(e == ep + ge) << (2 * t + 1);
+                const int32_t sv = j < n ? tget(tS, cap, j) : NINF, fv = j < n ? tget(tF, cap, j) : NINF;
+                gst(rec + j, sv);
+                gst(rec + wc + j, fv);
+                uint32_t fl = 0;
+                if (j < n) {
+                    const int32_t e = tget(tE, cap, j), ep = j ? tget(tE, cap, j - 1) : NINF;
+                    if (sv != NINF) fl |= CF_REAL;
+                    if (sv == e) fl |= CF_S_IS_E;
+                    if (e == ep + ge) fl |= CF_E_EXT;
+                    if (sv == fv) fl |= CF_S_IS_F;
+                    if (par) {
+                        const int32_t jp = j + dp;                       // the parent's cell at the same window position
+                        const int32_t sp1 = jp - 1 >= 0 ? st_S(*par, cap, par_size, jp - 1) : NINF;      // pos - 1 >= parent's trim
+                        const int32_t fp = st_F(*par, cap, par_size, jp);
+                        if (jp - 1 >= 0 && sv == sp1 + edge_score + profile_at(w, q, w.L, c, abs0 + j)) fl |= CF_MATCH;
+                        if (jp - 1 >= 0 && sp1 != NINF) fl |= CF_SP_REAL;
+                        if (fv == fp + edge_score + ge) fl |= CF_F_EXT;
                     }
                 }
-                gst(eb + q, (uint8_t)bits);
+                gst(fb + j, (uint8_t)fl);
             }
         }
     }
@@ -1782,6 +1861,7 @@ MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx, LV<int32_t> *S, L
     } else {
         const int32_t wc = col_wc(c);
         const int32_t *recS = w.cells + c.cells, *recF = recS + wc;
+        if (c.cells == NO_CELLS) w.status = ST_CAPACITY;          // cannot happen: a poppable column has its S / F record
         FOR_LANES(l) {
             for (int s = 0; s < 4; ++s) {
                 const int32_t a = org + 4 * l + s, j = a - c.trim, rx = a - c.org;
@@ -1833,7 +1913,7 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
     const DevLimits &lim = P.lim;
-    const ColMeta col = uni_col(gld(w.cols + i));
+    const ColMeta col = uni_col(col_load(w, i));
     const int32_t max_columns = (int32_t)uni(lim.max_columns);
     const uint32_t cell_words = uni(lim.cell_words);
     const double rel_cutoff = cfg.rel_score_cutoff, max_nodes_per_char = cfg.max_nodes_per_seq_char, max_ram = cfg.max_ram_per_alignment;
@@ -1942,10 +2022,13 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
         if ((int32_t)((uint32_t)max_val - (uint32_t)x.xdrop_cutoff) > xdrop) x.xdrop_cutoff = max_val - xdrop;
         x.best_score = imax(x.best_score, max_val);
         // commit the column: metadata + cells go to the arena (nothing waits on them)
-        const int32_t cur_wc = flush_column(w, w.st[cb], x.cell_top, size, uni(cfg.gap_ext));
+        const int32_t cur_wc = flush_column(w, w.st[cb], x.cell_top, size, uni(cfg.gap_ext), &w.st[pb], col.size, begin - col.trim,
+                                            score, c, start + begin, E.q);
         cur.cw |= (uint32_t)cur_wc << 8;
+        cur.base = 0;
         const int32_t my_idx = x.tsize;
-        gst(w.cols + my_idx, cur);
+        cur.self = my_idx;
+        col_store(w, my_idx, cur);
         w.st[cb].col = my_idx;
         x.cell_top += rec_words((uint32_t)cur_wc);
         x.tsize = my_idx + 1;
@@ -2073,7 +2156,11 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     if (x.tsize >= x.max_columns - 1) { w.status = ST_CAPACITY; return FR_ERROR; }
     if ((uint64_t)x.cell_top + rec_words((uint32_t)(window_size + 1 - begin + 8)) > x.cell_words) { w.status = ST_CAPACITY; return FR_ERROR; }
     // move the parent window to the child's origin (whole lanes)
+    // (the parent's cell just below the new origin — under the cut-off, but the match flag of the origin cell compares
+    // against its true value)
+    int32_t p_below = NINF;
     if (org != p_org) {
+        if (org - 1 >= p_org) p_below = reg_at(pS[0], pS[1], pS[2], pS[3], p_org, org - 1);
         const int32_t sh = (org - p_org) >> 2;
         for (int s = 0; s < 4; ++s) { pS[s] = wave_shift_down(pS[s], sh, NINF); pF[s] = wave_shift_down(pF[s], sh, NINF); }
         p_org = org;
@@ -2082,7 +2169,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     const int8_t *row = w.sm_rows + encode_char(c) * 128;      // a __shared__ array of the kernel
     const uint8_t *qq = E.q;
     const bool q_lds = w.q_lds != 0;
-    const LV<int32_t> Sm1_0 = wave_shift_up1(pS[3], NINF);        // parent at a - 1 for slot 0
+    const LV<int32_t> Sm1_0 = wave_shift_up1(pS[3], p_below);     // parent at a - 1 for slot 0
     LV<int32_t> cS[4], cF[4], cE[4], mraw[4], tv[4], mm[4];
     // profile_score_[c][start + a] (:38-59): the query character before window position a against the column's
     // character; 0 outside the query.  All loads are issued back to back at clamped addresses (no per-cell branches:
@@ -2335,32 +2422,60 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         }
     }
     // --- stores only from here on ---
-    // commit: metadata + one record (S, F, E bits) in window layout
+    // Will the frontier hand this column straight back (:491-504: it is the unique maximum)?  Then nothing ever reloads
+    // it and its slot is all it leaves behind; otherwise it also gets an S / F record.
+    const bool chain_on = converged != NINF && x.nn == 0 && (x.qn == 0 || converged > x.q_top)
+                          && (begin & 3) + size + 3 <= FW;
+    const bool deferred = converged != NINF && !chain_on;
+    // commit: the column's slot (metadata, flag byte per cell, 16-bit S) ...
     ColMeta cur;
-    cur.node = next; cur.parent = x.f_idx; cur.cw = (uint32_t)c | ((uint32_t)FW << 8); cur.org = org; cur.offset = next_offset;
-    cur.max_pos = max_pos; cur.trim = begin; cur.score = score; cur.cells = x.cell_top; cur.size = size;
-    {
-        int32_t *rec = w.cells + x.cell_top;
-        uint8_t *eb = (uint8_t *)(rec + 2 * FW);
+    cur.node = next; cur.parent = x.f_idx; cur.cw = (uint32_t)c | ((uint32_t)FW << 8) | CW_CHAIN; cur.org = org; cur.offset = next_offset;
+    cur.max_pos = max_pos; cur.trim = begin; cur.score = score; cur.size = size;
+    cur.base = max_val == NINF ? 0 : max_val;
+    cur.cells = deferred ? x.cell_top : NO_CELLS;
+    cur.self = my_idx;
+    if (!(w.P->ablate & 2u)) {
+        ColSlot *slot = w.cols + my_idx;
         const LV<int32_t> e_up = wave_shift_up1(cE[3], NINF);
+        const int32_t ptrim = x.f_trim;
         FOR_LANES(l) {
-            uint32_t bits = 0;
+            uint32_t fw = 0;
+            int32_t h[4];
             for (int s = 0; s < 4; ++s) {
-                const int32_t j = org + 4 * l + s - begin;
+                const int32_t a = org + 4 * l + s, j = a - begin;
                 const int32_t ep = j <= 0 ? NINF : (s == 0 ? e_up[l] : cE[s - 1][l]);
-                bits |= (uint32_t)(cS[s][l] == cE[s][l]) << (2 * s);
-                bits |= (uint32_t)(cE[s][l] == ep + ge) << (2 * s + 1);
+                const int32_t sv = cS[s][l], fv = cF[s][l];
+                const int32_t sp1 = s == 0 ? Sm1_0[l] : pS[s - 1][l];       // parent at a - 1 (ninf outside the parent column)
+                const bool pin = a - 1 >= ptrim;                           // pos - 1 >= the parent's trim (:963)
+                uint32_t fl = 0;
+                if (sv != NINF) fl |= CF_REAL;
+                if (sv == cE[s][l]) fl |= CF_S_IS_E;
+                if (cE[s][l] == ep + ge) fl |= CF_E_EXT;
+                if (pin && sv == mraw[s][l]) fl |= CF_MATCH;
+                if (sv == fv) fl |= CF_S_IS_F;
+                if (fv == pF[s][l] + score + ge) fl |= CF_F_EXT;
+                if (pin && sp1 != NINF) fl |= CF_SP_REAL;
+                fw |= fl << (8 * s);
+                h[s] = sv == NINF ? (int32_t)S16_NINF : sv - cur.base;
             }
-            if (!(w.P->ablate & 2u)) {
+            gst((uint32_t *)slot->flags + l, fw);
+            uint2 hv;
+            hv.x = ((uint32_t)h[0] & 0xFFFF) | ((uint32_t)h[1] << 16);
+            hv.y = ((uint32_t)h[2] & 0xFFFF) | ((uint32_t)h[3] << 16);
+            gst((uint2 *)slot->s16 + l, hv);
+        }
+        col_store(w, my_idx, cur);
+        // ... and, for a column that stays behind in the frontier, its window as an S / F record
+        if (deferred) {
+            int32_t *rec = w.cells + x.cell_top;
+            FOR_LANES(l) {
                 gst4(rec + 4 * l, cS[0][l], cS[1][l], cS[2][l], cS[3][l]);
                 gst4(rec + FW + 4 * l, cF[0][l], cF[1][l], cF[2][l], cF[3][l]);
-                gst(eb + l, (uint8_t)bits);
             }
+            x.cell_top += rec_words((uint32_t)FW);
         }
     }
-    if (!(w.P->ablate & 2u)) { FOR_LANES(l) { if (l == 0) gst(w.cols + my_idx, cur); } }
     x.tsize = my_idx + 1;
-    x.cell_top += rec_words((uint32_t)FW);
     // update_seed_filter, the stores
     if (cv_mode == CV_INSERT) {
         const int32_t vi = conv_insert(w, E.conv, cv_slot, ckey, query_start, cn);
@@ -2388,8 +2503,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     }
     if (w.status != ST_OK) return FR_ERROR;
     if (converged == NINF) return FR_END;
-    // the frontier would hand this column straight back iff it is the unique maximum (:491-504)
-    if (x.nn == 0 && (x.qn == 0 || converged > x.q_top) && fast_fits(cur)) {
+    if (chain_on) {
         for (int s = 0; s < 4; ++s) { pS[s] = cS[s]; pF[s] = cF[s]; }
         x.f_idx = my_idx; x.f_node = next; x.f_offset = next_offset; x.f_trim = begin; x.f_size = size; x.f_max_pos = max_pos;
         x.f_max_val = max_val; x.f_org = org;
@@ -2492,12 +2606,13 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         if ((uint64_t)rec_words((uint32_t)r.size + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
         const uint32_t root_cap3 = 3 * ref_capacity(1, (uint32_t)pushes);
         wave_sync();
-        const int32_t root_wc = flush_column(w, s0, 0, r.size, cfg.gap_ext);
+        const int32_t root_wc = flush_column(w, s0, 0, r.size, cfg.gap_ext, nullptr, 0, 0, 0, 0, 0, E.q);
         r.cw = (uint32_t)root_wc << 8;
+        r.base = 0; r.self = 0;
         s0.col = 0;
         x.cell_top = rec_words((uint32_t)root_wc);
         if (E.table_cap < 1) E.table_cap = 1;                 // emplace_back on an empty vector
-        gst(w.cols + 0, r);
+        col_store(w, 0, r);
         x.tsize = 1;
         x.table_size_bytes = (uint64_t)136 * E.table_cap + (uint64_t)root_cap3 * 4;
     }
@@ -2505,7 +2620,9 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     x.best_score = 0;
     x.qn = 0; x.nn = 0; x.n_tips = 0;
     frontier_push(w, queue_key(0, 0, 0));
-    const bool use_fast = !P.no_fast;
+    // the chain format keeps S as 16-bit offsets from the column maximum: cells live within x-drop (+ one match score) of
+    // it, so any x-drop up to 30000 fits; wider (the unit tests' "no x-drop") takes the general path
+    const bool use_fast = !P.no_fast && cfg.xdrop <= 30000;
     int mode = XM_POP;
     LV<int32_t> pS[4], pF[4];            // the chain window: S and F of the chain's current column, 4 cells per lane
     FOR_LANES(l) { for (int s = 0; s < 4; ++s) { pS[s][l] = NINF; pF[s][l] = NINF; } }
@@ -2530,7 +2647,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             }
             const int32_t i = (int32_t)uni(key_idx(qget(w.next_nodes, x.nn - 1)));
             --x.nn;
-            const ColMeta col = uni_col(gld(w.cols + i));
+            const ColMeta col = uni_col(col_load(w, i));
             if (use_fast && x.nn == 0 && fast_fits(col)) {
                 fast_load(w, col, i, pS, pF);
                 mode = XM_FAST;
@@ -2629,9 +2746,10 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
             int32_t n = 0;
             BtIndex b0 = { 0, 0, 0, 0 }, b1 = { 0, 0, 0, 0 };
             if (i < tsize) {
-                const ColMeta col = w.cols[i];
+                // one line per column: its slot's metadata and the flags of the start cell (S of a chain column is its
+                // maximum, i.e. `base`, at max_pos); the parent is never touched
+                const ColMeta col = col_load(w, i);
                 if (col.offset >= seed_dist) {
-                    const ColMeta par = w.cols[col.parent];
                     bool is_tip = false;
                     for (int32_t t = 0; t < er.n_tips; ++t) is_tip |= w.tips[t] == (uint32_t)i;
                     for (int pass = 0; pass < 2; ++pass) {
@@ -2641,13 +2759,13 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                             if (!(col.size + col.trim == window_size + 1 && col.max_pos != last_pos)) break;
                             start_pos = last_pos;
                         }
-                        if (start_pos < par.trim + 1) continue;
-                        int32_t sv = cell_S(w, col, start_pos), sp = cell_S(w, par, start_pos - 1);
-                        if (sv == NINF || sp == NINF) continue;
+                        // start_pos < par.trim + 1, or S_parent[start_pos - 1] == ninf: not a start cell (:846-849)
+                        const uint32_t fl = cell_flags(w, col, start_pos);
+                        if (!(fl & CF_REAL) || !(fl & CF_SP_REAL)) continue;
+                        const int32_t sv = (pass == 0 && col_chain(col)) ? col.base : cell_S(w, col, start_pos);
                         int32_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
                         if (sv + end_bonus >= min_start_score) {
-                            bool is_match = sv == sp + col.score + profile_at(w, E.q, w.L, col_char(col), seed_clipping + start_pos)
-                                && profile_op_at(E.q, w.L, col_char(col), seed_clipping + start_pos) == OP_MATCH;
+                            bool is_match = (fl & CF_MATCH) && profile_op_at(E.q, w.L, col_char(col), seed_clipping + start_pos) == OP_MATCH;
                             if (is_match || start_pos == last_pos || is_tip) {
                                 BtIndex bx;
                                 bx.score = sv + end_bonus; bx.neg_off_diag = -iabs(start_pos - col.offset + seed_offset);
@@ -2773,62 +2891,60 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
         };
         // The column chain is walked parent by parent.  Metadata is fetched one step ahead (the grandparent's with
         // this step's cell loads), so that every step costs one arena round trip instead of three dependent ones.
-        ColMeta col = gld(w.cols + j), par = col;
-        if (j) par = gld(w.cols + col.parent);
+        // The column chain is walked parent by parent; each step reads ONE thing: the flag byte of the current cell (all
+        // of backtrack's comparisons were evaluated when the column was computed).  The parent's metadata is fetched one
+        // step ahead.
+        ColMeta col = col_load(w, j), par = col;
+        if (j) par = col_load(w, col.parent);
         while (j) {
             ColMeta gp = par;
-            if (col.parent > 0) gp = gld(w.cols + par.parent);          // par is not the root
-            const int32_t trim_p = par.trim;
+            if (col.parent > 0) gp = col_load(w, par.parent);          // par is not the root
             align_offset = imin(col.offset, k_minus_1);
             if (pos == col.max_pos) prev_start_test_and_set(w, j);
-            const int32_t sv = cell_S(w, col, pos);
+            const uint32_t fl = cell_flags(w, col, pos);
             const uint32_t last_op = n_ops ? (w.rev_ops[n_ops - 1] & 7) : 99u;
-            if (sv == NINF) {
+            if (!(fl & CF_REAL)) {
                 j = 0;
-            } else if (pos && cell_S_is_E(w, col, pos) && (n_ops == 0 || last_op != OP_DELETION)) {
+            } else if (pos && (fl & CF_S_IS_E) && (n_ops == 0 || last_op != OP_DELETION)) {
                 uint32_t lop = OP_INSERTION;
                 while (lop == OP_INSERTION) {
                     cigar_append(w.rev_ops, &n_ops, lop, 1, cap, &w.status);
-                    lop = cell_E_extends(w, col, pos) ? OP_INSERTION : OP_MATCH;
+                    lop = (cell_flags(w, col, pos) & CF_E_EXT) ? OP_INSERTION : OP_MATCH;
                     --pos;
                     if (w.status != ST_OK) return false;
                 }
-            } else if (pos && pos >= trim_p + 1
-                       && sv == cell_S(w, par, pos - 1) + col.score
-                              + profile_at(w, E.q, w.L, col_char(col), seed_clipping + pos)) {
+            } else if (pos && (fl & CF_MATCH)) {
                 ++n_trace;
                 extra_score += col.score;
                 append_node(col.node, col_char(col), col.offset, profile_op_at(E.q, w.L, col_char(col), seed_clipping + pos));
                 --pos;
                 j = col.parent;
                 col = par; par = gp;
-            } else if (sv == cell_F(w, col, pos) && (n_ops == 0 || last_op != OP_INSERTION)) {
+            } else if ((fl & CF_S_IS_F) && (n_ops == 0 || last_op != OP_INSERTION)) {
                 uint32_t lop = OP_DELETION;
                 while (lop == OP_DELETION && j) {
-                    const ColMeta c2 = w.cols[j];
-                    const ColMeta p2 = w.cols[c2.parent];
+                    const ColMeta c2 = col_load(w, j);
                     align_offset = imin(c2.offset, k_minus_1);
-                    lop = cell_F(w, c2, pos) == cell_F(w, p2, pos) + c2.score + cfg.gap_ext
-                        ? OP_DELETION : OP_MATCH;
+                    lop = (cell_flags(w, c2, pos) & CF_F_EXT) ? OP_DELETION : OP_MATCH;
                     ++n_trace;
                     extra_score += c2.score;
                     append_node(c2.node, col_char(c2), c2.offset, OP_DELETION);
                     j = c2.parent;
                     if (w.status != ST_OK) return false;
                 }
-                if (j) { col = gld(w.cols + j); par = gld(w.cols + col.parent); }
+                if (j) { col = col_load(w, j); par = col_load(w, col.parent); }
             } else {
                 break;
             }
             if (w.status != ST_OK) return false;
         }
         if (n_trace >= min_trace_length && n_path && last_path_node) {
-            const ColMeta cj = w.cols[j];
+            const ColMeta cj = col_load(w, j);
             int32_t cur_cell_score = cell_S(w, cj, pos);
             best_score = imax(best_score, score - cur_cell_score);
             if (score - er.min_cell_score < best_score) break;
             if (score >= min_start_score && (!pos || cur_cell_score == 0)
-                    && (pos || cur_cell_score == w.cells[w.cols[0].cells])
+                    && (pos || cur_cell_score == gld(w.cells + col_load(w, 0).cells))
                     && (cfg.allow_left_trim || !j)) {
                 // construct_alignment (:774-798): clipping = pos, window = [pos, end_pos)
                 int32_t nc = 0;

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
     name=$1; shift
     timeout 600 rocprofv3 --pmc "$@" --output-format csv -d $REPO/gpurun_out/pmc_$name -o $name -- \
-        python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --no-cpu-baseline --parity-sample 0 \
+        python $REPO/bench.py --reads $READS --steps 1 --warmup 0 --host-steps 0 --no-cpu-baseline --parity-sample 0 \
         > $REPO/gpurun_out/pmc_$name.json 2> $REPO/gpurun_out/pmc_$name.log
 }
 run fetch FETCH_SIZE
