@@ -95,7 +95,12 @@ def main():
         log("graph: %d edges, device index %.1f MB, built in %.1fs; reads %d x %d" %
             (n_edges, G.device_bytes / 1e6, t_graph, args.reads, args.read_len))
     cfg = capi.config_cli(args.k)            # `metagraph align` defaults (cli/config/config.hpp:114-145)
-    A = aligner.Aligner(G, cfg)
+    lim = None
+    if os.environ.get("MGX_BENCH_LIMITS"):           # tuning probe: "max_columns,cell_arena_bytes" (smaller per-read arena slices)
+        mc, cab = [int(v) for v in os.environ["MGX_BENCH_LIMITS"].split(",")]
+        lim = capi.Limits()
+        lim.max_query_length, lim.max_columns, lim.max_seeds, lim.cell_arena_bytes = 0, mc, 0, cab
+    A = aligner.Aligner(G, cfg, lim)
 
     from metagraph_amd import gather as mg
 

@@ -3339,6 +3339,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
                 }
             }
             wave_sync();
+            if (P.ablate & 8u) { w.n_seeds[0] = w.n_seeds[1] = 0; }          // timing probe: fetch + pick-up + output only
         }
         if constexpr (PHASE == PH_SEED) {
             // publish: header, seeds, work key; the extension kernel writes the read's result record
