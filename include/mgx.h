@@ -65,7 +65,8 @@ typedef struct mgx_boss_view {
     uint32_t on_device;      /* 0: W/last/valid are host pointers; 1: device pointers (F always host) */
 } mgx_boss_view;
 
-/* Field-for-field mirror of DBGAlignerConfig (graph/alignment/aligner_config.hpp:18-94). */
+/* Field-for-field mirror of DBGAlignerConfig (graph/alignment/aligner_config.hpp:18-94): same members in the same order
+ * (explicit padding where the C++ struct has implicit padding), so a reference-side adapter copies member-wise. */
 typedef struct mgx_config {
     uint64_t num_alternative_paths;    /* :23 */
     uint64_t min_seed_length;          /* :24  (0 -> k, dbg_aligner.cpp:37-38) */
@@ -90,7 +91,11 @@ typedef struct mgx_config {
     uint8_t allow_left_trim;           /* :52 */
     uint8_t no_backtrack;              /* :53 (must be 0) */
     uint8_t seed_complexity_filter;    /* :54 */
-    uint8_t _pad1[5];
+    uint8_t alignment_edit_distance;          /* :56  read by mgx_config_set_scoring_matrix only, like the reference's */
+    int8_t alignment_match_score;             /* :57  set_scoring_matrix(); the aligner itself reads score_matrix       */
+    int8_t alignment_mm_transition_score;     /* :58  (a positive penalty, negated when the matrix is built)            */
+    int8_t alignment_mm_transversion_score;   /* :59 */
+    uint8_t _pad1[1];
     int8_t score_matrix[128][128];     /* :61 ScoreMatrix, [graph char][query char] */
 } mgx_config;
 
@@ -103,6 +108,9 @@ void mgx_config_init_cli(mgx_config *c, uint32_t k);
 void mgx_config_set_dna_matrix(mgx_config *c, int8_t match, int8_t mm_transition, int8_t mm_transversion);
 /* DBGAlignerConfig::unit_scoring_matrix over "ACGT" (aligner_config.cpp:185-204). */
 void mgx_config_set_unit_matrix(mgx_config *c, int8_t match);
+/* DBGAlignerConfig::set_scoring_matrix (aligner_config.cpp:128-162, DNA alphabet): from alignment_edit_distance /
+ * alignment_match_score / alignment_mm_*_score; edit distance also zeroes the end bonuses. */
+void mgx_config_set_scoring_matrix(mgx_config *c);
 
 /* Longest query the device path accepts (seed coordinates are 16-bit on the device; per-strand seed lists hold up to
  * 2 L + 64 entries).  Longer queries: MGX_ERR_UNSUPPORTED for the batch.  The reference has no such limit. */
@@ -116,6 +124,9 @@ typedef struct mgx_limits {
     uint64_t cell_arena_bytes;   /* S/E/F storage per in-flight read */
 } mgx_limits;
 void mgx_limits_init_default(mgx_limits *l, uint32_t max_query_length);
+/* The limits the last batch actually ran with (user limits, or what was derived from the config and the batch's
+ * longest read).  A caller that sees MGX_ERR_CAPACITY statuses re-runs those reads with larger values. */
+int mgx_aligner_get_limits(const struct mgx_aligner *a, mgx_limits *out);
 
 typedef struct mgx_graph mgx_graph;
 typedef struct mgx_aligner mgx_aligner;

@@ -29,7 +29,9 @@ class Config(C.Structure):
                 ("forward_and_reverse_complement", C.c_uint8), ("chain_alignments", C.c_uint8),
                 ("post_chain_alignments", C.c_uint8), ("global_xdrop", C.c_uint8),
                 ("allow_left_trim", C.c_uint8), ("no_backtrack", C.c_uint8),
-                ("seed_complexity_filter", C.c_uint8), ("_pad1", C.c_uint8 * 5),
+                ("seed_complexity_filter", C.c_uint8), ("alignment_edit_distance", C.c_uint8),
+                ("alignment_match_score", C.c_int8), ("alignment_mm_transition_score", C.c_int8),
+                ("alignment_mm_transversion_score", C.c_int8), ("_pad1", C.c_uint8 * 1),
                 ("score_matrix", (C.c_int8 * 128) * 128)]
 
 
@@ -162,6 +164,7 @@ def lib():
     L.mgx_aligner_create.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(Limits), C.POINTER(C.c_void_p)]
     L.mgx_aligner_destroy.argtypes = [C.c_void_p]
     L.mgx_aligner_get_config.argtypes = [C.c_void_p, C.POINTER(Config)]
+    L.mgx_aligner_get_limits.argtypes = [C.c_void_p, C.POINTER(Limits)]
     L.mgx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Results)]
     L.mgx_align_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.mgx_fetch_results.argtypes = [C.c_void_p, C.POINTER(Results)]
@@ -178,6 +181,7 @@ def lib():
     L.mgx_config_init_cli.argtypes = [C.POINTER(Config), C.c_uint32]
     L.mgx_config_set_dna_matrix.argtypes = [C.POINTER(Config), C.c_int8, C.c_int8, C.c_int8]
     L.mgx_config_set_unit_matrix.argtypes = [C.POINTER(Config), C.c_int8]
+    L.mgx_config_set_scoring_matrix.argtypes = [C.POINTER(Config)]
     L.mgx_limits_init_default.argtypes = [C.POINTER(Limits), C.c_uint32]
     L.mgx_format_tsv.argtypes = [C.POINTER(Results), C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t,
                                  C.c_int32, C.c_char_p, C.c_size_t]
@@ -250,5 +254,7 @@ def config_cli(k):
     c.gap_extension_penalty = -2
     c.left_end_bonus = 5
     c.right_end_bonus = 5
+    c.alignment_edit_distance = 0
+    c.alignment_match_score, c.alignment_mm_transition_score, c.alignment_mm_transversion_score = 2, 3, 3
     set_dna_matrix(c, 2, -3, -3)
     return c

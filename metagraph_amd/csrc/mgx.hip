@@ -318,6 +318,17 @@ void mgx_config_set_unit_matrix(mgx_config *c, int8_t match) {
     c->score_matrix['A']['A'] = c->score_matrix['C']['C'] = c->score_matrix['G']['G'] = c->score_matrix['T']['T'] = match;
 }
 
+void mgx_config_set_scoring_matrix(mgx_config *c) {
+    if (c->alignment_edit_distance) {
+        mgx_config_set_unit_matrix(c, 1);
+        c->left_end_bonus = 0;
+        c->right_end_bonus = 0;
+    } else {
+        mgx_config_set_dna_matrix(c, c->alignment_match_score, (int8_t)-c->alignment_mm_transition_score,
+                                  (int8_t)-c->alignment_mm_transversion_score);
+    }
+}
+
 void mgx_config_init_cli(mgx_config *c, uint32_t k) {
     mgx_config_init_default(c);
     c->min_seed_length = std::min<uint64_t>(19, k);
@@ -332,7 +343,11 @@ void mgx_config_init_cli(mgx_config *c, uint32_t k) {
     c->gap_extension_penalty = -2;
     c->left_end_bonus = 5;
     c->right_end_bonus = 5;
-    mgx_config_set_dna_matrix(c, 2, -3, -3);
+    c->alignment_edit_distance = 0;            /* cli/config/config.hpp:117-120 */
+    c->alignment_match_score = 2;
+    c->alignment_mm_transition_score = 3;
+    c->alignment_mm_transversion_score = 3;
+    mgx_config_set_scoring_matrix(c);
 }
 
 void mgx_limits_init_default(mgx_limits *l, uint32_t max_query_length) {
@@ -517,6 +532,16 @@ void mgx_aligner_destroy(mgx_aligner *a) {
 }
 
 int mgx_aligner_get_config(const mgx_aligner *a, mgx_config *out) { *out = a->cfg; return MGX_OK; }
+
+int mgx_aligner_get_limits(const mgx_aligner *a, mgx_limits *out) {
+    if (!a || !out) return fail(MGX_ERR_INVALID, "null argument");
+    memset(out, 0, sizeof(*out));
+    out->max_query_length = a->lim.Lmax;
+    out->max_columns = a->lim.max_columns;
+    out->max_seeds = a->lim.max_seeds;
+    out->cell_arena_bytes = (uint64_t)a->lim.cell_words * 4;
+    return MGX_OK;
+}
 
 // stage inputs, compute k-mer slot offsets and Lmax on the device
 static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device,

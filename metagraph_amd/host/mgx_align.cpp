@@ -2,10 +2,14 @@
 // TSV printing as in cli/align.cpp:403-480).  Graph input is a flat BOSS dump (k, n_edges, F[5], W[], last[]);
 // reading sdsl-serialised .dbg files is "next" (SURVEY 8f rank 2).  Usage:
 //   mgx_align GRAPH.boss READS.{fa,fq} [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]
+//             [-p THREADS] [--query-batch-size BASES]
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <mutex>
+#include <thread>
 
 #include "hip_dbg_aligner.hpp"
 
@@ -39,8 +43,16 @@ static bool read_records(const std::string &path, std::vector<IDBGAligner::Query
     return true;
 }
 
+// cli/align.cpp:415-480: records are read into batches of at most `query_batch_size` bases (default 100 MB,
+// cli/config/config.hpp:105), every batch is a task of a pool of `-p` workers; a task builds its own aligner over the
+// shared read-only graph and prints each query's line under a mutex as it completes (so with -p 1 output is in input
+// order, with more workers batches interleave — exactly the reference's behaviour).
 int main(int argc, char **argv) {
-    if (argc < 3) { fprintf(stderr, "usage: %s GRAPH.boss READS [options]\n", argv[0]); return 2; }
+    if (argc < 3) {
+        fprintf(stderr, "usage: %s GRAPH.boss READS [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]\n"
+                        "          [-p THREADS] [--query-batch-size BASES] [--max-columns N (test hook: small device arena)]\n", argv[0]);
+        return 2;
+    }
     std::ifstream gin(argv[1], std::ios::binary);
     if (!gin) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
     uint64_t hdr[7];
@@ -52,19 +64,56 @@ int main(int argc, char **argv) {
     gin.read((char *)last.data(), n + 1);
     DBGAlignerConfig cfg;
     mgx_config_init_cli(&cfg, k);
+    unsigned threads = 1;
+    uint64_t batch_size = 100000000ull;
+    mgx_limits lim;
+    bool have_lim = false;
+    mgx_limits_init_default(&lim, 0);
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--align-only-forwards")) cfg.forward_and_reverse_complement = 0;
         else if (!strcmp(argv[i], "--align-min-exact-match") && i + 1 < argc) cfg.min_exact_match = atof(argv[++i]);
         else if (!strcmp(argv[i], "--align-min-seed-length") && i + 1 < argc) cfg.min_seed_length = std::min<uint64_t>(atoi(argv[++i]), k);
+        else if (!strcmp(argv[i], "-p") && i + 1 < argc) threads = (unsigned)std::max(1, atoi(argv[++i]));
+        else if (!strcmp(argv[i], "--query-batch-size") && i + 1 < argc) batch_size = strtoull(argv[++i], nullptr, 10);
+        else if (!strcmp(argv[i], "--max-columns") && i + 1 < argc) { lim.max_columns = (uint32_t)atoi(argv[++i]); have_lim = true; }
     }
     try {
         HipBOSSGraph graph(k, n, W.data(), last.data(), hdr + 2);
-        HipDBGAligner aligner(graph, cfg);
-        std::vector<IDBGAligner::Query> batch;
-        if (!read_records(argv[2], &batch)) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
-        aligner.align_batch(batch, [&](const std::string &header, AlignmentResults &&paths) {
-            std::cout << format_alignment(header, paths, cfg.min_path_score);
-        });
+        std::vector<IDBGAligner::Query> all;
+        if (!read_records(argv[2], &all)) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
+        // batches by bases read (align.cpp:431-442: a record is added while the running total is <= batch_size)
+        std::vector<std::vector<IDBGAligner::Query>> batches;
+        for (size_t i = 0; i < all.size();) {
+            std::vector<IDBGAligner::Query> b;
+            uint64_t bytes = 0;
+            for (; i < all.size() && bytes <= batch_size; ++i) { bytes += all[i].second.size(); b.push_back(std::move(all[i])); }
+            batches.push_back(std::move(b));
+        }
+        std::mutex print_mutex, err_mutex;
+        std::atomic<size_t> next{ 0 };
+        std::string first_error;
+        auto worker = [&]() {
+            try {
+                for (;;) {
+                    const size_t bi = next.fetch_add(1);
+                    if (bi >= batches.size()) break;
+                    HipDBGAligner aligner(graph, cfg, have_lim ? &lim : nullptr);       // one aligner per task, shared graph
+                    aligner.align_batch(batches[bi], [&](const std::string &header, AlignmentResults &&paths) {
+                        const std::string res = format_alignment(header, paths, cfg.min_path_score);
+                        std::lock_guard<std::mutex> lock(print_mutex);
+                        std::cout << res;
+                    });
+                }
+            } catch (const std::exception &e) {
+                std::lock_guard<std::mutex> lock(err_mutex);
+                if (first_error.empty()) first_error = e.what();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &t : pool) t.join();
+        if (!first_error.empty()) { fprintf(stderr, "error: %s\n", first_error.c_str()); return 1; }
     } catch (const std::exception &e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -39,3 +39,37 @@ def test_mgx_align_driver_goldens(tmp_path):
             got = lines[int(idx)].split("\t")
             for fi, fv in fields.items():
                 assert got[int(fi)] == fv
+
+
+def _dump_mt_graph(tmp_path):
+    cli = KATS["cli"]
+    g = orc.Graph.build(cli["k"], read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"])), 0, False)
+    W, last, F, _ = g.export()
+    dump = tmp_path / "mt.boss"
+    with open(dump, "wb") as f:
+        f.write(struct.pack("<7Q", g.k, g.n_edges, *[int(x) for x in F]))
+        f.write(W.tobytes())
+        f.write(last.tobytes())
+    return cli, dump
+
+
+def test_mgx_align_batches_threads_and_capacity_retry(tmp_path):
+    """cli/align.cpp:415-480 shape: small batches on a pool of workers over one shared graph print the same lines (as a
+    set: completion order is the mutex's, as in the reference); and a device arena that is far too small for some reads
+    (--max-columns) is grown by the adapter until they fit instead of failing the batch."""
+    cli, dump = _dump_mt_graph(tmp_path)
+    exe = os.path.join(ROOT, "metagraph_amd", "_build", "mgx_align")
+    reads = os.path.join(HERE, "golden", cli["reads_fastq"])
+    base = [exe, str(dump), reads, "--align-min-exact-match", "0.0"]
+    ref = subprocess.run(base, capture_output=True, text=True, timeout=120)
+    assert ref.returncode == 0, ref.stderr
+    want = ref.stdout.rstrip("\n").split("\n")
+    r = subprocess.run(base + ["-p", "3", "--query-batch-size", "300"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert sorted(r.stdout.rstrip("\n").split("\n")) == sorted(want)
+    r = subprocess.run(base + ["-p", "1", "--query-batch-size", "300"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.rstrip("\n").split("\n") == want          # one worker: input order
+    r = subprocess.run(base + ["--max-columns", "70"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.rstrip("\n").split("\n") == want
