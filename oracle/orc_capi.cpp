@@ -160,6 +160,37 @@ uint32_t orc_graph_suffix_match(void *h, const char *str, uint32_t len, uint32_t
 }
 
 int orc_is_low_complexity(const char *s, uint32_t len) { return is_low_complexity(std::string_view(s, len)); }
+
+// Definition-level check of "sdust masks something" (Morgulis et al. 2006, as implemented by lh3/sdust with T = 20, W = 64),
+// written WITHOUT the incremental machinery (windows, running counts, perfect-interval list, L-suffix shortcut) that the
+// oracle's and the device's sdust restate: a sequence has a masked region iff some interval of at most W - 2 consecutive
+// triplets has  10 * (number of equal triplet pairs) > T * (number of triplets - 1)  — any such interval contains a perfect
+// interval (its highest-scoring subinterval), and every perfect interval is such an interval.
+// One property of the published implementation is part of the definition used here: a non-ACGT character restarts the
+// WORD (no triplet spans it) but not the WINDOW — sdust.c resets only `l` and `t` there, the triplet deque and its
+// counts live on — so "consecutive triplets" means consecutive among the triplets that exist, across such characters.
+int orc_sdust_bruteforce(const char *s, uint32_t len) {
+    const int T = 20, W = 64;
+    auto code = [](char c) -> int {
+        switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+                     case 'T': case 't': case 'U': case 'u': return 3; default: return 4; }
+    };
+    std::vector<int> trip;                      // the triplets that exist, in order
+    for (uint32_t i = 0; i + 3 <= len; ++i) {
+        int a = code(s[i]), b = code(s[i + 1]), c = code(s[i + 2]);
+        if (!((a | b | c) & 4)) trip.push_back((a << 4) | (b << 2) | c);
+    }
+    const int n = (int)trip.size();
+    for (int i = 0; i < n; ++i) {
+        int cnt[64] = { 0 };
+        long r = 0;
+        for (int j = i; j < n && j - i + 1 <= W - 2; ++j) {
+            r += cnt[trip[j]]++;                // pairs (x, j), x < j, with equal triplets
+            if (r * 10 > (long)T * (j - i)) return 1;
+        }
+    }
+    return 0;
+}
 int orc_check_config(const mgx_config *c) { return check_config_scores(*c); }
 uint64_t orc_oob_reads() { return g_oob_reads_total(); }
 

@@ -64,6 +64,7 @@ def L():
         _L.orc_graph_suffix_match.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64,
                                               C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]
         _L.orc_is_low_complexity.argtypes = [C.c_char_p, C.c_uint32]
+        _L.orc_sdust_bruteforce.argtypes = [C.c_char_p, C.c_uint32]
         _L.orc_check_config.argtypes = [C.POINTER(capi.Config)]
         _L.orc_oob_reads.restype = C.c_uint64
         _L.orc_align_batch.restype = C.c_void_p
