@@ -112,6 +112,10 @@ void mgx_config_set_unit_matrix(mgx_config *c, int8_t match);
  * alignment_match_score / alignment_mm_*_score; edit distance also zeroes the end bonuses. */
 void mgx_config_set_scoring_matrix(mgx_config *c);
 
+/* Largest DBGAlignerConfig::num_alternative_paths the device path keeps per query (a second instantiation of the
+ * extension kernel with room for that many alignments runs when it is > 1).  More: MGX_ERR_UNSUPPORTED. */
+#define MGX_MAX_ALTERNATIVE_PATHS 4u
+
 /* Longest query the device path accepts (seed coordinates are 16-bit on the device; per-strand seed lists hold up to
  * 2 L + 64 entries).  Longer queries: MGX_ERR_UNSUPPORTED for the batch.  The reference has no such limit. */
 #define MGX_MAX_QUERY_LENGTH 32704u

@@ -163,6 +163,14 @@ MGX_DEV ColMeta uni_col(const ColMeta &c) {
 
 struct BtIndex { int32_t score, neg_off_diag, neg_i, pos; };
 
+// Alignments per query this build can keep (DBGAlignerConfig::num_alternative_paths).  The product kernel is built for 1;
+// a second instantiation of the extension kernel (and the host model) is built for MGX_MAX_ALT_BUILD.
+#ifndef MGX_MAX_ALT
+#define MGX_MAX_ALT 1
+#endif
+constexpr int MAX_ALT = MGX_MAX_ALT;
+constexpr int N_ALN = 4 * MAX_ALT;           // alignment buffers: extension results, their reversals, backward results, the best
+
 // One hash slot holds everything a lookup needs (key, generation tag, the entry's vector number and the query range
 // its vector covers): a probe is ONE 32-byte access instead of slot -> entry -> range.
 struct alignas(32) ConvSlot { uint64_t key; uint32_t gen, idx; int32_t start, len; uint32_t pad0, pad1; };
@@ -312,9 +320,9 @@ struct Wave {
     const int8_t *sm_rows;       // score-matrix rows of the 6 possible path characters ($ACGT\\0) x 128, in LDS
     uint32_t *gen_store;         // conv-checker generation counters, persistent per arena slice
     ExtenderState ext[2];
-    DevAln aln[4];               // 0: extension result, 1: reversed seed for the backward pass,
-                                 // 2: backward extension result, 3: best (aggregator)
-    int32_t have_best;
+    DevAln aln[N_ALN];           // [0, A): extension results, [A, 2A): reversed seeds of the backward pass, [2A, 3A): backward
+                                 // extension results, [3A, 4A): the aggregator's queue (A = num_alternative_paths <= MAX_ALT)
+    int32_t have_best;           // alignments in the aggregator's queue
     int32_t seeds_done;          // seeds whose extension ran for this read (two-pass extension)
     LineCtr ctr;                 // BOSS block loads (lane-parallel regions add their wave sums)
     ExtendResult er;             // result of the last extend(); noinline callees must not write through
@@ -350,6 +358,20 @@ MGX_DEV void wave_set_blk_cache(Wave &w, const Block &b, uint32_t idx) {
     w.blk_cache_idx = idx;
 }
 
+// buffer roles for A = num_alternative_paths (runtime, <= MAX_ALT): [0, A) extension results, [A, 2A) their reversals (the
+// seeds of the backward pass), [2A, 3A) backward extension results, [3A, 4A) the aggregator's queue
+MGX_DEV int n_alt_of(const Wave &w) { return imax(1, imin((int)w.P->cfg.num_alt, MAX_ALT)); }
+#define Q0 (3 * n_alt_of(w))
+
+// LocalAlignmentLess (alignment.hpp:337-348): a < b
+MGX_DEV bool aln_less(const DevAln &a, const DevAln &b) {
+    int32_t ca = aln_clipping(a), cb = aln_clipping(b);
+    if (b.score != a.score) return b.score > a.score;
+    if (a.qlen != b.qlen) return a.qlen > b.qlen;
+    if (a.orientation != b.orientation) return a.orientation > b.orientation;
+    return ca > cb;
+}
+
 MGX_HD uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
 
 // byte size of one wave's arena slice
@@ -378,7 +400,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 16;                                            // gen_store
     b += 6 * align8((L + 16) * 4);                      // staging
     b += 32 + 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8(ent * L * 4));
-    b += 4 * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
+    b += (uint64_t)lim.n_aln * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
     return (b + 63) & ~63ull;          // slices keep the 32-byte alignment of the hash slots and the 16-byte one of the cell records
 }
 
@@ -460,7 +482,7 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
         w.ext[s].conv.slots = (ConvSlot *)take((uint64_t)lim.hash_size * sizeof(ConvSlot));
         w.ext[s].conv.vecs = (int32_t *)take(ent * L * 4);
     }
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < N_ALN && a < (int)lim.n_aln; ++a) {
         w.aln[a].nodes = (uint32_t *)take((uint64_t)lim.max_path * 4);
         w.aln[a].cigar = (uint32_t *)take((uint64_t)lim.max_path * 4);
         w.aln[a].seq = take(lim.max_path);
@@ -2706,8 +2728,9 @@ MGX_DEV void seed_as_alignment(Wave &w, const SeedRef &seed, DevAln &out);
 MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src);
 
 // seed_aln: the Alignment the seed was made from (backward pass) or nullptr for Seed-derived seeds
-MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, const DevAln *seed_aln,
-                       const ExtendResult &er, int32_t min_path_score, DevAln &out) {
+// Writes up to n_max alignments (num_alternative_paths, :1005 terminate_backtrack_start) into outs[0 .. ); returns how many.
+MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, const DevAln *seed_aln,
+                      const ExtendResult &er, int32_t min_path_score, DevAln *outs, int n_max) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = *w.P;
     const DevConfig &cfg = P.cfg;
@@ -2813,10 +2836,10 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
         first_bi = wave_bcast(lbest_at, ctz64(wave_ballot(hit)));
     }
     wave_sync();
-    bool produced = false;
+    int produced = 0;
     int32_t best_score = INT32_MIN;
     int32_t remaining = n_idx;
-    while (remaining > 0 && !produced) {        // terminate_backtrack_start: num_alternative_paths == 1
+    while (remaining > 0 && produced < n_max) {        // terminate_backtrack_start: extensions.size() >= num_alternative_paths
         // pop the lexicographic maximum (score, -off_diag, -i, pos) (:873-879): four lane-parallel passes
         int32_t bi = 0;
         if (first_bi >= 0) {
@@ -2911,7 +2934,7 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                     cigar_append(w.rev_ops, &n_ops, lop, 1, cap, &w.status);
                     lop = (cell_flags(w, col, pos) & CF_E_EXT) ? OP_INSERTION : OP_MATCH;
                     --pos;
-                    if (w.status != ST_OK) return false;
+                    if (w.status != ST_OK) return 0;
                 }
             } else if (pos && (fl & CF_MATCH)) {
                 ++n_trace;
@@ -2930,13 +2953,13 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                     extra_score += c2.score;
                     append_node(c2.node, col_char(c2), c2.offset, OP_DELETION);
                     j = c2.parent;
-                    if (w.status != ST_OK) return false;
+                    if (w.status != ST_OK) return 0;
                 }
                 if (j) { col = col_load(w, j); par = col_load(w, col.parent); }
             } else {
                 break;
             }
-            if (w.status != ST_OK) return false;
+            if (w.status != ST_OK) return 0;
         }
         if (n_trace >= min_trace_length && n_path && last_path_node) {
             const ColMeta cj = col_load(w, j);
@@ -2947,6 +2970,7 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                     && (pos || cur_cell_score == gld(w.cells + col_load(w, 0).cells))
                     && (cfg.allow_left_trim || !j)) {
                 // construct_alignment (:774-798): clipping = pos, window = [pos, end_pos)
+                DevAln &out = outs[produced];
                 int32_t nc = 0;
                 uint32_t clip_total = (uint32_t)(seed_clipping + pos);      // cigar clip + extend_query_begin
                 if (clip_total) out.cigar[nc++] = (clip_total << 3) | OP_CLIPPED;
@@ -2954,12 +2978,12 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                 for (int32_t x = n_ops - 1; x >= 0; --x) {
                     uint32_t op = w.rev_ops[x];
                     if (nc && (out.cigar[nc - 1] & 7) == (op & 7)) out.cigar[nc - 1] += (op >> 3) << 3;
-                    else { if (nc >= cap) { w.status = ST_CAPACITY; return false; } out.cigar[nc++] = op; }
+                    else { if (nc >= cap) { w.status = ST_CAPACITY; return 0; } out.cigar[nc++] = op; }
                 }
                 uint32_t end_clip = (uint32_t)(w.L - (seed_clipping + end_pos));   // extend_query_end
                 if (end_clip) {
                     if (nc && (out.cigar[nc - 1] & 7) == OP_CLIPPED) out.cigar[nc - 1] += end_clip << 3;
-                    else { if (nc >= cap) { w.status = ST_CAPACITY; return false; } out.cigar[nc++] = (end_clip << 3) | OP_CLIPPED; }
+                    else { if (nc >= cap) { w.status = ST_CAPACITY; return 0; } out.cigar[nc++] = (end_clip << 3) | OP_CLIPPED; }
                 }
                 wave_sync();
                 for (int32_t base = 0; base < imax(n_path, n_seq); base += WAVE) {
@@ -2974,17 +2998,18 @@ MGX_NI_G4 bool backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, c
                 out.qbegin = seed_clipping + pos; out.qlen = end_pos - pos;
                 out.orientation = seed.orientation; out.extra_score = extra_score;
                 wave_sync();
-                produced = true;
+                ++produced;
             }
         }
     }
     if (!produced && seed.score >= min_path_score) {       // extensions.emplace_back(*seed_) (:1030-1031)
-        if (seed_aln) copy_aln(out, *seed_aln);
-        else seed_as_alignment(w, seed, out);
-        produced = true;
+        if (seed_aln) copy_aln(outs[0], *seed_aln);
+        else seed_as_alignment(w, seed, outs[0]);
+        produced = 1;
     }
-    if (produced) {
+    for (int e = 0; e < produced; ++e) {
         // extension.trim_offset() (alignment.cpp:177-190)
+        DevAln &out = outs[e];
         if (out.offset && out.n_nodes > 1) {
             int32_t first_dummy = out.n_nodes;      // no npos nodes can occur on this path
             for (int32_t x = 0; x < out.n_nodes; ++x) if (!out.nodes[x]) { first_dummy = x; break; }
@@ -3074,7 +3099,9 @@ MGX_DEV SeedRef seedref_from_aln(const DevAln &a) {
 // ------------------------------------------------------------------------------------------------
 MGX_DEV int32_t global_cutoff(const Wave &w) {              // :141-149
     if (!w.have_best) return NINF;
-    int32_t cur_max = w.aln[3].score;
+    int mx = 0;                                             // std::max_element: the first of equal maxima
+    for (int t = 1; t < w.have_best; ++t) if (aln_less(w.aln[Q0 + mx], w.aln[Q0 + t])) mx = t;
+    int32_t cur_max = w.aln[Q0 + mx].score;
     return cur_max > 0 ? (int32_t)((double)cur_max * w.P->cfg.rel_score_cutoff) : cur_max;
 }
 
@@ -3089,22 +3116,17 @@ MGX_DEV bool aln_equal(const Wave &w, const DevAln &a, const DevAln &b) {     //
     return true;
 }
 
-// LocalAlignmentLess (alignment.hpp:337-348): a < b
-MGX_DEV bool aln_less(const DevAln &a, const DevAln &b) {
-    int32_t ca = aln_clipping(a), cb = aln_clipping(b);
-    if (b.score != a.score) return b.score > a.score;
-    if (a.qlen != b.qlen) return a.qlen > b.qlen;
-    if (a.orientation != b.orientation) return a.orientation > b.orientation;
-    return ca > cb;
-}
-
 MGX_NI_G4 void add_alignment(Wave &w, const DevAln &a) {
-    MGX_ASSUME_LDS(&w);       // :68-138
-    if (!w.have_best) { copy_aln(w.aln[3], a); w.have_best = 1; return; }
+    MGX_ASSUME_LDS(&w);       // :68-138 (unlabeled): a queue of at most num_alternative_paths alignments
+    const int n_alt = n_alt_of(w);
+    if (!w.have_best) { copy_aln(w.aln[Q0], a); w.have_best = 1; return; }
     if (a.score < global_cutoff(w)) return;
-    if (aln_equal(w, a, w.aln[3])) return;
-    if (aln_less(a, w.aln[3])) return;
-    copy_aln(w.aln[3], a);
+    for (int t = 0; t < w.have_best; ++t) if (aln_equal(w, a, w.aln[Q0 + t])) return;
+    if (w.have_best < n_alt) { copy_aln(w.aln[Q0 + w.have_best], a); ++w.have_best; return; }
+    int mn = 0;                                             // std::min_element: the first of equal minima
+    for (int t = 1; t < w.have_best; ++t) if (aln_less(w.aln[Q0 + t], w.aln[Q0 + mn])) mn = t;
+    if (aln_less(a, w.aln[Q0 + mn])) return;
+    copy_aln(w.aln[Q0 + mn], a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3156,49 +3178,62 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
         int32_t mps = imax(0, P.cfg.min_cell_score);          // extend(): min_path_score = max(0, min_cell_score)
-        bool have;
-        if (P.ablate & 4u) { seed_as_alignment(w, seed, w.aln[0]); have = true; }       // timing probe only
-        else have = backtrack(w, F, seed, nullptr, er, mps, w.aln[0]);
+        const int n_alt = n_alt_of(w);
+        int n_fwd;
+        if (P.ablate & 4u) { seed_as_alignment(w, seed, w.aln[0]); n_fwd = 1; }       // timing probe only
+        else n_fwd = backtrack(w, F, seed, nullptr, er, mps, &w.aln[0], n_alt);
         w.cyc[3] += cycle_clock() - t1;
         if (w.status != ST_OK) return;
-        if (have) {
-            DevAln &path = w.aln[0];
+        // every extension of this seed goes to the aggregator; those that can be continued to the left are reversed and
+        // become the seed list of ONE align_core on the backward extender (:677-729) ...
+        int n_rev = 0;
+        bool rev_alive[MAX_ALT];
+        {
             const uint64_t tm0 = cycle_clock();
-            if (path.score >= min_path_score_now(w)) add_alignment(w, path);
-            bool go_back = false;
-            if (aln_clipping(path) && !path.offset) {
-                copy_aln(w.aln[1], path);
-                go_back = reverse_complement_aln(w, w.aln[1]);
+            for (int e = 0; e < n_fwd; ++e) {
+                DevAln &path = w.aln[e];
+                if (path.score >= min_path_score_now(w)) add_alignment(w, path);
+                if (!aln_clipping(path) || path.offset) continue;
+                DevAln &rev = w.aln[n_alt + n_rev];
+                copy_aln(rev, path);
+                if (!reverse_complement_aln(w, rev)) continue;
+                rev_alive[n_rev++] = true;
             }
             w.cyc[7] += cycle_clock() - tm0;
-            if (aln_clipping(path) && !path.offset) {
-                if (go_back) {
-                    // align_core(ManualSeeder{rc path}, bwd_extender, ..., force_fixed_seed = true) (:708-729)
-                    SeedRef rseed = seedref_from_aln(w.aln[1]);
-                    int32_t mps2 = imax(0, min_path_score_now(w));
-                    conv_clear(B.conv);
-                    uint64_t t2 = cycle_clock();
-                    extend(w, B, rseed, true);
-                    uint64_t t3 = cycle_clock();
-                    w.cyc[2] += t3 - t2;
-                    const ExtendResult er2 = w.er;
+        }
+        // ... which extends them in order and drops a later one whose end the earlier extensions already reached with at
+        // least its score (align_core :360-384: check_seed between the seeds of the list)
+        for (int r = 0; r < n_rev; ++r) {
+            if (!rev_alive[r]) continue;
+            DevAln &rev = w.aln[n_alt + r];
+            SeedRef rseed = seedref_from_aln(rev);
+            int32_t mps2 = imax(0, min_path_score_now(w));
+            conv_clear(B.conv);
+            uint64_t t2 = cycle_clock();
+            extend(w, B, rseed, true);
+            uint64_t t3 = cycle_clock();
+            w.cyc[2] += t3 - t2;
+            const ExtendResult er2 = w.er;
+            if (w.status != ST_OK) return;
+            int n_bwd;
+            if (P.ablate & 4u) { copy_aln(w.aln[2 * n_alt], rev); n_bwd = 1; }         // timing probe only
+            else n_bwd = backtrack(w, B, rseed, &rev, er2, mps2, &w.aln[2 * n_alt], n_alt);
+            w.cyc[3] += cycle_clock() - t3;
+            if (w.status != ST_OK) return;
+            for (int b = 0; b < n_bwd; ++b) {
+                DevAln &p2 = w.aln[2 * n_alt + b];
+                if (reverse_complement_aln(w, p2)) {
+                    int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
+                    for (int32_t x = 0; x < p2.n_nodes; ++x)
+                        filter_nodes(w, F, p2.nodes[x], clip, w.L - eclip);
                     if (w.status != ST_OK) return;
-                    bool have2;
-                    if (P.ablate & 4u) { copy_aln(w.aln[2], w.aln[1]); have2 = true; }         // timing probe only
-                    else have2 = backtrack(w, B, rseed, &w.aln[1], er2, mps2, w.aln[2]);
-                    w.cyc[3] += cycle_clock() - t3;
-                    if (w.status != ST_OK) return;
-                    if (have2) {
-                        DevAln &p2 = w.aln[2];
-                        if (reverse_complement_aln(w, p2)) {
-                            int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
-                            for (int32_t x = 0; x < p2.n_nodes; ++x)
-                                filter_nodes(w, F, p2.nodes[x], clip, w.L - eclip);
-                            if (w.status != ST_OK) return;
-                            add_alignment(w, p2);
-                        }
-                    }
+                    add_alignment(w, p2);
                 }
+            }
+            for (int r2 = r + 1; r2 < n_rev; ++r2) {
+                if (!rev_alive[r2]) continue;
+                const DevAln &o = w.aln[n_alt + r2];
+                if (!check_seed(w, B, o.nodes[o.n_nodes - 1], o.qlen, aln_clipping(o), o.score)) rev_alive[r2] = false;
             }
         }
         for (int32_t j = i + 1; j < n; ++j) {
@@ -3229,7 +3264,11 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
         extend(w, F, seed, false);
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
-        if (backtrack(w, F, seed, nullptr, er, mps, w.aln[0])) add_alignment(w, w.aln[0]);
+        {
+            const int n_fwd = backtrack(w, F, seed, nullptr, er, mps, &w.aln[0], n_alt_of(w));
+            if (w.status != ST_OK) return;
+            for (int e = 0; e < n_fwd; ++e) add_alignment(w, w.aln[e]);
+        }
         if (w.status != ST_OK) return;
         for (int32_t j = i + 1; j < n; ++j) {
             if (!w.alive[0][j]) continue;
@@ -3447,38 +3486,72 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
 
     rr.status = w.status;
     rr.n_extensions = w.n_extensions; rr.n_columns = w.n_columns;
-    if (w.status == ST_OK && w.have_best && w.aln[3].n_nodes) {
-        const DevAln &a = w.aln[3];
-        uint32_t words = (uint32_t)a.n_nodes + (uint32_t)a.n_cigar + ((uint32_t)a.seq_len + 3) / 4;
-        LV<uint64_t> offv;
-        FOR_LANES(l) {
-            offv[l] = 0;
-            if (l == 0) {
-#if MGX_WAVE_EMU
-                offv[l] = *P.out_cursor; *P.out_cursor += words;
-#else
-                offv[l] = atomicAdd(P.out_cursor, (unsigned long long)words);
-#endif
-            }
+    if (w.status == ST_OK && w.have_best) {
+        // get_alignments (aligner_aggregator.hpp:180-202): stable sort ascending by LocalAlignmentLess, emitted from the
+        // back, empty alignments dropped
+        int ord[MAX_ALT];
+        int n_out = 0;
+        for (int t = 0; t < w.have_best; ++t) {
+            int pos = t;
+            while (pos > 0 && aln_less(w.aln[Q0 + t], w.aln[Q0 + ord[pos - 1]])) { ord[pos] = ord[pos - 1]; --pos; }
+            ord[pos] = t;
         }
-        uint64_t so = wave_bcast(offv, 0);
-        if (so + words > P.out_capacity) {
-            rr.status = ST_CAPACITY;
-        } else {
-            uint32_t *dst = P.out_stream + so;
-            uint8_t *dseq = (uint8_t *)(dst + a.n_nodes + a.n_cigar);
-            int32_t n = imax(imax(a.n_nodes, a.n_cigar), a.seq_len);
-            for (int32_t base = 0; base < n; base += WAVE) {
-                FOR_LANES(l) {
-                    int32_t x = base + l;
-                    if (x < a.n_nodes) dst[x] = a.nodes[x];
-                    if (x < a.n_cigar) dst[a.n_nodes + x] = a.cigar[x];
-                    if (x < a.seq_len) dseq[x] = a.seq[x];
+        uint32_t words = 0;
+        for (int t = w.have_best - 1; t >= 0; --t) {
+            const DevAln &a = w.aln[Q0 + ord[t]];
+            if (!a.n_nodes) continue;
+            words += (n_out ? 6u : 0u) + (uint32_t)a.n_nodes + (uint32_t)a.n_cigar + ((uint32_t)a.seq_len + 3) / 4;
+            ++n_out;
+        }
+        if (n_out) {
+            LV<uint64_t> offv;
+            FOR_LANES(l) {
+                offv[l] = 0;
+                if (l == 0) {
+#if MGX_WAVE_EMU
+                    offv[l] = *P.out_cursor; *P.out_cursor += words;
+#else
+                    offv[l] = atomicAdd(P.out_cursor, (unsigned long long)words);
+#endif
                 }
             }
-            rr.n_alignments = 1; rr.score = a.score; rr.offset = (uint32_t)a.offset;
-            rr.n_nodes = (uint32_t)a.n_nodes; rr.n_cigar = (uint32_t)a.n_cigar; rr.seq_len = (uint32_t)a.seq_len;
-            rr.orientation = (uint32_t)a.orientation; rr.stream_off = so;
+            uint64_t so = wave_bcast(offv, 0);
+            if (so + words > P.out_capacity) {
+                rr.status = ST_CAPACITY;
+            } else {
+                uint32_t *dst = P.out_stream + so;
+                int k_out = 0;
+                for (int t = w.have_best - 1; t >= 0; --t) {
+                    const DevAln &a = w.aln[Q0 + ord[t]];
+                    if (!a.n_nodes) continue;
+                    if (k_out == 0) {
+                        rr.score = a.score; rr.offset = (uint32_t)a.offset;
+                        rr.n_nodes = (uint32_t)a.n_nodes; rr.n_cigar = (uint32_t)a.n_cigar; rr.seq_len = (uint32_t)a.seq_len;
+                        rr.orientation = (uint32_t)a.orientation; rr.stream_off = so;
+                    } else {
+                        FOR_LANES(l) {
+                            if (l == 0) {
+                                dst[0] = (uint32_t)a.score; dst[1] = (uint32_t)a.offset; dst[2] = (uint32_t)a.n_nodes;
+                                dst[3] = (uint32_t)a.n_cigar; dst[4] = (uint32_t)a.seq_len; dst[5] = (uint32_t)a.orientation;
+                            }
+                        }
+                        dst += 6;
+                    }
+                    uint8_t *dseq = (uint8_t *)(dst + a.n_nodes + a.n_cigar);
+                    int32_t n = imax(imax(a.n_nodes, a.n_cigar), a.seq_len);
+                    for (int32_t base = 0; base < n; base += WAVE) {
+                        FOR_LANES(l) {
+                            int32_t x = base + l;
+                            if (x < a.n_nodes) dst[x] = a.nodes[x];
+                            if (x < a.n_cigar) dst[a.n_nodes + x] = a.cigar[x];
+                            if (x < a.seq_len) dseq[x] = a.seq[x];
+                        }
+                    }
+                    dst += (uint32_t)a.n_nodes + (uint32_t)a.n_cigar + ((uint32_t)a.seq_len + 3) / 4;
+                    ++k_out;
+                }
+                rr.n_alignments = n_out;
+            }
         }
     }
     FOR_LANES(l) { if (l == 0) P.results[read] = rr; }

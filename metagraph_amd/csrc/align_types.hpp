@@ -19,6 +19,7 @@ struct DevConfig {
     double min_exact_match, max_nodes_per_seq_char, max_ram_per_alignment, rel_score_cutoff;
     int32_t gap_open, gap_ext, left_end_bonus, right_end_bonus;
     uint32_t fwd_and_rc, allow_left_trim, seed_complexity_filter;
+    uint32_t num_alt;        // num_alternative_paths
 };
 
 struct DevLimits {
@@ -29,18 +30,20 @@ struct DevLimits {
     uint32_t max_alt;        // alternative sub-k nodes kept per read and strand
     uint32_t cell_words;     // int32 words of S/E/F storage per wave
     uint32_t hash_size;      // power of two
+    uint32_t n_aln;          // alignment buffers per read: 4 * num_alternative_paths
 };
 
 // per-read result header; variable-length parts live in the output stream
 struct ReadResult {
     int32_t status;          // ST_OK / ST_CAPACITY
-    int32_t n_alignments;    // 0 or 1
+    int32_t n_alignments;    // 0 .. num_alternative_paths; the scalars below describe alignment 0
     int32_t score;
     uint32_t offset;
     uint32_t n_nodes, n_cigar, seq_len;
     uint32_t orientation;
     uint64_t stream_off;     // word offset into the output stream: nodes[n_nodes] (u32),
-                             // cigar[n_cigar] (u32: len << 3 | op), seq bytes (padded to words)
+                             // cigar[n_cigar] (u32: len << 3 | op), seq bytes (padded to words); further alignments follow,
+                             // each as 6 words (score, offset, n_nodes, n_cigar, seq_len, orientation) + the same arrays
     // intermediate products for parity tests
     uint32_t num_matches_fwd, num_matches_rc, n_seeds_fwd, n_seeds_rc;
     uint32_t n_extensions, n_columns;

@@ -35,7 +35,10 @@ inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, Dev
     if (c.chain_alignments || c.post_chain_alignments) { *err = "seed/alignment chaining is not implemented"; return MGX_ERR_UNSUPPORTED; }
     if (!c.global_xdrop) { *err = "per-branch xdrop (labeled+coordinates mode) is not implemented"; return MGX_ERR_UNSUPPORTED; }
     if (c.no_backtrack) { *err = "no_backtrack is not implemented"; return MGX_ERR_UNSUPPORTED; }
-    if (c.num_alternative_paths != 1) { *err = "num_alternative_paths != 1 is not implemented on the device"; return MGX_ERR_UNSUPPORTED; }
+    if (c.num_alternative_paths < 1 || c.num_alternative_paths > MGX_MAX_ALTERNATIVE_PATHS) {
+        *err = "num_alternative_paths must be in 1.." + std::to_string(MGX_MAX_ALTERNATIVE_PATHS) + " on the device";
+        return MGX_ERR_UNSUPPORTED;
+    }
     if (c.xdrop <= 0) { *err = "xdrop must be positive"; return MGX_ERR_INVALID; }
     auto sat = [](uint64_t v) { return v >= INF_LEN ? INF_LEN : (uint32_t)v; };
     d->min_seed_length = sat(c.min_seed_length);
@@ -48,6 +51,7 @@ inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, Dev
     d->left_end_bonus = c.left_end_bonus; d->right_end_bonus = c.right_end_bonus;
     d->fwd_and_rc = c.forward_and_reverse_complement; d->allow_left_trim = c.allow_left_trim;
     d->seed_complexity_filter = c.seed_complexity_filter;
+    d->num_alt = (uint32_t)c.num_alternative_paths;
     return MGX_OK;
 }
 
@@ -83,6 +87,7 @@ inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lm
     }
     l.cell_words = (uint32_t)std::min<uint64_t>(cw, 0xFFFFFF00ull);
     l.hash_size = next_pow2(2ull * ((uint64_t)l.max_columns + l.max_path) + 2);
+    l.n_aln = 4 * (uint32_t)cfg.num_alternative_paths;
     return MGX_OK;
 }
 
@@ -94,41 +99,62 @@ struct HostResults {
     std::vector<char> seqs;
     std::vector<int32_t> status;
 
-    void decode(const ReadResult *rr, uint64_t n, const uint32_t *stream) {
+    // words one alignment occupies in the stream
+    static uint64_t aln_words(uint32_t n_nodes, uint32_t n_cigar, uint32_t seq_len) { return (uint64_t)n_nodes + n_cigar + ((uint64_t)seq_len + 3) / 4; }
+
+    // Stream layout of a read with n_alignments >= 1, from stream_off: alignment 0 = nodes, CIGAR runs (len << 3 | op),
+    // path characters (its scalars are in the header); every further alignment = 6 words (score, offset, n_nodes, n_cigar,
+    // seq_len, orientation) followed by the same three arrays.  `stream_words`: words available (bounds for untrusted input).
+    bool decode(const ReadResult *rr, uint64_t n, const uint32_t *stream, uint64_t stream_words = ~0ull) {
         aln_begin.assign(1, 0);
         alns.clear(); nodes.clear(); cigar.clear(); seqs.clear(); status.clear();
         for (uint64_t i = 0; i < n; ++i) {
             const ReadResult &r = rr[i];
             status.push_back(r.status);
-            if (r.status == ST_OK && r.n_alignments) {
-                mgx_alignment m;
-                memset(&m, 0, sizeof(m));
-                const uint32_t *p = stream + r.stream_off;
-                m.score = r.score; m.offset = r.offset; m.n_nodes = r.n_nodes; m.n_cigar = r.n_cigar; m.seq_len = r.seq_len;
-                m.orientation = (uint8_t)r.orientation;
-                m.nodes_begin = nodes.size(); m.cigar_begin = cigar.size(); m.seq_begin = seqs.size();
-                for (uint32_t x = 0; x < r.n_nodes; ++x) nodes.push_back(p[x]);
-                uint32_t nm = 0;
-                for (uint32_t x = 0; x < r.n_cigar; ++x) {
-                    mgx_cigar_op op;
-                    memset(&op, 0, sizeof(op));
-                    op.len = p[r.n_nodes + x] >> 3;
-                    op.op = (uint8_t)(p[r.n_nodes + x] & 7);
-                    if (op.op == MGX_OP_MATCH) nm += op.len;
-                    cigar.push_back(op);
+            if (r.status == ST_OK && r.n_alignments > 0) {
+                uint64_t at = r.stream_off;
+                for (int32_t a = 0; a < r.n_alignments; ++a) {
+                    int32_t score = r.score;
+                    uint32_t offset = r.offset, n_nodes = r.n_nodes, n_cigar = r.n_cigar, seq_len = r.seq_len, orientation = r.orientation;
+                    if (a) {
+                        if (at > stream_words || stream_words - at < 6) return false;
+                        const uint32_t *h = stream + at;
+                        score = (int32_t)h[0]; offset = h[1]; n_nodes = h[2]; n_cigar = h[3]; seq_len = h[4]; orientation = h[5];
+                        at += 6;
+                    }
+                    const uint64_t words = aln_words(n_nodes, n_cigar, seq_len);
+                    if (at > stream_words || words > stream_words - at) return false;
+                    const uint32_t *p = stream + at;
+                    at += words;
+                    mgx_alignment m;
+                    memset(&m, 0, sizeof(m));
+                    m.score = score; m.offset = offset; m.n_nodes = n_nodes; m.n_cigar = n_cigar; m.seq_len = seq_len;
+                    m.orientation = (uint8_t)orientation;
+                    m.nodes_begin = nodes.size(); m.cigar_begin = cigar.size(); m.seq_begin = seqs.size();
+                    for (uint32_t x = 0; x < n_nodes; ++x) nodes.push_back(p[x]);
+                    uint32_t nm = 0;
+                    for (uint32_t x = 0; x < n_cigar; ++x) {
+                        mgx_cigar_op op;
+                        memset(&op, 0, sizeof(op));
+                        op.len = p[n_nodes + x] >> 3;
+                        op.op = (uint8_t)(p[n_nodes + x] & 7);
+                        if (op.op == MGX_OP_MATCH) nm += op.len;
+                        cigar.push_back(op);
+                    }
+                    m.num_matches = nm;
+                    if (n_cigar) {
+                        const mgx_cigar_op &f = cigar[m.cigar_begin], &b = cigar.back();
+                        m.clipping = f.op == MGX_OP_CLIPPED ? f.len : 0;
+                        m.end_clipping = b.op == MGX_OP_CLIPPED ? b.len : 0;
+                    }
+                    const char *sq = reinterpret_cast<const char *>(p + n_nodes + n_cigar);
+                    seqs.insert(seqs.end(), sq, sq + seq_len);
+                    alns.push_back(m);
                 }
-                m.num_matches = nm;
-                if (r.n_cigar) {
-                    const mgx_cigar_op &f = cigar[m.cigar_begin], &b = cigar.back();
-                    m.clipping = f.op == MGX_OP_CLIPPED ? f.len : 0;
-                    m.end_clipping = b.op == MGX_OP_CLIPPED ? b.len : 0;
-                }
-                const char *sq = reinterpret_cast<const char *>(p + r.n_nodes + r.n_cigar);
-                seqs.insert(seqs.end(), sq, sq + r.seq_len);
-                alns.push_back(m);
             }
             aln_begin.push_back(alns.size());
         }
+        return true;
     }
 
     void view(mgx_results *out) const {

@@ -234,6 +234,9 @@ struct mgx_graph {
 extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);    // mgx_grp.hip, MGX_GROUP=8
 extern "C" int mgx_grp_waves_per_simd8(void);
 extern "C" unsigned mgx_grp_static_lds8(void);
+// the same kernel with room for MGX_MAX_ALTERNATIVE_PATHS alignments per query (num_alternative_paths > 1)
+extern "C" int mgx_launch_align_grp8_alt(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);
+extern "C" unsigned mgx_grp_static_lds8_alt(void);
 
 // The pipeline run_align launches: seeding by one wavefront per read (k_align<PH_SEED>), a radix sort of the reads by
 // predicted extension work, extension by 8-lane groups (8 reads per wavefront, mgx_grp.hip).  (Round 1 also carried
@@ -661,7 +664,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     }
     A->n_slots = (uint32_t)slots;
     if (int rc = A->results.ensure(n * sizeof(ReadResult))) return rc;
-    uint64_t words_per_read = (uint64_t)l.Lmax + l.Lmax / 4 + 40;
+    uint64_t words_per_read = ((uint64_t)l.Lmax + l.Lmax / 4 + 40) * std::max<uint64_t>(1, A->cfg.num_alternative_paths);
     // heuristic size (one alignment per read: nodes + CIGAR runs + path characters); a batch that needs more is re-run
     // with what it asked for (mgx_align_batch_device), so the size is never a correctness limit
     uint64_t out_words = std::max<uint64_t>(n * words_per_read + 1024, A->out_min_words);
@@ -740,11 +743,12 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         static const uint32_t pct = getenv("MGX_EXT_GROUPS_PCT") ? (uint32_t)std::min(100, std::max(1, atoi(getenv("MGX_EXT_GROUPS_PCT")))) : 100u;
         const uint32_t groups = 8;
         const uint32_t waves_cu = 4u * (uint32_t)mgx_grp_waves_per_simd8();
-        const uint32_t static_lds = mgx_grp_static_lds8();
+        const bool alt = A->cfg.num_alternative_paths > 1;
+        const uint32_t static_lds = alt ? mgx_grp_static_lds8_alt() : mgx_grp_static_lds8();
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 64u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
         if (const char *e = getenv("MGX_EXT_LDS_CAP")) per_group = std::min<uint32_t>(per_group, (uint32_t)atoi(e)) & ~15u;   // tuning probe
-        return mgx_launch_align_grp8(&P, (uint32_t)std::max<uint64_t>(8, slots * pct / 100), per_group, phase, nullptr);
+        return (alt ? mgx_launch_align_grp8_alt : mgx_launch_align_grp8)(&P, (uint32_t)std::max<uint64_t>(8, slots * pct / 100), per_group, phase, nullptr);
     };
     A->split_ran = split;
     if (split) {
@@ -913,16 +917,11 @@ int mgx_results_from_raw(const void *headers, uint64_t n, const uint32_t *stream
                          mgx_raw_store **store, mgx_results *out) {
     if ((!headers && n) || !store || !out || (!stream && stream_words)) return fail(MGX_ERR_INVALID, "null argument");
     const ReadResult *rr = static_cast<const ReadResult *>(headers);
-    for (uint64_t i = 0; i < n; ++i) {
-        const ReadResult &r = rr[i];
-        if (r.status != ST_OK || !r.n_alignments) continue;
-        const uint64_t words = (uint64_t)r.n_nodes + r.n_cigar + ((uint64_t)r.seq_len + 3) / 4;
-        if (r.stream_off > stream_words || words > stream_words - r.stream_off)
-            return fail(MGX_ERR_INVALID, "record %llu points outside the stream (%llu + %llu > %llu words)",
-                        (unsigned long long)i, (unsigned long long)r.stream_off, (unsigned long long)words, (unsigned long long)stream_words);
-    }
     auto *S = new mgx_raw_store();
-    S->host.decode(rr, n, stream);
+    if (!S->host.decode(rr, n, stream, stream_words)) {
+        delete S;
+        return fail(MGX_ERR_INVALID, "a record points outside the stream (%llu words)", (unsigned long long)stream_words);
+    }
     S->host.view(out);
     *store = S;
     return MGX_OK;

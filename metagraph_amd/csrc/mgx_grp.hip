@@ -7,7 +7,16 @@
 #endif
 #define MGX_CAT2(a, b) a##b
 #define MGX_CAT(a, b) MGX_CAT2(a, b)
+// Two builds of this file go into libmgx.so: the product (MGX_MAX_ALT = 1: one alignment per query) and one with room for
+// MGX_MAX_ALTERNATIVE_PATHS alignments per query (-DMGX_MAX_ALT=4 -DMGX_ALT_BUILD), launched when
+// DBGAlignerConfig::num_alternative_paths > 1; its bigger control block stays out of the product kernel's LDS.
+#ifdef MGX_ALT_BUILD
+#define MGX_SUFFIX(x) MGX_CAT(x, _alt)
+#define mgx MGX_CAT(MGX_CAT(mgx_grp, MGX_GROUP), a)
+#else
+#define MGX_SUFFIX(x) x
 #define mgx MGX_CAT(mgx_grp, MGX_GROUP)
+#endif
 #define MGX_PARAMS_IN_LDS 1     // the kernel keeps one copy of AlignParams in LDS; the per-read program reads it with ds_ loads
 #include "wave_group.hpp"
 #include "align_core.hpp"
@@ -24,7 +33,7 @@ using namespace mgx;
 
 // each group owns one read at a time, one arena slice and one slice of the dynamic LDS
 template <int PHASE>
-__global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_grp, MGX_GROUP)(AlignParams P, uint32_t lds_bytes, uint32_t n_groups) {
+__global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT(k_align_grp, MGX_GROUP))(AlignParams P, uint32_t lds_bytes, uint32_t n_groups) {
     const int g = group_id();
     const uint32_t slot = blockIdx.x * GROUPS_PER_WAVEFRONT + (uint32_t)g;
     __shared__ Wave ws[GROUPS_PER_WAVEFRONT];
@@ -76,12 +85,12 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_CAT(k_align_gr
 
 // n_groups = arena slices; lds_bytes = dynamic LDS per group
 // phase = PH_BOTH (fused) or PH_EXTEND (after the seeding kernel)
-extern "C" int MGX_CAT(mgx_launch_align_grp, MGX_GROUP)(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream) {
+extern "C" int MGX_SUFFIX(MGX_CAT(mgx_launch_align_grp, MGX_GROUP))(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream) {
     const AlignParams &P = *static_cast<const AlignParams *>(params);
     uint32_t blocks = (n_groups + GROUPS_PER_WAVEFRONT - 1) / GROUPS_PER_WAVEFRONT;
     if (phase != PH_EXTEND) return (int)hipErrorInvalidValue;      // only the extension half is instantiated for sub-wave groups
-    MGX_CAT(k_align_grp, MGX_GROUP)<PH_EXTEND><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
+    MGX_SUFFIX(MGX_CAT(k_align_grp, MGX_GROUP))<PH_EXTEND><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
     return (int)hipGetLastError();
 }
-extern "C" int MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP)(void) { return MGX_GRP_WAVES_PER_SIMD; }
-extern "C" unsigned MGX_CAT(mgx_grp_static_lds, MGX_GROUP)(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + sizeof(AlignParams) + 6 * 128); }
+extern "C" int MGX_SUFFIX(MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP))(void) { return MGX_GRP_WAVES_PER_SIMD; }
+extern "C" unsigned MGX_SUFFIX(MGX_CAT(mgx_grp_static_lds, MGX_GROUP))(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + sizeof(AlignParams) + 6 * 128); }

@@ -182,7 +182,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     std::vector<int8_t> sm(128 * 128);
     memcpy(sm.data(), cfg.score_matrix, 128 * 128);
     R->results.resize(n);
-    uint64_t out_words = n * ((uint64_t)R->lim.Lmax * 3 + 64) + 1024;
+    uint64_t out_words = n * ((uint64_t)R->lim.Lmax * 3 + 64) * std::max<uint64_t>(1, cfg.num_alternative_paths) + 1024;
     R->stream.assign(out_words, 0);
     R->seeds.assign(n * 2 * (uint64_t)R->lim.max_seeds, DevSeed{ 0, 0, 0, 0, 0 });
     unsigned long long cursors[2] = { 0, 0 };

@@ -1,0 +1,119 @@
+"""num_alternative_paths > 1 (AlignmentAggregator top-N, aligner_aggregator.hpp:68-202; backtrack producing several
+extensions, aligner_extender_methods.cpp:873-1031): the reference's own test align_low_similarity4
+(tests/graph/test_aligner.cpp:1365-1424, on tests/data/transcripts_100.fa) restated — its assertions on the oracle,
+and the kernels (host model; GPU) against the oracle's full alignment lists.  Tie order among equal alignments lives in
+absent third-party code (Priority-Deque) and is unpinned upstream; the assertions are the reference's: count, inequality,
+score order."""
+import os
+
+import pytest
+
+import orc
+from metagraph_amd import capi
+from test_oracle_kats import read_fasta, HERE
+
+QUERY = ("TCGATCGATCGATCGATCGATCGACGATCGATCGATCGATCGATCGACGATCGAT"
+         "CGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGA"
+         "TCGATCGATCGATCGACGATCGATCGATCGATCGATCGACGATCGATCGATCGAT"
+         "CGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGA"
+         "TCGATCGACGATCGATCGATCGATCGATCGACGATCGATCGATCGATCGATCGAT"
+         "CGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGA"
+         "CGATCGATCGATCGATCGATCGACGATCGATCGATCGATCGATCGATCGATCGAT"
+         "CGATCGATCGATCGATCGATCGA")
+MATCH = ("TCGATCAATCGATCAATCGATCAACGATCAATCGATCAATCGATCAACGATCAAT"
+         "CGATCAATCGATCAATCGATCAATCGATCAATCGATCAATCGATCAATCGATCAA"
+         "TCGATCAATCGATCAACGATCAATCGATCAATCGATCAACGATCAATCGATCAAT"
+         "CGATCAATCGATCAATCGATCAATCGATCAATCGATCAATCGATCAATCGATCAA"
+         "TCGATCAACGATCAATCGATCAATCGATCAACGATCAATCGATCAATCGATCAAT"
+         "CGATCAATCGATCAATCGATCAATCGATCAATCGATCAATCGATCAATCGATCAA"
+         "CGATCAATCGATCAATCGATCAACGATCAATCGATCAATCGATCAATCGATCAAT"
+         "CGATCAATCGATCAATCGATC")
+K = 6
+COMBOS = [(npc, xd, df) for npc in (10.0, 50.0) for xd in (27, 30) for df in (0.0, 1.0)]
+
+
+def _graph():
+    # build_graph_batch<DBGSuccinct>: dummy k-mers masked (test_dbg_helpers.cpp:379)
+    return orc.Graph.build(K, read_fasta(os.path.join(HERE, "golden", "transcripts_100.fa")), 0, True)
+
+
+def _config(npc, xdrop, df):
+    c = capi.config_default()
+    capi.set_dna_matrix(c, 2, -3, -3)
+    c.gap_opening_penalty, c.gap_extension_penalty = -5, -2
+    c.xdrop = xdrop
+    c.min_exact_match = df
+    c.max_nodes_per_seq_char = npc
+    c.num_alternative_paths = 2
+    c.min_path_score = 0
+    c.min_cell_score = 0
+    c.min_seed_length = K
+    return c
+
+
+def _exact(a, query):
+    return a["cigar"] == "%d=" % len(query) and a["sequence"] == query
+
+
+@pytest.mark.parametrize("npc,xdrop,df", COMBOS)
+def test_align_low_similarity4_on_the_oracle(npc, xdrop, df):
+    g = _graph()
+    cfg = _config(npc, xdrop, df)
+    paths, mpaths = orc.AlignRun(g, cfg, [QUERY, MATCH]).results()
+    if df == 0.0:
+        assert len(paths) == 2
+        assert paths[0] != paths[1]
+        assert paths[0]["score"] >= paths[1]["score"]
+    else:
+        assert len(paths) == 0
+    assert len(mpaths) >= 1
+    assert mpaths[0]["sequence"] == MATCH and _exact(mpaths[0], MATCH)
+
+
+@pytest.mark.parametrize("npc,xdrop,df", [(10.0, 27, 0.0), (10.0, 30, 0.0), (10.0, 27, 1.0)])
+def test_align_low_similarity4_through_the_kernels(npc, xdrop, df):
+    import emu_drv
+    g = _graph()
+    cfg = _config(npc, xdrop, df)
+    want = orc.AlignRun(g, cfg, [QUERY, MATCH]).results()
+    lim = capi.Limits()
+    lim.max_columns = 60000
+    got, status = emu_drv.EmuRun(emu_drv.EmuGraph(g), cfg, [QUERY, MATCH], limits=lim).results()
+    assert status == [0, 0]
+    assert got == want
+    assert len(got[0]) == (2 if df == 0.0 else 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("npc,xdrop,df", COMBOS)
+def test_align_low_similarity4_on_gpu(npc, xdrop, df):
+    from metagraph_amd import aligner
+    g = _graph()
+    W, last, F, valid = g.export()
+    G = aligner.Graph(g.k, W, last, F, valid)
+    cfg = _config(npc, xdrop, df)
+    want = orc.AlignRun(g, cfg, [QUERY, MATCH]).results()
+    lim = capi.Limits()
+    lim.max_columns = 60000
+    got, status = aligner.Aligner(G, cfg, lim).align_batch([QUERY, MATCH])
+    assert status == [0, 0]
+    assert got == want
+    if df == 0.0:
+        assert len(got[0]) == 2 and got[0][0] != got[0][1] and got[0][0]["score"] >= got[0][1]["score"]
+
+
+@pytest.mark.gpu
+def test_three_alternative_paths_random_reads_on_gpu():
+    from metagraph_amd import aligner
+    from test_emu_vs_oracle import make_world
+    g, reads = make_world(901, 15, genome_len=4000, n_reads=120, read_len=100, n_variants=60)
+    W, last, F, valid = g.export()
+    G = aligner.Graph(g.k, W, last, F, valid)
+    for n_alt in (2, 3, 4):
+        cfg = capi.config_cli(15)
+        cfg.num_alternative_paths = n_alt
+        want = orc.AlignRun(g, cfg, reads).results()
+        got, status = aligner.Aligner(G, cfg).align_batch(reads)
+        assert all(s == 0 for s in status)
+        assert got == want
+        assert max(len(a) for a in got) > 1

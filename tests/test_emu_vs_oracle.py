@@ -180,7 +180,7 @@ def test_two_pass_extension_retries_multi_seed_reads(monkeypatch):
 def test_split_pipeline_unit_kats(monkeypatch):
     monkeypatch.setenv("MGX_EMU_SPLIT", "1")
     for case in KATS["unit"]:
-        if case["expect"].get("throws") or case["config"].get("num_alternative_paths", 1) != 1:
+        if case["expect"].get("throws"):
             continue
         g = orc.Graph.build(case["k"], case["graph"], 0, case["mask_dummy"])
         eg = emu_drv.EmuGraph(g)
@@ -281,8 +281,7 @@ BIG.max_columns = 250000
 BIG.max_seeds = 2048
 
 
-@pytest.mark.parametrize("case", [c for c in KATS["unit"] if not c["expect"].get("throws")
-                                  and c["config"].get("num_alternative_paths", 1) == 1], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in KATS["unit"] if not c["expect"].get("throws")], ids=lambda c: c["name"])
 def test_unit_kats_through_kernels(case):
     g = orc.Graph.build(case["k"], case["graph"], 0, case["mask_dummy"])
     eg = emu_drv.EmuGraph(g)

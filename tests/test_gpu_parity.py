@@ -208,8 +208,7 @@ BIG.max_columns = 250000
 BIG.max_seeds = 2048
 
 
-@pytest.mark.parametrize("case", [c for c in KATS["unit"] if not c["expect"].get("throws")
-                                  and c["config"].get("num_alternative_paths", 1) == 1], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in KATS["unit"] if not c["expect"].get("throws")], ids=lambda c: c["name"])
 def test_reference_kats_on_gpu(case):
     g = orc.Graph.build(case["k"], case["graph"], 0, case["mask_dummy"])
     G = gpu_graph(g)
@@ -265,7 +264,7 @@ def test_unsupported_and_bad_config_fail_loudly():
     g, _ = make_world(3, 9, genome_len=300, n_reads=0)
     G = gpu_graph(g)
     cfg = capi.config_cli(9)
-    cfg.num_alternative_paths = 2
+    cfg.num_alternative_paths = 5                      # more than MGX_MAX_ALTERNATIVE_PATHS
     with pytest.raises(aligner.MgxError) as e:
         aligner.Aligner(G, cfg)
     assert e.value.code == capi.MGX_ERR_UNSUPPORTED
