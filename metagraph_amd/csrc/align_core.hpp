@@ -422,8 +422,9 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
         return r;
     };
     // persistent fast arrays
+    // both strands or neither: the query is read with LDS or global instructions according to q_lds, never generic ones
     w.q_lds = 2 * Lp <= lleft ? 1 : 0;
-    for (int s = 0; s < 2; ++s) w.q[s] = take_fast(Lp);
+    for (int s = 0; s < 2; ++s) w.q[s] = w.q_lds ? take_fast(Lp) : take(Lp);
     // overlay: the seeding tables and the extension's column staging are never live at the same time
     uint8_t *lp_mark = lp;
     uint32_t lleft_mark = lleft;
