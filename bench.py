@@ -224,10 +224,12 @@ def main():
                 "lines_per_read": {"k_map": round(lines_map / args.reads, 1), "k_seed": round(lines_seed / args.reads, 1),
                                    "k_extend": round((lines_align - lines_seed) / args.reads, 1)},
                 "columns_per_read": round(st["n_columns"] / args.reads, 2),
-                "phase_share": dict(zip(["prepare", "seeding", "extend", "backtrack", "driver", "output"],
+                # per-group timers of k_extend (a group also "spends" the time it waits for the other 7 reads of its
+                # wavefront, so these are shares of wavefront time, not of useful work)
+                "phase_share": dict(zip(["prepare", "seed_pickup", "extend", "backtrack", "driver", "output"],
                                         [round(c / max(1, sum(st["phase_cycles"][:6])), 3) for c in st["phase_cycles"][:6]])),
-                "extend_share": dict(zip(["pop", "stage_band", "outgoing", "column", "scan", "commit", "conv", "push"],
-                                         [round(c / max(1, sum(st["extend_cycles"])), 3) for c in st["extend_cycles"]]))}
+                "extend_share": dict(zip(["pop", "general_step", "chain_step"],
+                                         [round(c / max(1, st["phase_cycles"][2]), 3) for c in st["extend_cycles"][:3]]))}
 
     # ---------------- parity + CPU baseline (oracle = checker, never the thing measured) -----------------
     # The timed CPU leg is the restated reference path built -O3 -march=native -DNDEBUG on this host

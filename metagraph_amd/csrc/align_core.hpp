@@ -48,12 +48,20 @@
 
 // kernels that keep AlignParams in LDS (mgx_grp.hip) say so; elsewhere it is a kernel argument
 #if defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS
-#define MGX_ASSUME_PARAMS(p) MGX_ASSUME_LDS(p)
+// The sub-wave-group kernel keeps ONE copy of AlignParams per workgroup in LDS, as a namespace-scope __shared__ object:
+// every function, inlined or not, then reads it with ds_ instructions at a fixed address.  (Through a pointer kept in
+// the control block the compiler cannot tell the address space, and a FLAT load makes the wave wait for every global
+// load and store in flight — including the ones issued early on purpose.)
+#define MGX_PARAMS_OF(w) (::mgx::g_params)
 #else
-#define MGX_ASSUME_PARAMS(p) ((void)0)
+#define MGX_PARAMS_OF(w) (*(w).P)
 #endif
 
 namespace mgx {
+
+#if defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS
+__shared__ AlignParams g_params;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -261,6 +269,7 @@ struct XState {
     int32_t go, ge, xdrop, k, Lq, max_columns, seq_lds, rc;
     int32_t n_valid, n_for, n_count, pad3_;   // children of column n_for enumerated ahead of time into Wave::out_* (chain path)
     uint32_t hash_mask, cell_words;
+    int32_t seed_n_nodes, sn_base, sc_base, pad4_;   // seed replay: first entry of the register-cached node / character run
 };
 #else
 struct XState { int32_t unused_; };       // seeding-only translation units (k_seed) carry no extension state in LDS
@@ -269,7 +278,11 @@ struct XState { int32_t unused_; };       // seeding-only translation units (k_s
 #ifdef MGX_SEED_PROBE
 constexpr int XCYC_N = 8;
 #else
+#ifdef MGX_CHAIN_PROBE
+constexpr int XCYC_N = 8;                     // probe build: xcyc[] = the sections of chain_step (tools/probe_imbalance.py)
+#else
 constexpr int XCYC_N = 4;
+#endif
 #endif
 struct Wave {
     const AlignParams *P;
@@ -332,11 +345,7 @@ struct Wave {
     int32_t out_scores[5];
     uint8_t out_chars[8];
     uint64_t cyc[8];             // phase timers (shader cycles)
-#ifdef MGX_SEED_PROBE
-    uint64_t xcyc[8];            // seeding probe build: per-stage timers of make_seeder
-#else
-    uint64_t xcyc[4];            // extend() breakdown: pop, general steps, chain steps
-#endif
+    uint64_t xcyc[XCYC_N];       // extend() breakdown: pop, general steps, chain steps (probe builds: per-stage timers)
     uint32_t n_columns, n_extensions, n_fast_columns;
     int32_t status;
 };
@@ -360,7 +369,7 @@ MGX_DEV void wave_set_blk_cache(Wave &w, const Block &b, uint32_t idx) {
 
 // buffer roles for A = num_alternative_paths (runtime, <= MAX_ALT): [0, A) extension results, [A, 2A) their reversals (the
 // seeds of the backward pass), [2A, 3A) backward extension results, [3A, 4A) the aggregator's queue
-MGX_DEV int n_alt_of(const Wave &w) { return imax(1, imin((int)w.P->cfg.num_alt, MAX_ALT)); }
+MGX_DEV int n_alt_of(const Wave &w) { return imax(1, imin((int)MGX_PARAMS_OF(w).cfg.num_alt, MAX_ALT)); }
 #define Q0 (3 * n_alt_of(w))
 
 // LocalAlignmentLess (alignment.hpp:337-348): a < b
@@ -436,7 +445,13 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.rfirst = (uint32_t *)take_fast((L + 1) * 4);
     w.rlast = (uint32_t *)take_fast((L + 1) * 4);
     w.sd_own = (SdustScratch *)take_fast(sizeof(SdustScratch));
-    for (int b = 0; b < 4; ++b) w.bm[b] = (uint64_t *)take_fast(((L + 63) / 64 + 1) * 8);
+    {
+        // the four k-mer bitmaps are read together: all of them in LDS or none (three in LDS and one in the arena measured
+        // 10 % slower for the whole seeding kernel than none)
+        const uint64_t one = align8(((L + 63) / 64 + 1) * 8);
+        const bool fits = 4 * one <= lleft;
+        for (int b = 0; b < 4; ++b) w.bm[b] = (uint64_t *)(fits ? take_fast(one) : take(one));
+    }
     w.dust_eq = (uint64_t *)take_fast((L + 8) * 8);
     w.dust_t = take_fast(L + 8);
     uint8_t *lp_seed_end = lp;
@@ -741,7 +756,7 @@ MGX_DEV bool window_low_complexity(Wave &w, int s, int32_t begin, int32_t len) {
 // Linear partial sums: if every character of a strand is in ACGT and score(A,A) == score(C,C) == score(G,G) ==
 // score(T,T) == m > 0, then partial_sums_[x] == (L - x) * m exactly and the extender's per-cell test needs no table.
 MGX_DEV void detect_linear_psum(Wave &w) {
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const int32_t L = w.L;
     const int32_t mA = score_of(P, 'A', 'A');
     const bool same = mA > 0 && score_of(P, 'C', 'C') == mA && score_of(P, 'G', 'G') == mA && score_of(P, 'T', 'T') == mA;
@@ -762,7 +777,7 @@ MGX_DEV void detect_linear_psum(Wave &w) {
 
 MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding, bool for_extension) {
     MGX_ASSUME_LDS(&w);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const int32_t L = w.L;
     for (int32_t base = 0; base < L; base += WAVE) {
         FOR_LANES(l) {
@@ -847,7 +862,7 @@ MGX_DEV bool bits_test(const uint64_t *wds, int32_t i) { return (wds[i >> 6] >> 
 // bitmasks of the strand's k-mer positions: bm[0] = matched (node != 0), bm[1] = MEM stop (terminus of a
 // matched k-mer, or unmatched); one coalesced pass over nodes[] instead of per-position scalar loads
 MGX_DEV void kmer_masks(Wave &w, int s) {
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const int32_t n = w.n_kmers;
     const uint32_t *nodes = w.nodes[s];
     const int32_t nwords = (imax(n, 0) + 63) / 64 + 1;
@@ -897,7 +912,7 @@ MGX_DEV uint32_t num_exact_matching(const uint64_t *matched, int32_t n, int32_t 
 }
 
 MGX_DEV bool push_seed(Wave &w, int s, int32_t clip, int32_t len, int32_t offset, int32_t n_nodes, uint32_t node) {
-    if (w.n_seeds[s] >= (int32_t)w.P->lim.max_seeds) { w.status = ST_CAPACITY; return false; }
+    if (w.n_seeds[s] >= (int32_t)MGX_PARAMS_OF(w).lim.max_seeds) { w.status = ST_CAPACITY; return false; }
     DevSeed sd;
     sd.clipping = (uint16_t)clip; sd.length = (uint16_t)len; sd.offset = (uint16_t)offset;
     sd.n_nodes = (uint16_t)n_nodes; sd.node = node;
@@ -910,7 +925,7 @@ MGX_DEV bool push_seed(Wave &w, int s, int32_t clip, int32_t len, int32_t offset
 // MEMSeeder::get_seeds / ExactSeeder::get_seeds into w.seeds[s] (A/aligner_seeder_methods.cpp:67-93,360-424)
 MGX_NI_G2 void base_seeds(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const DevConfig &cfg = P.cfg;
     const int32_t k = (int32_t)P.g.k, L = w.L, n = w.n_kmers;
     const uint32_t *nodes = w.nodes[s];
@@ -949,7 +964,7 @@ constexpr uint32_t DEFERRED_RANGE = 0xFFFFFFFFu;     // rfirst[] marker: match l
 // *first = succ_last(rl), *last = ru
 MGX_DEV int32_t index_range_lane(const Wave &w, int s, int32_t i, int32_t len, int32_t min_len,
                                  uint64_t *first, uint64_t *last, LineCtr &ctr) {
-    const DevGraph &g = w.P->g;
+    const DevGraph &g = MGX_PARAMS_OF(w).g;
     const uint8_t *q = w.q[s] + i;
     *first = 0; *last = 0;
     if (len == 0) { *first = 1; *last = 1; return 0; }
@@ -1008,7 +1023,7 @@ MGX_DEV uint64_t xclock() {
 // SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358, non-canonical)
 MGX_NI_G2 void make_seeder(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const DevConfig &cfg = P.cfg;
     const DevGraph &g = P.g;
     const int32_t k = (int32_t)g.k, L = w.L;
@@ -1160,7 +1175,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             // call_incoming_to_target(bwd(e), node_last_value(e)) == parents of the node whose last edge is e
             int ni = incoming<true>(g, e, inc, fc, w.ctr);
             for (int t = 0; t < ni; ++t) {
-                if (alt_n >= w.P->lim.max_alt) { w.status = ST_CAPACITY; return; }
+                if (alt_n >= MGX_PARAMS_OF(w).lim.max_alt) { w.status = ST_CAPACITY; return; }
                 w.alt[alt_n++] = (uint32_t)inc[t];
                 ++cnt;
             }
@@ -1287,9 +1302,9 @@ MGX_DEV uint32_t conv_probe(const ConvChecker &c, uint32_t mask, uint64_t key, C
 
 // claim free slot `slot` for a new key; returns its vector number or -1 (capacity)
 MGX_DEV int32_t conv_insert(Wave &w, ConvChecker &c, uint32_t slot, uint64_t key, int32_t start, int32_t len) {
-    uint32_t cap = uni(w.P->lim.max_columns + w.P->lim.max_path);
+    uint32_t cap = uni(MGX_PARAMS_OF(w).lim.max_columns + MGX_PARAMS_OF(w).lim.max_path);
     const uint32_t ne = uni(c.n_entries);
-    if (ne >= cap || ne * 2 >= uni(w.P->lim.hash_size)) { w.status = ST_CAPACITY; return -1; }
+    if (ne >= cap || ne * 2 >= uni(MGX_PARAMS_OF(w).lim.hash_size)) { w.status = ST_CAPACITY; return -1; }
     c.n_entries = ne + 1;
     ConvSlot sl; sl.key = key; sl.gen = c.gen; sl.idx = ne; sl.start = start; sl.len = len; sl.pad0 = sl.pad1 = 0;
     conv_store_slot(c.slots + slot, sl);
@@ -1310,7 +1325,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
     // S values of the column: cells s_skip .. s_skip + size of the staged (two-tier) S array
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const int32_t s_cap = uni(w.st_cap);
     s_skip = uni(s_skip);
 #define s_cells(j) tget(s_tier, s_cap, s_skip + (j))
@@ -1392,7 +1407,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
 
 // check_seed (:66-88): true when the seed is still worth extending
 MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int32_t qlen, int32_t clipping, int32_t score) {
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     uint64_t key = (uint64_t)last_node + (E.rc_view ? P.g.n : 0);
     ConvSlot e;
     bool found;
@@ -1407,7 +1422,7 @@ MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int
 MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start, int32_t query_end) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const int32_t mscore = -NINF;
     int32_t size = query_end - query_start;
     ConvSlot e;
@@ -1640,7 +1655,7 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
                                int32_t prev_end, int32_t begin, int32_t size, uint8_t c, int32_t init_score,
                                int32_t offset, int32_t start, int32_t window_size, int32_t xdrop_cutoff) {
     MGX_ASSUME_LDS(&w);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const int32_t go = uni(P.cfg.gap_open), ge = uni(P.cfg.gap_ext);
     const int32_t L = uni(w.L);
     prev_size = uni(prev_size); prev_trim = uni(prev_trim); prev_end = uni(prev_end); begin = uni(begin);
@@ -1767,8 +1782,7 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
 
 // children of `node` in the graph the extender runs on (the graph itself, or its RCDBG view)
 MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node, uint32_t *nodes, uint8_t *chars, int32_t *scores) {
-    MGX_ASSUME_PARAMS(w.P);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     uint64_t nn[5];
     uint32_t cc[5];
     int n;
@@ -1811,7 +1825,7 @@ MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node,
 
 MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
                           uint32_t *nodes, uint8_t *chars, int32_t *scores) {
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const int32_t k = (int32_t)uni(P.g.k);
     const int32_t next_offset = col.offset + 1;
     const int32_t seed_pos = next_offset - uni(seed.offset);
@@ -1931,9 +1945,8 @@ enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 3, FR_STOP = 4, FR_ERROR = 5 };
 MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const int32_t i, const bool children_ready) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
-    MGX_ASSUME_PARAMS(w.P);
     XState &x = w.x;
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const DevConfig &cfg = P.cfg;
     const DevLimits &lim = P.lim;
     const ColMeta col = uni_col(col_load(w, i));
@@ -2076,7 +2089,17 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
 
 // ---- chain path: the only child of the window column, computed, judged and committed in registers ----
 // pS / pF: the window column (S and F of the chain's current parent), loop-carried registers of extend()
-MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *pF) {
+#ifdef MGX_CHAIN_PROBE
+#define CH_T(slot) { const uint64_t t_ = xclock(); w.xcyc[slot] += t_ - tch; tch = t_; }
+#else
+#define CH_T(slot)
+#endif
+// The seed replay reads the seed's node list and spelling WAVE entries at a time (one per lane) and hands them out by
+// lane broadcast: a column then starts without a dependent global load, whose wait would also drain the stores of the
+// column before (one vmcnt for loads and stores on gfx9).
+struct SeedRun { LV<uint32_t> nodes, chars; };
+
+MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *pF, SeedRun &run) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
     XState &x = w.x;
@@ -2084,6 +2107,9 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     const int32_t start = x.start, window_size = x.window_size, qlen = x.qlen;
     const int32_t go = x.go, ge = x.ge;
     const uint64_t tx1 = xclock();
+#ifdef MGX_CHAIN_PROBE
+    uint64_t tch = tx1;
+#endif
     // early cut-offs when off the optimal path (:521-547)
     if (x.f_max_val < x.best_score) {
         double node_counter = (double)x.tsize;
@@ -2116,8 +2142,23 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     int32_t score;
     if (in_seed && (next_offset < k || x.force_fixed)) {
         // the seed replay (:344-372): the node sequence and spelling of the seed, no graph access
-        next = gld(x.seed_nodes + (next_offset < k ? 0 : next_offset - k + 1));
-        c = x.seq_lds ? lds_u8(x.seed_seq + seed_pos) : gld(x.seed_seq + seed_pos);
+        const int32_t ni = next_offset < k ? 0 : next_offset - k + 1;
+        if ((uint32_t)(ni - x.sn_base) >= (uint32_t)WAVE) {
+            const int32_t last = x.seed_n_nodes - 1;
+            FOR_LANES(l) { run.nodes[l] = gld(x.seed_nodes + imin(ni + l, last)); }
+            x.sn_base = ni;
+        }
+        next = wave_bcast(run.nodes, ni - x.sn_base);
+        if (x.seq_lds) {
+            c = lds_u8(x.seed_seq + seed_pos);
+        } else {
+            if ((uint32_t)(seed_pos - x.sc_base) >= (uint32_t)WAVE) {
+                const int32_t last = x.seed_seq_len - 1;
+                FOR_LANES(l) { run.chars[l] = gld(x.seed_seq + imin(seed_pos + l, last)); }
+                x.sc_base = seed_pos;
+            }
+            c = (uint8_t)wave_bcast(run.chars, seed_pos - x.sc_base);
+        }
         score = (next_offset < k || next) ? 0 : (!x.f_node ? ge : go);
     } else {
         int n_out;
@@ -2144,6 +2185,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     ConvSlot csl;
     csl.key = 0; csl.gen = 0; csl.idx = 0; csl.start = 0; csl.len = 0; csl.pad0 = csl.pad1 = 0;
     if (next) csl = conv_load_slot(E.conv.slots + chash);
+    CH_T(0)
     // Expansion of the child's own node one column ahead (forward graph only): if this child continues the chain and
     // its successor comes from the graph, the two dependent loads of fwd() (select hint, target block) travel while
     // this column is computed.  Same primitives, same results; a speculation that does not pan out is simply dropped.
@@ -2155,8 +2197,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         const int32_t no2 = next_offset + 1, sp2 = no2 - x.seed_off;
         const bool replay2 = sp2 >= 0 && sp2 < x.seed_seq_len && (no2 < k || x.force_fixed);
         if (!x.rc && next > 1 && !replay2 && (next >> 6) == w.blk_cache_idx) {
-            MGX_ASSUME_PARAMS(w.P);
-            const DevGraph &g = w.P->g;
+                    const DevGraph &g = MGX_PARAMS_OF(w).g;
             const Block cur = wave_blk_cache(w);
             const uint32_t wv = block_W(cur, (int)(next & 63));
             if (wv == 0) {
@@ -2188,6 +2229,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         for (int s = 0; s < 4; ++s) { pS[s] = wave_shift_down(pS[s], sh, NINF); pF[s] = wave_shift_down(pF[s], sh, NINF); }
         p_org = org;
     }
+    CH_T(1)
     // update_column (:209-290): cell j = a - begin; j in [0, n_loop) is computed in blocks of four lanes
     const int8_t *row = w.sm_rows + encode_char(c) * 128;      // a __shared__ array of the kernel
     const uint8_t *qq = E.q;
@@ -2272,6 +2314,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             }
         }
     }
+    CH_T(2)
     // extend_ins_end (:293-328)
     int32_t size = size0, pushes = 0;
     if (size0 < max_size) {
@@ -2282,7 +2325,8 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             // while (v + ge >= cutoff) { v += ge; ++n_push; } bounded by the window end, in closed form (ge < 0)
             const int32_t room = max_size - (size0 + 1);
             int32_t n_push = 1 + room;
-            if (ge != 0) n_push = 1 + imin(room, (int32_t)(((int64_t)ins_score - (int64_t)xdrop_cutoff) / (int64_t)(-ge)));
+            // (the chain path runs with |cutoff| <= 30000 and scores below 2^24: the difference fits 32 bits)
+            if (ge != 0) n_push = 1 + imin(room, (int32_t)((uint32_t)(ins_score - xdrop_cutoff) / (uint32_t)(-ge)));
             if ((begin - org) + size0 + n_push > FW) {
                 // the parent window has moved: keep it consistent for the spill
                 x.f_org = p_org;
@@ -2306,7 +2350,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     Block pf_blk;
     pf_blk.cum[0] = pf_blk.cum[1] = pf_blk.cum[2] = pf_blk.cum[3] = 0; pf_blk.last_cum = 0; pf_blk.cum0 = 0;
     pf_blk.last_bits = 0; pf_blk.p0 = pf_blk.p1 = pf_blk.p2 = pf_blk.pf = 0;
-    if (pf && !pf_zero) pf_blk = load_block_uniform(w.P->g, pf_hint);
+    if (pf && !pf_zero) pf_blk = load_block_uniform(MGX_PARAMS_OF(w).g, pf_hint);
     // scan (:643-669): min_cell_score_, max_pos (closest to the diagonal), has_extension
     const int32_t psum_lin = x.psum_lin;
     const int32_t *psum = E.psum;
@@ -2347,6 +2391,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     x.table_size_bytes += (uint64_t)136 * (E.table_cap - table_cap_before) + (uint64_t)cur_cap3 * 4;
     if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > x.xdrop) x.xdrop_cutoff = max_val - x.xdrop;
     x.best_score = imax(x.best_score, max_val);
+    CH_T(3)
     // --- everything that LOADS comes first (a wait on a load also waits for every store issued before it) ---
     // update_seed_filter (:100-156), resolution: cell at window position a (j in [skip, size)) is query position
     // start + a - 1 of the node's vector.  A position outside the vector's old range holds ninf by definition, so
@@ -2376,7 +2421,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             mdo[l] = 0;
         }
         converged = wave_max(cm);
-        if (next != 0 && !(w.P->ablate & 1u)) {
+        if (next != 0 && !(MGX_PARAMS_OF(w).ablate & 1u)) {
             bool found;
             cv_slot = conv_probe_from(E.conv, cmask, ckey, chash, csl, found);
             if (!found) {
@@ -2417,13 +2462,14 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             }
         }
     }
+    CH_T(4)
     // the children of this column's node, enumerated ahead (see above): consume the target block now
     int pf_n = -1;
     if (pf) {
         if (pf_zero) {
             pf_n = 0;
         } else if (pf_blk.last_cum < pf_r && pf_blk.last_cum + (uint32_t)popc64(pf_blk.last_bits) >= pf_r) {
-            const DevGraph &g = w.P->g;
+            const DevGraph &g = MGX_PARAMS_OF(w).g;
             const int lj = select64(pf_blk.last_bits, (int)(pf_r - pf_blk.last_cum));     // fwd(): last edge of the target node
             const uint64_t m = lj > 0 ? (pf_blk.last_bits & mask_upto(lj - 1)) : 0;       // pred_last(lst - 1) inside this block
             if (m) {
@@ -2444,6 +2490,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             }
         }
     }
+    CH_T(5)
     // --- stores only from here on ---
     // Will the frontier hand this column straight back (:491-504: it is the unique maximum)?  Then nothing ever reloads
     // it and its slot is all it leaves behind; otherwise it also gets an S / F record.
@@ -2457,7 +2504,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     cur.base = max_val == NINF ? 0 : max_val;
     cur.cells = deferred ? x.cell_top : NO_CELLS;
     cur.self = my_idx;
-    if (!(w.P->ablate & 2u)) {
+    if (!(MGX_PARAMS_OF(w).ablate & 2u)) {
         ColSlot *slot = w.cols + my_idx;
         const LV<int32_t> e_up = wave_shift_up1(cE[3], NINF);
         const int32_t ptrim = x.f_trim;
@@ -2498,6 +2545,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             x.cell_top += rec_words((uint32_t)FW);
         }
     }
+    CH_T(6)
     x.tsize = my_idx + 1;
     // update_seed_filter, the stores
     if (cv_mode == CV_INSERT) {
@@ -2524,6 +2572,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             }
         }
     }
+    CH_T(7)
     if (w.status != ST_OK) return FR_ERROR;
     if (converged == NINF) return FR_END;
     if (chain_on) {
@@ -2532,7 +2581,9 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         x.f_max_val = max_val; x.f_org = org;
         if (pf_n >= 0) { x.n_valid = 1; x.n_for = my_idx; x.n_count = pf_n; }
         wave_sync();
+#ifndef MGX_CHAIN_PROBE
         w.xcyc[2] += xclock() - tx1;
+#endif
         return FR_CONT;
     }
     {
@@ -2544,18 +2595,21 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             frontier_push(w, key);
         }
     }
+#ifndef MGX_CHAIN_PROBE
     w.xcyc[2] += xclock() - tx1;
+#endif
     return FR_END;
 }
 
 // One function for the whole loop: a call boundary makes the callee wait for every store it issued (s_waitcnt before
 // s_setpc), which would drain each column's record stores at the end of each step.
-MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force_fixed_seed) {
+// (es: which of the wave's two extenders — taken as an index so that the extender state is addressed off the control
+// block, i.e. provably in LDS, rather than through a second generic pointer)
+MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fixed_seed) {
     MGX_ASSUME_LDS(&w);
-    MGX_ASSUME_LDS(&E);
-    MGX_ASSUME_PARAMS(w.P);
+    ExtenderState &E = w.ext[es];
     ExtendResult *res = &w.er;
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const DevConfig &cfg = P.cfg;
     const DevLimits &lim = P.lim;
     XState &x = w.x;
@@ -2580,6 +2634,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     x.rc_key_add = E.rc_view ? P.g.n : 0;
     x.rc = E.rc_view ? 1 : 0;
     x.n_valid = 0; x.n_for = -1; x.n_count = 0;
+    x.seed_n_nodes = uni(seed.n_nodes); x.sn_base = -0x40000000; x.sc_base = -0x40000000;
     x.rel_cutoff = cfg.rel_score_cutoff; x.max_nodes_per_char = cfg.max_nodes_per_seq_char; x.max_ram = cfg.max_ram_per_alignment;
     x.go = cfg.gap_open; x.ge = cfg.gap_ext; x.xdrop = cfg.xdrop; x.k = (int32_t)P.g.k; x.Lq = (int32_t)lim.Lmax;
     x.max_columns = (int32_t)lim.max_columns; x.hash_mask = lim.hash_size - 1; x.cell_words = lim.cell_words;
@@ -2648,6 +2703,8 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
     const bool use_fast = !P.no_fast && cfg.xdrop <= 30000;
     int mode = XM_POP;
     LV<int32_t> pS[4], pF[4];            // the chain window: S and F of the chain's current column, 4 cells per lane
+    SeedRun run;
+    FOR_LANES(l) { run.nodes[l] = 0; run.chars[l] = 0; }
     FOR_LANES(l) { for (int s = 0; s < 4; ++s) { pS[s][l] = NINF; pF[s][l] = NINF; } }
     for (;;) {
         int32_t gi = -1;                 // column for the general step of this iteration
@@ -2666,7 +2723,9 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
                 x.qn = qn; x.nn = nn;
                 x.q_top = qn ? key_score(qget(w.queue, qn - 1)) : INT32_MIN;
                 wave_sync();
+#ifndef MGX_CHAIN_PROBE
                 w.xcyc[0] += xclock() - tx0;
+#endif
             }
             const int32_t i = (int32_t)uni(key_idx(qget(w.next_nodes, x.nn - 1)));
             --x.nn;
@@ -2679,7 +2738,7 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
             }
         }
         if (mode == XM_FAST) {
-            const int r = chain_step(w, E, pS, pF);
+            const int r = chain_step(w, E, pS, pF, run);
             if (r == FR_CONT) continue;
             mode = XM_POP;
             if (r == FR_END) continue;
@@ -2693,7 +2752,9 @@ MGX_NI_G3 void extend(Wave &w, ExtenderState &E, const SeedRef &seed, bool force
         if (gi >= 0) {
             const uint64_t tg = xclock();
             const int bad = general_step(w, E, seed, gi, children_ready);
+#ifndef MGX_CHAIN_PROBE
             w.xcyc[1] += xclock() - tg;
+#endif
             if (bad) { res->table_size = 0; return; }
         }
     }
@@ -2733,7 +2794,7 @@ MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src);
 MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, const DevAln *seed_aln,
                       const ExtendResult &er, int32_t min_path_score, DevAln *outs, int n_max) {
     MGX_ASSUME_LDS(&w);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     const DevConfig &cfg = P.cfg;
     const int32_t k = (int32_t)P.g.k;
     const int32_t seed_clipping = seed.clipping;
@@ -3103,7 +3164,7 @@ MGX_DEV int32_t global_cutoff(const Wave &w) {              // :141-149
     int mx = 0;                                             // std::max_element: the first of equal maxima
     for (int t = 1; t < w.have_best; ++t) if (aln_less(w.aln[Q0 + mx], w.aln[Q0 + t])) mx = t;
     int32_t cur_max = w.aln[Q0 + mx].score;
-    return cur_max > 0 ? (int32_t)((double)cur_max * w.P->cfg.rel_score_cutoff) : cur_max;
+    return cur_max > 0 ? (int32_t)((double)cur_max * MGX_PARAMS_OF(w).cfg.rel_score_cutoff) : cur_max;
 }
 
 MGX_DEV bool aln_equal(const Wave &w, const DevAln &a, const DevAln &b) {     // Alignment::operator== (alignment.hpp:261-269)
@@ -3134,7 +3195,7 @@ MGX_NI_G4 void add_alignment(Wave &w, const DevAln &a) {
 // driver (DBGAligner<>::align_batch for one query, A/dbg_aligner.cpp:263-355,360-384,531-758)
 // ------------------------------------------------------------------------------------------------
 MGX_DEV SeedRef seedref_from_seed(const Wave &w, int s, int32_t idx, int32_t *sub_node_slot) {
-    const DevConfig &cfg = w.P->cfg;
+    const DevConfig &cfg = MGX_PARAMS_OF(w).cfg;
     DevSeed sd = w.seeds[s][idx];
     SeedRef r;
     r.clipping = sd.clipping; r.qlen = sd.length; r.offset = sd.offset; r.n_nodes = sd.n_nodes;
@@ -3152,13 +3213,13 @@ MGX_DEV SeedRef seedref_from_seed(const Wave &w, int s, int32_t idx, int32_t *su
 }
 
 MGX_DEV int32_t min_path_score_now(const Wave &w) {          // get_min_path_score (:277-282)
-    return imax(w.P->cfg.min_path_score, global_cutoff(w));
+    return imax(MGX_PARAMS_OF(w).cfg.min_path_score, global_cutoff(w));
 }
 
 // aln_both (:657-736): seeds of strand s; fwd extender = ext[s] on the graph, bwd extender = ext[1 - s] on RCDBG
 MGX_NI_G4 void aln_both(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     ExtenderState &F = w.ext[s];
     ExtenderState &B = w.ext[1 - s];
     F.rc_view = 0;
@@ -3173,7 +3234,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         conv_clear(F.conv);                                   // set_seed (:90-98)
         uint64_t t0 = cycle_clock();
         w.cyc[6] += t0 - tp0;
-        extend(w, F, seed, false);
+        extend(w, s, seed, false);
         uint64_t t1 = cycle_clock();
         w.cyc[2] += t1 - t0;
         const ExtendResult er = w.er;
@@ -3211,7 +3272,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
             int32_t mps2 = imax(0, min_path_score_now(w));
             conv_clear(B.conv);
             uint64_t t2 = cycle_clock();
-            extend(w, B, rseed, true);
+            extend(w, 1 - s, rseed, true);
             uint64_t t3 = cycle_clock();
             w.cyc[2] += t3 - t2;
             const ExtendResult er2 = w.er;
@@ -3251,7 +3312,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
 // align_core (:360-384) with the seeds of strand 0, forward only
 MGX_NI_G4 void align_core_fwd(Wave &w) {
     MGX_ASSUME_LDS(&w);
-    const AlignParams &P = *w.P;
+    const AlignParams &P = MGX_PARAMS_OF(w);
     ExtenderState &F = w.ext[0];
     F.rc_view = 0;
     const int32_t n = w.n_seeds[0];
@@ -3262,7 +3323,7 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
         SeedRef seed = seedref_from_seed(w, 0, i, nullptr);
         int32_t mps = imax(0, min_path_score_now(w));
         conv_clear(F.conv);
-        extend(w, F, seed, false);
+        extend(w, 0, seed, false);
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
         {
@@ -3459,7 +3520,11 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         stats_accum->bit_lines += w.ctr.bit_lines;
         stats_accum->seed_lines += w.ctr.rank_lines + w.ctr.select_lines + w.ctr.bit_lines;
         stats_accum->seeds += (uint32_t)(w.n_seeds[0] + w.n_seeds[1]);
-        for (int x = 0; x < 2; ++x) stats_accum->cyc[x] += w.cyc[x];
+#if !defined(MGX_SEED_PROBE) && !defined(MGX_CHAIN_PROBE)
+        // the seeding kernel's two timers go to the spare slots of the extension breakdown, so that cyc[] is the extension
+        // kernel's alone (the two kernels run different numbers of lanes per read: their cycles do not add up)
+        for (int x = 0; x < 2; ++x) stats_accum->xcyc[6 + x] += w.cyc[x];
+#endif
 #ifdef MGX_SEED_PROBE
         for (int x = 0; x < XCYC_N; ++x) stats_accum->xcyc[x] += w.xcyc[x];
 #endif

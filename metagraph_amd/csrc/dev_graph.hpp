@@ -126,7 +126,7 @@ MGX_DEV int select64(uint64_t x, int r) {
 
 MGX_DEV bool in_graph(const DevGraph &g, uint64_t v) {              // dbg_succinct.cpp:934-936
     if (v == 0 || v > g.n) return false;
-    return !g.valid || ((g.valid[v >> 6] >> (v & 63)) & 1);
+    return !g.valid || ((gld(g.valid + (v >> 6)) >> (v & 63)) & 1);       // (a global load, not a FLAT one)
 }
 
 template <bool U = false>
@@ -357,7 +357,7 @@ MGX_DEV int outgoing(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *c
 
 MGX_DEV uint32_t first_char(const DevGraph &g, uint64_t e, LineCtr &ctr) {
     ++ctr.bit_lines;
-    return (g.firstc[e >> 3] >> ((e & 7) * 4)) & 0xF;
+    return (gld(g.firstc + (e >> 3)) >> ((e & 7) * 4)) & 0xF;
 }
 
 // Parents of v with the first character of each parent k-mer, in the order of
@@ -433,7 +433,7 @@ MGX_DEV bool has_single_incoming(const DevGraph &g, uint64_t v, LineCtr &ctr) {
     if (v == 1) return false;
     uint64_t x = bwd(g, v, ctr);
     uint32_t w = node_last_value(g, v);
-    bool first_valid = !g.valid || ((g.valid[x >> 6] >> (x & 63)) & 1);
+    bool first_valid = !g.valid || ((gld(g.valid + (x >> 6)) >> (x & 63)) & 1);
     if (x + 1 == g.n + 1) return first_valid;
     bool flagged;
     if (first_valid) {

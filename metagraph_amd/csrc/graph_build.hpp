@@ -206,4 +206,130 @@ MGX_DEV void map_lane_step(const DevGraph &g, MapLane &m, LineCtr &ctr, FetchCha
     m.state = 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same state machine over 2-bit packed reads (k <= 32).  A streaming pre-pass (pack_read_word, one thread per
+// 32 bases) writes every strand as 64-bit words of 32 codes (A C G T = 0..3) plus one invalid-character flag per base;
+// word j of read r lives at index (offsets[r] >> 5) + r + j.  A lane keeps the codes of positions [i, i + 32) in one
+// register pair (`cur`), shifts two bits per k-mer and tops up from the next word every 32 k-mers: every character
+// index(), tighten_range, fwd and pick_edge look at (positions i .. i + k - 1) is a shift away, where the byte path
+// issues a global load, an alphabet switch and a complement per character.
+// ------------------------------------------------------------------------------------------------
+MGX_HD uint64_t packed_word_begin(uint64_t byte_offset, uint64_t read) { return (byte_offset >> 5) + read; }
+
+MGX_DEV void pack_read_word(const char *seq, int32_t L, int strand, int32_t j, uint64_t *codes, uint32_t *inv) {
+    uint64_t c = 0;
+    uint32_t v = 0;
+    for (int32_t t = 0; t < 32; ++t) {
+        const int32_t pos = 32 * j + t;
+        if (pos >= L) break;
+        const uint32_t code = strand_code(seq, L, strand, pos);
+        if (code == 5 || code == 0) v |= 1u << t;
+        else c |= (uint64_t)(code - 1) << (2 * t);
+    }
+    *codes = c;
+    *inv = v;
+}
+
+struct MapLanePacked {
+    const uint64_t *pk;       // packed codes of this chain's strand, word 0 = positions 0..31
+    const uint32_t *iv;       // invalid flags, same indexing
+    uint32_t *out;
+    uint8_t *out_len;
+    uint2 *out_rng;
+    int32_t min_rng_len;
+    int32_t n_words, n_kmers;
+    int32_t i;                // next k-mer position
+    int32_t t;
+    uint64_t cur, nxt;        // codes of positions [i, i + 32); the not yet consumed codes of the word after them
+    uint32_t icur, inxt;      // the same for the invalid flags
+    uint64_t edge, rl, ru;
+    Block blk;
+    int state;
+};
+
+MGX_DEV uint32_t packed_code(const MapLanePacked &m, int32_t off) { return (uint32_t)((m.cur >> (2 * off)) & 3) + 1; }
+
+MGX_DEV void packed_begin(MapLanePacked &m) {
+    m.cur = gld(m.pk); m.icur = gld(m.iv);
+    const int32_t j1 = m.n_words > 1 ? 1 : 0;
+    m.nxt = gld(m.pk + j1); m.inxt = gld(m.iv + j1);
+}
+
+// i -> i + 1
+MGX_DEV void packed_advance(MapLanePacked &m) {
+    m.cur = (m.cur >> 2) | ((m.nxt & 3) << 62);
+    m.icur = (m.icur >> 1) | ((m.inxt & 1) << 31);
+    m.nxt >>= 2; m.inxt >>= 1;
+    ++m.i;
+    if ((m.i & 31) == 0) {                               // position i + 32 starts word (i >> 5) + 1
+        const int32_t j = imin((m.i >> 5) + 1, m.n_words - 1);
+        m.nxt = gld(m.pk + j); m.inxt = gld(m.iv + j);
+    }
+}
+
+template <class FetchChain>
+MGX_DEV void map_lane_step_packed(const DevGraph &g, MapLanePacked &m, LineCtr &ctr, FetchChain fetch) {
+    const int32_t k = (int32_t)g.k;                      // <= 32
+    if (m.state == 0) {
+        if (!fetch(m)) { m.state = 3; return; }
+        m.i = 0; m.edge = 0;
+        if (m.n_kmers > 0) { packed_begin(m); m.state = 1; }
+        return;
+    }
+    if (m.state == 1) {
+        if (m.i >= m.n_kmers) { m.state = 0; return; }
+        const int32_t i = m.i;
+        const uint32_t kmask = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+        if (m.icur & kmask) { gst_stream(m.out + i, 0); m.edge = 0; packed_advance(m); return; }
+        if (m.edge) {
+            Block tgt;
+            uint64_t lst = fwd_from(g, m.edge, m.blk, packed_code(m, k - 2), tgt, ctr);
+            m.blk = tgt;
+            m.edge = lst ? pick_edge_from(g, lst, m.blk, packed_code(m, k - 1), ctr) : 0;
+            gst_stream(m.out + i, in_graph(g, m.edge) ? (uint32_t)m.edge : 0);
+            packed_advance(m);
+            return;
+        }
+        int32_t t0 = 1;
+        if (g.prefix_len && (int32_t)g.prefix_len <= k - 1) {
+            const uint32_t key = (uint32_t)(m.cur & ((1ull << (2 * g.prefix_len)) - 1ull));
+            prefix_range(g, key, &m.rl, &m.ru, ctr);
+            t0 = (int32_t)g.prefix_len;
+        } else {
+            initial_range(g, packed_code(m, 0), &m.rl, &m.ru);
+        }
+        if (m.rl > m.ru) {
+            if (m.out_len && t0 > 1 && k - 1 < MLEN_LT_PREFIX) gst_stream(m.out_len + i, MLEN_LT_PREFIX);
+            gst_stream(m.out + i, 0); m.edge = 0; packed_advance(m);
+            return;
+        }
+        m.t = t0;
+        m.state = 2;
+        return;
+    }
+    const int32_t i = m.i;
+    if (m.t < k - 1) {
+        if (!tighten_range(g, &m.rl, &m.ru, packed_code(m, m.t), ctr)) {
+            if (m.out_len && k - 1 < MLEN_LT_PREFIX) {
+                gst_stream(m.out_len + i, (uint8_t)m.t);
+                if (m.out_rng && m.t >= m.min_rng_len) m.out_rng[i] = make_uint2((uint32_t)m.rl, (uint32_t)m.ru);
+            }
+            gst_stream(m.out + i, 0); m.edge = 0; packed_advance(m); m.state = 1;
+            return;
+        }
+        ++m.t;
+        return;
+    }
+    ++ctr.rank_lines;
+    m.blk = load_block(g, (uint32_t)(m.ru >> 6));
+    m.edge = pick_edge_from(g, m.ru, m.blk, packed_code(m, k - 1), ctr);
+    gst_stream(m.out + i, in_graph(g, m.edge) ? (uint32_t)m.edge : 0);
+    if (!m.edge && m.out_len && k - 1 < MLEN_LT_PREFIX) {
+        gst_stream(m.out_len + i, (uint8_t)(k - 1));
+        if (m.out_rng && k - 1 >= m.min_rng_len) m.out_rng[i] = make_uint2((uint32_t)m.rl, (uint32_t)m.ru);
+    }
+    packed_advance(m);
+    m.state = 1;
+}
+
 } // namespace mgx

@@ -140,6 +140,66 @@ __global__ void __launch_bounds__(256, 6) k_map(DevGraph g, const char *seqs, co
     }
 }
 
+// 2-bit packing pre-pass of the mapping kernel (graph_build.hpp, pack_read_word): one thread per (read, 32-base word)
+__global__ void k_pack_reads(const char *seqs, const uint64_t *offsets, uint64_t n_reads, uint32_t words_per_read, int do_rc,
+                             uint64_t *pk_fwd, uint64_t *pk_rc, uint32_t *iv_fwd, uint32_t *iv_rc) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t read = t / words_per_read;
+    const int32_t j = (int32_t)(t % words_per_read);
+    if (read >= n_reads) return;
+    const uint64_t off = offsets[read];
+    const int32_t L = (int32_t)(offsets[read + 1] - off);
+    if (32 * j >= L) return;
+    const uint64_t w = packed_word_begin(off, read) + (uint64_t)j;
+    uint64_t c; uint32_t v;
+    pack_read_word(seqs + off, L, 0, j, &c, &v);
+    pk_fwd[w] = c; iv_fwd[w] = v;
+    if (do_rc) { pack_read_word(seqs + off, L, 1, j, &c, &v); pk_rc[w] = c; iv_rc[w] = v; }
+}
+
+// k_map over the packed reads (k <= 32): same chains, same primitives, same outputs (map_lane_step_packed)
+#ifndef MGX_MAP_PACKED_WAVES
+#define MGX_MAP_PACKED_WAVES 6
+#endif
+__global__ void __launch_bounds__(256, MGX_MAP_PACKED_WAVES) k_map_packed(DevGraph g, const uint64_t *offsets, const uint64_t *node_begin,
+                                             const uint64_t *pk_fwd, const uint64_t *pk_rc, const uint32_t *iv_fwd, const uint32_t *iv_rc,
+                                             uint32_t *nodes_fwd, uint32_t *nodes_rc, uint8_t *mlen_fwd, uint8_t *mlen_rc,
+                                             uint2 *rng_fwd, uint2 *rng_rc, int min_rng_len,
+                                             uint64_t n_reads, int do_rc, unsigned long long *cursor, KernelStats *stats) {
+    LineCtr ctr = { 0, 0, 0 };
+    MapLanePacked m;
+    m.state = 0;
+    const uint64_t n_chains = do_rc ? 2 * n_reads : n_reads;
+    auto fetch = [&](MapLanePacked &ml) -> bool {
+        uint64_t c = atomicAdd(cursor, 1ull);
+        if (c >= n_chains) return false;
+        const uint64_t read = do_rc ? (c >> 1) : c;
+        const int strand = do_rc ? (int)(c & 1) : 0;
+        const uint64_t off = offsets[read];
+        const int32_t L = (int32_t)(offsets[read + 1] - off);
+        const uint64_t w = packed_word_begin(off, read);
+        ml.pk = (strand ? pk_rc : pk_fwd) + w;
+        ml.iv = (strand ? iv_rc : iv_fwd) + w;
+        ml.n_words = (L + 31) >> 5;
+        ml.out = (strand ? nodes_rc : nodes_fwd) + node_begin[read];
+        ml.out_len = (strand ? mlen_rc : mlen_fwd) + node_begin[read];
+        uint2 *rg = strand ? rng_rc : rng_fwd;
+        ml.out_rng = rg ? rg + node_begin[read] : nullptr;
+        ml.min_rng_len = min_rng_len;
+        ml.n_kmers = L - (int32_t)g.k + 1;
+        return true;
+    };
+    while (m.state != 3) map_lane_step_packed(g, m, ctr, fetch);
+    uint32_t r = ctr.rank_lines, s = ctr.select_lines, b = ctr.bit_lines;
+    for (int d = 32; d >= 1; d >>= 1) { r += __shfl_xor(r, d, 64); s += __shfl_xor(s, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0 && (r | s | b)) {
+        atomicAdd(&stats->rank_lines, (unsigned long long)r);
+        atomicAdd(&stats->select_lines, (unsigned long long)s);
+        atomicAdd(&stats->bit_lines, (unsigned long long)b);
+        atomicAdd(&stats->map_lines, (unsigned long long)r + s + b);
+    }
+}
+
 // one wave per read, persistent over the batch; each wave owns one arena slice
 #ifndef MGX_ALIGN_WAVES_PER_SIMD
 #define MGX_ALIGN_WAVES_PER_SIMD 4
@@ -256,6 +316,7 @@ struct mgx_aligner {
     mgx_limits user_lim;
     bool have_user_lim = false;
     DevBuf mlen_fwd, mlen_rc;     // k_map's index() match lengths, one byte per k-mer position
+    DevBuf pk_fwd, pk_rc, iv_fwd, iv_rc;      // 2-bit packed reads + invalid flags of the mapping kernel (k <= 32)
     DevBuf rng_fwd, rng_rc;       // and the (rl, ru) of matches >= min_seed_length (8 B per position; optional)
     bool have_rng = false;
     DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, d_stats_map, scan_tmp, dbg_seeds;
@@ -597,7 +658,7 @@ static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets
     return MGX_OK;
 }
 
-static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, bool do_rc, bool mapped) {
+static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, bool do_rc, bool mapped, uint32_t Lmax) {
     // k_map's counters live in their own block: a re-run of the alignment stage (stream overflow) resets only its own
     HIP_TRY(hipMemsetAsync(A->d_stats_map.p, 0, sizeof(KernelStats), 0));
     HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), 0));
@@ -621,12 +682,33 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
         const uint64_t chains = (do_rc ? 2 : 1) * n;
         uint64_t blocks = std::min<uint64_t>((uint64_t)prop.multiProcessorCount * MGX_MAP_BLOCKS_PER_CU, (chains + 255) / 256);
         if (blocks == 0) blocks = 1;
-        k_map<<<(uint32_t)blocks, 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
+        static const bool no_pack = getenv("MGX_MAP_BYTES") != nullptr;          // A/B probe: the byte-per-character path
+        if (A->graph->g.k <= 32 && Lmax > 0 && !no_pack) {
+            // words: every read starts at (offset >> 5) + read and takes ceil(L / 32) of them
+            const uint64_t words = ((A->total_kmers + n * (uint64_t)A->graph->g.k) >> 5) + n + 2;
+            if (int rc = A->pk_fwd.ensure(words * 8)) return rc;
+            if (int rc = A->iv_fwd.ensure(words * 4)) return rc;
+            if (do_rc) { if (int rc = A->pk_rc.ensure(words * 8)) return rc; if (int rc = A->iv_rc.ensure(words * 4)) return rc; }
+            const uint32_t wpr = (Lmax + 31) / 32;
+            const uint64_t threads = n * wpr;
+            k_pack_reads<<<(uint32_t)((threads + 255) / 256), 256>>>(d_seqs, d_offsets, n, wpr, do_rc ? 1 : 0, A->pk_fwd.as<uint64_t>(),
+                                                                    A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            k_map_packed<<<(uint32_t)blocks, 256>>>(A->graph->g, d_offsets, A->node_begin.as<uint64_t>(),
+                                         A->pk_fwd.as<uint64_t>(), A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>(),
                                          A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(),
                                          A->mlen_fwd.as<uint8_t>(), A->mlen_rc.as<uint8_t>(),
                                          A->have_rng ? A->rng_fwd.as<uint2>() : nullptr, A->have_rng ? A->rng_rc.as<uint2>() : nullptr,
                                          (int)std::min<uint64_t>(A->cfg.min_seed_length, 1u << 20), n, do_rc ? 1 : 0,
                                          map_cursor, A->d_stats_map.as<KernelStats>());
+        } else {
+            k_map<<<(uint32_t)blocks, 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
+                                         A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(),
+                                         A->mlen_fwd.as<uint8_t>(), A->mlen_rc.as<uint8_t>(),
+                                         A->have_rng ? A->rng_fwd.as<uint2>() : nullptr, A->have_rng ? A->rng_rc.as<uint2>() : nullptr,
+                                         (int)std::min<uint64_t>(A->cfg.min_seed_length, 1u << 20), n, do_rc ? 1 : 0,
+                                         map_cursor, A->d_stats_map.as<KernelStats>());
+        }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(A->ev[1], 0));
@@ -753,8 +835,12 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     A->split_ran = split;
     if (split) {
         if (l.Lmax <= 192 && slots >= (uint64_t)prop.multiProcessorCount * 4 * 8) {
-            const uint32_t budget8 = (160u * 1024u) / (4 * 8) - static_lds - 64u;
-            const uint32_t lds8 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), budget8) & ~15u;
+            // (measured on 150-bp reads: the kernel is 10 % faster with 4944 B of LDS per wavefront than with 5056 B, although
+            // both leave room for 32 wavefronts per CU; hence the wider margin)
+            const uint32_t budget8 = (160u * 1024u) / (4 * 8) - static_lds - 192u;
+            uint32_t lds8 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), budget8) & ~15u;
+            if (const char *e = getenv("MGX_SEED_LDS_CAP")) lds8 = std::min<uint32_t>(lds8, (uint32_t)atoi(e)) & ~15u;     // tuning probe
+            if (getenv("MGX_SEED_LDS_PRINT")) fprintf(stderr, "k_seed: static_lds %u budget8 %u lds8 %u (fast_lds_bytes %u)\n", static_lds, budget8, lds8, fast_lds_bytes(l.Lmax));
             k_align<PH_SEED, 8><<<(uint32_t)prop.multiProcessorCount * 4 * 8, 64, lds8>>>(P, lds8);
         } else {
             k_align<PH_SEED><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
@@ -820,7 +906,7 @@ int mgx_map_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uin
     HIP_TRY(hipSetDevice(A->graph->device));
     const char *d_seqs; const uint64_t *d_offsets; uint32_t Lmax;
     if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc;
-    if (int rc = run_map(A, d_seqs, d_offsets, n, true, true)) return rc;
+    if (int rc = run_map(A, d_seqs, d_offsets, n, true, true, Lmax)) return rc;
     if (int rc = collect_stats(A, true, false)) return rc;
     A->m_node_begin.resize(n + 1);
     HIP_TRY(hipMemcpy(A->m_node_begin.data(), A->node_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost));
@@ -858,7 +944,7 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
     if (n == 0) { A->n_reads = 0; return MGX_OK; }
     if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc;
     bool mapped = A->cfg.max_seed_length >= A->graph->g.k;
-    if (int rc = run_map(A, d_seqs, d_offsets, n, A->cfg.forward_and_reverse_complement != 0, mapped)) return rc;
+    if (int rc = run_map(A, d_seqs, d_offsets, n, A->cfg.forward_and_reverse_complement != 0, mapped, Lmax)) return rc;
     for (;;) {
         if (int rc = run_align(A, d_seqs, d_offsets, n, Lmax)) return rc;
         if (int rc = collect_stats(A, mapped, true)) return rc;

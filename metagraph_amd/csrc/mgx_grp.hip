@@ -37,11 +37,10 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
     const int g = group_id();
     const uint32_t slot = blockIdx.x * GROUPS_PER_WAVEFRONT + (uint32_t)g;
     __shared__ Wave ws[GROUPS_PER_WAVEFRONT];
-    __shared__ AlignParams sP;                         // a kernel argument whose address is taken would live in scratch
     __shared__ int8_t sm_rows[6 * 128];
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&P);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&sP);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&g_params);      // (a kernel argument whose address is taken would live in scratch)
         for (uint32_t x = threadIdx.x; x < sizeof(AlignParams) / 4; x += 64) dst[x] = src[x];
     }
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -64,7 +63,7 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
         uint64_t item = wave_bcast(rv, 0);
         if (item >= n_items) break;
         const uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
-        align_read<PHASE>(w, sP, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
+        align_read<PHASE>(w, g_params, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
     }
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);

@@ -153,6 +153,40 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         const uint64_t n_chains = do_rc ? 2 * n : n;
         uint64_t cursor = 0;
         LineCtr ctr = { 0, 0, 0 };
+        if (k <= 32 && !getenv("MGX_MAP_BYTES")) {
+            // the product's packed path: k_pack_reads, then k_map_packed (same word layout)
+            const uint64_t words = (offsets[n] >> 5) + n + 2;
+            std::vector<uint64_t> pkf(words, 0), pkr(words, 0);
+            std::vector<uint32_t> ivf(words, 0), ivr(words, 0);
+            for (uint64_t r = 0; r < n; ++r) {
+                const int32_t L = (int32_t)(offsets[r + 1] - offsets[r]);
+                for (int32_t j = 0; 32 * j < L; ++j) {
+                    const uint64_t wd = packed_word_begin(offsets[r], r) + (uint64_t)j;
+                    pack_read_word(seqs + offsets[r], L, 0, j, &pkf[wd], &ivf[wd]);
+                    pack_read_word(seqs + offsets[r], L, 1, j, &pkr[wd], &ivr[wd]);
+                }
+            }
+            MapLanePacked m;
+            m.state = 0;
+            auto fetch = [&](MapLanePacked &ml) -> bool {
+                uint64_t c = cursor++;
+                if (c >= n_chains) return false;
+                uint64_t read = do_rc ? (c >> 1) : c;
+                const int strand = do_rc ? (int)(c & 1) : 0;
+                const int32_t L = (int32_t)(offsets[read + 1] - offsets[read]);
+                const uint64_t wd = packed_word_begin(offsets[read], read);
+                ml.pk = (strand ? pkr.data() : pkf.data()) + wd;
+                ml.iv = (strand ? ivr.data() : ivf.data()) + wd;
+                ml.n_words = (L + 31) >> 5;
+                ml.out = (strand ? nr.data() : nf.data()) + R->node_begin[read];
+                ml.out_len = (strand ? lr.data() : lf.data()) + R->node_begin[read];
+                ml.out_rng = (strand ? gr.data() : gf.data()) + R->node_begin[read];
+                ml.min_rng_len = (int32_t)std::min<uint64_t>(cfg.min_seed_length, 1u << 20);
+                ml.n_kmers = L - (int32_t)k + 1;
+                return true;
+            };
+            while (m.state != 3) map_lane_step_packed(G->g, m, ctr, fetch);
+        } else {
         MapLane m;
         m.state = 0;
         auto fetch = [&](MapLane &ml) -> bool {
@@ -170,6 +204,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
             return true;
         };
         while (m.state != 3) map_lane_step(G->g, m, ctr, fetch);
+        }
         R->stats.rank_lines += ctr.rank_lines; R->stats.select_lines += ctr.select_lines;
     }
     R->m_fwd.assign(nf.begin(), nf.end());
