@@ -278,7 +278,7 @@ struct XState { int32_t unused_; };       // seeding-only translation units (k_s
 #ifdef MGX_SEED_PROBE
 constexpr int XCYC_N = 8;
 #else
-#ifdef MGX_CHAIN_PROBE
+#if defined(MGX_CHAIN_PROBE) || defined(MGX_BT_PROBE)
 constexpr int XCYC_N = 8;                     // probe build: xcyc[] = the sections of chain_step (tools/probe_imbalance.py)
 #else
 constexpr int XCYC_N = 4;
@@ -1459,14 +1459,7 @@ MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t qu
 // extension (DefaultColumnExtender::extend, A/aligner_extender_methods.cpp:412-772)
 // ------------------------------------------------------------------------------------------------
 // metadata of column i <-> its slot (positions and sizes fit 16 bits: Lmax <= MGX_MAX_QUERY_LENGTH; gap scores are int8)
-MGX_DEV ColMeta col_load(const Wave &w, int32_t i) {
-    const ColSlot *sl = w.cols + i;
-    uint32_t m[8];
-#if MGX_WAVE_EMU
-    for (int t = 0; t < 8; ++t) m[t] = sl->m[t];
-#else
-    mgx_mem::load_bytes<32>(sl->m, m);
-#endif
+MGX_DEV ColMeta col_unpack(const uint32_t *m, int32_t i) {
     ColMeta c;
     c.node = m[0]; c.parent = (int32_t)m[1]; c.offset = (int32_t)m[2]; c.base = (int32_t)m[3]; c.cells = m[4];
     c.max_pos = (int32_t)(m[5] & 0xFFFF); c.trim = (int32_t)(m[5] >> 16);
@@ -1475,6 +1468,16 @@ MGX_DEV ColMeta col_load(const Wave &w, int32_t i) {
     c.cw = (m[7] & 0xFF) | (((m[7] >> 16) & 0x7FFF) << 8) | (m[7] & CW_CHAIN);
     c.self = i;
     return c;
+}
+MGX_DEV ColMeta col_load(const Wave &w, int32_t i) {
+    const ColSlot *sl = w.cols + i;
+    uint32_t m[8];
+#if MGX_WAVE_EMU
+    for (int t = 0; t < 8; ++t) m[t] = sl->m[t];
+#else
+    mgx_mem::load_bytes<32>(sl->m, m);
+#endif
+    return col_unpack(m, i);
 }
 MGX_DEV void col_pack(const ColMeta &c, uint32_t *m) {
     m[0] = c.node; m[1] = (uint32_t)c.parent; m[2] = (uint32_t)c.offset; m[3] = (uint32_t)c.base; m[4] = c.cells;
@@ -2769,9 +2772,9 @@ MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fix
 // Writes at most one alignment into `out`; returns whether one was produced.
 // ------------------------------------------------------------------------------------------------
 MGX_DEV bool prev_start_test_and_set(Wave &w, int32_t j) {
-    uint32_t word = w.prev_starts[j >> 5];
+    uint32_t word = gld(w.prev_starts + (j >> 5));
     bool was = (word >> (j & 31)) & 1;
-    if (!was) { w.prev_starts[j >> 5] = word | (1u << (j & 31)); }
+    if (!was) { gst(w.prev_starts + (j >> 5), word | (1u << (j & 31))); }
     return !was;       // true when newly inserted (emplace(...).second)
 }
 
@@ -2791,10 +2794,20 @@ MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src);
 
 // seed_aln: the Alignment the seed was made from (backward pass) or nullptr for Seed-derived seeds
 // Writes up to n_max alignments (num_alternative_paths, :1005 terminate_backtrack_start) into outs[0 .. ); returns how many.
-MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, const DevAln *seed_aln,
+MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln *seed_aln,
                       const ExtendResult &er, int32_t min_path_score, DevAln *outs, int n_max) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = MGX_PARAMS_OF(w);
+    // the extender's query: read with LDS or global instructions, never generic ones (a FLAT load waits for every store
+    // in flight, and the walk below stores three values per step)
+    const uint8_t *bq = w.ext[es].q;
+    const bool bq_lds = w.q_lds != 0;
+    auto op_at = [&](uint8_t c, int32_t abs_pos) -> uint8_t {      // profile_op_at
+        if (abs_pos < 1 || abs_pos > w.L) return OP_CLIPPED;
+        const uint32_t code = encode_char(c);
+        const uint8_t row = code != 5 ? decode_code(code) : 0;
+        return char_to_op(row, bq_lds ? lds_u8(bq + abs_pos - 1) : gld(bq + abs_pos - 1));
+    };
     const DevConfig &cfg = P.cfg;
     const int32_t k = (int32_t)P.g.k;
     const int32_t seed_clipping = seed.clipping;
@@ -2808,6 +2821,12 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
     const int32_t right_end_bonus = cfg.right_end_bonus;
     const int32_t cap = (int32_t)P.lim.max_path;
     const int32_t tsize = er.table_size;
+#ifdef MGX_BT_PROBE
+    uint64_t tbt = xclock();
+#define BT_T(slot) { const uint64_t t_ = xclock(); w.xcyc[slot] += t_ - tbt; tbt = t_; }
+#else
+#define BT_T(slot)
+#endif
     // candidate start cells (:815-867), one table column per lane; the order of `indices` is irrelevant
     // because the heap pops by the full (unique) tuple
     // tips as a bitset (prev_starts is cleared per extension and only used from here on; use a second region)
@@ -2850,7 +2869,7 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
                         const int32_t sv = (pass == 0 && col_chain(col)) ? col.base : cell_S(w, col, start_pos);
                         int32_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
                         if (sv + end_bonus >= min_start_score) {
-                            bool is_match = (fl & CF_MATCH) && profile_op_at(E.q, w.L, col_char(col), seed_clipping + start_pos) == OP_MATCH;
+                            bool is_match = (fl & CF_MATCH) && op_at(col_char(col), seed_clipping + start_pos) == OP_MATCH;
                             if (is_match || start_pos == last_pos || is_tip) {
                                 BtIndex bx;
                                 bx.score = sv + end_bonus; bx.neg_off_diag = -iabs(start_pos - col.offset + seed_offset);
@@ -2898,6 +2917,7 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
         first_bi = wave_bcast(lbest_at, ctz64(wave_ballot(hit)));
     }
     wave_sync();
+    BT_T(3)
     int produced = 0;
     int32_t best_score = INT32_MIN;
     int32_t remaining = n_idx;
@@ -2951,6 +2971,18 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
         if (score - er.min_cell_score < best_score) break;
 
         int32_t n_ops = 0, n_path = 0, n_seq = 0, n_trace = 0;
+        uint32_t cur_run = 0;                          // rev_ops[n_ops - 1], kept in a register: appending never reads memory
+        auto push_op = [&](uint32_t op, uint32_t num) {
+            if (!num) return;
+            if (n_ops == 0 || (cur_run & 7) != op) {
+                if (n_ops >= cap) { w.status = ST_CAPACITY; return; }
+                cur_run = (num << 3) | op;
+                gst(w.rev_ops + n_ops++, cur_run);
+            } else {
+                cur_run += num << 3;
+                gst(w.rev_ops + n_ops - 1, cur_run);
+            }
+        };
         int32_t dummy_counter = 0;
         int32_t pos = cur.pos;
         const int32_t end_pos = pos;
@@ -2959,16 +2991,16 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
         uint32_t last_path_node = 0;
         auto append_node = [&](uint32_t node, uint8_t c, int32_t offset, uint32_t op) {
             if (n_seq >= cap) { w.status = ST_CAPACITY; return; }
-            w.rev_seq[n_seq++] = c;
-            cigar_append(w.rev_ops, &n_ops, op, 1, cap, &w.status);
+            gst(w.rev_seq + n_seq++, c);
+            push_op(op, 1);
             if (offset >= k_minus_1) {
                 if (n_path >= cap) { w.status = ST_CAPACITY; return; }
-                w.rev_nodes[n_path++] = node;
+                gst(w.rev_nodes + n_path++, node);
                 last_path_node = node;
                 if (!node) {
                     ++dummy_counter;
                 } else if (dummy_counter) {
-                    cigar_append(w.rev_ops, &n_ops, OP_NODE_INSERTION, (uint32_t)dummy_counter, cap, &w.status);
+                    push_op(OP_NODE_INSERTION, (uint32_t)dummy_counter);
                     extra_score -= cfg.gap_open + (dummy_counter - 1) * cfg.gap_ext;
                     dummy_counter = 0;
                 }
@@ -2979,21 +3011,50 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
         // The column chain is walked parent by parent; each step reads ONE thing: the flag byte of the current cell (all
         // of backtrack's comparisons were evaluated when the column was computed).  The parent's metadata is fetched one
         // step ahead.
+        // Walking parent pointers is pointer chasing: one DRAM round trip per column.  Columns of an extension are mostly
+        // numbered along the path (a chain column's parent is the column before it), so the slots below the one the walk
+        // is about to read are fetched WAVE at a time, one per lane; the walk's own loads then hit the L2.  A guess only:
+        // a parent elsewhere is fetched on demand as before.  (Serving the walk from such a batch held in registers was
+        // measured too: no faster — the walk is bound by its chain of LDS round trips, not by these loads.)
+        int32_t pf_lo = INT32_MAX;
+        LV<uint32_t> pf_val;
+        FOR_LANES(l) { pf_val[l] = 0; }
+        // prev_starts bits set along the walk are collected per 32-column word and written when the walk leaves the word
+        // (nothing reads the set before the next pop)
+        int32_t ps_idx = -1;
+        uint32_t ps_bits = 0;
+        auto ps_flush = [&]() {
+            if (ps_idx >= 0 && ps_bits) gst(w.prev_starts + ps_idx, gld(w.prev_starts + ps_idx) | ps_bits);
+            ps_bits = 0;
+        };
         ColMeta col = col_load(w, j), par = col;
         if (j) par = col_load(w, col.parent);
         while (j) {
             ColMeta gp = par;
-            if (col.parent > 0) gp = col_load(w, par.parent);          // par is not the root
+            if (col.parent > 0) {                                      // par is not the root
+                const int32_t t = par.parent;
+                if (t < pf_lo) {
+#if !MGX_WAVE_EMU
+                    asm volatile("" : : "v"(pf_val.v));                // the previous batch has long arrived
+#endif
+                    FOR_LANES(l) { pf_val[l] = gld((const uint32_t *)(w.cols + imax(0, t - l))); }
+                    pf_lo = t - WAVE + 1;
+                }
+                gp = col_load(w, t);
+            }
             align_offset = imin(col.offset, k_minus_1);
-            if (pos == col.max_pos) prev_start_test_and_set(w, j);
+            if (pos == col.max_pos) {
+                if ((j >> 5) != ps_idx) { ps_flush(); ps_idx = j >> 5; }
+                ps_bits |= 1u << (j & 31);
+            }
             const uint32_t fl = cell_flags(w, col, pos);
-            const uint32_t last_op = n_ops ? (w.rev_ops[n_ops - 1] & 7) : 99u;
+            const uint32_t last_op = n_ops ? (cur_run & 7) : 99u;
             if (!(fl & CF_REAL)) {
                 j = 0;
             } else if (pos && (fl & CF_S_IS_E) && (n_ops == 0 || last_op != OP_DELETION)) {
                 uint32_t lop = OP_INSERTION;
                 while (lop == OP_INSERTION) {
-                    cigar_append(w.rev_ops, &n_ops, lop, 1, cap, &w.status);
+                    push_op(lop, 1);
                     lop = (cell_flags(w, col, pos) & CF_E_EXT) ? OP_INSERTION : OP_MATCH;
                     --pos;
                     if (w.status != ST_OK) return 0;
@@ -3001,7 +3062,7 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
             } else if (pos && (fl & CF_MATCH)) {
                 ++n_trace;
                 extra_score += col.score;
-                append_node(col.node, col_char(col), col.offset, profile_op_at(E.q, w.L, col_char(col), seed_clipping + pos));
+                append_node(col.node, col_char(col), col.offset, op_at(col_char(col), seed_clipping + pos));
                 --pos;
                 j = col.parent;
                 col = par; par = gp;
@@ -3023,6 +3084,11 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
             }
             if (w.status != ST_OK) return 0;
         }
+        ps_flush();
+        BT_T(4)
+#if !MGX_WAVE_EMU
+        asm volatile("" : : "v"(pf_val.v));
+#endif
         if (n_trace >= min_trace_length && n_path && last_path_node) {
             const ColMeta cj = col_load(w, j);
             int32_t cur_cell_score = cell_S(w, cj, pos);
@@ -3064,6 +3130,7 @@ MGX_NI_G4 int backtrack(Wave &w, const ExtenderState &E, const SeedRef &seed, co
             }
         }
     }
+    BT_T(5)
     if (!produced && seed.score >= min_path_score) {       // extensions.emplace_back(*seed_) (:1030-1031)
         if (seed_aln) copy_aln(outs[0], *seed_aln);
         else seed_as_alignment(w, seed, outs[0]);
@@ -3243,7 +3310,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         const int n_alt = n_alt_of(w);
         int n_fwd;
         if (P.ablate & 4u) { seed_as_alignment(w, seed, w.aln[0]); n_fwd = 1; }       // timing probe only
-        else n_fwd = backtrack(w, F, seed, nullptr, er, mps, &w.aln[0], n_alt);
+        else n_fwd = backtrack(w, s, seed, nullptr, er, mps, &w.aln[0], n_alt);
         w.cyc[3] += cycle_clock() - t1;
         if (w.status != ST_OK) return;
         // every extension of this seed goes to the aggregator; those that can be continued to the left are reversed and
@@ -3279,7 +3346,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
             if (w.status != ST_OK) return;
             int n_bwd;
             if (P.ablate & 4u) { copy_aln(w.aln[2 * n_alt], rev); n_bwd = 1; }         // timing probe only
-            else n_bwd = backtrack(w, B, rseed, &rev, er2, mps2, &w.aln[2 * n_alt], n_alt);
+            else n_bwd = backtrack(w, 1 - s, rseed, &rev, er2, mps2, &w.aln[2 * n_alt], n_alt);
             w.cyc[3] += cycle_clock() - t3;
             if (w.status != ST_OK) return;
             for (int b = 0; b < n_bwd; ++b) {
@@ -3327,7 +3394,7 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
         {
-            const int n_fwd = backtrack(w, F, seed, nullptr, er, mps, &w.aln[0], n_alt_of(w));
+            const int n_fwd = backtrack(w, 0, seed, nullptr, er, mps, &w.aln[0], n_alt_of(w));
             if (w.status != ST_OK) return;
             for (int e = 0; e < n_fwd; ++e) add_alignment(w, w.aln[e]);
         }
@@ -3526,6 +3593,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         for (int x = 0; x < 2; ++x) stats_accum->xcyc[6 + x] += w.cyc[x];
 #endif
 #ifdef MGX_SEED_PROBE
+        for (int x = 0; x < 2; ++x) stats_accum->cyc[x] += w.cyc[x];           // probe build: the seeding kernel's own timers
         for (int x = 0; x < XCYC_N; ++x) stats_accum->xcyc[x] += w.xcyc[x];
 #endif
         return;

@@ -6,7 +6,11 @@ cd "$(dirname "$0")/.."
 tag=$1; shift
 B=metagraph_amd/_build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
-/opt/rocm/bin/hipcc $FLAGS -DMGX_GROUP=8 "$@" -c -o $B/mgx_grp8_$tag.o metagraph_amd/csrc/mgx_grp.hip
+if [ -n "$VARIANT_ONLY_SEEDING_UNIT" ]; then     # the flags go to mgx.hip only
+    cp $B/mgx_grp8.o $B/mgx_grp8_$tag.o; VARIANT_ALL_UNITS=1
+else
+    /opt/rocm/bin/hipcc $FLAGS -DMGX_GROUP=8 "$@" -c -o $B/mgx_grp8_$tag.o metagraph_amd/csrc/mgx_grp.hip
+fi
 MGX_O=$B/mgx.o
 if [ -n "$VARIANT_ALL_UNITS" ]; then      # the flags also go to the seeding unit
     /opt/rocm/bin/hipcc $FLAGS "$@" -c -o $B/mgx_$tag.o metagraph_amd/csrc/mgx.hip

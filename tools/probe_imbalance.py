@@ -34,7 +34,15 @@ def run(r, tag):
                 "columns_per_read": round(st["n_columns"] / n, 1), "extensions_per_read": round(st["n_extensions"] / n, 2)}, flush=True)
     pc, xc = st["phase_cycles"], st["extend_cycles"]
     tot = max(1, sum(pc[:6]))
-    if "probe" in os.environ.get("MGX_LIB_PATH", ""):
+    if "seedprobe" in os.environ.get("MGX_LIB_PATH", ""):
+        names = ["kmer_masks", "base_seeds", "msl init", "lookups", "bookkeeping", "aggregate", "(sdust)", "(enumerate)"]
+        tot_s = max(1, pc[0] + pc[1])
+        print("   k_seed wave-time ms-equivalents: prepare %.1f seeding %.1f;" % (st["seeding_ms"] * pc[0] / tot_s, st["seeding_ms"] * pc[1] / tot_s),
+              {nm: round(st["seeding_ms"] * c / tot_s, 1) for nm, c in zip(names, xc)}, flush=True)
+        return
+    if "btprobe" in os.environ.get("MGX_LIB_PATH", ""):
+        print("   backtrack sections (ms-equivalents): scan %.1f walk %.1f pop+construct %.1f" % tuple(st["extend_ms"] * c / tot for c in xc[3:6]), flush=True)
+    elif "probe" in os.environ.get("MGX_LIB_PATH", ""):
         names = ["band+child", "prefetch+shift", "profile+dp", "ins_end+scan", "conv resolve", "children consume", "slot stores", "conv stores"]
         print("   chain_step sections (ms-equivalents):", {nm: round(st["extend_ms"] * c / tot, 1) for nm, c in zip(names, xc)}, flush=True)
         xc = [0] * 8
