@@ -9,8 +9,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-out_name = sys.argv[2] if len(sys.argv) > 2 else "r01_pmc_summary.json"
-KERNELS = {"k_map": "k_map(", "k_seed": "k_align<1", "k_extend": "k_align_grp8<2>", "k_align_fused": "k_align<3>"}
+out_name = sys.argv[2] if len(sys.argv) > 2 else "r02_pmc_summary.json"
+KERNELS = {"k_map": "k_map_packed", "k_pack_reads": "k_pack_reads", "k_map_bytes": "k_map(", "k_seed": "k_align<1", "k_extend": "k_align_grp8<2>"}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for path in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_*", "**", "*counter_collection.csv"), recursive=True):
