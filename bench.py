@@ -91,6 +91,10 @@ def main():
     reads = synth.sample_reads(genome, args.reads, args.read_len, 20240503 + rank).contiguous()
     offsets = (torch.arange(args.reads + 1, device=dev, dtype=torch.int64) * args.read_len).contiguous()
     torch.cuda.synchronize()
+    # the workload generator's temporaries go back to the device: the aligner sizes its per-read arena from free HBM, and
+    # torch's caching allocator would otherwise sit on the graph construction's sort buffers for the whole run
+    del genome
+    torch.cuda.empty_cache()
     if rank == 0:
         log("graph: %d edges, device index %.1f MB, built in %.1fs; reads %d x %d" %
             (n_edges, G.device_bytes / 1e6, t_graph, args.reads, args.read_len))

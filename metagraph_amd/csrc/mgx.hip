@@ -715,6 +715,13 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
     return MGX_OK;
 }
 
+// bits of the work-sort key: 12 of predicted work + the segment number (align_core.hpp, WORK_SEGMENT_SHIFT)
+static int work_key_bits(uint64_t n) {
+    int b = 12;
+    for (uint64_t seg = n ? (n - 1) >> WORK_SEGMENT_SHIFT : 0; seg; seg >>= 1) ++b;
+    return std::min(b, 32);
+}
+
 static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, uint32_t Lmax) {
     {
         std::string err;
@@ -731,7 +738,17 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     const bool split = mode == MODE_SPLIT8;      // always
     const uint64_t wave_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;   // seeding kernel: one wavefront per read
     const uint64_t want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * (uint64_t)mgx_grp_waves_per_simd8());
-    uint64_t budget = free_b / 2;
+    // The arena gets what is free after the buffers this stage allocates AFTER it (result records, output stream, seed
+    // stream, sort arrays: estimated generously) and a margin; buffers kept from an earlier batch are already outside
+    // `free_b`.  (Half of the free memory, as before, left 15 % of the extension kernel's groups without a slice at
+    // 10 M reads next to a host framework's cached allocations.)
+    const uint64_t later = n * (sizeof(ReadResult) + sizeof(SeedHdr) + 24 + 16)
+                           + (n * (((uint64_t)l.Lmax + l.Lmax / 4 + 40) * std::max<uint64_t>(1, A->cfg.num_alternative_paths)) + 1024) * 4
+                           + (n * 24 + A->total_kmers / 8 + 4096) * A->seed_scale * sizeof(DevSeed) + (1ull << 30);
+    const uint64_t held = A->results.bytes + A->stream.bytes + A->seed_stream.bytes + A->seed_hdr.bytes;     // re-used as far as they reach
+    const uint64_t need_later = later > held ? later - held : 0;
+    const uint64_t avail = (uint64_t)free_b + A->arena.bytes;             // a growing arena frees its old block first
+    uint64_t budget = avail > need_later ? (avail - need_later) / 10 * 9 : avail / 2;
     uint64_t slots = std::min<uint64_t>(std::min<uint64_t>(want_slots, std::max<uint64_t>(n, 1)), std::max<uint64_t>(1, budget / stride));
     if (slots == 0) slots = 1;
     {
@@ -745,6 +762,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         }
     }
     A->n_slots = (uint32_t)slots;
+    if (getenv("MGX_DEBUG_SLOTS")) fprintf(stderr, "run_align: n %llu stride %llu want_slots %llu slots %llu free %.1f GB\n", (unsigned long long)n, (unsigned long long)stride, (unsigned long long)want_slots, (unsigned long long)slots, free_b / 1e9);
     if (int rc = A->results.ensure(n * sizeof(ReadResult))) return rc;
     uint64_t words_per_read = ((uint64_t)l.Lmax + l.Lmax / 4 + 40) * std::max<uint64_t>(1, A->cfg.num_alternative_paths);
     // heuristic size (one alignment per read: nodes + CIGAR runs + path characters); a batch that needs more is re-run
@@ -804,7 +822,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         if (int rc = A->order.ensure(n * 4)) return rc;
         if (int rc = A->retry_list.ensure(n * 4 + 4)) return rc;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes, A->work_key.as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
-                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, 12, (hipStream_t)0));
+                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, work_key_bits(n), (hipStream_t)0));
         if (int rc = A->sort_tmp.ensure(sort_tmp_bytes)) return rc;
         P.seed_hdr = A->seed_hdr.as<SeedHdr>();
         P.seed_stream = A->seed_stream.as<DevSeed>();
@@ -849,7 +867,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         HIP_TRY(hipEventRecord(A->ev[4], 0));
         k_iota<<<(uint32_t)((n + 255) / 256), 256>>>(A->order_in.as<uint32_t>(), n);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, sort_tmp_bytes, A->work_key.as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
-                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, 12, (hipStream_t)0));
+                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, work_key_bits(n), (hipStream_t)0));
         HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));                      // rewind the read cursor
         P.order = A->order.as<uint32_t>();
         HIP_TRY(hipEventRecord(A->ev[5], 0));

@@ -22,6 +22,8 @@ W, last = boss["W"].contiguous(), boss["last"].contiguous()
 G = aligner.Graph(k, (W.data_ptr(), boss["n_edges"] + 1), (last.data_ptr(), boss["n_edges"] + 1), boss["F"], device=0, on_device=True)
 reads = synth.sample_reads(genome, n, L, 20240503).contiguous()
 offsets = (torch.arange(n + 1, device=dev, dtype=torch.int64) * L).contiguous()
+del genome
+torch.cuda.empty_cache()
 A = aligner.Aligner(G, capi.config_cli(k))
 
 
