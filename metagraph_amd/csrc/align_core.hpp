@@ -312,6 +312,7 @@ struct Wave {
             uint8_t *dust_t;             // triplet code per position (maybe_low_complexity)
             uint64_t *dust_eq;           // per position: which of the next 61 positions hold the same triplet
             int32_t lc_any[2];           // whole-strand sdust verdict: 0 = no maskable interval anywhere, 1 = some, -1 = unknown
+            int32_t lc_maybe;            // maybe_low_complexity of the read (either strand: see window_low_complexity), -1 = unknown
             int32_t inv_any[2];          // strand holds a character outside ACGT
             int32_t n_kmers;
         };
@@ -745,7 +746,13 @@ MGX_DEV bool maybe_low_complexity(Wave &w, int s) {
 // DUST score exceeds T; any such interval also exists in the whole strand, so if sdust on the whole strand
 // masks nothing, no window can be flagged.  Only strands with a masked region pay the per-window runs.
 MGX_DEV bool window_low_complexity(Wave &w, int s, int32_t begin, int32_t len) {
-    if (w.lc_any[s] < 0) w.lc_any[s] = (maybe_low_complexity(w, s) && is_low_complexity(w.q[s], w.L, w.sd)) ? 1 : 0;
+    if (w.lc_any[s] < 0) {
+        // The conservative test is mirror-symmetric — an interval of the reverse complement holds the reverse complements
+        // of the same triplets, so the same pairs of equal triplets at the same distances — hence one evaluation serves both
+        // strands of a read (the exact algorithm below still runs per strand).
+        if (w.lc_maybe < 0) w.lc_maybe = maybe_low_complexity(w, s) ? 1 : 0;
+        w.lc_any[s] = (w.lc_maybe && is_low_complexity(w.q[s], w.L, w.sd)) ? 1 : 0;
+    }
     if (!w.lc_any[s]) return false;
     return is_low_complexity(w.q[s] + begin, len, w.sd);
 }
@@ -3465,6 +3472,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     } else {
         prepare_query(w, P.seqs + off, (PHASE & PH_SEED) != 0, (PHASE & PH_EXTEND) != 0);
         w.lc_any[0] = w.lc_any[1] = -1;
+        w.lc_maybe = -1;
         w.cyc[0] = cycle_clock() - tstart;
         for (int s = 0; s < 2; ++s) {
             w.ext[s].q = w.q[s];
