@@ -266,6 +266,13 @@ size_t mgx_format_tsv(const mgx_results *res, uint64_t query_index, const char *
                       const char *query, size_t query_len, int32_t min_path_score,
                       char *buf, size_t buf_len);
 
+/* Format one query's results like `metagraph align --json` (cli/align.cpp:287-305): one line per alignment, the JSON of
+ * Alignment::to_json / path_json (alignment.cpp:704-963) as Json::writeString emits it with indentation "" (keys in
+ * lexicographic order, no white space); a query without alignments yields {"name":...,"sequence":""}.  `k` is the graph's
+ * node length (DeBruijnGraph::get_k()).  Returns the number of bytes needed (excluding NUL); writes at most buf_len bytes. */
+size_t mgx_format_json(const mgx_results *res, uint64_t query_index, const char *header,
+                       const char *query, size_t query_len, uint32_t k, char *buf, size_t buf_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,6 +186,9 @@ def lib():
     L.mgx_format_tsv.argtypes = [C.POINTER(Results), C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t,
                                  C.c_int32, C.c_char_p, C.c_size_t]
     L.mgx_format_tsv.restype = C.c_size_t
+    L.mgx_format_json.argtypes = [C.POINTER(Results), C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t,
+                                  C.c_uint32, C.c_char_p, C.c_size_t]
+    L.mgx_format_json.restype = C.c_size_t
     _lib = L
     return L
 
@@ -258,3 +261,13 @@ def config_cli(k):
     c.alignment_match_score, c.alignment_mm_transition_score, c.alignment_mm_transversion_score = 2, 3, 3
     set_dna_matrix(c, 2, -3, -3)
     return c
+
+
+def format_json(res, qi, header, query, k):
+    """`metagraph align --json` lines of query qi of an mgx_results view (host-side formatting, no GPU involved)."""
+    q = query if isinstance(query, bytes) else query.encode("latin-1")
+    h = header if isinstance(header, bytes) else header.encode()
+    n = lib().mgx_format_json(C.byref(res), qi, h, q, len(q), k, None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib().mgx_format_json(C.byref(res), qi, h, q, len(q), k, buf, n + 1)
+    return buf.value.decode("latin-1")

@@ -1103,4 +1103,152 @@ size_t mgx_format_tsv(const mgx_results *res, uint64_t qi, const char *header, c
     return s.size();
 }
 
+// ---- metagraph align --json (cli/align.cpp:287-305): Alignment::to_json (alignment.cpp:883-963) + path_json (:704-881),
+// written the way Json::writeString does with indentation "" (jsoncpp: object keys in lexicographic order, no white
+// space, doubles as %.17g with ".0" appended to integral values, strings with the standard escapes).
+namespace {
+void json_string(std::string &o, const char *p, size_t n) {
+    o += '"';
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char c = (unsigned char)p[i];
+        switch (c) {
+            case '"': o += "\\\""; break;
+            case '\\': o += "\\\\"; break;
+            case '\b': o += "\\b"; break;
+            case '\f': o += "\\f"; break;
+            case '\n': o += "\\n"; break;
+            case '\r': o += "\\r"; break;
+            case '\t': o += "\\t"; break;
+            default:
+                if (c < 0x20 || c >= 0x7F) { char b[8]; snprintf(b, sizeof(b), "\\u%04X", (unsigned)c); o += b; }
+                else o += (char)c;
+        }
+    }
+    o += '"';
+}
+void json_double(std::string &o, double v) {
+    char b[40];
+    snprintf(b, sizeof(b), "%.17g", v);
+    o += b;
+    if (!strpbrk(b, ".eEn")) o += ".0";
+}
+// one edit object: keys from_length, sequence, to_length (only those set)
+void json_edit(std::string &o, bool &first, long long from_len, const char *seq, size_t seq_len, long long to_len) {
+    if (!first) o += ',';
+    first = false;
+    o += '{';
+    bool f2 = true;
+    if (from_len >= 0) { o += "\"from_length\":" + std::to_string(from_len); f2 = false; }
+    if (seq) { if (!f2) o += ','; o += "\"sequence\":"; json_string(o, seq, seq_len); f2 = false; }
+    if (to_len >= 0) { if (!f2) o += ','; o += "\"to_length\":" + std::to_string(to_len); }
+    o += '}';
+}
+}  // namespace
+
+size_t mgx_format_json(const mgx_results *res, uint64_t qi, const char *header, const char *query, size_t query_len,
+                       uint32_t k, char *buf, size_t buf_len) {
+    // the query as AlignmentResults keeps it (alignment.cpp:1348-1372): upper case, bytes < 0 -> 127; and its reverse
+    // complement (COMPL_TAB, reverse_complement.hpp:31-62)
+    std::string fwd(query_len, 0), rc(query_len, 0);
+    for (size_t i = 0; i < query_len; ++i) {
+        const int8_t c = (int8_t)query[i];
+        fwd[i] = c >= 0 ? (char)toupper(c) : (char)127;
+    }
+    for (size_t i = 0; i < query_len; ++i) {
+        const unsigned char c = (unsigned char)fwd[query_len - 1 - i];
+        static const char up[] = "TVGHEFCDIJMLKNOPQYSAABWXRZ";
+        rc[i] = (c >= 'A' && c <= 'Z') ? up[c - 'A'] : (c >= 'a' && c <= 'z') ? (char)(up[c - 'a'] + 32) : c == 96 ? (char)64 : (char)c;
+    }
+    std::string s;
+    const size_t hl = strlen(header);
+    if (res->aln_begin[qi] == res->aln_begin[qi + 1]) {
+        // Alignment().to_json: an empty alignment carries its name and an empty sequence
+        s += "{\"name\":"; json_string(s, header, hl); s += ",\"sequence\":\"\"}\n";
+    }
+    for (uint64_t ai = res->aln_begin[qi]; ai < res->aln_begin[qi + 1]; ++ai) {
+        const mgx_alignment &a = res->alignments[ai];
+        const bool secondary = ai != res->aln_begin[qi];
+        const std::string &full = a.orientation ? rc : fwd;
+        const char *qv = full.data() + a.clipping;                     // query_view_
+        const size_t qv_len = query_len - a.clipping - a.end_clipping;
+        const mgx_cigar_op *cg = res->cigar + a.cigar_begin;
+        // mgx_cigar_op.op: 0 clipped, 1 mismatch, 2 match, 3 deletion, 4 insertion, 5 node insertion (aligner_cigar.hpp:19-26)
+        static const char opc[] = "SX=DIG";
+        s += "{\"annotation\":{\"cigar\":\"";
+        for (uint32_t x = 0; x < a.n_cigar; ++x) s += std::to_string(cg[x].len) + opc[cg[x].op];
+        s += '"';
+        if (a.seq_len) { s += ",\"ref_sequence\":"; json_string(s, res->seqs + a.seq_begin, a.seq_len); }
+        s += "},\"identity\":";
+        json_double(s, qv_len ? (double)a.num_matches / (double)qv_len : 0.0);
+        if (secondary) s += ",\"is_secondary\":true";
+        s += ",\"name\":"; json_string(s, header, hl);
+        if (a.n_nodes) {
+            // path_json: mappings of the first node (may cover up to node_size characters), then one per further node
+            const uint64_t *nodes = res->nodes + a.nodes_begin;
+            uint32_t ci = 0;
+            if (a.n_cigar && cg[0].op == 0) ++ci;
+            uint64_t c_off = 0;
+            const char *qs = qv;
+            s += ",\"path\":{";
+            if (nodes[0] == nodes[a.n_nodes - 1]) s += "\"is_circular\":true,";
+            s += "\"length\":" + std::to_string(a.n_nodes) + ",\"mapping\":[";
+            long long rank = 1;
+            size_t cur = a.offset;
+            {
+                s += "{\"edit\":[";
+                bool first = true;
+                while (cur < k && ci < a.n_cigar) {
+                    size_t next_pos = std::min<size_t>(k, cur + (cg[ci].len - c_off));
+                    const size_t next_size = next_pos - cur;
+                    const uint32_t op = cg[ci].op;
+                    if (op == 0) { ++ci; c_off = 0; continue; }               // trailing clip
+                    if (op == 1) { json_edit(s, first, (long long)next_size, qs, next_size, (long long)next_size); qs += next_size; }
+                    else if (op == 4) { json_edit(s, first, -1, qs, next_size, (long long)next_size); qs += next_size; next_pos = cur; }
+                    else if (op == 3) json_edit(s, first, (long long)next_size, nullptr, 0, -1);
+                    else if (op == 2) { json_edit(s, first, (long long)next_size, nullptr, 0, (long long)next_size); qs += next_size; }
+                    c_off += next_size;
+                    cur = next_pos;
+                    if (c_off == cg[ci].len) { ++ci; c_off = 0; }
+                }
+                s += "],\"position\":{\"node_id\":" + std::to_string(nodes[0]);
+                if (a.offset) s += ",\"offset\":" + std::to_string(a.offset);
+                s += "},\"rank\":" + std::to_string(rank++) + "}";
+            }
+            for (uint32_t ni = 1; ni < a.n_nodes && ci < a.n_cigar; ++ni) {
+                s += ",{\"edit\":[";
+                bool first = true;
+                if (cg[ci].op == 4 || cg[ci].op == 0) {
+                    const size_t len = cg[ci].len - c_off;
+                    json_edit(s, first, -1, qs, len, (long long)len);
+                    qs += len;
+                    ++ci; c_off = 0;
+                }
+                if (ci < a.n_cigar) {
+                    const uint32_t op = cg[ci].op;
+                    if (op == 1) { json_edit(s, first, 1, qs, 1, 1); ++qs; }
+                    else if (op == 3) json_edit(s, first, 1, nullptr, 0, -1);
+                    else if (op == 2) { json_edit(s, first, 1, nullptr, 0, 1); ++qs; }
+                    if (++c_off == cg[ci].len) { c_off = 0; ++ci; }
+                }
+                s += "],\"position\":{\"node_id\":" + std::to_string(nodes[ni]) + ",\"offset\":" + std::to_string(k - 1);
+                s += "},\"rank\":" + std::to_string(rank++) + "}";
+            }
+            s += "],\"name\":\"\"}";
+        }
+        if (a.clipping) s += ",\"query_position\":" + std::to_string(a.clipping);
+        s += std::string(",\"read_mapped\":") + (qv_len ? "true" : "false");
+        if (a.orientation) s += ",\"read_on_reverse_strand\":true";
+        s += ",\"score\":" + std::to_string(a.score);
+        s += ",\"sequence\":"; json_string(s, full.data(), full.size());
+        if (a.clipping) s += ",\"soft_clipped\":true";
+        s += "}\n";
+    }
+    if (buf && buf_len) {
+        size_t nc = std::min(buf_len - 1, s.size());
+        memcpy(buf, s.data(), nc);
+        buf[nc] = 0;
+    }
+    return s.size();
+}
+
 } // extern "C"

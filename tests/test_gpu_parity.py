@@ -255,9 +255,18 @@ def test_cli_json_golden_node_ids_on_gpu(edit_distance, name):
     g = orc.Graph.build(cli["k"], read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"])), 0, False)
     reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
     cfg = json_golden_config(cli["k"], edit_distance)
-    got, status = aligner.Aligner(gpu_graph(g), cfg).align_batch([r[1] for r in reads])
+    A = aligner.Aligner(gpu_graph(g), cfg)
+    got, status = A.align_batch([r[1] for r in reads])
     assert all(s == 0 for s in status)
     check_against_json_golden(got, reads, name)
+    # ... and the --json lines themselves, byte for byte (mgx_format_json)
+    import ctypes as C
+    blob, offs = aligner.pack_queries([r[1] for r in reads])
+    res = capi.Results()
+    assert capi.lib().mgx_align_batch(A.h, blob, offs.ctypes.data, len(reads), 0, C.byref(res)) == 0
+    want = [line for line in open(os.path.join(HERE, "golden", name)) if line.strip()]
+    for i, line in enumerate(want):
+        assert capi.format_json(res, i, reads[i][0].lstrip("@").split()[0], reads[i][1], cli["k"]) == line
 
 
 def test_unsupported_and_bad_config_fail_loudly():

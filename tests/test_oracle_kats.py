@@ -227,3 +227,22 @@ def test_cli_json_golden_node_ids(edit_distance, name):
     reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
     cfg = json_golden_config(cli["k"], edit_distance)
     check_against_json_golden(orc.AlignRun(g, cfg, [r[1] for r in reads]).results(), reads, name)
+
+
+@pytest.mark.parametrize("edit_distance,name", [(False, "genome_MT1.align.json"), (True, "genome_MT1.align.edit.json")])
+def test_json_output_is_byte_identical_to_the_reference_goldens(edit_distance, name):
+    """`metagraph align --json` (cli/align.cpp:287-305, Alignment::to_json / path_json alignment.cpp:704-963, written by
+    jsoncpp with indentation ""): the product's formatter mgx_format_json (host code of libmgx.so; no GPU involved),
+    fed the oracle's alignments, reproduces the reference's golden files byte for byte."""
+    import ctypes as C
+    cli = KATS["cli"]
+    g = orc.Graph.build(cli["k"], read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"])), 0, False)
+    reads = read_fastq(os.path.join(HERE, "golden", cli["reads_fastq"]))
+    cfg = json_golden_config(cli["k"], edit_distance)
+    run = orc.AlignRun(g, cfg, [r[1] for r in reads])
+    view = capi.Results()
+    orc.L().orc_results_view(run.r, C.byref(view))
+    want = [line for line in open(os.path.join(HERE, "golden", name)) if line.strip()]
+    for i, line in enumerate(want):
+        header = reads[i][0].lstrip("@").split()[0]
+        assert capi.format_json(view, i, header, reads[i][1], cli["k"]) == line
