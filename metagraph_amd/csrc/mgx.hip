@@ -272,10 +272,11 @@ struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    int ensure(size_t n) {
+    // headroom: 1/8 on top for buffers that grow with the batch; none for the arena, which is sized from the free memory
+    int ensure(size_t n, bool exact = false) {
         if (n <= bytes) return MGX_OK;
         if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        size_t want = n + n / 8 + 256;
+        size_t want = exact ? n : n + n / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { p = nullptr; return fail(MGX_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
         bytes = want;
@@ -755,7 +756,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         // The hash tables of the convergence checker are cleared by generation tags that persist in each slice,
         // so a slice only needs zeroing when its layout (stride) changes or the buffer is new.
         const size_t before = A->arena.bytes;
-        if (int rc = A->arena.ensure(slots * stride)) return rc;
+        if (int rc = A->arena.ensure(slots * stride, true)) return rc;
         if (A->arena.bytes != before || A->arena_stride != stride) {
             HIP_TRY(hipMemsetAsync(A->arena.p, 0, A->arena.bytes, 0));
             A->arena_stride = stride;
