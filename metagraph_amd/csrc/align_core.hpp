@@ -179,15 +179,19 @@ struct BtIndex { int32_t score, neg_off_diag, neg_i, pos; };
 constexpr int MAX_ALT = MGX_MAX_ALT;
 constexpr int N_ALN = 4 * MAX_ALT;           // alignment buffers: extension results, their reversals, backward results, the best
 
-// One hash slot holds everything a lookup needs (key, generation tag, the entry's vector number and the query range
-// its vector covers): a probe is ONE 32-byte access instead of slot -> entry -> range.
-struct alignas(32) ConvSlot { uint64_t key; uint32_t gen, idx; int32_t start, len; uint32_t pad0, pad1; };
+// One hash slot holds everything a lookup needs (key, generation tag, where the entry's vector lives and the query range
+// it covers): a probe is ONE 32-byte access instead of slot -> entry -> range.
+// The vectors come from a POOL (like the reference's per-node std::vector<score_t>, which holds only [start, start+len)):
+// an entry owns `cap` words at `off`; position p of its range is pool[off + p - start].  A column appends its window to
+// the pool, so consecutive columns write consecutive memory; a range that outgrows its allocation moves to the pool's top.
+struct alignas(32) ConvSlot { uint64_t key; uint32_t gen, off; int32_t start, len; uint32_t cap, pad1; };
 
 struct ConvChecker {             // SeedFilteringExtender::conv_checker_ (extender hpp:75-76)
     ConvSlot *slots;
-    int32_t *vecs;               // entry e covers query positions [start, start + len) at vecs[e * L + pos]
+    int32_t *pool;               // DevLimits::conv_pool_words words
     uint32_t n_entries;
     uint32_t gen;
+    uint32_t pool_top;           // words handed out since conv_clear
 };
 
 struct SdustScratch {            // working set of is_low_complexity(); lives in LDS on the device
@@ -409,7 +413,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path);   // rev_*
     b += 16;                                            // gen_store
     b += 6 * align8((L + 16) * 4);                      // staging
-    b += 32 + 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8(ent * L * 4));
+    b += 32 + 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8((uint64_t)lim.conv_pool_words * 4));
     b += (uint64_t)lim.n_aln * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
     return (b + 63) & ~63ull;          // slices keep the 32-byte alignment of the hash slots and the 16-byte one of the cell records
 }
@@ -497,7 +501,7 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     for (int s = 0; s < 2; ++s) {
         p = (uint8_t *)(((uint64_t)p + 31) & ~31ull);
         w.ext[s].conv.slots = (ConvSlot *)take((uint64_t)lim.hash_size * sizeof(ConvSlot));
-        w.ext[s].conv.vecs = (int32_t *)take(ent * L * 4);
+        w.ext[s].conv.pool = (int32_t *)take((uint64_t)lim.conv_pool_words * 4);
     }
     for (int a = 0; a < N_ALN && a < (int)lim.n_aln; ++a) {
         w.aln[a].nodes = (uint32_t *)take((uint64_t)lim.max_path * 4);
@@ -1252,7 +1256,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
 // ------------------------------------------------------------------------------------------------
 // convergence checker (SeedFilteringExtender, A/aligner_extender_methods.cpp:66-207)
 // ------------------------------------------------------------------------------------------------
-MGX_DEV void conv_clear(ConvChecker &c) { ++c.gen; c.n_entries = 0; }
+MGX_DEV void conv_clear(ConvChecker &c) { ++c.gen; c.n_entries = 0; c.pool_top = 0; }
 
 MGX_DEV uint32_t conv_hash(uint64_t key, uint32_t mask) {
     // any mixing works (results do not depend on it): node ids of one extension are near-consecutive BOSS indices
@@ -1265,15 +1269,15 @@ MGX_DEV ConvSlot conv_load_slot(const ConvSlot *p) {
     const uint4 *q = reinterpret_cast<const uint4 *>(p);
     const uint4 a = gld(q), b = gld(q + 1);
     ConvSlot sl;
-    sl.key = ((uint64_t)a.y << 32) | a.x; sl.gen = a.z; sl.idx = a.w;
-    sl.start = (int32_t)b.x; sl.len = (int32_t)b.y; sl.pad0 = sl.pad1 = 0;
+    sl.key = ((uint64_t)a.y << 32) | a.x; sl.gen = a.z; sl.off = a.w;
+    sl.start = (int32_t)b.x; sl.len = (int32_t)b.y; sl.cap = b.z; sl.pad1 = 0;
     return sl;
 }
 MGX_DEV void conv_store_slot(ConvSlot *p, const ConvSlot &sl) {
     uint4 *q = reinterpret_cast<uint4 *>(p);
     uint4 a, b;
-    a.x = (uint32_t)sl.key; a.y = (uint32_t)(sl.key >> 32); a.z = sl.gen; a.w = sl.idx;
-    b.x = (uint32_t)sl.start; b.y = (uint32_t)sl.len; b.z = 0; b.w = 0;
+    a.x = (uint32_t)sl.key; a.y = (uint32_t)(sl.key >> 32); a.z = sl.gen; a.w = sl.off;
+    b.x = (uint32_t)sl.start; b.y = (uint32_t)sl.len; b.z = sl.cap; b.w = 0;
     gst(q, a); gst(q + 1, b);
 }
 // the range half of a slot only (key / generation / vector number unchanged)
@@ -1307,15 +1311,51 @@ MGX_DEV uint32_t conv_probe(const ConvChecker &c, uint32_t mask, uint64_t key, C
     }
 }
 
-// claim free slot `slot` for a new key; returns its vector number or -1 (capacity)
-MGX_DEV int32_t conv_insert(Wave &w, ConvChecker &c, uint32_t slot, uint64_t key, int32_t start, int32_t len) {
-    uint32_t cap = uni(MGX_PARAMS_OF(w).lim.max_columns + MGX_PARAMS_OF(w).lim.max_path);
+// vec[p] for query position p of entry sl
+MGX_DEV int32_t *conv_vec(const ConvChecker &c, const ConvSlot &sl) { return c.pool + (int64_t)sl.off - (int64_t)sl.start; }
+
+// claim free slot `slot` for a new key with a vector for [start, start + len); returns its pool offset or -1 (capacity)
+MGX_DEV int64_t conv_insert(Wave &w, ConvChecker &c, uint32_t slot, uint64_t key, int32_t start, int32_t len) {
+    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
+    uint32_t cap = uni(lim.max_columns + lim.max_path);
     const uint32_t ne = uni(c.n_entries);
-    if (ne >= cap || ne * 2 >= uni(MGX_PARAMS_OF(w).lim.hash_size)) { w.status = ST_CAPACITY; return -1; }
+    const uint32_t top = uni(c.pool_top);
+    if (ne >= cap || ne * 2 >= uni(lim.hash_size) || (uint64_t)top + (uint32_t)len > uni(lim.conv_pool_words)) { w.status = ST_CAPACITY; return -1; }
     c.n_entries = ne + 1;
-    ConvSlot sl; sl.key = key; sl.gen = c.gen; sl.idx = ne; sl.start = start; sl.len = len; sl.pad0 = sl.pad1 = 0;
+    c.pool_top = top + (uint32_t)len;
+    ConvSlot sl; sl.key = key; sl.gen = c.gen; sl.off = top; sl.start = start; sl.len = len; sl.cap = (uint32_t)len; sl.pad1 = 0;
     conv_store_slot(c.slots + slot, sl);
-    return (int32_t)ne;
+    return (int64_t)top;
+}
+
+// Make entry `sl` (at `slot`) cover [ns, ns + nl), a superset of its range: in place if its allocation reaches (an entry at
+// the pool's top grows there), else it moves to the pool's top (old values copied; newly covered positions are left for the
+// caller to write, as with the reference's vector::insert + fill).  Updates the slot and `sl`; false = out of pool.
+MGX_DEV bool conv_cover(Wave &w, ConvChecker &c, uint32_t slot, ConvSlot &sl, int32_t ns, int32_t nl) {
+    const uint32_t words = uni(MGX_PARAMS_OF(w).lim.conv_pool_words);
+    const uint32_t top = uni(c.pool_top);
+    if (ns == sl.start && (uint32_t)nl <= sl.cap) {
+        sl.len = nl;
+    } else if (ns == sl.start && sl.off + sl.cap == top) {
+        if ((uint64_t)sl.off + (uint32_t)nl > words) { w.status = ST_CAPACITY; return false; }
+        c.pool_top = sl.off + (uint32_t)nl;
+        sl.cap = (uint32_t)nl; sl.len = nl;
+    } else {
+        if ((uint64_t)top + (uint32_t)nl > words) { w.status = ST_CAPACITY; return false; }
+        const int32_t *src = c.pool + sl.off;
+        int32_t *dst = c.pool + top + (sl.start - ns);
+        for (int32_t base = 0; base < sl.len; base += WAVE) {
+            LV<int32_t> v;
+            FOR_LANES(l) { const int32_t j = base + l; v[l] = j < sl.len ? gld(src + j) : 0; }
+            FOR_LANES(l) { const int32_t j = base + l; if (j < sl.len) gst(dst + j, v[l]); }
+        }
+        c.pool_top = top + (uint32_t)nl;
+        sl.off = top; sl.cap = (uint32_t)nl; sl.start = ns; sl.len = nl;
+    }
+    sl.start = ns;
+    conv_store_slot(c.slots + slot, sl);
+    wave_sync();
+    return true;
 }
 
 // fill vec positions [a, b) with `val`
@@ -1352,41 +1392,44 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
     ConvSlot e;
     bool found;
     const uint32_t slot = conv_probe(E.conv, mask, key, e, found);
-    const int32_t Lq = (int32_t)uni(P.lim.Lmax);
     if (!found) {
-        const int32_t idx = uni(conv_insert(w, E.conv, slot, key, query_start, size));
-        if (idx < 0) return NINF;
-        int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
+        const int64_t off = conv_insert(w, E.conv, slot, key, query_start, size);
+        if (off < 0) return NINF;
+        int32_t *vec = E.conv.pool + off - query_start;
         for (int32_t base = 0; base < size; base += WAVE) {
             FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
         }
         wave_sync();
         return column_max();
     }
-    const int32_t idx = (int32_t)e.idx;
-    int32_t *vec = (int32_t *)uni((uint64_t)(E.conv.vecs + (uint64_t)idx * Lq));
     int32_t start = uni(e.start), len = uni(e.len);
     if (query_start + size <= start) {
+        if (!conv_cover(w, E.conv, slot, e, query_start, start + len - query_start)) return NINF;
+        int32_t *vec = conv_vec(E.conv, e);
         fill_range(vec, query_start + size, start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
             FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
         }
-        conv_store_range(E.conv.slots + slot, query_start, start + len - query_start);
         wave_sync();
         return column_max();
     }
     if (query_start >= start + len) {
+        if (!conv_cover(w, E.conv, slot, e, start, query_start + size - start)) return NINF;
+        int32_t *vec = conv_vec(E.conv, e);
         fill_range(vec, start + len, query_start, NINF);
         for (int32_t base = 0; base < size; base += WAVE) {
             FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
         }
-        conv_store_range(E.conv.slots + slot, start, query_start + size - start);
         wave_sync();
         return column_max();
     }
-    if (query_start < start) { fill_range(vec, query_start, start, NINF); len += start - query_start; start = query_start; }
-    if (query_start + size > start + len) { fill_range(vec, start + len, query_start + size, NINF); len = query_start + size - start; }
-    conv_store_range(E.conv.slots + slot, start, len);
+    {
+        const int32_t ns = imin(start, query_start), ne = imax(start + len, query_start + size);
+        if (ns != start || ne != start + len) { if (!conv_cover(w, E.conv, slot, e, ns, ne - ns)) return NINF; }
+    }
+    int32_t *vec = conv_vec(E.conv, e);
+    if (query_start < start) fill_range(vec, query_start, start, NINF);
+    if (query_start + size > start + len) fill_range(vec, start + len, query_start + size, NINF);
     wave_sync();
     int32_t max_changed = NINF;
     const double rel = P.cfg.rel_score_cutoff;
@@ -1422,7 +1465,7 @@ MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int
     if (!found) return true;
     int32_t pos = qlen + clipping - 1;
     if (pos < e.start || pos - e.start >= e.len) return true;
-    return gld(E.conv.vecs + (uint64_t)e.idx * P.lim.Lmax + pos) < score;
+    return gld(conv_vec(E.conv, e) + pos) < score;
 }
 
 // filter_nodes (:158-207); the key is the raw node id (no RCDBG offset), as in the reference
@@ -1435,30 +1478,20 @@ MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t qu
     ConvSlot e;
     bool found;
     const uint32_t slot = conv_probe(E.conv, P.lim.hash_size - 1, (uint64_t)node, e, found);
-    const int32_t Lq = (int32_t)P.lim.Lmax;
     if (!found) {
-        const int32_t idx = conv_insert(w, E.conv, slot, (uint64_t)node, query_start, size);
-        if (idx < 0) return;
-        fill_range(E.conv.vecs + (uint64_t)idx * Lq, query_start, query_end, mscore);
+        const int64_t off = conv_insert(w, E.conv, slot, (uint64_t)node, query_start, size);
+        if (off < 0) return;
+        fill_range(E.conv.pool + off - query_start, query_start, query_end, mscore);
         wave_sync();
         return;
     }
-    int32_t *vec = E.conv.vecs + (uint64_t)e.idx * Lq;
-    int32_t start = e.start, len = e.len;
-    if (query_start + size <= start) {
-        fill_range(vec, query_start + size, start, NINF);
-        fill_range(vec, query_start, query_start + size, mscore);
-        len = start + len - query_start; start = query_start;
-    } else if (query_start >= start + len) {
-        fill_range(vec, start + len, query_start, NINF);
-        fill_range(vec, query_start, query_end, mscore);
-        len = query_start + size - start;
-    } else {
-        if (query_start < start) { fill_range(vec, query_start, start, NINF); len += start - query_start; start = query_start; }
-        if (query_start + size > start + len) { fill_range(vec, start + len, query_start + size, NINF); len = query_start + size - start; }
-        fill_range(vec, query_start, query_end, mscore);      // mscore is the maximum, so max(v, mscore) == mscore
-    }
-    conv_store_range(E.conv.slots + slot, start, len);
+    const int32_t start = e.start, len = e.len;
+    const int32_t ns = imin(start, query_start), ne = imax(start + len, query_end);
+    if (ns != start || ne != start + len) { if (!conv_cover(w, E.conv, slot, e, ns, ne - ns)) return; }
+    int32_t *vec = conv_vec(E.conv, e);
+    if (query_end <= start) fill_range(vec, query_end, start, NINF);                   // gap below the old range
+    else if (query_start >= start + len) fill_range(vec, start + len, query_start, NINF);   // gap above it
+    fill_range(vec, query_start, query_end, mscore);      // mscore is the maximum, so max(v, mscore) == mscore
     wave_sync();
 }
 
@@ -2193,7 +2226,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     const uint32_t cmask = x.hash_mask;
     const uint32_t chash = conv_hash(ckey, cmask);
     ConvSlot csl;
-    csl.key = 0; csl.gen = 0; csl.idx = 0; csl.start = 0; csl.len = 0; csl.pad0 = csl.pad1 = 0;
+    csl.key = 0; csl.gen = 0; csl.off = 0; csl.start = 0; csl.len = 0; csl.cap = 0; csl.pad1 = 0;
     if (next) csl = conv_load_slot(E.conv.slots + chash);
     CH_T(0)
     // Expansion of the child's own node one column ahead (forward graph only): if this child continues the chain and
@@ -2438,7 +2471,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
                 cv_mode = CV_INSERT;
             } else {
                 if (cv_slot != chash) csl = conv_load_slot(E.conv.slots + cv_slot);      // found by a later probe step
-                cv_vec = E.conv.vecs + (uint64_t)csl.idx * x.Lq;
+                cv_vec = conv_vec(E.conv, csl);
                 cv_vstart = csl.start; cv_vlen = csl.len;
                 if (query_start + cn <= cv_vstart) cv_mode = CV_BELOW;
                 else if (query_start >= cv_vstart + cv_vlen) cv_mode = CV_ABOVE;
@@ -2559,19 +2592,20 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     x.tsize = my_idx + 1;
     // update_seed_filter, the stores
     if (cv_mode == CV_INSERT) {
-        const int32_t vi = conv_insert(w, E.conv, cv_slot, ckey, query_start, cn);
-        if (vi < 0) return FR_ERROR;
-        cv_vec = E.conv.vecs + (uint64_t)vi * x.Lq;
-    } else if (cv_mode == CV_BELOW) {
-        fill_range(cv_vec, query_start + cn, cv_vstart, NINF);
-        conv_store_range(E.conv.slots + cv_slot, query_start, cv_vstart + cv_vlen - query_start);
-    } else if (cv_mode == CV_ABOVE) {
-        fill_range(cv_vec, cv_vstart + cv_vlen, query_start, NINF);
-        conv_store_range(E.conv.slots + cv_slot, cv_vstart, query_start + cn - cv_vstart);
-    } else if (cv_mode == CV_MERGE) {
+        const int64_t off = conv_insert(w, E.conv, cv_slot, ckey, query_start, cn);
+        if (off < 0) return FR_ERROR;
+        cv_vec = E.conv.pool + off - query_start;
+    } else if (cv_mode != CV_NONE) {
+        // a node seen before: its vector grows to the union of the ranges (moving to the pool's top if it has to), the gap
+        // between disjoint ranges reads ninf
         const int32_t nstart = imin(cv_vstart, query_start);
         const int32_t nend = imax(cv_vstart + cv_vlen, query_start + cn);
-        if (nstart != cv_vstart || nend != cv_vstart + cv_vlen) conv_store_range(E.conv.slots + cv_slot, nstart, nend - nstart);
+        if (nstart != cv_vstart || nend != cv_vstart + cv_vlen) {
+            if (!conv_cover(w, E.conv, cv_slot, csl, nstart, nend - nstart)) return FR_ERROR;
+            cv_vec = conv_vec(E.conv, csl);
+        }
+        if (cv_mode == CV_BELOW) fill_range(cv_vec, query_start + cn, cv_vstart, NINF);
+        else if (cv_mode == CV_ABOVE) fill_range(cv_vec, cv_vstart + cv_vlen, query_start, NINF);
     }
     if (cv_mode != CV_NONE) {
         const bool all = cv_mode != CV_MERGE;              // a new or disjoint range takes the column as it is

@@ -31,6 +31,7 @@ struct DevLimits {
     uint32_t cell_words;     // int32 words of S/E/F storage per wave
     uint32_t hash_size;      // power of two
     uint32_t n_aln;          // alignment buffers per read: 4 * num_alternative_paths
+    uint32_t conv_pool_words;    // int32 words of convergence vectors per extender (pool; see ConvSlot)
 };
 
 // per-read result header; variable-length parts live in the output stream

@@ -88,6 +88,11 @@ inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lm
     l.cell_words = (uint32_t)std::min<uint64_t>(cw, 0xFFFFFF00ull);
     l.hash_size = next_pow2(2ull * ((uint64_t)l.max_columns + l.max_path) + 2);
     l.n_aln = 4 * (uint32_t)cfg.num_alternative_paths;
+    // Convergence vectors (one per visited node, holding only the query range its columns touched) come from a pool sized by
+    // the cell budget: a column of w cells appends w words, a range that outgrows its allocation is re-appended.  Half the
+    // cell words per extender never binds on the test and bench workloads; a read that runs out gets MGX_ERR_CAPACITY
+    // and the adapter's retry (doubled cell_arena_bytes) doubles the pool with it.
+    l.conv_pool_words = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, (uint64_t)l.cell_words / 2 + 16ull * l.Lmax + 1024);
     return MGX_OK;
 }
 
