@@ -207,6 +207,9 @@ __global__ void __launch_bounds__(256, MGX_MAP_PACKED_WAVES) k_map_packed(DevGra
 // WPS = waves per SIMD the register allocation targets: 4 for the kernels that extend; the seeding-only instantiation of
 // short-read batches runs at 8 (64 VGPRs, seeding tables mostly in the arena) — a gather kernel gains more from the extra
 // wavefronts than it loses to spills (measured 112 vs 117 ms per 2 M reads)
+#ifndef MGX_SEED_WPS
+#define MGX_SEED_WPS 8          // waves per SIMD of the short-read seeding instantiation
+#endif
 template <int PHASE, int WPS = MGX_ALIGN_WAVES_PER_SIMD>
 __global__ void __launch_bounds__(64, WPS) k_align(AlignParams P, uint32_t lds_bytes) {
     const uint32_t slot = blockIdx.x;
@@ -853,14 +856,16 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     };
     A->split_ran = split;
     if (split) {
-        if (l.Lmax <= 192 && slots >= (uint64_t)prop.multiProcessorCount * 4 * 8) {
+        if (getenv("MGX_SEED_GROUPS")) {                 // A/B probe (needs a -DMGX_GRP_SEED_PROBE build of mgx_grp.hip)
+            if (int rc = launch_groups(PH_SEED)) return fail(MGX_ERR_NO_DEVICE, "group seeding kernel: %d", rc);
+        } else if (l.Lmax <= 192 && slots >= (uint64_t)prop.multiProcessorCount * 4 * 8) {
             // (measured on 150-bp reads: the kernel is 10 % faster with 4944 B of LDS per wavefront than with 5056 B, although
             // both leave room for 32 wavefronts per CU; hence the wider margin)
-            const uint32_t budget8 = (160u * 1024u) / (4 * 8) - static_lds - 192u;
+            const uint32_t budget8 = (160u * 1024u) / (4 * MGX_SEED_WPS) - static_lds - 192u;
             uint32_t lds8 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), budget8) & ~15u;
             if (const char *e = getenv("MGX_SEED_LDS_CAP")) lds8 = std::min<uint32_t>(lds8, (uint32_t)atoi(e)) & ~15u;     // tuning probe
             if (getenv("MGX_SEED_LDS_PRINT")) fprintf(stderr, "k_seed: static_lds %u budget8 %u lds8 %u (fast_lds_bytes %u)\n", static_lds, budget8, lds8, fast_lds_bytes(l.Lmax));
-            k_align<PH_SEED, 8><<<(uint32_t)prop.multiProcessorCount * 4 * 8, 64, lds8>>>(P, lds8);
+            k_align<PH_SEED, MGX_SEED_WPS><<<(uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, 64, lds8>>>(P, lds8);
         } else {
             k_align<PH_SEED><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
         }

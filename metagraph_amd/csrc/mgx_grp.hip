@@ -87,6 +87,12 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
 extern "C" int MGX_SUFFIX(MGX_CAT(mgx_launch_align_grp, MGX_GROUP))(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream) {
     const AlignParams &P = *static_cast<const AlignParams *>(params);
     uint32_t blocks = (n_groups + GROUPS_PER_WAVEFRONT - 1) / GROUPS_PER_WAVEFRONT;
+#if defined(MGX_GRP_SEED_PROBE) && !defined(MGX_ALT_BUILD)
+    if (phase == PH_SEED) {          // A/B probe: the seeding half with 8 lanes per read
+        MGX_SUFFIX(MGX_CAT(k_align_grp, MGX_GROUP))<PH_SEED><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
+        return (int)hipGetLastError();
+    }
+#endif
     if (phase != PH_EXTEND) return (int)hipErrorInvalidValue;      // only the extension half is instantiated for sub-wave groups
     MGX_SUFFIX(MGX_CAT(k_align_grp, MGX_GROUP))<PH_EXTEND><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
     return (int)hipGetLastError();
