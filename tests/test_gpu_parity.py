@@ -148,6 +148,19 @@ def test_baseline_config0_transcripts_k12(pipeline):
     assert sum(1 for r, q in zip(got, seqs) if r and r[0]["cigar"] == "%d=" % len(q)) >= 95
 
 
+def test_baseline_config0_transcripts_1000_k12():
+    """BASELINE.json configs[0] in full: `metagraph align` of tests/data/transcripts_1000.fa (1000 transcripts, 1.49 Mbp,
+    up to 11.7 kbp) against its own k = 12 DBGSuccinct graph, CLI defaults — every alignment equal to the oracle's."""
+    from test_oracle_kats import read_fasta, HERE
+    seqs = read_fasta(os.path.join(HERE, "golden", "transcripts_1000.fa"))
+    g = orc.Graph.build(12, seqs, 0, False)
+    cfg = capi.config_cli(12)
+    want = orc.AlignRun(g, cfg, seqs, threads=os.cpu_count() or 8, validate=False).results()
+    got, status = aligner.Aligner(gpu_graph(g), cfg).align_batch(seqs)
+    assert all(s == 0 for s in status)
+    assert got == want
+
+
 @pytest.mark.parametrize("min_seed,per_locus", [(15, 1000), (13, 2), (9, 1)])
 def test_sub_k_seeding_variants_on_gpu(min_seed, per_locus):
     """BASELINE configs[4] flavour (`--align-min-seed-length 15` and shorter, per-locus seed cap) on a repetitive

@@ -1,3 +1,4 @@
+import os
 """Known-answer tests of the reference for DBGSuccinct::call_nodes_with_suffix_matching_longest_prefix
 (M/tests/graph/succinct/test_dbg_succinct.cpp:162-527), transcribed as data and run against the oracle.
 This is the primitive behind the seeder's sub-k seeds (SURVEY 8a rows a12/a13)."""
@@ -193,3 +194,11 @@ def test_map_to_nodes_whole_sequence_equals_per_kmer(k):
     single = [m[0][0] for m in orc.AlignRun(g, cfg, kmers).mapping()]
     assert whole == single
     assert whole[0] == 0 and whole[1] == 0 and all(v != 0 for v in whole[2:])
+
+
+def test_build_stats_of_transcripts_1000_k20():
+    """integration_tests/test_build.py:30-48: `metagraph build --mask-dummy -k 20` on tests/data/transcripts_1000.fa reports
+    591997 nodes (k); the fixture builder's masked graph must hold exactly as many real k-mers."""
+    from test_oracle_kats import read_fasta, HERE
+    g = orc.Graph.build(20, read_fasta(os.path.join(HERE, "golden", "transcripts_1000.fa")), 0, True)
+    assert g.num_nodes == 591997
