@@ -3394,8 +3394,10 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
                 DevAln &p2 = w.aln[2 * n_alt + b];
                 if (reverse_complement_aln(w, p2)) {
                     int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
+                    const uint64_t tf0 = cycle_clock();
                     for (int32_t x = 0; x < p2.n_nodes; ++x)
                         filter_nodes(w, F, p2.nodes[x], clip, w.L - eclip);
+                    w.cyc[6] += cycle_clock() - tf0;                      // (timer 6: seed pick-up + filter_nodes)
                     if (w.status != ST_OK) return;
                     add_alignment(w, p2);
                 }
@@ -3406,12 +3408,18 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
                 if (!check_seed(w, B, o.nodes[o.n_nodes - 1], o.qlen, aln_clipping(o), o.score)) rev_alive[r2] = false;
             }
         }
-        for (int32_t j = i + 1; j < n; ++j) {
-            if (!w.alive[s][j]) continue;
-            DevSeed sj = w.seeds[s][j];
-            uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
-            SeedRef rj = seedref_from_seed(w, s, j, nullptr);
-            if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[s][j] = 0;   // filter_seed (:105-108)
+        // filter_seed (:105-108) for every later seed: independent look-ups into the convergence table, one seed per lane
+        // (reads of a pan-genome carry ~100 sub-k seeds: one after the other this loop was two thirds of the kernel there)
+        for (int32_t base = i + 1; base < n; base += WAVE) {
+            FOR_LANES(l) {
+                const int32_t j = base + l;
+                if (j < n && w.alive[s][j]) {
+                    DevSeed sj = w.seeds[s][j];
+                    uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
+                    SeedRef rj = seedref_from_seed(w, s, j, nullptr);
+                    if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[s][j] = 0;
+                }
+            }
         }
         wave_sync();
     }
@@ -3440,12 +3448,16 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
             for (int e = 0; e < n_fwd; ++e) add_alignment(w, w.aln[e]);
         }
         if (w.status != ST_OK) return;
-        for (int32_t j = i + 1; j < n; ++j) {
-            if (!w.alive[0][j]) continue;
-            DevSeed sj = w.seeds[0][j];
-            uint32_t last_node = sj.offset == 0 ? w.nodes[0][sj.clipping + sj.n_nodes - 1] : sj.node;
-            SeedRef rj = seedref_from_seed(w, 0, j, nullptr);
-            if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[0][j] = 0;
+        for (int32_t base = i + 1; base < n; base += WAVE) {
+            FOR_LANES(l) {
+                const int32_t j = base + l;
+                if (j < n && w.alive[0][j]) {
+                    DevSeed sj = w.seeds[0][j];
+                    uint32_t last_node = sj.offset == 0 ? w.nodes[0][sj.clipping + sj.n_nodes - 1] : sj.node;
+                    SeedRef rj = seedref_from_seed(w, 0, j, nullptr);
+                    if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[0][j] = 0;
+                }
+            }
         }
         wave_sync();
         (void)P;

@@ -85,7 +85,15 @@ def main():
            "reads_per_s": round(args.reads / dt, 1), "ms": round(1000 * dt, 1),
            "kernel_ms": {"k_map": round(st["seed_kernel_ms"], 1), "k_seed": round(st["seeding_ms"], 1), "k_extend": round(st["extend_ms"], 1)},
            "capacity_errors": int(st["n_capacity_errors"]), "seeds_per_read": round(st["n_seeds"] / args.reads, 2),
-           "columns_per_read": round(st["n_columns"] / args.reads, 1)}
+           "columns_per_read": round(st["n_columns"] / args.reads, 1),
+           "extensions_per_read": round(st["n_extensions"] / args.reads, 2),
+           "chain_column_fraction": round(st["n_fast_columns"] / max(1, st["n_columns"]), 3),
+           "k_extend_group_time_share": dict(zip(["prepare", "seed_pickup", "extend", "backtrack", "driver", "output"],
+                                                 [round(c / max(1, sum(st["phase_cycles"][:6])), 3) for c in st["phase_cycles"][:6]])),
+           "driver_detail_share": {"seedref+filter_nodes": round(st["phase_cycles"][6] / max(1, sum(st["phase_cycles"][:6])), 3),
+                                   "reverse+aggregate": round(st["phase_cycles"][7] / max(1, sum(st["phase_cycles"][:6])), 3)},
+           "extend_share": dict(zip(["pop", "general_step", "chain_step"],
+                                    [round(c / max(1, st["phase_cycles"][2]), 3) for c in st["extend_cycles"][:3]]))}
     if args.sample > 0:
         import orc
         orc.use_library(orc.build_fast())
