@@ -341,7 +341,8 @@ struct Wave {
     DevAln aln[N_ALN];           // [0, A): extension results, [A, 2A): reversed seeds of the backward pass, [2A, 3A): backward
                                  // extension results, [3A, 4A): the aggregator's queue (A = num_alternative_paths <= MAX_ALT)
     int32_t have_best;           // alignments in the aggregator's queue
-    int32_t seeds_done;          // seeds whose extension ran for this read (two-pass extension)
+    int32_t seeds_done;          // seeds whose extension ran for this read in this pass (multi-pass extension)
+    int32_t resume_phase, resume_i, no_limit;   // where this pass (re)starts: strand call 0 / 1, seed index; limit lifted
     LineCtr ctr;                 // BOSS block loads (lane-parallel regions add their wave sums)
     ExtendResult er;             // result of the last extend(); noinline callees must not write through
                                  // pointers into the caller's private frame, so outputs live here
@@ -416,6 +417,12 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 32 + 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8((uint64_t)lim.conv_pool_words * 4));
     b += (uint64_t)lim.n_aln * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
     return (b + 63) & ~63ull;          // slices keep the 32-byte alignment of the hash slots and the 16-byte one of the cell records
+}
+
+// bytes of one resume record of the multi-pass extension (AlignParams::resume_*; layout: resume_save)
+MGX_HD uint32_t resume_aln_bytes(const DevLimits &lim) { return 48u + 2u * (uint32_t)align8((uint64_t)lim.max_path * 4) + (uint32_t)align8(lim.max_path); }
+MGX_HD uint32_t resume_rec_bytes(const DevLimits &lim, uint32_t n_alt) {
+    return 64u + (uint32_t)align8(2ull * lim.max_seeds) + n_alt * resume_aln_bytes(lim);
 }
 
 // Carve the wave's workspace.  Small, latency-critical scalar arrays go to LDS (`lds`, `lds_bytes`)
@@ -3324,6 +3331,83 @@ MGX_DEV int32_t min_path_score_now(const Wave &w) {          // get_min_path_sco
     return imax(MGX_PARAMS_OF(w).cfg.min_path_score, global_cutoff(w));
 }
 
+// ---- resume records of the multi-pass extension (AlignParams::resume_*) ----
+// a DevAln whose arrays live in a record
+MGX_DEV DevAln resume_aln_view(const DevLimits &lim, uint8_t *p) {
+    DevAln a;
+    a.nodes = (uint32_t *)(p + 48);
+    a.cigar = (uint32_t *)(p + 48 + align8((uint64_t)lim.max_path * 4));
+    a.seq = p + 48 + 2 * align8((uint64_t)lim.max_path * 4);
+    a.n_nodes = a.n_cigar = a.seq_len = 0; a.score = a.offset = a.qbegin = a.qlen = a.orientation = a.extra_score = 0;
+    return a;
+}
+MGX_DEV void resume_save(Wave &w, uint8_t *rec) {
+    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
+    const int n_alt = n_alt_of(w);
+    int32_t *h = (int32_t *)rec;
+    FOR_LANES(l) {
+        if (l == 0) {
+            h[0] = w.resume_phase; h[1] = w.resume_i; h[2] = w.have_best;
+            h[3] = (int32_t)w.ext[0].table_cap; h[4] = (int32_t)w.ext[1].table_cap;
+            h[5] = (int32_t)w.n_extensions; h[6] = (int32_t)w.n_columns; h[7] = (int32_t)w.n_fast_columns;
+        }
+    }
+    uint8_t *al = rec + 64;
+    for (int s = 0; s < 2; ++s) {
+        const int32_t n = w.n_seeds[s];
+        for (int32_t base = 0; base < n; base += WAVE) {
+            FOR_LANES(l) { const int32_t x = base + l; if (x < n) al[(uint32_t)s * lim.max_seeds + x] = w.alive[s][x]; }
+        }
+    }
+    uint8_t *ap = rec + 64 + align8(2ull * lim.max_seeds);
+    for (int t = 0; t < w.have_best; ++t) {
+        uint8_t *p = ap + (uint32_t)t * resume_aln_bytes(lim);
+        DevAln v = resume_aln_view(lim, p);
+        copy_aln(v, w.aln[Q0 + t]);
+        int32_t *sc = (int32_t *)p;
+        FOR_LANES(l) {
+            if (l == 0) {
+                sc[0] = v.n_nodes; sc[1] = v.n_cigar; sc[2] = v.seq_len; sc[3] = v.score; sc[4] = v.offset;
+                sc[5] = v.qbegin; sc[6] = v.qlen; sc[7] = v.orientation; sc[8] = v.extra_score;
+            }
+        }
+    }
+    wave_sync();
+    (void)n_alt;
+}
+MGX_DEV void resume_load(Wave &w, const uint8_t *rec) {
+    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
+    const int32_t *h = (const int32_t *)rec;
+    w.resume_phase = uni(h[0]); w.resume_i = uni(h[1]); w.have_best = uni(h[2]);
+    w.ext[0].table_cap = (uint32_t)uni(h[3]); w.ext[1].table_cap = (uint32_t)uni(h[4]);
+    w.n_extensions = (uint32_t)uni(h[5]); w.n_columns = (uint32_t)uni(h[6]); w.n_fast_columns = (uint32_t)uni(h[7]);
+    const uint8_t *al = rec + 64;
+    for (int s = 0; s < 2; ++s) {
+        const int32_t n = w.n_seeds[s];
+        for (int32_t base = 0; base < n; base += WAVE) {
+            FOR_LANES(l) { const int32_t x = base + l; if (x < n) w.alive[s][x] = al[(uint32_t)s * lim.max_seeds + x]; }
+        }
+    }
+    const uint8_t *ap = rec + 64 + align8(2ull * lim.max_seeds);
+    for (int t = 0; t < w.have_best; ++t) {
+        uint8_t *p = const_cast<uint8_t *>(ap) + (uint32_t)t * resume_aln_bytes(lim);
+        DevAln v = resume_aln_view(lim, p);
+        const int32_t *sc = (const int32_t *)p;
+        v.n_nodes = uni(sc[0]); v.n_cigar = uni(sc[1]); v.seq_len = uni(sc[2]); v.score = uni(sc[3]); v.offset = uni(sc[4]);
+        v.qbegin = uni(sc[5]); v.qlen = uni(sc[6]); v.orientation = uni(sc[7]); v.extra_score = uni(sc[8]);
+        copy_aln(w.aln[Q0 + t], v);
+    }
+    wave_sync();
+}
+// a read that would start another seed beyond this pass's limit: true = stop here (status ST_RETRY, resume point recorded)
+MGX_DEV bool pass_limit_reached(Wave &w, int32_t next_i) {
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    if (!P.seed_limit || w.no_limit || w.seeds_done < (int32_t)P.seed_limit) return false;
+    w.resume_i = next_i;
+    w.status = ST_RETRY;
+    return true;
+}
+
 // aln_both (:657-736): seeds of strand s; fwd extender = ext[s] on the graph, bwd extender = ext[1 - s] on RCDBG
 MGX_NI_G4 void aln_both(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
@@ -3333,9 +3417,11 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
     F.rc_view = 0;
     B.rc_view = 1;
     const int32_t n = w.n_seeds[s];
-    for (int32_t i = 0; i < n; ++i) {
+    const int32_t i0 = w.resume_i;
+    w.resume_i = 0;
+    for (int32_t i = i0; i < n; ++i) {
         if (!w.alive[s][i]) continue;
-        if (P.seed_limit && w.seeds_done >= (int32_t)P.seed_limit) { w.status = ST_RETRY; return; }
+        if (pass_limit_reached(w, i)) return;
         ++w.seeds_done;
         const uint64_t tp0 = cycle_clock();
         SeedRef seed = seedref_from_seed(w, s, i, nullptr);
@@ -3432,9 +3518,11 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
     ExtenderState &F = w.ext[0];
     F.rc_view = 0;
     const int32_t n = w.n_seeds[0];
-    for (int32_t i = 0; i < n; ++i) {
+    const int32_t i0 = w.resume_i;
+    w.resume_i = 0;
+    for (int32_t i = i0; i < n; ++i) {
         if (!w.alive[0][i]) continue;
-        if (P.seed_limit && w.seeds_done >= (int32_t)P.seed_limit) { w.status = ST_RETRY; return; }
+        if (pass_limit_reached(w, i)) return;
         ++w.seeds_done;
         SeedRef seed = seedref_from_seed(w, 0, i, nullptr);
         int32_t mps = imax(0, min_path_score_now(w));
@@ -3485,7 +3573,8 @@ MGX_DEV uint32_t predicted_work(const Wave &w) {
 // pipeline: PH_SEED stops after build_seeders and publishes the seeds, PH_EXTEND picks them up.
 template <int PHASE = PH_BOTH>
 MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t slot, KernelStats *stats_accum,
-                        SdustScratch *sd, const int8_t *sm_rows, uint8_t *lds, uint32_t lds_bytes) {
+                        SdustScratch *sd, const int8_t *sm_rows, uint8_t *lds, uint32_t lds_bytes,
+                        const uint8_t *resume_rec = nullptr) {
     w.P = &P;
     w.sm_rows = sm_rows;
     carve(w, P, P.arena + (uint64_t)slot * P.arena_stride, lds, lds_bytes);
@@ -3495,6 +3584,8 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     w.status = ST_OK;
     w.have_best = 0;
     w.seeds_done = 0;
+    w.resume_phase = 0; w.resume_i = 0; w.no_limit = 0;
+    int64_t retry_pos = -1;              // this read's position in the retry list once its record is written
     w.ctr.rank_lines = w.ctr.select_lines = w.ctr.bit_lines = 0;
     w.n_columns = w.n_extensions = w.n_fast_columns = 0;
     const uint64_t nb = P.node_begin[read];
@@ -3614,16 +3705,54 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         const uint64_t tdrv = cycle_clock();
 #ifndef MGX_NO_EXTEND
         if ((PHASE & PH_EXTEND) && w.status == ST_OK) {
-            if (have_rc) {
-                // align_both_directions (:738-755)
-                uint32_t fm = w.num_matching[0], bm = w.num_matching[1];
-                // one call site for both orders: groups of a wavefront that start on different strands stay converged
-                const int first = fm >= bm ? 0 : 1;
-                const uint32_t m_first = first ? bm : fm, m_second = first ? fm : bm;
-                aln_both(w, first);
-                if (w.status == ST_OK && (double)m_second >= (double)m_first * P.cfg.rel_score_cutoff) aln_both(w, 1 - first);
-            } else {
-                align_core_fwd(w);
+            if (resume_rec) resume_load(w, resume_rec);          // a later pass: the aggregator, the live seeds, where it stopped
+            for (;;) {
+                if (have_rc) {
+                    // align_both_directions (:738-755)
+                    uint32_t fm = w.num_matching[0], bm = w.num_matching[1];
+                    // one call site for both orders and both passes: groups of a wavefront that are on different strands
+                    // stay converged
+                    const int first = fm >= bm ? 0 : 1;
+                    const uint32_t m_first = first ? bm : fm, m_second = first ? fm : bm;
+                    for (int ph = w.resume_phase; ph < 2 && w.status == ST_OK; ++ph) {
+                        if (ph == 1 && !((double)m_second >= (double)m_first * P.cfg.rel_score_cutoff)) break;
+                        if (ph != w.resume_phase) w.resume_i = 0;
+                        w.resume_phase = ph;
+                        aln_both(w, ph == 0 ? first : 1 - first);
+                    }
+                } else {
+                    align_core_fwd(w);
+                }
+                if (w.status != ST_RETRY || !P.resume_out) break;
+                // stopped by the pass's seed limit: take a retry position; without room for a record the read just goes on
+                LV<uint64_t> pv;
+                FOR_LANES(l) {
+                    pv[l] = 0;
+                    if (l == 0) {
+#if MGX_WAVE_EMU
+                        pv[l] = (*P.retry_count)++;
+#else
+                        pv[l] = atomicAdd(P.retry_count, 1ull);
+#endif
+                    }
+                }
+                const uint64_t pos = wave_bcast(pv, 0);
+                if (pos >= P.resume_cap) { w.no_limit = 1; w.status = ST_OK; continue; }
+                retry_pos = (int64_t)pos;
+                resume_save(w, P.resume_out + pos * P.resume_rec_bytes);
+                // work key of the next pass: this read's next live seed (same prediction as the seeding kernel's)
+                uint32_t key = 1;
+                {
+                    const int sidx = w.resume_phase == 0 ? (w.num_matching[0] >= w.num_matching[1] ? 0 : 1)
+                                                         : (w.num_matching[0] >= w.num_matching[1] ? 1 : 0);
+                    const int ss = have_rc ? sidx : 0;
+                    if (w.resume_i < w.n_seeds[ss]) {
+                        const int32_t clip = w.seeds[ss][w.resume_i].clipping;
+                        key = 1u + (uint32_t)imin(4094, (w.L - clip) + (clip > 0 ? w.L : 0));
+                    }
+                }
+                FOR_LANES(l) { if (l == 0) { P.retry_list[pos] = (uint32_t)read; P.retry_key[pos] = key; } }
+                break;
             }
         }
 #else
@@ -3657,9 +3786,10 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         return;
     }
     if (w.status == ST_RETRY) {
-        // pass 1 of the two-pass extension: this read goes on to another seed; hand it to pass 2 untouched
+        // this read goes on to another seed in the next pass: with a resume record (written above) or, without records,
+        // untouched and from scratch
         FOR_LANES(l) {
-            if (l == 0) {
+            if (l == 0 && retry_pos < 0) {
 #if MGX_WAVE_EMU
                 P.retry_list[(*P.retry_count)++] = (uint32_t)read;
 #else

@@ -110,6 +110,19 @@ struct AlignParams {
     uint32_t *retry_list;
     unsigned long long *retry_count;
     const unsigned long long *n_items_ptr;   // null: n_reads items
+    // Multi-pass extension with resume records: a pass extends at most seed_limit seeds per read; a read with live seeds
+    // left writes what outlives a seed — aggregator queue, live-seed flags, extender capacities, counters, where it stopped
+    // — into resume_out[its retry position] and a work key for its next seed into retry_key; the next pass sorts the
+    // positions by key and resumes them (order[] then holds retry positions: read = resume_reads[pos], record =
+    // resume_in + pos * resume_rec_bytes).  Convergence tables never outlive a seed, so nothing else crosses passes.
+    // resume_out == null keeps the from-scratch behaviour above.  A read whose position is >= resume_cap simply goes on
+    // without a limit in its current pass.
+    const uint8_t *resume_in;
+    const uint32_t *resume_reads;
+    uint8_t *resume_out;
+    uint32_t *retry_key;
+    uint32_t resume_rec_bytes, resume_cap;
+    uint64_t n_items;                        // items of this launch (0: n_items_ptr / n_reads)
     uint32_t no_fast;                    // A/B and test switch: every column through the general (staging buffer) path
     uint32_t ablate;                     // timing probes only (results become WRONG): bit 0 = no convergence table in the chain
                                          // step, bit 1 = no cell records / column metadata stores, bit 2 = no backtrack

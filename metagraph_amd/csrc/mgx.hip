@@ -325,6 +325,8 @@ struct mgx_aligner {
     bool have_rng = false;
     DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, d_stats_map, scan_tmp, dbg_seeds;
     DevBuf seed_hdr, seed_stream, work_key, work_key_sorted, order_in, order, sort_tmp, retry_list;    // split pipeline
+    DevBuf resume_pool[2], retry_list2, retry_key[2];      // multi-pass extension: resume records, retry lists and keys (ping-pong)
+    uint32_t n_passes = 0;
     DevLimits lim;
     uint64_t n_reads = 0, total_kmers = 0;
     uint32_t n_slots = 0;
@@ -877,22 +879,86 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));                      // rewind the read cursor
         P.order = A->order.as<uint32_t>();
         HIP_TRY(hipEventRecord(A->ev[5], 0));
-        // pass 1: every read, at most one seed each; pass 2: the reads that go on to another seed, from scratch
-        // (measured: the small second pass runs too inefficiently to pay — 653 vs 631 ms per 2 M reads — so it is off unless
-        // MGX_TWO_PASS=1; the mechanism stays as a tested tuning option)
-        static const bool two_pass = getenv("MGX_TWO_PASS") && atoi(getenv("MGX_TWO_PASS")) == 1;
-        for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
-            if (two_pass && pass == 0) {
+        // Passes.  MGX_MULTI_PASS=1 (default when a batch carries many seeds per read, see below): a pass extends at most
+        // one seed per read; reads with live seeds left write a resume record and are re-sorted by the work of their next
+        // seed for the next pass (AlignParams::resume_*).  Reads of a wavefront then differ by one extension at most,
+        // instead of waiting for the mate with the most seeds.  MGX_TWO_PASS=1: the older variant (pass 2 from scratch).
+        static const int two_pass_env = getenv("MGX_TWO_PASS") ? atoi(getenv("MGX_TWO_PASS")) : 0;
+        static const int multi_env = getenv("MGX_MULTI_PASS") ? atoi(getenv("MGX_MULTI_PASS")) : -1;
+        bool multi = multi_env == 1;
+        if (multi_env < 0) {
+            // automatic: worth it when reads run many extensions, i.e. carry many seeds (sub-k seeds of a pan-genome: ~100 per
+            // read; a plain read: a handful).  The seeding kernel has finished counting them by now.
+            unsigned long long seeds_total = 0;
+            HIP_TRY(hipMemcpy(&seeds_total, cur + 2, 8, hipMemcpyDeviceToHost));
+            multi = n > 0 && seeds_total / n >= 24;
+        }
+        A->n_passes = 1;
+        if (multi) {
+            const uint32_t rb = resume_rec_bytes(l, (uint32_t)std::max<uint64_t>(1, A->cfg.num_alternative_paths));
+            size_t fb = 0, tb = 0;
+            HIP_TRY(hipMemGetInfo(&fb, &tb));
+            const uint64_t have = A->resume_pool[0].bytes + A->resume_pool[1].bytes;
+            uint64_t cap = std::min<uint64_t>(n, ((uint64_t)fb / 2 + have) / (2ull * rb));      // two pools
+            if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
+            if (cap == 0) multi = false;
+            if (multi) {
+                for (int b = 0; b < 2; ++b) {
+                    if (int rc = A->resume_pool[b].ensure(cap * rb, true)) return rc;
+                    if (int rc = A->retry_key[b].ensure(n * 4 + 4)) return rc;
+                }
+                if (int rc = A->retry_list2.ensure(n * 4 + 4)) return rc;
+                DevBuf *lists[2] = { &A->retry_list, &A->retry_list2 };
                 P.seed_limit = 1;
-                P.retry_list = A->retry_list.as<uint32_t>();
+                P.resume_rec_bytes = rb; P.resume_cap = (uint32_t)cap;
                 P.retry_count = cur + 3;
-            } else if (two_pass) {
-                HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));              // rewind the read cursor
-                P.seed_limit = 0;
-                P.order = A->retry_list.as<uint32_t>();
-                P.n_items_ptr = cur + 3;
+                P.resume_in = nullptr; P.resume_reads = nullptr;
+                int out = 0;
+                uint64_t items = n;
+                for (uint32_t pass = 0;; ++pass) {
+                    P.resume_out = A->resume_pool[out].as<uint8_t>();
+                    P.retry_list = lists[out]->as<uint32_t>();
+                    P.retry_key = A->retry_key[out].as<uint32_t>();
+                    // later passes take more seeds per read, so that the number of launches stays small
+                    P.seed_limit = pass < 8 ? 1 : pass < 16 ? 4 : pass < 24 ? 16 : 0;
+                    HIP_TRY((hipError_t)launch_groups(PH_EXTEND));
+                    unsigned long long c = 0;
+                    HIP_TRY(hipMemcpy(&c, cur + 3, 8, hipMemcpyDeviceToHost));     // (synchronises with the pass)
+                    c = std::min<unsigned long long>(c, cap);
+                    A->n_passes = pass + 1;
+                    if (c == 0 || P.seed_limit == 0) break;
+                    // next pass: the retry positions of this one, sorted by their work key
+                    k_iota<<<(uint32_t)((c + 255) / 256), 256>>>(A->order_in.as<uint32_t>(), c);
+                    size_t tmp_bytes = sort_tmp_bytes;
+                    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, tmp_bytes, A->retry_key[out].as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
+                                                               A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)c, 0, 12, (hipStream_t)0));
+                    HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));              // rewind the read cursor
+                    HIP_TRY(hipMemsetAsync(cur + 3, 0, 8, 0));              // and the retry counter
+                    P.order = A->order.as<uint32_t>();
+                    P.n_items = c;
+                    P.resume_in = A->resume_pool[out].as<uint8_t>();
+                    P.resume_reads = lists[out]->as<uint32_t>();
+                    items = c;
+                    out ^= 1;
+                }
+                (void)items;
             }
-            HIP_TRY((hipError_t)launch_groups(PH_EXTEND));
+        }
+        if (!multi) {
+            const bool two_pass = two_pass_env == 1;
+            for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
+                if (two_pass && pass == 0) {
+                    P.seed_limit = 1;
+                    P.retry_list = A->retry_list.as<uint32_t>();
+                    P.retry_count = cur + 3;
+                } else if (two_pass) {
+                    HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));              // rewind the read cursor
+                    P.seed_limit = 0;
+                    P.order = A->retry_list.as<uint32_t>();
+                    P.n_items_ptr = cur + 3;
+                }
+                HIP_TRY((hipError_t)launch_groups(PH_EXTEND));
+            }
         }
     }
     HIP_TRY(hipEventRecord(A->ev[3], 0));

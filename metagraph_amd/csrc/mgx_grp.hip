@@ -55,15 +55,20 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
     uint8_t *lds = dyn_lds + (uint32_t)g * lds_bytes;
     KernelStats acc;
     memset(&acc, 0, sizeof(acc));
-    const uint64_t n_items = P.n_items_ptr ? *P.n_items_ptr : P.n_reads;
+    const uint64_t n_items = P.n_items ? P.n_items : (P.n_items_ptr ? *P.n_items_ptr : P.n_reads);
     for (;;) {
         LV<uint64_t> rv;
         rv.v = 0;
         if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
         uint64_t item = wave_bcast(rv, 0);
         if (item >= n_items) break;
-        const uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
-        align_read<PHASE>(w, g_params, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes);
+        uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
+        const uint8_t *rec = nullptr;
+        if (PHASE == PH_EXTEND && P.resume_in) {         // a later pass: `read` is a retry position of the pass before
+            rec = P.resume_in + read * P.resume_rec_bytes;
+            read = P.resume_reads[read];
+        }
+        align_read<PHASE>(w, g_params, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes, rec);
     }
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);

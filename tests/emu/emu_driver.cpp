@@ -253,16 +253,48 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         P.order = order.data();
-        // two-pass extension: at most one seed per read first, then the reads that go on, from scratch
+        const uint32_t ldsb = (uint32_t)(lds_env ? atoi(lds_env) : 2048);
+        const char *mp = getenv("MGX_EMU_MULTIPASS");
         std::vector<uint32_t> retry(n + 1);
         unsigned long long retry_count = 0;
+        if (mp && *mp == '1') {
+            // the product's multi-pass extension: one seed per read and pass, resume records in between, the retry positions
+            // of a pass sorted by their work key for the next one (MGX_EMU_RESUME_CAP: records a pass may write)
+            const uint32_t rb = resume_rec_bytes(R->lim, std::max<uint32_t>(1, (uint32_t)cfg.num_alternative_paths));
+            const char *cap_env = getenv("MGX_EMU_RESUME_CAP");
+            const uint32_t cap = cap_env ? (uint32_t)atoi(cap_env) : (uint32_t)n;
+            std::vector<uint8_t> pool_a((size_t)rb * std::max<uint32_t>(cap, 1)), pool_b((size_t)rb * std::max<uint32_t>(cap, 1));
+            std::vector<uint32_t> list_a(n + 1), list_b(n + 1), key_a(n + 1), key_b(n + 1), ord(n + 1);
+            P.seed_limit = 1; P.resume_rec_bytes = rb; P.resume_cap = cap;
+            P.retry_list = list_a.data(); P.retry_key = key_a.data(); P.retry_count = &retry_count; P.resume_out = pool_a.data();
+            for (uint64_t i = 0; i < n; ++i)
+                align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
+            R->retried = retry_count;
+            std::vector<uint8_t> *pin = &pool_a, *pout = &pool_b;
+            std::vector<uint32_t> *lin = &list_a, *lout = &list_b, *kin = &key_a, *kout = &key_b;
+            for (int pass = 1; retry_count; ++pass) {
+                const uint64_t c = std::min<uint64_t>(retry_count, cap);
+                for (uint64_t i = 0; i < c; ++i) ord[i] = (uint32_t)i;
+                std::stable_sort(ord.begin(), ord.begin() + c, [&](uint32_t a, uint32_t b) { return (*kin)[a] < (*kin)[b]; });
+                retry_count = 0;
+                P.resume_in = pin->data(); P.resume_reads = lin->data();
+                P.resume_out = pout->data(); P.retry_list = lout->data(); P.retry_key = kout->data();
+                for (uint64_t i = 0; i < c; ++i) {
+                    const uint32_t pos = ord[i];
+                    align_read<PH_EXTEND>(*w, P, (*lin)[pos], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb, pin->data() + (size_t)pos * rb);
+                }
+                std::swap(pin, pout); std::swap(lin, lout); std::swap(kin, kout);
+            }
+        } else {
+        // two-pass extension: at most one seed per read first, then the reads that go on, from scratch
         P.seed_limit = 1; P.retry_list = retry.data(); P.retry_count = &retry_count;
         for (uint64_t i = 0; i < n; ++i)
-            align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
+            align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
         P.seed_limit = 0; P.order = retry.data();
         for (uint64_t i = 0; i < retry_count; ++i)
-            align_read<PH_EXTEND>(*w, P, retry[i], 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
+            align_read<PH_EXTEND>(*w, P, retry[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
         R->retried = retry_count;
+        }
     } else {
         for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
     }

@@ -177,6 +177,29 @@ def test_two_pass_extension_retries_multi_seed_reads(monkeypatch):
     assert rng is not None
 
 
+@pytest.mark.parametrize("cap", ["", "2"])
+def test_multi_pass_extension_with_resume_records(cap, monkeypatch):
+    """The product's answer to reads with many seeds: a pass extends one seed per read, what outlives a seed (aggregator
+    queue, live-seed flags, extender capacities, counters, the place where the read stopped) travels to the next pass in a
+    resume record, and the positions are re-sorted by the work of their next seed.  Chimeric and multi-seed reads take up
+    to a dozen passes here; with room for only two records per pass the other reads simply go on without a limit.  The
+    results equal the oracle's either way."""
+    monkeypatch.setenv("MGX_EMU_SPLIT", "1")
+    monkeypatch.setenv("MGX_EMU_MULTIPASS", "1")
+    if cap:
+        monkeypatch.setenv("MGX_EMU_RESUME_CAP", cap)
+    g, reads = make_world(334, 15, genome_len=4000, n_reads=40, read_len=100, n_variants=60)
+    chim = [reads[i][:50] + reads[i + 1][40:90] for i in range(0, 30, 2)]
+    eg = emu_drv.EmuGraph(g)
+    for n_alt, min_seed in ((1, 15), (2, 15), (1, 11)):
+        cfg = capi.config_cli(15)
+        cfg.min_exact_match = 0.0
+        cfg.num_alternative_paths = n_alt
+        cfg.min_seed_length = min_seed
+        e = compare_full(g, eg, cfg, reads + chim)
+        assert e.retried() > 0
+
+
 def test_split_pipeline_unit_kats(monkeypatch):
     monkeypatch.setenv("MGX_EMU_SPLIT", "1")
     for case in KATS["unit"]:
