@@ -739,10 +739,19 @@ MGX_DEV bool maybe_low_complexity(Wave &w, int s) {
             int32_t e = base + l;
             bool h = false;
             if (e < L && tc[e] != 255) {
+                // eight masks per round, fetched together (the test of each d depends on the running sum, and with a break
+                // after every load the 61 loads of a lane were issued one after the other)
                 int32_t r = 0;
-                for (int32_t d = 1; d <= SPAN && e - d >= 0; ++d) {
-                    r += popc64(eq[e - d] & ((1ull << d) - 1));       // pairs (e - d, y) with y in (e - d, e]
-                    if (r * 10 > T * d) { h = true; break; }
+                for (int32_t d0 = 1; d0 <= SPAN && e - d0 >= 0 && !h; d0 += 8) {
+                    uint64_t v[8];
+                    for (int t = 0; t < 8; ++t) { const int32_t d = d0 + t; v[t] = (d <= SPAN && e - d >= 0) ? eq[e - d] : 0ull; }
+                    for (int t = 0; t < 8; ++t) {
+                        const int32_t d = d0 + t;
+                        if (d <= SPAN && e - d >= 0) {
+                            r += popc64(v[t] & ((1ull << d) - 1));    // pairs (e - d, y) with y in (e - d, e]
+                            h |= r * 10 > T * d;
+                        }
+                    }
                 }
             }
             hit[l] = h;
@@ -1191,7 +1200,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             uint64_t inc[5];
             uint32_t fc[5];
             // call_incoming_to_target(bwd(e), node_last_value(e)) == parents of the node whose last edge is e
-            int ni = incoming<true>(g, e, inc, fc, w.ctr);
+            int ni = incoming<true, false>(g, e, inc, fc, w.ctr);
             for (int t = 0; t < ni; ++t) {
                 if (alt_n >= MGX_PARAMS_OF(w).lim.max_alt) { w.status = ST_CAPACITY; return; }
                 w.alt[alt_n++] = (uint32_t)inc[t];

@@ -363,12 +363,14 @@ MGX_DEV uint32_t first_char(const DevGraph &g, uint64_t e, LineCtr &ctr) {
 // Parents of v with the first character of each parent k-mer, in the order of
 // BOSS::call_incoming_to_target (boss.cpp:766-786) as used by NodeFirstCache::call_incoming_kmers
 // (graph_extensions/node_first_cache.cpp:38-52).  Up to 5 parents ($ACGT first chars).
-template <bool U = false>
+// FIRST = false: the caller only wants the parent nodes (the seeder's suffix matches); the first-character table is then
+// not read at all (one random line per parent).
+template <bool U = false, bool FIRST = true>
 MGX_DEV int incoming(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *first_codes, LineCtr &ctr) {
     uint64_t x = bwd<U>(g, v, ctr);
     uint32_t d = node_last_value(g, v);
     int n = 0;
-    if (in_graph(g, x)) { nodes[n] = x; first_codes[n] = first_char(g, x, ctr); ++n; }
+    if (in_graph(g, x)) { nodes[n] = x; first_codes[n] = FIRST ? first_char(g, x, ctr) : 0u; ++n; }
     // edges after x labelled d + SIGMA, up to the next unflagged d
     uint64_t pos = x + 1;
     uint32_t bi = (uint32_t)(pos >> 6);
@@ -385,7 +387,7 @@ MGX_DEV int incoming(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *f
             int j = ctz64(flg);
             flg &= flg - 1;
             uint64_t e = ((uint64_t)bi << 6) + (uint32_t)j;
-            if (in_graph(g, e) && n < 5) { nodes[n] = e; first_codes[n] = first_char(g, e, ctr); ++n; }
+            if (in_graph(g, e) && n < 5) { nodes[n] = e; first_codes[n] = FIRST ? first_char(g, e, ctr) : 0u; ++n; }
         }
         if (stop) break;
         ++bi;
