@@ -986,6 +986,10 @@ MGX_NI_G2 void base_seeds(Wave &w, int s) {
 }
 
 constexpr uint32_t DEFERRED_RANGE = 0xFFFFFFFFu;     // rfirst[] marker: match length known, range not fetched yet
+// rfirst[] marker: the range holds ONE node and rlast[] is its last edge.  index_range returns (succ_last(rl), ru), both last
+// edges of nodes (boss.hpp:756-763), so first == last means one node, and select_last(rank_last(first)) == first: neither
+// the two ranks nor the select of dbg_succinct.cpp:349-375 need a memory access then (the common case).
+constexpr uint32_t SINGLE_NODE = 0xFFFFFFFEu;
 
 // BOSS::index_range (boss.hpp:720-764) for one lane: codes q[i .. i + len); returns matched length,
 // *first = succ_last(rl), *last = ru
@@ -1141,8 +1145,8 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                     }
                     if (m >= msl0 && first && first <= g.n) {
                         mlen = (uint16_t)m;
-                        rf = rank_last(g, first, lc);
-                        rl_ = rank_last(g, last, lc);
+                        if (first == last) { rf = SINGLE_NODE; rl_ = (uint32_t)first; }
+                        else { rf = rank_last(g, first, lc); rl_ = rank_last(g, last, lc); }
                     }
                 }
                 w.ml[i] = mlen; w.rfirst[i] = rf; w.rlast[i] = rl_;
@@ -1185,7 +1189,10 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             const int32_t m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
             const bool ok = m >= msl0 && first && first <= g.n;
             uint32_t rf = 0, rl_ = 0;
-            if (ok) { rf = rank_last(g, first, lc); rl_ = rank_last(g, last, lc); }
+            if (ok) {
+                if (first == last) { rf = SINGLE_NODE; rl_ = (uint32_t)first; }
+                else { rf = rank_last(g, first, lc); rl_ = rank_last(g, last, lc); }
+            }
             w.ctr.rank_lines += lc.rank_lines; w.ctr.select_lines += lc.select_lines; w.ctr.bit_lines += lc.bit_lines;
             wave_sync();
             FOR_LANES(l) { if (l == 0) { w.rfirst[i] = rf; w.rlast[i] = rl_; } }
@@ -1195,8 +1202,10 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         // enumerate nodes whose suffix matches (dbg_succinct.cpp:349-392)
         uint32_t first_alt = alt_n;
         uint32_t cnt = 0;
-        for (uint32_t r = w.rfirst[i]; r <= w.rlast[i]; ++r) {
-            uint64_t e = select_last<true>(g, r, w.ctr);
+        const bool one_node = w.rfirst[i] == SINGLE_NODE;
+        const uint32_t r_begin = one_node ? 0u : w.rfirst[i], r_end = one_node ? 0u : w.rlast[i];
+        for (uint32_t r = r_begin; r <= r_end; ++r) {
+            uint64_t e = one_node ? (uint64_t)w.rlast[i] : select_last<true>(g, r, w.ctr);
             uint64_t inc[5];
             uint32_t fc[5];
             // call_incoming_to_target(bwd(e), node_last_value(e)) == parents of the node whose last edge is e
