@@ -273,7 +273,17 @@ def main():
         Fc = (C.c_uint64 * 5)(*[int(x) for x in boss["F"]])
         view.F = C.cast(Fc, C.POINTER(C.c_uint64))
         og = orc.Graph(orc.L().orc_graph_from_boss(C.byref(view)))
-        threads = os.cpu_count() or 1
+        # threads the CPU leg may really use: the affinity mask and the cgroup CPU quota, not the machine's core count (the
+        # GPU boxes show 256 logical CPUs; profiles/r02_cpu_thread_scan.json: the restated path scales linearly to 16 threads,
+        # peaks at 64 and loses 25 % when 256 threads are started)
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if q != "max":
+                threads = max(1, min(threads, int(int(q) / int(per))))
+        except (OSError, ValueError):
+            pass
+        threads = min(threads, int(os.environ.get("MGX_BENCH_CPU_THREADS", 64)))
         orc.L().orc_graph_build_first_chars(og.h, threads)      # NodeFirstCache stand-in (one-off, untimed)
         nc = min(args.parity_sample if args.no_cpu_baseline else max(args.cpu_sample, args.parity_sample), args.reads)
         csample = [bytes(r) for r in reads[:nc].cpu().numpy()]
