@@ -202,3 +202,12 @@ def test_build_stats_of_transcripts_1000_k20():
     from test_oracle_kats import read_fasta, HERE
     g = orc.Graph.build(20, read_fasta(os.path.join(HERE, "golden", "transcripts_1000.fa")), 0, True)
     assert g.num_nodes == 591997
+
+
+def test_build_stats_of_canonical_genome_mt_k11():
+    """integration_tests/test_align.py:209-219: `metagraph build --mode canonical --mask-dummy -k 11` on genome.MT.fa reports
+    32782 nodes (k) (basic mode: 16438, already pinned).  The fixture builder's CANONICAL mode adds the reverse complement
+    of every sequence (boss_chunk_construct.cpp:357-359): groundwork for canonical / primary graphs."""
+    from test_oracle_kats import read_fasta, HERE
+    g = orc.Graph.build(11, read_fasta(os.path.join(HERE, "golden", "genome.MT.fa")), 1, True)
+    assert g.num_nodes == 32782
