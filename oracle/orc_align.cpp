@@ -222,8 +222,56 @@ void Alignment::reverse_complement(const GraphView &graph, std::string_view quer
         }
         return;
     }
-    // The generic branch (:563-693) is reached only for CanonicalDBG graphs, which are out of scope.
-    throw std::runtime_error("orc::Alignment::reverse_complement: only RCDBG views are restated");
+    // The generic branch (:563-702): the graph itself holds the reverse complement (CANONICAL-mode DBGSuccinct; the
+    // CanonicalDBG wrapper of PRIMARY graphs is not restated yet — SURVEY 8f rank 1).
+    const Graph &g = *graph.g;
+    if (g.mode != CANONICAL)
+        throw std::runtime_error("orc::Alignment::reverse_complement: plain graphs are reversed through the RCDBG view");
+    auto rc_seq_path = [&]() {                         // reverse_complement_seq_path, sequence_graph.cpp:563-573
+        reverse_complement_inplace(sequence);
+        nodes = g.map_to_nodes_sequentially(sequence);
+    };
+    if (!offset) {
+        rc_seq_path();
+    } else {
+        // :566-693: one node, `offset` characters of its k-mer are not part of the alignment
+        sequence = g.get_node_sequence(nodes[0]).substr(0, offset) + sequence;
+        if (sequence[0] == '$') {
+            // :569-651: a source dummy k-mer: walk forwards (always the last outgoing edge) until the k-mer holds no sentinel
+            const Boss &boss = g.boss;
+            size_t num_sentinels = sequence.find_last_of('$') + 1;
+            size_t num_first_steps = offset;           // no CanonicalDBG wrapper here
+            edge_t edge = nodes[0];
+            uint8_t edge_label = boss.get_W(edge) % SIGMA;
+            for (size_t i = 0; i < num_first_steps; ++i) {
+                edge = boss.fwd(edge, edge_label);
+                edge_label = boss.get_W(edge) % SIGMA;
+                if (edge_label == 0) { *this = Alignment(); return; }      // reverse complement not found
+                nodes[0] = g.validate_edge(edge);
+                sequence.push_back(decode_code(edge_label));
+            }
+            (void)num_sentinels;
+            sequence = sequence.substr(offset);
+            rc_seq_path();
+            sequence.assign(sequence.data() + offset, g.get_k() - offset);
+        } else {
+            rc_seq_path();
+            // :667-689: trim the ending of the reverse complement that corresponds to the added prefix; of several
+            // possible predecessors the first one is taken
+            for (size_t i = 0; i < offset; ++i) {
+                size_t indegree = 0;
+                g.call_incoming_kmers(nodes[0], [&](node_t prev, char) {
+                    ++indegree;
+                    if (indegree == 1) nodes[0] = prev;
+                });
+                if (!indegree) { *this = Alignment(); return; }
+                sequence.pop_back();
+            }
+        }
+    }
+    std::reverse(cigar.ops.begin(), cigar.ops.end());
+    orientation = !orientation;
+    query_view = query_rev_comp.substr(get_clipping(), query_rev_comp.size() - get_clipping() - get_end_clipping());
 }
 
 std::string spell_path(const GraphView &graph, const std::vector<node_t> &path, size_t offset) {
@@ -1285,7 +1333,8 @@ Aligner::Aligner(const Graph &graph, const mgx_config &config) : graph_(graph), 
     if (!check_config_scores(config_))
         throw std::runtime_error("Error: sum of min_cell_score and lowest penalty too low.");
     if (config_.chain_alignments) config_.allow_left_trim = false;
-    if (graph_.mode != BASIC) throw std::runtime_error("oracle: only BASIC graphs are restated");
+    // PRIMARY graphs must be wrapped into CanonicalDBG (dbg_aligner.cpp:52-53), which is not restated yet
+    if (graph_.mode == PRIMARY) throw std::runtime_error("oracle: PRIMARY graphs (CanonicalDBG wrapper) are not restated");
     if (config_.chain_alignments || config_.post_chain_alignments || !config_.global_xdrop || config_.no_backtrack)
         throw std::runtime_error("oracle: chaining / per-branch xdrop / no_backtrack are out of scope");
 }
@@ -1332,7 +1381,7 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
         SeederState seeder = make_suffix_seeder(graph_, this_query, false, nodes, config_, &wc);
         if (this_query.size() * config_.min_exact_match > seeder.num_matching) { seeder.seeds.clear(); seeder.num_matching = 0; }
 
-        bool have_rc = config_.forward_and_reverse_complement;
+        bool have_rc = config_.forward_and_reverse_complement || graph_.mode == CANONICAL;     // dbg_aligner.cpp:225-226
         SeederState seeder_rc;
         if (have_rc) {
             std::vector<node_t> nodes_rc = nodes;
@@ -1367,8 +1416,13 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
 
             auto aln_both = [&](std::string_view query, std::string_view query_rc, std::vector<Alignment> &&seeds,
                                 Extender &fwd_extender, Extender &bwd_extender) {
+                // :644-655: a CANONICAL-mode graph holds both strands itself — the backward pass runs on the same graph, and
+                // an alignment on the reverse strand is reported as the forward-strand alignment it mirrors
+                const bool use_rcdbg = graph_.mode != CANONICAL && config_.forward_and_reverse_complement;
+                auto is_reversible = [&](const Alignment &a) { return graph_.mode == CANONICAL && a.orientation && !a.offset; };
                 fwd_extender.set_graph(false);
-                bwd_extender.set_graph(true);          // RCDBG (use_rcdbg, :646-649)
+                bwd_extender.set_graph(use_rcdbg);
+                const GraphView plain{ &graph_, false };
                 if (seeds.empty()) return;
                 for (size_t i = 0; i < seeds.size(); ++i) {
                     if (seeds[i].empty()) continue;
@@ -1376,7 +1430,15 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
                     auto extensions = fwd_extender.get_extensions(seeds[i], min_path_score, false);
                     std::vector<Alignment> rc_of_alignments;
                     for (Alignment &path : extensions) {
-                        if (path.score >= get_min_path_score(path)) add_alignment(Alignment(path));
+                        if (path.score >= get_min_path_score(path)) {
+                            if (is_reversible(path)) {
+                                Alignment out_path = path;
+                                out_path.reverse_complement(plain, query_rc);
+                                add_alignment(std::move(out_path));
+                            } else {
+                                add_alignment(Alignment(path));
+                            }
+                        }
                         if (!path.get_clipping() || path.offset) continue;
                         path.reverse_complement(bwd_extender.view(), query_rc);
                         if (path.empty()) continue;
@@ -1384,10 +1446,12 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
                     }
                     align_core(std::move(rc_of_alignments), bwd_extender,
                         [&](Alignment &&path) {
-                            path.reverse_complement(bwd_extender.view(), query);
-                            if (path.empty()) return;
-                            for (node_t node : path.nodes)
-                                fwd_extender.filter_nodes(node, path.get_clipping(), query.size() - path.get_end_clipping());
+                            if (use_rcdbg || is_reversible(path)) {
+                                path.reverse_complement(bwd_extender.view(), query);
+                                if (path.empty()) return;
+                                for (node_t node : path.nodes)
+                                    fwd_extender.filter_nodes(node, path.get_clipping(), query.size() - path.get_end_clipping());
+                            }
                             add_alignment(std::move(path));
                         },
                         get_min_path_score, true);
