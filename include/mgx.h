@@ -61,7 +61,10 @@ typedef struct mgx_boss_view {
     const uint64_t *F;       /* sigma entries (boss.hpp:506-510) */
     const uint8_t *valid;    /* optional node mask, one byte per edge (dbg_succinct.cpp:934-936);
                                 NULL = every edge is a node, as after reset_mask() (cli/align.cpp:337-339) */
-    uint32_t mode;           /* MGX_MODE_*; only BASIC is implemented */
+    uint32_t mode;           /* MGX_MODE_*: BASIC and CANONICAL (a DBGSuccinct that stores both strands: the aligner then
+                              * always seeds both strands, runs the backward pass on the same graph and reports reverse-strand
+                              * alignments as the forward alignments they mirror, dbg_aligner.cpp:225,644-655).  PRIMARY graphs
+                              * are aligned through the CanonicalDBG wrapper upstream: MGX_ERR_UNSUPPORTED here. */
     uint32_t on_device;      /* 0: W/last/valid are host pointers; 1: device pointers (F always host) */
 } mgx_boss_view;
 

@@ -91,6 +91,10 @@ MGX_DEV uint8_t complement_char(uint8_t c) {         // COMPL_TAB, common/seq_to
 
 MGX_DEV uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
 
+} // namespace mgx
+#include "map_chain.hpp"
+namespace mgx {
+
 MGX_DEV uint8_t char_to_op(uint8_t a, uint8_t b) {   // initialize_opt_table (A/aligner_cigar.cpp:10-51)
     uint8_t ua = to_upper(a), ub = to_upper(b);
     bool valid = (ua == 'A' || ua == 'C' || ua == 'G' || ua == 'T');
@@ -3281,6 +3285,56 @@ MGX_NI_G4 bool reverse_complement_aln(Wave &w, DevAln &a) {
     return true;
 }
 
+// Alignment::reverse_complement on a graph that holds the reverse complement itself (CANONICAL-mode DBGSuccinct), for
+// alignments without an offset (alignment.cpp:563-565: every caller on this path has checked it): the path of the reverse
+// complement is found by mapping the reversed-complemented spelling (reverse_complement_seq_path, sequence_graph.cpp:563-573
+// -> BOSS::map_to_edges), here by one lane walking the byte chain of map_chain.hpp with strand = 1.
+MGX_NI_G4 bool reverse_complement_aln_canonical(Wave &w, DevAln &a) {
+    MGX_ASSUME_LDS(&w);
+    if (a.offset) { a.n_nodes = 0; return false; }
+    const DevGraph &g = MGX_PARAMS_OF(w).g;
+    const int32_t n_kmers = a.seq_len - (int32_t)g.k + 1;
+    LV<int32_t> nl;
+    FOR_LANES(l) {
+        LineCtr lc = { 0, 0, 0 };
+        if (l == 0 && n_kmers > 0) {
+            MapLane m;
+            m.state = 0;
+            bool given = false;
+            auto fetch = [&](MapLane &ml) -> bool {
+                if (given) return false;
+                given = true;
+                ml.strand = 1; ml.L = a.seq_len; ml.seq = (const char *)a.seq; ml.out = a.nodes;
+                ml.out_len = nullptr; ml.out_rng = nullptr; ml.min_rng_len = 0; ml.n_kmers = n_kmers;
+                return true;
+            };
+            while (m.state != 3) map_lane_step(g, m, lc, fetch);
+        }
+        nl[l] = (int32_t)(lc.rank_lines + lc.select_lines + lc.bit_lines);
+    }
+    w.ctr.rank_lines += (uint32_t)wave_sum(nl);
+    wave_sync();
+    a.n_nodes = imax(n_kmers, 0);
+    // spelling and CIGAR reversed (the nodes above are already those of the reversed spelling)
+    int32_t n = imax(a.n_cigar, a.seq_len);
+    for (int32_t base = 0; base < (n + 1) / 2; base += WAVE) {
+        FOR_LANES(l) {
+            int32_t x = base + l;
+            if (x < a.n_cigar / 2) { uint32_t t = a.cigar[x]; a.cigar[x] = a.cigar[a.n_cigar - 1 - x]; a.cigar[a.n_cigar - 1 - x] = t; }
+            if (x < (a.seq_len + 1) / 2) {
+                uint8_t t0 = complement_char(a.seq[x]), t1 = complement_char(a.seq[a.seq_len - 1 - x]);
+                a.seq[x] = t1; a.seq[a.seq_len - 1 - x] = t0;
+            }
+        }
+    }
+    wave_sync();
+    a.orientation = !a.orientation;
+    int32_t clip = aln_clipping(a), eclip = aln_end_clipping(a);
+    a.qbegin = clip;
+    a.qlen = w.L - clip - eclip;
+    return a.n_nodes > 0;
+}
+
 MGX_DEV SeedRef seedref_from_aln(const DevAln &a) {
     SeedRef s;
     s.nodes = a.nodes; s.seq = a.seq; s.n_nodes = a.n_nodes; s.seq_len = a.seq_len;
@@ -3432,8 +3486,12 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
     const AlignParams &P = MGX_PARAMS_OF(w);
     ExtenderState &F = w.ext[s];
     ExtenderState &B = w.ext[1 - s];
+    // A CANONICAL-mode graph holds both strands itself (:644-655): the backward pass runs on the same graph, alignments are
+    // flipped by re-mapping their reversed spelling, and an alignment on the reverse strand is reported as the forward
+    // alignment it mirrors (is_reversible: orientation && !offset).
+    const bool canon = P.cfg.canonical != 0;
     F.rc_view = 0;
-    B.rc_view = 1;
+    B.rc_view = canon ? 0 : 1;
     const int32_t n = w.n_seeds[s];
     const int32_t i0 = w.resume_i;
     w.resume_i = 0;
@@ -3466,9 +3524,22 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
             const uint64_t tm0 = cycle_clock();
             for (int e = 0; e < n_fwd; ++e) {
                 DevAln &path = w.aln[e];
+                DevAln &rev = w.aln[n_alt + n_rev];
+                if (canon) {
+                    // the mirror image serves both purposes: what is reported for a reverse-strand alignment (:683-689) and
+                    // the seed of the backward pass (:695) — the same reverse_complement(graph_, query_rc)
+                    const bool reversible = path.orientation && !path.offset;
+                    const bool to_left = aln_clipping(path) && !path.offset;
+                    const bool good = path.score >= min_path_score_now(w);
+                    bool have_rev = false;
+                    if ((good && reversible) || to_left) { copy_aln(rev, path); have_rev = reverse_complement_aln_canonical(w, rev); }
+                    if (good) { if (reversible) { if (have_rev) add_alignment(w, rev); } else add_alignment(w, path); }
+                    if (!to_left || !have_rev) continue;
+                    rev_alive[n_rev++] = true;
+                    continue;
+                }
                 if (path.score >= min_path_score_now(w)) add_alignment(w, path);
                 if (!aln_clipping(path) || path.offset) continue;
-                DevAln &rev = w.aln[n_alt + n_rev];
                 copy_aln(rev, path);
                 if (!reverse_complement_aln(w, rev)) continue;
                 rev_alive[n_rev++] = true;
@@ -3496,7 +3567,8 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
             if (w.status != ST_OK) return;
             for (int b = 0; b < n_bwd; ++b) {
                 DevAln &p2 = w.aln[2 * n_alt + b];
-                if (reverse_complement_aln(w, p2)) {
+                if (canon && !(p2.orientation && !p2.offset)) { add_alignment(w, p2); continue; }     // not reversible: as it is (:711)
+                if (canon ? reverse_complement_aln_canonical(w, p2) : reverse_complement_aln(w, p2)) {
                     int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
                     const uint64_t tf0 = cycle_clock();
                     for (int32_t x = 0; x < p2.n_nodes; ++x)

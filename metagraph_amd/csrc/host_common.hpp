@@ -52,6 +52,7 @@ inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, Dev
     d->fwd_and_rc = c.forward_and_reverse_complement; d->allow_left_trim = c.allow_left_trim;
     d->seed_complexity_filter = c.seed_complexity_filter;
     d->num_alt = (uint32_t)c.num_alternative_paths;
+    d->canonical = 0;                       // set from the graph's mode by the caller (with fwd_and_rc, dbg_aligner.cpp:225-226)
     return MGX_OK;
 }
 

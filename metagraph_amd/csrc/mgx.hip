@@ -293,6 +293,7 @@ struct mgx_graph {
     DevGraph g;
     DevBuf blocks, last_hint, w_hint[4], firstc, terminus, valid, prefix_tbl;
     uint64_t bytes = 0;
+    uint32_t mode = MGX_MODE_BASIC;
 };
 
 extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);    // mgx_grp.hip, MGX_GROUP=8
@@ -431,7 +432,10 @@ void mgx_limits_init_default(mgx_limits *l, uint32_t max_query_length) {
 int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
     if (!view || !out || !view->W || !view->last || !view->F) return fail(MGX_ERR_INVALID, "null BOSS view");
     if (view->sigma != SIGMA) return fail(MGX_ERR_UNSUPPORTED, "only the DNA alphabet $ACGT (sigma = 5) is implemented");
-    if (view->mode != MGX_MODE_BASIC) return fail(MGX_ERR_UNSUPPORTED, "only BASIC-mode graphs are implemented (canonical/primary are next)");
+    // CANONICAL: a DBGSuccinct that stores both strands (same index, different aligner flow).  PRIMARY graphs are aligned
+    // through the CanonicalDBG wrapper in the reference (dbg_aligner.cpp:52-53), which is not implemented.
+    if (view->mode != MGX_MODE_BASIC && view->mode != MGX_MODE_CANONICAL)
+        return fail(MGX_ERR_UNSUPPORTED, "PRIMARY-mode graphs (CanonicalDBG wrapper) are not implemented");
     if (view->k < 2 || view->k > 255) return fail(MGX_ERR_INVALID, "k out of range");
     if (view->n_edges == 0 || view->n_edges >= 0xFFFFFFF0ull) return fail(MGX_ERR_UNSUPPORTED, "edge count must fit 32 bits");
     if (mgx_device_count() <= device) return fail(MGX_ERR_NO_DEVICE, "HIP device %d not available", device);
@@ -439,6 +443,7 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
     auto *G = new mgx_graph();
     std::unique_ptr<mgx_graph> guard(G);
     G->device = device;
+    G->mode = view->mode;
     const uint64_t n = view->n_edges;
     const uint32_t n_blocks = (uint32_t)((n + 1 + 63) / 64);
     DevBuf dW, dLast, dValid, counts, cum;
@@ -580,6 +585,7 @@ int mgx_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_l
         int rc = prepare_config(*config, g->g.k, &A->cfg, &A->dcfg, &err);
         if (rc) return fail(rc, "%s", err.c_str());
     }
+    if (g->mode == MGX_MODE_CANONICAL) { A->dcfg.canonical = 1; A->dcfg.fwd_and_rc = 1; }     // dbg_aligner.cpp:225-226
     mgx_config &c = A->cfg;
     if (limits) { A->user_lim = *limits; A->have_user_lim = true; }
     HIP_TRY(hipSetDevice(g->device));
@@ -1034,7 +1040,7 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
     if (n == 0) { A->n_reads = 0; return MGX_OK; }
     if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc;
     bool mapped = A->cfg.max_seed_length >= A->graph->g.k;
-    if (int rc = run_map(A, d_seqs, d_offsets, n, A->cfg.forward_and_reverse_complement != 0, mapped, Lmax)) return rc;
+    if (int rc = run_map(A, d_seqs, d_offsets, n, A->dcfg.fwd_and_rc != 0, mapped, Lmax)) return rc;
     for (;;) {
         if (int rc = run_align(A, d_seqs, d_offsets, n, Lmax)) return rc;
         if (int rc = collect_stats(A, mapped, true)) return rc;

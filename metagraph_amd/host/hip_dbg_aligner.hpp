@@ -118,10 +118,10 @@ class HipBOSSGraph {
   public:
     // W/last: one byte per edge, n_edges + 1 entries; valid may be null (reset_mask(), cli/align.cpp:337-339)
     HipBOSSGraph(uint32_t k, uint64_t n_edges, const uint8_t *W, const uint8_t *last, const uint64_t F[5],
-                 const uint8_t *valid = nullptr, int device = 0) {
+                 const uint8_t *valid = nullptr, int device = 0, uint32_t mode = MGX_MODE_BASIC) {
         mgx_boss_view v{};
         v.k = k; v.sigma = 5; v.n_edges = n_edges; v.W = W; v.last = last; v.F = F; v.valid = valid;
-        v.mode = MGX_MODE_BASIC; v.on_device = 0;
+        v.mode = mode; v.on_device = 0;          // MGX_MODE_BASIC or MGX_MODE_CANONICAL (DeBruijnGraph::get_mode())
         if (int rc = mgx_graph_create(&v, device, &g_)) throw std::runtime_error(std::string("mgx_graph_create: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
     }
     ~HipBOSSGraph() { mgx_graph_destroy(g_); }

@@ -23,6 +23,7 @@ struct EmuGraph {
     std::vector<uint32_t> last_hint, w_hint[4], firstc;
     std::vector<uint64_t> terminus, valid;
     std::vector<uint2> prefix_tbl;
+    uint32_t mode = 0;
 };
 
 struct EmuRun {
@@ -43,6 +44,7 @@ extern "C" {
 
 void *emu_graph_create(const mgx_boss_view *view) {
     auto *G = new EmuGraph();
+    G->mode = view->mode;
     const uint64_t n = view->n_edges;
     const uint32_t n_blocks = (uint32_t)((n + 1 + 63) / 64);
     G->blocks.resize(n_blocks);
@@ -134,6 +136,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     DevConfig dcfg;
     int rc = prepare_config(*config, G->g.k, &cfg, &dcfg, &R->error);
     if (rc) return R;
+    if (G->mode == MGX_MODE_CANONICAL) { dcfg.canonical = 1; dcfg.fwd_and_rc = 1; }      // as mgx_aligner_create
     const uint32_t k = G->g.k;
     uint32_t Lmax = 0;
     R->node_begin.assign(n + 1, 0);
@@ -149,7 +152,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     memset(&R->stats, 0, sizeof(R->stats));
     if (mapped) {
         // the product's k_map: persistent lanes stepping the per-lane state machine (here: one lane)
-        const bool do_rc = map_only || cfg.forward_and_reverse_complement;
+        const bool do_rc = map_only || dcfg.fwd_and_rc;
         const uint64_t n_chains = do_rc ? 2 * n : n;
         uint64_t cursor = 0;
         LineCtr ctr = { 0, 0, 0 };

@@ -47,7 +47,7 @@ def L():
     return _L
 
 
-def boss_view(k, W, last, F, valid=None, on_device=0):
+def boss_view(k, W, last, F, valid=None, on_device=0, mode=0):
     """numpy arrays -> (BossView, keepalive)"""
     v = capi.BossView()
     v.k = k
@@ -58,15 +58,15 @@ def boss_view(k, W, last, F, valid=None, on_device=0):
     Fc = (C.c_uint64 * 5)(*[int(x) for x in F])
     v.F = C.cast(Fc, C.POINTER(C.c_uint64))
     v.valid = valid.ctypes.data if valid is not None else None
-    v.mode = 0
+    v.mode = mode
     v.on_device = on_device
     return v, (W, last, Fc, valid)
 
 
 class EmuGraph:
-    def __init__(self, orc_graph):
+    def __init__(self, orc_graph, mode=0):
         W, last, F, valid = orc_graph.export()
-        self.view, self._keep = boss_view(orc_graph.k, W, last, F, valid)
+        self.view, self._keep = boss_view(orc_graph.k, W, last, F, valid, mode=mode)
         self.h = L().emu_graph_create(C.byref(self.view))
         self.k = orc_graph.k
 
