@@ -2,7 +2,7 @@
 // TSV printing as in cli/align.cpp:403-480).  Graph input is a flat BOSS dump (k, n_edges, F[5], W[], last[]);
 // reading sdsl-serialised .dbg files is "next" (SURVEY 8f rank 2).  Usage:
 //   mgx_align GRAPH.boss READS.{fa,fq} [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]
-//             [-p THREADS] [--query-batch-size BASES]
+//             [-p THREADS] [--query-batch-size BASES] [--canonical (the dump is a CANONICAL-mode graph)]
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
     uint64_t batch_size = 100000000ull;
     mgx_limits lim;
     bool have_lim = false;
+    uint32_t graph_mode = MGX_MODE_BASIC;
     mgx_limits_init_default(&lim, 0);
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--align-only-forwards")) cfg.forward_and_reverse_complement = 0;
@@ -76,9 +77,10 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "-p") && i + 1 < argc) threads = (unsigned)std::max(1, atoi(argv[++i]));
         else if (!strcmp(argv[i], "--query-batch-size") && i + 1 < argc) batch_size = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--max-columns") && i + 1 < argc) { lim.max_columns = (uint32_t)atoi(argv[++i]); have_lim = true; }
+        else if (!strcmp(argv[i], "--canonical")) graph_mode = MGX_MODE_CANONICAL;
     }
     try {
-        HipBOSSGraph graph(k, n, W.data(), last.data(), hdr + 2);
+        HipBOSSGraph graph(k, n, W.data(), last.data(), hdr + 2, nullptr, 0, graph_mode);
         std::vector<IDBGAligner::Query> all;
         if (!read_records(argv[2], &all)) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
         // batches by bases read (align.cpp:431-442: a record is added while the running total is <= batch_size)

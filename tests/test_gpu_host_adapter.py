@@ -73,3 +73,30 @@ def test_mgx_align_batches_threads_and_capacity_retry(tmp_path):
     r = subprocess.run(base + ["--max-columns", "70"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.rstrip("\n").split("\n") == want
+
+
+def test_mgx_align_driver_on_a_canonical_graph(tmp_path):
+    """`metagraph align --align-min-exact-match 0.0 [--align-min-seed-length 10]` on the canonical genome.MT graph
+    (integration_tests/test_align.py:209-268) reproduced end to end: BOSS dump of the CANONICAL-mode fixture graph -> C++ adapter
+    -> libmgx.so -> TSV, byte for byte."""
+    from test_oracle_canonical import CANONICAL, CANONICAL_LINES, SUBK_LINE_5
+    cli = KATS["cli"]
+    g = orc.Graph.build(cli["k"], read_fasta(os.path.join(HERE, "golden", cli["graph_fasta"])), CANONICAL, False)
+    W, last, F, _ = g.export()
+    dump = tmp_path / "mt.canonical.boss"
+    with open(dump, "wb") as f:
+        f.write(struct.pack("<7Q", g.k, g.n_edges, *[int(x) for x in F]))
+        f.write(W.tobytes())
+        f.write(last.tobytes())
+    exe = os.path.join(ROOT, "metagraph_amd", "_build", "mgx_align")
+    reads = os.path.join(HERE, "golden", cli["reads_fastq"])
+    for extra, line5 in (([], None), (["--align-min-seed-length", "10"], SUBK_LINE_5)):
+        r = subprocess.run([exe, str(dump), reads, "--canonical", "--align-min-exact-match", "0.0"] + extra,
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        lines = r.stdout.rstrip("\n").split("\n")
+        assert len(lines) == 7
+        for i, want in CANONICAL_LINES.items():
+            assert lines[i] == want
+        if line5:
+            assert lines[5] == line5
