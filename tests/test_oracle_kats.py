@@ -246,3 +246,29 @@ def test_json_output_is_byte_identical_to_the_reference_goldens(edit_distance, n
     for i, line in enumerate(want):
         header = reads[i][0].lstrip("@").split()[0]
         assert capi.format_json(view, i, header, reads[i][1], cli["k"]) == line
+
+
+def test_json_output_of_secondary_and_empty_results_is_well_formed():
+    """No golden covers these two shapes; they follow Alignment::to_json directly (alignment.cpp:883-963): a second alignment
+    of a query carries "is_secondary":true (cli/align.cpp:291-298), a query without alignments prints the JSON of an empty
+    Alignment — its name and an empty sequence (:299-302).  Every line must parse, keys in jsoncpp's (lexicographic) order."""
+    import ctypes as C
+    import json
+    from test_alt_paths import QUERY, MATCH, K, _graph, _config
+    g = _graph()
+    cfg = _config(10.0, 27, 0.0)
+    run = orc.AlignRun(g, cfg, [QUERY, "ACGTACGTACGTACGTACGTAAAAAA"])
+    view = capi.Results()
+    orc.L().orc_results_view(run.r, C.byref(view))
+    lines = capi.format_json(view, 0, "q0", QUERY, K).splitlines()
+    assert len(lines) == 2
+    first, second = (json.loads(l) for l in lines)
+    assert "is_secondary" not in first and second["is_secondary"] is True
+    for js, line in ((first, lines[0]), (second, lines[1])):
+        assert js["name"] == "q0" and js["read_mapped"] is True
+        assert [m["rank"] for m in js["path"]["mapping"]] == list(range(1, js["path"]["length"] + 1))
+        assert list(js.keys()) == sorted(js.keys()) and line.startswith('{"annotation":{"cigar":"')
+    empty = capi.format_json(view, 1, "q1", "ACGTACGTACGTACGTACGTAAAAAA", K)
+    if view.aln_begin[1] == view.aln_begin[2]:
+        assert empty == '{"name":"q1","sequence":""}\n'
+    assert MATCH
