@@ -147,6 +147,30 @@ uint32_t orc_graph_outgoing(void *h, uint64_t v, int rc, uint64_t *nodes, char *
     view.call_outgoing_kmers(v, [&](node_t nn, char c) { if (n < 8) { nodes[n] = nn; chars[n] = c; } ++n; });
     return n;
 }
+// ---- CanonicalDBG wrapper over the (PRIMARY) graph h, for the wrapper's own KATs (tests/test_oracle_canonical_wrapper.py) ----
+// dir: 0 = call_outgoing_kmers, 1 = call_incoming_kmers; up to 8 (node, char) pairs; returns count
+uint32_t orc_canonical_adjacent(void *h, uint64_t v, int dir, uint64_t *nodes, char *chars) {
+    CanonicalView view(*static_cast<Graph *>(h));
+    uint32_t n = 0;
+    auto cb = [&](node_t nn, char c) { if (n < 8) { nodes[n] = nn; chars[n] = c; } ++n; };
+    if (dir == 0) view.call_outgoing_kmers(v, cb); else view.call_incoming_kmers(v, cb);
+    return n;
+}
+uint64_t orc_canonical_reverse_complement(void *h, uint64_t v) { return CanonicalView(*static_cast<Graph *>(h)).reverse_complement(v); }
+void orc_canonical_node_sequence(void *h, uint64_t v, char *out) {
+    std::string s = CanonicalView(*static_cast<Graph *>(h)).get_node_sequence(v);
+    std::memcpy(out, s.data(), s.size());
+}
+// map_to_nodes_sequentially; out has len - k + 1 entries
+void orc_canonical_map(void *h, const char *seq, uint32_t len, uint64_t *out) {
+    auto nodes = CanonicalView(*static_cast<Graph *>(h)).map_to_nodes_sequentially(std::string_view(seq, len));
+    for (size_t i = 0; i < nodes.size(); ++i) out[i] = nodes[i];
+}
+int orc_canonical_degrees(void *h, uint64_t v) {
+    CanonicalView view(*static_cast<Graph *>(h));
+    return (view.has_multiple_outgoing(v) ? 1 : 0) | (view.has_single_incoming(v) ? 2 : 0);
+}
+
 // suffix matching; returns number of nodes (written up to cap), *match_len = matched length
 uint32_t orc_graph_suffix_match(void *h, const char *str, uint32_t len, uint32_t min_len, uint64_t max_matches,
                                 uint64_t *nodes, uint32_t cap, uint32_t *match_len) {

@@ -591,4 +591,195 @@ std::string GraphView::get_node_sequence(node_t v) const {
     return s;
 }
 
+// ---------------------------------------------------------------------------------------------
+// CanonicalView (CanonicalDBG over a PRIMARY DBGSuccinct)
+// ---------------------------------------------------------------------------------------------
+CanonicalView::CanonicalView(const Graph &base)
+      : g(&base), offset(base.max_index()), k_odd(base.get_k() % 2), has_sentinel(base.valid.empty()) {}
+
+node_t CanonicalView::reverse_complement(node_t v) const {
+    // canonical_dbg.cpp:515-549 (the palindrome cache only memoises the string comparison below)
+    if (v > offset) return v - offset;
+    if (k_odd) return v + offset;
+    std::string seq = g->get_node_sequence(v), rev = seq;
+    reverse_complement_inplace(rev);
+    return rev == seq ? v : v + offset;
+}
+
+void CanonicalView::reverse_complement(std::string &seq, std::vector<node_t> &path) const {
+    // :551-560
+    reverse_complement_inplace(seq);
+    std::vector<node_t> rev(path.size());
+    for (size_t i = 0; i < path.size(); ++i) rev[path.size() - 1 - i] = path[i] ? reverse_complement(path[i]) : path[i];
+    path.swap(rev);
+}
+
+std::vector<node_t> CanonicalView::map_to_nodes_sequentially(std::string_view sequence) const {
+    // :55-146 without terminate(); the k-odd BOSS shortcut (:96-126: skip the forward look-up of k-mers found on the
+    // other strand) yields what the plain branch does: a node found forward wins, else the one found in the reverse
+    // complement (+offset), else npos — for odd k no k-mer is in the base graph on both strands
+    std::vector<node_t> out;
+    const size_t k = get_k();
+    if (sequence.size() < k) return out;
+    const size_t total = sequence.size() - k + 1;
+    std::vector<node_t> fwd = g->map_to_nodes_sequentially(sequence);
+    size_t matched = 0;
+    while (matched < fwd.size() && fwd[matched]) ++matched;           // "map until the first mismatch"
+    for (size_t i = 0; i < matched; ++i) out.push_back(fwd[i]);
+    if (matched == total) return out;
+    std::string_view rest = sequence.substr(matched);
+    std::string rev_seq(rest);
+    reverse_complement_inplace(rev_seq);
+    std::vector<node_t> rev_path = g->map_to_nodes_sequentially(rev_seq);
+    std::vector<node_t> path = g->map_to_nodes_sequentially(rest);
+    for (size_t j = 0; j < path.size(); ++j) {
+        node_t r = rev_path[rev_path.size() - 1 - j];
+        if (path[j]) out.push_back(path[j]);
+        else if (r) out.push_back(r + offset);
+        else out.push_back(NPOS);
+    }
+    return out;
+}
+
+std::string CanonicalView::get_node_sequence(node_t v) const {
+    node_t base = get_base_node(v);
+    std::string seq = g->get_node_sequence(base);
+    if (base != v) reverse_complement_inplace(seq);
+    return seq;
+}
+
+edge_t CanonicalView::prefix_rc(node_t, const std::string &spelling) const {
+    // node_first_cache.cpp:120-146
+    std::string rev = spelling;
+    rev.pop_back();
+    if (rev[0] == '$') return 0;
+    reverse_complement_inplace(rev);
+    auto enc = encode_seq(rev);
+    auto [e1, e2, len] = g->boss.index_range(enc.data(), enc.data() + enc.size());
+    (void)e1;
+    return len == enc.size() ? e2 : 0;
+}
+
+edge_t CanonicalView::suffix_rc(node_t, const std::string &spelling) const {
+    // node_first_cache.cpp:148-174
+    std::string rev = spelling.substr(1);
+    if (rev[0] == '$') return 0;
+    reverse_complement_inplace(rev);
+    auto enc = encode_seq(rev);
+    auto [e1, e2, len] = g->boss.index_range(enc.data(), enc.data() + enc.size());
+    (void)e2;
+    return len == enc.size() ? e1 : 0;
+}
+
+void CanonicalView::adjacent_incoming_rc_strand(node_t v, const std::string &hint,
+                                                const std::function<void(node_t, char)> &cb) const {
+    // :574-632 (DBGSuccinct branch): AGCCAT -> *AGCCA -> TGGCT*; children of the node TGGCT in the base graph
+    const Boss &boss = g->boss;
+    edge_t rc_edge = prefix_rc(v, hint);
+    if (!rc_edge) return;
+    edge_t e = rc_edge;                                  // BOSS::call_outgoing (boss.hpp:779-784)
+    do {
+        node_t prev = e;
+        if (g->in_graph(prev)) {
+            char c = decode_code(boss.get_W(e) % SIGMA);
+            if (!(hint.back() == '$' && c == '$')) cb(prev, c);
+        }
+    } while (--e && !boss.get_last(e));
+}
+
+void CanonicalView::adjacent_outgoing_rc_strand(node_t v, const std::string &hint,
+                                                const std::function<void(node_t, char)> &cb) const {
+    // :634-684 (DBGSuccinct branch): ATGGCT -> TGGCT* -> *AGCCA; parents of the node AGCCA in the base graph
+    const Boss &boss = g->boss;
+    edge_t rc_edge = suffix_rc(v, hint);
+    if (!rc_edge) return;
+    boss.call_incoming_to_target(boss.bwd(rc_edge), boss.get_node_last_value(rc_edge), [&](edge_t prev_edge) {
+        node_t prev = prev_edge;
+        if (!g->in_graph(prev)) return;
+        char c = decode_code(boss.get_node_seq(prev_edge)[0]);         // get_first_char (node_first_cache.cpp:9-23)
+        if (hint[0] == '$' && c == '$') return;
+        cb(prev, c);
+    });
+}
+
+void CanonicalView::call_outgoing_kmers(node_t v, const std::string &hint,
+                                        const std::function<void(node_t, char)> &cb) const {
+    // :156-240
+    if (v > offset) {
+        std::string rc_hint = hint;
+        reverse_complement_inplace(rc_hint);
+        call_incoming_kmers(v - offset, rc_hint, [&](node_t next, char c) { cb(reverse_complement(next), complement_char(c)); });
+        return;
+    }
+    node_t children[SIGMA] = { 0, 0, 0, 0, 0 };
+    size_t left = SIGMA - (has_sentinel ? 1 : 0);
+    g->call_outgoing_kmers(v, [&](node_t next, char c) {
+        if (c != '$') { cb(next, c); --left; }
+        children[encode_char(c) % SIGMA] = next;            // '$' -> 0
+    });
+    if (!left) return;
+    adjacent_outgoing_rc_strand(v, hint, [&](node_t next, char c) {
+        c = complement_char(c);
+        uint8_t s = c == '$' ? 0 : encode_char(c);
+        if (children[s] != NPOS && c != '$') {
+            if (k_odd) throw std::runtime_error("primary graph contains both forward and reverse complement");
+            return;                                          // `next` is a palindrome
+        }
+        next = reverse_complement(next);
+        if (c != '$') { cb(next, c); children[s] = next; --left; }
+    });
+    if (has_sentinel && children[0] && left + 1 == (size_t)SIGMA) cb(children[0], '$');
+}
+
+void CanonicalView::call_incoming_kmers(node_t v, const std::string &hint,
+                                        const std::function<void(node_t, char)> &cb) const {
+    // :242-330
+    if (v > offset) {
+        std::string rc_hint = hint;
+        reverse_complement_inplace(rc_hint);
+        call_outgoing_kmers(v - offset, rc_hint, [&](node_t prev, char c) { cb(reverse_complement(prev), complement_char(c)); });
+        return;
+    }
+    node_t parents[SIGMA] = { 0, 0, 0, 0, 0 };
+    size_t left = SIGMA - (has_sentinel ? 1 : 0);
+    g->call_incoming_kmers(v, [&](node_t prev, char c) {       // NodeFirstCache::call_incoming_kmers
+        if (c != '$') { cb(prev, c); --left; }
+        parents[c == '$' ? 0 : encode_char(c)] = prev;
+    });
+    if (!left) return;
+    adjacent_incoming_rc_strand(v, hint, [&](node_t prev, char c) {
+        c = complement_char(c);
+        uint8_t s = c == '$' ? 0 : encode_char(c);
+        if (parents[s] != NPOS && c != '$') {
+            if (k_odd) throw std::runtime_error("primary graph contains both forward and reverse complement");
+            return;
+        }
+        prev = reverse_complement(prev);
+        if (c != '$') { cb(prev, c); parents[s] = prev; --left; }
+    });
+    if (has_sentinel && parents[0] && left + 1 == (size_t)SIGMA) cb(parents[0], '$');
+}
+
+void CanonicalView::adjacent_incoming_nodes(node_t v, const std::function<void(node_t)> &cb) const {
+    if (v > offset) adjacent_outgoing_nodes(v - offset, [&](node_t prev) { cb(reverse_complement(prev)); });
+    else call_incoming_kmers(v, [&](node_t prev, char) { cb(prev); });
+}
+
+void CanonicalView::adjacent_outgoing_nodes(node_t v, const std::function<void(node_t)> &cb) const {
+    if (v > offset) adjacent_incoming_nodes(v - offset, [&](node_t next) { cb(reverse_complement(next)); });
+    else call_outgoing_kmers(v, [&](node_t next, char) { cb(next); });
+}
+
+bool CanonicalView::has_multiple_outgoing(node_t v) const {
+    size_t n = 0;
+    adjacent_outgoing_nodes(v, [&](node_t) { ++n; });
+    return n > 1;
+}
+
+bool CanonicalView::has_single_incoming(node_t v) const {
+    size_t n = 0;
+    adjacent_incoming_nodes(v, [&](node_t) { ++n; });
+    return n == 1;
+}
+
 } // namespace orc

@@ -128,4 +128,37 @@ struct GraphView {
     std::string get_node_sequence(node_t v) const;           // rc_dbg.hpp:118-122
 };
 
+// CanonicalDBG over a PRIMARY DBGSuccinct (graph/representation/canonical_dbg.{hpp,cpp}): every k-mer of the base graph
+// also stands for its reverse complement, which gets the id base + offset (offset = base graph's max_index).  Caches of the
+// reference (NodeFirstCache LRUs, is_palindrome_cache_) do not change results and are not modelled.
+struct CanonicalView {
+    const Graph *g = nullptr;
+    uint64_t offset = 0;                 // canonical_dbg.cpp:26
+    bool k_odd = false;                  // :27
+    bool has_sentinel = false;           // :41 (!dbg_succ->get_mask())
+    explicit CanonicalView(const Graph &base);
+
+    size_t get_k() const { return g->get_k(); }
+    uint64_t max_index() const { return 2 * offset; }        // canonical_dbg.hpp
+    node_t get_base_node(node_t v) const { return v > offset ? v - offset : v; }
+    node_t reverse_complement(node_t v) const;               // canonical_dbg.cpp:515-549
+    void reverse_complement(std::string &seq, std::vector<node_t> &path) const;   // :551-560
+    std::vector<node_t> map_to_nodes_sequentially(std::string_view seq) const;     // :55-146
+    std::string get_node_sequence(node_t v) const;           // :423-432
+    void call_outgoing_kmers(node_t v, const std::string &hint, const std::function<void(node_t, char)> &cb) const;   // :156-240
+    void call_incoming_kmers(node_t v, const std::string &hint, const std::function<void(node_t, char)> &cb) const;   // :242-330
+    void call_outgoing_kmers(node_t v, const std::function<void(node_t, char)> &cb) const { call_outgoing_kmers(v, get_node_sequence(v), cb); }
+    void call_incoming_kmers(node_t v, const std::function<void(node_t, char)> &cb) const { call_incoming_kmers(v, get_node_sequence(v), cb); }
+    void adjacent_outgoing_nodes(node_t v, const std::function<void(node_t)> &cb) const;   // :346-359
+    void adjacent_incoming_nodes(node_t v, const std::function<void(node_t)> &cb) const;   // :331-344
+    bool has_multiple_outgoing(node_t v) const;              // :361-375
+    bool has_single_incoming(node_t v) const;                // :377-387
+
+  private:
+    edge_t prefix_rc(node_t v, const std::string &spelling) const;     // NodeFirstCache::get_prefix_rc, node_first_cache.cpp:120-146
+    edge_t suffix_rc(node_t v, const std::string &spelling) const;     // NodeFirstCache::get_suffix_rc, :148-174
+    void adjacent_incoming_rc_strand(node_t v, const std::string &hint, const std::function<void(node_t, char)> &cb) const;  // :574-632
+    void adjacent_outgoing_rc_strand(node_t v, const std::string &hint, const std::function<void(node_t, char)> &cb) const;  // :634-684
+};
+
 } // namespace orc

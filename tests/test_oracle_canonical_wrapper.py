@@ -1,0 +1,119 @@
+"""The CanonicalDBG wrapper over PRIMARY DBGSuccinct graphs restated in the oracle (graph/representation/canonical_dbg.cpp:
+node space base + offset, map_to_nodes_sequentially :55-146, call_outgoing_kmers / call_incoming_kmers through the reverse
+complement's (k-1)-mer range :156-330,574-684, reverse_complement :515-560) against the wrapper's own KATs
+(tests/graph/test_canonical_dbg.cpp: InsertSequence :73-85, ReverseComplement :87-101, Traversals1 :103-158, Traversals2
+:160-195).  Groundwork for SURVEY 8(f) rank 1: the aligner does not run on this view yet.  The reference's test helper builds
+PRIMARY graphs from primary contigs; here the inputs are chosen so that the sequences themselves hold one k-mer of every
+pair (the assertions do not depend on which one)."""
+import ctypes as C
+
+import pytest
+
+import orc
+
+PRIMARY = 2
+
+
+def _L():
+    L = orc.L()
+    if not getattr(L, "_canon_ready", False):
+        L.orc_canonical_adjacent.restype = C.c_uint32
+        L.orc_canonical_adjacent.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_char_p]
+        L.orc_canonical_reverse_complement.restype = C.c_uint64
+        L.orc_canonical_reverse_complement.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_canonical_node_sequence.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p]
+        L.orc_canonical_map.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.orc_canonical_degrees.restype = C.c_int
+        L.orc_canonical_degrees.argtypes = [C.c_void_p, C.c_uint64]
+        L._canon_ready = True
+    return L
+
+
+def cmap(g, seq):
+    n = len(seq) - g.k + 1
+    out = (C.c_uint64 * max(1, n))()
+    _L().orc_canonical_map(g.h, seq.encode(), len(seq), out)
+    return [out[i] for i in range(max(0, n))]
+
+
+def adjacent(g, v, direction):
+    nodes = (C.c_uint64 * 8)()
+    chars = C.create_string_buffer(8)
+    n = _L().orc_canonical_adjacent(g.h, v, direction, nodes, chars)
+    return [(nodes[i], chars.raw[i:i + 1].decode()) for i in range(n)]
+
+
+def traverse(g, v, c):           # CanonicalDBG::traverse == the child reached over c
+    hits = [n for n, ch in adjacent(g, v, 0) if ch == c]
+    assert len(hits) <= 1
+    return hits[0] if hits else 0
+
+
+def traverse_back(g, v, c):
+    hits = [n for n, ch in adjacent(g, v, 1) if ch == c]
+    assert len(hits) <= 1
+    return hits[0] if hits else 0
+
+
+def node_seq(g, v):
+    buf = C.create_string_buffer(g.k)
+    _L().orc_canonical_node_sequence(g.h, v, buf)
+    return buf.raw[:g.k].decode()
+
+
+def rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def find(g, seq):
+    nodes = cmap(g, seq)
+    return bool(nodes) and all(nodes)
+
+
+def test_insert_sequence_and_reverse_complement():
+    # :73-101
+    g = orc.Graph.build(21, ["AAAAAAAAAAAAAAAAAAAAAAAAAAAAA", "CATGTACTAGCTGATCGTAGCTAGCTAGC"], 0, True)
+    assert find(g, "AAAAAAAAAAAAAAAAAAAAAAAAAAAAA") and find(g, "TTTTTTTTTTTTTTTTTTTTTTTTTTTTT")
+    assert find(g, "CATGTACTAGCTGATCGTAGCTAGCTAGC") and find(g, "GCTAGCTAGCTACGATCAGCTAGTACATG")
+    assert not find(g, "CATGTTTTTTTAATATATATATTTTTAGC") and not find(g, "GCTAAAAATATATATATTAAAAAAACATG")
+    # every k-mer and its mirror: ids differ by the offset, spellings are reverse complements
+    fwd = cmap(g, "CATGTACTAGCTGATCGTAGCTAGCTAGC")
+    rev = cmap(g, "GCTAGCTAGCTACGATCAGCTAGTACATG")
+    for a, b in zip(fwd, reversed(rev)):
+        assert _L().orc_canonical_reverse_complement(g.h, a) == b and _L().orc_canonical_reverse_complement(g.h, b) == a
+        assert node_seq(g, b) == rc(node_seq(g, a))
+
+
+@pytest.mark.parametrize("k", range(2, 10))
+def test_traversals1(k):
+    # :103-158
+    g = orc.Graph.build(k, ["A" * 100 + "C" * 100], 0, True)
+    it, jt = cmap(g, "A" * k)[-1], cmap(g, "T" * k)[-1]
+    assert it and jt and _L().orc_canonical_reverse_complement(g.h, it) == jt
+    it2 = cmap(g, "A" * (k - 1) + "C")[-1]
+    jt2 = cmap(g, "G" + "T" * (k - 1))[-1]
+    assert it2 and jt2
+    assert traverse(g, it, "A") == it and traverse(g, it, "C") == it2 and traverse_back(g, it2, "A") == it
+    assert traverse(g, jt, "T") == jt and traverse_back(g, jt, "G") == jt2 and traverse(g, jt2, "T") == jt
+    assert traverse(g, it, "G") == 0 and traverse_back(g, it2, "G") == 0
+    it = cmap(g, "G" * k)[-1]
+    assert it and cmap(g, "C" * k)[-1] == _L().orc_canonical_reverse_complement(g.h, it)
+    it2 = cmap(g, "G" * (k - 1) + "T")[-1]
+    assert it2
+    assert traverse(g, it, "A") == 0 and traverse(g, it, "G") == it and traverse(g, it, "T") == it2
+    assert traverse_back(g, it2, "G") == it
+
+
+@pytest.mark.parametrize("k", range(2, 11))
+def test_traversals2(k):
+    # :160-195 (the second input sequence of the reference test is the reverse complement of the first: one strand suffices)
+    g = orc.Graph.build(k, ["A" * 100 + "C" * 100], 0, True)
+    it = cmap(g, "A" * k)[-1]
+    assert it and traverse(g, it, "A") == it
+    nxt = traverse(g, it, "C")
+    assert nxt and nxt != it and traverse_back(g, nxt, "A") == it
+    assert traverse(g, it, "G") == 0 and traverse_back(g, it, "G") == 0
+    it = cmap(g, "G" * k)[-1]
+    assert it and traverse(g, it, "G") == it
+    assert traverse(g, it, "T") == cmap(g, "G" * (k - 1) + "T")[-1]
+    assert traverse_back(g, traverse(g, it, "T"), "G") == it
