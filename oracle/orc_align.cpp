@@ -222,25 +222,23 @@ void Alignment::reverse_complement(const GraphView &graph, std::string_view quer
         }
         return;
     }
-    // The generic branch (:563-702): the graph itself holds the reverse complement (CANONICAL-mode DBGSuccinct; the
-    // CanonicalDBG wrapper of PRIMARY graphs is not restated yet — SURVEY 8f rank 1).
+    // The generic branch (:563-702): the graph holds the reverse complement itself — a CANONICAL-mode DBGSuccinct or a
+    // PRIMARY one behind the CanonicalDBG wrapper (graph.canon).
     const Graph &g = *graph.g;
-    if (g.mode != CANONICAL)
+    const CanonicalView *canonical = graph.canon;
+    if (g.mode != CANONICAL && !canonical)
         throw std::runtime_error("orc::Alignment::reverse_complement: plain graphs are reversed through the RCDBG view");
-    auto rc_seq_path = [&]() {                         // reverse_complement_seq_path, sequence_graph.cpp:563-573
-        reverse_complement_inplace(sequence);
-        nodes = g.map_to_nodes_sequentially(sequence);
-    };
     if (!offset) {
-        rc_seq_path();
+        graph.reverse_complement_seq_path(sequence, nodes);
     } else {
         // :566-693: one node, `offset` characters of its k-mer are not part of the alignment
-        sequence = g.get_node_sequence(nodes[0]).substr(0, offset) + sequence;
+        sequence = graph.get_node_sequence(nodes[0]).substr(0, offset) + sequence;
         if (sequence[0] == '$') {
             // :569-651: a source dummy k-mer: walk forwards (always the last outgoing edge) until the k-mer holds no sentinel
             const Boss &boss = g.boss;
             size_t num_sentinels = sequence.find_last_of('$') + 1;
-            size_t num_first_steps = offset;           // no CanonicalDBG wrapper here
+            if (canonical && nodes[0] != canonical->get_base_node(nodes[0])) { *this = Alignment(); return; }   // :592-597
+            size_t num_first_steps = canonical ? std::min(offset, num_sentinels) : offset;
             edge_t edge = nodes[0];
             uint8_t edge_label = boss.get_W(edge) % SIGMA;
             for (size_t i = 0; i < num_first_steps; ++i) {
@@ -250,17 +248,28 @@ void Alignment::reverse_complement(const GraphView &graph, std::string_view quer
                 nodes[0] = g.validate_edge(edge);
                 sequence.push_back(decode_code(edge_label));
             }
-            (void)num_sentinels;
+            for (size_t i = num_first_steps; i < offset; ++i) {            // :626-645 (CanonicalDBG only)
+                node_t next_node = 0;
+                char last_char = 0;
+                canonical->call_outgoing_kmers(nodes[0], [&](node_t next, char c) {
+                    if (c == '$') return;
+                    next_node = next;
+                    last_char = c;
+                });
+                if (!next_node) { *this = Alignment(); return; }
+                nodes[0] = next_node;
+                sequence.push_back(last_char);
+            }
             sequence = sequence.substr(offset);
-            rc_seq_path();
+            graph.reverse_complement_seq_path(sequence, nodes);
             sequence.assign(sequence.data() + offset, g.get_k() - offset);
         } else {
-            rc_seq_path();
+            graph.reverse_complement_seq_path(sequence, nodes);
             // :667-689: trim the ending of the reverse complement that corresponds to the added prefix; of several
             // possible predecessors the first one is taken
             for (size_t i = 0; i < offset; ++i) {
                 size_t indegree = 0;
-                g.call_incoming_kmers(nodes[0], [&](node_t prev, char) {
+                graph.adjacent_incoming_nodes(nodes[0], [&](node_t prev) {
                     ++indegree;
                     if (indegree == 1) nodes[0] = prev;
                 });
@@ -496,13 +505,13 @@ std::vector<Seed> exact_get_seeds(const Graph &graph, std::string_view query, bo
     return seeds;
 }
 
-std::vector<Seed> mem_get_seeds(const Graph &graph, std::string_view query, bool orientation,
+std::vector<Seed> mem_get_seeds(const GraphView &graph, std::string_view query, bool orientation,
                                 const std::vector<node_t> &query_nodes, const mgx_config &config,
                                 size_t num_matching, WorkCounters *wc) {
     // aligner_seeder_methods.cpp:360-424 with the UniMEMSeeder terminator (hpp:116-135)
     size_t k = graph.get_k();
     if (k >= config.max_seed_length)
-        return exact_get_seeds(graph, query, orientation, query_nodes, config, num_matching);
+        return exact_get_seeds(*graph.g, query, orientation, query_nodes, config, num_matching);
     if (num_matching < config.min_exact_match * query.size()) return {};
 
     std::vector<uint8_t> flags(query_nodes.size(), 0);
@@ -537,9 +546,10 @@ std::vector<Seed> mem_get_seeds(const Graph &graph, std::string_view query, bool
 }
 
 // SuffixSeeder<UniMEMSeeder>(graph, query, orientation, nodes, config): ctor + generate_seeds()
-SeederState make_suffix_seeder(const Graph &graph, std::string_view query, bool orientation,
+SeederState make_suffix_seeder(const GraphView &view, std::string_view query, bool orientation,
                                const std::vector<node_t> &query_nodes, const mgx_config &config,
                                WorkCounters *wc) {
+    const Graph &graph = *view.g;                    // get_base_dbg_succ (:141-151)
     SeederState st;
     size_t k = graph.get_k();
     st.num_matching = num_exact_matching(query_nodes, k);           // ExactSeeder ctor (:37-47)
@@ -547,7 +557,7 @@ SeederState make_suffix_seeder(const Graph &graph, std::string_view query, bool 
     // generate_seeds (:153-358)
     if (query.size() < config.min_seed_length) return st;
     if (config.min_seed_length >= k) {
-        st.seeds = mem_get_seeds(graph, query, orientation, query_nodes, config, st.num_matching, wc);
+        st.seeds = mem_get_seeds(view, query, orientation, query_nodes, config, st.num_matching, wc);
         return st;
     }
 
@@ -555,7 +565,7 @@ SeederState make_suffix_seeder(const Graph &graph, std::string_view query, bool 
     std::vector<std::vector<Seed>> suffix_seeds(nslots);
     std::vector<size_t> min_seed_length(nslots, config.min_seed_length);
 
-    for (auto &&seed : mem_get_seeds(graph, query, orientation, query_nodes, config, st.num_matching, wc)) {
+    for (auto &&seed : mem_get_seeds(view, query, orientation, query_nodes, config, st.num_matching, wc)) {
         size_t i = seed.clipping;
         for (size_t j = 0; j < seed.nodes.size(); ++j) min_seed_length[i + j] = k;
         if (i + seed.nodes.size() < min_seed_length.size()) min_seed_length[i + seed.nodes.size()] = k;
@@ -594,6 +604,50 @@ SeederState make_suffix_seeder(const Graph &graph, std::string_view query, bool 
                 && alt_nodes[0] == suffix_seeds[last_full_id - 1][0].nodes[0])
             continue;
         for (node_t alt_node : alt_nodes) append_suffix_seed(i, alt_node, seed_length);
+    }
+
+    if (const CanonicalView *canonical = view.canon) {
+        // :251-314: sub-k matches in the reverse complement.  Matching is query prefix -> node suffix, so the query index j of
+        // a match to the reverse complement follows from the match length.
+        std::string query_rc(query);
+        reverse_complement_inplace(query_rc);
+        const Boss &boss = graph.boss;
+        for (size_t i = 0; i + config.min_seed_length <= query_rc.size(); ++i) {
+            size_t max_seed_length = std::min({ (size_t)config.max_seed_length, k - 1, query.size() - i });
+            size_t j_min = query_rc.size() - i - max_seed_length;
+            size_t j_max = query_rc.size() - i - config.min_seed_length;
+            while (j_min <= j_max && min_seed_length[j_min] > max_seed_length) { ++j_min; --max_seed_length; }
+            if (j_min > j_max) continue;
+            auto encoded = encode_seq(std::string_view(query_rc.data() + i, max_seed_length));
+            auto [first, last, seed_length] = boss.index_range(encoded.data(), encoded.data() + encoded.size());
+            size_t j = query_rc.size() - i - seed_length;
+            if (seed_length < config.min_seed_length || seed_length < min_seed_length[j]
+                    || (config.seed_complexity_filter && is_low_complexity(query.substr(j, seed_length))))
+                continue;
+            // suffix_to_prefix (:95-139): matched ***ATG, want ATG***: every node whose PREFIX is the match
+            using Range = std::tuple<edge_t, edge_t, size_t>;
+            auto call_nodes_in_range = [&](const Range &r) {
+                for (edge_t e = std::get<0>(r); e <= std::get<1>(r); ++e) {
+                    node_t node = graph.validate_edge(e);
+                    if (node) append_suffix_seed(j, canonical->reverse_complement(node), seed_length);
+                }
+            };
+            Range start(boss.pred_last(first - 1) + 1, last, seed_length);
+            if (seed_length == boss.k_) { call_nodes_in_range(start); continue; }
+            std::vector<Range> stack{ start };
+            while (!stack.empty()) {
+                Range cur = stack.back();
+                stack.pop_back();
+                ++std::get<2>(cur);
+                for (uint8_t c = 1; c < SIGMA; ++c) {
+                    Range next = cur;
+                    if (boss.tighten_range(&std::get<0>(next), &std::get<1>(next), c)) {
+                        if (std::get<2>(next) == boss.k_) call_nodes_in_range(next);
+                        else stack.push_back(next);
+                    }
+                }
+            }
+        }
     }
 
     // aggregate (:316-357)
@@ -736,10 +790,12 @@ void extend_ins_end(PVec &S, PVec &E, PVec &F, size_t max_size, score_t xdrop_cu
 
 class Extender {
   public:
-    Extender(const Graph &graph, const mgx_config &config, std::string_view query, WorkCounters *wc)
+    Extender(const Graph &graph, const mgx_config &config, std::string_view query, WorkCounters *wc,
+             const CanonicalView *canon = nullptr)
           : base_(&graph), config_(config), query_(query), wc_(wc) {
         view_.g = &graph;
         view_.rc = false;
+        view_.canon = canon;
         // aligner_extender_methods.cpp:22-60
         partial_sums_.assign(query_.size(), 0);
         for (size_t i = 0; i < query_.size(); ++i) partial_sums_[i] = sm(query_[i], query_[i]);
@@ -1333,8 +1389,7 @@ Aligner::Aligner(const Graph &graph, const mgx_config &config) : graph_(graph), 
     if (!check_config_scores(config_))
         throw std::runtime_error("Error: sum of min_cell_score and lowest penalty too low.");
     if (config_.chain_alignments) config_.allow_left_trim = false;
-    // PRIMARY graphs must be wrapped into CanonicalDBG (dbg_aligner.cpp:52-53), which is not restated yet
-    if (graph_.mode == PRIMARY) throw std::runtime_error("oracle: PRIMARY graphs (CanonicalDBG wrapper) are not restated");
+    // PRIMARY graphs are wrapped into CanonicalDBG (dbg_aligner.cpp:52-53; cli/align.cpp:383-399 wrap_graph)
     if (config_.chain_alignments || config_.post_chain_alignments || !config_.global_xdrop || config_.no_backtrack)
         throw std::runtime_error("oracle: chaining / per-branch xdrop / no_backtrack are out of scope");
 }
@@ -1351,6 +1406,11 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
     results->clear();
     results->resize(queries.size());
     const size_t k = graph_.get_k();
+    // a PRIMARY graph is seen through the CanonicalDBG wrapper, which reports CANONICAL mode (canonical_dbg.hpp)
+    const CanonicalView canon_store(graph_);
+    const CanonicalView *canon = graph_.mode == PRIMARY ? &canon_store : nullptr;
+    const GraphView gview{ &graph_, false, canon };
+    const bool canonical_mode = graph_.mode == CANONICAL || canon;
 
     for (size_t qi = 0; qi < queries.size(); ++qi) {
         const std::string &raw = queries[qi];
@@ -1372,27 +1432,26 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
         // build_seeders (dbg_aligner.cpp:193-248)
         std::vector<node_t> nodes;
         if (config_.max_seed_length >= k) {
-            nodes = graph_.map_to_nodes_sequentially(raw);
+            nodes = gview.map_to_nodes_sequentially(raw);
             wc.n_map_fwd += nodes.size();
         } else if (this_query.size() >= k) {
             nodes.resize(this_query.size() - k + 1);
         }
         res.nodes_fwd = nodes;
-        SeederState seeder = make_suffix_seeder(graph_, this_query, false, nodes, config_, &wc);
+        SeederState seeder = make_suffix_seeder(gview, this_query, false, nodes, config_, &wc);
         if (this_query.size() * config_.min_exact_match > seeder.num_matching) { seeder.seeds.clear(); seeder.num_matching = 0; }
 
-        bool have_rc = config_.forward_and_reverse_complement || graph_.mode == CANONICAL;     // dbg_aligner.cpp:225-226
+        bool have_rc = config_.forward_and_reverse_complement || canonical_mode;              // dbg_aligner.cpp:225-226
         SeederState seeder_rc;
         if (have_rc) {
             std::vector<node_t> nodes_rc = nodes;
             if (config_.max_seed_length >= k) {
                 std::string dummy(raw);
-                reverse_complement_inplace(dummy);              // sequence_graph.cpp:563-573 (BASIC)
-                nodes_rc = graph_.map_to_nodes_sequentially(dummy);
+                gview.reverse_complement_seq_path(dummy, nodes_rc);        // sequence_graph.cpp:563-573
                 wc.n_map_fwd += nodes_rc.size();
             }
             res.nodes_rc = nodes_rc;
-            seeder_rc = make_suffix_seeder(graph_, reverse, true, nodes_rc, config_, &wc);
+            seeder_rc = make_suffix_seeder(gview, reverse, true, nodes_rc, config_, &wc);
             if (reverse.size() * config_.min_exact_match > seeder_rc.num_matching) { seeder_rc.seeds.clear(); seeder_rc.num_matching = 0; }
         }
         res.seeds_fwd = seeder.seeds;
@@ -1407,9 +1466,9 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
             return std::max(config_.min_path_score, aggregator.get_global_cutoff());
         };
 
-        Extender extender(graph_, config_, this_query, &wc);
+        Extender extender(graph_, config_, this_query, &wc, canon);
         if (have_rc) {
-            Extender extender_rc(graph_, config_, reverse, &wc);
+            Extender extender_rc(graph_, config_, reverse, &wc, canon);
             // align_both_directions (dbg_aligner.cpp:531-758), no chaining
             auto fwd_seeds = seeds_to_alignments(seeder.seeds, config_);
             auto bwd_seeds = seeds_to_alignments(seeder_rc.seeds, config_);
@@ -1418,11 +1477,11 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
                                 Extender &fwd_extender, Extender &bwd_extender) {
                 // :644-655: a CANONICAL-mode graph holds both strands itself — the backward pass runs on the same graph, and
                 // an alignment on the reverse strand is reported as the forward-strand alignment it mirrors
-                const bool use_rcdbg = graph_.mode != CANONICAL && config_.forward_and_reverse_complement;
-                auto is_reversible = [&](const Alignment &a) { return graph_.mode == CANONICAL && a.orientation && !a.offset; };
+                const bool use_rcdbg = !canonical_mode && config_.forward_and_reverse_complement;
+                auto is_reversible = [&](const Alignment &a) { return canonical_mode && a.orientation && !a.offset; };
                 fwd_extender.set_graph(false);
                 bwd_extender.set_graph(use_rcdbg);
-                const GraphView plain{ &graph_, false };
+                const GraphView plain = gview;
                 if (seeds.empty()) return;
                 for (size_t i = 0; i < seeds.size(); ++i) {
                     if (seeds[i].empty()) continue;

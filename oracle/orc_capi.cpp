@@ -264,7 +264,8 @@ void *orc_align_batch(void *h, const mgx_config *config, const char *seqs, const
             for (auto &w : wcs) st->wc.add(w.w);
         }
         if (validate) {
-            GraphView view{ g, false };
+            const CanonicalView canon(*g);                                 // PRIMARY graphs are seen through CanonicalDBG
+            GraphView view{ g, false, g->mode == PRIMARY ? &canon : nullptr };
             const mgx_config &cfg = aligner.get_config();
             for (uint64_t i = 0; i < n; ++i)
                 for (auto &a : res[i].alignments) {

@@ -579,16 +579,37 @@ void Graph::call_nodes_with_suffix_matching_longest_prefix(
 // ---------------------------------------------------------------------------------------------
 // GraphView (RCDBG)
 // ---------------------------------------------------------------------------------------------
+uint64_t GraphView::max_index() const { return canon ? canon->max_index() : g->max_index(); }
+
 void GraphView::call_outgoing_kmers(node_t v, const std::function<void(node_t, char)> &cb) const {
+    if (canon) { canon->call_outgoing_kmers(v, cb); return; }
     if (!rc) { g->call_outgoing_kmers(v, cb); return; }
     // rc_dbg.hpp:88-99
     g->call_incoming_kmers(v, [&](node_t prev, char c) { cb(prev, complement_char(c)); });
 }
 
+void GraphView::adjacent_incoming_nodes(node_t v, const std::function<void(node_t)> &cb) const {
+    if (canon) { canon->adjacent_incoming_nodes(v, cb); return; }
+    g->call_incoming_kmers(v, [&](node_t prev, char) { cb(prev); });      // dbg_succinct.cpp:161-176
+}
+
 std::string GraphView::get_node_sequence(node_t v) const {
+    if (canon) return canon->get_node_sequence(v);
     std::string s = g->get_node_sequence(v);
     if (rc) reverse_complement_inplace(s);
     return s;
+}
+
+std::vector<node_t> GraphView::map_to_nodes_sequentially(std::string_view seq) const {
+    return canon ? canon->map_to_nodes_sequentially(seq) : g->map_to_nodes_sequentially(seq);
+}
+bool GraphView::has_multiple_outgoing(node_t v) const { return canon ? canon->has_multiple_outgoing(v) : g->has_multiple_outgoing(v); }
+bool GraphView::has_single_incoming(node_t v) const { return canon ? canon->has_single_incoming(v) : g->has_single_incoming(v); }
+
+void GraphView::reverse_complement_seq_path(std::string &seq, std::vector<node_t> &path) const {
+    if (canon) { canon->reverse_complement(seq, path); return; }          // sequence_graph.cpp:566-569
+    reverse_complement_inplace(seq);
+    path = g->map_to_nodes_sequentially(seq);
 }
 
 // ---------------------------------------------------------------------------------------------

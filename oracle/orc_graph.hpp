@@ -117,15 +117,25 @@ struct Graph {
     uint64_t num_nodes() const;
 };
 
-// View of a graph as either itself or its reverse complement (graph/representation/rc_dbg.hpp:15-154).
+struct CanonicalView;
+
+// View of a graph as itself, as its reverse complement (graph/representation/rc_dbg.hpp:15-154), or through the
+// CanonicalDBG wrapper of a PRIMARY graph (`canon`, never together with rc).
 struct GraphView {
     const Graph *g = nullptr;
     bool rc = false;
+    const CanonicalView *canon = nullptr;
     size_t get_k() const { return g->get_k(); }
-    uint64_t max_index() const { return g->max_index(); }
+    uint64_t max_index() const;
     // rc_dbg.hpp:88-99: children in the RC graph are parents in G with complemented first char
     void call_outgoing_kmers(node_t v, const std::function<void(node_t, char)> &cb) const;
+    void adjacent_incoming_nodes(node_t v, const std::function<void(node_t)> &cb) const;
     std::string get_node_sequence(node_t v) const;           // rc_dbg.hpp:118-122
+    std::vector<node_t> map_to_nodes_sequentially(std::string_view seq) const;
+    bool has_multiple_outgoing(node_t v) const;
+    bool has_single_incoming(node_t v) const;
+    // reverse_complement_seq_path (sequence_graph.cpp:563-573)
+    void reverse_complement_seq_path(std::string &seq, std::vector<node_t> &path) const;
 };
 
 // CanonicalDBG over a PRIMARY DBGSuccinct (graph/representation/canonical_dbg.{hpp,cpp}): every k-mer of the base graph

@@ -117,3 +117,53 @@ def test_traversals2(k):
     assert it and traverse(g, it, "G") == it
     assert traverse(g, it, "T") == cmap(g, "G" * (k - 1) + "T")[-1]
     assert traverse_back(g, traverse(g, it, "T"), "G") == it
+
+
+# ---- the aligner on the wrapper (PRIMARY graph + CanonicalDBG): the reference's PRIMARY KATs ----
+from metagraph_amd import capi  # noqa: E402
+
+
+def _cfg(**kw):
+    c = capi.config_default()
+    capi.set_dna_matrix(c, 2, -1, -2)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_align_suffix_seed_snp_canonical_primary_half():
+    # test_aligner.cpp:1483-1537, the DeBruijnGraph::PRIMARY iteration: DBGSuccinct(k, PRIMARY) + add_sequence(reference_rc),
+    # wrapped into CanonicalDBG; the query matches the reverse complement of what the graph stores
+    k = 18
+    reference, query = "AAAAACTTTCGAGGCCAA", "GGGGGCTTTCGAGGCCAA"
+    reference_rc = "TTGGCCTCGAAAGTTTTT"
+    g = orc.Graph.build(k, [reference_rc], PRIMARY, False)
+    cfg = _cfg(max_num_seeds_per_locus=capi.UINT64_MAX, min_cell_score=-2147483648 + 100, min_path_score=-2147483648 + 100,
+               min_seed_length=13)
+    run = orc.AlignRun(g, cfg, [query])
+    assert run.error == "", run.error
+    paths = run.results()[0]
+    assert len(paths) == 1
+    p = paths[0]
+    assert len(p["nodes"]) == 1
+    if p["sequence"] == reference[5:]:
+        assert p["cigar"] == "5S13=" and p["clipping"] == 5 and p["end_clipping"] == 0 and p["score"] == 26
+    else:
+        assert p["sequence"] == reference_rc[:13]
+        assert p["cigar"] == "13=5S" and p["clipping"] == 0 and p["end_clipping"] == 5 and p["score"] == 26
+    assert p["offset"] == 5 and p["num_matches"] == 13
+
+
+@pytest.mark.parametrize("max_seed_length", [0, 31 + 100])
+def test_align_suffix_seed_no_full_seeds(max_seed_length):
+    # test_aligner.cpp:1775-1800: one alignment, valid on the wrapped graph (is_valid runs inside AlignRun), with and
+    # without full-k-mer seeding
+    k = 31
+    reference = "CTGCTGCGCCATCGCAACCCACGGTTGCTTTTTGAGTCGCTGCTCACGTTAGCCATCACACTGACGTTAAGCTGGCTTTCGATGCTGTATC"
+    query = "CTTACTGCTGCGCTCTTCGCAAACCCCACGGTTTCTTGTTTTGAGCTCGCCTGCTCACGATACCCATACACACTGACGTTCAAGCTGGCTTTCGATGTTGTATC"
+    g = orc.Graph.build(k, [reference], PRIMARY, False)
+    cfg = _cfg(max_num_seeds_per_locus=capi.UINT64_MAX, min_cell_score=-2147483648 + 100, min_path_score=-2147483648 + 100,
+               min_seed_length=13, max_seed_length=max_seed_length)
+    run = orc.AlignRun(g, cfg, [query])
+    assert run.error == "", run.error
+    assert len(run.results()[0]) == 1
