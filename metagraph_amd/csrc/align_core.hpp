@@ -93,6 +93,7 @@ MGX_DEV uint8_t to_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(
 
 } // namespace mgx
 #include "map_chain.hpp"
+#include "canon_graph.hpp"
 namespace mgx {
 
 MGX_DEV uint8_t char_to_op(uint8_t a, uint8_t b) {   // initialize_opt_table (A/aligner_cigar.cpp:10-51)

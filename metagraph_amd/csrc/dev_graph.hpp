@@ -32,6 +32,7 @@ struct DevGraph {
     const uint32_t *w_hint[4];     // same for unflagged W == 1..4
     const uint32_t *firstc;        // first character code of every edge's k-mer, 8 nibbles per word
     const uint64_t *terminus;      // MEM-terminus bit per node (aligner_seeder_methods.hpp:121-125)
+    const uint64_t *terminus_rc;   // PRIMARY graphs: the same for wrapper id v + n (canon_graph.hpp), else nullptr
     const uint64_t *valid;         // node mask or nullptr (dbg_succinct.cpp:934-936)
     const uint2 *prefix_tbl;       // [4^prefix_len] edge range (rl, ru) of nodes whose suffix spells the key;
                                    // the device form of BOSS's suffix-range index (boss.hpp:645-663, boss.cpp:3177-3219)
@@ -335,7 +336,8 @@ MGX_DEV void initial_range(const DevGraph &g, uint32_t s, uint64_t *rl, uint64_t
 // Children of node v as DBGSuccinct::call_outgoing_kmers reports them (dbg_succinct.cpp:110-139),
 // minus sentinel-labelled children which the extender discards (aligner_extender_methods.cpp:381-384).
 // Writes up to 4 (node, label code) pairs in edge order; returns the count.
-MGX_DEV int outgoing(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *codes, LineCtr &ctr) {
+// *sentinel (optional) = v has a sentinel-labelled child that is in the graph.
+MGX_DEV int outgoing(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *codes, LineCtr &ctr, bool *sentinel = nullptr) {
     ++ctr.rank_lines;
     Block cur = load_block(g, (uint32_t)(v >> 6));
     uint32_t w = block_W(cur, (int)(v & 63));
@@ -351,6 +353,7 @@ MGX_DEV int outgoing(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *c
         if ((uint32_t)(i >> 6) != bi) { bi = (uint32_t)(i >> 6); ++ctr.rank_lines; b = load_block(g, bi); }
         uint32_t c = block_W(b, (int)(i & 63)) % SIGMA;
         if (c != 0 && in_graph(g, i)) { if (n < 4) { nodes[n] = i; codes[n] = c; } ++n; }
+        if (c == 0 && sentinel && in_graph(g, i)) *sentinel = true;
     }
     return n < 4 ? n : 4;
 }

@@ -21,7 +21,7 @@ struct EmuGraph {
     DevGraph g;
     std::vector<Block> blocks;
     std::vector<uint32_t> last_hint, w_hint[4], firstc;
-    std::vector<uint64_t> terminus, valid;
+    std::vector<uint64_t> terminus, terminus_rc, valid;
     std::vector<uint2> prefix_tbl;
     uint32_t mode = 0;
 };
@@ -91,6 +91,18 @@ void *emu_graph_create(const mgx_boss_view *view) {
     g.firstc = G->firstc.data();
     G->terminus.assign(n_blocks, 0);
     g.terminus = G->terminus.data();
+    if (G->mode == MGX_MODE_PRIMARY) {
+        // the wrapper's degrees (as k_terminus_primary in mgx.hip)
+        G->terminus_rc.assign(n_blocks, 0);
+        g.terminus_rc = G->terminus_rc.data();
+        for (uint64_t v = 1; v <= n; ++v) {
+            if (!in_graph(g, v)) continue;
+            const uint32_t t = build_terminus_primary(g, v);
+            if (t & 1) G->terminus[v >> 6] |= 1ull << (v & 63);
+            if (t & 2) G->terminus_rc[v >> 6] |= 1ull << (v & 63);
+        }
+        return G;
+    }
     for (uint64_t v = 1; v <= n; ++v)
         if (in_graph(g, v) && build_terminus(g, v)) G->terminus[v >> 6] |= 1ull << (v & 63);
     return G;
@@ -110,6 +122,25 @@ uint32_t emu_outgoing(void *h, uint64_t v, int rc, uint64_t *nodes, char *chars)
     int n = rc ? incoming(g, v, nn, cc, ctr) : outgoing(g, v, nn, cc, ctr);
     for (int t = 0; t < n; ++t) { nodes[t] = nn[t]; chars[t] = rc ? (char)complement_char(decode_code(cc[t])) : (char)decode_code(cc[t]); }
     return (uint32_t)n;
+}
+// CanonicalDBG::call_outgoing_kmers through canon_graph.hpp (wrapper ids); returns count, *sentinel = the degree counts' flag
+uint32_t emu_canon_children(void *h, uint64_t v, uint64_t *nodes, char *chars, int *sentinel) {
+    auto &g = static_cast<EmuGraph *>(h)->g;
+    LineCtr ctr = { 0, 0, 0 };
+    const bool is_rc = v > g.n;
+    Spell sp = base_spelling(g, is_rc ? v - g.n : v, ctr);
+    if (is_rc) sp = spell_reverse_complement(sp, (int32_t)g.k);
+    uint32_t nn[4]; uint8_t cc[4]; bool sent;
+    int n = canon_children(g, (uint32_t)v, sp, nn, cc, &sent, ctr);
+    for (int t = 0; t < n; ++t) { nodes[t] = nn[t]; chars[t] = (char)decode_code(cc[t]); }
+    *sentinel = sent;
+    return (uint32_t)n;
+}
+// bit 0: MEM terminus of wrapper id v (v <= n: base id, else v - n's reverse complement)
+int emu_terminus_primary(void *h, uint64_t v) {
+    auto &g = static_cast<EmuGraph *>(h)->g;
+    if (v > g.n) return (g.terminus_rc[(v - g.n) >> 6] >> ((v - g.n) & 63)) & 1;
+    return (g.terminus[v >> 6] >> (v & 63)) & 1;
 }
 // the lane-parallel conservative filter on a bare string (a Wave with just the fields it reads)
 int emu_maybe_low_complexity(const char *s, uint32_t len) {

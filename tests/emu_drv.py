@@ -31,6 +31,9 @@ def L():
         _L.emu_terminus.argtypes = [C.c_void_p, C.c_uint64]
         _L.emu_outgoing.restype = C.c_uint32
         _L.emu_outgoing.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_char_p]
+        _L.emu_canon_children.restype = C.c_uint32
+        _L.emu_canon_children.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_char_p, C.POINTER(C.c_int)]
+        _L.emu_terminus_primary.argtypes = [C.c_void_p, C.c_uint64]
         _L.emu_is_low_complexity.argtypes = [C.c_char_p, C.c_uint32]
         _L.emu_maybe_low_complexity.argtypes = [C.c_char_p, C.c_uint32]
         _L.emu_align.restype = C.c_void_p
@@ -80,6 +83,18 @@ class EmuGraph:
         chars = C.create_string_buffer(8)
         n = L().emu_outgoing(self.h, v, int(rc), nodes, chars)
         return [(nodes[i], chars.raw[i:i + 1].decode()) for i in range(n)]
+
+
+    def canon_children(self, v):
+        """CanonicalDBG::call_outgoing_kmers of wrapper id v (PRIMARY graphs) -> ([(node, char)], sentinel flag)"""
+        nodes = (C.c_uint64 * 8)()
+        chars = C.create_string_buffer(8)
+        sent = C.c_int(0)
+        n = L().emu_canon_children(self.h, v, nodes, chars, C.byref(sent))
+        return [(nodes[i], chars.raw[i:i + 1].decode()) for i in range(n)], bool(sent.value)
+
+    def terminus_primary(self, v):
+        return bool(L().emu_terminus_primary(self.h, v))
 
 
 class EmuRun:
