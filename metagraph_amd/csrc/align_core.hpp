@@ -909,7 +909,12 @@ MGX_DEV void kmer_masks(Wave &w, int s) {
                 uint32_t v = nodes[i];
                 if (v) {
                     bool term = (i + 1 == n) || nodes[i + 1] == 0;
-                    if (!term) term = (P.g.terminus[v >> 6] >> (v & 63)) & 1;
+                    if (!term) {
+                        // (PRIMARY graphs: ids above n are reverse complements, canon_graph.hpp)
+                        const bool rc_id = P.g.terminus_rc && v > P.g.n;
+                        const uint64_t u = rc_id ? v - P.g.n : v;
+                        term = ((rc_id ? P.g.terminus_rc : P.g.terminus)[u >> 6] >> (u & 63)) & 1;
+                    }
                     mt[l] = true; st[l] = term;
                 } else {
                     st[l] = true;
@@ -1056,7 +1061,92 @@ MGX_DEV uint64_t xclock() {
 #else
 #define SEED_T(slot, t0)
 #endif
-// SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358, non-canonical)
+// SuffixSeeder::generate_seeds on a CanonicalDBG (A/aligner_seeder_methods.cpp:251-314): sub-k matches of the query's
+// reverse complement.  index_range matches query prefix -> node suffix; the nodes wanted are those whose PREFIX spells the
+// match (suffix_to_prefix :95-139: a depth-first walk that tightens the range by every possible next character until the
+// label is complete), reported as their reverse complements at query position j = L - i - match length.  Runs after the
+// forward-strand positions with the same per-position bookkeeping (append_suffix_seed :195-213): msl / pos_start / pos_cnt
+// over w.alt, which keeps the nodes of one position contiguous — entries added to a position that already holds nodes from
+// the first phase are joined by moving the earlier ones to the end of w.alt.
+// The reference's walk uses a LIFO stack of ranges: a node's children are tightened for c = 1..4, complete ones are
+// reported at once and the others pushed, so incomplete children are visited in the order 4..1.  Tightening has no side
+// effects, so here each level keeps only its parent range and the next character to try (w.indices as scratch).
+MGX_DEV void primary_rc_suffix_seeds(Wave &w, int s, uint32_t alt_n) {
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    const DevConfig &cfg = P.cfg;
+    const DevGraph &g = P.g;
+    const int32_t k = (int32_t)g.k, L = w.L, boss_k = k - 1;
+    const int32_t msl0 = (int32_t)cfg.min_seed_length;
+    const int32_t nslots = L - msl0 + 1;
+    const int so = 1 - s;                                       // the other strand's text is this one's reverse complement
+    uint64_t *lvl = (uint64_t *)w.indices;                      // per level: rl, ru, next character
+    auto append = [&](int32_t jj, uint32_t node, int32_t sl) -> bool {
+        const uint32_t cap = MGX_PARAMS_OF(w).lim.max_alt;
+        if (sl > (int32_t)w.msl[jj]) { w.pos_cnt[jj] = 0; w.pos_full[jj] = 0; }
+        w.msl[jj] = (uint16_t)sl;
+        if (w.pos_cnt[jj] == 0) {
+            w.pos_start[jj] = alt_n; w.pos_full[jj] = 0;
+        } else if (w.pos_start[jj] + (uint32_t)w.pos_cnt[jj] != alt_n) {
+            const uint32_t c0 = (uint32_t)w.pos_cnt[jj], from = w.pos_start[jj];
+            if (alt_n + c0 >= cap) { w.status = ST_CAPACITY; return false; }
+            for (uint32_t x = 0; x < c0; ++x) w.alt[alt_n + x] = w.alt[from + x];
+            w.pos_start[jj] = alt_n;
+            alt_n += c0;
+        }
+        if (alt_n >= cap) { w.status = ST_CAPACITY; return false; }
+        w.alt[alt_n++] = node;
+        ++w.pos_cnt[jj];
+        w.bm[3][jj >> 6] |= 1ull << (jj & 63);
+        for (++jj; jj < nslots && sl > (int32_t)w.msl[jj]; ++jj) {
+            w.msl[jj] = (uint16_t)sl--;
+            w.pos_cnt[jj] = 0;
+            w.pos_full[jj] = 0;
+        }
+        return true;
+    };
+    for (int32_t i = 0; i + msl0 <= L; ++i) {
+        int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)boss_k), (uint32_t)(L - i));
+        int32_t j_min = L - i - max_len;
+        const int32_t j_max = L - i - msl0;
+        while (j_min <= j_max && (int32_t)w.msl[j_min] > max_len) { ++j_min; --max_len; }
+        if (j_min > j_max) continue;
+        uint64_t first, last;
+        const int32_t sl = index_range_lane(w, so, i, max_len, msl0, &first, &last, w.ctr);
+        if (sl < msl0) continue;
+        const int32_t j = L - i - sl;
+        if (sl < (int32_t)w.msl[j]) continue;
+        if (cfg.seed_complexity_filter && window_low_complexity(w, s, j, sl)) continue;
+        auto report = [&](uint64_t a, uint64_t b) -> bool {
+            for (uint64_t e = a; e <= b; ++e) {
+                if (!in_graph(g, e)) continue;
+                // CanonicalDBG::reverse_complement(node) (:515-549)
+                uint32_t id = (uint32_t)(e + g.n);
+                if (!(k & 1)) {
+                    const Spell sp = base_spelling(g, e, w.ctr);
+                    if (!sp.dollar && kmer_is_palindrome(sp.code, k)) id = (uint32_t)e;
+                }
+                if (!append(j, id, sl)) return false;
+            }
+            return true;
+        };
+        const uint64_t rl0 = pred_last(g, first - 1, w.ctr) + 1;
+        if (sl == boss_k) { if (!report(rl0, last)) return; continue; }
+        int32_t d = 0;
+        lvl[0] = rl0; lvl[1] = last; lvl[2] = (sl + 1 == boss_k) ? 1 : 4;
+        while (d >= 0) {
+            const bool leaves = sl + d + 1 == boss_k;
+            const uint32_t c = (uint32_t)lvl[3 * d + 2];
+            if (leaves ? c > 4 : c < 1) { --d; continue; }
+            lvl[3 * d + 2] = leaves ? c + 1 : c - 1;
+            uint64_t a = lvl[3 * d], b = lvl[3 * d + 1];
+            if (!tighten_range(g, &a, &b, c, w.ctr)) continue;
+            if (leaves) { if (!report(a, b)) return; }
+            else { ++d; lvl[3 * d] = a; lvl[3 * d + 1] = b; lvl[3 * d + 2] = (sl + d + 1 == boss_k) ? 1 : 4; }
+        }
+    }
+}
+
+// SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358; the CanonicalDBG part above)
 MGX_NI_G2 void make_seeder(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = MGX_PARAMS_OF(w);
@@ -1106,7 +1196,9 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     // Read tail (positions with fewer than k characters left): if the last k-mer is a node, its target node's
     // label ends with q[i..L) for every such i, so index_range matches all L - i characters.  The length is all
     // the replacement rules need for dominated positions; the range is fetched only if a position reports.
-    const bool tail_known = w.n_kmers > 0 && w.nodes[s][w.n_kmers - 1] != 0 && !w.inv_any[s];
+    // (PRIMARY graphs: only if the last k-mer was found in the base graph itself, not as a reverse complement)
+    const bool tail_known = w.n_kmers > 0 && w.nodes[s][w.n_kmers - 1] != 0 && !w.inv_any[s]
+                            && !(cfg.canonical == 2 && w.nodes[s][w.n_kmers - 1] > g.n);
     // lane-parallel longest-prefix lookups for every position that can report a seed
     for (int32_t base = 0; base < nslots; base += WAVE) {
         LV<int32_t> nr, ns;
@@ -1245,6 +1337,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             }
         }
     }
+    if (cfg.canonical == 2) { primary_rc_suffix_seeds(w, s, alt_n); if (w.status != ST_OK) return; }
     SEED_T(4, tp)
     // aggregate (:316-357): rebuild the seed list in position order
     // full seeds are already stored at [0, n_base); copy them out of the way first
@@ -1859,6 +1952,18 @@ MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node,
     uint64_t nn[5];
     uint32_t cc[5];
     int n;
+    if (P.cfg.canonical == 2) {
+        // CanonicalDBG::call_outgoing_kmers over a PRIMARY graph (canon_graph.hpp)
+        const uint32_t v = uni(node);
+        const bool is_rc = v > P.g.n;
+        Spell sp = base_spelling(P.g, is_rc ? v - P.g.n : v, w.ctr);
+        if (is_rc) sp = spell_reverse_complement(sp, (int32_t)P.g.k);
+        uint8_t codes[4];
+        bool sentinel;
+        n = canon_children(P.g, v, sp, nodes, codes, &sentinel, w.ctr);
+        for (int t = 0; t < n; ++t) { chars[t] = decode_code(codes[t]); scores[t] = 0; }
+        return n;
+    }
     if (!E.rc_view) {
         // DBGSuccinct::call_outgoing_kmers (dbg_succinct.cpp:110-139); the node's own block is usually the
         // target block of the expansion that created it
@@ -3336,6 +3441,39 @@ MGX_NI_G4 bool reverse_complement_aln_canonical(Wave &w, DevAln &a) {
     return a.n_nodes > 0;
 }
 
+// Alignment::reverse_complement on a PRIMARY graph behind CanonicalDBG, for alignments without an offset:
+// CanonicalDBG::reverse_complement(seq, path) (canonical_dbg.cpp:551-560) mirrors the path node by node — id v <-> v + n, a
+// palindromic k-mer (even k) keeps its id; node x spells seq[x .. x + k) — and the rest is the plain reversal.
+// (inlined into its callers: a third noinline level under aln_both is not safe on gfx950, see MGX_NI_MASK)
+MGX_DEV bool reverse_complement_aln_primary(Wave &w, DevAln &a) {
+    if (a.offset) { a.n_nodes = 0; return false; }
+    const DevGraph &g = MGX_PARAMS_OF(w).g;
+    const int32_t k = (int32_t)g.k;
+    const uint32_t n = (uint32_t)g.n;
+    for (int32_t base = 0; base < a.n_nodes; base += WAVE) {
+        FOR_LANES(l) {
+            const int32_t x = base + l;
+            if (x < a.n_nodes) {
+                uint32_t v = a.nodes[x];
+                if (v > n) v -= n;
+                else if (v) {
+                    bool pal = !(k & 1) && x + k <= a.seq_len;
+                    for (int32_t j = 0; pal && j < k / 2; ++j)
+                        pal = encode_char(a.seq[x + j]) + encode_char(a.seq[x + k - 1 - j]) == 5;
+                    if (!pal) v += n;
+                }
+                a.nodes[x] = v;
+            }
+        }
+    }
+    wave_sync();
+    return reverse_complement_aln(w, a);
+}
+
+MGX_DEV bool reverse_complement_aln_stored(Wave &w, DevAln &a) {
+    return MGX_PARAMS_OF(w).cfg.canonical == 2 ? reverse_complement_aln_primary(w, a) : reverse_complement_aln_canonical(w, a);
+}
+
 MGX_DEV SeedRef seedref_from_aln(const DevAln &a) {
     SeedRef s;
     s.nodes = a.nodes; s.seq = a.seq; s.n_nodes = a.n_nodes; s.seq_len = a.seq_len;
@@ -3533,7 +3671,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
                     const bool to_left = aln_clipping(path) && !path.offset;
                     const bool good = path.score >= min_path_score_now(w);
                     bool have_rev = false;
-                    if ((good && reversible) || to_left) { copy_aln(rev, path); have_rev = reverse_complement_aln_canonical(w, rev); }
+                    if ((good && reversible) || to_left) { copy_aln(rev, path); have_rev = reverse_complement_aln_stored(w, rev); }
                     if (good) { if (reversible) { if (have_rev) add_alignment(w, rev); } else add_alignment(w, path); }
                     if (!to_left || !have_rev) continue;
                     rev_alive[n_rev++] = true;
@@ -3569,7 +3707,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
             for (int b = 0; b < n_bwd; ++b) {
                 DevAln &p2 = w.aln[2 * n_alt + b];
                 if (canon && !(p2.orientation && !p2.offset)) { add_alignment(w, p2); continue; }     // not reversible: as it is (:711)
-                if (canon ? reverse_complement_aln_canonical(w, p2) : reverse_complement_aln(w, p2)) {
+                if (canon ? reverse_complement_aln_stored(w, p2) : reverse_complement_aln(w, p2)) {
                     int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
                     const uint64_t tf0 = cycle_clock();
                     for (int32_t x = 0; x < p2.n_nodes; ++x)

@@ -20,7 +20,8 @@ struct DevConfig {
     int32_t gap_open, gap_ext, left_end_bonus, right_end_bonus;
     uint32_t fwd_and_rc, allow_left_trim, seed_complexity_filter;
     uint32_t num_alt;        // num_alternative_paths
-    uint32_t canonical;      // the graph is a CANONICAL-mode DBGSuccinct (both strands stored): dbg_aligner.cpp:225,644-655
+    uint32_t canonical;      // 1: the graph is a CANONICAL-mode DBGSuccinct (both strands stored): dbg_aligner.cpp:225,644-655;
+                             // 2: a PRIMARY-mode one seen through the CanonicalDBG wrapper (canon_graph.hpp), same driver flow
 };
 
 struct DevLimits {

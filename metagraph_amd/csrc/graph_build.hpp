@@ -89,6 +89,25 @@ MGX_HD uint32_t choose_prefix_len(uint64_t n_edges, uint32_t k, uint32_t cap = 1
     return m;
 }
 
+// CanonicalDBG::map_to_nodes_sequentially (canonical_dbg.cpp:55-146) from the base graph's mappings of both strands: a k-mer
+// found forward keeps its id, one found only in the reverse complement gets that node's id + n; the reverse strand's path is
+// the mirror image (DeBruijnGraph::reverse_complement_seq_path -> CanonicalDBG::reverse_complement, :551-560).  One call
+// rewrites position i of the forward path and position n_kmers - 1 - i of the reverse path in place.
+MGX_DEV void canon_merge_pair(const DevGraph &g, const char *seq, int32_t L, int32_t i, uint32_t *nf, uint32_t *nr) {
+    const int32_t k = (int32_t)g.k, nk = L - k + 1;
+    const uint32_t a = nf[i], b = nr[nk - 1 - i];
+    uint32_t f = 0, r = 0;
+    if (a) {
+        bool pal = !(k & 1);
+        for (int32_t j = 0; pal && j < k / 2; ++j)
+            pal = encode_char((uint8_t)seq[i + j]) + encode_char((uint8_t)seq[i + k - 1 - j]) == 5;
+        f = a; r = pal ? a : a + (uint32_t)g.n;
+    } else if (b) {
+        f = b + (uint32_t)g.n; r = b;
+    }
+    nf[i] = f; nr[nk - 1 - i] = r;
+}
+
 // MEM terminus bit: has_multiple_outgoing(v) || !has_single_incoming(v) (aligner_seeder_methods.hpp:121-125)
 MGX_DEV bool build_terminus(const DevGraph &g, uint64_t v) {
     if (v == 0 || v > g.n) return false;

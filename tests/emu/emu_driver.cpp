@@ -168,6 +168,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     int rc = prepare_config(*config, G->g.k, &cfg, &dcfg, &R->error);
     if (rc) return R;
     if (G->mode == MGX_MODE_CANONICAL) { dcfg.canonical = 1; dcfg.fwd_and_rc = 1; }      // as mgx_aligner_create
+    if (G->mode == MGX_MODE_PRIMARY) { dcfg.canonical = 2; dcfg.fwd_and_rc = 1; }
     const uint32_t k = G->g.k;
     uint32_t Lmax = 0;
     R->node_begin.assign(n + 1, 0);
@@ -240,6 +241,14 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         while (m.state != 3) map_lane_step(G->g, m, ctr, fetch);
         }
         R->stats.rank_lines += ctr.rank_lines; R->stats.select_lines += ctr.select_lines;
+        if (G->mode == MGX_MODE_PRIMARY && do_rc) {
+            // the product's k_canon_merge
+            for (uint64_t r = 0; r < n; ++r) {
+                const int32_t L = (int32_t)(offsets[r + 1] - offsets[r]);
+                for (int32_t i = 0; i + (int32_t)k <= L; ++i)
+                    canon_merge_pair(G->g, seqs + offsets[r], L, i, nf.data() + R->node_begin[r], nr.data() + R->node_begin[r]);
+            }
+        }
     }
     R->m_fwd.assign(nf.begin(), nf.end());
     R->m_rc.assign(nr.begin(), nr.end());

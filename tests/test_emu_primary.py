@@ -50,3 +50,141 @@ def test_wrapper_children_and_terminus_bits(name, k, contigs, mask):
             assert eg.terminus_primary(v) == bool((deg & 1) or not (deg & 2)), (name, v)
             checked += 1
     assert checked > 1000
+
+
+# ---- the whole aligner on PRIMARY graphs: seeds, num_matches and full alignment lists against the oracle ----
+import random  # noqa: E402
+
+from metagraph_amd import capi  # noqa: E402
+from test_emu_vs_oracle import compare_full, rand_seq, mutate, rc  # noqa: E402
+from test_oracle_kats import read_fastq  # noqa: E402
+from test_oracle_canonical import _cfg  # noqa: E402
+
+
+def primary_world(seed, k, genome_len=3000, n_reads=40, read_len=100, mask=False, n_variants=10, order="input"):
+    rng = random.Random(seed)
+    genome = rand_seq(rng, genome_len)
+    seqs = [genome]
+    for _ in range(n_variants):
+        p = rng.randrange(k, genome_len - k)
+        alt = rng.choice([c for c in "ACGT" if c != genome[p]])
+        seqs.append(genome[p - k + 1:p] + alt + genome[p + 1:p + k])
+    g = orc.Graph.build(k, primary_contigs(seqs, k, order)[0], PRIMARY, mask)
+    reads = []
+    for i in range(n_reads):
+        if i % 10 == 9:
+            reads.append(rand_seq(rng, read_len))
+            continue
+        p = rng.randrange(0, genome_len - read_len)
+        r = mutate(rng, genome[p:p + read_len])
+        if rng.random() < 0.5:
+            r = rc(r)
+        if i % 7 == 3:
+            r = r[:len(r) // 2] + "N" + r[len(r) // 2 + 1:]
+        reads.append(r)
+    return g, reads
+
+
+def test_primary_kats_through_the_kernels():
+    # test_aligner.cpp:1483-1537 (PRIMARY iteration) and :1770-1800 (align_suffix_seed_no_full_seeds)
+    g = orc.Graph.build(18, ["TTGGCCTCGAAAGTTTTT"], PRIMARY, False)
+    cfg = _cfg(max_num_seeds_per_locus=capi.UINT64_MAX, min_cell_score=-2147483648 + 100, min_path_score=-2147483648 + 100,
+               min_seed_length=13)
+    compare_full(g, emu_drv.EmuGraph(g, mode=PRIMARY), cfg, ["GGGGGCTTTCGAGGCCAA"])
+    g = orc.Graph.build(31, ["CTGCTGCGCCATCGCAACCCACGGTTGCTTTTTGAGTCGCTGCTCACGTTAGCCATCACACTGACGTTAAGCTGGCTTTCGATGCTGTATC"],
+                        PRIMARY, False)
+    query = "CTTACTGCTGCGCTCTTCGCAAACCCCACGGTTTCTTGTTTTGAGCTCGCCTGCTCACGATACCCATACACACTGACGTTCAAGCTGGCTTTCGATGTTGTATC"
+    for msl in (0, 131):
+        cfg = _cfg(max_num_seeds_per_locus=capi.UINT64_MAX, min_cell_score=-2147483648 + 100,
+                   min_path_score=-2147483648 + 100, min_seed_length=13, max_seed_length=msl)
+        compare_full(g, emu_drv.EmuGraph(g, mode=PRIMARY), cfg, [query])
+
+
+@pytest.mark.parametrize("min_seed_length", [None, 10])
+@pytest.mark.parametrize("order", ["input", "colex"])
+def test_primary_cli_goldens_through_the_kernels(min_seed_length, order):
+    contigs, _ = primary_contigs(read_fasta(os.path.join(HERE, "golden", "genome.MT.fa")), 11, order)
+    g = orc.Graph.build(11, contigs, PRIMARY, False)
+    reads = read_fastq(os.path.join(HERE, "golden", "genome_MT1.fq"))
+    cfg = capi.config_cli(11)
+    cfg.min_exact_match = 0.0
+    if min_seed_length is not None:
+        cfg.min_seed_length = min_seed_length
+    e = compare_full(g, emu_drv.EmuGraph(g, mode=PRIMARY), cfg, [r[1] for r in reads])
+    got, _ = e.results()
+    assert (got[3][0]["cigar"], got[3][0]["score"]) == ("54=1X95=", 305)
+
+
+@pytest.mark.parametrize("k,mask,seed,order", [(11, False, 1, "input"), (19, False, 2, "lex"), (31, False, 3, "colex"),
+                                               (15, True, 4, "input"), (12, False, 5, "lex"), (8, True, 6, "input")])
+def test_primary_random_worlds(k, mask, seed, order):
+    g, reads = primary_world(700 + seed, k, mask=mask, order=order)
+    compare_full(g, emu_drv.EmuGraph(g, mode=PRIMARY), capi.config_cli(k), reads)
+
+
+@pytest.mark.parametrize("k,min_seed,per_locus", [(31, 15, 1000), (31, 13, 2), (21, 9, 1), (12, 6, 1000), (10, 5, 3)])
+def test_primary_sub_k_seeding_variants(k, min_seed, per_locus):
+    """Sub-k seeds on both strands of a repetitive genome: suffix ranges with several nodes, the per-locus cap, positions that
+    collect nodes from the forward phase and from the reverse-complement phase (suffix_to_prefix walks of several levels)."""
+    rng = random.Random(78)
+    unit = rand_seq(rng, 40)
+    genome = rand_seq(rng, 500) + unit + rand_seq(rng, 200) + rc(unit[:30]) + rand_seq(rng, 5) + unit[10:] + rand_seq(rng, 400)
+    g = orc.Graph.build(k, primary_contigs([genome], k, "lex")[0], PRIMARY, False)
+    reads = []
+    for i in range(30):
+        p = rng.randrange(0, len(genome) - 120)
+        r = mutate(rng, genome[p:p + 120], 0.04)
+        reads.append(rc(r) if i % 2 else r)
+    cfg = capi.config_cli(k)
+    cfg.min_seed_length = min_seed
+    cfg.max_num_seeds_per_locus = per_locus
+    cfg.min_exact_match = 0.0
+    compare_full(g, emu_drv.EmuGraph(g, mode=PRIMARY), cfg, reads)
+
+
+def test_primary_split_multipass_and_alternatives(monkeypatch):
+    monkeypatch.setenv("MGX_EMU_SPLIT", "1")
+    monkeypatch.setenv("MGX_EMU_MULTIPASS", "1")
+    g, reads = primary_world(750, 15, genome_len=4000, n_reads=40, n_variants=40)
+    chim = [reads[i][:50] + reads[i + 1][40:90] for i in range(0, 20, 2)]
+    eg = emu_drv.EmuGraph(g, mode=PRIMARY)
+    for n_alt, msl in ((1, 15), (2, 11)):
+        cfg = capi.config_cli(15)
+        cfg.min_exact_match = 0.0
+        cfg.num_alternative_paths = n_alt
+        cfg.min_seed_length = msl
+        compare_full(g, eg, cfg, reads + chim)
+
+
+def test_primary_forward_only_and_general_path(monkeypatch):
+    g, reads = primary_world(760, 13, n_reads=30, mask=True)
+    eg = emu_drv.EmuGraph(g, mode=PRIMARY)
+    cfg = capi.config_cli(13)
+    cfg.forward_and_reverse_complement = 0            # a CanonicalDBG aligns both strands regardless (dbg_aligner.cpp:225-226)
+    compare_full(g, eg, cfg, reads)
+    monkeypatch.setenv("MGX_NO_FAST", "1")            # every column through general_step
+    compare_full(g, eg, capi.config_cli(13), reads)
+
+
+def test_primary_mapping_is_the_wrappers():
+    g, reads = primary_world(770, 12, n_reads=20)
+    eg = emu_drv.EmuGraph(g, mode=PRIMARY)
+    lib = canon_lib()
+    e = emu_drv.EmuRun(eg, capi.config_cli(12), reads, map_only=True)
+    for q, ((fwd, rev), r) in enumerate(zip(e.mapping(), reads)):
+        out = (C.c_uint64 * (len(r) - 12 + 1))()
+        lib.orc_canonical_map(g.h, r.encode(), len(r), out)
+        assert list(fwd) == list(out), q
+        mirrored = [int(lib.orc_canonical_reverse_complement(g.h, v)) if v else 0 for v in out][::-1]
+        assert list(rev) == mirrored, q
+
+
+@pytest.mark.parametrize("lanes", ["8"])
+def test_primary_in_the_8_lane_group_model(lanes):
+    import subprocess
+    import sys
+    env = dict(os.environ, MGX_EMU_WAVE=lanes)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k",
+                        "random_worlds or split_multipass or sub_k_seeding", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
