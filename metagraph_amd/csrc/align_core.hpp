@@ -57,7 +57,16 @@
 #define MGX_PARAMS_OF(w) (*(w).P)
 #endif
 
+// PRIMARY graphs (DevConfig::canonical == 2, the CanonicalDBG wrapper of canon_graph.hpp) are compiled into separate
+// instantiations (-DMGX_WITH_PRIMARY=1: mgx_primary.hip for seeding, the mgx_grp.hip build that also carries alternative
+// paths for extension), so that the kernels every other graph runs on are the code they were without it.
+#ifndef MGX_WITH_PRIMARY
+#define MGX_WITH_PRIMARY 0
+#endif
+
 namespace mgx {
+
+constexpr bool kWithPrimary = MGX_WITH_PRIMARY != 0;
 
 #if defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS
 __shared__ AlignParams g_params;
@@ -911,9 +920,9 @@ MGX_DEV void kmer_masks(Wave &w, int s) {
                     bool term = (i + 1 == n) || nodes[i + 1] == 0;
                     if (!term) {
                         // (PRIMARY graphs: ids above n are reverse complements, canon_graph.hpp)
-                        const bool rc_id = P.g.terminus_rc && v > P.g.n;
+                        const bool rc_id = kWithPrimary && P.cfg.canonical == 2 && v > P.g.n;
                         const uint64_t u = rc_id ? v - P.g.n : v;
-                        term = ((rc_id ? P.g.terminus_rc : P.g.terminus)[u >> 6] >> (u & 63)) & 1;
+                        term = (P.g.terminus[(rc_id ? P.g.n_blocks : 0u) + (u >> 6)] >> (u & 63)) & 1;
                     }
                     mt[l] = true; st[l] = term;
                 } else {
@@ -1198,7 +1207,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     // the replacement rules need for dominated positions; the range is fetched only if a position reports.
     // (PRIMARY graphs: only if the last k-mer was found in the base graph itself, not as a reverse complement)
     const bool tail_known = w.n_kmers > 0 && w.nodes[s][w.n_kmers - 1] != 0 && !w.inv_any[s]
-                            && !(cfg.canonical == 2 && w.nodes[s][w.n_kmers - 1] > g.n);
+                            && !(kWithPrimary && cfg.canonical == 2 && w.nodes[s][w.n_kmers - 1] > g.n);
     // lane-parallel longest-prefix lookups for every position that can report a seed
     for (int32_t base = 0; base < nslots; base += WAVE) {
         LV<int32_t> nr, ns;
@@ -1337,7 +1346,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             }
         }
     }
-    if (cfg.canonical == 2) { primary_rc_suffix_seeds(w, s, alt_n); if (w.status != ST_OK) return; }
+    if (kWithPrimary && cfg.canonical == 2) { primary_rc_suffix_seeds(w, s, alt_n); if (w.status != ST_OK) return; }
     SEED_T(4, tp)
     // aggregate (:316-357): rebuild the seed list in position order
     // full seeds are already stored at [0, n_base); copy them out of the way first
@@ -1952,7 +1961,7 @@ MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node,
     uint64_t nn[5];
     uint32_t cc[5];
     int n;
-    if (P.cfg.canonical == 2) {
+    if (kWithPrimary && P.cfg.canonical == 2) {
         // CanonicalDBG::call_outgoing_kmers over a PRIMARY graph (canon_graph.hpp)
         const uint32_t v = uni(node);
         const bool is_rc = v > P.g.n;
@@ -3471,7 +3480,8 @@ MGX_DEV bool reverse_complement_aln_primary(Wave &w, DevAln &a) {
 }
 
 MGX_DEV bool reverse_complement_aln_stored(Wave &w, DevAln &a) {
-    return MGX_PARAMS_OF(w).cfg.canonical == 2 ? reverse_complement_aln_primary(w, a) : reverse_complement_aln_canonical(w, a);
+    if (kWithPrimary && MGX_PARAMS_OF(w).cfg.canonical == 2) return reverse_complement_aln_primary(w, a);
+    return reverse_complement_aln_canonical(w, a);
 }
 
 MGX_DEV SeedRef seedref_from_aln(const DevAln &a) {

@@ -31,8 +31,8 @@ struct DevGraph {
     const uint32_t *last_hint;     // block holding every 64-th set bit of last
     const uint32_t *w_hint[4];     // same for unflagged W == 1..4
     const uint32_t *firstc;        // first character code of every edge's k-mer, 8 nibbles per word
-    const uint64_t *terminus;      // MEM-terminus bit per node (aligner_seeder_methods.hpp:121-125)
-    const uint64_t *terminus_rc;   // PRIMARY graphs: the same for wrapper id v + n (canon_graph.hpp), else nullptr
+    const uint64_t *terminus;      // MEM-terminus bit per node (aligner_seeder_methods.hpp:121-125), n_blocks words; PRIMARY
+                                   // graphs: n_blocks more words with the bits of the wrapper ids v + n (canon_graph.hpp)
     const uint64_t *valid;         // node mask or nullptr (dbg_succinct.cpp:934-936)
     const uint2 *prefix_tbl;       // [4^prefix_len] edge range (rl, ru) of nodes whose suffix spells the key;
                                    // the device form of BOSS's suffix-range index (boss.hpp:645-663, boss.cpp:3177-3219)

@@ -89,6 +89,27 @@ __global__ void k_terminus(DevGraph g, uint64_t *bits) {
     if ((threadIdx.x & 63) == 0 && (v >> 6) < ((g.n + 64) >> 6)) bits[v >> 6] = m;
 }
 
+// PRIMARY graphs: the wrapper's terminus bits of both ids of every base node (canon_graph.hpp)
+__global__ void k_terminus_primary(DevGraph g, uint64_t *bits, uint64_t *bits_rc) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // blockDim multiple of 64
+    const uint32_t t = (v <= g.n && in_graph(g, v)) ? build_terminus_primary(g, v) : 0u;
+    const uint64_t m0 = __ballot(t & 1u), m1 = __ballot(t & 2u);
+    if ((threadIdx.x & 63) == 0 && (v >> 6) < ((g.n + 64) >> 6)) { bits[v >> 6] = m0; bits_rc[v >> 6] = m1; }
+}
+
+// PRIMARY graphs: base-graph mappings of both strands -> the wrapper's paths (canon_merge_pair), one wavefront per read
+__global__ void k_canon_merge(DevGraph g, const char *seqs, const uint64_t *offsets, const uint64_t *node_begin,
+                              uint32_t *nodes_fwd, uint32_t *nodes_rc, uint64_t n_reads) {
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = (int)(threadIdx.x & 63);
+    for (uint64_t read = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; read < n_reads; read += n_waves) {
+        const uint64_t off = offsets[read], nb = node_begin[read];
+        const int32_t L = (int32_t)(offsets[read + 1] - off);
+        const int32_t nk = (int32_t)(node_begin[read + 1] - nb);
+        for (int32_t i = lane; i < nk; i += 64) canon_merge_pair(g, seqs + off, L, i, nodes_fwd + nb, nodes_rc + nb);
+    }
+}
+
 __global__ void k_kmer_counts(const uint64_t *offsets, uint64_t n_reads, uint32_t k, uint64_t *counts, unsigned long long *lmax) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_reads) {
@@ -200,48 +221,7 @@ __global__ void __launch_bounds__(256, MGX_MAP_PACKED_WAVES) k_map_packed(DevGra
     }
 }
 
-// one wave per read, persistent over the batch; each wave owns one arena slice
-#ifndef MGX_ALIGN_WAVES_PER_SIMD
-#define MGX_ALIGN_WAVES_PER_SIMD 4
-#endif
-// WPS = waves per SIMD the register allocation targets: 4 for the kernels that extend; the seeding-only instantiation of
-// short-read batches runs at 8 (64 VGPRs, seeding tables mostly in the arena) — a gather kernel gains more from the extra
-// wavefronts than it loses to spills (measured 112 vs 117 ms per 2 M reads)
-#ifndef MGX_SEED_WPS
-#define MGX_SEED_WPS 8          // waves per SIMD of the short-read seeding instantiation
-#endif
-template <int PHASE, int WPS = MGX_ALIGN_WAVES_PER_SIMD>
-__global__ void __launch_bounds__(64, WPS) k_align(AlignParams P, uint32_t lds_bytes) {
-    const uint32_t slot = blockIdx.x;
-    __shared__ Wave w;                // the wave's scalar state lives in LDS, not in registers
-    __shared__ SdustScratch sd;
-    __shared__ int8_t sm_rows[6 * 128];
-    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
-    KernelStats acc;
-    memset(&acc, 0, sizeof(acc));
-    load_score_rows(P, sm_rows);
-    const uint64_t n_items = P.n_items_ptr ? *P.n_items_ptr : P.n_reads;
-    for (;;) {
-        LV<uint64_t> rv;
-        rv.v = 0;
-        if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
-        uint64_t item = wave_bcast(rv, 0);
-        if (item >= n_items) break;
-        const uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
-        align_read<PHASE>(w, P, read, slot, &acc, &sd, sm_rows, dyn_lds, lds_bytes);
-    }
-    if (lane_id() == 0) {
-        atomicAdd(&P.stats->rank_lines, acc.rank_lines);
-        atomicAdd(&P.stats->select_lines, acc.select_lines);
-        atomicAdd(&P.stats->bit_lines, acc.bit_lines);
-        atomicAdd(&P.stats->columns, acc.columns);
-        atomicAdd(&P.stats->extensions, acc.extensions);
-        atomicAdd(&P.stats->seeds, acc.seeds);
-        atomicAdd(&P.stats->capacity_errors, acc.capacity_errors);
-        if (acc.seed_lines) atomicAdd(&P.stats->seed_lines, acc.seed_lines);
-        for (int x = 0; x < 8; ++x) { atomicAdd(&P.stats->cyc[x], acc.cyc[x]); atomicAdd(&P.stats->xcyc[x], acc.xcyc[x]); }
-    }
-}
+#include "seed_kernel.hpp"
 
 __global__ void k_iota(uint32_t *v, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -299,7 +279,10 @@ struct mgx_graph {
 extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);    // mgx_grp.hip, MGX_GROUP=8
 extern "C" int mgx_grp_waves_per_simd8(void);
 extern "C" unsigned mgx_grp_static_lds8(void);
-// the same kernel with room for MGX_MAX_ALTERNATIVE_PATHS alignments per query (num_alternative_paths > 1)
+// the seeding kernel with the CanonicalDBG branches (mgx_primary.hip); wps8 selects the 8-waves-per-SIMD instantiation
+extern "C" int mgx_launch_seed_primary(const void *params, uint32_t blocks, uint32_t lds_bytes, int wps8, void *stream);
+// the same kernel with room for MGX_MAX_ALTERNATIVE_PATHS alignments per query (num_alternative_paths > 1) and with the
+// CanonicalDBG branches (PRIMARY graphs)
 extern "C" int mgx_launch_align_grp8_alt(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);
 extern "C" unsigned mgx_grp_static_lds8_alt(void);
 
@@ -432,12 +415,16 @@ void mgx_limits_init_default(mgx_limits *l, uint32_t max_query_length) {
 int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
     if (!view || !out || !view->W || !view->last || !view->F) return fail(MGX_ERR_INVALID, "null BOSS view");
     if (view->sigma != SIGMA) return fail(MGX_ERR_UNSUPPORTED, "only the DNA alphabet $ACGT (sigma = 5) is implemented");
-    // CANONICAL: a DBGSuccinct that stores both strands (same index, different aligner flow).  PRIMARY graphs are aligned
-    // through the CanonicalDBG wrapper in the reference (dbg_aligner.cpp:52-53), which is not implemented.
-    if (view->mode != MGX_MODE_BASIC && view->mode != MGX_MODE_CANONICAL)
-        return fail(MGX_ERR_UNSUPPORTED, "PRIMARY-mode graphs (CanonicalDBG wrapper) are not implemented");
+    // CANONICAL: a DBGSuccinct that stores both strands (same index, different aligner flow).  PRIMARY: one k-mer of every
+    // pair is stored and the reference aligns through the CanonicalDBG wrapper (dbg_aligner.cpp:52-53) — canon_graph.hpp.
+    if (view->mode != MGX_MODE_BASIC && view->mode != MGX_MODE_CANONICAL && view->mode != MGX_MODE_PRIMARY)
+        return fail(MGX_ERR_INVALID, "unknown graph mode %u", view->mode);
     if (view->k < 2 || view->k > 255) return fail(MGX_ERR_INVALID, "k out of range");
     if (view->n_edges == 0 || view->n_edges >= 0xFFFFFFF0ull) return fail(MGX_ERR_UNSUPPORTED, "edge count must fit 32 bits");
+    if (view->mode == MGX_MODE_PRIMARY) {
+        if (view->k > 32) return fail(MGX_ERR_UNSUPPORTED, "PRIMARY-mode graphs need k <= 32 (node spellings are held in two registers)");
+        if (view->n_edges * 2 >= 0xFFFFFFF0ull) return fail(MGX_ERR_UNSUPPORTED, "PRIMARY mode: ids of both strands must fit 32 bits");
+    }
     if (mgx_device_count() <= device) return fail(MGX_ERR_NO_DEVICE, "HIP device %d not available", device);
     HIP_TRY(hipSetDevice(device));
     auto *G = new mgx_graph();
@@ -556,12 +543,17 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
         HIP_TRY(hipDeviceSynchronize());
     }
     // MEM terminus bits
-    if (int rc = G->terminus.ensure((size_t)n_blocks * 8)) return rc;
+    if (int rc = G->terminus.ensure((size_t)n_blocks * 8 * (G->mode == MGX_MODE_PRIMARY ? 2 : 1))) return rc;
     g.terminus = G->terminus.as<uint64_t>();
-    k_terminus<<<n_blocks, 64>>>(g, G->terminus.as<uint64_t>());
+    if (G->mode == MGX_MODE_PRIMARY) {
+        k_terminus_primary<<<n_blocks, 64>>>(g, G->terminus.as<uint64_t>(), G->terminus.as<uint64_t>() + n_blocks);
+    } else {
+        k_terminus<<<n_blocks, 64>>>(g, G->terminus.as<uint64_t>());
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    G->bytes = G->blocks.bytes + G->last_hint.bytes + G->firstc.bytes + G->terminus.bytes + G->valid.bytes + G->prefix_tbl.bytes;
+    G->bytes = G->blocks.bytes + G->last_hint.bytes + G->firstc.bytes + G->terminus.bytes + G->valid.bytes
+               + G->prefix_tbl.bytes;
     for (int c = 0; c < 4; ++c) G->bytes += G->w_hint[c].bytes;
     *out = guard.release();
     return MGX_OK;
@@ -569,7 +561,9 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
 
 void mgx_graph_destroy(mgx_graph *g) { delete g; }
 uint32_t mgx_graph_k(const mgx_graph *g) { return g->g.k; }
-uint64_t mgx_graph_max_index(const mgx_graph *g) { return g->g.n; }
+uint64_t mgx_graph_max_index(const mgx_graph *g) {
+    return g->mode == MGX_MODE_PRIMARY ? 2 * g->g.n : g->g.n;            // CanonicalDBG::max_index (canonical_dbg.hpp:96)
+}
 uint64_t mgx_graph_device_bytes(const mgx_graph *g) { return g->bytes; }
 
 // ------------------------------------------------------------------------------------------------
@@ -586,6 +580,7 @@ int mgx_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_l
         if (rc) return fail(rc, "%s", err.c_str());
     }
     if (g->mode == MGX_MODE_CANONICAL) { A->dcfg.canonical = 1; A->dcfg.fwd_and_rc = 1; }     // dbg_aligner.cpp:225-226
+    if (g->mode == MGX_MODE_PRIMARY) { A->dcfg.canonical = 2; A->dcfg.fwd_and_rc = 1; }       // through the wrapper
     mgx_config &c = A->cfg;
     if (limits) { A->user_lim = *limits; A->have_user_lim = true; }
     HIP_TRY(hipSetDevice(g->device));
@@ -723,6 +718,11 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
         }
     }
     HIP_TRY(hipGetLastError());
+    if (A->graph->mode == MGX_MODE_PRIMARY && do_rc) {
+        k_canon_merge<<<(uint32_t)std::min<uint64_t>((n + 3) / 4, 65536), 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
+                                                                             A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(), n);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(A->ev[1], 0));
     return MGX_OK;
 }
@@ -855,7 +855,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         static const uint32_t pct = getenv("MGX_EXT_GROUPS_PCT") ? (uint32_t)std::min(100, std::max(1, atoi(getenv("MGX_EXT_GROUPS_PCT")))) : 100u;
         const uint32_t groups = 8;
         const uint32_t waves_cu = 4u * (uint32_t)mgx_grp_waves_per_simd8();
-        const bool alt = A->cfg.num_alternative_paths > 1;
+        const bool alt = A->cfg.num_alternative_paths > 1 || A->dcfg.canonical == 2;
         const uint32_t static_lds = alt ? mgx_grp_static_lds8_alt() : mgx_grp_static_lds8();
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 64u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
@@ -873,7 +873,14 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             uint32_t lds8 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), budget8) & ~15u;
             if (const char *e = getenv("MGX_SEED_LDS_CAP")) lds8 = std::min<uint32_t>(lds8, (uint32_t)atoi(e)) & ~15u;     // tuning probe
             if (getenv("MGX_SEED_LDS_PRINT")) fprintf(stderr, "k_seed: static_lds %u budget8 %u lds8 %u (fast_lds_bytes %u)\n", static_lds, budget8, lds8, fast_lds_bytes(l.Lmax));
-            k_align<PH_SEED, MGX_SEED_WPS><<<(uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, 64, lds8>>>(P, lds8);
+            if (A->dcfg.canonical == 2) {
+                if (int rc = mgx_launch_seed_primary(&P, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, lds8, 1, nullptr))
+                    return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
+            } else {
+                k_align<PH_SEED, MGX_SEED_WPS><<<(uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, 64, lds8>>>(P, lds8);
+            }
+        } else if (A->dcfg.canonical == 2) {
+            if (int rc = mgx_launch_seed_primary(&P, w_slots, lds_bytes, 0, nullptr)) return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
         } else {
             k_align<PH_SEED><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
         }

@@ -121,7 +121,7 @@ class HipBOSSGraph {
                  const uint8_t *valid = nullptr, int device = 0, uint32_t mode = MGX_MODE_BASIC) {
         mgx_boss_view v{};
         v.k = k; v.sigma = 5; v.n_edges = n_edges; v.W = W; v.last = last; v.F = F; v.valid = valid;
-        v.mode = mode; v.on_device = 0;          // MGX_MODE_BASIC or MGX_MODE_CANONICAL (DeBruijnGraph::get_mode())
+        v.mode = mode; v.on_device = 0;          // DeBruijnGraph::get_mode(); PRIMARY graphs are aligned through CanonicalDBG
         if (int rc = mgx_graph_create(&v, device, &g_)) throw std::runtime_error(std::string("mgx_graph_create: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
     }
     ~HipBOSSGraph() { mgx_graph_destroy(g_); }

@@ -2,7 +2,7 @@
 // TSV printing as in cli/align.cpp:403-480).  Graph input is a flat BOSS dump (k, n_edges, F[5], W[], last[]);
 // reading sdsl-serialised .dbg files is "next" (SURVEY 8f rank 2).  Usage:
 //   mgx_align GRAPH.boss READS.{fa,fq} [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]
-//             [-p THREADS] [--query-batch-size BASES] [--canonical (the dump is a CANONICAL-mode graph)]
+//             [-p THREADS] [--query-batch-size BASES] [--canonical | --primary (the dump is a CANONICAL- / PRIMARY-mode graph)]
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -78,6 +78,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--query-batch-size") && i + 1 < argc) batch_size = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--max-columns") && i + 1 < argc) { lim.max_columns = (uint32_t)atoi(argv[++i]); have_lim = true; }
         else if (!strcmp(argv[i], "--canonical")) graph_mode = MGX_MODE_CANONICAL;
+        else if (!strcmp(argv[i], "--primary")) graph_mode = MGX_MODE_PRIMARY;         // aligned through the CanonicalDBG wrapper
     }
     try {
         HipBOSSGraph graph(k, n, W.data(), last.data(), hdr + 2, nullptr, 0, graph_mode);

@@ -21,7 +21,7 @@ struct EmuGraph {
     DevGraph g;
     std::vector<Block> blocks;
     std::vector<uint32_t> last_hint, w_hint[4], firstc;
-    std::vector<uint64_t> terminus, terminus_rc, valid;
+    std::vector<uint64_t> terminus, valid;
     std::vector<uint2> prefix_tbl;
     uint32_t mode = 0;
 };
@@ -89,17 +89,15 @@ void *emu_graph_create(const mgx_boss_view *view) {
     G->firstc.assign((n + 1 + 7) / 8 + 1, 0);
     for (uint64_t e = 0; e <= n; ++e) G->firstc[e >> 3] |= (uint32_t)(D0[e] & 0xF) << (4 * (e & 7));
     g.firstc = G->firstc.data();
-    G->terminus.assign(n_blocks, 0);
+    G->terminus.assign((size_t)n_blocks * (G->mode == MGX_MODE_PRIMARY ? 2 : 1), 0);
     g.terminus = G->terminus.data();
     if (G->mode == MGX_MODE_PRIMARY) {
         // the wrapper's degrees (as k_terminus_primary in mgx.hip)
-        G->terminus_rc.assign(n_blocks, 0);
-        g.terminus_rc = G->terminus_rc.data();
         for (uint64_t v = 1; v <= n; ++v) {
             if (!in_graph(g, v)) continue;
             const uint32_t t = build_terminus_primary(g, v);
             if (t & 1) G->terminus[v >> 6] |= 1ull << (v & 63);
-            if (t & 2) G->terminus_rc[v >> 6] |= 1ull << (v & 63);
+            if (t & 2) G->terminus[n_blocks + (v >> 6)] |= 1ull << (v & 63);
         }
         return G;
     }
@@ -139,7 +137,7 @@ uint32_t emu_canon_children(void *h, uint64_t v, uint64_t *nodes, char *chars, i
 // bit 0: MEM terminus of wrapper id v (v <= n: base id, else v - n's reverse complement)
 int emu_terminus_primary(void *h, uint64_t v) {
     auto &g = static_cast<EmuGraph *>(h)->g;
-    if (v > g.n) return (g.terminus_rc[(v - g.n) >> 6] >> ((v - g.n) & 63)) & 1;
+    if (v > g.n) return (g.terminus[g.n_blocks + ((v - g.n) >> 6)] >> ((v - g.n) & 63)) & 1;
     return (g.terminus[v >> 6] >> (v & 63)) & 1;
 }
 // the lane-parallel conservative filter on a bare string (a Wave with just the fields it reads)

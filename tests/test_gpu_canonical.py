@@ -1,6 +1,6 @@
 """CANONICAL-mode DBGSuccinct graphs on the GPU through the C-ABI (mgx_boss_view.mode = MGX_MODE_CANONICAL): the reference's
 canonical KATs, the genome.MT canonical CLI goldens byte for byte through mgx_format_tsv, and seeded random worlds against the
-oracle; PRIMARY graphs (CanonicalDBG wrapper) are still refused."""
+oracle.  (PRIMARY graphs: tests/test_gpu_zz_primary.py.)"""
 import ctypes as C
 import os
 
@@ -69,8 +69,10 @@ def test_canonical_random_worlds_on_gpu(k, mask, seed):
     assert all(a["orientation"] == 0 for q in got for a in q)
 
 
-def test_primary_graphs_are_refused():
-    g = orc.Graph.build(7, ["AAAAGCTTTCGAGGCCAA"], 0, True)
+def test_primary_graphs_beyond_k_32_are_refused():
+    """PRIMARY graphs run through the CanonicalDBG wrapper (tests/test_gpu_zz_primary.py); node spellings are held in two
+    registers there, so k > 32 is refused loudly."""
+    g = orc.Graph.build(33, ["AAAAGCTTTCGAGGCCAATTGACCATGGTTACGATCGGATCCAGT"], 2, True)
     with pytest.raises(aligner.MgxError) as e:
         gpu_graph(g, mode=2)
     assert e.value.code == capi.MGX_ERR_UNSUPPORTED
