@@ -61,10 +61,13 @@ typedef struct mgx_boss_view {
     const uint64_t *F;       /* sigma entries (boss.hpp:506-510) */
     const uint8_t *valid;    /* optional node mask, one byte per edge (dbg_succinct.cpp:934-936);
                                 NULL = every edge is a node, as after reset_mask() (cli/align.cpp:337-339) */
-    uint32_t mode;           /* MGX_MODE_*: BASIC and CANONICAL (a DBGSuccinct that stores both strands: the aligner then
-                              * always seeds both strands, runs the backward pass on the same graph and reports reverse-strand
-                              * alignments as the forward alignments they mirror, dbg_aligner.cpp:225,644-655).  PRIMARY graphs
-                              * are aligned through the CanonicalDBG wrapper upstream: MGX_ERR_UNSUPPORTED here. */
+    uint32_t mode;           /* MGX_MODE_* = DeBruijnGraph::get_mode() of the DBGSuccinct.  CANONICAL (both strands stored): the
+                              * aligner always seeds both strands, runs the backward pass on the same graph and reports
+                              * reverse-strand alignments as the forward alignments they mirror (dbg_aligner.cpp:225,644-655).
+                              * PRIMARY (one k-mer of every pair stored): aligned through the CanonicalDBG wrapper as the reference
+                              * does (dbg_aligner.cpp:52-53, canonical_dbg.cpp): node ids above n_edges are reverse complements
+                              * (id - n_edges is the stored node), mgx_graph_max_index reports 2 * n_edges.  PRIMARY needs
+                              * k <= 32 and 2 * n_edges < 2^32 (MGX_ERR_UNSUPPORTED otherwise). */
     uint32_t on_device;      /* 0: W/last/valid are host pointers; 1: device pointers (F always host) */
 } mgx_boss_view;
 

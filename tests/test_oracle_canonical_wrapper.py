@@ -2,7 +2,7 @@
 node space base + offset, map_to_nodes_sequentially :55-146, call_outgoing_kmers / call_incoming_kmers through the reverse
 complement's (k-1)-mer range :156-330,574-684, reverse_complement :515-560) against the wrapper's own KATs
 (tests/graph/test_canonical_dbg.cpp: InsertSequence :73-85, ReverseComplement :87-101, Traversals1 :103-158, Traversals2
-:160-195).  Groundwork for SURVEY 8(f) rank 1: the aligner does not run on this view yet.  The reference's test helper builds
+:160-195).  SURVEY 8(f) rank 1; the aligner on this view: below, tests/test_oracle_primary_goldens.py and test_emu_primary.py.  The reference's test helper builds
 PRIMARY graphs from primary contigs; here the inputs are chosen so that the sequences themselves hold one k-mer of every
 pair (the assertions do not depend on which one)."""
 import ctypes as C
