@@ -94,6 +94,9 @@ q = "AGCTNCGAGGCCAA"
 case("align_straight_with_N", 264, 4, [r], q, expect=exp(11, r, ss(D212, r, q), "4=1X9=", 13))
 case("align_straight_forward_and_reverse_complement", 296, 4, [r], rc(r),
      expect=exp(11, r, ms(D212, rc(r)), "14=", 14, orientation=1))
+# the same through align_batch (:338-385); align_straight_max_size (:225-246) is commented out upstream
+case("align_straight_forward_and_reverse_complement_batch", 338, 4, [r], rc(r),
+     expect=exp(11, r, ms(D212, rc(r)), "14=", 14, orientation=1))
 r1, r2 = "AGCTTCGAA", "AGCTTCGAC"
 case("align_ending_branch", 387, 4, [r1, r2], r2, expect=exp(6, r2, ms(D212, r2), "9=", 9))
 r1, r2 = "AGCTTCGAATATTTGTT", "AGCTTCGACGATTTGTT"
