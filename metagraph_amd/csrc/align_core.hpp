@@ -920,7 +920,7 @@ MGX_DEV void kmer_masks(Wave &w, int s) {
                     bool term = (i + 1 == n) || nodes[i + 1] == 0;
                     if (!term) {
                         // (PRIMARY graphs: ids above n are reverse complements, canon_graph.hpp)
-                        const bool rc_id = kWithPrimary && P.cfg.canonical == 2 && v > P.g.n;
+                        const bool rc_id = kWithPrimary && P.cfg.canonical >= 2 && v > P.g.n;
                         const uint64_t u = rc_id ? v - P.g.n : v;
                         term = (P.g.terminus[(rc_id ? P.g.n_blocks : 0u) + (u >> 6)] >> (u & 63)) & 1;
                     }
@@ -1131,8 +1131,13 @@ MGX_DEV void primary_rc_suffix_seeds(Wave &w, int s, uint32_t alt_n) {
                 // CanonicalDBG::reverse_complement(node) (:515-549)
                 uint32_t id = (uint32_t)(e + g.n);
                 if (!(k & 1)) {
-                    const Spell sp = base_spelling(g, e, w.ctr);
-                    if (!sp.dollar && kmer_is_palindrome(sp.code, k)) id = (uint32_t)e;
+                    if (cfg.canonical == 3) {
+                        ++w.ctr.bit_lines;
+                        if ((gld(primary_tables(g).pal + (e >> 6)) >> (e & 63)) & 1) id = (uint32_t)e;
+                    } else {
+                        const Spell sp = base_spelling(g, e, w.ctr);
+                        if (!sp.dollar && kmer_is_palindrome(sp.code, k)) id = (uint32_t)e;
+                    }
                 }
                 if (!append(j, id, sl)) return false;
             }
@@ -1207,7 +1212,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     // the replacement rules need for dominated positions; the range is fetched only if a position reports.
     // (PRIMARY graphs: only if the last k-mer was found in the base graph itself, not as a reverse complement)
     const bool tail_known = w.n_kmers > 0 && w.nodes[s][w.n_kmers - 1] != 0 && !w.inv_any[s]
-                            && !(kWithPrimary && cfg.canonical == 2 && w.nodes[s][w.n_kmers - 1] > g.n);
+                            && !(kWithPrimary && cfg.canonical >= 2 && w.nodes[s][w.n_kmers - 1] > g.n);
     // lane-parallel longest-prefix lookups for every position that can report a seed
     for (int32_t base = 0; base < nslots; base += WAVE) {
         LV<int32_t> nr, ns;
@@ -1346,7 +1351,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             }
         }
     }
-    if (kWithPrimary && cfg.canonical == 2) { primary_rc_suffix_seeds(w, s, alt_n); if (w.status != ST_OK) return; }
+    if (kWithPrimary && cfg.canonical >= 2) { primary_rc_suffix_seeds(w, s, alt_n); if (w.status != ST_OK) return; }
     SEED_T(4, tp)
     // aggregate (:316-357): rebuild the seed list in position order
     // full seeds are already stored at [0, n_base); copy them out of the way first
@@ -1961,14 +1966,19 @@ MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node,
     uint64_t nn[5];
     uint32_t cc[5];
     int n;
-    if (kWithPrimary && P.cfg.canonical == 2) {
+    if (kWithPrimary && P.cfg.canonical >= 2) {
         // CanonicalDBG::call_outgoing_kmers over a PRIMARY graph (canon_graph.hpp)
         const uint32_t v = uni(node);
+        uint8_t codes[4];
+        bool sentinel;
+        if (P.cfg.canonical == 3) {                            // from the precomputed reverse-complement tables
+            n = canon_children_tables(P.g, v, nodes, codes, &sentinel, w.ctr);
+            for (int t = 0; t < n; ++t) { chars[t] = decode_code(codes[t]); scores[t] = 0; }
+            return n;
+        }
         const bool is_rc = v > P.g.n;
         Spell sp = base_spelling(P.g, is_rc ? v - P.g.n : v, w.ctr);
         if (is_rc) sp = spell_reverse_complement(sp, (int32_t)P.g.k);
-        uint8_t codes[4];
-        bool sentinel;
         n = canon_children(P.g, v, sp, nodes, codes, &sentinel, w.ctr);
         for (int t = 0; t < n; ++t) { chars[t] = decode_code(codes[t]); scores[t] = 0; }
         return n;
@@ -3480,7 +3490,7 @@ MGX_DEV bool reverse_complement_aln_primary(Wave &w, DevAln &a) {
 }
 
 MGX_DEV bool reverse_complement_aln_stored(Wave &w, DevAln &a) {
-    if (kWithPrimary && MGX_PARAMS_OF(w).cfg.canonical == 2) return reverse_complement_aln_primary(w, a);
+    if (kWithPrimary && MGX_PARAMS_OF(w).cfg.canonical >= 2) return reverse_complement_aln_primary(w, a);
     return reverse_complement_aln_canonical(w, a);
 }
 

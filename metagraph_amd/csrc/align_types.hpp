@@ -21,7 +21,8 @@ struct DevConfig {
     uint32_t fwd_and_rc, allow_left_trim, seed_complexity_filter;
     uint32_t num_alt;        // num_alternative_paths
     uint32_t canonical;      // 1: the graph is a CANONICAL-mode DBGSuccinct (both strands stored): dbg_aligner.cpp:225,644-655;
-                             // 2: a PRIMARY-mode one seen through the CanonicalDBG wrapper (canon_graph.hpp), same driver flow
+                             // 2: a PRIMARY-mode one seen through the CanonicalDBG wrapper (canon_graph.hpp), same driver flow;
+                             // 3: the same with the wrapper's look-ups read from the graph's reverse-complement tables
 };
 
 struct DevLimits {

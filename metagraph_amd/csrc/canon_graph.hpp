@@ -19,9 +19,9 @@
 // of the reverse complement: call_incoming_kmers(v) == call_outgoing_kmers(v + n) mirrored, which is how the MEM terminus
 // bits of both ids of a base node are computed at load time.
 //
-// This first version recomputes h (k - 1 bwd steps) and the look-up (k - 2 tighten_range steps) for every expansion and holds
-// the spelling in two 64-bit registers, hence k <= 32 for PRIMARY graphs.  The reference caches both behind LRU caches
-// (canonical_dbg.hpp:121-137); an incremental h along a chain of columns is the obvious next step.
+// canon_children() derives h (k - 1 bwd steps) and the look-up (k - 2 tighten_range steps) for every expansion and holds the
+// spelling in two 64-bit registers, hence k <= 32 for PRIMARY graphs; canon_children_tables() further down reads both from
+// tables built at load time and is what the kernels use by default.
 #pragma once
 #include "dev_graph.hpp"
 
@@ -152,6 +152,120 @@ MGX_DEV int canon_children(const DevGraph &g, uint32_t v, const Spell &h, uint32
         } while (!((b.last_bits >> (e & 63)) & 1));
         return n;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same traversal from two precomputed tables instead of spellings and look-ups (DevConfig::canonical == 3, the default).
+//
+// Everything canon_children derives from the spelling is a property of a BOSS node of the BASE graph: the looked-up node is
+// RC(X) for X = the target node of v (base id) or the source node of u (id u + n), and the palindrome test of a B-set child is
+// the palindrome test of the parent edge's own k-mer.  So a table with the last edge of RC(X) for every BOSS node X (0: no such
+// node, or X holds a sentinel; 4 bytes per node) and one palindrome bit per edge (even k) replace k - 1 bwd steps and k - 2
+// tighten_range steps per expansion by one table line.  The reference reaches the same end with LRU caches
+// (canonical_dbg.hpp:121-137); with 288 GB of HBM the table is the cheaper trade: it roughly doubles the 3.5 B/edge index —
+// still what a CANONICAL-mode graph of the same data costs.  Both live behind DevGraph::terminus (see primary_tables()).
+// ------------------------------------------------------------------------------------------------
+struct PrimaryTables {
+    const uint64_t *pal;          // bit e: the k-mer of edge e is its own reverse complement (all zero for odd k)
+    const uint32_t *rc_node;      // [BOSS node number] -> last edge of the reverse complement's BOSS node, or 0
+};
+// words of DevGraph::terminus for a PRIMARY graph: terminus | terminus of the ids v + n | pal | rc_node (32-bit entries)
+MGX_DEV PrimaryTables primary_tables(const DevGraph &g) {
+    PrimaryTables t;
+    t.pal = g.terminus + 2ull * g.n_blocks;
+    t.rc_node = reinterpret_cast<const uint32_t *>(g.terminus + 3ull * g.n_blocks);
+    return t;
+}
+
+// what the build kernel stores for the BOSS node whose last edge is `lst` (and, for even k, for edge e): see above
+MGX_DEV uint32_t build_rc_node(const DevGraph &g, uint64_t lst) {
+    LineCtr ctr = { 0, 0, 0 };
+    const int32_t k = (int32_t)g.k;
+    const Spell h = base_spelling(g, lst, ctr);              // node = the first k - 1 characters
+    if (h.dollar & ((1ull << (k - 1)) - 1)) return 0;
+    uint64_t t_rc = 0;
+    for (int32_t j = 0; j < k - 1; ++j) t_rc |= (3 - ((h.code >> (2 * (k - 2 - j))) & 3)) << (2 * j);
+    return (uint32_t)index_boss_node(g, t_rc, ctr);
+}
+MGX_DEV bool build_pal_bit(const DevGraph &g, uint64_t e) {
+    if (g.k & 1) return false;
+    LineCtr ctr = { 0, 0, 0 };
+    const Spell h = base_spelling(g, e, ctr);
+    return !h.dollar && kmer_is_palindrome(h.code, (int32_t)g.k);
+}
+
+MGX_DEV int canon_children_tables(const DevGraph &g, uint32_t v, uint32_t *nodes, uint8_t *codes, bool *sentinel, LineCtr &ctr) {
+    const PrimaryTables T = primary_tables(g);
+    const uint64_t off = g.n;
+    uint32_t have = 0;
+    int n = 0;
+    *sentinel = false;
+    uint64_t nn[5];
+    uint32_t cc[5];
+    auto child_id_b = [&](uint64_t p) -> uint32_t {
+        ++ctr.bit_lines;
+        return ((gld(T.pal + (p >> 6)) >> (p & 63)) & 1) ? (uint32_t)p : (uint32_t)(p + off);
+    };
+    if (v <= off) {
+        // set A, direct: DBGSuccinct::call_outgoing_kmers (as dev_graph.hpp outgoing()), keeping the target node's number
+        ++ctr.rank_lines;
+        Block cur = load_block(g, (uint32_t)(v >> 6));
+        const uint32_t wv = block_W(cur, (int)(v & 63));
+        if (v > 1 && wv == 0) return 0;
+        Block tgt;
+        const uint64_t lst = fwd_from(g, v, cur, wv % SIGMA, tgt, ctr);
+        uint64_t first = pred_last_from(g, lst - 1, ((lst - 1) >> 6) == (lst >> 6) ? tgt : load_block(g, (uint32_t)((lst - 1) >> 6)), ctr) + 1;
+        if (first < 2) first = 2;
+        Block b = tgt;
+        uint32_t bi = (uint32_t)(lst >> 6);
+        for (uint64_t i = first; i <= lst; ++i) {
+            if ((uint32_t)(i >> 6) != bi) { bi = (uint32_t)(i >> 6); ++ctr.rank_lines; b = load_block(g, bi); }
+            const uint32_t c = block_W(b, (int)(i & 63)) % SIGMA;
+            if (!in_graph(g, i)) continue;
+            if (c == 0) { *sentinel = true; continue; }
+            if (n < 4) { nodes[n] = (uint32_t)i; codes[n] = (uint8_t)c; have |= 1u << c; ++n; }
+        }
+        if (n == 4) return n;
+        // set B: parents of the reverse complement of the target node
+        const uint32_t node_no = tgt.last_cum + (uint32_t)popc64(tgt.last_bits & mask_upto((int)(lst & 63)));
+        ++ctr.bit_lines;
+        const uint64_t e = gld(T.rc_node + node_no);
+        if (!e) return n;
+        const int mi = incoming(g, e, nn, cc, ctr);
+        for (int t = 0; t < mi; ++t) {
+            if (cc[t] == 0) continue;
+            const uint32_t a = 5u - cc[t];
+            if (have & (1u << a)) continue;
+            nodes[n] = child_id_b(nn[t]); codes[n] = (uint8_t)a; have |= 1u << a; ++n;
+        }
+        return n;
+    }
+    const uint64_t u = v - off;
+    const int mi = incoming(g, u, nn, cc, ctr);                                    // set B, direct
+    for (int t = 0; t < mi; ++t) {
+        if (cc[t] == 0) { *sentinel = true; continue; }
+        const uint32_t a = 5u - cc[t];
+        nodes[n] = child_id_b(nn[t]); codes[n] = (uint8_t)a; have |= 1u << a; ++n;
+    }
+    if (n == 4) return n;
+    // set A: the edges of the reverse complement of u's source node, from its last edge backwards
+    const uint32_t node_no = rank_last(g, u - 1, ctr) + 1;
+    ++ctr.bit_lines;
+    uint64_t e = gld(T.rc_node + node_no);
+    if (!e) return n;
+    ++ctr.rank_lines;
+    Block b = load_block(g, (uint32_t)(e >> 6));
+    uint32_t bi = (uint32_t)(e >> 6);
+    do {
+        const uint32_t a = block_W(b, (int)(e & 63)) % SIGMA;
+        if (a != 0 && in_graph(g, e) && !(have & (1u << a)) && n < 4) {
+            nodes[n] = (uint32_t)e; codes[n] = (uint8_t)a; have |= 1u << a; ++n;
+        }
+        --e;
+        if (!e) break;
+        if ((uint32_t)(e >> 6) != bi) { bi = (uint32_t)(e >> 6); ++ctr.rank_lines; b = load_block(g, bi); }
+    } while (!((b.last_bits >> (e & 63)) & 1));
+    return n;
 }
 
 // number of callbacks of call_outgoing_kmers(v), the sentinel one included (:236-239: reported only when the base graph has

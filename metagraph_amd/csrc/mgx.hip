@@ -97,6 +97,20 @@ __global__ void k_terminus_primary(DevGraph g, uint64_t *bits, uint64_t *bits_rc
     if ((threadIdx.x & 63) == 0 && (v >> 6) < ((g.n + 64) >> 6)) { bits[v >> 6] = m0; bits_rc[v >> 6] = m1; }
 }
 
+// PRIMARY graphs (unless MGX_PRIMARY_TABLES=0): palindrome bit of every edge and, per BOSS node, the last edge of its
+// reverse complement's node (canon_graph.hpp, canon_children_tables)
+__global__ void k_primary_tables(DevGraph g, uint64_t *pal, uint32_t *rc_node) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;       // blockDim multiple of 64
+    const bool live = e >= 1 && e <= g.n;
+    const uint64_t m = __ballot(live && build_pal_bit(g, e));
+    if ((threadIdx.x & 63) == 0 && (e >> 6) < ((g.n + 64) >> 6)) pal[e >> 6] = m;
+    if (live) {
+        const Block b = load_block(g, (uint32_t)(e >> 6));
+        if ((b.last_bits >> (e & 63)) & 1)
+            rc_node[b.last_cum + (uint32_t)popc64(b.last_bits & mask_upto((int)(e & 63)))] = build_rc_node(g, e);
+    }
+}
+
 // PRIMARY graphs: base-graph mappings of both strands -> the wrapper's paths (canon_merge_pair), one wavefront per read
 __global__ void k_canon_merge(DevGraph g, const char *seqs, const uint64_t *offsets, const uint64_t *node_begin,
                               uint32_t *nodes_fwd, uint32_t *nodes_rc, uint64_t n_reads) {
@@ -274,6 +288,7 @@ struct mgx_graph {
     DevBuf blocks, last_hint, w_hint[4], firstc, terminus, valid, prefix_tbl;
     uint64_t bytes = 0;
     uint32_t mode = MGX_MODE_BASIC;
+    bool primary_tables = false;      // PRIMARY: reverse-complement tables built (default; MGX_PRIMARY_TABLES=0 turns them off)
 };
 
 extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);    // mgx_grp.hip, MGX_GROUP=8
@@ -543,10 +558,20 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
         HIP_TRY(hipDeviceSynchronize());
     }
     // MEM terminus bits
-    if (int rc = G->terminus.ensure((size_t)n_blocks * 8 * (G->mode == MGX_MODE_PRIMARY ? 2 : 1))) return rc;
+    // (PRIMARY graphs: terminus | terminus of the ids v + n | palindrome bits | rc_node table — canon_graph.hpp primary_tables().
+    // MGX_PRIMARY_TABLES=0 leaves the last two out (4 bytes per BOSS node less) and the wrapper re-derives spellings and look-ups
+    // per expansion: same results, ~7x the random lines)
+    G->primary_tables = G->mode == MGX_MODE_PRIMARY && !(getenv("MGX_PRIMARY_TABLES") && atoi(getenv("MGX_PRIMARY_TABLES")) == 0);
+    const size_t terminus_bytes = G->mode != MGX_MODE_PRIMARY ? (size_t)n_blocks * 8
+                                  : (size_t)n_blocks * 8 * 3 + (G->primary_tables ? (size_t)(tot[5] + 2) * 4 : 0);
+    if (int rc = G->terminus.ensure(terminus_bytes, true)) return rc;
+    if (G->mode == MGX_MODE_PRIMARY) HIP_TRY(hipMemset(G->terminus.p, 0, terminus_bytes));
     g.terminus = G->terminus.as<uint64_t>();
     if (G->mode == MGX_MODE_PRIMARY) {
         k_terminus_primary<<<n_blocks, 64>>>(g, G->terminus.as<uint64_t>(), G->terminus.as<uint64_t>() + n_blocks);
+        if (G->primary_tables)
+            k_primary_tables<<<n_blocks, 64>>>(g, G->terminus.as<uint64_t>() + 2ull * n_blocks,
+                                               reinterpret_cast<uint32_t *>(G->terminus.as<uint64_t>() + 3ull * n_blocks));
     } else {
         k_terminus<<<n_blocks, 64>>>(g, G->terminus.as<uint64_t>());
     }
@@ -580,7 +605,7 @@ int mgx_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_l
         if (rc) return fail(rc, "%s", err.c_str());
     }
     if (g->mode == MGX_MODE_CANONICAL) { A->dcfg.canonical = 1; A->dcfg.fwd_and_rc = 1; }     // dbg_aligner.cpp:225-226
-    if (g->mode == MGX_MODE_PRIMARY) { A->dcfg.canonical = 2; A->dcfg.fwd_and_rc = 1; }       // through the wrapper
+    if (g->mode == MGX_MODE_PRIMARY) { A->dcfg.canonical = g->primary_tables ? 3 : 2; A->dcfg.fwd_and_rc = 1; }   // through the wrapper
     mgx_config &c = A->cfg;
     if (limits) { A->user_lim = *limits; A->have_user_lim = true; }
     HIP_TRY(hipSetDevice(g->device));
@@ -855,7 +880,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         static const uint32_t pct = getenv("MGX_EXT_GROUPS_PCT") ? (uint32_t)std::min(100, std::max(1, atoi(getenv("MGX_EXT_GROUPS_PCT")))) : 100u;
         const uint32_t groups = 8;
         const uint32_t waves_cu = 4u * (uint32_t)mgx_grp_waves_per_simd8();
-        const bool alt = A->cfg.num_alternative_paths > 1 || A->dcfg.canonical == 2;
+        const bool alt = A->cfg.num_alternative_paths > 1 || A->dcfg.canonical >= 2;
         const uint32_t static_lds = alt ? mgx_grp_static_lds8_alt() : mgx_grp_static_lds8();
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 64u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
@@ -873,13 +898,13 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             uint32_t lds8 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), budget8) & ~15u;
             if (const char *e = getenv("MGX_SEED_LDS_CAP")) lds8 = std::min<uint32_t>(lds8, (uint32_t)atoi(e)) & ~15u;     // tuning probe
             if (getenv("MGX_SEED_LDS_PRINT")) fprintf(stderr, "k_seed: static_lds %u budget8 %u lds8 %u (fast_lds_bytes %u)\n", static_lds, budget8, lds8, fast_lds_bytes(l.Lmax));
-            if (A->dcfg.canonical == 2) {
+            if (A->dcfg.canonical >= 2) {
                 if (int rc = mgx_launch_seed_primary(&P, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, lds8, 1, nullptr))
                     return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
             } else {
                 k_align<PH_SEED, MGX_SEED_WPS><<<(uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, 64, lds8>>>(P, lds8);
             }
-        } else if (A->dcfg.canonical == 2) {
+        } else if (A->dcfg.canonical >= 2) {
             if (int rc = mgx_launch_seed_primary(&P, w_slots, lds_bytes, 0, nullptr)) return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
         } else {
             k_align<PH_SEED><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);

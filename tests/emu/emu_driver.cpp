@@ -24,6 +24,7 @@ struct EmuGraph {
     std::vector<uint64_t> terminus, valid;
     std::vector<uint2> prefix_tbl;
     uint32_t mode = 0;
+    bool tables = false;      // PRIMARY: reverse-complement tables built (default; MGX_PRIMARY_TABLES=0: off)
 };
 
 struct EmuRun {
@@ -89,7 +90,10 @@ void *emu_graph_create(const mgx_boss_view *view) {
     G->firstc.assign((n + 1 + 7) / 8 + 1, 0);
     for (uint64_t e = 0; e <= n; ++e) G->firstc[e >> 3] |= (uint32_t)(D0[e] & 0xF) << (4 * (e & 7));
     g.firstc = G->firstc.data();
-    G->terminus.assign((size_t)n_blocks * (G->mode == MGX_MODE_PRIMARY ? 2 : 1), 0);
+    // PRIMARY: terminus | terminus of the ids v + n | palindrome bits | rc_node table (canon_graph.hpp primary_tables())
+    const uint64_t n_nodes = rank_last(g, n, ctr);
+    G->tables = G->mode == MGX_MODE_PRIMARY && !(getenv("MGX_PRIMARY_TABLES") && atoi(getenv("MGX_PRIMARY_TABLES")) == 0);    // as mgx_graph_create
+    G->terminus.assign(G->mode == MGX_MODE_PRIMARY ? (size_t)n_blocks * 3 + (G->tables ? (n_nodes + 2) / 2 + 1 : 0) : (size_t)n_blocks, 0);
     g.terminus = G->terminus.data();
     if (G->mode == MGX_MODE_PRIMARY) {
         // the wrapper's degrees (as k_terminus_primary in mgx.hip)
@@ -98,6 +102,13 @@ void *emu_graph_create(const mgx_boss_view *view) {
             const uint32_t t = build_terminus_primary(g, v);
             if (t & 1) G->terminus[v >> 6] |= 1ull << (v & 63);
             if (t & 2) G->terminus[n_blocks + (v >> 6)] |= 1ull << (v & 63);
+        }
+        if (G->tables) {                                       // as k_primary_tables in mgx.hip
+            uint32_t *rcn = reinterpret_cast<uint32_t *>(G->terminus.data() + 3ull * n_blocks);
+            for (uint64_t e = 1; e <= n; ++e) {
+                if (build_pal_bit(g, e)) G->terminus[2ull * n_blocks + (e >> 6)] |= 1ull << (e & 63);
+                if (view->last[e]) rcn[rank_last(g, e, ctr)] = build_rc_node(g, e);
+            }
         }
         return G;
     }
@@ -129,7 +140,8 @@ uint32_t emu_canon_children(void *h, uint64_t v, uint64_t *nodes, char *chars, i
     Spell sp = base_spelling(g, is_rc ? v - g.n : v, ctr);
     if (is_rc) sp = spell_reverse_complement(sp, (int32_t)g.k);
     uint32_t nn[4]; uint8_t cc[4]; bool sent;
-    int n = canon_children(g, (uint32_t)v, sp, nn, cc, &sent, ctr);
+    int n = static_cast<EmuGraph *>(h)->tables ? canon_children_tables(g, (uint32_t)v, nn, cc, &sent, ctr)
+                                               : canon_children(g, (uint32_t)v, sp, nn, cc, &sent, ctr);
     for (int t = 0; t < n; ++t) { nodes[t] = nn[t]; chars[t] = (char)decode_code(cc[t]); }
     *sentinel = sent;
     return (uint32_t)n;
@@ -166,7 +178,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     int rc = prepare_config(*config, G->g.k, &cfg, &dcfg, &R->error);
     if (rc) return R;
     if (G->mode == MGX_MODE_CANONICAL) { dcfg.canonical = 1; dcfg.fwd_and_rc = 1; }      // as mgx_aligner_create
-    if (G->mode == MGX_MODE_PRIMARY) { dcfg.canonical = 2; dcfg.fwd_and_rc = 1; }
+    if (G->mode == MGX_MODE_PRIMARY) { dcfg.canonical = G->tables ? 3 : 2; dcfg.fwd_and_rc = 1; }
     const uint32_t k = G->g.k;
     uint32_t Lmax = 0;
     R->node_begin.assign(n + 1, 0);

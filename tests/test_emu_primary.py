@@ -179,12 +179,16 @@ def test_primary_mapping_is_the_wrappers():
         assert list(rev) == mirrored, q
 
 
-@pytest.mark.parametrize("lanes", ["8"])
-def test_primary_in_the_8_lane_group_model(lanes):
+@pytest.mark.parametrize("lanes,tables", [("8", "1"), ("", "0"), ("8", "0")])
+def test_primary_in_the_8_lane_group_model_and_without_tables(lanes, tables):
+    """The same checks with 8 lanes per read (the extension kernel's geometry), and with MGX_PRIMARY_TABLES=0: the wrapper
+    re-deriving spellings and look-ups per expansion instead of reading the reverse-complement tables (a load-time choice, so
+    these run in subprocesses)."""
     import subprocess
     import sys
-    env = dict(os.environ, MGX_EMU_WAVE=lanes)
+    env = dict(os.environ, MGX_EMU_WAVE=lanes, MGX_PRIMARY_TABLES=tables)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", os.path.abspath(__file__), "-k",
-                        "random_worlds or split_multipass or sub_k_seeding", "-p", "no:cacheprovider"],
+                        "random_worlds or split_multipass or sub_k_seeding or wrapper_children or cli_goldens or kats",
+                        "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -3,8 +3,9 @@ metagraph_amd/csrc/canon_graph.hpp — wrapper mapping, reverse-complement sub-k
 the reference's PRIMARY KATs, the primary genome.MT CLI goldens byte for byte (integration_tests/test_align.py:271-329) and
 seeded random worlds against the oracle.
 
-First hardware run (round 2): tools/check_primary_on_gpu.sh — the C++ driver on six primary graphs, 6514 reads, TSV byte-identical
-to the oracle's (profiles/r02_primary_hw_check.txt).  The file sorts last on purpose: it is the newest path."""
+Hardware runs in round 2: tools/check_primary_on_gpu.sh — the C++ driver on six primary graphs, 6514 reads, TSV byte-identical
+to the oracle's in both wrapper modes (profiles/r02_primary_hw_check.txt) — and this file before the table mode existed
+(profiles/r02_primary_gpu_pytest.txt).  The file sorts last on purpose: it is the newest path."""
 import ctypes as C
 import os
 import struct
@@ -21,6 +22,16 @@ from test_emu_primary import primary_world
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(autouse=True, params=["tables", "no-tables"])
+def _wrapper_mode(request, monkeypatch):
+    """Both ways the device walks the wrapper: reverse-complement tables built at load time (default) and, with
+    MGX_PRIMARY_TABLES=0, spellings and look-ups re-derived per expansion (read by mgx_graph_create)."""
+    if request.param == "no-tables":
+        monkeypatch.setenv("MGX_PRIMARY_TABLES", "0")
+    else:
+        monkeypatch.delenv("MGX_PRIMARY_TABLES", raising=False)
 
 
 def gpu_graph(g):
