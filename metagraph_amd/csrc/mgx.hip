@@ -743,7 +743,7 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
         }
     }
     HIP_TRY(hipGetLastError());
-    if (A->graph->mode == MGX_MODE_PRIMARY && do_rc) {
+    if (A->graph->mode == MGX_MODE_PRIMARY && do_rc && n) {
         k_canon_merge<<<(uint32_t)std::min<uint64_t>((n + 3) / 4, 65536), 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
                                                                              A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(), n);
         HIP_TRY(hipGetLastError());

@@ -192,3 +192,26 @@ def test_primary_in_the_8_lane_group_model_and_without_tables(lanes, tables):
                         "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_align_low_similarity4_rep_primary_through_the_kernels():
+    # tests/graph/test_aligner.cpp:1602-1634: three alignments of a low-complexity query on the k = 6 primary transcripts graph
+    from test_alt_paths import QUERY
+    contigs, _ = primary_contigs(read_fasta(os.path.join(HERE, "golden", "transcripts_100.fa")), 6)
+    g = orc.Graph.build(6, contigs, PRIMARY, True)
+    c = capi.config_default()
+    capi.set_dna_matrix(c, 2, -3, -3)
+    c.gap_opening_penalty, c.gap_extension_penalty = -5, -2
+    c.xdrop = 27
+    c.min_exact_match = 0.0
+    c.max_nodes_per_seq_char = 10.0
+    c.num_alternative_paths = 3
+    c.min_seed_length = 6
+    lim = capi.Limits()
+    lim.max_columns = 60000
+    want = orc.AlignRun(g, c, [QUERY]).results()
+    assert len(want[0]) == 3
+    e = emu_drv.EmuRun(emu_drv.EmuGraph(g, mode=PRIMARY), c, [QUERY], limits=lim)
+    assert e.error == ""
+    got, status = e.results()
+    assert status == [0] and got == want

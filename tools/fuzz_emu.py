@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the kernels' wave programs (host model, tests/emu) against the oracle: random graphs in all three
+modes, random aligner configurations, random reads; stops at the first difference and prints a reproducer.
+    python tools/fuzz_emu.py [--minutes M] [--seed S] [--lanes 64|8]
+CPU only (test infrastructure: the oracle is the checker, the host model runs the same sources the HIP build compiles)."""
+import argparse
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--minutes", type=float, default=5.0)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--lanes", default="")
+    args = ap.parse_args()
+    if args.lanes in ("8", "16"):
+        os.environ["MGX_EMU_WAVE"] = args.lanes
+    import emu_drv
+    import orc
+    from metagraph_amd import capi
+    from test_emu_vs_oracle import rand_seq, mutate, rc
+    from test_oracle_primary_goldens import primary_contigs
+
+    t_end = time.time() + 60 * args.minutes
+    it = 0
+    n_reads_total = 0
+    while time.time() < t_end:
+        seed = args.seed * 1000003 + it
+        rng = random.Random(seed)
+        it += 1
+        mode = rng.choice([0, 0, 1, 2, 2])
+        k = rng.choice([5, 6, 7, 8, 11, 12, 15, 19, 20, 27, 31, 32])
+        mask = rng.random() < 0.4
+        glen = rng.choice([300, 1000, 3000])
+        genome = rand_seq(rng, glen)
+        seqs = [genome]
+        if rng.random() < 0.5:                                   # repeats and inverted repeats
+            unit = rand_seq(rng, rng.choice([15, 40, 90]))
+            genome = genome[:glen // 3] + unit + genome[glen // 3:2 * glen // 3] + (rc(unit) if rng.random() < 0.5 else unit) + genome[2 * glen // 3:]
+            seqs = [genome]
+        for _ in range(rng.choice([0, 5, 30])):                  # variants (bubbles)
+            p = rng.randrange(k, len(genome) - k)
+            alt = rng.choice([c for c in "ACGT" if c != genome[p]])
+            seqs.append(genome[max(0, p - k + 1):p] + alt + genome[p + 1:p + k])
+        if mode == 2:
+            seqs = primary_contigs(seqs, k, rng.choice(["input", "lex", "colex"]))[0]
+        try:
+            g = orc.Graph.build(k, seqs, mode, mask)
+        except Exception as e:                                   # e.g. a primary set that is not one (palindromic overlap)
+            print("skip build:", e)
+            continue
+        eg = emu_drv.EmuGraph(g, mode=mode)
+        cfg = capi.config_cli(k)
+        cfg.min_exact_match = rng.choice([0.0, 0.0, 0.7])
+        if rng.random() < 0.5:
+            cfg.min_seed_length = rng.randrange(max(3, k // 3), k + 1)
+        if rng.random() < 0.3:
+            cfg.max_seed_length = rng.choice([k, k + 20, 2 ** 32])
+            if cfg.max_seed_length < cfg.min_seed_length:
+                cfg.max_seed_length = cfg.min_seed_length
+        cfg.max_num_seeds_per_locus = rng.choice([1, 2, 1000])
+        cfg.xdrop = rng.choice([10, 27, 27, 50])
+        cfg.num_alternative_paths = rng.choice([1, 1, 1, 2, 3])
+        cfg.forward_and_reverse_complement = rng.choice([0, 1, 1])
+        if rng.random() < 0.3:
+            capi.set_dna_matrix(cfg, 2, -rng.choice([1, 3]), -rng.choice([2, 3]))
+            cfg.gap_opening_penalty, cfg.gap_extension_penalty = -rng.choice([3, 5]), -rng.choice([1, 2])
+        cfg.seed_complexity_filter = rng.choice([0, 1])
+        cfg.max_nodes_per_seq_char = rng.choice([5.0, 12.5, 50.0])
+        reads = []
+        for i in range(rng.choice([5, 20])):
+            L = rng.choice([k - 1, k, k + 3, 40, 100, 150])
+            L = max(1, min(L, len(genome) - 1))
+            if rng.random() < 0.1:
+                r = rand_seq(rng, L)
+            else:
+                p = rng.randrange(0, len(genome) - L)
+                r = mutate(rng, genome[p:p + L], rng.choice([0.0, 0.02, 0.08]))
+            if rng.random() < 0.5:
+                r = rc(r)
+            if rng.random() < 0.1 and len(r) > 4:
+                q = rng.randrange(len(r))
+                r = r[:q] + rng.choice(["N", "n", "a", "x"]) + r[q + 1:]
+            if r:
+                reads.append(r)
+        for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST"):
+            os.environ.pop(v, None)
+        if rng.random() < 0.5:
+            os.environ["MGX_EMU_SPLIT"] = "1"
+            if rng.random() < 0.5:
+                os.environ["MGX_EMU_MULTIPASS"] = "1"
+        if rng.random() < 0.15:
+            os.environ["MGX_NO_FAST"] = "1"
+        desc = dict(seed=seed, mode=mode, k=k, mask=mask, glen=len(genome), n_seqs=len(seqs), msl=cfg.min_seed_length,
+                    maxsl=cfg.max_seed_length, per_locus=cfg.max_num_seeds_per_locus, xdrop=cfg.xdrop, n_alt=cfg.num_alternative_paths,
+                    fwd_rc=cfg.forward_and_reverse_complement, mem=cfg.min_exact_match,
+                    env={v: os.environ.get(v) for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST")})
+        try:
+            o = orc.AlignRun(g, cfg, reads)
+            if o.error:
+                print("oracle error (skipped):", o.error[:100], desc)
+                continue
+            e = emu_drv.EmuRun(eg, cfg, reads)
+            assert e.error == "", e.error
+            got, status = e.results()
+            want = o.results()
+            for q in range(len(reads)):
+                if status[q] != 0:
+                    continue                                     # capacity status: allowed, never a wrong answer
+                assert got[q] == want[q], ("read %d %s" % (q, reads[q]), got[q], want[q])
+            n_reads_total += len(reads)
+        except AssertionError as ex:
+            print("MISMATCH", desc)
+            print(str(ex)[:3000])
+            sys.exit(1)
+    print("ok: %d worlds, %d reads, no difference" % (it, n_reads_total))
+
+
+if __name__ == "__main__":
+    main()
