@@ -2,7 +2,7 @@
 node space base + offset, map_to_nodes_sequentially :55-146, call_outgoing_kmers / call_incoming_kmers through the reverse
 complement's (k-1)-mer range :156-330,574-684, reverse_complement :515-560) against the wrapper's own KATs
 (tests/graph/test_canonical_dbg.cpp: InsertSequence :73-85, ReverseComplement :87-101, Traversals1 :103-158, Traversals2
-:160-195).  SURVEY 8(f) rank 1; the aligner on this view: below, tests/test_oracle_primary_goldens.py and test_emu_primary.py.  The reference's test helper builds
+:160-195, the dummy k-mer traversals :1239-1640).  SURVEY 8(f) rank 1; the aligner on this view: below, tests/test_oracle_primary_goldens.py and test_emu_primary.py.  The reference's test helper builds
 PRIMARY graphs from primary contigs; here the inputs are chosen so that the sequences themselves hold one k-mer of every
 pair (the assertions do not depend on which one)."""
 import ctypes as C
@@ -117,6 +117,84 @@ def test_traversals2(k):
     assert it and traverse(g, it, "G") == it
     assert traverse(g, it, "T") == cmap(g, "G" * (k - 1) + "T")[-1]
     assert traverse_back(g, traverse(g, it, "T"), "G") == it
+
+
+# ---- dummy k-mers seen through the wrapper (test_canonical_dbg.cpp:1239-1640; unmasked DBGSuccinct(31, PRIMARY)) ----
+DUMMY_GRAPHS = {
+    "sink_source": ["CTTCCTTCCTTCTTTCCTTCCTTCCTTCCTC"],
+    "dummy": ["CTTCCTTCCTTCTTTCCTTCCTTCCTTCCTC", "AAGGAAGGAAGGAAGGAAAGAAGGAAGGAAG"],
+    "to_dummy_fwd": ["TGTGCGGCGGGAATATGTACGAAGCGCAGGA", "CCTGCGCTTCGTACATATTCCCGCCGCACAG"],
+    "to_dummy_bwd": ["TGTGCGGCGGGAATATGTACGAAGCGCAGGA", "TTCCTGCGCTTCGTACATATTCCCGCCGCAC"],
+    "no_dual": ["TCCTGCGCTTCGTACATATTCCCGCCGCACT", "TGTGCGGCGGGAATATGTACGAAGCGCAGGA"],
+    "no_dup_sink": ["TCCTGCGCTTCGTACATATTCCCGCCGCACT", "AGTGCGGCGGGAATATGTACGAAGCGCAGGC"],
+}
+
+
+def dummy_graph(name):
+    return orc.Graph.build(31, DUMMY_GRAPHS[name], PRIMARY, False)
+
+
+def base_node_spelled(g, spelling):
+    """the base graph's node (edge) with this spelling, sentinels included (the reference looks it up with index_range + bwd)"""
+    hits = [v for v in range(1, g.n_edges + 1) if g.node_sequence(v) == spelling]
+    assert len(hits) == 1, (spelling, hits)
+    return hits[0]
+
+
+def base_adjacent(g, v, incoming):
+    return g.outgoing(v, rc=False) if not incoming else [(n, rc(c) if c != "$" else c) for n, c in g.outgoing(v, rc=True)]
+
+
+def test_traversal_dummy_sink_and_source():
+    # :1239-1344: the only neighbours of the first k-mer of a lone sequence are dummy k-mers, in the base graph and through the wrapper
+    g = dummy_graph("sink_source")
+    node = cmap(g, "CTTCCTTCCTTCTTTCCTTCCTTCCTTCCTC")[0]
+    assert node
+    out = adjacent(g, node, 0)
+    assert [c for _, c in out] == ["$"] and node_seq(g, out[0][0])[-1] == "$"
+    inc = adjacent(g, node, 1)
+    assert [c for _, c in inc] == ["$"] and node_seq(g, inc[0][0])[0] == "$"
+
+
+def test_traversal_dummy():
+    # :1346-1395: a dummy source k-mer $X has its own child (C) and one more through the reverse complement (T)
+    g = dummy_graph("dummy")
+    v = base_node_spelled(g, "$" + "CTTCCTTCCTTCTTTCCTTCCTTCCTTCCT")
+    assert node_seq(g, v) == "$CTTCCTTCCTTCTTTCCTTCCTTCCTTCCT"
+    assert [c for _, c in g.outgoing(v)] == ["C"]
+    assert sorted(c for _, c in adjacent(g, v, 0)) == ["C", "T"]
+
+
+def test_traverse_no_dummy_to_dummy_forward_and_backward():
+    # :1397-1498: no step from a dummy source k-mer to the reverse complement of a dummy sink k-mer, in either direction
+    g = dummy_graph("to_dummy_fwd")
+    v = base_node_spelled(g, "$" + "TGTGCGGCGGGAATATGTACGAAGCGCAGG")
+    assert [c for _, c in g.outgoing(v)] == ["A"]
+    out = adjacent(g, v, 0)
+    assert out and all(c != "$" and node_seq(g, n)[-1] != "$" for n, c in out)
+    g = dummy_graph("to_dummy_bwd")
+    sink = base_node_spelled(g, "GTGCGGCGGGAATATGTACGAAGCGCAGGA" + "$")
+    node = _L().orc_canonical_reverse_complement(g.h, sink)
+    out = adjacent(g, node, 0)
+    assert out and all(c == "A" and node_seq(g, n)[-1] == "A" for n, c in out)
+
+
+def test_traverse_no_dual_dummy_and_no_duplicate_sink():
+    # :1500-1640: the reverse complements of dummy k-mers are not neighbours: exactly one sentinel callback per side
+    g = dummy_graph("no_dual")
+    v = base_node_spelled(g, "TGTGCGGCGGGAATATGTACGAAGCGCAGGA")
+    out = adjacent(g, v, 0)
+    assert sum(c == "$" for _, c in out) == 1 and sum(node_seq(g, n)[-1] == "$" for n, _ in out) == 1
+    v = base_node_spelled(g, "TCCTGCGCTTCGTACATATTCCCGCCGCACT")
+    inc = adjacent(g, v, 1)
+    assert sum(c == "$" for _, c in inc) == 1 and sum(node_seq(g, n)[0] == "$" for n, _ in inc) == 1
+    g = dummy_graph("no_dup_sink")
+    start = cmap(g, "TCCTGCGCTTCGTACATATTCCCGCCGCACT")[0]
+    out = adjacent(g, start, 0)
+    assert all(c == "$" for _, c in out) and len({n for n, _ in out}) == len(out)
+    start = cmap(g, "AGTGCGGCGGGAATATGTACGAAGCGCAGGC")[0]
+    inc = adjacent(g, start, 1)
+    assert all(c == "$" for _, c in inc) and len({n for n, _ in inc}) == len(inc)
 
 
 # ---- the aligner on the wrapper (PRIMARY graph + CanonicalDBG): the reference's PRIMARY KATs ----
