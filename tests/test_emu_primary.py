@@ -218,3 +218,22 @@ def test_align_low_similarity4_rep_primary_through_the_kernels():
     assert e.error == ""
     got, status = e.results()
     assert status == [0] and got == want
+
+
+def test_cli_map_counts_through_the_wrapper_and_the_kernels():
+    """`metagraph align --map --count-kmers` wraps a PRIMARY graph into CanonicalDBG first (cli/align.cpp:345-348): every k-mer
+    of the canonical graph is found through the wrapper, so discovered / k-mers are those of the canonical-graph golden
+    (integration_tests/test_align.py:124-150); the device mapping path returns the wrapper's ids."""
+    from test_oracle_canonical import CANONICAL_MAP_COUNTS
+    contigs, _ = primary_contigs(read_fasta(os.path.join(HERE, "golden", "genome.MT.fa")), 11, "lex")
+    g = orc.Graph.build(11, contigs, PRIMARY, True)
+    reads = [r[1] for r in read_fastq(os.path.join(HERE, "golden", "genome_MT1.fq"))]
+    lib = canon_lib()
+    paths = []
+    for r in reads:
+        out = (C.c_uint64 * (len(r) - 11 + 1))()
+        lib.orc_canonical_map(g.h, r.encode(), len(r), out)
+        paths.append(list(out))
+    assert ["%d/%d" % (sum(1 for v in p if v), len(p)) for p in paths] == [c.rsplit("/", 1)[0] for c in CANONICAL_MAP_COUNTS]
+    e = emu_drv.EmuRun(emu_drv.EmuGraph(g, mode=PRIMARY), capi.config_cli(11), reads, map_only=True)
+    assert [list(fwd) for fwd, _ in e.mapping()] == paths

@@ -113,3 +113,26 @@ def test_cli_golden_canonical_mode_sub_k_seeds():
     for i, want in CANONICAL_LINES.items():
         assert lines[i] == want
     assert lines[5] == SUBK_LINE_5
+
+
+# integration_tests/test_align.py:124-150: `metagraph align --map --count-kmers` on the canonical genome.MT graph prints
+# discovered / k-mers / distinct matched nodes per read (cli/align.cpp:152-164).  That caller uses DeBruijnGraph::map_to_nodes,
+# which on a CANONICAL-mode DBGSuccinct takes, per k-mer, the smaller of its own edge and its reverse complement's
+# (dbg_succinct.cpp:436-470) — not the aligner's map_to_nodes_sequentially; both strands' sequential mappings give it.
+CANONICAL_MAP_COUNTS = ["140/140/140", "140/140/140", "140/140/140", "129/140/129", "140/140/139", "2/140/2", "140/140/140"]
+
+
+def map_counts(paths):
+    return ["%d/%d/%d" % (sum(1 for v in p if v), len(p), len({v for v in p if v})) for p in paths]
+
+
+def canonical_map_to_nodes(fwd, rev):
+    """DBGSuccinct::map_to_nodes in CANONICAL mode from the two sequential mappings (a missing k-mer is missing on both strands)"""
+    return [min(a, b) if a and b else 0 for a, b in zip(fwd, rev[::-1])]
+
+
+def test_cli_map_counts_canonical_mode():
+    g = orc.Graph.build(11, read_fasta(os.path.join(HERE, "golden", "genome.MT.fa")), CANONICAL, True)
+    reads = read_fastq(os.path.join(HERE, "golden", "genome_MT1.fq"))
+    run = orc.AlignRun(g, capi.config_cli(11), [r[1] for r in reads])
+    assert map_counts([canonical_map_to_nodes(fwd, rev) for fwd, rev in run.mapping()]) == CANONICAL_MAP_COUNTS

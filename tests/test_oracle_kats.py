@@ -137,6 +137,7 @@ def test_cli_map_counts(mt_graph):
         matched = sum(1 for v in fwd if v)
         w = want.split("/")
         assert matched == int(w[0]) and len(fwd) == int(w[1]), (matched, len(fwd), want)
+        assert len({v for v in fwd if v}) == int(w[2]), want               # distinct matched nodes (cli/align.cpp:152-164)
 
 
 def test_no_undefined_reads():
