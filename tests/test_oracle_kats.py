@@ -273,3 +273,19 @@ def test_json_output_of_secondary_and_empty_results_is_well_formed():
     if view.aln_begin[1] == view.aln_begin[2]:
         assert empty == '{"name":"q1","sequence":""}\n'
     assert MATCH
+
+
+def test_cli_sub_k_map_counts(mt_graph):
+    """integration_tests/test_align.py:89-121: `align --map --count-kmers --align-length 10` on the k = 11 genome.MT graph: every
+    10-character window is looked up with call_nodes_with_suffix_matching_longest_prefix(window, ..., 10) and the FIRST node
+    reported counts (cli/align.cpp:114-131) — the look-up the sub-k seeder runs on."""
+    reads = read_fastq(os.path.join(HERE, "golden", KATS["cli"]["reads_fastq"]))
+    want = ["3/141/3", "141/141/141", "141/141/141", "1/141/1", "141/141/141", "4/141/4", "3/141/3"]
+    got = []
+    for _, seq, *_ in reads:
+        nodes = []
+        for i in range(len(seq) - 10 + 1):
+            hits, match_len = mt_graph.suffix_match(seq[i:i + 10], 10)
+            nodes.append(hits[0] if hits else 0)
+        got.append("%d/%d/%d" % (sum(1 for v in nodes if v), len(nodes), len({v for v in nodes if v})))
+    assert got == want
