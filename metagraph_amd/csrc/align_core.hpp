@@ -1113,14 +1113,46 @@ MGX_DEV void primary_rc_suffix_seeds(Wave &w, int s, uint32_t alt_n) {
         }
         return true;
     };
-    for (int32_t i = 0; i + msl0 <= L; ++i) {
+    // The look-up length of position i depends on min_seed_length[] as updated so far (:262-268), which only ever grows during
+    // this phase.  So all look-ups run first, one position per lane, at the lengths the bounds allow now; the sequential pass
+    // below takes a result as it is unless its match is longer than the (possibly smaller) length allowed by then — only that
+    // case changes the range — and redoes just those.  (w.ml / w.rfirst / w.rlast are free after the forward phase.)
+    auto allowed_length = [&](int32_t i) -> int32_t {            // 0: the position is skipped
         int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)boss_k), (uint32_t)(L - i));
         int32_t j_min = L - i - max_len;
         const int32_t j_max = L - i - msl0;
         while (j_min <= j_max && (int32_t)w.msl[j_min] > max_len) { ++j_min; --max_len; }
-        if (j_min > j_max) continue;
-        uint64_t first, last;
-        const int32_t sl = index_range_lane(w, so, i, max_len, msl0, &first, &last, w.ctr);
+        return j_min > j_max ? 0 : max_len;
+    };
+    for (int32_t base = 0; base + msl0 <= L; base += WAVE) {
+        LV<int32_t> nr, ns;
+        FOR_LANES(l) {
+            LineCtr lc = { 0, 0, 0 };
+            const int32_t i = base + l;
+            if (i + msl0 <= L) {
+                const int32_t max_len = allowed_length(i);
+                uint16_t m = 0;
+                uint32_t f = 0, la = 0;
+                if (max_len) {
+                    uint64_t first, last;
+                    const int32_t sl = index_range_lane(w, so, i, max_len, msl0, &first, &last, lc);
+                    if (sl >= msl0) { m = (uint16_t)sl; f = (uint32_t)first; la = (uint32_t)last; }
+                }
+                w.ml[i] = m; w.rfirst[i] = f; w.rlast[i] = la;
+            }
+            nr[l] = (int32_t)(lc.rank_lines + lc.bit_lines); ns[l] = (int32_t)lc.select_lines;
+        }
+        w.ctr.rank_lines += (uint32_t)wave_sum(nr);
+        w.ctr.select_lines += (uint32_t)wave_sum(ns);
+    }
+    wave_sync();
+    for (int32_t i = 0; i + msl0 <= L; ++i) {
+        if (!w.ml[i]) continue;                                  // skipped or shorter than min_seed_length then: still so now
+        const int32_t max_len = allowed_length(i);
+        if (!max_len) continue;
+        uint64_t first = w.rfirst[i], last = w.rlast[i];
+        int32_t sl = w.ml[i];
+        if (sl > max_len) sl = index_range_lane(w, so, i, max_len, msl0, &first, &last, w.ctr);
         if (sl < msl0) continue;
         const int32_t j = L - i - sl;
         if (sl < (int32_t)w.msl[j]) continue;

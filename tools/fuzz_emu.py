@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lanes", default="")
+    ap.add_argument("--modes", default="0,0,1,2,2", help="graph modes to draw from (0 BASIC, 1 CANONICAL, 2 PRIMARY)")
     args = ap.parse_args()
     if args.lanes in ("8", "16"):
         os.environ["MGX_EMU_WAVE"] = args.lanes
@@ -35,7 +36,7 @@ def main():
         seed = args.seed * 1000003 + it
         rng = random.Random(seed)
         it += 1
-        mode = rng.choice([0, 0, 1, 2, 2])
+        mode = rng.choice([int(m) for m in args.modes.split(",")])
         k = rng.choice([5, 6, 7, 8, 11, 12, 15, 19, 20, 27, 31, 32])
         mask = rng.random() < 0.4
         glen = rng.choice([300, 1000, 3000])
