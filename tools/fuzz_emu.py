@@ -91,18 +91,22 @@ def main():
                 r = r[:q] + rng.choice(["N", "n", "a", "x"]) + r[q + 1:]
             if r:
                 reads.append(r)
-        for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST"):
+        for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST", "MGX_EMU_LDS", "MGX_EMU_RESUME_CAP"):
             os.environ.pop(v, None)
+        if rng.random() < 0.5:                                   # modelled LDS size: which per-read arrays live in LDS / in the arena
+            os.environ["MGX_EMU_LDS"] = str(rng.choice([0, 256, 700, 1500, 4000, 20000]))
         if rng.random() < 0.5:
             os.environ["MGX_EMU_SPLIT"] = "1"
             if rng.random() < 0.5:
                 os.environ["MGX_EMU_MULTIPASS"] = "1"
+                if rng.random() < 0.3:
+                    os.environ["MGX_EMU_RESUME_CAP"] = str(rng.choice([1, 2, 5]))      # resume-record pool smaller than the batch
         if rng.random() < 0.15:
             os.environ["MGX_NO_FAST"] = "1"
         desc = dict(seed=seed, mode=mode, k=k, mask=mask, glen=len(genome), n_seqs=len(seqs), msl=cfg.min_seed_length,
                     maxsl=cfg.max_seed_length, per_locus=cfg.max_num_seeds_per_locus, xdrop=cfg.xdrop, n_alt=cfg.num_alternative_paths,
                     fwd_rc=cfg.forward_and_reverse_complement, mem=cfg.min_exact_match,
-                    env={v: os.environ.get(v) for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST")})
+                    env={v: os.environ.get(v) for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST", "MGX_EMU_LDS", "MGX_EMU_RESUME_CAP")})
         try:
             o = orc.AlignRun(g, cfg, reads)
             if o.error:
