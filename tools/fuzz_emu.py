@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lanes", default="")
+    ap.add_argument("--verbose", action="store_true", help="print every world before it runs (to find a slow or hanging one)")
     ap.add_argument("--modes", default="0,0,1,2,2", help="graph modes to draw from (0 BASIC, 1 CANONICAL, 2 PRIMARY)")
     args = ap.parse_args()
     if args.lanes in ("8", "16"):
@@ -39,7 +40,7 @@ def main():
         mode = rng.choice([int(m) for m in args.modes.split(",")])
         k = rng.choice([5, 6, 7, 8, 11, 12, 15, 19, 20, 27, 31, 32])
         mask = rng.random() < 0.4
-        glen = rng.choice([300, 1000, 3000])
+        glen = rng.choice([300, 1000, 3000, 6000])
         genome = rand_seq(rng, glen)
         seqs = [genome]
         if rng.random() < 0.5:                                   # repeats and inverted repeats
@@ -77,7 +78,9 @@ def main():
         cfg.max_nodes_per_seq_char = rng.choice([5.0, 12.5, 50.0])
         reads = []
         for i in range(rng.choice([5, 20])):
-            L = rng.choice([k - 1, k, k + 3, 40, 100, 150])
+            L = rng.choice([k - 1, k, k + 3, 40, 100, 150, 150, 400, 1200])      # long reads: wide bands, many seeds, long chains
+            if k < 11 and L > 150:
+                L = 150                                          # (tiny k x long reads: thousands of extensions per read, minutes per world)
             L = max(1, min(L, len(genome) - 1))
             if rng.random() < 0.1:
                 r = rand_seq(rng, L)
@@ -107,8 +110,13 @@ def main():
                     maxsl=cfg.max_seed_length, per_locus=cfg.max_num_seeds_per_locus, xdrop=cfg.xdrop, n_alt=cfg.num_alternative_paths,
                     fwd_rc=cfg.forward_and_reverse_complement, mem=cfg.min_exact_match,
                     env={v: os.environ.get(v) for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST", "MGX_EMU_LDS", "MGX_EMU_RESUME_CAP")})
+        if args.verbose:
+            print(desc, [len(r) for r in reads], flush=True)
         try:
+            t_w = time.time()
             o = orc.AlignRun(g, cfg, reads)
+            if args.verbose:
+                print('  oracle %.1fs' % (time.time() - t_w), flush=True)
             if o.error:
                 print("oracle error (skipped):", o.error[:100], desc)
                 continue
