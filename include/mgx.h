@@ -211,7 +211,8 @@ uint32_t mgx_abi_version(void);
 int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out);
 void mgx_graph_destroy(mgx_graph *g);
 uint32_t mgx_graph_k(const mgx_graph *g);            /* DeBruijnGraph::get_k  (sequence_graph.hpp:176) */
-uint64_t mgx_graph_max_index(const mgx_graph *g);    /* DeBruijnGraph::max_index (dbg_succinct.cpp:686-688) */
+uint64_t mgx_graph_max_index(const mgx_graph *g);    /* DeBruijnGraph::max_index (dbg_succinct.cpp:686-688); PRIMARY: 2 x that,
+                                                      * as CanonicalDBG::max_index (canonical_dbg.hpp:96) */
 uint64_t mgx_graph_device_bytes(const mgx_graph *g);
 
 /* DBGAligner<>::DBGAligner(graph, config) (dbg_aligner.cpp:33-61): clamps seed lengths,
@@ -253,7 +254,8 @@ void mgx_raw_store_free(mgx_raw_store *store);
 void mgx_aligner_keep_seeds(mgx_aligner *a, int keep);
 int mgx_fetch_seed_info(mgx_aligner *a, uint32_t *info6, uint32_t *seeds, uint32_t *max_seeds_out);
 
-/* Hot loop #1 only: map both strands to nodes (dbg_aligner.cpp:210,227-231). */
+/* Hot loop #1 only: map both strands to nodes (dbg_aligner.cpp:210,227-231): map_to_nodes_sequentially of the query and of
+ * its reverse complement; on a PRIMARY graph those of the CanonicalDBG wrapper (canonical_dbg.cpp:55-146,551-560). */
 int mgx_map_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uint64_t n_queries,
                   int seqs_on_device, mgx_mapping *out);
 
