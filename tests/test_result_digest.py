@@ -43,3 +43,32 @@ def test_digests_follow_a_permutation_and_see_every_field():
         assert d[q] != d1[q] and np.array_equal(np.delete(d, q), np.delete(d1, q))
         arr[idx] = old
     assert np.array_equal(query_digests(res1), d1)
+
+
+def test_kernels_are_order_independent_in_the_host_model(monkeypatch):
+    """The property tests/test_gpu_properties.py asserts on hardware, on the kernels' sources under the host model: split
+    pipeline with the work sort and the multi-pass extension, a batch and a permutation of it, compared through the digests
+    (and with the oracle's digests: the digest sees exactly what the field-by-field comparisons see)."""
+    import emu_drv
+    monkeypatch.setenv("MGX_EMU_SPLIT", "1")
+    monkeypatch.setenv("MGX_EMU_MULTIPASS", "1")
+    g, reads = make_world(4343, 19, n_reads=80)
+    reads += [reads[i][:50] + reads[i + 1][40:90] for i in range(0, 20, 2)]          # chimeras: several seeds per read
+    cfg = capi.config_cli(19)
+    cfg.min_exact_match = 0.0
+    eg = emu_drv.EmuGraph(g)
+
+    def emu_digests(batch):
+        e = emu_drv.EmuRun(eg, cfg, batch)
+        assert e.error == ""
+        res = capi.Results()
+        emu_drv.L().emu_results(e.r, C.byref(res))
+        return query_digests(res), e
+
+    d1, keep1 = emu_digests(reads)
+    perm = list(range(len(reads)))
+    random.Random(2).shuffle(perm)
+    d2, keep2 = emu_digests([reads[p] for p in perm])
+    assert np.array_equal(d2, d1[perm])
+    run, ores = _oracle_results(g, cfg, reads)
+    assert np.array_equal(query_digests(ores), d1)
