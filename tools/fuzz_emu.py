@@ -128,6 +128,12 @@ def main():
                 if status[q] != 0:
                     continue                                     # capacity status: allowed, never a wrong answer
                 assert got[q] == want[q], ("read %d %s" % (q, reads[q]), got[q], want[q])
+            if all(st == 0 for st in status):                    # the seeders' products too (seed lists, num_matches per strand)
+                info = e.seed_info()
+                for strand in (0, 1):
+                    for q, (ss, nm) in enumerate(o.seeds(strand)):
+                        assert info[q]["num_matches"][strand] == nm, ("num_matches", q, strand, reads[q])
+                        assert info[q]["seeds"][strand] == emu_drv.oracle_seeds_as_tuples(ss), ("seeds", q, strand, reads[q])
             n_reads_total += len(reads)
         except AssertionError as ex:
             print("MISMATCH", desc)
