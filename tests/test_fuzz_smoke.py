@@ -7,8 +7,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_fuzzer_runs_clean_for_a_quarter_minute():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "--minutes", "0.25", "--seed", "3"],
+def test_fuzzer_runs_clean_for_ten_seconds():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "--minutes", "0.15", "--seed", "3"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "no difference" in r.stdout

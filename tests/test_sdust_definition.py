@@ -13,7 +13,7 @@ import pytest
 import orc
 import emu_drv
 
-N_RANDOM = int(os.environ.get("MGX_SDUST_CASES", "120000"))
+N_RANDOM = int(os.environ.get("MGX_SDUST_CASES", "60000"))      # (120 000 in the long runs: MGX_SDUST_CASES)
 
 
 def gen_strings(seed, n):
