@@ -67,7 +67,7 @@ typedef struct mgx_boss_view {
                               * PRIMARY (one k-mer of every pair stored): aligned through the CanonicalDBG wrapper as the reference
                               * does (dbg_aligner.cpp:52-53, canonical_dbg.cpp): node ids above n_edges are reverse complements
                               * (id - n_edges is the stored node), mgx_graph_max_index reports 2 * n_edges.  PRIMARY needs
-                              * k <= 32 and 2 * n_edges < 2^32 (MGX_ERR_UNSUPPORTED otherwise). */
+                              * k <= 64 and 2 * n_edges < 2^32 (MGX_ERR_UNSUPPORTED otherwise). */
     uint32_t on_device;      /* 0: W/last/valid are host pointers; 1: device pointers (F always host) */
 } mgx_boss_view;
 

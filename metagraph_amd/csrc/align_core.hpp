@@ -1168,7 +1168,7 @@ MGX_DEV void primary_rc_suffix_seeds(Wave &w, int s, uint32_t alt_n) {
                         if ((gld(primary_tables(g).pal + (e >> 6)) >> (e & 63)) & 1) id = (uint32_t)e;
                     } else {
                         const Spell sp = base_spelling(g, e, w.ctr);
-                        if (!sp.dollar && kmer_is_palindrome(sp.code, k)) id = (uint32_t)e;
+                        if (kmer_is_palindrome(sp, k)) id = (uint32_t)e;
                     }
                 }
                 if (!append(j, id, sl)) return false;

@@ -20,26 +20,31 @@
 // bits of both ids of a base node are computed at load time.
 //
 // canon_children() derives h (k - 1 bwd steps) and the look-up (k - 2 tighten_range steps) for every expansion and holds the
-// spelling in two 64-bit registers, hence k <= 32 for PRIMARY graphs; canon_children_tables() further down reads both from
+// spelling in three 64-bit registers, hence k <= 64 for PRIMARY graphs; canon_children_tables() further down reads both from
 // tables built at load time and is what the kernels use by default.
 #pragma once
 #include "dev_graph.hpp"
 
 namespace mgx {
 
-// spelling of a node: character j (0 = first) at bits [2j, 2j + 2) as A C G T = 0..3; bit j of `dollar` marks a sentinel
-struct Spell { uint64_t code, dollar; };
+// spelling of a node (k <= 64): character j (0 = first) as A C G T = 0..3 in two bits of a 128-bit code, word j / 32, bits
+// [2 (j % 32), +2); bit j of `dollar` marks a sentinel
+struct Spell { uint64_t code[2], dollar; };
 
 MGX_DEV void spell_put(Spell &s, int32_t j, uint32_t c /* 0..4 */) {
     if (c == 0) s.dollar |= 1ull << j;
-    else s.code |= (uint64_t)(c - 1) << (2 * j);
+    else if (j < 32) s.code[0] |= (uint64_t)(c - 1) << (2 * j);
+    else s.code[1] |= (uint64_t)(c - 1) << (2 * (j - 32));
 }
-MGX_DEV uint32_t spell_get(const Spell &s, int32_t j) { return ((s.dollar >> j) & 1) ? 0u : (uint32_t)((s.code >> (2 * j)) & 3) + 1u; }
+MGX_DEV uint32_t spell_get(const Spell &s, int32_t j) {
+    if ((s.dollar >> j) & 1) return 0u;
+    return (uint32_t)(((j < 32 ? s.code[0] : s.code[1]) >> (2 * (j & 31))) & 3) + 1u;
+}
 
 // get_node_sequence of a base node (dbg_succinct.cpp:272-279 -> BOSS::get_node_seq boss.cpp:940-973 + the edge label)
 MGX_DEV Spell base_spelling(const DevGraph &g, uint64_t e, LineCtr &ctr) {
     const int32_t k = (int32_t)g.k;
-    Spell s = { 0, 0 };
+    Spell s = { { 0, 0 }, 0 };
     spell_put(s, k - 1, get_W(g, e, ctr) % SIGMA);
     uint64_t x = e;
     for (int32_t j = k - 2; j >= 0; --j) {
@@ -49,40 +54,48 @@ MGX_DEV Spell base_spelling(const DevGraph &g, uint64_t e, LineCtr &ctr) {
     return s;
 }
 
-MGX_DEV Spell spell_reverse_complement(const Spell &s, int32_t k) {
-    Spell r = { 0, 0 };
-    for (int32_t j = 0; j < k; ++j) {
-        const uint32_t c = spell_get(s, k - 1 - j);
+// reverse complement of the first `len` characters
+MGX_DEV Spell spell_reverse_complement(const Spell &s, int32_t len) {
+    Spell r = { { 0, 0 }, 0 };
+    for (int32_t j = 0; j < len; ++j) {
+        const uint32_t c = spell_get(s, len - 1 - j);
         spell_put(r, j, c ? 5u - c : 0u);                    // complement('$') == '$'
     }
     return r;
 }
 
-// is the k-mer with 2-bit codes `code` its own reverse complement?
-MGX_DEV bool kmer_is_palindrome(uint64_t code, int32_t k) {
-    if (k & 1) return false;
+// characters 1 .. k - 1 (the node every child starts from)
+MGX_DEV Spell spell_tail(const Spell &s, int32_t k) {
+    Spell r = { { 0, 0 }, 0 };
+    for (int32_t j = 0; j + 1 < k; ++j) spell_put(r, j, spell_get(s, j + 1));
+    return r;
+}
+
+// is the k-mer its own reverse complement?  (even k, no sentinel)
+MGX_DEV bool kmer_is_palindrome(const Spell &s, int32_t k) {
+    if ((k & 1) || s.dollar) return false;
     for (int32_t j = 0; j < k / 2; ++j)
-        if (((code >> (2 * j)) & 3) + ((code >> (2 * (k - 1 - j))) & 3) != 3) return false;
+        if (spell_get(s, j) + spell_get(s, k - 1 - j) != 5) return false;
     return true;
 }
 
-// last edge of the BOSS node spelled by the k - 1 codes of `t` (first character least significant), 0 if there is none:
+// last edge of the BOSS node spelled by the first k - 1 characters of `t` (no sentinel among them), 0 if there is none:
 // BOSS::index_range (boss.hpp:720-764) demanding a full match, as get_prefix_rc / get_suffix_rc do
-MGX_DEV uint64_t index_boss_node(const DevGraph &g, uint64_t t, LineCtr &ctr) {
+MGX_DEV uint64_t index_boss_node(const DevGraph &g, const Spell &t, LineCtr &ctr) {
     const int32_t len = (int32_t)g.k - 1;
     uint64_t rl = 1, ru = 0;
     int32_t it = 1;
     if (g.prefix_len && (int32_t)g.prefix_len <= len) {
-        const uint32_t key = (uint32_t)(t & ((1ull << (2 * g.prefix_len)) - 1));
+        const uint32_t key = (uint32_t)(t.code[0] & ((1ull << (2 * g.prefix_len)) - 1));      // prefix_len <= 16
         prefix_range(g, key, &rl, &ru, ctr);
         if (rl > ru) return 0;
         it = (int32_t)g.prefix_len;
     } else {
-        initial_range(g, (uint32_t)(t & 3) + 1, &rl, &ru);
+        initial_range(g, spell_get(t, 0), &rl, &ru);
         if (rl > ru) return 0;
     }
     for (; it < len; ++it)
-        if (!tighten_range(g, &rl, &ru, (uint32_t)((t >> (2 * it)) & 3) + 1, ctr)) return 0;
+        if (!tighten_range(g, &rl, &ru, spell_get(t, it), ctr)) return 0;
     return ru;
 }
 
@@ -97,12 +110,12 @@ MGX_DEV int canon_children(const DevGraph &g, uint32_t v, const Spell &h, uint32
     uint32_t have = 0;                                       // bit a: a child with code a was reported
     int n = 0;
     *sentinel = false;
-    const uint64_t tail = h.code >> 2;                       // h[1:], k - 1 codes
-    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    const Spell tail = spell_tail(h, k);                      // h[1:], k - 1 characters
     auto child_id_b = [&](uint64_t p, uint32_t a) -> uint32_t {
         // reverse_complement(p) (:515-549): p + n unless the k-mer (== the child h[1:] + a mirrored) is a palindrome
-        const uint64_t child = (tail | ((uint64_t)(a - 1) << (2 * (k - 1)))) & kmask;
-        return ((h.dollar >> 1) == 0 && kmer_is_palindrome(child, k)) ? (uint32_t)p : (uint32_t)(p + off);
+        Spell child = tail;
+        spell_put(child, k - 1, a);
+        return kmer_is_palindrome(child, k) ? (uint32_t)p : (uint32_t)(p + off);
     };
     const bool tail_clean = (h.dollar >> 1) == 0;            // no sentinel in h[1:]
     uint64_t nn[5];
@@ -112,9 +125,7 @@ MGX_DEV int canon_children(const DevGraph &g, uint32_t v, const Spell &h, uint32
         for (int t = 0; t < m; ++t) { nodes[n] = (uint32_t)nn[t]; codes[n] = (uint8_t)cc[t]; have |= 1u << cc[t]; ++n; }
         if (n == 4 || !tail_clean) return n;
         // set B: parents of the node RC(h[1:])
-        uint64_t t_rc = 0;
-        for (int32_t j = 0; j < k - 1; ++j) t_rc |= (3 - ((tail >> (2 * (k - 2 - j))) & 3)) << (2 * j);
-        const uint64_t e = index_boss_node(g, t_rc, ctr);
+        const uint64_t e = index_boss_node(g, spell_reverse_complement(tail, k - 1), ctr);
         if (!e) return n;
         const int mi = incoming(g, e, nn, cc, ctr);
         for (int t = 0; t < mi; ++t) {
@@ -135,7 +146,7 @@ MGX_DEV int canon_children(const DevGraph &g, uint32_t v, const Spell &h, uint32
         }
         if (n == 4 || !tail_clean) return n;
         // set A: the edges of the node h[1:], from its last edge backwards
-        uint64_t e = index_boss_node(g, tail & (kmask >> 2), ctr);
+        uint64_t e = index_boss_node(g, tail, ctr);
         if (!e) return n;
         ++ctr.rank_lines;
         Block b = load_block(g, (uint32_t)(e >> 6));
@@ -183,15 +194,13 @@ MGX_DEV uint32_t build_rc_node(const DevGraph &g, uint64_t lst) {
     const int32_t k = (int32_t)g.k;
     const Spell h = base_spelling(g, lst, ctr);              // node = the first k - 1 characters
     if (h.dollar & ((1ull << (k - 1)) - 1)) return 0;
-    uint64_t t_rc = 0;
-    for (int32_t j = 0; j < k - 1; ++j) t_rc |= (3 - ((h.code >> (2 * (k - 2 - j))) & 3)) << (2 * j);
-    return (uint32_t)index_boss_node(g, t_rc, ctr);
+    return (uint32_t)index_boss_node(g, spell_reverse_complement(h, k - 1), ctr);
 }
 MGX_DEV bool build_pal_bit(const DevGraph &g, uint64_t e) {
     if (g.k & 1) return false;
     LineCtr ctr = { 0, 0, 0 };
     const Spell h = base_spelling(g, e, ctr);
-    return !h.dollar && kmer_is_palindrome(h.code, (int32_t)g.k);
+    return kmer_is_palindrome(h, (int32_t)g.k);
 }
 
 MGX_DEV int canon_children_tables(const DevGraph &g, uint32_t v, uint32_t *nodes, uint8_t *codes, bool *sentinel, LineCtr &ctr) {

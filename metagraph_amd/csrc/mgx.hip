@@ -437,7 +437,7 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
     if (view->k < 2 || view->k > 255) return fail(MGX_ERR_INVALID, "k out of range");
     if (view->n_edges == 0 || view->n_edges >= 0xFFFFFFF0ull) return fail(MGX_ERR_UNSUPPORTED, "edge count must fit 32 bits");
     if (view->mode == MGX_MODE_PRIMARY) {
-        if (view->k > 32) return fail(MGX_ERR_UNSUPPORTED, "PRIMARY-mode graphs need k <= 32 (node spellings are held in two registers)");
+        if (view->k > 64) return fail(MGX_ERR_UNSUPPORTED, "PRIMARY-mode graphs need k <= 64 (the load-time kernels hold node spellings in registers)");
         if (view->n_edges * 2 >= 0xFFFFFFF0ull) return fail(MGX_ERR_UNSUPPORTED, "PRIMARY mode: ids of both strands must fit 32 bits");
     }
     if (mgx_device_count() <= device) return fail(MGX_ERR_NO_DEVICE, "HIP device %d not available", device);

@@ -49,7 +49,7 @@ class HipGraphHandle {
         v.W = W.data(); v.last = last.data(); v.F = F.data(); v.valid = valid.empty() ? nullptr : valid.data();
         // PRIMARY: `dbg` is the DBGSuccinct under the CanonicalDBG wrapper of cli/align.cpp:383-387; libmgx applies the wrapper
         // on the device and reports CanonicalDBG's node ids (id + dbg.max_index() = the reverse complement), so the
-        // Alignments rebuilt below are valid on the wrapper the caller holds (k <= 32)
+        // Alignments rebuilt below are valid on the wrapper the caller holds (k <= 64)
         v.mode = dbg.get_mode() == DeBruijnGraph::BASIC ? MGX_MODE_BASIC
                : dbg.get_mode() == DeBruijnGraph::CANONICAL ? MGX_MODE_CANONICAL : MGX_MODE_PRIMARY;
         if (int rc = mgx_graph_create(&v, device, &g_))

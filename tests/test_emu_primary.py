@@ -29,6 +29,8 @@ def _graphs():
     tr = read_fasta(os.path.join(HERE, "golden", "transcripts_100.fa"))[:12]
     yield "tr6-even-k", 6, primary_contigs(tr, 6)[0], True                       # even k: palindromic k-mers
     yield "tr8-even-k-unmasked", 8, primary_contigs(tr, 8, "colex")[0], False
+    yield "tr40-k-above-32", 40, primary_contigs(tr[:4], 40)[0], False
+    yield "tr64-max-k", 64, primary_contigs(tr[:4], 64, "lex")[0], True
     from test_oracle_canonical_wrapper import DUMMY_GRAPHS                          # test_canonical_dbg.cpp:1239-1640
     for name, seqs in DUMMY_GRAPHS.items():
         yield "dummy-" + name, 31, seqs, False
@@ -119,7 +121,8 @@ def test_primary_cli_goldens_through_the_kernels(min_seed_length, order):
 
 
 @pytest.mark.parametrize("k,mask,seed,order", [(11, False, 1, "input"), (19, False, 2, "lex"), (31, False, 3, "colex"),
-                                               (15, True, 4, "input"), (12, False, 5, "lex"), (8, True, 6, "input")])
+                                               (15, True, 4, "input"), (12, False, 5, "lex"), (8, True, 6, "input"),
+                                               (40, False, 7, "lex"), (63, True, 8, "input"), (64, False, 9, "colex")])
 def test_primary_random_worlds(k, mask, seed, order):
     g, reads = primary_world(700 + seed, k, mask=mask, order=order)
     compare_full(g, emu_drv.EmuGraph(g, mode=PRIMARY), capi.config_cli(k), reads)

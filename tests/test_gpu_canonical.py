@@ -69,10 +69,11 @@ def test_canonical_random_worlds_on_gpu(k, mask, seed):
     assert all(a["orientation"] == 0 for q in got for a in q)
 
 
-def test_primary_graphs_beyond_k_32_are_refused():
-    """PRIMARY graphs run through the CanonicalDBG wrapper (tests/test_gpu_zz_primary.py); node spellings are held in two
-    registers there, so k > 32 is refused loudly."""
-    g = orc.Graph.build(33, ["AAAAGCTTTCGAGGCCAATTGACCATGGTTACGATCGGATCCAGT"], 2, True)
+def test_primary_graphs_beyond_k_64_are_refused():
+    """PRIMARY graphs run through the CanonicalDBG wrapper (tests/test_gpu_zz_primary.py); the kernels that build its tables hold
+    node spellings in registers, so k > 64 is refused loudly."""
+    seq = "AAAAGCTTTCGAGGCCAATTGACCATGGTTACGATCGGATCCAGTTACCGGATTTACGCAGGTCAATGCCGTATTGCAC"
+    g = orc.Graph.build(65, [seq], 2, True)
     with pytest.raises(aligner.MgxError) as e:
         gpu_graph(g, mode=2)
     assert e.value.code == capi.MGX_ERR_UNSUPPORTED

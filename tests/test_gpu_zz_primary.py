@@ -83,7 +83,7 @@ def test_primary_cli_goldens_on_gpu(min_seed_length):
 
 
 @pytest.mark.parametrize("k,mask,seed,order", [(11, False, 1, "input"), (31, False, 3, "colex"), (15, True, 4, "input"),
-                                               (12, False, 5, "lex")])
+                                               (12, False, 5, "lex"), (40, False, 7, "lex")])
 def test_primary_random_worlds_on_gpu(k, mask, seed, order):
     g, reads = primary_world(700 + seed, k, mask=mask, order=order, n_reads=200)
     cfg = capi.config_cli(k)

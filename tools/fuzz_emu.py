@@ -38,7 +38,7 @@ def main():
         rng = random.Random(seed)
         it += 1
         mode = rng.choice([int(m) for m in args.modes.split(",")])
-        k = rng.choice([5, 6, 7, 8, 11, 12, 15, 19, 20, 27, 31, 32])
+        k = rng.choice([5, 6, 7, 8, 11, 12, 15, 19, 20, 27, 31, 32, 33, 40, 64])
         mask = rng.random() < 0.4
         glen = rng.choice([300, 1000, 3000, 6000])
         genome = rand_seq(rng, glen)
