@@ -1,7 +1,7 @@
 #!/bin/bash
-# Hardware check of the PRIMARY (CanonicalDBG) kernels without python (their first run, round 2): the C++ driver over libmgx.so on BOSS dumps of two
-# primary graphs, compared with the oracle's TSV lines prepared on the CPU side (gpurun_in/, see the python snippet in
-# DESIGN.md section 5).  Seconds of GPU time.  Writes gpurun_out/primary_check.txt.
+# Hardware check of the PRIMARY (CanonicalDBG) kernels without python (their first run, round 2): the C++ driver over libmgx.so on BOSS dumps of
+# primary graphs (genome.MT and four random worlds), compared with the oracle's TSV lines prepared on the CPU side (gpurun_in/, written by
+# tools/make_primary_check_inputs.py).  Seconds of GPU time.  Writes gpurun_out/primary_check.txt and primary_check2.txt.
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
 out=gpurun_out/primary_check.txt
