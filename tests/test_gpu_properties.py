@@ -2,7 +2,8 @@
 the results of a read depend on nothing but the read — not on its position in the batch (work sort, arena slot, wavefront
 mates, multi-pass schedule all change under a permutation), not on what the aligner handle ran before (idempotence).  Per-query
 digests over every field of every alignment (tests/result_digest.py, validated on the oracle in tests/test_result_digest.py).
-Default: the 98 Mbp bench graph (104 M edges, k = 31) with 2 M reads; MGX_PROP_READS=10000000 runs BASELINE's full batch."""
+Default: the 98 Mbp bench graph (104 M edges, k = 31) with 1 M reads (the digests take ~5 GB of host memory per million reads);
+MGX_PROP_READS=10000000 runs BASELINE's full batch."""
 import os
 
 import numpy as np
@@ -20,7 +21,7 @@ def test_results_do_not_depend_on_batch_order_or_history():
     torch.cuda.set_device(0)
     k, read_len = 31, 150
     genome_len = int(os.environ.get("MGX_PROP_GENOME", 98_000_000))
-    n_reads = int(os.environ.get("MGX_PROP_READS", 2_000_000))
+    n_reads = int(os.environ.get("MGX_PROP_READS", 1_000_000))
     genome = synth.random_genome(genome_len, 20240501, dev)
     boss = synth.build_boss([genome[None, :], synth.snp_windows(genome, genome_len // 490, k, 20240502)], k)
     torch.cuda.synchronize()
