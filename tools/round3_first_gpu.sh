@@ -7,7 +7,7 @@ set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof
 [ -d gpurun_in ] && bash tools/check_primary_on_gpu.sh
-MGX_NO_TORCH=1 timeout 300 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not torch and not torchrun and not transcripts_1000" > gpurun_out/r03_gpu_tests_no_torch.log 2>&1
+MGX_NO_TORCH=1 timeout 300 python -m pytest tests -m gpu -q -p no:cacheprovider -k "not torch and not torchrun and not batch_order and not transcripts_1000" > gpurun_out/r03_gpu_tests_no_torch.log 2>&1
 tail -3 gpurun_out/r03_gpu_tests_no_torch.log
 timeout 600 python bench.py --graph-mode primary --reads 2000000 --cpu-sample 20000 --cpu-1t-sample 500 > gpurun_out/r03_bench_primary.json 2> gpurun_out/r03_bench_primary.log
 tail -1 gpurun_out/r03_bench_primary.json | cut -c1-900
