@@ -39,6 +39,39 @@ struct EmuRun {
     uint64_t retried = 0;         // reads handed to pass 2 of the two-pass extension
     uint64_t out_used = 0;        // words of `stream` in use
 };
+#ifdef MGX_EMU_TRACE
+// traced build (make trace): every access of the wave program calls the hooks of trace_hooks.cpp
+extern "C" {
+void mgx_trace_region(const void *p, uint64_t bytes, const char *name);
+void mgx_trace_reset();
+void mgx_trace_on(int on);
+void mgx_trace_end_read();
+uint64_t mgx_trace_report(char *buf, uint64_t cap);
+}
+// the arena arrays of carve() (everything placed in the arena: lds = nullptr), by name
+static void trace_register_arena(const AlignParams &P, uint8_t *base, uint64_t stride) {
+    auto w = std::make_unique<Wave>();
+    carve(*w, P, base, nullptr, 0);
+    struct Pt { const void *p; const char *name; };
+    std::vector<Pt> pts = {
+        { w->q[0], "q" }, { w->msl, "seeding_scratch" }, { w->st[0].S.hi, "staging" }, { w->pk[0], "pk" }, { w->psum[0], "psum" },
+        { w->seeds[0], "seeds" }, { w->alive[0], "alive" }, { w->alt, "alt" }, { w->cells, "cells" }, { w->cols, "cols" },
+        { w->queue, "queue" }, { w->next_nodes, "next_nodes" }, { w->tips, "tips" }, { w->prev_starts, "prev_starts" },
+        { w->indices, "bt_indices" }, { w->rev_ops, "rev" }, { w->gen_store, "gen_store" },
+        { w->ext[0].conv.slots, "conv_slots" }, { w->ext[0].conv.pool, "conv_pool" },
+        { w->ext[1].conv.slots, "conv_slots" }, { w->ext[1].conv.pool, "conv_pool" },
+        { w->aln[0].nodes, "aln" },
+    };
+    std::sort(pts.begin(), pts.end(), [](const Pt &a, const Pt &b) { return a.p < b.p; });
+    for (size_t i = 0; i < pts.size(); ++i) {
+        const uint8_t *lo = (const uint8_t *)pts[i].p, *hi = i + 1 < pts.size() ? (const uint8_t *)pts[i + 1].p : base + stride;
+        mgx_trace_region(lo, (uint64_t)(hi - lo), pts[i].name);
+    }
+}
+#define TRACE_END_READ() mgx_trace_end_read()
+#else
+#define TRACE_END_READ() ((void)0)
+#endif
 } // namespace
 
 extern "C" {
@@ -339,6 +372,31 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
                 std::swap(pin, pout); std::swap(lin, lout); std::swap(kin, kout);
             }
         } else {
+#ifdef MGX_EMU_TRACE
+        if (getenv("MGX_EMU_TRACE_EXTEND")) {
+            // traffic model of the product's default extension launch: one pass, no seed limit, only this phase traced
+            mgx_trace_reset();
+            trace_register_arena(P, arena.data(), stride);
+            mgx_trace_region(G->blocks.data(), G->blocks.size() * sizeof(Block), "graph_blocks");
+            mgx_trace_region(G->last_hint.data(), G->last_hint.size() * 4, "graph_hints");
+            for (int c = 0; c < 4; ++c) mgx_trace_region(G->w_hint[c].data(), G->w_hint[c].size() * 4, "graph_hints");
+            mgx_trace_region(G->firstc.data(), G->firstc.size() * 4, "graph_firstc");
+            mgx_trace_region(G->terminus.data(), G->terminus.size() * 8, "graph_terminus");
+            mgx_trace_region(nf.data(), nf.size() * 4, "in_nodes"); mgx_trace_region(nr.data(), nr.size() * 4, "in_nodes");
+            mgx_trace_region(hdr.data(), hdr.size() * sizeof(SeedHdr), "in_seed_hdr");
+            mgx_trace_region(sstream.data(), sstream.size() * sizeof(DevSeed), "in_seed_stream");
+            mgx_trace_region(seqs, offsets[n], "in_reads");
+            mgx_trace_region(R->results.data(), R->results.size() * sizeof(ReadResult), "out_results");
+            mgx_trace_region(R->stream.data(), R->stream.size() * 4, "out_stream");
+            P.dbg_seeds = nullptr;
+            mgx_trace_on(1);
+            for (uint64_t i = 0; i < n; ++i) {
+                align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
+                TRACE_END_READ();
+            }
+            mgx_trace_on(0);
+        } else {
+#endif
         // two-pass extension: at most one seed per read first, then the reads that go on, from scratch
         P.seed_limit = 1; P.retry_list = retry.data(); P.retry_count = &retry_count;
         for (uint64_t i = 0; i < n; ++i)
@@ -347,6 +405,9 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         for (uint64_t i = 0; i < retry_count; ++i)
             align_read<PH_EXTEND>(*w, P, retry[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
         R->retried = retry_count;
+#ifdef MGX_EMU_TRACE
+        }
+#endif
         }
     } else {
         for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
@@ -394,5 +455,8 @@ void emu_stats(void *r, uint64_t *out8) {
     out8[4] = s.extensions; out8[5] = s.seeds; out8[6] = s.capacity_errors; out8[7] = s.fast_columns;
 }
 void emu_free(void *r) { delete static_cast<EmuRun *>(r); }
+#ifdef MGX_EMU_TRACE
+uint64_t emu_trace_report(char *buf, uint64_t cap) { return mgx_trace_report(buf, cap); }
+#endif
 
 } // extern "C"

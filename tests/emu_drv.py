@@ -18,6 +18,9 @@ def L():
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")], check=True)
         # MGX_EMU_WAVE=16 / 8 selects the model of the sub-wave-group kernels (default: one 64-lane wavefront)
         suffix = {"16": "_w16", "8": "_w8"}.get(os.environ.get("MGX_EMU_WAVE", ""), "")
+        if os.environ.get("MGX_EMU_TRACE_LIB"):                 # tools/traffic_model.py: the traced build (make trace)
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "trace"], check=True, stderr=subprocess.DEVNULL)
+            suffix = "_trace_w8"
         _L = C.CDLL(os.path.join(ROOT, "tests", "emu", "_build", "libmgxemu%s.so" % suffix))
         _L.emu_graph_create.restype = C.c_void_p
         _L.emu_graph_create.argtypes = [C.POINTER(capi.BossView)]
