@@ -139,14 +139,16 @@ struct ColMeta {                 // DPTColumn minus the vectors (aligner_extende
     uint32_t cells;              // word offset of the column's S / F record in the cell arena (see rec_words); NO_CELLS: none
     uint32_t cw;                 // path character (bits 0-7) | cells per array of the record (bits 8-30) | bit 31: chain format
     int32_t org;                 // window position of record / slot cell 0 (org <= trim)
-    int32_t base;                // chain format: S = base + s16
+    int32_t base;                // chain formats: S = base + 16-bit / 8-bit offset
     int32_t self;                // the column's own table index (not stored)
 };
 constexpr uint32_t NO_CELLS = 0xFFFFFFFFu;
-constexpr uint32_t CW_CHAIN = 0x80000000u;
+constexpr uint32_t CW_CHAIN = 0x80000000u;       // a chain-format column (S relative to `base`, flags in the slot) ...
+constexpr uint32_t CW_COMPACT = 0x40000000u;     // ... in the compact one-line form (see ColSlot)
 MGX_DEV uint8_t col_char(const ColMeta &c) { return (uint8_t)(c.cw & 0xFF); }
-MGX_DEV int32_t col_wc(const ColMeta &c) { return (int32_t)((c.cw & ~CW_CHAIN) >> 8); }
+MGX_DEV int32_t col_wc(const ColMeta &c) { return (int32_t)((c.cw & ~(CW_CHAIN | CW_COMPACT)) >> 8); }
 MGX_DEV bool col_chain(const ColMeta &c) { return (c.cw & CW_CHAIN) != 0; }
+MGX_DEV bool col_compact(const ColMeta &c) { return (c.cw & CW_COMPACT) != 0; }
 
 // What a column leaves in HBM.  Every column owns one slot of the table (`Wave::cols`): 32 bytes of metadata, one FLAG
 // byte per cell of the chain window and the window's S values as 16-bit offsets from `base` — one or two 64-byte lines
@@ -160,11 +162,24 @@ MGX_DEV bool col_chain(const ColMeta &c) { return (c.cw & CW_CHAIN) != 0; }
 // Columns of the general path (any width) keep S and F as int32 arrays plus their flag bytes in a record of the cell
 // arena (`cells`); a chain-format column gets such a record (S, F of its window) only when it stays behind in the
 // frontier, i.e. when something may have to reload it as a parent.
+// Three forms share the slot (round 3; the 128-byte slot of round 2 wrote two lines per column):
+//   general   m[8] as packed by col_pack; S / F / flags in the column's record of the cell arena.
+//   chain     m[8] + one flag byte per window cell here, the window's S as 16-bit offsets from `base` in the column's row
+//             of a SECOND array (`Wave::cols_s16`) that only reloads-as-data touch (convergence merges, the rare S reads
+//             of backtrack).
+//   compact   ONE 64-byte line for everything: 16 bytes of metadata and, for the first CCELLS = 24 window cells, the flag
+//             byte and S as an 8-bit offset from `base` (-128 = ninf).  Taken by a chain column whose window cells from
+//             CCELLS on hold neither S nor F (nothing can ever trace into them), whose S fit 8 bits (x-drop < ~100),
+//             and whose metadata fits the narrow fields; ~95 % of the columns of a short-read batch.
+//             words 0-3: node | parent:24 char code:3 score code:2 -:1 tag 01 | base:22 size:5 max_pos-trim:5 | offset:16 trim:15
+//             words 4 + 2 l, 5 + 2 l (l < 6): flag bytes / 8-bit S of window cells 4 l .. 4 l + 3
+//             (tag: bits 31-30 of word 1 are 00 or 11 in the other forms, whose word 1 is the parent index or -1)
 struct alignas(16) ColSlot {
     uint32_t m[8];
     uint8_t flags[FWS];
-    int16_t s16[FWS];
 };
+constexpr int32_t CCELLS = 24;
+constexpr int8_t S8_NINF = INT8_MIN;
 enum { CF_REAL = 1, CF_S_IS_E = 2, CF_E_EXT = 4, CF_MATCH = 8, CF_S_IS_F = 16, CF_F_EXT = 32, CF_SP_REAL = 64 };
 constexpr int16_t S16_NINF = INT16_MIN;
 
@@ -338,7 +353,8 @@ struct Wave {
     };
     // extension scratch
     int32_t *cells;
-    ColSlot *cols;                        // the column table: one slot per column (metadata, flags, 16-bit S of chain columns)
+    ColSlot *cols;                        // the column table: one slot per column (see ColSlot)
+    int16_t *cols_s16;                    // row i: 16-bit S of chain-format column i (FWS cells)
     uint64_t *queue, *next_nodes;         // frontier / current batch (arena; the chain path rarely touches them)
     Staging st[2];
     Tier stE;                             // E of the column being computed
@@ -421,6 +437,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += align8((uint64_t)lim.max_alt * 4);             // alt
     b += 16 + align8((uint64_t)lim.cell_words * 4);     // cells
     b += 64 + align8((uint64_t)lim.max_columns * sizeof(ColSlot));
+    b += 64 + align8((uint64_t)lim.max_columns * FWS * 2);   // cols_s16
     b += 2 * align8((uint64_t)lim.max_columns * 8);     // queue, next_nodes
     b += align8((uint64_t)lim.max_columns * 4);         // tips
     b += align8(((uint64_t)lim.max_columns + 31) / 32 * 4);   // prev_starts
@@ -510,6 +527,8 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.cells = (int32_t *)take((uint64_t)lim.cell_words * 4);
     p = (uint8_t *)(((uint64_t)p + 63) & ~63ull);                // a chain-format slot is exactly two 64-byte lines
     w.cols = (ColSlot *)take((uint64_t)lim.max_columns * sizeof(ColSlot));
+    p = (uint8_t *)(((uint64_t)p + 63) & ~63ull);
+    w.cols_s16 = (int16_t *)take((uint64_t)lim.max_columns * FWS * 2);
     w.queue = (uint64_t *)take((uint64_t)lim.max_columns * 8);
     w.next_nodes = (uint64_t *)take((uint64_t)lim.max_columns * 8);
     w.tips = (uint32_t *)take((uint64_t)lim.max_columns * 4);
@@ -1668,8 +1687,21 @@ MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t qu
 // extension (DefaultColumnExtender::extend, A/aligner_extender_methods.cpp:412-772)
 // ------------------------------------------------------------------------------------------------
 // metadata of column i <-> its slot (positions and sizes fit 16 bits: Lmax <= MGX_MAX_QUERY_LENGTH; gap scores are int8)
-MGX_DEV ColMeta col_unpack(const uint32_t *m, int32_t i) {
+MGX_DEV ColMeta col_unpack(const uint32_t *m, int32_t i, int32_t go, int32_t ge) {
     ColMeta c;
+    if ((m[1] >> 30) == 1u) {                                    // compact form
+        c.node = m[0]; c.parent = (int32_t)(m[1] & 0xFFFFFF);
+        const uint32_t code = (m[1] >> 24) & 7, sc = (m[1] >> 27) & 3;
+        c.base = (int32_t)(m[2] << 10) >> 10;
+        c.size = (int32_t)((m[2] >> 22) & 31);
+        c.offset = (int32_t)(m[3] & 0xFFFF); c.trim = (int32_t)((m[3] >> 16) & 0x7FFF);
+        c.max_pos = c.trim + (int32_t)(m[2] >> 27);
+        c.score = sc == 0 ? 0 : sc == 1 ? go : ge;
+        c.cells = NO_CELLS; c.org = c.trim & ~3;
+        c.cw = (uint32_t)decode_code(code) | ((uint32_t)CCELLS << 8) | CW_CHAIN | CW_COMPACT;
+        c.self = i;
+        return c;
+    }
     c.node = m[0]; c.parent = (int32_t)m[1]; c.offset = (int32_t)m[2]; c.base = (int32_t)m[3]; c.cells = m[4];
     c.max_pos = (int32_t)(m[5] & 0xFFFF); c.trim = (int32_t)(m[5] >> 16);
     c.size = (int32_t)(m[6] & 0xFFFF); c.org = (int32_t)(m[6] >> 16);
@@ -1686,7 +1718,8 @@ MGX_DEV ColMeta col_load(const Wave &w, int32_t i) {
 #else
     mgx_mem::load_bytes<32>(sl->m, m);
 #endif
-    return col_unpack(m, i);
+    const DevConfig &cfg = MGX_PARAMS_OF(w).cfg;
+    return col_unpack(m, i, cfg.gap_open, cfg.gap_ext);
 }
 MGX_DEV void col_pack(const ColMeta &c, uint32_t *m) {
     m[0] = c.node; m[1] = (uint32_t)c.parent; m[2] = (uint32_t)c.offset; m[3] = (uint32_t)c.base; m[4] = c.cells;
@@ -1720,8 +1753,12 @@ MGX_DEV bool cell_idx(const ColMeta &c, int32_t pos, int32_t &x) {
 MGX_DEV int32_t cell_S(const Wave &w, const ColMeta &c, int32_t pos) {
     int32_t x;
     if (!cell_idx(c, pos, x)) return NINF;
+    if (col_compact(c)) {
+        const int32_t v = (int32_t)gld((const int8_t *)(w.cols + c.self) + 20 + 8 * (x >> 2) + (x & 3));
+        return v == (int32_t)S8_NINF ? NINF : c.base + v;
+    }
     if (col_chain(c)) {
-        const int32_t v = (int32_t)gld(w.cols[c.self].s16 + x);
+        const int32_t v = (int32_t)gld(w.cols_s16 + (int64_t)c.self * FWS + x);
         return v == (int32_t)S16_NINF ? NINF : c.base + v;
     }
     return gld(w.cells + c.cells + x);
@@ -1729,6 +1766,7 @@ MGX_DEV int32_t cell_S(const Wave &w, const ColMeta &c, int32_t pos) {
 MGX_DEV uint32_t cell_flags(const Wave &w, const ColMeta &c, int32_t pos) {
     int32_t x;
     if (!cell_idx(c, pos, x)) return 0;
+    if (col_compact(c)) return gld((const uint8_t *)(w.cols + c.self) + 16 + 8 * (x >> 2) + (x & 3));
     if (col_chain(c)) return gld(w.cols[c.self].flags + x);
     return gld((const uint8_t *)(w.cells + c.cells + 2 * col_wc(c)) + x);
 }
@@ -2737,9 +2775,12 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         ColSlot *slot = w.cols + my_idx;
         const LV<int32_t> e_up = wave_shift_up1(cE[3], NINF);
         const int32_t ptrim = x.f_trim;
+        LV<uint32_t> fwv;
+        LV<int32_t> hs[4];
+        LV<bool> blocks;                           // what keeps this lane's cells out of the compact form
         FOR_LANES(l) {
             uint32_t fw = 0;
-            int32_t h[4];
+            bool blk = false;
             for (int s = 0; s < 4; ++s) {
                 const int32_t a = org + 4 * l + s, j = a - begin;
                 const int32_t ep = j <= 0 ? NINF : (s == 0 ? e_up[l] : cE[s - 1][l]);
@@ -2755,15 +2796,54 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
                 if (fv == pF[s][l] + score + ge) fl |= CF_F_EXT;
                 if (pin && sp1 != NINF) fl |= CF_SP_REAL;
                 fw |= fl << (8 * s);
-                h[s] = sv == NINF ? (int32_t)S16_NINF : sv - cur.base;
+                hs[s][l] = sv == NINF ? (int32_t)S16_NINF : sv - cur.base;
+                // compact form: cells from CCELLS on must hold neither S nor F (then no trace can reach them and their flag
+                // bytes are never consulted), and S must fit 8 bits
+                if (4 * l + s >= CCELLS) blk |= sv != NINF || fv != NINF;
+                else blk |= sv != NINF && (sv - cur.base < -127 || sv - cur.base > 127);
             }
-            gst((uint32_t *)slot->flags + l, fw);
-            uint2 hv;
-            hv.x = ((uint32_t)h[0] & 0xFFFF) | ((uint32_t)h[1] << 16);
-            hv.y = ((uint32_t)h[2] & 0xFFFF) | ((uint32_t)h[3] << 16);
-            gst((uint2 *)slot->s16 + l, hv);
+            fwv[l] = fw;
+            blocks[l] = blk;
         }
-        col_store(w, my_idx, cur);
+        const uint32_t ccode = encode_char(c);
+        const bool compact = !deferred && !MGX_PARAMS_OF(w).no_compact && wave_ballot(blocks) == 0 && next_offset <= 0xFFFF && begin <= 0x7FFF
+                             && cur.base > -(1 << 21) && cur.base < (1 << 21) && ccode <= 4 && decode_code(ccode) == c
+                             && (score == 0 || score == go || score == ge) && size <= 31 && x.f_idx < (1 << 24);
+        if (compact) {
+            const uint32_t sc = score == 0 ? 0u : (score == go ? 1u : 2u);
+            const uint32_t m0 = next, m1 = (uint32_t)x.f_idx | (ccode << 24) | (sc << 27) | (1u << 30);
+            const uint32_t m2 = ((uint32_t)cur.base & 0x3FFFFF) | ((uint32_t)size << 22) | ((uint32_t)(max_pos - begin) << 27);
+            const uint32_t m3 = (uint32_t)next_offset | ((uint32_t)begin << 16);
+            FOR_LANES(l) {
+                if (l < 8) {
+                    uint2 v;
+                    if (l < 6) {
+                        v.x = fwv[l];
+                        v.y = ((uint32_t)hs[0][l] & 0xFF) | (((uint32_t)hs[1][l] & 0xFF) << 8) | (((uint32_t)hs[2][l] & 0xFF) << 16) | ((uint32_t)hs[3][l] << 24);
+                        // (a 16-bit ninf code truncates to 0x00: restore the 8-bit one)
+                        if (hs[0][l] == (int32_t)S16_NINF) v.y = (v.y & ~0xFFu) | 0x80u;
+                        if (hs[1][l] == (int32_t)S16_NINF) v.y = (v.y & ~0xFF00u) | 0x8000u;
+                        if (hs[2][l] == (int32_t)S16_NINF) v.y = (v.y & ~0xFF0000u) | 0x800000u;
+                        if (hs[3][l] == (int32_t)S16_NINF) v.y = (v.y & 0x00FFFFFFu) | 0x80000000u;
+                    } else {
+                        v.x = l == 6 ? m0 : m2;
+                        v.y = l == 6 ? m1 : m3;
+                    }
+                    gst((uint2 *)slot + (l < 6 ? 2 + l : l - 6), v);
+                }
+            }
+            cur.cw = (uint32_t)c | ((uint32_t)CCELLS << 8) | CW_CHAIN | CW_COMPACT;
+        } else {
+            int16_t *srow = w.cols_s16 + (int64_t)my_idx * FWS;
+            FOR_LANES(l) {
+                gst((uint32_t *)slot->flags + l, fwv[l]);
+                uint2 hv;
+                hv.x = ((uint32_t)hs[0][l] & 0xFFFF) | ((uint32_t)hs[1][l] << 16);
+                hv.y = ((uint32_t)hs[2][l] & 0xFFFF) | ((uint32_t)hs[3][l] << 16);
+                gst((uint2 *)srow + l, hv);
+            }
+            col_store(w, my_idx, cur);
+        }
         // ... and, for a column that stays behind in the frontier, its window as an S / F record
         if (deferred) {
             int32_t *rec = w.cells + x.cell_top;
@@ -3739,6 +3819,8 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         }
         // ... which extends them in order and drops a later one whose end the earlier extensions already reached with at
         // least its score (align_core :360-384: check_seed between the seeds of the list)
+        const uint32_t *filt_nodes = nullptr;                 // lazily applied filter_nodes (see below)
+        int32_t filt_n = 0, filt_lo = 0, filt_hi = 0;
         for (int r = 0; r < n_rev; ++r) {
             if (!rev_alive[r]) continue;
             DevAln &rev = w.aln[n_alt + r];
@@ -3762,8 +3844,17 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
                 if (canon ? reverse_complement_aln_stored(w, p2) : reverse_complement_aln(w, p2)) {
                     int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
                     const uint64_t tf0 = cycle_clock();
-                    for (int32_t x = 0; x < p2.n_nodes; ++x)
-                        filter_nodes(w, F, p2.nodes[x], clip, w.L - eclip);
+                    if (n_alt == 1) {
+                        // filter_nodes (:716-719) marks [clip, L - eclip) of every path node with the maximal score in the FORWARD
+                        // extender's table.  Nothing reads that table before the next set_seed clears it except check_seed on
+                        // the later seeds below, so with one alignment per seed (one p2, which stays in its buffer until the next
+                        // seed's backtrack) the marks are not written at all: the check below tests the path's nodes directly.
+                        // (Written out, the marks were 150 vectors of 150 words per backward pass.)
+                        filt_nodes = p2.nodes; filt_n = p2.n_nodes; filt_lo = clip; filt_hi = w.L - eclip;
+                    } else {
+                        for (int32_t x = 0; x < p2.n_nodes; ++x)
+                            filter_nodes(w, F, p2.nodes[x], clip, w.L - eclip);
+                    }
                     w.cyc[6] += cycle_clock() - tf0;                      // (timer 6: seed pick-up + filter_nodes)
                     if (w.status != ST_OK) return;
                     add_alignment(w, p2);
@@ -3784,7 +3875,14 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
                     DevSeed sj = w.seeds[s][j];
                     uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
                     SeedRef rj = seedref_from_seed(w, s, j, nullptr);
-                    if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[s][j] = 0;
+                    bool dead = !check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score);
+                    // the deferred filter_nodes marks: position qlen + clipping - 1 of a node on the reversed backward
+                    // alignment holds the maximal score (check_seed: vec[pos] < score is false)
+                    const int32_t pos = rj.qlen + rj.clipping - 1;
+                    if (!dead && filt_n && pos >= filt_lo && pos < filt_hi) {
+                        for (int32_t x = 0; x < filt_n; ++x) dead |= gld(filt_nodes + x) == last_node;
+                    }
+                    if (dead) w.alive[s][j] = 0;
                 }
             }
         }

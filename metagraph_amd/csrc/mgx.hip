@@ -841,6 +841,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
     static const bool no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;      // A/B switch: general path only
     P.no_fast = no_fast || A->no_fast;
+    static const bool no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;
+    P.no_compact = no_compact;
     P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results
     size_t sort_tmp_bytes = 0;
     if (split) {

@@ -318,6 +318,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     P.results = R->results.data(); P.out_stream = R->stream.data(); P.out_capacity = out_words;
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();
     P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
+    P.no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;
     auto w = std::make_unique<Wave>();
     SdustScratch sd;
     // model a small LDS so that both placements (LDS / arena) of the fast arrays are exercised
