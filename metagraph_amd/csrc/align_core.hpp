@@ -208,20 +208,23 @@ struct BtIndex { int32_t score, neg_off_diag, neg_i, pos; };
 constexpr int MAX_ALT = MGX_MAX_ALT;
 constexpr int N_ALN = 4 * MAX_ALT;           // alignment buffers: extension results, their reversals, backward results, the best
 
-// One hash slot holds everything a lookup needs (key, generation tag, where the entry's vector lives and the query range
-// it covers): a probe is ONE 32-byte access instead of slot -> entry -> range.
-// The vectors come from a POOL (like the reference's per-node std::vector<score_t>, which holds only [start, start+len)):
-// an entry owns `cap` words at `off`; position p of its range is pool[off + p - start].  A column appends its window to
-// the pool, so consecutive columns write consecutive memory; a range that outgrows its allocation moves to the pool's top.
-struct alignas(32) ConvSlot { uint64_t key; uint32_t gen, off; int32_t start, len; uint32_t cap, pad1; };
-
+// the convergence table of one extender (layout and entry kinds: see the "convergence checker" section)
+struct ConvRec { uint32_t off; int32_t start, len; uint32_t cap; };      // a pool entry: words [off, off + cap) hold [start, start + len)
 struct ConvChecker {             // SeedFilteringExtender::conv_checker_ (extender hpp:75-76)
-    ConvSlot *slots;
+    uint64_t *tab;               // hash slots, all levels (conv_tab_slots())
+    ConvRec *recs;               // pool entries
     int32_t *pool;               // DevLimits::conv_pool_words words
-    uint32_t n_entries;
-    uint32_t gen;
+    uint32_t n_entries, n_recs;
+    uint32_t gen;                // 1 .. 255
     uint32_t pool_top;           // words handed out since conv_clear
+    uint32_t cap, base;          // current level: slots and its first slot in `tab`
+    uint32_t start;              // window origin (query position) of the extension the entries belong to
+    uint32_t dirty;              // highest level written since the generations last wrapped
 };
+
+constexpr uint32_t CONV_CAP0 = 512;
+MGX_HD uint32_t conv_cap0(uint32_t hash_size) { return hash_size < CONV_CAP0 ? hash_size : CONV_CAP0; }
+MGX_HD uint64_t conv_tab_slots(uint32_t hash_size) { return 2ull * hash_size; }          // all levels together (< 2 x the top one)
 
 struct SdustScratch {            // working set of is_low_complexity(); lives in LDS on the device
     int16_t cv[64], cw[64], c2[64];
@@ -297,11 +300,10 @@ struct XState {
     // parameter block behind a generic pointer: both would be FLAT loads there)
     const uint32_t *seed_nodes;
     const uint8_t *seed_seq;
-    uint64_t rc_key_add;                  // RCDBG views key the convergence table by node + max_index (:74-75,107-108)
     double rel_cutoff, max_nodes_per_char, max_ram;
     int32_t go, ge, xdrop, k, Lq, max_columns, seq_lds, rc;
     int32_t n_valid, n_for, n_count, pad3_;   // children of column n_for enumerated ahead of time into Wave::out_* (chain path)
-    uint32_t hash_mask, cell_words;
+    uint32_t alias_ok, cell_words;        // alias_ok: a node's first chain column enters the convergence table as an alias
     int32_t seed_n_nodes, sn_base, sc_base, pad4_;   // seed replay: first entry of the register-cached node / character run
 };
 #else
@@ -443,9 +445,9 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += align8(((uint64_t)lim.max_columns + 31) / 32 * 4);   // prev_starts
     b += align8((uint64_t)lim.max_columns * 2 * sizeof(BtIndex));
     b += 2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path);   // rev_*
-    b += 16;                                            // gen_store
+    b += 16;                                            // gen_store (generation + dirty level per extender)
     b += 6 * align8((L + 16) * 4);                      // staging
-    b += 32 + 2 * (align8((uint64_t)lim.hash_size * sizeof(ConvSlot)) + align8((uint64_t)lim.conv_pool_words * 4));
+    b += 64 + 2 * (align8(2ull * lim.hash_size * 8) + align8(((uint64_t)lim.max_columns + lim.max_path) * 16) + 64 + align8((uint64_t)lim.conv_pool_words * 4));
     b += (uint64_t)lim.n_aln * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
     return (b + 63) & ~63ull;          // slices keep the 32-byte alignment of the hash slots and the 16-byte one of the cell records
 }
@@ -539,8 +541,9 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.rev_seq = take(lim.max_path);
     w.gen_store = (uint32_t *)take(16);
     for (int s = 0; s < 2; ++s) {
-        p = (uint8_t *)(((uint64_t)p + 31) & ~31ull);
-        w.ext[s].conv.slots = (ConvSlot *)take((uint64_t)lim.hash_size * sizeof(ConvSlot));
+        p = (uint8_t *)(((uint64_t)p + 63) & ~63ull);              // level 0 of the hash table starts a line
+        w.ext[s].conv.tab = (uint64_t *)take(2ull * lim.hash_size * 8);          // conv_tab_slots()
+        w.ext[s].conv.recs = (ConvRec *)take(((uint64_t)lim.max_columns + lim.max_path) * 16);
         w.ext[s].conv.pool = (int32_t *)take((uint64_t)lim.conv_pool_words * 4);
     }
     for (int a = 0; a < N_ALN && a < (int)lim.n_aln; ++a) {
@@ -1442,248 +1445,6 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
 
 #ifndef MGX_NO_EXTEND    // translation units that only seed (mgx.hip: k_map, k_seed) skip the extension half
 // ------------------------------------------------------------------------------------------------
-// convergence checker (SeedFilteringExtender, A/aligner_extender_methods.cpp:66-207)
-// ------------------------------------------------------------------------------------------------
-MGX_DEV void conv_clear(ConvChecker &c) { ++c.gen; c.n_entries = 0; c.pool_top = 0; }
-
-MGX_DEV uint32_t conv_hash(uint64_t key, uint32_t mask) {
-    // any mixing works (results do not depend on it): node ids of one extension are near-consecutive BOSS indices
-    uint32_t h = ((uint32_t)key ^ (uint32_t)(key >> 32) * 0x9E3779B9u) * 0x85EBCA6Bu;
-    h ^= h >> 15;
-    return h & mask;
-}
-
-MGX_DEV ConvSlot conv_load_slot(const ConvSlot *p) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(p);
-    const uint4 a = gld(q), b = gld(q + 1);
-    ConvSlot sl;
-    sl.key = ((uint64_t)a.y << 32) | a.x; sl.gen = a.z; sl.off = a.w;
-    sl.start = (int32_t)b.x; sl.len = (int32_t)b.y; sl.cap = b.z; sl.pad1 = 0;
-    return sl;
-}
-MGX_DEV void conv_store_slot(ConvSlot *p, const ConvSlot &sl) {
-    uint4 *q = reinterpret_cast<uint4 *>(p);
-    uint4 a, b;
-    a.x = (uint32_t)sl.key; a.y = (uint32_t)(sl.key >> 32); a.z = sl.gen; a.w = sl.off;
-    b.x = (uint32_t)sl.start; b.y = (uint32_t)sl.len; b.z = sl.cap; b.w = 0;
-    gst(q, a); gst(q + 1, b);
-}
-// the range half of a slot only (key / generation / vector number unchanged)
-MGX_DEV void conv_store_range(ConvSlot *p, int32_t start, int32_t len) {
-    uint2 r; r.x = (uint32_t)start; r.y = (uint32_t)len;
-    gst(reinterpret_cast<uint2 *>(reinterpret_cast<uint4 *>(p) + 1), r);
-}
-
-// Linear probing from `h`: returns the slot of `key` (found = true, sl = its content) or the free slot where it would
-// be inserted.  `first` may carry the content of slot h loaded earlier (the chain path issues that load before the DP).
-MGX_DEV uint32_t conv_probe_from(const ConvChecker &c, uint32_t mask, uint64_t key, uint32_t h, ConvSlot sl, bool &found) {
-    const ConvSlot *slots = c.slots;
-    const uint32_t gen = c.gen;
-    for (;;) {
-        if (sl.gen != gen) { found = false; return h; }
-        if (sl.key == key) { found = true; return h; }
-        h = (h + 1) & mask;
-        sl = conv_load_slot(slots + h);
-    }
-}
-MGX_DEV uint32_t conv_probe(const ConvChecker &c, uint32_t mask, uint64_t key, ConvSlot &out, bool &found) {
-    uint32_t h = conv_hash(key, mask);
-    ConvSlot sl = conv_load_slot(c.slots + h);
-    const ConvSlot *slots = c.slots;
-    const uint32_t gen = c.gen;
-    for (;;) {
-        if (sl.gen != gen) { found = false; out = sl; return h; }
-        if (sl.key == key) { found = true; out = sl; return h; }
-        h = (h + 1) & mask;
-        sl = conv_load_slot(slots + h);
-    }
-}
-
-// vec[p] for query position p of entry sl
-MGX_DEV int32_t *conv_vec(const ConvChecker &c, const ConvSlot &sl) { return c.pool + (int64_t)sl.off - (int64_t)sl.start; }
-
-// claim free slot `slot` for a new key with a vector for [start, start + len); returns its pool offset or -1 (capacity)
-MGX_DEV int64_t conv_insert(Wave &w, ConvChecker &c, uint32_t slot, uint64_t key, int32_t start, int32_t len) {
-    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
-    uint32_t cap = uni(lim.max_columns + lim.max_path);
-    const uint32_t ne = uni(c.n_entries);
-    const uint32_t top = uni(c.pool_top);
-    if (ne >= cap || ne * 2 >= uni(lim.hash_size) || (uint64_t)top + (uint32_t)len > uni(lim.conv_pool_words)) { w.status = ST_CAPACITY; return -1; }
-    c.n_entries = ne + 1;
-    c.pool_top = top + (uint32_t)len;
-    ConvSlot sl; sl.key = key; sl.gen = c.gen; sl.off = top; sl.start = start; sl.len = len; sl.cap = (uint32_t)len; sl.pad1 = 0;
-    conv_store_slot(c.slots + slot, sl);
-    return (int64_t)top;
-}
-
-// Make entry `sl` (at `slot`) cover [ns, ns + nl), a superset of its range: in place if its allocation reaches (an entry at
-// the pool's top grows there), else it moves to the pool's top (old values copied; newly covered positions are left for the
-// caller to write, as with the reference's vector::insert + fill).  Updates the slot and `sl`; false = out of pool.
-MGX_DEV bool conv_cover(Wave &w, ConvChecker &c, uint32_t slot, ConvSlot &sl, int32_t ns, int32_t nl) {
-    const uint32_t words = uni(MGX_PARAMS_OF(w).lim.conv_pool_words);
-    const uint32_t top = uni(c.pool_top);
-    if (ns == sl.start && (uint32_t)nl <= sl.cap) {
-        sl.len = nl;
-    } else if (ns == sl.start && sl.off + sl.cap == top) {
-        if ((uint64_t)sl.off + (uint32_t)nl > words) { w.status = ST_CAPACITY; return false; }
-        c.pool_top = sl.off + (uint32_t)nl;
-        sl.cap = (uint32_t)nl; sl.len = nl;
-    } else {
-        if ((uint64_t)top + (uint32_t)nl > words) { w.status = ST_CAPACITY; return false; }
-        const int32_t *src = c.pool + sl.off;
-        int32_t *dst = c.pool + top + (sl.start - ns);
-        for (int32_t base = 0; base < sl.len; base += WAVE) {
-            LV<int32_t> v;
-            FOR_LANES(l) { const int32_t j = base + l; v[l] = j < sl.len ? gld(src + j) : 0; }
-            FOR_LANES(l) { const int32_t j = base + l; if (j < sl.len) gst(dst + j, v[l]); }
-        }
-        c.pool_top = top + (uint32_t)nl;
-        sl.off = top; sl.cap = (uint32_t)nl; sl.start = ns; sl.len = nl;
-    }
-    sl.start = ns;
-    conv_store_slot(c.slots + slot, sl);
-    wave_sync();
-    return true;
-}
-
-// fill vec positions [a, b) with `val`
-MGX_DEV void fill_range(int32_t *vec, int32_t a, int32_t b, int32_t val) {
-    for (int32_t base = a; base < b; base += WAVE) {
-        FOR_LANES(l) { int32_t j = base + l; if (j < b) gst(vec + j, val); }
-    }
-}
-
-// update_seed_filter (:100-156).  s = cells of the column (S at stride 3), size cells starting at
-// query position query_start.  Returns converged score (NINF = nothing improved).
-MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start,
-                                   const Tier s_tier, int32_t s_skip, int32_t size) {
-    MGX_ASSUME_LDS(&w);
-    MGX_ASSUME_LDS(&E);
-    // S values of the column: cells s_skip .. s_skip + size of the staged (two-tier) S array
-    const AlignParams &P = MGX_PARAMS_OF(w);
-    const int32_t s_cap = uni(w.st_cap);
-    s_skip = uni(s_skip);
-#define s_cells(j) tget(s_tier, s_cap, s_skip + (j))
-    auto column_max = [&]() {
-        int32_t m = INT32_MIN;
-        for (int32_t base = 0; base < size; base += WAVE) {
-            LV<int32_t> x;
-            FOR_LANES(l) { int32_t j = base + l; x[l] = j < size ? s_cells(j) : INT32_MIN; }
-            m = imax(m, wave_max(x));
-        }
-        return m;
-    };
-    if (node == 0) return column_max();
-    node = uni(node); query_start = uni(query_start); size = uni(size);
-    uint64_t key = (uint64_t)node + (uni(E.rc_view) ? uni(P.g.n) : 0);
-    uint32_t mask = uni(P.lim.hash_size) - 1;
-    ConvSlot e;
-    bool found;
-    const uint32_t slot = conv_probe(E.conv, mask, key, e, found);
-    if (!found) {
-        const int64_t off = conv_insert(w, E.conv, slot, key, query_start, size);
-        if (off < 0) return NINF;
-        int32_t *vec = E.conv.pool + off - query_start;
-        for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
-        }
-        wave_sync();
-        return column_max();
-    }
-    int32_t start = uni(e.start), len = uni(e.len);
-    if (query_start + size <= start) {
-        if (!conv_cover(w, E.conv, slot, e, query_start, start + len - query_start)) return NINF;
-        int32_t *vec = conv_vec(E.conv, e);
-        fill_range(vec, query_start + size, start, NINF);
-        for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
-        }
-        wave_sync();
-        return column_max();
-    }
-    if (query_start >= start + len) {
-        if (!conv_cover(w, E.conv, slot, e, start, query_start + size - start)) return NINF;
-        int32_t *vec = conv_vec(E.conv, e);
-        fill_range(vec, start + len, query_start, NINF);
-        for (int32_t base = 0; base < size; base += WAVE) {
-            FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
-        }
-        wave_sync();
-        return column_max();
-    }
-    {
-        const int32_t ns = imin(start, query_start), ne = imax(start + len, query_start + size);
-        if (ns != start || ne != start + len) { if (!conv_cover(w, E.conv, slot, e, ns, ne - ns)) return NINF; }
-    }
-    int32_t *vec = conv_vec(E.conv, e);
-    if (query_start < start) fill_range(vec, query_start, start, NINF);
-    if (query_start + size > start + len) fill_range(vec, start + len, query_start + size, NINF);
-    wave_sync();
-    int32_t max_changed = NINF;
-    const double rel = P.cfg.rel_score_cutoff;
-    for (int32_t base = 0; base < size; base += WAVE) {
-        LV<int32_t> x;
-        FOR_LANES(l) {
-            int32_t j = base + l;
-            x[l] = NINF;
-            if (j < size) {
-                int32_t sv = s_cells(j);
-                int32_t vv = gld(vec + query_start + j);
-                if ((double)sv > (double)vv * rel) {
-                    vv = imax(vv, sv);
-                    gst(vec + query_start + j, vv);
-                    x[l] = vv;
-                }
-            }
-        }
-        max_changed = imax(max_changed, wave_max(x));
-    }
-    wave_sync();
-    return max_changed;
-}
-#undef s_cells
-
-// check_seed (:66-88): true when the seed is still worth extending
-MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int32_t qlen, int32_t clipping, int32_t score) {
-    const AlignParams &P = MGX_PARAMS_OF(w);
-    uint64_t key = (uint64_t)last_node + (E.rc_view ? P.g.n : 0);
-    ConvSlot e;
-    bool found;
-    conv_probe(E.conv, P.lim.hash_size - 1, key, e, found);
-    if (!found) return true;
-    int32_t pos = qlen + clipping - 1;
-    if (pos < e.start || pos - e.start >= e.len) return true;
-    return gld(conv_vec(E.conv, e) + pos) < score;
-}
-
-// filter_nodes (:158-207); the key is the raw node id (no RCDBG offset), as in the reference
-MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start, int32_t query_end) {
-    MGX_ASSUME_LDS(&w);
-    MGX_ASSUME_LDS(&E);
-    const AlignParams &P = MGX_PARAMS_OF(w);
-    const int32_t mscore = -NINF;
-    int32_t size = query_end - query_start;
-    ConvSlot e;
-    bool found;
-    const uint32_t slot = conv_probe(E.conv, P.lim.hash_size - 1, (uint64_t)node, e, found);
-    if (!found) {
-        const int64_t off = conv_insert(w, E.conv, slot, (uint64_t)node, query_start, size);
-        if (off < 0) return;
-        fill_range(E.conv.pool + off - query_start, query_start, query_end, mscore);
-        wave_sync();
-        return;
-    }
-    const int32_t start = e.start, len = e.len;
-    const int32_t ns = imin(start, query_start), ne = imax(start + len, query_end);
-    if (ns != start || ne != start + len) { if (!conv_cover(w, E.conv, slot, e, ns, ne - ns)) return; }
-    int32_t *vec = conv_vec(E.conv, e);
-    if (query_end <= start) fill_range(vec, query_end, start, NINF);                   // gap below the old range
-    else if (query_start >= start + len) fill_range(vec, start + len, query_start, NINF);   // gap above it
-    fill_range(vec, query_start, query_end, mscore);      // mscore is the maximum, so max(v, mscore) == mscore
-    wave_sync();
-}
-
-// ------------------------------------------------------------------------------------------------
 // extension (DefaultColumnExtender::extend, A/aligner_extender_methods.cpp:412-772)
 // ------------------------------------------------------------------------------------------------
 // metadata of column i <-> its slot (positions and sizes fit 16 bits: Lmax <= MGX_MAX_QUERY_LENGTH; gap scores are int8)
@@ -1769,6 +1530,360 @@ MGX_DEV uint32_t cell_flags(const Wave &w, const ColMeta &c, int32_t pos) {
     if (col_compact(c)) return gld((const uint8_t *)(w.cols + c.self) + 16 + 8 * (x >> 2) + (x & 3));
     if (col_chain(c)) return gld(w.cols[c.self].flags + x);
     return gld((const uint8_t *)(w.cells + c.cells + 2 * col_wc(c)) + x);
+}
+
+// ------------------------------------------------------------------------------------------------
+// convergence checker (SeedFilteringExtender, A/aligner_extender_methods.cpp:66-207)
+// ------------------------------------------------------------------------------------------------
+// conv_checker_ maps a node to the best score reached per query position in this extension.  Round 3 layout (round 2 kept a
+// 32-byte slot per node in a table sized for the worst case plus an int32 copy of every column's window in a pool: one random
+// line read, one written and ~100 bytes appended per column, half of the kernel's traffic):
+//  * hash slots of 8 bytes: key (node id) | generation:8 kind:1 index:23.  The table grows by LEVELS of 512, 1024, ... slots
+//    (level t occupies [512 (2^t - 1), 512 (2^(t+1) - 1)) of `tab`; the top level has DevLimits::hash_size slots): a short
+//    extension only ever touches the 4 KB of level 0, which stay cache resident; a level is left for the next one when it is
+//    half full (the live slots are re-inserted).  Generation tags make clearing O(1); after 255 generations the levels used
+//    since the last wrap are zeroed.
+//  * kind 0, an ALIAS: the entry's vector IS the S window of chain-format column `index` (ColSlot: the compact or the two-line
+//    form) — the query range follows from the column's trim / size, the values from its 8- / 16-bit offsets and `base`.  Nothing
+//    but the 8-byte slot is written for a node's first column, which is what 99 % of the columns are.  Aliases need the column
+//    table to outlive the table's readers, so they are used only with one alignment per seed (see aln_both).
+//  * kind 1, a POOL entry: ConvRec `index` {pool offset, query range, capacity} and int32 words in the pool, as in round 2
+//    (position p of the range is pool[off + p - start]; an entry at the pool's top grows in place, else it moves there).
+//    Columns of the general path, filter_nodes marks and any entry that is written a second time (an alias is first copied out).
+// Keys are plain node ids: the reference adds max_index for RCDBG views (:74-75,107-108), a constant for all keys of one
+// extender's table here (an extender keeps its view), and filter_nodes (:158) uses the raw id on the forward extender, whose
+// view is the graph itself.
+
+MGX_DEV uint64_t cs_make(uint32_t key, uint32_t gen, uint32_t kind, uint32_t idx) {
+    return (uint64_t)key | ((uint64_t)((gen << 24) | (kind << 23) | idx) << 32);
+}
+MGX_DEV uint32_t cs_key(uint64_t e) { return (uint32_t)e; }
+MGX_DEV uint32_t cs_gen(uint64_t e) { return (uint32_t)(e >> 56); }
+MGX_DEV uint32_t cs_kind(uint64_t e) { return (uint32_t)(e >> 55) & 1u; }
+MGX_DEV uint32_t cs_idx(uint64_t e) { return (uint32_t)(e >> 32) & 0x7FFFFFu; }
+
+// set_seed (:90-98): a new generation, at level 0
+MGX_DEV void conv_clear(Wave &w, ConvChecker &c) {
+    const uint32_t hs = uni(MGX_PARAMS_OF(w).lim.hash_size);
+    uint32_t gen = uni(c.gen) + 1;
+    if (gen > 255) {
+        // every slot a generation of this round can have written lies in the levels up to `dirty`
+        const uint32_t cap0 = conv_cap0(hs);
+        const uint32_t n = cap0 * ((2u << uni(c.dirty)) - 1);
+        for (uint32_t base = 0; base < n; base += WAVE) {
+            FOR_LANES(l) { const uint32_t j = base + l; if (j < n) gst(c.tab + j, (uint64_t)0); }
+        }
+        wave_sync();
+        gen = 1;
+        c.dirty = 0;
+    }
+    c.gen = gen; c.n_entries = 0; c.n_recs = 0; c.pool_top = 0;
+    c.cap = conv_cap0(hs); c.base = 0;
+}
+
+MGX_DEV uint32_t conv_hash(uint32_t key, uint32_t mask) {
+    // any mixing works (results do not depend on it)
+    uint32_t h = (key ^ (key >> 15)) * 0x85EBCA6Bu;
+    h ^= h >> 13;
+    return h & mask;
+}
+
+// Linear probing from slot `h` of the current level, whose content `e` the caller has loaded: returns the slot of `key`
+// (found, e = its content) or the free slot where it would go.
+MGX_DEV uint32_t conv_probe_from(const ConvChecker &c, uint32_t key, uint32_t h, uint64_t &e, bool &found) {
+    const uint64_t *lv = c.tab + c.base;
+    const uint32_t gen = c.gen, mask = c.cap - 1;
+    for (;;) {
+        if (cs_gen(e) != gen) { found = false; return h; }
+        if (cs_key(e) == key) { found = true; return h; }
+        h = (h + 1) & mask;
+        e = gld(lv + h);
+    }
+}
+MGX_DEV uint32_t conv_probe(const ConvChecker &c, uint32_t key, uint64_t &e, bool &found) {
+    const uint32_t h = conv_hash(key, c.cap - 1);
+    e = gld(c.tab + c.base + h);
+    return conv_probe_from(c, key, h, e, found);
+}
+
+// a level that is half full hands over to the next one
+MGX_DEV void conv_grow(Wave &w, ConvChecker &c) {
+    const uint32_t hs = uni(MGX_PARAMS_OF(w).lim.hash_size);
+    while (uni(c.n_entries) * 2 > uni(c.cap) && uni(c.cap) < hs) {
+        const uint32_t ocap = uni(c.cap), obase = uni(c.base), gen = uni(c.gen);
+        const uint32_t ncap = 2 * ocap, nbase = obase + ocap;
+        const uint64_t *ol = c.tab + obase;
+        uint64_t *nl = c.tab + nbase;
+        // one live slot at a time (the probe sequences of a lane-parallel insert would collide); this runs once per 256,
+        // 512, ... distinct nodes of an extension
+        for (uint32_t j = 0; j < ocap; ++j) {
+            const uint64_t e = uni(gld(ol + j));
+            if (cs_gen(e) != gen) continue;
+            uint32_t h = conv_hash(cs_key(e), ncap - 1);
+            while (cs_gen(uni(gld(nl + h))) == gen) h = (h + 1) & (ncap - 1);
+            FOR_LANES(l) { if (l == 0) gst(nl + h, e); }
+            wave_sync();
+        }
+        c.cap = ncap; c.base = nbase;
+        uint32_t lvl = 0;
+        while ((conv_cap0(hs) << lvl) < ncap) ++lvl;
+        if (lvl > uni(c.dirty)) c.dirty = lvl;
+    }
+}
+
+// claim free slot `slot` of the current level for a new key; false = capacity (status set)
+MGX_DEV bool conv_claim(Wave &w, ConvChecker &c, uint32_t slot, uint32_t key, uint32_t kind, uint32_t idx) {
+    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
+    const uint32_t ne = uni(c.n_entries);
+    if (ne >= uni(lim.max_columns + lim.max_path) || ne * 2 >= uni(lim.hash_size)) { w.status = ST_CAPACITY; return false; }
+    c.n_entries = ne + 1;
+    FOR_LANES(l) { if (l == 0) gst(c.tab + c.base + slot, cs_make(key, c.gen, kind, idx)); }
+    wave_sync();
+    conv_grow(w, c);
+    return true;
+}
+
+MGX_DEV ConvRec conv_rec_load(const ConvChecker &c, uint32_t r) {
+    const uint4 v = gld(reinterpret_cast<const uint4 *>(c.recs + r));
+    ConvRec rec; rec.off = v.x; rec.start = (int32_t)v.y; rec.len = (int32_t)v.z; rec.cap = v.w;
+    return rec;
+}
+MGX_DEV void conv_rec_store(ConvChecker &c, uint32_t r, const ConvRec &rec) {
+    uint4 v; v.x = rec.off; v.y = (uint32_t)rec.start; v.z = (uint32_t)rec.len; v.w = rec.cap;
+    FOR_LANES(l) { if (l == 0) gst(reinterpret_cast<uint4 *>(c.recs + r), v); }
+}
+// vec[p] for query position p of pool entry rec
+MGX_DEV int32_t *conv_vec(const ConvChecker &c, const ConvRec &rec) { return c.pool + (int64_t)rec.off - (int64_t)rec.start; }
+
+// a new pool entry for [start, start + len) (words not initialised); returns the record number or -1 (capacity)
+MGX_DEV int32_t conv_new_rec(Wave &w, ConvChecker &c, int32_t start, int32_t len, ConvRec &rec) {
+    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
+    const uint32_t nr = uni(c.n_recs), top = uni(c.pool_top);
+    if (nr >= uni(lim.max_columns + lim.max_path) || (uint64_t)top + (uint32_t)len > uni(lim.conv_pool_words)) { w.status = ST_CAPACITY; return -1; }
+    c.n_recs = nr + 1;
+    c.pool_top = top + (uint32_t)len;
+    rec.off = top; rec.start = start; rec.len = len; rec.cap = (uint32_t)len;
+    conv_rec_store(c, nr, rec);
+    return (int32_t)nr;
+}
+
+// Make pool entry r cover [ns, ns + nl), a superset of its range: in place if its allocation reaches (an entry at the pool's
+// top grows there), else it moves to the pool's top (old values copied; newly covered positions are left for the caller to
+// write, as with the reference's vector::insert + fill).  Updates the record and `rec`; false = out of pool.
+MGX_DEV bool conv_cover(Wave &w, ConvChecker &c, uint32_t r, ConvRec &rec, int32_t ns, int32_t nl) {
+    const uint32_t words = uni(MGX_PARAMS_OF(w).lim.conv_pool_words);
+    const uint32_t top = uni(c.pool_top);
+    if (ns == rec.start && (uint32_t)nl <= rec.cap) {
+        rec.len = nl;
+    } else if (ns == rec.start && rec.off + rec.cap == top) {
+        if ((uint64_t)rec.off + (uint32_t)nl > words) { w.status = ST_CAPACITY; return false; }
+        c.pool_top = rec.off + (uint32_t)nl;
+        rec.cap = (uint32_t)nl; rec.len = nl;
+    } else {
+        if ((uint64_t)top + (uint32_t)nl > words) { w.status = ST_CAPACITY; return false; }
+        const int32_t *src = c.pool + rec.off;
+        int32_t *dst = c.pool + top + (rec.start - ns);
+        for (int32_t base = 0; base < rec.len; base += WAVE) {
+            LV<int32_t> v;
+            FOR_LANES(l) { const int32_t j = base + l; v[l] = j < rec.len ? gld(src + j) : 0; }
+            FOR_LANES(l) { const int32_t j = base + l; if (j < rec.len) gst(dst + j, v[l]); }
+        }
+        c.pool_top = top + (uint32_t)nl;
+        rec.off = top; rec.cap = (uint32_t)nl; rec.start = ns; rec.len = nl;
+    }
+    rec.start = ns;
+    conv_rec_store(c, r, rec);
+    wave_sync();
+    return true;
+}
+
+// fill vec positions [a, b) with `val`
+MGX_DEV void fill_range(int32_t *vec, int32_t a, int32_t b, int32_t val) {
+    for (int32_t base = a; base < b; base += WAVE) {
+        FOR_LANES(l) { int32_t j = base + l; if (j < b) gst(vec + j, val); }
+    }
+}
+
+// The query range an alias of column c stands for (update_seed_filter's arguments when the column was entered: cells
+// j in [skip, size) of the column at query positions start + trim + j - 1, skip = 1 for a window that starts at 0).
+MGX_DEV void conv_alias_range(const ConvChecker &c, const ColMeta &col, int32_t &qs, int32_t &len) {
+    const int32_t skip = col.trim ? 0 : 1;
+    qs = (int32_t)c.start + col.trim - (col.trim ? 1 : 0);
+    len = col.size - skip;
+}
+// value of an alias at query position p (inside its range)
+MGX_DEV int32_t conv_alias_at(const Wave &w, const ConvChecker &c, const ColMeta &col, int32_t p) {
+    return cell_S(w, col, p - (int32_t)c.start + 1);
+}
+
+// An alias about to be written a second time becomes a pool entry with the same content; `slot` is its hash slot (current
+// level).  Returns the record number (rec filled) or -1.
+MGX_DEV int32_t conv_materialize(Wave &w, ConvChecker &c, uint32_t slot, uint64_t e, ConvRec &rec) {
+    const ColMeta col = uni_col(col_load(w, (int32_t)cs_idx(e)));
+    int32_t qs, len;
+    conv_alias_range(c, col, qs, len);
+    const int32_t r = conv_new_rec(w, c, qs, len, rec);
+    if (r < 0) return -1;
+    int32_t *vec = conv_vec(c, rec);
+    for (int32_t base = 0; base < len; base += WAVE) {
+        LV<int32_t> v;
+        FOR_LANES(l) { const int32_t j = base + l; v[l] = j < len ? conv_alias_at(w, c, col, qs + j) : 0; }
+        FOR_LANES(l) { const int32_t j = base + l; if (j < len) gst(vec + qs + j, v[l]); }
+    }
+    FOR_LANES(l) { if (l == 0) gst(c.tab + c.base + slot, cs_make(cs_key(e), c.gen, 1u, (uint32_t)r)); }
+    wave_sync();
+    return r;
+}
+
+// update_seed_filter (:100-156) for a column of the general path: S in the staged (two-tier) array s_tier, cells
+// s_skip .. s_skip + size at query positions from query_start.  Returns converged score (NINF = nothing improved).
+MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start,
+                                   const Tier s_tier, int32_t s_skip, int32_t size) {
+    MGX_ASSUME_LDS(&w);
+    MGX_ASSUME_LDS(&E);
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    const int32_t s_cap = uni(w.st_cap);
+    s_skip = uni(s_skip);
+#define s_cells(j) tget(s_tier, s_cap, s_skip + (j))
+    auto column_max = [&]() {
+        int32_t m = INT32_MIN;
+        for (int32_t base = 0; base < size; base += WAVE) {
+            LV<int32_t> x;
+            FOR_LANES(l) { int32_t j = base + l; x[l] = j < size ? s_cells(j) : INT32_MIN; }
+            m = imax(m, wave_max(x));
+        }
+        return m;
+    };
+    auto store_column = [&](int32_t *vec) {
+        for (int32_t base = 0; base < size; base += WAVE) {
+            FOR_LANES(l) { int32_t j = base + l; if (j < size) gst(vec + query_start + j, s_cells(j)); }
+        }
+        wave_sync();
+    };
+    if (node == 0) return column_max();
+    node = uni(node); query_start = uni(query_start); size = uni(size);
+    ConvChecker &C = E.conv;
+    uint64_t e;
+    bool found;
+    const uint32_t slot = conv_probe(C, node, e, found);
+    ConvRec rec;
+    int32_t r;
+    if (!found) {
+        r = conv_new_rec(w, C, query_start, size, rec);
+        if (r < 0) return NINF;
+        if (!conv_claim(w, C, slot, node, 1u, (uint32_t)r)) return NINF;
+        store_column(conv_vec(C, rec));
+        return column_max();
+    }
+    if (cs_kind(e) == 0) {
+        r = conv_materialize(w, C, slot, e, rec);
+        if (r < 0) return NINF;
+    } else {
+        r = (int32_t)cs_idx(e);
+        rec = conv_rec_load(C, (uint32_t)r);
+    }
+    int32_t start = uni(rec.start), len = uni(rec.len);
+    if (query_start + size <= start) {
+        if (!conv_cover(w, C, (uint32_t)r, rec, query_start, start + len - query_start)) return NINF;
+        int32_t *vec = conv_vec(C, rec);
+        fill_range(vec, query_start + size, start, NINF);
+        store_column(vec);
+        return column_max();
+    }
+    if (query_start >= start + len) {
+        if (!conv_cover(w, C, (uint32_t)r, rec, start, query_start + size - start)) return NINF;
+        int32_t *vec = conv_vec(C, rec);
+        fill_range(vec, start + len, query_start, NINF);
+        store_column(vec);
+        return column_max();
+    }
+    {
+        const int32_t ns = imin(start, query_start), ne = imax(start + len, query_start + size);
+        if (ns != start || ne != start + len) { if (!conv_cover(w, C, (uint32_t)r, rec, ns, ne - ns)) return NINF; }
+    }
+    int32_t *vec = conv_vec(C, rec);
+    if (query_start < start) fill_range(vec, query_start, start, NINF);
+    if (query_start + size > start + len) fill_range(vec, start + len, query_start + size, NINF);
+    wave_sync();
+    int32_t max_changed = NINF;
+    const double rel = P.cfg.rel_score_cutoff;
+    for (int32_t base = 0; base < size; base += WAVE) {
+        LV<int32_t> x;
+        FOR_LANES(l) {
+            int32_t j = base + l;
+            x[l] = NINF;
+            if (j < size) {
+                int32_t sv = s_cells(j);
+                int32_t vv = gld(vec + query_start + j);
+                if ((double)sv > (double)vv * rel) {
+                    vv = imax(vv, sv);
+                    gst(vec + query_start + j, vv);
+                    x[l] = vv;
+                }
+            }
+        }
+        max_changed = imax(max_changed, wave_max(x));
+    }
+    wave_sync();
+    return max_changed;
+}
+#undef s_cells
+
+// check_seed (:66-88): true when the seed is still worth extending
+MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int32_t qlen, int32_t clipping, int32_t score) {
+    const ConvChecker &C = E.conv;
+    uint64_t e;
+    bool found;
+    conv_probe(C, last_node, e, found);
+    if (!found) return true;
+    const int32_t pos = qlen + clipping - 1;
+    if (cs_kind(e) == 0) {
+        const ColMeta col = col_load(w, (int32_t)cs_idx(e));
+        int32_t qs, len;
+        conv_alias_range(C, col, qs, len);
+        if (pos < qs || pos - qs >= len) return true;
+        return conv_alias_at(w, C, col, pos) < score;
+    }
+    const ConvRec rec = conv_rec_load(C, cs_idx(e));
+    if (pos < rec.start || pos - rec.start >= rec.len) return true;
+    return gld(conv_vec(C, rec) + pos) < score;
+}
+
+// filter_nodes (:158-207); written out only with several alignments per seed (aln_both applies it lazily otherwise)
+MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t query_start, int32_t query_end) {
+    MGX_ASSUME_LDS(&w);
+    MGX_ASSUME_LDS(&E);
+    const int32_t mscore = -NINF;
+    int32_t size = query_end - query_start;
+    ConvChecker &C = E.conv;
+    uint64_t e;
+    bool found;
+    const uint32_t slot = conv_probe(C, node, e, found);
+    ConvRec rec;
+    int32_t r;
+    if (!found) {
+        r = conv_new_rec(w, C, query_start, size, rec);
+        if (r < 0) return;
+        if (!conv_claim(w, C, slot, node, 1u, (uint32_t)r)) return;
+        fill_range(conv_vec(C, rec), query_start, query_end, mscore);
+        wave_sync();
+        return;
+    }
+    if (cs_kind(e) == 0) {
+        r = conv_materialize(w, C, slot, e, rec);
+        if (r < 0) return;
+    } else {
+        r = (int32_t)cs_idx(e);
+        rec = conv_rec_load(C, (uint32_t)r);
+    }
+    const int32_t start = rec.start, len = rec.len;
+    const int32_t ns = imin(start, query_start), ne = imax(start + len, query_end);
+    if (ns != start || ne != start + len) { if (!conv_cover(w, C, (uint32_t)r, rec, ns, ne - ns)) return; }
+    int32_t *vec = conv_vec(C, rec);
+    if (query_end <= start) fill_range(vec, query_end, start, NINF);                   // gap below the old range
+    else if (query_start >= start + len) fill_range(vec, start + len, query_start, NINF);   // gap above it
+    fill_range(vec, query_start, query_end, mscore);      // mscore is the maximum, so max(v, mscore) == mscore
+    wave_sync();
 }
 
 // capacity of a reference vector created with `size0` elements (+5 reserved) after `pushes` push_backs
@@ -2446,12 +2561,10 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     }
     c = to_upper(c);
     // the convergence table's slot for the child's node: issued now, consumed after the column is computed
-    const uint64_t ckey = (uint64_t)next + x.rc_key_add;
-    const uint32_t cmask = x.hash_mask;
-    const uint32_t chash = conv_hash(ckey, cmask);
-    ConvSlot csl;
-    csl.key = 0; csl.gen = 0; csl.off = 0; csl.start = 0; csl.len = 0; csl.cap = 0; csl.pad1 = 0;
-    if (next) csl = conv_load_slot(E.conv.slots + chash);
+    const uint32_t ckey = next;
+    const uint32_t chash = conv_hash(ckey, E.conv.cap - 1);
+    uint64_t cse = 0;
+    if (next) cse = gld(E.conv.tab + E.conv.base + chash);
     CH_T(0)
     // Expansion of the child's own node one column ahead (forward graph only): if this child continues the chain and
     // its successor comes from the graph, the two dependent loads of fwd() (select hint, target block) travel while
@@ -2670,6 +2783,9 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     enum { CV_NONE = 0, CV_INSERT = 1, CV_BELOW = 2, CV_ABOVE = 3, CV_MERGE = 4 };
     int cv_mode = CV_NONE;
     uint32_t cv_slot = 0;
+    int32_t cv_rec = -1;                       // pool record of a node seen before
+    ConvRec crec;
+    crec.off = 0; crec.start = 0; crec.len = 0; crec.cap = 0;
     int32_t cv_vstart = 0, cv_vlen = 0;
     int32_t *cv_vec = nullptr;
     LV<int32_t> mv[4];                         // CV_MERGE: value to store per cell ...
@@ -2690,13 +2806,16 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         converged = wave_max(cm);
         if (next != 0 && !(MGX_PARAMS_OF(w).ablate & 1u)) {
             bool found;
-            cv_slot = conv_probe_from(E.conv, cmask, ckey, chash, csl, found);
+            cv_slot = conv_probe_from(E.conv, ckey, chash, cse, found);
             if (!found) {
                 cv_mode = CV_INSERT;
             } else {
-                if (cv_slot != chash) csl = conv_load_slot(E.conv.slots + cv_slot);      // found by a later probe step
-                cv_vec = conv_vec(E.conv, csl);
-                cv_vstart = csl.start; cv_vlen = csl.len;
+                // a node seen before: its entry is written a second time, so an alias is copied out to the pool first
+                if (cs_kind(cse) == 0) cv_rec = conv_materialize(w, E.conv, cv_slot, cse, crec);
+                else { cv_rec = (int32_t)cs_idx(cse); crec = conv_rec_load(E.conv, (uint32_t)cv_rec); }
+                if (cv_rec < 0) return FR_ERROR;
+                cv_vec = conv_vec(E.conv, crec);
+                cv_vstart = crec.start; cv_vlen = crec.len;
                 if (query_start + cn <= cv_vstart) cv_mode = CV_BELOW;
                 else if (query_start >= cv_vstart + cv_vlen) cv_mode = CV_ABOVE;
                 else {
@@ -2858,17 +2977,24 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     x.tsize = my_idx + 1;
     // update_seed_filter, the stores
     if (cv_mode == CV_INSERT) {
-        const int64_t off = conv_insert(w, E.conv, cv_slot, ckey, query_start, cn);
-        if (off < 0) return FR_ERROR;
-        cv_vec = E.conv.pool + off - query_start;
+        if (x.alias_ok) {
+            // the node's first column: the table entry points at the column's own S window (its slot, just written)
+            if (!conv_claim(w, E.conv, cv_slot, ckey, 0u, (uint32_t)my_idx)) return FR_ERROR;
+            cv_mode = CV_NONE;
+        } else {
+            cv_rec = conv_new_rec(w, E.conv, query_start, cn, crec);
+            if (cv_rec < 0) return FR_ERROR;
+            if (!conv_claim(w, E.conv, cv_slot, ckey, 1u, (uint32_t)cv_rec)) return FR_ERROR;
+            cv_vec = conv_vec(E.conv, crec);
+        }
     } else if (cv_mode != CV_NONE) {
         // a node seen before: its vector grows to the union of the ranges (moving to the pool's top if it has to), the gap
         // between disjoint ranges reads ninf
         const int32_t nstart = imin(cv_vstart, query_start);
         const int32_t nend = imax(cv_vstart + cv_vlen, query_start + cn);
         if (nstart != cv_vstart || nend != cv_vstart + cv_vlen) {
-            if (!conv_cover(w, E.conv, cv_slot, csl, nstart, nend - nstart)) return FR_ERROR;
-            cv_vec = conv_vec(E.conv, csl);
+            if (!conv_cover(w, E.conv, (uint32_t)cv_rec, crec, nstart, nend - nstart)) return FR_ERROR;
+            cv_vec = conv_vec(E.conv, crec);
         }
         if (cv_mode == CV_BELOW) fill_range(cv_vec, query_start + cn, cv_vstart, NINF);
         else if (cv_mode == CV_ABOVE) fill_range(cv_vec, cv_vstart + cv_vlen, query_start, NINF);
@@ -2941,13 +3067,16 @@ MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fix
     x.seed_nodes = seed.nodes;
     x.seed_seq = seed.seq;
     x.seq_lds = (w.q_lds && seed.seq >= w.q[seed.orientation] && seed.seq < w.q[seed.orientation] + w.L) ? 1 : 0;
-    x.rc_key_add = E.rc_view ? P.g.n : 0;
     x.rc = E.rc_view ? 1 : 0;
     x.n_valid = 0; x.n_for = -1; x.n_count = 0;
     x.seed_n_nodes = uni(seed.n_nodes); x.sn_base = -0x40000000; x.sc_base = -0x40000000;
     x.rel_cutoff = cfg.rel_score_cutoff; x.max_nodes_per_char = cfg.max_nodes_per_seq_char; x.max_ram = cfg.max_ram_per_alignment;
     x.go = cfg.gap_open; x.ge = cfg.gap_ext; x.xdrop = cfg.xdrop; x.k = (int32_t)P.g.k; x.Lq = (int32_t)lim.Lmax;
-    x.max_columns = (int32_t)lim.max_columns; x.hash_mask = lim.hash_size - 1; x.cell_words = lim.cell_words;
+    x.max_columns = (int32_t)lim.max_columns; x.cell_words = lim.cell_words;
+    // aliases point into the one column table: usable when nothing runs another extension between this one and the last
+    // reader of its convergence table, i.e. with one alignment per seed (aln_both checks the later seeds before the backward pass)
+    x.alias_ok = n_alt_of(w) == 1 && !P.no_alias ? 1u : 0u;
+    E.conv.start = (uint32_t)x.start;
     x.cell_top = 0;
     x.tsize = 0;
     x.table_size_bytes = 0;
@@ -3772,7 +3901,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         ++w.seeds_done;
         const uint64_t tp0 = cycle_clock();
         SeedRef seed = seedref_from_seed(w, s, i, nullptr);
-        conv_clear(F.conv);                                   // set_seed (:90-98)
+        conv_clear(w, F.conv);                                // set_seed (:90-98)
         uint64_t t0 = cycle_clock();
         w.cyc[6] += t0 - tp0;
         extend(w, s, seed, false);
@@ -3821,12 +3950,40 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         // least its score (align_core :360-384: check_seed between the seeds of the list)
         const uint32_t *filt_nodes = nullptr;                 // lazily applied filter_nodes (see below)
         int32_t filt_n = 0, filt_lo = 0, filt_hi = 0;
+        // filter_seed (:105-108, :731-734) for every later seed: independent look-ups into the forward extender's convergence
+        // table, one seed per lane (reads of a pan-genome carry ~100 sub-k seeds: one after the other this loop was two thirds
+        // of the kernel there).  With one alignment per seed nothing writes that table between the forward extension and
+        // these checks (the backward pass has its own, filter_nodes is applied lazily), so the table part runs BEFORE the
+        // backward pass, while the column table its alias entries point into is still the forward extension's; the filter
+        // part follows the backward pass.  With several alignments per seed both run after it, on pool entries only.
+        auto check_later = [&](bool with_table, bool with_filter) {
+            for (int32_t base = i + 1; base < n; base += WAVE) {
+                FOR_LANES(l) {
+                    const int32_t j = base + l;
+                    if (j < n && w.alive[s][j]) {
+                        DevSeed sj = w.seeds[s][j];
+                        uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
+                        SeedRef rj = seedref_from_seed(w, s, j, nullptr);
+                        bool dead = with_table && !check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score);
+                        // the deferred filter_nodes marks: position qlen + clipping - 1 of a node on the reversed backward
+                        // alignment holds the maximal score (check_seed: vec[pos] < score is false)
+                        const int32_t pos = rj.qlen + rj.clipping - 1;
+                        if (with_filter && !dead && filt_n && pos >= filt_lo && pos < filt_hi) {
+                            for (int32_t x = 0; x < filt_n; ++x) dead |= gld(filt_nodes + x) == last_node;
+                        }
+                        if (dead) w.alive[s][j] = 0;
+                    }
+                }
+            }
+            wave_sync();
+        };
+        if (n_alt == 1) check_later(true, false);
         for (int r = 0; r < n_rev; ++r) {
             if (!rev_alive[r]) continue;
             DevAln &rev = w.aln[n_alt + r];
             SeedRef rseed = seedref_from_aln(rev);
             int32_t mps2 = imax(0, min_path_score_now(w));
-            conv_clear(B.conv);
+            conv_clear(w, B.conv);
             uint64_t t2 = cycle_clock();
             extend(w, 1 - s, rseed, true);
             uint64_t t3 = cycle_clock();
@@ -3866,27 +4023,8 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
                 if (!check_seed(w, B, o.nodes[o.n_nodes - 1], o.qlen, aln_clipping(o), o.score)) rev_alive[r2] = false;
             }
         }
-        // filter_seed (:105-108) for every later seed: independent look-ups into the convergence table, one seed per lane
-        // (reads of a pan-genome carry ~100 sub-k seeds: one after the other this loop was two thirds of the kernel there)
-        for (int32_t base = i + 1; base < n; base += WAVE) {
-            FOR_LANES(l) {
-                const int32_t j = base + l;
-                if (j < n && w.alive[s][j]) {
-                    DevSeed sj = w.seeds[s][j];
-                    uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
-                    SeedRef rj = seedref_from_seed(w, s, j, nullptr);
-                    bool dead = !check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score);
-                    // the deferred filter_nodes marks: position qlen + clipping - 1 of a node on the reversed backward
-                    // alignment holds the maximal score (check_seed: vec[pos] < score is false)
-                    const int32_t pos = rj.qlen + rj.clipping - 1;
-                    if (!dead && filt_n && pos >= filt_lo && pos < filt_hi) {
-                        for (int32_t x = 0; x < filt_n; ++x) dead |= gld(filt_nodes + x) == last_node;
-                    }
-                    if (dead) w.alive[s][j] = 0;
-                }
-            }
-        }
-        wave_sync();
+        if (n_alt == 1) { if (filt_n) check_later(false, true); }
+        else check_later(true, false);
     }
 }
 
@@ -3905,7 +4043,7 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
         ++w.seeds_done;
         SeedRef seed = seedref_from_seed(w, 0, i, nullptr);
         int32_t mps = imax(0, min_path_score_now(w));
-        conv_clear(F.conv);
+        conv_clear(w, F.conv);
         extend(w, 0, seed, false);
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
@@ -3996,11 +4134,12 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
             w.ext[s].psum_lin = (PHASE & PH_EXTEND) ? w.psum_lin[s] : 0;
             w.ext[s].table_cap = 0;
             w.ext[s].rc_view = 0;
-            w.ext[s].conv.n_entries = 0;
+            w.ext[s].conv.n_entries = 0; w.ext[s].conv.n_recs = 0; w.ext[s].conv.pool_top = 0;
+            w.ext[s].conv.cap = conv_cap0(P.lim.hash_size); w.ext[s].conv.base = 0; w.ext[s].conv.start = 0;
         }
         // generation tags make clearing the hash tables O(1); the counters persist in the arena
         // slice across the reads a wave slot processes
-        for (int s = 0; s < 2; ++s) w.ext[s].conv.gen = w.gen_store[s];
+        for (int s = 0; s < 2; ++s) { w.ext[s].conv.gen = w.gen_store[2 * s]; w.ext[s].conv.dirty = w.gen_store[2 * s + 1]; }
         const bool have_rc = P.cfg.fwd_and_rc != 0;
         // build_seeders (:193-248)
         const uint64_t tseed = cycle_clock();
@@ -4137,7 +4276,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
 #else
         static_assert(PHASE == PH_SEED, "this translation unit was built without the extension half");
 #endif
-        for (int s = 0; s < 2; ++s) w.gen_store[s] = w.ext[s].conv.gen;
+        for (int s = 0; s < 2; ++s) { w.gen_store[2 * s] = w.ext[s].conv.gen; w.gen_store[2 * s + 1] = w.ext[s].conv.dirty; }
         wave_sync();
         w.cyc[4] = cycle_clock() - tdrv - w.cyc[2] - w.cyc[3];
     }

@@ -34,7 +34,7 @@ struct DevLimits {
     uint32_t cell_words;     // int32 words of S/E/F storage per wave
     uint32_t hash_size;      // power of two
     uint32_t n_aln;          // alignment buffers per read: 4 * num_alternative_paths
-    uint32_t conv_pool_words;    // int32 words of convergence vectors per extender (pool; see ConvSlot)
+    uint32_t conv_pool_words;    // int32 words of convergence vectors per extender (pool; see the convergence checker section of align_core.hpp)
 };
 
 // per-read result header; variable-length parts live in the output stream
@@ -127,6 +127,7 @@ struct AlignParams {
     uint32_t resume_rec_bytes, resume_cap;
     uint64_t n_items;                        // items of this launch (0: n_items_ptr / n_reads)
     uint32_t no_fast;                    // A/B and test switch: every column through the general (staging buffer) path
+    uint32_t no_alias;                   // A/B and test switch: every convergence-table entry gets its own vector in the pool
     uint32_t no_compact;                 // A/B and test switch: chain columns always in the two-line form (ColSlot)
     uint32_t ablate;                     // timing probes only (results become WRONG): bit 0 = no convergence table in the chain
                                          // step, bit 1 = no cell records / column metadata stores, bit 2 = no backtrack

@@ -843,6 +843,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.no_fast = no_fast || A->no_fast;
     static const bool no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;
     P.no_compact = no_compact;
+    static const bool no_alias = getenv("MGX_NO_ALIAS") && atoi(getenv("MGX_NO_ALIAS")) == 1;
+    P.no_alias = no_alias;
     P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results
     size_t sort_tmp_bytes = 0;
     if (split) {

@@ -58,8 +58,8 @@ static void trace_register_arena(const AlignParams &P, uint8_t *base, uint64_t s
         { w->seeds[0], "seeds" }, { w->alive[0], "alive" }, { w->alt, "alt" }, { w->cells, "cells" }, { w->cols, "cols" },
         { w->queue, "queue" }, { w->next_nodes, "next_nodes" }, { w->tips, "tips" }, { w->prev_starts, "prev_starts" },
         { w->indices, "bt_indices" }, { w->rev_ops, "rev" }, { w->gen_store, "gen_store" },
-        { w->ext[0].conv.slots, "conv_slots" }, { w->ext[0].conv.pool, "conv_pool" },
-        { w->ext[1].conv.slots, "conv_slots" }, { w->ext[1].conv.pool, "conv_pool" },
+        { w->ext[0].conv.tab, "conv_slots" }, { w->ext[0].conv.recs, "conv_recs" }, { w->ext[0].conv.pool, "conv_pool" },
+        { w->ext[1].conv.tab, "conv_slots" }, { w->ext[1].conv.recs, "conv_recs" }, { w->ext[1].conv.pool, "conv_pool" },
         { w->aln[0].nodes, "aln" },
     };
     std::sort(pts.begin(), pts.end(), [](const Pt &a, const Pt &b) { return a.p < b.p; });
@@ -319,6 +319,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();
     P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
     P.no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;
+    P.no_alias = getenv("MGX_NO_ALIAS") && atoi(getenv("MGX_NO_ALIAS")) == 1;
     auto w = std::make_unique<Wave>();
     SdustScratch sd;
     // model a small LDS so that both placements (LDS / arena) of the fast arrays are exercised
