@@ -211,8 +211,7 @@ constexpr int N_ALN = 4 * MAX_ALT;           // alignment buffers: extension res
 // the convergence table of one extender (layout and entry kinds: see the "convergence checker" section)
 struct ConvRec { uint32_t off; int32_t start, len; uint32_t cap; };      // a pool entry: words [off, off + cap) hold [start, start + len)
 struct ConvChecker {             // SeedFilteringExtender::conv_checker_ (extender hpp:75-76)
-    uint64_t *tab;               // hash slots, all levels (conv_tab_slots())
-    ConvRec *recs;               // pool entries
+    uint64_t *tab;               // hash slots, all levels (conv_tab_slots()); the pool entries' ConvRecs follow them
     int32_t *pool;               // DevLimits::conv_pool_words words
     uint32_t n_entries, n_recs;
     uint32_t gen;                // 1 .. 255
@@ -382,8 +381,8 @@ struct Wave {
     uint32_t out_nodes[5];       // children of the column being expanded (call_outgoing)
     int32_t out_scores[5];
     uint8_t out_chars[8];
-    uint64_t cyc[8];             // phase timers (shader cycles)
-    uint64_t xcyc[XCYC_N];       // extend() breakdown: pop, general steps, chain steps (probe builds: per-stage timers)
+    uint32_t cyc[8];             // phase timers (shader cycles of one read: 32 bits; LDS bytes decide the kernel's occupancy)
+    uint32_t xcyc[XCYC_N];       // extend() breakdown: pop, general steps, chain steps (probe builds: per-stage timers)
     uint32_t n_columns, n_extensions, n_fast_columns;
     int32_t status;
 };
@@ -543,7 +542,7 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     for (int s = 0; s < 2; ++s) {
         p = (uint8_t *)(((uint64_t)p + 63) & ~63ull);              // level 0 of the hash table starts a line
         w.ext[s].conv.tab = (uint64_t *)take(2ull * lim.hash_size * 8);          // conv_tab_slots()
-        w.ext[s].conv.recs = (ConvRec *)take(((uint64_t)lim.max_columns + lim.max_path) * 16);
+        take(((uint64_t)lim.max_columns + lim.max_path) * 16);                   // ConvRecs (conv_recs())
         w.ext[s].conv.pool = (int32_t *)take((uint64_t)lim.conv_pool_words * 4);
     }
     for (int a = 0; a < N_ALN && a < (int)lim.n_aln; ++a) {
@@ -1643,14 +1642,18 @@ MGX_DEV bool conv_claim(Wave &w, ConvChecker &c, uint32_t slot, uint32_t key, ui
     return true;
 }
 
-MGX_DEV ConvRec conv_rec_load(const ConvChecker &c, uint32_t r) {
-    const uint4 v = gld(reinterpret_cast<const uint4 *>(c.recs + r));
+// the pool entries' records live right behind the hash levels (one pointer less in the LDS control block)
+MGX_DEV ConvRec *conv_recs(const Wave &w, const ConvChecker &c) {
+    return reinterpret_cast<ConvRec *>(c.tab + conv_tab_slots(uni(MGX_PARAMS_OF(w).lim.hash_size)));
+}
+MGX_DEV ConvRec conv_rec_load(const Wave &w, const ConvChecker &c, uint32_t r) {
+    const uint4 v = gld(reinterpret_cast<const uint4 *>(conv_recs(w, c) + r));
     ConvRec rec; rec.off = v.x; rec.start = (int32_t)v.y; rec.len = (int32_t)v.z; rec.cap = v.w;
     return rec;
 }
-MGX_DEV void conv_rec_store(ConvChecker &c, uint32_t r, const ConvRec &rec) {
+MGX_DEV void conv_rec_store(const Wave &w, ConvChecker &c, uint32_t r, const ConvRec &rec) {
     uint4 v; v.x = rec.off; v.y = (uint32_t)rec.start; v.z = (uint32_t)rec.len; v.w = rec.cap;
-    FOR_LANES(l) { if (l == 0) gst(reinterpret_cast<uint4 *>(c.recs + r), v); }
+    FOR_LANES(l) { if (l == 0) gst(reinterpret_cast<uint4 *>(conv_recs(w, c) + r), v); }
 }
 // vec[p] for query position p of pool entry rec
 MGX_DEV int32_t *conv_vec(const ConvChecker &c, const ConvRec &rec) { return c.pool + (int64_t)rec.off - (int64_t)rec.start; }
@@ -1663,7 +1666,7 @@ MGX_DEV int32_t conv_new_rec(Wave &w, ConvChecker &c, int32_t start, int32_t len
     c.n_recs = nr + 1;
     c.pool_top = top + (uint32_t)len;
     rec.off = top; rec.start = start; rec.len = len; rec.cap = (uint32_t)len;
-    conv_rec_store(c, nr, rec);
+    conv_rec_store(w, c, nr, rec);
     return (int32_t)nr;
 }
 
@@ -1692,7 +1695,7 @@ MGX_DEV bool conv_cover(Wave &w, ConvChecker &c, uint32_t r, ConvRec &rec, int32
         rec.off = top; rec.cap = (uint32_t)nl; rec.start = ns; rec.len = nl;
     }
     rec.start = ns;
-    conv_rec_store(c, r, rec);
+    conv_rec_store(w, c, r, rec);
     wave_sync();
     return true;
 }
@@ -1780,7 +1783,7 @@ MGX_NI_G5 int32_t update_seed_filter(Wave &w, ExtenderState &E, uint32_t node, i
         if (r < 0) return NINF;
     } else {
         r = (int32_t)cs_idx(e);
-        rec = conv_rec_load(C, (uint32_t)r);
+        rec = conv_rec_load(w, C, (uint32_t)r);
     }
     int32_t start = uni(rec.start), len = uni(rec.len);
     if (query_start + size <= start) {
@@ -1844,7 +1847,7 @@ MGX_DEV bool check_seed(Wave &w, const ExtenderState &E, uint32_t last_node, int
         if (pos < qs || pos - qs >= len) return true;
         return conv_alias_at(w, C, col, pos) < score;
     }
-    const ConvRec rec = conv_rec_load(C, cs_idx(e));
+    const ConvRec rec = conv_rec_load(w, C, cs_idx(e));
     if (pos < rec.start || pos - rec.start >= rec.len) return true;
     return gld(conv_vec(C, rec) + pos) < score;
 }
@@ -1874,7 +1877,7 @@ MGX_NI_G5 void filter_nodes(Wave &w, ExtenderState &E, uint32_t node, int32_t qu
         if (r < 0) return;
     } else {
         r = (int32_t)cs_idx(e);
-        rec = conv_rec_load(C, (uint32_t)r);
+        rec = conv_rec_load(w, C, (uint32_t)r);
     }
     const int32_t start = rec.start, len = rec.len;
     const int32_t ns = imin(start, query_start), ne = imax(start + len, query_end);
@@ -2812,7 +2815,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             } else {
                 // a node seen before: its entry is written a second time, so an alias is copied out to the pool first
                 if (cs_kind(cse) == 0) cv_rec = conv_materialize(w, E.conv, cv_slot, cse, crec);
-                else { cv_rec = (int32_t)cs_idx(cse); crec = conv_rec_load(E.conv, (uint32_t)cv_rec); }
+                else { cv_rec = (int32_t)cs_idx(cse); crec = conv_rec_load(w, E.conv, (uint32_t)cv_rec); }
                 if (cv_rec < 0) return FR_ERROR;
                 cv_vec = conv_vec(E.conv, crec);
                 cv_vstart = crec.start; cv_vlen = crec.len;

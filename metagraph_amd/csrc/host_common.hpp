@@ -83,8 +83,13 @@ inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lm
     uint64_t cw;
     if (u && u->cell_arena_bytes) cw = u->cell_arena_bytes / 4;
     else {
-        uint64_t band = cfg.xdrop < 1000 ? std::min<uint64_t>(l.Lmax + 8, 96) : (l.Lmax + 8);
-        cw = (uint64_t)l.max_columns * 3 * band + 3 * (l.Lmax + 16);
+        // S / F records of the cell arena: every column of the general path, and the chain columns that stay behind in the
+        // frontier (one 32-cell record).  Round 2 budgeted 3 x 96 words for every possible column; on short-read batches
+        // 98 % of the columns are chain columns that own nothing here, and the arena slices are what limits the number of
+        // resident groups at 10 M reads — a quarter of that, still 24 cells x 3 per possible column.  A read that runs out gets
+        // MGX_ERR_CAPACITY and the adapter's retry doubles the budget.
+        uint64_t band = cfg.xdrop < 1000 ? std::min<uint64_t>(l.Lmax + 8, 24) : (l.Lmax + 8);
+        cw = (uint64_t)l.max_columns * 3 * band + 3 * (l.Lmax + 16) + 4096;
     }
     l.cell_words = (uint32_t)std::min<uint64_t>(cw, 0xFFFFFF00ull);
     l.hash_size = next_pow2(2ull * ((uint64_t)l.max_columns + l.max_path) + 2);

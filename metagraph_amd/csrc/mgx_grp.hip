@@ -23,12 +23,19 @@
 
 using namespace mgx;
 
-// 2 waves per SIMD.  The kernel is bound by dependent round trips (halving the resident groups costs 1.77x) and its control
-// block is small enough for 3 (12 wavefronts per CU with both strands of a 150-bp read in LDS), but the 168-VGPR budget
-// that goes with 3 makes the code itself 1.7x slower at equal occupancy (measured: 1273 vs 734 ms per 4 M reads at 2
-// waves' worth of groups, 927 ms with all 3) — so the register allocation, not LDS, sets the occupancy here.
+// Waves per SIMD.  The kernel is bound by dependent round trips inside each group (halving the resident groups halves the
+// throughput: 315 -> 581 -> 1080 ms per 2 M reads at 100 / 50 / 25 % of the groups, profiles/r03_ab1.txt), so occupancy is
+// the lever.  Round 2 ran 2 waves: under its DRAM-saturating per-read traffic a third wave was slower (396 vs 318 ms).
+// With the round-3 traffic (one 64-byte slot per column, aliased convergence entries) 3 waves — the 168-VGPR budget, 16
+// scratch accesses in extend() — run 15 % faster (265 vs 313 ms).  4 waves do not fit: the control blocks of 8 groups
+// alone are 10 KB of the 10 KB a wavefront would get.  The build that carries alternative paths / PRIMARY graphs has a
+// bigger control block and stays at 2.
 #ifndef MGX_GRP_WAVES_PER_SIMD
+#ifdef MGX_ALT_BUILD
 #define MGX_GRP_WAVES_PER_SIMD 2
+#else
+#define MGX_GRP_WAVES_PER_SIMD 3
+#endif
 #endif
 
 // each group owns one read at a time, one arena slice and one slice of the dynamic LDS

@@ -63,17 +63,7 @@ MGX_DEV uint64_t wave_ballot(const LV<bool> &p) {
 MGX_DEV int32_t grp_shfl(int32_t v, int src) { return __builtin_amdgcn_ds_bpermute((group_base() + src) << 2, v); }
 
 template <class T>
-MGX_DEV T wave_bcast(const LV<T> &x, int src) {
-    if constexpr (sizeof(T) == 8) {
-        uint64_t u = (uint64_t)x.v;
-        uint32_t lo = (uint32_t)grp_shfl((int32_t)(uint32_t)u, src);
-        uint32_t hi = (uint32_t)grp_shfl((int32_t)(uint32_t)(u >> 32), src);
-        return (T)(((uint64_t)hi << 32) | lo);
-    } else {
-        return (T)grp_shfl((int32_t)x.v, src);
-    }
-}
-
+MGX_DEV T wave_bcast(const LV<T> &x, int src);
 // value of lane (l - 1) of the group; lane 0 receives `fill`
 MGX_DEV LV<int32_t> wave_shift_up1(const LV<int32_t> &x, int32_t fill) {
     LV<int32_t> r;
@@ -108,17 +98,40 @@ MGX_DEV LV<int32_t> wave_prefix_max(const LV<int32_t> &x) {
     return r;
 }
 
-MGX_DEV int32_t wave_max(const LV<int32_t> &x) {
-    LV<int32_t> p = wave_prefix_max(x);
-    return grp_shfl(p.v, WAVE - 1);
+// All-lanes reductions inside the group WITHOUT the LDS crossbar: a butterfly over DPP quad permutes ([1,0,3,2], [2,3,0,1]),
+// the half-row mirror (lane i <-> 7 - i: the other quad of an 8-lane group) and, for 16 lanes, the row mirror.  ds_bpermute
+// costs an LDS round trip (~100 cycles) per use and the extension kernel is bound by exactly such dependent round trips; a
+// DPP step is a VALU instruction.
+#define MGX_GRP_BFLY(OP)                                                                                        \
+    { int32_t t_ = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false); v = OP(v, t_); }                 \
+    { int32_t t_ = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false); v = OP(v, t_); }                 \
+    if (WAVE >= 8) { int32_t t_ = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false); v = OP(v, t_); } \
+    if (WAVE >= 16) { int32_t t_ = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false); v = OP(v, t_); }
+#define MGX_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define MGX_OP_OR(a, b) ((a) | (b))
+#define MGX_OP_ADD(a, b) ((a) + (b))
+MGX_DEV int32_t grp_all_max(int32_t v) { MGX_GRP_BFLY(MGX_OP_MAX) return v; }
+MGX_DEV int32_t grp_all_or(int32_t v) { MGX_GRP_BFLY(MGX_OP_OR) return v; }
+MGX_DEV int32_t grp_all_add(int32_t v) { MGX_GRP_BFLY(MGX_OP_ADD) return v; }
+#undef MGX_GRP_BFLY
+
+// value of lane `src` (group-uniform) in every lane of the group: the source lane's bits OR-ed across the group
+template <class T>
+MGX_DEV T wave_bcast(const LV<T> &x, int src) {
+    const bool me = lane_id() == src;
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t u = (uint64_t)x.v;
+        const uint32_t lo = (uint32_t)grp_all_or(me ? (int32_t)(uint32_t)u : 0);
+        const uint32_t hi = (uint32_t)grp_all_or(me ? (int32_t)(uint32_t)(u >> 32) : 0);
+        return (T)(((uint64_t)hi << 32) | lo);
+    } else {
+        return (T)grp_all_or(me ? (int32_t)x.v : 0);
+    }
 }
 
-MGX_DEV int32_t wave_min(const LV<int32_t> &x) {
-    LV<int32_t> n;
-    n.v = ~x.v;
-    LV<int32_t> p = wave_prefix_max(n);
-    return ~grp_shfl(p.v, WAVE - 1);
-}
+MGX_DEV int32_t wave_max(const LV<int32_t> &x) { return grp_all_max(x.v); }
+
+MGX_DEV int32_t wave_min(const LV<int32_t> &x) { return ~grp_all_max(~x.v); }
 
 MGX_DEV uint64_t wave_max_u64(const LV<uint64_t> &x) {
     uint64_t v = x.v;
@@ -132,12 +145,7 @@ MGX_DEV uint64_t wave_max_u64(const LV<uint64_t> &x) {
     return v;
 }
 
-MGX_DEV int32_t wave_sum(const LV<int32_t> &x) {
-    int32_t v = x.v;
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
-    return v;
-}
+MGX_DEV int32_t wave_sum(const LV<int32_t> &x) { return grp_all_add(x.v); }
 
 MGX_DEV LV<int32_t> wave_prefix_sum_excl(const LV<int32_t> &x) {
     int32_t v = x.v;

@@ -141,9 +141,15 @@ class HipDBGAlignerAdapter : public IDBGAligner {
                 for (uint64_t ai = res.aln_begin[t]; ai < res.aln_begin[t + 1]; ++ai) {
                     const mgx_alignment &a = res.alignments[ai];
                     const std::string &q = paths.get_query(a.orientation);
+                    // Alignment's constructor (alignment.hpp:142-152) starts cigar_ with (CLIPPED, clipping) and appends the cigar it
+                    // is given, and Cigar::append merges equal neighbouring operators: the device CIGAR's own leading soft clip
+                    // must not be passed a second time (the trailing one is part of the cigar argument, as in the reference)
                     Cigar cigar;
-                    for (uint32_t x = 0; x < a.n_cigar; ++x)
-                        cigar.append(static_cast<Cigar::Operator>(res.cigar[a.cigar_begin + x].op), res.cigar[a.cigar_begin + x].len);
+                    for (uint32_t x = 0; x < a.n_cigar; ++x) {
+                        const mgx_cigar_op &op = res.cigar[a.cigar_begin + x];
+                        if (x == 0 && op.op == MGX_OP_CLIPPED && a.clipping) continue;
+                        cigar.append(static_cast<Cigar::Operator>(op.op), op.len);
+                    }
                     std::vector<DeBruijnGraph::node_index> nodes(res.nodes + a.nodes_begin, res.nodes + a.nodes_begin + a.n_nodes);
                     paths.emplace_back(Alignment(
                         std::string_view(q).substr(a.clipping, q.size() - a.clipping - a.end_clipping),

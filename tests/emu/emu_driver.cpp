@@ -58,8 +58,8 @@ static void trace_register_arena(const AlignParams &P, uint8_t *base, uint64_t s
         { w->seeds[0], "seeds" }, { w->alive[0], "alive" }, { w->alt, "alt" }, { w->cells, "cells" }, { w->cols, "cols" },
         { w->queue, "queue" }, { w->next_nodes, "next_nodes" }, { w->tips, "tips" }, { w->prev_starts, "prev_starts" },
         { w->indices, "bt_indices" }, { w->rev_ops, "rev" }, { w->gen_store, "gen_store" },
-        { w->ext[0].conv.tab, "conv_slots" }, { w->ext[0].conv.recs, "conv_recs" }, { w->ext[0].conv.pool, "conv_pool" },
-        { w->ext[1].conv.tab, "conv_slots" }, { w->ext[1].conv.recs, "conv_recs" }, { w->ext[1].conv.pool, "conv_pool" },
+        { w->ext[0].conv.tab, "conv_slots" }, { w->ext[0].conv.tab + conv_tab_slots(P.lim.hash_size), "conv_recs" }, { w->ext[0].conv.pool, "conv_pool" },
+        { w->ext[1].conv.tab, "conv_slots" }, { w->ext[1].conv.tab + conv_tab_slots(P.lim.hash_size), "conv_recs" }, { w->ext[1].conv.pool, "conv_pool" },
         { w->aln[0].nodes, "aln" },
     };
     std::sort(pts.begin(), pts.end(), [](const Pt &a, const Pt &b) { return a.p < b.p; });

@@ -299,15 +299,16 @@ def test_unsupported_and_bad_config_fail_loudly():
 
 
 def test_small_cell_budget_gives_capacity_statuses_not_wrong_answers():
-    """mgx_limits.cell_arena_bytes also sizes the pool of the convergence vectors: with a budget far too small, reads either
-    come out exactly as the oracle's or carry MGX_ERR_CAPACITY — never a truncated alignment — and the same reads succeed
-    under the default limits (what the adapter's retry relies on)."""
+    """mgx_limits.cell_arena_bytes sizes the S / F records of the general path and the pool of the convergence vectors: with a
+    budget far too small (round 3: chain columns no longer use either, so it takes a budget below one general-path column),
+    reads either come out exactly as the oracle's or carry MGX_ERR_CAPACITY — never a truncated alignment — and the same
+    reads succeed under the default limits (what the adapter's retry relies on)."""
     g, reads = make_world(4242, 21, genome_len=6000, n_reads=200, read_len=150)
     cfg = capi.config_cli(21)
     want = orc.AlignRun(g, cfg, reads).results()
     G = gpu_graph(g)
     lim = capi.Limits()
-    lim.cell_arena_bytes = 4096
+    lim.cell_arena_bytes = 1600
     got, status = aligner.Aligner(G, cfg, lim).align_batch(reads)
     assert any(s == capi.MGX_ERR_CAPACITY for s in status)
     for q, s in enumerate(status):
