@@ -305,8 +305,16 @@ struct XState {
     uint32_t alias_ok, cell_words;        // alias_ok: a node's first chain column enters the convergence table as an alias
     int32_t seed_n_nodes, sn_base, sc_base, pad4_;   // seed replay: first entry of the register-cached node / character run
 };
+// what the backtracking keeps between its steps (bt_begin / bt_step); overlays XState, which is dead by then
+struct BtState {
+    int32_t es, n_max, min_path_score, produced, best_score, remaining, first_bi, stage;
+    // the trace walk in progress
+    int32_t j, score, pos, end_pos, n_ops, n_path, n_seq, n_trace, dummy_counter, align_offset, extra_score;
+    uint32_t cur_run, last_path_node;
+};
 #else
 struct XState { int32_t unused_; };       // seeding-only translation units (k_seed) carry no extension state in LDS
+struct BtState { int32_t unused_; };
 #endif
 
 #ifdef MGX_SEED_PROBE
@@ -351,6 +359,7 @@ struct Wave {
             int32_t n_kmers;
         };
         XState x;
+        BtState bt;
     };
     // extension scratch
     int32_t *cells;
@@ -2208,21 +2217,26 @@ MGX_DEV int graph_children(Wave &w, const ExtenderState &E, const uint32_t node,
 }
 
 
-MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const SeedRef &seed, const ColMeta &col, bool force_fixed_seed,
+// (the seed's node list, spelling and offset come from the extension's loop state, where extend_begin() put them: the
+// extension can then be advanced step by step without its caller's SeedRef)
+MGX_DEV int call_outgoing(Wave &w, const ExtenderState &E, const ColMeta &col, bool force_fixed_seed,
                           uint32_t *nodes, uint8_t *chars, int32_t *scores) {
     const AlignParams &P = MGX_PARAMS_OF(w);
+    const XState &xs = w.x;
+    const uint32_t *seed_nodes = xs.seed_nodes;
+    const uint8_t *seed_seq = xs.seed_seq;
     const int32_t k = (int32_t)uni(P.g.k);
     const int32_t next_offset = col.offset + 1;
-    const int32_t seed_pos = next_offset - uni(seed.offset);
-    const bool in_seed = seed_pos >= 0 && seed_pos < uni(seed.seq_len);
+    const int32_t seed_pos = next_offset - uni(xs.seed_off);
+    const bool in_seed = seed_pos >= 0 && seed_pos < uni(xs.seed_seq_len);
     if (in_seed && next_offset < k) {
-        nodes[0] = seed.nodes[0]; chars[0] = seed.seq[seed_pos]; scores[0] = 0;
+        nodes[0] = seed_nodes[0]; chars[0] = seed_seq[seed_pos]; scores[0] = 0;
         return 1;
     }
     if (in_seed && force_fixed_seed) {
         int32_t node_i = next_offset - k + 1;
-        uint32_t next_node = seed.nodes[node_i];
-        nodes[0] = next_node; chars[0] = seed.seq[seed_pos];
+        uint32_t next_node = seed_nodes[node_i];
+        nodes[0] = next_node; chars[0] = seed_seq[seed_pos];
         scores[0] = next_node ? 0 : (!col.node ? P.cfg.gap_ext : P.cfg.gap_open);
         return 1;
     }
@@ -2327,7 +2341,7 @@ enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 3, FR_STOP = 4, FR_ERROR = 5 };
 
 // ---- general path: one popped column `i` with all its children (staging buffers, frontier arrays) ----
 // returns 0, or 1 = the extension is over (capacity error; w.status says which)
-MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const int32_t i, const bool children_ready) {
+MGX_DEV int general_step(Wave &w, ExtenderState &E, const int32_t i, const bool children_ready) {
     MGX_ASSUME_LDS(&w);
     MGX_ASSUME_LDS(&E);
     XState &x = w.x;
@@ -2376,7 +2390,7 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const SeedRef &seed, const i
     uint8_t *out_chars = w.out_chars;
     int32_t *out_scores = w.out_scores;
     if (!children_ready) x.n_valid = 0;                       // the children list is about to be overwritten
-    const int n_out = children_ready ? x.f_n_out : uni(call_outgoing(w, E, seed, col, force_fixed_seed, out_nodes, out_chars, out_scores));
+    const int n_out = children_ready ? x.f_n_out : uni(call_outgoing(w, E, col, force_fixed_seed, out_nodes, out_chars, out_scores));
     wave_sync();
     if (n_out == 0) {
         if (x.n_tips < max_columns) gst(w.tips + x.n_tips++, (uint32_t)i);
@@ -3040,11 +3054,25 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     return FR_END;
 }
 
-// One function for the whole loop: a call boundary makes the callee wait for every store it issued (s_waitcnt before
-// s_setpc), which would drain each column's record stores at the end of each step.
-// (es: which of the wave's two extenders — taken as an index so that the extender state is addressed off the control
-// block, i.e. provably in LDS, rather than through a second generic pointer)
-MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fixed_seed) {
+// The extension is cut into three pieces so that its steps can be driven from outside (the flat group loop of round 3, in
+// which every 8-lane group advances its own read) as well as by the loop of extend():
+//   extend_begin   set_seed + the root column; false = capacity (status set)
+//   extend_step    one pop / chain step / general step; XS_MORE, XS_DONE (results in Wave::er) or XS_ERROR
+// The chain window and the seed-replay run are registers of whoever drives the steps (ChainRegs).
+struct ChainRegs {
+    LV<int32_t> pS[4], pF[4];            // the chain window: S and F of the chain's current column, 4 cells per lane
+    SeedRun run;
+    int mode;
+};
+enum { XS_MORE = 0, XS_DONE = 1, XS_ERROR = 2 };
+
+MGX_DEV void chain_regs_reset(ChainRegs &R) {
+    FOR_LANES(l) { R.run.nodes[l] = 0; R.run.chars[l] = 0; }
+    FOR_LANES(l) { for (int s = 0; s < 4; ++s) { R.pS[s][l] = NINF; R.pF[s][l] = NINF; } }
+    R.mode = XM_POP;
+}
+
+MGX_DEV bool extend_begin(Wave &w, const int es, const SeedRef &seed, bool force_fixed_seed) {
     MGX_ASSUME_LDS(&w);
     ExtenderState &E = w.ext[es];
     ExtendResult *res = &w.er;
@@ -3123,7 +3151,7 @@ MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fix
             }
         }
         r.size = 1 + pushes;
-        if ((uint64_t)rec_words((uint32_t)r.size + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return; }
+        if ((uint64_t)rec_words((uint32_t)r.size + 8) > lim.cell_words) { w.status = ST_CAPACITY; res->table_size = 0; return false; }
         const uint32_t root_cap3 = 3 * ref_capacity(1, (uint32_t)pushes);
         wave_sync();
         const int32_t root_wc = flush_column(w, s0, 0, r.size, cfg.gap_ext, nullptr, 0, 0, 0, 0, 0, E.q);
@@ -3140,20 +3168,33 @@ MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fix
     x.best_score = 0;
     x.qn = 0; x.nn = 0; x.n_tips = 0;
     frontier_push(w, queue_key(0, 0, 0));
+    return true;
+}
+
+MGX_DEV int extend_step(Wave &w, const int es, ChainRegs &R) {
+    MGX_ASSUME_LDS(&w);
+    ExtenderState &E = w.ext[es];
+    ExtendResult *res = &w.er;
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    XState &x = w.x;
     // the chain format keeps S as 16-bit offsets from the column maximum: cells live within x-drop (+ one match score) of
     // it, so any x-drop up to 30000 fits; wider (the unit tests' "no x-drop") takes the general path
-    const bool use_fast = !P.no_fast && cfg.xdrop <= 30000;
-    int mode = XM_POP;
-    LV<int32_t> pS[4], pF[4];            // the chain window: S and F of the chain's current column, 4 cells per lane
-    SeedRun run;
-    FOR_LANES(l) { run.nodes[l] = 0; run.chars[l] = 0; }
-    FOR_LANES(l) { for (int s = 0; s < 4; ++s) { pS[s][l] = NINF; pF[s][l] = NINF; } }
-    for (;;) {
+    const bool use_fast = !P.no_fast && P.cfg.xdrop <= 30000;
+    int &mode = R.mode;
+    LV<int32_t> *pS = R.pS, *pF = R.pF;
+    SeedRun &run = R.run;
+    {
         int32_t gi = -1;                 // column for the general step of this iteration
         bool children_ready = false;
         if (mode == XM_POP) {
             if (x.nn == 0) {
-                if (x.qn == 0) break;
+                if (x.qn == 0) {
+                    wave_sync();
+                    res->n_tips = x.n_tips;
+                    res->min_cell_score = x.min_cell_score;
+                    res->table_size = x.tsize;
+                    return XS_DONE;
+                }
                 uint64_t tx0 = xclock();
                 // pop every entry that shares the top score, in descending tuple order (:491-500)
                 int32_t qn = x.qn, nn = 0;
@@ -3181,11 +3222,11 @@ MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fix
         }
         if (mode == XM_FAST) {
             const int r = chain_step(w, E, pS, pF, run);
-            if (r == FR_CONT) continue;
+            if (r == FR_CONT) return XS_MORE;
             mode = XM_POP;
-            if (r == FR_END) continue;
-            if (r == FR_STOP) { x.qn = 0; x.nn = 0; continue; }
-            if (r == FR_ERROR) { res->table_size = 0; return; }
+            if (r == FR_END) return XS_MORE;
+            if (r == FR_STOP) { x.qn = 0; x.nn = 0; return XS_MORE; }
+            if (r == FR_ERROR) { res->table_size = 0; return XS_ERROR; }
             // FR_FALLBACK: the parent goes through the general code (children already enumerated)
             fast_spill(w, pS, pF);
             gi = x.f_idx;
@@ -3193,17 +3234,25 @@ MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fix
         }
         if (gi >= 0) {
             const uint64_t tg = xclock();
-            const int bad = general_step(w, E, seed, gi, children_ready);
+            const int bad = general_step(w, E, gi, children_ready);
 #ifndef MGX_CHAIN_PROBE
             w.xcyc[1] += xclock() - tg;
 #endif
-            if (bad) { res->table_size = 0; return; }
+            if (bad) { res->table_size = 0; return XS_ERROR; }
         }
     }
-    wave_sync();
-    res->n_tips = x.n_tips;
-    res->min_cell_score = x.min_cell_score;
-    res->table_size = x.tsize;
+    return XS_MORE;
+}
+
+// One function for the whole loop: a call boundary makes the callee wait for every store it issued (s_waitcnt before
+// s_setpc), which would drain each column's record stores at the end of each step.
+// (es: which of the wave's two extenders — taken as an index so that the extender state is addressed off the control
+// block, i.e. provably in LDS, rather than through a second generic pointer)
+MGX_NI_G3 void extend(Wave &w, const int es, const SeedRef &seed, bool force_fixed_seed) {
+    if (!extend_begin(w, es, seed, force_fixed_seed)) return;
+    ChainRegs R;
+    chain_regs_reset(R);
+    while (extend_step(w, es, R) == XS_MORE) {}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3231,14 +3280,19 @@ MGX_DEV void seed_as_alignment(Wave &w, const SeedRef &seed, DevAln &out);
 
 MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src);
 
+// Backtracking in resumable pieces (round 3): bt_begin() collects the start cells, bt_step() advances the pop / walk /
+// construct cycle by a bounded number of walk steps and says when it is over.  backtrack() drives them to the end (the
+// per-read program of the legacy path); the flat group loop calls bt_step() once per iteration, so that a group whose
+// extension ended walks its trace while its wave-mates are still extending.  State between steps: BtState (LDS, overlaid
+// with the extension's loop state, which is dead by then; the extension's results are in Wave::er).
+enum { BT_POP = 0, BT_WALK = 1, BT_FINISH = 2, BT_OVER = 3 };
+
 // seed_aln: the Alignment the seed was made from (backward pass) or nullptr for Seed-derived seeds
-// Writes up to n_max alignments (num_alternative_paths, :1005 terminate_backtrack_start) into outs[0 .. ); returns how many.
-MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln *seed_aln,
-                      const ExtendResult &er, int32_t min_path_score, DevAln *outs, int n_max) {
+MGX_DEV void bt_begin(Wave &w, const int es, const SeedRef &seed, int32_t min_path_score, int n_max) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = MGX_PARAMS_OF(w);
-    // the extender's query: read with LDS or global instructions, never generic ones (a FLAT load waits for every store
-    // in flight, and the walk below stores three values per step)
+    const ExtendResult er = w.er;
+    BtState &b = w.bt;
     const uint8_t *bq = w.ext[es].q;
     const bool bq_lds = w.q_lds != 0;
     auto op_at = [&](uint8_t c, int32_t abs_pos) -> uint8_t {      // profile_op_at
@@ -3251,14 +3305,11 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
     const int32_t k = (int32_t)P.g.k;
     const int32_t seed_clipping = seed.clipping;
     const int32_t seed_offset = seed.offset - 1;
-    const int32_t k_minus_1 = k - 1;
     const int32_t window_size = w.L - seed.clipping;
     const int32_t last_pos = window_size;
     const int32_t seed_dist = imax(k, seed.seq_len) - 1;
     const int32_t min_start_score = min_path_score;
-    const int32_t min_trace_length = k - seed.offset;
     const int32_t right_end_bonus = cfg.right_end_bonus;
-    const int32_t cap = (int32_t)P.lim.max_path;
     const int32_t tsize = er.table_size;
 #ifdef MGX_BT_PROBE
     uint64_t tbt = xclock();
@@ -3268,18 +3319,17 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
 #endif
     // candidate start cells (:815-867), one table column per lane; the order of `indices` is irrelevant
     // because the heap pops by the full (unique) tuple
-    // tips as a bitset (prev_starts is cleared per extension and only used from here on; use a second region)
     int32_t n_idx = 0;
     // every lane also keeps the lexicographic maximum (score, -off_diag, -i, pos) of the candidates it wrote and where it
     // wrote it: the first pop of the heap — usually the only one — then needs no pass over the list in memory
     LV<BtIndex> lbest;
     LV<int32_t> lbest_at;
     FOR_LANES(l) { lbest[l] = BtIndex{ INT32_MIN, INT32_MIN, INT32_MIN, INT32_MIN }; lbest_at[l] = -1; }
-    auto bt_greater = [](const BtIndex &a, const BtIndex &b) {
-        if (a.score != b.score) return a.score > b.score;
-        if (a.neg_off_diag != b.neg_off_diag) return a.neg_off_diag > b.neg_off_diag;
-        if (a.neg_i != b.neg_i) return a.neg_i > b.neg_i;
-        return a.pos > b.pos;
+    auto bt_greater = [](const BtIndex &a, const BtIndex &c) {
+        if (a.score != c.score) return a.score > c.score;
+        if (a.neg_off_diag != c.neg_off_diag) return a.neg_off_diag > c.neg_off_diag;
+        if (a.neg_i != c.neg_i) return a.neg_i > c.neg_i;
+        return a.pos > c.pos;
     };
     for (int32_t base = 1; base < tsize; base += WAVE) {
         LV<int32_t> cnt;
@@ -3357,60 +3407,102 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
     }
     wave_sync();
     BT_T(3)
-    int produced = 0;
-    int32_t best_score = INT32_MIN;
-    int32_t remaining = n_idx;
-    while (remaining > 0 && produced < n_max) {        // terminate_backtrack_start: extensions.size() >= num_alternative_paths
-        // pop the lexicographic maximum (score, -off_diag, -i, pos) (:873-879): four lane-parallel passes
-        int32_t bi = 0;
-        if (first_bi >= 0) {
-            bi = first_bi;
-            first_bi = -1;
+    b.es = es; b.n_max = n_max; b.min_path_score = min_path_score;
+    b.produced = 0; b.best_score = INT32_MIN; b.remaining = n_idx; b.first_bi = first_bi;
+    b.stage = BT_POP;
+}
+
+// Advances the backtracking by at most `max_walk` steps of a trace walk; true when it is over (b.produced alignments in
+// outs[0 ..); up to n_max = num_alternative_paths, :1005 terminate_backtrack_start).
+MGX_DEV bool bt_step(Wave &w, const SeedRef &seed, const DevAln *seed_aln, DevAln *outs, int32_t max_walk) {
+    MGX_ASSUME_LDS(&w);
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    const ExtendResult er = w.er;
+    BtState &b = w.bt;
+    const int es = b.es;
+    // the extender's query: read with LDS or global instructions, never generic ones (a FLAT load waits for every store
+    // in flight, and the walk below stores three values per step)
+    const uint8_t *bq = w.ext[es].q;
+    const bool bq_lds = w.q_lds != 0;
+    auto op_at = [&](uint8_t c, int32_t abs_pos) -> uint8_t {      // profile_op_at
+        if (abs_pos < 1 || abs_pos > w.L) return OP_CLIPPED;
+        const uint32_t code = encode_char(c);
+        const uint8_t row = code != 5 ? decode_code(code) : 0;
+        return char_to_op(row, bq_lds ? lds_u8(bq + abs_pos - 1) : gld(bq + abs_pos - 1));
+    };
+    const DevConfig &cfg = P.cfg;
+    const int32_t k = (int32_t)P.g.k;
+    const int32_t seed_clipping = seed.clipping;
+    const int32_t k_minus_1 = k - 1;
+    const int32_t min_start_score = b.min_path_score;
+    const int32_t min_trace_length = k - seed.offset;
+    const int32_t cap = (int32_t)P.lim.max_path;
+#ifdef MGX_BT_PROBE
+    uint64_t tbt = xclock();
+#endif
+    if (b.stage == BT_POP) {
+        if (!(b.remaining > 0 && b.produced < b.n_max)) {        // terminate_backtrack_start: extensions.size() >= num_alternative_paths
+            b.stage = BT_FINISH;
         } else {
-            int32_t m_score = INT32_MIN, m_off = INT32_MIN, m_i = INT32_MIN, m_pos = INT32_MIN;
-            for (int pass = 0; pass < 4; ++pass) {
-                int32_t best = INT32_MIN;
+            // pop the lexicographic maximum (score, -off_diag, -i, pos) (:873-879): four lane-parallel passes
+            const int32_t remaining = b.remaining;
+            int32_t bi = 0;
+            if (b.first_bi >= 0) {
+                bi = b.first_bi;
+                b.first_bi = -1;
+            } else {
+                int32_t m_score = INT32_MIN, m_off = INT32_MIN, m_i = INT32_MIN, m_pos = INT32_MIN;
+                for (int pass = 0; pass < 4; ++pass) {
+                    int32_t best = INT32_MIN;
+                    for (int32_t base = 0; base < remaining; base += WAVE) {
+                        LV<int32_t> v;
+                        FOR_LANES(l) {
+                            int32_t x = base + l;
+                            int32_t val = INT32_MIN;
+                            if (x < remaining) {
+                                BtIndex a = w.indices[x];
+                                bool ok = (pass < 1 || a.score == m_score) && (pass < 2 || a.neg_off_diag == m_off) && (pass < 3 || a.neg_i == m_i);
+                                if (ok) val = pass == 0 ? a.score : pass == 1 ? a.neg_off_diag : pass == 2 ? a.neg_i : a.pos;
+                            }
+                            v[l] = val;
+                        }
+                        best = imax(best, wave_max(v));
+                    }
+                    if (pass == 0) m_score = best; else if (pass == 1) m_off = best; else if (pass == 2) m_i = best; else m_pos = best;
+                }
                 for (int32_t base = 0; base < remaining; base += WAVE) {
-                    LV<int32_t> v;
+                    LV<bool> hit;
                     FOR_LANES(l) {
                         int32_t x = base + l;
-                        int32_t val = INT32_MIN;
+                        bool h = false;
                         if (x < remaining) {
                             BtIndex a = w.indices[x];
-                            bool ok = (pass < 1 || a.score == m_score) && (pass < 2 || a.neg_off_diag == m_off) && (pass < 3 || a.neg_i == m_i);
-                            if (ok) val = pass == 0 ? a.score : pass == 1 ? a.neg_off_diag : pass == 2 ? a.neg_i : a.pos;
+                            h = a.score == m_score && a.neg_off_diag == m_off && a.neg_i == m_i && a.pos == m_pos;
                         }
-                        v[l] = val;
+                        hit[l] = h;
                     }
-                    best = imax(best, wave_max(v));
+                    uint64_t mk = wave_ballot(hit);
+                    if (mk) { bi = base + ctz64(mk); break; }
                 }
-                if (pass == 0) m_score = best; else if (pass == 1) m_off = best; else if (pass == 2) m_i = best; else m_pos = best;
             }
-            for (int32_t base = 0; base < remaining; base += WAVE) {
-                LV<bool> hit;
-                FOR_LANES(l) {
-                    int32_t x = base + l;
-                    bool h = false;
-                    if (x < remaining) {
-                        BtIndex a = w.indices[x];
-                        h = a.score == m_score && a.neg_off_diag == m_off && a.neg_i == m_i && a.pos == m_pos;
-                    }
-                    hit[l] = h;
-                }
-                uint64_t mk = wave_ballot(hit);
-                if (mk) { bi = base + ctz64(mk); break; }
+            BtIndex cur = w.indices[bi];
+            w.indices[bi] = w.indices[remaining - 1];
+            b.remaining = remaining - 1;
+            const int32_t j = -cur.neg_i;
+            if (!prev_start_test_and_set(w, j)) return false;       // skip_backtrack_start (next pop on the next step)
+            if (cur.score - er.min_cell_score < b.best_score) { b.stage = BT_FINISH; }
+            else {
+                b.j = j; b.score = cur.score; b.pos = cur.pos; b.end_pos = cur.pos;
+                b.n_ops = 0; b.n_path = 0; b.n_seq = 0; b.n_trace = 0; b.cur_run = 0; b.dummy_counter = 0;
+                b.align_offset = seed.offset; b.extra_score = 0; b.last_path_node = 0;
+                b.stage = BT_WALK;
             }
         }
-        BtIndex cur = w.indices[bi];
-        w.indices[bi] = w.indices[remaining - 1];
-        --remaining;
-        int32_t j = -cur.neg_i;
-        if (!prev_start_test_and_set(w, j)) continue;       // skip_backtrack_start
-        int32_t score = cur.score;
-        if (score - er.min_cell_score < best_score) break;
-
-        int32_t n_ops = 0, n_path = 0, n_seq = 0, n_trace = 0;
-        uint32_t cur_run = 0;                          // rev_ops[n_ops - 1], kept in a register: appending never reads memory
+    }
+    if (b.stage == BT_WALK) {
+        int32_t score = b.score;
+        int32_t n_ops = b.n_ops, n_path = b.n_path, n_seq = b.n_seq, n_trace = b.n_trace;
+        uint32_t cur_run = b.cur_run;                  // rev_ops[n_ops - 1], kept in a register: appending never reads memory
         auto push_op = [&](uint32_t op, uint32_t num) {
             if (!num) return;
             if (n_ops == 0 || (cur_run & 7) != op) {
@@ -3422,12 +3514,13 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
                 gst(w.rev_ops + n_ops - 1, cur_run);
             }
         };
-        int32_t dummy_counter = 0;
-        int32_t pos = cur.pos;
-        const int32_t end_pos = pos;
-        int32_t align_offset = seed.offset;
-        int32_t extra_score = 0;
-        uint32_t last_path_node = 0;
+        int32_t dummy_counter = b.dummy_counter;
+        int32_t pos = b.pos;
+        const int32_t end_pos = b.end_pos;
+        int32_t align_offset = b.align_offset;
+        int32_t extra_score = b.extra_score;
+        uint32_t last_path_node = b.last_path_node;
+        int32_t j = b.j;
         auto append_node = [&](uint32_t node, uint8_t c, int32_t offset, uint32_t op) {
             if (n_seq >= cap) { w.status = ST_CAPACITY; return; }
             gst(w.rev_seq + n_seq++, c);
@@ -3445,8 +3538,6 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
                 }
             }
         };
-        // The column chain is walked parent by parent.  Metadata is fetched one step ahead (the grandparent's with
-        // this step's cell loads), so that every step costs one arena round trip instead of three dependent ones.
         // The column chain is walked parent by parent; each step reads ONE thing: the flag byte of the current cell (all
         // of backtrack's comparisons were evaluated when the column was computed).  The parent's metadata is fetched one
         // step ahead.
@@ -3466,9 +3557,14 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
             if (ps_idx >= 0 && ps_bits) gst(w.prev_starts + ps_idx, gld(w.prev_starts + ps_idx) | ps_bits);
             ps_bits = 0;
         };
+        // (col, par) = (column j, its parent) at the top of every step
         ColMeta col = col_load(w, j), par = col;
         if (j) par = col_load(w, col.parent);
-        while (j) {
+        bool walk_over = false;
+        int32_t steps = 0;
+        for (;;) {
+            if (!j) { walk_over = true; break; }
+            if (steps++ >= max_walk) break;
             ColMeta gp = par;
             if (col.parent > 0) {                                      // par is not the root
                 const int32_t t = par.parent;
@@ -3496,7 +3592,7 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
                     push_op(lop, 1);
                     lop = (cell_flags(w, col, pos) & CF_E_EXT) ? OP_INSERTION : OP_MATCH;
                     --pos;
-                    if (w.status != ST_OK) return 0;
+                    if (w.status != ST_OK) return true;
                 }
             } else if (pos && (fl & CF_MATCH)) {
                 ++n_trace;
@@ -3515,29 +3611,41 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
                     extra_score += c2.score;
                     append_node(c2.node, col_char(c2), c2.offset, OP_DELETION);
                     j = c2.parent;
-                    if (w.status != ST_OK) return 0;
+                    if (w.status != ST_OK) return true;
                 }
                 if (j) { col = col_load(w, j); par = col_load(w, col.parent); }
             } else {
+                walk_over = true;
                 break;
             }
-            if (w.status != ST_OK) return 0;
+            if (w.status != ST_OK) return true;
         }
         ps_flush();
-        BT_T(4)
 #if !MGX_WAVE_EMU
         asm volatile("" : : "v"(pf_val.v));
 #endif
+        if (!walk_over) {
+            // out of steps for this call: park the walk
+            b.j = j; b.pos = pos; b.n_ops = n_ops; b.n_path = n_path; b.n_seq = n_seq; b.n_trace = n_trace; b.cur_run = cur_run;
+            b.dummy_counter = dummy_counter; b.align_offset = align_offset; b.extra_score = extra_score; b.last_path_node = last_path_node;
+            wave_sync();
+            return false;
+        }
+#ifdef MGX_BT_PROBE
+        BT_T(4)
+#endif
+        b.stage = BT_POP;
         if (n_trace >= min_trace_length && n_path && last_path_node) {
             const ColMeta cj = col_load(w, j);
             int32_t cur_cell_score = cell_S(w, cj, pos);
-            best_score = imax(best_score, score - cur_cell_score);
-            if (score - er.min_cell_score < best_score) break;
-            if (score >= min_start_score && (!pos || cur_cell_score == 0)
+            b.best_score = imax(b.best_score, score - cur_cell_score);
+            if (score - er.min_cell_score < b.best_score) {
+                b.stage = BT_FINISH;
+            } else if (score >= min_start_score && (!pos || cur_cell_score == 0)
                     && (pos || cur_cell_score == gld(w.cells + col_load(w, 0).cells))
                     && (cfg.allow_left_trim || !j)) {
                 // construct_alignment (:774-798): clipping = pos, window = [pos, end_pos)
-                DevAln &out = outs[produced];
+                DevAln &out = outs[b.produced];
                 int32_t nc = 0;
                 uint32_t clip_total = (uint32_t)(seed_clipping + pos);      // cigar clip + extend_query_begin
                 if (clip_total) out.cigar[nc++] = (clip_total << 3) | OP_CLIPPED;
@@ -3545,12 +3653,12 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
                 for (int32_t x = n_ops - 1; x >= 0; --x) {
                     uint32_t op = w.rev_ops[x];
                     if (nc && (out.cigar[nc - 1] & 7) == (op & 7)) out.cigar[nc - 1] += (op >> 3) << 3;
-                    else { if (nc >= cap) { w.status = ST_CAPACITY; return 0; } out.cigar[nc++] = op; }
+                    else { if (nc >= cap) { w.status = ST_CAPACITY; return true; } out.cigar[nc++] = op; }
                 }
                 uint32_t end_clip = (uint32_t)(w.L - (seed_clipping + end_pos));   // extend_query_end
                 if (end_clip) {
                     if (nc && (out.cigar[nc - 1] & 7) == OP_CLIPPED) out.cigar[nc - 1] += end_clip << 3;
-                    else { if (nc >= cap) { w.status = ST_CAPACITY; return 0; } out.cigar[nc++] = (end_clip << 3) | OP_CLIPPED; }
+                    else { if (nc >= cap) { w.status = ST_CAPACITY; return true; } out.cigar[nc++] = (end_clip << 3) | OP_CLIPPED; }
                 }
                 wave_sync();
                 for (int32_t base = 0; base < imax(n_path, n_seq); base += WAVE) {
@@ -3565,33 +3673,50 @@ MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln
                 out.qbegin = seed_clipping + pos; out.qlen = end_pos - pos;
                 out.orientation = seed.orientation; out.extra_score = extra_score;
                 wave_sync();
-                ++produced;
+                ++b.produced;
             }
         }
+        if (b.stage == BT_POP) return false;           // next pop on the next step
     }
-    BT_T(5)
-    if (!produced && seed.score >= min_path_score) {       // extensions.emplace_back(*seed_) (:1030-1031)
-        if (seed_aln) copy_aln(outs[0], *seed_aln);
-        else seed_as_alignment(w, seed, outs[0]);
-        produced = 1;
-    }
-    for (int e = 0; e < produced; ++e) {
-        // extension.trim_offset() (alignment.cpp:177-190)
-        DevAln &out = outs[e];
-        if (out.offset && out.n_nodes > 1) {
-            int32_t first_dummy = out.n_nodes;      // no npos nodes can occur on this path
-            for (int32_t x = 0; x < out.n_nodes; ++x) if (!out.nodes[x]) { first_dummy = x; break; }
-            int32_t trim = imin(imin(out.offset, out.n_nodes - 1), first_dummy - 1);
-            if (trim > 0) {
-                // erase the first `trim` nodes (wave-uniform in-place shift)
-                for (int32_t x = 0; x + trim < out.n_nodes; ++x) out.nodes[x] = out.nodes[x + trim];
-                out.n_nodes -= trim;
-                out.offset -= trim;
-            }
+    if (b.stage == BT_FINISH) {
+#ifdef MGX_BT_PROBE
+        BT_T(5)
+#endif
+        int produced = b.produced;
+        if (!produced && seed.score >= b.min_path_score) {       // extensions.emplace_back(*seed_) (:1030-1031)
+            if (seed_aln) copy_aln(outs[0], *seed_aln);
+            else seed_as_alignment(w, seed, outs[0]);
+            produced = 1;
         }
-        wave_sync();
+        for (int e = 0; e < produced; ++e) {
+            // extension.trim_offset() (alignment.cpp:177-190)
+            DevAln &out = outs[e];
+            if (out.offset && out.n_nodes > 1) {
+                int32_t first_dummy = out.n_nodes;      // no npos nodes can occur on this path
+                for (int32_t x = 0; x < out.n_nodes; ++x) if (!out.nodes[x]) { first_dummy = x; break; }
+                int32_t trim = imin(imin(out.offset, out.n_nodes - 1), first_dummy - 1);
+                if (trim > 0) {
+                    // erase the first `trim` nodes (wave-uniform in-place shift)
+                    for (int32_t x = 0; x + trim < out.n_nodes; ++x) out.nodes[x] = out.nodes[x + trim];
+                    out.n_nodes -= trim;
+                    out.offset -= trim;
+                }
+            }
+            wave_sync();
+        }
+        b.produced = produced;
+        b.stage = BT_OVER;
     }
-    return produced;
+    return b.stage == BT_OVER;
+}
+
+// Writes up to n_max alignments into outs[0 .. ); returns how many (0 with w.status set on a capacity error).
+MGX_NI_G4 int backtrack(Wave &w, const int es, const SeedRef &seed, const DevAln *seed_aln,
+                      const ExtendResult &er, int32_t min_path_score, DevAln *outs, int n_max) {
+    (void)er;                                           // == w.er, where extend() left it
+    bt_begin(w, es, seed, min_path_score, n_max);
+    while (!bt_step(w, seed, seed_aln, outs, INT32_MAX)) {}
+    return w.status == ST_OK ? w.bt.produced : 0;
 }
 
 // Alignment(const Seed&, config) or a copy of an Alignment used as seed
