@@ -70,6 +70,10 @@ constexpr bool kWithPrimary = MGX_WITH_PRIMARY != 0;
 
 #if defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS
 __shared__ AlignParams g_params;
+__shared__ int8_t g_sm_rows[6 * 128];      // score-matrix rows of the 6 possible path characters ($ACGT\0) x 128
+#define MGX_SM_ROWS(w) (::mgx::g_sm_rows)
+#else
+#define MGX_SM_ROWS(w) ((w).sm_rows)
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -326,8 +330,20 @@ constexpr int XCYC_N = 8;                     // probe build: xcyc[] = the secti
 constexpr int XCYC_N = 4;
 #endif
 #endif
+// the flat group loop's per-read state (see flat_drive): what the group is doing, where the read's driver stands
+struct FlatState {
+    uint8_t act, ds, ph, s;      // activity (ACT_*), driver state (DS_*), strand phase (0 / 1), strand of the current aln_both
+    uint8_t filt, pad_[3];       // a reversed backward alignment awaits its lazy filter_nodes (aln[2])
+    int32_t i;                   // seed index
+    uint64_t read;               // the group's current read
+};
+
 struct Wave {
-    const AlignParams *P;
+#if !(defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS)
+    const AlignParams *P;        // (the sub-wave-group kernel keeps the parameter block and the score rows as workgroup-wide
+                                 // __shared__ objects: 16 bytes less per control block, which is what keeps both query
+                                 // strands of a 150-bp read in LDS at 3 waves per SIMD)
+#endif
     int32_t L;                   // query length
     int32_t q_lds;               // the strands q[0], q[1] live in LDS (carve)
     uint8_t *q[2];
@@ -375,11 +391,14 @@ struct Wave {
     BtIndex *indices;
     uint32_t *rev_ops, *rev_nodes;
     uint8_t *rev_seq;
+#if !(defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS)
     const int8_t *sm_rows;       // score-matrix rows of the 6 possible path characters ($ACGT\\0) x 128, in LDS
+#endif
     uint32_t *gen_store;         // conv-checker generation counters, persistent per arena slice
     ExtenderState ext[2];
     DevAln aln[N_ALN];           // [0, A): extension results, [A, 2A): reversed seeds of the backward pass, [2A, 3A): backward
                                  // extension results, [3A, 4A): the aggregator's queue (A = num_alternative_paths <= MAX_ALT)
+    FlatState fs;
     int32_t have_best;           // alignments in the aggregator's queue
     int32_t seeds_done;          // seeds whose extension ran for this read in this pass (multi-pass extension)
     int32_t resume_phase, resume_i, no_limit;   // where this pass (re)starts: strand call 0 / 1, seed index; limit lifted
@@ -594,7 +613,7 @@ MGX_DEV void load_score_rows(const AlignParams &P, int8_t *dst) {
 // the query character one before absolute window position; 0 in the first cell and the padding
 MGX_DEV int32_t profile_at(const Wave &w, const uint8_t *q, int32_t L, uint8_t c, int32_t abs_pos) {
     if (abs_pos < 1 || abs_pos > L) return 0;
-    return w.sm_rows[encode_char(c) * 128 + (q[abs_pos - 1] & 127)];      // row 5 = score_matrix['\0']
+    return MGX_SM_ROWS(w)[encode_char(c) * 128 + (q[abs_pos - 1] & 127)];      // row 5 = score_matrix['\0']
 }
 
 MGX_DEV uint8_t profile_op_at(const uint8_t *q, int32_t L, uint8_t c, int32_t abs_pos) {
@@ -2049,8 +2068,8 @@ MGX_NI_G5 int32_t compute_column(Wave &w, const ExtenderState &E, int32_t prev_s
 #define CF_SET(j, v) tset(cF, cap, (j), (v))
     const int32_t trim = begin;
     const int32_t max_size = window_size + 1 - trim;
-    MGX_ASSUME_LDS(w.sm_rows);                               // the score rows are a __shared__ array of the kernel
-    const int8_t *row = w.sm_rows + encode_char(c) * 128;    // profile_score_[encode(c)] (:38-59)
+    MGX_ASSUME_LDS(MGX_SM_ROWS(w));                          // the score rows are a __shared__ array of the kernel
+    const int8_t *row = MGX_SM_ROWS(w) + encode_char(c) * 128;    // profile_score_[encode(c)] (:38-59)
     const uint8_t *qq = (const uint8_t *)uni((uint64_t)E.q);
     // DPTColumn::create: size + 5 cells of ninf (we initialise everything update_column may touch)
     const int32_t init_n = imin(max_size, size) + 8;
@@ -2628,7 +2647,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     }
     CH_T(1)
     // update_column (:209-290): cell j = a - begin; j in [0, n_loop) is computed in blocks of four lanes
-    const int8_t *row = w.sm_rows + encode_char(c) * 128;      // a __shared__ array of the kernel
+    const int8_t *row = MGX_SM_ROWS(w) + encode_char(c) * 128; // a __shared__ array of the kernel
     const uint8_t *qq = E.q;
     const bool q_lds = w.q_lds != 0;
     const LV<int32_t> Sm1_0 = wave_shift_up1(pS[3], p_below);     // parent at a - 1 for slot 0
@@ -4220,8 +4239,12 @@ template <int PHASE = PH_BOTH>
 MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t slot, KernelStats *stats_accum,
                         SdustScratch *sd, const int8_t *sm_rows, uint8_t *lds, uint32_t lds_bytes,
                         const uint8_t *resume_rec = nullptr) {
+#if !(defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS)
     w.P = &P;
     w.sm_rows = sm_rows;
+#else
+    (void)sm_rows;
+#endif
     carve(w, P, P.arena + (uint64_t)slot * P.arena_stride, lds, lds_bytes);
     w.sd = sd ? sd : w.sd_own;
     const uint64_t off = P.offsets[read];
@@ -4535,5 +4558,492 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     for (int x = 0; x < 8; ++x) stats_accum->cyc[x] += w.cyc[x];
     for (int x = 0; x < XCYC_N; ++x) stats_accum->xcyc[x] += w.xcyc[x];
 }
+
+
+#ifndef MGX_NO_EXTEND
+// ------------------------------------------------------------------------------------------------
+// The flat group loop (round 3): every 8-lane group of a wavefront advances its OWN read.
+//
+// In the per-read program above, control flow is shared by the groups of a wavefront down to the loop level: a group whose
+// extension ends waits at the loop exit until the longest extension among its wave-mates ends, again after the trace
+// walk, again before the next read is fetched — a quarter of the extension kernel's time on the bench batch
+// (profiles/r03_ab1.txt: 315 ms for distinct reads, 230 ms with every read replicated 8 x), most of it on seed-rich
+// reads.  Here the read's program is a state machine and the wavefront runs ONE loop whose iteration gives every group
+// one step of whatever it is doing: a step of its extension (extend_step), up to FLAT_BT_STEPS steps of its trace walk
+// (bt_step), or a driver transition (flat_drive: everything between those — seed pick, strand flip, aggregator, filters —
+// run to the next extension or backtrack), or the fetch of its next read.  Groups in different activities are serialised
+// by EXEC masking within the iteration only; nobody waits for a wave-mate's loop to end.
+//
+// The driver restates aln_both / align_core_fwd / align_read's extension half for one alignment per seed
+// (num_alternative_paths == 1; the alternative-path build keeps the per-read program for N > 1), with the same calls in
+// the same order per read: results are identical by construction, and the host model runs both.
+// ------------------------------------------------------------------------------------------------
+enum { ACT_FETCH = 0, ACT_DRIVE = 1, ACT_EXTEND = 2, ACT_BT = 3, ACT_FINISH = 4, ACT_EXIT = 5 };
+enum { DS_PHASE = 0, DS_SEED = 1, DS_FWD_EXT = 2, DS_FWD_BT = 3, DS_BWD_EXT = 4, DS_BWD_BT = 5, DS_SEED_DONE = 6, DS_END = 7 };
+constexpr int32_t FLAT_BT_STEPS = 12;       // trace-walk steps per iteration (about the instructions of one chain step)
+
+MGX_DEV int flat_es(const Wave &w) { return w.fs.ds == DS_BWD_EXT || w.fs.ds == DS_BWD_BT ? 1 - (int)w.fs.s : (int)w.fs.s; }
+
+// what the read's current backtrack works on: forward = the seed itself, into aln[0]; backward = the reversed forward
+// alignment aln[1], into aln[2]
+MGX_DEV SeedRef flat_bt_seed(const Wave &w) {
+    if (w.fs.ds == DS_FWD_BT) return seedref_from_seed(w, (int)w.fs.s, w.fs.i, nullptr);
+    return seedref_from_aln(w.aln[1]);
+}
+
+// later seeds of the strand against the forward extender's convergence table / the deferred filter_nodes marks (aln_both)
+MGX_DEV void flat_check_later(Wave &w, bool with_table, bool with_filter) {
+    const int s = (int)w.fs.s;
+    const int32_t n = w.n_seeds[s], i = w.fs.i;
+    ExtenderState &F = w.ext[s];
+    const DevAln &p2 = w.aln[2];
+    const uint32_t *filt_nodes = p2.nodes;
+    const int32_t filt_n = with_filter ? p2.n_nodes : 0;
+    const int32_t filt_lo = aln_clipping(p2), filt_hi = w.L - aln_end_clipping(p2);
+    for (int32_t base = i + 1; base < n; base += WAVE) {
+        FOR_LANES(l) {
+            const int32_t j = base + l;
+            if (j < n && w.alive[s][j]) {
+                DevSeed sj = w.seeds[s][j];
+                uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
+                SeedRef rj = seedref_from_seed(w, s, j, nullptr);
+                bool dead = with_table && !check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score);
+                const int32_t pos = rj.qlen + rj.clipping - 1;
+                if (with_filter && !dead && filt_n && pos >= filt_lo && pos < filt_hi) {
+                    for (int32_t x = 0; x < filt_n; ++x) dead |= gld(filt_nodes + x) == last_node;
+                }
+                if (dead) w.alive[s][j] = 0;
+            }
+        }
+    }
+    wave_sync();
+}
+
+// Driver transitions until the read needs an extension (-> ACT_EXTEND, begun), a backtrack (-> ACT_BT, begun) or is over
+// (-> ACT_FINISH).  aln_both (:657-736) / align_core (:360-384) / align_both_directions (:738-755), N = 1.
+MGX_DEV void flat_drive(Wave &w) {
+    MGX_ASSUME_LDS(&w);
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    FlatState &f = w.fs;
+    const bool canon = P.cfg.canonical != 0;
+    const bool have_rc = P.cfg.fwd_and_rc != 0;
+    for (;;) {
+        int want = 0;                       // 1: begin an extension, 2: begin a backtrack
+        int es = 0;
+        bool force = false;
+        int32_t mps = 0;
+        SeedRef seed;
+        seed.nodes = nullptr; seed.seq = nullptr; seed.n_nodes = seed.seq_len = 0;
+        seed.clipping = seed.end_clipping = seed.qlen = seed.offset = seed.score = seed.orientation = 0;
+        const int s = (int)f.s;
+        if (f.ds == DS_PHASE) {
+            // align_both_directions: the strand with more matches first, the other if it is within rel_score_cutoff
+            const uint32_t fm = w.num_matching[0], bm = w.num_matching[1];
+            const int first = fm >= bm ? 0 : 1;
+            const uint32_t m_first = first ? bm : fm, m_second = first ? fm : bm;
+            const int ph = (int)f.ph;
+            if (w.status != ST_OK || ph >= (have_rc ? 2 : 1)
+                    || (have_rc && ph == 1 && !((double)m_second >= (double)m_first * P.cfg.rel_score_cutoff))) { f.ds = DS_END; continue; }
+            if (ph != w.resume_phase) w.resume_i = 0;
+            w.resume_phase = ph;
+            f.s = (uint8_t)(have_rc ? (ph == 0 ? first : 1 - first) : 0);
+            w.ext[f.s].rc_view = 0;
+            if (have_rc) w.ext[1 - f.s].rc_view = canon ? 0 : 1;
+            f.i = w.resume_i;
+            w.resume_i = 0;
+            f.ds = DS_SEED;
+            continue;
+        }
+        if (f.ds == DS_SEED) {
+            const int32_t n = w.n_seeds[s];
+            int32_t i = f.i;
+            while (i < n && !w.alive[s][i]) ++i;
+            f.i = i;
+            if (i >= n) { f.ph = (uint8_t)(f.ph + 1); f.ds = DS_PHASE; continue; }
+            if (pass_limit_reached(w, i)) { f.ds = DS_END; continue; }
+            ++w.seeds_done;
+            seed = seedref_from_seed(w, s, i, nullptr);
+            conv_clear(w, w.ext[s].conv);                         // set_seed (:90-98)
+            f.filt = 0;
+            es = s; force = false; want = 1;
+            f.ds = DS_FWD_EXT;
+        } else if (f.ds == DS_FWD_EXT) {
+            if (w.status != ST_OK) { f.ds = DS_END; continue; }
+            seed = seedref_from_seed(w, s, f.i, nullptr);
+            // aln_both: extend(): min_path_score = max(0, min_cell_score); align_core: get_min_path_score
+            mps = have_rc ? imax(0, P.cfg.min_cell_score) : imax(0, min_path_score_now(w));
+            es = s; want = 2;
+            f.ds = DS_FWD_BT;
+        } else if (f.ds == DS_FWD_BT) {
+            if (w.status != ST_OK) { f.ds = DS_END; continue; }
+            const int n_fwd = w.bt.produced;
+            bool have_rev = false;
+            if (!have_rc) {
+                for (int e = 0; e < n_fwd; ++e) add_alignment(w, w.aln[e]);
+                if (w.status != ST_OK) { f.ds = DS_END; continue; }
+                flat_check_later(w, true, false);
+                f.ds = DS_SEED_DONE;
+                continue;
+            }
+            if (n_fwd) {
+                DevAln &path = w.aln[0];
+                DevAln &rev = w.aln[1];
+                if (canon) {
+                    const bool reversible = path.orientation && !path.offset;
+                    const bool to_left = aln_clipping(path) && !path.offset;
+                    const bool good = path.score >= min_path_score_now(w);
+                    bool got = false;
+                    if ((good && reversible) || to_left) { copy_aln(rev, path); got = reverse_complement_aln_stored(w, rev); }
+                    if (good) { if (reversible) { if (got) add_alignment(w, rev); } else add_alignment(w, path); }
+                    have_rev = to_left && got;
+                } else {
+                    if (path.score >= min_path_score_now(w)) add_alignment(w, path);
+                    if (aln_clipping(path) && !path.offset) {
+                        copy_aln(rev, path);
+                        have_rev = reverse_complement_aln(w, rev);
+                    }
+                }
+            }
+            flat_check_later(w, true, false);                     // before the backward pass overwrites the column table
+            if (!have_rev) { f.ds = DS_SEED_DONE; continue; }
+            seed = seedref_from_aln(w.aln[1]);
+            conv_clear(w, w.ext[1 - s].conv);
+            es = 1 - s; force = true; want = 1;
+            f.ds = DS_BWD_EXT;
+        } else if (f.ds == DS_BWD_EXT) {
+            if (w.status != ST_OK) { f.ds = DS_END; continue; }
+            seed = seedref_from_aln(w.aln[1]);
+            mps = imax(0, min_path_score_now(w));
+            es = 1 - s; want = 2;
+            f.ds = DS_BWD_BT;
+        } else if (f.ds == DS_BWD_BT) {
+            if (w.status != ST_OK) { f.ds = DS_END; continue; }
+            const int n_bwd = w.bt.produced;
+            if (n_bwd) {
+                DevAln &p2 = w.aln[2];
+                if (canon && !(p2.orientation && !p2.offset)) {
+                    add_alignment(w, p2);                          // not reversible: as it is (:711)
+                } else if (canon ? reverse_complement_aln_stored(w, p2) : reverse_complement_aln(w, p2)) {
+                    f.filt = 1;                                    // filter_nodes, applied lazily (flat_check_later)
+                    add_alignment(w, p2);
+                }
+            }
+            if (w.status != ST_OK) { f.ds = DS_END; continue; }
+            f.ds = DS_SEED_DONE;
+            continue;
+        } else if (f.ds == DS_SEED_DONE) {
+            if (f.filt) flat_check_later(w, false, true);
+            f.filt = 0;
+            f.i = f.i + 1;
+            f.ds = DS_SEED;
+            continue;
+        } else {                                                   // DS_END
+            f.act = ACT_FINISH;
+            return;
+        }
+        if (want == 1) {
+            if (!extend_begin(w, es, seed, force)) continue;      // capacity: the *_EXT state sees the status
+            f.act = ACT_EXTEND;
+            return;
+        }
+        bt_begin(w, es, seed, mps, 1);
+        f.act = ACT_BT;
+        return;
+    }
+}
+
+// align_read's part before the driver, for the extension kernel: workspace, query, the seeds of the seeding kernel.
+// false = the read is over already (status says why)
+MGX_DEV bool flat_read_begin(Wave &w, const AlignParams &P, uint64_t read, uint32_t slot, uint8_t *lds, uint32_t lds_bytes,
+                               const uint8_t *resume_rec) {
+    MGX_ASSUME_LDS(&w);
+#if !(defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS)
+    w.P = &P;
+#endif
+    carve(w, P, P.arena + (uint64_t)slot * P.arena_stride, lds, lds_bytes);
+    w.sd = w.sd_own;
+    const uint64_t off = P.offsets[read];
+    w.L = (int32_t)(P.offsets[read + 1] - off);
+    w.status = ST_OK;
+    w.have_best = 0;
+    w.seeds_done = 0;
+    w.resume_phase = 0; w.resume_i = 0; w.no_limit = 0;
+    w.ctr.rank_lines = w.ctr.select_lines = w.ctr.bit_lines = 0;
+    w.n_columns = w.n_extensions = w.n_fast_columns = 0;
+    const uint64_t nb = P.node_begin[read];
+    w.n_kmers = (int32_t)(P.node_begin[read + 1] - nb);
+    w.nodes[0] = P.nodes_fwd + nb;
+    w.nodes[1] = P.nodes_rc + nb;
+    for (int x = 0; x < 8; ++x) w.cyc[x] = 0;
+    for (int x = 0; x < XCYC_N; ++x) w.xcyc[x] = 0;
+    const uint64_t tstart = cycle_clock();
+    w.n_seeds[0] = w.n_seeds[1] = 0; w.num_matching[0] = w.num_matching[1] = 0;
+    if (w.L > (int32_t)P.lim.Lmax) { w.status = ST_CAPACITY; return false; }
+    prepare_query(w, P.seqs + off, false, true);
+    w.cyc[0] = (uint32_t)(cycle_clock() - tstart);
+    for (int s = 0; s < 2; ++s) {
+        w.ext[s].q = w.q[s];
+        w.ext[s].psum = w.psum[s];
+        w.ext[s].psum_lin = w.psum_lin[s];
+        w.ext[s].table_cap = 0;
+        w.ext[s].rc_view = 0;
+        w.ext[s].conv.n_entries = 0; w.ext[s].conv.n_recs = 0; w.ext[s].conv.pool_top = 0;
+        w.ext[s].conv.cap = conv_cap0(P.lim.hash_size); w.ext[s].conv.base = 0; w.ext[s].conv.start = 0;
+        w.ext[s].conv.gen = w.gen_store[2 * s]; w.ext[s].conv.dirty = w.gen_store[2 * s + 1];
+    }
+    const uint64_t tseed = cycle_clock();
+    const SeedHdr h = P.seed_hdr[read];
+    w.status = h.status;
+    for (int s = 0; s < 2; ++s) { w.n_seeds[s] = h.n_seeds[s]; w.num_matching[s] = h.num_matching[s]; }
+    if (w.status == ST_OK) {
+        const DevSeed *src = P.seed_stream + h.off;
+        for (int s = 0; s < 2; ++s) {
+            const int32_t n = w.n_seeds[s];
+            for (int32_t base = 0; base < n; base += WAVE) {
+                FOR_LANES(l) {
+                    int32_t x = base + l;
+                    if (x < n) { w.seeds[s][x] = src[x]; w.alive[s][x] = 1; }
+                }
+            }
+            src += n;
+        }
+    }
+    wave_sync();
+    if (P.ablate & 8u) { w.n_seeds[0] = w.n_seeds[1] = 0; }          // timing probe: fetch + pick-up + output only
+    if (P.dbg_seeds && w.status == ST_OK) {
+        for (int s = 0; s < 2; ++s)
+            for (int32_t i = 0; i < w.n_seeds[s]; ++i)
+                P.dbg_seeds[((uint64_t)read * 2 + s) * P.lim.max_seeds + i] = w.seeds[s][i];
+    }
+    wave_sync();
+    w.cyc[1] = (uint32_t)(cycle_clock() - tseed);
+    if (w.status != ST_OK) return false;
+    if (resume_rec) resume_load(w, resume_rec);          // a later pass: the aggregator, the live seeds, where it stopped
+    w.fs.ph = (uint8_t)w.resume_phase; w.fs.s = 0; w.fs.i = 0; w.fs.filt = 0; w.fs.ds = DS_PHASE;
+    return true;
+}
+
+// align_read's part after the driver: retry bookkeeping of the multi-pass extension, the result record, the output stream.
+// true = the driver goes on with this read (no room for a resume record: the pass limit is lifted)
+MGX_DEV bool flat_read_end(Wave &w, const AlignParams &P, uint64_t read, KernelStats *stats_accum) {
+    MGX_ASSUME_LDS(&w);
+    int64_t retry_pos = -1;
+    if (w.status == ST_RETRY && P.resume_out) {
+        // stopped by the pass's seed limit: take a retry position; without room for a record the read just goes on
+        LV<uint64_t> pv;
+        FOR_LANES(l) {
+            pv[l] = 0;
+            if (l == 0) {
+#if MGX_WAVE_EMU
+                pv[l] = (*P.retry_count)++;
+#else
+                pv[l] = atomicAdd(P.retry_count, 1ull);
+#endif
+            }
+        }
+        const uint64_t pos = wave_bcast(pv, 0);
+        if (pos >= P.resume_cap) {
+            w.no_limit = 1; w.status = ST_OK;
+            w.fs.ph = (uint8_t)w.resume_phase; w.fs.ds = DS_PHASE;
+            return true;
+        }
+        retry_pos = (int64_t)pos;
+        resume_save(w, P.resume_out + pos * P.resume_rec_bytes);
+        // work key of the next pass: this read's next live seed (same prediction as the seeding kernel's)
+        uint32_t key = 1;
+        {
+            const bool have_rc = P.cfg.fwd_and_rc != 0;
+            const int sidx = w.resume_phase == 0 ? (w.num_matching[0] >= w.num_matching[1] ? 0 : 1)
+                                                 : (w.num_matching[0] >= w.num_matching[1] ? 1 : 0);
+            const int ss = have_rc ? sidx : 0;
+            if (w.resume_i < w.n_seeds[ss]) {
+                const int32_t clip = w.seeds[ss][w.resume_i].clipping;
+                key = 1u + (uint32_t)imin(4094, (w.L - clip) + (clip > 0 ? w.L : 0));
+            }
+        }
+        FOR_LANES(l) { if (l == 0) { P.retry_list[pos] = (uint32_t)read; P.retry_key[pos] = key; } }
+    }
+    if (w.L <= (int32_t)P.lim.Lmax) {
+        for (int s = 0; s < 2; ++s) { w.gen_store[2 * s] = w.ext[s].conv.gen; w.gen_store[2 * s + 1] = w.ext[s].conv.dirty; }
+        wave_sync();
+    }
+    if (w.status == ST_RETRY) {
+        // this read goes on to another seed in the next pass: with a resume record (written above) or, without records,
+        // untouched and from scratch
+        FOR_LANES(l) {
+            if (l == 0 && retry_pos < 0) {
+#if MGX_WAVE_EMU
+                P.retry_list[(*P.retry_count)++] = (uint32_t)read;
+#else
+                P.retry_list[atomicAdd(P.retry_count, 1ull)] = (uint32_t)read;
+#endif
+            }
+        }
+        stats_accum->rank_lines += w.ctr.rank_lines;
+        stats_accum->select_lines += w.ctr.select_lines;
+        stats_accum->bit_lines += w.ctr.bit_lines;
+        for (int x = 0; x < 8; ++x) stats_accum->cyc[x] += w.cyc[x];
+        for (int x = 0; x < XCYC_N; ++x) stats_accum->xcyc[x] += w.xcyc[x];
+        return false;
+    }
+    const uint64_t tout = cycle_clock();
+    ReadResult rr;
+    rr.status = w.status; rr.n_alignments = 0; rr.score = 0; rr.offset = 0; rr.n_nodes = rr.n_cigar = rr.seq_len = 0;
+    rr.orientation = 0; rr.stream_off = 0;
+    rr.num_matches_fwd = w.num_matching[0]; rr.num_matches_rc = w.num_matching[1];
+    rr.n_seeds_fwd = (uint32_t)w.n_seeds[0]; rr.n_seeds_rc = (uint32_t)w.n_seeds[1];
+    rr.n_extensions = w.n_extensions; rr.n_columns = w.n_columns;
+    if (w.status == ST_OK && w.have_best) {
+        // get_alignments (aligner_aggregator.hpp:180-202), one alignment: emitted unless empty
+        const DevAln &a = w.aln[Q0];
+        if (a.n_nodes) {
+            const uint32_t words = (uint32_t)a.n_nodes + (uint32_t)a.n_cigar + ((uint32_t)a.seq_len + 3) / 4;
+            LV<uint64_t> offv;
+            FOR_LANES(l) {
+                offv[l] = 0;
+                if (l == 0) {
+#if MGX_WAVE_EMU
+                    offv[l] = *P.out_cursor; *P.out_cursor += words;
+#else
+                    offv[l] = atomicAdd(P.out_cursor, (unsigned long long)words);
+#endif
+                }
+            }
+            const uint64_t so = wave_bcast(offv, 0);
+            if (so + words > P.out_capacity) {
+                rr.status = ST_CAPACITY;
+            } else {
+                uint32_t *dst = P.out_stream + so;
+                rr.score = a.score; rr.offset = (uint32_t)a.offset;
+                rr.n_nodes = (uint32_t)a.n_nodes; rr.n_cigar = (uint32_t)a.n_cigar; rr.seq_len = (uint32_t)a.seq_len;
+                rr.orientation = (uint32_t)a.orientation; rr.stream_off = so;
+                uint8_t *dseq = (uint8_t *)(dst + a.n_nodes + a.n_cigar);
+                const int32_t n = imax(imax(a.n_nodes, a.n_cigar), a.seq_len);
+                for (int32_t base = 0; base < n; base += WAVE) {
+                    FOR_LANES(l) {
+                        int32_t x = base + l;
+                        if (x < a.n_nodes) dst[x] = a.nodes[x];
+                        if (x < a.n_cigar) dst[a.n_nodes + x] = a.cigar[x];
+                        if (x < a.seq_len) dseq[x] = a.seq[x];
+                    }
+                }
+                rr.n_alignments = 1;
+            }
+        }
+    }
+    FOR_LANES(l) { if (l == 0) P.results[read] = rr; }
+    stats_accum->rank_lines += w.ctr.rank_lines;
+    stats_accum->select_lines += w.ctr.select_lines;
+    stats_accum->bit_lines += w.ctr.bit_lines;
+    stats_accum->columns += w.n_columns;
+    stats_accum->fast_columns += w.n_fast_columns;
+    stats_accum->extensions += w.n_extensions;
+    stats_accum->capacity_errors += rr.status != ST_OK;
+    w.cyc[5] = (uint32_t)(cycle_clock() - tout);
+    for (int x = 0; x < 8; ++x) stats_accum->cyc[x] += w.cyc[x];
+    for (int x = 0; x < XCYC_N; ++x) stats_accum->xcyc[x] += w.xcyc[x];
+    return false;
+}
+
+// the read's current backtrack, advanced by one batch of walk steps (its own function: the loop around it keeps the chain
+// registers of the extension live)
+MGX_DEV bool flat_bt_step(Wave &w) {
+    MGX_ASSUME_LDS(&w);
+    const SeedRef seed = flat_bt_seed(w);
+    const bool fwd = w.fs.ds == DS_FWD_BT;
+    return bt_step(w, seed, fwd ? nullptr : &w.aln[1], fwd ? &w.aln[0] : &w.aln[2], FLAT_BT_STEPS);
+}
+
+#if !MGX_WAVE_EMU
+// ---- the kernel's loop: rounds of [service] -> [extension loop] -> [service] -> [trace loop] ----
+// Measured (profiles/r03_ab1.txt) the groups of a wavefront lose most at the joins BETWEEN phases, waiting for wave-mates
+// whose read has another extension to run.  Giving every group one step per iteration of a single loop would remove all
+// waiting, but then a trace step (a twelfth of a chain step) costs the wavefront a whole iteration whenever fewer than all
+// groups are walking, and calls inside the step loop wreck its register allocation (1719 spilled VGPRs against 18).  So the
+// phases themselves stay lock-step — every group runs ONE extension in the extension loop, ONE backtrack in the trace
+// loop — and flat_service() does everything in between per group: a group whose read is finished fetches its next read
+// there and joins the next extension loop with it, instead of idling through its wave-mates' second extensions.
+MGX_NI_G4 void flat_service(Wave &w, uint32_t slot, KernelStats *stats_accum, uint8_t *lds, uint32_t lds_bytes, uint64_t n_items) {
+    MGX_ASSUME_LDS(&w);
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    FlatState &f = w.fs;
+    for (;;) {
+        if (f.act == ACT_FETCH) {
+            LV<uint64_t> rv;
+            rv.v = 0;
+            if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
+            const uint64_t item = wave_bcast(rv, 0);
+            if (item >= n_items) { f.act = ACT_EXIT; break; }
+            uint64_t read = P.order ? P.order[item] : item;
+            const uint8_t *rec = nullptr;
+            if (P.resume_in) {                                   // a later pass: `read` is a retry position of the pass before
+                rec = P.resume_in + read * P.resume_rec_bytes;
+                read = P.resume_reads[read];
+            }
+            f.read = read;
+            f.act = flat_read_begin(w, P, read, slot, lds, lds_bytes, rec) ? ACT_DRIVE : ACT_FINISH;
+        }
+        if (f.act == ACT_DRIVE) {
+            const uint64_t t0 = cycle_clock();
+            flat_drive(w);
+            w.cyc[4] += (uint32_t)(cycle_clock() - t0);
+        }
+        if (f.act == ACT_FINISH) f.act = flat_read_end(w, P, f.read, stats_accum) ? ACT_DRIVE : ACT_FETCH;
+        if (f.act == ACT_EXTEND || f.act == ACT_BT) break;
+    }
+}
+// the read's backtrack, to the end
+MGX_NI_G4 void flat_bt_all(Wave &w) {
+    MGX_ASSUME_LDS(&w);
+    const uint64_t t0 = cycle_clock();
+    const SeedRef seed = flat_bt_seed(w);
+    const bool fwd = w.fs.ds == DS_FWD_BT;
+    while (!bt_step(w, seed, fwd ? nullptr : &w.aln[1], fwd ? &w.aln[0] : &w.aln[2], INT32_MAX)) {}
+    w.fs.act = ACT_DRIVE;
+    w.cyc[3] += (uint32_t)(cycle_clock() - t0);
+}
+// the read's extension, to the end (its own function, like extend(): with calls in the same function the step loop got 1600 spilled VGPRs instead of 28)
+MGX_NI_G3 void flat_extend_all(Wave &w) {
+    MGX_ASSUME_LDS(&w);
+    const uint64_t t0 = cycle_clock();
+    const int es = flat_es(w);
+    ChainRegs R;
+    chain_regs_reset(R);
+    while (extend_step(w, es, R) == XS_MORE) {}
+    w.fs.act = ACT_DRIVE;
+    w.cyc[2] += (uint32_t)(cycle_clock() - t0);
+}
+#endif
+
+// One iteration of the group's loop: w.fs.act says what the group is doing.  `fetch(read, rec)` hands out the next read
+// (false: none left).  R: the extension's chain registers, `read`: the group's current read — both loop-carried by the
+// caller.
+template <class Fetch>
+MGX_DEV void flat_iteration(Wave &w, const AlignParams &P, uint32_t slot, KernelStats *stats_accum, uint8_t *lds, uint32_t lds_bytes,
+                            ChainRegs &R, uint64_t &read, Fetch fetch) {
+    FlatState &f = w.fs;
+    if (f.act == ACT_FETCH) {
+        const uint8_t *rec = nullptr;
+        if (!fetch(read, rec)) { f.act = ACT_EXIT; return; }
+        f.act = flat_read_begin(w, P, read, slot, lds, lds_bytes, rec) ? ACT_DRIVE : ACT_FINISH;
+    }
+    if (f.act == ACT_DRIVE) {
+        const uint64_t t0 = cycle_clock();
+        flat_drive(w);
+        w.cyc[4] += (uint32_t)(cycle_clock() - t0);
+        if (f.act == ACT_EXTEND) chain_regs_reset(R);
+    }
+    if (f.act == ACT_EXTEND) {
+        const uint64_t t0 = cycle_clock();
+        if (extend_step(w, flat_es(w), R) != XS_MORE) f.act = ACT_DRIVE;
+        w.cyc[2] += (uint32_t)(cycle_clock() - t0);
+    } else if (f.act == ACT_BT) {
+        const uint64_t t0 = cycle_clock();
+        if (flat_bt_step(w)) f.act = ACT_DRIVE;
+        w.cyc[3] += (uint32_t)(cycle_clock() - t0);
+    }
+    if (f.act == ACT_FINISH) f.act = flat_read_end(w, P, read, stats_accum) ? ACT_DRIVE : ACT_FETCH;
+}
+#endif  // MGX_NO_EXTEND
 
 } // namespace mgx

@@ -127,6 +127,7 @@ struct AlignParams {
     uint32_t resume_rec_bytes, resume_cap;
     uint64_t n_items;                        // items of this launch (0: n_items_ptr / n_reads)
     uint32_t no_fast;                    // A/B and test switch: every column through the general (staging buffer) path
+    uint32_t no_flat;                    // A/B and test switch: the per-read program instead of the flat group loop
     uint32_t no_alias;                   // A/B and test switch: every convergence-table entry gets its own vector in the pool
     uint32_t no_compact;                 // A/B and test switch: chain columns always in the two-line form (ColSlot)
     uint32_t ablate;                     // timing probes only (results become WRONG): bit 0 = no convergence table in the chain

@@ -846,6 +846,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.no_compact = no_compact;
     static const bool no_alias = getenv("MGX_NO_ALIAS") && atoi(getenv("MGX_NO_ALIAS")) == 1;
     P.no_alias = no_alias;
+    static const bool no_flat = getenv("MGX_NO_FLAT") && atoi(getenv("MGX_NO_FLAT")) == 1;
+    P.no_flat = no_flat;
     P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results
     size_t sort_tmp_bytes = 0;
     if (split) {

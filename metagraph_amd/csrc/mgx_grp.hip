@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
     const int g = group_id();
     const uint32_t slot = blockIdx.x * GROUPS_PER_WAVEFRONT + (uint32_t)g;
     __shared__ Wave ws[GROUPS_PER_WAVEFRONT];
-    __shared__ int8_t sm_rows[6 * 128];
+    int8_t *sm_rows = g_sm_rows;
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&P);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&g_params);      // (a kernel argument whose address is taken would live in scratch)
@@ -63,20 +63,49 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
     KernelStats acc;
     memset(&acc, 0, sizeof(acc));
     const uint64_t n_items = P.n_items ? P.n_items : (P.n_items_ptr ? *P.n_items_ptr : P.n_reads);
-    for (;;) {
+    // next work item of this group: position `item` of the (sorted) order, or a retry position of the pass before
+    auto fetch = [&](uint64_t &read, const uint8_t *&rec) -> bool {
         LV<uint64_t> rv;
         rv.v = 0;
-        if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
-        uint64_t item = wave_bcast(rv, 0);
-        if (item >= n_items) break;
-        uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
-        const uint8_t *rec = nullptr;
-        if (PHASE == PH_EXTEND && P.resume_in) {         // a later pass: `read` is a retry position of the pass before
-            rec = P.resume_in + read * P.resume_rec_bytes;
-            read = P.resume_reads[read];
+        if (lane_id() == 0) rv.v = atomicAdd(g_params.read_cursor, 1ull);
+        const uint64_t item = wave_bcast(rv, 0);
+        if (item >= n_items) return false;
+        read = (PHASE == PH_EXTEND && g_params.order) ? g_params.order[item] : item;
+        rec = nullptr;
+        if (PHASE == PH_EXTEND && g_params.resume_in) {         // a later pass: `read` is a retry position of the pass before
+            rec = g_params.resume_in + read * g_params.resume_rec_bytes;
+            read = g_params.resume_reads[read];
         }
-        align_read<PHASE>(w, g_params, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes, rec);
+        return true;
+    };
+    // (the product build has no per-read program at all: one alignment per seed always takes the flat loop; the build that
+    // carries alternative paths keeps both, and -DMGX_KEEP_LEGACY=1 gives an A/B build that obeys MGX_NO_FLAT)
+#if defined(MGX_ALT_BUILD) || defined(MGX_KEEP_LEGACY)
+    const bool flat = PHASE == PH_EXTEND && n_alt_of(w) == 1 && !g_params.no_flat;
+#else
+    constexpr bool flat = PHASE == PH_EXTEND;
+#endif
+    if (flat) {
+        // rounds of service -> extension loop -> service -> trace loop (align_core.hpp, flat_service): the phases are
+        // lock-step, the reads are not
+        w.fs.act = ACT_FETCH;
+        for (;;) {
+            flat_service(w, slot, &acc, lds, lds_bytes, n_items);
+            if (w.fs.act == ACT_EXIT) break;
+            if (w.fs.act == ACT_EXTEND) flat_extend_all(w);
+            else flat_bt_all(w);
+        }
     }
+#if defined(MGX_ALT_BUILD) || defined(MGX_KEEP_LEGACY) || defined(MGX_GRP_SEED_PROBE)
+    else {
+        for (;;) {
+            uint64_t read = 0;
+            const uint8_t *rec = nullptr;
+            if (!fetch(read, rec)) break;
+            align_read<PHASE>(w, g_params, read, slot, &acc, nullptr, sm_rows, lds, lds_bytes, rec);
+        }
+    }
+#endif
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);
         atomicAdd(&P.stats->select_lines, acc.select_lines);
@@ -110,4 +139,4 @@ extern "C" int MGX_SUFFIX(MGX_CAT(mgx_launch_align_grp, MGX_GROUP))(const void *
     return (int)hipGetLastError();
 }
 extern "C" int MGX_SUFFIX(MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP))(void) { return MGX_GRP_WAVES_PER_SIMD; }
-extern "C" unsigned MGX_SUFFIX(MGX_CAT(mgx_grp_static_lds, MGX_GROUP))(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + sizeof(AlignParams) + 6 * 128); }
+extern "C" unsigned MGX_SUFFIX(MGX_CAT(mgx_grp_static_lds, MGX_GROUP))(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + sizeof(AlignParams) + sizeof(g_sm_rows)); }

@@ -328,6 +328,23 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     std::vector<int8_t> rows(6 * 128);
     load_score_rows(P, rows.data());
     const char *split = getenv("MGX_EMU_SPLIT");
+    // the extension phase of one read: through the flat group loop (the product's default with one alignment per seed; a
+    // single group here, so every transition of the state machine is exercised, not the interleaving) or the per-read program
+    const bool flat = cfg.num_alternative_paths == 1 && !(getenv("MGX_NO_FLAT") && atoi(getenv("MGX_NO_FLAT")) == 1);
+    const uint32_t ldsb_all = (uint32_t)(lds_env ? atoi(lds_env) : 2048);
+    auto run_extend = [&](uint64_t read, const uint8_t *rec) {
+        if (!flat) { align_read<PH_EXTEND>(*w, P, read, 0, &R->stats, &sd, rows.data(), lds.data(), ldsb_all, rec); return; }
+#if !(defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS)
+        w->sm_rows = rows.data();
+#endif
+        ChainRegs CR;
+        chain_regs_reset(CR);
+        bool given = false;
+        uint64_t cur = 0;
+        w->fs.act = ACT_FETCH;
+        auto fetch = [&](uint64_t &r, const uint8_t *&rc) { if (given) return false; given = true; r = read; rc = rec; return true; };
+        do { flat_iteration(*w, P, 0, &R->stats, lds.data(), ldsb_all, CR, cur, fetch); } while (w->fs.act != ACT_EXIT);
+    };
     if (split && *split == '1') {
         // the two-kernel pipeline: seeding phase for every read, stable sort by predicted work, extension phase
         std::vector<SeedHdr> hdr(n);
@@ -356,7 +373,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
             P.seed_limit = 1; P.resume_rec_bytes = rb; P.resume_cap = cap;
             P.retry_list = list_a.data(); P.retry_key = key_a.data(); P.retry_count = &retry_count; P.resume_out = pool_a.data();
             for (uint64_t i = 0; i < n; ++i)
-                align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
+                run_extend(order[i], nullptr);
             R->retried = retry_count;
             std::vector<uint8_t> *pin = &pool_a, *pout = &pool_b;
             std::vector<uint32_t> *lin = &list_a, *lout = &list_b, *kin = &key_a, *kout = &key_b;
@@ -369,7 +386,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
                 P.resume_out = pout->data(); P.retry_list = lout->data(); P.retry_key = kout->data();
                 for (uint64_t i = 0; i < c; ++i) {
                     const uint32_t pos = ord[i];
-                    align_read<PH_EXTEND>(*w, P, (*lin)[pos], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb, pin->data() + (size_t)pos * rb);
+                    run_extend((*lin)[pos], pin->data() + (size_t)pos * rb);
                 }
                 std::swap(pin, pout); std::swap(lin, lout); std::swap(kin, kout);
             }
@@ -393,7 +410,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
             P.dbg_seeds = nullptr;
             mgx_trace_on(1);
             for (uint64_t i = 0; i < n; ++i) {
-                align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
+                run_extend(order[i], nullptr);
                 TRACE_END_READ();
             }
             mgx_trace_on(0);
@@ -402,10 +419,10 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         // two-pass extension: at most one seed per read first, then the reads that go on, from scratch
         P.seed_limit = 1; P.retry_list = retry.data(); P.retry_count = &retry_count;
         for (uint64_t i = 0; i < n; ++i)
-            align_read<PH_EXTEND>(*w, P, order[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
+            run_extend(order[i], nullptr);
         P.seed_limit = 0; P.order = retry.data();
         for (uint64_t i = 0; i < retry_count; ++i)
-            align_read<PH_EXTEND>(*w, P, retry[i], 0, &R->stats, &sd, rows.data(), lds.data(), ldsb);
+            run_extend(retry[i], nullptr);
         R->retried = retry_count;
 #ifdef MGX_EMU_TRACE
         }
