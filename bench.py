@@ -217,11 +217,12 @@ def main():
     traffic, traffic_src, gather = None, None, None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        pmc = json.load(open(os.path.join(here, "profiles", "r02_pmc_summary.json")))
+        pmc_name = next(n for n in ("r03_pmc_summary.json", "r02_pmc_summary.json") if os.path.exists(os.path.join(here, "profiles", n)))
+        pmc = json.load(open(os.path.join(here, "profiles", pmc_name)))
         per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read")
         if per_read:
             traffic = round(per_read * args.reads)
-            traffic_src = "profiles/r02_pmc_summary.json (%d-read PMC run, scaled per read)" % pmc["reads_per_launch"]
+            traffic_src = "profiles/%s (%d-read PMC run, scaled per read)" % (pmc_name, pmc["reads_per_launch"])
         # These kernels gather 64-B lines at random: next to the 8 TB/s streaming peak, every kernel is also stated against the
         # MEASURED ceiling of dependent random 64-B line loads (tools/gather_ceiling.hip, profiles/r02_gather_ceiling.json):
         # fabric lines per second (PMC traffic / 64 B) over the DRAM-resident ceiling.

@@ -212,7 +212,11 @@ MGX_DEV void gst4(int32_t *p, int32_t a, int32_t b, int32_t c, int32_t d) {
 // one-shot 8-byte load that should not displace reusable lines (graph blocks, hints) from L2 / Infinity Cache
 // write-once / read-once scalars of the batch streams (node ids, match lengths, ranges): nontemporal
 template <class T, class V> MGX_DEV void gst_stream(T *p, V v) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(MGX_PROBE_NO_STREAM_STORES)
+    (void)p; (void)v;                      // timing probe only (results are WRONG): what do k_map's output stores cost?
+#elif defined(MGX_PROBE_PLAIN_STREAM_STORES) && defined(__HIP_DEVICE_COMPILE__)
+    *(__attribute__((address_space(1))) T *)p = (T)v;
+#elif defined(__HIP_DEVICE_COMPILE__)
     __builtin_nontemporal_store((T)v, (__attribute__((address_space(1))) T *)p);
 #else
     *p = (T)v;

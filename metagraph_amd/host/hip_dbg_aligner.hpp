@@ -11,6 +11,7 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <algorithm>
 #include <stdexcept>
 #include <string>
@@ -131,6 +132,23 @@ class HipBOSSGraph {
     mgx_graph *handle() const { return g_; }
   private:
     mgx_graph *g_ = nullptr;
+};
+
+// In-process multi-GPU (the natural drop-in for `metagraph align`, which is ONE process with a pool of batch tasks,
+// cli/align.cpp:440-475): one replica of the graph per device; worker w of the pool aligns its batches on device w % D.  Reads
+// shard by batch, the graph is replicated, nothing is exchanged between devices — results come back per batch on the host.
+class HipGraphSet {
+  public:
+    HipGraphSet(int n_devices, uint32_t k, uint64_t n_edges, const uint8_t *W, const uint8_t *last, const uint64_t F[5],
+                const uint8_t *valid = nullptr, uint32_t mode = MGX_MODE_BASIC) {
+        if (n_devices < 1) throw std::runtime_error("HipGraphSet: at least one device");
+        for (int d = 0; d < n_devices; ++d) replicas_.emplace_back(new HipBOSSGraph(k, n_edges, W, last, F, valid, d, mode));
+    }
+    size_t size() const { return replicas_.size(); }
+    static size_t device_of_worker(size_t worker, size_t n_devices) { return worker % n_devices; }
+    const HipBOSSGraph &for_worker(size_t worker) const { return *replicas_[device_of_worker(worker, replicas_.size())]; }
+  private:
+    std::vector<std::unique_ptr<HipBOSSGraph>> replicas_;
 };
 
 class IDBGAligner {

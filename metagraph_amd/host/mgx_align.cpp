@@ -3,6 +3,8 @@
 // reading sdsl-serialised .dbg files is "next" (SURVEY 8f rank 2).  Usage:
 //   mgx_align GRAPH.boss READS.{fa,fq} [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]
 //             [-p THREADS] [--query-batch-size BASES] [--canonical | --primary (the dump is a CANONICAL- / PRIMARY-mode graph)]
+//             [--devices D]   in-process multi-GPU: one graph replica per device, whole batches routed round-robin, no collective
+//                             (the reference's unit of parallelism, cli/align.cpp:440-475: one task per batch)
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -69,6 +71,7 @@ int main(int argc, char **argv) {
     mgx_limits lim;
     bool have_lim = false;
     uint32_t graph_mode = MGX_MODE_BASIC;
+    int devices = 1;
     mgx_limits_init_default(&lim, 0);
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--align-only-forwards")) cfg.forward_and_reverse_complement = 0;
@@ -77,11 +80,19 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "-p") && i + 1 < argc) threads = (unsigned)std::max(1, atoi(argv[++i]));
         else if (!strcmp(argv[i], "--query-batch-size") && i + 1 < argc) batch_size = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--max-columns") && i + 1 < argc) { lim.max_columns = (uint32_t)atoi(argv[++i]); have_lim = true; }
+        else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, atoi(argv[++i]));
         else if (!strcmp(argv[i], "--canonical")) graph_mode = MGX_MODE_CANONICAL;
         else if (!strcmp(argv[i], "--primary")) graph_mode = MGX_MODE_PRIMARY;         // aligned through the CanonicalDBG wrapper
     }
     try {
-        HipBOSSGraph graph(k, n, W.data(), last.data(), hdr + 2, nullptr, 0, graph_mode);
+        // one replica of the index per device (3.5 B/edge + the suffix-range table each); more devices than the box shows is an
+        // error of the caller's, reported like any other
+        if (devices > mgx_device_count() && mgx_device_count() > 0) {
+            fprintf(stderr, "error: --devices %d but %d HIP device(s) visible\n", devices, mgx_device_count());
+            return 1;
+        }
+        HipGraphSet graphs(devices, k, n, W.data(), last.data(), hdr + 2, nullptr, graph_mode);
+        if ((unsigned)devices > threads) threads = (unsigned)devices;                  // at least one worker per device
         std::vector<IDBGAligner::Query> all;
         if (!read_records(argv[2], &all)) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
         // batches by bases read (align.cpp:431-442: a record is added while the running total is <= batch_size)
@@ -95,8 +106,9 @@ int main(int argc, char **argv) {
         std::mutex print_mutex, err_mutex;
         std::atomic<size_t> next{ 0 };
         std::string first_error;
-        auto worker = [&]() {
+        auto worker = [&](unsigned worker_id) {
             try {
+                const HipBOSSGraph &graph = graphs.for_worker(worker_id);               // a worker stays on its device
                 for (;;) {
                     const size_t bi = next.fetch_add(1);
                     if (bi >= batches.size()) break;
@@ -113,8 +125,8 @@ int main(int argc, char **argv) {
             }
         };
         std::vector<std::thread> pool;
-        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker);
-        worker();
+        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+        worker(0);
         for (auto &t : pool) t.join();
         if (!first_error.empty()) { fprintf(stderr, "error: %s\n", first_error.c_str()); return 1; }
     } catch (const std::exception &e) {

@@ -73,6 +73,13 @@ def test_mgx_align_batches_threads_and_capacity_retry(tmp_path):
     r = subprocess.run(base + ["--max-columns", "70"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.rstrip("\n").split("\n") == want
+    # in-process multi-device routing (HipGraphSet: one graph replica per device, worker w on device w % D): D = 1 here
+    # behaves like the plain run; asking for more devices than the box shows is refused, not silently clamped
+    r = subprocess.run(base + ["--devices", "1", "-p", "2", "--query-batch-size", "300"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert sorted(r.stdout.rstrip("\n").split("\n")) == sorted(want)
+    r = subprocess.run(base + ["--devices", "64"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--devices" in r.stderr
 
 
 def test_mgx_align_driver_on_a_canonical_graph(tmp_path):

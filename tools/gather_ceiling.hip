@@ -39,7 +39,11 @@ __global__ void __launch_bounds__(64) k_chase(const uint4 *buf, uint64_t n_lines
             uint4 a = p[0], b = p[1], cc = p[2], d = p[3];
             uint64_t v = ((uint64_t)(a.x ^ b.y ^ cc.z ^ d.w) << 32) | (a.y + b.z + cc.w + d.x);
             acc += v;
-            idx[c] = (v ^ (idx[c] * 0xD6E8FEB86659FD93ull)) % n_lines;
+            // the next index depends on the loaded data AND on the step and the chain: a map idx -> idx alone (round 2) sends every
+            // chain into the same few short cycles of the random mapping after ~sqrt(n) steps — for the 104 MB set that is
+            // ~1000 steps, after which the "working set" was a few thousand lines sitting in L1 / L2 (the 200 G lines/s of
+            // profiles/r02_gather_ceiling.json); the 9 GB set (tail ~8000 steps) was not affected
+            idx[c] = ((v + s * 0x9E3779B97F4A7C15ull + (tid * CHAINS + c)) ^ (idx[c] * 0xD6E8FEB86659FD93ull)) % n_lines;
         }
     }
     if (acc == 0x1234567) sink[0] = acc;
