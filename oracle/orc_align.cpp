@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstring>
 #include <deque>
+#include <limits>
+#include <map>
 #include <memory>
 #include <numeric>
 #include <queue>
@@ -181,7 +183,7 @@ Alignment::Alignment(const Seed &seed, const mgx_config &config)
         sequence(seed.query_view),
         score(match_score(config, seed.query_view) + (!seed.clipping ? config.left_end_bonus : 0)
                 + (!seed.end_clipping ? config.right_end_bonus : 0)),
-        cigar(MGX_OP_CLIPPED, seed.clipping) {
+        cigar(MGX_OP_CLIPPED, seed.clipping), label_columns(seed.label_columns) {
     cigar.append(MGX_OP_MATCH, query_view.size());
     cigar.append(MGX_OP_CLIPPED, seed.end_clipping);
 }
@@ -788,11 +790,96 @@ void extend_ins_end(PVec &S, PVec &E, PVec &F, size_t max_size, score_t xdrop_cu
     }
 }
 
+// =============================================================================================
+// AnnotationBuffer (A/annotation_buffer.{hpp,cpp}), annotation without coordinates
+// =============================================================================================
+constexpr Label kNannot = std::numeric_limits<Label>::max();      // aligner_labeled.cpp:20 ("dummy index for unfetched annotations")
+
+class AnnotationBuffer {
+  public:
+    // graph: the graph the aligner runs on — a BASIC DBGSuccinct, or a PRIMARY one seen through the CanonicalDBG wrapper
+    // (`canon`); a CANONICAL-mode DBGSuccinct would take the spell_path + map_to_nodes branch (:60-63), not restated
+    AnnotationBuffer(const Graph &graph, const CanonicalView *canon, const Annotation &annotation)
+          : graph_(graph), canonical_(canon), annotation_(annotation) {
+        column_sets_.push_back(Columns{});               // "the first element is the empty label set" (hpp:76-78)
+        column_index_[Columns{}] = 0;
+        if (graph_.mode == CANONICAL && !canon)
+            throw std::runtime_error("oracle: label-aware alignment on CANONICAL-mode graphs is not restated");
+    }
+
+    void queue_path(std::vector<node_t> &&path) { queued_paths_.push_back(std::move(path)); }     // hpp:29-31
+
+    // annotation_buffer.cpp:34-193
+    void fetch_queued_annotations() {
+        std::vector<node_t> queued_nodes;
+        std::vector<uint64_t> queued_rows;
+        for (const auto &path : queued_paths_) {
+            std::vector<node_t> base_path;
+            if (canonical_) {
+                base_path.reserve(path.size());
+                for (node_t node : path) base_path.emplace_back(canonical_->get_base_node(node));
+            } else {
+                base_path = path;                        // BASIC (the buffer's graph is never an RCDBG view)
+            }
+            for (size_t i = 0; i < path.size(); ++i) {
+                if (base_path[i] == NPOS) { node_to_cols_.try_emplace(path[i], 0); continue; }
+                if (!graph_.boss.get_W(base_path[i])) {  // "skip dummy nodes"
+                    node_to_cols_.try_emplace(base_path[i], 0);
+                    continue;
+                }
+                uint64_t row = base_path[i] - 1;         // AnnotatedDBG::graph_to_anno_index
+                if (node_to_cols_.try_emplace(base_path[i], kNannotIdx).second) {
+                    queued_rows.push_back(row);
+                    queued_nodes.push_back(base_path[i]);
+                }
+            }
+        }
+        queued_paths_.clear();
+        if (queued_nodes.empty()) return;
+        std::vector<Columns> rows = annotation_.get_rows(queued_rows);
+        for (size_t x = 0; x < rows.size(); ++x) {
+            std::sort(rows[x].begin(), rows[x].end());
+            size_t label_i = cache_column_set(std::move(rows[x]));
+            node_to_cols_[queued_nodes[x]] = label_i;    // push_node_labels: BASIC and the canonical wrapper both key by the base node
+        }
+    }
+
+    // get_labels_and_coords().first (:195-217)
+    const Columns *get_labels(node_t node) const {
+        if (canonical_) node = canonical_->get_base_node(node);
+        auto it = node_to_cols_.find(node);
+        if (it == node_to_cols_.end() || it->second == kNannotIdx) return nullptr;
+        return &column_sets_[it->second];
+    }
+
+    // cache_column_set (hpp:55-60): VectorSet::emplace — the index of the equal set already stored, or of a new entry
+    size_t cache_column_set(Columns &&cols) {
+        auto it = column_index_.find(cols);
+        if (it != column_index_.end()) return it->second;
+        size_t idx = column_sets_.size();
+        column_index_.emplace(cols, idx);
+        column_sets_.push_back(std::move(cols));
+        return idx;
+    }
+    const Columns &get_cached_column_set(size_t i) const { return column_sets_.at(i); }
+    size_t num_nodes_buffered() const { return node_to_cols_.size(); }
+
+  private:
+    static constexpr size_t kNannotIdx = std::numeric_limits<size_t>::max();
+    const Graph &graph_;
+    const CanonicalView *canonical_;
+    const Annotation &annotation_;
+    std::deque<Columns> column_sets_;                    // (deque: references handed out stay valid while sets are added)
+    std::map<Columns, size_t> column_index_;
+    std::unordered_map<node_t, size_t> node_to_cols_;
+    std::vector<std::vector<node_t>> queued_paths_;
+};
+
 class Extender {
   public:
     Extender(const Graph &graph, const mgx_config &config, std::string_view query, WorkCounters *wc,
-             const CanonicalView *canon = nullptr)
-          : base_(&graph), config_(config), query_(query), wc_(wc) {
+             const CanonicalView *canon = nullptr, AnnotationBuffer *annotation_buffer = nullptr)
+          : base_(&graph), config_(config), query_(query), wc_(wc), ab_(annotation_buffer) {
         view_.g = &graph;
         view_.rc = false;
         view_.canon = canon;
@@ -822,6 +909,13 @@ class Extender {
         seed_ = &seed;                                   // set_seed (:90-98)
         explored_nodes_previous_ += conv_checker_.size();
         conv_checker_.clear();
+        if (ab_) {
+            // LabeledExtender::set_seed (aligner_labeled.cpp:139-174, no coordinates): the first node of the seed has
+            // already been flushed; the seed's labels are what backtracking still has to account for
+            last_flushed_table_i_ = 1;
+            remaining_labels_i_ = ab_->cache_column_set(Columns(seed.label_columns));
+            node_labels_.assign(1, remaining_labels_i_);
+        }
         return extend(min_path_score, force_fixed_seed);
     }
 
@@ -878,6 +972,12 @@ class Extender {
     std::string_view query_;
     WorkCounters *wc_;
     const Alignment *seed_ = nullptr;
+    // LabeledExtender (aligner_labeled.hpp:86-106); ab_ == nullptr: DefaultColumnExtender
+    AnnotationBuffer *ab_ = nullptr;
+    size_t last_flushed_table_i_ = 0;
+    std::vector<size_t> node_labels_;
+    size_t remaining_labels_i_ = 0;
+    Columns label_intersection_, label_diff_;
     std::vector<score_t> partial_sums_;
     std::vector<score_t> profile_score_[6];
     std::vector<uint8_t> profile_op_[6];
@@ -899,6 +999,113 @@ class Extender {
         char ua = up(a), ub = up(b);
         bool valid = (ua == 'A' || ua == 'C' || ua == 'G' || ua == 'T');
         return (valid && ua == ub) ? MGX_OP_MATCH : MGX_OP_MISMATCH;
+    }
+
+    // DefaultColumnExtender::pop (hpp:190) / LabeledExtender::pop (aligner_labeled.hpp:76-81)
+    void pop(size_t i) {
+        table.erase(table.begin() + i);
+        if (ab_) {
+            last_flushed_table_i_ = std::min(i, last_flushed_table_i_);
+            node_labels_.erase(node_labels_.begin() + i);
+        }
+    }
+
+    // LabeledExtender::flush (aligner_labeled.cpp:81-137)
+    void flush() {
+        ab_->fetch_queued_annotations();
+        for ( ; last_flushed_table_i_ < table.size(); ++last_flushed_table_i_) {
+            Column &table_elem = table[last_flushed_table_i_];
+            size_t parent_i = table_elem.parent_i;
+            auto clear = [&]() {
+                node_labels_[last_flushed_table_i_] = 0;
+                std::fill(table_elem.S.buf.begin(), table_elem.S.buf.begin() + table_elem.S.sz, NINF);
+                std::fill(table_elem.E.buf.begin(), table_elem.E.buf.begin() + table_elem.E.sz, NINF);
+                std::fill(table_elem.F.buf.begin(), table_elem.F.buf.begin() + table_elem.F.sz, NINF);
+            };
+            if (!node_labels_[parent_i]) { clear(); continue; }
+            if (table_elem.node == NPOS) continue;
+            const Columns &parent_labels = ab_->get_cached_column_set(node_labels_[parent_i]);
+            const Columns *cur_labels = ab_->get_labels(table_elem.node);
+            if (!cur_labels) throw std::logic_error("oracle: flush(): labels of a table node were not fetched");
+            Columns intersect_labels;
+            std::set_intersection(parent_labels.begin(), parent_labels.end(), cur_labels->begin(), cur_labels->end(),
+                                  std::back_inserter(intersect_labels));
+            if (intersect_labels.empty()) clear();
+            else node_labels_[last_flushed_table_i_] = ab_->cache_column_set(std::move(intersect_labels));
+        }
+    }
+
+    // LabeledExtender::call_outgoing (aligner_labeled.cpp:176-302, the branch without coordinates)
+    void call_outgoing_labeled(node_t node, const std::function<void(node_t, char, score_t)> &callback,
+                               size_t table_i, bool force_fixed_seed) {
+        size_t next_offset = table[table_i].offset + 1;
+        bool in_seed = next_offset - seed_->offset < seed_->sequence.size()
+                        && (next_offset < view_.get_k() || force_fixed_seed);
+        std::vector<std::tuple<node_t, char, score_t>> outgoing;
+        call_outgoing(node, [&](node_t next, char c, score_t score) {
+            outgoing.emplace_back(next, c, score);
+            if (!in_seed) ab_->queue_path({ next });
+        }, table_i, force_fixed_seed);
+        if (outgoing.empty()) return;
+        if (outgoing.size() == 1) {
+            // "Assume that annotations are preserved in unitigs. Violations of this assumption are corrected after the
+            // next flush"
+            const auto &[next, c, score] = outgoing[0];
+            node_labels_.emplace_back(node_labels_[table_i]);
+            callback(next, c, score);
+            return;
+        }
+        flush();
+        if (!node_labels_[table_i]) return;
+        const Columns columns = ab_->get_cached_column_set(node_labels_[table_i]);     // (copy: the set may grow below)
+        for (const auto &[next, c, score] : outgoing) {
+            const Columns *next_labels = ab_->get_labels(next);
+            if (!next_labels) throw std::logic_error("oracle: call_outgoing(): labels of a child were not fetched");
+            Columns intersect_labels;
+            std::set_intersection(columns.begin(), columns.end(), next_labels->begin(), next_labels->end(),
+                                  std::back_inserter(intersect_labels));
+            if (intersect_labels.size()) {
+                node_labels_.push_back(ab_->cache_column_set(std::move(intersect_labels)));
+                callback(next, c, score);
+            }
+        }
+    }
+
+    // terminate_backtrack_start (hpp:178-180 / aligner_labeled.hpp:49-52)
+    bool terminate_backtrack_start(const std::vector<Alignment> &extensions) const {
+        return ab_ ? !remaining_labels_i_ : extensions.size() >= config_.num_alternative_paths;
+    }
+    // skip_backtrack_start (hpp:183-185 / aligner_labeled.cpp:304-326)
+    bool skip_backtrack_start(size_t i) {
+        if (!prev_starts.emplace(i).second) return true;
+        if (!ab_) return false;
+        const Columns &end_labels = ab_->get_cached_column_set(node_labels_[i]);
+        const Columns &left_labels = ab_->get_cached_column_set(remaining_labels_i_);
+        label_intersection_.clear();
+        label_diff_.clear();
+        // utils::set_intersection_difference (common/algorithms.hpp:160-180): a & b, a - b
+        auto a = left_labels.begin(), a_end = left_labels.end();
+        auto b = end_labels.begin(), b_end = end_labels.end();
+        while (a != a_end) {
+            if (b == b_end || *a < *b) { label_diff_.push_back(*a); ++a; }
+            else if (*a > *b) { ++b; }
+            else { label_intersection_.push_back(*a); ++a; ++b; }
+        }
+        label_diff_.push_back(kNannot);
+        return label_intersection_.empty();
+    }
+    // call_alignments (hpp:200-214 / aligner_labeled.cpp:328-448 without coordinates)
+    void call_alignments(Alignment &&alignment, std::vector<Alignment> &extensions) {
+        if (ab_) {
+            alignment.label_columns = std::move(label_intersection_);
+            label_intersection_ = Columns{};
+            if (label_diff_.size() && label_diff_.back() == kNannot) {
+                label_diff_.pop_back();
+                remaining_labels_i_ = ab_->cache_column_set(std::move(label_diff_));
+                label_diff_ = Columns{};
+            }
+        }
+        extensions.emplace_back(std::move(alignment));
     }
 
     void table_emplace(Column &&col) {
@@ -1053,10 +1260,13 @@ class Extender {
                     prev_end = e + col.trim;
                     if (prev_end <= begin) continue;
 
-                    call_outgoing(col.node, [&](node_t next, char c, score_t s) {
+                    const node_t col_node = col.node;      // (a flush inside the labeled call may not move `col`, but keep a copy)
+                    auto collect = [&](node_t next, char c, score_t s) {
                         c = toupper((unsigned char)c);
                         outgoing.emplace_back(next, c, s);
-                    }, i, force_fixed_seed);
+                    };
+                    if (ab_) call_outgoing_labeled(col_node, collect, i, force_fixed_seed);
+                    else call_outgoing(col_node, collect, i, force_fixed_seed);
 
                     if (outgoing.empty()) { tips.push_back(i); continue; }
                 }
@@ -1102,8 +1312,8 @@ class Extender {
                     score_t max_val = cur.S[cur.max_pos - cur.trim];
                     // target_length == 0: offset - seed_offset >= 1 always, so has_extension is left as computed
 
-                    if (!in_seed && max_val < xdrop_cutoff) { table.pop_back(); continue; }
-                    if (!in_seed && !has_extension) { table.pop_back(); continue; }
+                    if (!in_seed && max_val < xdrop_cutoff) { pop(table.size() - 1); continue; }
+                    if (!in_seed && !has_extension) { pop(table.size() - 1); continue; }
 
                     table_sizediff = table_cap_table() - table_sizediff;
                     table_size_bytes_ += kSizeofColumn * table_sizediff
@@ -1142,6 +1352,7 @@ class Extender {
     std::vector<Alignment> backtrack(score_t min_path_score, std::string_view window, score_t right_end_bonus,
                                      const std::vector<size_t> &tips, size_t k) {
         // aligner_extender_methods.cpp:800-1034 with target_node = npos
+        if (ab_) flush();                               // LabeledExtender::backtrack (aligner_labeled.hpp:32-43)
         std::vector<Alignment> extensions;
         size_t seed_clipping = seed_->get_clipping();
         ssize_t_ seed_offset = static_cast<ssize_t_>(seed_->offset) - 1;
@@ -1189,9 +1400,9 @@ class Extender {
             std::pop_heap(indices.begin(), rit.base());
             const auto [start_score, neg_off_diag, neg_j_start, start_pos] = *rit;
             (void)neg_off_diag;
-            if (extensions.size() >= config_.num_alternative_paths) break;
+            if (terminate_backtrack_start(extensions)) break;
             size_t j = -neg_j_start;
-            if (!prev_starts.emplace(j).second) continue;
+            if (skip_backtrack_start(j)) continue;
 
             std::vector<node_t> path;
             std::vector<size_t> trace;
@@ -1275,8 +1486,8 @@ class Extender {
                         && (!pos || cur_cell_score == 0)
                         && (pos || cur_cell_score == table[0].S[0])
                         && (config_.allow_left_trim || !j)) {
-                    extensions.emplace_back(construct_alignment(ops, pos, window.substr(pos, end_pos - pos),
-                                                                path, seq, score, align_offset, extra_score));
+                    call_alignments(construct_alignment(ops, pos, window.substr(pos, end_pos - pos),
+                                                        path, seq, score, align_offset, extra_score), extensions);
                 }
             }
         }
@@ -1370,7 +1581,391 @@ void align_core(std::vector<Alignment> seeds, Extender &extender,
     }
 }
 
+// =============================================================================================
+// AlignmentAggregator with labels (A/aligner_aggregator.hpp:24-206): one queue per label + the global one
+// =============================================================================================
+class LabeledAggregator {
+    typedef std::shared_ptr<Alignment> Ptr;
+    typedef std::vector<Ptr> Queue;                      // PriorityDeque: only its minimum / maximum / content are observable
+  public:
+    explicit LabeledAggregator(const mgx_config &config) : config_(config) {}
+
+    // :68-138; returns true if the alignment was added
+    bool add_alignment(Alignment &&alignment) {
+        auto a = std::make_shared<Alignment>(std::move(alignment));
+        if (unlabeled_.empty()) {
+            unlabeled_.push_back(a);
+            for (Label c : a->label_columns) queue_of(c).push_back(a);
+            return true;
+        }
+        if (a->score < get_global_cutoff()) return false;
+        auto push_to_queue = [&](Queue &queue) {
+            for (const auto &aln : queue) if (*a == *aln) return false;       // (post_chain_alignments == false)
+            if (queue.size() < config_.num_alternative_paths) { queue.push_back(a); return true; }
+            auto min_it = minimum(queue);
+            if (cmp_(*a, **min_it)) return false;
+            *min_it = a;                                 // queue.update(queue.begin(), a): the minimum is replaced
+            return true;
+        };
+        if (a->label_columns.empty()) return push_to_queue(unlabeled_);
+        if (path_queue_.empty()) {
+            // the first labeled alignment: the global queue only serves the global cut-off from now on (:110-117)
+            if (unlabeled_.size() > 1) {
+                Ptr mx = *maximum(unlabeled_);
+                unlabeled_.clear();
+                unlabeled_.push_back(std::move(mx));
+            }
+        }
+        bool added = false;
+        for (Label c : a->label_columns) added |= push_to_queue(queue_of(c));
+        if (!added) return false;
+        if (!cmp_(*a, **maximum(unlabeled_))) *minimum(unlabeled_) = a;       // update(begin(), a) on a one-element queue
+        return true;
+    }
+
+    score_t get_global_cutoff() const {                  // :141-149
+        if (unlabeled_.empty()) return NINF;
+        score_t cur_max = (*maximum(unlabeled_))->score;
+        return cur_max > 0 ? cur_max * config_.rel_score_cutoff : cur_max;
+    }
+    score_t get_score_cutoff(const Columns &labels) const {      // :152-166
+        score_t global_min = get_global_cutoff();
+        score_t min_score = std::numeric_limits<score_t>::max();
+        for (Label label : labels) {
+            min_score = std::min(min_score, get_label_cutoff(label));
+            if (min_score < global_min) return global_min;
+        }
+        return min_score;
+    }
+    size_t num_aligned_labels() const { return path_queue_.size(); }
+
+    std::vector<Alignment> get_alignments() {            // :180-202
+        std::vector<Ptr> ptrs;
+        for (const auto &entry : path_queue_) std::copy(entry.second.begin(), entry.second.end(), std::back_inserter(ptrs));
+        std::copy(unlabeled_.begin(), unlabeled_.end(), std::back_inserter(ptrs));
+        path_queue_.clear();
+        unlabeled_.clear();
+        // std::sort in the reference; equal alignments are the same object or compare equal in every reported field but the
+        // labels, and a moved-from duplicate is dropped below, so the order among equals only shows when two DIFFERENT
+        // alignments tie under LocalAlignmentLess (unpinned upstream, like the unlabeled case)
+        std::stable_sort(ptrs.begin(), ptrs.end(), [&](const Ptr &x, const Ptr &y) { return cmp_(*x, *y); });
+        std::vector<Alignment> out;
+        for (auto it = ptrs.rbegin(); it != ptrs.rend(); ++it) {
+            if ((*it)->size()) {
+                out.emplace_back(std::move(**it));
+                **it = Alignment();
+            }
+        }
+        return out;
+    }
+
+  private:
+    const mgx_config &config_;
+    std::vector<std::pair<Label, Queue>> path_queue_;   // VectorMap<Label, PathQueue>: insertion order
+    Queue unlabeled_;
+    LocalAlignmentLess cmp_;
+
+    Queue &queue_of(Label c) {
+        for (auto &e : path_queue_) if (e.first == c) return e.second;
+        path_queue_.emplace_back(c, Queue{});
+        return path_queue_.back().second;
+    }
+    const Queue *find_queue(Label c) const {
+        for (const auto &e : path_queue_) if (e.first == c) return &e.second;
+        return nullptr;
+    }
+    Queue::iterator minimum(Queue &q) const {
+        return std::min_element(q.begin(), q.end(), [&](const Ptr &x, const Ptr &y) { return cmp_(*x, *y); });
+    }
+    Queue::const_iterator maximum(const Queue &q) const {
+        return std::max_element(q.begin(), q.end(), [&](const Ptr &x, const Ptr &y) { return cmp_(*x, *y); });
+    }
+    Queue::iterator maximum(Queue &q) const {
+        return std::max_element(q.begin(), q.end(), [&](const Ptr &x, const Ptr &y) { return cmp_(*x, *y); });
+    }
+    score_t get_label_cutoff(Label label) const {       // :168-177
+        const Queue *q = find_queue(label);
+        if (!q || q->size() < config_.num_alternative_paths) return NINF;
+        return (*std::min_element(q->begin(), q->end(), [&](const Ptr &x, const Ptr &y) { return cmp_(*x, *y); }))->score;
+    }
+};
+
+// filter_seed (A/dbg_aligner.cpp:105-149, no coordinates): a seed that check_seed rejected keeps only the labels the
+// previous seed did not have
+void filter_seed_labeled(const Alignment &prev, Alignment &a) {
+    if (prev.label_columns.empty()) { a = Alignment(); return; }
+    Columns diff;
+    std::set_difference(a.label_columns.begin(), a.label_columns.end(), prev.label_columns.begin(), prev.label_columns.end(),
+                        std::back_inserter(diff));
+    if (diff.empty()) a = Alignment();
+    else std::swap(a.label_columns, diff);
+}
+
+// align_core (A/dbg_aligner.cpp:360-384) with labeled seeds
+void align_core_labeled(std::vector<Alignment> seeds, Extender &extender,
+                        const std::function<void(Alignment &&)> &callback,
+                        const std::function<score_t(const Alignment &)> &get_min_path_score,
+                        bool force_fixed_seed) {
+    for (size_t i = 0; i < seeds.size(); ++i) {
+        if (seeds[i].empty()) continue;
+        score_t min_path_score = get_min_path_score(seeds[i]);
+        for (auto &&ext : extender.get_extensions(seeds[i], min_path_score, force_fixed_seed)) callback(std::move(ext));
+        for (size_t j = i + 1; j < seeds.size(); ++j)
+            if (seeds[j].size() && !extender.check_seed(seeds[j])) filter_seed_labeled(seeds[i], seeds[j]);
+    }
+}
+
+// get_num_char_matches_in_seeds (A/alignment.hpp:100-127).  Quirk kept: `aln` refers to the seed that has the offset, so the
+// inner loop's condition does not change and runs to the end — nothing after the first sub-k seed is counted.
+size_t get_num_char_matches_in_seeds(const std::vector<Seed> &seeds) {
+    size_t num_matching = 0, last_q_end = 0;
+    for (size_t i = 0; i < seeds.size(); ++i) {
+        const Seed &aln = seeds[i];
+        if (aln.nodes.empty()) continue;
+        size_t q_begin = aln.clipping, q_end = q_begin + aln.query_view.size();
+        if (q_end > last_q_end) {
+            num_matching += q_end - q_begin;
+            if (q_begin < last_q_end) num_matching -= last_q_end - q_begin;
+        }
+        if (aln.offset) i = seeds.size() - 1;
+        last_q_end = q_end;
+    }
+    return num_matching;
+}
+
 } // namespace
+
+// =============================================================================================
+// Annotation (ColumnMajor get_rows, AnnotatedDBG::annotate_sequence)
+// =============================================================================================
+std::vector<Columns> Annotation::get_rows(const std::vector<uint64_t> &rows) const {
+    // column_major.cpp:27-44: for every column, for every requested row: test the bit
+    std::vector<Columns> out(rows.size());
+    for (size_t j = 0; j < columns.size(); ++j)
+        for (size_t i = 0; i < rows.size(); ++i)
+            if (rows[i] < n_rows && get(rows[i], j)) out[i].push_back(j);
+    return out;
+}
+
+void Annotation::annotate_sequence(const Graph &graph, std::string_view sequence, size_t column) {
+    // annotated_dbg.cpp:55-75: graph_->map_to_nodes(sequence, [&](node_index i) { if (i > 0) indices.push_back(graph_to_anno_index(i)); })
+    // BASIC graphs: map_to_nodes == map_to_nodes_sequentially; a PRIMARY graph is annotated through its CanonicalDBG wrapper
+    // (CanonicalDBG::map_to_nodes reports base nodes, canonical_dbg.cpp:148-154)
+    if (graph.mode == CANONICAL) throw std::runtime_error("oracle: annotating CANONICAL-mode graphs is not restated");
+    std::vector<node_t> nodes;
+    if (graph.mode == PRIMARY) {
+        CanonicalView canon(graph);
+        nodes = canon.map_to_nodes_sequentially(sequence);
+        for (node_t &v : nodes) v = canon.get_base_node(v);
+    } else {
+        nodes = graph.map_to_nodes_sequentially(sequence);
+    }
+    for (node_t v : nodes) if (v > 0) set(v - 1, column);
+}
+
+// =============================================================================================
+// LabeledAligner (A/aligner_labeled.cpp:450-721 + DBGAligner::align_batch / align_both_directions with labeled seeds)
+// =============================================================================================
+LabeledAligner::LabeledAligner(const Graph &graph, const mgx_config &config, const Annotation &annotation)
+      : graph_(graph), config_(config), annotation_(annotation) {
+    // DBGAligner ctor (dbg_aligner.cpp:33-61) ...
+    size_t k = graph_.get_k();
+    if (!config_.min_seed_length) config_.min_seed_length = k;
+    if (!config_.max_seed_length) config_.max_seed_length = k;
+    uint64_t lo = std::min(config_.min_seed_length, config_.max_seed_length);
+    uint64_t hi = std::max(config_.min_seed_length, config_.max_seed_length);
+    config_.min_seed_length = lo;
+    config_.max_seed_length = hi;
+    if (!check_config_scores(config_))
+        throw std::runtime_error("Error: sum of min_cell_score and lowest penalty too low.");
+    if (config_.chain_alignments || config_.post_chain_alignments || !config_.global_xdrop || config_.no_backtrack)
+        throw std::runtime_error("oracle: chaining / per-branch xdrop / no_backtrack are out of scope");
+    // ... then LabeledAligner's (aligner_labeled.cpp:463-465; no coordinates: no chaining)
+    config_.min_seed_length = std::min<uint64_t>(k, config_.min_seed_length);
+    config_.max_seed_length = std::min<uint64_t>(k, config_.max_seed_length);
+}
+
+AlignmentResults LabeledAligner::align(std::string_view query) const {
+    std::vector<AlignmentResults> res;
+    align_batch({ std::string(query) }, &res);
+    return std::move(res[0]);
+}
+
+namespace {
+// LabeledAligner::filter_seeds (aligner_labeled.cpp:612-721, no coordinates); returns the new num_matching
+size_t filter_seeds(std::vector<Seed> &seeds, const AnnotationBuffer &ab, const mgx_config &config, size_t k) {
+    if (seeds.empty()) return 0;
+    size_t query_size = seeds[0].clipping + seeds[0].end_clipping + seeds[0].query_view.size();
+    Columns labels;
+    {
+        std::vector<std::pair<Label, std::vector<bool>>> label_mapper;          // VectorMap: insertion order
+        auto indicator_of = [&](Label c) -> std::vector<bool> & {
+            for (auto &e : label_mapper) if (e.first == c) return e.second;
+            label_mapper.emplace_back(c, std::vector<bool>());
+            return label_mapper.back().second;
+        };
+        for (const Seed &seed : seeds) {
+            size_t end = seed.clipping + k - seed.offset;
+            const Columns *node_labels = ab.get_labels(seed.nodes[0]);
+            if (!node_labels) throw std::logic_error("oracle: filter_seeds(): seed labels not fetched");
+            for (Label label : *node_labels) {
+                std::vector<bool> &indicator = indicator_of(label);
+                if (indicator.empty()) indicator.assign(query_size, false);
+                for (size_t i = seed.clipping; i < end; ++i) indicator[i] = true;
+            }
+        }
+        if (label_mapper.empty()) { seeds.clear(); return 0; }
+        std::vector<std::pair<Label, uint64_t>> label_counts;
+        for (const auto &e : label_mapper)
+            label_counts.emplace_back(e.first, (uint64_t)std::count(e.second.begin(), e.second.end(), true));
+        // std::sort(..., utils::GreaterSecond()): only the SET of labels at or above the cut-off is used afterwards
+        std::stable_sort(label_counts.begin(), label_counts.end(), [](const auto &a, const auto &b) { return a.second > b.second; });
+        double cutoff = config.min_exact_match * query_size;
+        auto it = std::find_if(label_counts.begin(), label_counts.end(), [cutoff](const auto &a) { return a.second < cutoff; });
+        label_counts.erase(it, label_counts.end());
+        for (const auto &lc : label_counts) labels.push_back(lc.first);
+    }
+    if (labels.empty()) { seeds.clear(); return 0; }
+    std::sort(labels.begin(), labels.end());
+    for (Seed &seed : seeds) {
+        if (!seed.has_label_encoder) {
+            seed.label_columns.clear();
+            const Columns *fetch_labels = ab.get_labels(seed.nodes[0]);
+            std::set_intersection(fetch_labels->begin(), fetch_labels->end(), labels.begin(), labels.end(),
+                                  std::back_inserter(seed.label_columns));
+            if (seed.label_columns.size()) seed.has_label_encoder = true;
+        }
+    }
+    seeds.erase(std::remove_if(seeds.begin(), seeds.end(),
+                               [](const Seed &a) { return !a.has_label_encoder || a.label_columns.empty(); }), seeds.end());
+    return get_num_char_matches_in_seeds(seeds);
+}
+} // namespace
+
+void LabeledAligner::align_batch(const std::vector<std::string> &queries, std::vector<AlignmentResults> *results) const {
+    results->clear();
+    results->resize(queries.size());
+    const size_t k = graph_.get_k();
+    const CanonicalView canon_store(graph_);
+    const CanonicalView *canon = graph_.mode == PRIMARY ? &canon_store : nullptr;
+    const GraphView gview{ &graph_, false, canon };
+    const bool canonical_mode = graph_.mode == CANONICAL || canon;
+    AnnotationBuffer annotation_buffer(graph_, canon, annotation_);              // aligner member, shared by the batch
+
+    // build_seeders (dbg_aligner.cpp:193-248) for the whole batch, then the label filter (aligner_labeled.cpp:479-558)
+    struct QuerySeeds { std::vector<Seed> fwd, rc; size_t nm_fwd = 0, nm_rc = 0; bool has_rc = false; };
+    std::vector<QuerySeeds> batch(queries.size());
+    for (size_t qi = 0; qi < queries.size(); ++qi) {
+        const std::string &raw = queries[qi];
+        AlignmentResults &res = (*results)[qi];
+        res.query.reserve(std::max<size_t>(raw.size(), 32) + 8);
+        for (char ch : raw) { int8_t c = (int8_t)ch; res.query.push_back(c >= 0 ? (char)toupper(c) : (char)127); }
+        res.query_rc.reserve(res.query.capacity());
+        res.query_rc = res.query;
+        reverse_complement_inplace(res.query_rc);
+        std::string_view this_query = res.query, reverse = res.query_rc;
+        std::vector<node_t> nodes;
+        if (config_.max_seed_length >= k) nodes = gview.map_to_nodes_sequentially(raw);
+        else if (this_query.size() >= k) nodes.resize(this_query.size() - k + 1);
+        SeederState seeder = make_suffix_seeder(gview, this_query, false, nodes, config_, nullptr);
+        if (this_query.size() * config_.min_exact_match > seeder.num_matching) { seeder.seeds.clear(); seeder.num_matching = 0; }
+        QuerySeeds &qs = batch[qi];
+        qs.fwd = std::move(seeder.seeds); qs.nm_fwd = seeder.num_matching;
+        qs.has_rc = config_.forward_and_reverse_complement || canonical_mode;
+        if (qs.has_rc) {
+            std::vector<node_t> nodes_rc = nodes;
+            if (config_.max_seed_length >= k) { std::string dummy(raw); gview.reverse_complement_seq_path(dummy, nodes_rc); }
+            SeederState seeder_rc = make_suffix_seeder(gview, reverse, true, nodes_rc, config_, nullptr);
+            if (reverse.size() * config_.min_exact_match > seeder_rc.num_matching) { seeder_rc.seeds.clear(); seeder_rc.num_matching = 0; }
+            qs.rc = std::move(seeder_rc.seeds); qs.nm_rc = seeder_rc.num_matching;
+        }
+        for (const Seed &seed : qs.fwd) annotation_buffer.queue_path(std::vector<node_t>(seed.nodes));
+        for (const Seed &seed : qs.rc) annotation_buffer.queue_path(std::vector<node_t>(seed.nodes));
+    }
+    annotation_buffer.fetch_queued_annotations();
+    for (QuerySeeds &qs : batch) {
+        if (qs.fwd.size()) qs.nm_fwd = filter_seeds(qs.fwd, annotation_buffer, config_, k);
+        if (qs.has_rc && qs.rc.size()) qs.nm_rc = filter_seeds(qs.rc, annotation_buffer, config_, k);
+    }
+
+    // DBGAligner::align_batch (dbg_aligner.cpp:263-355)
+    for (size_t qi = 0; qi < queries.size(); ++qi) {
+        AlignmentResults &res = (*results)[qi];
+        QuerySeeds &qs = batch[qi];
+        std::string_view this_query = res.query, reverse = res.query_rc;
+        res.seeds_fwd = qs.fwd; res.seeds_rc = qs.rc;
+        res.num_matches_fwd = qs.nm_fwd; res.num_matches_rc = qs.nm_rc;
+        LabeledAggregator aggregator(config_);
+        auto add_alignment = [&](Alignment &&a) { aggregator.add_alignment(std::move(a)); };
+        auto get_min_path_score = [&](const Alignment &seed) {
+            return std::max(config_.min_path_score, seed.label_columns.size() ? aggregator.get_score_cutoff(seed.label_columns)
+                                                                              : aggregator.get_global_cutoff());
+        };
+        Extender extender(graph_, config_, this_query, nullptr, canon, &annotation_buffer);
+        if (qs.has_rc) {
+            Extender extender_rc(graph_, config_, reverse, nullptr, canon, &annotation_buffer);
+            auto fwd_seeds = seeds_to_alignments(qs.fwd, config_);
+            auto bwd_seeds = seeds_to_alignments(qs.rc, config_);
+            // align_both_directions (dbg_aligner.cpp:531-758), the branch without chaining
+            auto aln_both = [&](std::string_view query, std::string_view query_rc, std::vector<Alignment> &&seeds,
+                                Extender &fwd_extender, Extender &bwd_extender) {
+                const bool use_rcdbg = !canonical_mode && config_.forward_and_reverse_complement;
+                auto is_reversible = [&](const Alignment &a) { return canonical_mode && a.orientation && !a.offset; };
+                fwd_extender.set_graph(false);
+                bwd_extender.set_graph(use_rcdbg);
+                const GraphView plain = gview;
+                if (seeds.empty()) return;
+                for (size_t i = 0; i < seeds.size(); ++i) {
+                    if (seeds[i].empty()) continue;
+                    score_t min_path_score = config_.min_cell_score;
+                    auto extensions = fwd_extender.get_extensions(seeds[i], min_path_score, false);
+                    std::vector<Alignment> rc_of_alignments;
+                    for (Alignment &path : extensions) {
+                        if (path.score >= get_min_path_score(path)) {
+                            if (is_reversible(path)) {
+                                Alignment out_path = path;
+                                out_path.reverse_complement(plain, query_rc);
+                                add_alignment(std::move(out_path));
+                            } else {
+                                add_alignment(Alignment(path));
+                            }
+                        }
+                        if (!path.get_clipping() || path.offset) continue;
+                        path.reverse_complement(bwd_extender.view(), query_rc);
+                        if (path.empty()) continue;
+                        rc_of_alignments.emplace_back(std::move(path));
+                    }
+                    align_core_labeled(std::move(rc_of_alignments), bwd_extender,
+                        [&](Alignment &&path) {
+                            if (use_rcdbg || is_reversible(path)) {
+                                path.reverse_complement(bwd_extender.view(), query);
+                                if (path.empty()) return;
+                                for (node_t node : path.nodes)
+                                    fwd_extender.filter_nodes(node, path.get_clipping(), query.size() - path.get_end_clipping());
+                            }
+                            add_alignment(std::move(path));
+                        },
+                        get_min_path_score, true);
+                    for (size_t j = i + 1; j < seeds.size(); ++j)
+                        if (seeds[j].size() && !fwd_extender.check_seed(seeds[j])) filter_seed_labeled(seeds[i], seeds[j]);
+                }
+            };
+            size_t fwd_num_matches = qs.nm_fwd, bwd_num_matches = qs.nm_rc;
+            if (fwd_num_matches >= bwd_num_matches) {
+                aln_both(this_query, reverse, std::move(fwd_seeds), extender, extender_rc);
+                if (bwd_num_matches >= fwd_num_matches * config_.rel_score_cutoff)
+                    aln_both(reverse, this_query, std::move(bwd_seeds), extender_rc, extender);
+            } else {
+                aln_both(reverse, this_query, std::move(bwd_seeds), extender_rc, extender);
+                if (fwd_num_matches >= bwd_num_matches * config_.rel_score_cutoff)
+                    aln_both(this_query, reverse, std::move(fwd_seeds), extender, extender_rc);
+            }
+        } else {
+            align_core_labeled(seeds_to_alignments(qs.fwd, config_), extender, add_alignment, get_min_path_score, false);
+        }
+        res.alignments = aggregator.get_alignments();
+    }
+}
 
 uint64_t g_oob_reads_total() { return g_oob_reads.load(); }
 

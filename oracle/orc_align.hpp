@@ -41,6 +41,9 @@ struct Cigar {
     bool operator==(const Cigar &o) const { return ops == o.ops; }
 };
 
+typedef uint64_t Label;                      // annotation column = label id (annot::matrix::BinaryMatrix::Column)
+typedef std::vector<Label> Columns;          // Alignment::Columns: a sorted label set
+
 // A/alignment.hpp:32-98
 struct Seed {
     std::string_view query_view;
@@ -48,6 +51,8 @@ struct Seed {
     bool orientation = false;
     size_t offset = 0;
     uint32_t clipping = 0, end_clipping = 0;
+    Columns label_columns;                   // :84 (filled by LabeledAligner::filter_seeds)
+    bool has_label_encoder = false;          // :82 label_encoder != nullptr
 };
 
 // A/alignment.hpp:132-331
@@ -60,6 +65,7 @@ struct Alignment {
     score_t score = 0;
     Cigar cigar;
     score_t extra_score = 0;
+    Columns label_columns;                   // alignment.hpp:285 (coordinates: not restated)
 
     Alignment() {}
     Alignment(std::string_view query, std::vector<node_t> &&nodes_, std::string &&seq, score_t score_,
@@ -129,6 +135,39 @@ class Aligner {
   private:
     const Graph &graph_;
     mgx_config config_;
+};
+
+// The annotation as the aligner sees it: a binary matrix rows x columns, row = node - 1
+// (AnnotatedDBG::graph_to_anno_index, annotated_dbg.hpp:50-52), column = label.  Restated as ColumnMajor
+// (annotation/binary_matrix/column_sparse/column_major.cpp:27-44: get_rows tests every column's bit vector at every
+// requested row) on plain 64-bit words — one word holds 64 consecutive rows of one label.
+struct Annotation {
+    uint64_t n_rows = 0;
+    std::vector<std::vector<uint64_t>> columns;
+    void resize(uint64_t rows, size_t n_columns) { n_rows = rows; columns.assign(n_columns, std::vector<uint64_t>((rows + 63) / 64, 0)); }
+    void set(uint64_t row, size_t column) { columns[column][row >> 6] |= 1ull << (row & 63); }
+    bool get(uint64_t row, size_t column) const { return (columns[column][row >> 6] >> (row & 63)) & 1; }
+    std::vector<Columns> get_rows(const std::vector<uint64_t> &rows) const;      // column_major.cpp:27-44 (labels ascending)
+    // AnnotatedDBG::annotate_sequence (annotated_dbg.cpp:55-75): every k-mer of `sequence` found in the graph gets `column`
+    void annotate_sequence(const Graph &graph, std::string_view sequence, size_t column);
+};
+
+// LabeledAligner<SuffixSeeder<ExactSeeder>, LabeledExtender, LocalAlignmentLess> (A/aligner_labeled.{hpp,cpp}), annotation
+// without coordinates: seeds are filtered by label (build_seeders :479-558, filter_seeds :612-721), every column of the DP
+// table carries a label set that is intersected along the tree (LabeledExtender::call_outgoing :176-302, flush :81-137),
+// backtracking reports one alignment per not-yet-seen seed label set (skip_backtrack_start :304-326, call_alignments
+// :328-448), the aggregator keeps a queue per label (aligner_aggregator.hpp:68-138).
+class LabeledAligner {
+  public:
+    LabeledAligner(const Graph &graph, const mgx_config &config, const Annotation &annotation);   // aligner_labeled.cpp:450-466
+    const mgx_config &get_config() const { return config_; }
+    void align_batch(const std::vector<std::string> &queries, std::vector<AlignmentResults> *results) const;
+    AlignmentResults align(std::string_view query) const;
+
+  private:
+    const Graph &graph_;
+    mgx_config config_;
+    const Annotation &annotation_;
 };
 
 // cli/align.cpp:254-285 + fmt formatter alignment.hpp:426-433

@@ -34,6 +34,8 @@ struct ResultStore {
     std::string tsv;
     WorkCounters wc;
     std::string error;
+    // label-aware runs: the label set of every alignment (same order as `alignments`)
+    std::vector<uint64_t> label_begin, labels;
 };
 
 void flatten(const std::vector<AlignmentResults> &res, ResultStore *st, int32_t min_path_score) {
@@ -53,6 +55,9 @@ void flatten(const std::vector<AlignmentResults> &res, ResultStore *st, int32_t 
             for (auto &op : a.cigar.ops) { mgx_cigar_op o; std::memset(&o, 0, sizeof(o)); o.len = op.second; o.op = op.first; st->cigar.push_back(o); }
             st->seqs += a.sequence;
             st->alignments.push_back(m);
+            if (st->label_begin.empty()) st->label_begin.push_back(0);
+            st->labels.insert(st->labels.end(), a.label_columns.begin(), a.label_columns.end());
+            st->label_begin.push_back(st->labels.size());
         }
         st->aln_begin.push_back(st->alignments.size());
         st->status.push_back(MGX_OK);
@@ -279,6 +284,72 @@ void *orc_align_batch(void *h, const mgx_config *config, const char *seqs, const
         st->error = e.what();
     }
     return st;
+}
+
+// ---- label-aware alignment (LabeledAligner, A/aligner_labeled.{hpp,cpp}; annotation without coordinates) ----
+void *orc_annotation_create(void *graph, uint32_t n_labels) {
+    auto *g = static_cast<Graph *>(graph);
+    auto *a = new Annotation();
+    a->resize(g->boss.n, n_labels);                      // rows = graph_to_anno_index(max_index) + 1
+    return a;
+}
+void orc_annotation_free(void *a) { delete static_cast<Annotation *>(a); }
+// AnnotatedDBG::annotate_sequence(sequence, { label })
+int orc_annotation_annotate(void *a, void *graph, const char *seq, uint32_t len, uint32_t label, char *err, uint32_t err_cap) {
+    try { static_cast<Annotation *>(a)->annotate_sequence(*static_cast<Graph *>(graph), std::string_view(seq, len), label); }
+    catch (const std::exception &e) { if (err && err_cap) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; } return 1; }
+    return 0;
+}
+void orc_annotation_set(void *a, uint64_t row, uint32_t label) { static_cast<Annotation *>(a)->set(row, label); }
+// BinaryMatrix::get_rows for `n` rows: out_begin[n + 1], labels appended to out_labels (capacity cap); returns the label count
+uint64_t orc_annotation_get_rows(void *a, const uint64_t *rows, uint64_t n, uint64_t *out_begin, uint64_t *out_labels, uint64_t cap) {
+    std::vector<uint64_t> r(rows, rows + n);
+    auto res = static_cast<Annotation *>(a)->get_rows(r);
+    uint64_t total = 0;
+    out_begin[0] = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        for (uint64_t l : res[i]) { if (total < cap) out_labels[total] = l; ++total; }
+        out_begin[i + 1] = total;
+    }
+    return total;
+}
+const uint64_t *orc_annotation_column_words(void *a, uint32_t label, uint64_t *n_words) {
+    auto *an = static_cast<Annotation *>(a);
+    *n_words = an->columns[label].size();
+    return an->columns[label].data();
+}
+void *orc_align_batch_labeled(void *h, const mgx_config *config, void *annotation, const char *seqs, const uint64_t *offsets,
+                              uint64_t n, int validate) {
+    auto *g = static_cast<Graph *>(h);
+    auto *st = new ResultStore();
+    try {
+        LabeledAligner aligner(*g, *config, *static_cast<Annotation *>(annotation));
+        std::vector<std::string> queries(n);
+        for (uint64_t i = 0; i < n; ++i) queries[i].assign(seqs + offsets[i], seqs + offsets[i + 1]);
+        std::vector<AlignmentResults> res(n);
+        aligner.align_batch(queries, &res);
+        if (validate) {
+            const CanonicalView canon(*g);
+            GraphView view{ g, false, g->mode == PRIMARY ? &canon : nullptr };
+            const mgx_config &cfg = aligner.get_config();
+            for (uint64_t i = 0; i < n; ++i)
+                for (auto &a : res[i].alignments) {
+                    std::string why;
+                    if (!a.is_valid(view, &cfg, &why)) { st->error = "query " + std::to_string(i) + ": " + why; break; }
+                }
+        }
+        flatten(res, st, config->min_path_score);
+    } catch (const std::exception &e) {
+        st->error = e.what();
+    }
+    return st;
+}
+// label sets of the alignments of a run, in the order of mgx_results.alignments
+void orc_results_labels(void *r, const uint64_t **begin, const uint64_t **labels) {
+    auto *st = static_cast<ResultStore *>(r);
+    if (st->label_begin.empty()) st->label_begin.push_back(0);
+    *begin = st->label_begin.data();
+    *labels = st->labels.data();
 }
 
 const char *orc_results_error(void *r) { return static_cast<ResultStore *>(r)->error.c_str(); }

@@ -217,3 +217,78 @@ def make_config(case_cfg, matrix, base=None):
     for key, val in case_cfg.items():
         setattr(c, key, val)
     return c
+
+
+class Annotation:
+    """ColumnMajor-style label matrix over the nodes of `graph` (oracle/orc_align.hpp, struct Annotation)."""
+
+    def __init__(self, graph, n_labels):
+        lib = L()
+        lib.orc_annotation_create.restype = C.c_void_p
+        lib.orc_annotation_create.argtypes = [C.c_void_p, C.c_uint32]
+        lib.orc_annotation_free.argtypes = [C.c_void_p]
+        lib.orc_annotation_annotate.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32]
+        lib.orc_annotation_get_rows.restype = C.c_uint64
+        lib.orc_annotation_get_rows.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint64]
+        lib.orc_annotation_column_words.restype = C.POINTER(C.c_uint64)
+        lib.orc_annotation_column_words.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+        self.graph = graph
+        self.n_labels = n_labels
+        self.h = lib.orc_annotation_create(graph.h, n_labels)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L().orc_annotation_free(self.h)
+            self.h = None
+
+    def annotate(self, seq, label):
+        """AnnotatedDBG::annotate_sequence(seq, {label})"""
+        err = C.create_string_buffer(256)
+        b = seq.encode()
+        if L().orc_annotation_annotate(self.h, self.graph.h, b, len(b), label, err, 256):
+            raise RuntimeError(err.value.decode())
+
+    def get_rows(self, rows):
+        """-> one ascending label list per requested row (row = node - 1)"""
+        n = len(rows)
+        r = (C.c_uint64 * max(1, n))(*rows)
+        begin = (C.c_uint64 * (n + 1))()
+        cap = max(1, n * self.n_labels)
+        out = (C.c_uint64 * cap)()
+        L().orc_annotation_get_rows(self.h, r, n, begin, out, cap)
+        return [[out[i] for i in range(begin[q], begin[q + 1])] for q in range(n)]
+
+    def column_words(self, label):
+        import numpy as np
+        nw = C.c_uint64()
+        p = L().orc_annotation_column_words(self.h, label, C.byref(nw))
+        return np.ctypeslib.as_array(p, shape=(nw.value,)).copy()
+
+
+class LabeledAlignRun(AlignRun):
+    """LabeledAligner<>::align_batch on the oracle; results() as AlignRun plus labels() per alignment."""
+
+    def __init__(self, graph, config, annotation, queries, validate=True):
+        lib = L()
+        lib.orc_align_batch_labeled.restype = C.c_void_p
+        lib.orc_align_batch_labeled.argtypes = [C.c_void_p, C.POINTER(capi.Config), C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64),
+                                                C.c_uint64, C.c_int]
+        blob, offs = pack_queries(queries)
+        self._keep = (blob, offs, annotation)
+        self.r = lib.orc_align_batch_labeled(graph.h, C.byref(config), annotation.h, blob,
+                                             offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(queries), int(validate))
+        self.error = lib.orc_results_error(self.r).decode()
+        self.n = len(queries)
+
+    def labels(self):
+        """-> per query: the label list of each of its alignments"""
+        v = capi.Results()
+        L().orc_results_view(self.r, C.byref(v))
+        begin = C.POINTER(C.c_uint64)()
+        labs = C.POINTER(C.c_uint64)()
+        L().orc_results_labels.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64))]
+        L().orc_results_labels(self.r, C.byref(begin), C.byref(labs))
+        out = []
+        for q in range(self.n):
+            out.append([[labs[i] for i in range(begin[a], begin[a + 1])] for a in range(v.aln_begin[q], v.aln_begin[q + 1])])
+        return out
