@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 1
+#define MGX_ABI_VERSION 2      /* 2 (round 3): mgx_annotation_*; mgx_stats / mgx_config grew in round 2 without a bump (callers built
+                                * against 1 must be rebuilt: mgx_aligner_stats writes the larger struct) */
 
 enum {
     MGX_OK = 0,
@@ -280,6 +281,31 @@ size_t mgx_format_tsv(const mgx_results *res, uint64_t query_index, const char *
  * node length (DeBruijnGraph::get_k()).  Returns the number of bytes needed (excluding NUL); writes at most buf_len bytes. */
 size_t mgx_format_json(const mgx_results *res, uint64_t query_index, const char *header,
                        const char *query, size_t query_len, uint32_t k, char *buf, size_t buf_len);
+
+/*
+ * Label-aware alignment (graph/alignment/aligner_labeled.{hpp,cpp}, annotation_buffer.{hpp,cpp}; BASELINE config 3).
+ * What runs on the device this round is the path's hot primitive: the ONE batched BinaryMatrix::get_rows of
+ * AnnotationBuffer::fetch_queued_annotations (annotation_buffer.cpp:182; ColumnMajor::get_rows,
+ * annotation/binary_matrix/column_sparse/column_major.cpp:27-44 — 1000 columns x |rows| random bit tests in the
+ * reference).  LabeledExtender's label bookkeeping itself is restated in the oracle only.
+ *
+ * mgx_annotation_create stands in for the annotator argument of LabeledAligner<>(graph, config, annotator)
+ * (aligner_labeled.hpp:125-127): the binary matrix as column bit vectors, columns[j] = ceil(n_rows / 64) words, bit r =
+ * row r carries label j; row = AnnotatedDBG::graph_to_anno_index(node) = node - 1 (graph/annotated_dbg.hpp:50-52).
+ * The device keeps it row-major (one 8-byte word per row; rows with several labels point into a label list).
+ */
+typedef struct mgx_annotation mgx_annotation;
+int mgx_annotation_create(uint64_t n_rows, uint32_t n_labels, const uint64_t *const *columns, int device, mgx_annotation **out);
+void mgx_annotation_destroy(mgx_annotation *a);
+uint64_t mgx_annotation_device_bytes(const mgx_annotation *a);
+uint64_t mgx_annotation_num_rows(const mgx_annotation *a);
+uint32_t mgx_annotation_num_labels(const mgx_annotation *a);
+/* BinaryMatrix::get_rows for a batch of rows, as CSR: labels of rows[i] = out_labels[out_begin[i] .. out_begin[i + 1]),
+ * ascending (what annotation_buffer.cpp:185 sorts into).  out_begin has n + 1 entries; `cap` = entries out_labels holds: a
+ * batch with more returns MGX_ERR_CAPACITY with the needed count in *n_labels_out (out_begin is complete, out_labels
+ * untouched).  rows_on_device / out_on_device != 0: device pointers (rows already in HBM / results left in HBM). */
+int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n, int rows_on_device,
+                            uint64_t *out_begin, uint32_t *out_labels, uint64_t cap, int out_on_device, uint64_t *n_labels_out);
 
 #ifdef __cplusplus
 }

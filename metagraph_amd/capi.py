@@ -7,6 +7,7 @@ import ctypes as C
 import os
 
 MGX_OK = 0
+MGX_ABI_VERSION = 2
 MGX_ERR_INVALID, MGX_ERR_NO_DEVICE, MGX_ERR_UNSUPPORTED, MGX_ERR_CONFIG, MGX_ERR_CAPACITY, MGX_ERR_OOM = -1, -2, -3, -4, -5, -6
 OP_CHARS = "SX=DIG"
 
@@ -152,6 +153,14 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.mgx_last_error.restype = C.c_char_p
     L.mgx_abi_version.restype = C.c_uint32
+    if L.mgx_abi_version() != MGX_ABI_VERSION:          # struct layouts (mgx_stats, mgx_config) are part of the ABI
+        raise OSError("libmgx.so has ABI version %d, this binding was written for %d: rebuild" % (L.mgx_abi_version(), MGX_ABI_VERSION))
+    L.mgx_annotation_create.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+    L.mgx_annotation_destroy.argtypes = [C.c_void_p]
+    L.mgx_annotation_device_bytes.argtypes = [C.c_void_p]
+    L.mgx_annotation_device_bytes.restype = C.c_uint64
+    L.mgx_annotation_get_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+                                          C.POINTER(C.c_uint64)]
     L.mgx_device_count.restype = C.c_int
     L.mgx_graph_create.argtypes = [C.POINTER(BossView), C.c_int, C.POINTER(C.c_void_p)]
     L.mgx_graph_destroy.argtypes = [C.c_void_p]

@@ -355,6 +355,8 @@ int mgx_device_count(void) {
     return n;
 }
 const char *mgx_last_error(void) { return g_err.c_str(); }
+// the other translation units of libmgx.so (mgx_annot.hip) report through the same thread-local message
+extern "C" void mgx_set_last_error(const char *msg) { g_err = msg ? msg : ""; }
 uint32_t mgx_abi_version(void) { return MGX_ABI_VERSION; }
 
 void mgx_config_init_default(mgx_config *c) {

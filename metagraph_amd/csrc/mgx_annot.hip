@@ -1,0 +1,256 @@
+// mgx_annot.hip — the label matrix of label-aware alignment on the device (BASELINE config 3).
+//
+// What the reference does on this path: AnnotationBuffer::fetch_queued_annotations (annotation_buffer.cpp:34-193) turns the
+// queued nodes of a whole batch into rows and calls BinaryMatrix::get_rows ONCE (:182); with a ColumnCompressed annotation
+// that is ColumnMajor::get_rows (annotation/binary_matrix/column_sparse/column_major.cpp:27-44): for every one of the ~1000
+// columns, a bit test at every requested row — 1000 random accesses per row, the hot spot of config 3.
+//
+// On the device the matrix is turned ROW-major once, at mgx_annotation_create: a row query then costs one 8-byte access
+// in the common case.  Layout (HBM):
+//     head[row]   u64   count:16 | first label:24 | offset:24+ ... see pack(): rows with <= 1 label are answered from this
+//                       word alone (in config 3 a label is a contiguous genome segment: almost every node has exactly one);
+//     more[]      u32   for rows with several labels: their labels in ascending order at head's offset.
+// Built from the caller's column bit vectors (one per label, bit r = row r, 64 rows per word — the host form of
+// ColumnMajor) by three passes of streaming kernels: count per row, exclusive scan (hipcub), fill in label order, which
+// makes every row's list ascending (the order get_rows' callers sort into, annotation_buffer.cpp:185).
+//
+// get_rows(rows[n]) -> CSR (begin[n + 1], labels[]): count kernel, scan, gather kernel — dependent random accesses only to
+// head[] (8 B per row) and, for multi-label rows, one run of more[].
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mgx.h"
+
+extern "C" void mgx_set_last_error(const char *msg);     // mgx.hip
+
+namespace {
+int afail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    mgx_set_last_error(buf);
+    return code;
+}
+#define HIP_TRY_A(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) return afail(MGX_ERR_NO_DEVICE, "%s: %s", #e, hipGetErrorString(r_)); } while (0)
+
+// head word: bits 0-15 label count (saturating at 0xFFFF = "see more[] length word"), bits 16-63 payload: the single label
+// (count == 1) or the offset of the row's list in more[] (count >= 2)
+__host__ __device__ inline uint64_t head_pack(uint32_t count, uint64_t payload) { return (uint64_t)(count > 0xFFFE ? 0xFFFF : count) | (payload << 16); }
+__host__ __device__ inline uint32_t head_count16(uint64_t h) { return (uint32_t)(h & 0xFFFF); }
+__host__ __device__ inline uint64_t head_payload(uint64_t h) { return h >> 16; }
+
+// one thread per 64-row word of ONE column: add its set bits to the rows' counts (columns are processed one launch after
+// the other, so two threads never touch the same row)
+__global__ void k_annot_count(const uint64_t *col_bits, uint64_t n_words, uint64_t n_rows, uint32_t *count) {
+    const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    uint64_t bits = col_bits[wi];
+    while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        const uint64_t row = wi * 64 + (uint64_t)b;
+        if (row < n_rows) ++count[row];
+    }
+}
+// second sweep over the columns, in label order: rows with one label keep it in the head word, the others append to their
+// list (fill[] = labels written so far)
+__global__ void k_annot_fill(const uint64_t *col_bits, uint64_t n_words, uint64_t n_rows, uint32_t label, const uint32_t *count,
+                             const uint64_t *offset, uint32_t *fill, uint64_t *head, uint32_t *more) {
+    const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    uint64_t bits = col_bits[wi];
+    while (bits) {
+        const int b = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
+        const uint64_t row = wi * 64 + (uint64_t)b;
+        if (row >= n_rows) continue;
+        const uint32_t c = count[row];
+        if (c == 1) head[row] = head_pack(1, label);
+        else { more[offset[row] + fill[row]] = label; ++fill[row]; }
+    }
+}
+// rows with several labels: count | offset; rows without: 0
+__global__ void k_annot_heads(uint64_t n_rows, const uint32_t *count, const uint64_t *offset, uint64_t *head) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t c = count[r];
+    if (c == 0) head[r] = 0;
+    else if (c >= 2) head[r] = head_pack(c, offset[r]);
+}
+// list lengths of multi-label rows only (single labels live in the head word)
+__global__ void k_annot_multi(uint64_t n_rows, const uint32_t *count, uint64_t *len) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rows) len[r] = count[r] >= 2 ? count[r] : 0;
+}
+
+// get_rows, pass 1: labels per requested row (rows >= n_rows have none, like a row past the matrix in the reference's debug
+// builds would assert; here it is an empty row)
+__global__ void k_rows_count(const uint64_t *head, const uint32_t *count, uint64_t n_rows, const uint64_t *rows, uint64_t n, uint64_t *out_cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = rows[i];
+    uint64_t c = 0;
+    if (r < n_rows) {
+        const uint64_t h = head[r];
+        c = head_count16(h);
+        if (c == 0xFFFF) c = count[r];
+    }
+    out_cnt[i] = c;
+}
+// pass 2: the labels, at the scanned offsets
+__global__ void k_rows_gather(const uint64_t *head, const uint32_t *more, uint64_t n_rows, const uint64_t *rows, uint64_t n,
+                              const uint64_t *out_begin, uint32_t *out_labels, uint64_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = rows[i];
+    if (r >= n_rows) return;
+    const uint64_t b = out_begin[i], e = out_begin[i + 1];
+    if (e == b || e > cap) return;
+    const uint64_t h = head[r];
+    if (e - b == 1) { out_labels[b] = (uint32_t)head_payload(h); return; }
+    const uint32_t *src = more + head_payload(h);
+    for (uint64_t x = 0; x < e - b; ++x) out_labels[b + x] = src[x];
+}
+} // namespace
+
+struct mgx_annotation {
+    int device = 0;
+    uint64_t n_rows = 0;
+    uint32_t n_labels = 0;
+    uint64_t n_more = 0;          // entries of more[]
+    uint64_t *head = nullptr;
+    uint32_t *count = nullptr;    // exact label count per row (rows with >= 0xFFFF labels need it; 4 B per row)
+    uint32_t *more = nullptr;
+    uint64_t bytes = 0;
+    // scratch of get_rows, grown on demand
+    uint64_t *d_rows = nullptr, *d_begin = nullptr;
+    uint32_t *d_labels = nullptr;
+    void *d_tmp = nullptr;
+    uint64_t cap_rows = 0, cap_labels = 0, cap_tmp = 0;
+};
+
+extern "C" {
+
+/* LabeledAligner<>(graph, config, annotator) takes the annotator (aligner_labeled.hpp:125-127); its binary matrix arrives
+ * here as column bit vectors: columns[j] points to ceil(n_rows / 64) words, bit r of the vector = row r has label j
+ * (row = AnnotatedDBG::graph_to_anno_index(node) = node - 1, annotated_dbg.hpp:50-52). */
+int mgx_annotation_create(uint64_t n_rows, uint32_t n_labels, const uint64_t *const *columns, int device, mgx_annotation **out) {
+    if (!out || (!columns && n_labels) || n_labels >= (1u << 24)) return afail(MGX_ERR_INVALID, "mgx_annotation_create: bad arguments");
+    if (mgx_device_count() <= device) return afail(MGX_ERR_NO_DEVICE, "HIP device %d not available", device);
+    HIP_TRY_A(hipSetDevice(device));
+    auto *A = new mgx_annotation();
+    A->device = device; A->n_rows = n_rows; A->n_labels = n_labels;
+    const uint64_t n_words = (n_rows + 63) / 64;
+    uint64_t *d_col = nullptr, *d_off = nullptr, *d_len = nullptr;
+    uint32_t *d_fill = nullptr;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_col); (void)hipFree(d_off); (void)hipFree(d_len); (void)hipFree(d_fill); (void)hipFree(d_tmp); };
+    auto bail = [&](int rc) { cleanup(); (void)hipFree(A->head); (void)hipFree(A->count); (void)hipFree(A->more); delete A; return rc; };
+#define HIP_TRY_B(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) return bail(afail(MGX_ERR_NO_DEVICE, "%s: %s", #e, hipGetErrorString(r_))); } while (0)
+    HIP_TRY_B(hipMalloc(&A->head, std::max<uint64_t>(1, n_rows) * 8));
+    HIP_TRY_B(hipMalloc(&A->count, std::max<uint64_t>(1, n_rows) * 4));
+    HIP_TRY_B(hipMemset(A->count, 0, std::max<uint64_t>(1, n_rows) * 4));
+    HIP_TRY_B(hipMalloc(&d_col, std::max<uint64_t>(1, n_words) * 8));
+    const uint32_t tb = 256;
+    const uint32_t wblocks = (uint32_t)((n_words + tb - 1) / tb), rblocks = (uint32_t)((n_rows + tb - 1) / tb);
+    for (uint32_t j = 0; j < n_labels && n_words; ++j) {
+        HIP_TRY_B(hipMemcpy(d_col, columns[j], n_words * 8, hipMemcpyHostToDevice));
+        k_annot_count<<<wblocks, tb>>>(d_col, n_words, n_rows, A->count);
+    }
+    HIP_TRY_B(hipGetLastError());
+    // offsets of the multi-label rows' lists
+    HIP_TRY_B(hipMalloc(&d_len, (n_rows + 1) * 8));
+    HIP_TRY_B(hipMalloc(&d_off, (n_rows + 1) * 8));
+    HIP_TRY_B(hipMemset(d_len, 0, (n_rows + 1) * 8));
+    if (n_rows) k_annot_multi<<<rblocks, tb>>>(n_rows, A->count, d_len);
+    size_t tmp_bytes = 0;
+    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_len, d_off, n_rows + 1));
+    HIP_TRY_B(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_len, d_off, n_rows + 1));
+    HIP_TRY_B(hipMemcpy(&A->n_more, d_off + n_rows, 8, hipMemcpyDeviceToHost));
+    HIP_TRY_B(hipMalloc(&A->more, std::max<uint64_t>(1, A->n_more) * 4));
+    HIP_TRY_B(hipMalloc(&d_fill, std::max<uint64_t>(1, n_rows) * 4));
+    HIP_TRY_B(hipMemset(d_fill, 0, std::max<uint64_t>(1, n_rows) * 4));
+    if (n_rows) k_annot_heads<<<rblocks, tb>>>(n_rows, A->count, d_off, A->head);
+    for (uint32_t j = 0; j < n_labels && n_words; ++j) {
+        HIP_TRY_B(hipMemcpy(d_col, columns[j], n_words * 8, hipMemcpyHostToDevice));
+        k_annot_fill<<<wblocks, tb>>>(d_col, n_words, n_rows, j, A->count, d_off, d_fill, A->head, A->more);
+    }
+    HIP_TRY_B(hipGetLastError());
+    HIP_TRY_B(hipDeviceSynchronize());
+#undef HIP_TRY_B
+    cleanup();
+    A->bytes = n_rows * 12 + A->n_more * 4;
+    *out = A;
+    return MGX_OK;
+}
+
+void mgx_annotation_destroy(mgx_annotation *a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    (void)hipFree(a->head); (void)hipFree(a->count); (void)hipFree(a->more);
+    (void)hipFree(a->d_rows); (void)hipFree(a->d_begin); (void)hipFree(a->d_labels); (void)hipFree(a->d_tmp);
+    delete a;
+}
+uint64_t mgx_annotation_device_bytes(const mgx_annotation *a) { return a ? a->bytes : 0; }
+uint64_t mgx_annotation_num_rows(const mgx_annotation *a) { return a ? a->n_rows : 0; }
+uint32_t mgx_annotation_num_labels(const mgx_annotation *a) { return a ? a->n_labels : 0; }
+
+/* BinaryMatrix::get_rows(rows) (annotation/binary_matrix/base/binary_matrix.hpp; ColumnMajor: column_major.cpp:27-44) for a
+ * whole batch of rows — the ONE call of AnnotationBuffer::fetch_queued_annotations (annotation_buffer.cpp:182) — answered
+ * as CSR: labels of rows[i] = out_labels[out_begin[i] .. out_begin[i + 1]), ascending.  `cap` = entries out_labels can hold;
+ * if the batch has more, nothing is written to out_labels, *n_labels_out tells how many and the call returns MGX_ERR_CAPACITY.
+ * rows_on_device / out_on_device: the pointers are device pointers (rows already in HBM, result left in HBM). */
+int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n, int rows_on_device,
+                            uint64_t *out_begin, uint32_t *out_labels, uint64_t cap, int out_on_device, uint64_t *n_labels_out) {
+    if (!a || (!rows && n) || !out_begin || (!out_labels && cap)) return afail(MGX_ERR_INVALID, "mgx_annotation_get_rows: bad arguments");
+    if (mgx_device_count() <= a->device) return afail(MGX_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY_A(hipSetDevice(a->device));
+    const uint32_t tb = 256;
+    const uint32_t blocks = (uint32_t)((n + tb - 1) / tb);
+    if (n + 1 > a->cap_rows) {
+        (void)hipFree(a->d_rows); (void)hipFree(a->d_begin); a->d_rows = a->d_begin = nullptr; a->cap_rows = 0;
+        const uint64_t want = n + 1 + n / 8;
+        HIP_TRY_A(hipMalloc(&a->d_rows, want * 8));
+        HIP_TRY_A(hipMalloc(&a->d_begin, (want + 1) * 8));
+        a->cap_rows = want;
+    }
+    const uint64_t *d_rows = rows;
+    if (!rows_on_device && n) { HIP_TRY_A(hipMemcpy(a->d_rows, rows, n * 8, hipMemcpyHostToDevice)); d_rows = a->d_rows; }
+    uint64_t *d_begin = out_on_device ? out_begin : a->d_begin;
+    // counts -> exclusive scan in place (n + 1 entries, the last one 0 before the scan)
+    HIP_TRY_A(hipMemset(d_begin + n, 0, 8));
+    if (n) k_rows_count<<<blocks, tb>>>(a->head, a->count, a->n_rows, d_rows, n, d_begin);
+    size_t tmp_bytes = 0;
+    HIP_TRY_A(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_begin, d_begin, n + 1));
+    if (tmp_bytes > a->cap_tmp) { (void)hipFree(a->d_tmp); a->d_tmp = nullptr; HIP_TRY_A(hipMalloc(&a->d_tmp, tmp_bytes + 256)); a->cap_tmp = tmp_bytes + 256; }
+    HIP_TRY_A(hipcub::DeviceScan::ExclusiveSum(a->d_tmp, tmp_bytes, d_begin, d_begin, n + 1));
+    uint64_t total = 0;
+    HIP_TRY_A(hipMemcpy(&total, d_begin + n, 8, hipMemcpyDeviceToHost));
+    if (n_labels_out) *n_labels_out = total;
+    if (!out_on_device) HIP_TRY_A(hipMemcpy(out_begin, d_begin, (n + 1) * 8, hipMemcpyDeviceToHost));
+    if (total > cap) return afail(MGX_ERR_CAPACITY, "mgx_annotation_get_rows: %llu labels, room for %llu", (unsigned long long)total, (unsigned long long)cap);
+    uint32_t *d_labels = out_labels;
+    if (!out_on_device) {
+        if (total > a->cap_labels) {
+            (void)hipFree(a->d_labels); a->d_labels = nullptr; a->cap_labels = 0;
+            HIP_TRY_A(hipMalloc(&a->d_labels, (total + total / 8 + 16) * 4));
+            a->cap_labels = total + total / 8 + 16;
+        }
+        d_labels = a->d_labels;
+    }
+    if (n && total) k_rows_gather<<<blocks, tb>>>(a->head, a->more, a->n_rows, d_rows, n, d_begin, d_labels, cap);
+    HIP_TRY_A(hipGetLastError());
+    if (!out_on_device && total) HIP_TRY_A(hipMemcpy(out_labels, d_labels, total * 4, hipMemcpyDeviceToHost));
+    else HIP_TRY_A(hipDeviceSynchronize());
+    return MGX_OK;
+}
+
+} // extern "C"
