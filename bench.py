@@ -111,13 +111,21 @@ def main():
 
     from metagraph_amd import gather as mg
 
+    gatherer = mg.ResultGatherer(dist, rank, world) if dist else None
+
     def step():
+        # Every alignment travels to rank 0 over RCCL/xGMI: fixed-size headers + the variable-length stream (~0.7 KB per read).
+        # The gather of batch i is launched asynchronously on a snapshot of the results and travels while batch i + 1 is
+        # aligned; it is waited for before the next one starts, and the last one inside the timed region (sync()).
         A.align_device(reads.data_ptr(), offsets.data_ptr(), args.reads)
         if dist:
-            # every alignment travels to rank 0 over RCCL/xGMI: fixed-size headers + the variable-length stream
-            mg.gather_device_results(A, dist, rank, world, dev)
+            gatherer.finish()
+            hdr, stream, used = mg.device_result_tensors(A, dev)
+            gatherer.start(hdr, stream, used)
 
     def sync():
+        if dist:
+            gatherer.finish()
         torch.cuda.synchronize()
         if dist:
             dist.barrier()

@@ -84,9 +84,24 @@ WORKER_FULL = textwrap.dedent("""
     hdr = torch.frombuffer(bytearray(hb), dtype=torch.uint8)
     used = len(sb) // 4
     cap = torch.tensor([used]); dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-    stream = torch.zeros(4 * int(cap.item()) + 64, dtype=torch.uint8)         # capacity >= every rank's use
+    # stream buffers as the aligner sizes them: per rank — rank 0's is SHORTER than what rank 1 uses (the padded-temporary path)
+    stream = torch.zeros(4 * (int(cap.item()) if rank else used) + 64 * rank, dtype=torch.uint8)
     stream[:len(sb)] = torch.frombuffer(bytearray(sb), dtype=torch.uint8) if sb else stream[:0]
-    got = mg.gather_raw(dist, rank, world, hdr, stream, used)
+    # the pipeline form bench.py uses: batch A's gather is launched on a snapshot, the buffers are then overwritten (the "next
+    # batch"), and batch A must still arrive intact; the blocking form (gather_raw) must agree with it
+    gat = mg.ResultGatherer(dist, rank, world)
+    gat.start(hdr, stream, used)
+    keep_h, keep_s = hdr.clone(), stream.clone()
+    hdr.fill_(0xEE); stream.fill_(0xEE)
+    got = [(h.clone(), s.clone()) for h, s in gat.finish()] if rank == 0 else gat.finish()
+    hdr.copy_(keep_h); stream.copy_(keep_s)
+    gat.start(hdr, stream, used)                   # a second batch through the same (reused) buffers
+    got2 = gat.finish()
+    got3 = mg.gather_raw(dist, rank, world, hdr, stream, used)
+    if rank == 0:
+        for r in range(world):
+            for other in (got2, got3):
+                assert torch.equal(got[r][0], other[r][0]) and torch.equal(got[r][1], other[r][1])
     shards = [None] * world
     dist.all_gather_object(shards, shard)
     if rank == 0:
