@@ -234,13 +234,16 @@ def main():
         # These kernels gather 64-B lines at random: next to the 8 TB/s streaming peak, every kernel is also stated against the
         # MEASURED ceiling of dependent random 64-B line loads (tools/gather_ceiling.hip, profiles/r02_gather_ceiling.json):
         # fabric lines per second (PMC traffic / 64 B) over the DRAM-resident ceiling.
-        ceil = json.load(open(os.path.join(here, "profiles", "r02_gather_ceiling.json")))
+        ceil_name = next(n for n in ("r03_gather_ceiling.json", "r02_gather_ceiling.json") if os.path.exists(os.path.join(here, "profiles", n)))
+        ceil = json.load(open(os.path.join(here, "profiles", ceil_name)))
         dram = max(r["chains1"] for r in ceil["sets"][1]["rows"]) * 1e9
         cache = max(r["chains1"] for r in ceil["sets"][0]["rows"]) * 1e9
         counted = {"k_map": lines_map, "k_seed": lines_seed, "k_extend": lines_align - lines_seed}
         gather = {"ceiling_lines_per_s": {"dram_9GB_set": dram, "infinity_cache_104MB_set": cache},
+                  "source": "profiles/" + ceil_name,
                   "note": "block_lines = 64-B BOSS index lines the kernel itself counts (exact); fabric_lines = PMC bytes / 64 B "
-                          "(all arrays, Infinity-Cache hits included, FETCH_SIZE doubled as the guide prescribes for gfx950)",
+                          "(all arrays, Infinity-Cache hits included; FETCH_SIZE as calibrated in profiles/r03_pmc_calibration.json: "
+                          "64-B line gathers are tallied 1:1)",
                   "kernels": {}}
         for name, (ms, _) in kernels.items():
             if ms <= 0:
@@ -339,7 +342,12 @@ def main():
                    "sample": "first %d reads of the same workload, same graph, %d threads, %.1fs" % (nc, threads, dt),
                    "build": "-O3 -march=native -DNDEBUG", "cpu_model": model,
                    "single_thread": {"value": round(one, 1), "sample": "%d reads, %.1fs" % (n1, d1)},
-                   "thread_scaling_efficiency": round((nc / dt) / (one * threads), 3), "thread_scan": scan}
+                   "thread_scaling_efficiency": round((nc / dt) / (one * threads), 3), "thread_scan": scan,
+                   # north_star asks for "the node's host cores"; the GPU boxes grant this process a CPU quota (cores above),
+                   # so the whole-socket figure can only be extrapolated: single-thread rate x physical cores, which the
+                   # measured scaling up to the quota (efficiency above) supports as an upper estimate
+                   "extrapolated_whole_socket": {"cores": 128, "value": round(one * 128, 1),
+                                                 "note": "single-thread rate x 128 physical cores (2 x EPYC 9575F); not measured"}}
 
     out = {"metric": "aligned reads/sec (150 bp, k=31)", "value": round(value, 1), "unit": "reads/s",
            "value_host_inclusive": round(host_value, 1) if host_value else None,
