@@ -149,6 +149,7 @@ struct HostResults {
                         memset(&op, 0, sizeof(op));
                         op.len = p[n_nodes + x] >> 3;
                         op.op = (uint8_t)(p[n_nodes + x] & 7);
+                        if (op.op > MGX_OP_NODE_INSERTION) return false;      // 6, 7: not an operator (mgx_format_tsv indexes by it)
                         if (op.op == MGX_OP_MATCH) nm += op.len;
                         cigar.push_back(op);
                     }
