@@ -230,10 +230,13 @@ MGX_HD uint32_t conv_cap0(uint32_t hash_size) { return hash_size < CONV_CAP0 ? h
 MGX_HD uint64_t conv_tab_slots(uint32_t hash_size) { return 2ull * hash_size; }          // all levels together (< 2 x the top one)
 
 struct SdustScratch {            // working set of is_low_complexity(); lives in LDS on the device
-    int16_t cv[64], cw[64], c2[64];
     int16_t Ps[64], Pf[64], Pr[64], Pl[64];   // perfect intervals (at most one per window position)
-    int16_t wqw[64];                          // window deque (ring)
+    // the triplet counters and the window deque (ring): memory only where a read has fewer than 64 lanes; the 64-lane
+    // instantiation keeps them in registers (RegTab64) and its kernel allocates just the first SDUST_LDS_BYTES of this struct
+    int16_t cv[64], cw[64], c2[64];
+    int16_t wqw[64];
 };
+constexpr uint32_t SDUST_LDS_BYTES_REGTAB = 4 * 64 * 2;
 
 struct DevAln {                  // Alignment (alignment.hpp:132-331)
     uint32_t *nodes;

@@ -880,7 +880,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     // latency-critical scalar arrays go to LDS when they fit next to the other resident waves of the CU
     // per-wavefront share of the CU's 160 KB minus the kernel's static LDS (control block, sdust scratch, score rows);
     // overshooting by a few bytes costs a whole resident wavefront per CU
-    const uint32_t static_lds = (uint32_t)((sizeof(Wave) + sizeof(SdustScratch) + 6 * 128 + 127) & ~127ull);
+    // (the seeding kernels: control block + the interval lists of the sdust scratch; no score rows — seed_kernel.hpp)
+    const uint32_t static_lds = (uint32_t)((sizeof(Wave) + SDUST_LDS_BYTES_REGTAB + 16 + 127) & ~127ull);
     uint32_t lds_budget = (160u * 1024u) / (4 * MGX_ALIGN_WAVES_PER_SIMD) - static_lds - 64u;
     uint32_t lds_bytes = std::min<uint32_t>(fast_lds_bytes(l.Lmax), lds_budget) & ~15u;
     const uint32_t w_slots = (uint32_t)std::min<uint64_t>(slots, wave_slots);

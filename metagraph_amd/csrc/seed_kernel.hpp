@@ -18,12 +18,16 @@ __global__ void __launch_bounds__(64, WPS) k_align(mgx::AlignParams P, uint32_t 
     const uint32_t slot = blockIdx.x;
     using namespace mgx;
     __shared__ Wave w;                // the wave's scalar state lives in LDS, not in registers
-    __shared__ SdustScratch sd;
-    __shared__ int8_t sm_rows[6 * 128];
+    // (a seeding-only instantiation needs neither the score rows nor, with the sdust counters in registers, more than the
+    // interval lists of the scratch: 1280 bytes more of the CU's LDS for the per-read seeding tables of every wavefront)
+    constexpr bool kExtends = (PHASE & PH_EXTEND) != 0;
+    __shared__ __attribute__((aligned(16))) uint8_t sd_buf[kExtends || !MGX_HAS_REGTAB ? sizeof(SdustScratch) : SDUST_LDS_BYTES_REGTAB];
+    __shared__ int8_t sm_rows[kExtends ? 6 * 128 : 16];
+    SdustScratch &sd = *reinterpret_cast<SdustScratch *>(sd_buf);
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     KernelStats acc;
     memset(&acc, 0, sizeof(acc));
-    mgx::load_score_rows(P, sm_rows);
+    if (kExtends) mgx::load_score_rows(P, sm_rows);
     const uint64_t n_items = P.n_items_ptr ? *P.n_items_ptr : P.n_reads;
     for (;;) {
         LV<uint64_t> rv;

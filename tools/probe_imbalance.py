@@ -24,7 +24,10 @@ reads = synth.sample_reads(genome, n, L, 20240503).contiguous()
 offsets = (torch.arange(n + 1, device=dev, dtype=torch.int64) * L).contiguous()
 del genome
 torch.cuda.empty_cache()
-A = aligner.Aligner(G, capi.config_cli(k))
+cfg = capi.config_cli(k)
+if os.environ.get("PROBE_NO_SDUST"):           # ablation (different results): what does the complexity filter cost k_seed?
+    cfg.seed_complexity_filter = 0
+A = aligner.Aligner(G, cfg)
 
 
 def run(r, tag):
