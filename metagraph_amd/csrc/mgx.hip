@@ -301,6 +301,9 @@ extern "C" int mgx_launch_seed_primary(const void *params, uint32_t blocks, uint
 extern "C" int mgx_launch_align_grp8_alt(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);
 extern "C" unsigned mgx_grp_static_lds8_alt(void);
 extern "C" int mgx_grp_waves_per_simd8_alt(void);
+extern "C" int mgx_launch_align_grp8_prim(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);
+extern "C" unsigned mgx_grp_static_lds8_prim(void);
+extern "C" int mgx_grp_waves_per_simd8_prim(void);
 
 // The pipeline run_align launches: seeding by one wavefront per read (k_align<PH_SEED>), a radix sort of the reads by
 // predicted extension work, extension by 8-lane groups (8 reads per wavefront, mgx_grp.hip).  (Round 1 also carried
@@ -889,13 +892,19 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         // tuning probe: MGX_EXT_GROUPS_PCT=50 launches half the resident groups (occupancy experiments)
         static const uint32_t pct = getenv("MGX_EXT_GROUPS_PCT") ? (uint32_t)std::min(100, std::max(1, atoi(getenv("MGX_EXT_GROUPS_PCT")))) : 100u;
         const uint32_t groups = 8;
-        const bool alt = A->cfg.num_alternative_paths > 1 || A->dcfg.canonical >= 2;
-        const uint32_t waves_cu = 4u * (uint32_t)(alt ? mgx_grp_waves_per_simd8_alt() : mgx_grp_waves_per_simd8());
-        const uint32_t static_lds = alt ? mgx_grp_static_lds8_alt() : mgx_grp_static_lds8();
+        // three builds of the extension kernel (mgx_grp.hip): the product, the product with the CanonicalDBG branches (PRIMARY
+        // graphs), and the one with room for alternative paths (either kind of graph; MGX_PRIMARY_ALT_BUILD=1: A/B switch that
+        // sends PRIMARY graphs there as rounds 2-3 did)
+        static const bool prim_to_alt = getenv("MGX_PRIMARY_ALT_BUILD") && atoi(getenv("MGX_PRIMARY_ALT_BUILD")) == 1;
+        const bool primary = A->dcfg.canonical >= 2;
+        const bool alt = A->cfg.num_alternative_paths > 1 || (primary && prim_to_alt);
+        const bool prim = primary && !alt;
+        const uint32_t waves_cu = 4u * (uint32_t)(alt ? mgx_grp_waves_per_simd8_alt() : prim ? mgx_grp_waves_per_simd8_prim() : mgx_grp_waves_per_simd8());
+        const uint32_t static_lds = alt ? mgx_grp_static_lds8_alt() : prim ? mgx_grp_static_lds8_prim() : mgx_grp_static_lds8();
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 64u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
         if (const char *e = getenv("MGX_EXT_LDS_CAP")) per_group = std::min<uint32_t>(per_group, (uint32_t)atoi(e)) & ~15u;   // tuning probe
-        return (alt ? mgx_launch_align_grp8_alt : mgx_launch_align_grp8)(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), per_group, phase, nullptr);      // never more groups than arena slices (a partial wavefront is fine: the kernel returns for slot >= n_groups)
+        return (alt ? mgx_launch_align_grp8_alt : prim ? mgx_launch_align_grp8_prim : mgx_launch_align_grp8)(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), per_group, phase, nullptr);      // never more groups than arena slices (a partial wavefront is fine: the kernel returns for slot >= n_groups)
     };
     A->split_ran = split;
     if (split) {

@@ -10,9 +10,15 @@
 // Two builds of this file go into libmgx.so: the product (MGX_MAX_ALT = 1: one alignment per query) and one with room for
 // MGX_MAX_ALTERNATIVE_PATHS alignments per query (-DMGX_MAX_ALT=4 -DMGX_ALT_BUILD), launched when
 // DBGAlignerConfig::num_alternative_paths > 1; its bigger control block stays out of the product kernel's LDS.
-#ifdef MGX_ALT_BUILD
+// A third build (-DMGX_PRIM_BUILD -DMGX_WITH_PRIMARY=1) is the product kernel with the CanonicalDBG branches compiled in: PRIMARY
+// graphs with one alignment per query run the rounds at 3 waves per SIMD like every other graph, instead of sharing the
+// 2-wave build of the alternative paths.
+#if defined(MGX_ALT_BUILD)
 #define MGX_SUFFIX(x) MGX_CAT(x, _alt)
 #define mgx MGX_CAT(MGX_CAT(mgx_grp, MGX_GROUP), a)
+#elif defined(MGX_PRIM_BUILD)
+#define MGX_SUFFIX(x) MGX_CAT(x, _prim)
+#define mgx MGX_CAT(MGX_CAT(mgx_grp, MGX_GROUP), p)
 #else
 #define MGX_SUFFIX(x) x
 #define mgx MGX_CAT(mgx_grp, MGX_GROUP)
