@@ -921,7 +921,10 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                 if (int rc = mgx_launch_seed_primary(&P, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, lds8, 1, nullptr))
                     return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
             } else {
-                k_align<PH_SEED, MGX_SEED_WPS><<<(uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, 64, lds8>>>(P, lds8);
+                // tuning probe: MGX_SEED_WAVES_PCT=50 launches half the resident wavefronts (is the kernel bound by what each
+                // wavefront waits for, or by what all of them move?)
+                static const uint32_t spct = getenv("MGX_SEED_WAVES_PCT") ? (uint32_t)std::min(100, std::max(1, atoi(getenv("MGX_SEED_WAVES_PCT")))) : 100u;
+                k_align<PH_SEED, MGX_SEED_WPS><<<std::max(1u, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS * spct / 100), 64, lds8>>>(P, lds8);
             }
         } else if (A->dcfg.canonical >= 2) {
             if (int rc = mgx_launch_seed_primary(&P, w_slots, lds_bytes, 0, nullptr)) return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
