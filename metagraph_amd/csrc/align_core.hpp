@@ -2361,6 +2361,10 @@ MGX_DEV void fast_spill(Wave &w, const LV<int32_t> *S, const LV<int32_t> *F) {
 enum { XM_POP = 0, XM_FAST = 1 };
 enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 3, FR_STOP = 4, FR_ERROR = 5 };
 
+} // namespace mgx
+#include "lane_column.hpp"
+namespace mgx {
+
 // ---- general path: one popped column `i` with all its children (staging buffers, frontier arrays) ----
 // returns 0, or 1 = the extension is over (capacity error; w.status says which)
 MGX_DEV int general_step(Wave &w, ExtenderState &E, const int32_t i, const bool children_ready) {
@@ -2538,6 +2542,29 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         if ((double)x.table_size_bytes / 1000000.0 > x.max_ram) return FR_STOP;
     }
     int32_t p_org = x.f_org;
+#if defined(MGX_LANE_CHECK) && MGX_WAVE_EMU
+    // host-model check of lane_column() against this function, cell by cell (FW == LFW builds only: 8 lanes per read)
+    static_assert(FW == LFW, "the lane check runs in the 8-lane host model");
+    int32_t lc_ps[LFW], lc_pf[LFW], lc_s[LFW], lc_f[LFW];
+    FOR_LANES(l) { for (int s = 0; s < 4; ++s) { lc_ps[4 * l + s] = pS[s][l]; lc_pf[4 * l + s] = pF[s][l]; } }
+    const int32_t lc_p_org = x.f_org, lc_min_cell = x.min_cell_score, lc_best = x.best_score;
+    LaneColumnOut lc_out;
+    auto lane_run = [&](int32_t next_offset_, int32_t score_, bool in_seed_, uint8_t c_) {
+        LaneColumnIn li;
+        for (int cx = 0; cx < LFW; ++cx) { lc_s[cx] = lc_ps[cx]; lc_f[cx] = lc_pf[cx]; }
+        li.p_org = lc_p_org; li.p_trim = x.f_trim; li.p_size = x.f_size;
+        li.xdrop_cutoff = xdrop_cutoff; li.start = start; li.window_size = window_size; li.qlen = qlen; li.go = go; li.ge = ge;
+        li.next_offset = next_offset_; li.score = score_; li.in_seed = in_seed_;
+        li.best_score = lc_best; li.min_cell_score = lc_min_cell; li.rel_cutoff = x.rel_cutoff;
+        li.partial_sum_offset = x.partial_sum_offset; li.psum_lin = x.psum_lin; li.psum = E.psum; li.seed_off = x.seed_off;
+        li.q = E.q; li.row = MGX_SM_ROWS(w) + encode_char(c_) * 128;
+        return lane_column(li, lc_s, lc_f, lc_out);
+    };
+    auto lane_fail = [&](const char *what) { fprintf(stderr, "lane_column != chain_step: %s\n", what); abort(); };
+#define MGX_LC(expr) expr
+#else
+#define MGX_LC(expr)
+#endif
     // band within the x-drop cutoff (:549-560)
     int32_t begin, prev_end;
     {
@@ -2552,7 +2579,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         }
         begin = wave_min(lo); prev_end = wave_max(hi);
     }
-    if (prev_end <= begin) return FR_END;
+    if (prev_end <= begin) { MGX_LC(if (lane_run(x.f_offset + 1, 0, false, 'A') != LC_EMPTY_BAND) lane_fail("empty band");) return FR_END; }
     // the child (call_outgoing :330-387)
     const int32_t next_offset = x.f_offset + 1;
     const int32_t seed_pos = next_offset - x.seed_off;
@@ -2635,7 +2662,11 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     // from here on a fallback hands the one child over through the children list (general_step reads it from there)
     x.f_n_out = 1;
     w.out_nodes[0] = next; w.out_chars[0] = c; w.out_scores[0] = score;
-    if ((begin - org) + imax(n_loop, size0) > FW) { wave_sync(); return FR_FALLBACK; }
+    if ((begin - org) + imax(n_loop, size0) > FW) {
+        MGX_LC(if (lane_run(next_offset, score, in_seed, c) != LC_FALLBACK) lane_fail("window fallback");)
+        wave_sync();
+        return FR_FALLBACK;
+    }
     if (x.tsize >= x.max_columns - 1) { w.status = ST_CAPACITY; return FR_ERROR; }
     if ((uint64_t)x.cell_top + rec_words((uint32_t)(window_size + 1 - begin + 8)) > x.cell_words) { w.status = ST_CAPACITY; return FR_ERROR; }
     // move the parent window to the child's origin (whole lanes)
@@ -2749,6 +2780,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             if ((begin - org) + size0 + n_push > FW) {
                 // the parent window has moved: keep it consistent for the spill
                 x.f_org = p_org;
+                MGX_LC(if (lane_run(next_offset, score, in_seed, c) != LC_FALLBACK) lane_fail("ins_end fallback");)
                 return FR_FALLBACK;
             }
             FOR_LANES(l) {
@@ -2805,7 +2837,10 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         lkey[l] = kk;
     }
     const int32_t max_pos = begin + (wave_min(lkey) & 4095);          // j < FW <= 256, distance < 2^19 (Lmax <= 32704)
-    if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) return FR_END;      // pop(table.size() - 1)
+    if ((!in_seed && max_val < xdrop_cutoff) || (!in_seed && !has_extension)) {      // pop(table.size() - 1)
+        MGX_LC(if (lane_run(next_offset, score, in_seed, c) != LC_POP || lc_out.min_cell_score != x.min_cell_score) lane_fail("pop");)
+        return FR_END;
+    }
     const uint32_t cur_cap3 = 3 * ref_capacity((uint32_t)size0, (uint32_t)pushes);
     x.table_size_bytes += (uint64_t)136 * (E.table_cap - table_cap_before) + (uint64_t)cur_cap3 * 4;
     if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > x.xdrop) x.xdrop_cutoff = max_val - x.xdrop;
@@ -2963,6 +2998,22 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             fwv[l] = fw;
             blocks[l] = blk;
         }
+#if defined(MGX_LANE_CHECK) && MGX_WAVE_EMU
+        {
+            if (lane_run(next_offset, score, in_seed, c) != LC_OK) lane_fail("return code of a committed column");
+            if (lc_out.begin != begin || lc_out.size != size || lc_out.size0 != size0 || lc_out.pushes != pushes || lc_out.org != org) lane_fail("geometry");
+            if (lc_out.max_val != max_val || lc_out.max_pos != max_pos || lc_out.has_extension != has_extension
+                    || lc_out.min_cell_score != x.min_cell_score) lane_fail("scan");
+            if (cv_mode != CV_MERGE && lc_out.converged != converged) lane_fail("converged");
+            FOR_LANES(l) {
+                for (int s = 0; s < 4; ++s) {
+                    const int xx = 4 * l + s;
+                    if (lc_s[xx] != cS[s][l] || lc_f[xx] != cF[s][l]) lane_fail("cells");
+                    if ((uint8_t)(lc_out.fw[xx >> 2] >> (8 * (xx & 3))) != (uint8_t)(fwv[l] >> (8 * s))) lane_fail("flags");
+                }
+            }
+        }
+#endif
         const uint32_t ccode = encode_char(c);
         const bool compact = !deferred && !MGX_PARAMS_OF(w).no_compact && wave_ballot(blocks) == 0 && next_offset <= 0xFFFF && begin <= 0x7FFF
                              && cur.base > -(1 << 21) && cur.base < (1 << 21) && ccode <= 4 && decode_code(ccode) == c

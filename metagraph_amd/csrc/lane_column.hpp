@@ -1,0 +1,171 @@
+// lane_column.hpp — one column of a register-resident chain, computed by ONE lane (round 3 groundwork for the lane-per-read
+// chain kernel of DESIGN.md §9.1; not part of any product kernel yet).
+//
+// chain_step() (align_core.hpp) spreads the window of a column over the 8 lanes of a group, four cells per lane, and pays for
+// it with cross-lane scans and with per-read bookkeeping executed as full vector instructions for 8 reads.  lane_column() is
+// the same arithmetic — DefaultColumnExtender::update_column (A/aligner_extender_methods.cpp:209-290) with its 4-wide
+// overshoot and scalar tail, extend_ins_end (:293-328), the scan (:643-669) and the flag byte per cell that backtrack reads
+// (ColSlot) — with the whole window of LFW cells in one lane, cell after cell: the E chain is a running scalar, nothing
+// crosses lanes, and a wavefront computes 64 columns of 64 reads per pass.
+//
+// Pinned against chain_step() cell by cell: an -DMGX_LANE_CHECK build of the host model (8 lanes per read: FW == LFW) calls it
+// on the inputs of every chain step of every extension the CPU suite and the fuzzing campaign run, and aborts on the first
+// difference (tests/test_lane_column.py).  tools/lane_column_bench.hip measures it on the GPU.
+#pragma once
+
+namespace mgx {
+
+constexpr int LFW = 32;                              // window cells held by a lane (== FW of the 8-lane groups)
+
+struct LaneColumnIn {
+    int32_t p_org, p_trim, p_size;                   // the parent's window origin, trim and size (XState::f_org, f_trim, f_size)
+    int32_t xdrop_cutoff, start, window_size, qlen, go, ge;
+    int32_t next_offset, score;                      // the child's offset and edge score (call_outgoing)
+    bool in_seed;
+    int32_t best_score, min_cell_score;
+    double rel_cutoff;
+    int32_t partial_sum_offset, psum_lin;
+    const int32_t *psum;                             // partial sums of the strand (used when psum_lin == 0)
+    int32_t seed_off;
+    const uint8_t *q;                                // the extender's query
+    const int8_t *row;                               // score-matrix row of the child's character (128 entries)
+};
+
+struct LaneColumnOut {
+    uint32_t fw[LFW / 4];                            // CF_* per cell, four cells per word (cell x: byte x & 3 of word x >> 2)
+    int32_t begin, size, size0, pushes, org;
+    int32_t max_val, max_pos, min_cell_score, converged;
+    bool has_extension;
+};
+
+enum { LC_OK = 0, LC_EMPTY_BAND = 1, LC_FALLBACK = 2, LC_POP = 3 };
+
+// S, F: in = the parent's window (cell x is window position in.p_org + x), out = the child's (cell x is position out.org + x).
+// LC_EMPTY_BAND: no parent cell within the x-drop (chain_step returns FR_END before anything else; window untouched).
+// LC_FALLBACK: the column does not fit the window (untouched if the band itself does not fit; clobbered if the insertion
+// run behind the column's end does not).  LC_POP: computed, but popped again (:646-653: below the cut-off or nothing left to
+// gain).  LC_OK: S / F / out hold the column as chain_step would commit it.
+MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColumnOut &out) {
+    const int32_t go = in.go, ge = in.ge, score = in.score, cutoff = in.xdrop_cutoff;
+    // band within the x-drop cut-off (:549-560)
+    int32_t begin = INT32_MAX, prev_end = INT32_MIN;
+#pragma unroll
+    for (int x = 0; x < LFW; ++x) {
+        const int32_t a = in.p_org + x, j = a - in.p_trim;
+        if (j >= 0 && j < in.p_size && S[x] >= cutoff) { begin = imin(begin, a); prev_end = imax(prev_end, a + 1); }
+    }
+    if (prev_end <= begin) return LC_EMPTY_BAND;
+    const int32_t end = imin(prev_end, in.window_size) + 1;
+    const int32_t size0 = end - begin;
+    const int32_t max_size = in.window_size + 1 - begin;
+    const int32_t n_prev = prev_end - begin, n_loop = (n_prev + 3) & ~3;
+    const int32_t org = begin & ~3;
+    if ((begin - org) + imax(n_loop, size0) > LFW) return LC_FALLBACK;
+    // the parent moves to the child's origin, four cells at a time (both origins are multiples of four); the cell just below
+    // the new origin is kept: the first cell's match compares against it
+    int32_t p_below = NINF;
+    for (int32_t sh = org - in.p_org; sh >= 4; sh -= 4) {
+        p_below = S[3];
+#pragma unroll
+        for (int x = 0; x < LFW - 4; ++x) { S[x] = S[x + 4]; F[x] = F[x + 4]; }
+#pragma unroll
+        for (int x = LFW - 4; x < LFW; ++x) { S[x] = NINF; F[x] = NINF; }
+    }
+    const bool tail = size0 > imax(1, n_prev);                    // scalar tail (:284-289)
+    const int32_t diag_i = in.next_offset - (in.seed_off - 1);
+    const int32_t extension_cutoff = (int32_t)fma_f64((double)in.best_score, in.rel_cutoff, (double)in.partial_sum_offset);
+    const int32_t skip = begin ? 0 : 1;
+    int32_t sm1 = p_below;                           // parent S at a - 1
+    int32_t run = INT32_MIN;                         // max over the cells so far of m + go - j ge
+    int32_t e_next = NINF;                           // E[j] of the cell at hand as the recurrence gives it
+    int32_t ce_prev = NINF;                          // E of the cell before, final
+    bool pushing = false;                            // extend_ins_end (:293-328), decided at the column's last cell
+    int32_t ins_score = 0, n_push = 0;
+    int32_t mx = INT32_MIN, mn = INT32_MAX, key = INT32_MAX, conv = INT32_MIN;
+    bool ext = false;
+#pragma unroll
+    for (int w4 = 0; w4 < LFW / 4; ++w4) out.fw[w4] = 0;
+#pragma unroll
+    for (int x = 0; x < LFW; ++x) {
+        const int32_t a = org + x, j = a - begin;
+        const int32_t ps = S[x], pf = F[x];          // the parent at a
+        const int32_t ap = in.start + a;
+        int32_t prof = 0;
+        if (ap >= 1 && ap <= in.qlen) prof = (int32_t)in.row[in.q[ap - 1] & 127];
+        const int32_t mraw = sm1 + prof + score;
+        const bool inl = j >= 0 && j < n_loop;
+        int32_t del = NINF;
+        if (in.next_offset > 1) del = imax(ps + go, pf + ge) + score;
+        const int32_t match = j >= 1 ? mraw : NINF;
+        const int32_t m = imax(match, del);
+        int32_t fv = inl ? del : NINF;
+        if (inl) run = imax(run, m + go - j * ge);
+        int32_t ce = (j >= 0 && j <= n_loop) ? e_next : NINF;
+        int32_t sv = NINF;
+        if (inl) { sv = imax(m, e_next); if (!(sv > cutoff - 1)) sv = NINF; }
+        // E[j + 1] = max(E[j] + ge, m[j] + go) in closed form over the column (E[0] = ninf extended j + 1 times, saturating)
+        int32_t en = NINF;
+        if (inl) {
+            const int32_t from_open = run + j * ge;
+            const int32_t dec = (j + 1) * ge;
+            const int32_t from_e0 = dec < -100 ? INT32_MIN : NINF + dec;
+            en = imax(from_open, from_e0);
+        }
+        e_next = en;
+        if (j == size0 - 1) {
+            if (tail) { const int32_t mt = imax(mraw, ce); if (mt >= cutoff) sv = mt; }
+            if (size0 < max_size) {
+                const int32_t ins = imax(sv + go, ce + ge);
+                if (ins >= cutoff) {
+                    const int32_t room = max_size - (size0 + 1);
+                    n_push = 1 + room;
+                    if (ge != 0) n_push = 1 + imin(room, (int32_t)((uint32_t)(ins - cutoff) / (uint32_t)(-ge)));
+                    if ((begin - org) + size0 + n_push > LFW) return LC_FALLBACK;
+                    pushing = true;
+                    ins_score = ins;
+                }
+            }
+        }
+        bool in_col = j >= 0 && j < size0;
+        if (pushing && j >= size0) {
+            const int32_t t = j - size0;
+            if (t < n_push) { const int32_t v = ins_score + t * ge; sv = v; ce = v; fv = NINF; in_col = true; }
+            else { sv = NINF; ce = NINF; fv = NINF; }
+        }
+        // scan (:643-669) and what the convergence table takes for a node's first column
+        if (in_col) {
+            const int32_t kk = (iabs(a - diag_i) << 12) | j;
+            if (sv > mx) { mx = sv; key = kk; } else if (sv == mx) key = imin(key, kk);
+            if (sv != NINF) mn = imin(mn, sv);
+            ext |= sv + (in.psum_lin ? (in.qlen - (in.start + a)) * in.psum_lin : in.psum[in.start + a]) >= extension_cutoff;
+            if (j >= skip) conv = imax(conv, sv);
+        }
+        // the flag byte (what backtrack compares, evaluated once: ColSlot)
+        {
+            const int32_t ep = (j <= 0 || x == 0) ? NINF : ce_prev;
+            const bool pin = a - 1 >= in.p_trim;
+            uint32_t fl = 0;
+            if (sv != NINF) fl |= CF_REAL;
+            if (sv == ce) fl |= CF_S_IS_E;
+            if (ce == ep + ge) fl |= CF_E_EXT;
+            if (pin && sv == mraw) fl |= CF_MATCH;
+            if (sv == fv) fl |= CF_S_IS_F;
+            if (fv == pf + score + ge) fl |= CF_F_EXT;
+            if (pin && sm1 != NINF) fl |= CF_SP_REAL;
+            out.fw[x >> 2] |= fl << (8 * (x & 3));
+        }
+        S[x] = sv; F[x] = fv;
+        sm1 = ps; ce_prev = ce;
+    }
+    const int32_t pushes = pushing ? n_push : 0;
+    out.min_cell_score = imin(in.min_cell_score, mn);
+    out.has_extension = in.in_seed || ext;
+    out.max_val = mx;
+    out.max_pos = begin + (key & 4095);
+    out.begin = begin; out.size = size0 + pushes; out.size0 = size0; out.pushes = pushes; out.org = org;
+    out.converged = conv;
+    if ((!in.in_seed && mx < cutoff) || (!in.in_seed && !out.has_extension)) return LC_POP;
+    return LC_OK;
+}
+
+} // namespace mgx

@@ -21,6 +21,9 @@ def L():
         if os.environ.get("MGX_EMU_TRACE_LIB"):                 # tools/traffic_model.py: the traced build (make trace)
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "trace"], check=True, stderr=subprocess.DEVNULL)
             suffix = "_trace_w8"
+        if os.environ.get("MGX_EMU_LANE_CHECK"):                # tests/test_lane_column.py: chain_step cross-checks lane_column()
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "lanecheck"], check=True)
+            suffix = "_lanecheck_w8"
         _L = C.CDLL(os.path.join(ROOT, "tests", "emu", "_build", "libmgxemu%s.so" % suffix))
         _L.emu_graph_create.restype = C.c_void_p
         _L.emu_graph_create.argtypes = [C.POINTER(capi.BossView)]
