@@ -75,6 +75,8 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
     const int32_t diag_i = in.next_offset - (in.seed_off - 1);
     const int32_t extension_cutoff = (int32_t)fma_f64((double)in.best_score, in.rel_cutoff, (double)in.partial_sum_offset);
     const int32_t skip = begin ? 0 : 1;
+    const int32_t bo = begin - org;                  // window cell of the column's cell 0 (0 .. 3)
+    const bool has_del = in.next_offset > 1;
     int32_t sm1 = p_below;                           // parent S at a - 1
     int32_t run = INT32_MIN;                         // max over the cells so far of m + go - j ge
     int32_t e_next = NINF;                           // E[j] of the cell at hand as the recurrence gives it
@@ -83,79 +85,88 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
     int32_t ins_score = 0, n_push = 0;
     int32_t mx = INT32_MIN, mn = INT32_MAX, key = INT32_MAX, conv = INT32_MIN;
     bool ext = false;
+    // cells from `hi` on hold nothing (beyond the overshoot of update_column and beyond the column's end): whole blocks of four
+    // are skipped; the insertion run may move the end once, when the pass reaches the column's last cell
+    int32_t hi = bo + imax(n_loop, size0);
 #pragma unroll
-    for (int w4 = 0; w4 < LFW / 4; ++w4) out.fw[w4] = 0;
+    for (int b = 0; b < LFW / 4; ++b) {
+        uint32_t fwb = 0;
+        if (4 * b < hi) {
 #pragma unroll
-    for (int x = 0; x < LFW; ++x) {
-        const int32_t a = org + x, j = a - begin;
-        const int32_t ps = S[x], pf = F[x];          // the parent at a
-        const int32_t ap = in.start + a;
-        int32_t prof = 0;
-        if (ap >= 1 && ap <= in.qlen) prof = (int32_t)in.row[in.q[ap - 1] & 127];
-        const int32_t mraw = sm1 + prof + score;
-        const bool inl = j >= 0 && j < n_loop;
-        int32_t del = NINF;
-        if (in.next_offset > 1) del = imax(ps + go, pf + ge) + score;
-        const int32_t match = j >= 1 ? mraw : NINF;
-        const int32_t m = imax(match, del);
-        int32_t fv = inl ? del : NINF;
-        if (inl) run = imax(run, m + go - j * ge);
-        int32_t ce = (j >= 0 && j <= n_loop) ? e_next : NINF;
-        int32_t sv = NINF;
-        if (inl) { sv = imax(m, e_next); if (!(sv > cutoff - 1)) sv = NINF; }
-        // E[j + 1] = max(E[j] + ge, m[j] + go) in closed form over the column (E[0] = ninf extended j + 1 times, saturating)
-        int32_t en = NINF;
-        if (inl) {
-            const int32_t from_open = run + j * ge;
-            const int32_t dec = (j + 1) * ge;
-            const int32_t from_e0 = dec < -100 ? INT32_MIN : NINF + dec;
-            en = imax(from_open, from_e0);
-        }
-        e_next = en;
-        if (j == size0 - 1) {
-            if (tail) { const int32_t mt = imax(mraw, ce); if (mt >= cutoff) sv = mt; }
-            if (size0 < max_size) {
-                const int32_t ins = imax(sv + go, ce + ge);
-                if (ins >= cutoff) {
-                    const int32_t room = max_size - (size0 + 1);
-                    n_push = 1 + room;
-                    if (ge != 0) n_push = 1 + imin(room, (int32_t)((uint32_t)(ins - cutoff) / (uint32_t)(-ge)));
-                    if ((begin - org) + size0 + n_push > LFW) return LC_FALLBACK;
-                    pushing = true;
-                    ins_score = ins;
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int x = 4 * b + s4;
+                const int32_t a = org + x, jj = x - bo;
+                const int32_t ps = S[x], pf = F[x];          // the parent at a
+                const int32_t ap = in.start + a;
+                int32_t prof = 0;
+                if (ap >= 1 && ap <= in.qlen) prof = (int32_t)in.row[in.q[ap - 1] & 127];
+                const int32_t mraw = sm1 + prof + score;
+                const bool inl = (uint32_t)jj < (uint32_t)n_loop;
+                const int32_t del = has_del ? imax(ps + go, pf + ge) + score : NINF;
+                const int32_t match = jj >= 1 ? mraw : NINF;
+                const int32_t m = imax(match, del);
+                int32_t fv = inl ? del : NINF;
+                run = inl ? imax(run, m + go - jj * ge) : run;
+                int32_t ce = (jj >= 0 && jj <= n_loop) ? e_next : NINF;
+                int32_t sv = imax(m, e_next);
+                sv = (inl && sv > cutoff - 1) ? sv : NINF;
+                // E[j + 1] = max(E[j] + ge, m[j] + go) in closed form over the column (E[0] = ninf extended j + 1 times, saturating)
+                const int32_t dec = (jj + 1) * ge;
+                const int32_t from_e0 = dec < -100 ? INT32_MIN : NINF + dec;
+                e_next = inl ? imax(run + jj * ge, from_e0) : NINF;
+                if (jj == size0 - 1) {
+                    if (tail) { const int32_t mt = imax(mraw, ce); if (mt >= cutoff) sv = mt; }
+                    if (size0 < max_size) {
+                        const int32_t ins = imax(sv + go, ce + ge);
+                        if (ins >= cutoff) {
+                            const int32_t room = max_size - (size0 + 1);
+                            n_push = 1 + room;
+                            if (ge != 0) n_push = 1 + imin(room, (int32_t)((uint32_t)(ins - cutoff) / (uint32_t)(-ge)));
+                            if (bo + size0 + n_push > LFW) return LC_FALLBACK;
+                            pushing = true;
+                            ins_score = ins;
+                            hi = imax(hi, bo + size0 + n_push);
+                        }
+                    }
                 }
+                bool in_col = (uint32_t)jj < (uint32_t)size0;
+                if (pushing && jj >= size0) {
+                    const int32_t t = jj - size0;
+                    const bool pc = t < n_push;
+                    const int32_t v = ins_score + t * ge;
+                    sv = pc ? v : NINF; ce = pc ? v : NINF; fv = NINF; in_col = pc;
+                }
+                // scan (:643-669) and what the convergence table takes for a node's first column
+                if (in_col) {
+                    const int32_t kk = (iabs(a - diag_i) << 12) | jj;
+                    key = sv > mx ? kk : (sv == mx ? imin(key, kk) : key);
+                    mx = imax(mx, sv);
+                    mn = sv != NINF ? imin(mn, sv) : mn;
+                    ext |= sv + (in.psum_lin ? (in.qlen - (in.start + a)) * in.psum_lin : in.psum[in.start + a]) >= extension_cutoff;
+                    conv = jj >= skip ? imax(conv, sv) : conv;
+                }
+                // the flag byte (what backtrack compares, evaluated once: ColSlot)
+                {
+                    const int32_t ep = (jj <= 0 || x == 0) ? NINF : ce_prev;
+                    const bool pin = a - 1 >= in.p_trim;
+                    uint32_t fl = 0;
+                    fl |= sv != NINF ? CF_REAL : 0;
+                    fl |= sv == ce ? CF_S_IS_E : 0;
+                    fl |= ce == ep + ge ? CF_E_EXT : 0;
+                    fl |= (pin && sv == mraw) ? CF_MATCH : 0;
+                    fl |= sv == fv ? CF_S_IS_F : 0;
+                    fl |= fv == pf + score + ge ? CF_F_EXT : 0;
+                    fl |= (pin && sm1 != NINF) ? CF_SP_REAL : 0;
+                    fwb |= fl << (8 * s4);
+                }
+                S[x] = sv; F[x] = fv;
+                sm1 = ps; ce_prev = ce;
             }
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { S[4 * b + s4] = NINF; F[4 * b + s4] = NINF; }
         }
-        bool in_col = j >= 0 && j < size0;
-        if (pushing && j >= size0) {
-            const int32_t t = j - size0;
-            if (t < n_push) { const int32_t v = ins_score + t * ge; sv = v; ce = v; fv = NINF; in_col = true; }
-            else { sv = NINF; ce = NINF; fv = NINF; }
-        }
-        // scan (:643-669) and what the convergence table takes for a node's first column
-        if (in_col) {
-            const int32_t kk = (iabs(a - diag_i) << 12) | j;
-            if (sv > mx) { mx = sv; key = kk; } else if (sv == mx) key = imin(key, kk);
-            if (sv != NINF) mn = imin(mn, sv);
-            ext |= sv + (in.psum_lin ? (in.qlen - (in.start + a)) * in.psum_lin : in.psum[in.start + a]) >= extension_cutoff;
-            if (j >= skip) conv = imax(conv, sv);
-        }
-        // the flag byte (what backtrack compares, evaluated once: ColSlot)
-        {
-            const int32_t ep = (j <= 0 || x == 0) ? NINF : ce_prev;
-            const bool pin = a - 1 >= in.p_trim;
-            uint32_t fl = 0;
-            if (sv != NINF) fl |= CF_REAL;
-            if (sv == ce) fl |= CF_S_IS_E;
-            if (ce == ep + ge) fl |= CF_E_EXT;
-            if (pin && sv == mraw) fl |= CF_MATCH;
-            if (sv == fv) fl |= CF_S_IS_F;
-            if (fv == pf + score + ge) fl |= CF_F_EXT;
-            if (pin && sm1 != NINF) fl |= CF_SP_REAL;
-            out.fw[x >> 2] |= fl << (8 * (x & 3));
-        }
-        S[x] = sv; F[x] = fv;
-        sm1 = ps; ce_prev = ce;
+        out.fw[b] = fwb;
     }
     const int32_t pushes = pushing ? n_push : 0;
     out.min_cell_score = imin(in.min_cell_score, mn);
