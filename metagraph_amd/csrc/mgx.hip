@@ -904,6 +904,19 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 64u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
         if (const char *e = getenv("MGX_EXT_LDS_CAP")) per_group = std::min<uint32_t>(per_group, (uint32_t)atoi(e)) & ~15u;   // tuning probe
+        {
+            // Fewer reads than resident groups (long-read batches, single queries): spread them over the wavefronts.  The 8
+            // groups of a wavefront execute in lock-step, and reads of 1 .. 12 kbp side by side wait for each other's general
+            // steps two thirds of the time (config 0: 1.35 s with 8 reads per wavefront on 125 of 3072 wavefronts).  The arena
+            // slices stay what they are: slot = wavefront x groups_per_wave + group.
+            const uint64_t launch_groups_n = std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100));
+            const uint64_t resident_waves = (uint64_t)prop.multiProcessorCount * waves_cu;
+            static const int gpw_env = getenv("MGX_GROUPS_PER_WAVE") ? atoi(getenv("MGX_GROUPS_PER_WAVE")) : -1;      // A/B: 0 = all 8
+            const uint64_t items = P.n_items ? P.n_items : n;                       // (a later pass of the multi-pass extension: its retry positions)
+            const uint64_t busy = std::min<uint64_t>(launch_groups_n, std::max<uint64_t>(1, items));
+            const uint64_t want_gpw = std::min<uint64_t>(groups, std::max<uint64_t>(1, (busy + resident_waves - 1) / resident_waves));
+            P.groups_per_wave = gpw_env >= 0 ? (uint32_t)std::min(8, gpw_env) : (want_gpw < groups ? (uint32_t)want_gpw : 0u);
+        }
         return (alt ? mgx_launch_align_grp8_alt : prim ? mgx_launch_align_grp8_prim : mgx_launch_align_grp8)(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), per_group, phase, nullptr);      // never more groups than arena slices (a partial wavefront is fine: the kernel returns for slot >= n_groups)
     };
     A->split_ran = split;

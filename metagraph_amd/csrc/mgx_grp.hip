@@ -48,7 +48,9 @@ using namespace mgx;
 template <int PHASE>
 __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT(k_align_grp, MGX_GROUP))(AlignParams P, uint32_t lds_bytes, uint32_t n_groups) {
     const int g = group_id();
-    const uint32_t slot = blockIdx.x * GROUPS_PER_WAVEFRONT + (uint32_t)g;
+    // (a small batch is spread over the wavefronts: only the first `groups_per_wave` groups of each take reads, see mgx.hip)
+    const uint32_t gpw = P.groups_per_wave ? P.groups_per_wave : (uint32_t)GROUPS_PER_WAVEFRONT;
+    const uint32_t slot = blockIdx.x * gpw + (uint32_t)g;
     __shared__ Wave ws[GROUPS_PER_WAVEFRONT];
     int8_t *sm_rows = g_sm_rows;
     {
@@ -64,6 +66,7 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
     }
     __syncthreads();
     if (slot >= n_groups) return;                      // the last wavefront may hold fewer groups than arena slices exist
+    if ((uint32_t)g >= gpw) return;
     Wave &w = ws[g];
     uint8_t *lds = dyn_lds + (uint32_t)g * lds_bytes;
     KernelStats acc;
@@ -133,7 +136,8 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
 // phase = PH_BOTH (fused) or PH_EXTEND (after the seeding kernel)
 extern "C" int MGX_SUFFIX(MGX_CAT(mgx_launch_align_grp, MGX_GROUP))(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream) {
     const AlignParams &P = *static_cast<const AlignParams *>(params);
-    uint32_t blocks = (n_groups + GROUPS_PER_WAVEFRONT - 1) / GROUPS_PER_WAVEFRONT;
+    const uint32_t gpw = P.groups_per_wave ? P.groups_per_wave : (uint32_t)GROUPS_PER_WAVEFRONT;
+    uint32_t blocks = (n_groups + gpw - 1) / gpw;
 #if defined(MGX_GRP_SEED_PROBE) && !defined(MGX_ALT_BUILD)
     if (phase == PH_SEED) {          // A/B probe: the seeding half with 8 lanes per read
         MGX_SUFFIX(MGX_CAT(k_align_grp, MGX_GROUP))<PH_SEED><<<blocks, 64, lds_bytes * GROUPS_PER_WAVEFRONT, (hipStream_t)stream>>>(P, lds_bytes, n_groups);
