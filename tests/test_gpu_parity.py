@@ -317,3 +317,31 @@ def test_small_cell_budget_gives_capacity_statuses_not_wrong_answers():
             assert got[q] == want[q]
     got, status = aligner.Aligner(G, cfg).align_batch(reads)
     assert all(s == 0 for s in status) and got == want
+
+
+@pytest.mark.parametrize("per_wave", ["0", "1", "3", "8"])
+def test_reads_per_wavefront_do_not_change_results(per_wave):
+    """A batch with fewer reads than resident groups is spread over the wavefronts (AlignParams::groups_per_wave, chosen by the
+    host from the batch size); MGX_GROUPS_PER_WAVE forces 8 (= 0), 1, 3 or 8 groups of a wavefront to take reads.  Scheduling
+    only: the oracle's alignments either way.  (A subprocess: the library reads the switch once.)"""
+    import subprocess
+    import sys
+    import textwrap
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from metagraph_amd import capi
+        from test_emu_vs_oracle import make_world
+        from test_gpu_parity import compare_gpu, gpu_graph
+        g, reads = make_world(515, 21, genome_len=6000, n_reads=300, read_len=120)
+        compare_gpu(g, gpu_graph(g), capi.config_cli(21), reads)
+        cfg = capi.config_cli(21)
+        cfg.min_seed_length = 13
+        cfg.min_exact_match = 0.0
+        compare_gpu(g, gpu_graph(g), cfg, reads[:120], check_seeds=False)
+        print("OK")
+    """) % (os.path.dirname(here), here)
+    env = dict(os.environ, MGX_GROUPS_PER_WAVE=per_wave)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
