@@ -301,6 +301,9 @@ extern "C" int mgx_launch_seed_primary(const void *params, uint32_t blocks, uint
 extern "C" int mgx_launch_align_grp8_alt(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);
 extern "C" unsigned mgx_grp_static_lds8_alt(void);
 extern "C" int mgx_grp_waves_per_simd8_alt(void);
+extern "C" int mgx_launch_ext64(const void *params, uint32_t blocks, uint32_t lds_bytes, void *stream);      // mgx_ext64.hip
+extern "C" unsigned mgx_ext64_static_lds(void);
+extern "C" int mgx_ext64_waves_per_simd(void);
 extern "C" int mgx_launch_align_grp8_prim(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);
 extern "C" unsigned mgx_grp_static_lds8_prim(void);
 extern "C" int mgx_grp_waves_per_simd8_prim(void);
@@ -916,6 +919,14 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             const uint64_t busy = std::min<uint64_t>(launch_groups_n, std::max<uint64_t>(1, items));
             const uint64_t want_gpw = std::min<uint64_t>(groups, std::max<uint64_t>(1, (busy + resident_waves - 1) / resident_waves));
             P.groups_per_wave = gpw_env >= 0 ? (uint32_t)std::min(8, gpw_env) : (want_gpw < groups ? (uint32_t)want_gpw : 0u);
+        }
+        // One read per wavefront: the 64-lane instantiation (mgx_ext64.hip) — the read has the wavefront to itself, so it may as
+        // well use all of its lanes.  MGX_EXT64=0: A/B switch.
+        static const bool ext64 = !(getenv("MGX_EXT64") && atoi(getenv("MGX_EXT64")) == 0);
+        if (ext64 && phase == PH_EXTEND && P.groups_per_wave == 1) {
+            const uint32_t wcu = 4u * (uint32_t)mgx_ext64_waves_per_simd();
+            const uint32_t lds64 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), (160u * 1024u) / wcu - mgx_ext64_static_lds() - 128u) & ~15u;
+            return mgx_launch_ext64(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), lds64, nullptr);
         }
         return (alt ? mgx_launch_align_grp8_alt : prim ? mgx_launch_align_grp8_prim : mgx_launch_align_grp8)(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), per_group, phase, nullptr);      // never more groups than arena slices (a partial wavefront is fine: the kernel returns for slot >= n_groups)
     };

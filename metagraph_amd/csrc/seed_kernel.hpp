@@ -28,21 +28,27 @@ __global__ void __launch_bounds__(64, WPS) k_align(mgx::AlignParams P, uint32_t 
     KernelStats acc;
     memset(&acc, 0, sizeof(acc));
     if (kExtends) mgx::load_score_rows(P, sm_rows);
-    const uint64_t n_items = P.n_items_ptr ? *P.n_items_ptr : P.n_reads;
+    const uint64_t n_items = P.n_items ? P.n_items : (P.n_items_ptr ? *P.n_items_ptr : P.n_reads);
     for (;;) {
         LV<uint64_t> rv;
         rv.v = 0;
         if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
         uint64_t item = wave_bcast(rv, 0);
         if (item >= n_items) break;
-        const uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
-        align_read<PHASE>(w, P, read, slot, &acc, &sd, sm_rows, dyn_lds, lds_bytes);
+        uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
+        const uint8_t *rec = nullptr;
+        if (PHASE == PH_EXTEND && P.resume_in) {         // a later pass of the multi-pass extension: `read` is a retry position
+            rec = P.resume_in + read * P.resume_rec_bytes;
+            read = P.resume_reads[read];
+        }
+        align_read<PHASE>(w, P, read, slot, &acc, &sd, sm_rows, dyn_lds, lds_bytes, rec);
     }
     if (lane_id() == 0) {
         atomicAdd(&P.stats->rank_lines, acc.rank_lines);
         atomicAdd(&P.stats->select_lines, acc.select_lines);
         atomicAdd(&P.stats->bit_lines, acc.bit_lines);
         atomicAdd(&P.stats->columns, acc.columns);
+        if (acc.fast_columns) atomicAdd(&P.stats->fast_columns, acc.fast_columns);
         atomicAdd(&P.stats->extensions, acc.extensions);
         atomicAdd(&P.stats->seeds, acc.seeds);
         atomicAdd(&P.stats->capacity_errors, acc.capacity_errors);

@@ -71,6 +71,15 @@ MGX_DEV LV<int32_t> wave_shift_up1(const LV<int32_t> &x, int32_t fill) {
     return r;
 }
 
+// value of lane (l + n) (n >= 0, wave-uniform); lanes past the end receive `fill`
+MGX_DEV LV<int32_t> wave_shift_down(const LV<int32_t> &x, int32_t n, int32_t fill) {
+    LV<int32_t> r;
+    const int src = lane_id() + n;
+    const int32_t t = __builtin_amdgcn_ds_bpermute((src & (WAVE - 1)) << 2, x.v);
+    r.v = src < WAVE ? t : fill;
+    return r;
+}
+
 // inclusive prefix max over lanes: 4 row-shift DPP steps inside each row of 16, then row_bcast:15 and
 // row_bcast:31 carry the row totals across rows (the classic GCN/CDNA wave64 scan; no LDS traffic)
 #define MGX_DPP_MAX(v, ctrl, rmask, bmask)                                                          \
