@@ -15,7 +15,11 @@
 
 namespace mgx {
 
-constexpr int LFW = 32;                              // window cells held by a lane (== FW of the 8-lane groups)
+#ifndef MGX_LFW
+#define MGX_LFW 32
+#endif
+constexpr int LFW = MGX_LFW;                         // window cells held by a lane (32 == FW of the 8-lane groups, which the
+                                                     // cross-check needs; the microbenchmark also measures 24, the compact slot's cells)
 
 struct LaneColumnIn {
     int32_t p_org, p_trim, p_size;                   // the parent's window origin, trim and size (XState::f_org, f_trim, f_size)

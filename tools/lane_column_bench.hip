@@ -147,10 +147,11 @@ int main(int argc, char **argv) {
     CHECK(hipMemcpy(d_reads, reads.data(), reads.size(), hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_slots, max_lanes * slot_cols * 64));
     CHECK(hipMalloc(&d_ctr, 16)); CHECK(hipMalloc(&d_sum, 4));
-    printf("{\"device\": \"%s\", \"cus\": %d, \"reads\": %llu, \"read_length\": %d, \"what\": \"lane_column() per column + one 64-byte slot store, one lane per read\",\n  \"product_columns_per_s\": 1.54e9, \"rows\": [\n",
-           prop.name, n_cu, (unsigned long long)n_reads, L);
+    printf("{\"device\": \"%s\", \"cus\": %d, \"reads\": %llu, \"read_length\": %d, \"window_cells\": %d, \"what\": \"lane_column() per column + one 64-byte slot store, one lane per read\",\n  \"product_columns_per_s\": 1.54e9, \"rows\": [\n",
+           prop.name, n_cu, (unsigned long long)n_reads, L, LFW);
     run<1>(d_reads, d_slots, slot_cols, n_reads, 50, n_cu, d_ctr, d_sum); printf(",\n");
     run<2>(d_reads, d_slots, slot_cols, n_reads, 50, n_cu, d_ctr, d_sum); printf(",\n");
+    run<3>(d_reads, d_slots, slot_cols, n_reads, 50, n_cu, d_ctr, d_sum); printf(",\n");
     run<4>(d_reads, d_slots, slot_cols, n_reads, 50, n_cu, d_ctr, d_sum); printf(",\n");
     run<8>(d_reads, d_slots, slot_cols, n_reads, 50, n_cu, d_ctr, d_sum); printf(",\n");
     run<4>(d_reads, d_slots, slot_cols, n_reads, 0, n_cu, d_ctr, d_sum); printf("\n  ]}\n");
