@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -1109,6 +1110,18 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
     return MGX_OK;
 }
 
+// MGX_HOST_TIMERS=1: host-side wall time per stage of a batch on stderr (where does a one-read batch spend its 2 ms?)
+struct HostStageTimer {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    static bool on() { static const bool v = getenv("MGX_HOST_TIMERS") && atoi(getenv("MGX_HOST_TIMERS")) == 1; return v; }
+    explicit HostStageTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~HostStageTimer() {
+        if (on()) fprintf(stderr, "mgx host stage %-14s %8.1f us\n", name,
+                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
 // kernels only; results stay in HBM
 int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device) {
     if (!A || !seqs || !offsets) return fail(MGX_ERR_INVALID, "null argument");
@@ -1116,12 +1129,12 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
     HIP_TRY(hipSetDevice(A->graph->device));
     const char *d_seqs; const uint64_t *d_offsets; uint32_t Lmax;
     if (n == 0) { A->n_reads = 0; return MGX_OK; }
-    if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc;
+    { HostStageTimer t("stage_batch"); if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc; }
     bool mapped = A->cfg.max_seed_length >= A->graph->g.k;
-    if (int rc = run_map(A, d_seqs, d_offsets, n, A->dcfg.fwd_and_rc != 0, mapped, Lmax)) return rc;
+    { HostStageTimer t("run_map"); if (int rc = run_map(A, d_seqs, d_offsets, n, A->dcfg.fwd_and_rc != 0, mapped, Lmax)) return rc; }
     for (;;) {
-        if (int rc = run_align(A, d_seqs, d_offsets, n, Lmax)) return rc;
-        if (int rc = collect_stats(A, mapped, true)) return rc;
+        { HostStageTimer t("run_align"); if (int rc = run_align(A, d_seqs, d_offsets, n, Lmax)) return rc; }
+        { HostStageTimer t("collect_stats"); if (int rc = collect_stats(A, mapped, true)) return rc; }
         // both streams keep counting past their capacity: reads that found no room got a capacity status and the
         // stage is redone with what it asked for
         unsigned long long out_wanted = 0, seeds_wanted = 0;
@@ -1142,6 +1155,7 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
 }
 
 int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
+    HostStageTimer t_fetch("fetch_results");
     const uint64_t n = A->n_reads;
     HIP_TRY(hipSetDevice(A->graph->device));
     A->h_results.resize(n);

@@ -25,7 +25,7 @@ reads = synth.sample_reads(genome, 64, L, 20240503).view(64, L).cpu().numpy()
 seqs = ["".join(chr(c) for c in row) for row in reads]
 A = aligner.Aligner(G, capi.config_cli(k))
 out = {"graph_edges": int(boss["n_edges"]), "k": k, "read_length": L}
-for n in (1, 8, 64):
+for n in ((1,) if os.environ.get("MGX_HOST_TIMERS") else (1, 8, 64)):
     A.align_batch(seqs[:n])                      # first call: buffers allocated
     ts = []
     for rep in range(30):
