@@ -3641,6 +3641,75 @@ MGX_DEV bool bt_step(Wave &w, const SeedRef &seed, const DevAln *seed_aln, DevAl
         for (;;) {
             if (!j) { walk_over = true; break; }
             if (steps++ >= max_walk) break;
+            // A run of diagonal steps at once.  The typical trace is matches / mismatches along consecutive chain columns
+            // (column j - 1 is the parent of column j, one query position back per step), and walking it one dependent
+            // round trip per step is what the trace loop spends its time on.  Lane l looks at the step l ahead — column
+            // j - l at position pos - l — on its own: slot metadata and the cell's flag byte, two loads in flight per lane
+            // instead of one per step; the leading lanes whose cell takes the match branch below and whose parent is the
+            // next lane's column are applied together (same appends, same marks, in the same order).  Anything else — an
+            // insertion or deletion, a column in another format, a dummy node, the end of the trace — stops the run and is
+            // left to the step-by-step code.
+            if ((n_ops == 0 || (cur_run & 7) != OP_DELETION) && dummy_counter == 0 && !MGX_PARAMS_OF(w).no_bt_runs) {
+                LV<bool> okv, linkv, mpv, mmv;
+                LV<int32_t> parv, offv, scv;
+                LV<uint32_t> nodev, chv;
+                FOR_LANES(l) {
+                    const int32_t cl = j - l, pl = pos - l;
+                    bool ok = cl >= 1 && pl >= 1;
+                    ColMeta m = col;
+                    if (ok && l) m = col_load(w, cl);
+                    ok = ok && col_compact(m) && m.node != 0;
+                    uint32_t fl = 0;
+                    if (ok) fl = cell_flags(w, m, pl);
+                    ok = ok && (fl & CF_REAL) && (fl & CF_MATCH) && !(fl & CF_S_IS_E);
+                    okv[l] = ok;
+                    linkv[l] = ok && m.parent == cl - 1;
+                    parv[l] = m.parent; offv[l] = m.offset; scv[l] = ok ? m.score : 0;
+                    nodev[l] = m.node; chv[l] = col_char(m);
+                    mpv[l] = ok && pl == m.max_pos;
+                    mmv[l] = ok && op_at(col_char(m), seed_clipping + pl) != OP_MATCH;
+                }
+                const uint64_t okm = wave_ballot(okv), lkm = wave_ballot(linkv);
+                int32_t r = 0;
+                while (r < WAVE && ((okm >> r) & 1) && (r == 0 || ((lkm >> (r - 1)) & 1))) ++r;
+                if (r >= 2 && n_seq + r <= cap && n_path + r <= cap && n_ops + r <= cap) {
+                    const uint64_t rmask = r >= 64 ? ~0ull : ((1ull << r) - 1);
+                    // prev_starts marks, step by step as below (nothing reads them before the next pop)
+                    const uint64_t mpm = wave_ballot(mpv) & rmask;
+                    for (int32_t l = 0; l < r; ++l) {
+                        if (!((mpm >> l) & 1)) continue;
+                        const int32_t cj = j - l;
+                        if ((cj >> 5) != ps_idx) { ps_flush(); ps_idx = cj >> 5; }
+                        ps_bits |= 1u << (cj & 31);
+                    }
+                    // append_node x r: characters, CIGAR operators (one run if they are all matches), nodes from offset k - 1 on
+                    FOR_LANES(l) { if (l < r) gst(w.rev_seq + n_seq + l, (uint8_t)chv[l]); }
+                    n_seq += r;
+                    const uint64_t mmm = wave_ballot(mmv) & rmask;
+                    if (!mmm) {
+                        push_op(OP_MATCH, (uint32_t)r);
+                    } else {
+                        for (int32_t l = 0; l < r; ++l) push_op(((mmm >> l) & 1) ? OP_MISMATCH : OP_MATCH, 1);
+                    }
+                    LV<bool> pnv;
+                    FOR_LANES(l) { pnv[l] = l < r && offv[l] >= k_minus_1; }
+                    const int32_t np = popc64(wave_ballot(pnv));          // a prefix of the run: offsets fall by one per step
+                    FOR_LANES(l) { if (l < np) gst(w.rev_nodes + n_path + l, nodev[l]); }
+                    if (np) last_path_node = wave_bcast(nodev, np - 1);
+                    n_path += np;
+                    n_trace += r;
+                    LV<int32_t> scr;
+                    FOR_LANES(l) { scr[l] = l < r ? scv[l] : 0; }
+                    extra_score += wave_sum(scr);
+                    align_offset = imin(wave_bcast(offv, r - 1), k_minus_1);
+                    pos -= r;
+                    j = wave_bcast(parv, r - 1);
+                    steps += r - 1;
+                    if (j) { col = col_load(w, j); par = col_load(w, col.parent); }
+                    if (w.status != ST_OK) return true;
+                    continue;
+                }
+            }
             ColMeta gp = par;
             if (col.parent > 0) {                                      // par is not the root
                 const int32_t t = par.parent;

@@ -130,6 +130,7 @@ struct AlignParams {
     uint32_t no_flat;                    // A/B and test switch: the per-read program instead of the flat group loop
     uint32_t no_alias;                   // A/B and test switch: every convergence-table entry gets its own vector in the pool
     uint32_t no_compact;                 // A/B and test switch: chain columns always in the two-line form (ColSlot)
+    uint32_t no_bt_runs;                 // A/B and test switch: the trace walk one step at a time (no lane-parallel diagonal runs)
     uint32_t groups_per_wave;            // extension kernel: groups of a wavefront that take reads (0 = all).  A batch with fewer reads
                                          // than resident groups is spread over the wavefronts, so that a long read does not run in
                                          // lock-step with seven others

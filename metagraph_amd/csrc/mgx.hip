@@ -855,6 +855,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.no_compact = no_compact;
     static const bool no_alias = getenv("MGX_NO_ALIAS") && atoi(getenv("MGX_NO_ALIAS")) == 1;
     P.no_alias = no_alias;
+    static const bool no_bt_runs = getenv("MGX_NO_BT_RUNS") && atoi(getenv("MGX_NO_BT_RUNS")) == 1;
+    P.no_bt_runs = no_bt_runs;
     static const bool no_flat = getenv("MGX_NO_FLAT") && atoi(getenv("MGX_NO_FLAT")) == 1;
     P.no_flat = no_flat;
     P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results

@@ -320,6 +320,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
     P.no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;
     P.no_alias = getenv("MGX_NO_ALIAS") && atoi(getenv("MGX_NO_ALIAS")) == 1;
+    P.no_bt_runs = getenv("MGX_NO_BT_RUNS") && atoi(getenv("MGX_NO_BT_RUNS")) == 1;
     auto w = std::make_unique<Wave>();
     SdustScratch sd;
     // model a small LDS so that both placements (LDS / arena) of the fast arrays are exercised
