@@ -92,6 +92,7 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
     // cells from `hi` on hold nothing (beyond the overshoot of update_column and beyond the column's end): whole blocks of four
     // are skipped; the insertion run may move the end once, when the pass reaches the column's last cell
     int32_t hi = bo + imax(n_loop, size0);
+    bool fallback = false;
 #pragma unroll
     for (int b = 0; b < LFW / 4; ++b) {
         uint32_t fwb = 0;
@@ -126,28 +127,36 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
                             const int32_t room = max_size - (size0 + 1);
                             n_push = 1 + room;
                             if (ge != 0) n_push = 1 + imin(room, (int32_t)((uint32_t)(ins - cutoff) / (uint32_t)(-ge)));
-                            if (bo + size0 + n_push > LFW) return LC_FALLBACK;
-                            pushing = true;
+                            // (no exit out of the unrolled pass: an exit edge makes the compiler keep two copies of the window and
+                            // move one onto the other at every block; the pass runs on and its result is discarded)
+                            fallback = bo + size0 + n_push > LFW;
+                            n_push = fallback ? 0 : n_push;
+                            pushing = !fallback;
                             ins_score = ins;
                             hi = imax(hi, bo + size0 + n_push);
                         }
                     }
                 }
-                bool in_col = (uint32_t)jj < (uint32_t)size0;
-                if (pushing && jj >= size0) {
+                {
+                    // behind the column's last cell: the insertion run, then nothing
                     const int32_t t = jj - size0;
-                    const bool pc = t < n_push;
+                    const bool beyond = pushing && t >= 0;
+                    const bool pc = beyond && t < n_push;
                     const int32_t v = ins_score + t * ge;
-                    sv = pc ? v : NINF; ce = pc ? v : NINF; fv = NINF; in_col = pc;
-                }
-                // scan (:643-669) and what the convergence table takes for a node's first column
-                if (in_col) {
+                    sv = beyond ? (pc ? v : NINF) : sv;
+                    ce = beyond ? (pc ? v : NINF) : ce;
+                    fv = beyond ? NINF : fv;
+                    const bool in_col = (uint32_t)jj < (uint32_t)size0 || pc;
+                    // scan (:643-669) and what the convergence table takes for a node's first column (selects, not branches: every
+                    // branch in the unrolled pass costs the compiler's exec-mask bookkeeping 32 times over)
                     const int32_t kk = (iabs(a - diag_i) << 12) | jj;
-                    key = sv > mx ? kk : (sv == mx ? imin(key, kk) : key);
-                    mx = imax(mx, sv);
-                    mn = sv != NINF ? imin(mn, sv) : mn;
-                    ext |= sv + (in.psum_lin ? (in.qlen - (in.start + a)) * in.psum_lin : in.psum[in.start + a]) >= extension_cutoff;
-                    conv = jj >= skip ? imax(conv, sv) : conv;
+                    const int32_t svc = in_col ? sv : INT32_MIN;                       // a cell outside the column never wins
+                    key = svc > mx ? kk : ((svc == mx && in_col) ? imin(key, kk) : key);
+                    mx = imax(mx, svc);
+                    mn = (in_col && sv != NINF) ? imin(mn, sv) : mn;
+                    const int32_t ps_here = in.psum_lin ? (in.qlen - (in.start + a)) * in.psum_lin : (in_col ? in.psum[in.start + a] : 0);
+                    ext |= in_col && sv + ps_here >= extension_cutoff;
+                    conv = (in_col && jj >= skip) ? imax(conv, sv) : conv;
                 }
                 // the flag byte (what backtrack compares, evaluated once: ColSlot)
                 {
@@ -172,6 +181,7 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
         }
         out.fw[b] = fwb;
     }
+    if (fallback) return LC_FALLBACK;
     const int32_t pushes = pushing ? n_push : 0;
     out.min_cell_score = imin(in.min_cell_score, mn);
     out.has_extension = in.in_seed || ext;
