@@ -25,7 +25,9 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 2      /* 2 (round 3): mgx_annotation_*; mgx_stats / mgx_config grew in round 2 without a bump (callers built
+#define MGX_ABI_VERSION 3      /* 3 (round 4): mgx_alignment::n_labels / labels_begin, mgx_results::labels (label-aware alignment),
+                                * mgx_stats::extend_kernels / n_lane_reads / lane_ms, "key=value" options of mgx_aligner_set_pipeline;
+                                * 2 (round 3): mgx_annotation_*; mgx_stats / mgx_config grew in round 2 without a bump (callers built
                                 * against 1 must be rebuilt: mgx_aligner_stats writes the larger struct) */
 
 enum {
@@ -159,7 +161,9 @@ typedef struct mgx_alignment {
     uint64_t cigar_begin;     /* index into mgx_results.cigar */
     uint64_t seq_begin;       /* index into mgx_results.seqs  */
     uint8_t orientation;      /* get_orientation(): 1 = reverse complement of the query matched */
-    uint8_t _pad[7];
+    uint8_t _pad[3];
+    uint32_t n_labels;        /* label_columns.size() (alignment.hpp:327; 0 without an annotation) */
+    uint64_t labels_begin;    /* index into mgx_results.labels: the alignment's label columns, ascending */
 } mgx_alignment;
 
 /* Results of one batch: AlignmentResults per query (alignment.hpp:366-406), in batch order. */
@@ -171,6 +175,7 @@ typedef struct mgx_results {
     const mgx_cigar_op *cigar;
     const char *seqs;
     const int32_t *status;            /* per query: MGX_OK or MGX_ERR_CAPACITY */
+    const uint32_t *labels;           /* Alignment::label_columns of all alignments (label-aware alignment; else NULL) */
 } mgx_results;
 
 /* Seeding-only output (DeBruijnGraph::map_to_nodes_sequentially for both strands). */
@@ -201,7 +206,12 @@ typedef struct mgx_stats {
                                                  extension kernel */
     uint64_t n_seed_lines;      /* split pipeline: part of the line counters issued by the seeding kernel */
     uint64_t n_fast_columns;    /* part of n_columns computed by the register-resident chain path */
+    uint64_t extend_kernels;    /* which extension kernels the last batch launched (MGX_KERNEL_* bits): what a parity test
+                                   asserts so that it is known to have exercised the kernel it means to */
+    uint64_t n_lane_reads;      /* reads the lane-per-read kernel finished on its own (the rest went on to the group kernel) */
+    double lane_ms;             /* HIP-event time of the lane-per-read kernel (part of extend_ms) */
 } mgx_stats;
+enum { MGX_KERNEL_GRP8 = 1, MGX_KERNEL_GRP8_PRIM = 2, MGX_KERNEL_GRP8_ALT = 4, MGX_KERNEL_EXT64 = 8, MGX_KERNEL_LANE = 16 };
 
 int mgx_device_count(void);                 /* number of visible HIP devices (0 without a GPU) */
 const char *mgx_last_error(void);
@@ -261,11 +271,19 @@ int mgx_map_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uin
                   int seqs_on_device, mgx_mapping *out);
 
 int mgx_aligner_stats(const mgx_aligner *a, mgx_stats *out);
+/* Test hook: launches of each extension kernel since the library was loaded, out5[b] = the kernel of bit b of MGX_KERNEL_*
+ * (8-lane groups, its PRIMARY build, its alternative-paths build, the 64-lane kernel, the lane-per-read kernel). */
+void mgx_kernel_launch_counts(uint64_t *out5);
 
-/* Test hook.  "split8" names the (only) pipeline: seeding kernel with one wavefront per read, radix sort of the reads
- * by predicted extension work, extension kernel with 8 lanes per read.  "general" / "chain" switch the extension
- * kernel's register-resident chain path off / on (results are identical; parity tests run both).  Unknown name:
- * MGX_ERR_INVALID. */
+/* Kernel-selection switches; every setting gives the same alignments (the parity suite runs them all).  "split8" names the
+ * (only) pipeline: seeding kernel with one wavefront per read, radix sort of the reads by predicted extension work, extension
+ * kernel(s).  "general" / "chain": the extension's register-resident chain path off / on.  "key=value" (-1 = automatic):
+ *   ext64=0|1            small batches on the one-read-per-wavefront 64-lane kernel (default 1) or on the 8-lane groups
+ *   groups_per_wave=n    8-lane kernel: n = 1 .. 8 groups of a wavefront take reads, 0 = all (default: from the batch size)
+ *   multi_pass=0|1       one extension per read and launch (default: automatic from the seeds per read); two_pass=1
+ *   lane=0|1             the lane-per-read kernel in front of the group kernel (default: automatic)
+ *   no_compact / no_alias / no_bt_runs / no_flat / primary_alt_build = 1   A/B forms of the column records and loops
+ * Unknown name: MGX_ERR_INVALID.  (Measurement probes that change results or occupancy exist only in -DMGX_PROBES builds.) */
 int mgx_aligner_set_pipeline(mgx_aligner *a, const char *name);
 
 /* Format one query's results exactly like format_alignment() (cli/align.cpp:254-285):

@@ -71,13 +71,19 @@ class Graph:
 
 
 class Aligner:
-    """DBGAligner<> on the GPU (default seeder/extender, BASIC graphs)."""
+    """DBGAligner<> on the GPU (default seeder/extender)."""
+
+    # kernel-selection options (mgx_aligner_set_pipeline "key=value") every new aligner starts with: all of them give the
+    # same alignments; the parity suite sets this to run a kernel the automatic choice would not pick for its batch sizes
+    default_options = ()
 
     def __init__(self, graph, config, limits=None):
         self.graph = graph
         self.h = C.c_void_p()
         _check(capi.lib().mgx_aligner_create(graph.h, C.byref(config), C.byref(limits) if limits is not None else None,
                                              C.byref(self.h)))
+        for opt in Aligner.default_options:
+            self.set_pipeline(opt)
 
     def close(self):
         if getattr(self, "h", None) and capi is not None:
@@ -118,7 +124,8 @@ class Aligner:
         return out
 
     def set_pipeline(self, name):
-        """Tuning/test hook: 'split8' (the pipeline), 'general' / 'chain' (extension chain path off / on)."""
+        """Kernel selection: 'split8' (the pipeline), 'general' / 'chain' (extension chain path off / on), 'key=value'
+        options (include/mgx.h, mgx_aligner_set_pipeline); results never depend on it."""
         L = capi.lib()
         L.mgx_aligner_set_pipeline.argtypes = [C.c_void_p, C.c_char_p]
         _check(L.mgx_aligner_set_pipeline(self.h, name.encode()))

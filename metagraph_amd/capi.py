@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 MGX_OK = 0
-MGX_ABI_VERSION = 2
+MGX_ABI_VERSION = 3
 MGX_ERR_INVALID, MGX_ERR_NO_DEVICE, MGX_ERR_UNSUPPORTED, MGX_ERR_CONFIG, MGX_ERR_CAPACITY, MGX_ERR_OOM = -1, -2, -3, -4, -5, -6
 OP_CHARS = "SX=DIG"
 
@@ -50,13 +50,14 @@ class Alignment(C.Structure):
                 ("end_clipping", C.c_uint32), ("num_matches", C.c_uint32), ("n_nodes", C.c_uint32),
                 ("n_cigar", C.c_uint32), ("seq_len", C.c_uint32), ("nodes_begin", C.c_uint64),
                 ("cigar_begin", C.c_uint64), ("seq_begin", C.c_uint64), ("orientation", C.c_uint8),
-                ("_pad", C.c_uint8 * 7)]
+                ("_pad", C.c_uint8 * 3), ("n_labels", C.c_uint32), ("labels_begin", C.c_uint64)]
 
 
 class Results(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("aln_begin", C.POINTER(C.c_uint64)),
                 ("alignments", C.POINTER(Alignment)), ("nodes", C.POINTER(C.c_uint64)),
-                ("cigar", C.POINTER(CigarOp)), ("seqs", C.POINTER(C.c_char)), ("status", C.POINTER(C.c_int32))]
+                ("cigar", C.POINTER(CigarOp)), ("seqs", C.POINTER(C.c_char)), ("status", C.POINTER(C.c_int32)),
+                ("labels", C.POINTER(C.c_uint32))]
 
 
 class Mapping(C.Structure):
@@ -70,7 +71,11 @@ class Stats(C.Structure):
                 ("n_seeds", C.c_uint64), ("n_map_lines", C.c_uint64), ("n_capacity_errors", C.c_uint64), ("phase_cycles", C.c_uint64 * 8), ("extend_cycles", C.c_uint64 * 8),
                 ("seed_kernel_ms", C.c_double), ("align_kernel_ms", C.c_double),
                 ("seeding_ms", C.c_double), ("sort_ms", C.c_double), ("extend_ms", C.c_double), ("n_seed_lines", C.c_uint64),
-                ("n_fast_columns", C.c_uint64)]
+                ("n_fast_columns", C.c_uint64), ("extend_kernels", C.c_uint64), ("n_lane_reads", C.c_uint64),
+                ("lane_ms", C.c_double)]
+
+
+KERNEL_GRP8, KERNEL_GRP8_PRIM, KERNEL_GRP8_ALT, KERNEL_EXT64, KERNEL_LANE = 1, 2, 4, 8, 16
 
 
 def results_to_py(res):
@@ -107,7 +112,7 @@ def results_arrays(res):
     aln_dt = np.dtype([("score", "<i4"), ("offset", "<u4"), ("clipping", "<u4"), ("end_clipping", "<u4"),
                        ("num_matches", "<u4"), ("n_nodes", "<u4"), ("n_cigar", "<u4"), ("seq_len", "<u4"),
                        ("nodes_begin", "<u8"), ("cigar_begin", "<u8"), ("seq_begin", "<u8"), ("orientation", "u1"),
-                       ("_pad", "u1", (7,))])
+                       ("_pad", "u1", (3,)), ("n_labels", "<u4"), ("labels_begin", "<u8")])
     assert aln_dt.itemsize == C.sizeof(Alignment)
     alns = arr(res.alignments, na, aln_dt)
     tn = int(alns["n_nodes"].sum()) if na else 0

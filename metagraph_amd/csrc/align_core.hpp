@@ -64,6 +64,13 @@
 #define MGX_WITH_PRIMARY 0
 #endif
 
+// timing ablations (results become WRONG) are compiled into -DMGX_PROBES builds only
+#ifdef MGX_PROBES
+#define MGX_ABLATED(w, bit) ((MGX_PARAMS_OF(w).ablate & (bit)) != 0)
+#else
+#define MGX_ABLATED(w, bit) false
+#endif
+
 namespace mgx {
 
 constexpr bool kWithPrimary = MGX_WITH_PRIMARY != 0;
@@ -293,7 +300,12 @@ struct Staging { Tier S, F; int32_t col; };
 // the step functions of the flat extension loop are separate small functions.  fS / fF: S and F of the chain path's
 // current column, four consecutive window positions per lane starting at f_org.
 #ifndef MGX_NO_EXTEND
-constexpr int32_t FW = 4 * WAVE;
+constexpr int32_t FW = 4 * WAVE;                  // cells of the register window (4 per lane)
+// Cells of it the chain path may use: what a column slot holds (FWS).  The 64-lane instantiation (mgx_ext64.hip: FW = 256)
+// shares the arena layout of the 8-lane groups, so its chain columns are confined to the first FWS cells of the window — lanes
+// from FWS / 4 on stay ninf — and a wider band takes the general path, as it does in the 8-lane kernel.
+constexpr int32_t CHW = FW < FWS ? FW : FWS;
+static_assert(CHW <= FWS && CHW <= FW && (CHW & 3) == 0, "a chain column must fit its slot");
 struct XState {
     int32_t xdrop_cutoff, best_score, tsize, min_cell_score, qn, nn, n_tips;
     int32_t q_top;                        // score of the frontier's top entry (INT32_MIN when empty)
@@ -2295,7 +2307,7 @@ MGX_DEV int32_t reg_at(const LV<int32_t> &A0, const LV<int32_t> &A1, const LV<in
     return wave_bcast(t, x >> 2);
 }
 
-MGX_DEV bool fast_fits(const ColMeta &c) { return (c.trim & 3) + c.size + 3 <= FW; }
+MGX_DEV bool fast_fits(const ColMeta &c) { return (c.trim & 3) + c.size + 3 <= CHW; }
 
 // load column `idx` (metadata c) into the chain window from its staging buffer or its arena record
 MGX_DEV void fast_load(Wave &w, const ColMeta &c, int32_t idx, LV<int32_t> *S, LV<int32_t> *F) {
@@ -2662,7 +2674,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     // from here on a fallback hands the one child over through the children list (general_step reads it from there)
     x.f_n_out = 1;
     w.out_nodes[0] = next; w.out_chars[0] = c; w.out_scores[0] = score;
-    if ((begin - org) + imax(n_loop, size0) > FW) {
+    if ((begin - org) + imax(n_loop, size0) > CHW) {
         MGX_LC(if (lane_run(next_offset, score, in_seed, c) != LC_FALLBACK) lane_fail("window fallback");)
         wave_sync();
         return FR_FALLBACK;
@@ -2777,7 +2789,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             int32_t n_push = 1 + room;
             // (the chain path runs with |cutoff| <= 30000 and scores below 2^24: the difference fits 32 bits)
             if (ge != 0) n_push = 1 + imin(room, (int32_t)((uint32_t)(ins_score - xdrop_cutoff) / (uint32_t)(-ge)));
-            if ((begin - org) + size0 + n_push > FW) {
+            if ((begin - org) + size0 + n_push > CHW) {
                 // the parent window has moved: keep it consistent for the spill
                 x.f_org = p_org;
                 MGX_LC(if (lane_run(next_offset, score, in_seed, c) != LC_FALLBACK) lane_fail("ins_end fallback");)
@@ -2878,7 +2890,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             mdo[l] = 0;
         }
         converged = wave_max(cm);
-        if (next != 0 && !(MGX_PARAMS_OF(w).ablate & 1u)) {
+        if (next != 0 && !MGX_ABLATED(w, 1u)) {
             bool found;
             cv_slot = conv_probe_from(E.conv, ckey, chash, cse, found);
             if (!found) {
@@ -2955,16 +2967,16 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
     // Will the frontier hand this column straight back (:491-504: it is the unique maximum)?  Then nothing ever reloads
     // it and its slot is all it leaves behind; otherwise it also gets an S / F record.
     const bool chain_on = converged != NINF && x.nn == 0 && (x.qn == 0 || converged > x.q_top)
-                          && (begin & 3) + size + 3 <= FW;
+                          && (begin & 3) + size + 3 <= CHW;
     const bool deferred = converged != NINF && !chain_on;
     // commit: the column's slot (metadata, flag byte per cell, 16-bit S) ...
     ColMeta cur;
-    cur.node = next; cur.parent = x.f_idx; cur.cw = (uint32_t)c | ((uint32_t)FW << 8) | CW_CHAIN; cur.org = org; cur.offset = next_offset;
+    cur.node = next; cur.parent = x.f_idx; cur.cw = (uint32_t)c | ((uint32_t)CHW << 8) | CW_CHAIN; cur.org = org; cur.offset = next_offset;
     cur.max_pos = max_pos; cur.trim = begin; cur.score = score; cur.size = size;
     cur.base = max_val == NINF ? 0 : max_val;
     cur.cells = deferred ? x.cell_top : NO_CELLS;
     cur.self = my_idx;
-    if (!(MGX_PARAMS_OF(w).ablate & 2u)) {
+    if (!MGX_ABLATED(w, 2u)) {
         ColSlot *slot = w.cols + my_idx;
         const LV<int32_t> e_up = wave_shift_up1(cE[3], NINF);
         const int32_t ptrim = x.f_trim;
@@ -3048,11 +3060,13 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         } else {
             int16_t *srow = w.cols_s16 + (int64_t)my_idx * FWS;
             FOR_LANES(l) {
-                gst((uint32_t *)slot->flags + l, fwv[l]);
-                uint2 hv;
-                hv.x = ((uint32_t)hs[0][l] & 0xFFFF) | ((uint32_t)hs[1][l] << 16);
-                hv.y = ((uint32_t)hs[2][l] & 0xFFFF) | ((uint32_t)hs[3][l] << 16);
-                gst((uint2 *)srow + l, hv);
+                if (4 * l < CHW) {
+                    gst((uint32_t *)slot->flags + l, fwv[l]);
+                    uint2 hv;
+                    hv.x = ((uint32_t)hs[0][l] & 0xFFFF) | ((uint32_t)hs[1][l] << 16);
+                    hv.y = ((uint32_t)hs[2][l] & 0xFFFF) | ((uint32_t)hs[3][l] << 16);
+                    gst((uint2 *)srow + l, hv);
+                }
             }
             col_store(w, my_idx, cur);
         }
@@ -3060,10 +3074,12 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         if (deferred) {
             int32_t *rec = w.cells + x.cell_top;
             FOR_LANES(l) {
-                gst4(rec + 4 * l, cS[0][l], cS[1][l], cS[2][l], cS[3][l]);
-                gst4(rec + FW + 4 * l, cF[0][l], cF[1][l], cF[2][l], cF[3][l]);
+                if (4 * l < CHW) {
+                    gst4(rec + 4 * l, cS[0][l], cS[1][l], cS[2][l], cS[3][l]);
+                    gst4(rec + CHW + 4 * l, cF[0][l], cF[1][l], cF[2][l], cF[3][l]);
+                }
             }
-            x.cell_top += rec_words((uint32_t)FW);
+            x.cell_top += rec_words((uint32_t)CHW);
         }
     }
     CH_T(6)
@@ -4185,7 +4201,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
         int32_t mps = imax(0, P.cfg.min_cell_score);          // extend(): min_path_score = max(0, min_cell_score)
         const int n_alt = n_alt_of(w);
         int n_fwd;
-        if (P.ablate & 4u) { seed_as_alignment(w, seed, w.aln[0]); n_fwd = 1; }       // timing probe only
+        if (MGX_ABLATED(w, 4u)) { seed_as_alignment(w, seed, w.aln[0]); n_fwd = 1; }       // timing probe only
         else n_fwd = backtrack(w, s, seed, nullptr, er, mps, &w.aln[0], n_alt);
         w.cyc[3] += cycle_clock() - t1;
         if (w.status != ST_OK) return;
@@ -4264,7 +4280,7 @@ MGX_NI_G4 void aln_both(Wave &w, int s) {
             const ExtendResult er2 = w.er;
             if (w.status != ST_OK) return;
             int n_bwd;
-            if (P.ablate & 4u) { copy_aln(w.aln[2 * n_alt], rev); n_bwd = 1; }         // timing probe only
+            if (MGX_ABLATED(w, 4u)) { copy_aln(w.aln[2 * n_alt], rev); n_bwd = 1; }         // timing probe only
             else n_bwd = backtrack(w, 1 - s, rseed, &rev, er2, mps2, &w.aln[2 * n_alt], n_alt);
             w.cyc[3] += cycle_clock() - t3;
             if (w.status != ST_OK) return;
@@ -4448,7 +4464,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
                 }
             }
             wave_sync();
-            if (P.ablate & 8u) { w.n_seeds[0] = w.n_seeds[1] = 0; }          // timing probe: fetch + pick-up + output only
+            if (MGX_ABLATED(w, 8u)) { w.n_seeds[0] = w.n_seeds[1] = 0; }          // timing probe: fetch + pick-up + output only
         }
         if constexpr (PHASE == PH_SEED) {
             // publish: header, seeds, work key; the extension kernel writes the read's result record
@@ -4935,7 +4951,7 @@ MGX_DEV bool flat_read_begin(Wave &w, const AlignParams &P, uint64_t read, uint3
         }
     }
     wave_sync();
-    if (P.ablate & 8u) { w.n_seeds[0] = w.n_seeds[1] = 0; }          // timing probe: fetch + pick-up + output only
+    if (MGX_ABLATED(w, 8u)) { w.n_seeds[0] = w.n_seeds[1] = 0; }          // timing probe: fetch + pick-up + output only
     if (P.dbg_seeds && w.status == ST_OK) {
         for (int s = 0; s < 2; ++s)
             for (int32_t i = 0; i < w.n_seeds[s]; ++i)

@@ -109,6 +109,7 @@ struct HostResults {
     std::vector<mgx_cigar_op> cigar;
     std::vector<char> seqs;
     std::vector<int32_t> status;
+    std::vector<uint32_t> labels;      // label columns of all alignments (label-aware alignment only)
 
     // words one alignment occupies in the stream
     static uint64_t aln_words(uint32_t n_nodes, uint32_t n_cigar, uint32_t seq_len) { return (uint64_t)n_nodes + n_cigar + ((uint64_t)seq_len + 3) / 4; }
@@ -177,6 +178,7 @@ struct HostResults {
         out->cigar = cigar.data();
         out->seqs = seqs.data();
         out->status = status.data();
+        out->labels = labels.empty() ? nullptr : labels.data();
     }
 };
 

@@ -44,20 +44,36 @@ struct LaneColumnOut {
 
 enum { LC_OK = 0, LC_EMPTY_BAND = 1, LC_FALLBACK = 2, LC_POP = 3 };
 
+// profile_score_[c][start + a] (:38-59) of the child's character against the query, by window cell: prepare(ap0) is told the
+// absolute position of cell 0 once the window's origin is known, at(x, ap) returns the score of cell x (ap == ap0 + x).
+// This one reads the byte query and the score-matrix row (the 8-lane groups' data; the cross-check build); the lane-per-read
+// kernel brings its own over the 2-bit packed strand (lane_read.hpp).
+struct LaneProfBytes {
+    const uint8_t *q; const int8_t *row; int32_t qlen;
+    MGX_HD void prepare(int32_t) {}
+    MGX_HD int32_t at(int, int32_t ap) const { return (ap >= 1 && ap <= qlen) ? (int32_t)row[q[ap - 1] & 127] : 0; }
+};
+
+// band within the x-drop cut-off (:549-560): [begin, prev_end) in window positions; empty when prev_end <= begin
+MGX_HD void lane_band(const LaneColumnIn &in, const int32_t *S, int32_t &begin, int32_t &prev_end) {
+    begin = INT32_MAX; prev_end = INT32_MIN;
+#pragma unroll
+    for (int x = 0; x < LFW; ++x) {
+        const int32_t a = in.p_org + x, j = a - in.p_trim;
+        if (j >= 0 && j < in.p_size && S[x] >= in.xdrop_cutoff) { begin = imin(begin, a); prev_end = imax(prev_end, a + 1); }
+    }
+}
+
 // S, F: in = the parent's window (cell x is window position in.p_org + x), out = the child's (cell x is position out.org + x).
 // LC_EMPTY_BAND: no parent cell within the x-drop (chain_step returns FR_END before anything else; window untouched).
 // LC_FALLBACK: the column does not fit the window (untouched if the band itself does not fit; clobbered if the insertion
 // run behind the column's end does not).  LC_POP: computed, but popped again (:646-653: below the cut-off or nothing left to
 // gain).  LC_OK: S / F / out hold the column as chain_step would commit it.
-MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColumnOut &out) {
+template <class Prof>
+MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColumnOut &out, Prof &profile) {
     const int32_t go = in.go, ge = in.ge, score = in.score, cutoff = in.xdrop_cutoff;
-    // band within the x-drop cut-off (:549-560)
-    int32_t begin = INT32_MAX, prev_end = INT32_MIN;
-#pragma unroll
-    for (int x = 0; x < LFW; ++x) {
-        const int32_t a = in.p_org + x, j = a - in.p_trim;
-        if (j >= 0 && j < in.p_size && S[x] >= cutoff) { begin = imin(begin, a); prev_end = imax(prev_end, a + 1); }
-    }
+    int32_t begin, prev_end;
+    lane_band(in, S, begin, prev_end);
     if (prev_end <= begin) return LC_EMPTY_BAND;
     const int32_t end = imin(prev_end, in.window_size) + 1;
     const int32_t size0 = end - begin;
@@ -65,6 +81,7 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
     const int32_t n_prev = prev_end - begin, n_loop = (n_prev + 3) & ~3;
     const int32_t org = begin & ~3;
     if ((begin - org) + imax(n_loop, size0) > LFW) return LC_FALLBACK;
+    profile.prepare(in.start + org);
     // the parent moves to the child's origin, four cells at a time (both origins are multiples of four); the cell just below
     // the new origin is kept: the first cell's match compares against it
     int32_t p_below = NINF;
@@ -103,8 +120,7 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
                 const int32_t a = org + x, jj = x - bo;
                 const int32_t ps = S[x], pf = F[x];          // the parent at a
                 const int32_t ap = in.start + a;
-                int32_t prof = 0;
-                if (ap >= 1 && ap <= in.qlen) prof = (int32_t)in.row[in.q[ap - 1] & 127];
+                const int32_t prof = profile.at(x, ap);
                 const int32_t mraw = sm1 + prof + score;
                 const bool inl = (uint32_t)jj < (uint32_t)n_loop;
                 const int32_t del = has_del ? imax(ps + go, pf + ge) + score : NINF;
@@ -191,6 +207,13 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
     out.converged = conv;
     if ((!in.in_seed && mx < cutoff) || (!in.in_seed && !out.has_extension)) return LC_POP;
     return LC_OK;
+}
+
+// the byte-query form (LaneColumnIn::q / row)
+MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColumnOut &out) {
+    LaneProfBytes pb;
+    pb.q = in.q; pb.row = in.row; pb.qlen = in.qlen;
+    return lane_column(in, S, F, out, pb);
 }
 
 } // namespace mgx

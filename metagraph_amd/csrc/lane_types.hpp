@@ -1,0 +1,71 @@
+// lane_types.hpp — what the host needs to know about the lane-per-read kernel (lane_read.hpp, mgx_lane.hip): its launch
+// parameters, its scratch layout and the test of whether a batch's configuration is one the kernel takes at all.
+#pragma once
+#include <string>
+
+#include "../../include/mgx.h"
+#include "align_types.hpp"
+
+
+namespace mgx {
+
+constexpr int LANE_MAX_L = 256;            // longest read a lane takes (packed strand in LDS: LANE_QWORDS words per lane)
+constexpr int LANE_QWORDS = LANE_MAX_L / 32 + 2;
+constexpr int LANE_MAX_RUNS = 16;          // CIGAR runs of a trace kept in LDS
+constexpr int LANE_MAX_LATER = 4;          // later seeds of the strand checked against the extension
+constexpr int LANE_SLOT_BYTES = 64;        // per column: 32 flag bytes + node + base + geometry (+ 4 unused words)
+constexpr int LANE_S8_BYTES = 32;          // per column: S of the window as 8-bit offsets from `base` (read at the trace's end only)
+
+// what one launch of the lane kernel needs on top of AlignParams
+struct LaneParams {
+    AlignParams P;
+    const uint64_t *pk[2];               // 2-bit packed strands (k_pack_reads): word j of read r at packed_word_begin(offsets[r], r) + j
+    const uint32_t *iv[2];               // invalid-character flags, same indexing
+    uint8_t *scratch;                    // per resident lane: column slots | S8 rows | node table
+    uint64_t scratch_stride;
+    uint32_t max_cols;                   // columns a lane's scratch holds (Lmax + 2)
+    uint32_t hash_slots;                 // power of two >= 2 * max_cols
+    uint32_t tag_seed;                   // changes per launch (node-table entries of earlier launches read as empty)
+    uint32_t t4[4];                      // score_matrix[c][q] for c, q in ACGT: row c as four bytes (q = A in the low byte)
+    int32_t self_score;                  // score(A, A) == ... == score(T, T) > 0 (else the kernel is not launched)
+    uint32_t *bail_list;                 // reads for the group kernel, in processing order
+    unsigned long long *bail_count;
+    unsigned long long *done_count;
+};
+
+inline uint64_t lane_scratch_bytes(uint32_t max_cols, uint32_t hash_slots) {
+    return (uint64_t)max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)hash_slots * 8;
+}
+
+
+// Whether the lane-per-read kernel may run in front of the group kernel for this configuration (every read it cannot finish
+// goes to the group kernel anyway; this only rules out configurations in which its shortcuts would not be exact or no read
+// could finish), and the scoring constants it runs with.  `why`: the first reason against.
+inline bool lane_enabled(const mgx_config &c, const DevConfig &d, uint32_t k, uint32_t Lmax, bool no_fast, LaneParams *LP, std::string *why) {
+    auto no = [&](const char *w) { if (why) *why = w; return false; };
+    if (d.num_alt != 1) return no("alternative paths");
+    if (d.canonical != 0) return no("CANONICAL / PRIMARY graph");
+    if (k > 32 || k < 2) return no("k > 32: reads are not 2-bit packed");
+    if (Lmax < 1 || Lmax > (uint32_t)LANE_MAX_L) return no("reads longer than a lane takes");
+    if (no_fast || c.xdrop > 30000) return no("chain path off");
+    const char acgt[4] = { 'A', 'C', 'G', 'T' };
+    const int m = c.score_matrix[(int)'A'][(int)'A'];
+    if (m <= 0) return no("match score");
+    for (int x = 0; x < 4; ++x) {
+        if (c.score_matrix[(int)acgt[x]][(int)acgt[x]] != m) return no("match scores differ");
+        uint32_t row = 0;
+        for (int y = 0; y < 4; ++y) {
+            const int v = c.score_matrix[(int)acgt[x]][(int)acgt[y]];
+            if (v > m) return no("a mismatch scores above a match");
+            row |= (uint32_t)(uint8_t)(int8_t)v << (8 * y);
+        }
+        LP->t4[x] = row;
+    }
+    if (c.gap_opening_penalty > 0 || c.gap_extension_penalty > 0) return no("positive gap scores");
+    if (c.left_end_bonus < 0) return no("negative left end bonus");
+    if (!(c.rel_score_cutoff >= 0.0 && c.rel_score_cutoff <= 1.0)) return no("rel_score_cutoff outside [0, 1]");
+    LP->self_score = m;
+    return true;
+}
+
+} // namespace mgx

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -313,6 +314,21 @@ extern "C" int mgx_grp_waves_per_simd8_prim(void);
 // predicted extension work, extension by 8-lane groups (8 reads per wavefront, mgx_grp.hip).  (Round 1 also carried
 // fused and 16- / 64- / 1-lane instantiations for A/B measurements; they are gone.)
 enum AlignMode { MODE_SPLIT8 = 4, MODE_BAD = -1 };
+
+// launches of every extension kernel since the library was loaded (mgx_kernel_launch_counts; bit order of MGX_KERNEL_*)
+static std::atomic<uint64_t> g_kernel_launches[5];
+
+// Measurement probes (occupancy scans, LDS caps, ablations that give WRONG results) exist only in -DMGX_PROBES builds
+// (tools/build_variant.sh); the product library ignores their environment variables.
+#ifdef MGX_PROBES
+static bool probe_env_set(const char *name) { const char *e = getenv(name); return e && *e && strcmp(e, "0") != 0; }
+static uint32_t probe_env_u32(const char *name, uint32_t dflt) { const char *e = getenv(name); return e ? (uint32_t)atoi(e) : dflt; }
+static uint32_t probe_env_pct(const char *name) { const char *e = getenv(name); return e ? (uint32_t)std::min(100, std::max(1, atoi(e))) : 100u; }
+#else
+static inline bool probe_env_set(const char *) { return false; }
+static inline uint32_t probe_env_u32(const char *, uint32_t dflt) { return dflt; }
+static inline uint32_t probe_env_pct(const char *) { return 100u; }
+#endif
 static AlignMode parse_mode(const char *e) {
     if (!e) return MODE_BAD;
     if (!strcmp(e, "split8")) return MODE_SPLIT8;
@@ -346,12 +362,25 @@ struct mgx_aligner {
     mgx_stats hstats;
     hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     bool split_ran = false;
+    uint64_t kernels_ran = 0;     // MGX_KERNEL_* bits of the extension kernels the last batch launched
     uint64_t seed_scale = 1, seed_cap = 0;
     AlignMode mode = default_mode();
     uint64_t arena_stride = 0;
     uint64_t out_words = 0;       // capacity of `stream` for the current batch shape
     uint64_t out_min_words = 0;   // raised when a batch overflowed the heuristic size
     bool no_fast = false;         // test hook: extension through the general path only
+    // Result-preserving kernel-selection switches (mgx_aligner_set_pipeline "key=value"; INTEGRATION.md "run-time switches").
+    // Every combination gives the same alignments; the parity suite runs the kernels the automatic choice would not pick for
+    // its small batches through them.  -1 = automatic.
+    struct Options {
+        int ext64 = 1;            // 0: never the 64-lane one-read-per-wavefront kernel (small batches run the 8-lane groups)
+        int groups_per_wave = -1; // 0 = all 8 groups of a wavefront take reads, 1 .. 8 = that many
+        int multi_pass = -1;      // multi-pass extension on / off
+        int two_pass = 0;
+        int no_compact = 0, no_alias = 0, no_bt_runs = 0, no_flat = 0;
+        int primary_alt_build = 0;
+        int lane = -1;            // the lane-per-read kernel in front of the extension kernel: -1 auto, 0 off, 1 forced
+    } opt;
 };
 
 extern "C" {
@@ -724,7 +753,7 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
         const uint64_t chains = (do_rc ? 2 : 1) * n;
         uint64_t blocks = std::min<uint64_t>((uint64_t)prop.multiProcessorCount * MGX_MAP_BLOCKS_PER_CU, (chains + 255) / 256);
         if (blocks == 0) blocks = 1;
-        static const bool no_pack = getenv("MGX_MAP_BYTES") != nullptr;          // A/B probe: the byte-per-character path
+        const bool no_pack = probe_env_set("MGX_MAP_BYTES");          // A/B probe: the byte-per-character path
         if (A->graph->g.k <= 32 && Lmax > 0 && !no_pack) {
             // words: every read starts at (offset >> 5) + read and takes ceil(L / 32) of them
             const uint64_t words = ((A->total_kmers + n * (uint64_t)A->graph->g.k) >> 5) + n + 2;
@@ -784,7 +813,11 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     const AlignMode mode = A->mode;
     const bool split = mode == MODE_SPLIT8;      // always
     const uint64_t wave_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;   // seeding kernel: one wavefront per read
-    const uint64_t want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * (uint64_t)mgx_grp_waves_per_simd8());
+    // (the extension kernel that will run: the same alt / prim selection as launch_groups below)
+    const bool sel_primary = A->dcfg.canonical >= 2;
+    const bool sel_alt = A->cfg.num_alternative_paths > 1 || (sel_primary && A->opt.primary_alt_build == 1);
+    const uint64_t ext_wps = sel_alt ? mgx_grp_waves_per_simd8_alt() : sel_primary ? mgx_grp_waves_per_simd8_prim() : mgx_grp_waves_per_simd8();
+    const uint64_t want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * ext_wps);
     // The arena gets what is free after the buffers this stage allocates AFTER it (result records, output stream, seed
     // stream, sort arrays: estimated generously) and a margin; buffers kept from an earlier batch are already outside
     // `free_b`.  (Half of the free memory, as before, left 15 % of the extension kernel's groups without a slice at
@@ -809,7 +842,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         }
     }
     A->n_slots = (uint32_t)slots;
-    if (getenv("MGX_DEBUG_SLOTS")) fprintf(stderr, "run_align: n %llu stride %llu want_slots %llu slots %llu free %.1f GB\n", (unsigned long long)n, (unsigned long long)stride, (unsigned long long)want_slots, (unsigned long long)slots, free_b / 1e9);
+    if (probe_env_set("MGX_DEBUG_SLOTS")) fprintf(stderr, "run_align: n %llu stride %llu want_slots %llu slots %llu free %.1f GB\n", (unsigned long long)n, (unsigned long long)stride, (unsigned long long)want_slots, (unsigned long long)slots, free_b / 1e9);
     if (int rc = A->results.ensure(n * sizeof(ReadResult))) return rc;
     uint64_t words_per_read = ((uint64_t)l.Lmax + l.Lmax / 4 + 40) * std::max<uint64_t>(1, A->cfg.num_alternative_paths);
     // heuristic size (one alignment per read: nodes + CIGAR runs + path characters); a batch that needs more is re-run
@@ -849,17 +882,14 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.read_cursor = cur + 1;
     P.stats = A->d_stats.as<KernelStats>();
     P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
-    static const bool no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;      // A/B switch: general path only
-    P.no_fast = no_fast || A->no_fast;
-    static const bool no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;
-    P.no_compact = no_compact;
-    static const bool no_alias = getenv("MGX_NO_ALIAS") && atoi(getenv("MGX_NO_ALIAS")) == 1;
-    P.no_alias = no_alias;
-    static const bool no_bt_runs = getenv("MGX_NO_BT_RUNS") && atoi(getenv("MGX_NO_BT_RUNS")) == 1;
-    P.no_bt_runs = no_bt_runs;
-    static const bool no_flat = getenv("MGX_NO_FLAT") && atoi(getenv("MGX_NO_FLAT")) == 1;
-    P.no_flat = no_flat;
-    P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results
+    P.no_fast = A->no_fast;
+    P.no_compact = A->opt.no_compact != 0;
+    P.no_alias = A->opt.no_alias != 0;
+    P.no_bt_runs = A->opt.no_bt_runs != 0;
+    P.no_flat = A->opt.no_flat != 0;
+#ifdef MGX_PROBES
+    P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results (probe builds only)
+#endif
     size_t sort_tmp_bytes = 0;
     if (split) {
         // seeds travel from the seeding kernel to the extension kernel through a compact stream
@@ -896,12 +926,12 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     const uint32_t w_slots = (uint32_t)std::min<uint64_t>(slots, wave_slots);
     auto launch_groups = [&](int phase) -> int {
         // tuning probe: MGX_EXT_GROUPS_PCT=50 launches half the resident groups (occupancy experiments)
-        static const uint32_t pct = getenv("MGX_EXT_GROUPS_PCT") ? (uint32_t)std::min(100, std::max(1, atoi(getenv("MGX_EXT_GROUPS_PCT")))) : 100u;
+        const uint32_t pct = probe_env_pct("MGX_EXT_GROUPS_PCT");
         const uint32_t groups = 8;
         // three builds of the extension kernel (mgx_grp.hip): the product, the product with the CanonicalDBG branches (PRIMARY
         // graphs), and the one with room for alternative paths (either kind of graph; MGX_PRIMARY_ALT_BUILD=1: A/B switch that
         // sends PRIMARY graphs there as rounds 2-3 did)
-        static const bool prim_to_alt = getenv("MGX_PRIMARY_ALT_BUILD") && atoi(getenv("MGX_PRIMARY_ALT_BUILD")) == 1;
+        const bool prim_to_alt = A->opt.primary_alt_build == 1;
         const bool primary = A->dcfg.canonical >= 2;
         const bool alt = A->cfg.num_alternative_paths > 1 || (primary && prim_to_alt);
         const bool prim = primary && !alt;
@@ -909,7 +939,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         const uint32_t static_lds = alt ? mgx_grp_static_lds8_alt() : prim ? mgx_grp_static_lds8_prim() : mgx_grp_static_lds8();
         uint32_t per_wave = (160u * 1024u) / waves_cu - static_lds - 64u;
         uint32_t per_group = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave / groups) & ~15u;
-        if (const char *e = getenv("MGX_EXT_LDS_CAP")) per_group = std::min<uint32_t>(per_group, (uint32_t)atoi(e)) & ~15u;   // tuning probe
+        per_group = std::min<uint32_t>(per_group, probe_env_u32("MGX_EXT_LDS_CAP", per_group)) & ~15u;   // tuning probe
         {
             // Fewer reads than resident groups (long-read batches, single queries): spread them over the wavefronts.  The 8
             // groups of a wavefront execute in lock-step, and reads of 1 .. 12 kbp side by side wait for each other's general
@@ -917,7 +947,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             // slices stay what they are: slot = wavefront x groups_per_wave + group.
             const uint64_t launch_groups_n = std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100));
             const uint64_t resident_waves = (uint64_t)prop.multiProcessorCount * waves_cu;
-            static const int gpw_env = getenv("MGX_GROUPS_PER_WAVE") ? atoi(getenv("MGX_GROUPS_PER_WAVE")) : -1;      // A/B: 0 = all 8
+            const int gpw_env = A->opt.groups_per_wave;      // 0 = all 8
             const uint64_t items = P.n_items ? P.n_items : n;                       // (a later pass of the multi-pass extension: its retry positions)
             const uint64_t busy = std::min<uint64_t>(launch_groups_n, std::max<uint64_t>(1, items));
             const uint64_t want_gpw = std::min<uint64_t>(groups, std::max<uint64_t>(1, (busy + resident_waves - 1) / resident_waves));
@@ -925,32 +955,37 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         }
         // One read per wavefront: the 64-lane instantiation (mgx_ext64.hip) — the read has the wavefront to itself, so it may as
         // well use all of its lanes.  MGX_EXT64=0: A/B switch.
-        static const bool ext64 = !(getenv("MGX_EXT64") && atoi(getenv("MGX_EXT64")) == 0);
+        const bool ext64 = A->opt.ext64 != 0;
         if (ext64 && phase == PH_EXTEND && P.groups_per_wave == 1) {
             const uint32_t wcu = 4u * (uint32_t)mgx_ext64_waves_per_simd();
             const uint32_t lds64 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), (160u * 1024u) / wcu - mgx_ext64_static_lds() - 128u) & ~15u;
+            A->kernels_ran |= MGX_KERNEL_EXT64;
+            ++g_kernel_launches[3];
             return mgx_launch_ext64(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), lds64, nullptr);
         }
+        A->kernels_ran |= alt ? MGX_KERNEL_GRP8_ALT : prim ? MGX_KERNEL_GRP8_PRIM : MGX_KERNEL_GRP8;
+        ++g_kernel_launches[alt ? 2 : prim ? 1 : 0];
         return (alt ? mgx_launch_align_grp8_alt : prim ? mgx_launch_align_grp8_prim : mgx_launch_align_grp8)(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), per_group, phase, nullptr);      // never more groups than arena slices (a partial wavefront is fine: the kernel returns for slot >= n_groups)
     };
     A->split_ran = split;
+    A->kernels_ran = 0;
     if (split) {
-        if (getenv("MGX_SEED_GROUPS")) {                 // A/B probe (needs a -DMGX_GRP_SEED_PROBE build of mgx_grp.hip)
+        if (probe_env_set("MGX_SEED_GROUPS")) {                 // A/B probe (needs a -DMGX_GRP_SEED_PROBE build of mgx_grp.hip)
             if (int rc = launch_groups(PH_SEED)) return fail(MGX_ERR_NO_DEVICE, "group seeding kernel: %d", rc);
         } else if (l.Lmax <= 192 && slots >= (uint64_t)prop.multiProcessorCount * 4 * 8) {
             // (measured on 150-bp reads: the kernel is 10 % faster with 4944 B of LDS per wavefront than with 5056 B, although
             // both leave room for 32 wavefronts per CU; hence the wider margin)
             const uint32_t budget8 = (160u * 1024u) / (4 * MGX_SEED_WPS) - static_lds - 192u;
             uint32_t lds8 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), budget8) & ~15u;
-            if (const char *e = getenv("MGX_SEED_LDS_CAP")) lds8 = std::min<uint32_t>(lds8, (uint32_t)atoi(e)) & ~15u;     // tuning probe
-            if (getenv("MGX_SEED_LDS_PRINT")) fprintf(stderr, "k_seed: static_lds %u budget8 %u lds8 %u (fast_lds_bytes %u)\n", static_lds, budget8, lds8, fast_lds_bytes(l.Lmax));
+            lds8 = std::min<uint32_t>(lds8, probe_env_u32("MGX_SEED_LDS_CAP", lds8)) & ~15u;     // tuning probe
+            if (probe_env_set("MGX_SEED_LDS_PRINT")) fprintf(stderr, "k_seed: static_lds %u budget8 %u lds8 %u (fast_lds_bytes %u)\n", static_lds, budget8, lds8, fast_lds_bytes(l.Lmax));
             if (A->dcfg.canonical >= 2) {
                 if (int rc = mgx_launch_seed_primary(&P, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, lds8, 1, nullptr))
                     return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
             } else {
                 // tuning probe: MGX_SEED_WAVES_PCT=50 launches half the resident wavefronts (is the kernel bound by what each
                 // wavefront waits for, or by what all of them move?)
-                static const uint32_t spct = getenv("MGX_SEED_WAVES_PCT") ? (uint32_t)std::min(100, std::max(1, atoi(getenv("MGX_SEED_WAVES_PCT")))) : 100u;
+                const uint32_t spct = probe_env_pct("MGX_SEED_WAVES_PCT");
                 k_align<PH_SEED, MGX_SEED_WPS><<<std::max(1u, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS * spct / 100), 64, lds8>>>(P, lds8);
             }
         } else if (A->dcfg.canonical >= 2) {
@@ -970,8 +1005,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         // one seed per read; reads with live seeds left write a resume record and are re-sorted by the work of their next
         // seed for the next pass (AlignParams::resume_*).  Reads of a wavefront then differ by one extension at most,
         // instead of waiting for the mate with the most seeds.  MGX_TWO_PASS=1: the older variant (pass 2 from scratch).
-        static const int two_pass_env = getenv("MGX_TWO_PASS") ? atoi(getenv("MGX_TWO_PASS")) : 0;
-        static const int multi_env = getenv("MGX_MULTI_PASS") ? atoi(getenv("MGX_MULTI_PASS")) : -1;
+        const int two_pass_env = A->opt.two_pass;
+        const int multi_env = A->opt.multi_pass;
         bool multi = multi_env == 1;
         if (multi_env < 0) {
             // automatic: worth it when reads run many extensions, i.e. carry many seeds (sub-k seeds of a pan-genome: ~100 per
@@ -1065,6 +1100,7 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     s.n_columns = ks.columns; s.n_extensions = ks.extensions; s.n_seeds = ks.seeds;
     s.n_map_lines = ks.map_lines; s.n_capacity_errors = ks.capacity_errors; s.n_seed_lines = ks.seed_lines;
     s.n_fast_columns = ks.fast_columns;
+    s.extend_kernels = A->kernels_ran;
     for (int x = 0; x < 8; ++x) { s.phase_cycles[x] = ks.cyc[x]; s.extend_cycles[x] = ks.xcyc[x]; }
     float ms = 0;
     if (mapped) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[0], A->ev[1])); s.seed_kernel_ms = ms; }
@@ -1107,6 +1143,23 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
     // "+general" / "+chain" suffix-free test switches: the extension's register-resident chain path off / on
     if (name && !strcmp(name, "general")) { A->no_fast = true; return MGX_OK; }
     if (name && !strcmp(name, "chain")) { A->no_fast = false; return MGX_OK; }
+    if (name && strchr(name, '=')) {
+        const std::string key(name, strchr(name, '=') - name);
+        const int v = atoi(strchr(name, '=') + 1);
+        mgx_aligner::Options &o = A->opt;
+        if (key == "ext64") o.ext64 = v;
+        else if (key == "groups_per_wave") o.groups_per_wave = std::min(8, v);
+        else if (key == "multi_pass") o.multi_pass = v;
+        else if (key == "two_pass") o.two_pass = v;
+        else if (key == "no_compact") o.no_compact = v;
+        else if (key == "no_alias") o.no_alias = v;
+        else if (key == "no_bt_runs") o.no_bt_runs = v;
+        else if (key == "no_flat") o.no_flat = v;
+        else if (key == "primary_alt_build") o.primary_alt_build = v;
+        else if (key == "lane") o.lane = v;
+        else return fail(MGX_ERR_INVALID, "unknown option '%s'", name);
+        return MGX_OK;
+    }
     if (m == MODE_BAD) return fail(MGX_ERR_INVALID, "unknown pipeline '%s'", name ? name : "(null)");
     A->mode = m;
     return MGX_OK;
@@ -1116,7 +1169,7 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
 struct HostStageTimer {
     const char *name;
     std::chrono::steady_clock::time_point t0;
-    static bool on() { static const bool v = getenv("MGX_HOST_TIMERS") && atoi(getenv("MGX_HOST_TIMERS")) == 1; return v; }
+    static bool on() { static const bool v = probe_env_set("MGX_HOST_TIMERS"); return v; }
     explicit HostStageTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
     ~HostStageTimer() {
         if (on()) fprintf(stderr, "mgx host stage %-14s %8.1f us\n", name,
@@ -1240,6 +1293,7 @@ int mgx_fetch_seed_info(mgx_aligner *A, uint32_t *info6, uint32_t *seeds /* [n][
 }
 
 int mgx_aligner_stats(const mgx_aligner *A, mgx_stats *out) { *out = A->hstats; return MGX_OK; }
+void mgx_kernel_launch_counts(uint64_t *out5) { for (int x = 0; x < 5; ++x) out5[x] = g_kernel_launches[x].load(); }
 
 size_t mgx_format_tsv(const mgx_results *res, uint64_t qi, const char *header, const char *query, size_t query_len,
                       int32_t min_path_score, char *buf, size_t buf_len) {

@@ -362,6 +362,7 @@ void orc_results_view(void *r, mgx_results *out) {
     out->cigar = st->cigar.data();
     out->seqs = st->seqs.data();
     out->status = st->status.data();
+    out->labels = nullptr;             // (the oracle hands its label sets out through orc_results_labels)
 }
 void orc_results_mapping(void *r, mgx_mapping *out) {
     auto *st = static_cast<ResultStore *>(r);

@@ -33,3 +33,44 @@ def pytest_collection_modifyitems(config, items):
         for it in items:
             if "gpu" in it.keywords:
                 it.add_marker(skip)
+
+
+# ---- which extension kernel a GPU parity test runs on ----
+# The automatic choice sends the small batches of the parity suite to the 64-lane one-read-per-wavefront kernel; the
+# benchmark's batches run on the 8-lane groups (k_align_grp8, its _prim and _alt builds) behind the lane-per-read kernel.
+# A test that takes the `kernels` fixture runs once per variant; the fixture sets the result-preserving kernel-selection
+# options every Aligner of the test starts with and asserts afterwards (libmgx's launch counters) that the kernels it
+# means to cover were the ones launched.
+KERNEL_VARIANTS = {
+    # name: (options, counters that must have moved, counters that must not have moved)
+    "auto": ((), (), ()),
+    "grp8": (("ext64=0", "lane=0"), ("grp8_any",), ("ext64", "lane")),              # 8-lane groups, reads spread over wavefronts
+    "grp8x8": (("ext64=0", "lane=0", "groups_per_wave=0"), ("grp8_any",), ("ext64", "lane")),   # ... 8 reads per wavefront
+}
+
+
+def _launch_counts():
+    import ctypes as C
+    from metagraph_amd import capi
+    out = (C.c_uint64 * 5)()
+    capi.lib().mgx_kernel_launch_counts(out)
+    c = list(out)
+    return {"grp8": c[0], "grp8_prim": c[1], "grp8_alt": c[2], "ext64": c[3], "lane": c[4], "grp8_any": c[0] + c[1] + c[2]}
+
+
+@pytest.fixture(params=list(KERNEL_VARIANTS))
+def kernels(request):
+    from metagraph_amd import aligner
+    opts, must, must_not = KERNEL_VARIANTS[request.param]
+    before = _launch_counts()
+    old = aligner.Aligner.default_options
+    aligner.Aligner.default_options = tuple(opts)
+    try:
+        yield request.param
+    finally:
+        aligner.Aligner.default_options = old
+    after = _launch_counts()
+    for name in must:
+        assert after[name] > before[name], "variant %s never launched %s" % (request.param, name)
+    for name in must_not:
+        assert after[name] == before[name], "variant %s launched %s" % (request.param, name)

@@ -225,6 +225,9 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     std::vector<uint2> gf(R->node_begin[n] + 1), gr(R->node_begin[n] + 1);
     bool mapped = cfg.max_seed_length >= k;
     memset(&R->stats, 0, sizeof(R->stats));
+    std::vector<uint64_t> pkf, pkr;          // 2-bit packed strands + invalid flags (k_pack_reads); the lane-per-read path reads them too
+    std::vector<uint32_t> ivf, ivr;
+    bool have_packed = false;
     if (mapped) {
         // the product's k_map: persistent lanes stepping the per-lane state machine (here: one lane)
         const bool do_rc = map_only || dcfg.fwd_and_rc;
@@ -234,8 +237,8 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         if (k <= 32 && !getenv("MGX_MAP_BYTES")) {
             // the product's packed path: k_pack_reads, then k_map_packed (same word layout)
             const uint64_t words = (offsets[n] >> 5) + n + 2;
-            std::vector<uint64_t> pkf(words, 0), pkr(words, 0);
-            std::vector<uint32_t> ivf(words, 0), ivr(words, 0);
+            pkf.assign(words, 0); pkr.assign(words, 0); ivf.assign(words, 0); ivr.assign(words, 0);
+            have_packed = true;
             for (uint64_t r = 0; r < n; ++r) {
                 const int32_t L = (int32_t)(offsets[r + 1] - offsets[r]);
                 for (int32_t j = 0; 32 * j < L; ++j) {
@@ -360,6 +363,49 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         P.order = order.data();
         const uint32_t ldsb = (uint32_t)(lds_env ? atoi(lds_env) : 2048);
+        // MGX_EMU_LANE=1: the lane-per-read kernel in front of the group kernel, as mgx.hip launches it (lane_enabled() decides
+        // whether the batch qualifies): every read goes through lane_read() first; the reads it bails on are aligned by the
+        // wave program from scratch, in their order
+        const char *lane_env = getenv("MGX_EMU_LANE");
+        std::vector<uint32_t> lane_rest;
+        if (lane_env && *lane_env == '1' && have_packed) {
+            LaneParams LP;
+            memset(&LP, 0, sizeof(LP));
+            std::string why;
+            if (lane_enabled(cfg, dcfg, k, R->lim.Lmax, P.no_fast != 0, &LP, &why)) {
+                LP.P = P;
+                LP.pk[0] = pkf.data(); LP.pk[1] = pkr.data(); LP.iv[0] = ivf.data(); LP.iv[1] = ivr.data();
+                LP.max_cols = R->lim.Lmax + 2;
+                LP.hash_slots = 4; while (LP.hash_slots < 2 * LP.max_cols) LP.hash_slots *= 2;
+                LP.scratch_stride = lane_scratch_bytes(LP.max_cols, LP.hash_slots);
+                std::vector<uint8_t> scratch(LP.scratch_stride, 0);
+                LP.scratch = scratch.data();
+                LP.tag_seed = 12345;
+                std::vector<uint64_t> qw(LANE_QWORDS);
+                std::vector<uint32_t> runs(LANE_MAX_RUNS);
+                LaneChip chip = { qw.data(), 1, runs.data(), 1 };
+                for (uint64_t i = 0; i < n; ++i) {
+                    LaneCounters lc = { 0, 0, 0, 0 };
+                    LaneResult LR;
+                    memset(&LR, 0, sizeof(LR));
+                    if (lane_read(LP, order[i], (uint32_t)i, scratch.data(), chip, lc, LR) == LR_DONE) {
+                        const uint64_t so = cursors[0];
+                        cursors[0] += LR.words;
+                        lane_emit(LP, order[i], scratch.data(), chip, LR, so);
+                        R->stats.columns += LR.rr.n_columns; R->stats.fast_columns += LR.rr.n_columns; R->stats.extensions += LR.rr.n_extensions;
+                        R->stats.capacity_errors += LR.rr.status != ST_OK;
+                        ++R->lane_done;
+                    } else {
+                        lane_rest.push_back(order[i]);
+                    }
+                    R->stats.rank_lines += lc.rank_lines; R->stats.select_lines += lc.select_lines;
+                }
+                order = lane_rest;
+                P.order = order.data();
+                n_ext = order.size();
+                R->lane_ran = 1;
+            }
+        }
         const char *mp = getenv("MGX_EMU_MULTIPASS");
         std::vector<uint32_t> retry(n + 1);
         unsigned long long retry_count = 0;

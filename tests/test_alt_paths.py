@@ -86,7 +86,7 @@ def test_align_low_similarity4_through_the_kernels(npc, xdrop, df):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("npc,xdrop,df", COMBOS)
-def test_align_low_similarity4_on_gpu(npc, xdrop, df):
+def test_align_low_similarity4_on_gpu(npc, xdrop, df, kernels):
     from metagraph_amd import aligner
     g = _graph()
     W, last, F, valid = g.export()
@@ -103,7 +103,7 @@ def test_align_low_similarity4_on_gpu(npc, xdrop, df):
 
 
 @pytest.mark.gpu
-def test_three_alternative_paths_random_reads_on_gpu():
+def test_three_alternative_paths_random_reads_on_gpu(kernels):
     from metagraph_amd import aligner
     from test_emu_vs_oracle import make_world
     g, reads = make_world(901, 15, genome_len=4000, n_reads=120, read_len=100, n_variants=60)
@@ -117,3 +117,24 @@ def test_three_alternative_paths_random_reads_on_gpu():
         assert all(s == 0 for s in status)
         assert got == want
         assert max(len(a) for a in got) > 1
+
+
+@pytest.mark.gpu
+def test_two_alternative_paths_at_full_occupancy_on_gpu():
+    """30 000 reads with num_alternative_paths = 2: more reads than resident groups, so the alternative-paths build of the
+    8-lane kernel (k_align_grp8_alt) runs 8 reads per wavefront at full occupancy; every read against the oracle."""
+    import os
+    from metagraph_amd import aligner
+    from test_emu_vs_oracle import make_world
+    g, reads = make_world(902, 25, genome_len=100000, n_reads=30000, read_len=150, n_variants=1500)
+    W, last, F, valid = g.export()
+    G = aligner.Graph(g.k, W, last, F, valid)
+    cfg = capi.config_cli(25)
+    cfg.num_alternative_paths = 2
+    A = aligner.Aligner(G, cfg)
+    got, status = A.align_batch(reads)
+    assert all(s == 0 for s in status)
+    assert A.stats()["extend_kernels"] & capi.KERNEL_GRP8_ALT
+    want = orc.AlignRun(g, cfg, reads, threads=os.cpu_count() or 8, validate=False).results()
+    assert got == want
+    assert max(len(a) for a in got) > 1

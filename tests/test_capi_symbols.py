@@ -21,7 +21,7 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 20
     for n in names:
         assert hasattr(L, n), "libmgx.so does not export %s" % n
-    assert L.mgx_abi_version() == capi.MGX_ABI_VERSION == 2
+    assert L.mgx_abi_version() == capi.MGX_ABI_VERSION == 3
 
 
 def test_struct_layouts_match_header():
@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert bytes(c) == bytes(ref)
     L.mgx_config_init_default(C.byref(c))
     assert bytes(c)[:96] == bytes(capi.config_default())[:96]
-    assert C.sizeof(capi.Alignment) == 64 and C.sizeof(capi.CigarOp) == 8
+    assert C.sizeof(capi.Alignment) == 72 and C.sizeof(capi.CigarOp) == 8
 
 
 def test_no_device_is_an_error_not_a_fallback():

@@ -20,7 +20,7 @@ def gpu_graph(g, mode=CANONICAL):
     return aligner.Graph(g.k, W, last, F, valid, mode=mode)
 
 
-def test_canonical_kats_on_gpu():
+def test_canonical_kats_on_gpu(kernels):
     g = orc.Graph.build(7, ["AAAAGCTTTCGAGGCCAA"], CANONICAL, True)
     cfg = _cfg()
     got, status = aligner.Aligner(gpu_graph(g), cfg).align_batch(["AAAAGTTTTCGAGGCCAA"])
@@ -35,7 +35,7 @@ def test_canonical_kats_on_gpu():
 
 
 @pytest.mark.parametrize("min_seed_length", [None, 10])
-def test_canonical_cli_goldens_on_gpu(min_seed_length):
+def test_canonical_cli_goldens_on_gpu(min_seed_length, kernels):
     # integration_tests/test_align.py:209-268
     g = orc.Graph.build(11, read_fasta(os.path.join(HERE, "golden", "genome.MT.fa")), CANONICAL, True)
     reads = read_fastq(os.path.join(HERE, "golden", "genome_MT1.fq"))
@@ -59,7 +59,7 @@ def test_canonical_cli_goldens_on_gpu(min_seed_length):
 
 
 @pytest.mark.parametrize("k,mask,seed", [(11, False, 1), (31, False, 3), (15, True, 4)])
-def test_canonical_random_worlds_on_gpu(k, mask, seed):
+def test_canonical_random_worlds_on_gpu(k, mask, seed, kernels):
     g, reads = canonical_world(900 + seed, k, mask=mask, n_reads=200)
     cfg = capi.config_cli(k)
     want = orc.AlignRun(g, cfg, reads).results()

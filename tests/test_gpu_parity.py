@@ -55,7 +55,7 @@ def test_mapping(k, mask):
 
 
 @pytest.mark.parametrize("k,mask,seed", [(11, False, 1), (19, False, 2), (31, False, 3), (11, True, 4), (31, True, 5)])
-def test_align_cli_config(k, mask, seed):
+def test_align_cli_config(k, mask, seed, kernels):
     g, reads = make_world(100 + seed, k, mask=mask)
     compare_gpu(g, gpu_graph(g), capi.config_cli(k), reads)
 
@@ -64,7 +64,7 @@ PIPELINES = ["split8", "split8+general"]     # "+general": the extension's regis
 
 
 @pytest.mark.parametrize("pipeline", PIPELINES)
-def test_every_pipeline_matches_the_oracle(pipeline):
+def test_every_pipeline_matches_the_oracle(pipeline, kernels):
     """The product pipeline (seeding kernel, work sort, 8-lane extension kernel) gives the oracle's results with the
     extension's register-resident chain path on and off."""
     g, reads = make_world(500, 31, genome_len=6000, n_reads=150, read_len=150, n_variants=30)
@@ -162,7 +162,7 @@ def test_baseline_config0_transcripts_1000_k12():
 
 
 @pytest.mark.parametrize("min_seed,per_locus", [(15, 1000), (13, 2), (9, 1)])
-def test_sub_k_seeding_variants_on_gpu(min_seed, per_locus):
+def test_sub_k_seeding_variants_on_gpu(min_seed, per_locus, kernels):
     """BASELINE configs[4] flavour (`--align-min-seed-length 15` and shorter, per-locus seed cap) on a repetitive
     genome; same construction as the CPU-model test."""
     from test_emu_vs_oracle import rand_seq
@@ -182,7 +182,7 @@ def test_sub_k_seeding_variants_on_gpu(min_seed, per_locus):
 
 
 @pytest.mark.parametrize("k", [15, 31])
-def test_reads_with_invalid_and_lower_case_characters_on_gpu(k):
+def test_reads_with_invalid_and_lower_case_characters_on_gpu(k, kernels):
     from test_emu_vs_oracle import noisy_reads
     g, reads = make_world(520 + k, k, n_reads=40, read_len=120)
     cfg = capi.config_cli(k)
@@ -198,7 +198,7 @@ def test_unknown_pipeline_is_an_error():
     assert e.value.code == capi.MGX_ERR_INVALID
 
 
-def test_align_forward_only_and_no_min_exact_match():
+def test_align_forward_only_and_no_min_exact_match(kernels):
     g, reads = make_world(201, 13, n_reads=40)
     cfg = capi.config_cli(13)
     cfg.forward_and_reverse_complement = 0
@@ -206,7 +206,7 @@ def test_align_forward_only_and_no_min_exact_match():
     compare_gpu(g, gpu_graph(g), cfg, reads)
 
 
-def test_align_many_reads_k31():
+def test_align_many_reads_k31(kernels):
     rng = random.Random(77)
     g, reads = make_world(1001, 31, genome_len=50000, n_reads=3000, read_len=150, n_variants=200)
     reads = [mutate(rng, r, sub=0.04, ins=0.01, dele=0.01) if i % 3 == 0 else r for i, r in enumerate(reads)]
@@ -222,7 +222,7 @@ BIG.max_seeds = 2048
 
 
 @pytest.mark.parametrize("case", [c for c in KATS["unit"] if not c["expect"].get("throws")], ids=lambda c: c["name"])
-def test_reference_kats_on_gpu(case):
+def test_reference_kats_on_gpu(case, kernels):
     g = orc.Graph.build(case["k"], case["graph"], 0, case["mask_dummy"])
     G = gpu_graph(g)
     for extend in (False, True):
@@ -232,7 +232,7 @@ def test_reference_kats_on_gpu(case):
         compare_gpu(g, G, cfg, [case["query"]], limits=BIG)
 
 
-def test_cli_goldens_on_gpu():
+def test_cli_goldens_on_gpu(kernels):
     """metagraph align goldens (integration_tests/test_align.py) byte-for-byte through mgx_format_tsv."""
     from test_oracle_kats import read_fasta, read_fastq, HERE
     cli = KATS["cli"]
@@ -260,7 +260,7 @@ def test_cli_goldens_on_gpu():
 
 
 @pytest.mark.parametrize("edit_distance,name", [(False, "genome_MT1.align.json"), (True, "genome_MT1.align.edit.json")])
-def test_cli_json_golden_node_ids_on_gpu(edit_distance, name):
+def test_cli_json_golden_node_ids_on_gpu(edit_distance, name, kernels):
     """The reference's JSON goldens (node ids of every alignment; default and edit-distance scoring) straight
     against the HIP path."""
     from test_oracle_kats import read_fasta, read_fastq, HERE, check_against_json_golden, json_golden_config
@@ -319,29 +319,43 @@ def test_small_cell_budget_gives_capacity_statuses_not_wrong_answers():
     assert all(s == 0 for s in status) and got == want
 
 
-@pytest.mark.parametrize("per_wave", ["0", "1", "3", "8"])
+@pytest.mark.parametrize("per_wave", [0, 1, 3, 8])
 def test_reads_per_wavefront_do_not_change_results(per_wave):
     """A batch with fewer reads than resident groups is spread over the wavefronts (AlignParams::groups_per_wave, chosen by the
-    host from the batch size); MGX_GROUPS_PER_WAVE forces 8 (= 0), 1, 3 or 8 groups of a wavefront to take reads.  Scheduling
-    only: the oracle's alignments either way.  (A subprocess: the library reads the switch once.)"""
-    import subprocess
-    import sys
-    import textwrap
-    here = os.path.dirname(os.path.abspath(__file__))
-    code = textwrap.dedent("""
-        import sys
-        sys.path.insert(0, %r); sys.path.insert(0, %r)
-        from metagraph_amd import capi
-        from test_emu_vs_oracle import make_world
-        from test_gpu_parity import compare_gpu, gpu_graph
-        g, reads = make_world(515, 21, genome_len=6000, n_reads=300, read_len=120)
-        compare_gpu(g, gpu_graph(g), capi.config_cli(21), reads)
+    host from the batch size); the option groups_per_wave forces 8 (= 0), 1, 3 or 8 groups of a wavefront to take reads, with
+    1 on the 8-lane kernel (ext64=0) and on the 64-lane one.  Scheduling only: the oracle's alignments either way."""
+    g, reads = make_world(515, 21, genome_len=6000, n_reads=300, read_len=120)
+    for ext64 in ((0, 1) if per_wave == 1 else (0,)):
+        opts = "split8+ext64=%d+lane=0+groups_per_wave=%d" % (ext64, per_wave)
+        A = compare_gpu(g, gpu_graph(g), capi.config_cli(21), reads, pipeline=opts)
+        assert A.stats()["extend_kernels"] == (capi.KERNEL_EXT64 if ext64 and per_wave == 1 else capi.KERNEL_GRP8)
         cfg = capi.config_cli(21)
         cfg.min_seed_length = 13
         cfg.min_exact_match = 0.0
-        compare_gpu(g, gpu_graph(g), cfg, reads[:120], check_seeds=False)
-        print("OK")
-    """) % (os.path.dirname(here), here)
-    env = dict(os.environ, MGX_GROUPS_PER_WAVE=per_wave)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+        compare_gpu(g, gpu_graph(g), cfg, reads[:120], check_seeds=False, pipeline=opts)
+
+
+def test_probe_switches_are_not_in_the_product_library(monkeypatch):
+    """The measurement probes of earlier rounds (MGX_ABLATE: timing ablations with WRONG results; occupancy / LDS caps) exist
+    in -DMGX_PROBES builds only: the product library must ignore their environment variables."""
+    g, reads = make_world(516, 21, genome_len=5000, n_reads=200, read_len=120)
+    for var, val in (("MGX_ABLATE", "15"), ("MGX_EXT_GROUPS_PCT", "1"), ("MGX_NO_FAST", "1"), ("MGX_EXT64", "0"), ("MGX_SEED_LDS_CAP", "16")):
+        monkeypatch.setenv(var, val)
+    A = compare_gpu(g, gpu_graph(g), capi.config_cli(21), reads)
+    st = A.stats()
+    assert st["n_fast_columns"] > 0 and st["extend_kernels"] == capi.KERNEL_EXT64
+
+
+@pytest.mark.parametrize("xdrop", [100, 300])
+def test_wide_bands_on_single_read_batches(xdrop, kernels):
+    """Large x-drop and indel-rich long reads make DP bands wider than a chain column's slot (32 cells); a one-read batch
+    runs on the 64-lane kernel, whose register window is 256 cells wide but whose column slots are the 8-lane layout's:
+    such columns must take the general path there too (round 3 wrote them past their slots)."""
+    rng = random.Random(9 + xdrop)
+    g, reads = make_world(910, 21, genome_len=9000, n_reads=12, read_len=600, n_variants=20)
+    cfg = capi.config_cli(21)
+    cfg.xdrop = xdrop
+    cfg.min_exact_match = 0.0
+    G = gpu_graph(g)
+    for r in reads:
+        compare_gpu(g, G, cfg, [mutate(rng, r, sub=0.03, ins=0.02, dele=0.02)], limits=BIG, check_seeds=False)

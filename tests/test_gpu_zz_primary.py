@@ -39,7 +39,7 @@ def gpu_graph(g):
     return aligner.Graph(g.k, W, last, F, valid, mode=PRIMARY)
 
 
-def test_primary_kats_on_gpu():
+def test_primary_kats_on_gpu(kernels):
     g = orc.Graph.build(18, ["TTGGCCTCGAAAGTTTTT"], PRIMARY, False)
     cfg = _cfg(max_num_seeds_per_locus=capi.UINT64_MAX, min_cell_score=-2147483648 + 100, min_path_score=-2147483648 + 100,
                min_seed_length=13)
@@ -56,7 +56,7 @@ def test_primary_kats_on_gpu():
 
 
 @pytest.mark.parametrize("min_seed_length", [None, 10])
-def test_primary_cli_goldens_on_gpu(min_seed_length):
+def test_primary_cli_goldens_on_gpu(min_seed_length, kernels):
     contigs, _ = primary_contigs(read_fasta(os.path.join(HERE, "golden", "genome.MT.fa")), 11)
     g = orc.Graph.build(11, contigs, PRIMARY, False)
     reads = read_fastq(os.path.join(HERE, "golden", "genome_MT1.fq"))
@@ -84,7 +84,7 @@ def test_primary_cli_goldens_on_gpu(min_seed_length):
 
 @pytest.mark.parametrize("k,mask,seed,order", [(11, False, 1, "input"), (31, False, 3, "colex"), (15, True, 4, "input"),
                                                (12, False, 5, "lex"), (40, False, 7, "lex")])
-def test_primary_random_worlds_on_gpu(k, mask, seed, order):
+def test_primary_random_worlds_on_gpu(k, mask, seed, order, kernels):
     g, reads = primary_world(700 + seed, k, mask=mask, order=order, n_reads=200)
     cfg = capi.config_cli(k)
     want = orc.AlignRun(g, cfg, reads).results()
@@ -93,7 +93,7 @@ def test_primary_random_worlds_on_gpu(k, mask, seed, order):
     assert got == want
 
 
-def test_primary_alternative_paths_and_sub_k_on_gpu():
+def test_primary_alternative_paths_and_sub_k_on_gpu(kernels):
     g, reads = primary_world(750, 15, genome_len=4000, n_reads=200, n_variants=40)
     gg = gpu_graph(g)
     for n_alt, msl in ((1, 15), (2, 11), (1, 9)):
@@ -104,6 +104,20 @@ def test_primary_alternative_paths_and_sub_k_on_gpu():
         got, status = aligner.Aligner(gg, cfg).align_batch(reads)
         assert all(s == 0 for s in status)
         assert got == orc.AlignRun(g, cfg, reads).results()
+
+
+def test_primary_world_at_full_occupancy_on_gpu():
+    """30 000 reads on a PRIMARY graph: more reads than resident groups, so the 8-lane PRIMARY product kernel
+    (k_align_grp8_prim) runs 8 reads per wavefront at full occupancy, as the benchmark's --graph-mode primary does; every
+    read against the oracle."""
+    g, reads = primary_world(760, 31, genome_len=120000, n_reads=30000, read_len=150, n_variants=600)
+    cfg = capi.config_cli(31)
+    A = aligner.Aligner(gpu_graph(g), cfg)
+    got, status = A.align_batch(reads)
+    assert all(s == 0 for s in status)
+    assert A.stats()["extend_kernels"] & capi.KERNEL_GRP8_PRIM
+    want = orc.AlignRun(g, cfg, reads, threads=os.cpu_count() or 8, validate=False).results()
+    assert got == want
 
 
 def test_mgx_align_driver_on_a_primary_graph(tmp_path):
