@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-steps", type=int, default=2, help="steps of the PCIe-inclusive variant (0 = skip)")
     ap.add_argument("--cpu-1t-sample", type=int, default=1500, help="reads of the single-thread CPU leg")
+    ap.add_argument("--options", default="", help="kernel-selection options for A/B runs, '+'-separated (mgx_aligner_set_pipeline, "
+                    "e.g. lane=0: without the lane-per-read kernel); results never depend on them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,6 +110,8 @@ def main():
         lim = capi.Limits()
         lim.max_query_length, lim.max_columns, lim.max_seeds, lim.cell_arena_bytes = 0, mc, 0, cab
     A = aligner.Aligner(G, cfg, lim)
+    for opt in [o for o in args.options.split("+") if o]:
+        A.set_pipeline(opt)
 
     from metagraph_amd import gather as mg
 
@@ -211,7 +215,9 @@ def main():
                    "k_seed": (st["seeding_ms"], 64.0 * lines_seed + io_seed),
                    "k_extend": (st["extend_ms"], 64.0 * (lines_align - lines_seed) + io_ext)}
         kernel_ms = {"k_map": round(k_map, 3), "k_seed": round(st["seeding_ms"], 3), "work_sort": round(st["sort_ms"], 3),
-                     "k_extend": round(st["extend_ms"], 3)}
+                     "k_extend": round(st["extend_ms"], 3), "k_lane_part_of_k_extend": round(st["lane_ms"], 3),
+                     "reads_finished_by_k_lane": st["n_lane_reads"],
+                     "reads_k_lane_passed_on_by_reason": st["lane_bail_reads"]}
     else:
         kernels = {"k_map": (k_map, 64.0 * lines_map + io_map),
                    "k_align": (k_align, 64.0 * lines_align + io_ext)}

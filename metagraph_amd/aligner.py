@@ -143,6 +143,7 @@ class Aligner:
         d = {f[0]: getattr(s, f[0]) for f in capi.Stats._fields_}
         d["phase_cycles"] = list(s.phase_cycles)
         d["extend_cycles"] = list(s.extend_cycles)
+        d["lane_bail_reads"] = {i: int(v) for i, v in enumerate(s.lane_bail_reads) if v}
         return d
 
     def format_tsv(self, res, qi, header, query):

@@ -2569,7 +2569,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         li.next_offset = next_offset_; li.score = score_; li.in_seed = in_seed_;
         li.best_score = lc_best; li.min_cell_score = lc_min_cell; li.rel_cutoff = x.rel_cutoff;
         li.partial_sum_offset = x.partial_sum_offset; li.psum_lin = x.psum_lin; li.psum = E.psum; li.seed_off = x.seed_off;
-        li.q = E.q; li.row = MGX_SM_ROWS(w) + encode_char(c_) * 128;
+        li.q = E.q; li.row = MGX_SM_ROWS(w) + encode_char(c_) * 128; li.band_given = 0; li.band_begin = li.band_prev_end = 0;
         return lane_column(li, lc_s, lc_f, lc_out);
     };
     auto lane_fail = [&](const char *what) { fprintf(stderr, "lane_column != chain_step: %s\n", what); abort(); };

@@ -15,6 +15,14 @@
 
 namespace mgx {
 
+// keeps the instruction scheduler from interleaving the eight four-cell blocks of the column pass: hoisting the profile scores and
+// band tests of all 32 cells to the front of the pass costs ~100 live registers in the lane-per-read kernel
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_NO_SCHED_FENCE)
+#define LANE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define LANE_SCHED_FENCE() ((void)0)
+#endif
+
 #ifndef MGX_LFW
 #define MGX_LFW 32
 #endif
@@ -31,6 +39,8 @@ struct LaneColumnIn {
     int32_t partial_sum_offset, psum_lin;
     const int32_t *psum;                             // partial sums of the strand (used when psum_lin == 0)
     int32_t seed_off;
+    int32_t band_given, band_begin, band_prev_end;   // != 0: the parent's band as computed earlier (the children of a fork share the
+                                                     // band found with the cut-off at the time the parent was popped)
     const uint8_t *q;                                // the extender's query
     const int8_t *row;                               // score-matrix row of the child's character (128 entries)
 };
@@ -73,7 +83,8 @@ template <class Prof>
 MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColumnOut &out, Prof &profile) {
     const int32_t go = in.go, ge = in.ge, score = in.score, cutoff = in.xdrop_cutoff;
     int32_t begin, prev_end;
-    lane_band(in, S, begin, prev_end);
+    if (in.band_given) { begin = in.band_begin; prev_end = in.band_prev_end; }
+    else lane_band(in, S, begin, prev_end);
     if (prev_end <= begin) return LC_EMPTY_BAND;
     const int32_t end = imin(prev_end, in.window_size) + 1;
     const int32_t size0 = end - begin;
@@ -196,6 +207,7 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
             for (int s4 = 0; s4 < 4; ++s4) { S[4 * b + s4] = NINF; F[4 * b + s4] = NINF; }
         }
         out.fw[b] = fwb;
+        LANE_SCHED_FENCE();
     }
     if (fallback) return LC_FALLBACK;
     const int32_t pushes = pushing ? n_push : 0;

@@ -32,7 +32,29 @@ namespace mgx {
 struct LaneChip {
     uint64_t *qw; int32_t qstride;       // packed strand of the read: word i at qw[i * qstride]
     uint32_t *runs; int32_t rstride;     // CIGAR runs of the trace, last first: run i at runs[i * rstride]
+    uint32_t *cold; int32_t cstride;     // the lane's cold state (below): word i at cold[i * cstride]
 };
+
+// Per-read state that is touched once per column or less — the best backtrack start, the parked child of a fork, the columns that
+// stayed behind, the modelled capacities ... — lives in LDS, not in VGPRs: the DP window (64 registers) and the column pass need
+// the register file (the kernel was at 250+ VGPRs and spilling with all of it in registers).  Accessed as plain variables through
+// the macros below.
+enum { CD_B_SCORE, CD_B_NOD, CD_B_I, CD_B_POS, CD_T_SCORE, CD_T_NOD, CD_T_POS,
+       CD_FA_ALIVE, CD_FA_CONV, CD_FA_ORG, CD_FA_TRIM, CD_FA_SIZE, CD_FA_OFFSET, CD_FA_MAX, CD_FA_IDX, CD_FA_TS, CD_FA_TN, CD_FA_TP, CD_FA_NODE,
+       CD_D_SCORE0, CD_D_SCORE1, CD_D_SCORE2, CD_D_MAX0, CD_D_MAX1, CD_D_MAX2,
+       CD_KID_N0, CD_KID_C0, CD_KID_N1, CD_KID_C1,
+       CD_TABLE_CAP, CD_TSB_LO, CD_TSB_HI, CD_CELL_TOP, CD_NCOLS, CD_F_NODE, CD_F_IDX, CD_F_MAX,
+       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_ROOT_PUSHES, CD_CTR_RANK, CD_CTR_SEL,
+       LANE_COLD_WORDS };
+static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
+#define LANE_CI(f) (*(int32_t *)(chip.cold + (f) * chip.cstride))
+#define LANE_CU(f) (*(chip.cold + (f) * chip.cstride))
+// hides where a value came from: what is computed from it afterwards is computed again, not kept in registers across the column loop
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LANE_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define LANE_OPAQUE(x) ((void)0)
+#endif
 
 // profile scores over the packed strand (see LaneProfBytes)
 struct LaneProfPacked {
@@ -55,7 +77,17 @@ struct LaneProfPacked {
 
 enum { LR_DONE = 0, LR_BAIL = 1 };
 
-struct LaneCounters { uint32_t rank_lines, select_lines, columns, seeds; };
+struct LaneCounters { uint32_t rank_lines, select_lines, columns, reason; };     // reason: which test sent the read to the group kernel
+#define LANE_BAIL(code) do { ctr.reason = (code); return LR_BAIL; } while (0)
+
+// a global store the compiler will not merge with its neighbours
+MGX_DEV void lane_store_single(uint32_t *p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *(volatile __attribute__((address_space(1))) uint32_t *)(uintptr_t)p = v;
+#else
+    *p = v;
+#endif
+}
 
 // value of window cell x (dynamic) of a register window: a chain of selects, never an indexed access (the window must stay in
 // registers)
@@ -78,10 +110,10 @@ MGX_HD uint32_t lane_hash(uint32_t key, uint32_t mask) {
     return h & mask;
 }
 
-// the single child of `v` on the forward graph (DBGSuccinct::call_outgoing_kmers, dbg_succinct.cpp:110-139, minus the
-// sentinel-labelled children the extender drops, aligner_extender_methods.cpp:381-384; dev_graph.hpp outgoing() without its
-// arrays): returns the number of children (0, 1, or 2 = "more than one"), the child and its label code in *node / *code
-MGX_DEV int lane_single_child(const DevGraph &g, uint32_t vv, uint32_t *node, uint32_t *code, LaneCounters &ctr) {
+// the children of `v` on the forward graph (DBGSuccinct::call_outgoing_kmers, dbg_succinct.cpp:110-139, minus the sentinel-
+// labelled children the extender drops, aligner_extender_methods.cpp:381-384; dev_graph.hpp outgoing() without its arrays):
+// returns their number — 3 stands for "more than two" — and the first two (node, label code) in edge order
+MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t &n0, uint32_t &c0, uint32_t &n1, uint32_t &c1, const LaneChip &chip) {
     LineCtr lc = { 0, 0, 0 };
     const uint64_t v = vv;
     ++lc.rank_lines;
@@ -98,24 +130,61 @@ MGX_DEV int lane_single_child(const DevGraph &g, uint32_t vv, uint32_t *node, ui
         for (uint64_t i = first; i <= lst; ++i) {
             if ((uint32_t)(i >> 6) != bi) { bi = (uint32_t)(i >> 6); ++lc.rank_lines; b = load_block(g, bi); }
             const uint32_t c = block_W(b, (int)(i & 63)) % SIGMA;
-            if (c != 0 && in_graph(g, i)) { if (n == 0) { *node = (uint32_t)i; *code = c; } ++n; }
+            if (c != 0 && in_graph(g, i)) {
+                if (n == 0) { n0 = (uint32_t)i; c0 = c; } else if (n == 1) { n1 = (uint32_t)i; c1 = c; }
+                ++n;
+            }
         }
     }
-    ctr.rank_lines += lc.rank_lines; ctr.select_lines += lc.select_lines;
-    return n > 1 ? 2 : n;
+    LANE_CU(CD_CTR_RANK) += lc.rank_lines; LANE_CU(CD_CTR_SEL) += lc.select_lines;
+    return n > 2 ? 3 : n;
 }
 
 // what lane_read() leaves for lane_emit(): the result record and where the alignment's pieces are
 struct LaneResult {
     ReadResult rr;
     int32_t have_aln;
-    int32_t score, offset, clip, end_clip, n_runs, j_lo, n_nodes, n_seq, j_first_node, strand;
+    int32_t score, offset, clip, end_clip, n_runs, j_hi, n_nodes, n_seq, trim, strand;      // j_hi: last column of the path; trim: nodes trim_offset dropped
     uint32_t words;                      // words of the output stream the alignment takes
 };
 
 // One read.  `item`: its position in the launch (tags the node table).  scratch: this lane's LaneParams::scratch slice.
 // Returns LR_DONE (R filled: lane_emit() writes results[read] and the output stream) or LR_BAIL (nothing to write).
-MGX_DEV int lane_read(const LaneParams &LP, const uint64_t read, const uint32_t item, uint8_t *scratch, const LaneChip &chip,
+#define b_score LANE_CI(CD_B_SCORE)
+#define b_nod LANE_CI(CD_B_NOD)
+#define b_i LANE_CI(CD_B_I)
+#define b_pos LANE_CI(CD_B_POS)
+#define t_score LANE_CI(CD_T_SCORE)
+#define t_nod LANE_CI(CD_T_NOD)
+#define t_pos LANE_CI(CD_T_POS)
+#define fa_alive LANE_CI(CD_FA_ALIVE)
+#define fa_conv LANE_CI(CD_FA_CONV)
+#define fa_org LANE_CI(CD_FA_ORG)
+#define fa_trim LANE_CI(CD_FA_TRIM)
+#define fa_size LANE_CI(CD_FA_SIZE)
+#define fa_offset LANE_CI(CD_FA_OFFSET)
+#define fa_max_val LANE_CI(CD_FA_MAX)
+#define fa_idx LANE_CI(CD_FA_IDX)
+#define fa_t_score LANE_CI(CD_FA_TS)
+#define fa_t_nod LANE_CI(CD_FA_TN)
+#define fa_t_pos LANE_CI(CD_FA_TP)
+#define fa_node LANE_CU(CD_FA_NODE)
+#define d_score(t) LANE_CI(CD_D_SCORE0 + (t))
+#define d_max(t) LANE_CI(CD_D_MAX0 + (t))
+#define kid_node0 LANE_CU(CD_KID_N0)
+#define kid_code0 LANE_CU(CD_KID_C0)
+#define kid_node1 LANE_CU(CD_KID_N1)
+#define kid_code1 LANE_CU(CD_KID_C1)
+#define table_cap LANE_CU(CD_TABLE_CAP)
+#define tsb_lo LANE_CU(CD_TSB_LO)
+#define tsb_hi LANE_CU(CD_TSB_HI)
+#define table_size_bytes() (((uint64_t)tsb_hi << 32) | tsb_lo)
+#define cell_top LANE_CU(CD_CELL_TOP)
+#define cols_done LANE_CI(CD_NCOLS)
+#define f_node LANE_CU(CD_F_NODE)
+#define f_idx LANE_CI(CD_F_IDX)
+#define f_max_val LANE_CI(CD_F_MAX)
+MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, uint8_t *scratch, const LaneChip &chip,
                       LaneCounters &ctr, LaneResult &R) {
     const AlignParams &P = LP.P;
     const DevConfig &cfg = P.cfg;
@@ -123,277 +192,456 @@ MGX_DEV int lane_read(const LaneParams &LP, const uint64_t read, const uint32_t 
     const int32_t k = (int32_t)P.g.k;
     const int32_t go = cfg.gap_open, ge = cfg.gap_ext;
     const int32_t m = LP.self_score;
-    // ---- the read and its seeds (flat_read_begin) ----
-    const uint64_t off = gld(P.offsets + read);
-    const int32_t L = (int32_t)(gld(P.offsets + read + 1) - off);
-    if (L > (int32_t)lim.Lmax || L > LANE_MAX_L) return LR_BAIL;
-    const SeedHdr *hp = P.seed_hdr + read;
-    const int32_t h_status = gld(&hp->status);
-    if (h_status != ST_OK) return LR_BAIL;
-    const uint64_t h_off = gld(&hp->off);
-    const uint32_t nm0 = gld(&hp->num_matching[0]), nm1 = gld(&hp->num_matching[1]);
-    const int32_t ns0 = (int32_t)gld(&hp->n_seeds[0]), ns1 = (int32_t)gld(&hp->n_seeds[1]);
     const bool have_rc = cfg.fwd_and_rc != 0;
-    // align_both_directions (:738-755): the strand with more matches; the other one only if it is within rel_score_cutoff
-    const int first = nm0 >= nm1 ? 0 : 1;
-    const int s = have_rc ? first : 0;
-    if (have_rc) {
-        const uint32_t m_first = first ? nm1 : nm0, m_second = first ? nm0 : nm1;
-        const int32_t n_second = first ? ns0 : ns1;
-        if ((double)m_second >= (double)m_first * cfg.rel_score_cutoff && n_second > 0) return LR_BAIL;     // a second strand to align
-    }
-    const int32_t n = s ? ns1 : ns0;
-    ReadResult &rr = R.rr;
-    rr.status = ST_OK; rr.n_alignments = 0; rr.score = 0; rr.offset = 0; rr.n_nodes = rr.n_cigar = rr.seq_len = 0;
-    rr.orientation = 0; rr.stream_off = 0;
-    rr.num_matches_fwd = nm0; rr.num_matches_rc = nm1; rr.n_seeds_fwd = (uint32_t)ns0; rr.n_seeds_rc = (uint32_t)ns1;
-    rr.n_extensions = 0; rr.n_columns = 0;
-    const DevSeed *seeds = P.seed_stream + h_off + (s ? ns0 : 0);
     uint8_t *slots = scratch;
-    uint8_t *s8rows = scratch + (uint64_t)LP.max_cols * LANE_SLOT_BYTES;
-    uint64_t *htab = (uint64_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES));
+    // (the other arrays of the scratch slice: addressed from its base where they are used, not held in registers)
+    auto s8rows = [&]() -> uint8_t * { return scratch + (uint64_t)LP.max_cols * LANE_SLOT_BYTES; };
+    auto htab = [&]() -> uint64_t * { return (uint64_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES)); };
+    auto save_p = [&]() -> uint32_t * { return (uint32_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8); };
+    auto save_a = [&]() -> uint32_t * { return save_p() + 2 * LFW; };
+    // ---- the read and its seeds (flat_read_begin).  What is derived from the seed header here is derived again after the
+    // extension, where the later seeds and the result need it: nothing of it is live across the column loop.
+    int32_t L, n, s;
+    {
+        const uint64_t off = gld(P.offsets + read);
+        L = (int32_t)(gld(P.offsets + read + 1) - off);
+        if (L > (int32_t)lim.Lmax || L > LANE_MAX_L) LANE_BAIL(1);
+        const SeedHdr *hp = P.seed_hdr + read;
+        if (gld(&hp->status) != ST_OK) LANE_BAIL(2);
+        const uint32_t nm0 = gld(&hp->num_matching[0]), nm1 = gld(&hp->num_matching[1]);
+        const int32_t ns0 = (int32_t)gld(&hp->n_seeds[0]), ns1 = (int32_t)gld(&hp->n_seeds[1]);
+        // align_both_directions (:738-755): the strand with more matches; the other one only if it is within rel_score_cutoff
+        const int first = nm0 >= nm1 ? 0 : 1;
+        s = have_rc ? first : 0;
+        if (have_rc) {
+            const uint32_t m_first = first ? nm1 : nm0, m_second = first ? nm0 : nm1;
+            const int32_t n_second = first ? ns0 : ns1;
+            if ((double)m_second >= (double)m_first * cfg.rel_score_cutoff && n_second > 0) LANE_BAIL(3);     // a second strand to align
+        }
+        n = s ? ns1 : ns0;
+    }
+    int32_t n_extensions = 0;
     bool have_aln = false;
     // the alignment, as far as the output needs it
     int32_t a_score = 0, a_offset = 0, a_clip = 0, a_end_clip = 0, a_n_runs = 0;
-    int32_t a_j_lo = 0, a_j_hi = 0, a_n_nodes = 0, a_n_seq = 0, a_j_first_node = 0;
+    int32_t a_j_hi = 0, a_n_nodes = 0, a_n_seq = 0;
+    cols_done = 0;
+    LANE_CU(CD_CTR_RANK) = 0; LANE_CU(CD_CTR_SEL) = 0;
     if (n > 0) {
-        if (n - 1 > LANE_MAX_LATER) return LR_BAIL;
-        // the strand: 2-bit packed by k_pack_reads; any character outside ACGT (psum_lin == 0) is not for this kernel
-        const uint64_t wb = packed_word_begin(off, read);
-        const int32_t nw = (L + 31) >> 5;
-        uint32_t any_inv = 0;
-        for (int32_t j = 0; j < LANE_QWORDS; ++j) {
-            uint64_t v = 0;
-            if (j < nw) { v = gld(LP.pk[s] + wb + j); any_inv |= gld(LP.iv[s] + wb + j); }
-            chip.qw[j * chip.qstride] = v;
-        }
-        if (any_inv) return LR_BAIL;
+        if (n > LANE_MAX_SEEDS) LANE_BAIL(4);
         auto qcode = [&](int32_t qi) -> uint32_t { return (uint32_t)(chip.qw[(qi >> 5) * chip.qstride] >> (2 * (qi & 31))) & 3u; };
-        // ---- seed 0 (seedref_from_seed) and the later seeds ----
-        const uint64_t nb = gld(P.node_begin + read);
-        const uint32_t *rnodes = (s ? P.nodes_rc : P.nodes_fwd) + nb;
-        const DevSeed *s0 = seeds;
-        const int32_t clipping = (int32_t)gld(&s0->clipping), seed_len = (int32_t)gld(&s0->length);
-        const int32_t seed_off = (int32_t)gld(&s0->offset);
-        const uint32_t node0 = seed_off == 0 ? gld(rnodes + clipping) : gld(&s0->node);
-        if (node0 == 0) return LR_BAIL;
-        const int32_t end_clipping0 = L - clipping - seed_len;
-        const int32_t seed_score = seed_len * m + (!clipping ? cfg.left_end_bonus : 0) + (!end_clipping0 ? cfg.right_end_bonus : 0);
-        uint32_t later_node[LANE_MAX_LATER];
-        int32_t later_pos[LANE_MAX_LATER], later_score[LANE_MAX_LATER];
-        uint32_t later_live = 0;           // bit t: later seed t has not been found dead yet
-#pragma unroll
-        for (int t = 0; t < LANE_MAX_LATER; ++t) {
-            later_node[t] = 0; later_pos[t] = 0; later_score[t] = 0;
-            if (t + 1 < n) {
-                const DevSeed *sj = seeds + t + 1;
-                const int32_t cl = (int32_t)gld(&sj->clipping), len = (int32_t)gld(&sj->length), so = (int32_t)gld(&sj->offset);
-                const int32_t nn = (int32_t)gld(&sj->n_nodes);
-                later_node[t] = so == 0 ? gld(rnodes + cl + nn - 1) : gld(&sj->node);
-                later_pos[t] = len + cl - 1;
-                later_score[t] = len * m + (!cl ? cfg.left_end_bonus : 0) + (!(L - cl - len) ? cfg.right_end_bonus : 0);
-                later_live |= 1u << t;
-                if (later_node[t] == node0) return LR_BAIL;          // (its check would need the merged vector of the replay columns)
+        int32_t clipping;
+        {
+            // the strand: 2-bit packed by k_pack_reads; any character outside ACGT (psum_lin == 0) is not for this kernel
+            const uint64_t off = gld(P.offsets + read);
+            const uint64_t wb = packed_word_begin(off, read);
+            const int32_t nw = (L + 31) >> 5;
+            uint32_t any_inv = 0;
+            for (int32_t j = 0; j < LANE_QWORDS; ++j) {
+                uint64_t v = 0;
+                if (j < nw) { v = gld(LP.pk[s] + wb + j); any_inv |= gld(LP.iv[s] + wb + j); }
+                chip.qw[j * chip.qstride] = v;
             }
+            if (any_inv) LANE_BAIL(5);
+            // ---- seed 0 (seedref_from_seed) ----
+            const SeedHdr *hp = P.seed_hdr + read;
+            const DevSeed *s0 = P.seed_stream + gld(&hp->off) + (s ? (int32_t)gld(&hp->n_seeds[0]) : 0);
+            const uint32_t *rnodes = (s ? P.nodes_rc : P.nodes_fwd) + gld(P.node_begin + read);
+            clipping = (int32_t)gld(&s0->clipping);
+            const int32_t seed_len = (int32_t)gld(&s0->length), seed_off = (int32_t)gld(&s0->offset);
+            const uint32_t node0 = seed_off == 0 ? gld(rnodes + clipping) : gld(&s0->node);
+            if (node0 == 0) LANE_BAIL(6);
+            LANE_CI(CD_SEED_LEN) = seed_len; LANE_CI(CD_SEED_OFF) = seed_off; LANE_CU(CD_NODE0) = node0;
         }
+#define c_seed_len LANE_CI(CD_SEED_LEN)
+#define c_seed_off LANE_CI(CD_SEED_OFF)
+#define c_node0 LANE_CU(CD_NODE0)
         // ---- extend_begin (:412-470): set_seed, the root column ----
         const int32_t xdrop = cfg.xdrop;
         int32_t xdrop_cutoff = imax(-xdrop, NINF + 1);
         const int32_t start = clipping, window_size = L - start, qlen = L;
-        const int32_t sroot = (cfg.left_end_bonus && !clipping) ? cfg.left_end_bonus : 0;
-        int32_t root_pushes = 0;
-        const int32_t root_ins = imax(sroot + go, NINF + ge);
-        if (1 < window_size + 1 && root_ins >= xdrop_cutoff) {
-            int32_t n_push = 1;
-            const int32_t room = window_size + 1 - 2;
-            if (ge == 0) n_push += room;
-            else { int32_t v = root_ins; while (n_push - 1 < room && v + ge >= xdrop_cutoff) { v += ge; ++n_push; } }
-            root_pushes = n_push;
-        }
-        const int32_t root_size = 1 + root_pushes;
-        auto root_S = [&](int32_t pos) -> int32_t {
-            return pos == 0 ? sroot : (pos >= 1 && pos <= root_pushes ? root_ins + (pos - 1) * ge : NINF);
-        };
-        if ((uint64_t)rec_words((uint32_t)root_size + 8) > lim.cell_words) return LR_BAIL;
-        const uint32_t cell_top = rec_words((uint32_t)((root_size + 5 + 3) & ~3));
-        uint32_t table_cap = 1;
-        int32_t tsize = 1;
-        uint64_t table_size_bytes = (uint64_t)136 * table_cap + (uint64_t)(3 * ref_capacity(1, (uint32_t)root_pushes)) * 4;
-        int32_t min_cell_score = 0, best_score = 0;
-        rr.n_extensions = 1;
-        // the root leaves the frontier and enters the chain window (extend_step: fast_fits + fast_load)
-        if (root_size + 3 > LFW) return LR_BAIL;
-        int32_t S[LFW], F[LFW];
-#pragma unroll
-        for (int x = 0; x < LFW; ++x) { S[x] = x < root_size ? root_S(x) : NINF; F[x] = NINF; }
-        int32_t f_org = 0, f_trim = 0, f_size = root_size, f_offset = seed_off - 1, f_max_val = sroot;
-        uint32_t f_node = node0;
-        // backtrack start cells, collected while the columns are in registers (bt_begin :815-867)
-        const int32_t seed_dist = imax(k, seed_len) - 1;
         const int32_t last_pos = window_size;
-        const int32_t seed_offset = seed_off - 1;
         const int32_t min_start_score = have_rc ? imax(0, cfg.min_cell_score) : imax(0, cfg.min_path_score);
-        int32_t b_score = INT32_MIN, b_nod = INT32_MIN, b_i = 0, b_pos = 0;         // the best (score, -off_diag, -i, pos)
-        int32_t t_score = INT32_MIN, t_nod = 0, t_pos = 0;                          // the last column's start cell if it were a tip
+        int32_t tsize = 1;
+        int32_t min_cell_score = 0, best_score = 0;
+        int32_t S[LFW], F[LFW];
+        int32_t f_org = 0, f_trim = 0, f_size, f_offset = c_seed_off - 1;
+        {
+            const int32_t sroot = (cfg.left_end_bonus && !clipping) ? cfg.left_end_bonus : 0;
+            int32_t root_pushes = 0;
+            const int32_t root_ins = imax(sroot + go, NINF + ge);
+            if (1 < window_size + 1 && root_ins >= xdrop_cutoff) {
+                int32_t n_push = 1;
+                const int32_t room = window_size + 1 - 2;
+                if (ge == 0) n_push += room;
+                else { int32_t v = root_ins; while (n_push - 1 < room && v + ge >= xdrop_cutoff) { v += ge; ++n_push; } }
+                root_pushes = n_push;
+            }
+            const int32_t root_size = 1 + root_pushes;
+            LANE_CI(CD_ROOT_PUSHES) = root_pushes;
+            if ((uint64_t)rec_words((uint32_t)root_size + 8) > lim.cell_words) LANE_BAIL(8);
+            table_cap = 1;
+            const uint64_t tsb0 = (uint64_t)136 * 1 + (uint64_t)(3 * ref_capacity(1, (uint32_t)root_pushes)) * 4;
+            tsb_lo = (uint32_t)tsb0; tsb_hi = (uint32_t)(tsb0 >> 32);
+            n_extensions = 1;
+            // the root leaves the frontier and enters the chain window (extend_step: fast_fits + fast_load)
+            if (root_size + 3 > LFW) LANE_BAIL(9);
+#pragma unroll
+            for (int x = 0; x < LFW; ++x) {
+                S[x] = x == 0 ? sroot : (x <= root_pushes ? root_ins + (x - 1) * ge : NINF);
+                F[x] = NINF;
+            }
+            f_size = root_size;
+            f_max_val = sroot; f_idx = 0; f_node = c_node0;
+            cell_top = rec_words((uint32_t)((root_size + 5 + 3) & ~3));
+        }
+        // backtrack start cells, collected while the columns are in registers (bt_begin :815-867)
+        b_score = INT32_MIN; b_nod = INT32_MIN; b_i = 0; b_pos = 0;                 // the best (score, -off_diag, -i, pos)
+        t_score = INT32_MIN; t_nod = 0; t_pos = 0;                                  // the head column's start cell if it were a tip
         auto cand = [&](int32_t sc, int32_t nod, int32_t i, int32_t pos) {
-            const bool better = sc != b_score ? sc > b_score : (nod != b_nod ? nod > b_nod : (-i != -b_i ? -i > -b_i : pos > b_pos));
-            if (b_score == INT32_MIN || better) { b_score = sc; b_nod = nod; b_i = i; b_pos = pos; }
+            const int32_t bs = b_score, bn = b_nod, bi = b_i, bp = b_pos;
+            const bool better = sc != bs ? sc > bs : (nod != bn ? nod > bn : (-i != -bi ? -i > -bi : pos > bp));
+            if (bs == INT32_MIN || better) { b_score = sc; b_nod = nod; b_i = i; b_pos = pos; }
         };
         const uint32_t tag = ((LP.tag_seed + item) * 0x9E3779B1u >> 12) | 1u;              // 20 bits, never 0
         const uint32_t hmask = LP.hash_slots - 1;
         LaneProfPacked prof;
         prof.qw = chip.qw; prof.qstride = chip.qstride; prof.qlen = qlen; prof.rowp = 0; prof.w = 0;
-        // ---- the extension: chain steps (extend_step / chain_step) ----
-        for (;;) {
-            // early cut-offs when off the optimal path (:521-547)
-            if (f_max_val < best_score) {
-                if ((double)tsize / (double)window_size >= cfg.max_nodes_per_seq_char) break;
-                if ((double)table_size_bytes / 1000000.0 > cfg.max_ram_per_alignment) break;
+        // ---- the extension (extend_step): chain steps along the head column, a general step where the graph forks ----
+        // The frontier (:477-504) is the head column — the one whose window is in registers — plus the few columns that stayed
+        // behind: the other child of a fork, kept as (converged score, column maximum).  A column that stays behind is only ever
+        // popped to die here: when its turn comes, its cells must all lie below the x-drop cut-off the head has raised since
+        // (band test :549-560) — a read where one would go on leaves this kernel.
+#pragma unroll
+        for (int t = 0; t < LANE_MAX_DEFER; ++t) { d_score(t) = INT32_MIN; d_max(t) = NINF; }
+        // the children of the head that are being computed (call_outgoing :330-387): one, or the two of a fork
+        kid_node0 = 0; kid_code0 = 0; kid_node1 = 0; kid_code1 = 0;
+        int n_kids = 0, kid = 0;
+        // the first child of a fork, parked while the second is computed (its window in the lane's scratch)
+        fa_alive = 0; fa_conv = 0; fa_org = 0; fa_trim = 0; fa_size = 0; fa_offset = 0; fa_max_val = 0; fa_idx = 0;
+        fa_t_score = INT32_MIN; fa_t_nod = 0; fa_t_pos = 0; fa_node = 0;
+        // (one dword per store, on purpose: merged into 16-byte stores they want four consecutive registers each, and pinning
+        // the window to such tuples made the allocator spill 600+ registers around the column pass; forks are rare)
+        auto win_save = [&](uint32_t *dst) {
+#pragma unroll
+            for (int x = 0; x < LFW; ++x) { lane_store_single(dst + x, (uint32_t)S[x]); lane_store_single(dst + LFW + x, (uint32_t)F[x]); }
+        };
+        auto win_load = [&](const uint32_t *src) {
+#pragma unroll
+            for (int x = 0; x < LFW; ++x) { S[x] = (int32_t)gld(src + x); F[x] = (int32_t)gld(src + LFW + x); }
+        };
+        // One loop iteration = one column: the (next) child of the head.  The window S / F is written at exactly two places — the
+        // reload at the top (the parent again for the second child of a fork; the parked first child when it becomes the head)
+        // and lane_column() — and the loop has one back edge: with the window assigned on several paths the register allocator
+        // kept copies of it and spilled hundreds of registers.
+        int32_t hd_begin = 0, hd_prev_end = 0;
+        bool reload = false, reload_parked = false, ext_over = false;
+        while (!ext_over) {
+            if (reload) { win_load(reload_parked ? save_a() : save_p()); reload = false; }
+            bool head_dead = false;
+            if (n_kids == 0) {
+                // a new head: early cut-offs when off the optimal path (:521-547), its band, its children
+                bool stop_all = false;
+                if (f_max_val < best_score) {
+                    if ((double)tsize / (double)window_size >= cfg.max_nodes_per_seq_char) stop_all = true;
+                    else if ((double)table_size_bytes() / 1000000.0 > cfg.max_ram_per_alignment) stop_all = true;
+                }
+                if (stop_all) {
+                    ext_over = true;                                                   // (the frontier is dropped with it)
+                } else {
+                    // (the band is the head's, computed once with the cut-off at that time: the children of a fork share it, :549-560)
+                    LaneColumnIn bin;
+                    bin.p_org = f_org; bin.p_trim = f_trim; bin.p_size = f_size; bin.xdrop_cutoff = xdrop_cutoff;
+                    lane_band(bin, S, hd_begin, hd_prev_end);
+                    head_dead = hd_prev_end <= hd_begin;
+                    if (!head_dead) {
+                        const int32_t no = f_offset + 1, sp = no - c_seed_off;
+                        if (sp >= 0 && sp < c_seed_len && no < k) {
+                            kid_node0 = c_node0; kid_code0 = qcode(clipping + sp) + 1; n_kids = 1;  // the seed's first node, its spelling
+                        } else {
+                            uint32_t kn0 = 0, kc0 = 0, kn1 = 0, kc1 = 0;
+                            const int nc = lane_children(P.g, f_node, kn0, kc0, kn1, kc1, chip);
+                            if (nc > 2) LANE_BAIL(10);                                 // more than two children
+                            kid_node0 = kn0; kid_code0 = kc0; kid_node1 = kn1; kid_code1 = kc1;
+                            if (nc == 0) {                                             // a tip: its start cell counts after all
+                                if (t_score != INT32_MIN) cand(t_score, t_nod, f_idx, t_pos);
+                                head_dead = true;
+                            }
+                            n_kids = nc;
+                        }
+                        kid = 0;
+                        fa_alive = 0;
+                    }
+                }
             }
-            LaneColumnIn in;
-            in.p_org = f_org; in.p_trim = f_trim; in.p_size = f_size;
-            in.xdrop_cutoff = xdrop_cutoff; in.start = start; in.window_size = window_size; in.qlen = qlen; in.go = go; in.ge = ge;
-            int32_t begin, prev_end;
-            lane_band(in, S, begin, prev_end);
-            if (prev_end <= begin) break;
-            // the child (call_outgoing :330-387)
+            // the child computed in this iteration (if any)
+            int32_t c_alive = 0, c_conv = NINF, c_org = 0, c_trim = 0, c_size = 0, c_max_val = 0, c_idx = 0;
+            int32_t c_t_score = INT32_MIN, c_t_nod = 0, c_t_pos = 0;
+            uint32_t c_node = 0;
             const int32_t next_offset = f_offset + 1;
-            const int32_t seed_pos = next_offset - seed_off;
-            const bool in_seed = seed_pos >= 0 && seed_pos < seed_len;
-            uint32_t next, ccode;
-            if (in_seed && next_offset < k) {
-                next = node0; ccode = qcode(clipping + seed_pos) + 1;             // the seed's first node, its spelling
-            } else {
-                const int nc = lane_single_child(P.g, f_node, &next, &ccode, ctr);
-                if (nc == 0) {                                                     // a tip: its start cell counts after all
-                    if (t_score != INT32_MIN) cand(t_score, t_nod, tsize - 1, t_pos);
-                    break;
-                }
-                if (nc != 1) return LR_BAIL;                                       // a fork
-            }
-            if (next == 0) return LR_BAIL;
-            if (tsize >= (int32_t)LP.max_cols - 1 || tsize >= (int32_t)lim.max_columns - 1) return LR_BAIL;
-            if ((uint64_t)cell_top + rec_words((uint32_t)(window_size + 1 - begin + 8)) > lim.cell_words) return LR_BAIL;
-            // The node table: first visits only (a node seen before would merge convergence vectors, update_seed_filter
-            // :100-156).  The replay columns all carry the seed's first node and DO merge — but all the chain needs from the
-            // merge is whether some cell improved on the node's vector (converged != ninf), and a replay column's diagonal cell
-            // always does: the replayed characters are the query's own, so that cell scores sroot + (t + 1) m, more than any
-            // earlier column (fewer graph characters, hence at most sroot + (t' + 1) m) left at its query position.  (Needs
-            // m > 0 >= gaps, mismatches <= m, sroot >= 0, 0 <= rel_score_cutoff <= 1: checked before the kernel is launched.)
-            // The vector itself is never needed: a later seed ending in that node, or the graph leading back to it, bails.
-            const bool replay = in_seed && next_offset < k;
-            const bool probe = !replay || f_offset == seed_off - 1;
-            uint32_t hs = lane_hash(next, hmask);
-            uint64_t he = probe ? gld(htab + hs) : 0;
-            in.next_offset = next_offset; in.score = 0; in.in_seed = in_seed;
-            in.best_score = best_score; in.min_cell_score = min_cell_score; in.rel_cutoff = cfg.rel_score_cutoff;
-            in.partial_sum_offset = 0; in.psum_lin = m; in.psum = nullptr; in.seed_off = seed_off; in.q = nullptr; in.row = nullptr;
-            prof.rowp = ccode == 1 ? LP.t4[0] : ccode == 2 ? LP.t4[1] : ccode == 3 ? LP.t4[2] : LP.t4[3];
-            LaneColumnOut out;
-            const int rc = lane_column(in, S, F, out, prof);
-            if (rc == LC_FALLBACK) return LR_BAIL;
-            const uint32_t table_cap_before = table_cap;
-            if ((uint32_t)tsize == table_cap) table_cap = imax<uint32_t>(1u, 2 * table_cap);
-            ++rr.n_columns;
-            min_cell_score = out.min_cell_score;
-            if (rc == LC_POP) break;                                               // pop(table.size() - 1) (:646-653)
-            table_size_bytes += (uint64_t)136 * (table_cap - table_cap_before)
-                                + (uint64_t)(3 * ref_capacity((uint32_t)out.size0, (uint32_t)out.pushes)) * 4;
-            const int32_t max_val = out.max_val;
-            if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
-            best_score = imax(best_score, max_val);
-            const int32_t my_idx = tsize;
-            if (probe) {
-                for (;;) {
-                    if ((uint32_t)(he >> 44) != tag) break;                        // free (or left by another read)
-                    if ((uint32_t)he == next) return LR_BAIL;                     // seen before
-                    hs = (hs + 1) & hmask;
-                    he = gld(htab + hs);
-                }
-                gst(htab + hs, (uint64_t)next | ((uint64_t)tag << 44) | ((uint64_t)(uint32_t)my_idx << 32));
-            }
-            // (replay columns: see above; the column's own maximum stands in for the merged score, ninf neither way)
-            const int32_t converged = out.converged;
-            const int32_t size = out.size, org = out.org;
-            // the frontier hands the column straight back (:491-504) — or it would stay behind with a record of its own
-            if (converged != NINF && !((begin & 3) + size + 3 <= LFW)) return LR_BAIL;
-            // commit: the slot (flags, node, base, geometry) and the S row
-            const int32_t base = max_val == NINF ? 0 : max_val;
-            {
-                uint32_t sw[8];
-                bool wide = false;
-#pragma unroll
-                for (int b = 0; b < LFW / 4; ++b) {
-                    uint32_t v = 0;
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const int32_t sv = S[4 * b + q4];
-                        const int32_t d = sv - base;
-                        wide |= sv != NINF && d < -127;
-                        v |= (sv == NINF ? 0x80u : ((uint32_t)d & 0xFFu)) << (8 * q4);
+            const bool compute = !ext_over && !head_dead && n_kids > 0;
+            const bool forked = n_kids == 2;
+            if (compute) {
+                if (forked && kid == 0) win_save(save_p());                            // the parent is needed twice
+                const uint32_t next = kid == 0 ? kid_node0 : kid_node1, ccode = kid == 0 ? kid_code0 : kid_code1;
+                const int32_t seed_off = c_seed_off;
+                const int32_t seed_pos = next_offset - seed_off;
+                const bool in_seed = seed_pos >= 0 && seed_pos < c_seed_len;
+                LaneColumnIn in;
+                in.p_org = f_org; in.p_trim = f_trim; in.p_size = f_size;
+                in.xdrop_cutoff = xdrop_cutoff; in.start = start; in.window_size = window_size; in.qlen = qlen; in.go = go; in.ge = ge;
+                const int32_t begin = hd_begin;
+                in.band_given = 1; in.band_begin = hd_begin; in.band_prev_end = hd_prev_end;
+                if (next == 0) LANE_BAIL(11);
+                if (tsize >= (int32_t)LP.max_cols - 1 || tsize >= (int32_t)lim.max_columns - 1) LANE_BAIL(12);
+                // (the cell arena of the group kernel: its capacity test, with room for every record a column that stays behind
+                // could own there — a read near that limit is the group kernel's to report)
+                if ((uint64_t)cell_top + (LANE_MAX_DEFER + 1) * rec_words((uint32_t)LFW) + rec_words((uint32_t)(window_size + 1 - begin + 8)) > lim.cell_words) LANE_BAIL(13);
+                // The node table: first visits only (a node seen before would merge convergence vectors, update_seed_filter
+                // :100-156).  The replay columns all carry the seed's first node and DO merge — but all the chain needs from the
+                // merge is whether some cell improved on the node's vector (converged != ninf), and a replay column's diagonal cell
+                // always does: the replayed characters are the query's own, so that cell scores sroot + (t + 1) m, more than any
+                // earlier column (fewer graph characters, hence at most sroot + (t' + 1) m) left at its query position.  (Needs
+                // m > 0 >= gaps, mismatches <= m, sroot >= 0, 0 <= rel_score_cutoff <= 1: checked before the kernel is launched.)
+                // The vector itself is never needed: a later seed ending in that node, or the graph leading back to it, bails.
+                const bool replay = in_seed && next_offset < k;
+                const bool probe = !replay || f_offset == seed_off - 1;
+                uint32_t hs = lane_hash(next, hmask);
+                uint64_t he = probe ? gld(htab() + hs) : 0;
+                in.next_offset = next_offset; in.score = 0; in.in_seed = in_seed;
+                in.best_score = best_score; in.min_cell_score = min_cell_score; in.rel_cutoff = cfg.rel_score_cutoff;
+                in.partial_sum_offset = 0; in.psum_lin = m; in.psum = nullptr; in.seed_off = seed_off; in.q = nullptr; in.row = nullptr;
+                prof.rowp = ccode == 1 ? LP.t4[0] : ccode == 2 ? LP.t4[1] : ccode == 3 ? LP.t4[2] : LP.t4[3];
+                LaneColumnOut out;
+                const int rc = lane_column(in, S, F, out, prof);
+                if (rc == LC_FALLBACK) LANE_BAIL(14);
+                const uint32_t table_cap_before = table_cap;
+                if ((uint32_t)tsize == table_cap) table_cap = imax<uint32_t>(1u, 2 * table_cap);
+                ++cols_done;
+                min_cell_score = out.min_cell_score;
+                if (rc != LC_POP) {                                                    // (else pop(table.size() - 1), :646-653)
+                    {
+                        const uint64_t tsb = table_size_bytes() + (uint64_t)136 * (table_cap - table_cap_before)
+                                             + (uint64_t)(3 * ref_capacity((uint32_t)out.size0, (uint32_t)out.pushes)) * 4;
+                        tsb_lo = (uint32_t)tsb; tsb_hi = (uint32_t)(tsb >> 32);
                     }
-                    sw[b] = v;
-                }
-                if (wide) return LR_BAIL;
-                uint32_t *sl = (uint32_t *)(slots + (uint64_t)my_idx * LANE_SLOT_BYTES);
-                uint32_t *sr = (uint32_t *)(s8rows + (uint64_t)my_idx * LANE_S8_BYTES);
-#pragma unroll
-                for (int b = 0; b < 8; ++b) gst(sl + b, out.fw[b]);
-                gst(sl + 8, next);
-                gst(sl + 9, (uint32_t)base);
-                gst(sl + 10, (uint32_t)begin | ((uint32_t)size << 16) | (ccode << 24));
-#pragma unroll
-                for (int b = 0; b < 8; ++b) gst(sr + b, sw[b]);
-            }
-            tsize = my_idx + 1;
-            // check_seed (:66-88) of the later seeds whose last node this is: its (first and only) column is in registers
-#pragma unroll
-            for (int t = 0; t < LANE_MAX_LATER; ++t) {
-                if (((later_live >> t) & 1u) && later_node[t] == next) {
-                    const int32_t skip = begin ? 0 : 1;
-                    const int32_t qs = start + begin - (begin ? 1 : 0), len = size - skip;
-                    const int32_t pos = later_pos[t];
-                    if (!(pos < qs || pos - qs >= len)) {
-                        const int32_t a = pos - start + 1;
-                        // (cell_S: outside [trim, trim + size + 5) or the slot's cells the column holds nothing)
-                        const int32_t v = (a - begin >= 0 && a - begin < size + 5) ? lane_win_at(S, a - org) : NINF;
-                        if (!(v < later_score[t])) later_live &= ~(1u << t);
+                    const int32_t max_val = out.max_val;
+                    if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
+                    best_score = imax(best_score, max_val);
+                    const int32_t my_idx = tsize;
+                    if (probe) {
+                        for (;;) {
+                            if ((uint32_t)(he >> 44) != tag) break;                    // free (or left by another read)
+                            if ((uint32_t)he == next) LANE_BAIL(15);                 // seen before
+                            hs = (hs + 1) & hmask;
+                            he = gld(htab() + hs);
+                        }
+                        gst(htab() + hs, (uint64_t)next | ((uint64_t)tag << 44) | ((uint64_t)(uint32_t)my_idx << 32));
                     }
-                }
-            }
-            // start cells of this column (bt_begin :815-867)
-            t_score = INT32_MIN;
-            if (next_offset >= seed_dist) {
-                const int32_t max_pos = out.max_pos;
-                {
-                    const uint32_t fl = lane_flags_at(out.fw, max_pos - org);
-                    if ((fl & CF_REAL) && (fl & CF_SP_REAL)) {
-                        const int32_t eb = max_pos == last_pos ? cfg.right_end_bonus : 0;
-                        if (base + eb >= min_start_score) {
-                            const int32_t ap = clipping + max_pos;
-                            const bool is_match = (fl & CF_MATCH) && ap >= 1 && ap <= L && qcode(ap - 1) + 1 == ccode;
-                            const int32_t nod = -iabs(max_pos - next_offset + seed_offset);
-                            if (is_match || max_pos == last_pos) cand(base + eb, nod, my_idx, max_pos);
-                            else { t_score = base + eb; t_nod = nod; t_pos = max_pos; }
+                    // (replay columns: see above; the column's own maximum stands in for the merged score, ninf neither way)
+                    const int32_t converged = out.converged;
+                    const int32_t size = out.size, org = out.org;
+                    // commit: the slot (flags, node, base, geometry, parent) and the S row
+                    const int32_t base = max_val == NINF ? 0 : max_val;
+                    {
+                        uint32_t sw[8];
+                        bool wide = false;
+#pragma unroll
+                        for (int b = 0; b < LFW / 4; ++b) {
+                            uint32_t v = 0;
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                const int32_t sv = S[4 * b + q4];
+                                const int32_t d = sv - base;
+                                wide |= sv != NINF && d < -127;
+                                v |= (sv == NINF ? 0x80u : ((uint32_t)d & 0xFFu)) << (8 * q4);
+                            }
+                            sw[b] = v;
+                        }
+                        if (wide) LANE_BAIL(17);
+                        uint32_t *sl = (uint32_t *)(slots + (uint64_t)my_idx * LANE_SLOT_BYTES);
+                        uint32_t *sr = (uint32_t *)(s8rows() + (uint64_t)my_idx * LANE_S8_BYTES);
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) gst(sl + b, out.fw[b]);
+                        gst(sl + 8, next);
+                        gst(sl + 9, (uint32_t)base);
+                        gst(sl + 10, (uint32_t)begin | ((uint32_t)size << 16) | (ccode << 24));
+                        gst(sl + 11, (uint32_t)f_idx | ((uint32_t)next_offset << 16));
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) gst(sr + b, sw[b]);
+                    }
+                    tsize = my_idx + 1;
+                    // a column of the general path (the children of a fork) owns an S / F record of the cell arena there
+                    if (forked) cell_top += rec_words((uint32_t)((size + 5 + 3) & ~3));
+                    // start cells of this column (bt_begin :815-867)
+                    if (next_offset >= imax(k, c_seed_len) - 1) {
+                        const int32_t max_pos = out.max_pos;
+                        {
+                            const uint32_t fl = lane_flags_at(out.fw, max_pos - org);
+                            if ((fl & CF_REAL) && (fl & CF_SP_REAL)) {
+                                const int32_t eb = max_pos == last_pos ? cfg.right_end_bonus : 0;
+                                if (base + eb >= min_start_score) {
+                                    const int32_t ap = clipping + max_pos;
+                                    const bool is_match = (fl & CF_MATCH) && ap >= 1 && ap <= L && qcode(ap - 1) + 1 == ccode;
+                                    const int32_t nod = -iabs(max_pos - next_offset + seed_off - 1);
+                                    if (is_match || max_pos == last_pos) cand(base + eb, nod, my_idx, max_pos);
+                                    else { c_t_score = base + eb; c_t_nod = nod; c_t_pos = max_pos; }
+                                }
+                            }
+                        }
+                        if (size + begin == window_size + 1 && max_pos != last_pos) {
+                            const uint32_t fl = lane_flags_at(out.fw, last_pos - org);
+                            if ((fl & CF_REAL) && (fl & CF_SP_REAL)) {
+                                const int32_t sv = lane_win_at(S, last_pos - org);
+                                if (sv + cfg.right_end_bonus >= min_start_score)
+                                    cand(sv + cfg.right_end_bonus, -iabs(last_pos - next_offset + seed_off - 1), my_idx, last_pos);
+                            }
                         }
                     }
-                }
-                if (size + begin == window_size + 1 && max_pos != last_pos) {
-                    const uint32_t fl = lane_flags_at(out.fw, last_pos - org);
-                    if ((fl & CF_REAL) && (fl & CF_SP_REAL)) {
-                        const int32_t sv = lane_win_at(S, last_pos - org);
-                        if (sv + cfg.right_end_bonus >= min_start_score)
-                            cand(sv + cfg.right_end_bonus, -iabs(last_pos - next_offset + seed_offset), my_idx, last_pos);
+                    if (converged != NINF) {
+                        c_alive = 1; c_conv = converged; c_org = org; c_trim = begin; c_size = size; c_max_val = max_val; c_idx = my_idx;
+                        c_node = next;
                     }
                 }
             }
-            if (converged == NINF) break;
-            f_org = org; f_trim = begin; f_size = size; f_offset = next_offset; f_max_val = max_val; f_node = next;
+            if (!ext_over) {
+                if (compute && forked && kid == 0) {
+                    // the first child of a fork waits (window in scratch) while the second is computed from the same parent
+                    fa_alive = c_alive; fa_conv = c_conv; fa_org = c_org; fa_trim = c_trim; fa_size = c_size; fa_offset = next_offset;
+                    fa_max_val = c_max_val; fa_idx = c_idx; fa_node = c_node; fa_t_score = c_t_score; fa_t_nod = c_t_nod; fa_t_pos = c_t_pos;
+                    if (c_alive) win_save(save_a());
+                    kid = 1;
+                    reload = true; reload_parked = false;
+                } else {
+                    bool none = true;
+#pragma unroll
+                    for (int t = 0; t < LANE_MAX_DEFER; ++t) none &= d_score(t) == INT32_MIN;
+                    if (compute && !forked && c_alive && none) {
+                        // the common case: one child, nothing else in the frontier (chain_step's chain_on): it is the next head
+                        if (!((c_trim & 3) + c_size + 3 <= LFW)) LANE_BAIL(16);        // (it would stay behind with a record of its own)
+                        f_org = c_org; f_trim = c_trim; f_size = c_size; f_offset = next_offset; f_max_val = c_max_val; f_node = c_node;
+                        f_idx = c_idx; t_score = c_t_score; t_nod = c_t_nod; t_pos = c_t_pos;
+                    } else {
+                        // the frontier hands out the next head (:491-504): the best of the children just computed and the columns
+                        // that stayed behind.  A child goes on as the head; a column that stayed behind must be dead by now.
+                        if (!(compute && forked)) fa_alive = 0;
+                        bool have_head = false, frontier_done = false;
+                        while (!frontier_done) {
+                            int32_t top = INT32_MIN;
+                            int n_top = 0;
+#pragma unroll
+                            for (int t = 0; t < LANE_MAX_DEFER; ++t) {
+                                const int32_t ds = d_score(t);
+                                if (ds != INT32_MIN) { if (ds > top) { top = ds; n_top = 1; } else if (ds == top) ++n_top; }
+                            }
+                            if (fa_alive) { if (fa_conv > top) { top = fa_conv; n_top = 1; } else if (fa_conv == top) ++n_top; }
+                            if (c_alive) { if (c_conv > top) { top = c_conv; n_top = 1; } else if (c_conv == top) ++n_top; }
+                            const bool a_top = fa_alive && fa_conv == top, c_top = c_alive && c_conv == top;
+                            if (top == INT32_MIN) {
+                                frontier_done = true;                                  // the frontier is empty
+                            } else if (a_top || c_top) {
+                                if (n_top > 1) LANE_BAIL(27);                          // an equal-score batch (:491-500): the general path
+                                // the other child stays behind
+                                const int32_t o_alive = a_top ? c_alive : (int32_t)fa_alive, o_conv = a_top ? c_conv : (int32_t)fa_conv;
+                                const int32_t o_max = a_top ? c_max_val : (int32_t)fa_max_val;
+                                if (o_alive) {
+                                    bool put = false;
+#pragma unroll
+                                    for (int t = 0; t < LANE_MAX_DEFER; ++t) {
+                                        if (!put && d_score(t) == INT32_MIN) { d_score(t) = o_conv; d_max(t) = o_max; put = true; }
+                                    }
+                                    if (!put) LANE_BAIL(28);
+                                    // (a chain column that stays behind gets an S / F record there; a fork's children have theirs)
+                                    if (!forked) cell_top += rec_words((uint32_t)LFW);
+                                }
+                                if (a_top) {
+                                    reload = true; reload_parked = true;               // its window comes back at the top of the loop
+                                    f_org = fa_org; f_trim = fa_trim; f_size = fa_size; f_offset = fa_offset; f_max_val = fa_max_val;
+                                    f_node = fa_node; f_idx = fa_idx; t_score = fa_t_score; t_nod = fa_t_nod; t_pos = fa_t_pos;
+                                } else {
+                                    f_org = c_org; f_trim = c_trim; f_size = c_size; f_offset = next_offset; f_max_val = c_max_val;
+                                    f_node = c_node; f_idx = c_idx; t_score = c_t_score; t_nod = c_t_nod; t_pos = c_t_pos;
+                                }
+                                if (!((f_trim & 3) + f_size + 3 <= LFW)) LANE_BAIL(16);    // (fast_fits: the general path would take it)
+                                have_head = true;
+                                frontier_done = true;
+                            } else {
+                                // a column that stayed behind is popped: cut-offs, then its band — which must be empty
+                                bool done1 = false, stop_all = false;
+#pragma unroll
+                                for (int t = 0; t < LANE_MAX_DEFER; ++t) {
+                                    if (!done1 && d_score(t) == top) {
+                                        done1 = true;
+                                        const int32_t dm = d_max(t);
+                                        if (dm < best_score) {
+                                            if ((double)tsize / (double)window_size >= cfg.max_nodes_per_seq_char) stop_all = true;
+                                            else if ((double)table_size_bytes() / 1000000.0 > cfg.max_ram_per_alignment) stop_all = true;
+                                        }
+                                        if (!stop_all && dm >= xdrop_cutoff) LANE_BAIL(29);  // it would be extended
+                                        d_score(t) = INT32_MIN;
+                                    }
+                                }
+                                if (stop_all) frontier_done = true;
+                            }
+                        }
+                        if (!have_head) ext_over = true;
+                    }
+                    n_kids = 0;
+                }
+            }
         }
-        ctr.columns += rr.n_columns;
+        ctr.columns += (uint32_t)cols_done;
+        // ---- after the extension: everything below is derived afresh from the read's index and the lane's cold state ----
+        LANE_OPAQUE(read);
+        const int32_t seed_off = c_seed_off, seed_len = c_seed_len;
+        const uint32_t node0 = c_node0;
+        const SeedHdr *hp2 = P.seed_hdr + read;
+        const DevSeed *seeds = P.seed_stream + gld(&hp2->off) + (s ? (int32_t)gld(&hp2->n_seeds[0]) : 0);
+        const uint32_t *rnodes = (s ? P.nodes_rc : P.nodes_fwd) + gld(P.node_begin + read);
+        const int32_t sroot = (cfg.left_end_bonus && !clipping) ? cfg.left_end_bonus : 0;
+        const int32_t root_pushes = LANE_CI(CD_ROOT_PUSHES), root_size = 1 + root_pushes;
+        const int32_t root_ins = imax(sroot + go, NINF + ge);
+        auto root_S = [&](int32_t pos) -> int32_t {
+            return pos == 0 ? sroot : (pos >= 1 && pos <= root_pushes ? root_ins + (pos - 1) * ge : NINF);
+        };
+        (void)seed_len;
         // ---- backtrack (:869-1034): the best start cell, one trace ----
-        if (b_score == INT32_MIN) return LR_BAIL;                                  // no start cell: the seed itself would be reported
-        if (later_live) return LR_BAIL;                                            // a later seed survives: more extensions to run
+        if (b_score == INT32_MIN) LANE_BAIL(18);                                  // no start cell: the seed itself would be reported
+        // ---- check_seed (:66-88) of the later seeds against this extension's convergence table: each must be dead, or there
+        // are more extensions to run.  A node's entry is its first (and only) column here: the node table gives the column, the
+        // column's S row the score at the seed's last query position.
+        for (int32_t t = 1; t < n; ++t) {
+            const DevSeed *sj = seeds + t;
+            const int32_t cl = (int32_t)gld(&sj->clipping), len = (int32_t)gld(&sj->length), so = (int32_t)gld(&sj->offset);
+            const int32_t nn = (int32_t)gld(&sj->n_nodes);
+            const uint32_t ln = so == 0 ? gld(rnodes + cl + nn - 1) : gld(&sj->node);
+            const int32_t lpos = len + cl - 1;
+            const int32_t lscore = len * m + (!cl ? cfg.left_end_bonus : 0) + (!(L - cl - len) ? cfg.right_end_bonus : 0);
+            if (ln == node0) LANE_BAIL(7);                                           // (its entry is the replay columns' merged vector)
+            uint32_t hs = lane_hash(ln, hmask);
+            int32_t idx = -1;
+            for (;;) {
+                const uint64_t he = gld(htab() + hs);
+                if ((uint32_t)(he >> 44) != tag) break;
+                if ((uint32_t)he == ln) { idx = (int32_t)((he >> 32) & 0xFFFu); break; }
+                hs = (hs + 1) & hmask;
+            }
+            if (idx < 0) LANE_BAIL(19);                                              // not in the table: the seed lives
+            const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)idx * LANE_SLOT_BYTES);
+            if (gld(sl + 8) != ln) LANE_BAIL(19);                                    // (an entry another launch left behind)
+            const uint32_t geom = gld(sl + 10);
+            const int32_t cbegin = (int32_t)(geom & 0xFFFF), csize = (int32_t)((geom >> 16) & 0xFF);
+            const int32_t skip = cbegin ? 0 : 1;
+            const int32_t qs = start + cbegin - (cbegin ? 1 : 0), qn = csize - skip;
+            if (lpos < qs || lpos - qs >= qn) LANE_BAIL(19);                         // outside the entry's range: the seed lives
+            const int32_t a = lpos - start + 1, x = a - (cbegin & ~3);
+            int32_t v = NINF;
+            if (a - cbegin >= 0 && a - cbegin < csize + 5 && x < LFW) {
+                const int32_t d = (int32_t)(int8_t)gld(s8rows() + (uint64_t)idx * LANE_S8_BYTES + x);
+                if (d != -128) v = (int32_t)gld(sl + 9) + d;
+            }
+            if (v < lscore) LANE_BAIL(19);                                           // the seed lives
+        }
         const int32_t k_minus_1 = k - 1;
         const int32_t min_trace_length = k - seed_off;
         const int32_t cap = (int32_t)lim.max_path;
@@ -416,6 +664,7 @@ MGX_DEV int lane_read(const LaneParams &LP, const uint64_t read, const uint32_t 
             }
         };
         auto slot_geom = [&](int32_t jj) -> uint32_t { return gld((const uint32_t *)(slots + (uint64_t)jj * LANE_SLOT_BYTES) + 10); };
+        auto slot_link = [&](int32_t jj) -> uint32_t { return gld((const uint32_t *)(slots + (uint64_t)jj * LANE_SLOT_BYTES) + 11); };     // parent | offset << 16
         auto slot_flags = [&](int32_t jj, uint32_t geom, int32_t p) -> uint32_t {
             const int32_t begin = (int32_t)(geom & 0xFFFF), size = (int32_t)((geom >> 16) & 0xFF);
             const int32_t jx = p - begin, x = p - (begin & ~3);
@@ -425,8 +674,9 @@ MGX_DEV int lane_read(const LaneParams &LP, const uint64_t read, const uint32_t 
         for (;;) {
             if (!j) break;
             const uint32_t geom = slot_geom(j);
+            const uint32_t link = slot_link(j);
             const uint32_t ccode = geom >> 24;
-            const int32_t col_offset = seed_off - 1 + j;
+            const int32_t col_offset = (int32_t)(link >> 16);
             align_offset = imin(col_offset, k_minus_1);
             const uint32_t fl = slot_flags(j, geom, pos);
             const uint32_t last_op = n_runs ? (cur_run & 7) : 99u;
@@ -448,30 +698,31 @@ MGX_DEV int lane_read(const LaneParams &LP, const uint64_t read, const uint32_t 
                 push_op(op, 1);
                 if (col_offset >= k_minus_1) ++n_path;
                 --pos;
-                --j;
+                j = (int32_t)(link & 0xFFFFu);
                 j_stop = j;
             } else if ((fl & CF_S_IS_F) && (n_runs == 0 || last_op != OP_INSERTION)) {
                 uint32_t lop = OP_DELETION;
                 while (lop == OP_DELETION && j && !bad) {
                     const uint32_t g2 = slot_geom(j);
-                    const int32_t o2 = seed_off - 1 + j;
+                    const uint32_t l2 = slot_link(j);
+                    const int32_t o2 = (int32_t)(l2 >> 16);
                     align_offset = imin(o2, k_minus_1);
                     lop = (slot_flags(j, g2, pos) & CF_F_EXT) ? OP_DELETION : OP_MATCH;
                     ++n_trace;
                     ++n_seq;
                     push_op(OP_DELETION, 1);
                     if (o2 >= k_minus_1) ++n_path;
-                    --j;
+                    j = (int32_t)(l2 & 0xFFFFu);
                     j_stop = j;
                 }
             } else {
                 j_stop = j;
                 break;
             }
-            if (bad || n_seq > cap || n_path > cap) return LR_BAIL;
+            if (bad || n_seq > cap || n_path > cap) LANE_BAIL(20);
         }
-        if (bad) return LR_BAIL;
-        if (!(n_trace >= min_trace_length && n_path)) return LR_BAIL;             // (the next start cell would be tried)
+        if (bad) LANE_BAIL(21);
+        if (!(n_trace >= min_trace_length && n_path)) LANE_BAIL(22);             // (the next start cell would be tried)
         {
             // the cell the trace ended in (the root's cells are known in closed form)
             int32_t cur_cell_score;
@@ -484,41 +735,89 @@ MGX_DEV int lane_read(const LaneParams &LP, const uint64_t read, const uint32_t 
                 const int32_t jx = pos - begin, x = pos - (begin & ~3);
                 cur_cell_score = NINF;
                 if (jx >= 0 && jx < size + 5 && x < LFW) {
-                    const int32_t v = (int32_t)(int8_t)gld(s8rows + (uint64_t)j * LANE_S8_BYTES + x);
+                    const int32_t v = (int32_t)(int8_t)gld(s8rows() + (uint64_t)j * LANE_S8_BYTES + x);
                     const int32_t cb = (int32_t)gld((const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES) + 9);
                     if (v != -128) cur_cell_score = cb + v;
                 }
             }
             const int32_t bt_best = score - cur_cell_score;                         // best_score = max(INT32_MIN, .)
-            if (score - min_cell_score < bt_best) return LR_BAIL;                   // no alignment from this extension
+            if (score - min_cell_score < bt_best) LANE_BAIL(23);                   // no alignment from this extension
             if (!(score >= min_start_score && (!pos || cur_cell_score == 0) && (pos || cur_cell_score == sroot)
-                  && (cfg.allow_left_trim || !j))) return LR_BAIL;                 // (the next start cell would be tried)
+                  && (cfg.allow_left_trim || !j))) LANE_BAIL(24);                 // (the next start cell would be tried)
         }
         // construct_alignment (:774-798) + trim_offset (alignment.cpp:177-190)
         a_clip = clipping + pos;
         a_end_clip = L - (clipping + end_pos);
         a_score = score; a_offset = align_offset; a_n_runs = n_runs;
-        a_j_lo = j_stop + 1; a_j_hi = j_start; a_n_seq = n_seq; a_n_nodes = n_path;
-        a_j_first_node = imax(a_j_lo, k - seed_off);
-        if (a_j_hi - a_j_lo + 1 != n_seq || a_j_hi - imax(a_j_lo, k - seed_off) + 1 != n_path) return LR_BAIL;   // (cannot happen: every column left appends once)
+        // (the path: the columns the trace left by a match or a deletion, from j_start down its parent links — n_seq of them, the
+        // n_path with offset >= k - 1 carry the alignment's nodes)
+        (void)j_stop;
+        a_j_hi = j_start; a_n_seq = n_seq; a_n_nodes = n_path;
         if (a_offset && a_n_nodes > 1) {
             const int32_t trim = imin(a_offset, a_n_nodes - 1);
-            if (trim > 0) { a_j_first_node += trim; a_n_nodes -= trim; a_offset -= trim; }
+            if (trim > 0) { a_n_nodes -= trim; a_offset -= trim; }
         }
         have_aln = true;
         // ---- aln_both after the forward pass (:683-736), no backward pass in this kernel ----
         if (have_rc) {
-            if (a_clip && !a_offset) return LR_BAIL;                                // extend backwards from the reversed alignment
+            if (a_clip && !a_offset) LANE_BAIL(26);                                // extend backwards from the reversed alignment
             if (!(a_score >= cfg.min_path_score)) have_aln = false;                 // get_min_path_score with an empty aggregator
         }
-        (void)seed_score;
     }
+    {
+        ReadResult &rr = R.rr;
+        rr.status = ST_OK; rr.n_alignments = 0; rr.score = 0; rr.offset = 0; rr.n_nodes = rr.n_cigar = rr.seq_len = 0;
+        rr.orientation = 0; rr.stream_off = 0;
+        const SeedHdr *hp = P.seed_hdr + read;
+        rr.num_matches_fwd = gld(&hp->num_matching[0]); rr.num_matches_rc = gld(&hp->num_matching[1]);
+        rr.n_seeds_fwd = (uint32_t)gld(&hp->n_seeds[0]); rr.n_seeds_rc = (uint32_t)gld(&hp->n_seeds[1]);
+        rr.n_extensions = (uint32_t)n_extensions; rr.n_columns = n > 0 ? (uint32_t)cols_done : 0u;
+    }
+    ctr.rank_lines += LANE_CU(CD_CTR_RANK); ctr.select_lines += LANE_CU(CD_CTR_SEL);
     R.have_aln = (have_aln && a_n_nodes) ? 1 : 0;
     R.score = a_score; R.offset = a_offset; R.clip = a_clip; R.end_clip = a_end_clip; R.n_runs = a_n_runs;
-    R.j_lo = a_j_lo; R.n_nodes = a_n_nodes; R.n_seq = a_n_seq; R.j_first_node = a_j_first_node; R.strand = s;
+    R.j_hi = a_j_hi; R.n_nodes = a_n_nodes; R.n_seq = a_n_seq; R.trim = 0; R.strand = s;
     R.words = R.have_aln ? (uint32_t)a_n_nodes + (uint32_t)((a_clip ? 1 : 0) + a_n_runs + (a_end_clip ? 1 : 0)) + ((uint32_t)a_n_seq + 3) / 4 : 0u;
     return LR_DONE;
 }
+
+#undef c_seed_len
+#undef c_seed_off
+#undef c_node0
+#undef b_score
+#undef b_nod
+#undef b_i
+#undef b_pos
+#undef t_score
+#undef t_nod
+#undef t_pos
+#undef fa_alive
+#undef fa_conv
+#undef fa_org
+#undef fa_trim
+#undef fa_size
+#undef fa_offset
+#undef fa_max_val
+#undef fa_idx
+#undef fa_t_score
+#undef fa_t_nod
+#undef fa_t_pos
+#undef fa_node
+#undef d_score
+#undef d_max
+#undef kid_node0
+#undef kid_code0
+#undef kid_node1
+#undef kid_code1
+#undef table_cap
+#undef tsb_lo
+#undef tsb_hi
+#undef table_size_bytes
+#undef cell_top
+#undef cols_done
+#undef f_node
+#undef f_idx
+#undef f_max_val
 
 // flat_read_end: the aggregator's one alignment -> output stream at word `so` (R.words of them, handed out by the caller: one
 // atomic per wavefront on the device), the result record, the seed dump of the test hook
@@ -533,22 +832,23 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
         } else {
             uint32_t *dst = P.out_stream + so;
             const int32_t n_cigar = (R.clip ? 1 : 0) + R.n_runs + (R.end_clip ? 1 : 0);
-            // nodes of the columns whose offset reaches k - 1, first to last, minus what trim_offset dropped
-            for (int32_t x = 0; x < R.n_nodes; ++x)
-                gst(dst + x, gld((const uint32_t *)(slots + (uint64_t)(R.j_first_node + x) * LANE_SLOT_BYTES) + 8));
             int32_t nc = 0;
             if (R.clip) gst(dst + R.n_nodes + nc++, ((uint32_t)R.clip << 3) | OP_CLIPPED);
             for (int32_t x = R.n_runs - 1; x >= 0; --x) gst(dst + R.n_nodes + nc++, chip.runs[x * chip.rstride]);
             if (R.end_clip) gst(dst + R.n_nodes + nc++, ((uint32_t)R.end_clip << 3) | OP_CLIPPED);
-            uint32_t *dseq = dst + R.n_nodes + n_cigar;
-            for (int32_t x = 0; x < R.n_seq; x += 4) {
-                uint32_t v = 0;
-                for (int32_t t = 0; t < 4 && x + t < R.n_seq; ++t) {
-                    const uint32_t cc = gld((const uint32_t *)(slots + (uint64_t)(R.j_lo + x + t) * LANE_SLOT_BYTES) + 10) >> 24;
-                    v |= (uint32_t)decode_code(cc) << (8 * t);
-                }
-                gst(dseq + (x >> 2), v);
+            // the path, last column first, down the parent links: characters of all its columns, nodes of those whose offset
+            // reaches k - 1 (minus the leading ones trim_offset dropped)
+            uint8_t *dseq = (uint8_t *)(dst + R.n_nodes + n_cigar);
+            const int32_t k_minus_1 = (int32_t)P.g.k - 1;
+            int32_t j = R.j_hi, ni = R.n_nodes - 1;
+            for (int32_t x = R.n_seq - 1; x >= 0; --x) {
+                const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES);
+                const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
+                gst(dseq + x, decode_code(geom >> 24));
+                if ((int32_t)(link >> 16) >= k_minus_1) { if (ni >= 0) gst(dst + ni, node); --ni; }
+                j = (int32_t)(link & 0xFFFFu);
             }
+            for (int32_t x = R.n_seq; x & 3; ++x) gst(dseq + x, (uint8_t)0);          // (pad the last word)
             rr.score = R.score; rr.offset = (uint32_t)R.offset;
             rr.n_nodes = (uint32_t)R.n_nodes; rr.n_cigar = (uint32_t)n_cigar; rr.seq_len = (uint32_t)R.n_seq;
             rr.orientation = (uint32_t)R.strand; rr.stream_off = so;

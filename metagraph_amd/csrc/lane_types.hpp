@@ -1,6 +1,7 @@
 // lane_types.hpp — what the host needs to know about the lane-per-read kernel (lane_read.hpp, mgx_lane.hip): its launch
 // parameters, its scratch layout and the test of whether a batch's configuration is one the kernel takes at all.
 #pragma once
+#include <algorithm>
 #include <string>
 
 #include "../../include/mgx.h"
@@ -12,8 +13,9 @@ namespace mgx {
 constexpr int LANE_MAX_L = 256;            // longest read a lane takes (packed strand in LDS: LANE_QWORDS words per lane)
 constexpr int LANE_QWORDS = LANE_MAX_L / 32 + 2;
 constexpr int LANE_MAX_RUNS = 16;          // CIGAR runs of a trace kept in LDS
-constexpr int LANE_MAX_LATER = 4;          // later seeds of the strand checked against the extension
+constexpr int LANE_MAX_SEEDS = 512;        // seeds of the strand (the later ones are checked against the extension one by one)
 constexpr int LANE_SLOT_BYTES = 64;        // per column: 32 flag bytes + node + base + geometry (+ 4 unused words)
+constexpr int LANE_MAX_DEFER = 3;          // columns that may stay behind in the frontier (the other children of forks)
 constexpr int LANE_S8_BYTES = 32;          // per column: S of the window as 8-bit offsets from `base` (read at the trace's end only)
 
 // what one launch of the lane kernel needs on top of AlignParams
@@ -23,7 +25,7 @@ struct LaneParams {
     const uint32_t *iv[2];               // invalid-character flags, same indexing
     uint8_t *scratch;                    // per resident lane: column slots | S8 rows | node table
     uint64_t scratch_stride;
-    uint32_t max_cols;                   // columns a lane's scratch holds (Lmax + 2)
+    uint32_t max_cols;                   // columns a lane's scratch holds (lane_max_cols)
     uint32_t hash_slots;                 // power of two >= 2 * max_cols
     uint32_t tag_seed;                   // changes per launch (node-table entries of earlier launches read as empty)
     uint32_t t4[4];                      // score_matrix[c][q] for c, q in ACGT: row c as four bytes (q = A in the low byte)
@@ -31,10 +33,17 @@ struct LaneParams {
     uint32_t *bail_list;                 // reads for the group kernel, in processing order
     unsigned long long *bail_count;
     unsigned long long *done_count;
+    unsigned long long *bail_hist;       // [32] reads passed on, by the LANE_BAIL code of the test that sent them (lane_read.hpp)
 };
 
+// columns of an extension along one path: the root, one per query character, the deletions past the query's end that the x-drop
+// still allows, the spare slot of the `size >= capacity - 1` test (a read that needs more goes to the group kernel)
+inline uint32_t lane_max_cols(uint32_t Lmax, int32_t xdrop) {
+    return Lmax + (uint32_t)std::min<int64_t>(Lmax, std::max<int64_t>(xdrop, 0)) + 8;
+}
+
 inline uint64_t lane_scratch_bytes(uint32_t max_cols, uint32_t hash_slots) {
-    return (uint64_t)max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)hash_slots * 8;
+    return (uint64_t)max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)hash_slots * 8 + 2 * 2 * 32 * 4;      // + two parked windows (S, F of 32 cells)
 }
 
 

@@ -17,6 +17,7 @@
 #define MGX_NO_EXTEND 1      // this unit holds k_map and the seeding kernel; the extension lives in mgx_grp.hip
 #include "graph_build.hpp"
 #include "host_common.hpp"
+#include "lane_types.hpp"
 
 using namespace mgx;
 
@@ -304,6 +305,8 @@ extern "C" int mgx_launch_align_grp8_alt(const void *params, uint32_t n_groups, 
 extern "C" unsigned mgx_grp_static_lds8_alt(void);
 extern "C" int mgx_grp_waves_per_simd8_alt(void);
 extern "C" int mgx_launch_ext64(const void *params, uint32_t blocks, uint32_t lds_bytes, void *stream);      // mgx_ext64.hip
+extern "C" int mgx_launch_lane(const void *d_params, uint32_t blocks, void *stream);                         // mgx_lane.hip
+extern "C" int mgx_lane_waves_per_simd(void);
 extern "C" unsigned mgx_ext64_static_lds(void);
 extern "C" int mgx_ext64_waves_per_simd(void);
 extern "C" int mgx_launch_align_grp8_prim(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);
@@ -349,6 +352,11 @@ struct mgx_aligner {
     DevBuf score_matrix, seqs, offsets, counts, node_begin, nodes_fwd, nodes_rc, arena, results, stream, cursors, d_stats, d_stats_map, scan_tmp, dbg_seeds;
     DevBuf seed_hdr, seed_stream, work_key, work_key_sorted, order_in, order, sort_tmp, retry_list;    // split pipeline
     DevBuf resume_pool[2], retry_list2, retry_key[2];      // multi-pass extension: resume records, retry lists and keys (ping-pong)
+    DevBuf lane_scratch, lane_params, lane_bail, lane_hist;           // lane-per-read kernel: per-lane scratch, its parameter block, the reads it passes on
+    bool packed_valid = false;    // pk_* / iv_* hold this batch's strands (k <= 32 and the batch was mapped)
+    uint32_t lane_epoch = 0;
+    uint64_t lane_done = 0;
+    unsigned long long lane_hist_h[32] = { 0 };
     uint32_t n_passes = 0;
     DevLimits lim;
     uint64_t n_reads = 0, total_kmers = 0;
@@ -360,7 +368,7 @@ struct mgx_aligner {
     HostResults host;
     std::vector<uint64_t> m_node_begin, m_fwd, m_rc;
     mgx_stats hstats;
-    hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     bool split_ran = false;
     uint64_t kernels_ran = 0;     // MGX_KERNEL_* bits of the extension kernels the last batch launched
     uint64_t seed_scale = 1, seed_cap = 0;
@@ -733,6 +741,7 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
     // k_map's counters live in their own block: a re-run of the alignment stage (stream overflow) resets only its own
     HIP_TRY(hipMemsetAsync(A->d_stats_map.p, 0, sizeof(KernelStats), 0));
     HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), 0));
+    A->packed_valid = false;
     if (!mapped) {
         // max_seed_length < k: nodes are not mapped (dbg_aligner.cpp:209-213)
         HIP_TRY(hipMemsetAsync(A->nodes_fwd.p, 0, (A->total_kmers + 1) * 4, 0));
@@ -765,6 +774,7 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
             k_pack_reads<<<(uint32_t)((threads + 255) / 256), 256>>>(d_seqs, d_offsets, n, wpr, do_rc ? 1 : 0, A->pk_fwd.as<uint64_t>(),
                                                                     A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>());
             HIP_TRY(hipGetLastError());
+            A->packed_valid = true;
             k_map_packed<<<(uint32_t)blocks, 256>>>(A->graph->g, d_offsets, A->node_begin.as<uint64_t>(),
                                          A->pk_fwd.as<uint64_t>(), A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>(),
                                          A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(),
@@ -808,6 +818,23 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     const uint64_t stride = arena_bytes(l);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, A->graph->device));
+    // The lane-per-read kernel (mgx_lane.hip) in front of the group kernel: does this batch's configuration qualify?  Its
+    // scratch is taken before the arena is sized from what is free.
+    LaneParams LP;
+    memset(&LP, 0, sizeof(LP));
+    std::string lane_why;
+    const uint32_t lane_blocks = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)mgx_lane_waves_per_simd();
+    bool lane_ok = A->opt.lane != 0 && A->packed_valid && A->mode == MODE_SPLIT8 && !A->opt.two_pass && A->opt.multi_pass != 1
+                   && lane_enabled(A->cfg, A->dcfg, A->graph->g.k, l.Lmax, A->no_fast, &LP, &lane_why)
+                   && (A->opt.lane == 1 || n >= (uint64_t)lane_blocks * 16);       // (a small batch: the spread / 64-lane kernels are quicker)
+    if (lane_ok) {
+        LP.max_cols = lane_max_cols(l.Lmax, A->dcfg.xdrop);
+        LP.hash_slots = next_pow2(2ull * LP.max_cols);
+        LP.scratch_stride = (lane_scratch_bytes(LP.max_cols, LP.hash_slots) + 63) & ~63ull;
+        const size_t before = A->lane_scratch.bytes;
+        if (A->lane_scratch.ensure((size_t)lane_blocks * 64 * LP.scratch_stride, true) != MGX_OK) lane_ok = false;      // (no room: the group kernel alone)
+        else if (A->lane_scratch.bytes != before) HIP_TRY(hipMemsetAsync(A->lane_scratch.p, 0, A->lane_scratch.bytes, 0));    // node tables start empty
+    }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const AlignMode mode = A->mode;
@@ -1016,7 +1043,45 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             multi = n > 0 && seeds_total / n >= 24;
         }
         A->n_passes = 1;
-        if (multi) {
+        A->lane_done = 0;
+        memset(A->lane_hist_h, 0, sizeof(A->lane_hist_h));
+        HIP_TRY(hipEventRecord(A->ev[6], 0));
+        bool nothing_left = false;
+        if (lane_ok && !multi && n) {
+            // every read through the lane kernel first, in the sorted order; what it lists goes on to the group kernel below
+            if (int rc = A->lane_bail.ensure(n * 4 + 4)) return rc;
+            if (int rc = A->lane_params.ensure(sizeof(LaneParams))) return rc;
+            if (int rc = A->lane_hist.ensure(32 * 8)) return rc;
+            HIP_TRY(hipMemsetAsync(A->lane_hist.p, 0, 32 * 8, 0));
+            HIP_TRY(hipMemsetAsync(cur + 5, 0, 16, 0));
+            LP.P = P;
+            LP.P.n_items = n;
+            LP.pk[0] = A->pk_fwd.as<uint64_t>(); LP.pk[1] = A->pk_rc.as<uint64_t>();
+            LP.iv[0] = A->iv_fwd.as<uint32_t>(); LP.iv[1] = A->iv_rc.as<uint32_t>();
+            LP.scratch = A->lane_scratch.as<uint8_t>();
+            LP.tag_seed = ++A->lane_epoch * 0x632BE5ABu;
+            LP.bail_list = A->lane_bail.as<uint32_t>();
+            LP.bail_count = cur + 5;
+            LP.done_count = cur + 6;
+            LP.bail_hist = A->lane_hist.as<unsigned long long>();
+            HIP_TRY(hipMemcpy(A->lane_params.p, &LP, sizeof(LP), hipMemcpyHostToDevice));
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>(lane_blocks, (n + 63) / 64);
+            if (int rc = mgx_launch_lane(A->lane_params.p, blocks, nullptr)) return fail(MGX_ERR_NO_DEVICE, "lane kernel: %d", rc);
+            A->kernels_ran |= MGX_KERNEL_LANE;
+            ++g_kernel_launches[4];
+            HIP_TRY(hipEventRecord(A->ev[6], 0));
+            unsigned long long counts[2] = { 0, 0 };
+            HIP_TRY(hipMemcpy(counts, cur + 5, 16, hipMemcpyDeviceToHost));     // (synchronises with the kernel)
+            A->lane_done = counts[1];
+            HIP_TRY(hipMemcpy(A->lane_hist_h, A->lane_hist.p, 32 * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));                          // rewind the read cursor
+            P.order = A->lane_bail.as<uint32_t>();
+            P.n_items = counts[0];
+            nothing_left = counts[0] == 0;
+        }
+        if (nothing_left) {
+            // (every read finished in the lane kernel)
+        } else if (multi) {
             const uint32_t rb = resume_rec_bytes(l, (uint32_t)std::max<uint64_t>(1, A->cfg.num_alternative_paths));
             size_t fb = 0, tb = 0;
             HIP_TRY(hipMemGetInfo(&fb, &tb));
@@ -1066,7 +1131,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                 (void)items;
             }
         }
-        if (!multi) {
+        if (!multi && !nothing_left) {
             const bool two_pass = two_pass_env == 1;
             for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
                 if (two_pass && pass == 0) {
@@ -1101,6 +1166,8 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     s.n_map_lines = ks.map_lines; s.n_capacity_errors = ks.capacity_errors; s.n_seed_lines = ks.seed_lines;
     s.n_fast_columns = ks.fast_columns;
     s.extend_kernels = A->kernels_ran;
+    s.n_lane_reads = A->lane_done;
+    for (int x = 0; x < 32; ++x) s.lane_bail_reads[x] = A->lane_hist_h[x];
     for (int x = 0; x < 8; ++x) { s.phase_cycles[x] = ks.cyc[x]; s.extend_cycles[x] = ks.xcyc[x]; }
     float ms = 0;
     if (mapped) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[0], A->ev[1])); s.seed_kernel_ms = ms; }
@@ -1109,6 +1176,7 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
         HIP_TRY(hipEventElapsedTime(&ms, A->ev[2], A->ev[4])); s.seeding_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, A->ev[4], A->ev[5])); s.sort_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, A->ev[5], A->ev[3])); s.extend_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, A->ev[5], A->ev[6])); s.lane_ms = ms;
     }
     return MGX_OK;
 }

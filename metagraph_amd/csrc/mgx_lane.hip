@@ -1,0 +1,120 @@
+// mgx_lane.hip — the lane-per-read kernel (lane_read.hpp): every lane of a wavefront aligns its own read, 64 reads per
+// instruction, in front of the 8-lane group kernel of mgx_grp.hip.  A lane finishes a "simple" read completely (result record
+// + output stream) or lists it for the group kernel, which then aligns it from scratch; see lane_read.hpp for the contract.
+//
+// Shape: persistent wavefronts; a wavefront takes 64 consecutive items of the work-sorted order at a time (neighbours need about
+// the same number of columns), runs lane_read() on them — the column loop is where the lanes spend their time; a lane whose read
+// ends or bails early idles until its 63 wave-mates are through — hands out the output-stream words of the whole wavefront with
+// ONE atomic, and writes results.  Per-lane state: the DP window (32 S + 32 F cells) and the bookkeeping of one extension in
+// VGPRs; the packed query and the CIGAR runs of the trace in LDS (word-major, conflict free); column slots, S rows and the node
+// table in a private slice of HBM scratch.
+#include <hip/hip_runtime.h>
+
+#define mgx mgx_lane_ns
+#include "wave.hpp"
+#include "graph_build.hpp"
+#include "lane_read.hpp"
+
+using namespace mgx;
+
+#ifndef MGX_LANE_WAVES_PER_SIMD
+#define MGX_LANE_WAVES_PER_SIMD 2
+#endif
+
+__global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const LaneParams *__restrict__ LPp) {
+    // (the parameter block stays in memory: its ~90 uniform words are re-read with scalar loads where they are used instead of
+    // occupying — and spilling — scalar registers across the column loop)
+    const LaneParams &LP = *LPp;
+    __shared__ uint64_t s_qw[LANE_QWORDS][64];
+    __shared__ uint32_t s_runs[LANE_MAX_RUNS][64];
+    __shared__ uint32_t s_cold[LANE_COLD_WORDS][64];
+    const int lane = (int)threadIdx.x;
+    const uint64_t slot = (uint64_t)blockIdx.x * 64 + (uint64_t)lane;
+    uint8_t *scratch = LP.scratch + slot * LP.scratch_stride;
+    LaneChip chip;
+    chip.qw = &s_qw[0][lane]; chip.qstride = 64;
+    chip.runs = &s_runs[0][lane]; chip.rstride = 64;
+    chip.cold = &s_cold[0][lane]; chip.cstride = 64;
+    const uint64_t n_items = LP.P.n_items ? LP.P.n_items : LP.P.n_reads;
+    LaneCounters ctr = { 0, 0, 0, 0 };
+    uint32_t n_done = 0, n_ext = 0, n_cap = 0;
+    for (;;) {
+        LV<uint64_t> bv;
+        bv.v = 0;
+        if (lane == 0) bv.v = atomicAdd(LP.P.read_cursor, 64ull);
+        const uint64_t base = wave_bcast(bv, 0);
+        if (base >= n_items) break;
+        const uint64_t item = base + (uint64_t)lane;
+        const bool active = item < n_items;
+        uint64_t read = 0;
+        int rc = LR_DONE;
+        LaneResult R;
+        R.words = 0; R.have_aln = 0;
+        if (active) {
+            read = LP.P.order ? (uint64_t)gld(LP.P.order + item) : item;
+            rc = lane_read(LP, read, (uint32_t)item, scratch, chip, ctr, R);
+        }
+        const bool done = active && rc == LR_DONE, bail = active && rc != LR_DONE;
+        // output-stream words of the wavefront's finished reads: one atomic, a prefix sum over the lanes
+        LV<int32_t> wv;
+        wv.v = done ? (int32_t)R.words : 0;
+        const LV<int32_t> pre = wave_prefix_sum_excl(wv);
+        const int32_t total = wave_sum(wv);
+        LV<uint64_t> sv;
+        sv.v = 0;
+        if (lane == 0 && total) sv.v = atomicAdd(LP.P.out_cursor, (unsigned long long)total);
+        const uint64_t so = wave_bcast(sv, 0) + (uint64_t)pre.v;
+        if (done) {
+            lane_emit(LP, read, scratch, chip, R, so);
+            ++n_done; n_ext += R.rr.n_extensions; n_cap += R.rr.status != ST_OK;
+        }
+        // the reads for the group kernel, in processing order
+        LV<bool> bl;
+        bl.v = bail;
+        const uint64_t bm = wave_ballot(bl);
+        if (bm) {
+            LV<uint64_t> pv;
+            pv.v = 0;
+            if (lane == 0) pv.v = atomicAdd(LP.bail_count, (unsigned long long)popc64(bm));
+            const uint64_t p0 = wave_bcast(pv, 0);
+            if (bail) gst(LP.bail_list + p0 + (uint64_t)popc64(bm & ((1ull << lane) - 1)), (uint32_t)read);
+            // ... and why, for the statistics: one atomic per distinct reason of the wavefront
+            uint64_t left = bm;
+            while (left) {
+                LV<uint32_t> rv;
+                rv.v = ctr.reason;
+                const uint32_t code = wave_bcast(rv, ctz64(left)) & 31u;
+                LV<bool> same;
+                same.v = bail && (ctr.reason & 31u) == code;
+                const uint64_t sm = wave_ballot(same);
+                if (lane == 0) atomicAdd(LP.bail_hist + code, (unsigned long long)popc64(sm));
+                left &= ~sm;
+            }
+        }
+    }
+    // counters: one atomic per wavefront and counter
+    LV<int32_t> v;
+    v.v = (int32_t)ctr.rank_lines; const int32_t rl = wave_sum(v);
+    v.v = (int32_t)ctr.select_lines; const int32_t sl = wave_sum(v);
+    v.v = (int32_t)ctr.columns; const int32_t cl = wave_sum(v);
+    v.v = (int32_t)n_done; const int32_t nd = wave_sum(v);
+    v.v = (int32_t)n_ext; const int32_t ne = wave_sum(v);
+    v.v = (int32_t)n_cap; const int32_t nc = wave_sum(v);
+    if (lane == 0) {
+        atomicAdd(&LP.P.stats->rank_lines, (unsigned long long)rl);
+        atomicAdd(&LP.P.stats->select_lines, (unsigned long long)sl);
+        atomicAdd(&LP.P.stats->columns, (unsigned long long)cl);
+        atomicAdd(&LP.P.stats->fast_columns, (unsigned long long)cl);
+        atomicAdd(&LP.P.stats->extensions, (unsigned long long)ne);
+        atomicAdd(&LP.P.stats->capacity_errors, (unsigned long long)nc);
+        atomicAdd(LP.done_count, (unsigned long long)nd);
+    }
+}
+
+// blocks = resident wavefronts (each lane owns scratch slice blockIdx * 64 + lane)
+// d_params: the LaneParams of this launch in device memory
+extern "C" int mgx_launch_lane(const void *d_params, uint32_t blocks, void *stream) {
+    k_lane<<<blocks, 64, 0, (hipStream_t)stream>>>(static_cast<const LaneParams *>(d_params));
+    return (int)hipGetLastError();
+}
+extern "C" int mgx_lane_waves_per_simd(void) { return MGX_LANE_WAVES_PER_SIMD; }

@@ -46,6 +46,8 @@ KERNEL_VARIANTS = {
     "auto": ((), (), ()),
     "grp8": (("ext64=0", "lane=0"), ("grp8_any",), ("ext64", "lane")),              # 8-lane groups, reads spread over wavefronts
     "grp8x8": (("ext64=0", "lane=0", "groups_per_wave=0"), ("grp8_any",), ("ext64", "lane")),   # ... 8 reads per wavefront
+    "lane": (("ext64=0", "lane=1", "groups_per_wave=0"), (), ("ext64",)),           # the lane-per-read kernel first (where the
+                                                                                    # configuration qualifies), 8-lane groups behind it
 }
 
 

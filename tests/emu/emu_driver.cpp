@@ -13,6 +13,7 @@
 
 #include "graph_build.hpp"
 #include "host_common.hpp"
+#include "lane_read.hpp"
 
 using namespace mgx;
 
@@ -38,6 +39,9 @@ struct EmuRun {
     KernelStats stats;
     uint64_t retried = 0;         // reads handed to pass 2 of the two-pass extension
     uint64_t out_used = 0;        // words of `stream` in use
+    uint64_t lane_done = 0, lane_ran = 0;     // MGX_EMU_LANE: reads the lane-per-read path finished; whether it ran at all
+    uint64_t lane_bail[32] = { 0 };            // ... and why it sent the others on (LANE_BAIL codes)
+    std::vector<uint8_t> lane_reason;          // per read: 0 = finished by the lane path, else the code
 };
 #ifdef MGX_EMU_TRACE
 // traced build (make trace): every access of the wave program calls the hooks of trace_hooks.cpp
@@ -368,6 +372,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         // wave program from scratch, in their order
         const char *lane_env = getenv("MGX_EMU_LANE");
         std::vector<uint32_t> lane_rest;
+        uint64_t n_ext = n;                  // reads the wave program's extension phase takes
         if (lane_env && *lane_env == '1' && have_packed) {
             LaneParams LP;
             memset(&LP, 0, sizeof(LP));
@@ -375,7 +380,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
             if (lane_enabled(cfg, dcfg, k, R->lim.Lmax, P.no_fast != 0, &LP, &why)) {
                 LP.P = P;
                 LP.pk[0] = pkf.data(); LP.pk[1] = pkr.data(); LP.iv[0] = ivf.data(); LP.iv[1] = ivr.data();
-                LP.max_cols = R->lim.Lmax + 2;
+                LP.max_cols = lane_max_cols(R->lim.Lmax, dcfg.xdrop);
                 LP.hash_slots = 4; while (LP.hash_slots < 2 * LP.max_cols) LP.hash_slots *= 2;
                 LP.scratch_stride = lane_scratch_bytes(LP.max_cols, LP.hash_slots);
                 std::vector<uint8_t> scratch(LP.scratch_stride, 0);
@@ -383,7 +388,9 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
                 LP.tag_seed = 12345;
                 std::vector<uint64_t> qw(LANE_QWORDS);
                 std::vector<uint32_t> runs(LANE_MAX_RUNS);
-                LaneChip chip = { qw.data(), 1, runs.data(), 1 };
+                std::vector<uint32_t> cold(LANE_COLD_WORDS);
+                LaneChip chip = { qw.data(), 1, runs.data(), 1, cold.data(), 1 };
+                R->lane_reason.assign(n, 0);
                 for (uint64_t i = 0; i < n; ++i) {
                     LaneCounters lc = { 0, 0, 0, 0 };
                     LaneResult LR;
@@ -397,6 +404,8 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
                         ++R->lane_done;
                     } else {
                         lane_rest.push_back(order[i]);
+                        if (lc.reason < 32) ++R->lane_bail[lc.reason];
+                        R->lane_reason[order[i]] = (uint8_t)lc.reason;
                     }
                     R->stats.rank_lines += lc.rank_lines; R->stats.select_lines += lc.select_lines;
                 }
@@ -419,7 +428,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
             std::vector<uint32_t> list_a(n + 1), list_b(n + 1), key_a(n + 1), key_b(n + 1), ord(n + 1);
             P.seed_limit = 1; P.resume_rec_bytes = rb; P.resume_cap = cap;
             P.retry_list = list_a.data(); P.retry_key = key_a.data(); P.retry_count = &retry_count; P.resume_out = pool_a.data();
-            for (uint64_t i = 0; i < n; ++i)
+            for (uint64_t i = 0; i < n_ext; ++i)
                 run_extend(order[i], nullptr);
             R->retried = retry_count;
             std::vector<uint8_t> *pin = &pool_a, *pout = &pool_b;
@@ -456,7 +465,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
             mgx_trace_region(R->stream.data(), R->stream.size() * 4, "out_stream");
             P.dbg_seeds = nullptr;
             mgx_trace_on(1);
-            for (uint64_t i = 0; i < n; ++i) {
+            for (uint64_t i = 0; i < n_ext; ++i) {
                 run_extend(order[i], nullptr);
                 TRACE_END_READ();
             }
@@ -465,7 +474,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
 #endif
         // two-pass extension: at most one seed per read first, then the reads that go on, from scratch
         P.seed_limit = 1; P.retry_list = retry.data(); P.retry_count = &retry_count;
-        for (uint64_t i = 0; i < n; ++i)
+        for (uint64_t i = 0; i < n_ext; ++i)
             run_extend(order[i], nullptr);
         P.seed_limit = 0; P.order = retry.data();
         for (uint64_t i = 0; i < retry_count; ++i)
@@ -515,6 +524,9 @@ uint32_t emu_seed_info(void *r, uint32_t *info6, uint32_t *seeds) {
         }
     return R->lim.max_seeds;
 }
+void emu_lane_stats(void *r, uint64_t *out2) { out2[0] = static_cast<EmuRun *>(r)->lane_ran; out2[1] = static_cast<EmuRun *>(r)->lane_done; }
+void emu_lane_reasons(void *r, uint8_t *out, uint64_t n) { auto &v = static_cast<EmuRun *>(r)->lane_reason; for (uint64_t i = 0; i < n && i < v.size(); ++i) out[i] = v[i]; }
+void emu_lane_bails(void *r, uint64_t *out32) { for (int x = 0; x < 32; ++x) out32[x] = static_cast<EmuRun *>(r)->lane_bail[x]; }
 void emu_stats(void *r, uint64_t *out8) {
     auto &s = static_cast<EmuRun *>(r)->stats;
     out8[0] = s.rank_lines; out8[1] = s.select_lines; out8[2] = s.bit_lines; out8[3] = s.columns;

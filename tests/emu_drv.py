@@ -152,6 +152,27 @@ class EmuRun:
         L().emu_seed_info(self.r, info, seeds)
         return decode_seed_info(self.n, ms, info, seeds)
 
+    def lane_stats(self):
+        """MGX_EMU_LANE=1 runs: (whether the lane-per-read path ran for the batch, reads it finished)"""
+        a = (C.c_uint64 * 2)()
+        L().emu_lane_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L().emu_lane_stats(self.r, a)
+        return bool(a[0]), int(a[1])
+
+    def lane_reasons(self):
+        """per read: 0 = finished by the lane-per-read path, else the LANE_BAIL code that sent it on"""
+        a = (C.c_uint8 * max(1, self.n))()
+        L().emu_lane_reasons.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.c_uint64]
+        L().emu_lane_reasons(self.r, a, self.n)
+        return list(a)[:self.n]
+
+    def lane_bails(self):
+        """reads the lane-per-read path sent on to the wave program, by LANE_BAIL code (lane_read.hpp)"""
+        a = (C.c_uint64 * 32)()
+        L().emu_lane_bails.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L().emu_lane_bails(self.r, a)
+        return {i: int(a[i]) for i in range(32) if a[i]}
+
     def stats(self):
         a = (C.c_uint64 * 8)()
         L().emu_stats(self.r, a)

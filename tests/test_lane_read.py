@@ -1,0 +1,135 @@
+"""The lane-per-read path (metagraph_amd/csrc/lane_read.hpp: one lane aligns a whole "simple" read; the reads it cannot finish
+go to the wave program from scratch) in the host model, against the oracle: every read of every world, whichever of the two
+paths it took, must come out as the oracle's; and the path must actually take the reads it is meant for."""
+import os
+import random
+
+import pytest
+
+import emu_drv
+import orc
+from metagraph_amd import capi
+from test_emu_vs_oracle import make_world, mutate, noisy_reads, rand_seq, rc
+
+
+@pytest.fixture(autouse=True)
+def _lane_env(monkeypatch):
+    monkeypatch.setenv("MGX_EMU_SPLIT", "1")
+    monkeypatch.setenv("MGX_EMU_LANE", "1")
+
+
+def run_both(g, cfg, reads, limits=None):
+    want = orc.AlignRun(g, cfg, reads).results()
+    r = emu_drv.EmuRun(emu_drv.EmuGraph(g), cfg, reads, limits)
+    assert r.error == "", r.error
+    got, status = r.results()
+    assert all(s == 0 for s in status), status
+    for q in range(len(reads)):
+        assert got[q] == want[q], (q, reads[q], got[q], want[q])
+    return r
+
+
+def bench_like_world(seed, n_reads, k=31, genome_len=40000, read_len=150, snp_every=0):
+    """the benchmark's read model: 1 % substitutions, 0.05 % insertions / deletions, 5 % random reads, both strands; with
+    snp_every > 0 the graph also holds the alternative allele of one SNP per that many bases (bench.py: 200 000 SNP windows in 98
+    Mbp, one per 490 bp), i.e. bubbles the extensions fork at"""
+    rng = random.Random(seed)
+    G = rand_seq(rng, genome_len)
+    seqs = [G]
+    if snp_every:
+        for p in range(k + rng.randrange(snp_every), genome_len - k, snp_every):
+            alt = rng.choice([c for c in "ACGT" if c != G[p]])
+            seqs.append(G[p - k + 1:p] + alt + G[p + 1:p + k])
+    g = orc.Graph.build(k, seqs, 0, False)
+    reads = []
+    for _ in range(n_reads):
+        if rng.random() < 0.05:
+            reads.append(rand_seq(rng, read_len))
+            continue
+        p = rng.randrange(0, len(G) - read_len - 10)
+        out = []
+        for c in G[p:p + read_len + 5]:
+            x = rng.random()
+            if x < 0.01:
+                out.append(rng.choice([b for b in "ACGT" if b != c]))
+            elif x < 0.0105:
+                continue
+            elif x < 0.011:
+                out.append(c)
+                out.append(rng.choice("ACGT"))
+            else:
+                out.append(c)
+        r = "".join(out)[:read_len]
+        reads.append(rc(r) if rng.random() < 0.5 else r)
+    return g, reads
+
+
+@pytest.mark.parametrize("snp_every", [0, 490, 60])
+def test_bench_like_reads_mostly_finish_in_the_lane_path(snp_every):
+    g, reads = bench_like_world(1 + snp_every, 1500, snp_every=snp_every)
+    r = run_both(g, capi.config_cli(31), reads)
+    ran, done = r.lane_stats()
+    assert ran and done > (0.7 if snp_every != 60 else 0.4) * len(reads), (done, r.lane_bails())
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_worlds_through_the_lane_path(seed):
+    rng = random.Random(1000 + seed)
+    k = rng.choice([9, 11, 15, 21, 31])
+    g, reads = make_world(1000 + seed, k, genome_len=rng.choice([600, 3000, 9000]), n_reads=150, read_len=rng.choice([60, 100, 150]),
+                          n_variants=rng.choice([0, 5, 40]), mask=seed % 4 == 3)
+    reads = [mutate(rng, x, sub=0.03, ins=0.01, dele=0.01) if i % 3 == 0 else x for i, x in enumerate(reads)]
+    reads += ["", "ACGT", "N" * 80, "A" * 90, reads[0][:40]]
+    cfg = capi.config_cli(k)
+    if seed % 2:
+        cfg.min_exact_match = 0.0
+    r = run_both(g, cfg, reads)
+    assert r.lane_stats()[0]
+
+
+@pytest.mark.parametrize("variant", ["forward_only", "end_bonus", "sub_k", "edit_distance", "xdrop_wide", "left_trim_off", "noisy"])
+def test_configurations_through_the_lane_path(variant):
+    g, reads = make_world(77, 21, genome_len=5000, n_reads=160, read_len=120, n_variants=15)
+    cfg = capi.config_cli(21)
+    if variant == "forward_only":
+        cfg.forward_and_reverse_complement = 0
+        cfg.min_exact_match = 0.0
+    elif variant == "end_bonus":
+        cfg.left_end_bonus = 3
+        cfg.right_end_bonus = 4
+    elif variant == "sub_k":
+        cfg.min_seed_length = 13
+        cfg.min_exact_match = 0.0
+    elif variant == "edit_distance":
+        capi.set_unit_matrix(cfg, 1)
+        cfg.gap_opening_penalty = -1
+        cfg.gap_extension_penalty = -1
+    elif variant == "xdrop_wide":
+        cfg.xdrop = 60
+    elif variant == "left_trim_off":
+        cfg.allow_left_trim = 0
+    elif variant == "noisy":
+        reads = noisy_reads(3, reads)
+    r = run_both(g, cfg, reads)
+    assert r.lane_stats()[0]
+
+
+def test_cycles_and_repeats_leave_the_lane_path():
+    """a tandem repeat: the extension walks a cycle of the graph, i.e. meets nodes it has seen before"""
+    rng = random.Random(5)
+    unit = rand_seq(rng, 25)
+    genome = rand_seq(rng, 300) + unit * 8 + rand_seq(rng, 300)
+    g = orc.Graph.build(15, [genome], 0, False)
+    reads = [genome[p:p + 120] for p in range(200, 420, 7)]
+    r = run_both(g, capi.config_cli(15), reads)
+    assert r.lane_stats()[0] and r.lane_bails()
+
+
+def test_the_lane_path_is_not_taken_where_it_would_not_be_exact():
+    g, reads = make_world(78, 15, genome_len=2000, n_reads=30)
+    cfg = capi.config_cli(15)
+    cfg.num_alternative_paths = 2
+    assert not run_both(g, cfg, reads).lane_stats()[0]
+    cfg = capi.config_cli(15)
+    cfg.left_end_bonus = -1
+    assert not run_both(g, cfg, reads).lane_stats()[0]

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--lanes", default="")
     ap.add_argument("--verbose", action="store_true", help="print every world before it runs (to find a slow or hanging one)")
     ap.add_argument("--modes", default="0,0,1,2,2", help="graph modes to draw from (0 BASIC, 1 CANONICAL, 2 PRIMARY)")
+    ap.add_argument("--lane", action="store_true", help="campaign of the lane-per-read path: BASIC graphs, k <= 32, one alignment per "
+                    "query, the split pipeline with MGX_EMU_LANE=1, short reads, more reads per world, scoring variants")
     args = ap.parse_args()
     if args.lanes in ("8", "16"):
         os.environ["MGX_EMU_WAVE"] = args.lanes
@@ -33,12 +35,16 @@ def main():
     t_end = time.time() + 60 * args.minutes
     it = 0
     n_reads_total = 0
+    n_lane_total = 0
     while time.time() < t_end:
         seed = args.seed * 1000003 + it
         rng = random.Random(seed)
         it += 1
         mode = rng.choice([int(m) for m in args.modes.split(",")])
         k = rng.choice([5, 6, 7, 8, 11, 12, 15, 19, 20, 27, 31, 32, 33, 40, 64])
+        if args.lane:
+            mode = 0
+            k = rng.choice([7, 8, 11, 12, 15, 19, 20, 27, 31, 32])
         mask = rng.random() < 0.4
         glen = rng.choice([300, 1000, 3000, 6000])
         genome = rand_seq(rng, glen)
@@ -70,6 +76,15 @@ def main():
         cfg.max_num_seeds_per_locus = rng.choice([1, 2, 1000])
         cfg.xdrop = rng.choice([10, 27, 27, 50])
         cfg.num_alternative_paths = rng.choice([1, 1, 1, 2, 3])
+        if args.lane:
+            cfg.num_alternative_paths = 1
+            cfg.xdrop = rng.choice([10, 27, 27, 50, 80])
+            if rng.random() < 0.3:
+                cfg.left_end_bonus, cfg.right_end_bonus = rng.choice([0, 2, 5]), rng.choice([0, 3, 5])
+            if rng.random() < 0.2:
+                cfg.allow_left_trim = 0
+            if rng.random() < 0.2:
+                cfg.min_path_score = rng.choice([20, 60, 150])
         cfg.forward_and_reverse_complement = rng.choice([0, 1, 1])
         if rng.random() < 0.3:
             capi.set_dna_matrix(cfg, 2, -rng.choice([1, 3]), -rng.choice([2, 3]))
@@ -77,8 +92,10 @@ def main():
         cfg.seed_complexity_filter = rng.choice([0, 1])
         cfg.max_nodes_per_seq_char = rng.choice([5.0, 12.5, 50.0])
         reads = []
-        for i in range(rng.choice([5, 20])):
+        for i in range(rng.choice([5, 20]) if not args.lane else rng.choice([20, 80])):
             L = rng.choice([k - 1, k, k + 3, 40, 100, 150, 150, 400, 1200])      # long reads: wide bands, many seeds, long chains
+            if args.lane:
+                L = rng.choice([k, k + 3, 40, 75, 100, 150, 150, 150, 250, 256, 257])
             if k < 11 and L > 150:
                 L = 150                                          # (tiny k x long reads: thousands of extensions per read, minutes per world)
             L = max(1, min(L, len(genome) - 1))
@@ -106,6 +123,12 @@ def main():
                     os.environ["MGX_EMU_RESUME_CAP"] = str(rng.choice([1, 2, 5]))      # resume-record pool smaller than the batch
         if rng.random() < 0.15:
             os.environ["MGX_NO_FAST"] = "1"
+        os.environ.pop("MGX_EMU_LANE", None)
+        if args.lane:
+            os.environ.pop("MGX_NO_FAST", None)
+            os.environ.pop("MGX_EMU_MULTIPASS", None)
+            os.environ["MGX_EMU_SPLIT"] = "1"
+            os.environ["MGX_EMU_LANE"] = "1"
         desc = dict(seed=seed, mode=mode, k=k, mask=mask, glen=len(genome), n_seqs=len(seqs), msl=cfg.min_seed_length,
                     maxsl=cfg.max_seed_length, per_locus=cfg.max_num_seeds_per_locus, xdrop=cfg.xdrop, n_alt=cfg.num_alternative_paths,
                     fwd_rc=cfg.forward_and_reverse_complement, mem=cfg.min_exact_match,
@@ -114,7 +137,9 @@ def main():
             print(desc, [len(r) for r in reads], flush=True)
         try:
             t_w = time.time()
-            o = orc.AlignRun(g, cfg, reads)
+            # (end bonuses: the reference's own Alignment::is_valid — a debug assertion there — rejects some alignments it
+            # produces; the comparison is against what it produces)
+            o = orc.AlignRun(g, cfg, reads, validate=not (cfg.left_end_bonus or cfg.right_end_bonus))
             if args.verbose:
                 print('  oracle %.1fs' % (time.time() - t_w), flush=True)
             if o.error:
@@ -135,11 +160,13 @@ def main():
                         assert info[q]["num_matches"][strand] == nm, ("num_matches", q, strand, reads[q])
                         assert info[q]["seeds"][strand] == emu_drv.oracle_seeds_as_tuples(ss), ("seeds", q, strand, reads[q])
             n_reads_total += len(reads)
+            if args.lane:
+                n_lane_total += e.lane_stats()[1]
         except AssertionError as ex:
             print("MISMATCH", desc)
             print(str(ex)[:3000])
             sys.exit(1)
-    print("ok: %d worlds, %d reads, no difference" % (it, n_reads_total))
+    print("ok: %d worlds, %d reads, no difference" % (it, n_reads_total) + (" (%d reads finished by the lane path)" % n_lane_total if args.lane else ""))
 
 
 if __name__ == "__main__":

@@ -59,6 +59,7 @@ __global__ void __launch_bounds__(64, WPS) k_lane_chain(const uint8_t *reads, ui
         }
         for (int col = 0; col < L; ++col) {
             LaneColumnIn in;
+            in.band_given = 0; in.band_begin = in.band_prev_end = 0;
             in.p_org = p_org; in.p_trim = p_trim; in.p_size = p_size;
             in.xdrop_cutoff = cutoff; in.start = 0; in.window_size = L; in.qlen = L; in.go = go; in.ge = ge;
             in.next_offset = col + 1; in.score = 0; in.in_seed = false;
