@@ -40,11 +40,11 @@ struct LaneChip {
 // the register file (the kernel was at 250+ VGPRs and spilling with all of it in registers).  Accessed as plain variables through
 // the macros below.
 enum { CD_B_SCORE, CD_B_NOD, CD_B_I, CD_B_POS, CD_T_SCORE, CD_T_NOD, CD_T_POS,
-       CD_FA_ALIVE, CD_FA_CONV, CD_FA_ORG, CD_FA_TRIM, CD_FA_SIZE, CD_FA_OFFSET, CD_FA_MAX, CD_FA_IDX, CD_FA_TS, CD_FA_TN, CD_FA_TP, CD_FA_NODE,
+       CD_FA_ALIVE, CD_FA_CONV, CD_FA_MAX,
        CD_D_SCORE0, CD_D_SCORE1, CD_D_SCORE2, CD_D_MAX0, CD_D_MAX1, CD_D_MAX2,
        CD_KID_N0, CD_KID_C0, CD_KID_N1, CD_KID_C1,
        CD_TABLE_CAP, CD_TSB_LO, CD_TSB_HI, CD_CELL_TOP, CD_NCOLS, CD_F_NODE, CD_F_IDX, CD_F_MAX,
-       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_ROOT_PUSHES, CD_CTR_RANK, CD_CTR_SEL,
+       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_ROOT_PUSHES, CD_CTR_RANK, CD_CTR_SEL, CD_FWD_N_NODES, CD_FWD_N_SEQ, CD_STRAND, CD_HAVE_ALN, CD_MODE, CD_CLIP, CD_L, CD_NSEEDS, CD_NEXT,
        LANE_COLD_WORDS };
 static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 #define LANE_CI(f) (*(int32_t *)(chip.cold + (f) * chip.cstride))
@@ -52,8 +52,10 @@ static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 // hides where a value came from: what is computed from it afterwards is computed again, not kept in registers across the column loop
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LANE_OPAQUE(x) asm volatile("" : "+v"(x))
+#define LANE_OPAQUE_PTR(p) asm volatile("" : "+v"(p))
 #else
 #define LANE_OPAQUE(x) ((void)0)
+#define LANE_OPAQUE_PTR(p) ((void)0)
 #endif
 
 // profile scores over the packed strand (see LaneProfBytes)
@@ -75,10 +77,53 @@ struct LaneProfPacked {
     }
 };
 
-enum { LR_DONE = 0, LR_BAIL = 1 };
+enum { LR_DONE = 0, LR_BAIL = 1, LR_AGAIN = 2 };      // LR_AGAIN: call again for the same read with pass = 1 (the backward pass)
 
-struct LaneCounters { uint32_t rank_lines, select_lines, columns, reason; };     // reason: which test sent the read to the group kernel
+struct LaneCounters { uint32_t reason; };     // reason: which test sent the read to the group kernel
 #define LANE_BAIL(code) do { ctr.reason = (code); return LR_BAIL; } while (0)
+
+// the children of `v` on the reverse-complement view of the graph (RCDBG::call_outgoing_kmers, rc_dbg.hpp:88-99): the parents of
+// v with the complement of the first character of their k-mers (BOSS::call_incoming_to_target boss.cpp:766-786 through
+// NodeFirstCache, node_first_cache.cpp:38-52; dev_graph.hpp incoming() without its arrays); a '$' first character is dropped
+// (aligner_extender_methods.cpp:381-384).  Same return convention as lane_children.
+MGX_DEV int lane_parents(const DevGraph &g, uint32_t vv, uint32_t &n0, uint32_t &c0, uint32_t &n1, uint32_t &c1, const LaneChip &chip) {
+    LineCtr lc = { 0, 0, 0 };
+    const uint64_t v = vv;
+    int n = 0;
+    auto add = [&](uint64_t e) {
+        const uint32_t cc = first_char(g, e, lc);
+        if (cc == 0) return;
+        if (n == 0) { n0 = (uint32_t)e; c0 = 5u - cc; } else if (n == 1) { n1 = (uint32_t)e; c1 = 5u - cc; }
+        ++n;
+    };
+    const uint64_t x = bwd(g, v, lc);
+    const uint32_t d = node_last_value(g, v);
+    if (in_graph(g, x)) add(x);
+    // edges after x labelled d + SIGMA, up to the next unflagged d
+    uint64_t pos = x + 1;
+    uint32_t bi = (uint32_t)(pos >> 6);
+    while (pos <= g.n) {
+        ++lc.rank_lines;
+        const Block b = load_block(g, bi);
+        const uint64_t from = ~(mask_upto((int)(pos & 63)) >> 1);          // bits >= pos & 63
+        uint64_t cm = code_mask(b, d) & from;
+        if (bi == g.n_blocks - 1 && ((g.n + 1) & 63)) cm &= mask_upto((int)(g.n & 63));
+        const uint64_t stop = cm & ~b.pf;
+        uint64_t flg = cm & b.pf;
+        if (stop) flg &= mask_upto(ctz64(stop));
+        while (flg) {
+            const int j = ctz64(flg);
+            flg &= flg - 1;
+            const uint64_t e = ((uint64_t)bi << 6) + (uint32_t)j;
+            if (in_graph(g, e)) add(e);
+        }
+        if (stop) break;
+        ++bi;
+        pos = (uint64_t)bi << 6;
+    }
+    LANE_CU(CD_CTR_RANK) += lc.rank_lines + lc.bit_lines; LANE_CU(CD_CTR_SEL) += lc.select_lines;
+    return n > 2 ? 3 : n;
+}
 
 // a global store the compiler will not merge with its neighbours
 MGX_DEV void lane_store_single(uint32_t *p, uint32_t v) {
@@ -140,10 +185,22 @@ MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t &n0, uint32_t
     return n > 2 ? 3 : n;
 }
 
+// where the alignment lane_emit() writes out lives: the column slots of the (only) extension, walked down the parent links; the
+// path arrays the forward alignment was moved to when a backward pass followed; or the slots of the backward extension, whose
+// reversal (Alignment::reverse_complement) is what a walk down the parent links yields anyway
+enum { LANE_EMIT_SLOTS = 0, LANE_EMIT_ARRAYS = 1, LANE_EMIT_SLOTS_REVERSED = 2 };
+
+// the lane's record in its scratch slice (lane_read's arec): words 26 .. 31 are counters that outlive a read — columns, rank-type
+// lines, select-type lines, reads finished, extensions, capacity statuses
+MGX_DEV uint32_t *lane_record(const LaneParams &LP, uint8_t *scratch) {
+    return (uint32_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8) + 4 * LFW
+           + 2 * LP.max_cols + LANE_MAX_RUNS;
+}
+
 // what lane_read() leaves for lane_emit(): the result record and where the alignment's pieces are
 struct LaneResult {
     ReadResult rr;
-    int32_t have_aln;
+    int32_t have_aln, mode;              // mode: where lane_emit() finds the alignment (LANE_EMIT_*)
     int32_t score, offset, clip, end_clip, n_runs, j_hi, n_nodes, n_seq, trim, strand;      // j_hi: last column of the path; trim: nodes trim_offset dropped
     uint32_t words;                      // words of the output stream the alignment takes
 };
@@ -159,16 +216,7 @@ struct LaneResult {
 #define t_pos LANE_CI(CD_T_POS)
 #define fa_alive LANE_CI(CD_FA_ALIVE)
 #define fa_conv LANE_CI(CD_FA_CONV)
-#define fa_org LANE_CI(CD_FA_ORG)
-#define fa_trim LANE_CI(CD_FA_TRIM)
-#define fa_size LANE_CI(CD_FA_SIZE)
-#define fa_offset LANE_CI(CD_FA_OFFSET)
 #define fa_max_val LANE_CI(CD_FA_MAX)
-#define fa_idx LANE_CI(CD_FA_IDX)
-#define fa_t_score LANE_CI(CD_FA_TS)
-#define fa_t_nod LANE_CI(CD_FA_TN)
-#define fa_t_pos LANE_CI(CD_FA_TP)
-#define fa_node LANE_CU(CD_FA_NODE)
 #define d_score(t) LANE_CI(CD_D_SCORE0 + (t))
 #define d_max(t) LANE_CI(CD_D_MAX0 + (t))
 #define kid_node0 LANE_CU(CD_KID_N0)
@@ -184,7 +232,8 @@ struct LaneResult {
 #define f_node LANE_CU(CD_F_NODE)
 #define f_idx LANE_CI(CD_F_IDX)
 #define f_max_val LANE_CI(CD_F_MAX)
-MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, uint8_t *scratch, const LaneChip &chip,
+// pass: 0 = a new read; 1 = the backward pass of the read whose call with pass 0 returned LR_AGAIN (same lane, nothing in between).
+MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, const int pass, uint8_t *scratch, const LaneChip &chip,
                       LaneCounters &ctr, LaneResult &R) {
     const AlignParams &P = LP.P;
     const DevConfig &cfg = P.cfg;
@@ -194,15 +243,24 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
     const int32_t m = LP.self_score;
     const bool have_rc = cfg.fwd_and_rc != 0;
     uint8_t *slots = scratch;
-    // (the other arrays of the scratch slice: addressed from its base where they are used, not held in registers)
-    auto s8rows = [&]() -> uint8_t * { return scratch + (uint64_t)LP.max_cols * LANE_SLOT_BYTES; };
-    auto htab = [&]() -> uint64_t * { return (uint64_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES)); };
-    auto save_p = [&]() -> uint32_t * { return (uint32_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8); };
+    // The other arrays of the scratch slice are addressed from its base WHERE THEY ARE USED: left to itself the compiler hoists
+    // every one of these address computations out of the column loop and keeps a dozen 64-bit pointers in registers across it.
+    auto sbase = [&]() -> uint8_t * { uint8_t *b = scratch; LANE_OPAQUE_PTR(b); return b; };
+    auto s8rows = [&]() -> uint8_t * { return sbase() + (uint64_t)LP.max_cols * LANE_SLOT_BYTES; };
+    auto htab = [&]() -> uint64_t * { return (uint64_t *)(sbase() + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES)); };
+    auto save_p = [&]() -> uint32_t * { return (uint32_t *)(sbase() + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8); };
     auto save_a = [&]() -> uint32_t * { return save_p() + 2 * LFW; };
+    auto pa_node = [&]() -> uint32_t * { return save_p() + 4 * LFW; };            // the forward alignment's nodes and character codes,
+    auto pa_code = [&]() -> uint32_t * { return pa_node() + LP.max_cols; };       // in path order (the seed of the backward pass)
+    auto runs_fwd = [&]() -> uint32_t * { return pa_code() + LP.max_cols; };      // ... and its CIGAR runs
+    // the alignment found so far, as the output needs it (written once per pass, read at the end: memory, not registers):
+    // [0 .. 8) score, offset, clip, end clip, runs, last column, nodes, characters; [8 .. 12) the forward alignment while the
+    // backward pass runs: in the aggregator?, score, clip, end clip; [16 .. 25) the parked child of a fork; [26 .. 32) counters
+    auto arec = [&]() -> uint32_t * { return runs_fwd() + LANE_MAX_RUNS; };
     // ---- the read and its seeds (flat_read_begin).  What is derived from the seed header here is derived again after the
     // extension, where the later seeds and the result need it: nothing of it is live across the column loop.
-    int32_t L, n, s;
-    {
+    int32_t L, n;
+    if (!pass) {
         const uint64_t off = gld(P.offsets + read);
         L = (int32_t)(gld(P.offsets + read + 1) - off);
         if (L > (int32_t)lim.Lmax || L > LANE_MAX_L) LANE_BAIL(1);
@@ -212,37 +270,41 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         const int32_t ns0 = (int32_t)gld(&hp->n_seeds[0]), ns1 = (int32_t)gld(&hp->n_seeds[1]);
         // align_both_directions (:738-755): the strand with more matches; the other one only if it is within rel_score_cutoff
         const int first = nm0 >= nm1 ? 0 : 1;
-        s = have_rc ? first : 0;
+        const int s = have_rc ? first : 0;
         if (have_rc) {
             const uint32_t m_first = first ? nm1 : nm0, m_second = first ? nm0 : nm1;
             const int32_t n_second = first ? ns0 : ns1;
             if ((double)m_second >= (double)m_first * cfg.rel_score_cutoff && n_second > 0) LANE_BAIL(3);     // a second strand to align
         }
         n = s ? ns1 : ns0;
+        // the result: which alignment (LaneResult::mode) and its scalars
+        LANE_CI(CD_HAVE_ALN) = 0; LANE_CI(CD_MODE) = 0; LANE_CI(CD_STRAND) = s; LANE_CI(CD_L) = L; LANE_CI(CD_NSEEDS) = n;
+        cols_done = 0;
+        LANE_CU(CD_CTR_RANK) = 0; LANE_CU(CD_CTR_SEL) = 0;
+    } else {
+        L = LANE_CI(CD_L); n = LANE_CI(CD_NSEEDS);
     }
-    int32_t n_extensions = 0;
-    bool have_aln = false;
-    // the alignment, as far as the output needs it
-    int32_t a_score = 0, a_offset = 0, a_clip = 0, a_end_clip = 0, a_n_runs = 0;
-    int32_t a_j_hi = 0, a_n_nodes = 0, a_n_seq = 0;
-    cols_done = 0;
-    LANE_CU(CD_CTR_RANK) = 0; LANE_CU(CD_CTR_SEL) = 0;
+    const int32_t n_extensions = n > 0 ? pass + 1 : 0;
     if (n > 0) {
         if (n > LANE_MAX_SEEDS) LANE_BAIL(4);
         auto qcode = [&](int32_t qi) -> uint32_t { return (uint32_t)(chip.qw[(qi >> 5) * chip.qstride] >> (2 * (qi & 31))) & 3u; };
-        int32_t clipping;
-        {
-            // the strand: 2-bit packed by k_pack_reads; any character outside ACGT (psum_lin == 0) is not for this kernel
+        // the strand of a pass: 2-bit packed by k_pack_reads; any character outside ACGT (psum_lin == 0) is not for this kernel
+        auto load_strand = [&](int strand) -> bool {
             const uint64_t off = gld(P.offsets + read);
             const uint64_t wb = packed_word_begin(off, read);
             const int32_t nw = (L + 31) >> 5;
             uint32_t any_inv = 0;
             for (int32_t j = 0; j < LANE_QWORDS; ++j) {
                 uint64_t v = 0;
-                if (j < nw) { v = gld(LP.pk[s] + wb + j); any_inv |= gld(LP.iv[s] + wb + j); }
+                if (j < nw) { v = gld(LP.pk[strand] + wb + j); any_inv |= gld(LP.iv[strand] + wb + j); }
                 chip.qw[j * chip.qstride] = v;
             }
-            if (any_inv) LANE_BAIL(5);
+            return any_inv == 0;
+        };
+        int32_t clipping;
+        if (!pass) {
+            const int s = LANE_CI(CD_STRAND);
+            if (!load_strand(s)) LANE_BAIL(5);
             // ---- seed 0 (seedref_from_seed) ----
             const SeedHdr *hp = P.seed_hdr + read;
             const DevSeed *s0 = P.seed_stream + gld(&hp->off) + (s ? (int32_t)gld(&hp->n_seeds[0]) : 0);
@@ -252,20 +314,40 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             const uint32_t node0 = seed_off == 0 ? gld(rnodes + clipping) : gld(&s0->node);
             if (node0 == 0) LANE_BAIL(6);
             LANE_CI(CD_SEED_LEN) = seed_len; LANE_CI(CD_SEED_OFF) = seed_off; LANE_CU(CD_NODE0) = node0;
+        } else {
+            clipping = LANE_CI(CD_CLIP);            // (the seed of the backward pass and its strand: set up when pass 0 ended)
         }
 #define c_seed_len LANE_CI(CD_SEED_LEN)
 #define c_seed_off LANE_CI(CD_SEED_OFF)
 #define c_node0 LANE_CU(CD_NODE0)
-        // ---- extend_begin (:412-470): set_seed, the root column ----
+#define c_fwd_n_nodes LANE_CI(CD_FWD_N_NODES)
+#define c_fwd_n_seq LANE_CI(CD_FWD_N_SEQ)
         const int32_t xdrop = cfg.xdrop;
+        const uint32_t tag = ((LP.tag_seed + item) * 0x9E3779B1u >> 12) | 1u;              // 20 bits, never 0
+        const uint32_t hmask = LP.hash_slots - 1;
+        // the forward alignment while the backward pass runs (pass 1), for the aggregator's choice at the end
+        // Pass 0: the seed, forward on the graph.  Pass 1 (aln_both :683-736, when the forward alignment starts inside the query):
+        // its reversal as the seed (force_fixed_seed), on the other strand of the query and the reverse-complement view of the
+        // graph.  One call of this function per pass (the caller keeps the lane on its read), so that the column pass exists once
+        // in the kernel and nothing of a pass is live across the other's column loop.
+        do {
+        // ---- extend_begin (:412-470): set_seed, the root column ----
         int32_t xdrop_cutoff = imax(-xdrop, NINF + 1);
         const int32_t start = clipping, window_size = L - start, qlen = L;
         const int32_t last_pos = window_size;
-        const int32_t min_start_score = have_rc ? imax(0, cfg.min_cell_score) : imax(0, cfg.min_path_score);
+        // extend() / backtrack's min_path_score: aln_both passes max(0, min_cell_score) forward, get_min_path_score backward
+        // (the aggregator holds the forward alignment by then); align_core without a reverse strand: get_min_path_score
+        int32_t min_start_score = have_rc ? imax(0, cfg.min_cell_score) : imax(0, cfg.min_path_score);
+        if (pass) {
+            const int32_t fw_added = (int32_t)gld(arec() + 8), fw_score = (int32_t)gld(arec() + 9);
+            const int32_t gcut = !fw_added ? NINF : (fw_score > 0 ? (int32_t)((double)fw_score * cfg.rel_score_cutoff) : fw_score);
+            min_start_score = imax(0, imax(cfg.min_path_score, gcut));
+        }
+        const uint32_t ptag = pass ? (((tag ^ 0x5A5A5u) & 0xFFFFFu) | 1u) : tag;
         int32_t tsize = 1;
         int32_t min_cell_score = 0, best_score = 0;
         int32_t S[LFW], F[LFW];
-        int32_t f_org = 0, f_trim = 0, f_size, f_offset = c_seed_off - 1;
+        int32_t f_org = 0, f_trim = 0, f_size, f_offset;
         {
             const int32_t sroot = (cfg.left_end_bonus && !clipping) ? cfg.left_end_bonus : 0;
             int32_t root_pushes = 0;
@@ -280,10 +362,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             const int32_t root_size = 1 + root_pushes;
             LANE_CI(CD_ROOT_PUSHES) = root_pushes;
             if ((uint64_t)rec_words((uint32_t)root_size + 8) > lim.cell_words) LANE_BAIL(8);
+            // (the table of a strand's extender keeps its capacity between extensions; a read's two passes use two extenders)
             table_cap = 1;
             const uint64_t tsb0 = (uint64_t)136 * 1 + (uint64_t)(3 * ref_capacity(1, (uint32_t)root_pushes)) * 4;
             tsb_lo = (uint32_t)tsb0; tsb_hi = (uint32_t)(tsb0 >> 32);
-            n_extensions = 1;
             // the root leaves the frontier and enters the chain window (extend_step: fast_fits + fast_load)
             if (root_size + 3 > LFW) LANE_BAIL(9);
 #pragma unroll
@@ -292,6 +374,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 F[x] = NINF;
             }
             f_size = root_size;
+            f_offset = c_seed_off - 1;
             f_max_val = sroot; f_idx = 0; f_node = c_node0;
             cell_top = rec_words((uint32_t)((root_size + 5 + 3) & ~3));
         }
@@ -303,8 +386,6 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             const bool better = sc != bs ? sc > bs : (nod != bn ? nod > bn : (-i != -bi ? -i > -bi : pos > bp));
             if (bs == INT32_MIN || better) { b_score = sc; b_nod = nod; b_i = i; b_pos = pos; }
         };
-        const uint32_t tag = ((LP.tag_seed + item) * 0x9E3779B1u >> 12) | 1u;              // 20 bits, never 0
-        const uint32_t hmask = LP.hash_slots - 1;
         LaneProfPacked prof;
         prof.qw = chip.qw; prof.qstride = chip.qstride; prof.qlen = qlen; prof.rowp = 0; prof.w = 0;
         // ---- the extension (extend_step): chain steps along the head column, a general step where the graph forks ----
@@ -318,8 +399,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         kid_node0 = 0; kid_code0 = 0; kid_node1 = 0; kid_code1 = 0;
         int n_kids = 0, kid = 0;
         // the first child of a fork, parked while the second is computed (its window in the lane's scratch)
-        fa_alive = 0; fa_conv = 0; fa_org = 0; fa_trim = 0; fa_size = 0; fa_offset = 0; fa_max_val = 0; fa_idx = 0;
-        fa_t_score = INT32_MIN; fa_t_nod = 0; fa_t_pos = 0; fa_node = 0;
+        fa_alive = 0; fa_conv = 0; fa_max_val = 0;
         // (one dword per store, on purpose: merged into 16-byte stores they want four consecutive registers each, and pinning
         // the window to such tuples made the allocator spill 600+ registers around the column pass; forks are rare)
         auto win_save = [&](uint32_t *dst) {
@@ -356,11 +436,24 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     head_dead = hd_prev_end <= hd_begin;
                     if (!head_dead) {
                         const int32_t no = f_offset + 1, sp = no - c_seed_off;
-                        if (sp >= 0 && sp < c_seed_len && no < k) {
-                            kid_node0 = c_node0; kid_code0 = qcode(clipping + sp) + 1; n_kids = 1;  // the seed's first node, its spelling
+                        if (sp >= 0 && sp < c_seed_len && (no < k || pass)) {
+                            if (!pass) {
+                                kid_node0 = c_node0; kid_code0 = qcode(clipping + sp) + 1;   // the seed's first node, its spelling
+                            } else {
+                                // force_fixed_seed (:344-372): the reversed forward alignment, node by node — its spelling is
+                                // the complement of the path's, read backwards (A <-> T, C <-> G: code 5 - c)
+                                const int32_t fn = c_fwd_n_nodes, fq = c_fwd_n_seq;
+                                kid_code0 = 5u - gld(pa_code() + (fq - 1 - sp));
+                                kid_node0 = gld(pa_node() + (fn - 1 - imax(0, no - k + 1)));
+                                // (the columns of the first node merge convergence vectors; that is decided without the
+                                // vectors only while the replayed characters are the query's own, see below)
+                                if (no < k && qcode(clipping + sp) + 1 != kid_code0) LANE_BAIL(30);
+                            }
+                            n_kids = 1;
                         } else {
                             uint32_t kn0 = 0, kc0 = 0, kn1 = 0, kc1 = 0;
-                            const int nc = lane_children(P.g, f_node, kn0, kc0, kn1, kc1, chip);
+                            const int nc = pass ? lane_parents(P.g, f_node, kn0, kc0, kn1, kc1, chip)
+                                                : lane_children(P.g, f_node, kn0, kc0, kn1, kc1, chip);
                             if (nc > 2) LANE_BAIL(10);                                 // more than two children
                             kid_node0 = kn0; kid_code0 = kc0; kid_node1 = kn1; kid_code1 = kc1;
                             if (nc == 0) {                                             // a tip: its start cell counts after all
@@ -404,7 +497,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 // earlier column (fewer graph characters, hence at most sroot + (t' + 1) m) left at its query position.  (Needs
                 // m > 0 >= gaps, mismatches <= m, sroot >= 0, 0 <= rel_score_cutoff <= 1: checked before the kernel is launched.)
                 // The vector itself is never needed: a later seed ending in that node, or the graph leading back to it, bails.
-                const bool replay = in_seed && next_offset < k;
+                const bool replay = in_seed && next_offset < k;      // (columns of the seed's first node)
                 const bool probe = !replay || f_offset == seed_off - 1;
                 uint32_t hs = lane_hash(next, hmask);
                 uint64_t he = probe ? gld(htab() + hs) : 0;
@@ -431,12 +524,12 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     const int32_t my_idx = tsize;
                     if (probe) {
                         for (;;) {
-                            if ((uint32_t)(he >> 44) != tag) break;                    // free (or left by another read)
+                            if ((uint32_t)(he >> 44) != ptag) break;                   // free (or left by another read / pass)
                             if ((uint32_t)he == next) LANE_BAIL(15);                 // seen before
                             hs = (hs + 1) & hmask;
                             he = gld(htab() + hs);
                         }
-                        gst(htab() + hs, (uint64_t)next | ((uint64_t)tag << 44) | ((uint64_t)(uint32_t)my_idx << 32));
+                        gst(htab() + hs, (uint64_t)next | ((uint64_t)ptag << 44) | ((uint64_t)(uint32_t)my_idx << 32));
                     }
                     // (replay columns: see above; the column's own maximum stands in for the merged score, ninf neither way)
                     const int32_t converged = out.converged;
@@ -507,8 +600,11 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             if (!ext_over) {
                 if (compute && forked && kid == 0) {
                     // the first child of a fork waits (window in scratch) while the second is computed from the same parent
-                    fa_alive = c_alive; fa_conv = c_conv; fa_org = c_org; fa_trim = c_trim; fa_size = c_size; fa_offset = next_offset;
-                    fa_max_val = c_max_val; fa_idx = c_idx; fa_node = c_node; fa_t_score = c_t_score; fa_t_nod = c_t_nod; fa_t_pos = c_t_pos;
+                    fa_alive = c_alive; fa_conv = c_conv; fa_max_val = c_max_val;
+                    // (the rest of the parked child: to the lane's scratch, next to its window)
+                    gst(arec() + 16, (uint32_t)c_org); gst(arec() + 17, (uint32_t)c_trim); gst(arec() + 18, (uint32_t)c_size);
+                    gst(arec() + 19, (uint32_t)next_offset); gst(arec() + 20, (uint32_t)c_idx); gst(arec() + 21, (uint32_t)c_t_score);
+                    gst(arec() + 22, (uint32_t)c_t_nod); gst(arec() + 23, (uint32_t)c_t_pos); gst(arec() + 24, c_node);
                     if (c_alive) win_save(save_a());
                     kid = 1;
                     reload = true; reload_parked = false;
@@ -556,8 +652,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 }
                                 if (a_top) {
                                     reload = true; reload_parked = true;               // its window comes back at the top of the loop
-                                    f_org = fa_org; f_trim = fa_trim; f_size = fa_size; f_offset = fa_offset; f_max_val = fa_max_val;
-                                    f_node = fa_node; f_idx = fa_idx; t_score = fa_t_score; t_nod = fa_t_nod; t_pos = fa_t_pos;
+                                    f_org = (int32_t)gld(arec() + 16); f_trim = (int32_t)gld(arec() + 17); f_size = (int32_t)gld(arec() + 18);
+                                    f_offset = (int32_t)gld(arec() + 19); f_max_val = fa_max_val;
+                                    f_node = gld(arec() + 24); f_idx = (int32_t)gld(arec() + 20); t_score = (int32_t)gld(arec() + 21);
+                                    t_nod = (int32_t)gld(arec() + 22); t_pos = (int32_t)gld(arec() + 23);
                                 } else {
                                     f_org = c_org; f_trim = c_trim; f_size = c_size; f_offset = next_offset; f_max_val = c_max_val;
                                     f_node = c_node; f_idx = c_idx; t_score = c_t_score; t_nod = c_t_nod; t_pos = c_t_pos;
@@ -590,14 +688,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 }
             }
         }
-        ctr.columns += (uint32_t)cols_done;
         // ---- after the extension: everything below is derived afresh from the read's index and the lane's cold state ----
         LANE_OPAQUE(read);
         const int32_t seed_off = c_seed_off, seed_len = c_seed_len;
         const uint32_t node0 = c_node0;
-        const SeedHdr *hp2 = P.seed_hdr + read;
-        const DevSeed *seeds = P.seed_stream + gld(&hp2->off) + (s ? (int32_t)gld(&hp2->n_seeds[0]) : 0);
-        const uint32_t *rnodes = (s ? P.nodes_rc : P.nodes_fwd) + gld(P.node_begin + read);
         const int32_t sroot = (cfg.left_end_bonus && !clipping) ? cfg.left_end_bonus : 0;
         const int32_t root_pushes = LANE_CI(CD_ROOT_PUSHES), root_size = 1 + root_pushes;
         const int32_t root_ins = imax(sroot + go, NINF + ge);
@@ -605,11 +699,15 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             return pos == 0 ? sroot : (pos >= 1 && pos <= root_pushes ? root_ins + (pos - 1) * ge : NINF);
         };
         (void)seed_len;
-        // ---- backtrack (:869-1034): the best start cell, one trace ----
-        if (b_score == INT32_MIN) LANE_BAIL(18);                                  // no start cell: the seed itself would be reported
-        // ---- check_seed (:66-88) of the later seeds against this extension's convergence table: each must be dead, or there
-        // are more extensions to run.  A node's entry is its first (and only) column here: the node table gives the column, the
-        // column's S row the score at the seed's last query position.
+        if (!pass) {
+        // ---- check_seed (:66-88) of the later seeds against the forward extension's convergence table: each must be dead, or
+        // there are more extensions to run.  A node's entry is its first (and only) column here: the node table gives the column,
+        // the column's S row the score at the seed's last query position.  (Before the backward pass reuses the tables, as
+        // aln_both does.)
+        const int s = LANE_CI(CD_STRAND);
+        const SeedHdr *hp2 = P.seed_hdr + read;
+        const DevSeed *seeds = P.seed_stream + gld(&hp2->off) + (s ? (int32_t)gld(&hp2->n_seeds[0]) : 0);
+        const uint32_t *rnodes = (s ? P.nodes_rc : P.nodes_fwd) + gld(P.node_begin + read);
         for (int32_t t = 1; t < n; ++t) {
             const DevSeed *sj = seeds + t;
             const int32_t cl = (int32_t)gld(&sj->clipping), len = (int32_t)gld(&sj->length), so = (int32_t)gld(&sj->offset);
@@ -622,7 +720,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             int32_t idx = -1;
             for (;;) {
                 const uint64_t he = gld(htab() + hs);
-                if ((uint32_t)(he >> 44) != tag) break;
+                if ((uint32_t)(he >> 44) != ptag) break;
                 if ((uint32_t)he == ln) { idx = (int32_t)((he >> 32) & 0xFFFu); break; }
                 hs = (hs + 1) & hmask;
             }
@@ -642,6 +740,13 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             }
             if (v < lscore) LANE_BAIL(19);                                           // the seed lives
         }
+        }
+        // ---- backtrack (:869-1034): the best start cell, one trace.  Without a start cell the extension yields its seed
+        // (:1030-1031): forward, a case for the group kernel; backward, the reversed forward alignment — nothing new.
+        bool got = b_score != INT32_MIN;
+        if (!got && !pass) LANE_BAIL(18);
+        int32_t x_score = 0, x_offset = 0, x_clip = 0, x_end_clip = 0, x_n_runs = 0, x_j_hi = 0, x_n_nodes = 0, x_n_seq = 0;
+        if (got) {
         const int32_t k_minus_1 = k - 1;
         const int32_t min_trace_length = k - seed_off;
         const int32_t cap = (int32_t)lim.max_path;
@@ -746,23 +851,78 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                   && (cfg.allow_left_trim || !j))) LANE_BAIL(24);                 // (the next start cell would be tried)
         }
         // construct_alignment (:774-798) + trim_offset (alignment.cpp:177-190)
-        a_clip = clipping + pos;
-        a_end_clip = L - (clipping + end_pos);
-        a_score = score; a_offset = align_offset; a_n_runs = n_runs;
+        x_clip = clipping + pos;
+        x_end_clip = L - (clipping + end_pos);
+        x_score = score; x_offset = align_offset; x_n_runs = n_runs;
         // (the path: the columns the trace left by a match or a deletion, from j_start down its parent links — n_seq of them, the
         // n_path with offset >= k - 1 carry the alignment's nodes)
         (void)j_stop;
-        a_j_hi = j_start; a_n_seq = n_seq; a_n_nodes = n_path;
-        if (a_offset && a_n_nodes > 1) {
-            const int32_t trim = imin(a_offset, a_n_nodes - 1);
-            if (trim > 0) { a_n_nodes -= trim; a_offset -= trim; }
+        x_j_hi = j_start; x_n_seq = n_seq; x_n_nodes = n_path;
+        if (x_offset && x_n_nodes > 1) {
+            const int32_t trim = imin(x_offset, x_n_nodes - 1);
+            if (trim > 0) { x_n_nodes -= trim; x_offset -= trim; }
         }
-        have_aln = true;
-        // ---- aln_both after the forward pass (:683-736), no backward pass in this kernel ----
-        if (have_rc) {
-            if (a_clip && !a_offset) LANE_BAIL(26);                                // extend backwards from the reversed alignment
-            if (!(a_score >= cfg.min_path_score)) have_aln = false;                 // get_min_path_score with an empty aggregator
         }
+        if (!pass) {
+            // ---- aln_both after the forward pass (:683-736) ----
+            gst(arec() + 0, (uint32_t)x_score); gst(arec() + 1, (uint32_t)x_offset); gst(arec() + 2, (uint32_t)x_clip);
+            gst(arec() + 3, (uint32_t)x_end_clip); gst(arec() + 4, (uint32_t)x_n_runs); gst(arec() + 5, (uint32_t)x_j_hi);
+            gst(arec() + 6, (uint32_t)x_n_nodes); gst(arec() + 7, (uint32_t)x_n_seq);
+            LANE_CI(CD_HAVE_ALN) = 1; LANE_CI(CD_MODE) = LANE_EMIT_SLOTS;
+            if (!have_rc) break;
+            if (!(x_score >= cfg.min_path_score)) LANE_CI(CD_HAVE_ALN) = 0;         // get_min_path_score with an empty aggregator
+            if (!(x_clip && !x_offset)) break;                        // nothing to extend backwards
+            // The backward pass: the forward alignment, reversed (Alignment::reverse_complement :563-565 on the RCDBG view: nodes
+            // and CIGAR reversed, spelling complemented), is the seed.  Its nodes, characters and CIGAR runs move to the lane's
+            // scratch — the backward extension reuses the column slots — in path order.
+            if (!x_n_nodes) LANE_BAIL(26);
+            {
+                int32_t jj = x_j_hi, ni = x_n_nodes - 1;
+                for (int32_t xx = x_n_seq - 1; xx >= 0; --xx) {
+                    const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)jj * LANE_SLOT_BYTES);
+                    const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
+                    gst(pa_code() + xx, geom >> 24);
+                    if ((int32_t)(link >> 16) >= k - 1) { if (ni >= 0) gst(pa_node() + ni, node); --ni; }
+                    jj = (int32_t)(link & 0xFFFFu);
+                }
+                for (int32_t xx = 0; xx < x_n_runs; ++xx) gst(runs_fwd() + xx, chip.runs[xx * chip.rstride]);
+            }
+            gst(arec() + 8, (uint32_t)LANE_CI(CD_HAVE_ALN)); gst(arec() + 9, (uint32_t)x_score); gst(arec() + 10, (uint32_t)x_clip);
+            gst(arec() + 11, (uint32_t)x_end_clip);
+            c_fwd_n_nodes = x_n_nodes; c_fwd_n_seq = x_n_seq;
+            LANE_CI(CD_MODE) = LANE_EMIT_ARRAYS;
+            // seedref_from_aln of the reversal: clipping = the alignment's end clipping, the whole spelling is the seed
+            LANE_CI(CD_CLIP) = x_end_clip;
+            c_seed_len = x_n_seq; c_seed_off = 0; c_node0 = gld(pa_node() + (x_n_nodes - 1));
+            if (!load_strand(1 - LANE_CI(CD_STRAND))) LANE_BAIL(5);
+            return LR_AGAIN;
+        }
+        // ---- pass 1 is over (:700-722): the backward alignment, reversed again, joins the aggregator ----
+        // (a backward extension without a start cell yields its seed — the forward alignment once more, which the aggregator has
+        // or, below its score threshold, takes now: the latter is left to the group kernel)
+        const int32_t fw_added = (int32_t)gld(arec() + 8);
+        if (!got) { if (!fw_added) LANE_BAIL(31); break; }
+        // (reverse_complement() refuses an alignment with an offset: dropped, like one without nodes)
+        if (!x_offset && x_n_nodes) {
+            bool take = true;
+            if (fw_added) {
+                const int32_t fw_score = (int32_t)gld(arec() + 9), fw_clip = (int32_t)gld(arec() + 10), fw_end_clip = (int32_t)gld(arec() + 11);
+                const int32_t gcut = fw_score > 0 ? (int32_t)((double)fw_score * cfg.rel_score_cutoff) : fw_score;
+                // add_alignment (:68-138, one alignment): below the cut-off it is dropped; else it replaces the queue's alignment
+                // unless it is less (LocalAlignmentLess, alignment.hpp:337-348; an equal alignment changes nothing either way)
+                const int32_t b_qlen = L - x_clip - x_end_clip, f_qlen = L - fw_clip - fw_end_clip;
+                const int32_t b_clip_rev = x_end_clip;                                  // its clipping once reversed
+                const bool less = fw_score != x_score ? fw_score > x_score : (b_qlen != f_qlen ? b_qlen > f_qlen : b_clip_rev > fw_clip);
+                if (x_score < gcut || less) take = false;
+            }
+            if (take) {
+                LANE_CI(CD_HAVE_ALN) = 1; LANE_CI(CD_MODE) = LANE_EMIT_SLOTS_REVERSED;
+                gst(arec() + 0, (uint32_t)x_score); gst(arec() + 1, 0u); gst(arec() + 2, (uint32_t)x_end_clip);
+                gst(arec() + 3, (uint32_t)x_clip); gst(arec() + 4, (uint32_t)x_n_runs); gst(arec() + 5, (uint32_t)x_j_hi);
+                gst(arec() + 6, (uint32_t)x_n_nodes); gst(arec() + 7, (uint32_t)x_n_seq);
+            }
+        }
+        } while (0);
     }
     {
         ReadResult &rr = R.rr;
@@ -773,14 +933,29 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         rr.n_seeds_fwd = (uint32_t)gld(&hp->n_seeds[0]); rr.n_seeds_rc = (uint32_t)gld(&hp->n_seeds[1]);
         rr.n_extensions = (uint32_t)n_extensions; rr.n_columns = n > 0 ? (uint32_t)cols_done : 0u;
     }
-    ctr.rank_lines += LANE_CU(CD_CTR_RANK); ctr.select_lines += LANE_CU(CD_CTR_SEL);
-    R.have_aln = (have_aln && a_n_nodes) ? 1 : 0;
-    R.score = a_score; R.offset = a_offset; R.clip = a_clip; R.end_clip = a_end_clip; R.n_runs = a_n_runs;
-    R.j_hi = a_j_hi; R.n_nodes = a_n_nodes; R.n_seq = a_n_seq; R.trim = 0; R.strand = s;
-    R.words = R.have_aln ? (uint32_t)a_n_nodes + (uint32_t)((a_clip ? 1 : 0) + a_n_runs + (a_end_clip ? 1 : 0)) + ((uint32_t)a_n_seq + 3) / 4 : 0u;
+    // the lane's counters (kept in its scratch, summed when the kernel ends): columns, block lines
+    gst(arec() + 26, gld(arec() + 26) + (n > 0 ? (uint32_t)cols_done : 0u));
+    gst(arec() + 27, gld(arec() + 27) + LANE_CU(CD_CTR_RANK));
+    gst(arec() + 28, gld(arec() + 28) + LANE_CU(CD_CTR_SEL));
+    {
+        const int32_t have_aln = n > 0 ? LANE_CI(CD_HAVE_ALN) : 0;
+        const int32_t a_n_nodes = have_aln ? (int32_t)gld(arec() + 6) : 0;
+        R.have_aln = (have_aln && a_n_nodes) ? 1 : 0;
+        R.mode = LANE_CI(CD_MODE);
+        R.strand = LANE_CI(CD_STRAND);
+        R.words = 0; R.trim = 0;
+        if (R.have_aln) {
+            R.score = (int32_t)gld(arec() + 0); R.offset = (int32_t)gld(arec() + 1); R.clip = (int32_t)gld(arec() + 2);
+            R.end_clip = (int32_t)gld(arec() + 3); R.n_runs = (int32_t)gld(arec() + 4); R.j_hi = (int32_t)gld(arec() + 5);
+            R.n_nodes = a_n_nodes; R.n_seq = (int32_t)gld(arec() + 7);
+            R.words = (uint32_t)R.n_nodes + (uint32_t)((R.clip ? 1 : 0) + R.n_runs + (R.end_clip ? 1 : 0)) + ((uint32_t)R.n_seq + 3) / 4;
+        }
+    }
     return LR_DONE;
 }
 
+#undef c_fwd_n_nodes
+#undef c_fwd_n_seq
 #undef c_seed_len
 #undef c_seed_off
 #undef c_node0
@@ -793,16 +968,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 #undef t_pos
 #undef fa_alive
 #undef fa_conv
-#undef fa_org
-#undef fa_trim
-#undef fa_size
-#undef fa_offset
 #undef fa_max_val
-#undef fa_idx
-#undef fa_t_score
-#undef fa_t_nod
-#undef fa_t_pos
-#undef fa_node
 #undef d_score
 #undef d_max
 #undef kid_node0
@@ -832,22 +998,43 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
         } else {
             uint32_t *dst = P.out_stream + so;
             const int32_t n_cigar = (R.clip ? 1 : 0) + R.n_runs + (R.end_clip ? 1 : 0);
-            int32_t nc = 0;
-            if (R.clip) gst(dst + R.n_nodes + nc++, ((uint32_t)R.clip << 3) | OP_CLIPPED);
-            for (int32_t x = R.n_runs - 1; x >= 0; --x) gst(dst + R.n_nodes + nc++, chip.runs[x * chip.rstride]);
-            if (R.end_clip) gst(dst + R.n_nodes + nc++, ((uint32_t)R.end_clip << 3) | OP_CLIPPED);
-            // the path, last column first, down the parent links: characters of all its columns, nodes of those whose offset
-            // reaches k - 1 (minus the leading ones trim_offset dropped)
             uint8_t *dseq = (uint8_t *)(dst + R.n_nodes + n_cigar);
             const int32_t k_minus_1 = (int32_t)P.g.k - 1;
-            int32_t j = R.j_hi, ni = R.n_nodes - 1;
-            for (int32_t x = R.n_seq - 1; x >= 0; --x) {
-                const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES);
-                const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
-                gst(dseq + x, decode_code(geom >> 24));
-                if ((int32_t)(link >> 16) >= k_minus_1) { if (ni >= 0) gst(dst + ni, node); --ni; }
-                j = (int32_t)(link & 0xFFFFu);
+            int32_t nc = 0;
+            if (R.clip) gst(dst + R.n_nodes + nc++, ((uint32_t)R.clip << 3) | OP_CLIPPED);
+            if (R.mode == LANE_EMIT_SLOTS) {
+                for (int32_t x = R.n_runs - 1; x >= 0; --x) gst(dst + R.n_nodes + nc++, chip.runs[x * chip.rstride]);
+                // the path, last column first, down the parent links: characters of all its columns, nodes of those whose offset
+                // reaches k - 1 (minus the leading ones trim_offset dropped)
+                int32_t j = R.j_hi, ni = R.n_nodes - 1;
+                for (int32_t x = R.n_seq - 1; x >= 0; --x) {
+                    const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES);
+                    const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
+                    gst(dseq + x, decode_code(geom >> 24));
+                    if ((int32_t)(link >> 16) >= k_minus_1) { if (ni >= 0) gst(dst + ni, node); --ni; }
+                    j = (int32_t)(link & 0xFFFFu);
+                }
+            } else if (R.mode == LANE_EMIT_ARRAYS) {
+                // the forward alignment as the backward pass kept it: path order, runs last first
+                const uint32_t *pn = (const uint32_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8) + 4 * LFW;
+                const uint32_t *pc = pn + LP.max_cols, *pr = pc + LP.max_cols;
+                for (int32_t x = R.n_runs - 1; x >= 0; --x) gst(dst + R.n_nodes + nc++, gld(pr + x));
+                for (int32_t x = 0; x < R.n_nodes; ++x) gst(dst + x, gld(pn + x));
+                for (int32_t x = 0; x < R.n_seq; ++x) gst(dseq + x, decode_code(gld(pc + x)));
+            } else {
+                // the backward alignment reversed (Alignment::reverse_complement): its runs in the order the trace recorded them,
+                // its columns in the order the parent links give them, characters complemented
+                for (int32_t x = 0; x < R.n_runs; ++x) gst(dst + R.n_nodes + nc++, chip.runs[x * chip.rstride]);
+                int32_t j = R.j_hi, ni = 0;
+                for (int32_t x = 0; x < R.n_seq; ++x) {
+                    const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES);
+                    const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
+                    gst(dseq + x, decode_code(5u - (geom >> 24)));
+                    if ((int32_t)(link >> 16) >= k_minus_1) { if (ni < R.n_nodes) gst(dst + ni, node); ++ni; }
+                    j = (int32_t)(link & 0xFFFFu);
+                }
             }
+            if (R.end_clip) gst(dst + R.n_nodes + nc++, ((uint32_t)R.end_clip << 3) | OP_CLIPPED);
             for (int32_t x = R.n_seq; x & 3; ++x) gst(dseq + x, (uint8_t)0);          // (pad the last word)
             rr.score = R.score; rr.offset = (uint32_t)R.offset;
             rr.n_nodes = (uint32_t)R.n_nodes; rr.n_cigar = (uint32_t)n_cigar; rr.seq_len = (uint32_t)R.n_seq;

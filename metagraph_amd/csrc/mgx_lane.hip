@@ -36,25 +36,39 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
     chip.runs = &s_runs[0][lane]; chip.rstride = 64;
     chip.cold = &s_cold[0][lane]; chip.cstride = 64;
     const uint64_t n_items = LP.P.n_items ? LP.P.n_items : LP.P.n_reads;
-    LaneCounters ctr = { 0, 0, 0, 0 };
-    uint32_t n_done = 0, n_ext = 0, n_cap = 0;
+    LaneCounters ctr = { 0 };
+    {
+        uint32_t *rec = lane_record(LP, scratch);
+        for (int x = 26; x < 32; ++x) gst(rec + x, 0u);
+    }
+    // Every lane holds one read at a time: a new one from the sorted order, or — after LR_AGAIN — the same one for its backward
+    // pass, while its wave-mates move on to new reads.
+    uint64_t read = 0, item = 0;
+    int pass = 0;
+    bool holding = false;
     for (;;) {
+        LV<bool> wantv;
+        wantv.v = !holding;
+        const uint64_t wm = wave_ballot(wantv);
         LV<uint64_t> bv;
         bv.v = 0;
-        if (lane == 0) bv.v = atomicAdd(LP.P.read_cursor, 64ull);
+        if (lane == 0 && wm) bv.v = atomicAdd(LP.P.read_cursor, (unsigned long long)popc64(wm));
         const uint64_t base = wave_bcast(bv, 0);
-        if (base >= n_items) break;
-        const uint64_t item = base + (uint64_t)lane;
-        const bool active = item < n_items;
-        uint64_t read = 0;
+        if (!holding) {
+            item = base + (uint64_t)popc64(wm & ((1ull << lane) - 1));
+            pass = 0;
+            if (item < n_items) { holding = true; read = LP.P.order ? (uint64_t)gld(LP.P.order + item) : item; }
+        }
+        LV<bool> actv;
+        actv.v = holding;
+        if (!wave_ballot(actv)) break;                       // nobody holds a read and the order is exhausted
+        const bool active = holding;
         int rc = LR_DONE;
         LaneResult R;
         R.words = 0; R.have_aln = 0;
-        if (active) {
-            read = LP.P.order ? (uint64_t)gld(LP.P.order + item) : item;
-            rc = lane_read(LP, read, (uint32_t)item, scratch, chip, ctr, R);
-        }
-        const bool done = active && rc == LR_DONE, bail = active && rc != LR_DONE;
+        if (active) rc = lane_read(LP, read, (uint32_t)item, pass, scratch, chip, ctr, R);
+        if (active && rc == LR_AGAIN) pass = 1; else holding = false;
+        const bool done = active && rc == LR_DONE, bail = active && rc == LR_BAIL;
         // output-stream words of the wavefront's finished reads: one atomic, a prefix sum over the lanes
         LV<int32_t> wv;
         wv.v = done ? (int32_t)R.words : 0;
@@ -66,7 +80,9 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
         const uint64_t so = wave_bcast(sv, 0) + (uint64_t)pre.v;
         if (done) {
             lane_emit(LP, read, scratch, chip, R, so);
-            ++n_done; n_ext += R.rr.n_extensions; n_cap += R.rr.status != ST_OK;
+            uint32_t *rec = lane_record(LP, scratch);
+            gst(rec + 29, gld(rec + 29) + 1u); gst(rec + 30, gld(rec + 30) + R.rr.n_extensions);
+            gst(rec + 31, gld(rec + 31) + (uint32_t)(R.rr.status != ST_OK));
         }
         // the reads for the group kernel, in processing order
         LV<bool> bl;
@@ -93,13 +109,14 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
         }
     }
     // counters: one atomic per wavefront and counter
+    const uint32_t *rec = lane_record(LP, scratch);
     LV<int32_t> v;
-    v.v = (int32_t)ctr.rank_lines; const int32_t rl = wave_sum(v);
-    v.v = (int32_t)ctr.select_lines; const int32_t sl = wave_sum(v);
-    v.v = (int32_t)ctr.columns; const int32_t cl = wave_sum(v);
-    v.v = (int32_t)n_done; const int32_t nd = wave_sum(v);
-    v.v = (int32_t)n_ext; const int32_t ne = wave_sum(v);
-    v.v = (int32_t)n_cap; const int32_t nc = wave_sum(v);
+    v.v = (int32_t)gld(rec + 27); const int32_t rl = wave_sum(v);
+    v.v = (int32_t)gld(rec + 28); const int32_t sl = wave_sum(v);
+    v.v = (int32_t)gld(rec + 26); const int32_t cl = wave_sum(v);
+    v.v = (int32_t)gld(rec + 29); const int32_t nd = wave_sum(v);
+    v.v = (int32_t)gld(rec + 30); const int32_t ne = wave_sum(v);
+    v.v = (int32_t)gld(rec + 31); const int32_t nc = wave_sum(v);
     if (lane == 0) {
         atomicAdd(&LP.P.stats->rank_lines, (unsigned long long)rl);
         atomicAdd(&LP.P.stats->select_lines, (unsigned long long)sl);

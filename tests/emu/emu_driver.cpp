@@ -392,10 +392,14 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
                 LaneChip chip = { qw.data(), 1, runs.data(), 1, cold.data(), 1 };
                 R->lane_reason.assign(n, 0);
                 for (uint64_t i = 0; i < n; ++i) {
-                    LaneCounters lc = { 0, 0, 0, 0 };
+                    LaneCounters lc = { 0 };
+                    uint32_t *lrec = lane_record(LP, scratch.data());
+                    lrec[27] = 0; lrec[28] = 0;
                     LaneResult LR;
                     memset(&LR, 0, sizeof(LR));
-                    if (lane_read(LP, order[i], (uint32_t)i, scratch.data(), chip, lc, LR) == LR_DONE) {
+                    int lrc = lane_read(LP, order[i], (uint32_t)i, 0, scratch.data(), chip, lc, LR);
+                    if (lrc == LR_AGAIN) lrc = lane_read(LP, order[i], (uint32_t)i, 1, scratch.data(), chip, lc, LR);
+                    if (lrc == LR_DONE) {
                         const uint64_t so = cursors[0];
                         cursors[0] += LR.words;
                         lane_emit(LP, order[i], scratch.data(), chip, LR, so);
@@ -407,7 +411,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
                         if (lc.reason < 32) ++R->lane_bail[lc.reason];
                         R->lane_reason[order[i]] = (uint8_t)lc.reason;
                     }
-                    R->stats.rank_lines += lc.rank_lines; R->stats.select_lines += lc.select_lines;
+                    R->stats.rank_lines += lrec[27]; R->stats.select_lines += lrec[28];
                 }
                 order = lane_rest;
                 P.order = order.data();
