@@ -7,9 +7,10 @@ over one batch of synthetic reads already resident in HBM.  Workload (BASELINE.j
 of the graph and its own read shard (weak scaling) and the complete alignments (result headers AND the
 variable-length node / CIGAR / path-spelling stream) are gathered to rank 0 over RCCL inside the timed region.
 
-`value` is the device-resident rate (reads and results in HBM, as the bench contract prescribes);
-`value_host_inclusive` is SURVEY 8(d)'s variant of the same step with the read H2D and the result D2H (pinned
-host buffers) inside the timed region.
+`value` is SURVEY 8(d)'s metric: reads start in pinned host memory and the complete results end there — the read H2D and
+the result D2H run on a side stream, double-buffered, so that they overlap the kernels of the neighbouring batches
+(all --steps batches are timed, the last D2H included).  `value_device_resident` is the same step with reads and
+results left in HBM (what rounds 1-3 reported as `value`).
 
 Prints ONE JSON line (rank 0).  PyTorch is plumbing only (device tensors, streams, torch.distributed).
 """
@@ -50,11 +51,14 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("MGX_BENCH_CPU_SAMPLE", 200000)))
     ap.add_argument("--parity-sample", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-steps", type=int, default=2, help="steps of the PCIe-inclusive variant (0 = skip)")
+    ap.add_argument("--host-steps", type=int, default=-1, help="batches of the PCIe-inclusive pipeline (default: --steps; 0 = skip: "
+                    "`value` then falls back to the device-resident rate and says so)")
     ap.add_argument("--cpu-1t-sample", type=int, default=1500, help="reads of the single-thread CPU leg")
     ap.add_argument("--options", default="", help="kernel-selection options for A/B runs, '+'-separated (mgx_aligner_set_pipeline, "
                     "e.g. lane=0: without the lane-per-read kernel); results never depend on them")
     args = ap.parse_args()
+    if args.host_steps < 0:
+        args.host_steps = args.steps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -156,30 +160,61 @@ def main():
     total_reads = args.reads * world
     value = total_reads / (elapsed / max(1, args.steps))
 
-    # ---------------- SURVEY 8(d) variant: read H2D and result D2H inside the timed region ----------------
-    # pinned host buffers; reads go up, the complete results (headers + used part of the stream) come down
+    # ---------------- read H2D and result D2H inside the timed region, overlapped with the kernels ----------------
+    # Two device read buffers and two pinned result buffers; copies run on a side stream (libmgx's kernels run on the default
+    # stream): batch i + 1's reads go up and batch i - 1's results (a device-side snapshot taken right after its kernels, a
+    # few ms) come down while batch i is aligned.  The complete results (headers + used part of the stream) reach the host.
     host_value, host_ms = None, None
     if args.host_steps > 0:
         reads_h = reads.cpu().pin_memory()
         offsets_h = offsets.cpu().pin_memory()
-        hdr_d, stream_d, used = mg.device_result_tensors(A, dev)
-        hdr_h = torch.empty(hdr_d.numel(), dtype=torch.uint8).pin_memory()
-        stream_h = torch.empty(stream_d.numel(), dtype=torch.uint8).pin_memory()
+        rbuf = [reads, torch.empty_like(reads)]
+        obuf = [offsets, torch.empty_like(offsets)]
+        hdr_d, stream_d, used0 = mg.device_result_tensors(A, dev)
+        hdr_h = [torch.empty(hdr_d.numel(), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        stream_h = [torch.empty(min(stream_d.numel(), 4 * used0 + (64 << 20)), dtype=torch.uint8).pin_memory() for _ in range(2)]
+        side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
 
-        def host_step():
-            reads.copy_(reads_h, non_blocking=True)
-            offsets.copy_(offsets_h, non_blocking=True)
-            A.align_device(reads.data_ptr(), offsets.data_ptr(), args.reads)
-            hd, sd, u = mg.device_result_tensors(A, dev)
-            hdr_h.copy_(hd, non_blocking=True)
-            stream_h[:4 * u].copy_(sd[:4 * u], non_blocking=True)
-            if dist:
-                mg.gather_device_results(A, dist, rank, world, dev)
-        host_step()
+        def upload(i):
+            ev = torch.cuda.Event()
+            with torch.cuda.stream(side):
+                rbuf[i % 2].copy_(reads_h, non_blocking=True)
+                obuf[i % 2].copy_(offsets_h, non_blocking=True)
+                ev.record(side)
+            return ev
+
+        def host_pipeline(n_steps):
+            up = upload(0)
+            down_done = [None, None]
+            for i in range(n_steps):
+                nxt = upload(i + 1) if i + 1 < n_steps else None
+                main.wait_event(up)
+                A.align_device(rbuf[i % 2].data_ptr(), obuf[i % 2].data_ptr(), args.reads)
+                hd, sd, u = mg.device_result_tensors(A, dev)
+                assert 4 * u <= stream_h[i % 2].numel(), "pinned result buffer too small"
+                snap_h, snap_s = hd.clone(), sd[:4 * u].clone()          # the next batch overwrites the aligner's buffers
+                ready = torch.cuda.Event()
+                ready.record(main)
+                if down_done[i % 2] is not None:
+                    down_done[i % 2].synchronize()                       # (its pinned buffer is free again)
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    hdr_h[i % 2].copy_(snap_h, non_blocking=True)
+                    stream_h[i % 2][:4 * u].copy_(snap_s, non_blocking=True)
+                    snap_h.record_stream(side); snap_s.record_stream(side)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                down_done[i % 2] = done
+                if dist:
+                    mg.gather_device_results(A, dist, rank, world, dev)
+                up = nxt
+            side.synchronize()
+
+        host_pipeline(1)
         sync()
         th = time.time()
-        for _ in range(args.host_steps):
-            host_step()
+        host_pipeline(args.host_steps)
         sync()
         eh = time.time() - th
         if dist:
@@ -188,7 +223,7 @@ def main():
             eh = float(tmax.item())
         host_ms = 1000.0 * eh / args.host_steps
         host_value = total_reads / (eh / args.host_steps)
-        del reads_h, offsets_h, hdr_h, stream_h
+        del reads_h, offsets_h, hdr_h, stream_h, rbuf, obuf
 
     if rank != 0:
         if dist:
@@ -210,18 +245,26 @@ def main():
     io_seed = args.reads * (args.read_len + 2 * 4 * n_kmers + 32) + 12 * st["n_seeds"]
     io_ext = args.reads * (args.read_len + 96 + 2 * 4 * n_kmers + 32) + 12 * st["n_seeds"]
     split = st["extend_ms"] > 0
+    lane_ms = st["lane_ms"]
+    lines_lane = st["n_lane_lines"]
     if split:
+        # k_lane (one lane per read: finishes the simple reads) and k_extend (8 lanes per read: the reads k_lane passed on) share
+        # the extension stage; each read's I/O bytes are charged to the kernel that finished it, every read's seeds and node
+        # arrays to k_lane (it looks at all of them)
+        lane_reads = st["n_lane_reads"]
+        ext_reads = args.reads - lane_reads if lane_ms > 0 else args.reads
+        io_per_read = args.read_len + 96 + 2 * 4 * n_kmers + 32
         kernels = {"k_map": (k_map, 64.0 * lines_map + io_map),
                    "k_seed": (st["seeding_ms"], 64.0 * lines_seed + io_seed),
-                   "k_extend": (st["extend_ms"], 64.0 * (lines_align - lines_seed) + io_ext)}
+                   "k_extend": (st["extend_ms"] - lane_ms, 64.0 * (lines_align - lines_seed - lines_lane) + ext_reads * io_per_read
+                                + (12 * st["n_seeds"] if lane_ms <= 0 else 0))}
         kernel_ms = {"k_map": round(k_map, 3), "k_seed": round(st["seeding_ms"], 3), "work_sort": round(st["sort_ms"], 3),
-                     "k_extend": round(st["extend_ms"], 3), "k_lane_part_of_k_extend": round(st["lane_ms"], 3),
-                     "reads_finished_by_k_lane": st["n_lane_reads"],
-                     "reads_k_lane_passed_on_by_reason": st["lane_bail_reads"]}
-    else:
-        kernels = {"k_map": (k_map, 64.0 * lines_map + io_map),
-                   "k_align": (k_align, 64.0 * lines_align + io_ext)}
-        kernel_ms = {"k_map": round(k_map, 3), "k_align": round(k_align, 3)}
+                     "k_extend": round(st["extend_ms"] - lane_ms, 3)}
+        if lane_ms > 0:
+            kernels["k_lane"] = (lane_ms, 64.0 * lines_lane + args.reads * io_per_read + 12 * st["n_seeds"])
+            kernel_ms["k_lane"] = round(lane_ms, 3)
+            kernel_ms["reads_finished_by_k_lane"] = lane_reads
+            kernel_ms["reads_k_lane_passed_on_by_reason"] = st["lane_bail_reads"]
     dom = max(kernels, key=lambda n: kernels[n][0])
     dom_ms, dom_bytes = kernels[dom]
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -231,7 +274,7 @@ def main():
     traffic, traffic_src, gather = None, None, None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        pmc_name = next(n for n in ("r03_pmc_summary.json", "r02_pmc_summary.json") if os.path.exists(os.path.join(here, "profiles", n)))
+        pmc_name = next(n for n in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json") if os.path.exists(os.path.join(here, "profiles", n)))
         pmc = json.load(open(os.path.join(here, "profiles", pmc_name)))
         per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read")
         if per_read:
@@ -244,7 +287,7 @@ def main():
         ceil = json.load(open(os.path.join(here, "profiles", ceil_name)))
         dram = max(r["chains1"] for r in ceil["sets"][1]["rows"]) * 1e9
         cache = max(r["chains1"] for r in ceil["sets"][0]["rows"]) * 1e9
-        counted = {"k_map": lines_map, "k_seed": lines_seed, "k_extend": lines_align - lines_seed}
+        counted = {"k_map": lines_map, "k_seed": lines_seed, "k_extend": lines_align - lines_seed - lines_lane, "k_lane": lines_lane}
         gather = {"ceiling_lines_per_s": {"dram_9GB_set": dram, "infinity_cache_104MB_set": cache},
                   "source": "profiles/" + ceil_name,
                   "note": "block_lines = 64-B BOSS index lines the kernel itself counts (exact); fabric_lines = PMC bytes / 64 B "
@@ -270,8 +313,10 @@ def main():
                 "kernel_ms": kernel_ms,
                 "algorithmic_GBps": {n: round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0 for n, (ms, b) in kernels.items()},
                 "lines_per_read": {"k_map": round(lines_map / args.reads, 1), "k_seed": round(lines_seed / args.reads, 1),
-                                   "k_extend": round((lines_align - lines_seed) / args.reads, 1)},
+                                   "k_extend": round((lines_align - lines_seed - lines_lane) / args.reads, 1),
+                                   "k_lane": round(lines_lane / args.reads, 1)},
                 "columns_per_read": round(st["n_columns"] / args.reads, 2),
+                "columns_per_read_in_k_lane": round(st["n_lane_columns"] / args.reads, 2),
                 # per-group timers of k_extend (a group also "spends" the time it waits for the other 7 reads of its
                 # wavefront, so these are shares of wavefront time, not of useful work)
                 "phase_share": dict(zip(["prepare", "seed_pickup", "extend", "backtrack", "driver", "output"],
@@ -336,10 +381,13 @@ def main():
             except OSError:
                 pass
             one = n1 / d1
-            scan = None
-            if os.environ.get("MGX_BENCH_THREAD_SCAN"):
-                scan = {}
-                for th in [int(x) for x in os.environ["MGX_BENCH_THREAD_SCAN"].split(",")]:
+            # thread scan up to the quota (MGX_BENCH_THREAD_SCAN overrides the thread counts): how the restated CPU path scales on
+            # this host, next to the quota itself and the whole-node extrapolation below
+            scan = {}
+            scan_list = [int(x) for x in os.environ["MGX_BENCH_THREAD_SCAN"].split(",")] if os.environ.get("MGX_BENCH_THREAD_SCAN") \
+                else sorted(set(t for t in (1, 2, 4, 8, 16, 32, 64, threads) if t <= threads))
+            if scan_list:
+                for th in scan_list:
                     ns = min(nc, max(2000, 400 * th))
                     ts = time.time()
                     orc.AlignRun(og, cfg, csample[:ns], threads=th, validate=False)
@@ -349,16 +397,19 @@ def main():
                    "build": "-O3 -march=native -DNDEBUG", "cpu_model": model,
                    "single_thread": {"value": round(one, 1), "sample": "%d reads, %.1fs" % (n1, d1)},
                    "thread_scaling_efficiency": round((nc / dt) / (one * threads), 3), "thread_scan": scan,
+                   "cpu_quota_threads": threads,
                    # north_star asks for "the node's host cores"; the GPU boxes grant this process a CPU quota (cores above),
                    # so the whole-socket figure can only be extrapolated: single-thread rate x physical cores, which the
                    # measured scaling up to the quota (efficiency above) supports as an upper estimate
                    "extrapolated_whole_socket": {"cores": 128, "value": round(one * 128, 1),
                                                  "note": "single-thread rate x 128 physical cores (2 x EPYC 9575F); not measured"}}
 
-    out = {"metric": "aligned reads/sec (150 bp, k=31)", "value": round(value, 1), "unit": "reads/s",
-           "value_host_inclusive": round(host_value, 1) if host_value else None,
-           "ms_per_step_host_inclusive": round(host_ms, 3) if host_ms else None,
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+    # `value`: SURVEY 8(d) — host buffers in, host buffers out (the pipelined run above); the device-resident rate next to it
+    out = {"metric": "aligned reads/sec (150 bp, k=31)", "value": round(host_value if host_value else value, 1), "unit": "reads/s",
+           "value_is": "host-inclusive (read H2D + result D2H overlapped with the kernels)" if host_value else "device-resident (--host-steps 0)",
+           "value_device_resident": round(value, 1), "ms_per_step_device_resident": round(ms_per_step, 3),
+           "n_gpus": world, "steps": args.host_steps if host_value else args.steps, "warmup": args.warmup,
+           "ms_per_step": round(host_ms if host_value else ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
            "config": {"workload": "%d synthetic %d bp reads per GPU vs %d-edge k=%d BOSS graph (%.0f Mbp iid genome + %d SNP windows%s), CLI-default scoring" %
                       (args.reads, args.read_len, n_edges, args.k, args.genome / 1e6, args.snps,
@@ -366,6 +417,8 @@ def main():
                       "reads_per_gpu": args.reads, "graph_edges": n_edges, "k": args.k, "graph_mode": args.graph_mode, "parallelism": "reads sharded x%d, graph replicated" % world},
            "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
     print(json.dumps(out), flush=True)
+    # a batch that lost alignments to a capacity limit is not a valid measurement
+    assert st["n_capacity_errors"] == 0, "%d reads ended with a capacity status" % st["n_capacity_errors"]
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -210,6 +210,8 @@ typedef struct mgx_stats {
                                    asserts so that it is known to have exercised the kernel it means to */
     uint64_t n_lane_reads;      /* reads the lane-per-read kernel finished on its own (the rest went on to the group kernel) */
     double lane_ms;             /* HIP-event time of the lane-per-read kernel (part of extend_ms) */
+    uint64_t n_lane_lines;      /* part of the line counters issued by the lane-per-read kernel */
+    uint64_t n_lane_columns;    /* part of n_columns computed by it (for the reads it passes on too) */
     uint64_t lane_bail_reads[32]; /* reads the lane-per-read kernel passed on to the group kernel, by reason (the LANE_BAIL codes of
                                    csrc/lane_read.hpp: 3 second strand, 4 many seeds, 5 invalid characters, 10 fork, 14 / 16 wide band,
                                    15 node seen before, 19 a later seed survives, 26 backward extension, ...) */

@@ -72,7 +72,8 @@ class Stats(C.Structure):
                 ("seed_kernel_ms", C.c_double), ("align_kernel_ms", C.c_double),
                 ("seeding_ms", C.c_double), ("sort_ms", C.c_double), ("extend_ms", C.c_double), ("n_seed_lines", C.c_uint64),
                 ("n_fast_columns", C.c_uint64), ("extend_kernels", C.c_uint64), ("n_lane_reads", C.c_uint64),
-                ("lane_ms", C.c_double), ("lane_bail_reads", C.c_uint64 * 32)]
+                ("lane_ms", C.c_double), ("n_lane_lines", C.c_uint64), ("n_lane_columns", C.c_uint64),
+                ("lane_bail_reads", C.c_uint64 * 32)]
 
 
 KERNEL_GRP8, KERNEL_GRP8_PRIM, KERNEL_GRP8_ALT, KERNEL_EXT64, KERNEL_LANE = 1, 2, 4, 8, 16

@@ -75,6 +75,8 @@ struct KernelStats {
     unsigned long long xcyc[8];     // extend() breakdown
     unsigned long long cyc[8];      // shader cycles per phase: prepare, seeding, extend, backtrack, driver rest, output
     unsigned long long fast_columns; // DP columns computed by the register-resident chain path (part of `columns`)
+    unsigned long long lane_lines;   // part of the line counters issued by the lane-per-read kernel
+    unsigned long long lane_columns; // part of `columns` computed by the lane-per-read kernel (finished and passed-on reads)
 };
 
 struct AlignParams {

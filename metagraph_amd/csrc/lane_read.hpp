@@ -44,7 +44,7 @@ enum { CD_B_SCORE, CD_B_NOD, CD_B_I, CD_B_POS, CD_T_SCORE, CD_T_NOD, CD_T_POS,
        CD_D_SCORE0, CD_D_SCORE1, CD_D_SCORE2, CD_D_MAX0, CD_D_MAX1, CD_D_MAX2,
        CD_KID_N0, CD_KID_C0, CD_KID_N1, CD_KID_C1,
        CD_TABLE_CAP, CD_TSB_LO, CD_TSB_HI, CD_CELL_TOP, CD_NCOLS, CD_F_NODE, CD_F_IDX, CD_F_MAX,
-       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_ROOT_PUSHES, CD_CTR_RANK, CD_CTR_SEL, CD_FWD_N_NODES, CD_FWD_N_SEQ, CD_STRAND, CD_HAVE_ALN, CD_MODE, CD_CLIP, CD_L, CD_NSEEDS, CD_NEXT,
+       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_ROOT_PUSHES, CD_CTR_RANK, CD_CTR_SEL, CD_FWD_N_NODES, CD_FWD_N_SEQ, CD_STRAND, CD_HAVE_ALN, CD_MODE, CD_CLIP, CD_L, CD_NSEEDS, CD_REPLAY_TOP, CD_REPLAY_MATCHING,
        LANE_COLD_WORDS };
 static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 #define LANE_CI(f) (*(int32_t *)(chip.cold + (f) * chip.cstride))
@@ -415,6 +415,9 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         // and lane_column() — and the loop has one back edge: with the window assigned on several paths the register allocator
         // kept copies of it and spilled hundreds of registers.
         int32_t hd_begin = 0, hd_prev_end = 0;
+#define replay_top LANE_CI(CD_REPLAY_TOP)
+#define replay_matching LANE_CI(CD_REPLAY_MATCHING)
+        replay_top = -1; replay_matching = 1;
         bool reload = false, reload_parked = false, ext_over = false;
         while (!ext_over) {
             if (reload) { win_load(reload_parked ? save_a() : save_p()); reload = false; }
@@ -445,9 +448,6 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 const int32_t fn = c_fwd_n_nodes, fq = c_fwd_n_seq;
                                 kid_code0 = 5u - gld(pa_code() + (fq - 1 - sp));
                                 kid_node0 = gld(pa_node() + (fn - 1 - imax(0, no - k + 1)));
-                                // (the columns of the first node merge convergence vectors; that is decided without the
-                                // vectors only while the replayed characters are the query's own, see below)
-                                if (no < k && qcode(clipping + sp) + 1 != kid_code0) LANE_BAIL(30);
                             }
                             n_kids = 1;
                         } else {
@@ -534,6 +534,24 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     // (replay columns: see above; the column's own maximum stands in for the merged score, ninf neither way)
                     const int32_t converged = out.converged;
                     const int32_t size = out.size, org = out.org;
+                    if (pass && replay) {
+                        // The backward pass replays the PATH's characters, which may differ from the query's.  While they have
+                        // all matched, the argument above holds.  After a mismatch this one has to: a cell with a score at a
+                        // window position above every earlier column of the node lies outside the node's vector (the ranges of
+                        // these columns are contiguous), reads ninf there and improves on it — converged != ninf.  (The band's
+                        // upper end advances with the diagonal once the insertion run behind it has its steady length.)  With
+                        // neither, the merge itself would decide: the group kernel's case.
+                        int32_t top = -1;
+#pragma unroll
+                        for (int x = 0; x < LFW; ++x) top = S[x] != NINF ? org + x : top;
+                        if (!(top >= begin && top < begin + size)) top = -1;
+                        const int32_t ap = clipping + seed_pos + 1;                     // the query character under the diagonal cell
+                        const bool same = ap >= 1 && ap <= L && qcode(ap - 1) + 1 == ccode;
+                        if (probe) replay_matching = 1;
+                        if (!same) replay_matching = 0;
+                        if (!probe && !replay_matching && !(top > replay_top)) LANE_BAIL(30);
+                        replay_top = probe ? top : imax(replay_top, top);
+                    }
                     // commit: the slot (flags, node, base, geometry, parent) and the S row
                     const int32_t base = max_val == NINF ? 0 : max_val;
                     {
@@ -954,6 +972,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
     return LR_DONE;
 }
 
+#undef replay_top
+#undef replay_matching
 #undef c_fwd_n_nodes
 #undef c_fwd_n_seq
 #undef c_seed_len

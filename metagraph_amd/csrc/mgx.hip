@@ -1167,6 +1167,7 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     s.n_fast_columns = ks.fast_columns;
     s.extend_kernels = A->kernels_ran;
     s.n_lane_reads = A->lane_done;
+    s.n_lane_lines = ks.lane_lines; s.n_lane_columns = ks.lane_columns;
     for (int x = 0; x < 32; ++x) s.lane_bail_reads[x] = A->lane_hist_h[x];
     for (int x = 0; x < 8; ++x) { s.phase_cycles[x] = ks.cyc[x]; s.extend_cycles[x] = ks.xcyc[x]; }
     float ms = 0;

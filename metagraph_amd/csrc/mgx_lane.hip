@@ -122,6 +122,8 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
         atomicAdd(&LP.P.stats->select_lines, (unsigned long long)sl);
         atomicAdd(&LP.P.stats->columns, (unsigned long long)cl);
         atomicAdd(&LP.P.stats->fast_columns, (unsigned long long)cl);
+        atomicAdd(&LP.P.stats->lane_lines, (unsigned long long)rl + (unsigned long long)sl);
+        atomicAdd(&LP.P.stats->lane_columns, (unsigned long long)cl);
         atomicAdd(&LP.P.stats->extensions, (unsigned long long)ne);
         atomicAdd(&LP.P.stats->capacity_errors, (unsigned long long)nc);
         atomicAdd(LP.done_count, (unsigned long long)nd);

@@ -88,6 +88,8 @@ def test_align_low_similarity4_through_the_kernels(npc, xdrop, df):
 @pytest.mark.parametrize("npc,xdrop,df", COMBOS)
 def test_align_low_similarity4_on_gpu(npc, xdrop, df, kernels):
     from metagraph_amd import aligner
+    if kernels not in ("auto", "grp8x8") and npc == 50.0 and df == 0.0:
+        pytest.skip("the 50-nodes-per-character searches take over a minute on the 8-lane kernel: once is enough")
     g = _graph()
     W, last, F, valid = g.export()
     G = aligner.Graph(g.k, W, last, F, valid)
