@@ -190,6 +190,50 @@ MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t &n0, uint32_t
 // reversal (Alignment::reverse_complement) is what a walk down the parent links yields anyway
 enum { LANE_EMIT_SLOTS = 0, LANE_EMIT_ARRAYS = 1, LANE_EMIT_SLOTS_REVERSED = 2 };
 
+// update_seed_filter (:100-156) for column c of a node whose columns all belong to one replay (the first node of a seed): merges
+// the column's S row into the node's vector cv[query position] (range state in vr[0] = start, vr[1] = length; length 0 = none yet)
+// exactly as chain_step does — a disjoint range is taken as it is (the gap reads ninf), an overlapping one cell by cell: a cell
+// counts as improved when S > old * rel_score_cutoff — and returns the converged score (ninf: nothing improved).
+MGX_DEV int32_t lane_merge_column(const uint8_t *slots, const uint8_t *s8rows, int32_t *cv, uint32_t *vr, int32_t c, int32_t start, double rel) {
+    const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)c * LANE_SLOT_BYTES);
+    const int32_t base = (int32_t)gld(sl + 9);
+    const uint32_t geom = gld(sl + 10);
+    const int32_t begin = (int32_t)(geom & 0xFFFF), size = (int32_t)((geom >> 16) & 0xFF), org = begin & ~3;
+    const int32_t skip = begin ? 0 : 1;
+    const int32_t cn = size - skip, query_start = start + begin - (begin ? 1 : 0);
+    auto cell_S = [&](int32_t j) -> int32_t {                       // cell j of the column (window position begin + j)
+        const int32_t d = (int32_t)(int8_t)gld(s8rows + (uint64_t)c * LANE_S8_BYTES + (begin + j - org));
+        return d == -128 ? NINF : base + d;
+    };
+    const int32_t vstart = (int32_t)gld(vr), vlen = (int32_t)gld(vr + 1);
+    int32_t converged = NINF;
+    if (vlen == 0) {
+        for (int32_t j = skip; j < size; ++j) { const int32_t sv = cell_S(j); gst(cv + start + begin + j - 1, sv); converged = imax(converged, sv); }
+        gst(vr, (uint32_t)query_start); gst(vr + 1, (uint32_t)cn);
+        return converged;
+    }
+    const int32_t vlast = vstart + vlen - 1;
+    if (query_start + cn <= vstart || query_start >= vstart + vlen) {
+        for (int32_t j = skip; j < size; ++j) { const int32_t sv = cell_S(j); gst(cv + start + begin + j - 1, sv); converged = imax(converged, sv); }
+        if (query_start + cn <= vstart) { for (int32_t p = query_start + cn; p < vstart; ++p) gst(cv + p, NINF); }
+        else { for (int32_t p = vstart + vlen; p < query_start; ++p) gst(cv + p, NINF); }
+    } else {
+        for (int32_t j = skip; j < size; ++j) {
+            const int32_t pos = start + begin + j - 1;
+            const bool old = pos >= vstart && pos <= vlast;
+            const int32_t sv = cell_S(j);
+            const int32_t vv = old ? gld(cv + pos) : NINF;
+            const bool up = (double)sv > (double)vv * rel;
+            const int32_t nv = up ? imax(vv, sv) : NINF;
+            if (up || !old) gst(cv + pos, nv);
+            if (up) converged = imax(converged, nv);
+        }
+    }
+    const int32_t nstart = imin(vstart, query_start), nend = imax(vstart + vlen, query_start + cn);
+    gst(vr, (uint32_t)nstart); gst(vr + 1, (uint32_t)(nend - nstart));
+    return converged;
+}
+
 // the lane's record in its scratch slice (lane_read's arec): words 26 .. 31 are counters that outlive a read — columns, rank-type
 // lines, select-type lines, reads finished, extensions, capacity statuses
 MGX_DEV uint32_t *lane_record(const LaneParams &LP, uint8_t *scratch) {
@@ -532,26 +576,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         gst(htab() + hs, (uint64_t)next | ((uint64_t)ptag << 44) | ((uint64_t)(uint32_t)my_idx << 32));
                     }
                     // (replay columns: see above; the column's own maximum stands in for the merged score, ninf neither way)
-                    const int32_t converged = out.converged;
+                    int32_t converged = out.converged;
                     const int32_t size = out.size, org = out.org;
-                    if (pass && replay) {
-                        // The backward pass replays the PATH's characters, which may differ from the query's.  While they have
-                        // all matched, the argument above holds.  After a mismatch this one has to: a cell with a score at a
-                        // window position above every earlier column of the node lies outside the node's vector (the ranges of
-                        // these columns are contiguous), reads ninf there and improves on it — converged != ninf.  (The band's
-                        // upper end advances with the diagonal once the insertion run behind it has its steady length.)  With
-                        // neither, the merge itself would decide: the group kernel's case.
-                        int32_t top = -1;
-#pragma unroll
-                        for (int x = 0; x < LFW; ++x) top = S[x] != NINF ? org + x : top;
-                        if (!(top >= begin && top < begin + size)) top = -1;
-                        const int32_t ap = clipping + seed_pos + 1;                     // the query character under the diagonal cell
-                        const bool same = ap >= 1 && ap <= L && qcode(ap - 1) + 1 == ccode;
-                        if (probe) replay_matching = 1;
-                        if (!same) replay_matching = 0;
-                        if (!probe && !replay_matching && !(top > replay_top)) LANE_BAIL(30);
-                        replay_top = probe ? top : imax(replay_top, top);
-                    }
                     // commit: the slot (flags, node, base, geometry, parent) and the S row
                     const int32_t base = max_val == NINF ? 0 : max_val;
                     {
@@ -582,6 +608,31 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         for (int b = 0; b < 8; ++b) gst(sr + b, sw[b]);
                     }
                     tsize = my_idx + 1;
+                    if (pass && replay) {
+                        // The backward pass replays the PATH's characters, which may differ from the query's.  While they have
+                        // all matched, the argument above holds.  After a mismatch this one may: a cell with a score at a
+                        // window position above every earlier column of the node lies outside the node's vector (the ranges of
+                        // these columns are contiguous), reads ninf there and improves on it — converged != ninf.  With
+                        // neither, the merge itself decides: the node's vector is built from the S rows of its columns so far
+                        // (lane_merge_column, update_seed_filter :100-156 as chain_step restates it) and kept from there on.
+                        int32_t top = -1;
+#pragma unroll
+                        for (int x = 0; x < LFW; ++x) top = S[x] != NINF ? org + x : top;
+                        if (!(top >= begin && top < begin + size)) top = -1;
+                        const int32_t ap = clipping + seed_pos + 1;                     // the query character under the diagonal cell
+                        const bool same = ap >= 1 && ap <= L && qcode(ap - 1) + 1 == ccode;
+                        if (probe) { replay_matching = 1; gst(arec() + 12, 0u); }
+                        if (!same) replay_matching = 0;
+                        const bool exact_on = gld(arec() + 12) != 0;
+                        if (exact_on || (!probe && !replay_matching && !(top > replay_top))) {
+                            int32_t *cv = (int32_t *)(arec() + 32);
+                            int32_t c0 = my_idx;
+                            if (!exact_on) { c0 = 1; gst(arec() + 12, 1u); gst(arec() + 14, 0u); }       // (no vector yet:) the columns so far, then this one
+                            for (int32_t c = c0; c <= my_idx; ++c)
+                                converged = lane_merge_column(slots, s8rows(), cv, arec() + 13, c, start, cfg.rel_score_cutoff);
+                        }
+                        replay_top = probe ? top : imax(replay_top, top);
+                    }
                     // a column of the general path (the children of a fork) owns an S / F record of the cell arena there
                     if (forked) cell_top += rec_words((uint32_t)((size + 5 + 3) & ~3));
                     // start cells of this column (bt_begin :815-867)

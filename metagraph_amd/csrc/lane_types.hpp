@@ -44,7 +44,7 @@ inline uint32_t lane_max_cols(uint32_t Lmax, int32_t xdrop) {
 
 inline uint64_t lane_scratch_bytes(uint32_t max_cols, uint32_t hash_slots) {
     return (uint64_t)max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)hash_slots * 8 + 2 * 2 * 32 * 4      // + two parked windows (S, F of 32 cells)
-           + (uint64_t)max_cols * 8 + LANE_MAX_RUNS * 4 + 32 * 4;      // + the forward alignment while the backward pass runs (nodes, characters, CIGAR runs), the result's scalars
+           + (uint64_t)max_cols * 8 + LANE_MAX_RUNS * 4 + 32 * 4 + (uint64_t)(LANE_MAX_L + 8) * 4;      // ... and the merged vector of a replayed node      // + the forward alignment while the backward pass runs (nodes, characters, CIGAR runs), the result's scalars
 }
 
 
