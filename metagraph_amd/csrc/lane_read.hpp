@@ -293,7 +293,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
     auto s8rows = [&]() -> uint8_t * { return sbase() + (uint64_t)LP.max_cols * LANE_SLOT_BYTES; };
     auto htab = [&]() -> uint64_t * { return (uint64_t *)(sbase() + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES)); };
     auto save_p = [&]() -> uint32_t * { return (uint32_t *)(sbase() + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8); };
-    auto save_a = [&]() -> uint32_t * { return save_p() + 2 * LFW; };
+    auto save_a = [&]() -> uint32_t * { return save_p() + 2 * LFW; };      // (unused since the parked child lives in a frontier slot)
     auto pa_node = [&]() -> uint32_t * { return save_p() + 4 * LFW; };            // the forward alignment's nodes and character codes,
     auto pa_code = [&]() -> uint32_t * { return pa_node() + LP.max_cols; };       // in path order (the seed of the backward pass)
     auto runs_fwd = [&]() -> uint32_t * { return pa_code() + LP.max_cols; };      // ... and its CIGAR runs
@@ -301,6 +301,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
     // [0 .. 8) score, offset, clip, end clip, runs, last column, nodes, characters; [8 .. 12) the forward alignment while the
     // backward pass runs: in the aggregator?, score, clip, end clip; [16 .. 25) the parked child of a fork; [26 .. 32) counters
     auto arec = [&]() -> uint32_t * { return runs_fwd() + LANE_MAX_RUNS; };
+    // a column that stays behind in the frontier: its window (S, F) and what makes it the head again — slot t of LANE_MAX_DEFER
+    auto dsave = [&](int t) -> uint32_t * { return arec() + 32 + (LANE_MAX_L + 8) + t * LANE_DSLOT_WORDS; };
     // ---- the read and its seeds (flat_read_begin).  What is derived from the seed header here is derived again after the
     // extension, where the later seeds and the result need it: nothing of it is live across the column loop.
     int32_t L, n;
@@ -462,9 +464,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 #define replay_top LANE_CI(CD_REPLAY_TOP)
 #define replay_matching LANE_CI(CD_REPLAY_MATCHING)
         replay_top = -1; replay_matching = 1;
-        bool reload = false, reload_parked = false, ext_over = false;
+        bool reload = false, ext_over = false;
+        int reload_slot = -1;                               // -1: the parent of a fork again; else the frontier slot whose column is the head now
         while (!ext_over) {
-            if (reload) { win_load(reload_parked ? save_a() : save_p()); reload = false; }
+            if (reload) { win_load(reload_slot < 0 ? save_p() : dsave(reload_slot)); reload = false; }
             bool head_dead = false;
             if (n_kids == 0) {
                 // a new head: early cut-offs when off the optimal path (:521-547), its band, its children
@@ -669,14 +672,21 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             if (!ext_over) {
                 if (compute && forked && kid == 0) {
                     // the first child of a fork waits (window in scratch) while the second is computed from the same parent
-                    fa_alive = c_alive; fa_conv = c_conv; fa_max_val = c_max_val;
-                    // (the rest of the parked child: to the lane's scratch, next to its window)
-                    gst(arec() + 16, (uint32_t)c_org); gst(arec() + 17, (uint32_t)c_trim); gst(arec() + 18, (uint32_t)c_size);
-                    gst(arec() + 19, (uint32_t)next_offset); gst(arec() + 20, (uint32_t)c_idx); gst(arec() + 21, (uint32_t)c_t_score);
-                    gst(arec() + 22, (uint32_t)c_t_nod); gst(arec() + 23, (uint32_t)c_t_pos); gst(arec() + 24, c_node);
-                    if (c_alive) win_save(save_a());
+                    fa_alive = 0; fa_conv = c_conv; fa_max_val = c_max_val;
+                    if (c_alive) {
+                        int slot = -1;
+#pragma unroll
+                        for (int t = LANE_MAX_DEFER - 1; t >= 0; --t) slot = d_score(t) == INT32_MIN ? t : slot;
+                        if (slot < 0) LANE_BAIL(28);
+                        fa_alive = 1 + slot;
+                        uint32_t *ds = dsave(slot);
+                        win_save(ds);
+                        gst(ds + 64, (uint32_t)c_org); gst(ds + 65, (uint32_t)c_trim); gst(ds + 66, (uint32_t)c_size);
+                        gst(ds + 67, (uint32_t)next_offset); gst(ds + 68, (uint32_t)c_idx); gst(ds + 69, (uint32_t)c_t_score);
+                        gst(ds + 70, (uint32_t)c_t_nod); gst(ds + 71, (uint32_t)c_t_pos); gst(ds + 72, c_node);
+                    }
                     kid = 1;
-                    reload = true; reload_parked = false;
+                    reload = true; reload_slot = -1;
                 } else {
                     bool none = true;
 #pragma unroll
@@ -691,6 +701,35 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         // that stayed behind.  A child goes on as the head; a column that stayed behind must be dead by now.
                         if (!(compute && forked)) fa_alive = 0;
                         bool have_head = false, frontier_done = false;
+                        // a column goes (back) into the frontier: the parked child has its slot already, the child in registers takes
+                        // a free one — window, what makes it the head again, and (score, maximum) for the pops
+                        auto stay_behind_c = [&](int avoid) -> bool {      // avoid: the slot whose column is about to become the head
+                            int slot = -1;
+#pragma unroll
+                            for (int t = LANE_MAX_DEFER - 1; t >= 0; --t) slot = (d_score(t) == INT32_MIN && t + 1 != fa_alive && t != avoid) ? t : slot;
+                            if (slot < 0) return false;
+                            uint32_t *ds = dsave(slot);
+                            win_save(ds);
+                            gst(ds + 64, (uint32_t)c_org); gst(ds + 65, (uint32_t)c_trim); gst(ds + 66, (uint32_t)c_size);
+                            gst(ds + 67, (uint32_t)next_offset); gst(ds + 68, (uint32_t)c_idx); gst(ds + 69, (uint32_t)c_t_score);
+                            gst(ds + 70, (uint32_t)c_t_nod); gst(ds + 71, (uint32_t)c_t_pos); gst(ds + 72, c_node);
+#pragma unroll
+                            for (int t = 0; t < LANE_MAX_DEFER; ++t) { if (t == slot) { d_score(t) = c_conv; d_max(t) = c_max_val; } }
+                            // (a chain column that stays behind gets an S / F record in the cell arena; a fork's children have theirs)
+                            if (!forked) cell_top += rec_words((uint32_t)LFW);
+                            return true;
+                        };
+                        auto stay_behind_a = [&]() {
+#pragma unroll
+                            for (int t = 0; t < LANE_MAX_DEFER; ++t) { if (t + 1 == fa_alive) { d_score(t) = fa_conv; d_max(t) = fa_max_val; } }
+                        };
+                        auto head_from_slot = [&](int slot) {
+                            const uint32_t *ds = dsave(slot);
+                            f_org = (int32_t)gld(ds + 64); f_trim = (int32_t)gld(ds + 65); f_size = (int32_t)gld(ds + 66);
+                            f_offset = (int32_t)gld(ds + 67); f_idx = (int32_t)gld(ds + 68); t_score = (int32_t)gld(ds + 69);
+                            t_nod = (int32_t)gld(ds + 70); t_pos = (int32_t)gld(ds + 71); f_node = gld(ds + 72);
+                            reload = true; reload_slot = slot;                     // its window comes back at the top of the loop
+                        };
                         while (!frontier_done) {
                             int32_t top = INT32_MIN;
                             int n_top = 0;
@@ -706,26 +745,12 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 frontier_done = true;                                  // the frontier is empty
                             } else if (a_top || c_top) {
                                 if (n_top > 1) LANE_BAIL(27);                          // an equal-score batch (:491-500): the general path
-                                // the other child stays behind
-                                const int32_t o_alive = a_top ? c_alive : (int32_t)fa_alive, o_conv = a_top ? c_conv : (int32_t)fa_conv;
-                                const int32_t o_max = a_top ? c_max_val : (int32_t)fa_max_val;
-                                if (o_alive) {
-                                    bool put = false;
-#pragma unroll
-                                    for (int t = 0; t < LANE_MAX_DEFER; ++t) {
-                                        if (!put && d_score(t) == INT32_MIN) { d_score(t) = o_conv; d_max(t) = o_max; put = true; }
-                                    }
-                                    if (!put) LANE_BAIL(28);
-                                    // (a chain column that stays behind gets an S / F record there; a fork's children have theirs)
-                                    if (!forked) cell_top += rec_words((uint32_t)LFW);
-                                }
                                 if (a_top) {
-                                    reload = true; reload_parked = true;               // its window comes back at the top of the loop
-                                    f_org = (int32_t)gld(arec() + 16); f_trim = (int32_t)gld(arec() + 17); f_size = (int32_t)gld(arec() + 18);
-                                    f_offset = (int32_t)gld(arec() + 19); f_max_val = fa_max_val;
-                                    f_node = gld(arec() + 24); f_idx = (int32_t)gld(arec() + 20); t_score = (int32_t)gld(arec() + 21);
-                                    t_nod = (int32_t)gld(arec() + 22); t_pos = (int32_t)gld(arec() + 23);
+                                    if (c_alive && !stay_behind_c(fa_alive - 1)) LANE_BAIL(28);
+                                    f_max_val = fa_max_val;
+                                    head_from_slot(fa_alive - 1);
                                 } else {
+                                    if (fa_alive) stay_behind_a();
                                     f_org = c_org; f_trim = c_trim; f_size = c_size; f_offset = next_offset; f_max_val = c_max_val;
                                     f_node = c_node; f_idx = c_idx; t_score = c_t_score; t_nod = c_t_nod; t_pos = c_t_pos;
                                 }
@@ -733,22 +758,39 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 have_head = true;
                                 frontier_done = true;
                             } else {
-                                // a column that stayed behind is popped: cut-offs, then its band — which must be empty
-                                bool done1 = false, stop_all = false;
+                                // a column that stayed behind is popped: cut-offs, then its band — empty: it is dead; else it is the head
+                                if (n_top > 1) {
+                                    // (an equal-score batch of such columns: harmless if they are all dead, else the general path)
+                                    bool any_live = false;
 #pragma unroll
-                                for (int t = 0; t < LANE_MAX_DEFER; ++t) {
-                                    if (!done1 && d_score(t) == top) {
-                                        done1 = true;
-                                        const int32_t dm = d_max(t);
-                                        if (dm < best_score) {
-                                            if ((double)tsize / (double)window_size >= cfg.max_nodes_per_seq_char) stop_all = true;
-                                            else if ((double)table_size_bytes() / 1000000.0 > cfg.max_ram_per_alignment) stop_all = true;
-                                        }
-                                        if (!stop_all && dm >= xdrop_cutoff) LANE_BAIL(29);  // it would be extended
-                                        d_score(t) = INT32_MIN;
-                                    }
+                                    for (int t = 0; t < LANE_MAX_DEFER; ++t) any_live |= d_score(t) == top && d_max(t) >= xdrop_cutoff;
+                                    if (any_live) LANE_BAIL(27);
                                 }
-                                if (stop_all) frontier_done = true;
+                                int slot = -1;
+#pragma unroll
+                                for (int t = LANE_MAX_DEFER - 1; t >= 0; --t) slot = d_score(t) == top ? t : slot;
+                                int32_t dm = NINF;
+#pragma unroll
+                                for (int t = 0; t < LANE_MAX_DEFER; ++t) dm = t == slot ? (int32_t)d_max(t) : dm;
+                                bool stop_all = false;
+                                if (dm < best_score) {
+                                    if ((double)tsize / (double)window_size >= cfg.max_nodes_per_seq_char) stop_all = true;
+                                    else if ((double)table_size_bytes() / 1000000.0 > cfg.max_ram_per_alignment) stop_all = true;
+                                }
+#pragma unroll
+                                for (int t = 0; t < LANE_MAX_DEFER; ++t) { if (t == slot) d_score(t) = INT32_MIN; }
+                                if (stop_all) {
+                                    frontier_done = true;                              // (extend() drops the whole frontier)
+                                } else if (dm >= xdrop_cutoff) {
+                                    // it goes on: the children just computed stay behind in their turn
+                                    if (fa_alive) stay_behind_a();
+                                    if (c_alive && !stay_behind_c(slot)) LANE_BAIL(28);
+                                    f_max_val = dm;
+                                    head_from_slot(slot);
+                                    if (!((f_trim & 3) + f_size + 3 <= LFW)) LANE_BAIL(16);
+                                    have_head = true;
+                                    frontier_done = true;
+                                }
                             }
                         }
                         if (!have_head) ext_over = true;

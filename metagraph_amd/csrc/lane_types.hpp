@@ -16,6 +16,7 @@ constexpr int LANE_MAX_RUNS = 16;          // CIGAR runs of a trace kept in LDS
 constexpr int LANE_MAX_SEEDS = 512;        // seeds of the strand (the later ones are checked against the extension one by one)
 constexpr int LANE_SLOT_BYTES = 64;        // per column: 32 flag bytes + node + base + geometry (+ 4 unused words)
 constexpr int LANE_MAX_DEFER = 3;          // columns that may stay behind in the frontier (the other children of forks)
+constexpr int LANE_DSLOT_WORDS = 80;       // a column that stays behind: its window (64 words) + nine words of column state
 constexpr int LANE_S8_BYTES = 32;          // per column: S of the window as 8-bit offsets from `base` (read at the trace's end only)
 
 // what one launch of the lane kernel needs on top of AlignParams
@@ -44,7 +45,8 @@ inline uint32_t lane_max_cols(uint32_t Lmax, int32_t xdrop) {
 
 inline uint64_t lane_scratch_bytes(uint32_t max_cols, uint32_t hash_slots) {
     return (uint64_t)max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)hash_slots * 8 + 2 * 2 * 32 * 4      // + two parked windows (S, F of 32 cells)
-           + (uint64_t)max_cols * 8 + LANE_MAX_RUNS * 4 + 32 * 4 + (uint64_t)(LANE_MAX_L + 8) * 4;      // ... and the merged vector of a replayed node      // + the forward alignment while the backward pass runs (nodes, characters, CIGAR runs), the result's scalars
+           + (uint64_t)max_cols * 8 + LANE_MAX_RUNS * 4 + 32 * 4 + (uint64_t)(LANE_MAX_L + 8) * 4       // ... and the merged vector of a replayed node
+           + (uint64_t)LANE_MAX_DEFER * LANE_DSLOT_WORDS * 4;      // + the columns that stayed behind in the frontier      // + the forward alignment while the backward pass runs (nodes, characters, CIGAR runs), the result's scalars
 }
 
 
