@@ -90,9 +90,12 @@ def results_to_py(res):
             cig = "".join("%d%s" % (res.cigar[a.cigar_begin + i].len, OP_CHARS[res.cigar[a.cigar_begin + i].op])
                           for i in range(a.n_cigar))
             seq = C.string_at(C.addressof(res.seqs.contents) + a.seq_begin, a.seq_len).decode() if a.seq_len else ""
-            alns.append({"score": a.score, "offset": a.offset, "clipping": a.clipping,
-                         "end_clipping": a.end_clipping, "num_matches": a.num_matches, "nodes": nodes,
-                         "cigar": cig, "sequence": seq, "orientation": int(a.orientation)})
+            d = {"score": a.score, "offset": a.offset, "clipping": a.clipping,
+                 "end_clipping": a.end_clipping, "num_matches": a.num_matches, "nodes": nodes,
+                 "cigar": cig, "sequence": seq, "orientation": int(a.orientation)}
+            if res.labels:                     # label-aware alignment only
+                d["labels"] = [res.labels[a.labels_begin + i] for i in range(a.n_labels)]
+            alns.append(d)
         out.append(alns)
     return out
 

@@ -63,6 +63,12 @@
 #ifndef MGX_WITH_PRIMARY
 #define MGX_WITH_PRIMARY 0
 #endif
+// Label-aware alignment (LabeledAligner / LabeledExtender, A/aligner_labeled.{hpp,cpp}) is compiled into its own instantiation
+// of the extension kernel (-DMGX_WITH_LABELS=1: mgx_lab64.hip) and into the host model; AlignParams::labeled switches it on
+// at run time there.  Every other kernel is the code it was without it.
+#ifndef MGX_WITH_LABELS
+#define MGX_WITH_LABELS 0
+#endif
 
 // timing ablations (results become WRONG) are compiled into -DMGX_PROBES builds only
 #ifdef MGX_PROBES
@@ -74,6 +80,7 @@
 namespace mgx {
 
 constexpr bool kWithPrimary = MGX_WITH_PRIMARY != 0;
+constexpr bool kWithLabels = MGX_WITH_LABELS != 0;
 
 #if defined(MGX_PARAMS_IN_LDS) && MGX_PARAMS_IN_LDS
 __shared__ AlignParams g_params;
@@ -217,7 +224,10 @@ struct BtIndex { int32_t score, neg_off_diag, neg_i, pos; };
 #define MGX_MAX_ALT 1
 #endif
 constexpr int MAX_ALT = MGX_MAX_ALT;
-constexpr int N_ALN = 4 * MAX_ALT;           // alignment buffers: extension results, their reversals, backward results, the best
+// label-aware alignment: a backtracking reports up to LAB_EXT alignments (one per label subset of the seed), the per-label
+// aggregator holds up to LAB_POOL_PER_ALT x num_alternative_paths alignments (DevLimits::lab_ext / lab_pool, host_common.hpp)
+constexpr int LAB_EXT = 8, LAB_POOL_PER_ALT = 32;
+constexpr int N_ALN = kWithLabels ? 3 * LAB_EXT + LAB_POOL_PER_ALT * MAX_ALT : 4 * MAX_ALT;   // alignment buffers: extension results, their reversals, backward results, the best
 
 // the convergence table of one extender (layout and entry kinds: see the "convergence checker" section)
 struct ConvRec { uint32_t off; int32_t start, len; uint32_t cap; };      // a pool entry: words [off, off + cap) hold [start, start + len)
@@ -254,6 +264,9 @@ struct DevAln {                  // Alignment (alignment.hpp:132-331)
     int32_t qbegin, qlen;        // query_view within the strand's query
     int32_t orientation;         // strand of the query this alignment is on
     int32_t extra_score;
+#if MGX_WITH_LABELS
+    uint32_t lab;                // label_columns (alignment.hpp:285): a set of the read's label arena (label_sets.hpp), 0 = none
+#endif
 };
 
 MGX_DEV int32_t aln_clipping(const DevAln &a) {
@@ -270,6 +283,9 @@ struct SeedRef {
     int32_t n_nodes, seq_len;
     int32_t clipping, end_clipping, qlen, offset, score;
     int32_t orientation;
+#if MGX_WITH_LABELS
+    uint32_t lab;                // the seed's label_columns
+#endif
 };
 
 struct ExtenderState {           // one per strand (Extender object in dbg_aligner.cpp:287,292)
@@ -428,6 +444,18 @@ struct Wave {
     uint32_t xcyc[XCYC_N];       // extend() breakdown: pop, general steps, chain steps (probe builds: per-stage timers)
     uint32_t n_columns, n_extensions, n_fast_columns;
     int32_t status;
+#if MGX_WITH_LABELS
+    // label-aware alignment (label_sets.hpp / label_driver.hpp)
+    uint32_t *lab;               // the read's label-set arena: word 0 = 0 (the empty set), per-extension sets grow up from
+    uint32_t lab_lo, lab_hi;     // lab_lo, per-read sets (seeds, alignments) grow down from lab_hi
+    uint32_t *col_lab;           // [max_columns] LabeledExtender::node_labels_ of the DP table
+    uint32_t *seed_lab[2];       // [max_seeds] label_columns of the seeds
+    int32_t last_flushed;        // LabeledExtender::last_flushed_table_i_
+    uint32_t remaining_lab;      // remaining_labels_i_
+    uint32_t bt_isect, bt_diff;  // label_intersection_ / label_diff_ of the start cell being walked
+    uint32_t out_lab[5];         // label sets of the children in out_nodes
+    uint32_t *agg;               // the per-label aggregator's queues (label_driver.hpp)
+#endif
 };
 
 MGX_DEV Block wave_blk_cache(const Wave &w) {
@@ -463,6 +491,10 @@ MGX_DEV bool aln_less(const DevAln &a, const DevAln &b) {
 
 MGX_HD uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
 
+// words of the per-label aggregator's state (label_driver.hpp): header, one record per label queue, reference counts
+constexpr uint32_t LAB_MAX_QUEUES = 64;
+MGX_HD uint64_t lab_agg_words(const DevLimits &lim) { return 16 + (uint64_t)LAB_MAX_QUEUES * 8 + lim.lab_pool + 8 + (LAB_MAX_QUEUES * 4 + 16) + lim.lab_pool + 8; }
+
 // byte size of one wave's arena slice
 MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     uint64_t L = lim.Lmax, Lp = align8(L + 8);
@@ -491,6 +523,9 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 6 * align8((L + 16) * 4);                      // staging
     b += 64 + 2 * (align8(2ull * lim.hash_size * 8) + align8(((uint64_t)lim.max_columns + lim.max_path) * 16) + 64 + align8((uint64_t)lim.conv_pool_words * 4));
     b += (uint64_t)lim.n_aln * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
+    if (lim.lab_words)                                  // label-aware alignment: set arena, column / seed handles, aggregator queues
+        b += align8((uint64_t)lim.lab_words * 4) + align8((uint64_t)lim.max_columns * 4) + 2 * align8((uint64_t)lim.max_seeds * 4)
+             + align8(lab_agg_words(lim) * 4);
     return (b + 63) & ~63ull;          // slices keep the 32-byte alignment of the hash slots and the 16-byte one of the cell records
 }
 
@@ -593,6 +628,16 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
         w.aln[a].cigar = (uint32_t *)take((uint64_t)lim.max_path * 4);
         w.aln[a].seq = take(lim.max_path);
     }
+#if MGX_WITH_LABELS
+    if (lim.lab_words) {
+        w.lab = (uint32_t *)take((uint64_t)lim.lab_words * 4);
+        w.col_lab = (uint32_t *)take((uint64_t)lim.max_columns * 4);
+        for (int s = 0; s < 2; ++s) w.seed_lab[s] = (uint32_t *)take((uint64_t)lim.max_seeds * 4);
+        w.agg = (uint32_t *)take(lab_agg_words(lim) * 4);
+    } else {
+        w.lab = nullptr; w.col_lab = nullptr; w.seed_lab[0] = w.seed_lab[1] = nullptr; w.agg = nullptr;
+    }
+#endif
 }
 
 // LDS bytes that hold every "fast" array of carve() for a given Lmax
@@ -2376,6 +2421,9 @@ enum { FR_CONT = 0, FR_END = 1, FR_FALLBACK = 3, FR_STOP = 4, FR_ERROR = 5 };
 } // namespace mgx
 #include "lane_column.hpp"
 namespace mgx {
+#if MGX_WITH_LABELS
+#include "label_sets.hpp"
+#endif
 
 // ---- general path: one popped column `i` with all its children (staging buffers, frontier arrays) ----
 // returns 0, or 1 = the extension is over (capacity error; w.status says which)
@@ -2428,8 +2476,17 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const int32_t i, const bool 
     uint8_t *out_chars = w.out_chars;
     int32_t *out_scores = w.out_scores;
     if (!children_ready) x.n_valid = 0;                       // the children list is about to be overwritten
+#if MGX_WITH_LABELS
+    int n_out = children_ready ? x.f_n_out : uni(call_outgoing(w, E, col, force_fixed_seed, out_nodes, out_chars, out_scores));
+    wave_sync();
+    if (P.labeled) {
+        n_out = lab_filter_children(w, i, n_out);           // LabeledExtender::call_outgoing
+        if (w.status != ST_OK) return 1;
+    }
+#else
     const int n_out = children_ready ? x.f_n_out : uni(call_outgoing(w, E, col, force_fixed_seed, out_nodes, out_chars, out_scores));
     wave_sync();
+#endif
     if (n_out == 0) {
         if (x.n_tips < max_columns) gst(w.tips + x.n_tips++, (uint32_t)i);
         return 0;
@@ -2502,6 +2559,9 @@ MGX_DEV int general_step(Wave &w, ExtenderState &E, const int32_t i, const bool 
         const int32_t my_idx = x.tsize;
         cur.self = my_idx;
         col_store(w, my_idx, cur);
+#if MGX_WITH_LABELS
+        if (P.labeled) w.col_lab[my_idx] = w.out_lab[oi];
+#endif
         w.st[cb].col = my_idx;
         x.cell_top += rec_words((uint32_t)cur_wc);
         x.tsize = my_idx + 1;
@@ -3199,6 +3259,18 @@ MGX_DEV bool extend_begin(Wave &w, const int es, const SeedRef &seed, bool force
     // aliases point into the one column table: usable when nothing runs another extension between this one and the last
     // reader of its convergence table, i.e. with one alignment per seed (aln_both checks the later seeds before the backward pass)
     x.alias_ok = n_alt_of(w) == 1 && !P.no_alias ? 1u : 0u;
+#if MGX_WITH_LABELS
+    if (P.labeled) {
+        // LabeledExtender::set_seed (aligner_labeled.cpp:139-174, no coordinates): the seed's first node counts as flushed,
+        // the seed's labels are what backtracking has to account for; the per-extension sets of the last extension are dead
+        x.alias_ok = 0;
+        w.lab_lo = 1;
+        w.last_flushed = 1;
+        w.remaining_lab = seed.lab;
+        w.col_lab[0] = seed.lab;
+        w.bt_isect = w.bt_diff = 0;
+    }
+#endif
     E.conv.start = (uint32_t)x.start;
     x.cell_top = 0;
     x.tsize = 0;
@@ -3271,7 +3343,7 @@ MGX_DEV int extend_step(Wave &w, const int es, ChainRegs &R) {
     XState &x = w.x;
     // the chain format keeps S as 16-bit offsets from the column maximum: cells live within x-drop (+ one match score) of
     // it, so any x-drop up to 30000 fits; wider (the unit tests' "no x-drop") takes the general path
-    const bool use_fast = !P.no_fast && P.cfg.xdrop <= 30000;
+    const bool use_fast = !P.no_fast && P.cfg.xdrop <= 30000 && !(kWithLabels && P.labeled);      // (labels: every column through general_step)
     int &mode = R.mode;
     LV<int32_t> *pS = R.pS, *pF = R.pF;
     SeedRun &run = R.run;
@@ -3403,6 +3475,9 @@ MGX_DEV void bt_begin(Wave &w, const int es, const SeedRef &seed, int32_t min_pa
     const int32_t min_start_score = min_path_score;
     const int32_t right_end_bonus = cfg.right_end_bonus;
     const int32_t tsize = er.table_size;
+#if MGX_WITH_LABELS
+    if (P.labeled) { lab_flush(w, tsize); if (w.status != ST_OK) { w.bt.stage = BT_OVER; w.bt.produced = 0; return; } }     // LabeledExtender::backtrack (aligner_labeled.hpp:32-43)
+#endif
 #ifdef MGX_BT_PROBE
     uint64_t tbt = xclock();
 #define BT_T(slot) { const uint64_t t_ = xclock(); w.xcyc[slot] += t_ - tbt; tbt = t_; }
@@ -3533,7 +3608,13 @@ MGX_DEV bool bt_step(Wave &w, const SeedRef &seed, const DevAln *seed_aln, DevAl
     uint64_t tbt = xclock();
 #endif
     if (b.stage == BT_POP) {
+#if MGX_WITH_LABELS
+        // LabeledExtender::terminate_backtrack_start (aligner_labeled.hpp:49-52): until every label of the seed is accounted for
+        const bool lab_on = P.labeled != 0;
+        if (lab_on ? !(b.remaining > 0 && w.remaining_lab) : !(b.remaining > 0 && b.produced < b.n_max)) {
+#else
         if (!(b.remaining > 0 && b.produced < b.n_max)) {        // terminate_backtrack_start: extensions.size() >= num_alternative_paths
+#endif
             b.stage = BT_FINISH;
         } else {
             // pop the lexicographic maximum (score, -off_diag, -i, pos) (:873-879): four lane-parallel passes
@@ -3582,6 +3663,15 @@ MGX_DEV bool bt_step(Wave &w, const SeedRef &seed, const DevAln *seed_aln, DevAl
             b.remaining = remaining - 1;
             const int32_t j = -cur.neg_i;
             if (!prev_start_test_and_set(w, j)) return false;       // skip_backtrack_start (next pop on the next step)
+#if MGX_WITH_LABELS
+            if (lab_on) {
+                // LabeledExtender::skip_backtrack_start (aligner_labeled.cpp:304-326): the labels this start cell can still
+                // account for; none: skip it
+                lab_isect_diff(w, w.remaining_lab, w.col_lab[j], &w.bt_isect, &w.bt_diff);
+                if (w.status != ST_OK) return true;
+                if (!w.bt_isect) return false;
+            }
+#endif
             if (cur.score - er.min_cell_score < b.best_score) { b.stage = BT_FINISH; }
             else {
                 b.j = j; b.score = cur.score; b.pos = cur.pos; b.end_pos = cur.pos;
@@ -3806,6 +3896,9 @@ MGX_DEV bool bt_step(Wave &w, const SeedRef &seed, const DevAln *seed_aln, DevAl
                     && (pos || cur_cell_score == gld(w.cells + col_load(w, 0).cells))
                     && (cfg.allow_left_trim || !j)) {
                 // construct_alignment (:774-798): clipping = pos, window = [pos, end_pos)
+#if MGX_WITH_LABELS
+                if (b.produced >= b.n_max) { w.status = ST_CAPACITY; return true; }      // (labels: more alignments than buffers)
+#endif
                 DevAln &out = outs[b.produced];
                 int32_t nc = 0;
                 uint32_t clip_total = (uint32_t)(seed_clipping + pos);      // cigar clip + extend_query_begin
@@ -3833,6 +3926,15 @@ MGX_DEV bool bt_step(Wave &w, const SeedRef &seed, const DevAln *seed_aln, DevAl
                 out.score = score; out.offset = align_offset;
                 out.qbegin = seed_clipping + pos; out.qlen = end_pos - pos;
                 out.orientation = seed.orientation; out.extra_score = extra_score;
+#if MGX_WITH_LABELS
+                if (P.labeled) {
+                    // LabeledExtender::call_alignments (aligner_labeled.cpp:328-448, no coordinates)
+                    out.lab = lab_persist(w, w.bt_isect);
+                    w.remaining_lab = w.bt_diff;
+                    w.bt_isect = 0;
+                    if (w.status != ST_OK) return true;
+                } else out.lab = 0;
+#endif
                 wave_sync();
                 ++b.produced;
             }
@@ -3897,6 +3999,9 @@ MGX_DEV void seed_as_alignment(Wave &w, const SeedRef &seed, DevAln &out) {
     out.n_cigar = nc; out.n_nodes = seed.n_nodes; out.seq_len = seed.seq_len;
     out.score = seed.score; out.offset = seed.offset;
     out.qbegin = seed.clipping; out.qlen = seed.qlen; out.orientation = seed.orientation; out.extra_score = 0;
+#if MGX_WITH_LABELS
+    out.lab = seed.lab;
+#endif
     wave_sync();
 }
 
@@ -3913,6 +4018,9 @@ MGX_NI_G4 void copy_aln(DevAln &dst, const DevAln &src) {
     dst.n_nodes = src.n_nodes; dst.n_cigar = src.n_cigar; dst.seq_len = src.seq_len;
     dst.score = src.score; dst.offset = src.offset; dst.qbegin = src.qbegin; dst.qlen = src.qlen;
     dst.orientation = src.orientation; dst.extra_score = src.extra_score;
+#if MGX_WITH_LABELS
+    dst.lab = src.lab;
+#endif
     wave_sync();
 }
 
@@ -4029,6 +4137,9 @@ MGX_DEV SeedRef seedref_from_aln(const DevAln &a) {
     s.nodes = a.nodes; s.seq = a.seq; s.n_nodes = a.n_nodes; s.seq_len = a.seq_len;
     s.clipping = aln_clipping(a); s.end_clipping = aln_end_clipping(a); s.qlen = a.qlen;
     s.offset = a.offset; s.score = a.score; s.orientation = a.orientation;
+#if MGX_WITH_LABELS
+    s.lab = a.lab;
+#endif
     return s;
 }
 
@@ -4084,6 +4195,9 @@ MGX_DEV SeedRef seedref_from_seed(const Wave &w, int s, int32_t idx, int32_t *su
     int32_t ms = w.psum_lin[s] ? (int32_t)sd.length * w.psum_lin[s]
                                : w.psum[s][sd.clipping] - w.psum[s][sd.clipping + sd.length];
     r.score = ms + (!sd.clipping ? cfg.left_end_bonus : 0) + (!r.end_clipping ? cfg.right_end_bonus : 0);
+#if MGX_WITH_LABELS
+    r.lab = MGX_PARAMS_OF(w).labeled ? w.seed_lab[s][idx] : 0;
+#endif
     (void)sub_node_slot;
     return r;
 }
@@ -4358,6 +4472,10 @@ MGX_NI_G4 void align_core_fwd(Wave &w) {
     }
 }
 
+#if MGX_WITH_LABELS
+#include "label_driver.hpp"
+#endif
+
 #endif  // MGX_NO_EXTEND
 
 // Predicted extension work of a read from its seeds: (number of extensions, columns), the sort key that
@@ -4466,6 +4584,15 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
             wave_sync();
             if (MGX_ABLATED(w, 8u)) { w.n_seeds[0] = w.n_seeds[1] = 0; }          // timing probe: fetch + pick-up + output only
         }
+#if MGX_WITH_LABELS && !defined(MGX_NO_EXTEND)
+        if ((PHASE & PH_EXTEND) && P.labeled && w.status == ST_OK) {
+            // LabeledAligner::build_seeders (aligner_labeled.cpp:479-558): the label filter on top of the seeders' output
+            w.lab[0] = 0; w.lab_lo = 1; w.lab_hi = P.lim.lab_words;
+            lab_agg_reset(w);
+            lab_filter_seeds(w, 0);
+            if (have_rc && w.status == ST_OK) lab_filter_seeds(w, 1);
+        }
+#endif
         if constexpr (PHASE == PH_SEED) {
             // publish: header, seeds, work key; the extension kernel writes the read's result record
             SeedHdr h;
@@ -4529,9 +4656,15 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
                         if (ph == 1 && !((double)m_second >= (double)m_first * P.cfg.rel_score_cutoff)) break;
                         if (ph != w.resume_phase) w.resume_i = 0;
                         w.resume_phase = ph;
+#if MGX_WITH_LABELS
+                        if (P.labeled) { lab_aln_both(w, ph == 0 ? first : 1 - first); continue; }
+#endif
                         aln_both(w, ph == 0 ? first : 1 - first);
                     }
                 } else {
+#if MGX_WITH_LABELS
+                    if (P.labeled) lab_align_core_fwd(w); else
+#endif
                     align_core_fwd(w);
                 }
                 if (w.status != ST_RETRY || !P.resume_out) break;
@@ -4619,6 +4752,66 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
 
     rr.status = w.status;
     rr.n_extensions = w.n_extensions; rr.n_columns = w.n_columns;
+#if MGX_WITH_LABELS && !defined(MGX_NO_EXTEND)
+    if (P.labeled && w.status == ST_OK && (PHASE & PH_EXTEND)) {
+        // the labeled aggregator's alignments; stream layout as below, with every alignment followed by its label count and
+        // its labels (ascending)
+        uint32_t *order = w.agg + ag_list0(P.lim) + (LAB_MAX_QUEUES * 4 + 16);
+        const int n_out = lab_get_alignments(w, order);
+        uint32_t words = 0;
+        for (int t = 0; t < n_out; ++t) {
+            const DevAln &a = lab_pool_aln(w, order[t]);
+            words += (t ? 6u : 0u) + (uint32_t)a.n_nodes + (uint32_t)a.n_cigar + ((uint32_t)a.seq_len + 3) / 4 + 1u + (a.lab ? lab_size(w, a.lab) : 0u);
+        }
+        if (n_out) {
+            LV<uint64_t> offv;
+            FOR_LANES(l) {
+                offv[l] = 0;
+                if (l == 0) {
+#if MGX_WAVE_EMU
+                    offv[l] = *P.out_cursor; *P.out_cursor += words;
+#else
+                    offv[l] = atomicAdd(P.out_cursor, (unsigned long long)words);
+#endif
+                }
+            }
+            const uint64_t so = wave_bcast(offv, 0);
+            if (so + words > P.out_capacity) {
+                rr.status = ST_CAPACITY;
+            } else {
+                uint32_t *dst = P.out_stream + so;
+                for (int t = 0; t < n_out; ++t) {
+                    const DevAln &a = lab_pool_aln(w, order[t]);
+                    if (t == 0) {
+                        rr.score = a.score; rr.offset = (uint32_t)a.offset;
+                        rr.n_nodes = (uint32_t)a.n_nodes; rr.n_cigar = (uint32_t)a.n_cigar; rr.seq_len = (uint32_t)a.seq_len;
+                        rr.orientation = (uint32_t)a.orientation; rr.stream_off = so;
+                    } else {
+                        dst[0] = (uint32_t)a.score; dst[1] = (uint32_t)a.offset; dst[2] = (uint32_t)a.n_nodes;
+                        dst[3] = (uint32_t)a.n_cigar; dst[4] = (uint32_t)a.seq_len; dst[5] = (uint32_t)a.orientation;
+                        dst += 6;
+                    }
+                    uint8_t *dseq = (uint8_t *)(dst + a.n_nodes + a.n_cigar);
+                    const int32_t n = imax(imax(a.n_nodes, a.n_cigar), a.seq_len);
+                    for (int32_t base = 0; base < n; base += WAVE) {
+                        FOR_LANES(l) {
+                            int32_t x = base + l;
+                            if (x < a.n_nodes) dst[x] = a.nodes[x];
+                            if (x < a.n_cigar) dst[a.n_nodes + x] = a.cigar[x];
+                            if (x < a.seq_len) dseq[x] = a.seq[x];
+                        }
+                    }
+                    dst += (uint32_t)a.n_nodes + (uint32_t)a.n_cigar + ((uint32_t)a.seq_len + 3) / 4;
+                    const uint32_t nl = a.lab ? lab_size(w, a.lab) : 0u;
+                    dst[0] = nl;
+                    for (uint32_t x = 0; x < nl; ++x) dst[1 + x] = lab_at(w, a.lab, x);
+                    dst += 1 + nl;
+                }
+                rr.n_alignments = n_out;
+            }
+        }
+    } else
+#endif
     if (w.status == ST_OK && w.have_best) {
         // get_alignments (aligner_aggregator.hpp:180-202): stable sort ascending by LocalAlignmentLess, emitted from the
         // back, empty alignments dropped

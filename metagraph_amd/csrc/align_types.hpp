@@ -35,6 +35,10 @@ struct DevLimits {
     uint32_t hash_size;      // power of two
     uint32_t n_aln;          // alignment buffers per read: 4 * num_alternative_paths
     uint32_t conv_pool_words;    // int32 words of convergence vectors per extender (pool; see the convergence checker section of align_core.hpp)
+    // label-aware alignment only (0 otherwise; see the "label sets" section of align_core.hpp)
+    uint32_t lab_words;          // uint32 words of the per-read label-set arena
+    uint32_t lab_ext;            // alignments one backtracking may report (one per label subset of its seed)
+    uint32_t lab_pool;           // alignments the per-label aggregator may hold at a time
 };
 
 // per-read result header; variable-length parts live in the output stream
@@ -136,6 +140,13 @@ struct AlignParams {
     uint32_t groups_per_wave;            // extension kernel: groups of a wavefront that take reads (0 = all).  A batch with fewer reads
                                          // than resident groups is spread over the wavefronts, so that a long read does not run in
                                          // lock-step with seven others
+    // label-aware alignment (LabeledAligner, A/aligner_labeled.{hpp,cpp}): the row-major label matrix of mgx_annot.hip —
+    // row = node - 1 (AnnotatedDBG::graph_to_anno_index); head word: count:16 | single label or offset into more[]
+    uint32_t labeled;                    // 1: label-aware (kernels built with MGX_WITH_LABELS only)
+    const uint64_t *anno_head;
+    const uint32_t *anno_count;
+    const uint32_t *anno_more;
+    uint64_t anno_rows;
     uint32_t ablate;                     // timing probes only (results become WRONG): bit 0 = no convergence table in the chain
                                          // step, bit 1 = no cell records / column metadata stores, bit 2 = no backtrack
 };

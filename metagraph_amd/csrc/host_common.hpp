@@ -23,7 +23,7 @@ inline bool check_config_scores(const mgx_config &c) {
 
 // DBGAligner<>::DBGAligner (dbg_aligner.cpp:33-61) + what this build implements.  Returns MGX_OK or
 // an error code with a message in *err.
-inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, DevConfig *d, std::string *err) {
+inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, DevConfig *d, std::string *err, bool labeled = false) {
     *out = in;
     mgx_config &c = *out;
     if (!c.min_seed_length) c.min_seed_length = k;
@@ -31,6 +31,11 @@ inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, Dev
     uint64_t lo = std::min(c.min_seed_length, c.max_seed_length), hi = std::max(c.min_seed_length, c.max_seed_length);
     c.min_seed_length = lo;
     c.max_seed_length = hi;
+    if (labeled) {
+        // LabeledAligner's ctor on top of DBGAligner's (aligner_labeled.cpp:463-465; no coordinates: no chaining)
+        c.min_seed_length = std::min<uint64_t>(k, c.min_seed_length);
+        c.max_seed_length = std::min<uint64_t>(k, c.max_seed_length);
+    }
     if (!check_config_scores(c)) { *err = "Error: sum of min_cell_score and lowest penalty too low."; return MGX_ERR_CONFIG; }
     if (c.chain_alignments || c.post_chain_alignments) { *err = "seed/alignment chaining is not implemented"; return MGX_ERR_UNSUPPORTED; }
     if (!c.global_xdrop) { *err = "per-branch xdrop (labeled+coordinates mode) is not implemented"; return MGX_ERR_UNSUPPORTED; }
@@ -58,7 +63,7 @@ inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, Dev
 
 inline uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
-inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lmax, DevLimits *lim, std::string *err) {
+inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lmax, DevLimits *lim, std::string *err, bool labeled = false) {
     DevLimits &l = *lim;
     if (u && u->max_query_length && Lmax > u->max_query_length) {
         *err = "a query of length " + std::to_string(Lmax) + " exceeds mgx_limits.max_query_length = " + std::to_string(u->max_query_length);
@@ -99,6 +104,18 @@ inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lm
     // cell words per extender never binds on the test and bench workloads; a read that runs out gets MGX_ERR_CAPACITY
     // and the adapter's retry (doubled cell_arena_bytes) doubles the pool with it.
     l.conv_pool_words = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, (uint64_t)l.cell_words / 2 + 16ull * l.Lmax + 1024);
+    l.lab_words = l.lab_ext = l.lab_pool = 0;
+    if (labeled) {
+        // Label-aware alignment: a backtracking reports one alignment per label subset of its seed and the aggregator keeps a
+        // queue per label, so the alignment buffers are [0, E) extension results, [E, 2E) their reversals, [2E, 3E) backward
+        // results, [3E, 3E + pool) the aggregator's alignments.  A read that outgrows any of them gets MGX_ERR_CAPACITY.
+        l.lab_ext = 8;
+        l.lab_pool = 32 * (uint32_t)std::max<uint64_t>(1, cfg.num_alternative_paths);
+        l.n_aln = 3 * l.lab_ext + l.lab_pool;
+        // label sets: per-extension sets (one per fork and per flushed column that lost labels), per-read sets (seeds,
+        // alignments), the seed filter's position bitmaps (one per label seen on the read's seeds)
+        l.lab_words = (uint32_t)std::min<uint64_t>(1u << 24, 16384 + 8ull * l.max_columns + 64ull * ((l.Lmax + 31) / 32 + 2));
+    }
     return MGX_OK;
 }
 
@@ -117,9 +134,10 @@ struct HostResults {
     // Stream layout of a read with n_alignments >= 1, from stream_off: alignment 0 = nodes, CIGAR runs (len << 3 | op),
     // path characters (its scalars are in the header); every further alignment = 6 words (score, offset, n_nodes, n_cigar,
     // seq_len, orientation) followed by the same three arrays.  `stream_words`: words available (bounds for untrusted input).
-    bool decode(const ReadResult *rr, uint64_t n, const uint32_t *stream, uint64_t stream_words = ~0ull) {
+    // Label-aware runs (`labeled`): every alignment's arrays are followed by its label count and its labels.
+    bool decode(const ReadResult *rr, uint64_t n, const uint32_t *stream, uint64_t stream_words = ~0ull, bool labeled = false) {
         aln_begin.assign(1, 0);
-        alns.clear(); nodes.clear(); cigar.clear(); seqs.clear(); status.clear();
+        alns.clear(); nodes.clear(); cigar.clear(); seqs.clear(); status.clear(); labels.clear();
         for (uint64_t i = 0; i < n; ++i) {
             const ReadResult &r = rr[i];
             status.push_back(r.status);
@@ -162,6 +180,14 @@ struct HostResults {
                     }
                     const char *sq = reinterpret_cast<const char *>(p + n_nodes + n_cigar);
                     seqs.insert(seqs.end(), sq, sq + seq_len);
+                    if (labeled) {
+                        if (at >= stream_words) return false;
+                        const uint32_t nl = stream[at];
+                        if (nl > stream_words - at - 1) return false;
+                        m.n_labels = nl; m.labels_begin = labels.size();
+                        labels.insert(labels.end(), stream + at + 1, stream + at + 1 + nl);
+                        at += 1 + (uint64_t)nl;
+                    }
                     alns.push_back(m);
                 }
             }

@@ -1,0 +1,374 @@
+// label_driver.hpp — the per-read driver of label-aware alignment: LabeledAligner::filter_seeds, the per-label
+// AlignmentAggregator and DBGAligner::align_both_directions / align_core with labeled seeds (A/aligner_labeled.cpp:612-721,
+// A/aligner_aggregator.hpp:24-206, A/dbg_aligner.cpp:105-149,360-384,531-758).  Included by align_core.hpp inside namespace mgx
+// in builds with MGX_WITH_LABELS; BASIC-mode graphs, annotation without coordinates (the reference's ColumnCompressed case).
+//
+// Alignment buffers (DevLimits::lab_ext = E, lab_pool): [0, E) the extensions of the current seed, [E, 2E) their reversals
+// (seeds of the backward pass), [2E, 3E) backward extensions, [3E, 3E + pool) the aggregator's alignments.  The reference's
+// queues hold shared_ptrs; here a queue holds pool indices and Wave::agg counts the references.
+
+enum { AG_NQ = 0, AG_UNL_N = 1, AG_UNL = 2, AG_Q0 = 16, AG_QW = 8 };
+MGX_DEV uint32_t ag_ref0() { return AG_Q0 + LAB_MAX_QUEUES * AG_QW; }
+MGX_DEV uint32_t ag_list0(const DevLimits &lim) { return ag_ref0() + lim.lab_pool + 8; }
+MGX_DEV int lab_e(const Wave &w) { return (int)MGX_PARAMS_OF(w).lim.lab_ext; }
+MGX_DEV DevAln &lab_pool_aln(Wave &w, uint32_t p) { return w.aln[3 * lab_e(w) + (int)p]; }
+
+MGX_DEV void lab_agg_reset(Wave &w) {
+    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
+    w.agg[AG_NQ] = 0; w.agg[AG_UNL_N] = 0;
+    for (uint32_t p = 0; p < lim.lab_pool; ++p) w.agg[ag_ref0() + p] = 0;
+}
+
+// ---- LabeledAligner::filter_seeds (aligner_labeled.cpp:612-721, no coordinates) for the seeds of strand s ----
+// A label counts the query positions covered by the first k-mers of the seeds whose first node carries it; labels below
+// min_exact_match x |query| are dropped, every seed keeps the labels of its first node that are left, seeds without any go.
+MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
+    MGX_ASSUME_LDS(&w);
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    const int32_t n = w.n_seeds[s];
+    if (!n) return;
+    const int32_t k = (int32_t)P.g.k, L = w.L;
+    const uint32_t W = (uint32_t)(L + 31) / 32;
+    // scratch: the backtracking's start-cell list (dead between extensions)
+    uint32_t *scr = (uint32_t *)w.indices;
+    const uint64_t cap_words = (uint64_t)P.lim.max_columns * 2 * (sizeof(BtIndex) / 4);
+    if (cap_words < 64 + (uint64_t)W) { w.status = ST_CAPACITY; return; }
+    const uint32_t max_l = (uint32_t)imin<uint64_t>(64, (cap_words - 64) / W);
+    uint32_t *mlab = scr, *bits = scr + 64;
+    uint32_t nl = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const DevSeed sd = w.seeds[s][i];
+        const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
+        const int32_t end = imin((int32_t)sd.clipping + k - (int32_t)sd.offset, L);
+        const LabRow r = lab_row(w, node0);
+        for (uint32_t x = 0; x < r.n; ++x) {
+            const uint32_t lbl = row_at(r, x);
+            uint32_t t = 0;
+            while (t < nl && mlab[t] != lbl) ++t;
+            if (t == nl) {
+                if (nl == max_l) { w.status = ST_CAPACITY; return; }
+                mlab[nl] = lbl;
+                for (uint32_t y = 0; y < W; ++y) bits[nl * W + y] = 0;
+                ++nl;
+            }
+            for (int32_t pos = sd.clipping; pos < end; ++pos) bits[t * W + ((uint32_t)pos >> 5)] |= 1u << (pos & 31);
+        }
+    }
+    if (!nl) { w.n_seeds[s] = 0; w.num_matching[s] = 0; return; }
+    // labels at or above the cut-off, ascending (only the SET is used afterwards)
+    const double cutoff = P.cfg.min_exact_match * (double)L;
+    uint32_t nk = 0;
+    for (uint32_t t = 0; t < nl; ++t) {
+        uint32_t cnt = 0;
+        for (uint32_t y = 0; y < W; ++y) cnt += (uint32_t)popc64((uint64_t)bits[t * W + y]);
+        if ((double)cnt < cutoff) continue;
+        const uint32_t lbl = mlab[t];
+        uint32_t pos = nk;                                   // (nk <= t: the slots below t are free to reuse)
+        while (pos > 0 && mlab[pos - 1] > lbl) { mlab[pos] = mlab[pos - 1]; --pos; }
+        mlab[pos] = lbl;
+        ++nk;
+    }
+    if (!nk) { w.n_seeds[s] = 0; w.num_matching[s] = 0; return; }
+    uint32_t cntk = 0;
+    for (uint32_t t = 0; t < nk; ++t) lab_push(w, cntk, mlab[t]);
+    const uint32_t hk = lab_end(w, cntk);
+    if (w.status != ST_OK) return;
+    uint32_t hk_kept = 0;                                    // the whole set, kept for the read (made once)
+    int32_t m = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const DevSeed sd = w.seeds[s][i];
+        const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
+        const LabRow r = lab_row(w, node0);
+        uint32_t h = lab_isect_row(w, hk, r);
+        if (w.status != ST_OK) return;
+        if (!h) continue;
+        if (h == hk) { if (!hk_kept) hk_kept = lab_persist(w, hk); h = hk_kept; }
+        else h = lab_persist(w, h);
+        if (w.status != ST_OK) return;
+        w.seeds[s][m] = sd; w.seed_lab[s][m] = h; w.alive[s][m] = 1;
+        ++m;
+    }
+    w.n_seeds[s] = m;
+    // get_num_char_matches_in_seeds (alignment.hpp:100-127) incl. its quirk: nothing after the first sub-k seed is counted
+    uint32_t num_matching = 0;
+    int32_t last_q_end = 0;
+    for (int32_t i = 0; i < m; ++i) {
+        const DevSeed sd = w.seeds[s][i];
+        const int32_t q_begin = sd.clipping, q_end = q_begin + (int32_t)sd.length;
+        if (q_end > last_q_end) {
+            num_matching += (uint32_t)(q_end - q_begin);
+            if (q_begin < last_q_end) num_matching -= (uint32_t)(last_q_end - q_begin);
+        }
+        if (sd.offset) i = m - 1;
+        last_q_end = q_end;
+    }
+    w.num_matching[s] = num_matching;
+    wave_sync();
+}
+
+// ---- AlignmentAggregator with labels (aligner_aggregator.hpp:24-206) ----
+MGX_DEV int lab_pool_alloc(Wave &w) {
+    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
+    for (uint32_t p = 0; p < lim.lab_pool; ++p) if (!w.agg[ag_ref0() + p]) return (int)p;
+    w.status = ST_CAPACITY;
+    return -1;
+}
+// (queues are short: items[] of a queue record or of the unlabeled queue, *size its length)
+MGX_DEV int lab_q_max(Wave &w, const uint32_t *items, uint32_t size) {       // std::max_element: the first of equal maxima
+    uint32_t mx = 0;
+    for (uint32_t t = 1; t < size; ++t) if (aln_less(lab_pool_aln(w, items[mx]), lab_pool_aln(w, items[t]))) mx = t;
+    return (int)mx;
+}
+MGX_DEV int lab_q_min(Wave &w, const uint32_t *items, uint32_t size) {       // std::min_element: the first of equal minima
+    uint32_t mn = 0;
+    for (uint32_t t = 1; t < size; ++t) if (aln_less(lab_pool_aln(w, items[t]), lab_pool_aln(w, items[mn]))) mn = t;
+    return (int)mn;
+}
+MGX_DEV int32_t lab_global_cutoff(Wave &w) {                // get_global_cutoff (:141-149)
+    const uint32_t un = w.agg[AG_UNL_N];
+    if (!un) return NINF;
+    const int32_t cur_max = lab_pool_aln(w, w.agg[AG_UNL + lab_q_max(w, w.agg + AG_UNL, un)]).score;
+    return cur_max > 0 ? (int32_t)((double)cur_max * MGX_PARAMS_OF(w).cfg.rel_score_cutoff) : cur_max;
+}
+MGX_DEV int lab_find_queue(const Wave &w, uint32_t label) {
+    const uint32_t nq = w.agg[AG_NQ];
+    for (uint32_t q = 0; q < nq; ++q) if (w.agg[AG_Q0 + q * AG_QW] == label) return (int)q;
+    return -1;
+}
+MGX_DEV int32_t lab_label_cutoff(Wave &w, uint32_t label) {  // get_label_cutoff (:168-177)
+    const int q = lab_find_queue(w, label);
+    if (q < 0) return NINF;
+    const uint32_t *rec = w.agg + AG_Q0 + (uint32_t)q * AG_QW;
+    if (rec[1] < (uint32_t)n_alt_of(w)) return NINF;
+    return lab_pool_aln(w, rec[2 + lab_q_min(w, rec + 2, rec[1])]).score;
+}
+MGX_DEV int32_t lab_score_cutoff(Wave &w, uint32_t lab) {    // get_score_cutoff (:152-166)
+    const int32_t global_min = lab_global_cutoff(w);
+    int32_t min_score = INT32_MAX;
+    const uint32_t n = lab_size(w, lab);
+    for (uint32_t x = 0; x < n; ++x) {
+        min_score = imin(min_score, lab_label_cutoff(w, lab_at(w, lab, x)));
+        if (min_score < global_min) return global_min;
+    }
+    return min_score;
+}
+// get_min_path_score of align_batch (dbg_aligner.cpp:277-282 with labels)
+MGX_DEV int32_t lab_min_path_score(Wave &w, uint32_t lab) {
+    return imax(MGX_PARAMS_OF(w).cfg.min_path_score, lab ? lab_score_cutoff(w, lab) : lab_global_cutoff(w));
+}
+
+// add_alignment (:68-138); true if the alignment was added
+MGX_NI_G4 bool lab_add_alignment(Wave &w, const DevAln &a) {
+    MGX_ASSUME_LDS(&w);
+    uint32_t *g = w.agg;
+    const uint32_t n_alt = (uint32_t)n_alt_of(w);
+    int pa = -1;                                            // a's slot in the pool once it is needed
+    auto own = [&]() -> int {
+        if (pa < 0) { pa = lab_pool_alloc(w); if (pa >= 0) copy_aln(lab_pool_aln(w, (uint32_t)pa), a); }
+        return pa;
+    };
+    auto queue_of = [&](uint32_t label) -> int {
+        int q = lab_find_queue(w, label);
+        if (q >= 0) return q;
+        if (g[AG_NQ] >= LAB_MAX_QUEUES) { w.status = ST_CAPACITY; return -1; }
+        q = (int)g[AG_NQ]++;
+        g[AG_Q0 + (uint32_t)q * AG_QW] = label; g[AG_Q0 + (uint32_t)q * AG_QW + 1] = 0;
+        return q;
+    };
+    const uint32_t nl = a.lab ? lab_size(w, a.lab) : 0;
+    if (!g[AG_UNL_N]) {
+        if (own() < 0) return false;
+        g[AG_UNL] = (uint32_t)pa; g[AG_UNL_N] = 1; ++g[ag_ref0() + (uint32_t)pa];
+        for (uint32_t x = 0; x < nl; ++x) {
+            const int q = queue_of(lab_at(w, a.lab, x));
+            if (q < 0) return false;
+            uint32_t *rec = g + AG_Q0 + (uint32_t)q * AG_QW;
+            rec[2 + rec[1]++] = (uint32_t)pa; ++g[ag_ref0() + (uint32_t)pa];
+        }
+        return true;
+    }
+    if (a.score < lab_global_cutoff(w)) return false;
+    auto push_to_queue = [&](uint32_t *items, uint32_t *size) -> bool {
+        for (uint32_t t = 0; t < *size; ++t) if (aln_equal(w, a, lab_pool_aln(w, items[t]))) return false;
+        if (*size < n_alt) {
+            if (own() < 0) return false;
+            items[(*size)++] = (uint32_t)pa; ++g[ag_ref0() + (uint32_t)pa];
+            return true;
+        }
+        const int mn = lab_q_min(w, items, *size);
+        if (aln_less(a, lab_pool_aln(w, items[mn]))) return false;
+        if (own() < 0) return false;
+        ++g[ag_ref0() + (uint32_t)pa];                       // (before the release: the slot `a` was copied to stays taken)
+        --g[ag_ref0() + items[mn]];
+        items[mn] = (uint32_t)pa;                            // queue.update(minimum, a)
+        return true;
+    };
+    if (!nl) return push_to_queue(g + AG_UNL, g + AG_UNL_N);
+    if (!g[AG_NQ] && g[AG_UNL_N] > 1) {
+        // the first labeled alignment: the global queue only serves the global cut-off from now on (:110-117)
+        const uint32_t keep = g[AG_UNL + lab_q_max(w, g + AG_UNL, g[AG_UNL_N])];
+        for (uint32_t t = 0; t < g[AG_UNL_N]; ++t) if (g[AG_UNL + t] != keep) --g[ag_ref0() + g[AG_UNL + t]];
+        g[AG_UNL] = keep; g[AG_UNL_N] = 1;
+    }
+    bool added = false;
+    for (uint32_t x = 0; x < nl; ++x) {
+        const int q = queue_of(lab_at(w, a.lab, x));
+        if (q < 0) return false;
+        uint32_t *rec = g + AG_Q0 + (uint32_t)q * AG_QW;
+        added |= push_to_queue(rec + 2, rec + 1);
+        if (w.status != ST_OK) return false;
+    }
+    if (!added) return false;
+    if (!aln_less(a, lab_pool_aln(w, g[AG_UNL + lab_q_max(w, g + AG_UNL, g[AG_UNL_N])]))) {
+        const int mn = lab_q_min(w, g + AG_UNL, g[AG_UNL_N]);
+        ++g[ag_ref0() + (uint32_t)pa];
+        --g[ag_ref0() + g[AG_UNL + mn]];
+        g[AG_UNL + mn] = (uint32_t)pa;
+    }
+    return true;
+}
+
+// filter_seed (dbg_aligner.cpp:105-149, no coordinates): a seed (or reversed alignment) that check_seed rejected keeps only the
+// labels the extended one did not have; returns the labels left (0: the seed is dropped)
+MGX_DEV uint32_t lab_filter_seed(Wave &w, uint32_t prev_lab, uint32_t lab) {
+    if (!prev_lab) return 0;
+    const uint32_t d = lab_diff(w, lab, prev_lab);
+    return lab_persist(w, d);
+}
+
+// ---- align_both_directions (dbg_aligner.cpp:531-758, the branch without chaining) with labeled seeds, BASIC graphs ----
+MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
+    MGX_ASSUME_LDS(&w);
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    ExtenderState &F = w.ext[s];
+    ExtenderState &B = w.ext[1 - s];
+    F.rc_view = 0;
+    B.rc_view = 1;                                            // use_rcdbg
+    const int E = lab_e(w);
+    const int32_t n = w.n_seeds[s];
+    for (int32_t i = 0; i < n; ++i) {
+        if (!w.alive[s][i]) continue;
+        SeedRef seed = seedref_from_seed(w, s, i, nullptr);
+        conv_clear(w, F.conv);
+        extend(w, s, seed, false);
+        const ExtendResult er = w.er;
+        if (w.status != ST_OK) return;
+        const int n_fwd = backtrack(w, s, seed, nullptr, er, imax(0, P.cfg.min_cell_score), &w.aln[0], E);
+        if (w.status != ST_OK) return;
+        int n_rev = 0;
+        bool rev_alive[LAB_EXT];
+        for (int e = 0; e < n_fwd; ++e) {
+            DevAln &path = w.aln[e];
+            if (path.score >= lab_min_path_score(w, path.lab)) { lab_add_alignment(w, path); if (w.status != ST_OK) return; }
+            if (!aln_clipping(path) || path.offset) continue;
+            DevAln &rev = w.aln[E + n_rev];
+            copy_aln(rev, path);
+            if (!reverse_complement_aln(w, rev)) continue;
+            rev_alive[n_rev++] = true;
+        }
+        // align_core (:360-384) on the backward extender over the reversed extensions
+        for (int r = 0; r < n_rev; ++r) {
+            if (!rev_alive[r]) continue;
+            DevAln &rev = w.aln[E + r];
+            SeedRef rseed = seedref_from_aln(rev);
+            const int32_t mps2 = imax(0, lab_min_path_score(w, rev.lab));
+            conv_clear(w, B.conv);
+            extend(w, 1 - s, rseed, true);
+            const ExtendResult er2 = w.er;
+            if (w.status != ST_OK) return;
+            const int n_bwd = backtrack(w, 1 - s, rseed, &rev, er2, mps2, &w.aln[2 * E], E);
+            if (w.status != ST_OK) return;
+            for (int b = 0; b < n_bwd; ++b) {
+                DevAln &p2 = w.aln[2 * E + b];
+                if (!reverse_complement_aln(w, p2)) continue;
+                const int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
+                for (int32_t x = 0; x < p2.n_nodes; ++x) filter_nodes(w, F, p2.nodes[x], clip, w.L - eclip);
+                if (w.status != ST_OK) return;
+                lab_add_alignment(w, p2);
+                if (w.status != ST_OK) return;
+            }
+            for (int r2 = r + 1; r2 < n_rev; ++r2) {
+                if (!rev_alive[r2]) continue;
+                DevAln &o = w.aln[E + r2];
+                if (!check_seed(w, B, o.nodes[o.n_nodes - 1], o.qlen, aln_clipping(o), o.score)) {
+                    o.lab = lab_filter_seed(w, rev.lab, o.lab);
+                    if (w.status != ST_OK) return;
+                    if (!o.lab) rev_alive[r2] = false;
+                }
+            }
+        }
+        for (int32_t j = i + 1; j < n; ++j) {
+            if (!w.alive[s][j]) continue;
+            const DevSeed sj = w.seeds[s][j];
+            const uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
+            const SeedRef rj = seedref_from_seed(w, s, j, nullptr);
+            if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) {
+                w.seed_lab[s][j] = lab_filter_seed(w, w.seed_lab[s][i], w.seed_lab[s][j]);
+                if (w.status != ST_OK) return;
+                if (!w.seed_lab[s][j]) w.alive[s][j] = 0;
+            }
+        }
+    }
+}
+
+// align_core (:360-384) with the labeled seeds of strand 0, forward only
+MGX_NI_G4 void lab_align_core_fwd(Wave &w) {
+    MGX_ASSUME_LDS(&w);
+    ExtenderState &F = w.ext[0];
+    F.rc_view = 0;
+    const int E = lab_e(w);
+    const int32_t n = w.n_seeds[0];
+    for (int32_t i = 0; i < n; ++i) {
+        if (!w.alive[0][i]) continue;
+        SeedRef seed = seedref_from_seed(w, 0, i, nullptr);
+        const int32_t mps = imax(0, lab_min_path_score(w, seed.lab));
+        conv_clear(w, F.conv);
+        extend(w, 0, seed, false);
+        const ExtendResult er = w.er;
+        if (w.status != ST_OK) return;
+        const int n_fwd = backtrack(w, 0, seed, nullptr, er, mps, &w.aln[0], E);
+        if (w.status != ST_OK) return;
+        for (int e = 0; e < n_fwd; ++e) { lab_add_alignment(w, w.aln[e]); if (w.status != ST_OK) return; }
+        for (int32_t j = i + 1; j < n; ++j) {
+            if (!w.alive[0][j]) continue;
+            const DevSeed sj = w.seeds[0][j];
+            const uint32_t last_node = sj.offset == 0 ? w.nodes[0][sj.clipping + sj.n_nodes - 1] : sj.node;
+            const SeedRef rj = seedref_from_seed(w, 0, j, nullptr);
+            if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) {
+                w.seed_lab[0][j] = lab_filter_seed(w, w.seed_lab[0][i], w.seed_lab[0][j]);
+                if (w.status != ST_OK) return;
+                if (!w.seed_lab[0][j]) w.alive[0][j] = 0;
+            }
+        }
+    }
+}
+
+// get_alignments (:180-202): every queue's alignments in the queues' insertion order, then the global queue's; stable sort
+// ascending by LocalAlignmentLess; emitted from the back, an alignment that sits in several queues once (where it comes
+// first from the back).  Writes the emission order (pool indices) to order[] and returns its length.
+MGX_DEV int lab_get_alignments(Wave &w, uint32_t *order) {
+    const DevLimits &lim = MGX_PARAMS_OF(w).lim;
+    uint32_t *g = w.agg;
+    uint32_t *list = g + ag_list0(lim);
+    int n = 0;
+    auto insert = [&](uint32_t p) {
+        int pos = n;
+        while (pos > 0 && aln_less(lab_pool_aln(w, p), lab_pool_aln(w, list[pos - 1]))) { list[pos] = list[pos - 1]; --pos; }
+        list[pos] = p;
+        ++n;
+    };
+    for (uint32_t q = 0; q < g[AG_NQ]; ++q) {
+        const uint32_t *rec = g + AG_Q0 + q * AG_QW;
+        for (uint32_t t = 0; t < rec[1]; ++t) insert(rec[2 + t]);
+    }
+    for (uint32_t t = 0; t < g[AG_UNL_N]; ++t) insert(g[AG_UNL + t]);
+    int m = 0;
+    for (int t = n - 1; t >= 0; --t) {
+        const uint32_t p = list[t];
+        bool seen = false;
+        for (int x = 0; x < m; ++x) seen |= order[x] == p;
+        if (seen || !lab_pool_aln(w, p).n_nodes) continue;
+        order[m++] = p;
+    }
+    return m;
+}

@@ -1,0 +1,187 @@
+// label_sets.hpp — label sets of label-aware alignment and the LabeledExtender's bookkeeping on the DP table
+// (A/aligner_labeled.{hpp,cpp}, annotation without coordinates).  Included by align_core.hpp inside namespace mgx, in
+// builds with MGX_WITH_LABELS only; AlignParams::labeled switches the hooks on at run time.
+//
+// What the reference keeps and what stands in for it here:
+//   * AnnotationBuffer (annotation_buffer.{hpp,cpp}) caches node -> label set for the nodes it was asked to fetch and interns
+//     the sets (cache_column_set).  Here a node's labels ARE its row of the row-major label matrix (mgx_annot.hip): lab_row()
+//     reads them where they are needed, so there is nothing to queue or fetch; dummy nodes (W == 0) have no labels
+//     (annotation_buffer.cpp: "skip dummy nodes").
+//   * A label set (Alignment::Columns, a sorted vector) is a run of the read's label arena (Wave::lab): word h = its size,
+//     words h + 1 .. its labels in ascending order; the handle h = 0 is the empty set, which is what the reference's set
+//     index 0 is.  Handles are never compared for anything but emptiness, so sets are not interned; an intersection that
+//     keeps every label of its first operand returns that operand's handle (the common case along a path), so straight
+//     stretches of the graph allocate nothing.
+//   * Sets made during an extension (columns, the labels still to be reported) live from extend_begin to the end of its
+//     backtracking: they grow up from lab_lo, which extend_begin resets.  Sets that outlive it (seeds, alignments) grow down
+//     from lab_hi for the whole read.  The two meeting is ST_CAPACITY.
+//   * LabeledExtender::node_labels_ is Wave::col_lab (one handle per table column), last_flushed_table_i_ /
+//     remaining_labels_i_ are Wave::last_flushed / remaining_lab.
+//
+// Everything here is uniform (scalar) code of the wave program: label sets of short reads hold a handful of labels.
+
+MGX_DEV uint32_t lab_size(const Wave &w, uint32_t h) { return w.lab[h]; }
+MGX_DEV uint32_t lab_at(const Wave &w, uint32_t h, uint32_t i) { return w.lab[h + 1 + i]; }
+
+// a set under construction at lab_lo: lab_push() appends (ascending), lab_end() closes it; nothing else may allocate in between
+MGX_DEV void lab_push(Wave &w, uint32_t &n, uint32_t label) {
+    if ((uint64_t)w.lab_lo + 2 + n >= w.lab_hi) { w.status = ST_CAPACITY; return; }
+    w.lab[w.lab_lo + 1 + n] = label;
+    ++n;
+}
+MGX_DEV uint32_t lab_end(Wave &w, uint32_t n) {
+    if (!n || w.status != ST_OK) return 0;
+    const uint32_t h = w.lab_lo;
+    w.lab[h] = n;
+    w.lab_lo = h + 1 + n;
+    return h;
+}
+// a copy that lives as long as the read (no copy for a set that already does)
+MGX_DEV uint32_t lab_persist(Wave &w, uint32_t h) {
+    if (!h || h >= w.lab_hi) return h;
+    const uint32_t n = w.lab[h];
+    if ((uint64_t)w.lab_lo + n + 2 >= w.lab_hi) { w.status = ST_CAPACITY; return 0; }
+    const uint32_t d = w.lab_hi - (n + 1);
+    for (uint32_t x = 0; x <= n; ++x) w.lab[d + x] = w.lab[h + x];
+    w.lab_hi = d;
+    return d;
+}
+
+// the labels of a node: its row of the label matrix (row = node - 1: AnnotatedDBG::graph_to_anno_index, annotated_dbg.hpp:50-52)
+struct LabRow { uint32_t n, one; const uint32_t *more; };
+MGX_DEV uint32_t row_at(const LabRow &r, uint32_t i) { return r.n == 1 ? r.one : r.more[i]; }
+MGX_DEV LabRow lab_row(Wave &w, uint32_t node) {
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    LabRow r;
+    r.n = 0; r.one = 0; r.more = nullptr;
+    if (!node || node > P.g.n) return r;                     // npos (annotation_buffer.cpp:59-62)
+    // "skip dummy nodes" (annotation_buffer.cpp:64-68): !boss.get_W(node)
+    ++w.ctr.rank_lines;
+    const Block b = load_block_uniform(P.g, uni(node >> 6));
+    if (block_W(b, (int)(node & 63)) == 0) return r;
+    const uint64_t row = (uint64_t)node - 1;
+    if (row >= P.anno_rows) return r;
+    const uint64_t h = P.anno_head[row];
+    uint32_t c = (uint32_t)(h & 0xFFFF);
+    if (c == 0xFFFF) c = P.anno_count[row];
+    r.n = c;
+    if (c == 1) r.one = (uint32_t)(h >> 16);
+    else if (c >= 2) r.more = P.anno_more + (h >> 16);
+    return r;
+}
+
+// set h & the labels of a row; h itself if nothing is lost
+MGX_DEV uint32_t lab_isect_row(Wave &w, uint32_t h, const LabRow &r) {
+    if (!h || !r.n) return 0;
+    const uint32_t n = lab_size(w, h);
+    uint32_t cnt = 0, i = 0, j = 0;
+    while (i < n && j < r.n) {
+        const uint32_t a = lab_at(w, h, i), b = row_at(r, j);
+        if (a < b) ++i;
+        else if (b < a) ++j;
+        else { lab_push(w, cnt, a); ++i; ++j; }
+        if (w.status != ST_OK) return 0;
+    }
+    if (cnt == n) return h;
+    return lab_end(w, cnt);
+}
+// a & b; a itself if nothing is lost
+MGX_DEV uint32_t lab_isect(Wave &w, uint32_t a, uint32_t b) {
+    if (!a || !b) return 0;
+    const uint32_t na = lab_size(w, a), nb = lab_size(w, b);
+    uint32_t cnt = 0, i = 0, j = 0;
+    while (i < na && j < nb) {
+        const uint32_t x = lab_at(w, a, i), y = lab_at(w, b, j);
+        if (x < y) ++i;
+        else if (y < x) ++j;
+        else { lab_push(w, cnt, x); ++i; ++j; }
+        if (w.status != ST_OK) return 0;
+    }
+    if (cnt == na) return a;
+    return lab_end(w, cnt);
+}
+// a - b; a itself if nothing is lost
+MGX_DEV uint32_t lab_diff(Wave &w, uint32_t a, uint32_t b) {
+    if (!a) return 0;
+    if (!b) return a;
+    const uint32_t na = lab_size(w, a), nb = lab_size(w, b);
+    uint32_t cnt = 0, j = 0;
+    for (uint32_t i = 0; i < na; ++i) {
+        const uint32_t x = lab_at(w, a, i);
+        while (j < nb && lab_at(w, b, j) < x) ++j;
+        if (j < nb && lab_at(w, b, j) == x) continue;
+        lab_push(w, cnt, x);
+        if (w.status != ST_OK) return 0;
+    }
+    if (cnt == na) return a;
+    return lab_end(w, cnt);
+}
+// utils::set_intersection_difference (common/algorithms.hpp:160-180): a & b and a - b
+MGX_DEV void lab_isect_diff(Wave &w, uint32_t a, uint32_t b, uint32_t *isect, uint32_t *diff) {
+    *isect = lab_isect(w, a, b);
+    *diff = (w.status == ST_OK) ? lab_diff(w, a, b) : 0;
+}
+
+// LabeledExtender::flush's clear(): S, E, F of the column become ninf (aligner_labeled.cpp:92-100).  On the device a column
+// of the general path is an S / F record plus one flag byte per cell that relates it to its parent; nothing reads a parent's
+// E.  A cleared column's children are cleared by the same flush (their parent has no labels), so the flags of columns that
+// stay never refer to cleared values.
+MGX_DEV void lab_clear_column(Wave &w, int32_t idx) {
+    const ColMeta c = uni_col(col_load(w, idx));
+    w.col_lab[idx] = 0;
+    if (c.cells == NO_CELLS || col_chain(c)) { w.status = ST_CAPACITY; return; }       // cannot happen: labeled extensions use the general path only
+    const int32_t wc = col_wc(c);
+    int32_t *rec = w.cells + c.cells;
+    uint8_t *fb = (uint8_t *)(rec + 2 * wc);
+    for (int32_t base = 0; base < wc; base += WAVE) {
+        FOR_LANES(l) {
+            const int32_t j = base + l;
+            if (j < wc) { gst(rec + j, NINF); gst(rec + wc + j, NINF); gst(fb + j, (uint8_t)0); }
+        }
+    }
+    for (int b = 0; b < 2; ++b) if (w.st[b].col == idx) w.st[b].col = -1;          // a staged copy is stale now
+    wave_sync();
+}
+
+// LabeledExtender::flush (aligner_labeled.cpp:81-137): the columns added since the last flush inherited their parent's labels
+// unseen ("annotations are preserved in unitigs"); now each is intersected with its node's labels, and a column left without
+// labels is cleared
+MGX_DEV void lab_flush(Wave &w, int32_t tsize) {
+    for (; w.last_flushed < tsize; ++w.last_flushed) {
+        const int32_t i = w.last_flushed;
+        const ColMeta c = uni_col(col_load(w, i));
+        const uint32_t ph = w.col_lab[c.parent];
+        if (!ph) { lab_clear_column(w, i); if (w.status != ST_OK) return; continue; }
+        if (!c.node) continue;
+        const LabRow r = lab_row(w, c.node);
+        const uint32_t nh = lab_isect_row(w, ph, r);
+        if (w.status != ST_OK) return;
+        if (!nh) { lab_clear_column(w, i); if (w.status != ST_OK) return; }
+        else w.col_lab[i] = nh;
+    }
+}
+
+// LabeledExtender::call_outgoing (aligner_labeled.cpp:176-302, the branch without coordinates) on the children of column i in
+// Wave::out_*: an only child inherits the column's labels unseen; at a fork the table is flushed and every child keeps the
+// labels it shares with the column — a child that shares none is dropped.  Returns the number of children left; their label
+// sets are in Wave::out_lab.
+MGX_DEV int lab_filter_children(Wave &w, int32_t i, int n_out) {
+    if (n_out <= 0) return n_out;
+    if (n_out == 1) { w.out_lab[0] = w.col_lab[i]; return 1; }
+    lab_flush(w, w.x.tsize);
+    if (w.status != ST_OK) return 0;
+    const uint32_t ph = w.col_lab[i];
+    if (!ph) return 0;
+    int m = 0;
+    for (int oi = 0; oi < n_out; ++oi) {
+        const uint32_t next = w.out_nodes[oi];
+        const LabRow r = lab_row(w, next);
+        const uint32_t h = lab_isect_row(w, ph, r);
+        if (w.status != ST_OK) return 0;
+        if (!h) continue;
+        w.out_nodes[m] = next; w.out_chars[m] = w.out_chars[oi]; w.out_scores[m] = w.out_scores[oi];
+        w.out_lab[m] = h;
+        ++m;
+    }
+    return m;
+}

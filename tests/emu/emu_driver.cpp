@@ -43,6 +43,13 @@ struct EmuRun {
     uint64_t lane_bail[32] = { 0 };            // ... and why it sent the others on (LANE_BAIL codes)
     std::vector<uint8_t> lane_reason;          // per read: 0 = finished by the lane path, else the code
 };
+// the label matrix in the device's row-major form (mgx_annot.hip: head word = count:16 | single label or offset into more[])
+struct EmuAnno {
+    std::vector<uint64_t> head;
+    std::vector<uint32_t> count, more;
+    uint64_t n_rows = 0;
+    uint32_t n_labels = 0;
+};
 #ifdef MGX_EMU_TRACE
 // traced build (make trace): every access of the wave program calls the hooks of trace_hooks.cpp
 extern "C" {
@@ -206,13 +213,45 @@ int emu_is_low_complexity(const char *s, uint32_t len) {
     return is_low_complexity((const uint8_t *)s, (int32_t)len, &sd);
 }
 
+// columns[j]: ceil(n_rows / 64) words, bit r = row r has label j (as mgx_annotation_create)
+void *emu_annotation_create(uint64_t n_rows, uint32_t n_labels, const uint64_t *const *columns) {
+    auto *A = new EmuAnno();
+    A->n_rows = n_rows; A->n_labels = n_labels;
+    A->head.assign(n_rows + 1, 0); A->count.assign(n_rows + 1, 0);
+    for (uint32_t j = 0; j < n_labels; ++j)
+        for (uint64_t r = 0; r < n_rows; ++r) if ((columns[j][r >> 6] >> (r & 63)) & 1) ++A->count[r];
+    std::vector<uint64_t> off(n_rows + 1, 0);
+    uint64_t tot = 0;
+    for (uint64_t r = 0; r < n_rows; ++r) { off[r] = tot; if (A->count[r] >= 2) tot += A->count[r]; }
+    A->more.assign(tot + 1, 0);
+    std::vector<uint32_t> fill(n_rows + 1, 0);
+    for (uint32_t j = 0; j < n_labels; ++j)
+        for (uint64_t r = 0; r < n_rows; ++r) {
+            if (!((columns[j][r >> 6] >> (r & 63)) & 1)) continue;
+            if (A->count[r] == 1) A->head[r] = 1ull | ((uint64_t)j << 16);
+            else A->more[off[r] + fill[r]++] = j;
+        }
+    for (uint64_t r = 0; r < n_rows; ++r)
+        if (A->count[r] >= 2) A->head[r] = (uint64_t)(A->count[r] > 0xFFFE ? 0xFFFF : A->count[r]) | (off[r] << 16);
+    return A;
+}
+void emu_annotation_free(void *a) { delete static_cast<EmuAnno *>(a); }
+
+void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_limits *limits, const char *seqs, const uint64_t *offsets,
+                     uint64_t n, int map_only);
 void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, const char *seqs, const uint64_t *offsets,
                 uint64_t n, int map_only) {
+    return emu_align_anno(gh, nullptr, config, limits, seqs, offsets, n, map_only);
+}
+// anno != nullptr: label-aware alignment (LabeledAligner) with that label matrix
+void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_limits *limits, const char *seqs, const uint64_t *offsets,
+                     uint64_t n, int map_only) {
     auto *G = static_cast<EmuGraph *>(gh);
+    auto *AN = static_cast<EmuAnno *>(anno);
     auto *R = new EmuRun();
     mgx_config cfg;
     DevConfig dcfg;
-    int rc = prepare_config(*config, G->g.k, &cfg, &dcfg, &R->error);
+    int rc = prepare_config(*config, G->g.k, &cfg, &dcfg, &R->error, AN != nullptr);
     if (rc) return R;
     if (G->mode == MGX_MODE_CANONICAL) { dcfg.canonical = 1; dcfg.fwd_and_rc = 1; }      // as mgx_aligner_create
     if (G->mode == MGX_MODE_PRIMARY) { dcfg.canonical = G->tables ? 3 : 2; dcfg.fwd_and_rc = 1; }
@@ -303,14 +342,15 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     R->m_fwd.assign(nf.begin(), nf.end());
     R->m_rc.assign(nr.begin(), nr.end());
     if (map_only) return R;
-    rc = derive_limits(cfg, limits, Lmax, &R->lim, &R->error);
+    if (AN && G->mode != MGX_MODE_BASIC) { R->error = "label-aware alignment: BASIC-mode graphs only"; return R; }
+    rc = derive_limits(cfg, limits, Lmax, &R->lim, &R->error, AN != nullptr);
     if (rc) return R;
     const uint64_t stride = arena_bytes(R->lim);
     std::vector<uint8_t> arena(stride, 0);
     std::vector<int8_t> sm(128 * 128);
     memcpy(sm.data(), cfg.score_matrix, 128 * 128);
     R->results.resize(n);
-    uint64_t out_words = n * ((uint64_t)R->lim.Lmax * 3 + 64) * std::max<uint64_t>(1, cfg.num_alternative_paths) + 1024;
+    uint64_t out_words = n * ((uint64_t)R->lim.Lmax * 3 + 64) * std::max<uint64_t>(1, AN ? R->lim.lab_pool : cfg.num_alternative_paths) + 1024;
     R->stream.assign(out_words, 0);
     R->seeds.assign(n * 2 * (uint64_t)R->lim.max_seeds, DevSeed{ 0, 0, 0, 0, 0 });
     unsigned long long cursors[2] = { 0, 0 };
@@ -325,6 +365,10 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     P.results = R->results.data(); P.out_stream = R->stream.data(); P.out_capacity = out_words;
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();
     P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
+    if (AN) {
+        P.labeled = 1; P.no_fast = 1;
+        P.anno_head = AN->head.data(); P.anno_count = AN->count.data(); P.anno_more = AN->more.data(); P.anno_rows = AN->n_rows;
+    }
     P.no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;
     P.no_alias = getenv("MGX_NO_ALIAS") && atoi(getenv("MGX_NO_ALIAS")) == 1;
     P.no_bt_runs = getenv("MGX_NO_BT_RUNS") && atoi(getenv("MGX_NO_BT_RUNS")) == 1;
@@ -338,7 +382,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
     const char *split = getenv("MGX_EMU_SPLIT");
     // the extension phase of one read: through the flat group loop (the product's default with one alignment per seed; a
     // single group here, so every transition of the state machine is exercised, not the interleaving) or the per-read program
-    const bool flat = cfg.num_alternative_paths == 1 && !(getenv("MGX_NO_FLAT") && atoi(getenv("MGX_NO_FLAT")) == 1);
+    const bool flat = cfg.num_alternative_paths == 1 && !AN && !(getenv("MGX_NO_FLAT") && atoi(getenv("MGX_NO_FLAT")) == 1);
     const uint32_t ldsb_all = (uint32_t)(lds_env ? atoi(lds_env) : 2048);
     auto run_extend = [&](uint64_t read, const uint8_t *rec) {
         if (!flat) { align_read<PH_EXTEND>(*w, P, read, 0, &R->stats, &sd, rows.data(), lds.data(), ldsb_all, rec); return; }
@@ -373,7 +417,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         const char *lane_env = getenv("MGX_EMU_LANE");
         std::vector<uint32_t> lane_rest;
         uint64_t n_ext = n;                  // reads the wave program's extension phase takes
-        if (lane_env && *lane_env == '1' && have_packed) {
+        if (lane_env && *lane_env == '1' && have_packed && !AN) {
             LaneParams LP;
             memset(&LP, 0, sizeof(LP));
             std::string why;
@@ -422,7 +466,10 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         const char *mp = getenv("MGX_EMU_MULTIPASS");
         std::vector<uint32_t> retry(n + 1);
         unsigned long long retry_count = 0;
-        if (mp && *mp == '1') {
+        if (AN) {
+            // label-aware alignment: one pass, no seed limit (the per-read program)
+            for (uint64_t i = 0; i < n_ext; ++i) run_extend(order[i], nullptr);
+        } else if (mp && *mp == '1') {
             // the product's multi-pass extension: one seed per read and pass, resume records in between, the retry positions
             // of a pass sorted by their work key for the next one (MGX_EMU_RESUME_CAP: records a pass may write)
             const uint32_t rb = resume_rec_bytes(R->lim, std::max<uint32_t>(1, (uint32_t)cfg.num_alternative_paths));
@@ -492,7 +539,7 @@ void *emu_align(void *gh, const mgx_config *config, const mgx_limits *limits, co
         for (uint64_t i = 0; i < n; ++i) align_read(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
     }
     R->out_used = std::min<uint64_t>(cursors[0], out_words);
-    R->host.decode(R->results.data(), n, R->stream.data());
+    R->host.decode(R->results.data(), n, R->stream.data(), ~0ull, AN != nullptr);
     return R;
 }
 

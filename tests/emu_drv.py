@@ -45,6 +45,12 @@ def L():
         _L.emu_align.restype = C.c_void_p
         _L.emu_align.argtypes = [C.c_void_p, C.POINTER(capi.Config), C.POINTER(capi.Limits), C.c_char_p,
                                  C.POINTER(C.c_uint64), C.c_uint64, C.c_int]
+        _L.emu_annotation_create.restype = C.c_void_p
+        _L.emu_annotation_create.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p)]
+        _L.emu_annotation_free.argtypes = [C.c_void_p]
+        _L.emu_align_anno.restype = C.c_void_p
+        _L.emu_align_anno.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(capi.Config), C.POINTER(capi.Limits), C.c_char_p,
+                                      C.POINTER(C.c_uint64), C.c_uint64, C.c_int]
         _L.emu_error.restype = C.c_char_p
         _L.emu_error.argtypes = [C.c_void_p]
         _L.emu_results.argtypes = [C.c_void_p, C.POINTER(capi.Results)]
@@ -103,14 +109,31 @@ class EmuGraph:
         return bool(L().emu_terminus_primary(self.h, v))
 
 
+class EmuAnnotation:
+    """The label matrix in the device's row-major form, from an orc.Annotation (its column bit vectors)."""
+
+    def __init__(self, orc_annotation):
+        self.n_labels = orc_annotation.n_labels
+        self._cols = [np.ascontiguousarray(orc_annotation.column_words(j), dtype=np.uint64) for j in range(self.n_labels)]
+        ptrs = (C.c_void_p * max(1, self.n_labels))(*[c.ctypes.data for c in self._cols])
+        self.n_rows = orc_annotation.graph.n_edges
+        self.h = L().emu_annotation_create(self.n_rows, self.n_labels, ptrs)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            L().emu_annotation_free(self.h)
+            self.h = None
+
+
 class EmuRun:
-    def __init__(self, graph, config, queries, limits=None, map_only=False):
+    def __init__(self, graph, config, queries, limits=None, map_only=False, annotation=None):
         from orc import pack_queries
         blob, offs = pack_queries(queries)
-        self._keep = (blob, offs)
+        self._keep = (blob, offs, annotation)
         self.n = len(queries)
-        self.r = L().emu_align(graph.h, C.byref(config), C.byref(limits) if limits is not None else None, blob,
-                               offs.ctypes.data_as(C.POINTER(C.c_uint64)), self.n, int(map_only))
+        self.r = L().emu_align_anno(graph.h, annotation.h if annotation is not None else None, C.byref(config),
+                                    C.byref(limits) if limits is not None else None, blob,
+                                    offs.ctypes.data_as(C.POINTER(C.c_uint64)), self.n, int(map_only))
         self.error = L().emu_error(self.r).decode()
 
     def __del__(self):

@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--modes", default="0,0,1,2,2", help="graph modes to draw from (0 BASIC, 1 CANONICAL, 2 PRIMARY)")
     ap.add_argument("--lane", action="store_true", help="campaign of the lane-per-read path: BASIC graphs, k <= 32, one alignment per "
                     "query, the split pipeline with MGX_EMU_LANE=1, short reads, more reads per world, scoring variants")
+    ap.add_argument("--labels", action="store_true", help="campaign of label-aware alignment (LabeledAligner): BASIC graphs built from "
+                    "several diverged strains, a label per strain and per genome segment, compared with the oracle's LabeledAligner "
+                    "(alignment lists and their label sets)")
     args = ap.parse_args()
     if args.lanes in ("8", "16"):
         os.environ["MGX_EMU_WAVE"] = args.lanes
@@ -45,6 +48,9 @@ def main():
         if args.lane:
             mode = 0
             k = rng.choice([7, 8, 11, 12, 15, 19, 20, 27, 31, 32])
+        if args.labels:
+            mode = 0
+            k = rng.choice([5, 7, 8, 11, 12, 15, 19, 20, 31, 33])
         mask = rng.random() < 0.4
         glen = rng.choice([300, 1000, 3000, 6000])
         genome = rand_seq(rng, glen)
@@ -57,6 +63,26 @@ def main():
             p = rng.randrange(k, len(genome) - k)
             alt = rng.choice([c for c in "ACGT" if c != genome[p]])
             seqs.append(genome[max(0, p - k + 1):p] + alt + genome[p + 1:p + k])
+        label_seqs = []                                          # (sequence, label) pairs of the annotation
+        if args.labels:
+            # strains: copies of the genome with SNPs / indels, one label each; plus labels on segments of the genome (overlapping
+            # the strain labels); some sequence in the graph carries no label at all
+            n_strains = rng.choice([1, 2, 3, 6])
+            for sidx in range(n_strains):
+                st = genome if sidx == 0 else mutate(rng, genome, rng.choice([0.005, 0.02, 0.05]))
+                if len(st) <= k + 2:
+                    st = genome
+                seqs.append(st)
+                label_seqs.append((st, sidx))
+            n_lab = n_strains
+            for _ in range(rng.choice([0, 2, 5])):
+                a = rng.randrange(0, max(1, len(genome) - 2 * k))
+                b = min(len(genome), a + rng.choice([2 * k, 100, 400]))
+                label_seqs.append((genome[a:b], n_lab))
+                n_lab += 1
+            if rng.random() < 0.3:                               # an unlabeled contig sharing a stretch with the genome
+                a = rng.randrange(0, max(1, len(genome) - 3 * k))
+                seqs.append(rand_seq(rng, 2 * k) + genome[a:a + 3 * k] + rand_seq(rng, 2 * k))
         if mode == 2:
             seqs = primary_contigs(seqs, k, rng.choice(["input", "lex", "colex"]))[0]
         try:
@@ -65,6 +91,12 @@ def main():
             print("skip build:", e)
             continue
         eg = emu_drv.EmuGraph(g, mode=mode)
+        anno = ea = None
+        if args.labels:
+            anno = orc.Annotation(g, max(1, max(l for _, l in label_seqs) + 1))
+            for sq, lbl in label_seqs:
+                anno.annotate(sq, lbl)
+            ea = emu_drv.EmuAnnotation(anno)
         cfg = capi.config_cli(k)
         cfg.min_exact_match = rng.choice([0.0, 0.0, 0.7])
         if rng.random() < 0.5:
@@ -129,6 +161,11 @@ def main():
             os.environ.pop("MGX_EMU_MULTIPASS", None)
             os.environ["MGX_EMU_SPLIT"] = "1"
             os.environ["MGX_EMU_LANE"] = "1"
+        if args.labels:
+            os.environ.pop("MGX_EMU_MULTIPASS", None)
+            cfg.num_alternative_paths = rng.choice([1, 1, 1, 2])
+            if rng.random() < 0.3:
+                cfg.left_end_bonus, cfg.right_end_bonus = rng.choice([0, 2, 5]), rng.choice([0, 3, 5])
         desc = dict(seed=seed, mode=mode, k=k, mask=mask, glen=len(genome), n_seqs=len(seqs), msl=cfg.min_seed_length,
                     maxsl=cfg.max_seed_length, per_locus=cfg.max_num_seeds_per_locus, xdrop=cfg.xdrop, n_alt=cfg.num_alternative_paths,
                     fwd_rc=cfg.forward_and_reverse_complement, mem=cfg.min_exact_match,
@@ -139,16 +176,26 @@ def main():
             t_w = time.time()
             # (end bonuses: the reference's own Alignment::is_valid — a debug assertion there — rejects some alignments it
             # produces; the comparison is against what it produces)
-            o = orc.AlignRun(g, cfg, reads, validate=not (cfg.left_end_bonus or cfg.right_end_bonus))
+            if args.labels:
+                o = orc.LabeledAlignRun(g, cfg, anno, reads, validate=not (cfg.left_end_bonus or cfg.right_end_bonus))
+            else:
+                o = orc.AlignRun(g, cfg, reads, validate=not (cfg.left_end_bonus or cfg.right_end_bonus))
             if args.verbose:
                 print('  oracle %.1fs' % (time.time() - t_w), flush=True)
             if o.error:
                 print("oracle error (skipped):", o.error[:100], desc)
                 continue
-            e = emu_drv.EmuRun(eg, cfg, reads)
+            e = emu_drv.EmuRun(eg, cfg, reads, annotation=ea)
             assert e.error == "", e.error
             got, status = e.results()
             want = o.results()
+            if args.labels:
+                for q, per_aln in enumerate(o.labels()):
+                    for a, ls in zip(want[q], per_aln):
+                        a["labels"] = [int(x) for x in ls]
+                n_cap = sum(1 for st in status if st != 0)
+                if n_cap:
+                    print("  capacity:", n_cap, "of", len(reads), desc)
             for q in range(len(reads)):
                 if status[q] != 0:
                     continue                                     # capacity status: allowed, never a wrong answer
