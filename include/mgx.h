@@ -216,7 +216,8 @@ typedef struct mgx_stats {
                                    csrc/lane_read.hpp: 3 second strand, 4 many seeds, 5 invalid characters, 10 fork, 14 / 16 wide band,
                                    15 node seen before, 19 a later seed survives, 26 backward extension, ...) */
 } mgx_stats;
-enum { MGX_KERNEL_GRP8 = 1, MGX_KERNEL_GRP8_PRIM = 2, MGX_KERNEL_GRP8_ALT = 4, MGX_KERNEL_EXT64 = 8, MGX_KERNEL_LANE = 16 };
+enum { MGX_KERNEL_GRP8 = 1, MGX_KERNEL_GRP8_PRIM = 2, MGX_KERNEL_GRP8_ALT = 4, MGX_KERNEL_EXT64 = 8, MGX_KERNEL_LANE = 16,
+       MGX_KERNEL_LAB64 = 32 /* the label-aware build of the 64-lane kernel */ };
 
 int mgx_device_count(void);                 /* number of visible HIP devices (0 without a GPU) */
 const char *mgx_last_error(void);
@@ -329,6 +330,28 @@ uint32_t mgx_annotation_num_labels(const mgx_annotation *a);
  * untouched).  rows_on_device / out_on_device != 0: device pointers (rows already in HBM / results left in HBM). */
 int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n, int rows_on_device,
                             uint64_t *out_begin, uint32_t *out_labels, uint64_t cap, int out_on_device, uint64_t *n_labels_out);
+
+/* LabeledAligner<>(graph, config, annotator) (aligner_labeled.hpp:125-127; ctor aligner_labeled.cpp:450-466: DBGAligner's
+ * clamps, then min / max_seed_length <= k): an aligner whose batches run label-aware — seeds filtered by label
+ * (filter_seeds, aligner_labeled.cpp:612-721), every DP column carries the labels shared along its path
+ * (LabeledExtender::call_outgoing / flush, :81-137,176-302), backtracking reports one alignment per label subset of the seed
+ * (:304-448), the aggregator keeps num_alternative_paths alignments per label (aligner_aggregator.hpp:68-206).  Every
+ * mgx_alignment of its results carries its labels (n_labels, labels_begin into mgx_results.labels, ascending).  Used with
+ * mgx_align_batch / mgx_align_batch_device / mgx_fetch_results like any aligner; `annotation` must outlive it and live on
+ * the graph's device, with at least as many rows as the graph has nodes (row = node - 1).
+ * This round: BASIC-mode graphs, annotations without coordinates (ColumnCompressed), num_alternative_paths <= 2;
+ * anything else: MGX_ERR_UNSUPPORTED.  A read whose label bookkeeping outgrows its arena gets MGX_ERR_CAPACITY. */
+int mgx_labeled_aligner_create(const mgx_graph *graph, const mgx_config *config, const mgx_limits *limits,
+                               const mgx_annotation *annotation, mgx_aligner **out);
+/* mgx_format_tsv for label-aware results: every alignment's fields are followed by its labels' names joined by ';'
+ * (cli/align.cpp:274-281; label_names[j] = LabelEncoder::decode(j); a label without a name prints its number). */
+size_t mgx_format_tsv_labeled(const mgx_results *res, uint64_t query_index, const char *header,
+                              const char *query, size_t query_len, int32_t min_path_score,
+                              const char *const *label_names, uint32_t n_label_names, char *buf, size_t buf_len);
+/* mgx_results_from_raw for the records of a label-aware aligner (labeled != 0: every alignment's arrays are followed by
+ * its label list in the stream). */
+int mgx_results_from_raw_labeled(const void *headers, uint64_t n_queries, const uint32_t *stream, uint64_t stream_words,
+                                 int labeled, mgx_raw_store **store, mgx_results *out);
 
 #ifdef __cplusplus
 }

@@ -70,18 +70,42 @@ class Graph:
         return capi.lib().mgx_graph_device_bytes(self.h)
 
 
+class Annotation:
+    """The label matrix of an annotated graph on the GPU (mgx_annotation_create): columns[j] = the bit vector of label j over the
+    rows (row = node - 1), 64 rows per uint64 word."""
+
+    def __init__(self, n_rows, columns, device=0):
+        self._cols = [np.ascontiguousarray(c, dtype=np.uint64) for c in columns]
+        ptrs = (C.c_void_p * max(1, len(self._cols)))(*[c.ctypes.data for c in self._cols])
+        self.h = C.c_void_p()
+        self.n_rows, self.n_labels = n_rows, len(self._cols)
+        _check(capi.lib().mgx_annotation_create(n_rows, len(self._cols), ptrs, device, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None) and capi is not None:
+            capi.lib().mgx_annotation_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 class Aligner:
-    """DBGAligner<> on the GPU (default seeder/extender)."""
+    """DBGAligner<> on the GPU (default seeder/extender); with `annotation`: LabeledAligner<> (aligner_labeled.hpp:125-127)."""
 
     # kernel-selection options (mgx_aligner_set_pipeline "key=value") every new aligner starts with: all of them give the
     # same alignments; the parity suite sets this to run a kernel the automatic choice would not pick for its batch sizes
     default_options = ()
 
-    def __init__(self, graph, config, limits=None):
+    def __init__(self, graph, config, limits=None, annotation=None):
         self.graph = graph
+        self.annotation = annotation
         self.h = C.c_void_p()
-        _check(capi.lib().mgx_aligner_create(graph.h, C.byref(config), C.byref(limits) if limits is not None else None,
-                                             C.byref(self.h)))
+        if annotation is not None:
+            _check(capi.lib().mgx_labeled_aligner_create(graph.h, C.byref(config), C.byref(limits) if limits is not None else None,
+                                                         annotation.h, C.byref(self.h)))
+        else:
+            _check(capi.lib().mgx_aligner_create(graph.h, C.byref(config), C.byref(limits) if limits is not None else None,
+                                                 C.byref(self.h)))
         for opt in Aligner.default_options:
             self.set_pipeline(opt)
 

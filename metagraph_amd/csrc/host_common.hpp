@@ -115,6 +115,10 @@ inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lm
         // label sets: per-extension sets (one per fork and per flushed column that lost labels), per-read sets (seeds,
         // alignments), the seed filter's position bitmaps (one per label seen on the read's seeds)
         l.lab_words = (uint32_t)std::min<uint64_t>(1u << 24, 16384 + 8ull * l.max_columns + 64ull * ((l.Lmax + 31) / 32 + 2));
+        // every column goes through the general path (pool entries, no aliases) and every backward alignment writes its
+        // filter_nodes marks (a vector of the aligned query range per path node): room for a few of them on short reads
+        l.conv_pool_words = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, (uint64_t)l.conv_pool_words
+                                                          + std::min<uint64_t>(4ull * (l.Lmax + 8) * (l.Lmax + 8), 1ull << 22));
     }
     return MGX_OK;
 }

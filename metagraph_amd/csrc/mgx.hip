@@ -306,6 +306,13 @@ extern "C" unsigned mgx_grp_static_lds8_alt(void);
 extern "C" int mgx_grp_waves_per_simd8_alt(void);
 extern "C" int mgx_launch_ext64(const void *params, uint32_t blocks, uint32_t lds_bytes, void *stream);      // mgx_ext64.hip
 extern "C" int mgx_launch_lane(const void *d_params, uint32_t blocks, void *stream);                         // mgx_lane.hip
+// the 64-lane extension kernel with the label-aware extender compiled in (mgx_lab64.hip: -DMGX_WITH_LABELS=1)
+extern "C" int mgx_launch_lab64(const void *params, uint32_t blocks, uint32_t lds_bytes, void *stream);
+extern "C" unsigned mgx_lab64_static_lds(void);
+extern "C" int mgx_lab64_waves_per_simd(void);
+extern "C" int mgx_lab64_max_alt(void);
+extern "C" void mgx_annotation_device_view(const mgx_annotation *a, int *device, uint64_t *n_rows, const uint64_t **head,
+                                           const uint32_t **count, const uint32_t **more);                    // mgx_annot.hip
 extern "C" int mgx_lane_waves_per_simd(void);
 extern "C" unsigned mgx_ext64_static_lds(void);
 extern "C" int mgx_ext64_waves_per_simd(void);
@@ -341,6 +348,7 @@ static AlignMode default_mode() { return MODE_SPLIT8; }
 
 struct mgx_aligner {
     const mgx_graph *graph = nullptr;
+    const mgx_annotation *anno = nullptr;      // label-aware alignment (mgx_labeled_aligner_create)
     mgx_config cfg;
     DevConfig dcfg;
     mgx_limits user_lim;
@@ -641,15 +649,31 @@ uint64_t mgx_graph_device_bytes(const mgx_graph *g) { return g->bytes; }
 // ------------------------------------------------------------------------------------------------
 // aligner
 // ------------------------------------------------------------------------------------------------
-int mgx_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_limits *limits, mgx_aligner **out) {
+static int aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_limits *limits, const mgx_annotation *anno,
+                          mgx_aligner **out) {
     if (!g || !config || !out) return fail(MGX_ERR_INVALID, "null argument");
     auto *A = new mgx_aligner();
     std::unique_ptr<mgx_aligner> guard(A);
     A->graph = g;
+    A->anno = anno;
     {
         std::string err;
-        int rc = prepare_config(*config, g->g.k, &A->cfg, &A->dcfg, &err);
+        int rc = prepare_config(*config, g->g.k, &A->cfg, &A->dcfg, &err, anno != nullptr);
         if (rc) return fail(rc, "%s", err.c_str());
+    }
+    if (anno) {
+        // LabeledAligner<>(graph, config, annotator) (aligner_labeled.hpp:125-127).  On the device: BASIC-mode graphs (the
+        // reference looks labels up by base node through the CanonicalDBG wrapper for PRIMARY graphs and by spelling for
+        // CANONICAL ones: not on the device yet), annotation without coordinates, as many alternative paths per label as
+        // the labeled kernel build holds.
+        if (g->mode != MGX_MODE_BASIC) return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment runs on BASIC-mode graphs only");
+        if (A->cfg.num_alternative_paths > (uint64_t)mgx_lab64_max_alt())
+            return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment: num_alternative_paths <= %d on the device", mgx_lab64_max_alt());
+        int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;
+        mgx_annotation_device_view(anno, &adev, &arows, &h, &c, &m);
+        if (adev != g->device) return fail(MGX_ERR_INVALID, "the annotation lives on device %d, the graph on device %d", adev, g->device);
+        if (arows < g->g.n) return fail(MGX_ERR_INVALID, "the annotation has %llu rows, the graph %llu nodes (row = node - 1)",
+                                        (unsigned long long)arows, (unsigned long long)g->g.n);
     }
     if (g->mode == MGX_MODE_CANONICAL) { A->dcfg.canonical = 1; A->dcfg.fwd_and_rc = 1; }     // dbg_aligner.cpp:225-226
     if (g->mode == MGX_MODE_PRIMARY) { A->dcfg.canonical = g->primary_tables ? 3 : 2; A->dcfg.fwd_and_rc = 1; }   // through the wrapper
@@ -666,6 +690,14 @@ int mgx_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_l
     memset(&A->lim, 0, sizeof(A->lim));
     *out = guard.release();
     return MGX_OK;
+}
+int mgx_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_limits *limits, mgx_aligner **out) {
+    return aligner_create(g, config, limits, nullptr, out);
+}
+int mgx_labeled_aligner_create(const mgx_graph *g, const mgx_config *config, const mgx_limits *limits, const mgx_annotation *annotation,
+                               mgx_aligner **out) {
+    if (!annotation) return fail(MGX_ERR_INVALID, "null argument");
+    return aligner_create(g, config, limits, annotation, out);
 }
 
 void mgx_aligner_destroy(mgx_aligner *a) {
@@ -811,9 +843,10 @@ static int work_key_bits(uint64_t n) {
 static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, uint32_t Lmax) {
     {
         std::string err;
-        int rc = derive_limits(A->cfg, A->have_user_lim ? &A->user_lim : nullptr, Lmax, &A->lim, &err);
+        int rc = derive_limits(A->cfg, A->have_user_lim ? &A->user_lim : nullptr, Lmax, &A->lim, &err, A->anno != nullptr);
         if (rc) return fail(rc, "%s", err.c_str());
     }
+    const bool labeled = A->anno != nullptr;
     const DevLimits &l = A->lim;
     const uint64_t stride = arena_bytes(l);
     hipDeviceProp_t prop;
@@ -824,7 +857,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     memset(&LP, 0, sizeof(LP));
     std::string lane_why;
     const uint32_t lane_blocks = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)mgx_lane_waves_per_simd();
-    bool lane_ok = A->opt.lane != 0 && A->packed_valid && A->mode == MODE_SPLIT8 && !A->opt.two_pass && A->opt.multi_pass != 1
+    bool lane_ok = !labeled && A->opt.lane != 0 && A->packed_valid && A->mode == MODE_SPLIT8 && !A->opt.two_pass && A->opt.multi_pass != 1
                    && lane_enabled(A->cfg, A->dcfg, A->graph->g.k, l.Lmax, A->no_fast, &LP, &lane_why)
                    && (A->opt.lane == 1 || n >= (uint64_t)lane_blocks * 16);       // (a small batch: the spread / 64-lane kernels are quicker)
     if (lane_ok) {
@@ -844,7 +877,9 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     const bool sel_primary = A->dcfg.canonical >= 2;
     const bool sel_alt = A->cfg.num_alternative_paths > 1 || (sel_primary && A->opt.primary_alt_build == 1);
     const uint64_t ext_wps = sel_alt ? mgx_grp_waves_per_simd8_alt() : sel_primary ? mgx_grp_waves_per_simd8_prim() : mgx_grp_waves_per_simd8();
-    const uint64_t want_slots = std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * ext_wps);
+    // (label-aware batches: seeding as ever, extension on the one-read-per-wavefront labeled kernel)
+    const uint64_t want_slots = labeled ? std::max<uint64_t>(wave_slots, (uint64_t)prop.multiProcessorCount * 4 * mgx_lab64_waves_per_simd())
+                                        : std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * ext_wps);
     // The arena gets what is free after the buffers this stage allocates AFTER it (result records, output stream, seed
     // stream, sort arrays: estimated generously) and a margin; buffers kept from an earlier batch are already outside
     // `free_b`.  (Half of the free memory, as before, left 15 % of the extension kernel's groups without a slice at
@@ -872,6 +907,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     if (probe_env_set("MGX_DEBUG_SLOTS")) fprintf(stderr, "run_align: n %llu stride %llu want_slots %llu slots %llu free %.1f GB\n", (unsigned long long)n, (unsigned long long)stride, (unsigned long long)want_slots, (unsigned long long)slots, free_b / 1e9);
     if (int rc = A->results.ensure(n * sizeof(ReadResult))) return rc;
     uint64_t words_per_read = ((uint64_t)l.Lmax + l.Lmax / 4 + 40) * std::max<uint64_t>(1, A->cfg.num_alternative_paths);
+    if (labeled) words_per_read = words_per_read * 2 + 16;      // (an alignment per label group + the label lists; heuristic as below)
     // heuristic size (one alignment per read: nodes + CIGAR runs + path characters); a batch that needs more is re-run
     // with what it asked for (mgx_align_batch_device), so the size is never a correctness limit
     uint64_t out_words = std::max<uint64_t>(n * words_per_read + 1024, A->out_min_words);
@@ -914,6 +950,13 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.no_alias = A->opt.no_alias != 0;
     P.no_bt_runs = A->opt.no_bt_runs != 0;
     P.no_flat = A->opt.no_flat != 0;
+    if (labeled) {
+        int adev = 0;
+        mgx_annotation_device_view(A->anno, &adev, &P.anno_rows, &P.anno_head, &P.anno_count, &P.anno_more);
+        P.labeled = 1;
+        P.no_fast = 1;            // every column through the general path (column label sets live on the DP table's records)
+        P.no_alias = 1;
+    }
 #ifdef MGX_PROBES
     P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results (probe builds only)
 #endif
@@ -982,6 +1025,15 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         }
         // One read per wavefront: the 64-lane instantiation (mgx_ext64.hip) — the read has the wavefront to itself, so it may as
         // well use all of its lanes.  MGX_EXT64=0: A/B switch.
+        if (labeled) {
+            // label-aware extension: one read per wavefront on the labeled build of the 64-lane kernel (mgx_lab64.hip)
+            const uint32_t wcu = 4u * (uint32_t)mgx_lab64_waves_per_simd();
+            const uint32_t lds64 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), (160u * 1024u) / wcu - mgx_lab64_static_lds() - 128u) & ~15u;
+            const uint64_t resident = (uint64_t)prop.multiProcessorCount * wcu;
+            P.groups_per_wave = 1;
+            A->kernels_ran |= MGX_KERNEL_LAB64;
+            return mgx_launch_lab64(&P, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(slots, resident)), lds64, nullptr);
+        }
         const bool ext64 = A->opt.ext64 != 0;
         if (ext64 && phase == PH_EXTEND && P.groups_per_wave == 1) {
             const uint32_t wcu = 4u * (uint32_t)mgx_ext64_waves_per_simd();
@@ -1034,8 +1086,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         // instead of waiting for the mate with the most seeds.  MGX_TWO_PASS=1: the older variant (pass 2 from scratch).
         const int two_pass_env = A->opt.two_pass;
         const int multi_env = A->opt.multi_pass;
-        bool multi = multi_env == 1;
-        if (multi_env < 0) {
+        bool multi = multi_env == 1 && !labeled;
+        if (multi_env < 0 && !labeled) {
             // automatic: worth it when reads run many extensions, i.e. carry many seeds (sub-k seeds of a pan-genome: ~100 per
             // read; a plain read: a handful).  The seeding kernel has finished counting them by now.
             unsigned long long seeds_total = 0;
@@ -1132,7 +1184,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             }
         }
         if (!multi && !nothing_left) {
-            const bool two_pass = two_pass_env == 1;
+            const bool two_pass = two_pass_env == 1 && !labeled;
             for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {
                 if (two_pass && pass == 0) {
                     P.seed_limit = 1;
@@ -1291,7 +1343,7 @@ int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
     }
     A->h_stream.resize(used);
     if (used) HIP_TRY(hipMemcpy(A->h_stream.data(), A->stream.p, used * 4, hipMemcpyDeviceToHost));
-    A->host.decode(A->h_results.data(), n, A->h_stream.data());
+    A->host.decode(A->h_results.data(), n, A->h_stream.data(), ~0ull, A->anno != nullptr);
     A->host.view(out);
     return MGX_OK;
 }
@@ -1313,10 +1365,14 @@ struct mgx_raw_store { HostResults host; };
 
 int mgx_results_from_raw(const void *headers, uint64_t n, const uint32_t *stream, uint64_t stream_words,
                          mgx_raw_store **store, mgx_results *out) {
+    return mgx_results_from_raw_labeled(headers, n, stream, stream_words, 0, store, out);
+}
+int mgx_results_from_raw_labeled(const void *headers, uint64_t n, const uint32_t *stream, uint64_t stream_words, int labeled,
+                                 mgx_raw_store **store, mgx_results *out) {
     if ((!headers && n) || !store || !out || (!stream && stream_words)) return fail(MGX_ERR_INVALID, "null argument");
     const ReadResult *rr = static_cast<const ReadResult *>(headers);
     auto *S = new mgx_raw_store();
-    if (!S->host.decode(rr, n, stream, stream_words)) {
+    if (!S->host.decode(rr, n, stream, stream_words, labeled != 0)) {
         delete S;
         return fail(MGX_ERR_INVALID, "a record points outside the stream (%llu words)", (unsigned long long)stream_words);
     }
@@ -1366,6 +1422,11 @@ void mgx_kernel_launch_counts(uint64_t *out5) { for (int x = 0; x < 5; ++x) out5
 
 size_t mgx_format_tsv(const mgx_results *res, uint64_t qi, const char *header, const char *query, size_t query_len,
                       int32_t min_path_score, char *buf, size_t buf_len) {
+    return mgx_format_tsv_labeled(res, qi, header, query, query_len, min_path_score, nullptr, 0, buf, buf_len);
+}
+size_t mgx_format_tsv_labeled(const mgx_results *res, uint64_t qi, const char *header, const char *query, size_t query_len,
+                              int32_t min_path_score, const char *const *label_names, uint32_t n_label_names,
+                              char *buf, size_t buf_len) {
     // cli/align.cpp:262-285 + alignment.hpp:426-433; the query is printed normalised (AlignmentResults ctor)
     std::string s(header);
     s += '\t';
@@ -1387,6 +1448,16 @@ size_t mgx_format_tsv(const mgx_results *res, uint64_t qi, const char *header, c
                 s += std::to_string(op.len) + ops[op.op];
             }
             s += '\t' + std::to_string(a.offset);
+            if (res->labels && a.n_labels) {
+                // cli/align.cpp:274-281: the label names (LabelEncoder::decode), joined by ';'
+                s += '\t';
+                for (uint32_t x = 0; x < a.n_labels; ++x) {
+                    const uint32_t lbl = res->labels[a.labels_begin + x];
+                    if (x) s += ';';
+                    if (label_names && lbl < n_label_names) s += label_names[lbl];
+                    else s += std::to_string(lbl);
+                }
+            }
         }
         s += '\n';
     }

@@ -202,6 +202,11 @@ void mgx_annotation_destroy(mgx_annotation *a) {
 uint64_t mgx_annotation_device_bytes(const mgx_annotation *a) { return a ? a->bytes : 0; }
 uint64_t mgx_annotation_num_rows(const mgx_annotation *a) { return a ? a->n_rows : 0; }
 uint32_t mgx_annotation_num_labels(const mgx_annotation *a) { return a ? a->n_labels : 0; }
+// the matrix as the label-aware extension kernel reads it (mgx.hip fills AlignParams::anno_* from this; library-internal)
+extern "C" void mgx_annotation_device_view(const mgx_annotation *a, int *device, uint64_t *n_rows, const uint64_t **head,
+                                           const uint32_t **count, const uint32_t **more) {
+    *device = a->device; *n_rows = a->n_rows; *head = a->head; *count = a->count; *more = a->more;
+}
 
 /* BinaryMatrix::get_rows(rows) (annotation/binary_matrix/base/binary_matrix.hpp; ColumnMajor: column_major.cpp:27-44) for a
  * whole batch of rows — the ONE call of AnnotationBuffer::fetch_queued_annotations (annotation_buffer.cpp:182) — answered

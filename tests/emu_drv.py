@@ -24,7 +24,7 @@ def L():
         if os.environ.get("MGX_EMU_LANE_CHECK"):                # tests/test_lane_column.py: chain_step cross-checks lane_column()
             subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "lanecheck"], check=True)
             suffix = "_lanecheck_w8"
-        _L = C.CDLL(os.path.join(ROOT, "tests", "emu", "_build", "libmgxemu%s.so" % suffix))
+        _L = C.CDLL(os.environ.get("MGX_EMU_LIB") or os.path.join(ROOT, "tests", "emu", "_build", "libmgxemu%s.so" % suffix))   # (MGX_EMU_LIB: an instrumented build)
         _L.emu_graph_create.restype = C.c_void_p
         _L.emu_graph_create.argtypes = [C.POINTER(capi.BossView)]
         _L.emu_graph_free.argtypes = [C.c_void_p]

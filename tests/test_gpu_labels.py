@@ -1,0 +1,125 @@
+"""Label-aware alignment on the GPU (mgx_labeled_aligner_create -> the labeled build of the 64-lane extension kernel,
+mgx_lab64.hip) against the oracle's LabeledAligner through the C-ABI: full alignment lists AND label lists.  The reference's
+label tests on BASIC graphs (tests/annotation/test_aligner_labeled.cpp), 200 small random labeled worlds, 1000-read worlds,
+the TSV line with its label column (cli/align.cpp:274-281).  Needs a real MI355X."""
+import ctypes as C
+
+import pytest
+
+import orc
+from metagraph_amd import aligner, capi
+from labeled_worlds import labeled_world, with_labels
+from test_gpu_parity import gpu_graph
+from test_oracle_labeled import CASES, build
+from emu_drv import oracle_seeds_as_tuples
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_annotation(anno):
+    return aligner.Annotation(anno.graph.n_edges, [anno.column_words(j) for j in range(anno.n_labels)])
+
+
+def compare_gpu_labeled(g, anno, cfg, reads, validate=True, check_seeds=True):
+    o = orc.LabeledAlignRun(g, cfg, anno, reads, validate=validate)
+    assert o.error == "", o.error
+    G, AN = gpu_graph(g), gpu_annotation(anno)
+    A = aligner.Aligner(G, cfg, annotation=AN)
+    A.keep_seeds(check_seeds)
+    got, status = A.align_batch(reads)
+    assert all(s == 0 for s in status), status
+    want = with_labels(o)
+    for q in range(len(reads)):
+        assert got[q] == want[q], (q, reads[q], got[q], want[q])
+    assert A.stats()["extend_kernels"] == capi.KERNEL_LAB64          # the labeled kernel is the one that ran
+    return A, want
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if CASES[n]["mode"] == 0))
+def test_reference_label_kats_on_gpu(name):
+    case = CASES[name]
+    g, anno, cfg = build(case)
+    for query, expect in case["expect"].items():
+        _, want = compare_gpu_labeled(g, anno, cfg, [query], validate=not (cfg.left_end_bonus or cfg.right_end_bonus), check_seeds=False)
+        assert len(want[0]) == len(expect)
+        for a in want[0]:                                    # the reference's own assertions (get_alignment_labels)
+            names = [case["labels"][l] for l in a["labels"]]
+            assert names and any(expect.get(nm) == a["sequence"] for nm in names)
+
+
+def test_200_random_labeled_worlds_on_gpu():
+    n_multi_aln = n_multi_label = n_reads = 0
+    for seed in range(200):
+        k = [7, 11, 12, 15, 19, 31][seed % 6]
+        g, anno, reads = labeled_world(1000 + seed, k, n_strains=[1, 2, 3, 6][seed % 4], genome_len=[400, 1500][seed % 2],
+                                       n_reads=12, read_len=[60, 100, 150][seed % 3], divergence=[0.01, 0.02, 0.05][seed % 3])
+        cfg = capi.config_cli(k)
+        if seed % 2:
+            cfg.min_seed_length = max(5, k - 4)
+        if seed % 5 == 0:
+            cfg.num_alternative_paths = 2
+        if seed % 7 == 0:
+            cfg.forward_and_reverse_complement = 0
+        _, want = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=False)
+        n_reads += len(reads)
+        n_multi_aln += sum(1 for a in want if len(a) > 1)
+        n_multi_label += sum(1 for a in want for x in a if len(x["labels"]) > 1)
+    assert n_multi_aln > 100 and n_multi_label > 100, (n_reads, n_multi_aln, n_multi_label)
+
+
+@pytest.mark.parametrize("seed,k,n_strains", [(1, 31, 8), (2, 19, 4)])
+def test_1000_read_labeled_world_on_gpu(seed, k, n_strains):
+    g, anno, reads = labeled_world(7000 + seed, k, n_strains=n_strains, genome_len=20000, n_reads=1000, read_len=150,
+                                   n_segments=12, divergence=0.02)
+    A, want = compare_gpu_labeled(g, anno, capi.config_cli(k), reads, check_seeds=False)
+    assert sum(1 for a in want if a) > 500
+    assert sum(1 for a in want if len(a) > 1) > 20
+
+
+def test_label_filter_products_on_gpu():
+    """the seed lists and num_matching after LabeledAligner::filter_seeds (what the extension kernel works from)"""
+    g, anno, reads = labeled_world(42, 15, n_strains=3, n_reads=30)
+    cfg = capi.config_cli(15)
+    cfg.min_seed_length = 11
+    o = orc.LabeledAlignRun(g, cfg, anno, reads)
+    A, _ = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=True)
+    info = A.seed_info(len(reads))
+    for strand in (0, 1):
+        for q, (ss, nm) in enumerate(o.seeds(strand)):
+            assert info[q]["num_matches"][strand] == nm, (q, strand)
+            assert info[q]["seeds"][strand] == oracle_seeds_as_tuples(ss), (q, strand, reads[q])
+
+
+def test_labeled_tsv_line():
+    case = CASES["SimpleTangleGraph"]
+    g, anno, cfg = build(case)
+    query = "CGAATGCAT"
+    G, AN = gpu_graph(g), gpu_annotation(anno)
+    A = aligner.Aligner(G, cfg, annotation=AN)
+    blob, offs = aligner.pack_queries([query])
+    res = capi.Results()
+    assert capi.lib().mgx_align_batch(A.h, blob, offs.ctypes.data, 1, 0, C.byref(res)) == 0
+    names = (C.c_char_p * 3)(b"A", b"B", b"C")
+    L = capi.lib()
+    n = L.mgx_format_tsv_labeled(C.byref(res), 0, b"q1", query.encode(), len(query), cfg.min_path_score, names, 3, None, 0)
+    buf = C.create_string_buffer(n + 1)
+    L.mgx_format_tsv_labeled(C.byref(res), 0, b"q1", query.encode(), len(query), cfg.min_path_score, names, 3, buf, n + 1)
+    line = buf.value.decode()
+    o = orc.LabeledAlignRun(g, cfg, anno, [query])
+    want = "q1\t" + query
+    for a, ls in zip(o.results()[0], o.labels()[0]):         # format_alignment (cli/align.cpp:262-283) with the label column
+        want += "\t%s\t%s\t%d\t%d\t%s\t%d\t%s" % ("-" if a["orientation"] else "+", a["sequence"], a["score"], a["num_matches"],
+                                                a["cigar"], a["offset"], ";".join("ABC"[l] for l in ls))
+    assert line == want + "\n"
+
+
+def test_labeled_aligner_refuses_what_it_cannot_do():
+    from test_oracle_primary_goldens import primary_contigs
+    contigs = primary_contigs(["GTCGAAATTAGTCGAAA"], 5, "input")[0]
+    g = orc.Graph.build(5, contigs, 2, True)
+    W, last, F, valid = g.export()
+    G = aligner.Graph(g.k, W, last, F, valid, mode=2)
+    AN = gpu_annotation(orc.Annotation(g, 1))
+    with pytest.raises(aligner.MgxError) as e:
+        aligner.Aligner(G, capi.config_cli(5), annotation=AN)
+    assert e.value.code == capi.MGX_ERR_UNSUPPORTED

@@ -1,0 +1,70 @@
+"""Label-aware alignment in the kernels' wave program (label_sets.hpp / label_driver.hpp: LabeledExtender's flush /
+call_outgoing / label-bounded backtracking, the per-label aggregator, filter_seeds) under the host model, against the
+oracle's LabeledAligner — full alignment lists AND their label sets: the reference's label tests on BASIC graphs
+(tests/annotation/test_aligner_labeled.cpp, see test_oracle_labeled.py) and random worlds of diverged strains.  CPU only; the
+GPU half is tests/test_gpu_labels.py."""
+import pytest
+
+import emu_drv
+import orc
+from metagraph_amd import capi
+from labeled_worlds import labeled_world, with_labels
+from test_oracle_labeled import CASES, build
+
+
+SEEN = {"multi_aln": 0, "multi_label": 0, "worlds": 0}
+
+
+def compare_emu_labeled(g, anno, cfg, reads, validate=True):
+    o = orc.LabeledAlignRun(g, cfg, anno, reads, validate=validate)
+    assert o.error == "", o.error
+    e = emu_drv.EmuRun(emu_drv.EmuGraph(g), cfg, reads, annotation=emu_drv.EmuAnnotation(anno))
+    assert e.error == "", e.error
+    got, status = e.results()
+    want = with_labels(o)
+    assert all(s == 0 for s in status), status
+    for q in range(len(reads)):
+        assert got[q] == want[q], (q, reads[q], got[q], want[q])
+    info = e.seed_info()                                   # the label filter's products: seed lists and num_matching per strand
+    for strand in (0, 1):
+        for q, (ss, nm) in enumerate(o.seeds(strand)):
+            assert info[q]["num_matches"][strand] == nm, (q, strand)
+            assert info[q]["seeds"][strand] == emu_drv.oracle_seeds_as_tuples(ss), (q, strand, reads[q])
+    return want
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if CASES[n]["mode"] == 0))
+def test_reference_label_kats_in_the_wave_program(name):
+    case = CASES[name]
+    g, anno, cfg = build(case)
+    for query, expect in case["expect"].items():
+        want = compare_emu_labeled(g, anno, cfg, [query], validate=not (cfg.left_end_bonus or cfg.right_end_bonus))
+        assert len(want[0]) == len(expect)
+
+
+@pytest.mark.parametrize("seed,k,n_strains,divergence", [(1, 11, 3, 0.02), (2, 19, 6, 0.05), (3, 7, 2, 0.02), (4, 31, 4, 0.01),
+                                                        (5, 12, 1, 0.0), (6, 15, 6, 0.02)])
+def test_random_labeled_worlds(seed, k, n_strains, divergence, monkeypatch):
+    g, anno, reads = labeled_world(seed, k, n_strains=n_strains, divergence=divergence)
+    cfg = capi.config_cli(k)
+    if seed % 2:
+        cfg.min_seed_length = max(5, k - 4)                # sub-k seeds
+    if seed == 6:
+        cfg.num_alternative_paths = 2
+    if seed % 3 == 0:
+        monkeypatch.setenv("MGX_EMU_SPLIT", "1")           # seeding phase, sort, extension phase (the device's pipeline)
+    want = compare_emu_labeled(g, anno, cfg, reads)
+    SEEN["multi_aln"] += sum(1 for a in want if len(a) > 1)
+    SEEN["multi_label"] += sum(1 for a in want for x in a if len(x["labels"]) > 1)
+    SEEN["worlds"] += 1
+    if SEEN["worlds"] == 6:          # (over the six worlds: reads with several alignments and alignments with several labels occur)
+        assert SEEN["multi_aln"] >= 5 and SEEN["multi_label"] >= 5, SEEN
+
+
+def test_labeled_needs_a_basic_graph():
+    from test_oracle_primary_goldens import primary_contigs
+    contigs = primary_contigs(["GTCGAAATTAGTCGAAA"], 5, "input")[0]
+    g = orc.Graph.build(5, contigs, 2, True)
+    anno = orc.Annotation(g, 1)
+    e = emu_drv.EmuRun(emu_drv.EmuGraph(g, mode=2), capi.config_cli(5), ["GTCGAAA"], annotation=emu_drv.EmuAnnotation(anno))
+    assert "BASIC" in e.error

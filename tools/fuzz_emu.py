@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--minutes", type=float, default=5.0)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lanes", default="")
+    ap.add_argument("--start", type=int, default=0, help="first world of the seed's sequence (to re-run a reported one)")
+    ap.add_argument("--worlds", type=int, default=0, help="stop after this many worlds (0: by time)")
     ap.add_argument("--verbose", action="store_true", help="print every world before it runs (to find a slow or hanging one)")
     ap.add_argument("--modes", default="0,0,1,2,2", help="graph modes to draw from (0 BASIC, 1 CANONICAL, 2 PRIMARY)")
     ap.add_argument("--lane", action="store_true", help="campaign of the lane-per-read path: BASIC graphs, k <= 32, one alignment per "
@@ -36,10 +38,11 @@ def main():
     from test_oracle_primary_goldens import primary_contigs
 
     t_end = time.time() + 60 * args.minutes
-    it = 0
+    it = args.start
     n_reads_total = 0
     n_lane_total = 0
-    while time.time() < t_end:
+    lab_hist = [0] * 12                  # --labels: reads by their number of alignments (0..5+), alignments by their number of labels
+    while time.time() < t_end and not (args.worlds and it >= args.start + args.worlds):
         seed = args.seed * 1000003 + it
         rng = random.Random(seed)
         it += 1
@@ -196,6 +199,10 @@ def main():
                 n_cap = sum(1 for st in status if st != 0)
                 if n_cap:
                     print("  capacity:", n_cap, "of", len(reads), desc)
+                for q in range(len(reads)):
+                    lab_hist[min(len(want[q]), 5)] += 1
+                    for a in want[q]:
+                        lab_hist[6 + min(len(a["labels"]), 5)] += 1
             for q in range(len(reads)):
                 if status[q] != 0:
                     continue                                     # capacity status: allowed, never a wrong answer
@@ -213,7 +220,8 @@ def main():
             print("MISMATCH", desc)
             print(str(ex)[:3000])
             sys.exit(1)
-    print("ok: %d worlds, %d reads, no difference" % (it, n_reads_total) + (" (%d reads finished by the lane path)" % n_lane_total if args.lane else ""))
+    print("ok: %d worlds, %d reads, no difference" % (it, n_reads_total) + (" (%d reads finished by the lane path)" % n_lane_total if args.lane else "")
+          + (" (reads with 0..5+ alignments: %s; alignments with 0..5+ labels: %s)" % (lab_hist[:6], lab_hist[6:]) if args.labels else ""))
 
 
 if __name__ == "__main__":
