@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--host-steps", type=int, default=-1, help="batches of the PCIe-inclusive pipeline (default: --steps; 0 = skip: "
                     "`value` then falls back to the device-resident rate and says so)")
     ap.add_argument("--cpu-1t-sample", type=int, default=1500, help="reads of the single-thread CPU leg")
+    ap.add_argument("--labels", type=int, default=0, help="BASELINE config 3: label-aware alignment (LabeledAligner) against an "
+                    "annotation of this many labels, label j = the j-th segment of the genome (+ 15 positions into its neighbours)")
     ap.add_argument("--options", default="", help="kernel-selection options for A/B runs, '+'-separated (mgx_aligner_set_pipeline, "
                     "e.g. lane=0: without the lane-per-read kernel); results never depend on them")
     args = ap.parse_args()
@@ -97,6 +99,58 @@ def main():
     G = aligner.Graph(args.k, (W.data_ptr(), n_edges + 1), (last.data_ptr(), n_edges + 1), boss["F"],
                       device=local_rank, on_device=True, mode=2 if args.graph_mode == "primary" else 0)
     t_graph = time.time() - t0
+    AN, anno_pairs, t_anno = None, None, 0.0
+    if args.labels:
+        # the annotation: map the genome's k-mers to nodes (k_map through the C-ABI, chunks of 60 kbp), label j on the nodes of
+        # genome segment j widened by 15 positions (so that nodes at the boundaries carry two labels); the SNP windows' alternative
+        # k-mers carry no label.  (row, label) pairs go to mgx_annotation_create_sparse from device memory.
+        assert args.graph_mode == "basic", "label-aware alignment: BASIC-mode graphs"
+        ta = time.time()
+        A0 = aligner.Aligner(G, capi.config_cli(args.k))
+        chunk, step_len = 60000, 60000 - (args.k - 1)
+        starts = torch.arange(0, args.genome - args.k + 1, step_len, device=dev, dtype=torch.int64)
+        node_of = torch.zeros(args.genome - args.k + 1, dtype=torch.int64, device=dev)
+        lut_acgt = torch.tensor([ord(c) for c in synth.CHARS], dtype=torch.uint8, device=dev)
+        per_call = 256
+        for c0 in range(0, len(starts), per_call):
+            st_c = starts[c0:c0 + per_call]
+            lens = torch.minimum(torch.full_like(st_c, chunk), args.genome - st_c)
+            offs_c = torch.zeros(len(st_c) + 1, dtype=torch.int64, device=dev)
+            offs_c[1:] = torch.cumsum(lens, 0)
+            idx = torch.arange(int(offs_c[-1]), device=dev, dtype=torch.int64)
+            which = torch.searchsorted(offs_c[1:], idx, right=True)
+            seq_c = lut_acgt[genome[st_c[which] + (idx - offs_c[which])].long()].contiguous()
+            m = capi.Mapping()
+            rcm = lib.mgx_map_batch(A0.h, C.c_void_p(seq_c.data_ptr()), C.c_void_p(offs_c.data_ptr()), len(st_c), 1, C.byref(m))
+            assert rcm == 0, lib.mgx_last_error()
+            nb = np.ctypeslib.as_array(m.node_begin, shape=(len(st_c) + 1,))
+            nf = torch.from_numpy(np.ctypeslib.as_array(m.nodes_fwd, shape=(int(nb[-1]),)).astype(np.int64)).to(dev)
+            nbt = torch.from_numpy(nb.astype(np.int64)).to(dev)
+            kidx = torch.arange(int(nb[-1]), device=dev, dtype=torch.int64)
+            wc = torch.searchsorted(nbt[1:], kidx, right=True)
+            node_of[st_c[wc] + (kidx - nbt[wc])] = nf
+        del A0
+        assert int((node_of == 0).sum()) == 0, "a k-mer of the genome is missing from the graph"
+        seg = (args.genome + args.labels - 1) // args.labels
+        pos = torch.arange(args.genome - args.k + 1, device=dev, dtype=torch.int64)
+        keys = []
+        for shift in (0, -15, 15):               # own segment, and the neighbour's within 15 positions of a boundary
+            lab = torch.clamp((pos + shift) // seg, 0, args.labels - 1)
+            keys.append(lab << 40 | (node_of - 1))
+        keys = torch.unique(torch.cat(keys))     # sorted by (label, row), duplicates (a k-mer twice in one segment) removed
+        del pos, lab
+        labs = keys >> 40
+        rows_d = (keys & ((1 << 40) - 1)).contiguous()
+        col_begin = torch.zeros(args.labels + 1, dtype=torch.int64, device=dev)
+        col_begin[1:] = torch.cumsum(torch.bincount(labs, minlength=args.labels), 0)
+        torch.cuda.synchronize()
+        AN = aligner.Annotation.from_sparse(n_edges, col_begin.cpu().numpy().astype(np.uint64), rows_d.data_ptr(), device=local_rank, on_device=True)
+        anno_pairs = (col_begin.cpu().numpy(), rows_d.cpu().numpy())
+        t_anno = time.time() - ta
+        del keys, labs, rows_d, node_of
+        if rank == 0:
+            log("annotation: %d labels, %d (row, label) pairs, %.1f MB on the device, built in %.1fs" %
+                (args.labels, len(anno_pairs[1]), AN.device_bytes / 1e6, t_anno))
     reads = synth.sample_reads(genome, args.reads, args.read_len, 20240503 + rank).contiguous()
     offsets = (torch.arange(args.reads + 1, device=dev, dtype=torch.int64) * args.read_len).contiguous()
     torch.cuda.synchronize()
@@ -113,7 +167,7 @@ def main():
         mc, cab = [int(v) for v in os.environ["MGX_BENCH_LIMITS"].split(",")]
         lim = capi.Limits()
         lim.max_query_length, lim.max_columns, lim.max_seeds, lim.cell_arena_bytes = 0, mc, 0, cab
-    A = aligner.Aligner(G, cfg, lim)
+    A = aligner.Aligner(G, cfg, lim, annotation=AN)
     for opt in [o for o in args.options.split("+") if o]:
         A.set_pipeline(opt)
 
@@ -252,6 +306,8 @@ def main():
         # the extension stage; each read's I/O bytes are charged to the kernel that finished it, every read's seeds and node
         # arrays to k_lane (it looks at all of them)
         lane_reads = st["n_lane_reads"]
+        if not (st["extend_kernels"] & capi.KERNEL_LANE):
+            lane_ms = 0.0
         ext_reads = args.reads - lane_reads if lane_ms > 0 else args.reads
         io_per_read = args.read_len + 96 + 2 * 4 * n_kmers + 32
         kernels = {"k_map": (k_map, 64.0 * lines_map + io_map),
@@ -260,7 +316,7 @@ def main():
                                 + (12 * st["n_seeds"] if lane_ms <= 0 else 0))}
         kernel_ms = {"k_map": round(k_map, 3), "k_seed": round(st["seeding_ms"], 3), "work_sort": round(st["sort_ms"], 3),
                      "k_extend": round(st["extend_ms"] - lane_ms, 3)}
-        if lane_ms > 0:
+        if lane_ms > 0 and (st["extend_kernels"] & capi.KERNEL_LANE):
             kernels["k_lane"] = (lane_ms, 64.0 * lines_lane + args.reads * io_per_read + 12 * st["n_seeds"])
             kernel_ms["k_lane"] = round(lane_ms, 3)
             kernel_ms["reads_finished_by_k_lane"] = lane_reads
@@ -276,7 +332,7 @@ def main():
         here = os.path.dirname(os.path.abspath(__file__))
         pmc_name = next(n for n in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json") if os.path.exists(os.path.join(here, "profiles", n)))
         pmc = json.load(open(os.path.join(here, "profiles", pmc_name)))
-        per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read")
+        per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read") if not args.labels else None    # (the PMC passes are of the unlabeled kernels)
         if per_read:
             traffic = round(per_read * args.reads)
             traffic_src = "profiles/%s (%d-read PMC run, scaled per read)" % (pmc_name, pmc["reads_per_launch"])
@@ -354,7 +410,20 @@ def main():
         nc = min(args.parity_sample if args.no_cpu_baseline else max(args.cpu_sample, args.parity_sample), args.reads)
         csample = [bytes(r) for r in reads[:nc].cpu().numpy()]
         tc = time.time()
-        orun = orc.AlignRun(og, cfg, csample, threads=threads, validate=False)
+        if args.labels:
+            # the oracle's LabeledAligner on the same annotation (column bit vectors filled from the same pairs); single thread
+            nc = min(nc, args.parity_sample)
+            csample = csample[:nc]
+            oanno = orc.Annotation(og, args.labels)
+            cb, rw = anno_pairs
+            for j in range(args.labels):
+                r = rw[int(cb[j]):int(cb[j + 1])].astype(np.int64)
+                np.bitwise_or.at(oanno.column_view(j), r >> 6, (np.uint64(1) << (r & 63).astype(np.uint64)))
+            threads = 1
+            tc = time.time()
+            orun = orc.LabeledAlignRun(og, cfg, oanno, csample, validate=False)
+        else:
+            orun = orc.AlignRun(og, cfg, csample, threads=threads, validate=False)
         dt = time.time() - tc
         # GPU results of the same reads through the C-ABI with host buffers, compared field by field
         blob, offs = aligner.pack_queries(csample)
@@ -364,10 +433,27 @@ def main():
         ores = capi.Results()
         orc.L().orc_results_view(orun.r, C.byref(ores))
         mism = capi.count_result_mismatches(gres, ores)
+        if args.labels:
+            # ... and every alignment's label list
+            olab = orun.labels()
+            ai = 0
+            for q in range(nc):
+                for ls in olab[q]:
+                    if ai < gres.aln_begin[nc]:
+                        a = gres.alignments[ai]
+                        if [int(gres.labels[a.labels_begin + x]) for x in range(a.n_labels)] != [int(x) for x in ls]:
+                            mism += 1
+                    ai += 1
+            if ai != gres.aln_begin[nc]:
+                mism += 1
         cap_err = int(sum(1 for i in range(nc) if gres.status[i] != 0))
         parity = {"sample": nc, "mismatches": int(mism), "capacity_errors": cap_err,
                   "full_batch_capacity_errors": int(st["n_capacity_errors"])}
-        if not args.no_cpu_baseline:
+        if args.labels and not args.no_cpu_baseline:
+            cpu = {"value": round(nc / dt, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+                   "sample": "first %d reads of the same workload, same graph and annotation, the restated LabeledAligner on 1 thread, %.1fs" % (nc, dt),
+                   "build": "-O3 -march=native -DNDEBUG"}
+        elif not args.no_cpu_baseline:
             n1 = min(args.cpu_1t_sample, nc)
             t1s = time.time()
             orc.AlignRun(og, cfg, csample[:n1], threads=1, validate=False)
@@ -413,7 +499,8 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
            "config": {"workload": "%d synthetic %d bp reads per GPU vs %d-edge k=%d BOSS graph (%.0f Mbp iid genome + %d SNP windows%s), CLI-default scoring" %
                       (args.reads, args.read_len, n_edges, args.k, args.genome / 1e6, args.snps,
-                       "; PRIMARY mode through the CanonicalDBG wrapper" if args.graph_mode == "primary" else ""),
+                       ("; PRIMARY mode through the CanonicalDBG wrapper" if args.graph_mode == "primary" else "")
+                       + ("; label-aware (LabeledAligner) with a %d-label annotation, one label per genome segment" % args.labels if args.labels else "")),
                       "reads_per_gpu": args.reads, "graph_edges": n_edges, "k": args.k, "graph_mode": args.graph_mode, "parallelism": "reads sharded x%d, graph replicated" % world},
            "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
     print(json.dumps(out), flush=True)

@@ -217,7 +217,7 @@ typedef struct mgx_stats {
                                    15 node seen before, 19 a later seed survives, 26 backward extension, ...) */
 } mgx_stats;
 enum { MGX_KERNEL_GRP8 = 1, MGX_KERNEL_GRP8_PRIM = 2, MGX_KERNEL_GRP8_ALT = 4, MGX_KERNEL_EXT64 = 8, MGX_KERNEL_LANE = 16,
-       MGX_KERNEL_LAB64 = 32 /* the label-aware build of the 64-lane kernel */ };
+       MGX_KERNEL_LAB64 = 32, MGX_KERNEL_GRP8_LAB = 64 /* the label-aware builds of the 64-lane and the 8-lane kernel */ };
 
 int mgx_device_count(void);                 /* number of visible HIP devices (0 without a GPU) */
 const char *mgx_last_error(void);
@@ -284,7 +284,8 @@ void mgx_kernel_launch_counts(uint64_t *out5);
 /* Kernel-selection switches; every setting gives the same alignments (the parity suite runs them all).  "split8" names the
  * (only) pipeline: seeding kernel with one wavefront per read, radix sort of the reads by predicted extension work, extension
  * kernel(s).  "general" / "chain": the extension's register-resident chain path off / on.  "key=value" (-1 = automatic):
- *   ext64=0|1            small batches on the one-read-per-wavefront 64-lane kernel (default 1) or on the 8-lane groups
+ *   ext64=0|1|2          small batches on the one-read-per-wavefront 64-lane kernel (default 1) or on the 8-lane groups;
+ *                        label-aware aligners: 2 = every batch on the 64-lane labeled kernel
  *   groups_per_wave=n    8-lane kernel: n = 1 .. 8 groups of a wavefront take reads, 0 = all (default: from the batch size)
  *   multi_pass=0|1       one extension per read and launch (default: automatic from the seeds per read); two_pass=1
  *   lane=0|1             the lane-per-read kernel in front of the group kernel (default: automatic)
@@ -320,6 +321,12 @@ size_t mgx_format_json(const mgx_results *res, uint64_t query_index, const char 
  */
 typedef struct mgx_annotation mgx_annotation;
 int mgx_annotation_create(uint64_t n_rows, uint32_t n_labels, const uint64_t *const *columns, int device, mgx_annotation **out);
+/* The same from the columns' set rows, the content of a ColumnCompressed annotation (one sd_vector of row indices per label):
+ * rows[col_begin[j] .. col_begin[j + 1]) = the rows with label j (any order, no duplicates); col_begin: host array of
+ * n_labels + 1 entries; rows: host or (on_device != 0) device pointer.  One sort on the device instead of n_labels bit vectors
+ * of n_rows bits each on the host. */
+int mgx_annotation_create_sparse(uint64_t n_rows, uint32_t n_labels, const uint64_t *col_begin, const uint64_t *rows,
+                                 int on_device, int device, mgx_annotation **out);
 void mgx_annotation_destroy(mgx_annotation *a);
 uint64_t mgx_annotation_device_bytes(const mgx_annotation *a);
 uint64_t mgx_annotation_num_rows(const mgx_annotation *a);

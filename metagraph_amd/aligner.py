@@ -81,6 +81,28 @@ class Annotation:
         self.n_rows, self.n_labels = n_rows, len(self._cols)
         _check(capi.lib().mgx_annotation_create(n_rows, len(self._cols), ptrs, device, C.byref(self.h)))
 
+    @classmethod
+    def from_sparse(cls, n_rows, col_begin, rows, device=0, on_device=False):
+        """mgx_annotation_create_sparse: rows[col_begin[j] : col_begin[j + 1]] = the rows with label j (a ColumnCompressed
+        annotation's content).  col_begin: host uint64 array of n_labels + 1 entries; rows: host uint64 array, or a device
+        pointer with on_device=True."""
+        self = cls.__new__(cls)
+        cb = np.ascontiguousarray(col_begin, dtype=np.uint64)
+        self._cols = [cb]
+        rp = rows
+        if not on_device:
+            r = np.ascontiguousarray(rows, dtype=np.uint64)
+            self._cols.append(r)
+            rp = r.ctypes.data
+        self.h = C.c_void_p()
+        self.n_rows, self.n_labels = n_rows, len(cb) - 1
+        _check(capi.lib().mgx_annotation_create_sparse(n_rows, len(cb) - 1, cb.ctypes.data, rp, 1 if on_device else 0, device, C.byref(self.h)))
+        return self
+
+    @property
+    def device_bytes(self):
+        return capi.lib().mgx_annotation_device_bytes(self.h)
+
     def close(self):
         if getattr(self, "h", None) and capi is not None:
             capi.lib().mgx_annotation_destroy(self.h)

@@ -76,7 +76,7 @@ class Stats(C.Structure):
                 ("lane_bail_reads", C.c_uint64 * 32)]
 
 
-KERNEL_GRP8, KERNEL_GRP8_PRIM, KERNEL_GRP8_ALT, KERNEL_EXT64, KERNEL_LANE, KERNEL_LAB64 = 1, 2, 4, 8, 16, 32
+KERNEL_GRP8, KERNEL_GRP8_PRIM, KERNEL_GRP8_ALT, KERNEL_EXT64, KERNEL_LANE, KERNEL_LAB64, KERNEL_GRP8_LAB = 1, 2, 4, 8, 16, 32, 64
 
 
 def results_to_py(res):
@@ -166,6 +166,7 @@ def lib():
         raise OSError("libmgx.so has ABI version %d, this binding was written for %d: rebuild" % (L.mgx_abi_version(), MGX_ABI_VERSION))
     L.mgx_annotation_create.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
     L.mgx_annotation_destroy.argtypes = [C.c_void_p]
+    L.mgx_annotation_create_sparse.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.mgx_labeled_aligner_create.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(Limits), C.c_void_p, C.POINTER(C.c_void_p)]
     L.mgx_format_tsv_labeled.argtypes = [C.POINTER(Results), C.c_uint64, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int32,
                                          C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_size_t]

@@ -427,8 +427,12 @@ struct Wave {
 #endif
     uint32_t *gen_store;         // conv-checker generation counters, persistent per arena slice
     ExtenderState ext[2];
+#if MGX_WITH_LABELS
+    DevAln *aln;                 // (builds with the label-aware extender hold many more alignments: the records live in the arena)
+#else
     DevAln aln[N_ALN];           // [0, A): extension results, [A, 2A): reversed seeds of the backward pass, [2A, 3A): backward
                                  // extension results, [3A, 4A): the aggregator's queue (A = num_alternative_paths <= MAX_ALT)
+#endif
     FlatState fs;
     int32_t have_best;           // alignments in the aggregator's queue
     int32_t seeds_done;          // seeds whose extension ran for this read in this pass (multi-pass extension)
@@ -523,6 +527,8 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     b += 6 * align8((L + 16) * 4);                      // staging
     b += 64 + 2 * (align8(2ull * lim.hash_size * 8) + align8(((uint64_t)lim.max_columns + lim.max_path) * 16) + 64 + align8((uint64_t)lim.conv_pool_words * 4));
     b += (uint64_t)lim.n_aln * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
+    if (lim.lab_words || kWithLabels)                   // builds with the label-aware extender: the alignment records themselves
+        b += align8((uint64_t)lim.n_aln * sizeof(DevAln));
     if (lim.lab_words)                                  // label-aware alignment: set arena, column / seed handles, aggregator queues
         b += align8((uint64_t)lim.lab_words * 4) + align8((uint64_t)lim.max_columns * 4) + 2 * align8((uint64_t)lim.max_seeds * 4)
              + align8(lab_agg_words(lim) * 4);
@@ -623,12 +629,19 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
         take(((uint64_t)lim.max_columns + lim.max_path) * 16);                   // ConvRecs (conv_recs())
         w.ext[s].conv.pool = (int32_t *)take((uint64_t)lim.conv_pool_words * 4);
     }
+    // (the label part of the arena follows the alignment buffers of ALL n_aln alignments, also in builds that use fewer)
+    uint8_t *aln_end = p + (uint64_t)lim.n_aln * (2 * align8((uint64_t)lim.max_path * 4) + align8(lim.max_path));
+#if MGX_WITH_LABELS
+    w.aln = (DevAln *)aln_end;
+    aln_end += align8((uint64_t)lim.n_aln * sizeof(DevAln));
+#endif
     for (int a = 0; a < N_ALN && a < (int)lim.n_aln; ++a) {
         w.aln[a].nodes = (uint32_t *)take((uint64_t)lim.max_path * 4);
         w.aln[a].cigar = (uint32_t *)take((uint64_t)lim.max_path * 4);
         w.aln[a].seq = take(lim.max_path);
     }
 #if MGX_WITH_LABELS
+    p = aln_end;
     if (lim.lab_words) {
         w.lab = (uint32_t *)take((uint64_t)lim.lab_words * 4);
         w.col_lab = (uint32_t *)take((uint64_t)lim.max_columns * 4);
@@ -3143,6 +3156,10 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         }
     }
     CH_T(6)
+#if MGX_WITH_LABELS
+    // LabeledExtender::call_outgoing, the only-child case (aligner_labeled.cpp:224-231): the parent's labels, unseen
+    if (MGX_PARAMS_OF(w).labeled) w.col_lab[my_idx] = w.col_lab[x.f_idx];
+#endif
     x.tsize = my_idx + 1;
     // update_seed_filter, the stores
     if (cv_mode == CV_INSERT) {
@@ -3343,7 +3360,7 @@ MGX_DEV int extend_step(Wave &w, const int es, ChainRegs &R) {
     XState &x = w.x;
     // the chain format keeps S as 16-bit offsets from the column maximum: cells live within x-drop (+ one match score) of
     // it, so any x-drop up to 30000 fits; wider (the unit tests' "no x-drop") takes the general path
-    const bool use_fast = !P.no_fast && P.cfg.xdrop <= 30000 && !(kWithLabels && P.labeled);      // (labels: every column through general_step)
+    const bool use_fast = !P.no_fast && P.cfg.xdrop <= 30000;
     int &mode = R.mode;
     LV<int32_t> *pS = R.pS, *pF = R.pF;
     SeedRun &run = R.run;

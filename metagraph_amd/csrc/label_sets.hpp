@@ -123,20 +123,40 @@ MGX_DEV void lab_isect_diff(Wave &w, uint32_t a, uint32_t b, uint32_t *isect, ui
 }
 
 // LabeledExtender::flush's clear(): S, E, F of the column become ninf (aligner_labeled.cpp:92-100).  On the device a column
-// of the general path is an S / F record plus one flag byte per cell that relates it to its parent; nothing reads a parent's
-// E.  A cleared column's children are cleared by the same flush (their parent has no labels), so the flags of columns that
-// stay never refer to cleared values.
+// is what it left in HBM (ColSlot): S (and F where something may reload it) plus one flag byte per cell that relates it to its
+// parent; nothing reads a parent's E.  Every form is cleared in place: S / F read ninf, every flag byte 0.  A cleared column's
+// children are cleared by the same flush (their parent has no labels), so the flags of columns that stay never refer to
+// cleared values; the chain window in registers is never a cleared column (a flush runs at a fork — the window has been
+// spilled and is the fork's parent, which keeps its labels if it gets children — or before backtracking).
 MGX_DEV void lab_clear_column(Wave &w, int32_t idx) {
     const ColMeta c = uni_col(col_load(w, idx));
     w.col_lab[idx] = 0;
-    if (c.cells == NO_CELLS || col_chain(c)) { w.status = ST_CAPACITY; return; }       // cannot happen: labeled extensions use the general path only
-    const int32_t wc = col_wc(c);
-    int32_t *rec = w.cells + c.cells;
-    uint8_t *fb = (uint8_t *)(rec + 2 * wc);
-    for (int32_t base = 0; base < wc; base += WAVE) {
-        FOR_LANES(l) {
-            const int32_t j = base + l;
-            if (j < wc) { gst(rec + j, NINF); gst(rec + wc + j, NINF); gst(fb + j, (uint8_t)0); }
+    if (col_compact(c)) {
+        // one line: words 4 + 2 l = four flag bytes, 5 + 2 l = four 8-bit S (l < 6)
+        uint32_t *m = (uint32_t *)(w.cols + idx);
+        FOR_LANES(l) { if (l < 6) { gst(m + 4 + 2 * l, 0u); gst(m + 5 + 2 * l, 0x80808080u); } }
+    } else if (col_chain(c)) {
+        uint8_t *fl = w.cols[idx].flags;
+        int16_t *srow = w.cols_s16 + (int64_t)idx * FWS;
+        for (int32_t base = 0; base < FWS; base += WAVE) {
+            FOR_LANES(l) { const int32_t j = base + l; if (j < FWS) { gst(fl + j, (uint8_t)0); gst(srow + j, S16_NINF); } }
+        }
+        if (c.cells != NO_CELLS) {                           // stayed behind in the frontier: its window as an S / F record
+            int32_t *rec = w.cells + c.cells;
+            for (int32_t base = 0; base < 2 * CHW; base += WAVE) {
+                FOR_LANES(l) { const int32_t j = base + l; if (j < 2 * CHW) gst(rec + j, NINF); }
+            }
+        }
+    } else {
+        if (c.cells == NO_CELLS) { w.status = ST_CAPACITY; return; }       // cannot happen: a general column owns a record
+        const int32_t wc = col_wc(c);
+        int32_t *rec = w.cells + c.cells;
+        uint8_t *fb = (uint8_t *)(rec + 2 * wc);
+        for (int32_t base = 0; base < wc; base += WAVE) {
+            FOR_LANES(l) {
+                const int32_t j = base + l;
+                if (j < wc) { gst(rec + j, NINF); gst(rec + wc + j, NINF); gst(fb + j, (uint8_t)0); }
+            }
         }
     }
     for (int b = 0; b < 2; ++b) if (w.st[b].col == idx) w.st[b].col = -1;          // a staged copy is stale now

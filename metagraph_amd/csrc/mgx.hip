@@ -307,6 +307,10 @@ extern "C" int mgx_grp_waves_per_simd8_alt(void);
 extern "C" int mgx_launch_ext64(const void *params, uint32_t blocks, uint32_t lds_bytes, void *stream);      // mgx_ext64.hip
 extern "C" int mgx_launch_lane(const void *d_params, uint32_t blocks, void *stream);                         // mgx_lane.hip
 // the 64-lane extension kernel with the label-aware extender compiled in (mgx_lab64.hip: -DMGX_WITH_LABELS=1)
+extern "C" int mgx_launch_align_grp8_lab(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);   // mgx_grp.hip, the labeled build
+extern "C" unsigned mgx_grp_static_lds8_lab(void);
+extern "C" int mgx_grp_waves_per_simd8_lab(void);
+extern "C" int mgx_grp_max_alt8_lab(void);
 extern "C" int mgx_launch_lab64(const void *params, uint32_t blocks, uint32_t lds_bytes, void *stream);
 extern "C" unsigned mgx_lab64_static_lds(void);
 extern "C" int mgx_lab64_waves_per_simd(void);
@@ -667,8 +671,8 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
         // CANONICAL ones: not on the device yet), annotation without coordinates, as many alternative paths per label as
         // the labeled kernel build holds.
         if (g->mode != MGX_MODE_BASIC) return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment runs on BASIC-mode graphs only");
-        if (A->cfg.num_alternative_paths > (uint64_t)mgx_lab64_max_alt())
-            return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment: num_alternative_paths <= %d on the device", mgx_lab64_max_alt());
+        if (A->cfg.num_alternative_paths > (uint64_t)std::min(mgx_lab64_max_alt(), mgx_grp_max_alt8_lab()))
+            return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment: num_alternative_paths <= %d on the device", std::min(mgx_lab64_max_alt(), mgx_grp_max_alt8_lab()));
         int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;
         mgx_annotation_device_view(anno, &adev, &arows, &h, &c, &m);
         if (adev != g->device) return fail(MGX_ERR_INVALID, "the annotation lives on device %d, the graph on device %d", adev, g->device);
@@ -878,7 +882,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     const bool sel_alt = A->cfg.num_alternative_paths > 1 || (sel_primary && A->opt.primary_alt_build == 1);
     const uint64_t ext_wps = sel_alt ? mgx_grp_waves_per_simd8_alt() : sel_primary ? mgx_grp_waves_per_simd8_prim() : mgx_grp_waves_per_simd8();
     // (label-aware batches: seeding as ever, extension on the one-read-per-wavefront labeled kernel)
-    const uint64_t want_slots = labeled ? std::max<uint64_t>(wave_slots, (uint64_t)prop.multiProcessorCount * 4 * mgx_lab64_waves_per_simd())
+    const uint64_t want_slots = labeled ? std::max<uint64_t>(wave_slots, (uint64_t)prop.multiProcessorCount * 4 * 8 * mgx_grp_waves_per_simd8_lab())
                                         : std::max<uint64_t>(split ? wave_slots : 0, (uint64_t)prop.multiProcessorCount * 4 * 8 * ext_wps);
     // The arena gets what is free after the buffers this stage allocates AFTER it (result records, output stream, seed
     // stream, sort arrays: estimated generously) and a margin; buffers kept from an earlier batch are already outside
@@ -954,8 +958,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         int adev = 0;
         mgx_annotation_device_view(A->anno, &adev, &P.anno_rows, &P.anno_head, &P.anno_count, &P.anno_more);
         P.labeled = 1;
-        P.no_fast = 1;            // every column through the general path (column label sets live on the DP table's records)
-        P.no_alias = 1;
+        P.no_alias = 1;           // (a flush clears columns in place: convergence entries must not alias their S windows)
     }
 #ifdef MGX_PROBES
     P.ablate = getenv("MGX_ABLATE") ? (uint32_t)atoi(getenv("MGX_ABLATE")) : 0u;      // timing probes: WRONG results (probe builds only)
@@ -1026,13 +1029,24 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         // One read per wavefront: the 64-lane instantiation (mgx_ext64.hip) — the read has the wavefront to itself, so it may as
         // well use all of its lanes.  MGX_EXT64=0: A/B switch.
         if (labeled) {
-            // label-aware extension: one read per wavefront on the labeled build of the 64-lane kernel (mgx_lab64.hip)
-            const uint32_t wcu = 4u * (uint32_t)mgx_lab64_waves_per_simd();
-            const uint32_t lds64 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), (160u * 1024u) / wcu - mgx_lab64_static_lds() - 128u) & ~15u;
-            const uint64_t resident = (uint64_t)prop.multiProcessorCount * wcu;
-            P.groups_per_wave = 1;
-            A->kernels_ran |= MGX_KERNEL_LAB64;
-            return mgx_launch_lab64(&P, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(slots, resident)), lds64, nullptr);
+            // label-aware extension: the labeled builds — 8 reads per wavefront (mgx_grp.hip, per-read program), or one read
+            // per wavefront on the 64-lane kernel (mgx_lab64.hip) for batches with fewer reads than resident wavefronts
+            const uint32_t wcu64 = 4u * (uint32_t)mgx_lab64_waves_per_simd();
+            const uint64_t resident64 = (uint64_t)prop.multiProcessorCount * wcu64;
+            const uint64_t items = P.n_items ? P.n_items : n;
+            if ((items <= resident64 && A->opt.ext64 != 0) || A->opt.ext64 == 2) {
+                const uint32_t lds64 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), (160u * 1024u) / wcu64 - mgx_lab64_static_lds() - 128u) & ~15u;
+                P.groups_per_wave = 1;
+                A->kernels_ran |= MGX_KERNEL_LAB64;
+                return mgx_launch_lab64(&P, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(slots, resident64)), lds64, nullptr);
+            }
+            const uint32_t wcu = 4u * (uint32_t)mgx_grp_waves_per_simd8_lab();
+            const uint32_t per_wave_l = (160u * 1024u) / wcu - mgx_grp_static_lds8_lab() - 64u;
+            const uint32_t per_group_l = std::min<uint32_t>(fast_lds_bytes(l.Lmax), per_wave_l / 8) & ~15u;
+            const int gpw_opt = A->opt.groups_per_wave;
+            P.groups_per_wave = gpw_opt > 0 ? (uint32_t)std::min(8, gpw_opt) : 0u;
+            A->kernels_ran |= MGX_KERNEL_GRP8_LAB;
+            return mgx_launch_align_grp8_lab(&P, (uint32_t)slots, per_group_l, phase, nullptr);
         }
         const bool ext64 = A->opt.ext64 != 0;
         if (ext64 && phase == PH_EXTEND && P.groups_per_wave == 1) {

@@ -118,6 +118,35 @@ __global__ void k_rows_gather(const uint64_t *head, const uint32_t *more, uint64
     const uint32_t *src = more + head_payload(h);
     for (uint64_t x = 0; x < e - b; ++x) out_labels[b + x] = src[x];
 }
+// ---- construction from the columns' set rows (mgx_annotation_create_sparse) ----
+// pair p (the p-th set bit of the matrix in column order) -> key = row << 24 | label; its label by bisection of col_begin
+__global__ void k_pairs_keys(const uint64_t *col_begin, uint32_t n_labels, const uint64_t *rows, uint64_t n_pairs, uint64_t *keys) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    uint32_t lo = 0, hi = n_labels;                      // the last label with col_begin[label] <= p
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (col_begin[mid] <= p) lo = mid; else hi = mid; }
+    keys[p] = (rows[p] << 24) | lo;
+}
+// sorted keys: the first pair of every row counts the row's run; rows with one label are complete after this
+__global__ void k_pairs_count(const uint64_t *keys, uint64_t n_pairs, uint64_t n_rows, uint32_t *count, uint64_t *head) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint64_t row = keys[p] >> 24;
+    if (row >= n_rows || (p && (keys[p - 1] >> 24) == row)) return;
+    uint64_t e = p + 1;
+    while (e < n_pairs && (keys[e] >> 24) == row) ++e;
+    count[row] = (uint32_t)(e - p);
+    if (e - p == 1) head[row] = head_pack(1, keys[p] & 0xFFFFFF);
+}
+__global__ void k_pairs_fill(const uint64_t *keys, uint64_t n_pairs, uint64_t n_rows, const uint32_t *count, const uint64_t *offset, uint32_t *more) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint64_t row = keys[p] >> 24;
+    if (row >= n_rows || (p && (keys[p - 1] >> 24) == row)) return;
+    const uint32_t c = count[row];
+    if (c < 2) return;
+    for (uint32_t x = 0; x < c; ++x) more[offset[row] + x] = (uint32_t)(keys[p + x] & 0xFFFFFF);      // ascending: the keys are sorted
+}
 } // namespace
 
 struct mgx_annotation {
@@ -183,6 +212,72 @@ int mgx_annotation_create(uint64_t n_rows, uint32_t n_labels, const uint64_t *co
         HIP_TRY_B(hipMemcpy(d_col, columns[j], n_words * 8, hipMemcpyHostToDevice));
         k_annot_fill<<<wblocks, tb>>>(d_col, n_words, n_rows, j, A->count, d_off, d_fill, A->head, A->more);
     }
+    HIP_TRY_B(hipGetLastError());
+    HIP_TRY_B(hipDeviceSynchronize());
+#undef HIP_TRY_B
+    cleanup();
+    A->bytes = n_rows * 12 + A->n_more * 4;
+    *out = A;
+    return MGX_OK;
+}
+
+/* The same matrix from the columns' set rows — what a ColumnCompressed annotation stores (one sd_vector of row indices per
+ * label; annotation/representation/column_compressed): rows[col_begin[j] .. col_begin[j + 1]) = the rows that carry label j
+ * (any order, no duplicates).  on_device != 0: `rows` is a device pointer (col_begin is always a host array of n_labels + 1
+ * entries).  Built by one sort of (row, label) keys on the device. */
+int mgx_annotation_create_sparse(uint64_t n_rows, uint32_t n_labels, const uint64_t *col_begin, const uint64_t *rows, int on_device,
+                                 int device, mgx_annotation **out) {
+    if (!out || !col_begin || n_labels >= (1u << 24) || n_rows >= (1ull << 40)) return afail(MGX_ERR_INVALID, "mgx_annotation_create_sparse: bad arguments");
+    const uint64_t n_pairs = col_begin[n_labels];
+    if (!rows && n_pairs) return afail(MGX_ERR_INVALID, "mgx_annotation_create_sparse: bad arguments");
+    if (mgx_device_count() <= device) return afail(MGX_ERR_NO_DEVICE, "HIP device %d not available", device);
+    HIP_TRY_A(hipSetDevice(device));
+    auto *A = new mgx_annotation();
+    A->device = device; A->n_rows = n_rows; A->n_labels = n_labels;
+    uint64_t *d_cb = nullptr, *d_rows = nullptr, *d_keys = nullptr, *d_sorted = nullptr, *d_off = nullptr, *d_len = nullptr;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_cb); (void)hipFree(d_rows); (void)hipFree(d_keys); (void)hipFree(d_sorted); (void)hipFree(d_off); (void)hipFree(d_len); (void)hipFree(d_tmp); };
+    auto bail = [&](int rc) { cleanup(); (void)hipFree(A->head); (void)hipFree(A->count); (void)hipFree(A->more); delete A; return rc; };
+#define HIP_TRY_B(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) return bail(afail(MGX_ERR_NO_DEVICE, "%s: %s", #e, hipGetErrorString(r_))); } while (0)
+    HIP_TRY_B(hipMalloc(&A->head, std::max<uint64_t>(1, n_rows) * 8));
+    HIP_TRY_B(hipMalloc(&A->count, std::max<uint64_t>(1, n_rows) * 4));
+    HIP_TRY_B(hipMemset(A->count, 0, std::max<uint64_t>(1, n_rows) * 4));
+    HIP_TRY_B(hipMemset(A->head, 0, std::max<uint64_t>(1, n_rows) * 8));
+    const uint32_t tb = 256;
+    const uint32_t pblocks = (uint32_t)((n_pairs + tb - 1) / tb), rblocks = (uint32_t)((n_rows + tb - 1) / tb);
+    HIP_TRY_B(hipMalloc(&d_len, (n_rows + 1) * 8));
+    HIP_TRY_B(hipMalloc(&d_off, (n_rows + 1) * 8));
+    HIP_TRY_B(hipMemset(d_len, 0, (n_rows + 1) * 8));
+    if (n_pairs) {
+        HIP_TRY_B(hipMalloc(&d_cb, ((uint64_t)n_labels + 1) * 8));
+        HIP_TRY_B(hipMemcpy(d_cb, col_begin, ((uint64_t)n_labels + 1) * 8, hipMemcpyHostToDevice));
+        const uint64_t *src = rows;
+        if (!on_device) {
+            HIP_TRY_B(hipMalloc(&d_rows, n_pairs * 8));
+            HIP_TRY_B(hipMemcpy(d_rows, rows, n_pairs * 8, hipMemcpyHostToDevice));
+            src = d_rows;
+        }
+        HIP_TRY_B(hipMalloc(&d_keys, n_pairs * 8));
+        HIP_TRY_B(hipMalloc(&d_sorted, n_pairs * 8));
+        k_pairs_keys<<<pblocks, tb>>>(d_cb, n_labels, src, n_pairs, d_keys);
+        int end_bit = 24;
+        while (end_bit < 64 && (n_rows >> (end_bit - 24))) ++end_bit;
+        size_t sort_bytes = 0;
+        HIP_TRY_B(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, d_keys, d_sorted, n_pairs, 0, end_bit));
+        HIP_TRY_B(hipMalloc(&d_tmp, std::max<size_t>(sort_bytes, 16)));
+        HIP_TRY_B(hipcub::DeviceRadixSort::SortKeys(d_tmp, sort_bytes, d_keys, d_sorted, n_pairs, 0, end_bit));
+        (void)hipFree(d_tmp); d_tmp = nullptr;
+        k_pairs_count<<<pblocks, tb>>>(d_sorted, n_pairs, n_rows, A->count, A->head);
+    }
+    if (n_rows) k_annot_multi<<<rblocks, tb>>>(n_rows, A->count, d_len);
+    size_t tmp_bytes = 0;
+    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_len, d_off, n_rows + 1));
+    HIP_TRY_B(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    HIP_TRY_B(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_len, d_off, n_rows + 1));
+    HIP_TRY_B(hipMemcpy(&A->n_more, d_off + n_rows, 8, hipMemcpyDeviceToHost));
+    HIP_TRY_B(hipMalloc(&A->more, std::max<uint64_t>(1, A->n_more) * 4));
+    if (n_rows) k_annot_heads<<<rblocks, tb>>>(n_rows, A->count, d_off, A->head);
+    if (n_pairs) k_pairs_fill<<<pblocks, tb>>>(d_sorted, n_pairs, n_rows, A->count, d_off, A->more);
     HIP_TRY_B(hipGetLastError());
     HIP_TRY_B(hipDeviceSynchronize());
 #undef HIP_TRY_B

@@ -13,7 +13,12 @@
 // A third build (-DMGX_PRIM_BUILD -DMGX_WITH_PRIMARY=1) is the product kernel with the CanonicalDBG branches compiled in: PRIMARY
 // graphs with one alignment per query run the rounds at 3 waves per SIMD like every other graph, instead of sharing the
 // 2-wave build of the alternative paths.
-#if defined(MGX_ALT_BUILD)
+// A fourth build (-DMGX_LAB_BUILD -DMGX_ALT_BUILD -DMGX_WITH_LABELS=1 -DMGX_MAX_ALT=2) carries the label-aware extender
+// (label_sets.hpp / label_driver.hpp): the batches of a mgx_labeled_aligner_create aligner, through the per-read program.
+#if defined(MGX_LAB_BUILD)
+#define MGX_SUFFIX(x) MGX_CAT(x, _lab)
+#define mgx MGX_CAT(MGX_CAT(mgx_grp, MGX_GROUP), l)
+#elif defined(MGX_ALT_BUILD)
 #define MGX_SUFFIX(x) MGX_CAT(x, _alt)
 #define mgx MGX_CAT(MGX_CAT(mgx_grp, MGX_GROUP), a)
 #elif defined(MGX_PRIM_BUILD)
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(64, MGX_GRP_WAVES_PER_SIMD) MGX_SUFFIX(MGX_CAT
     // (the product build has no per-read program at all: one alignment per seed always takes the flat loop; the build that
     // carries alternative paths keeps both, and -DMGX_KEEP_LEGACY=1 gives an A/B build that obeys MGX_NO_FLAT)
 #if defined(MGX_ALT_BUILD) || defined(MGX_KEEP_LEGACY)
-    const bool flat = PHASE == PH_EXTEND && n_alt_of(w) == 1 && !g_params.no_flat;
+    const bool flat = PHASE == PH_EXTEND && n_alt_of(w) == 1 && !g_params.no_flat && !(kWithLabels && g_params.labeled);
 #else
     constexpr bool flat = PHASE == PH_EXTEND;
 #endif
@@ -149,4 +154,7 @@ extern "C" int MGX_SUFFIX(MGX_CAT(mgx_launch_align_grp, MGX_GROUP))(const void *
     return (int)hipGetLastError();
 }
 extern "C" int MGX_SUFFIX(MGX_CAT(mgx_grp_waves_per_simd, MGX_GROUP))(void) { return MGX_GRP_WAVES_PER_SIMD; }
+#if defined(MGX_LAB_BUILD)
+extern "C" int MGX_SUFFIX(MGX_CAT(mgx_grp_max_alt, MGX_GROUP))(void) { return MGX_MAX_ALT; }
+#endif
 extern "C" unsigned MGX_SUFFIX(MGX_CAT(mgx_grp_static_lds, MGX_GROUP))(void) { return (unsigned)(sizeof(Wave) * GROUPS_PER_WAVEFRONT + sizeof(AlignParams) + sizeof(g_sm_rows)); }

@@ -366,7 +366,7 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();
     P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
     if (AN) {
-        P.labeled = 1; P.no_fast = 1;
+        P.labeled = 1; P.no_alias = 1;        // as mgx.hip
         P.anno_head = AN->head.data(); P.anno_count = AN->count.data(); P.anno_more = AN->more.data(); P.anno_rows = AN->n_rows;
     }
     P.no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;

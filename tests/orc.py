@@ -264,6 +264,13 @@ class Annotation:
         p = L().orc_annotation_column_words(self.h, label, C.byref(nw))
         return np.ctypeslib.as_array(p, shape=(nw.value,)).copy()
 
+    def column_view(self, label):
+        """the column's bit vector itself (writable: bulk construction of large annotations)"""
+        import numpy as np
+        nw = C.c_uint64()
+        p = L().orc_annotation_column_words(self.h, label, C.byref(nw))
+        return np.ctypeslib.as_array(p, shape=(nw.value,))
+
 
 class LabeledAlignRun(AlignRun):
     """LabeledAligner<>::align_batch on the oracle; results() as AlignRun plus labels() per alignment."""

@@ -79,3 +79,28 @@ def test_get_rows_on_random_matrices(n_rows, n_labels, density):
         rc = L.mgx_annotation_get_rows(h, r.ctypes.data, len(rows), 0, begin.ctypes.data, labels.ctypes.data, total - 1, 0, C.byref(need))
         assert rc == capi.MGX_ERR_CAPACITY and need.value == total and int(begin[-1]) == total
     L.mgx_annotation_destroy(h)
+
+
+@pytest.mark.parametrize("n_rows,n_labels,density", [(1000, 3, 0.5), (70000, 1000, 0.001), (300, 70, 0.9), (500, 5, 0.0)])
+def test_sparse_construction_gives_the_same_matrix(n_rows, n_labels, density):
+    """mgx_annotation_create_sparse (the columns' set rows: a ColumnCompressed annotation's content) == mgx_annotation_create
+    (column bit vectors) on every row"""
+    from metagraph_amd import aligner
+    rng = np.random.default_rng(7 * n_rows + n_labels)
+    cols, col_begin, rows_all = [], [0], []
+    for j in range(n_labels):
+        bits = rng.random(n_rows) < density
+        w = np.zeros((n_rows + 63) // 64, dtype=np.uint64)
+        r = np.nonzero(bits)[0].astype(np.int64)
+        np.bitwise_or.at(w, r >> 6, np.uint64(1) << (r & 63).astype(np.uint64))
+        cols.append(w)
+        rr = r.copy()
+        rng.shuffle(rr)                                   # (any order within a column)
+        rows_all.append(rr.astype(np.uint64))
+        col_begin.append(col_begin[-1] + len(rr))
+    h, keep = make_device(cols, n_rows)
+    S = aligner.Annotation.from_sparse(n_rows, np.asarray(col_begin, dtype=np.uint64),
+                                       np.concatenate(rows_all) if rows_all else np.zeros(0, dtype=np.uint64))
+    q = list(range(n_rows)) + [n_rows + 3]
+    assert device_rows(S.h, q) == device_rows(h, q)
+    capi.lib().mgx_annotation_destroy(h)

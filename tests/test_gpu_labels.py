@@ -20,34 +20,43 @@ def gpu_annotation(anno):
     return aligner.Annotation(anno.graph.n_edges, [anno.column_words(j) for j in range(anno.n_labels)])
 
 
-def compare_gpu_labeled(g, anno, cfg, reads, validate=True, check_seeds=True):
+# the two labeled builds of the extension kernel: 64 lanes per read (batches smaller than the resident wavefronts take it by
+# themselves) and 8 reads per wavefront; "ext64=2" / "ext64=0" force one or the other
+KERNELS = {"lab64": ("ext64=2", capi.KERNEL_LAB64), "grp8_lab": ("ext64=0", capi.KERNEL_GRP8_LAB)}
+
+
+def compare_gpu_labeled(g, anno, cfg, reads, validate=True, check_seeds=True, kernel="lab64"):
     o = orc.LabeledAlignRun(g, cfg, anno, reads, validate=validate)
     assert o.error == "", o.error
     G, AN = gpu_graph(g), gpu_annotation(anno)
     A = aligner.Aligner(G, cfg, annotation=AN)
+    A.set_pipeline(KERNELS[kernel][0])
     A.keep_seeds(check_seeds)
     got, status = A.align_batch(reads)
     assert all(s == 0 for s in status), status
     want = with_labels(o)
     for q in range(len(reads)):
         assert got[q] == want[q], (q, reads[q], got[q], want[q])
-    assert A.stats()["extend_kernels"] == capi.KERNEL_LAB64          # the labeled kernel is the one that ran
+    assert A.stats()["extend_kernels"] == KERNELS[kernel][1]          # the labeled kernel asked for is the one that ran
     return A, want
 
 
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
 @pytest.mark.parametrize("name", sorted(n for n in CASES if CASES[n]["mode"] == 0))
-def test_reference_label_kats_on_gpu(name):
+def test_reference_label_kats_on_gpu(name, kernel):
     case = CASES[name]
     g, anno, cfg = build(case)
     for query, expect in case["expect"].items():
-        _, want = compare_gpu_labeled(g, anno, cfg, [query], validate=not (cfg.left_end_bonus or cfg.right_end_bonus), check_seeds=False)
+        _, want = compare_gpu_labeled(g, anno, cfg, [query], validate=not (cfg.left_end_bonus or cfg.right_end_bonus), check_seeds=False,
+                                      kernel=kernel)
         assert len(want[0]) == len(expect)
         for a in want[0]:                                    # the reference's own assertions (get_alignment_labels)
             names = [case["labels"][l] for l in a["labels"]]
             assert names and any(expect.get(nm) == a["sequence"] for nm in names)
 
 
-def test_200_random_labeled_worlds_on_gpu():
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+def test_200_random_labeled_worlds_on_gpu(kernel):
     n_multi_aln = n_multi_label = n_reads = 0
     for seed in range(200):
         k = [7, 11, 12, 15, 19, 31][seed % 6]
@@ -60,18 +69,19 @@ def test_200_random_labeled_worlds_on_gpu():
             cfg.num_alternative_paths = 2
         if seed % 7 == 0:
             cfg.forward_and_reverse_complement = 0
-        _, want = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=False)
+        _, want = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=False, kernel=kernel)
         n_reads += len(reads)
         n_multi_aln += sum(1 for a in want if len(a) > 1)
         n_multi_label += sum(1 for a in want for x in a if len(x["labels"]) > 1)
     assert n_multi_aln > 100 and n_multi_label > 100, (n_reads, n_multi_aln, n_multi_label)
 
 
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
 @pytest.mark.parametrize("seed,k,n_strains", [(1, 31, 8), (2, 19, 4)])
-def test_1000_read_labeled_world_on_gpu(seed, k, n_strains):
+def test_1000_read_labeled_world_on_gpu(seed, k, n_strains, kernel):
     g, anno, reads = labeled_world(7000 + seed, k, n_strains=n_strains, genome_len=20000, n_reads=1000, read_len=150,
                                    n_segments=12, divergence=0.02)
-    A, want = compare_gpu_labeled(g, anno, capi.config_cli(k), reads, check_seeds=False)
+    A, want = compare_gpu_labeled(g, anno, capi.config_cli(k), reads, check_seeds=False, kernel=kernel)
     assert sum(1 for a in want if a) > 500
     assert sum(1 for a in want if len(a) > 1) > 20
 
