@@ -142,7 +142,8 @@ struct AlignParams {
                                          // lock-step with seven others
     // label-aware alignment (LabeledAligner, A/aligner_labeled.{hpp,cpp}): the row-major label matrix of mgx_annot.hip —
     // row = node - 1 (AnnotatedDBG::graph_to_anno_index); head word: count:16 | single label or offset into more[]
-    uint32_t labeled;                    // 1: label-aware (kernels built with MGX_WITH_LABELS only)
+    uint32_t labeled;                    // bit 0: label-aware (kernels built with MGX_WITH_LABELS only); bit 1: no row of a dummy node
+                                         // (W == 0) holds a label, so the "skip dummy nodes" test of the reference is the row itself
     const uint64_t *anno_head;
     const uint32_t *anno_count;
     const uint32_t *anno_more;

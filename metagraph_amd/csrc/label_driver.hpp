@@ -22,6 +22,17 @@ MGX_DEV void lab_agg_reset(Wave &w) {
 // ---- LabeledAligner::filter_seeds (aligner_labeled.cpp:612-721, no coordinates) for the seeds of strand s ----
 // A label counts the query positions covered by the first k-mers of the seeds whose first node carries it; labels below
 // min_exact_match x |query| are dropped, every seed keeps the labels of its first node that are left, seeds without any go.
+// With LabeledAligner's seed lengths (<= k) a 150-bp read carries ~120 one-k-mer seeds per strand, nearly all with the same
+// label(s) and first k-mers that overlap their neighbour's: the rows of the seeds' first nodes are fetched one seed per lane,
+// and the position bitmaps are written one coalesced range per run of seeds (same label, touching ranges) — exact for any
+// order of the seeds, a handful of writes for the usual one.
+MGX_DEV LabRow lab_row_of_head(const AlignParams &P, uint64_t head, uint64_t row) {
+    LabRow r;
+    uint32_t c = (uint32_t)(head & 0xFFFF);
+    if (c == 0xFFFF) c = P.anno_count[row];
+    r.n = c; r.one = (uint32_t)(head >> 16); r.more = c >= 2 ? P.anno_more + (head >> 16) : nullptr;
+    return r;
+}
 MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = MGX_PARAMS_OF(w);
@@ -29,20 +40,66 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
     if (!n) return;
     const int32_t k = (int32_t)P.g.k, L = w.L;
     const uint32_t W = (uint32_t)(L + 31) / 32;
-    // scratch: the backtracking's start-cell list (dead between extensions)
+    // scratch: the backtracking's start-cell list (dead between extensions): 64 label slots, the seeds' head words, the bitmaps
     uint32_t *scr = (uint32_t *)w.indices;
     const uint64_t cap_words = (uint64_t)P.lim.max_columns * 2 * (sizeof(BtIndex) / 4);
-    if (cap_words < 64 + (uint64_t)W) { w.status = ST_CAPACITY; return; }
-    const uint32_t max_l = (uint32_t)imin<uint64_t>(64, (cap_words - 64) / W);
-    uint32_t *mlab = scr, *bits = scr + 64;
+    const uint64_t heads_words = 2ull * (uint64_t)n;
+    if (cap_words < 64 + heads_words + (uint64_t)W) { w.status = ST_CAPACITY; return; }
+    const uint32_t max_l = (uint32_t)imin<uint64_t>(64, (cap_words - 64 - heads_words) / W);
+    uint32_t *mlab = scr;
+    uint64_t *heads = (uint64_t *)(scr + 64);
+    uint32_t *bits = scr + 64 + heads_words;
+    // the rows of the seeds' first nodes, one seed per lane ("skip dummy nodes": W == 0 has no labels)
+    LV<int32_t> lines;
+    FOR_LANES(l) { lines[l] = 0; }
+    for (int32_t base = 0; base < n; base += WAVE) {
+        FOR_LANES(l) {
+            const int32_t i = base + l;
+            if (i < n) {
+                const DevSeed sd = w.seeds[s][i];
+                const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
+                uint64_t h = 0;
+                if (node0 && node0 <= P.g.n && (uint64_t)node0 - 1 < P.anno_rows) {
+                    bool real = true;
+                    if (!(P.labeled & 2u)) {
+                        LineCtr lc = { 0, 0, 0 };
+                        real = get_W(P.g, node0, lc) != 0;
+                        lines[l] += (int32_t)(lc.rank_lines + lc.select_lines + lc.bit_lines);
+                    }
+                    if (real) h = gld(P.anno_head + ((uint64_t)node0 - 1));
+                }
+                gst(heads + i, h);
+            }
+        }
+    }
+    w.ctr.rank_lines += (uint32_t)wave_sum(lines);
+    wave_sync();
     uint32_t nl = 0;
+    // the run being collected: label slot t, positions [run_lo, run_hi)
+    int32_t run_t = -1, run_lo = 0, run_hi = 0;
+    auto flush_run = [&]() {
+        if (run_t < 0 || run_hi <= run_lo) return;
+        uint32_t *bw = bits + (uint32_t)run_t * W;
+        for (int32_t wd = run_lo >> 5; wd <= (run_hi - 1) >> 5; ++wd) {
+            const int32_t a = imax(run_lo, wd << 5) & 31, b = imin(run_hi, (wd + 1) << 5) - (wd << 5);      // bits [a, b) of word wd
+            const uint32_t mask = (b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1u)) & ~((1u << a) - 1u);
+            bw[wd] |= mask;
+        }
+    };
     for (int32_t i = 0; i < n; ++i) {
+        const uint64_t h = heads[i];
+        if (!(h & 0xFFFF)) continue;
         const DevSeed sd = w.seeds[s][i];
         const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
-        const int32_t end = imin((int32_t)sd.clipping + k - (int32_t)sd.offset, L);
-        const LabRow r = lab_row(w, node0);
+        const int32_t lo = sd.clipping, hi = imin((int32_t)sd.clipping + k - (int32_t)sd.offset, L);
+        const LabRow r = lab_row_of_head(P, h, (uint64_t)node0 - 1);
         for (uint32_t x = 0; x < r.n; ++x) {
             const uint32_t lbl = row_at(r, x);
+            if (run_t >= 0 && mlab[run_t] == lbl && lo <= run_hi && hi >= run_lo) {      // touches the run: grow it
+                run_lo = imin(run_lo, lo); run_hi = imax(run_hi, hi);
+                continue;
+            }
+            flush_run();
             uint32_t t = 0;
             while (t < nl && mlab[t] != lbl) ++t;
             if (t == nl) {
@@ -51,9 +108,10 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
                 for (uint32_t y = 0; y < W; ++y) bits[nl * W + y] = 0;
                 ++nl;
             }
-            for (int32_t pos = sd.clipping; pos < end; ++pos) bits[t * W + ((uint32_t)pos >> 5)] |= 1u << (pos & 31);
+            run_t = (int32_t)t; run_lo = lo; run_hi = hi;
         }
     }
+    flush_run();
     if (!nl) { w.n_seeds[s] = 0; w.num_matching[s] = 0; return; }
     // labels at or above the cut-off, ascending (only the SET is used afterwards)
     const double cutoff = P.cfg.min_exact_match * (double)L;
@@ -74,17 +132,29 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
     const uint32_t hk = lab_end(w, cntk);
     if (w.status != ST_OK) return;
     uint32_t hk_kept = 0;                                    // the whole set, kept for the read (made once)
+    // (a seed whose row is one label: its set is {that label} or nothing — the same handle for every seed with that label)
+    uint32_t one_lbl = 0xFFFFFFFFu, one_h = 0;
     int32_t m = 0;
     for (int32_t i = 0; i < n; ++i) {
+        const uint64_t hd = heads[i];
+        if (!(hd & 0xFFFF)) continue;
         const DevSeed sd = w.seeds[s][i];
-        const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
-        const LabRow r = lab_row(w, node0);
-        uint32_t h = lab_isect_row(w, hk, r);
-        if (w.status != ST_OK) return;
+        uint32_t h;
+        if ((hd & 0xFFFF) == 1 && (uint32_t)(hd >> 16) == one_lbl) {
+            h = one_h;
+        } else {
+            const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
+            const LabRow r = lab_row_of_head(P, hd, (uint64_t)node0 - 1);
+            h = lab_isect_row(w, hk, r);
+            if (w.status != ST_OK) return;
+            if (h) {
+                if (h == hk) { if (!hk_kept) hk_kept = lab_persist(w, hk); h = hk_kept; }
+                else h = lab_persist(w, h);
+                if (w.status != ST_OK) return;
+            }
+            if ((hd & 0xFFFF) == 1) { one_lbl = (uint32_t)(hd >> 16); one_h = h; }
+        }
         if (!h) continue;
-        if (h == hk) { if (!hk_kept) hk_kept = lab_persist(w, hk); h = hk_kept; }
-        else h = lab_persist(w, h);
-        if (w.status != ST_OK) return;
         w.seeds[s][m] = sd; w.seed_lab[s][m] = h; w.alive[s][m] = 1;
         ++m;
     }
@@ -236,6 +306,33 @@ MGX_DEV uint32_t lab_filter_seed(Wave &w, uint32_t prev_lab, uint32_t lab) {
     return lab_persist(w, d);
 }
 
+// filter_seed for every later seed of the list after seed i's extensions (dbg_aligner.cpp:379-382 / :731-734): the look-ups into
+// the extender's convergence table are independent — one seed per lane — and the label bookkeeping of the rejected ones
+// follows, in order
+MGX_DEV void lab_check_later(Wave &w, const ExtenderState &F, int s, int32_t i, int32_t n) {
+    for (int32_t base = i + 1; base < n; base += WAVE) {
+        FOR_LANES(l) {
+            const int32_t j = base + l;
+            if (j < n && w.alive[s][j]) {
+                const DevSeed sj = w.seeds[s][j];
+                const uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
+                const SeedRef rj = seedref_from_seed(w, s, j, nullptr);
+                if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[s][j] = 2;       // rejected: see below
+            }
+        }
+    }
+    wave_sync();
+    const uint32_t prev = w.seed_lab[s][i];
+    uint32_t memo_in = 0xFFFFFFFFu, memo_out = 0;            // (runs of seeds share one label set)
+    for (int32_t j = i + 1; j < n; ++j) {
+        if (w.alive[s][j] != 2) continue;
+        const uint32_t cur = w.seed_lab[s][j];
+        if (cur != memo_in) { memo_out = lab_filter_seed(w, prev, cur); memo_in = cur; if (w.status != ST_OK) return; }
+        w.seed_lab[s][j] = memo_out;
+        w.alive[s][j] = memo_out ? 1 : 0;
+    }
+}
+
 // ---- align_both_directions (dbg_aligner.cpp:531-758, the branch without chaining) with labeled seeds, BASIC graphs ----
 MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
@@ -250,10 +347,14 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
         if (!w.alive[s][i]) continue;
         SeedRef seed = seedref_from_seed(w, s, i, nullptr);
         conv_clear(w, F.conv);
+        uint64_t t0 = cycle_clock();
         extend(w, s, seed, false);
+        uint64_t t1 = cycle_clock();
+        w.cyc[2] += t1 - t0;
         const ExtendResult er = w.er;
         if (w.status != ST_OK) return;
         const int n_fwd = backtrack(w, s, seed, nullptr, er, imax(0, P.cfg.min_cell_score), &w.aln[0], E);
+        w.cyc[3] += cycle_clock() - t1;
         if (w.status != ST_OK) return;
         int n_rev = 0;
         bool rev_alive[LAB_EXT];
@@ -273,10 +374,14 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
             SeedRef rseed = seedref_from_aln(rev);
             const int32_t mps2 = imax(0, lab_min_path_score(w, rev.lab));
             conv_clear(w, B.conv);
+            const uint64_t t2 = cycle_clock();
             extend(w, 1 - s, rseed, true);
+            const uint64_t t3 = cycle_clock();
+            w.cyc[2] += t3 - t2;
             const ExtendResult er2 = w.er;
             if (w.status != ST_OK) return;
             const int n_bwd = backtrack(w, 1 - s, rseed, &rev, er2, mps2, &w.aln[2 * E], E);
+            w.cyc[3] += cycle_clock() - t3;
             if (w.status != ST_OK) return;
             for (int b = 0; b < n_bwd; ++b) {
                 DevAln &p2 = w.aln[2 * E + b];
@@ -297,17 +402,8 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
                 }
             }
         }
-        for (int32_t j = i + 1; j < n; ++j) {
-            if (!w.alive[s][j]) continue;
-            const DevSeed sj = w.seeds[s][j];
-            const uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
-            const SeedRef rj = seedref_from_seed(w, s, j, nullptr);
-            if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) {
-                w.seed_lab[s][j] = lab_filter_seed(w, w.seed_lab[s][i], w.seed_lab[s][j]);
-                if (w.status != ST_OK) return;
-                if (!w.seed_lab[s][j]) w.alive[s][j] = 0;
-            }
-        }
+        lab_check_later(w, F, s, i, n);
+        if (w.status != ST_OK) return;
     }
 }
 
@@ -329,17 +425,8 @@ MGX_NI_G4 void lab_align_core_fwd(Wave &w) {
         const int n_fwd = backtrack(w, 0, seed, nullptr, er, mps, &w.aln[0], E);
         if (w.status != ST_OK) return;
         for (int e = 0; e < n_fwd; ++e) { lab_add_alignment(w, w.aln[e]); if (w.status != ST_OK) return; }
-        for (int32_t j = i + 1; j < n; ++j) {
-            if (!w.alive[0][j]) continue;
-            const DevSeed sj = w.seeds[0][j];
-            const uint32_t last_node = sj.offset == 0 ? w.nodes[0][sj.clipping + sj.n_nodes - 1] : sj.node;
-            const SeedRef rj = seedref_from_seed(w, 0, j, nullptr);
-            if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) {
-                w.seed_lab[0][j] = lab_filter_seed(w, w.seed_lab[0][i], w.seed_lab[0][j]);
-                if (w.status != ST_OK) return;
-                if (!w.seed_lab[0][j]) w.alive[0][j] = 0;
-            }
-        }
+        lab_check_later(w, F, 0, i, n);
+        if (w.status != ST_OK) return;
     }
 }
 

@@ -55,10 +55,13 @@ MGX_DEV LabRow lab_row(Wave &w, uint32_t node) {
     LabRow r;
     r.n = 0; r.one = 0; r.more = nullptr;
     if (!node || node > P.g.n) return r;                     // npos (annotation_buffer.cpp:59-62)
-    // "skip dummy nodes" (annotation_buffer.cpp:64-68): !boss.get_W(node)
-    ++w.ctr.rank_lines;
-    const Block b = load_block_uniform(P.g, uni(node >> 6));
-    if (block_W(b, (int)(node & 63)) == 0) return r;
+    // "skip dummy nodes" (annotation_buffer.cpp:64-68): !boss.get_W(node) — unless the annotation was checked to hold no
+    // label on any dummy node's row (AlignParams::labeled bit 1: mgx_labeled_aligner_create looks once), when the row alone says it
+    if (!(P.labeled & 2u)) {
+        ++w.ctr.rank_lines;
+        const Block b = load_block_uniform(P.g, uni(node >> 6));
+        if (block_W(b, (int)(node & 63)) == 0) return r;
+    }
     const uint64_t row = (uint64_t)node - 1;
     if (row >= P.anno_rows) return r;
     const uint64_t h = P.anno_head[row];
@@ -166,14 +169,46 @@ MGX_DEV void lab_clear_column(Wave &w, int32_t idx) {
 // LabeledExtender::flush (aligner_labeled.cpp:81-137): the columns added since the last flush inherited their parent's labels
 // unseen ("annotations are preserved in unitigs"); now each is intersected with its node's labels, and a column left without
 // labels is cleared
+// Two passes: the columns' (node, parent) and the head words of their nodes' rows are gathered one column per lane into
+// the backtracking's start-cell list (unused during an extension and before bt_begin fills it) — three dependent loads per
+// column that would otherwise run one column after the other; the intersections then follow in table order.
 MGX_DEV void lab_flush(Wave &w, int32_t tsize) {
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    const int32_t first = w.last_flushed;
+    if (first >= tsize) return;
+    uint64_t *scr = (uint64_t *)w.indices;                   // per column: head word, node | parent << 32
+    LV<int32_t> lines;
+    FOR_LANES(l) { lines[l] = 0; }
+    for (int32_t base = first; base < tsize; base += WAVE) {
+        FOR_LANES(l) {
+            const int32_t i = base + l;
+            if (i < tsize) {
+                const ColMeta c = col_load(w, i);
+                uint64_t h = 0;
+                if (c.node && c.node <= P.g.n && (uint64_t)c.node - 1 < P.anno_rows) {
+                    bool real = true;
+                    if (!(P.labeled & 2u)) { LineCtr lc = { 0, 0, 0 }; real = get_W(P.g, c.node, lc) != 0; lines[l] += (int32_t)(lc.rank_lines + lc.select_lines + lc.bit_lines); }
+                    if (real) h = gld(P.anno_head + ((uint64_t)c.node - 1));
+                }
+                gst(scr + 2 * (i - first), h);
+                gst(scr + 2 * (i - first) + 1, (uint64_t)c.node | ((uint64_t)(uint32_t)c.parent << 32));
+            }
+        }
+    }
+    w.ctr.rank_lines += (uint32_t)wave_sum(lines);
+    wave_sync();
     for (; w.last_flushed < tsize; ++w.last_flushed) {
         const int32_t i = w.last_flushed;
-        const ColMeta c = uni_col(col_load(w, i));
-        const uint32_t ph = w.col_lab[c.parent];
+        const uint64_t hd = scr[2 * (i - first)], np = scr[2 * (i - first) + 1];
+        const uint32_t node = (uint32_t)np;
+        const int32_t parent = (int32_t)(uint32_t)(np >> 32);
+        const uint32_t ph = w.col_lab[parent];
         if (!ph) { lab_clear_column(w, i); if (w.status != ST_OK) return; continue; }
-        if (!c.node) continue;
-        const LabRow r = lab_row(w, c.node);
+        if (!node) continue;
+        LabRow r;
+        uint32_t cn = (uint32_t)(hd & 0xFFFF);
+        if (cn == 0xFFFF) cn = P.anno_count[(uint64_t)node - 1];
+        r.n = cn; r.one = (uint32_t)(hd >> 16); r.more = cn >= 2 ? P.anno_more + (hd >> 16) : nullptr;
         const uint32_t nh = lab_isect_row(w, ph, r);
         if (w.status != ST_OK) return;
         if (!nh) { lab_clear_column(w, i); if (w.status != ST_OK) return; }

@@ -245,6 +245,16 @@ __global__ void k_iota(uint32_t *v, uint64_t n) {
     if (i < n) v[i] = (uint32_t)i;
 }
 
+// label-aware alignment: does any dummy node (W == 0: the reference's AnnotationBuffer gives those no labels whatever their row
+// says, annotation_buffer.cpp:64-68) have a label in the matrix?  Checked once per aligner; if none does — annotations are built
+// from real k-mers — the kernels skip the W look-up in front of every row access.
+__global__ void k_anno_dummy_rows(DevGraph g, const uint64_t *head, uint64_t n_rows, uint32_t *flag) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (v > g.n || v - 1 >= n_rows || head[v - 1] == 0) return;
+    LineCtr lc = { 0, 0, 0 };
+    if (get_W(g, v, lc) == 0) atomicOr(flag, 1u);
+}
+
 // =================================================================================================
 // host side
 // =================================================================================================
@@ -353,6 +363,7 @@ static AlignMode default_mode() { return MODE_SPLIT8; }
 struct mgx_aligner {
     const mgx_graph *graph = nullptr;
     const mgx_annotation *anno = nullptr;      // label-aware alignment (mgx_labeled_aligner_create)
+    bool anno_dummy_clean = false;             // no row of a dummy node holds a label (k_anno_dummy_rows)
     mgx_config cfg;
     DevConfig dcfg;
     mgx_limits user_lim;
@@ -684,6 +695,17 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
     mgx_config &c = A->cfg;
     if (limits) { A->user_lim = *limits; A->have_user_lim = true; }
     HIP_TRY(hipSetDevice(g->device));
+    if (anno) {
+        int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;
+        mgx_annotation_device_view(anno, &adev, &arows, &h, &c, &m);
+        uint32_t *d_flag = nullptr, flag = 1;
+        HIP_TRY(hipMalloc(&d_flag, 4));
+        HIP_TRY(hipMemset(d_flag, 0, 4));
+        if (g->g.n) k_anno_dummy_rows<<<(uint32_t)((g->g.n + 255) / 256), 256>>>(g->g, h, arows, d_flag);
+        HIP_TRY(hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d_flag);
+        A->anno_dummy_clean = flag == 0;
+    }
     if (int rc = A->score_matrix.ensure(128 * 128)) return rc;
     HIP_TRY(hipMemcpy(A->score_matrix.p, c.score_matrix, 128 * 128, hipMemcpyHostToDevice));
     if (int rc = A->cursors.ensure(64)) return rc;
@@ -957,7 +979,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     if (labeled) {
         int adev = 0;
         mgx_annotation_device_view(A->anno, &adev, &P.anno_rows, &P.anno_head, &P.anno_count, &P.anno_more);
-        P.labeled = 1;
+        P.labeled = 1u | (A->anno_dummy_clean ? 2u : 0u);
         P.no_alias = 1;           // (a flush clears columns in place: convergence entries must not alias their S windows)
     }
 #ifdef MGX_PROBES

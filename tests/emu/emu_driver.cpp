@@ -367,6 +367,13 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
     if (AN) {
         P.labeled = 1; P.no_alias = 1;        // as mgx.hip
+        {
+            bool clean = true;                 // k_anno_dummy_rows: no dummy node's row holds a label
+            LineCtr lc = { 0, 0, 0 };
+            for (uint64_t v = 1; v <= G->g.n && v - 1 < AN->n_rows && clean; ++v)
+                if (AN->head[v - 1] && get_W(G->g, v, lc) == 0) clean = false;
+            if (clean && !getenv("MGX_EMU_LAB_WCHECK")) P.labeled |= 2u;      // (MGX_EMU_LAB_WCHECK=1: keep the per-access test)
+        }
         P.anno_head = AN->head.data(); P.anno_count = AN->count.data(); P.anno_more = AN->more.data(); P.anno_rows = AN->n_rows;
     }
     P.no_compact = getenv("MGX_NO_COMPACT") && atoi(getenv("MGX_NO_COMPACT")) == 1;
