@@ -57,7 +57,7 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
             const int32_t i = base + l;
             if (i < n) {
                 const DevSeed sd = w.seeds[s][i];
-                const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
+                const uint32_t node0 = lab_base_node(P, sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node);
                 uint64_t h = 0;
                 if (node0 && node0 <= P.g.n && (uint64_t)node0 - 1 < P.anno_rows) {
                     bool real = true;
@@ -90,7 +90,7 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
         const uint64_t h = heads[i];
         if (!(h & 0xFFFF)) continue;
         const DevSeed sd = w.seeds[s][i];
-        const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
+        const uint32_t node0 = lab_base_node(P, sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node);
         const int32_t lo = sd.clipping, hi = imin((int32_t)sd.clipping + k - (int32_t)sd.offset, L);
         const LabRow r = lab_row_of_head(P, h, (uint64_t)node0 - 1);
         for (uint32_t x = 0; x < r.n; ++x) {
@@ -143,7 +143,7 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
         if ((hd & 0xFFFF) == 1 && (uint32_t)(hd >> 16) == one_lbl) {
             h = one_h;
         } else {
-            const uint32_t node0 = sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node;
+            const uint32_t node0 = lab_base_node(P, sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node);
             const LabRow r = lab_row_of_head(P, hd, (uint64_t)node0 - 1);
             h = lab_isect_row(w, hk, r);
             if (w.status != ST_OK) return;
@@ -339,8 +339,11 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
     const AlignParams &P = MGX_PARAMS_OF(w);
     ExtenderState &F = w.ext[s];
     ExtenderState &B = w.ext[1 - s];
+    // a PRIMARY graph behind the CanonicalDBG wrapper holds both strands (:644-655): the backward pass runs on the same graph,
+    // an alignment on the reverse strand is reported as the forward alignment it mirrors (is_reversible: orientation && !offset)
+    const bool canon = kWithPrimary && P.cfg.canonical != 0;
     F.rc_view = 0;
-    B.rc_view = 1;                                            // use_rcdbg
+    B.rc_view = canon ? 0 : 1;                                // use_rcdbg
     const int E = lab_e(w);
     const int32_t n = w.n_seeds[s];
     for (int32_t i = 0; i < n; ++i) {
@@ -360,9 +363,25 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
         bool rev_alive[LAB_EXT];
         for (int e = 0; e < n_fwd; ++e) {
             DevAln &path = w.aln[e];
+            DevAln &rev = w.aln[E + n_rev];
+            if (canon) {
+                // the mirror image serves both purposes: what is reported for a reverse-strand alignment (:683-689) and the seed
+                // of the backward pass (:695) — the same reverse_complement(graph_, query_rc)
+                const bool reversible = path.orientation && !path.offset;
+                const bool to_left = aln_clipping(path) && !path.offset;
+                const bool good = path.score >= lab_min_path_score(w, path.lab);
+                bool have_rev = false;
+                if ((good && reversible) || to_left) { copy_aln(rev, path); have_rev = reverse_complement_aln_stored(w, rev); }
+                if (good) {
+                    if (reversible) { if (have_rev) lab_add_alignment(w, rev); } else lab_add_alignment(w, path);
+                    if (w.status != ST_OK) return;
+                }
+                if (!to_left || !have_rev) continue;
+                rev_alive[n_rev++] = true;
+                continue;
+            }
             if (path.score >= lab_min_path_score(w, path.lab)) { lab_add_alignment(w, path); if (w.status != ST_OK) return; }
             if (!aln_clipping(path) || path.offset) continue;
-            DevAln &rev = w.aln[E + n_rev];
             copy_aln(rev, path);
             if (!reverse_complement_aln(w, rev)) continue;
             rev_alive[n_rev++] = true;
@@ -385,7 +404,12 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
             if (w.status != ST_OK) return;
             for (int b = 0; b < n_bwd; ++b) {
                 DevAln &p2 = w.aln[2 * E + b];
-                if (!reverse_complement_aln(w, p2)) continue;
+                if (canon && !(p2.orientation && !p2.offset)) {       // not reversible: as it is (:711)
+                    lab_add_alignment(w, p2);
+                    if (w.status != ST_OK) return;
+                    continue;
+                }
+                if (!(canon ? reverse_complement_aln_stored(w, p2) : reverse_complement_aln(w, p2))) continue;
                 const int32_t clip = aln_clipping(p2), eclip = aln_end_clipping(p2);
                 for (int32_t x = 0; x < p2.n_nodes; ++x) filter_nodes(w, F, p2.nodes[x], clip, w.L - eclip);
                 if (w.status != ST_OK) return;

@@ -47,6 +47,12 @@ MGX_DEV uint32_t lab_persist(Wave &w, uint32_t h) {
     return d;
 }
 
+// A PRIMARY graph is annotated and looked up by BASE node: the wrapper's ids above n are the reverse complements of the base
+// nodes v - n (CanonicalDBG::get_base_node, canonical_dbg.hpp; annotation_buffer.cpp:41-63, :195-217)
+MGX_DEV uint32_t lab_base_node(const AlignParams &P, uint32_t node) {
+    return (kWithPrimary && P.cfg.canonical >= 2 && node > P.g.n) ? node - (uint32_t)P.g.n : node;
+}
+
 // the labels of a node: its row of the label matrix (row = node - 1: AnnotatedDBG::graph_to_anno_index, annotated_dbg.hpp:50-52)
 struct LabRow { uint32_t n, one; const uint32_t *more; };
 MGX_DEV uint32_t row_at(const LabRow &r, uint32_t i) { return r.n == 1 ? r.one : r.more[i]; }
@@ -54,6 +60,7 @@ MGX_DEV LabRow lab_row(Wave &w, uint32_t node) {
     const AlignParams &P = MGX_PARAMS_OF(w);
     LabRow r;
     r.n = 0; r.one = 0; r.more = nullptr;
+    node = lab_base_node(P, node);
     if (!node || node > P.g.n) return r;                     // npos (annotation_buffer.cpp:59-62)
     // "skip dummy nodes" (annotation_buffer.cpp:64-68): !boss.get_W(node) — unless the annotation was checked to hold no
     // label on any dummy node's row (AlignParams::labeled bit 1: mgx_labeled_aligner_create looks once), when the row alone says it
@@ -184,14 +191,15 @@ MGX_DEV void lab_flush(Wave &w, int32_t tsize) {
             const int32_t i = base + l;
             if (i < tsize) {
                 const ColMeta c = col_load(w, i);
+                const uint32_t bn = lab_base_node(P, c.node);
                 uint64_t h = 0;
-                if (c.node && c.node <= P.g.n && (uint64_t)c.node - 1 < P.anno_rows) {
+                if (bn && bn <= P.g.n && (uint64_t)bn - 1 < P.anno_rows) {
                     bool real = true;
-                    if (!(P.labeled & 2u)) { LineCtr lc = { 0, 0, 0 }; real = get_W(P.g, c.node, lc) != 0; lines[l] += (int32_t)(lc.rank_lines + lc.select_lines + lc.bit_lines); }
-                    if (real) h = gld(P.anno_head + ((uint64_t)c.node - 1));
+                    if (!(P.labeled & 2u)) { LineCtr lc = { 0, 0, 0 }; real = get_W(P.g, bn, lc) != 0; lines[l] += (int32_t)(lc.rank_lines + lc.select_lines + lc.bit_lines); }
+                    if (real) h = gld(P.anno_head + ((uint64_t)bn - 1));
                 }
                 gst(scr + 2 * (i - first), h);
-                gst(scr + 2 * (i - first) + 1, (uint64_t)c.node | ((uint64_t)(uint32_t)c.parent << 32));
+                gst(scr + 2 * (i - first) + 1, (uint64_t)bn | ((uint64_t)(uint32_t)c.parent << 32));
             }
         }
     }

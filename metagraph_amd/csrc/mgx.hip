@@ -681,7 +681,7 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
         // reference looks labels up by base node through the CanonicalDBG wrapper for PRIMARY graphs and by spelling for
         // CANONICAL ones: not on the device yet), annotation without coordinates, as many alternative paths per label as
         // the labeled kernel build holds.
-        if (g->mode != MGX_MODE_BASIC) return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment runs on BASIC-mode graphs only");
+        if (g->mode == MGX_MODE_CANONICAL) return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment on CANONICAL-mode graphs is not on the device (BASIC and PRIMARY are)");
         if (A->cfg.num_alternative_paths > (uint64_t)std::min(mgx_lab64_max_alt(), mgx_grp_max_alt8_lab()))
             return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment: num_alternative_paths <= %d on the device", std::min(mgx_lab64_max_alt(), mgx_grp_max_alt8_lab()));
         int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;

@@ -6,6 +6,7 @@
 
 #define mgx mgx_lab64
 #define MGX_WITH_LABELS 1
+#define MGX_WITH_PRIMARY 1
 #ifndef MGX_MAX_ALT
 #define MGX_MAX_ALT 2
 #endif

@@ -342,7 +342,7 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     R->m_fwd.assign(nf.begin(), nf.end());
     R->m_rc.assign(nr.begin(), nr.end());
     if (map_only) return R;
-    if (AN && G->mode != MGX_MODE_BASIC) { R->error = "label-aware alignment: BASIC-mode graphs only"; return R; }
+    if (AN && G->mode == MGX_MODE_CANONICAL) { R->error = "label-aware alignment: BASIC- and PRIMARY-mode graphs only"; return R; }
     rc = derive_limits(cfg, limits, Lmax, &R->lim, &R->error, AN != nullptr);
     if (rc) return R;
     const uint64_t stride = arena_bytes(R->lim);

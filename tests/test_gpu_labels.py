@@ -25,10 +25,15 @@ def gpu_annotation(anno):
 KERNELS = {"lab64": ("ext64=2", capi.KERNEL_LAB64), "grp8_lab": ("ext64=0", capi.KERNEL_GRP8_LAB)}
 
 
-def compare_gpu_labeled(g, anno, cfg, reads, validate=True, check_seeds=True, kernel="lab64"):
+def compare_gpu_labeled(g, anno, cfg, reads, validate=True, check_seeds=True, kernel="lab64", mode=0):
     o = orc.LabeledAlignRun(g, cfg, anno, reads, validate=validate)
     assert o.error == "", o.error
-    G, AN = gpu_graph(g), gpu_annotation(anno)
+    if mode:
+        W, last, F, valid = g.export()
+        G = aligner.Graph(g.k, W, last, F, valid, mode=mode)
+    else:
+        G = gpu_graph(g)
+    AN = gpu_annotation(anno)
     A = aligner.Aligner(G, cfg, annotation=AN)
     A.set_pipeline(KERNELS[kernel][0])
     A.keep_seeds(check_seeds)
@@ -42,13 +47,13 @@ def compare_gpu_labeled(g, anno, cfg, reads, validate=True, check_seeds=True, ke
 
 
 @pytest.mark.parametrize("kernel", sorted(KERNELS))
-@pytest.mark.parametrize("name", sorted(n for n in CASES if CASES[n]["mode"] == 0))
+@pytest.mark.parametrize("name", sorted(CASES))
 def test_reference_label_kats_on_gpu(name, kernel):
     case = CASES[name]
     g, anno, cfg = build(case)
     for query, expect in case["expect"].items():
         _, want = compare_gpu_labeled(g, anno, cfg, [query], validate=not (cfg.left_end_bonus or cfg.right_end_bonus), check_seeds=False,
-                                      kernel=kernel)
+                                      kernel=kernel, mode=case["mode"])
         assert len(want[0]) == len(expect)
         for a in want[0]:                                    # the reference's own assertions (get_alignment_labels)
             names = [case["labels"][l] for l in a["labels"]]
@@ -123,13 +128,30 @@ def test_labeled_tsv_line():
     assert line == want + "\n"
 
 
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+@pytest.mark.parametrize("seed,k", [(1, 11), (2, 15), (3, 7), (4, 19), (5, 31)])
+def test_labeled_alignment_on_primary_graphs_on_gpu(seed, k, kernel):
+    """PRIMARY graphs through the CanonicalDBG wrapper: labels by base node, mirrored reverse-strand alignments"""
+    from test_labeled_emu import primary_labeled_world
+    g, anno, reads = primary_labeled_world(seed, k)
+    cfg = capi.config_cli(k)
+    if seed == 2:
+        cfg.min_seed_length = 11
+    _, want = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=False, kernel=kernel, mode=2)
+    assert sum(1 for a in want if a) >= 8
+
+
 def test_labeled_aligner_refuses_what_it_cannot_do():
-    from test_oracle_primary_goldens import primary_contigs
-    contigs = primary_contigs(["GTCGAAATTAGTCGAAA"], 5, "input")[0]
-    g = orc.Graph.build(5, contigs, 2, True)
+    g = orc.Graph.build(5, ["GTCGAAATTAGTCGAAA"], 1, False)
     W, last, F, valid = g.export()
-    G = aligner.Graph(g.k, W, last, F, valid, mode=2)
+    G = aligner.Graph(g.k, W, last, F, valid, mode=1)
     AN = gpu_annotation(orc.Annotation(g, 1))
     with pytest.raises(aligner.MgxError) as e:
         aligner.Aligner(G, capi.config_cli(5), annotation=AN)
+    assert e.value.code == capi.MGX_ERR_UNSUPPORTED
+    cfg = capi.config_cli(5)
+    cfg.num_alternative_paths = 3
+    g0 = orc.Graph.build(5, ["GTCGAAATTAGTCGAAA"], 0, False)
+    with pytest.raises(aligner.MgxError) as e:
+        aligner.Aligner(gpu_graph(g0), cfg, annotation=gpu_annotation(orc.Annotation(g0, 1)))
     assert e.value.code == capi.MGX_ERR_UNSUPPORTED

@@ -15,10 +15,10 @@ from test_oracle_labeled import CASES, build
 SEEN = {"multi_aln": 0, "multi_label": 0, "worlds": 0}
 
 
-def compare_emu_labeled(g, anno, cfg, reads, validate=True):
+def compare_emu_labeled(g, anno, cfg, reads, validate=True, mode=0):
     o = orc.LabeledAlignRun(g, cfg, anno, reads, validate=validate)
     assert o.error == "", o.error
-    e = emu_drv.EmuRun(emu_drv.EmuGraph(g), cfg, reads, annotation=emu_drv.EmuAnnotation(anno))
+    e = emu_drv.EmuRun(emu_drv.EmuGraph(g, mode=mode), cfg, reads, annotation=emu_drv.EmuAnnotation(anno))
     assert e.error == "", e.error
     got, status = e.results()
     want = with_labels(o)
@@ -33,12 +33,12 @@ def compare_emu_labeled(g, anno, cfg, reads, validate=True):
     return want
 
 
-@pytest.mark.parametrize("name", sorted(n for n in CASES if CASES[n]["mode"] == 0))
+@pytest.mark.parametrize("name", sorted(CASES))
 def test_reference_label_kats_in_the_wave_program(name):
     case = CASES[name]
     g, anno, cfg = build(case)
     for query, expect in case["expect"].items():
-        want = compare_emu_labeled(g, anno, cfg, [query], validate=not (cfg.left_end_bonus or cfg.right_end_bonus))
+        want = compare_emu_labeled(g, anno, cfg, [query], validate=not (cfg.left_end_bonus or cfg.right_end_bonus), mode=case["mode"])
         assert len(want[0]) == len(expect)
 
 
@@ -61,10 +61,42 @@ def test_random_labeled_worlds(seed, k, n_strains, divergence, monkeypatch):
         assert SEEN["multi_aln"] >= 5 and SEEN["multi_label"] >= 5, SEEN
 
 
-def test_labeled_needs_a_basic_graph():
+def primary_labeled_world(seed, k):
+    """a PRIMARY graph (seen through the CanonicalDBG wrapper) over two strains, labels per strain and per segment"""
+    import random
+    from test_emu_vs_oracle import rand_seq, mutate, rc
     from test_oracle_primary_goldens import primary_contigs
-    contigs = primary_contigs(["GTCGAAATTAGTCGAAA"], 5, "input")[0]
-    g = orc.Graph.build(5, contigs, 2, True)
+    rng = random.Random(seed)
+    genome = rand_seq(rng, 900)
+    strains = [genome, mutate(rng, genome, 0.03)]
+    contigs = primary_contigs(strains, k, "input")[0]
+    g = orc.Graph.build(k, contigs, 2, True)
+    anno = orc.Annotation(g, 4)
+    for j, st in enumerate(strains):
+        anno.annotate(st, j)
+    anno.annotate(genome[100:400], 2)
+    anno.annotate(rc(genome[500:800]), 3)                 # (annotated from the other strand: the same base nodes)
+    reads = []
+    for i in range(16):
+        st = rng.choice(strains)
+        p = rng.randrange(0, len(st) - 80)
+        r = mutate(rng, st[p:p + 80], rng.choice([0.0, 0.03]))
+        reads.append(rc(r) if i % 2 else r)
+    return g, anno, reads
+
+
+@pytest.mark.parametrize("seed,k", [(1, 11), (2, 15), (3, 7)])
+def test_labeled_alignment_on_primary_graphs(seed, k):
+    g, anno, reads = primary_labeled_world(seed, k)
+    cfg = capi.config_cli(k)
+    if seed == 2:
+        cfg.min_seed_length = 11
+    want = compare_emu_labeled(g, anno, cfg, reads, mode=2)
+    assert sum(1 for a in want if a) >= 8
+
+
+def test_labeled_refuses_canonical_mode_graphs():
+    g = orc.Graph.build(5, ["GTCGAAATTAGTCGAAA"], 1, False)
     anno = orc.Annotation(g, 1)
-    e = emu_drv.EmuRun(emu_drv.EmuGraph(g, mode=2), capi.config_cli(5), ["GTCGAAA"], annotation=emu_drv.EmuAnnotation(anno))
-    assert "BASIC" in e.error
+    e = emu_drv.EmuRun(emu_drv.EmuGraph(g, mode=1), capi.config_cli(5), ["GTCGAAA"], annotation=emu_drv.EmuAnnotation(anno))
+    assert "PRIMARY" in e.error
