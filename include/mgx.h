@@ -332,7 +332,8 @@ uint64_t mgx_annotation_device_bytes(const mgx_annotation *a);
 uint64_t mgx_annotation_num_rows(const mgx_annotation *a);
 uint32_t mgx_annotation_num_labels(const mgx_annotation *a);
 /* BinaryMatrix::get_rows for a batch of rows, as CSR: labels of rows[i] = out_labels[out_begin[i] .. out_begin[i + 1]),
- * ascending (what annotation_buffer.cpp:185 sorts into).  out_begin has n + 1 entries; `cap` = entries out_labels holds: a
+ * ascending (what annotation_buffer.cpp:185 sorts into).  Calls on one handle are serialised inside (the handle owns the scratch
+ * buffers); they run on the null stream.  out_begin has n + 1 entries; `cap` = entries out_labels holds: a
  * batch with more returns MGX_ERR_CAPACITY with the needed count in *n_labels_out (out_begin is complete, out_labels
  * untouched).  rows_on_device / out_on_device != 0: device pointers (rows already in HBM / results left in HBM). */
 int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n, int rows_on_device,

@@ -21,6 +21,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -158,7 +159,9 @@ struct mgx_annotation {
     uint32_t *count = nullptr;    // exact label count per row (rows with >= 0xFFFF labels need it; 4 B per row)
     uint32_t *more = nullptr;
     uint64_t bytes = 0;
-    // scratch of get_rows, grown on demand
+    // scratch of get_rows, grown on demand; get_rows calls on one handle are serialised (workers of one process share the
+    // annotation: mgx_align --devices, cli/align.cpp's thread pool)
+    std::mutex rows_mutex;
     uint64_t *d_rows = nullptr, *d_begin = nullptr;
     uint32_t *d_labels = nullptr;
     void *d_tmp = nullptr;
@@ -172,6 +175,7 @@ extern "C" {
  * (row = AnnotatedDBG::graph_to_anno_index(node) = node - 1, annotated_dbg.hpp:50-52). */
 int mgx_annotation_create(uint64_t n_rows, uint32_t n_labels, const uint64_t *const *columns, int device, mgx_annotation **out) {
     if (!out || (!columns && n_labels) || n_labels >= (1u << 24)) return afail(MGX_ERR_INVALID, "mgx_annotation_create: bad arguments");
+    for (uint32_t j = 0; j < n_labels && n_rows; ++j) if (!columns[j]) return afail(MGX_ERR_INVALID, "mgx_annotation_create: column %u is null", j);
     if (mgx_device_count() <= device) return afail(MGX_ERR_NO_DEVICE, "HIP device %d not available", device);
     HIP_TRY_A(hipSetDevice(device));
     auto *A = new mgx_annotation();
@@ -312,6 +316,7 @@ int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n,
                             uint64_t *out_begin, uint32_t *out_labels, uint64_t cap, int out_on_device, uint64_t *n_labels_out) {
     if (!a || (!rows && n) || !out_begin || (!out_labels && cap)) return afail(MGX_ERR_INVALID, "mgx_annotation_get_rows: bad arguments");
     if (mgx_device_count() <= a->device) return afail(MGX_ERR_NO_DEVICE, "no HIP device");
+    std::lock_guard<std::mutex> lock(a->rows_mutex);
     HIP_TRY_A(hipSetDevice(a->device));
     const uint32_t tb = 256;
     const uint32_t blocks = (uint32_t)((n + tb - 1) / tb);

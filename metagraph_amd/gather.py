@@ -121,6 +121,12 @@ class ResultGatherer:
         for wk in works:
             if wk is not None:
                 wk.wait()
+        # Work.wait() orders the CURRENT torch stream behind the collectives; the consumers of these views are not torch
+        # kernels (host decode through raw pointers, libmgx on the legacy null stream), so the stream is drained here
+        if works and any(wk is not None for wk in works):
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()
         self._pending = None
         if self.rank != 0:
             return None
