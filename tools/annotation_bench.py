@@ -56,6 +56,42 @@ for rep in range(3):
     dt = time.time() - t0
     assert rc == 0, L.mgx_last_error()
     best = dt if best is None else min(best, dt)
+# device-resident I/O, timed with HIP events on the stream the kernels run on (the null stream): what the call costs when its
+# caller keeps rows and results in HBM — no PCIe in the figure
+hip = C.CDLL("libamdhip64.so")
+def hip_ok(rc):
+    assert rc == 0, "hip error %d" % rc
+d_rows, d_begin, d_labels = C.c_void_p(), C.c_void_p(), C.c_void_p()
+hip_ok(hip.hipMalloc(C.byref(d_rows), C.c_size_t(args.queries * 8)))
+hip_ok(hip.hipMalloc(C.byref(d_begin), C.c_size_t((args.queries + 1) * 8)))
+hip_ok(hip.hipMalloc(C.byref(d_labels), C.c_size_t(len(labels) * 4)))
+hip_ok(hip.hipMemcpy(d_rows, C.c_void_p(rows.ctypes.data), C.c_size_t(args.queries * 8), 1))
+ev0, ev1 = C.c_void_p(), C.c_void_p()
+hip_ok(hip.hipEventCreate(C.byref(ev0))); hip_ok(hip.hipEventCreate(C.byref(ev1)))
+dev_ms = []
+for rep in range(5):
+    hip_ok(hip.hipEventRecord(ev0, None))
+    rc = L.mgx_annotation_get_rows(h, d_rows, args.queries, 1, d_begin, d_labels, len(labels), 1, C.byref(need))
+    hip_ok(hip.hipEventRecord(ev1, None))
+    hip_ok(hip.hipEventSynchronize(ev1))
+    assert rc == 0, L.mgx_last_error()
+    ms = C.c_float()
+    hip_ok(hip.hipEventElapsedTime(C.byref(ms), ev0, ev1))
+    dev_ms.append(ms.value)
+begin_d = np.zeros(args.queries + 1, dtype=np.uint64)
+labels_d = np.zeros(len(labels), dtype=np.uint32)
+hip_ok(hip.hipMemcpy(C.c_void_p(begin_d.ctypes.data), d_begin, C.c_size_t((args.queries + 1) * 8), 2))
+hip_ok(hip.hipMemcpy(C.c_void_p(labels_d.ctypes.data), d_labels, C.c_size_t(len(labels) * 4), 2))
+assert np.array_equal(begin_d, begin) and np.array_equal(labels_d[:int(need.value)], labels[:int(need.value)]), "device-resident results differ"
+dev_best = min(dev_ms[1:]) * 1e-3
+# every row costs one dependent 8-byte access to head[] (a 64-byte line), rows with two labels one more to more[]
+lines = args.queries + int((np.diff(begin) >= 2).sum())
+ceiling = None
+try:
+    ceil = json.load(open(os.path.join(ROOT, "profiles", "r03_gather_ceiling.json")))
+    ceiling = max(r["chains1"] for r in ceil["sets"][1]["rows"]) * 1e9       # dependent random 64-B lines/s, DRAM-resident set
+except (OSError, KeyError, ValueError, IndexError):
+    pass
 # spot check against the construction
 for i in rng.integers(0, args.queries, size=2000):
     r = int(rows[i]); got = [int(x) for x in labels[int(begin[i]):int(begin[i + 1])]]
@@ -64,4 +100,11 @@ for i in rng.integers(0, args.queries, size=2000):
 print(json.dumps({"rows": n_rows, "labels": n_labels, "device_bytes": int(L.mgx_annotation_device_bytes(h)),
                   "create_s_incl_h2d_of_columns": round(t_create, 2), "queries": args.queries,
                   "get_rows_s_host_in_host_out": round(best, 4), "rows_per_s": round(args.queries / best),
-                  "labels_returned": int(need.value), "spot_check": "2000 rows ok"}))
+                  "labels_returned": int(need.value), "spot_check": "2000 rows ok",
+                  "get_rows_ms_device_resident_hip_events": [round(x, 3) for x in dev_ms],
+                  "rows_per_s_device_resident": round(args.queries / dev_best),
+                  "random_lines_per_s": round(lines / dev_best),
+                  "frac_of_measured_random_line_ceiling": round(lines / dev_best / ceiling, 3) if ceiling else None,
+                  "ceiling_lines_per_s": ceiling,
+                  "note": "device-resident: rows, begin[] and labels[] in HBM, HIP events on the null stream around the call (count "
+                          "kernel, scan, gather kernel); the host-in / host-out figure above includes the PCIe copies of rows and results"}))
