@@ -23,6 +23,22 @@ def test_bench_step_under_torchrun_nccl_single_rank():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 1 and out["value"] > 0 and out["value_host_inclusive"] > 0
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["value_device_resident"] > 0 and out["value_is"].startswith("host-inclusive")
     assert out["parity"]["sample"] == 30000 and out["parity"]["mismatches"] == 0 and out["parity"]["capacity_errors"] == 0
     assert out["roofline"]["frac"] > 0 and out["cpu_baseline"]["single_thread"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_config3_labels_at_reduced_size():
+    """BASELINE config 3 through bench.py: the annotation built on the device from the genome's mapped nodes
+    (mgx_map_batch -> mgx_annotation_create_sparse), the label-aware aligner on the 8-reads-per-wavefront labeled kernel,
+    alignments AND label lists of the sample against the oracle's LabeledAligner"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--labels", "40", "--steps", "1", "--warmup", "1",
+           "--reads", "40000", "--genome", "400000", "--snps", "800", "--parity-sample", "1500", "--host-steps", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert "label-aware" in out["config"]["workload"] and out["value"] > 0
+    assert out["parity"]["sample"] == 1500 and out["parity"]["mismatches"] == 0 and out["parity"]["capacity_errors"] == 0
+    assert out["parity"]["full_batch_capacity_errors"] == 0
+    assert out["roofline"]["kernel_ms"]["k_extend"] > 0 and out["cpu_baseline"]["cores"] == 1
