@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+for v in ${AB_VARIANTS:-"" laneold laner1}; do
+  if [ -n "$v" ]; then export MGX_LIB_PATH=$GRAFT_REPO_ROOT/metagraph_amd/_build/libmgx_$v.so; else unset MGX_LIB_PATH; fi
+  timeout 300 python bench.py --reads 4000000 --host-steps 0 --no-cpu-baseline --parity-sample 0 --steps 3 > gpurun_out/ab_$v.json 2>/dev/null
+  python -c "
+import json; d=json.load(open('gpurun_out/ab_$v.json')); k=d['roofline']['kernel_ms']; print('variant[$v]', d['ms_per_step_device_resident'], k['k_lane'], k['k_extend'], k['reads_finished_by_k_lane'])"
+done
