@@ -1091,6 +1091,8 @@ MGX_DEV bool push_seed(Wave &w, int s, int32_t clip, int32_t len, int32_t offset
 }
 
 // MEMSeeder::get_seeds / ExactSeeder::get_seeds into w.seeds[s] (A/aligner_seeder_methods.cpp:67-93,360-424)
+// MANY: one seed per matched k-mer (max_seed_length <= k; see make_seeder)
+template <bool MANY>
 MGX_NI_G2 void base_seeds(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = MGX_PARAMS_OF(w);
@@ -1099,9 +1101,41 @@ MGX_NI_G2 void base_seeds(Wave &w, int s) {
     const uint32_t *nodes = w.nodes[s];
     w.n_seeds[s] = 0;
     if ((double)w.num_matching[s] < cfg.min_exact_match * (double)L) return;
-    if ((uint32_t)k >= cfg.max_seed_length) {
+    if (MANY) {
         // ExactSeeder::get_seeds
         if (cfg.max_seed_length < (uint32_t)k) return;
+        // One seed per matched k-mer (label-aware alignment clamps max_seed_length to k: ~120 seeds per strand of a 150-bp
+        // read).  When no window of the strand can be low-complexity — the whole-strand verdict window_low_complexity()
+        // caches — the seeds are written one k-mer per lane, in position order; else position by position.
+        const int32_t i0 = bits_next(w.bm[0], n, 0, true);       // the first matched k-mer (kmer_masks)
+        if (i0 >= n) return;
+        bool plain = !cfg.seed_complexity_filter;
+        if (!plain) { (void)window_low_complexity(w, s, i0, k); plain = w.lc_any[s] == 0; }
+        if (plain) {
+            const int32_t max_seeds = (int32_t)MGX_PARAMS_OF(w).lim.max_seeds;
+            int32_t ns = 0;
+            for (int32_t base = i0; base < n; base += WAVE) {
+                LV<bool> has;
+                LV<uint32_t> nd;
+                FOR_LANES(l) { const int32_t i = base + l; nd[l] = i < n ? gld(nodes + i) : 0u; has[l] = nd[l] != 0; }
+                const uint64_t mk = wave_ballot(has);
+                const int32_t cnt = popc64(mk);
+                if (ns + cnt > max_seeds) { w.status = ST_CAPACITY; w.n_seeds[s] = ns; return; }
+                FOR_LANES(l) {
+                    if (has[l]) {
+                        const int32_t pos = ns + popc64(mk & ((1ull << l) - 1));
+                        DevSeed sd;
+                        sd.clipping = (uint16_t)(base + l); sd.length = (uint16_t)k; sd.offset = 0; sd.n_nodes = 1; sd.node = nd[l];
+                        w.seeds[s][pos] = sd;
+                        w.alive[s][pos] = 1;
+                    }
+                }
+                ns += cnt;
+            }
+            w.n_seeds[s] = ns;
+            wave_sync();
+            return;
+        }
         for (int32_t i = 0; i < n; ++i) {
             if (nodes[i]) {
                 if (!cfg.seed_complexity_filter || !window_low_complexity(w, s, i, k))
@@ -1315,6 +1349,10 @@ MGX_DEV void primary_rc_suffix_seeds(Wave &w, int s, uint32_t alt_n) {
 }
 
 // SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358; the CanonicalDBG part above)
+// Two instantiations: MANY = one seed per matched k-mer (max_seed_length <= k: label-aware alignment, ~120 base seeds per strand
+// of a short read), whose bookkeeping runs one seed / one slot per lane; else a handful of MEMs, seed by seed.  (As run-time
+// branches of one function the lane-parallel blocks cost the few-seed kernel 3 %: profiles/r04_ab4_seed_agg.txt.)
+template <bool MANY>
 MGX_NI_G2 void make_seeder(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = MGX_PARAMS_OF(w);
@@ -1329,11 +1367,11 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     SEED_T(0, tp)
     w.n_seeds[s] = 0;
     if ((uint32_t)L < cfg.min_seed_length) return;
-    if (cfg.min_seed_length >= (uint32_t)k) { base_seeds(w, s); return; }
+    if (cfg.min_seed_length >= (uint32_t)k) { base_seeds<MANY>(w, s); return; }
 
     const int32_t msl0 = (int32_t)cfg.min_seed_length;
     const int32_t nslots = L - msl0 + 1;
-    base_seeds(w, s);
+    base_seeds<MANY>(w, s);
     SEED_T(1, tp)
     if (w.status != ST_OK) return;
     const int32_t n_base = w.n_seeds[s];
@@ -1349,17 +1387,43 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         FOR_LANES(l) { if (l == 0) for (int32_t x = 0; x < nwords; ++x) { w.bm[2][x] = 0; w.bm[3][x] = 0; } }
     }
     wave_sync();
-    for (int32_t b = 0; b < n_base; ++b) {
-        DevSeed sd = w.seeds[s][b];
-        int32_t i = sd.clipping;
-        w.bm[3][i >> 6] |= 1ull << (i & 63);
-        for (int32_t j = 0; j < sd.n_nodes; ++j) w.msl[i + j] = (uint16_t)k;
-        if (i + sd.n_nodes < nslots) w.msl[i + sd.n_nodes] = (uint16_t)k;
-        w.pos_full[i] = 1;            // suffix_seeds[i] holds exactly this full seed
-        w.pos_cnt[i] = 1;
-        w.pos_start[i] = (uint32_t)b; // index of the full seed among the base seeds
+    if (MANY) {
+        // (one base seed per lane: seeds cover disjoint positions, and where their msl ranges touch they write the same value)
+        for (int32_t base = 0; base < n_base; base += WAVE) {
+            FOR_LANES(l) {
+                const int32_t b = base + l;
+                if (b < n_base) {
+                    const DevSeed sd = w.seeds[s][b];
+                    const int32_t i = sd.clipping;
+                    for (int32_t j = 0; j < sd.n_nodes; ++j) w.msl[i + j] = (uint16_t)k;
+                    if (i + sd.n_nodes < nslots) w.msl[i + sd.n_nodes] = (uint16_t)k;
+                    w.pos_full[i] = 1;            // suffix_seeds[i] holds exactly this full seed
+                    w.pos_cnt[i] = 1;
+                    w.pos_start[i] = (uint32_t)b; // index of the full seed among the base seeds
+                }
+            }
+        }
+        wave_sync();
+        for (int32_t base = 0; base < nslots; base += WAVE) {          // slots that hold a base seed
+            LV<bool> fl;
+            FOR_LANES(l) { const int32_t i = base + l; fl[l] = i < nslots && w.pos_full[i] != 0; }
+            const uint64_t fb = wave_ballot(fl);
+            FOR_LANES(l) { if (l == 0 && fb) w.bm[3][base >> 6] |= fb << (base & 63); }
+        }
+        wave_sync();
+    } else {
+        for (int32_t b = 0; b < n_base; ++b) {
+            DevSeed sd = w.seeds[s][b];
+            int32_t i = sd.clipping;
+            w.bm[3][i >> 6] |= 1ull << (i & 63);
+            for (int32_t j = 0; j < sd.n_nodes; ++j) w.msl[i + j] = (uint16_t)k;
+            if (i + sd.n_nodes < nslots) w.msl[i + sd.n_nodes] = (uint16_t)k;
+            w.pos_full[i] = 1;            // suffix_seeds[i] holds exactly this full seed
+            w.pos_cnt[i] = 1;
+            w.pos_start[i] = (uint32_t)b; // index of the full seed among the base seeds
+        }
+        wave_sync();
     }
-    wave_sync();
     SEED_T(2, tp)
     // Read tail (positions with fewer than k characters left): if the last k-mer is a node, its target node's
     // label ends with q[i..L) for every such i, so index_range matches all L - i characters.  The length is all
@@ -1510,33 +1574,98 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     // aggregate (:316-357): rebuild the seed list in position order
     // full seeds are already stored at [0, n_base); copy them out of the way first
     DevSeed *tmp = (DevSeed *)w.indices;         // scratch big enough for n_base <= L seeds
-    for (int32_t b = 0; b < n_base; ++b) tmp[b] = w.seeds[s][b];
-    w.n_seeds[s] = 0;
     uint32_t num_matching = 0;
-    int32_t last_end = 0;
-    // slots that can hold seeds: positions of base seeds and of lookup hits (pos_cnt is only ever raised there)
-    for (int32_t i = bits_next(w.bm[3], nslots, 0, true); i < nslots; i = bits_next(w.bm[3], nslots, i + 1, true)) {
-        int32_t cnt = w.pos_cnt[i];
-        if (!cnt) continue;
-        bool full = w.pos_full[i];
-        bool emitted = false;
-        int32_t begin = i, end = 0;
-        if (full) {
-            DevSeed fs = tmp[w.pos_start[i]];
-            if (!push_seed(w, s, fs.clipping, fs.length, 0, fs.n_nodes, fs.node)) return;
-            end = begin + fs.length;
-            emitted = true;
-        } else if ((uint32_t)cnt <= cfg.max_num_seeds_per_locus) {
-            int32_t sl = w.msl[i];
-            for (int32_t a = 0; a < cnt; ++a)
-                if (!push_seed(w, s, i, sl, k - sl, 1, w.alt[w.pos_start[i] + a])) return;
-            end = begin + sl;
-            emitted = true;
+    if (MANY) {
+        for (int32_t base = 0; base < n_base; base += WAVE) {
+            FOR_LANES(l) { const int32_t b = base + l; if (b < n_base) tmp[b] = w.seeds[s][b]; }
         }
-        if (emitted) {
-            if (begin < last_end) num_matching += end - begin - (last_end - begin);
-            else num_matching += end - begin;
-            last_end = end;
+        wave_sync();
+        // One slot per lane: what it emits (its full seed, or its sub-k seeds if they are at most max_num_seeds_per_locus), where
+        // (prefix sums over the slots in position order), and — for num_matching, whose update looks at the END of the slot
+        // emitted before (:343-350) — the ends of the emitted slots in order (in rfirst[], dead by now).
+        int32_t n_out = 0, n_emit = 0;
+        const int32_t max_seeds = (int32_t)MGX_PARAMS_OF(w).lim.max_seeds;
+        uint32_t *ends = w.rfirst;
+        for (int32_t base = 0; base < nslots; base += WAVE) {
+            const uint64_t word = w.bm[3][base >> 6] >> (base & 63);     // (WAVE divides 64: a chunk never straddles two words)
+            if (!(WAVE == 64 ? word : (word & ((1ull << (WAVE & 63)) - 1)))) continue;
+            LV<int32_t> ns, em, bg, en;
+            LV<bool> fullv;
+            FOR_LANES(l) {
+                const int32_t i = base + l;
+                int32_t cnt = (i < nslots && ((word >> l) & 1)) ? (int32_t)w.pos_cnt[i] : 0;
+                const bool full = cnt && w.pos_full[i];
+                int32_t end = 0, nseed = 0;
+                if (full) { const DevSeed fs = tmp[w.pos_start[i]]; end = i + (int32_t)fs.length; nseed = 1; }
+                else if (cnt && (uint32_t)cnt <= cfg.max_num_seeds_per_locus) { end = i + (int32_t)w.msl[i]; nseed = cnt; }
+                ns[l] = nseed; em[l] = nseed ? 1 : 0; bg[l] = i; en[l] = end; fullv[l] = full;
+            }
+            const LV<int32_t> so = wave_prefix_sum_excl(ns), eo = wave_prefix_sum_excl(em);
+            const int32_t tot = wave_sum(ns), tot_e = wave_sum(em);
+            if (n_out + tot > max_seeds) { w.status = ST_CAPACITY; return; }
+            FOR_LANES(l) {
+                if (ns[l]) {
+                    const int32_t i = bg[l];
+                    ends[n_emit + eo[l]] = (uint32_t)en[l];
+                    DevSeed *dst = w.seeds[s] + n_out + so[l];
+                    if (fullv[l]) {
+                        dst[0] = tmp[w.pos_start[i]];
+                        w.alive[s][n_out + so[l]] = 1;
+                    } else {
+                        const int32_t sl = (int32_t)w.msl[i];
+                        for (int32_t a2 = 0; a2 < ns[l]; ++a2) {
+                            DevSeed sd;
+                            sd.clipping = (uint16_t)i; sd.length = (uint16_t)sl; sd.offset = (uint16_t)(k - sl); sd.n_nodes = 1;
+                            sd.node = w.alt[w.pos_start[i] + a2];
+                            dst[a2] = sd;
+                            w.alive[s][n_out + so[l] + a2] = 1;
+                        }
+                    }
+                }
+            }
+            wave_sync();
+            LV<int32_t> contrib;
+            FOR_LANES(l) {
+                int32_t c = 0;
+                if (ns[l]) {
+                    const int32_t e_idx = n_emit + eo[l];
+                    const int32_t last_end = e_idx ? (int32_t)ends[e_idx - 1] : 0;
+                    c = bg[l] < last_end ? en[l] - last_end : en[l] - bg[l];
+                }
+                contrib[l] = c;
+            }
+            num_matching += (uint32_t)wave_sum(contrib);
+            n_out += tot; n_emit += tot_e;
+        }
+        w.n_seeds[s] = n_out;
+    } else {
+        for (int32_t b = 0; b < n_base; ++b) tmp[b] = w.seeds[s][b];
+        w.n_seeds[s] = 0;
+        int32_t last_end = 0;
+        // slots that can hold seeds: positions of base seeds and of lookup hits (pos_cnt is only ever raised there)
+        for (int32_t i = bits_next(w.bm[3], nslots, 0, true); i < nslots; i = bits_next(w.bm[3], nslots, i + 1, true)) {
+            int32_t cnt = w.pos_cnt[i];
+            if (!cnt) continue;
+            bool full = w.pos_full[i];
+            bool emitted = false;
+            int32_t begin = i, end = 0;
+            if (full) {
+                DevSeed fs = tmp[w.pos_start[i]];
+                if (!push_seed(w, s, fs.clipping, fs.length, 0, fs.n_nodes, fs.node)) return;
+                end = begin + fs.length;
+                emitted = true;
+            } else if ((uint32_t)cnt <= cfg.max_num_seeds_per_locus) {
+                int32_t sl = w.msl[i];
+                for (int32_t a = 0; a < cnt; ++a)
+                    if (!push_seed(w, s, i, sl, k - sl, 1, w.alt[w.pos_start[i] + a])) return;
+                end = begin + sl;
+                emitted = true;
+            }
+            if (emitted) {
+                if (begin < last_end) num_matching += end - begin - (last_end - begin);
+                else num_matching += end - begin;
+                last_end = end;
+            }
         }
     }
     w.num_matching[s] = num_matching;
@@ -4572,10 +4701,11 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         // build_seeders (:193-248)
         const uint64_t tseed = cycle_clock();
         if constexpr (PHASE & PH_SEED) {
-            make_seeder(w, 0);
+            const bool many = (uint32_t)P.g.k >= P.cfg.max_seed_length;
+            if (many) make_seeder<true>(w, 0); else make_seeder<false>(w, 0);
             if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[0]) { w.n_seeds[0] = 0; w.num_matching[0] = 0; }
             if (have_rc && w.status == ST_OK) {
-                make_seeder(w, 1);
+                if (many) make_seeder<true>(w, 1); else make_seeder<false>(w, 1);
                 if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[1]) { w.n_seeds[1] = 0; w.num_matching[1] = 0; }
             } else {
                 w.n_seeds[1] = 0; w.num_matching[1] = 0;
