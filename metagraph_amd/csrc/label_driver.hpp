@@ -40,21 +40,32 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
     if (!n) return;
     const int32_t k = (int32_t)P.g.k, L = w.L;
     const uint32_t W = (uint32_t)(L + 31) / 32;
-    // scratch: the backtracking's start-cell list (dead between extensions): 64 label slots, the seeds' head words, the bitmaps
+    // scratch: the backtracking's start-cell list (dead between extensions)
     uint32_t *scr = (uint32_t *)w.indices;
     const uint64_t cap_words = (uint64_t)P.lim.max_columns * 2 * (sizeof(BtIndex) / 4);
-    const uint64_t heads_words = 2ull * (uint64_t)n;
-    if (cap_words < 64 + heads_words + (uint64_t)W) { w.status = ST_CAPACITY; return; }
-    const uint32_t max_l = (uint32_t)imin<uint64_t>(64, (cap_words - 64 - heads_words) / W);
-    uint32_t *mlab = scr;
-    uint64_t *heads = (uint64_t *)(scr + 64);
-    uint32_t *bits = scr + 64 + heads_words;
-    // the rows of the seeds' first nodes, one seed per lane ("skip dummy nodes": W == 0 has no labels)
+    const uint32_t nrw = 2 * (((uint32_t)n + 63) / 64);
+    const uint64_t fixed_words = 64 + 2ull * n + n + (n & 1) + nrw + n + n;
+    if (cap_words < fixed_words + (uint64_t)W) { w.status = ST_CAPACITY; return; }
+    const uint32_t max_l = (uint32_t)imin<uint64_t>(64, (cap_words - fixed_words) / W);
+    uint32_t *mlab = scr;                                    // labels seen on the seeds' first nodes (VectorMap order)
+    uint64_t *heads = (uint64_t *)(scr + 64);                // per seed: the head word of its first node's row (0: no labels)
+    uint32_t *span = scr + 64 + 2 * n;                       // per seed: first k-mer's query range, lo | hi << 16
+    uint64_t *rs = (uint64_t *)(span + n + (n & 1));         // bit i: seed i starts a run (below)
+    uint32_t *sh = (uint32_t *)rs + nrw;                     // per run start: the run's label set
+    uint32_t *ends = sh + n;                                 // per kept seed: its query end (num_matching)
+    uint32_t *bits = ends + n;                               // per label: covered query positions
+    // Pass 1, one seed per lane: the row of its first node ("skip dummy nodes": W == 0 has no labels) and whether it CONTINUES
+    // the run of the seed before — both rows are the same single label and its range touches and extends the other's — so that
+    // the sequential parts below run per run of seeds, not per seed (a read's ~120 one-k-mer seeds are a handful of runs)
+    for (uint32_t x = 0; x < nrw / 2; ++x) rs[x] = 0;
     LV<int32_t> lines;
     FOR_LANES(l) { lines[l] = 0; }
+    int32_t c_lbl = -1, c_lo = 0, c_hi = 0, c_simple = 0;       // the last seed of the chunk before
     for (int32_t base = 0; base < n; base += WAVE) {
+        LV<int32_t> lbl, lo, hi, simple;
         FOR_LANES(l) {
             const int32_t i = base + l;
+            lbl[l] = -1; lo[l] = 0; hi[l] = 0; simple[l] = 0;
             if (i < n) {
                 const DevSeed sd = w.seeds[s][i];
                 const uint32_t node0 = lab_base_node(P, sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node);
@@ -68,50 +79,57 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
                     }
                     if (real) h = gld(P.anno_head + ((uint64_t)node0 - 1));
                 }
+                lo[l] = (int32_t)sd.clipping; hi[l] = imin((int32_t)sd.clipping + k - (int32_t)sd.offset, L);
+                simple[l] = (h & 0xFFFF) == 1 ? 1 : 0;
+                lbl[l] = simple[l] ? (int32_t)(uint32_t)(h >> 16) : -1;
                 gst(heads + i, h);
+                gst(span + i, (uint32_t)lo[l] | ((uint32_t)hi[l] << 16));
             }
         }
+        const LV<int32_t> p_lbl = wave_shift_up1(lbl, c_lbl), p_lo = wave_shift_up1(lo, c_lo), p_hi = wave_shift_up1(hi, c_hi),
+                          p_simple = wave_shift_up1(simple, c_simple);
+        LV<bool> st;
+        FOR_LANES(l) {
+            const int32_t i = base + l;
+            const bool cont = i > 0 && simple[l] && p_simple[l] && lbl[l] == p_lbl[l] && lo[l] >= p_lo[l] && lo[l] <= p_hi[l] && hi[l] >= p_hi[l];
+            st[l] = i < n && !cont;
+        }
+        const uint64_t sb = wave_ballot(st);
+        FOR_LANES(l) { if (l == 0 && sb) rs[base >> 6] |= sb << (base & 63); }
+        c_lbl = wave_bcast(lbl, WAVE - 1); c_lo = wave_bcast(lo, WAVE - 1); c_hi = wave_bcast(hi, WAVE - 1); c_simple = wave_bcast(simple, WAVE - 1);
+        wave_sync();
     }
     w.ctr.rank_lines += (uint32_t)wave_sum(lines);
     wave_sync();
+    // Pass 2, per run: its labels' position bitmaps (label_mapper / indicator, :620-640)
     uint32_t nl = 0;
-    // the run being collected: label slot t, positions [run_lo, run_hi)
-    int32_t run_t = -1, run_lo = 0, run_hi = 0;
-    auto flush_run = [&]() {
-        if (run_t < 0 || run_hi <= run_lo) return;
-        uint32_t *bw = bits + (uint32_t)run_t * W;
-        for (int32_t wd = run_lo >> 5; wd <= (run_hi - 1) >> 5; ++wd) {
-            const int32_t a = imax(run_lo, wd << 5) & 31, b = imin(run_hi, (wd + 1) << 5) - (wd << 5);      // bits [a, b) of word wd
-            const uint32_t mask = (b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1u)) & ~((1u << a) - 1u);
-            bw[wd] |= mask;
-        }
-    };
-    for (int32_t i = 0; i < n; ++i) {
+    for (int32_t i = bits_next(rs, n, 0, true); i < n; ) {
+        const int32_t j = bits_next(rs, n, i + 1, true);             // the next run's start (n: none)
         const uint64_t h = heads[i];
-        if (!(h & 0xFFFF)) continue;
-        const DevSeed sd = w.seeds[s][i];
-        const uint32_t node0 = lab_base_node(P, sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node);
-        const int32_t lo = sd.clipping, hi = imin((int32_t)sd.clipping + k - (int32_t)sd.offset, L);
-        const LabRow r = lab_row_of_head(P, h, (uint64_t)node0 - 1);
-        for (uint32_t x = 0; x < r.n; ++x) {
-            const uint32_t lbl = row_at(r, x);
-            if (run_t >= 0 && mlab[run_t] == lbl && lo <= run_hi && hi >= run_lo) {      // touches the run: grow it
-                run_lo = imin(run_lo, lo); run_hi = imax(run_hi, hi);
-                continue;
+        if (h & 0xFFFF) {
+            const DevSeed sd = w.seeds[s][i];
+            const uint32_t node0 = lab_base_node(P, sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node);
+            const LabRow r = lab_row_of_head(P, h, (uint64_t)node0 - 1);
+            const int32_t lo = (int32_t)(span[i] & 0xFFFF), hi = (int32_t)(span[j - 1] >> 16);     // (a run of several seeds: single-label rows, ranges nested in order)
+            for (uint32_t x = 0; x < r.n; ++x) {
+                const uint32_t lbl = row_at(r, x);
+                uint32_t t = 0;
+                while (t < nl && mlab[t] != lbl) ++t;
+                if (t == nl) {
+                    if (nl == max_l) { w.status = ST_CAPACITY; return; }
+                    mlab[nl] = lbl;
+                    for (uint32_t y = 0; y < W; ++y) bits[nl * W + y] = 0;
+                    ++nl;
+                }
+                uint32_t *bw = bits + t * W;
+                for (int32_t wd = lo >> 5; hi > lo && wd <= (hi - 1) >> 5; ++wd) {
+                    const int32_t a0 = imax(lo, wd << 5) & 31, b0 = imin(hi, (wd + 1) << 5) - (wd << 5);      // bits [a0, b0) of word wd
+                    bw[wd] |= (b0 >= 32 ? 0xFFFFFFFFu : ((1u << b0) - 1u)) & ~((1u << a0) - 1u);
+                }
             }
-            flush_run();
-            uint32_t t = 0;
-            while (t < nl && mlab[t] != lbl) ++t;
-            if (t == nl) {
-                if (nl == max_l) { w.status = ST_CAPACITY; return; }
-                mlab[nl] = lbl;
-                for (uint32_t y = 0; y < W; ++y) bits[nl * W + y] = 0;
-                ++nl;
-            }
-            run_t = (int32_t)t; run_lo = lo; run_hi = hi;
         }
+        i = j;
     }
-    flush_run();
     if (!nl) { w.n_seeds[s] = 0; w.num_matching[s] = 0; return; }
     // labels at or above the cut-off, ascending (only the SET is used afterwards)
     const double cutoff = P.cfg.min_exact_match * (double)L;
@@ -131,47 +149,82 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
     for (uint32_t t = 0; t < nk; ++t) lab_push(w, cntk, mlab[t]);
     const uint32_t hk = lab_end(w, cntk);
     if (w.status != ST_OK) return;
+    // Pass 3, per run: the label set its seeds keep (first node's labels & the labels left, :700-712)
     uint32_t hk_kept = 0;                                    // the whole set, kept for the read (made once)
-    // (a seed whose row is one label: its set is {that label} or nothing — the same handle for every seed with that label)
-    uint32_t one_lbl = 0xFFFFFFFFu, one_h = 0;
-    int32_t m = 0;
-    for (int32_t i = 0; i < n; ++i) {
+    uint32_t one_lbl = 0xFFFFFFFFu, one_h = 0;               // (runs with the same single label share their set)
+    for (int32_t i = bits_next(rs, n, 0, true); i < n; i = bits_next(rs, n, i + 1, true)) {
         const uint64_t hd = heads[i];
-        if (!(hd & 0xFFFF)) continue;
-        const DevSeed sd = w.seeds[s][i];
-        uint32_t h;
-        if ((hd & 0xFFFF) == 1 && (uint32_t)(hd >> 16) == one_lbl) {
-            h = one_h;
-        } else {
-            const uint32_t node0 = lab_base_node(P, sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node);
-            const LabRow r = lab_row_of_head(P, hd, (uint64_t)node0 - 1);
-            h = lab_isect_row(w, hk, r);
-            if (w.status != ST_OK) return;
-            if (h) {
-                if (h == hk) { if (!hk_kept) hk_kept = lab_persist(w, hk); h = hk_kept; }
-                else h = lab_persist(w, h);
+        uint32_t h = 0;
+        if (hd & 0xFFFF) {
+            if ((hd & 0xFFFF) == 1 && (uint32_t)(hd >> 16) == one_lbl) {
+                h = one_h;
+            } else {
+                const DevSeed sd = w.seeds[s][i];
+                const uint32_t node0 = lab_base_node(P, sd.offset == 0 ? w.nodes[s][sd.clipping] : sd.node);
+                const LabRow r = lab_row_of_head(P, hd, (uint64_t)node0 - 1);
+                h = lab_isect_row(w, hk, r);
                 if (w.status != ST_OK) return;
+                if (h) {
+                    if (h == hk) { if (!hk_kept) hk_kept = lab_persist(w, hk); h = hk_kept; }
+                    else h = lab_persist(w, h);
+                    if (w.status != ST_OK) return;
+                }
+                if ((hd & 0xFFFF) == 1) { one_lbl = (uint32_t)(hd >> 16); one_h = h; }
             }
-            if ((hd & 0xFFFF) == 1) { one_lbl = (uint32_t)(hd >> 16); one_h = h; }
         }
-        if (!h) continue;
-        w.seeds[s][m] = sd; w.seed_lab[s][m] = h; w.alive[s][m] = 1;
-        ++m;
+        sh[i] = h;
+    }
+    wave_sync();
+    // Pass 4, one seed per lane: seeds without labels go (:714-716), the others move up; num_matching of what is left
+    // (get_num_char_matches_in_seeds, alignment.hpp:100-127, incl. its quirk: nothing after the first sub-k seed is counted)
+    int32_t m = 0, first_off = INT32_MAX;
+    uint32_t num_matching = 0;
+    for (int32_t base = 0; base < n; base += WAVE) {
+        LV<int32_t> keep, qb, qe, offp;
+        LV<uint32_t> hset;
+        LV<DevSeed> sdv;
+        FOR_LANES(l) {
+            const int32_t i = base + l;
+            keep[l] = 0; qb[l] = 0; qe[l] = 0; offp[l] = INT32_MAX; hset[l] = 0;
+            if (i < n) {
+                // the run seed i belongs to: the last start at or before i
+                int32_t wd = i >> 6;
+                uint64_t bw = rs[wd] & (~0ull >> (63 - (i & 63)));
+                while (!bw) bw = rs[--wd];
+                const int32_t st = (wd << 6) + 63 - clz64(bw);
+                const uint32_t h = sh[st];
+                sdv[l] = w.seeds[s][i];
+                if (h) { keep[l] = 1; hset[l] = h; qb[l] = (int32_t)sdv[l].clipping; qe[l] = qb[l] + (int32_t)sdv[l].length; }
+            }
+        }
+        wave_sync();
+        const LV<int32_t> po = wave_prefix_sum_excl(keep);
+        const int32_t tot = wave_sum(keep);
+        FOR_LANES(l) {
+            if (keep[l]) {
+                const int32_t pos = m + po[l];
+                w.seeds[s][pos] = sdv[l]; w.seed_lab[s][pos] = hset[l]; w.alive[s][pos] = 1;
+                ends[pos] = (uint32_t)qe[l];
+                if (sdv[l].offset) offp[l] = pos;
+            }
+        }
+        wave_sync();
+        const int32_t lim_pos = imin(first_off, wave_min(offp));      // seeds up to the first sub-k seed count
+        LV<int32_t> contrib;
+        FOR_LANES(l) {
+            int32_t c = 0;
+            const int32_t pos = m + po[l];
+            if (keep[l] && pos <= lim_pos) {
+                const int32_t last_q_end = pos ? (int32_t)ends[pos - 1] : 0;
+                if (qe[l] > last_q_end) c = (qe[l] - qb[l]) - (qb[l] < last_q_end ? last_q_end - qb[l] : 0);
+            }
+            contrib[l] = c;
+        }
+        num_matching += (uint32_t)wave_sum(contrib);
+        first_off = lim_pos;
+        m += tot;
     }
     w.n_seeds[s] = m;
-    // get_num_char_matches_in_seeds (alignment.hpp:100-127) incl. its quirk: nothing after the first sub-k seed is counted
-    uint32_t num_matching = 0;
-    int32_t last_q_end = 0;
-    for (int32_t i = 0; i < m; ++i) {
-        const DevSeed sd = w.seeds[s][i];
-        const int32_t q_begin = sd.clipping, q_end = q_begin + (int32_t)sd.length;
-        if (q_end > last_q_end) {
-            num_matching += (uint32_t)(q_end - q_begin);
-            if (q_begin < last_q_end) num_matching -= (uint32_t)(last_q_end - q_begin);
-        }
-        if (sd.offset) i = m - 1;
-        last_q_end = q_end;
-    }
     w.num_matching[s] = num_matching;
     wave_sync();
 }

@@ -205,6 +205,9 @@ MGX_DEV void lab_flush(Wave &w, int32_t tsize) {
     }
     w.ctr.rank_lines += (uint32_t)wave_sum(lines);
     wave_sync();
+    // (along a path the same (parent's set, row) pair repeats column after column: its intersection is computed once)
+    uint32_t memo_ph = 0, memo_nh = 0;
+    uint64_t memo_hd = ~0ull;
     for (; w.last_flushed < tsize; ++w.last_flushed) {
         const int32_t i = w.last_flushed;
         const uint64_t hd = scr[2 * (i - first)], np = scr[2 * (i - first) + 1];
@@ -213,6 +216,10 @@ MGX_DEV void lab_flush(Wave &w, int32_t tsize) {
         const uint32_t ph = w.col_lab[parent];
         if (!ph) { lab_clear_column(w, i); if (w.status != ST_OK) return; continue; }
         if (!node) continue;
+        if (ph == memo_ph && hd == memo_hd && memo_nh) {
+            w.col_lab[i] = memo_nh;
+            continue;
+        }
         LabRow r;
         uint32_t cn = (uint32_t)(hd & 0xFFFF);
         if (cn == 0xFFFF) cn = P.anno_count[(uint64_t)node - 1];
@@ -221,6 +228,7 @@ MGX_DEV void lab_flush(Wave &w, int32_t tsize) {
         if (w.status != ST_OK) return;
         if (!nh) { lab_clear_column(w, i); if (w.status != ST_OK) return; }
         else w.col_lab[i] = nh;
+        memo_ph = ph; memo_hd = hd; memo_nh = nh;
     }
 }
 
