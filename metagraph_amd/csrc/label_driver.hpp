@@ -363,6 +363,7 @@ MGX_DEV uint32_t lab_filter_seed(Wave &w, uint32_t prev_lab, uint32_t lab) {
 // the extender's convergence table are independent — one seed per lane — and the label bookkeeping of the rejected ones
 // follows, in order
 MGX_DEV void lab_check_later(Wave &w, const ExtenderState &F, int s, int32_t i, int32_t n) {
+    const uint32_t prev = w.seed_lab[s][i];
     for (int32_t base = i + 1; base < n; base += WAVE) {
         FOR_LANES(l) {
             const int32_t j = base + l;
@@ -370,19 +371,27 @@ MGX_DEV void lab_check_later(Wave &w, const ExtenderState &F, int s, int32_t i, 
                 const DevSeed sj = w.seeds[s][j];
                 const uint32_t last_node = sj.offset == 0 ? w.nodes[s][sj.clipping + sj.n_nodes - 1] : sj.node;
                 const SeedRef rj = seedref_from_seed(w, s, j, nullptr);
-                if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score)) w.alive[s][j] = 2;       // rejected: see below
+                // rejected: it keeps the labels seed i did not have — none if it holds the very set of seed i (the usual case:
+                // the read's seeds share one set); other sets are worked out below, in order
+                if (!check_seed(w, F, last_node, rj.qlen, rj.clipping, rj.score))
+                    w.alive[s][j] = (prev && w.seed_lab[s][j] == prev) ? 0 : 2;
             }
         }
     }
     wave_sync();
-    const uint32_t prev = w.seed_lab[s][i];
     uint32_t memo_in = 0xFFFFFFFFu, memo_out = 0;            // (runs of seeds share one label set)
-    for (int32_t j = i + 1; j < n; ++j) {
-        if (w.alive[s][j] != 2) continue;
-        const uint32_t cur = w.seed_lab[s][j];
-        if (cur != memo_in) { memo_out = lab_filter_seed(w, prev, cur); memo_in = cur; if (w.status != ST_OK) return; }
-        w.seed_lab[s][j] = memo_out;
-        w.alive[s][j] = memo_out ? 1 : 0;
+    for (int32_t base = i + 1; base < n; base += WAVE) {
+        LV<bool> todo;
+        FOR_LANES(l) { const int32_t j = base + l; todo[l] = j < n && w.alive[s][j] == 2; }
+        uint64_t tb = wave_ballot(todo);
+        while (tb) {
+            const int32_t j = base + ctz64(tb);
+            tb &= tb - 1;
+            const uint32_t cur = w.seed_lab[s][j];
+            if (cur != memo_in) { memo_out = lab_filter_seed(w, prev, cur); memo_in = cur; if (w.status != ST_OK) return; }
+            w.seed_lab[s][j] = memo_out;
+            w.alive[s][j] = memo_out ? 1 : 0;
+        }
     }
 }
 

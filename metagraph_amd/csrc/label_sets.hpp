@@ -184,11 +184,21 @@ MGX_DEV void lab_flush(Wave &w, int32_t tsize) {
     const int32_t first = w.last_flushed;
     if (first >= tsize) return;
     uint64_t *scr = (uint64_t *)w.indices;                   // per column: head word, node | parent << 32
+    // The usual outcome is "nothing changes": the columns since the last flush lie on one path whose nodes all carry the labels
+    // the path set out with.  Checked while gathering: every column still holds the set ph0 the first one inherited, so does its
+    // parent, and its row equals the first column's row, which loses no label of ph0 — then every intersection below would
+    // return ph0 again and the table order pass is skipped.
+    const ColMeta c0 = uni_col(col_load(w, first));
+    const uint32_t ph0 = w.col_lab[c0.parent];
     LV<int32_t> lines;
-    FOR_LANES(l) { lines[l] = 0; }
+    LV<bool> differs;
+    FOR_LANES(l) { lines[l] = 0; differs[l] = false; }
+    uint64_t hd0 = 0;
     for (int32_t base = first; base < tsize; base += WAVE) {
+        LV<uint64_t> hv;
         FOR_LANES(l) {
             const int32_t i = base + l;
+            hv[l] = 0;
             if (i < tsize) {
                 const ColMeta c = col_load(w, i);
                 const uint32_t bn = lab_base_node(P, c.node);
@@ -200,11 +210,26 @@ MGX_DEV void lab_flush(Wave &w, int32_t tsize) {
                 }
                 gst(scr + 2 * (i - first), h);
                 gst(scr + 2 * (i - first) + 1, (uint64_t)bn | ((uint64_t)(uint32_t)c.parent << 32));
+                hv[l] = h;
+                if (!bn || gld(w.col_lab + i) != ph0 || gld(w.col_lab + c.parent) != ph0) differs[l] = true;
             }
         }
+        if (base == first) hd0 = wave_bcast(hv, 0);
+        FOR_LANES(l) { if (base + l < tsize && hv[l] != hd0) differs[l] = true; }
     }
     w.ctr.rank_lines += (uint32_t)wave_sum(lines);
     wave_sync();
+    if (ph0 && (hd0 & 0xFFFF) && !wave_ballot(differs)) {
+        LabRow r0;
+        uint32_t cn0 = (uint32_t)(hd0 & 0xFFFF);
+        if (cn0 == 0xFFFF) cn0 = P.anno_count[(uint64_t)lab_base_node(P, c0.node) - 1];
+        r0.n = cn0; r0.one = (uint32_t)(hd0 >> 16); r0.more = cn0 >= 2 ? P.anno_more + (hd0 >> 16) : nullptr;
+        const uint32_t lo_before = w.lab_lo;
+        const uint32_t nh0 = lab_isect_row(w, ph0, r0);
+        if (w.status != ST_OK) return;
+        if (nh0 == ph0) { w.last_flushed = tsize; return; }
+        w.lab_lo = lo_before;                                // (a strict subset: the pass below makes it again, once)
+    }
     // (along a path the same (parent's set, row) pair repeats column after column: its intersection is computed once)
     uint32_t memo_ph = 0, memo_nh = 0;
     uint64_t memo_hd = ~0ull;
