@@ -1429,6 +1429,8 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     // label ends with q[i..L) for every such i, so index_range matches all L - i characters.  The length is all
     // the replacement rules need for dominated positions; the range is fetched only if a position reports.
     // (PRIMARY graphs: only if the last k-mer was found in the base graph itself, not as a reverse complement)
+    uint32_t *pre = (uint32_t *)w.cells;             // per position: parents of a single matched node (the extension's cell arena is idle)
+    const bool pre_fits = (uint64_t)5 * (uint64_t)nslots <= MGX_PARAMS_OF(w).lim.cell_words;
     const bool tail_known = w.n_kmers > 0 && w.nodes[s][w.n_kmers - 1] != 0 && !w.inv_any[s]
                             && !(kWithPrimary && cfg.canonical >= 2 && w.nodes[s][w.n_kmers - 1] > g.n);
     // lane-parallel longest-prefix lookups for every position that can report a seed
@@ -1474,7 +1476,17 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                     }
                     if (m >= msl0 && first && first <= g.n) {
                         mlen = (uint16_t)m;
-                        if (first == last) { rf = SINGLE_NODE; rl_ = (uint32_t)first; }
+                        if (first == last) {
+                            rf = SINGLE_NODE; rl_ = (uint32_t)first;
+                            // the parents of that node (what the position contributes if it reports, below), fetched here,
+                            // one position per lane, instead of one reporting position after the other: most of these never
+                            // report — a longer match to their left covers them — but a dependent chain of three or four lines
+                            // per reporting position was 30 % of this kernel
+                            if (pre_fits) {
+                                const int np = incoming_nodes32(g, first, pre + 5 * i + 1, 4, lc);
+                                gst(pre + 5 * i, (uint32_t)np);
+                            }
+                        }
                         else { rf = rank_last(g, first, lc); rl_ = rank_last(g, last, lc); }
                     }
                 }
@@ -1511,7 +1523,9 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
 #else
         if (cfg.seed_complexity_filter && window_low_complexity(w, s, i, cur_msl)) continue;
 #endif
+        bool fresh_range = false;
         if (w.rfirst[i] == DEFERRED_RANGE) {
+            fresh_range = true;
             // deferred tail lookup: this position does report, so its node range is needed after all
             uint64_t first, last;
             LineCtr lc = { 0, 0, 0 };
@@ -1533,6 +1547,13 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         uint32_t cnt = 0;
         const bool one_node = w.rfirst[i] == SINGLE_NODE;
         const uint32_t r_begin = one_node ? 0u : w.rfirst[i], r_end = one_node ? 0u : w.rlast[i];
+        const uint32_t np = (one_node && !fresh_range && pre_fits) ? pre[5 * i] : 0xFFFFFFFFu;
+        if (np <= 4u) {
+            // (fetched with the lookups above)
+            if (alt_n + np > MGX_PARAMS_OF(w).lim.max_alt) { w.status = ST_CAPACITY; return; }
+            for (uint32_t t = 0; t < np; ++t) w.alt[alt_n++] = pre[5 * i + 1 + t];
+            cnt = np;
+        } else
         for (uint32_t r = r_begin; r <= r_end; ++r) {
             uint64_t e = one_node ? (uint64_t)w.rlast[i] : select_last<true>(g, r, w.ctr);
             uint64_t inc[5];

@@ -399,6 +399,37 @@ MGX_DEV int incoming(const DevGraph &g, uint64_t v, uint64_t *nodes, uint32_t *f
     return n;
 }
 
+// the same parents, written as 32-bit ids to out[0 .. cap) (memory of the caller's choosing); returns their number, which may
+// exceed cap (then only the first cap were written)
+MGX_DEV int incoming_nodes32(const DevGraph &g, uint64_t v, uint32_t *out, int cap, LineCtr &ctr) {
+    const uint64_t x = bwd(g, v, ctr);
+    const uint32_t d = node_last_value(g, v);
+    int n = 0;
+    if (in_graph(g, x)) { if (n < cap) gst(out + n, (uint32_t)x); ++n; }
+    uint64_t pos = x + 1;
+    uint32_t bi = (uint32_t)(pos >> 6);
+    while (pos <= g.n) {
+        ++ctr.rank_lines;
+        const Block b = load_block(g, bi);
+        const uint64_t from = ~(mask_upto((int)(pos & 63)) >> 1);
+        uint64_t cm = code_mask(b, d) & from;
+        if (bi == g.n_blocks - 1 && ((g.n + 1) & 63)) cm &= mask_upto((int)(g.n & 63));
+        const uint64_t stop = cm & ~b.pf;
+        uint64_t flg = cm & b.pf;
+        if (stop) flg &= mask_upto(ctz64(stop));
+        while (flg) {
+            const int j = ctz64(flg);
+            flg &= flg - 1;
+            const uint64_t e = ((uint64_t)bi << 6) + (uint32_t)j;
+            if (in_graph(g, e)) { if (n < cap) gst(out + n, (uint32_t)e); ++n; }
+        }
+        if (stop) break;
+        ++bi;
+        pos = (uint64_t)bi << 6;
+    }
+    return n;
+}
+
 // has_multiple_outgoing (dbg_succinct.cpp:609-624)
 MGX_DEV bool has_multiple_outgoing(const DevGraph &g, uint64_t v, LineCtr &ctr) {
     if (v == 1) return succ_last(g, 1, ctr) > 2;
