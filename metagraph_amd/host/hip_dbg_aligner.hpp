@@ -61,6 +61,8 @@ class Alignment {
     const Cigar &get_cigar() const { return cigar_; }
     uint32_t get_clipping() const { return cigar_.get_clipping(); }
     uint32_t get_end_clipping() const { return cigar_.get_end_clipping(); }
+    // Alignment::label_columns (alignment.hpp:285): the labels of a label-aware aligner's alignment, ascending; else empty
+    const std::vector<uint64_t> &get_label_columns() const { return label_columns_; }
     // fmt formatter of the reference (alignment.hpp:426-433)
     std::string to_tsv_fields() const {
         return std::string(orientation_ ? "-" : "+") + "\t" + sequence_ + "\t" + std::to_string(score_) + "\t"
@@ -75,6 +77,7 @@ class Alignment {
     std::string sequence_;
     int32_t score_ = 0;
     Cigar cigar_;
+    std::vector<uint64_t> label_columns_;
 };
 
 class AlignmentResults {
@@ -168,12 +171,37 @@ class IDBGAligner {
     virtual bool has_coordinates() const = 0;
 };
 
+// The annotator argument of LabeledAligner<> (aligner_labeled.hpp:125-127): the label matrix on the graph's device, from the
+// set rows of every column (what a ColumnCompressed annotation stores; row = AnnotatedDBG::graph_to_anno_index(node) = node - 1)
+class HipAnnotation {
+  public:
+    HipAnnotation(uint64_t n_rows, const std::vector<uint64_t> &col_begin, const std::vector<uint64_t> &rows, int device = 0) {
+        if (col_begin.empty()) throw std::runtime_error("HipAnnotation: col_begin needs n_labels + 1 entries");
+        if (int rc = mgx_annotation_create_sparse(n_rows, (uint32_t)(col_begin.size() - 1), col_begin.data(), rows.data(), 0, device, &a_))
+            throw std::runtime_error(std::string("mgx_annotation_create_sparse: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
+    }
+    ~HipAnnotation() { mgx_annotation_destroy(a_); }
+    HipAnnotation(const HipAnnotation &) = delete;
+    uint32_t num_labels() const { return mgx_annotation_num_labels(a_); }
+    mgx_annotation *handle() const { return a_; }
+  private:
+    mgx_annotation *a_ = nullptr;
+};
+
 class HipDBGAligner : public IDBGAligner {
   public:
     // throws std::runtime_error like the reference when check_config_scores() fails (dbg_aligner.cpp:55-56)
     HipDBGAligner(const HipBOSSGraph &graph, const DBGAlignerConfig &config, const mgx_limits *limits = nullptr)
           : graph_(graph) {
         if (int rc = mgx_aligner_create(graph.handle(), &config, limits, &a_))
+            throw std::runtime_error(std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")");
+        mgx_aligner_get_config(a_, &config_);
+    }
+    // LabeledAligner<>(graph, config, annotator): every alignment of the results carries its label_columns
+    HipDBGAligner(const HipBOSSGraph &graph, const DBGAlignerConfig &config, const HipAnnotation &annotation,
+                  const mgx_limits *limits = nullptr)
+          : graph_(graph), annotation_(&annotation) {
+        if (int rc = mgx_labeled_aligner_create(graph.handle(), &config, limits, annotation.handle(), &a_))
             throw std::runtime_error(std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")");
         mgx_aligner_get_config(a_, &config_);
     }
@@ -219,6 +247,8 @@ class HipDBGAligner : public IDBGAligner {
                         a.cigar_.data().emplace_back(res.cigar[m.cigar_begin + x].op, res.cigar[m.cigar_begin + x].len);
                     const std::string &q = paths.get_query(m.orientation);
                     a.query_view_ = std::string_view(q).substr(m.clipping, q.size() - m.clipping - m.end_clipping);
+                    if (res.labels && m.n_labels)
+                        a.label_columns_.assign(res.labels + m.labels_begin, res.labels + m.labels_begin + m.n_labels);
                     paths.alignments_.push_back(std::move(a));
                 }
             }
@@ -232,7 +262,8 @@ class HipDBGAligner : public IDBGAligner {
             lim.max_seeds = std::min<uint32_t>(65535u, lim.max_seeds * 2);
             lim.cell_arena_bytes = lim.cell_arena_bytes * 2;
             mgx_aligner *next = nullptr;
-            if (int rc = mgx_aligner_create(graph_.handle(), &config_, &lim, &next))
+            if (int rc = annotation_ ? mgx_labeled_aligner_create(graph_.handle(), &config_, &lim, annotation_->handle(), &next)
+                                     : mgx_aligner_create(graph_.handle(), &config_, &lim, &next))
                 throw std::runtime_error(std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")");
             if (tmp) mgx_aligner_destroy(tmp);
             tmp = next;
@@ -244,17 +275,30 @@ class HipDBGAligner : public IDBGAligner {
 
   private:
     const HipBOSSGraph &graph_;
+    const HipAnnotation *annotation_ = nullptr;
     DBGAlignerConfig config_;
     mgx_aligner *a_ = nullptr;
 };
 
-// format_alignment (cli/align.cpp:254-285), TSV branch
-inline std::string format_alignment(const std::string &header, const AlignmentResults &paths, int32_t min_path_score) {
+// format_alignment (cli/align.cpp:254-285), TSV branch; label_names: LabelEncoder::decode for label-aware results (:274-281)
+inline std::string format_alignment(const std::string &header, const AlignmentResults &paths, int32_t min_path_score,
+                                    const std::vector<std::string> *label_names = nullptr) {
     std::string s = header + "\t" + paths.get_query();
     if (paths.empty()) {
         s += "\t*\t*\t" + std::to_string(min_path_score) + "\t*\t*\t*\n";
     } else {
-        for (const auto &p : paths) s += "\t" + p.to_tsv_fields();
+        for (const auto &p : paths) {
+            s += "\t" + p.to_tsv_fields();
+            if (p.get_label_columns().size()) {
+                s += "\t";
+                bool first = true;
+                for (uint64_t c : p.get_label_columns()) {
+                    if (!first) s += ";";
+                    first = false;
+                    s += (label_names && c < label_names->size()) ? (*label_names)[c] : std::to_string(c);
+                }
+            }
+        }
         s += "\n";
     }
     return s;

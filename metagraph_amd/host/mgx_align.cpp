@@ -4,12 +4,16 @@
 //   mgx_align GRAPH.boss READS.{fa,fq} [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]
 //             [-p THREADS] [--query-batch-size BASES] [--canonical | --primary (the dump is a CANONICAL- / PRIMARY-mode graph)]
 //             [--devices D]   in-process multi-GPU: one graph replica per device, whole batches routed round-robin, no collective
+//             [-a ANNOTATION.cols]  label-aware alignment (metagraph align -a: LabeledAligner): a dump of the annotation's columns —
+//                                   u64 n_rows, u64 n_labels, then per label: u64 name length, the name, u64 count, count x u64 rows
+//                                   (row = node - 1); every alignment is printed with its labels' names (cli/align.cpp:274-281)
 //                             (the reference's unit of parallelism, cli/align.cpp:440-475: one task per batch)
 #include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -72,6 +76,7 @@ int main(int argc, char **argv) {
     bool have_lim = false;
     uint32_t graph_mode = MGX_MODE_BASIC;
     int devices = 1;
+    const char *anno_path = nullptr;
     mgx_limits_init_default(&lim, 0);
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--align-only-forwards")) cfg.forward_and_reverse_complement = 0;
@@ -81,6 +86,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--query-batch-size") && i + 1 < argc) batch_size = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--max-columns") && i + 1 < argc) { lim.max_columns = (uint32_t)atoi(argv[++i]); have_lim = true; }
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, atoi(argv[++i]));
+        else if (!strcmp(argv[i], "-a") && i + 1 < argc) anno_path = argv[++i];
         else if (!strcmp(argv[i], "--canonical")) graph_mode = MGX_MODE_CANONICAL;
         else if (!strcmp(argv[i], "--primary")) graph_mode = MGX_MODE_PRIMARY;         // aligned through the CanonicalDBG wrapper
     }
@@ -92,6 +98,30 @@ int main(int argc, char **argv) {
             return 1;
         }
         HipGraphSet graphs(devices, k, n, W.data(), last.data(), hdr + 2, nullptr, graph_mode);
+        std::unique_ptr<HipAnnotation> annotation;
+        std::vector<std::string> label_names;
+        if (anno_path) {
+            if (devices != 1) { fprintf(stderr, "error: -a with --devices 1 only (one annotation replica)\n"); return 1; }
+            std::ifstream ain(anno_path, std::ios::binary);
+            if (!ain) { fprintf(stderr, "cannot open %s\n", anno_path); return 1; }
+            uint64_t n_rows = 0, n_labels = 0;
+            ain.read((char *)&n_rows, 8); ain.read((char *)&n_labels, 8);
+            std::vector<uint64_t> col_begin{ 0 }, rows;
+            for (uint64_t j = 0; j < n_labels && ain; ++j) {
+                uint64_t len = 0, cnt = 0;
+                ain.read((char *)&len, 8);
+                std::string name(len, '\0');
+                ain.read(name.data(), (std::streamsize)len);
+                ain.read((char *)&cnt, 8);
+                const size_t at = rows.size();
+                rows.resize(at + cnt);
+                ain.read((char *)(rows.data() + at), (std::streamsize)(cnt * 8));
+                col_begin.push_back(rows.size());
+                label_names.push_back(std::move(name));
+            }
+            if (!ain || col_begin.size() != n_labels + 1) { fprintf(stderr, "bad annotation dump %s\n", anno_path); return 1; }
+            annotation = std::make_unique<HipAnnotation>(n_rows, col_begin, rows, 0);
+        }
         if ((unsigned)devices > threads) threads = (unsigned)devices;                  // at least one worker per device
         std::vector<IDBGAligner::Query> all;
         if (!read_records(argv[2], &all)) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
@@ -112,9 +142,13 @@ int main(int argc, char **argv) {
                 for (;;) {
                     const size_t bi = next.fetch_add(1);
                     if (bi >= batches.size()) break;
-                    HipDBGAligner aligner(graph, cfg, have_lim ? &lim : nullptr);       // one aligner per task, shared graph
+                    // one aligner per task, shared graph (and annotation: LabeledAligner<>(graph, config, annotator))
+                    std::unique_ptr<HipDBGAligner> aligner_p(annotation
+                        ? new HipDBGAligner(graph, cfg, *annotation, have_lim ? &lim : nullptr)
+                        : new HipDBGAligner(graph, cfg, have_lim ? &lim : nullptr));
+                    HipDBGAligner &aligner = *aligner_p;
                     aligner.align_batch(batches[bi], [&](const std::string &header, AlignmentResults &&paths) {
-                        const std::string res = format_alignment(header, paths, cfg.min_path_score);
+                        const std::string res = format_alignment(header, paths, cfg.min_path_score, annotation ? &label_names : nullptr);
                         std::lock_guard<std::mutex> lock(print_mutex);
                         std::cout << res;
                     });

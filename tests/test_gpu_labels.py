@@ -155,3 +155,44 @@ def test_labeled_aligner_refuses_what_it_cannot_do():
     with pytest.raises(aligner.MgxError) as e:
         aligner.Aligner(gpu_graph(g0), cfg, annotation=gpu_annotation(orc.Annotation(g0, 1)))
     assert e.value.code == capi.MGX_ERR_UNSUPPORTED
+
+
+def test_mgx_align_driver_with_an_annotation(tmp_path):
+    """`metagraph align -a`: the C++ adapter's labeled constructor (HipDBGAligner(graph, config, annotation)) and the driver's
+    label column (format_alignment, cli/align.cpp:274-281) on the reference's SimpleTangleGraph"""
+    import os
+    import struct
+    import subprocess
+    case = CASES["SimpleTangleGraph"]
+    g, anno, cfg = build(case)
+    W, last, F, valid = g.export()
+    dump = tmp_path / "g.boss"
+    with open(dump, "wb") as f:
+        f.write(struct.pack("<7Q", g.k, g.n_edges, *[int(x) for x in F]))
+        f.write(W.tobytes())
+        f.write(last.tobytes())
+    cols = tmp_path / "g.cols"
+    with open(cols, "wb") as f:
+        f.write(struct.pack("<2Q", g.n_edges, len(case["labels"])))
+        for j, name in enumerate(case["labels"]):
+            words = anno.column_words(j)
+            rows = [r for r in range(g.n_edges) if (int(words[r >> 6]) >> (r & 63)) & 1]
+            f.write(struct.pack("<Q", len(name)) + name.encode() + struct.pack("<Q", len(rows)) + struct.pack("<%dQ" % len(rows), *rows))
+    query = "CGAATGCAT"
+    fa = tmp_path / "q.fa"
+    fa.write_text(">q1\n%s\n" % query)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "metagraph_amd", "_build", "mgx_align")
+    # (the unit test's scoring is not the CLI's: compare with the oracle run under the driver's configuration)
+    cli_cfg = capi.config_cli(g.k)
+    cli_cfg.min_exact_match = 0.0
+    r = subprocess.run([exe, str(dump), str(fa), "-a", str(cols), "--align-min-exact-match", "0.0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    o = orc.LabeledAlignRun(g, cli_cfg, anno, [query])
+    want = "q1\t" + query
+    for a, ls in zip(o.results()[0], o.labels()[0]):
+        want += "\t%s\t%s\t%d\t%d\t%s\t%d\t%s" % ("-" if a["orientation"] else "+", a["sequence"], a["score"], a["num_matches"],
+                                                a["cigar"], a["offset"], ";".join(case["labels"][l] for l in ls))
+    if not o.results()[0]:
+        want += "\t*\t*\t%d\t*\t*\t*" % cli_cfg.min_path_score
+    assert r.stdout == want + "\n"
+    assert o.results()[0], "the case should align"
