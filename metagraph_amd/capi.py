@@ -197,6 +197,7 @@ def lib():
     L.mgx_device_stream_capacity.argtypes = [C.c_void_p]
     L.mgx_device_stream_capacity.restype = C.c_uint64
     L.mgx_results_from_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(Results)]
+    L.mgx_results_from_raw_labeled.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(Results)]
     L.mgx_raw_store_free.argtypes = [C.c_void_p]
     L.mgx_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Mapping)]
     L.mgx_aligner_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]

@@ -142,7 +142,8 @@ class RawResults:
     """Host decode of one rank's raw records through the C-ABI (no GPU needed): keeps the native store alive and exposes
     the mgx_results view."""
 
-    def __init__(self, headers_u8, stream_u8):
+    def __init__(self, headers_u8, stream_u8, labeled=False):
+        """labeled: the records come from a label-aware aligner (every alignment is followed by its label list)"""
         L = capi.lib()
         h = np.ascontiguousarray(headers_u8, dtype=np.uint8)
         s = np.ascontiguousarray(stream_u8, dtype=np.uint8)
@@ -150,8 +151,8 @@ class RawResults:
         self._keep = (h, s)
         self.store = C.c_void_p()
         self.res = capi.Results()
-        rc = L.mgx_results_from_raw(h.ctypes.data, h.size // HEADER_BYTES, s.ctypes.data, s.size // 4,
-                                    C.byref(self.store), C.byref(self.res))
+        rc = L.mgx_results_from_raw_labeled(h.ctypes.data, h.size // HEADER_BYTES, s.ctypes.data, s.size // 4, 1 if labeled else 0,
+                                            C.byref(self.store), C.byref(self.res))
         if rc != 0:
             raise RuntimeError("mgx_results_from_raw: %s" % L.mgx_last_error().decode())
 

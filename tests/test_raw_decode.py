@@ -66,3 +66,23 @@ def test_header_pointing_past_the_stream_is_refused(raw_records):
             break
     with pytest.raises(RuntimeError):
         mg.RawResults(h2, s)
+
+
+def test_labeled_records_decode_with_their_label_lists():
+    """records of a label-aware aligner (every alignment followed by its label list in the stream) through
+    mgx_results_from_raw_labeled: the same alignments and labels as the run's own decode; a label count pointing past the
+    stream is refused"""
+    import orc
+    from labeled_worlds import labeled_world
+    g, anno, reads = labeled_world(3, 11, n_strains=3, n_reads=16)
+    run = emu_drv.EmuRun(emu_drv.EmuGraph(g), capi.config_cli(11), reads, annotation=emu_drv.EmuAnnotation(anno))
+    assert not run.error
+    hb, sb = run.raw()
+    h, s = np.frombuffer(hb, dtype=np.uint8).copy(), np.frombuffer(sb, dtype=np.uint8).copy()
+    raw = mg.RawResults(h, s, labeled=True)
+    got = capi.results_to_py(raw.res)
+    want, _ = run.results()
+    assert got == want and any("labels" in a and a["labels"] for q in got for a in q)
+    raw.close()
+    with pytest.raises(RuntimeError):
+        mg.RawResults(h, s[: s.size - 4], labeled=True)          # the last alignment's labels are cut off
