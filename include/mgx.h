@@ -347,7 +347,8 @@ int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n,
  * mgx_alignment of its results carries its labels (n_labels, labels_begin into mgx_results.labels, ascending).  Used with
  * mgx_align_batch / mgx_align_batch_device / mgx_fetch_results like any aligner; `annotation` must outlive it and live on
  * the graph's device, with at least as many rows as the graph has nodes (row = node - 1).
- * This round: BASIC- and PRIMARY-mode graphs (PRIMARY: through the CanonicalDBG wrapper, labels looked up by base node as
+ * This round: BASIC-, PRIMARY- and CANONICAL-mode graphs (PRIMARY: through the CanonicalDBG wrapper, labels looked up by base
+ * node; CANONICAL: by the k-mer's representative, the smaller BOSS index of the k-mer and its reverse complement — as
  * annotation_buffer.cpp:41-63 does), annotations without coordinates (ColumnCompressed), num_alternative_paths <= 2;
  * anything else: MGX_ERR_UNSUPPORTED.  A read whose label bookkeeping outgrows its arena gets MGX_ERR_CAPACITY. */
 int mgx_labeled_aligner_create(const mgx_graph *graph, const mgx_config *config, const mgx_limits *limits,

@@ -148,6 +148,7 @@ struct AlignParams {
     const uint32_t *anno_count;
     const uint32_t *anno_more;
     uint64_t anno_rows;
+    const uint32_t *anno_base;           // CANONICAL-mode graphs: node -> the representative whose row holds its labels (canon_repr_node), else null
     uint32_t ablate;                     // timing probes only (results become WRONG): bit 0 = no convergence table in the chain
                                          // step, bit 1 = no cell records / column metadata stores, bit 2 = no backtrack
 };

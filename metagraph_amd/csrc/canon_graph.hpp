@@ -99,6 +99,29 @@ MGX_DEV uint64_t index_boss_node(const DevGraph &g, const Spell &t, LineCtr &ctr
     return ru;
 }
 
+// The representative of node v's k-mer on a CANONICAL-mode graph, as DBGSuccinct::map_to_nodes defines it
+// (dbg_succinct.cpp:436-481: "the definition of a canonical k-mer is redefined: use k-mer with smaller index in the BOSS table"):
+// the smaller of v and the edge of its reverse complement (BOSS::map_to_edges: the node of the first k - 1 characters, then the
+// edge with the last character's label), validated; 0 (npos) for a k-mer with a sentinel, a missing reverse complement or a
+// masked edge.  This is the node whose row an annotation of a CANONICAL graph holds (AnnotationBuffer, annotation_buffer.cpp:56-62).
+MGX_DEV uint32_t canon_repr_node(const DevGraph &g, uint64_t v) {
+    LineCtr ctr = { 0, 0, 0 };
+    const int32_t k = (int32_t)g.k;
+    if (v < 1 || v > g.n) return 0;
+    const Spell h = base_spelling(g, v, ctr);
+    if (h.dollar & ((k >= 64 ? 0ull : (1ull << k)) - 1)) return 0;
+    const Spell r = spell_reverse_complement(h, k);
+    const uint64_t ru = index_boss_node(g, r, ctr);
+    if (!ru) return 0;
+    const uint32_t c = spell_get(r, k - 1);
+    const uint64_t first = pred_last(g, ru - 1, ctr) + 1;
+    uint64_t e = 0;
+    for (uint64_t i = first; i <= ru && !e; ++i) if (get_W(g, i, ctr) % SIGMA == c) e = i;
+    if (!e) return 0;
+    const uint64_t m = e < v ? e : v;
+    return in_graph(g, m) ? (uint32_t)m : 0u;
+}
+
 // CanonicalDBG::call_outgoing_kmers(v) for wrapper node v with spelling h, sentinel-labelled children left out (what the
 // extender keeps, aligner_extender_methods.cpp:381-384).  Writes up to 4 (node, code 1..4) pairs in the reference's callback
 // order; *sentinel = the base graph reported a sentinel neighbour on the direct side (children[0] / parents[0] of the

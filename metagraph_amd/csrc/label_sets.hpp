@@ -49,7 +49,10 @@ MGX_DEV uint32_t lab_persist(Wave &w, uint32_t h) {
 
 // A PRIMARY graph is annotated and looked up by BASE node: the wrapper's ids above n are the reverse complements of the base
 // nodes v - n (CanonicalDBG::get_base_node, canonical_dbg.hpp; annotation_buffer.cpp:41-63, :195-217)
+// A CANONICAL-mode graph is annotated and looked up by the k-mer's representative — the smaller BOSS index of the k-mer and its
+// reverse complement (annotation_buffer.cpp:56-62: spell_path + map_to_nodes; here a table built once per aligner)
 MGX_DEV uint32_t lab_base_node(const AlignParams &P, uint32_t node) {
+    if (P.anno_base) return (node && node <= P.g.n) ? P.anno_base[node] : 0u;
     return (kWithPrimary && P.cfg.canonical >= 2 && node > P.g.n) ? node - (uint32_t)P.g.n : node;
 }
 

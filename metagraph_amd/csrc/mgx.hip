@@ -248,6 +248,13 @@ __global__ void k_iota(uint32_t *v, uint64_t n) {
 // label-aware alignment: does any dummy node (W == 0: the reference's AnnotationBuffer gives those no labels whatever their row
 // says, annotation_buffer.cpp:64-68) have a label in the matrix?  Checked once per aligner; if none does — annotations are built
 // from real k-mers — the kernels skip the W look-up in front of every row access.
+// label-aware alignment on a CANONICAL-mode graph: node -> the representative of its k-mer (canon_repr_node), whose row holds
+// the node's labels
+__global__ void k_canon_repr(DevGraph g, uint32_t *out) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > g.n) return;
+    out[v] = v ? canon_repr_node(g, v) : 0u;
+}
 __global__ void k_anno_dummy_rows(DevGraph g, const uint64_t *head, uint64_t n_rows, uint32_t *flag) {
     const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
     if (v > g.n || v - 1 >= n_rows || head[v - 1] == 0) return;
@@ -364,6 +371,7 @@ struct mgx_aligner {
     const mgx_graph *graph = nullptr;
     const mgx_annotation *anno = nullptr;      // label-aware alignment (mgx_labeled_aligner_create)
     bool anno_dummy_clean = false;             // no row of a dummy node holds a label (k_anno_dummy_rows)
+    DevBuf anno_base;                          // CANONICAL-mode graphs: node -> representative (k_canon_repr)
     mgx_config cfg;
     DevConfig dcfg;
     mgx_limits user_lim;
@@ -681,7 +689,6 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
         // reference looks labels up by base node through the CanonicalDBG wrapper for PRIMARY graphs and by spelling for
         // CANONICAL ones: not on the device yet), annotation without coordinates, as many alternative paths per label as
         // the labeled kernel build holds.
-        if (g->mode == MGX_MODE_CANONICAL) return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment on CANONICAL-mode graphs is not on the device (BASIC and PRIMARY are)");
         if (A->cfg.num_alternative_paths > (uint64_t)std::min(mgx_lab64_max_alt(), mgx_grp_max_alt8_lab()))
             return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment: num_alternative_paths <= %d on the device", std::min(mgx_lab64_max_alt(), mgx_grp_max_alt8_lab()));
         int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;
@@ -705,6 +712,12 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
         HIP_TRY(hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));
         (void)hipFree(d_flag);
         A->anno_dummy_clean = flag == 0;
+        if (g->mode == MGX_MODE_CANONICAL) {
+            if (int rc = A->anno_base.ensure((g->g.n + 1) * 4)) return rc;
+            k_canon_repr<<<(uint32_t)((g->g.n + 256) / 256), 256>>>(g->g, A->anno_base.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+        }
     }
     if (int rc = A->score_matrix.ensure(128 * 128)) return rc;
     HIP_TRY(hipMemcpy(A->score_matrix.p, c.score_matrix, 128 * 128, hipMemcpyHostToDevice));
@@ -980,6 +993,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         int adev = 0;
         mgx_annotation_device_view(A->anno, &adev, &P.anno_rows, &P.anno_head, &P.anno_count, &P.anno_more);
         P.labeled = 1u | (A->anno_dummy_clean ? 2u : 0u);
+        P.anno_base = A->graph->mode == MGX_MODE_CANONICAL ? A->anno_base.as<uint32_t>() : nullptr;
         P.no_alias = 1;           // (a flush clears columns in place: convergence entries must not alias their S windows)
     }
 #ifdef MGX_PROBES

@@ -693,6 +693,7 @@ std::vector<Alignment> seeds_to_alignments(const std::vector<Seed> &seeds, const
 // =============================================================================================
 constexpr size_t kPadding = 5;                          // extender hpp:107
 std::atomic<uint64_t> g_oob_reads{0};
+std::atomic<uint64_t> g_unfetched_label_lookups{0};
 
 // std::vector<score_t> with the capacity behaviour the reference relies on (padding reads/writes
 // past size()).  Growth mirrors libstdc++ (capacity doubles on overflow).
@@ -803,8 +804,6 @@ class AnnotationBuffer {
           : graph_(graph), canonical_(canon), annotation_(annotation) {
         column_sets_.push_back(Columns{});               // "the first element is the empty label set" (hpp:76-78)
         column_index_[Columns{}] = 0;
-        if (graph_.mode == CANONICAL && !canon)
-            throw std::runtime_error("oracle: label-aware alignment on CANONICAL-mode graphs is not restated");
     }
 
     void queue_path(std::vector<node_t> &&path) { queued_paths_.push_back(std::move(path)); }     // hpp:29-31
@@ -815,7 +814,14 @@ class AnnotationBuffer {
         std::vector<uint64_t> queued_rows;
         for (const auto &path : queued_paths_) {
             std::vector<node_t> base_path;
-            if (canonical_) {
+            if (graph_.mode == CANONICAL) {
+                // "TODO: avoid this call of spell_path" (:58-62): the path spelled and mapped again — on a CANONICAL-mode graph
+                // map_to_nodes gives the k-mer's representative, the smaller BOSS index of the k-mer and its reverse complement
+                for (node_t node : path) {
+                    std::vector<node_t> m = node ? graph_.map_to_nodes(graph_.get_node_sequence(node)) : std::vector<node_t>{};
+                    base_path.push_back(m.size() == 1 ? m[0] : NPOS);
+                }
+            } else if (canonical_) {
                 base_path.reserve(path.size());
                 for (node_t node : path) base_path.emplace_back(canonical_->get_base_node(node));
             } else {
@@ -825,12 +831,38 @@ class AnnotationBuffer {
                 if (base_path[i] == NPOS) { node_to_cols_.try_emplace(path[i], 0); continue; }
                 if (!graph_.boss.get_W(base_path[i])) {  // "skip dummy nodes"
                     node_to_cols_.try_emplace(base_path[i], 0);
+                    if (graph_.mode == CANONICAL && base_path[i] != path[i]) node_to_cols_.emplace(path[i], 0);
                     continue;
                 }
                 uint64_t row = base_path[i] - 1;         // AnnotatedDBG::graph_to_anno_index
-                if (node_to_cols_.try_emplace(base_path[i], kNannotIdx).second) {
+                if (graph_.mode != CANONICAL) {
+                    if (node_to_cols_.try_emplace(base_path[i], kNannotIdx).second) {
+                        queued_rows.push_back(row);
+                        queued_nodes.push_back(base_path[i]);
+                    }
+                    continue;
+                }
+                // CANONICAL (:96-135): a node and its representative share one label set; whichever of the two is known
+                // first gives it to the other
+                auto find_a = node_to_cols_.find(path[i]);
+                auto find_b = node_to_cols_.find(base_path[i]);
+                if (find_a == node_to_cols_.end() && find_b == node_to_cols_.end()) {
+                    node_to_cols_.try_emplace(path[i], kNannotIdx);
                     queued_rows.push_back(row);
-                    queued_nodes.push_back(base_path[i]);
+                    queued_nodes.push_back(path[i]);
+                    if (path[i] != base_path[i]) {
+                        node_to_cols_.emplace(base_path[i], kNannotIdx);
+                        queued_rows.push_back(row);
+                        queued_nodes.push_back(base_path[i]);
+                    }
+                } else if (find_a == node_to_cols_.end()) {
+                    node_to_cols_.try_emplace(path[i], find_b->second);
+                    if (find_b->second == kNannotIdx) { queued_rows.push_back(row); queued_nodes.push_back(path[i]); }
+                } else if (find_b == node_to_cols_.end()) {
+                    node_to_cols_.try_emplace(base_path[i], find_a->second);
+                } else {
+                    size_t label_i = std::min(find_a->second, find_b->second);
+                    if (label_i != kNannotIdx) { find_a->second = label_i; find_b->second = label_i; }
                 }
             }
         }
@@ -841,14 +873,39 @@ class AnnotationBuffer {
             std::sort(rows[x].begin(), rows[x].end());
             size_t label_i = cache_column_set(std::move(rows[x]));
             node_to_cols_[queued_nodes[x]] = label_i;    // push_node_labels: BASIC and the canonical wrapper both key by the base node
+            if (graph_.mode == CANONICAL && !canonical_) {
+                // (:150-158) a CANONICAL-mode graph: the queued node, and its representative if that has no entry yet
+                const node_t base_node = (node_t)(queued_rows[x] + 1);
+                if (base_node != queued_nodes[x]) node_to_cols_.try_emplace(base_node, label_i);
+            }
         }
     }
 
     // get_labels_and_coords().first (:195-217)
     const Columns *get_labels(node_t node) const {
-        if (canonical_) node = canonical_->get_base_node(node);
+        if (canonical_) node = canonical_->get_base_node(node);       // (CANONICAL-mode graphs: every queued node has an entry of its own)
         auto it = node_to_cols_.find(node);
-        if (it == node_to_cols_.end() || it->second == kNannotIdx) return nullptr;
+        if (it == node_to_cols_.end() || it->second == kNannotIdx) {
+            // On a CANONICAL-mode graph the reference can ask for a node it never queued: the nodes of a reversed alignment that
+            // seeds the backward pass (replayed "in_seed", aligner_labeled.cpp:186-195) are the reverse complements of the forward
+            // pass's nodes, and only the one of each pair that IS the representative got an entry (annotation_buffer.cpp:96-135).
+            // The reference asserts (aligner_labeled.cpp:143-146, :110) and is undefined in a release build.  Defined here — and on
+            // the device — as what the buffer would have answered had the node been queued: the labels of its representative;
+            // counted (orc_unfetched_label_lookups), like the out-of-bounds reads of backtrack.
+            if (graph_.mode != CANONICAL || canonical_ || !node) return nullptr;
+            ++g_unfetched_label_lookups;
+            auto *self = const_cast<AnnotationBuffer *>(this);
+            std::vector<node_t> m = graph_.map_to_nodes(graph_.get_node_sequence(node));
+            const node_t base = m.size() == 1 ? m[0] : NPOS;
+            size_t label_i = 0;
+            if (base != NPOS && graph_.boss.get_W(base)) {
+                std::vector<Columns> rows = annotation_.get_rows({ base - 1 });
+                std::sort(rows[0].begin(), rows[0].end());
+                label_i = self->cache_column_set(std::move(rows[0]));
+            }
+            self->node_to_cols_[node] = label_i;
+            return &column_sets_[label_i];
+        }
         return &column_sets_[it->second];
     }
 
@@ -1751,14 +1808,13 @@ void Annotation::annotate_sequence(const Graph &graph, std::string_view sequence
     // annotated_dbg.cpp:55-75: graph_->map_to_nodes(sequence, [&](node_index i) { if (i > 0) indices.push_back(graph_to_anno_index(i)); })
     // BASIC graphs: map_to_nodes == map_to_nodes_sequentially; a PRIMARY graph is annotated through its CanonicalDBG wrapper
     // (CanonicalDBG::map_to_nodes reports base nodes, canonical_dbg.cpp:148-154)
-    if (graph.mode == CANONICAL) throw std::runtime_error("oracle: annotating CANONICAL-mode graphs is not restated");
     std::vector<node_t> nodes;
     if (graph.mode == PRIMARY) {
         CanonicalView canon(graph);
         nodes = canon.map_to_nodes_sequentially(sequence);
         for (node_t &v : nodes) v = canon.get_base_node(v);
     } else {
-        nodes = graph.map_to_nodes_sequentially(sequence);
+        nodes = graph.map_to_nodes(sequence);            // (CANONICAL mode: the k-mers' representatives)
     }
     for (node_t v : nodes) if (v > 0) set(v - 1, column);
 }
@@ -1968,6 +2024,7 @@ void LabeledAligner::align_batch(const std::vector<std::string> &queries, std::v
 }
 
 uint64_t g_oob_reads_total() { return g_oob_reads.load(); }
+uint64_t g_unfetched_label_lookups_total() { return g_unfetched_label_lookups.load(); }
 
 // =============================================================================================
 // DBGAligner (A/dbg_aligner.cpp)

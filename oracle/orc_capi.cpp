@@ -13,7 +13,7 @@
 
 using namespace orc;
 
-namespace orc { extern uint64_t g_oob_reads_total(); }
+namespace orc { extern uint64_t g_oob_reads_total(); extern uint64_t g_unfetched_label_lookups_total(); }
 
 namespace {
 struct ResultStore {
@@ -222,6 +222,8 @@ int orc_sdust_bruteforce(const char *s, uint32_t len) {
 }
 int orc_check_config(const mgx_config *c) { return check_config_scores(*c); }
 uint64_t orc_oob_reads() { return g_oob_reads_total(); }
+// label look-ups of nodes the reference's AnnotationBuffer was never asked to fetch (CANONICAL-mode graphs: undefined upstream)
+uint64_t orc_unfetched_label_lookups() { return g_unfetched_label_lookups_total(); }
 
 // Align a batch with `threads` worker threads (thread pool over sub-batches like cli/align.cpp:415-480).
 // validate != 0 additionally runs Alignment::is_valid on every result (alignment.cpp:1316-1345).

@@ -455,6 +455,26 @@ std::vector<node_t> Graph::map_to_nodes_sequentially(std::string_view seq) const
     return nodes;
 }
 
+std::vector<node_t> Graph::map_to_nodes(std::string_view seq) const {
+    // dbg_succinct.cpp:428-500 (no Bloom filter).  CANONICAL mode: "the definition of a canonical k-mer is redefined: use k-mer
+    // with smaller index in the BOSS table"; a k-mer that is missing skips its reverse complement
+    if (mode != CANONICAL) return map_to_nodes_sequentially(seq);
+    std::vector<node_t> nodes;
+    if (seq.size() < get_k()) return nodes;
+    std::string rc(seq);
+    reverse_complement_inplace(rc);
+    auto fwd_edges = boss.map_to_edges(encode_seq(seq));
+    auto rc_edges = boss.map_to_edges(encode_seq(rc));
+    const size_t n = fwd_edges.size();
+    nodes.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        edge_t e = fwd_edges[i];
+        if (e) e = std::min(e, rc_edges[n - 1 - i]);
+        nodes.push_back(validate_edge(e));
+    }
+    return nodes;
+}
+
 void Graph::call_outgoing_kmers(node_t v, const std::function<void(node_t, char)> &cb) const {
     // dbg_succinct.cpp:110-139
     uint8_t w = 0;

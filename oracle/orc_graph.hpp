@@ -106,6 +106,7 @@ struct Graph {
     void mask_dummy_kmers();                                 // dbg_succinct.cpp:924-932, boss.cpp:1765-1775
 
     std::vector<node_t> map_to_nodes_sequentially(std::string_view seq) const; // dbg_succinct.cpp:285-305
+    std::vector<node_t> map_to_nodes(std::string_view seq) const;               // dbg_succinct.cpp:428-500 (CANONICAL: the smaller BOSS index of a k-mer and its reverse complement)
     void call_outgoing_kmers(node_t v, const std::function<void(node_t, char)> &cb) const; // :110-139
     void call_incoming_kmers(node_t v, const std::function<void(node_t, char)> &cb) const; // node_first_cache.cpp:38-52
     bool has_multiple_outgoing(node_t v) const;              // dbg_succinct.cpp:609-624

@@ -342,7 +342,6 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     R->m_fwd.assign(nf.begin(), nf.end());
     R->m_rc.assign(nr.begin(), nr.end());
     if (map_only) return R;
-    if (AN && G->mode == MGX_MODE_CANONICAL) { R->error = "label-aware alignment: BASIC- and PRIMARY-mode graphs only"; return R; }
     rc = derive_limits(cfg, limits, Lmax, &R->lim, &R->error, AN != nullptr);
     if (rc) return R;
     const uint64_t stride = arena_bytes(R->lim);
@@ -356,6 +355,7 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     unsigned long long cursors[2] = { 0, 0 };
     AlignParams P;
     memset(&P, 0, sizeof(P));
+    std::vector<uint32_t> anno_base;
     P.g = G->g; P.cfg = dcfg; P.lim = R->lim; P.score_matrix = sm.data();
     P.seqs = seqs; P.offsets = offsets; P.node_begin = R->node_begin.data();
     P.nodes_fwd = nf.data(); P.nodes_rc = nr.data(); P.n_reads = n;
@@ -367,6 +367,11 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
     if (AN) {
         P.labeled = 1; P.no_alias = 1;        // as mgx.hip
+        if (G->mode == MGX_MODE_CANONICAL) {   // k_canon_repr
+            anno_base.assign(G->g.n + 1, 0);
+            for (uint64_t v = 1; v <= G->g.n; ++v) anno_base[v] = canon_repr_node(G->g, v);
+            P.anno_base = anno_base.data();
+        }
         {
             bool clean = true;                 // k_anno_dummy_rows: no dummy node's row holds a label
             LineCtr lc = { 0, 0, 0 };

@@ -141,14 +141,21 @@ def test_labeled_alignment_on_primary_graphs_on_gpu(seed, k, kernel):
     assert sum(1 for a in want if a) >= 8
 
 
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+@pytest.mark.parametrize("seed,k", [(1, 11), (2, 15), (3, 7), (4, 19), (5, 31)])
+def test_labeled_alignment_on_canonical_mode_graphs_on_gpu(seed, k, kernel):
+    """CANONICAL-mode graphs: labels by the k-mer's representative (the smaller BOSS index of the k-mer and its reverse
+    complement: a table built once per aligner), alignments flipped by re-mapping their reversed spelling"""
+    from test_labeled_emu import canonical_labeled_world
+    g, anno, reads = canonical_labeled_world(seed, k)
+    cfg = capi.config_cli(k)
+    if seed == 2:
+        cfg.min_seed_length = 11
+    _, want = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=False, kernel=kernel, mode=1)
+    assert sum(1 for a in want if a) >= 8
+
+
 def test_labeled_aligner_refuses_what_it_cannot_do():
-    g = orc.Graph.build(5, ["GTCGAAATTAGTCGAAA"], 1, False)
-    W, last, F, valid = g.export()
-    G = aligner.Graph(g.k, W, last, F, valid, mode=1)
-    AN = gpu_annotation(orc.Annotation(g, 1))
-    with pytest.raises(aligner.MgxError) as e:
-        aligner.Aligner(G, capi.config_cli(5), annotation=AN)
-    assert e.value.code == capi.MGX_ERR_UNSUPPORTED
     cfg = capi.config_cli(5)
     cfg.num_alternative_paths = 3
     g0 = orc.Graph.build(5, ["GTCGAAATTAGTCGAAA"], 0, False)

@@ -95,8 +95,33 @@ def test_labeled_alignment_on_primary_graphs(seed, k):
     assert sum(1 for a in want if a) >= 8
 
 
-def test_labeled_refuses_canonical_mode_graphs():
-    g = orc.Graph.build(5, ["GTCGAAATTAGTCGAAA"], 1, False)
-    anno = orc.Annotation(g, 1)
-    e = emu_drv.EmuRun(emu_drv.EmuGraph(g, mode=1), capi.config_cli(5), ["GTCGAAA"], annotation=emu_drv.EmuAnnotation(anno))
-    assert "PRIMARY" in e.error
+def canonical_labeled_world(seed, k):
+    """a CANONICAL-mode graph (both strands stored) over two strains; labels live on the k-mers' representatives"""
+    import random
+    from test_emu_vs_oracle import rand_seq, mutate, rc
+    rng = random.Random(seed)
+    genome = rand_seq(rng, 700)
+    strains = [genome, mutate(rng, genome, 0.03)]
+    g = orc.Graph.build(k, strains, 1, True)
+    anno = orc.Annotation(g, 4)
+    for j, st in enumerate(strains):
+        anno.annotate(st, j)
+    anno.annotate(genome[100:350], 2)
+    anno.annotate(rc(genome[400:650]), 3)                 # (annotated from the other strand: the same representatives)
+    reads = []
+    for i in range(16):
+        st = rng.choice(strains)
+        p = rng.randrange(0, len(st) - 80)
+        r = mutate(rng, st[p:p + 80], rng.choice([0.0, 0.03]))
+        reads.append(rc(r) if i % 2 else r)
+    return g, anno, reads
+
+
+@pytest.mark.parametrize("seed,k", [(1, 11), (2, 15), (3, 7)])
+def test_labeled_alignment_on_canonical_mode_graphs(seed, k):
+    g, anno, reads = canonical_labeled_world(seed, k)
+    cfg = capi.config_cli(k)
+    if seed == 2:
+        cfg.min_seed_length = 11
+    want = compare_emu_labeled(g, anno, cfg, reads, mode=1)
+    assert sum(1 for a in want if a) >= 8

@@ -19,8 +19,11 @@ CASES = {
     "SimpleTangleGraphSuffixSeed": dict(k=4, sequences=["TGCCT", "TCGAATGCCT", "TGGAATGCAT"], labels="ABC", mode=0,
                                         cfg=dict(min_seed_length=2, left_end_bonus=5, right_end_bonus=5), matrix=("dna", 2, -1, -1),
                                         expect={"TGAAATGCAT": {"C": "TGGAATGCAT", "B": "TCGAATGCCT"}}),
-    # :719-778, the PRIMARY half (a PRIMARY DBGSuccinct seen through CanonicalDBG; the CANONICAL-mode half needs the
-    # AnnotationBuffer's spell_path + map_to_nodes branch, which is not restated)
+    # :719-778: both halves of the test — a CANONICAL-mode DBGSuccinct (labels by the k-mer's representative: AnnotationBuffer's
+    # spell_path + map_to_nodes branch, annotation_buffer.cpp:56-62,96-135) and a PRIMARY one seen through CanonicalDBG
+    "CanonicalTangleGraph_canonical": dict(k=5, sequences=["GTCGAAA", "TTAGTCGAAA", "TCAGTCGATT"], labels="ABC", mode=1,
+                                           cfg={}, matrix=("dna", 2, -1, -2),
+                                           expect={"TTAGTTCAAA": {"B": "TTAGTCGAAA"}}),
     "CanonicalTangleGraph_primary": dict(k=5, sequences=["GTCGAAA", "TTAGTCGAAA", "TCAGTCGATT"], labels="ABC", mode=2,
                                          cfg={}, matrix=("dna", 2, -1, -2),
                                          expect={"TTAGTTCAAA": {"B": "TTAGTCGAAA"}}),
@@ -48,9 +51,14 @@ def build(case):
 def test_reference_labeled_kats(name):
     case = CASES[name]
     g, anno, cfg = build(case)
+    import ctypes as C
+    orc.L().orc_unfetched_label_lookups.restype = C.c_uint64
+    before = orc.L().orc_unfetched_label_lookups()
     for query, want in case["expect"].items():
         run = orc.LabeledAlignRun(g, cfg, anno, [query])
         assert run.error == "", run.error
+        # (the upstream cases stay inside what the reference defines: no label look-up of a node its buffer never fetched)
+        assert orc.L().orc_unfetched_label_lookups() == before
         alns = run.results()[0]
         labs = run.labels()[0]
         assert len(alns) == len(want), (name, query, [(a["sequence"], a["cigar"], l) for a, l in zip(alns, labs)])
@@ -61,6 +69,8 @@ def test_reference_labeled_kats(name):
             assert any(want[nm] == a["sequence"] for nm in names), (a["sequence"], names, want)
             # every reported label covers every k-mer of the alignment's spelling (get_alignment_labels, check_full_coverage)
             n = g.n_edges
+            if case["mode"] == 1:
+                continue                                                          # (rows are those of the k-mers' representatives)
             rows = [(v - n if v > n else v) - 1 for v in a["nodes"] if v]         # (wrapper ids above n: the base node's row)
             for per_node in anno.get_rows(rows):
                 assert set(ls) <= set(per_node)

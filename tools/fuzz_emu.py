@@ -52,7 +52,7 @@ def main():
             mode = 0
             k = rng.choice([7, 8, 11, 12, 15, 19, 20, 27, 31, 32])
         if args.labels:
-            mode = rng.choice([0, 0, 2])
+            mode = rng.choice([0, 0, 1, 2])
             k = rng.choice([5, 7, 8, 11, 12, 15, 19, 20, 31, 33])
         mask = rng.random() < 0.4
         glen = rng.choice([300, 1000, 3000, 6000])
