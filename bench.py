@@ -330,9 +330,11 @@ def main():
     traffic, traffic_src, gather = None, None, None
     try:
         here = os.path.dirname(os.path.abspath(__file__))
-        pmc_name = next(n for n in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json") if os.path.exists(os.path.join(here, "profiles", n)))
+        # (label-aware runs have PMC passes of their own: other kernels, other seeds per read)
+        pmc_names = ("r04_labels_pmc_summary.json",) if args.labels else ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
+        pmc_name = next(n for n in pmc_names if os.path.exists(os.path.join(here, "profiles", n)))
         pmc = json.load(open(os.path.join(here, "profiles", pmc_name)))
-        per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read") if not args.labels else None    # (the PMC passes are of the unlabeled kernels)
+        per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read")
         if per_read:
             traffic = round(per_read * args.reads)
             traffic_src = "profiles/%s (%d-read PMC run, scaled per read)" % (pmc_name, pmc["reads_per_launch"])
