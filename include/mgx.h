@@ -363,6 +363,45 @@ size_t mgx_format_tsv_labeled(const mgx_results *res, uint64_t query_index, cons
 int mgx_results_from_raw_labeled(const void *headers, uint64_t n_queries, const uint32_t *stream, uint64_t stream_words,
                                  int labeled, mgx_raw_store **store, mgx_results *out);
 
+/*
+ * Files: the graph and annotation files the reference writes, read on the host and handed to
+ * mgx_graph_create / mgx_annotation_create_sparse.  What a stand-alone caller (host/mgx_align) needs in place of
+ * DBGSuccinct::load (dbg_succinct.cpp:690-785 over BOSS::load, boss.cpp:338-394) and ColumnCompressed::load / merge_load
+ * (annotate_column_compressed.cpp:436-481,493-640); inside MetaGraph the adapter takes both from the loaded objects
+ * (INTEGRATION.md 2).  Read: BOSS states SMALL, STAT and FAST (DYN: MGX_ERR_UNSUPPORTED), any alphabet in
+ * mgx_boss_file_read (the device index itself is DNA only); columns stored as sd_vector, bit_vector_stat or rrr_vector<63>
+ * (bit_vector_smart writes the first two), both label-encoder formats.  The `.edgemask` file next to a `.dbg` is not read:
+ * `metagraph align` drops the mask (cli/align.cpp:337-339).  Which layouts are pinned on reference-written files:
+ * csrc/boss_files.hpp.  Malformed file: MGX_ERR_INVALID with the field named in mgx_last_error; the *_read calls need no GPU.
+ */
+typedef struct mgx_boss_file {
+    uint32_t k;              /* DBG k (BOSS k + 1) */
+    uint32_t sigma;          /* alphabet size incl. '$' (F's length): 5 = DNA */
+    uint32_t mode;           /* MGX_MODE_* as stored behind the BOSS table (dbg_succinct.cpp:701) */
+    uint32_t state;          /* BOSS::State of the file (boss.hpp:325): 1 SMALL, 3 STAT, 4 FAST */
+    uint64_t n_edges;
+    const uint64_t *F;       /* sigma entries */
+    const uint8_t *W;        /* n_edges + 1 bytes, the layout of mgx_boss_view */
+    const uint8_t *last;
+    void *owner;             /* private */
+} mgx_boss_file;
+int mgx_boss_file_read(const char *path, mgx_boss_file *out);
+void mgx_boss_file_free(mgx_boss_file *f);
+/* mgx_boss_file_read + mgx_graph_create: DBGSuccinct::load for the device */
+int mgx_graph_load_dbg(const char *path, int device, mgx_graph **out);
+
+typedef struct mgx_column_file mgx_column_file;
+/* One or several `.column.annodbg` files over the same rows, their columns side by side in argument order (merge_load;
+ * a label occurring in two files: MGX_ERR_UNSUPPORTED). */
+int mgx_column_file_read(const char *const *paths, uint32_t n_paths, mgx_column_file **out);
+void mgx_column_file_free(mgx_column_file *f);
+uint64_t mgx_column_file_num_rows(const mgx_column_file *f);
+uint32_t mgx_column_file_num_labels(const mgx_column_file *f);
+const char *mgx_column_file_label(const mgx_column_file *f, uint32_t j);      /* LabelEncoder::decode(j) */
+const uint64_t *mgx_column_file_col_begin(const mgx_column_file *f);          /* num_labels + 1 entries */
+const uint64_t *mgx_column_file_rows(const mgx_column_file *f);               /* the arguments of mgx_annotation_create_sparse */
+int mgx_annotation_create_from_file(const mgx_column_file *f, int device, mgx_annotation **out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,37 @@ def pack_queries(queries):
     return b"".join(bs), offs
 
 
+def read_boss_file(path, arrays=True):
+    """mgx_boss_file_read (host only, no GPU): k, sigma, mode, state, n_edges, F and — with arrays — W / last of a `.dbg` file."""
+    L = capi.lib()
+    f = capi.BossFile()
+    _check(L.mgx_boss_file_read(str(path).encode(), C.byref(f)))
+    try:
+        out = {"k": f.k, "sigma": f.sigma, "mode": f.mode, "state": f.state, "n_edges": f.n_edges, "F": [int(f.F[i]) for i in range(f.sigma)]}
+        if arrays:
+            out["W"] = np.ctypeslib.as_array(f.W, shape=(f.n_edges + 1,)).copy()
+            out["last"] = np.ctypeslib.as_array(f.last, shape=(f.n_edges + 1,)).copy()
+        return out
+    finally:
+        L.mgx_boss_file_free(C.byref(f))
+
+
+def read_column_files(paths):
+    """mgx_column_file_read (host only): (n_rows, label names, col_begin, rows) of one or several `.column.annodbg` files."""
+    L = capi.lib()
+    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+    h = C.c_void_p()
+    _check(L.mgx_column_file_read(arr, len(paths), C.byref(h)))
+    try:
+        n = L.mgx_column_file_num_labels(h)
+        names = [L.mgx_column_file_label(h, j).decode() for j in range(n)]
+        cb = np.ctypeslib.as_array(L.mgx_column_file_col_begin(h), shape=(n + 1,)).copy()
+        rows = np.ctypeslib.as_array(L.mgx_column_file_rows(h), shape=(int(cb[-1]),)).copy() if int(cb[-1]) else np.zeros(0, dtype=np.uint64)
+        return int(L.mgx_column_file_num_rows(h)), names, cb, rows
+    finally:
+        L.mgx_column_file_free(h)
+
+
 class Graph:
     """A BOSS table on the GPU.  W/last: uint8 arrays of n_edges + 1 entries (slot 0 unused)."""
 
@@ -57,6 +88,17 @@ class Graph:
         _check(L.mgx_graph_create(C.byref(v), device, C.byref(self.h)))
         self.k = k
         self.n_edges = v.n_edges
+
+    @classmethod
+    def load(cls, path, device=0):
+        """mgx_graph_load_dbg: a `.dbg` file written by the reference (DBGSuccinct::load, dbg_succinct.cpp:690-785)."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        _check(capi.lib().mgx_graph_load_dbg(str(path).encode(), device, C.byref(self.h)))
+        self.k = capi.lib().mgx_graph_k(self.h)
+        f = read_boss_file(path, arrays=False)
+        self.n_edges, self.mode = f["n_edges"], f["mode"]
+        return self
 
     def close(self):
         if getattr(self, "h", None) and capi is not None:      # capi is None during interpreter shutdown
@@ -97,6 +139,16 @@ class Annotation:
         self.h = C.c_void_p()
         self.n_rows, self.n_labels = n_rows, len(cb) - 1
         _check(capi.lib().mgx_annotation_create_sparse(n_rows, len(cb) - 1, cb.ctypes.data, rp, 1 if on_device else 0, device, C.byref(self.h)))
+        return self
+
+    @classmethod
+    def load(cls, paths, device=0):
+        """`.column.annodbg` files written by the reference (ColumnCompressed::load / merge_load); label names in .labels."""
+        if isinstance(paths, (str, bytes)) or hasattr(paths, "__fspath__"):
+            paths = [paths]
+        n_rows, names, cb, rows = read_column_files(paths)
+        self = cls.from_sparse(n_rows, cb, rows, device=device)
+        self.labels = names
         return self
 
     @property

@@ -18,6 +18,12 @@ class BossView(C.Structure):
                 ("valid", C.c_void_p), ("mode", C.c_uint32), ("on_device", C.c_uint32)]
 
 
+class BossFile(C.Structure):
+    """mgx_boss_file (include/mgx.h, "files")"""
+    _fields_ = [("k", C.c_uint32), ("sigma", C.c_uint32), ("mode", C.c_uint32), ("state", C.c_uint32), ("n_edges", C.c_uint64),
+                ("F", C.POINTER(C.c_uint64)), ("W", C.POINTER(C.c_uint8)), ("last", C.POINTER(C.c_uint8)), ("owner", C.c_void_p)]
+
+
 class Config(C.Structure):
     _fields_ = [("num_alternative_paths", C.c_uint64), ("min_seed_length", C.c_uint64),
                 ("max_seed_length", C.c_uint64), ("max_num_seeds_per_locus", C.c_uint64),
@@ -176,6 +182,22 @@ def lib():
     L.mgx_annotation_get_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
                                           C.POINTER(C.c_uint64)]
     L.mgx_device_count.restype = C.c_int
+    L.mgx_boss_file_read.argtypes = [C.c_char_p, C.POINTER(BossFile)]
+    L.mgx_boss_file_free.argtypes = [C.POINTER(BossFile)]
+    L.mgx_graph_load_dbg.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.mgx_column_file_read.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p)]
+    L.mgx_column_file_free.argtypes = [C.c_void_p]
+    L.mgx_column_file_num_rows.argtypes = [C.c_void_p]
+    L.mgx_column_file_num_rows.restype = C.c_uint64
+    L.mgx_column_file_num_labels.argtypes = [C.c_void_p]
+    L.mgx_column_file_num_labels.restype = C.c_uint32
+    L.mgx_column_file_label.argtypes = [C.c_void_p, C.c_uint32]
+    L.mgx_column_file_label.restype = C.c_char_p
+    L.mgx_column_file_col_begin.argtypes = [C.c_void_p]
+    L.mgx_column_file_col_begin.restype = C.POINTER(C.c_uint64)
+    L.mgx_column_file_rows.argtypes = [C.c_void_p]
+    L.mgx_column_file_rows.restype = C.POINTER(C.c_uint64)
+    L.mgx_annotation_create_from_file.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     L.mgx_graph_create.argtypes = [C.POINTER(BossView), C.c_int, C.POINTER(C.c_void_p)]
     L.mgx_graph_destroy.argtypes = [C.c_void_p]
     L.mgx_graph_k.argtypes = [C.c_void_p]

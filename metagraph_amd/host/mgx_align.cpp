@@ -1,12 +1,14 @@
 // mgx_align — minimal `metagraph align`-shaped driver over HipDBGAligner (host side only: batching and
-// TSV printing as in cli/align.cpp:403-480).  Graph input is a flat BOSS dump (k, n_edges, F[5], W[], last[]);
-// reading sdsl-serialised .dbg files is "next" (SURVEY 8f rank 2).  Usage:
-//   mgx_align GRAPH.boss READS.{fa,fq} [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]
+// TSV printing as in cli/align.cpp:403-480).  Graph input: a `.dbg` file written by the reference (mgx_boss_file_read:
+// SMALL / STAT / FAST state, DNA; the graph's mode is the file's) or a flat BOSS dump (k, n_edges, F[5], W[], last[]).  Usage:
+//   mgx_align GRAPH.{dbg,boss} READS.{fa,fq} [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]
 //             [-p THREADS] [--query-batch-size BASES] [--canonical | --primary (the dump is a CANONICAL- / PRIMARY-mode graph)]
 //             [--devices D]   in-process multi-GPU: one graph replica per device, whole batches routed round-robin, no collective
-//             [-a ANNOTATION.cols]  label-aware alignment (metagraph align -a: LabeledAligner): a dump of the annotation's columns —
-//                                   u64 n_rows, u64 n_labels, then per label: u64 name length, the name, u64 count, count x u64 rows
-//                                   (row = node - 1); every alignment is printed with its labels' names (cli/align.cpp:274-281)
+//             [-a ANNOTATION]  label-aware alignment (metagraph align -a: LabeledAligner); every alignment is printed with its
+//                              labels' names (cli/align.cpp:274-281).  ANNOTATION: `.column.annodbg` files written by the
+//                              reference (-a may be repeated: their columns side by side, mgx_column_file_read), or a dump of
+//                              the columns — u64 n_rows, u64 n_labels, then per label: u64 name length, the name, u64 count,
+//                              count x u64 rows (row = node - 1)
 //                             (the reference's unit of parallelism, cli/align.cpp:440-475: one task per batch)
 #include <atomic>
 #include <cstdio>
@@ -59,24 +61,39 @@ int main(int argc, char **argv) {
                         "          [-p THREADS] [--query-batch-size BASES] [--max-columns N (test hook: small device arena)]\n", argv[0]);
         return 2;
     }
-    std::ifstream gin(argv[1], std::ios::binary);
-    if (!gin) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
+    auto ends_with = [](const std::string &s, const char *suffix) { const size_t n = strlen(suffix); return s.size() >= n && !s.compare(s.size() - n, n, suffix); };
     uint64_t hdr[7];
-    gin.read((char *)hdr, sizeof(hdr));           // k, n_edges, F[0..4]
-    uint32_t k = (uint32_t)hdr[0];
-    uint64_t n = hdr[1];
-    std::vector<uint8_t> W(n + 1), last(n + 1);
-    gin.read((char *)W.data(), n + 1);
-    gin.read((char *)last.data(), n + 1);
+    std::vector<uint8_t> W, last;
+    uint32_t graph_mode = MGX_MODE_BASIC;
+    if (ends_with(argv[1], ".dbg")) {             // DBGSuccinct::load (dbg_succinct.cpp:690-711)
+        mgx_boss_file f;
+        if (mgx_boss_file_read(argv[1], &f) != MGX_OK) { fprintf(stderr, "error: %s\n", mgx_last_error()); return 1; }
+        if (f.sigma != 5) { fprintf(stderr, "error: %s: alphabet of %u characters; DNA graphs only\n", argv[1], f.sigma); mgx_boss_file_free(&f); return 1; }
+        hdr[0] = f.k; hdr[1] = f.n_edges;
+        for (int i = 0; i < 5; ++i) hdr[2 + i] = f.F[i];
+        W.assign(f.W, f.W + f.n_edges + 1);
+        last.assign(f.last, f.last + f.n_edges + 1);
+        graph_mode = f.mode;
+        mgx_boss_file_free(&f);
+    } else {
+        std::ifstream gin(argv[1], std::ios::binary);
+        if (!gin) { fprintf(stderr, "cannot open %s\n", argv[1]); return 1; }
+        gin.read((char *)hdr, sizeof(hdr));       // k, n_edges, F[0..4]
+        W.resize(hdr[1] + 1); last.resize(hdr[1] + 1);
+        gin.read((char *)W.data(), (std::streamsize)W.size());
+        gin.read((char *)last.data(), (std::streamsize)last.size());
+        if (!gin) { fprintf(stderr, "bad BOSS dump %s\n", argv[1]); return 1; }
+    }
+    const uint32_t k = (uint32_t)hdr[0];
+    const uint64_t n = hdr[1];
     DBGAlignerConfig cfg;
     mgx_config_init_cli(&cfg, k);
     unsigned threads = 1;
     uint64_t batch_size = 100000000ull;
     mgx_limits lim;
     bool have_lim = false;
-    uint32_t graph_mode = MGX_MODE_BASIC;
     int devices = 1;
-    const char *anno_path = nullptr;
+    std::vector<const char *> anno_paths;
     mgx_limits_init_default(&lim, 0);
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--align-only-forwards")) cfg.forward_and_reverse_complement = 0;
@@ -86,7 +103,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--query-batch-size") && i + 1 < argc) batch_size = strtoull(argv[++i], nullptr, 10);
         else if (!strcmp(argv[i], "--max-columns") && i + 1 < argc) { lim.max_columns = (uint32_t)atoi(argv[++i]); have_lim = true; }
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, atoi(argv[++i]));
-        else if (!strcmp(argv[i], "-a") && i + 1 < argc) anno_path = argv[++i];
+        else if (!strcmp(argv[i], "-a") && i + 1 < argc) anno_paths.push_back(argv[++i]);
         else if (!strcmp(argv[i], "--canonical")) graph_mode = MGX_MODE_CANONICAL;
         else if (!strcmp(argv[i], "--primary")) graph_mode = MGX_MODE_PRIMARY;         // aligned through the CanonicalDBG wrapper
     }
@@ -100,8 +117,21 @@ int main(int argc, char **argv) {
         HipGraphSet graphs(devices, k, n, W.data(), last.data(), hdr + 2, nullptr, graph_mode);
         std::unique_ptr<HipAnnotation> annotation;
         std::vector<std::string> label_names;
-        if (anno_path) {
-            if (devices != 1) { fprintf(stderr, "error: -a with --devices 1 only (one annotation replica)\n"); return 1; }
+        if (!anno_paths.empty() && devices != 1) { fprintf(stderr, "error: -a with --devices 1 only (one annotation replica)\n"); return 1; }
+        if (!anno_paths.empty() && ends_with(anno_paths[0], ".annodbg")) {      // ColumnCompressed::merge_load
+            mgx_column_file *cf = nullptr;
+            if (mgx_column_file_read(anno_paths.data(), (uint32_t)anno_paths.size(), &cf) != MGX_OK) { fprintf(stderr, "error: %s\n", mgx_last_error()); return 1; }
+            const uint32_t nl = mgx_column_file_num_labels(cf);
+            for (uint32_t j = 0; j < nl; ++j) label_names.emplace_back(mgx_column_file_label(cf, j));
+            const uint64_t *cb = mgx_column_file_col_begin(cf), *rw = mgx_column_file_rows(cf);
+            const uint64_t n_rows = mgx_column_file_num_rows(cf);
+            std::vector<uint64_t> col_begin(cb, cb + nl + 1), rows(rw, rw + cb[nl]);
+            mgx_column_file_free(cf);
+            // AnnotatedDBG::check_compatibility (annotated_dbg.cpp): one row per node
+            if (n_rows != n) { fprintf(stderr, "error: the annotation has %llu rows, the graph %llu nodes\n", (unsigned long long)n_rows, (unsigned long long)n); return 1; }
+            annotation = std::make_unique<HipAnnotation>(n_rows, col_begin, rows, 0);
+        } else if (!anno_paths.empty()) {
+            const char *anno_path = anno_paths[0];
             std::ifstream ain(anno_path, std::ios::binary);
             if (!ain) { fprintf(stderr, "cannot open %s\n", anno_path); return 1; }
             uint64_t n_rows = 0, n_labels = 0;

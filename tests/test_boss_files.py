@@ -1,0 +1,264 @@
+"""The readers of the reference's own files (csrc/boss_files.hpp behind mgx_boss_file_read / mgx_column_file_read; host code,
+no GPU): pinned on the four files the reference wrote itself (examples/data/graphs: a DNA and a protein graph in the SMALL
+state, their ColumnCompressed annotations), then on files of the same layout written by tests/sdsl_writer.py — whose rrr, sd and
+stat encoders reproduce the reference-written bytes — for the states and sizes those four do not cover."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import orc
+import sdsl_writer as sw
+from metagraph_amd import aligner as A
+from metagraph_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def read_fasta(path):
+    out, cur = [], []
+    for line in open(path):
+        line = line.strip()
+        if line.startswith(">"):
+            if cur:
+                out.append("".join(cur))
+            cur = []
+        elif line:
+            cur.append(line)
+    if cur:
+        out.append("".join(cur))
+    return out
+
+
+def test_reference_written_dna_graph_decodes_to_the_builders_table():
+    """test_DNA_graph.dbg (SMALL state: wt_huff<rrr_vector<63>> + rrr last) -> exactly the W / last / F our fixture builder
+    makes of test_DNA_sequences.fa: pins the rrr decoder (enumeration order, complemented dense blocks), the tree walk and
+    the builder's edge order on a table the reference built."""
+    f = A.read_boss_file(os.path.join(GOLD, "test_DNA_graph.dbg"))
+    assert (f["k"], f["sigma"], f["mode"], f["state"], f["n_edges"]) == (20, 5, 0, 1, 25)
+    g = orc.Graph.build(20, read_fasta(os.path.join(GOLD, "test_DNA_sequences.fa")), 0, False)
+    W, last, F, _ = g.export()
+    assert f["F"] == [int(x) for x in F]
+    assert np.array_equal(f["W"], np.asarray(W, dtype=np.uint8))
+    assert np.array_equal(f["last"], np.asarray(last, dtype=np.uint8))
+
+
+def test_reference_written_protein_graph_is_a_consistent_boss_table():
+    """test_Protein_graph.dbg: 27 characters, a 500-bit (8-block) rrr level vector with sparse and dense blocks.  The decoded
+    table must be a BOSS table: for every character c, the edges labelled c (unflagged) are as many as the nodes ending in c
+    (the ones of `last` inside F's range of c) — the bijection fwd() relies on."""
+    f = A.read_boss_file(os.path.join(GOLD, "test_Protein_graph.dbg"))
+    assert (f["k"], f["sigma"], f["mode"], f["state"], f["n_edges"]) == (20, 27, 0, 1, 118)
+    W, last, F = f["W"], f["last"], f["F"] + [118]
+    assert last[0] == 0 and W[0] == 0
+    for c in range(1, 27):
+        assert int((W == c).sum()) == int(last[F[c] + 1:F[c + 1] + 1].sum()), c
+    assert int((W >= 27).sum()) + int((W[1:] < 27).sum()) == 118
+    with pytest.raises(A.MgxError) as e:             # the device index is DNA only — refused before any device call
+        A.Graph.load(os.path.join(GOLD, "test_Protein_graph.dbg"))
+    assert e.value.code == capi.MGX_ERR_UNSUPPORTED and "alphabet" in str(e.value)
+
+
+def test_reference_written_annotations():
+    """test_DNA_graph.column.annodbg (legacy label encoder; one sd_vector column, stored inverted) and
+    test_Protein_graph.column.annodbg (one bit_vector_stat column: plain vector + rank_support_v5 + select_support_mcl):
+    parsed to the last byte; the DNA column is the set of nodes the annotated sequences map to."""
+    n, names, cb, rows = A.read_column_files([os.path.join(GOLD, "test_DNA_graph.column.annodbg")])
+    assert (n, names, cb.tolist()) == (25, ["test_DNA_sequences.fa"], [0, 24])
+    seqs = read_fasta(os.path.join(GOLD, "test_DNA_sequences.fa"))
+    g = orc.Graph.build(20, seqs, 0, False)
+    ann = orc.Annotation(g, 1)
+    for s in seqs:
+        ann.annotate(s, 0)                                         # AnnotatedDBG::annotate_sequence; row = node - 1
+    words = ann.column_words(0)
+    assert [r for r in range(25) if (int(words[r >> 6]) >> (r & 63)) & 1] == rows.tolist()
+    n, names, cb, rows = A.read_column_files([os.path.join(GOLD, "test_Protein_graph.column.annodbg")])
+    assert (n, names, len(rows)) == (118, ["test_Protein_sequences.fa"], 57)
+    assert np.all(np.diff(rows.astype(np.int64)) > 0) and rows[-1] < 118
+
+
+def test_writer_reproduces_the_reference_written_bytes():
+    """tests/sdsl_writer.py against the reference's files: both annotation files whole, and the two rrr vectors and the tail
+    (mode + empty suffix-range index) of the DNA graph — so the files it writes for the other tests are the reference's layout."""
+    for name, code in (("DNA", sw.CODE_SD), ("Protein", sw.CODE_STAT)):
+        path = os.path.join(GOLD, "test_%s_graph.column.annodbg" % name)
+        n, names, cb, rows = A.read_column_files([path])
+        assert sw.column_file(n, names, [rows], codes=[code]) == open(path, "rb").read()
+    gold = open(os.path.join(GOLD, "test_DNA_graph.dbg"), "rb").read()
+    f = A.read_boss_file(os.path.join(GOLD, "test_DNA_graph.dbg"))
+    last = [int(x) for x in f["last"]]
+    mine = sw.dbg_file(f["k"], f["W"], last, f["F"], mode=0, state=sw.STATE_SMALL)
+    assert mine[:80] == gold[:80]                                   # F, k, state, size, sigma
+    # (the offsets below are of the golden file: 2921 logsigma, 2929 the representation code of `last`)
+    assert gold[2929:2937] == sw.be(sw.CODE_RRR)
+    r = sw.rrr_vector63(last)
+    assert gold[2937:2937 + len(r)] == r
+    assert gold[2937 + len(r):] == mine[-58:] and len(gold) == 2937 + len(r) + 58
+    # the level bit vector of W under the golden file's own tree: path[] (bit j = the j-th turn), bytes 873..2921
+    path = {c: struct.unpack_from("<Q", gold, 873 + 8 * c)[0] for c in range(5)}
+    turns = {c: [(p >> j) & 1 for j in range(p >> 56)] for c, p in path.items()}
+    W = [int(x) for x in f["W"]]
+    levels = [turns[w][0] for w in W]
+    for prefix in ([0], [1], [1, 1]):
+        levels += [turns[w][len(prefix)] for w in W if turns[w][:len(prefix)] == prefix and len(turns[w]) > len(prefix)]
+    r = sw.rrr_vector63(levels)
+    assert gold[80:80 + len(r)] == r and 80 + len(r) == 155
+
+
+def random_table(rng, k, n_seqs, length, mode=0):
+    seqs = ["".join(rng.choice(list("ACGT"), size=length)) for _ in range(n_seqs)]
+    g = orc.Graph.build(k, seqs, mode, False)
+    W, last, F, _ = g.export()
+    return np.asarray(W, dtype=np.uint8), np.asarray(last, dtype=np.uint8), [int(x) for x in F]
+
+
+@pytest.mark.parametrize("state,last_code", [(sw.STATE_SMALL, sw.CODE_RRR), (sw.STATE_SMALL, sw.CODE_SD), (sw.STATE_STAT, None), (sw.STATE_FAST, None)])
+def test_written_graphs_round_trip(tmp_path, state, last_code):
+    """every readable state, tables of a few thousand edges (dozens of rrr blocks, `last` dense enough for all-ones blocks),
+    the three graph modes, with and without the suffix-range index behind the mode"""
+    rng = np.random.default_rng(7 + state)
+    for case in range(4):
+        k = int(rng.integers(4, 12))
+        W, last, F = random_table(rng, k, int(rng.integers(1, 5)), int(rng.integers(30, 900)))
+        mode = case % 3
+        path = tmp_path / ("g%d.dbg" % case)
+        path.write_bytes(sw.dbg_file(k, W, last, F, mode=mode, state=state, last_code=last_code or sw.CODE_RRR, suffix_index=case != 3))
+        f = A.read_boss_file(path)
+        assert (f["k"], f["mode"], f["state"], f["n_edges"], f["F"]) == (k, mode, state, len(W) - 1, F)
+        assert np.array_equal(f["W"], W) and np.array_equal(f["last"], last)
+
+
+def test_rrr_blocks_of_every_class(tmp_path):
+    """`last` vectors made of blocks with 0, 1, ..., 63 ones (and a ragged final block), through the SMALL state"""
+    rng = np.random.default_rng(11)
+    bits = [0]
+    for k in list(range(64)) + [63, 0, 63, 31, 32]:
+        blk = [1] * k + [0] * (63 - k)
+        rng.shuffle(blk)
+        bits += blk
+    bits = bits[:-17]
+    n = len(bits)
+    W = rng.integers(0, 10, size=n).astype(np.uint8)
+    W[0] = 0
+    path = tmp_path / "classes.dbg"
+    path.write_bytes(sw.dbg_file(9, W, bits, [0, 1, 2, 3, n - 1], state=sw.STATE_SMALL))
+    f = A.read_boss_file(path)
+    assert f["last"].tolist() == bits and np.array_equal(f["W"], W)
+
+
+def test_select_supports_over_many_arguments(tmp_path):
+    """more than 4096 ones and zeros: several select superblocks (long and mini), in `last` (STAT) and in an sd column"""
+    rng = np.random.default_rng(5)
+    n = 20000
+    last = (rng.random(n) < 0.7).astype(np.uint8)
+    last[0] = 0
+    W = rng.integers(0, 10, size=n).astype(np.uint8)
+    W[0] = 0
+    path = tmp_path / "big.dbg"
+    path.write_bytes(sw.dbg_file(12, W, last, [0, 5, 50, 500, 5000], mode=2, state=sw.STATE_STAT))
+    f = A.read_boss_file(path)
+    assert np.array_equal(f["last"], last) and np.array_equal(f["W"], W) and f["mode"] == 2
+    cols = [np.flatnonzero(rng.random(n) < p) for p in (0.4, 0.9, 0.001, 0.0)]
+    ap = tmp_path / "big.column.annodbg"
+    ap.write_bytes(sw.column_file(n, ["a", "b", "c", "d"], cols, codes=[sw.CODE_SD, sw.CODE_SD, sw.CODE_SD, sw.CODE_SD], v2=True))
+    nr, names, cb, rows = A.read_column_files([ap])
+    assert (nr, names) == (n, ["a", "b", "c", "d"])
+    for j, c in enumerate(cols):
+        assert np.array_equal(rows[int(cb[j]):int(cb[j + 1])], c.astype(np.uint64))
+
+
+@pytest.mark.parametrize("v2", [False, True])
+def test_written_annotations_round_trip(tmp_path, v2):
+    """both label-encoder formats; sd (plain and inverted), stat and rrr columns; a long label; several files side by side"""
+    rng = np.random.default_rng(3 + v2)
+    n = 777
+    labels = ["sample_%d" % j for j in range(5)] + ["x" * 300]
+    cols = [np.flatnonzero(rng.random(n) < p) for p in (0.01, 0.5, 0.95, 0.0, 1.0, 0.3)]
+    codes = [sw.CODE_SD, sw.CODE_STAT, sw.CODE_SD, sw.CODE_SD, sw.CODE_SD, sw.CODE_RRR]
+    a, b = tmp_path / "a.column.annodbg", tmp_path / "b.column.annodbg"
+    a.write_bytes(sw.column_file(n, labels[:4], cols[:4], codes=codes[:4], v2=v2))
+    b.write_bytes(sw.column_file(n, labels[4:], cols[4:], codes=codes[4:], v2=v2))
+    nr, names, cb, rows = A.read_column_files([a, b])
+    assert (nr, names) == (n, labels)
+    for j, c in enumerate(cols):
+        assert np.array_equal(rows[int(cb[j]):int(cb[j + 1])], c.astype(np.uint64)), j
+    with pytest.raises(A.MgxError) as e:             # the same label in two files
+        A.read_column_files([a, a])
+    assert e.value.code == capi.MGX_ERR_UNSUPPORTED
+    c = tmp_path / "c.column.annodbg"
+    c.write_bytes(sw.column_file(n + 1, ["other"], [[0]], v2=v2))
+    with pytest.raises(A.MgxError) as e:             # files over different rows
+        A.read_column_files([a, c])
+    assert e.value.code == capi.MGX_ERR_INVALID and "rows" in str(e.value)
+
+
+def test_malformed_files_are_errors_not_crashes(tmp_path):
+    """every truncation of a small graph / annotation file and 3000 single-byte corruptions: MGX_ERR_INVALID / UNSUPPORTED
+    with a message, or a table that still passes the reader's checks — never a crash, never an out-of-bounds read"""
+    rng = np.random.default_rng(1)
+    W, last, F = random_table(rng, 6, 2, 60)
+    files = [(sw.dbg_file(6, W, last, F, state=st, last_code=lc), A.read_boss_file, ".dbg")
+             for st, lc in ((sw.STATE_SMALL, sw.CODE_RRR), (sw.STATE_SMALL, sw.CODE_SD), (sw.STATE_STAT, sw.CODE_RRR), (sw.STATE_FAST, sw.CODE_RRR))]
+    files.append((sw.column_file(90, ["a", "b", "c"], [[1, 5, 80], list(range(0, 90, 2)), list(range(85))],
+                                 codes=[sw.CODE_SD, sw.CODE_STAT, sw.CODE_RRR]), lambda p: A.read_column_files([p]), ".column.annodbg"))
+    p = tmp_path / "x"
+    for data, read, ext in files:
+        path = str(p) + ext
+        open(path, "wb").write(data)
+        read(path)
+        mode_at = len(data) - 58 if ext == ".dbg" else len(data)
+        for cut in range(0, len(data), 1 if len(data) < 6000 else 7):
+            open(path, "wb").write(data[:cut])
+            if ext == ".dbg" and cut >= mode_at + 8:
+                read(path)                                    # whatever follows the mode is not read
+                continue
+            with pytest.raises(A.MgxError) as e:
+                read(path)
+            assert e.value.code in (capi.MGX_ERR_INVALID, capi.MGX_ERR_UNSUPPORTED) and str(e.value)
+        for _ in range(600):
+            bad = bytearray(data)
+            at = int(rng.integers(0, len(bad)))
+            bad[at] ^= 1 << int(rng.integers(0, 8))
+            open(path, "wb").write(bytes(bad))
+            try:
+                read(path)
+            except A.MgxError as e:
+                assert e.code in (capi.MGX_ERR_INVALID, capi.MGX_ERR_UNSUPPORTED)
+    with pytest.raises(A.MgxError):
+        A.read_boss_file(tmp_path / "does_not_exist.dbg")
+    dyn = bytearray(files[0][0])
+    dyn[6 * 8 + 8 + 7] = sw.STATE_DYN                        # the state word
+    open(str(p) + ".dbg", "wb").write(bytes(dyn))
+    with pytest.raises(A.MgxError) as e:
+        A.read_boss_file(str(p) + ".dbg")
+    assert e.value.code == capi.MGX_ERR_UNSUPPORTED and "DYN" in str(e.value)
+
+
+def test_reader_under_sanitizers(tmp_path):
+    """the parser itself compiled with -fsanitize=address,undefined over 4 x 20 000 mutated files (truncations, bit flips,
+    overwritten and inserted fields) of every container kind: no out-of-bounds access, no overflow, no leak"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "files_fuzz")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe,
+                    os.path.join(HERE, "files_fuzz.cpp")], check=True)
+    rng = np.random.default_rng(2)
+    W, last, F = random_table(rng, 7, 3, 150)
+    cases = [("dbg", sw.dbg_file(7, W, last, F, state=sw.STATE_SMALL, last_code=sw.CODE_RRR)),
+             ("dbg", sw.dbg_file(7, W, last, F, state=sw.STATE_SMALL, last_code=sw.CODE_SD)),
+             ("dbg", sw.dbg_file(7, W, last, F, state=sw.STATE_STAT)),
+             ("dbg", sw.dbg_file(7, W, last, F, state=sw.STATE_FAST)),
+             ("dbg", open(os.path.join(GOLD, "test_Protein_graph.dbg"), "rb").read()),
+             ("columns", sw.column_file(300, ["a", "b", "c", "d"], [[1, 5, 80], list(range(0, 300, 2)), list(range(285)), [7]],
+                                        codes=[sw.CODE_SD, sw.CODE_STAT, sw.CODE_RRR, sw.CODE_SD], v2=True)),
+             ("columns", open(os.path.join(GOLD, "test_DNA_graph.column.annodbg"), "rb").read())]
+    for i, (kind, data) in enumerate(cases):
+        path = tmp_path / ("f%d" % i)
+        path.write_bytes(data)
+        r = subprocess.run([exe, kind, str(path), "20000", str(i + 1)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:allocator_may_return_null=1"))
+        assert r.returncode == 0, (kind, i, r.stdout[-500:], r.stderr[-3000:])
