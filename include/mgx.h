@@ -370,8 +370,8 @@ int mgx_results_from_raw_labeled(const void *headers, uint64_t n_queries, const 
  * (annotate_column_compressed.cpp:436-481,493-640); inside MetaGraph the adapter takes both from the loaded objects
  * (INTEGRATION.md 2).  Read: BOSS states SMALL, STAT and FAST (DYN: MGX_ERR_UNSUPPORTED), any alphabet in
  * mgx_boss_file_read (the device index itself is DNA only); columns stored as sd_vector, bit_vector_stat or rrr_vector<63>
- * (bit_vector_smart writes the first two), both label-encoder formats.  The `.edgemask` file next to a `.dbg` is not read:
- * `metagraph align` drops the mask (cli/align.cpp:337-339).  Which layouts are pinned on reference-written files:
+ * (bit_vector_smart writes the first two), both label-encoder formats.  The `.edgemask` next
+ * to a `.dbg`: mgx_edgemask_read.  Which layouts are pinned on reference-written files:
  * csrc/boss_files.hpp.  Malformed file: MGX_ERR_INVALID with the field named in mgx_last_error; the *_read calls need no GPU.
  */
 typedef struct mgx_boss_file {
@@ -387,6 +387,11 @@ typedef struct mgx_boss_file {
 } mgx_boss_file;
 int mgx_boss_file_read(const char *path, mgx_boss_file *out);
 void mgx_boss_file_free(mgx_boss_file *f);
+/* The `.edgemask` file next to a `.dbg` (dbg_succinct.cpp:719-752) as mgx_boss_view.valid bytes: valid_out has n_edges + 1
+ * entries; `state` = mgx_boss_file.state of the graph (it decides the mask's vector type).  mgx_graph_load_dbg does not apply
+ * it — `metagraph align` resets the mask after loading (cli/align.cpp:337-339); a caller that keeps the mask builds the view
+ * from mgx_boss_file_read + this. */
+int mgx_edgemask_read(const char *path, uint32_t state, uint64_t n_edges, uint8_t *valid_out);
 /* mgx_boss_file_read + mgx_graph_create: DBGSuccinct::load for the device */
 int mgx_graph_load_dbg(const char *path, int device, mgx_graph **out);
 

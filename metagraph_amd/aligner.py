@@ -44,6 +44,13 @@ def read_boss_file(path, arrays=True):
         L.mgx_boss_file_free(C.byref(f))
 
 
+def read_edgemask(path, state, n_edges):
+    """mgx_edgemask_read (host only): the valid-edge bytes (mgx_boss_view.valid) of the `.edgemask` next to a `.dbg`"""
+    out = np.zeros(n_edges + 1, dtype=np.uint8)
+    _check(capi.lib().mgx_edgemask_read(str(path).encode(), state, n_edges, out.ctypes.data))
+    return out
+
+
 def read_column_files(paths):
     """mgx_column_file_read (host only): (n_rows, label names, col_begin, rows) of one or several `.column.annodbg` files."""
     L = capi.lib()

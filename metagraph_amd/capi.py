@@ -184,6 +184,7 @@ def lib():
     L.mgx_device_count.restype = C.c_int
     L.mgx_boss_file_read.argtypes = [C.c_char_p, C.POINTER(BossFile)]
     L.mgx_boss_file_free.argtypes = [C.POINTER(BossFile)]
+    L.mgx_edgemask_read.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64, C.c_void_p]
     L.mgx_graph_load_dbg.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.mgx_column_file_read.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_void_p)]
     L.mgx_column_file_free.argtypes = [C.c_void_p]

@@ -360,6 +360,18 @@ inline BossFile read_dbg(const std::string &path) {
     return parse_dbg(buf.data(), buf.size());
 }
 
+// The `.edgemask` next to a `.dbg` (DBGSuccinct::load, dbg_succinct.cpp:719-752): the valid-edge bits, n_edges + 1 of them with
+// bit 0 clear; a bit_vector_stat for FAST-state graphs, a bit_vector_small otherwise (:724-741).  `metagraph align` drops the
+// mask after loading (cli/align.cpp:337-339); callers that keep it (the unit tests' masked graphs) pass it as mgx_boss_view.valid.
+inline std::vector<uint8_t> parse_edgemask(const uint8_t *data, size_t n, uint32_t state, uint64_t n_edges) {
+    Cursor c(data, n);
+    const Bits v = state == STATE_FAST ? read_bit_vector_stat(c, "edge mask") : read_adaptive(c, "edge mask", n_edges + 1);
+    if (v.bits != n_edges + 1 || v.bit(0)) throw ParseError("edge mask is not compatible with the graph");      // :749-752
+    std::vector<uint8_t> out(n_edges + 1);
+    for (uint64_t i = 0; i <= n_edges; ++i) out[i] = v.bit(i);
+    return out;
+}
+
 struct ColumnFile {
     uint64_t n_rows = 0;
     std::vector<std::string> labels;

@@ -58,6 +58,16 @@ void mgx_boss_file_free(mgx_boss_file *f) {
     memset(f, 0, sizeof(*f));
 }
 
+int mgx_edgemask_read(const char *path, uint32_t state, uint64_t n_edges, uint8_t *valid_out) {
+    if (!path || !valid_out) return ffail(MGX_ERR_INVALID, "mgx_edgemask_read: bad arguments");
+    return guarded(path, [&]() {
+        const std::vector<uint8_t> buf = mgx::files::read_whole_file(path);
+        const std::vector<uint8_t> v = mgx::files::parse_edgemask(buf.data(), buf.size(), state, n_edges);
+        memcpy(valid_out, v.data(), v.size());
+        return (int)MGX_OK;
+    });
+}
+
 int mgx_graph_load_dbg(const char *path, int device, mgx_graph **out) {
     if (!path || !out) return ffail(MGX_ERR_INVALID, "mgx_graph_load_dbg: bad arguments");
     mgx_boss_file f;

@@ -271,3 +271,13 @@ def column_file(n_rows, labels, columns, codes=None, v2=False):
         bits = [1 if r in s else 0 for r in range(n_rows)]
         out += adaptive(bits, codes[j] if codes else CODE_SD)
     return out
+
+
+def edgemask_file(valid, state):
+    """the `.edgemask` of DBGSuccinct::serialize: a bit_vector_stat next to a FAST-state graph, a bit_vector_small otherwise
+    (the smaller of sd and rrr; here: sd when few edges are masked or few are valid)"""
+    bits = [int(b) for b in valid]
+    if state == STATE_FAST:
+        return bit_vector_stat(bits)
+    ones = sum(bits)
+    return adaptive(bits, CODE_SD if min(ones, len(bits) - ones) * 8 < len(bits) else CODE_RRR)

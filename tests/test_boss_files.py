@@ -262,3 +262,26 @@ def test_reader_under_sanitizers(tmp_path):
         r = subprocess.run([exe, kind, str(path), "20000", str(i + 1)], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:allocator_may_return_null=1"))
         assert r.returncode == 0, (kind, i, r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("state", [sw.STATE_SMALL, sw.STATE_STAT, sw.STATE_FAST])
+def test_edgemask_round_trip(tmp_path, state):
+    """the valid-edge mask next to a graph file (dbg_succinct.cpp:719-752): the builder's dummy mask through every vector type"""
+    rng = np.random.default_rng(state)
+    seqs = ["".join(rng.choice(list("ACGT"), size=400)) for _ in range(3)]
+    g = orc.Graph.build(9, seqs, 0, True)                      # mask_dummy_kmers
+    W, last, F, valid = g.export()
+    assert valid is not None and 0 < int(np.asarray(valid).sum()) < len(W) - 1
+    for v in (np.asarray(valid, dtype=np.uint8), (rng.random(len(W)) < 0.5).astype(np.uint8)):
+        v[0] = 0
+        path = tmp_path / "m.edgemask"
+        path.write_bytes(sw.edgemask_file(v, state))
+        assert np.array_equal(A.read_edgemask(path, state, len(W) - 1), v)
+    with pytest.raises(A.MgxError) as e:                       # a mask of another graph
+        A.read_edgemask(path, state, len(W))
+    assert e.value.code == capi.MGX_ERR_INVALID
+    v[0] = 1
+    path.write_bytes(sw.edgemask_file(v, state))
+    with pytest.raises(A.MgxError) as e:                       # slot 0 marked valid (:749)
+        A.read_edgemask(path, state, len(W) - 1)
+    assert e.value.code == capi.MGX_ERR_INVALID and "compatible" in str(e.value)
