@@ -231,6 +231,8 @@ uint32_t mgx_graph_k(const mgx_graph *g);            /* DeBruijnGraph::get_k  (s
 uint64_t mgx_graph_max_index(const mgx_graph *g);    /* DeBruijnGraph::max_index (dbg_succinct.cpp:686-688); PRIMARY: 2 x that,
                                                       * as CanonicalDBG::max_index (canonical_dbg.hpp:96) */
 uint64_t mgx_graph_device_bytes(const mgx_graph *g);
+uint64_t mgx_graph_num_edges(const mgx_graph *g);    /* boss::BOSS::num_edges: the edges of the stored table (PRIMARY: not doubled) */
+uint32_t mgx_graph_mode(const mgx_graph *g);         /* MGX_MODE_* the graph was created (or loaded) with */
 
 /* DBGAligner<>::DBGAligner(graph, config) (dbg_aligner.cpp:33-61): clamps seed lengths,
  * validates scores.  `limits` may be NULL (defaults for 512-bp reads). */

@@ -103,8 +103,7 @@ class Graph:
         self.h = C.c_void_p()
         _check(capi.lib().mgx_graph_load_dbg(str(path).encode(), device, C.byref(self.h)))
         self.k = capi.lib().mgx_graph_k(self.h)
-        f = read_boss_file(path, arrays=False)
-        self.n_edges, self.mode = f["n_edges"], f["mode"]
+        self.n_edges, self.mode = capi.lib().mgx_graph_num_edges(self.h), capi.lib().mgx_graph_mode(self.h)
         return self
 
     def close(self):

@@ -206,6 +206,10 @@ def lib():
     L.mgx_graph_max_index.argtypes = [C.c_void_p]
     L.mgx_graph_max_index.restype = C.c_uint64
     L.mgx_graph_device_bytes.argtypes = [C.c_void_p]
+    L.mgx_graph_num_edges.argtypes = [C.c_void_p]
+    L.mgx_graph_num_edges.restype = C.c_uint64
+    L.mgx_graph_mode.argtypes = [C.c_void_p]
+    L.mgx_graph_mode.restype = C.c_uint32
     L.mgx_graph_device_bytes.restype = C.c_uint64
     L.mgx_aligner_create.argtypes = [C.c_void_p, C.POINTER(Config), C.POINTER(Limits), C.POINTER(C.c_void_p)]
     L.mgx_aligner_destroy.argtypes = [C.c_void_p]

@@ -668,6 +668,8 @@ uint64_t mgx_graph_max_index(const mgx_graph *g) {
     return g->mode == MGX_MODE_PRIMARY ? 2 * g->g.n : g->g.n;            // CanonicalDBG::max_index (canonical_dbg.hpp:96)
 }
 uint64_t mgx_graph_device_bytes(const mgx_graph *g) { return g->bytes; }
+uint64_t mgx_graph_num_edges(const mgx_graph *g) { return g->g.n; }
+uint32_t mgx_graph_mode(const mgx_graph *g) { return g->mode; }
 
 // ------------------------------------------------------------------------------------------------
 // aligner
