@@ -38,7 +38,7 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)      # (8: the fill and drain of the host-side double buffering amortised, ~10 s)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=int(os.environ.get("MGX_BENCH_READS", 10_000_000)))
     ap.add_argument("--genome", type=int, default=int(os.environ.get("MGX_BENCH_GENOME", 98_000_000)))
