@@ -1457,7 +1457,13 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                         if (need && w.rng[s]) known = (int32_t)ml;
                     }
                 }
-                if (need && tail_known && i >= w.n_kmers && max_len == L - i && max_len >= msl0) {
+                // (MANY: not deferred.  With a full seed at every matched k-mer the last-full-seed rule below (:240-244) drops the
+                // tail positions' seeds one after the other without raising msl[] behind them, so ALL of them report and each
+                // deferred range was a walk of ~25 dependent steps by the whole wavefront — 40 % of the label-aware seeding kernel,
+                // profiles/r04_ab7_seed_sections.txt; here the tail positions walk side by side, one per lane.)
+                // (Few seeds: only the first tail position reports, and raises msl[] for those behind it; looking it up here instead
+                // moves 12 ms per 2 M reads from the bookkeeping to this loop and saves 1 — same file.)
+                if (!MANY && need && tail_known && i >= w.n_kmers && max_len == L - i && max_len >= msl0) {
                     mlen = (uint16_t)max_len;
                     rf = DEFERRED_RANGE;
                     need = false;

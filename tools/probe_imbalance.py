@@ -27,6 +27,8 @@ torch.cuda.empty_cache()
 cfg = capi.config_cli(k)
 if os.environ.get("PROBE_NO_SDUST"):           # ablation (different results): what does the complexity filter cost k_seed?
     cfg.seed_complexity_filter = 0
+if os.environ.get("PROBE_MAX_SEED_K"):         # the seeding of label-aware alignment (LabeledAligner clamps max_seed_length to k: one seed per k-mer)
+    cfg.max_seed_length = k
 A = aligner.Aligner(G, cfg)
 
 
