@@ -2909,7 +2909,11 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         return FR_FALLBACK;
     }
     if (x.tsize >= x.max_columns - 1) { w.status = ST_CAPACITY; return FR_ERROR; }
-    if ((uint64_t)x.cell_top + rec_words((uint32_t)(window_size + 1 - begin + 8)) > x.cell_words) { w.status = ST_CAPACITY; return FR_ERROR; }
+    // (room for the record a column that stays behind in the frontier writes below: always a whole chain window of CHW cells, which
+    // near the read's end is MORE than the window-sized record the general path would need — with only the latter tested, such a
+    // record ran past the cell arena into the first column slots when the arena was nearly full; found by the fuzz campaign's
+    // address-sanitized run; tests/test_fuzz_smoke.py keeps the world)
+    if ((uint64_t)x.cell_top + imax<uint32_t>(rec_words((uint32_t)(window_size + 1 - begin + 8)), rec_words((uint32_t)CHW)) > x.cell_words) { w.status = ST_CAPACITY; return FR_ERROR; }
     // move the parent window to the child's origin (whole lanes)
     // (the parent's cell just below the new origin — under the cut-off, but the match flag of the origin cell compares
     // against its true value)
@@ -3302,6 +3306,9 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
         // ... and, for a column that stays behind in the frontier, its window as an S / F record
         if (deferred) {
             int32_t *rec = w.cells + x.cell_top;
+#if MGX_WAVE_EMU
+            if ((uint64_t)x.cell_top + rec_words((uint32_t)CHW) > x.cell_words) { fprintf(stderr, "chain_step: S / F record past the cell arena\n"); abort(); }
+#endif
             FOR_LANES(l) {
                 if (4 * l < CHW) {
                     gst4(rec + 4 * l, cS[0][l], cS[1][l], cS[2][l], cS[3][l]);

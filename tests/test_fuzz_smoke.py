@@ -12,3 +12,14 @@ def test_fuzzer_runs_clean_for_ten_seconds():
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "no difference" in r.stdout
+
+
+def test_deferred_chain_record_stays_inside_the_cell_arena():
+    """World 504 of the lane campaign's seed 9404 (k = 7, reads of 7 to 154 bp, small arenas): a chain column that stays behind
+    in the frontier writes a whole chain window's S / F record, and chain_step tested the cell arena for the smaller, window-sized
+    record only — near a read's end the record ran into the first column slots (found under -fsanitize=address as a wild read in
+    the trace walk).  The host model aborts on a record past the arena, whatever the arena's layout."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_emu.py"), "--seed", "9404", "--lane", "--start", "504", "--worlds", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "no difference" in r.stdout
