@@ -592,7 +592,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 #pragma unroll
                             for (int q4 = 0; q4 < 4; ++q4) {
                                 const int32_t sv = S[4 * b + q4];
-                                const int32_t d = sv - base;
+                                const int32_t d = (int32_t)((uint32_t)sv - (uint32_t)base);      // (sv may be ninf: its d is not used, but must not overflow)
                                 wide |= sv != NINF && d < -127;
                                 v |= (sv == NINF ? 0x80u : ((uint32_t)d & 0xFFu)) << (8 * q4);
                             }
