@@ -499,6 +499,17 @@ MGX_HD uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
 constexpr uint32_t LAB_MAX_QUEUES = 64;
 MGX_HD uint64_t lab_agg_words(const DevLimits &lim) { return 16 + (uint64_t)LAB_MAX_QUEUES * 8 + lim.lab_pool + 8 + (LAB_MAX_QUEUES * 4 + 16) + lim.lab_pool + 8; }
 
+// Test builds only (tools/fuzz_asan.sh: the host model under -fsanitize=address with -DMGX_ARENA_REDZONE=64): a poisoned gap behind
+// each of the arena's larger arrays, so that an index past the end of one is reported instead of landing in its neighbour — the
+// sanitizer by itself only sees the arena as one allocation.  0 in every product build: no gap, same layout.
+#ifndef MGX_ARENA_REDZONE
+#define MGX_ARENA_REDZONE 0
+#endif
+constexpr uint64_t ARENA_REDZONES = 16;                 // take_rz() calls of carve()
+#if MGX_ARENA_REDZONE
+#include <sanitizer/asan_interface.h>
+#endif
+
 // byte size of one wave's arena slice
 MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     uint64_t L = lim.Lmax, Lp = align8(L + 8);
@@ -532,6 +543,7 @@ MGX_HD uint64_t arena_bytes(const DevLimits &lim) {
     if (lim.lab_words)                                  // label-aware alignment: set arena, column / seed handles, aggregator queues
         b += align8((uint64_t)lim.lab_words * 4) + align8((uint64_t)lim.max_columns * 4) + 2 * align8((uint64_t)lim.max_seeds * 4)
              + align8(lab_agg_words(lim) * 4);
+    b += ARENA_REDZONES * MGX_ARENA_REDZONE;
     return (b + 63) & ~63ull;          // slices keep the 32-byte alignment of the hash slots and the 16-byte one of the cell records
 }
 
@@ -551,6 +563,11 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     uint8_t *lp = lds;
     uint32_t lleft = lds_bytes;
     auto take = [&](uint64_t bytes) { uint8_t *r = p; p += align8(bytes); return r; };
+#if MGX_ARENA_REDZONE
+    auto take_rz = [&](uint64_t bytes) { uint8_t *r = p; p += align8(bytes); ASAN_POISON_MEMORY_REGION(p, MGX_ARENA_REDZONE); p += MGX_ARENA_REDZONE; return r; };
+#else
+    auto take_rz = take;
+#endif
     auto take_fast = [&](uint64_t bytes) {
         uint64_t b8 = align8(bytes);
         uint8_t *r = p;
@@ -605,23 +622,23 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     if (lleft_seed_end < lleft) { lp = lp_seed_end; lleft = lleft_seed_end; }     // past the larger side of the overlay
     for (int s = 0; s < 2; ++s) w.pk[s] = (uint32_t *)take_fast(((L + 15) / 16 + 2) * 4);
     for (int s = 0; s < 2; ++s) w.psum[s] = (int32_t *)take_fast((L + 1) * 4);
-    for (int s = 0; s < 2; ++s) w.seeds[s] = (DevSeed *)take((uint64_t)lim.max_seeds * sizeof(DevSeed));
-    for (int s = 0; s < 2; ++s) w.alive[s] = take(lim.max_seeds);
-    w.alt = (uint32_t *)take((uint64_t)lim.max_alt * 4);
+    for (int s = 0; s < 2; ++s) w.seeds[s] = (DevSeed *)take_rz((uint64_t)lim.max_seeds * sizeof(DevSeed));
+    for (int s = 0; s < 2; ++s) w.alive[s] = take_rz(lim.max_seeds);
+    w.alt = (uint32_t *)take_rz((uint64_t)lim.max_alt * 4);
     p = (uint8_t *)(((uint64_t)p + 15) & ~15ull);                // cell records are written with 16-byte stores
-    w.cells = (int32_t *)take((uint64_t)lim.cell_words * 4);
+    w.cells = (int32_t *)take_rz((uint64_t)lim.cell_words * 4);
     p = (uint8_t *)(((uint64_t)p + 63) & ~63ull);                // a chain-format slot is exactly two 64-byte lines
-    w.cols = (ColSlot *)take((uint64_t)lim.max_columns * sizeof(ColSlot));
+    w.cols = (ColSlot *)take_rz((uint64_t)lim.max_columns * sizeof(ColSlot));
     p = (uint8_t *)(((uint64_t)p + 63) & ~63ull);
-    w.cols_s16 = (int16_t *)take((uint64_t)lim.max_columns * FWS * 2);
-    w.queue = (uint64_t *)take((uint64_t)lim.max_columns * 8);
-    w.next_nodes = (uint64_t *)take((uint64_t)lim.max_columns * 8);
-    w.tips = (uint32_t *)take((uint64_t)lim.max_columns * 4);
-    w.prev_starts = (uint32_t *)take(((uint64_t)lim.max_columns + 31) / 32 * 4);
-    w.indices = (BtIndex *)take((uint64_t)lim.max_columns * 2 * sizeof(BtIndex));
-    w.rev_ops = (uint32_t *)take((uint64_t)lim.max_path * 4);
-    w.rev_nodes = (uint32_t *)take((uint64_t)lim.max_path * 4);
-    w.rev_seq = take(lim.max_path);
+    w.cols_s16 = (int16_t *)take_rz((uint64_t)lim.max_columns * FWS * 2);
+    w.queue = (uint64_t *)take_rz((uint64_t)lim.max_columns * 8);
+    w.next_nodes = (uint64_t *)take_rz((uint64_t)lim.max_columns * 8);
+    w.tips = (uint32_t *)take_rz((uint64_t)lim.max_columns * 4);
+    w.prev_starts = (uint32_t *)take_rz(((uint64_t)lim.max_columns + 31) / 32 * 4);
+    w.indices = (BtIndex *)take_rz((uint64_t)lim.max_columns * 2 * sizeof(BtIndex));
+    w.rev_ops = (uint32_t *)take_rz((uint64_t)lim.max_path * 4);
+    w.rev_nodes = (uint32_t *)take_rz((uint64_t)lim.max_path * 4);
+    w.rev_seq = take_rz(lim.max_path);
     w.gen_store = (uint32_t *)take(16);
     for (int s = 0; s < 2; ++s) {
         p = (uint8_t *)(((uint64_t)p + 63) & ~63ull);              // level 0 of the hash table starts a line
