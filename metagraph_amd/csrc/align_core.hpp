@@ -505,7 +505,7 @@ MGX_HD uint64_t lab_agg_words(const DevLimits &lim) { return 16 + (uint64_t)LAB_
 #ifndef MGX_ARENA_REDZONE
 #define MGX_ARENA_REDZONE 0
 #endif
-constexpr uint64_t ARENA_REDZONES = 16;                 // take_rz() calls of carve()
+constexpr uint64_t ARENA_REDZONES = 21;                 // take_rz() calls of carve() (16 + 5 of the label part)
 #if MGX_ARENA_REDZONE
 #include <sanitizer/asan_interface.h>
 #endif
@@ -660,10 +660,10 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
 #if MGX_WITH_LABELS
     p = aln_end;
     if (lim.lab_words) {
-        w.lab = (uint32_t *)take((uint64_t)lim.lab_words * 4);
-        w.col_lab = (uint32_t *)take((uint64_t)lim.max_columns * 4);
-        for (int s = 0; s < 2; ++s) w.seed_lab[s] = (uint32_t *)take((uint64_t)lim.max_seeds * 4);
-        w.agg = (uint32_t *)take(lab_agg_words(lim) * 4);
+        w.lab = (uint32_t *)take_rz((uint64_t)lim.lab_words * 4);
+        w.col_lab = (uint32_t *)take_rz((uint64_t)lim.max_columns * 4);
+        for (int s = 0; s < 2; ++s) w.seed_lab[s] = (uint32_t *)take_rz((uint64_t)lim.max_seeds * 4);
+        w.agg = (uint32_t *)take_rz(lab_agg_words(lim) * 4);
     } else {
         w.lab = nullptr; w.col_lab = nullptr; w.seed_lab[0] = w.seed_lab[1] = nullptr; w.agg = nullptr;
     }
