@@ -2907,7 +2907,7 @@ MGX_DEV int chain_step(Wave &w, ExtenderState &E, LV<int32_t> *pS, LV<int32_t> *
             if (wv == 0) {
                 pf = true; pf_zero = 1;                          // sink dummy: no children (dbg_succinct.cpp:113)
             } else {
-                pf_r = g.NF[wv % SIGMA] + block_rank_W(cur, (int)(next & 63), wv % SIGMA, (next >> 6) == 0);
+                pf_r = nf_of(g, wv % SIGMA) + block_rank_W(cur, (int)(next & 63), wv % SIGMA, (next >> 6) == 0);
                 if (pf_r) { pf = true; pf_hint = gld(g.last_hint + ((pf_r - 1) >> 6)); }
             }
         }

@@ -30,6 +30,11 @@ struct DevGraph {
     const Block *blocks;
     const uint32_t *last_hint;     // block holding every 64-th set bit of last
     const uint32_t *w_hint[4];     // same for unflagged W == 1..4
+    const uint32_t *sel_anchor;    // select_last(j << sel_shift), j = 0 .. sel_n - 1 (positions; the last entry closes the last segment):
+    uint32_t sel_shift, sel_n;     // a table small enough for LDS from which the block of select_last(r) is PREDICTED by linear
+                                   // interpolation (sel_predict); select_last_scan then scans from the predicted block in
+                                   // whichever direction r lies, so the prediction is a hint, not a promise — fwd becomes one
+                                   // dependent load (+ the occasional neighbour) where last_hint costs a fetch of its own first
     const uint32_t *firstc;        // first character code of every edge's k-mer, 8 nibbles per word
     const uint64_t *terminus;      // MEM-terminus bit per node (aligner_seeder_methods.hpp:121-125), n_blocks words; PRIMARY
                                    // graphs: n_blocks more words with the bits of the wrapper ids v + n (canon_graph.hpp)
@@ -183,6 +188,27 @@ MGX_DEV uint64_t select_last_blk(const DevGraph &g, uint32_t r, Block &b, LineCt
     return ((uint64_t)bi << 6) + (uint32_t)select64(b.last_bits, (int)(r - b.last_cum));
 }
 
+// the block select_last(r) is expected in, r >= 1: linear interpolation between the anchors around r (tab = g.sel_anchor or a
+// copy of it in faster memory)
+MGX_DEV uint32_t sel_predict(const uint32_t *tab, uint32_t shift, uint32_t r) {
+    const uint32_t j = r >> shift, lo = tab[j], hi = tab[j + 1];
+    const uint32_t frac = r & ((1u << shift) - 1u);
+    return (lo + (uint32_t)(((uint64_t)(hi - lo) * frac) >> shift)) >> 6;
+}
+
+// select_last(r), r >= 1, by a scan from block `bi` in whichever direction r lies; also returns the block of the answer
+template <bool U = false>
+MGX_DEV uint64_t select_last_scan(const DevGraph &g, uint32_t r, uint32_t bi, Block &b, LineCtr &ctr) {
+    for (;;) {
+        ++ctr.select_lines;
+        b = load_block_t<U>(g, bi);
+        if (b.last_cum >= r) { --bi; continue; }                      // (block 0 has last_cum 0 < r)
+        if (b.last_cum + (uint32_t)popc64(b.last_bits) >= r) break;
+        ++bi;
+    }
+    return ((uint64_t)bi << 6) + (uint32_t)select64(b.last_bits, (int)(r - b.last_cum));
+}
+
 template <bool U = false>
 MGX_DEV uint64_t select_last(const DevGraph &g, uint32_t r, LineCtr &ctr) {
     if (r == 0) return 0;
@@ -193,7 +219,8 @@ MGX_DEV uint64_t select_last(const DevGraph &g, uint32_t r, LineCtr &ctr) {
 // position of the r-th unflagged c in W (wavelet_tree::select as used by boss.cpp:635); c in 1..4
 template <bool U = false>
 MGX_DEV uint64_t select_W(const DevGraph &g, uint32_t c, uint32_t r, LineCtr &ctr) {
-    uint32_t bi = load_hint<U>(g.w_hint[c - 1] + ((r - 1) >> 6));
+    const uint32_t *wh = c == 1 ? g.w_hint[0] : c == 2 ? g.w_hint[1] : c == 3 ? g.w_hint[2] : g.w_hint[3];     // (as nf_of: no runtime index into g)
+    uint32_t bi = load_hint<U>(wh + ((r - 1) >> 6));
     for (;;) {
         ++ctr.select_lines;
         Block b = load_block_t<U>(g, bi);
@@ -252,11 +279,26 @@ MGX_DEV uint32_t node_last_value(const DevGraph &g, uint64_t i) {       // boss.
     return SIGMA - 1;
 }
 
+// NF[c] for a per-lane c.  g lives in the kernel-argument segment: `g.NF[c]` with a runtime index is a LOAD from it (a
+// dependent round trip in front of every select hint); with constant indices the five values are scalar registers.
+MGX_DEV uint32_t nf_of(const DevGraph &g, uint32_t c) {
+    const uint32_t lo = (c & 1) ? g.NF[1] : g.NF[0];
+    const uint32_t mid = (c & 1) ? g.NF[3] : g.NF[2];
+    const uint32_t r = (c & 2) ? mid : lo;
+    return c >= 4 ? g.NF[4] : r;
+}
+MGX_DEV uint32_t f_of(const DevGraph &g, uint32_t c) {
+    const uint32_t lo = (c & 1) ? g.F[1] : g.F[0];
+    const uint32_t mid = (c & 1) ? g.F[3] : g.F[2];
+    const uint32_t r = (c & 2) ? mid : lo;
+    return c >= 4 ? g.F[4] : r;
+}
+
 // fwd(i, c) = select_last(NF[c] + rank_W(i, c)) (boss.cpp:642-652); cur = loaded block of i.
 // Returns the target's last edge and its block.
 template <bool U = false>
 MGX_DEV uint64_t fwd_from(const DevGraph &g, uint64_t i, const Block &cur, uint32_t c, Block &tgt, LineCtr &ctr) {
-    uint32_t r = g.NF[c] + block_rank_W(cur, (int)(i & 63), c, (i >> 6) == 0);
+    uint32_t r = nf_of(g, c) + block_rank_W(cur, (int)(i & 63), c, (i >> 6) == 0);
     if (r == 0) { tgt = cur; return 0; }
     return select_last_blk<U>(g, r, tgt, ctr);
 }
@@ -288,7 +330,7 @@ MGX_DEV uint64_t bwd(const DevGraph &g, uint64_t i, LineCtr &ctr) {
     uint32_t target_node = rank_last<U>(g, i - 1, ctr) + 1;
     if (target_node == 1) return 1;
     uint32_t c = node_last_value(g, i);
-    return select_W<U>(g, c, target_node - g.NF[c], ctr);
+    return select_W<U>(g, c, target_node - nf_of(g, c), ctr);
 }
 
 // tighten_range (boss.hpp:682-693).  Narrow ranges are the common case, so the two ranks share one block
@@ -309,7 +351,8 @@ MGX_DEV bool tighten_range(const DevGraph &g, uint64_t *rl, uint64_t *ru, uint32
         rk_rl = block_rank_W(bl, (int)(lo & 63), s, (lo >> 6) == 0) + 1;
     }
     if (rk_rl > rk_ru) return false;
-    const uint32_t r_hi = g.NF[s] + rk_ru, r_lo = g.NF[s] + rk_rl - 1;
+    const uint32_t nfs = nf_of(g, s);
+    const uint32_t r_hi = nfs + rk_ru, r_lo = nfs + rk_rl - 1;
     Block sb;
     const uint64_t pos_hi = select_last_blk(g, r_hi, sb, ctr);
     *ru = pos_hi;
@@ -329,8 +372,9 @@ MGX_DEV void prefix_range(const DevGraph &g, uint32_t key, uint64_t *rl, uint64_
 }
 
 MGX_DEV void initial_range(const DevGraph &g, uint32_t s, uint64_t *rl, uint64_t *ru) {   // boss.hpp:665-677
-    *rl = (uint64_t)g.F[s] + 1 < g.n + 1 ? (uint64_t)g.F[s] + 1 : g.n + 1;
-    *ru = s + 1 < SIGMA ? g.F[s + 1] : g.n;
+    const uint64_t fs = f_of(g, s);
+    *rl = fs + 1 < g.n + 1 ? fs + 1 : g.n + 1;
+    *ru = s + 1 < SIGMA ? (uint64_t)f_of(g, s + 1) : g.n;
 }
 
 // Children of node v as DBGSuccinct::call_outgoing_kmers reports them (dbg_succinct.cpp:110-139),

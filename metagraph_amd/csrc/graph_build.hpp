@@ -57,6 +57,27 @@ MGX_DEV void build_block_pass2(uint32_t b, Block *blocks, const uint32_t *cum, u
     }
 }
 
+// the select anchors (dev_graph.hpp sel_anchor): entry j, one thread per entry.  The last segment is shorter than 2^shift
+// ranks: its closing entry is extrapolated so that the segment's slope is right.
+MGX_HD uint32_t sel_anchor_shift(uint64_t total_last, uint32_t max_entries) {
+    uint32_t s = 6;
+    while ((total_last >> s) + 2 > max_entries) ++s;
+    return s;
+}
+MGX_DEV void build_sel_anchor(const DevGraph &g, uint32_t j, uint32_t shift, uint32_t n_entries, uint32_t total_last, uint32_t *out) {
+    LineCtr ctr = { 0, 0, 0 };
+    const uint64_t r = (uint64_t)j << shift;
+    if (r == 0) { out[j] = 0; return; }
+    if (r <= total_last) { out[j] = (uint32_t)select_last(g, (uint32_t)r, ctr); return; }
+    // the closing entry (and padding behind it)
+    const uint64_t r0 = (uint64_t)(j - 1) << shift;
+    if (j + 1 < n_entries || r0 > total_last) { out[j] = (uint32_t)g.n; return; }
+    const uint64_t p0 = r0 ? select_last(g, (uint32_t)r0, ctr) : 0, p1 = select_last(g, total_last, ctr);
+    const uint64_t span = total_last - r0;                     // ranks of the last segment (>= 1 here)
+    const uint64_t ext = p0 + (((p1 - p0) << shift) + span - 1) / (span ? span : 1);
+    out[j] = (uint32_t)(ext > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ext);
+}
+
 // parent pointer used to propagate first characters: P[e] = bwd(e) (boss.cpp:623-636)
 MGX_DEV uint32_t build_parent(const DevGraph &g, uint64_t e) {
     if (e == 0) return 0;

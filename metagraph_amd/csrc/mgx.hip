@@ -16,6 +16,7 @@
 #include "../../include/mgx.h"
 #define MGX_NO_EXTEND 1      // this unit holds k_map and the seeding kernel; the extension lives in mgx_grp.hip
 #include "graph_build.hpp"
+#include "map_pipe.hpp"
 #include "host_common.hpp"
 #include "lane_types.hpp"
 
@@ -30,6 +31,10 @@ __global__ void k_build_pass1(const uint8_t *W, const uint8_t *last, uint64_t n,
 }
 
 struct HintPtrs { uint32_t *last_hint; uint32_t *w_hint[4]; };
+__global__ void k_sel_anchor(DevGraph g, uint32_t shift, uint32_t n_entries, uint32_t total_last, uint32_t *out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_entries) build_sel_anchor(g, j, shift, n_entries, total_last, out);
+}
 
 __global__ void k_build_pass2(Block *blocks, const uint32_t *cum, HintPtrs hp, uint32_t n_blocks) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -238,6 +243,40 @@ __global__ void __launch_bounds__(256, MGX_MAP_PACKED_WAVES) k_map_packed(DevGra
     }
 }
 
+// k_map as a request / response machine (map_pipe.hpp): one memory round trip per iteration for all lanes of a wavefront
+#ifndef MGX_MAP_PIPE_WAVES
+#define MGX_MAP_PIPE_WAVES 4
+#endif
+#ifndef MGX_SEL_ANCHOR_MAX
+#define MGX_SEL_ANCHOR_MAX 8192      // entries of the select-anchor table (32 KB of LDS per workgroup of k_map_pipe)
+#endif
+__shared__ uint32_t s_sel_anchor[MGX_SEL_ANCHOR_MAX];       // DevGraph::sel_anchor, one copy per workgroup
+struct SelPredictLds {
+    uint32_t shift;
+    __device__ __forceinline__ uint32_t operator()(uint32_t r) const { return sel_predict(s_sel_anchor, shift, r); }
+};
+__global__ void __launch_bounds__(256, MGX_MAP_PIPE_WAVES) k_map_pipe(DevGraph g, MapArgs a, KernelStats *stats) {
+    for (uint32_t j = threadIdx.x; j < g.sel_n; j += blockDim.x) s_sel_anchor[j] = g.sel_anchor[j];
+    __syncthreads();
+    LineCtr ctr = { 0, 0, 0 };
+    MapPipe m;
+    map_pipe_init(m);
+    ChainClaim claim(a.cursor);
+    const SelPredictLds pred = { g.sel_shift };
+    for (;;) {
+        const bool live = map_pipe_step(g, a, m, ctr, claim, pred);
+        if (!__ballot(live)) break;
+    }
+    uint32_t r = ctr.rank_lines, s = ctr.select_lines, b = ctr.bit_lines;
+    for (int d = 32; d >= 1; d >>= 1) { r += __shfl_xor(r, d, 64); s += __shfl_xor(s, d, 64); b += __shfl_xor(b, d, 64); }
+    if ((threadIdx.x & 63) == 0 && (r | s | b)) {
+        atomicAdd(&stats->rank_lines, (unsigned long long)r);
+        atomicAdd(&stats->select_lines, (unsigned long long)s);
+        atomicAdd(&stats->bit_lines, (unsigned long long)b);
+        atomicAdd(&stats->map_lines, (unsigned long long)r + s + b);
+    }
+}
+
 #include "seed_kernel.hpp"
 
 __global__ void k_iota(uint32_t *v, uint64_t n) {
@@ -305,7 +344,7 @@ struct DevBuf {
 struct mgx_graph {
     int device = 0;
     DevGraph g;
-    DevBuf blocks, last_hint, w_hint[4], firstc, terminus, valid, prefix_tbl;
+    DevBuf blocks, last_hint, w_hint[4], sel_anchor, firstc, terminus, valid, prefix_tbl;
     uint64_t bytes = 0;
     uint32_t mode = MGX_MODE_BASIC;
     bool primary_tables = false;      // PRIMARY: reverse-complement tables built (default; MGX_PRIMARY_TABLES=0 turns them off)
@@ -419,6 +458,7 @@ struct mgx_aligner {
         int no_compact = 0, no_alias = 0, no_bt_runs = 0, no_flat = 0;
         int primary_alt_build = 0;
         int lane = -1;            // the lane-per-read kernel in front of the extension kernel: -1 auto, 0 off, 1 forced
+        int map_pipe = 1;         // k_map as the request / response machine (map_pipe.hpp); 0 = one chain step per lane (rounds 1-4)
     } opt;
 };
 
@@ -580,6 +620,14 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
             g.NF[c] = hb[0].last_cum + (uint32_t)__builtin_popcountll(m);
         }
     }
+    {
+        g.sel_shift = sel_anchor_shift(tot[5], MGX_SEL_ANCHOR_MAX);
+        g.sel_n = (uint32_t)(tot[5] >> g.sel_shift) + 2;
+        if (int rc = G->sel_anchor.ensure((size_t)g.sel_n * 4)) return rc;
+        k_sel_anchor<<<(g.sel_n + 255) / 256, 256>>>(g, g.sel_shift, g.sel_n, (uint32_t)tot[5], G->sel_anchor.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+        g.sel_anchor = G->sel_anchor.as<uint32_t>();
+    }
     // node mask
     if (view->valid) {
         const uint8_t *valid = view->valid;
@@ -655,7 +703,7 @@ int mgx_graph_create(const mgx_boss_view *view, int device, mgx_graph **out) {
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    G->bytes = G->blocks.bytes + G->last_hint.bytes + G->firstc.bytes + G->terminus.bytes + G->valid.bytes
+    G->bytes = G->blocks.bytes + G->last_hint.bytes + G->sel_anchor.bytes + G->firstc.bytes + G->terminus.bytes + G->valid.bytes
                + G->prefix_tbl.bytes;
     for (int c = 0; c < 4; ++c) G->bytes += G->w_hint[c].bytes;
     *out = guard.release();
@@ -848,6 +896,19 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
                                                                     A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             A->packed_valid = true;
+            if (A->opt.map_pipe) {
+                MapArgs ma;
+                ma.offsets = d_offsets; ma.node_begin = A->node_begin.as<uint64_t>();
+                ma.pk_fwd = A->pk_fwd.as<uint64_t>(); ma.pk_rc = A->pk_rc.as<uint64_t>();
+                ma.iv_fwd = A->iv_fwd.as<uint32_t>(); ma.iv_rc = A->iv_rc.as<uint32_t>();
+                ma.nodes_fwd = A->nodes_fwd.as<uint32_t>(); ma.nodes_rc = A->nodes_rc.as<uint32_t>();
+                ma.mlen_fwd = A->mlen_fwd.as<uint8_t>(); ma.mlen_rc = A->mlen_rc.as<uint8_t>();
+                ma.rng_fwd = A->have_rng ? A->rng_fwd.as<uint2>() : nullptr; ma.rng_rc = A->have_rng ? A->rng_rc.as<uint2>() : nullptr;
+                ma.min_rng_len = (int32_t)std::min<uint64_t>(A->cfg.min_seed_length, 1u << 20);
+                ma.n_reads = n; ma.do_rc = do_rc ? 1 : 0; ma.cursor = map_cursor;
+                const uint64_t pblocks = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)prop.multiProcessorCount * MGX_MAP_PIPE_WAVES, (chains + 255) / 256));
+                k_map_pipe<<<(uint32_t)pblocks, 256>>>(A->graph->g, ma, A->d_stats_map.as<KernelStats>());
+            } else
             k_map_packed<<<(uint32_t)blocks, 256>>>(A->graph->g, d_offsets, A->node_begin.as<uint64_t>(),
                                          A->pk_fwd.as<uint64_t>(), A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>(),
                                          A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(),
@@ -1330,6 +1391,7 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
         else if (key == "no_flat") o.no_flat = v;
         else if (key == "primary_alt_build") o.primary_alt_build = v;
         else if (key == "lane") o.lane = v;
+        else if (key == "map_pipe") o.map_pipe = v;
         else return fail(MGX_ERR_INVALID, "unknown option '%s'", name);
         return MGX_OK;
     }

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "graph_build.hpp"
+#include "map_pipe.hpp"
 #include "host_common.hpp"
 #include "lane_read.hpp"
 
@@ -21,7 +22,7 @@ namespace {
 struct EmuGraph {
     DevGraph g;
     std::vector<Block> blocks;
-    std::vector<uint32_t> last_hint, w_hint[4], firstc;
+    std::vector<uint32_t> last_hint, w_hint[4], sel_anchor, firstc;
     std::vector<uint64_t> terminus, valid;
     std::vector<uint2> prefix_tbl;
     uint32_t mode = 0;
@@ -34,6 +35,8 @@ struct EmuRun {
     std::vector<uint32_t> stream;
     HostResults host;
     std::vector<uint64_t> node_begin, m_fwd, m_rc;
+    std::vector<uint8_t> m_len[2];          // k_map's side outputs (match lengths, ranges): test_map_pipe.py
+    std::vector<uint2> m_rng[2];
     std::vector<DevSeed> seeds;
     DevLimits lim;
     KernelStats stats;
@@ -111,6 +114,15 @@ void *emu_graph_create(const mgx_boss_view *view) {
     LineCtr ctr = { 0, 0, 0 };
     for (int c = 0; c < SIGMA; ++c) { g.F[c] = (uint32_t)view->F[c]; }
     for (int c = 0; c < SIGMA; ++c) g.NF[c] = rank_last(g, g.F[c], ctr);
+    {
+        // a deliberately COARSE table on the model's small graphs (a handful of segments): the scan must cope with bad predictions
+        const char *e = getenv("MGX_SEL_ANCHOR_MAX");
+        g.sel_shift = sel_anchor_shift(tot[5], e ? (uint32_t)atoi(e) : 6u);
+        g.sel_n = (uint32_t)(tot[5] >> g.sel_shift) + 2;
+        G->sel_anchor.assign(g.sel_n, 0);
+        for (uint32_t j = 0; j < g.sel_n; ++j) build_sel_anchor(g, j, g.sel_shift, g.sel_n, (uint32_t)tot[5], G->sel_anchor.data());
+        g.sel_anchor = G->sel_anchor.data();
+    }
     if (view->valid) {
         G->valid.assign(n_blocks, 0);
         for (uint64_t e = 0; e <= n; ++e) if (view->valid[e]) G->valid[e >> 6] |= 1ull << (e & 63);
@@ -290,6 +302,23 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
                     pack_read_word(seqs + offsets[r], L, 1, j, &pkr[wd], &ivr[wd]);
                 }
             }
+            if (!getenv("MGX_MAP_LANES")) {
+                // the product's k_map_pipe: the request / response machine of map_pipe.hpp (here: one lane)
+                MapArgs ma;
+                ma.offsets = offsets; ma.node_begin = R->node_begin.data();
+                ma.pk_fwd = pkf.data(); ma.pk_rc = pkr.data(); ma.iv_fwd = ivf.data(); ma.iv_rc = ivr.data();
+                ma.nodes_fwd = nf.data(); ma.nodes_rc = nr.data(); ma.mlen_fwd = lf.data(); ma.mlen_rc = lr.data();
+                ma.rng_fwd = gf.data(); ma.rng_rc = gr.data();
+                ma.min_rng_len = (int32_t)std::min<uint64_t>(cfg.min_seed_length, 1u << 20);
+                ma.n_reads = n; ma.do_rc = do_rc ? 1 : 0;
+                unsigned long long cur2 = 0;
+                ma.cursor = &cur2;
+                MapPipe mp;
+                map_pipe_init(mp);
+                ChainClaim claim(ma.cursor);
+                const SelPredictGlobal pred = { G->g.sel_anchor, G->g.sel_shift };
+                while (map_pipe_step(G->g, ma, mp, ctr, claim, pred)) {}
+            } else {
             MapLanePacked m;
             m.state = 0;
             auto fetch = [&](MapLanePacked &ml) -> bool {
@@ -310,6 +339,7 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
                 return true;
             };
             while (m.state != 3) map_lane_step_packed(G->g, m, ctr, fetch);
+            }
         } else {
         MapLane m;
         m.state = 0;
@@ -341,6 +371,7 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     }
     R->m_fwd.assign(nf.begin(), nf.end());
     R->m_rc.assign(nr.begin(), nr.end());
+    R->m_len[0] = lf; R->m_len[1] = lr; R->m_rng[0] = gf; R->m_rng[1] = gr;
     if (map_only) return R;
     rc = derive_limits(cfg, limits, Lmax, &R->lim, &R->error, AN != nullptr);
     if (rc) return R;
@@ -570,6 +601,14 @@ void emu_mapping(void *r, mgx_mapping *out) {
     out->node_begin = R->node_begin.data();
     out->nodes_fwd = R->m_fwd.data();
     out->nodes_rc = R->m_rc.data();
+}
+// k_map's side outputs: per k-mer position and strand the match length byte and, where it was written, the (rl, ru) range
+// (entries the kernel does not write hold MLEN_UNKNOWN / the zero range)
+uint64_t emu_map_side(void *r, int strand, const uint8_t **mlen, const uint32_t **rng) {
+    auto *R = static_cast<EmuRun *>(r);
+    *mlen = R->m_len[strand].data();
+    *rng = reinterpret_cast<const uint32_t *>(R->m_rng[strand].data());
+    return R->m_len[strand].size();
 }
 // info6 per read + seeds [n][2][max_seeds][4]
 uint32_t emu_seed_info(void *r, uint32_t *info6, uint32_t *seeds) {

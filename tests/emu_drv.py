@@ -168,6 +168,17 @@ class EmuRun:
             out.append(([m.nodes_fwd[i] for i in range(b, e)], [m.nodes_rc[i] for i in range(b, e)]))
         return out
 
+    def map_side(self):
+        """k_map's side outputs per strand: (match-length bytes, (rl, ru) words)"""
+        out = []
+        L().emu_map_side.restype = C.c_uint64
+        L().emu_map_side.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        for s in (0, 1):
+            lp, rp = C.c_void_p(), C.c_void_p()
+            n = L().emu_map_side(self.r, s, C.byref(lp), C.byref(rp))
+            out.append((C.string_at(lp.value, n) if n else b"", C.string_at(rp.value, 8 * n) if n else b""))
+        return out
+
     def seed_info(self):
         info = (C.c_uint32 * (6 * self.n))()
         ms = L().emu_seed_info(self.r, info, None)
