@@ -843,12 +843,12 @@ MGX_NI_G1 bool is_low_complexity(const uint8_t *s, int32_t l_seq, SdustScratch *
 // sdust's serial state machine: per position a 61-bit mask of the following positions with the same triplet, then
 // r(start, end) accumulates popcounts while the start walks back.  Strands with a non-ACGT character are not judged
 // here (`true`).
-MGX_DEV bool maybe_low_complexity(Wave &w, int s) {
+MGX_DEV bool maybe_low_complexity(Wave &w, int s, uint8_t *tc_at = nullptr, uint64_t *eq_at = nullptr) {
     constexpr int32_t T = 20, SPAN = 61;
     const int32_t L = w.L;
     const uint8_t *q = w.q[s];
-    uint8_t *tc = w.dust_t;
-    uint64_t *eq = w.dust_eq;
+    uint8_t *tc = tc_at ? tc_at : w.dust_t;
+    uint64_t *eq = eq_at ? eq_at : w.dust_eq;
     uint64_t invalid = 0;
     for (int32_t base = 0; base < L; base += WAVE) {
         LV<bool> bad;
@@ -1384,6 +1384,20 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     SEED_T(0, tp)
     w.n_seeds[s] = 0;
     if ((uint32_t)L < cfg.min_seed_length) return;
+    if (cfg.seed_complexity_filter && w.lc_maybe < 0 && cfg.min_seed_length < (uint32_t)k) {
+        // The DUST pre-filter of the read (window_low_complexity), evaluated HERE instead of at the first position that asks:
+        // nearly every read has such a position (the read tail), and here the per-position tables below are not in use yet, so
+        // its two arrays — 61 reads of each entry per lane — can overlay them where they live, which is LDS; at their own
+        // place behind those tables they were in the arena, and the filter a fifth of this kernel's time.
+        const uint64_t Lm = MGX_PARAMS_OF(w).lim.Lmax;           // (carve() sized the tables for the batch's longest read)
+        uint8_t *lo = (uint8_t *)w.msl, *hi = (uint8_t *)w.rlast + align8((Lm + 1) * 4);
+        const uint64_t need = align8((uint64_t)(L + 8) * 8) + align8((uint64_t)L + 8);
+        const uint64_t tables = 3 * align8((Lm + 1) * 2) + align8(Lm + 1) + 3 * align8((Lm + 1) * 4);
+        // one contiguous run (all of them in LDS, or all in the arena)?
+        const bool overlay = (uint64_t)(hi - lo) == tables && tables >= need && ((uint64_t)lo & 7) == 0;
+        w.lc_maybe = (overlay ? maybe_low_complexity(w, s, lo + align8((uint64_t)(L + 8) * 8), (uint64_t *)lo)
+                              : maybe_low_complexity(w, s)) ? 1 : 0;
+    }
     if (cfg.min_seed_length >= (uint32_t)k) { base_seeds<MANY>(w, s); return; }
 
     const int32_t msl0 = (int32_t)cfg.min_seed_length;
@@ -1464,12 +1478,13 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                 uint32_t rf = 0, rl_ = 0;
                 bool need = max_len >= (int32_t)w.msl[i];
                 int32_t known = -1;                              // match length with a stored range, if any
+                int32_t known_at = i;                            // the slot of rng[] that holds it
                 if (need && w.mlen[s] && i < w.n_kmers && max_len == k - 1) {
                     // k_map's index() walked this very chain (BOSS::index_range == index() up to the failing
                     // character): skip lookups that cannot reach min_seed_length, reuse the range of those that do
                     const uint32_t ml = w.mlen[s][i];
-                    if (ml == 254) need = msl0 <= (int32_t)g.prefix_len;
-                    else if (ml < 254) {
+                    if (ml == MLEN_LT_PREFIX) need = msl0 <= (int32_t)g.prefix_len;
+                    else if (ml < MLEN_TAIL) {
                         need = (int32_t)ml >= msl0;
                         if (need && w.rng[s]) known = (int32_t)ml;
                     }
@@ -1480,7 +1495,13 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                 // profiles/r04_ab7_seed_sections.txt; here the tail positions walk side by side, one per lane.)
                 // (Few seeds: only the first tail position reports, and raises msl[] for those behind it; looking it up here instead
                 // moves 12 ms per 2 M reads from the bookkeeping to this loop and saves 1 — same file.)
-                if (!MANY && need && tail_known && i >= w.n_kmers && max_len == L - i && max_len >= msl0) {
+                // the tail position two behind the last k-mer — the one that reports when that k-mer is covered by a MEM — has its
+                // range from k_map (MLEN_TAIL, map_pipe.hpp): there the walk is one of 64 per wavefront
+                if (need && tail_known && i == w.n_kmers + 1 && max_len == L - i && max_len == k - 2 && max_len >= msl0 && w.mlen[s]
+                        && w.rng[s] && w.mlen[s][w.n_kmers - 1] == MLEN_TAIL) {
+                    known = max_len; known_at = w.n_kmers - 1;
+                }
+                if (!MANY && known < 0 && need && tail_known && i >= w.n_kmers && max_len == L - i && max_len >= msl0) {
                     mlen = (uint16_t)max_len;
                     rf = DEFERRED_RANGE;
                     need = false;
@@ -1489,7 +1510,7 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
                     uint64_t first, last;
                     int32_t m;
                     if (known >= 0) {
-                        const uint2 r = w.rng[s][i];
+                        const uint2 r = w.rng[s][known_at];
                         ++lc.bit_lines;
                         first = succ_last(g, r.x, lc);           // index_range's return (boss.hpp:756-763)
                         last = r.y;

@@ -30,6 +30,11 @@ MGX_DEV uint32_t strand_code(const char *seq, int32_t L, int strand, int32_t pos
 // the table's prefix), MLEN_UNKNOWN = index() did not run there.  The seeder's sub-k lookup walks exactly the
 // same chain (BOSS::index_range, boss.hpp:720-764), so it can skip lookups that cannot reach min_seed_length.
 constexpr uint8_t MLEN_UNKNOWN = 255, MLEN_LT_PREFIX = 254;
+// at the LAST k-mer position of a strand, when that k-mer is a node (k_map_pipe only): the range slot of the position holds
+// index_range of the read-tail position two further on (its k - 2 characters, all matched) — the one sub-k position of the
+// tail that reports a seed when the last k-mer is part of a MEM (SuffixSeeder, aligner_seeder_methods.cpp:216-249); the seeding
+// kernel would otherwise walk that range by itself, one read per wavefront
+constexpr uint8_t MLEN_TAIL = 253;
 
 struct MapLane {
     const char *seq;

@@ -53,6 +53,8 @@ struct MapPipe {
     uint64_t wbase, nbase;        // word 0 of the chain's strand in pk_* / iv_*; node_begin of its read
     int32_t strand, n_words, n_kmers;
     int32_t i, t;                 // k-mer position; characters matched so far (lookup), or -1 while walking
+    int32_t tail;                 // the read-tail lookup behind the last k-mer (MLEN_TAIL): 0 not tried, 1 in progress, 2 over
+    uint32_t last_node;           // what the last settled k-mer stored
     uint64_t cur, nxt;            // codes of positions [i, i + 32); the not yet consumed codes of the word after them
     uint32_t icur, inxt;
     uint32_t edge, rl, ru;        // (edge indices fit 32 bits on the device)
@@ -74,6 +76,7 @@ struct MapPipe {
 
 MGX_DEV void map_pipe_init(MapPipe &m) {
     m.state = MP_IDLE; m.purpose = PU_WALK; m.bg = BG_WANT; m.blk_idx = MP_NO_BLOCK; m.i = 0; m.n_kmers = 0; m.edge = 0; m.t = -1;
+    m.tail = 2; m.last_node = 0;
     m.cur = m.nxt = 0; m.icur = m.inxt = 0; m.rl = m.ru = 0; m.r_hi = m.r_lo = m.rk_ru = 0; m.req = 0;
     m.wbase = m.nbase = 0; m.strand = 0; m.n_words = 0;
     m.st_flags = 0; m.st_node = m.st_len = 0; m.st_idx = m.st_rng = 0;
@@ -205,8 +208,11 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
         ++ctr.bit_lines;
         m.rl = (uint32_t)v8; m.ru = (uint32_t)(v8 >> 32);
         if (m.rl > m.ru) {
-            if (lens && g.prefix_len > 1) out_len(MLEN_LT_PREFIX);
-            m.edge = 0; m.t = -1; act = ACT_ADVANCE;
+            if (m.tail == 1) { m.tail = 2; m.t = -1; act = ACT_POS; }           // (the seeder will walk it itself, from scratch)
+            else {
+                if (lens && g.prefix_len > 1) out_len(MLEN_LT_PREFIX);
+                m.edge = 0; m.t = -1; act = ACT_ADVANCE;
+            }
         } else { m.t = (int32_t)g.prefix_len; act = ACT_TIGHT; }
     } else if (st == MP_SEL) {
         // select_last(r) by a scan in either direction (select_last_scan, dev_graph.hpp)
@@ -252,7 +258,13 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
         if (act == ACT_TIGHT) {
             // tighten_range(rl, ru, q[i + t]) (boss.hpp:682-693), or — all k - 1 characters matched — the edge itself
             const uint32_t hb = m.ru >> 6;
-            if (hb != m.blk_idx) { m.req = hb; m.state = MP_BLK; m.purpose = PU_HI; act = ACT_NONE; }
+            if (m.tail == 1 && m.t >= k - 2) {
+                // the read-tail range is complete: into the slots of the last k-mer position
+                m.st_flags |= 2u | 4u | ((uint32_t)m.strand << 8);
+                m.st_idx = m.nbase + (uint64_t)(m.n_kmers - 1); m.st_len = MLEN_TAIL;
+                m.st_rng = ((uint64_t)m.ru << 32) | m.rl;
+                m.tail = 2; m.t = -1; act = ACT_POS;
+            } else if (hb != m.blk_idx) { m.req = hb; m.state = MP_BLK; m.purpose = PU_HI; act = ACT_NONE; }
             else if (m.t < k - 1) act = ACT_RANK;
             else { m.edge = m.ru; act = ACT_PICK; }
         }
@@ -266,7 +278,8 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
             else { m.rk_ru = rk_ru; m.req = lo >> 6; m.state = MP_BLK; m.purpose = PU_LO; act = ACT_NONE; }
         }
         if (act == ACT_SEL) {
-            if (rk_rl > rk_ru) {
+            if (rk_rl > rk_ru && m.tail == 1) { m.tail = 2; m.t = -1; act = ACT_POS; }
+            else if (rk_rl > rk_ru) {
                 // index() fails at character t: what matched, and its range, go to the seeder (graph_build.hpp MLEN_*)
                 if (lens) {
                     out_len((uint8_t)m.t);
@@ -295,7 +308,8 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
         if (act == ACT_ADVANCE && (m.st_flags & 1)) { m.state = MP_SETTLE; act = ACT_NONE; }      // second k-mer settled in this iteration
         if (act == ACT_ADVANCE) {
             // the k-mer at position i is settled: m.edge (0 = not found)
-            out_node(in_graph(g, m.edge) ? m.edge : 0u);
+            m.last_node = in_graph(g, m.edge) ? m.edge : 0u;
+            out_node(m.last_node);
             if (m.t == k - 1 && !m.edge && lens) {
                 out_len((uint8_t)(k - 1));
                 if (rngs && k - 1 >= a.min_rng_len) out_rng();
@@ -311,13 +325,25 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
             } else act = ACT_POS;
         }
         if (act == ACT_POS) {
-            if (m.i >= m.n_kmers) {
+            if (m.i >= m.n_kmers && m.tail == 0) {
+                // behind the last k-mer, if it is a node: index_range of the tail position i + 1 (its k - 2 characters follow
+                // the node's first two), for the seeding kernel (MLEN_TAIL)
+                m.tail = 2;
+                const uint32_t tmask = (1u << (k - 2)) - 1u;
+                if (m.last_node && lens && rngs && g.prefix_len && (int32_t)g.prefix_len <= k - 2 && k - 2 >= a.min_rng_len
+                        && !((m.icur >> 1) & tmask)) {
+                    m.tail = 1;
+                    m.cur >>= 2;
+                    m.req = (uint32_t)(m.cur & ((1ull << (2 * g.prefix_len)) - 1ull));
+                    m.state = MP_PREFIX; act = ACT_NONE;
+                }
+            } else if (m.i >= m.n_kmers) {
                 // chain finished: take the prefetched one
                 if (m.bg == BG_READY) {
                     m.wbase = m.bg_w; m.nbase = m.bg_nb; m.strand = m.bg_strand;
                     m.n_words = (m.bg_L + 31) >> 5; m.n_kmers = m.bg_L - k + 1;
                     m.cur = m.bg_cur; m.nxt = m.bg_nxt; m.icur = m.bg_icur; m.inxt = m.bg_inxt;
-                    m.i = 0; m.edge = 0; m.t = -1;
+                    m.i = 0; m.edge = 0; m.t = -1; m.tail = 0; m.last_node = 0;
                     m.bg = BG_WANT;
                     m.state = MP_IDLE;                     // (and on with its first k-mer: act stays ACT_POS)
                 } else {

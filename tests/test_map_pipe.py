@@ -12,6 +12,44 @@ from metagraph_amd import capi
 from test_emu_vs_oracle import make_world, rand_seq
 
 
+MLEN_TAIL = 253
+
+
+def without_tails(side):
+    """map_side() with the read-tail entries (MLEN_TAIL: only the pipe writes them) blanked"""
+    out = []
+    for mlen, rng in side:
+        ml, rg = bytearray(mlen), bytearray(rng)
+        for i, v in enumerate(ml):
+            if v == MLEN_TAIL:
+                ml[i] = 255
+                rg[8 * i:8 * i + 8] = bytes(8)
+        out.append((bytes(ml), bytes(rg)))
+    return out
+
+
+def check_tails(g, k, reads, run):
+    """every MLEN_TAIL entry holds index_range of the tail position behind it: the edges whose node ends with the k - 2
+    characters after the last k-mer's first two, found here by brute force over the graph's spellings"""
+    import struct
+    from test_emu_vs_oracle import rc
+    spell = {v: g.node_sequence(v) for v in range(1, g.n_edges + 1)}
+    n_checked = 0
+    for strand, (mlen, rng) in enumerate(run.map_side()):
+        nb = 0
+        for q, r in enumerate(reads):
+            nk = max(0, len(r) - k + 1)
+            if nk and mlen[nb + nk - 1] == MLEN_TAIL:
+                s = r.upper() if strand == 0 else rc(r.upper())
+                tail = s[len(s) - (k - 2):]
+                rl, ru = struct.unpack_from("<II", rng, 8 * (nb + nk - 1))
+                want = [v for v, sp in spell.items() if sp[:k - 1].endswith(tail)]
+                assert want and (rl, ru) == (min(want), max(want)) and len(want) == ru - rl + 1, (q, strand, rl, ru, want[:4])
+                n_checked += 1
+            nb += nk
+    return n_checked
+
+
 def both_machines(eg, cfg, reads):
     os.environ.pop("MGX_MAP_LANES", None)
     a = emu_drv.EmuRun(eg, cfg, reads, map_only=True)
@@ -39,8 +77,10 @@ def test_pipe_equals_lane_machine_and_oracle(k, mask, seed):
             cfg.min_seed_length = min(msl, k)
         a, b = both_machines(eg, cfg, reads)
         assert a.mapping() == b.mapping()
-        assert a.map_side() == b.map_side()
+        assert without_tails(a.map_side()) == b.map_side()
         assert a.mapping() == orc.AlignRun(g, cfg, reads).mapping()
+        n_tails = check_tails(g, k, reads, a)
+        assert n_tails > 0 or k < 8 or cfg.min_seed_length > k - 2
 
 
 def test_pipe_on_a_repetitive_graph_with_wide_ranges():
@@ -53,6 +93,8 @@ def test_pipe_on_a_repetitive_graph_with_wide_ranges():
     reads = [genome[p:p + 120] for p in range(0, 3000, 37)] + [rand_seq(rng, 100) for _ in range(10)]
     eg = emu_drv.EmuGraph(g)
     cfg = capi.config_cli(k)
+    cfg.min_seed_length = 8
     a, b = both_machines(eg, cfg, reads)
     assert a.mapping() == b.mapping() == orc.AlignRun(g, cfg, reads).mapping()
-    assert a.map_side() == b.map_side()
+    assert without_tails(a.map_side()) == b.map_side()
+    assert check_tails(g, k, reads, a) > 0
