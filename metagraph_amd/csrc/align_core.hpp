@@ -1390,11 +1390,16 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         // its two arrays — 61 reads of each entry per lane — can overlay them where they live, which is LDS; at their own
         // place behind those tables they were in the arena, and the filter a fifth of this kernel's time.
         const uint64_t Lm = MGX_PARAMS_OF(w).lim.Lmax;           // (carve() sized the tables for the batch's longest read)
-        uint8_t *lo = (uint8_t *)w.msl, *hi = (uint8_t *)w.rlast + align8((Lm + 1) * 4);
+        uint8_t *lo = (uint8_t *)w.msl;
         const uint64_t need = align8((uint64_t)(L + 8) * 8) + align8((uint64_t)L + 8);
-        const uint64_t tables = 3 * align8((Lm + 1) * 2) + align8(Lm + 1) + 3 * align8((Lm + 1) * 4);
-        // one contiguous run (all of them in LDS, or all in the arena)?
-        const bool overlay = (uint64_t)(hi - lo) == tables && tables >= need && ((uint64_t)lo & 7) == 0;
+        // the run of tables that lie back to back from msl on (carve() places them in this order; the first ones are in LDS)
+        const uint8_t *at[7] = { (const uint8_t *)w.msl, (const uint8_t *)w.pos_cnt, (const uint8_t *)w.ml, w.pos_full,
+                                 (const uint8_t *)w.pos_start, (const uint8_t *)w.rfirst, (const uint8_t *)w.rlast };
+        const uint64_t sz[7] = { align8((Lm + 1) * 2), align8((Lm + 1) * 2), align8((Lm + 1) * 2), align8(Lm + 1),
+                                 align8((Lm + 1) * 4), align8((Lm + 1) * 4), align8((Lm + 1) * 4) };
+        uint64_t run = 0;
+        for (int t = 0; t < 7 && at[t] == lo + run; ++t) run += sz[t];
+        const bool overlay = run >= need && ((uint64_t)lo & 7) == 0;
         w.lc_maybe = (overlay ? maybe_low_complexity(w, s, lo + align8((uint64_t)(L + 8) * 8), (uint64_t *)lo)
                               : maybe_low_complexity(w, s)) ? 1 : 0;
     }

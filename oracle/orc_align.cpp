@@ -198,6 +198,107 @@ void Alignment::extend_query_end(const char *end) {
     if (full_query_end < end) cigar.append(MGX_OP_CLIPPED, end - full_query_end);
 }
 
+bool Alignment::append(Alignment &&other) {
+    // alignment.cpp:94-175; label_coordinates are not restated, label_columns are intersected (:148-160)
+    bool ret_val = false;
+    if (label_columns.size() && other.label_columns.empty()) label_columns.clear();
+    if (label_columns.size()) {
+        Columns merged;
+        std::set_intersection(label_columns.begin(), label_columns.end(), other.label_columns.begin(), other.label_columns.end(),
+                              std::back_inserter(merged));
+        if (merged.empty()) { *this = Alignment(); return true; }
+        ret_val = merged.size() < label_columns.size();
+        std::swap(label_columns, merged);
+    }
+    nodes.insert(nodes.end(), other.nodes.begin(), other.nodes.end());
+    sequence += std::move(other.sequence);
+    score += other.score;
+    cigar.append(std::move(other.cigar));
+    // expand the query window to cover both alignments (:171-173)
+    query_view = std::string_view(query_view.data(), (other.query_view.data() + other.query_view.size()) - query_view.data());
+    return ret_val;
+}
+
+size_t Alignment::trim_query_prefix(size_t n, size_t node_overlap, const mgx_config &config, bool trim_excess_deletions) {
+    // alignment.cpp:192-278
+    size_t clipping = get_clipping();
+    const char *query_begin = query_view.data() - clipping;
+    auto it = cigar.ops.begin() + static_cast<bool>(clipping);
+    size_t cigar_offset = 0;
+    auto s_it = sequence.begin();
+    auto node_it = nodes.begin();
+    auto consume_ref = [&]() {
+        ++s_it;
+        if (offset < node_overlap) ++offset;
+        else if (node_it + 1 < nodes.end()) ++node_it;
+        else *this = Alignment();
+    };
+    while (n || (trim_excess_deletions && it->first == MGX_OP_DELETION)) {
+        if (it == cigar.ops.end()) { *this = Alignment(); return 0; }
+        switch (it->first) {
+            case MGX_OP_MATCH:
+            case MGX_OP_MISMATCH:
+                score -= config.score_matrix[(uint8_t)query_view[0] & 127][(uint8_t)*s_it & 127];
+                query_view.remove_prefix(1);
+                --n;
+                consume_ref();
+                if (empty()) return 0;
+                break;
+            case MGX_OP_INSERTION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                query_view.remove_prefix(1);
+                --n;
+                break;
+            case MGX_OP_DELETION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                consume_ref();
+                if (empty()) return 0;
+                break;
+            default:
+                throw std::runtime_error("trimming chains not supported");       // (assert(false) in the reference, :249-251)
+        }
+        ++cigar_offset;
+        if (cigar_offset == it->second) { ++it; cigar_offset = 0; }
+    }
+    if (!clipping && it != cigar.ops.begin()) score -= config.left_end_bonus;
+    nodes.erase(nodes.begin(), node_it);
+    sequence.erase(sequence.begin(), s_it);
+    it->second -= cigar_offset;
+    cigar.ops.erase(cigar.ops.begin(), it);
+    extend_query_begin(query_begin);
+    return cigar_offset;
+}
+
+void Alignment::insert_gap_prefix(ptrdiff_t gap_length, size_t node_overlap, const mgx_config &config) {
+    // alignment.cpp:1154-1234
+    size_t extra_nodes = node_overlap + 1;
+    if (gap_length < 0) {
+        // alignments overlap: extra_nodes = k - 1 - matching_overlap
+        trim_clipping();
+        extra_nodes += gap_length - 1;
+        if (offset) nodes.erase(nodes.begin(), nodes.begin() + offset + gap_length);
+        if (extra_nodes) {
+            score += config.gap_opening_penalty + (score_t)(extra_nodes - 1) * config.gap_extension_penalty;
+            cigar.ops.insert(cigar.ops.begin(), Cigar::value_type(MGX_OP_NODE_INSERTION, (uint32_t)extra_nodes));
+        }
+    } else {
+        // no overlap: extra_nodes = k
+        trim_clipping();
+        sequence = std::string(1, '$') + sequence;
+        cigar.ops.insert(cigar.ops.begin(), Cigar::value_type(MGX_OP_DELETION, 1));
+        score += config.gap_opening_penalty;
+        if (static_cast<size_t>(gap_length) <= node_overlap) {
+            // overlap is small, so add only the required dummy nodes
+            trim_offset();
+            score += config.gap_opening_penalty + (score_t)(extra_nodes - 2) * config.gap_extension_penalty;
+            cigar.ops.insert(cigar.ops.begin(), Cigar::value_type(MGX_OP_NODE_INSERTION, (uint32_t)(extra_nodes - 1)));
+        }
+        extend_query_begin(query_view.data() - gap_length);
+    }
+    nodes.insert(nodes.begin(), extra_nodes, 0);
+    offset = node_overlap;
+}
+
 size_t Alignment::trim_offset() {
     // alignment.cpp:177-190
     if (!offset || nodes.size() <= 1) return 0;
@@ -1589,8 +1690,9 @@ class Aggregator {
         auto a = std::make_shared<Alignment>(std::move(alignment));
         if (queue_.empty()) { queue_.push_back(a); return true; }
         if (a->score < get_global_cutoff()) return false;
-        for (const auto &aln : queue_) if (*a == *aln) return false;
-        if (queue_.size() < config_.num_alternative_paths) { queue_.push_back(a); return true; }
+        for (const auto &aln : queue_) if (*a == *aln) return (bool)config_.post_chain_alignments;       // :88-91
+        // "If post-alignment chaining is requested, never skip any alignments" (:92-96)
+        if (config_.post_chain_alignments || queue_.size() < config_.num_alternative_paths) { queue_.push_back(a); return true; }
         auto min_it = std::min_element(queue_.begin(), queue_.end(),
             [&](const auto &x, const auto &y) { return cmp_(*x, *y); });
         if (cmp_(*a, **min_it)) return false;
@@ -1623,6 +1725,89 @@ class Aggregator {
     std::vector<std::shared_ptr<Alignment>> queue_;
     LocalAlignmentLess cmp_;
 };
+
+// construct_alignment_chain (A/aligner_chainer.cpp:623-720)
+static void construct_alignment_chain(size_t node_overlap, const mgx_config &config, std::string_view query, Alignment &&chain,
+                                      std::vector<Alignment>::iterator begin, std::vector<Alignment>::iterator end,
+                                      std::vector<score_t> *best_score, const std::function<void(Alignment &&)> &callback) {
+    const char *chain_begin = chain.query_view.data();
+    const char *chain_end = chain.query_view.data() + chain.query_view.size();
+    if (begin == end || chain_end == query.data() + query.size()) { callback(std::move(chain)); return; }
+    score_t score = chain.score;
+    bool called = false;
+    for (auto it = begin; it != end; ++it) {
+        if (it->offset) continue;                                    // "TODO: handle this case later" (:647-649)
+        const char *next_begin = it->query_view.data();
+        const char *next_end = it->query_view.data() + it->query_view.size();
+        if (next_begin <= chain_begin || next_end == chain_end) continue;
+        if (chain.label_columns.size()) {                            // utils::share_element (:657-663)
+            Columns shared;
+            std::set_intersection(it->label_columns.begin(), it->label_columns.end(), chain.label_columns.begin(),
+                                  chain.label_columns.end(), std::back_inserter(shared));
+            if (shared.empty()) continue;
+        }
+        Alignment aln = *it;
+        if (next_begin >= chain_end) {
+            // no overlap
+            aln.insert_gap_prefix(next_begin - chain_end, node_overlap, config);
+        } else {
+            // trim, then fill in dummy nodes: first trim front of the incoming alignment (:672-680)
+            size_t overlap = std::min(static_cast<size_t>((chain.cigar.ops.end() - 2)->second),
+                                      aln.trim_query_prefix(chain_end - it->query_view.data(), node_overlap, config));
+            if (aln.empty() || aln.sequence.size() <= node_overlap
+                    || (aln.cigar.ops.begin() + static_cast<bool>(aln.get_clipping()))->first != MGX_OP_MATCH)
+                continue;
+            if (overlap < node_overlap) aln.insert_gap_prefix(-(ptrdiff_t)overlap, node_overlap, config);
+            else aln.trim_clipping();
+        }
+        score_t next_score = score + aln.score;
+        if (next_score <= (*best_score)[next_end - query.data()]) continue;
+        (*best_score)[next_end - query.data()] = next_score;
+        // use append instead of splice because any clipping in aln represents internally clipped characters (:703-707)
+        Alignment next_chain = chain;
+        next_chain.trim_end_clipping();
+        bool changed = next_chain.append(std::move(aln));
+        if (next_chain.size()) {
+            construct_alignment_chain(node_overlap, config, query, std::move(next_chain), it + 1, end, best_score, callback);
+            called |= changed;
+        }
+    }
+    if (!called) callback(std::move(chain));
+}
+
+// chain_alignments<LocalAlignmentLess> (A/aligner_chainer.cpp:555-620): post-alignment chaining of a query's alignments
+// (config.post_chain_alignments; node_overlap = k - 1, dbg_aligner.cpp:328-332)
+std::vector<Alignment> chain_alignments(std::vector<Alignment> &&alignments, std::string_view query, std::string_view rc_query,
+                                        const mgx_config &config, size_t node_overlap) {
+    if (alignments.size() < 2 || !config.post_chain_alignments) return std::move(alignments);
+    mgx_config no_chain_config = config;
+    no_chain_config.post_chain_alignments = 0;
+    Aggregator aggregator(no_chain_config);
+    alignments.erase(std::remove_if(alignments.begin(), alignments.end(), [&](Alignment &a) {
+        if (!a.get_clipping() && !a.get_end_clipping()) { aggregator.add_alignment(std::move(a)); return true; }
+        return false;
+    }), alignments.end());
+    std::sort(alignments.begin(), alignments.end(), [](const Alignment &a, const Alignment &b) {
+        return std::make_tuple(a.orientation, a.get_clipping() + a.query_view.size(), a.get_clipping(), b.score, a.sequence.size())
+             < std::make_tuple(b.orientation, b.get_clipping() + b.query_view.size(), b.get_clipping(), a.score, b.sequence.size());
+    });
+    auto run = [&](std::string_view this_query, auto begin, auto end) {
+        std::vector<score_t> best_score(this_query.size() + 1, 0);
+        for (auto it = begin; it != end; ++it) {
+            size_t end_pos = it->query_view.data() + it->query_view.size() - this_query.data();
+            if (it->score > best_score[end_pos]) {
+                best_score[end_pos] = it->score;
+                construct_alignment_chain(node_overlap, config, this_query, Alignment(*it), it + 1, end, &best_score,
+                                          [&](Alignment &&chain) { aggregator.add_alignment(std::move(chain)); });
+            }
+        }
+    };
+    // recursively construct chains
+    auto split_it = std::find_if(alignments.begin(), alignments.end(), [](const Alignment &a) { return a.orientation; });
+    run(query, alignments.begin(), split_it);
+    run(rc_query, split_it, alignments.end());
+    return aggregator.get_alignments();
+}
 
 // align_core (A/dbg_aligner.cpp:360-384); filter_seed for unlabeled seeds clears the seed (:105-108)
 void align_core(std::vector<Alignment> seeds, Extender &extender,
@@ -2042,8 +2227,9 @@ Aligner::Aligner(const Graph &graph, const mgx_config &config) : graph_(graph), 
         throw std::runtime_error("Error: sum of min_cell_score and lowest penalty too low.");
     if (config_.chain_alignments) config_.allow_left_trim = false;
     // PRIMARY graphs are wrapped into CanonicalDBG (dbg_aligner.cpp:52-53; cli/align.cpp:383-399 wrap_graph)
-    if (config_.chain_alignments || config_.post_chain_alignments || !config_.global_xdrop || config_.no_backtrack)
-        throw std::runtime_error("oracle: chaining / per-branch xdrop / no_backtrack are out of scope");
+    // (post_chain_alignments: restated — chain_alignments above; seed chaining is not)
+    if (config_.chain_alignments || !config_.global_xdrop || config_.no_backtrack)
+        throw std::runtime_error("oracle: seed chaining / per-branch xdrop / no_backtrack are out of scope");
 }
 
 AlignmentResults Aligner::align(std::string_view query) const {
@@ -2186,7 +2372,8 @@ void Aligner::align_batch(const std::vector<std::string> &queries, std::vector<A
             align_core(seeds_to_alignments(seeder.seeds, config_), extender, add_alignment, get_min_path_score, false);
         }
 
-        res.alignments = aggregator.get_alignments();       // chain_alignments is a pass-through (aligner_chainer.cpp:556-561)
+        // dbg_aligner.cpp:328-332 (a pass-through unless config.post_chain_alignments, aligner_chainer.cpp:556-561)
+        res.alignments = chain_alignments(aggregator.get_alignments(), this_query, reverse, config_, k - 1);
         if (counters) counters->add(wc);
     }
 }

@@ -79,6 +79,11 @@ struct Alignment {
     void extend_query_begin(const char *begin);                      // alignment.hpp:209-214
     void extend_query_end(const char *end);                          // alignment.hpp:216-222
     size_t trim_offset();                                            // alignment.cpp:177-190
+    size_t trim_clipping() { return cigar.trim_clipping(); }         // alignment.hpp:224
+    size_t trim_end_clipping() { return cigar.trim_end_clipping(); } // alignment.hpp:225
+    bool append(Alignment &&other);                                  // alignment.cpp:94-175 (no coordinates)
+    size_t trim_query_prefix(size_t n, size_t node_overlap, const mgx_config &config, bool trim_excess_deletions = true); // :192-278
+    void insert_gap_prefix(ptrdiff_t gap_length, size_t node_overlap, const mgx_config &config);                        // :1154-1234
     void reverse_complement(const GraphView &graph, std::string_view query_rev_comp); // alignment.cpp:540-702
     bool is_valid(const GraphView &graph, const mgx_config *config, std::string *why = nullptr) const; // :1316-1345
     bool operator==(const Alignment &o) const {
