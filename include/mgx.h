@@ -94,8 +94,14 @@ typedef struct mgx_config {
     int8_t left_end_bonus;             /* :45 */
     int8_t right_end_bonus;            /* :46 */
     uint8_t forward_and_reverse_complement; /* :48 */
-    uint8_t chain_alignments;          /* :49 (must be 0) */
-    uint8_t post_chain_alignments;     /* :50 (must be 0) */
+    uint8_t chain_alignments;          /* :49 (must be 0: seed chaining, aligner_chainer.cpp:47-339, is not built) */
+    uint8_t post_chain_alignments;     /* :50: chain_alignments (aligner_chainer.cpp:555-720) over every query's alignments.  The
+                                        * device then keeps EVERY alignment of a query (aligner_aggregator.hpp:88-96; at most
+                                        * 4 x MGX_MAX_ALTERNATIVE_PATHS - 3 x num_alternative_paths = 13 with the default of
+                                        * one alternative path — a query with more has status MGX_ERR_CAPACITY) and the
+                                        * chaining runs on the host inside mgx_fetch_results / mgx_align_batch; results left
+                                        * on the device (mgx_device_results) are the un-chained ones: decode them and call
+                                        * mgx_chain_alignments.  Not with an annotation. */
     uint8_t global_xdrop;              /* :51 (must be 1) */
     uint8_t allow_left_trim;           /* :52 */
     uint8_t no_backtrack;              /* :53 (must be 0) */
@@ -269,6 +275,12 @@ typedef struct mgx_raw_store mgx_raw_store;
 int mgx_results_from_raw(const void *headers, uint64_t n_queries, const uint32_t *stream, uint64_t stream_words,
                          mgx_raw_store **store, mgx_results *out);
 void mgx_raw_store_free(mgx_raw_store *store);
+/* chain_alignments<LocalAlignmentLess> (aligner_chainer.cpp:555-720, called at dbg_aligner.cpp:328-332) over the decoded
+ * results of a batch whose aligner had post_chain_alignments set: queries seqs[offsets[q] .. offsets[q + 1]) as they were
+ * aligned, k = the graph's k (node_overlap = k - 1).  Host code, needs no GPU.  A chain's nodes hold 0 where the path has no
+ * graph node, its spelling '$' at a gap, its CIGAR MGX_OP_NODE_INSERTION runs and clipping runs inside. */
+int mgx_chain_alignments(const mgx_config *config, uint32_t k, const mgx_results *in, const char *seqs, const uint64_t *offsets,
+                         mgx_raw_store **store, mgx_results *out);
 /* Test hooks: keep and fetch the per-read seed lists (DBGAligner::build_seeders products). */
 void mgx_aligner_keep_seeds(mgx_aligner *a, int keep);
 int mgx_fetch_seed_info(mgx_aligner *a, uint32_t *info6, uint32_t *seeds, uint32_t *max_seeds_out);

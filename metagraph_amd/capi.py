@@ -106,6 +106,22 @@ def results_to_py(res):
     return out
 
 
+def chain_alignments(config, k, res, queries):
+    """mgx_chain_alignments over a Results view (host code: no GPU needed) -> decoded lists, as results_to_py"""
+    import numpy as np
+    blob = b"".join(q.encode() if isinstance(q, str) else bytes(q) for q in queries)
+    offs = np.zeros(len(queries) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(q) for q in queries])
+    store, out = C.c_void_p(), Results()
+    rc = lib().mgx_chain_alignments(C.byref(config), k, C.byref(res), blob, offs.ctypes.data, C.byref(store), C.byref(out))
+    if rc:
+        raise RuntimeError(lib().mgx_last_error().decode())
+    try:
+        return results_to_py(out)
+    finally:
+        lib().mgx_raw_store_free(store)
+
+
 def results_arrays(res):
     """numpy views of an mgx_results (valid while the owner keeps the batch alive)"""
     import numpy as np
@@ -224,6 +240,9 @@ def lib():
     L.mgx_device_stream_capacity.argtypes = [C.c_void_p]
     L.mgx_device_stream_capacity.restype = C.c_uint64
     L.mgx_results_from_raw.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(Results)]
+    L.mgx_chain_alignments.argtypes = [C.POINTER(Config), C.c_uint32, C.POINTER(Results), C.c_char_p, C.c_void_p,
+                                       C.POINTER(C.c_void_p), C.POINTER(Results)]
+    L.mgx_chain_alignments.restype = C.c_int
     L.mgx_results_from_raw_labeled.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(Results)]
     L.mgx_raw_store_free.argtypes = [C.c_void_p]
     L.mgx_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Mapping)]

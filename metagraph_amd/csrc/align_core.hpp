@@ -4390,11 +4390,15 @@ MGX_DEV bool aln_equal(const Wave &w, const DevAln &a, const DevAln &b) {     //
 
 MGX_NI_G4 void add_alignment(Wave &w, const DevAln &a) {
     MGX_ASSUME_LDS(&w);       // :68-138 (unlabeled): a queue of at most num_alternative_paths alignments
-    const int n_alt = n_alt_of(w);
+    const DevConfig &dc = MGX_PARAMS_OF(w).cfg;
+    const int n_alt = dc.post_chain ? imax(1, imin((int)dc.agg_cap, N_ALN - 3 * n_alt_of(w))) : n_alt_of(w);
     if (!w.have_best) { copy_aln(w.aln[Q0], a); w.have_best = 1; return; }
     if (a.score < global_cutoff(w)) return;
     for (int t = 0; t < w.have_best; ++t) if (aln_equal(w, a, w.aln[Q0 + t])) return;
     if (w.have_best < n_alt) { copy_aln(w.aln[Q0 + w.have_best], a); ++w.have_best; return; }
+    // post_chain_alignments: "never skip any alignments" (:92-96) — the host chains them (chain_host.hpp); a query with more
+    // than the queue holds is a capacity status, not a silently shortened list
+    if (dc.post_chain) { w.status = ST_CAPACITY; return; }
     int mn = 0;                                             // std::min_element: the first of equal minima
     for (int t = 1; t < w.have_best; ++t) if (aln_less(w.aln[Q0 + t], w.aln[Q0 + mn])) mn = t;
     if (aln_less(a, w.aln[Q0 + mn])) return;
@@ -5039,7 +5043,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     if (w.status == ST_OK && w.have_best) {
         // get_alignments (aligner_aggregator.hpp:180-202): stable sort ascending by LocalAlignmentLess, emitted from the
         // back, empty alignments dropped
-        int ord[MAX_ALT];
+        int ord[N_ALN];                   // (post_chain_alignments: the queue may hold more than MAX_ALT)
         int n_out = 0;
         for (int t = 0; t < w.have_best; ++t) {
             int pos = t;

@@ -20,6 +20,8 @@ struct DevConfig {
     int32_t gap_open, gap_ext, left_end_bonus, right_end_bonus;
     uint32_t fwd_and_rc, allow_left_trim, seed_complexity_filter;
     uint32_t num_alt;        // num_alternative_paths
+    uint32_t agg_cap;        // alignments the aggregator of a query can hold: num_alt, or — post_chain — MGX_MAX_ALTERNATIVE_PATHS
+    uint32_t post_chain;     // post_chain_alignments: the aggregator never drops an alignment (aligner_aggregator.hpp:88-96)
     uint32_t canonical;      // 1: the graph is a CANONICAL-mode DBGSuccinct (both strands stored): dbg_aligner.cpp:225,644-655;
                              // 2: a PRIMARY-mode one seen through the CanonicalDBG wrapper (canon_graph.hpp), same driver flow;
                              // 3: the same with the wrapper's look-ups read from the graph's reverse-complement tables

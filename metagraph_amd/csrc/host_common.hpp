@@ -11,6 +11,12 @@
 
 namespace mgx {
 
+// alignments per query the device keeps with post_chain_alignments: the kernels built for MGX_MAX_ALTERNATIVE_PATHS have
+// 4 x that many alignment buffers per query, 3 x num_alternative_paths of them serve the extensions (align_core.hpp N_ALN)
+inline uint32_t post_chain_capacity(uint64_t num_alternative_paths) {
+    return 4u * (uint32_t)MGX_MAX_ALTERNATIVE_PATHS - 3u * (uint32_t)std::min<uint64_t>(num_alternative_paths, MGX_MAX_ALTERNATIVE_PATHS);
+}
+
 inline bool check_config_scores(const mgx_config &c) {
     // aligner_config.cpp:39-66
     int8_t min_penalty = INT8_MAX;
@@ -37,7 +43,8 @@ inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, Dev
         c.max_seed_length = std::min<uint64_t>(k, c.max_seed_length);
     }
     if (!check_config_scores(c)) { *err = "Error: sum of min_cell_score and lowest penalty too low."; return MGX_ERR_CONFIG; }
-    if (c.chain_alignments || c.post_chain_alignments) { *err = "seed/alignment chaining is not implemented"; return MGX_ERR_UNSUPPORTED; }
+    if (c.chain_alignments) { *err = "seed chaining (chain_alignments) is not implemented"; return MGX_ERR_UNSUPPORTED; }
+    if (c.post_chain_alignments && labeled) { *err = "post_chain_alignments with an annotation is not implemented"; return MGX_ERR_UNSUPPORTED; }
     if (!c.global_xdrop) { *err = "per-branch xdrop (labeled+coordinates mode) is not implemented"; return MGX_ERR_UNSUPPORTED; }
     if (c.no_backtrack) { *err = "no_backtrack is not implemented"; return MGX_ERR_UNSUPPORTED; }
     if (c.num_alternative_paths < 1 || c.num_alternative_paths > MGX_MAX_ALTERNATIVE_PATHS) {
@@ -57,6 +64,10 @@ inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, Dev
     d->fwd_and_rc = c.forward_and_reverse_complement; d->allow_left_trim = c.allow_left_trim;
     d->seed_complexity_filter = c.seed_complexity_filter;
     d->num_alt = (uint32_t)c.num_alternative_paths;
+    // post_chain_alignments: the aggregator keeps every alignment of a query (aligner_aggregator.hpp:88-96) for chain_host.hpp;
+    // on the device "every" is post_chain_capacity() — a query with more gets MGX_ERR_CAPACITY, never a dropped alignment
+    d->post_chain = c.post_chain_alignments ? 1u : 0u;
+    d->agg_cap = c.post_chain_alignments ? post_chain_capacity(c.num_alternative_paths) : d->num_alt;
     d->canonical = 0;                       // set from the graph's mode by the caller (with fwd_and_rc, dbg_aligner.cpp:225-226)
     return MGX_OK;
 }
@@ -98,7 +109,9 @@ inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lm
     }
     l.cell_words = (uint32_t)std::min<uint64_t>(cw, 0xFFFFFF00ull);
     l.hash_size = next_pow2(2ull * ((uint64_t)l.max_columns + l.max_path) + 2);
-    l.n_aln = 4 * (uint32_t)cfg.num_alternative_paths;
+    // [0, 3 A): extension results, their reversals, backward results (A = num_alternative_paths); then the aggregator's queue
+    l.n_aln = 3 * (uint32_t)cfg.num_alternative_paths
+              + (cfg.post_chain_alignments ? post_chain_capacity(cfg.num_alternative_paths) : (uint32_t)cfg.num_alternative_paths);
     // Convergence vectors (one per visited node, holding only the query range its columns touched) come from a pool sized by
     // the cell budget: a column of w cells appends w words, a range that outgrows its allocation is re-appended.  Half the
     // cell words per extender never binds on the test and bench workloads; a read that runs out gets MGX_ERR_CAPACITY

@@ -55,7 +55,7 @@ inline uint64_t lane_scratch_bytes(uint32_t max_cols, uint32_t hash_slots) {
 // could finish), and the scoring constants it runs with.  `why`: the first reason against.
 inline bool lane_enabled(const mgx_config &c, const DevConfig &d, uint32_t k, uint32_t Lmax, bool no_fast, LaneParams *LP, std::string *why) {
     auto no = [&](const char *w) { if (why) *why = w; return false; };
-    if (d.num_alt != 1) return no("alternative paths");
+    if (d.num_alt != 1 || d.post_chain) return no("alternative paths");
     if (d.canonical != 0) return no("CANONICAL / PRIMARY graph");
     if (k > 32 || k < 2) return no("k > 32: reads are not 2-bit packed");
     if (Lmax < 1 || Lmax > (uint32_t)LANE_MAX_L) return no("reads longer than a lane takes");

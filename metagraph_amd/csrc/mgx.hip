@@ -18,6 +18,7 @@
 #include "graph_build.hpp"
 #include "map_pipe.hpp"
 #include "host_common.hpp"
+#include "chain_host.hpp"
 #include "lane_types.hpp"
 
 using namespace mgx;
@@ -436,6 +437,9 @@ struct mgx_aligner {
     std::vector<ReadResult> h_results;
     std::vector<uint32_t> h_stream;
     HostResults host;
+    HostResults host_chained;          // post_chain_alignments: `host` after chain_host.hpp
+    const char *last_d_seqs = nullptr;           // the batch mgx_align_batch_device ran last (device pointers)
+    const uint64_t *last_d_offsets = nullptr;
     std::vector<uint64_t> m_node_begin, m_fwd, m_rc;
     mgx_stats hstats;
     hipEvent_t ev[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -977,7 +981,9 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     const uint64_t wave_slots = (uint64_t)prop.multiProcessorCount * 4 * MGX_ALIGN_WAVES_PER_SIMD;   // seeding kernel: one wavefront per read
     // (the extension kernel that will run: the same alt / prim selection as launch_groups below)
     const bool sel_primary = A->dcfg.canonical >= 2;
-    const bool sel_alt = A->cfg.num_alternative_paths > 1 || (sel_primary && A->opt.primary_alt_build == 1);
+    // (post_chain_alignments keeps up to MGX_MAX_ALTERNATIVE_PATHS alignments per query: the build with room for them)
+    const uint64_t agg_cap = std::max<uint64_t>(1, A->cfg.post_chain_alignments ? (uint64_t)post_chain_capacity(A->cfg.num_alternative_paths) : A->cfg.num_alternative_paths);
+    const bool sel_alt = agg_cap > 1 || (sel_primary && A->opt.primary_alt_build == 1);
     const uint64_t ext_wps = sel_alt ? mgx_grp_waves_per_simd8_alt() : sel_primary ? mgx_grp_waves_per_simd8_prim() : mgx_grp_waves_per_simd8();
     // (label-aware batches: seeding as ever, extension on the one-read-per-wavefront labeled kernel)
     const uint64_t want_slots = labeled ? std::max<uint64_t>(wave_slots, (uint64_t)prop.multiProcessorCount * 4 * 8 * mgx_grp_waves_per_simd8_lab())
@@ -987,7 +993,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     // `free_b`.  (Half of the free memory, as before, left 15 % of the extension kernel's groups without a slice at
     // 10 M reads next to a host framework's cached allocations.)
     const uint64_t later = n * (sizeof(ReadResult) + sizeof(SeedHdr) + 24 + 16)
-                           + (n * (((uint64_t)l.Lmax + l.Lmax / 4 + 40) * std::max<uint64_t>(1, A->cfg.num_alternative_paths)) + 1024) * 4
+                           + (n * (((uint64_t)l.Lmax + l.Lmax / 4 + 40) * agg_cap) + 1024) * 4
                            + (n * 24 + A->total_kmers / 8 + 4096) * A->seed_scale * sizeof(DevSeed) + (1ull << 30);
     const uint64_t held = A->results.bytes + A->stream.bytes + A->seed_stream.bytes + A->seed_hdr.bytes;     // re-used as far as they reach
     const uint64_t need_later = later > held ? later - held : 0;
@@ -1008,7 +1014,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     A->n_slots = (uint32_t)slots;
     if (probe_env_set("MGX_DEBUG_SLOTS")) fprintf(stderr, "run_align: n %llu stride %llu want_slots %llu slots %llu free %.1f GB\n", (unsigned long long)n, (unsigned long long)stride, (unsigned long long)want_slots, (unsigned long long)slots, free_b / 1e9);
     if (int rc = A->results.ensure(n * sizeof(ReadResult))) return rc;
-    uint64_t words_per_read = ((uint64_t)l.Lmax + l.Lmax / 4 + 40) * std::max<uint64_t>(1, A->cfg.num_alternative_paths);
+    uint64_t words_per_read = ((uint64_t)l.Lmax + l.Lmax / 4 + 40) * agg_cap;
     if (labeled) words_per_read = words_per_read * 2 + 16;      // (an alignment per label group + the label lists; heuristic as below)
     // heuristic size (one alignment per read: nodes + CIGAR runs + path characters); a batch that needs more is re-run
     // with what it asked for (mgx_align_batch_device), so the size is never a correctness limit
@@ -1051,7 +1057,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.no_compact = A->opt.no_compact != 0;
     P.no_alias = A->opt.no_alias != 0;
     P.no_bt_runs = A->opt.no_bt_runs != 0;
-    P.no_flat = A->opt.no_flat != 0;
+    P.no_flat = A->opt.no_flat != 0 || A->cfg.post_chain_alignments;       // (the flat group loop is the one-alignment-per-query driver)
     if (labeled) {
         int adev = 0;
         mgx_annotation_device_view(A->anno, &adev, &P.anno_rows, &P.anno_head, &P.anno_count, &P.anno_more);
@@ -1105,7 +1111,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         // sends PRIMARY graphs there as rounds 2-3 did)
         const bool prim_to_alt = A->opt.primary_alt_build == 1;
         const bool primary = A->dcfg.canonical >= 2;
-        const bool alt = A->cfg.num_alternative_paths > 1 || (primary && prim_to_alt);
+        const bool alt = agg_cap > 1 || (primary && prim_to_alt);
         const bool prim = primary && !alt;
         const uint32_t waves_cu = 4u * (uint32_t)(alt ? mgx_grp_waves_per_simd8_alt() : prim ? mgx_grp_waves_per_simd8_prim() : mgx_grp_waves_per_simd8());
         const uint32_t static_lds = alt ? mgx_grp_static_lds8_alt() : prim ? mgx_grp_static_lds8_prim() : mgx_grp_static_lds8();
@@ -1199,8 +1205,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         // instead of waiting for the mate with the most seeds.  MGX_TWO_PASS=1: the older variant (pass 2 from scratch).
         const int two_pass_env = A->opt.two_pass;
         const int multi_env = A->opt.multi_pass;
-        bool multi = multi_env == 1 && !labeled;
-        if (multi_env < 0 && !labeled) {
+        bool multi = multi_env == 1 && !labeled && !A->cfg.post_chain_alignments;      // (resume records hold num_alternative_paths alignments)
+        if (multi_env < 0 && !labeled && !A->cfg.post_chain_alignments) {
             // automatic: worth it when reads run many extensions, i.e. carry many seeds (sub-k seeds of a pan-genome: ~100 per
             // read; a plain read: a handful).  The seeding kernel has finished counting them by now.
             unsigned long long seeds_total = 0;
@@ -1420,6 +1426,7 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
     const char *d_seqs; const uint64_t *d_offsets; uint32_t Lmax;
     if (n == 0) { A->n_reads = 0; return MGX_OK; }
     { HostStageTimer t("stage_batch"); if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc; }
+    A->last_d_seqs = d_seqs; A->last_d_offsets = d_offsets;
     bool mapped = A->cfg.max_seed_length >= A->graph->g.k;
     { HostStageTimer t("run_map"); if (int rc = run_map(A, d_seqs, d_offsets, n, A->dcfg.fwd_and_rc != 0, mapped, Lmax)) return rc; }
     for (;;) {
@@ -1459,6 +1466,16 @@ int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
     if (used) HIP_TRY(hipMemcpy(A->h_stream.data(), A->stream.p, used * 4, hipMemcpyDeviceToHost));
     A->host.decode(A->h_results.data(), n, A->h_stream.data(), ~0ull, A->anno != nullptr);
     A->host.view(out);
+    if (A->cfg.post_chain_alignments && n) {
+        // chain_alignments (dbg_aligner.cpp:328-332) on the host: needs the reads once more (a few bytes per alignment kept)
+        std::vector<uint64_t> offs(n + 1);
+        HIP_TRY(hipMemcpy(offs.data(), A->last_d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
+        std::vector<char> reads(offs[n] + 1);
+        if (offs[n]) HIP_TRY(hipMemcpy(reads.data(), A->last_d_seqs, offs[n], hipMemcpyDeviceToHost));
+        mgx_results plain = *out;
+        chain_results(plain, reads.data(), offs.data(), A->cfg, A->graph->g.k, &A->host_chained);
+        A->host_chained.view(out);
+    }
     return MGX_OK;
 }
 
@@ -1496,6 +1513,19 @@ int mgx_results_from_raw_labeled(const void *headers, uint64_t n, const uint32_t
 }
 
 void mgx_raw_store_free(mgx_raw_store *store) { delete store; }
+
+// chain_alignments (aligner_chainer.cpp:555-720) over decoded results — what mgx_fetch_results does itself when the aligner's
+// config has post_chain_alignments set; for results decoded elsewhere (mgx_results_from_raw after a gather).  Host code.
+int mgx_chain_alignments(const mgx_config *config, uint32_t k, const mgx_results *in, const char *seqs, const uint64_t *offsets,
+                         mgx_raw_store **store, mgx_results *out) {
+    if (!config || !in || !store || !out || (in->n_queries && (!seqs || !offsets))) return fail(MGX_ERR_INVALID, "null argument");
+    if (k < 2) return fail(MGX_ERR_INVALID, "k out of range");
+    auto *S = new mgx_raw_store();
+    chain_results(*in, seqs, offsets, *config, k, &S->host);
+    S->host.view(out);
+    *store = S;
+    return MGX_OK;
+}
 
 int mgx_align_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_results *out) {
     if (!out) return fail(MGX_ERR_INVALID, "null argument");

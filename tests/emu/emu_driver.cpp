@@ -380,7 +380,7 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     std::vector<int8_t> sm(128 * 128);
     memcpy(sm.data(), cfg.score_matrix, 128 * 128);
     R->results.resize(n);
-    uint64_t out_words = n * ((uint64_t)R->lim.Lmax * 3 + 64) * std::max<uint64_t>(1, AN ? R->lim.lab_pool : cfg.num_alternative_paths) + 1024;
+    uint64_t out_words = n * ((uint64_t)R->lim.Lmax * 3 + 64) * std::max<uint64_t>(1, AN ? R->lim.lab_pool : (cfg.post_chain_alignments ? (uint64_t)post_chain_capacity(cfg.num_alternative_paths) : cfg.num_alternative_paths)) + 1024;
     R->stream.assign(out_words, 0);
     R->seeds.assign(n * 2 * (uint64_t)R->lim.max_seeds, DevSeed{ 0, 0, 0, 0, 0 });
     unsigned long long cursors[2] = { 0, 0 };
@@ -425,7 +425,7 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     const char *split = getenv("MGX_EMU_SPLIT");
     // the extension phase of one read: through the flat group loop (the product's default with one alignment per seed; a
     // single group here, so every transition of the state machine is exercised, not the interleaving) or the per-read program
-    const bool flat = cfg.num_alternative_paths == 1 && !AN && !(getenv("MGX_NO_FLAT") && atoi(getenv("MGX_NO_FLAT")) == 1);
+    const bool flat = cfg.num_alternative_paths == 1 && !cfg.post_chain_alignments && !AN && !(getenv("MGX_NO_FLAT") && atoi(getenv("MGX_NO_FLAT")) == 1);
     const uint32_t ldsb_all = (uint32_t)(lds_env ? atoi(lds_env) : 2048);
     auto run_extend = [&](uint64_t read, const uint8_t *rec) {
         if (!flat) { align_read<PH_EXTEND>(*w, P, read, 0, &R->stats, &sd, rows.data(), lds.data(), ldsb_all, rec); return; }
