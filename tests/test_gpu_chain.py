@@ -37,11 +37,11 @@ def test_chaining_stitched_reads_on_gpu():
     n_chained = n_capacity = 0
     for seed in range(4):
         rng = random.Random(900 + seed)
-        k = rng.choice([10, 12, 15, 21])
+        k = rng.choice([12, 15, 21])
         genome = rand_seq(rng, 6000)
         g = orc.Graph.build(k, [genome], 0, False)
         cfg = chain_config(k, (2, -1, -2) if seed % 2 else (2, -3, -3), None)
-        cfg.min_seed_length = min(k, 8)
+        cfg.min_seed_length = k if seed % 2 else 10         # (many sub-k seeds: many alignments to keep)
         queries = []
         for _ in range(300):
             a, b = rng.randrange(0, 5800), rng.randrange(0, 5800)
@@ -61,7 +61,8 @@ def test_chaining_stitched_reads_on_gpu():
                 continue
             assert got[q] == want[q], (seed, q, queries[q], got[q], want[q])
             n_chained += any(0 in a["nodes"] for a in got[q])
-    assert n_chained > 100 and n_capacity <= 60, (n_chained, n_capacity)
+    # (a query with more than 13 alignments above the cut-off has a capacity status: include/mgx.h, post_chain_alignments)
+    assert n_chained > 100 and n_capacity <= 240, (n_chained, n_capacity)
 
 
 def test_post_chain_with_an_annotation_is_refused():
