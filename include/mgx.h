@@ -323,10 +323,12 @@ size_t mgx_format_json(const mgx_results *res, uint64_t query_index, const char 
 
 /*
  * Label-aware alignment (graph/alignment/aligner_labeled.{hpp,cpp}, annotation_buffer.{hpp,cpp}; BASELINE config 3).
- * What runs on the device this round is the path's hot primitive: the ONE batched BinaryMatrix::get_rows of
- * AnnotationBuffer::fetch_queued_annotations (annotation_buffer.cpp:182; ColumnMajor::get_rows,
- * annotation/binary_matrix/column_sparse/column_major.cpp:27-44 — 1000 columns x |rows| random bit tests in the
- * reference).  LabeledExtender's label bookkeeping itself is restated in the oracle only.
+ * On the device: the whole LabeledAligner — filter_seeds, LabeledExtender's per-column label sets (flush / call_outgoing / the
+ * label-bounded backtracking), the per-label aggregator (mgx_labeled_aligner_create below) — over a row-major label matrix
+ * whose rows ARE the label sets AnnotationBuffer would fetch, plus the batched BinaryMatrix::get_rows of
+ * AnnotationBuffer::fetch_queued_annotations as an entry point of its own (annotation_buffer.cpp:182; ColumnMajor::get_rows,
+ * annotation/binary_matrix/column_sparse/column_major.cpp:27-44 — 1000 columns x |rows| random bit tests in the reference).
+ * Not built: label coordinates and seed chaining (aligner_labeled.cpp:361-448,685-700, aligner_chainer.cpp:47-339).
  *
  * mgx_annotation_create stands in for the annotator argument of LabeledAligner<>(graph, config, annotator)
  * (aligner_labeled.hpp:125-127): the binary matrix as column bit vectors, columns[j] = ceil(n_rows / 64) words, bit r =
@@ -364,7 +366,13 @@ int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n,
  * This round: BASIC-, PRIMARY- and CANONICAL-mode graphs (PRIMARY: through the CanonicalDBG wrapper, labels looked up by base
  * node; CANONICAL: by the k-mer's representative, the smaller BOSS index of the k-mer and its reverse complement — as
  * annotation_buffer.cpp:41-63 does), annotations without coordinates (ColumnCompressed), num_alternative_paths <= 2;
- * anything else: MGX_ERR_UNSUPPORTED.  A read whose label bookkeeping outgrows its arena gets MGX_ERR_CAPACITY. */
+ * anything else: MGX_ERR_UNSUPPORTED.  A read whose label bookkeeping outgrows its arena gets MGX_ERR_CAPACITY.
+ * One case the reference leaves UNDEFINED on CANONICAL-mode graphs: the reversed alignment that seeds a backward pass holds
+ * reverse-complement nodes its AnnotationBuffer was never asked to fetch; set_seed / flush assert on them
+ * (aligner_labeled.cpp:110,143-146) and a release build reads through a null pointer.  The library answers such a look-up
+ * with the labels of the node's representative — what a fetch would have found; the oracle does the same and counts them
+ * (orc_unfetched_label_lookups: 0 on the reference's own label tests, which is what pins this path; reads that do need
+ * such a look-up agree between library and oracle but have no reference behaviour to agree with). */
 int mgx_labeled_aligner_create(const mgx_graph *graph, const mgx_config *config, const mgx_limits *limits,
                                const mgx_annotation *annotation, mgx_aligner **out);
 /* mgx_format_tsv for label-aware results: every alignment's fields are followed by its labels' names joined by ';'

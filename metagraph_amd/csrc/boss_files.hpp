@@ -424,6 +424,10 @@ inline ColumnFile parse_columns(const uint8_t *data, size_t n) {
             std::vector<uint64_t> ones;
             size = read_sd_vector(c, "column", f.n_rows, [&](uint64_t p) { ones.push_back(p); });
             if (c.u8("column")) {                    // inverted: the stored positions are the rows WITHOUT the label
+                // (the expansion has one entry per row: a crafted header must not make a tiny file allocate terabytes — a real
+                // column file of n_rows rows is at least n_rows / 8 bytes of some column only if dense, so bound the TOTAL
+                // of expanded rows instead: 2^33 entries = 64 GB of row indices is beyond anything one load call should do)
+                if (size > (1ull << 33) || f.rows.size() + size > (1ull << 33)) throw Unsupported("column: inverted column of more than 2^33 rows");
                 size_t q = 0;
                 for (uint64_t r = 0; r < size; ++r) { if (q < ones.size() && ones[q] == r) ++q; else f.rows.push_back(r); }
             } else f.rows.insert(f.rows.end(), ones.begin(), ones.end());
@@ -431,7 +435,11 @@ inline ColumnFile parse_columns(const uint8_t *data, size_t n) {
             const Bits v = code == CODE_STAT ? read_bit_vector_stat(c, "column") : read_rrr63(c, "column");
             size = v.bits;
             for (uint64_t wi = 0; wi + 1 < v.w.size(); ++wi)
-                for (uint64_t x = v.w[wi]; x; x &= x - 1) f.rows.push_back(wi * 64 + (uint64_t)__builtin_ctzll(x));
+                for (uint64_t x = v.w[wi]; x; x &= x - 1) {
+                    const uint64_t r = wi * 64 + (uint64_t)__builtin_ctzll(x);
+                    if (r >= v.bits) throw ParseError("column: a bit is set behind the vector's last position");      // (tail bits of the last word)
+                    f.rows.push_back(r);
+                }
         } else if (code == CODE_IL4096) throw Unsupported("column: bit_vector_il<4096> is not read");
         else throw ParseError("column: unknown bit vector representation " + std::to_string(code));
         if (size != f.n_rows) throw ParseError("inconsistent column size");          // :466-467

@@ -1,7 +1,8 @@
 // label_driver.hpp — the per-read driver of label-aware alignment: LabeledAligner::filter_seeds, the per-label
 // AlignmentAggregator and DBGAligner::align_both_directions / align_core with labeled seeds (A/aligner_labeled.cpp:612-721,
 // A/aligner_aggregator.hpp:24-206, A/dbg_aligner.cpp:105-149,360-384,531-758).  Included by align_core.hpp inside namespace mgx
-// in builds with MGX_WITH_LABELS; BASIC-mode graphs, annotation without coordinates (the reference's ColumnCompressed case).
+// in builds with MGX_WITH_LABELS; BASIC-, PRIMARY- and CANONICAL-mode graphs, annotation without coordinates (the
+// reference's ColumnCompressed case).
 //
 // Alignment buffers (DevLimits::lab_ext = E, lab_pool): [0, E) the extensions of the current seed, [E, 2E) their reversals
 // (seeds of the backward pass), [2E, 3E) backward extensions, [3E, 3E + pool) the aggregator's alignments.  The reference's
@@ -395,7 +396,7 @@ MGX_DEV void lab_check_later(Wave &w, const ExtenderState &F, int s, int32_t i, 
     }
 }
 
-// ---- align_both_directions (dbg_aligner.cpp:531-758, the branch without chaining) with labeled seeds, BASIC graphs ----
+// ---- align_both_directions (dbg_aligner.cpp:531-758, the branch without chaining) with labeled seeds (every graph mode) ----
 MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = MGX_PARAMS_OF(w);

@@ -8,7 +8,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
+#include <tuple>
 #include <atomic>
 #include <string>
 #include <vector>
@@ -349,6 +352,12 @@ struct mgx_graph {
     uint64_t bytes = 0;
     uint32_t mode = MGX_MODE_BASIC;
     bool primary_tables = false;      // PRIMARY: reverse-complement tables built (default; MGX_PRIMARY_TABLES=0 turns them off)
+    // What label-aware aligners derive from the whole graph, computed once per graph (and annotation) instead of once per
+    // aligner — the host adapters build one aligner per batch and worker thread:
+    mutable std::mutex label_mu;
+    mutable DevBuf canon_repr;        // CANONICAL-mode graphs: node -> the representative of its k-mer (k_canon_repr, 4 B per node)
+    mutable bool canon_repr_ready = false;
+    mutable std::map<std::tuple<const void *, const void *, uint64_t>, bool> dummy_clean;   // per annotation (handle, matrix, rows)
 };
 
 extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);    // mgx_grp.hip, MGX_GROUP=8
@@ -411,7 +420,6 @@ struct mgx_aligner {
     const mgx_graph *graph = nullptr;
     const mgx_annotation *anno = nullptr;      // label-aware alignment (mgx_labeled_aligner_create)
     bool anno_dummy_clean = false;             // no row of a dummy node holds a label (k_anno_dummy_rows)
-    DevBuf anno_base;                          // CANONICAL-mode graphs: node -> representative (k_canon_repr)
     mgx_config cfg;
     DevConfig dcfg;
     mgx_limits user_lim;
@@ -739,10 +747,10 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
         if (rc) return fail(rc, "%s", err.c_str());
     }
     if (anno) {
-        // LabeledAligner<>(graph, config, annotator) (aligner_labeled.hpp:125-127).  On the device: BASIC-mode graphs (the
-        // reference looks labels up by base node through the CanonicalDBG wrapper for PRIMARY graphs and by spelling for
-        // CANONICAL ones: not on the device yet), annotation without coordinates, as many alternative paths per label as
-        // the labeled kernel build holds.
+        // LabeledAligner<>(graph, config, annotator) (aligner_labeled.hpp:125-127).  On the device: BASIC-, PRIMARY- and
+        // CANONICAL-mode graphs (labels looked up by base node through the CanonicalDBG wrapper, resp. by the k-mer's
+        // representative: include/mgx.h), annotation without coordinates, as many alternative paths per label as the
+        // labeled kernel build holds.
         if (A->cfg.num_alternative_paths > (uint64_t)std::min(mgx_lab64_max_alt(), mgx_grp_max_alt8_lab()))
             return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment: num_alternative_paths <= %d on the device", std::min(mgx_lab64_max_alt(), mgx_grp_max_alt8_lab()));
         int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;
@@ -759,18 +767,25 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
     if (anno) {
         int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;
         mgx_annotation_device_view(anno, &adev, &arows, &h, &c, &m);
-        uint32_t *d_flag = nullptr, flag = 1;
-        HIP_TRY(hipMalloc(&d_flag, 4));
-        HIP_TRY(hipMemset(d_flag, 0, 4));
-        if (g->g.n) k_anno_dummy_rows<<<(uint32_t)((g->g.n + 255) / 256), 256>>>(g->g, h, arows, d_flag);
-        HIP_TRY(hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));
-        (void)hipFree(d_flag);
-        A->anno_dummy_clean = flag == 0;
-        if (g->mode == MGX_MODE_CANONICAL) {
-            if (int rc = A->anno_base.ensure((g->g.n + 1) * 4)) return rc;
-            k_canon_repr<<<(uint32_t)((g->g.n + 256) / 256), 256>>>(g->g, A->anno_base.as<uint32_t>());
+        std::lock_guard<std::mutex> lock(g->label_mu);
+        const auto key = std::make_tuple((const void *)anno, (const void *)h, arows);
+        auto it = g->dummy_clean.find(key);
+        if (it == g->dummy_clean.end()) {
+            uint32_t *d_flag = nullptr, flag = 1;
+            HIP_TRY(hipMalloc(&d_flag, 4));
+            HIP_TRY(hipMemset(d_flag, 0, 4));
+            if (g->g.n) k_anno_dummy_rows<<<(uint32_t)((g->g.n + 255) / 256), 256>>>(g->g, h, arows, d_flag);
+            HIP_TRY(hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost));
+            (void)hipFree(d_flag);
+            it = g->dummy_clean.emplace(key, flag == 0).first;
+        }
+        A->anno_dummy_clean = it->second;
+        if (g->mode == MGX_MODE_CANONICAL && !g->canon_repr_ready) {
+            if (int rc = g->canon_repr.ensure((g->g.n + 1) * 4)) return rc;
+            k_canon_repr<<<(uint32_t)((g->g.n + 256) / 256), 256>>>(g->g, g->canon_repr.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());
+            g->canon_repr_ready = true;
         }
     }
     if (int rc = A->score_matrix.ensure(128 * 128)) return rc;
@@ -1062,7 +1077,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         int adev = 0;
         mgx_annotation_device_view(A->anno, &adev, &P.anno_rows, &P.anno_head, &P.anno_count, &P.anno_more);
         P.labeled = 1u | (A->anno_dummy_clean ? 2u : 0u);
-        P.anno_base = A->graph->mode == MGX_MODE_CANONICAL ? A->anno_base.as<uint32_t>() : nullptr;
+        P.anno_base = A->graph->mode == MGX_MODE_CANONICAL ? A->graph->canon_repr.as<uint32_t>() : nullptr;
         P.no_alias = 1;           // (a flush clears columns in place: convergence entries must not alias their S windows)
     }
 #ifdef MGX_PROBES

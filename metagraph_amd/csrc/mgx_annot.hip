@@ -121,9 +121,12 @@ __global__ void k_rows_gather(const uint64_t *head, const uint32_t *more, uint64
 }
 // ---- construction from the columns' set rows (mgx_annotation_create_sparse) ----
 // pair p (the p-th set bit of the matrix in column order) -> key = row << 24 | label; its label by bisection of col_begin
-__global__ void k_pairs_keys(const uint64_t *col_begin, uint32_t n_labels, const uint64_t *rows, uint64_t n_pairs, uint64_t *keys) {
+__global__ void k_pairs_keys(const uint64_t *col_begin, uint32_t n_labels, const uint64_t *rows, uint64_t n_pairs, uint64_t n_rows,
+                             uint64_t *keys, uint32_t *bad) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
+    // (a row outside the matrix would sort — the radix sort covers the bits of n_rows only — into a valid row's run)
+    if (rows[p] >= n_rows) { atomicOr(bad, 1u); keys[p] = 0; return; }
     uint32_t lo = 0, hi = n_labels;                      // the last label with col_begin[label] <= p
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (col_begin[mid] <= p) lo = mid; else hi = mid; }
     keys[p] = (rows[p] << 24) | lo;
@@ -234,6 +237,9 @@ int mgx_annotation_create_sparse(uint64_t n_rows, uint32_t n_labels, const uint6
     if (!out || !col_begin || n_labels >= (1u << 24) || n_rows >= (1ull << 40)) return afail(MGX_ERR_INVALID, "mgx_annotation_create_sparse: bad arguments");
     const uint64_t n_pairs = col_begin[n_labels];
     if (!rows && n_pairs) return afail(MGX_ERR_INVALID, "mgx_annotation_create_sparse: bad arguments");
+    for (uint32_t j = 0; j < n_labels; ++j)
+        if (col_begin[j] > col_begin[j + 1]) return afail(MGX_ERR_INVALID, "mgx_annotation_create_sparse: col_begin must be ascending (label %u)", j);
+    if (col_begin[0] != 0) return afail(MGX_ERR_INVALID, "mgx_annotation_create_sparse: col_begin[0] must be 0");
     if (mgx_device_count() <= device) return afail(MGX_ERR_NO_DEVICE, "HIP device %d not available", device);
     HIP_TRY_A(hipSetDevice(device));
     auto *A = new mgx_annotation();
@@ -263,7 +269,14 @@ int mgx_annotation_create_sparse(uint64_t n_rows, uint32_t n_labels, const uint6
         }
         HIP_TRY_B(hipMalloc(&d_keys, n_pairs * 8));
         HIP_TRY_B(hipMalloc(&d_sorted, n_pairs * 8));
-        k_pairs_keys<<<pblocks, tb>>>(d_cb, n_labels, src, n_pairs, d_keys);
+        uint32_t *d_bad = nullptr, bad = 0;
+        HIP_TRY_B(hipMalloc(&d_bad, 4));
+        HIP_TRY_B(hipMemset(d_bad, 0, 4));
+        k_pairs_keys<<<pblocks, tb>>>(d_cb, n_labels, src, n_pairs, n_rows, d_keys, d_bad);
+        const hipError_t rb = hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
+        (void)hipFree(d_bad);
+        if (rb != hipSuccess) return bail(afail(MGX_ERR_NO_DEVICE, "hipMemcpy: %s", hipGetErrorString(rb)));
+        if (bad) return bail(afail(MGX_ERR_INVALID, "mgx_annotation_create_sparse: a row index is outside the matrix (%llu rows)", (unsigned long long)n_rows));
         int end_bit = 24;
         while (end_bit < 64 && (n_rows >> (end_bit - 24))) ++end_bit;
         size_t sort_bytes = 0;

@@ -51,6 +51,16 @@ KERNEL_VARIANTS = {
 }
 
 
+_LANE_SESSION = {"tests": 0, "launches": 0}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    # a "lane" variant that never launched k_lane would be the other variants run twice
+    if _LANE_SESSION["tests"] >= 20 and _LANE_SESSION["launches"] == 0:
+        print("\nERROR: %d tests ran in the 'lane' kernel variant and the lane-per-read kernel was never launched" % _LANE_SESSION["tests"])
+        session.exitstatus = 1
+
+
 def _launch_counts():
     import ctypes as C
     from metagraph_amd import capi
@@ -82,6 +92,11 @@ def kernels(request):
     if rep is None or not rep.passed:                        # (skipped or failed in its body: nothing to conclude from the counters)
         return
     after = _launch_counts()
+    if request.param == "lane":
+        # the lane-per-read kernel only takes the configurations lane_enabled() accepts (BASIC graphs, one alignment per query,
+        # k <= 32 ...): not every test of the variant qualifies, but over the session many do (pytest_sessionfinish below)
+        _LANE_SESSION["tests"] += 1
+        _LANE_SESSION["launches"] += after["lane"] - before["lane"]
     for name in must:
         assert after[name] > before[name], "variant %s never launched %s" % (request.param, name)
     for name in must_not:

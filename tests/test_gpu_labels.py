@@ -151,8 +151,14 @@ def test_labeled_alignment_on_canonical_mode_graphs_on_gpu(seed, k, kernel):
     cfg = capi.config_cli(k)
     if seed == 2:
         cfg.min_seed_length = 11
+    import ctypes as C
+    orc.L().orc_unfetched_label_lookups.restype = C.c_uint64
+    before = orc.L().orc_unfetched_label_lookups()
     _, want = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=False, kernel=kernel, mode=1)
     assert sum(1 for a in want if a) >= 8
+    # look-ups the reference leaves undefined (include/mgx.h, mgx_labeled_aligner_create): library and oracle agree on these
+    # reads, the reference has no behaviour to compare with — reported, not asserted (the golden label tests assert 0)
+    print("canonical labeled world %d: %d look-ups of un-fetched nodes in the oracle" % (seed, orc.L().orc_unfetched_label_lookups() - before))
 
 
 def test_labeled_aligner_refuses_what_it_cannot_do():
