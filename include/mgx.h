@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 3      /* 3 (round 4): mgx_alignment::n_labels / labels_begin, mgx_results::labels (label-aware alignment),
+#define MGX_ABI_VERSION 4      /* 4 (round 5): mgx_stats::n_capacity_retried, mgx_chain_alignments, post_chain_alignments accepted;
+                                * 3 (round 4): mgx_alignment::n_labels / labels_begin, mgx_results::labels (label-aware alignment),
                                 * mgx_stats::extend_kernels / n_lane_reads / lane_ms, "key=value" options of mgx_aligner_set_pipeline;
                                 * 2 (round 3): mgx_annotation_*; mgx_stats / mgx_config grew in round 2 without a bump (callers built
                                 * against 1 must be rebuilt: mgx_aligner_stats writes the larger struct) */
@@ -221,6 +222,8 @@ typedef struct mgx_stats {
     uint64_t lane_bail_reads[32]; /* reads the lane-per-read kernel passed on to the group kernel, by reason (the LANE_BAIL codes of
                                    csrc/lane_read.hpp: 3 second strand, 4 many seeds, 5 invalid characters, 10 fork, 14 / 16 wide band,
                                    15 node seen before, 19 a later seed survives, 26 backward extension, ...) */
+    uint64_t n_capacity_retried; /* queries the last mgx_align_batch re-aligned with doubled limits after an MGX_ERR_CAPACITY status
+                                   (they are in its results like any other query; n_capacity_errors counts them too) */
 } mgx_stats;
 enum { MGX_KERNEL_GRP8 = 1, MGX_KERNEL_GRP8_PRIM = 2, MGX_KERNEL_GRP8_ALT = 4, MGX_KERNEL_EXT64 = 8, MGX_KERNEL_LANE = 16,
        MGX_KERNEL_LAB64 = 32, MGX_KERNEL_GRP8_LAB = 64 /* the label-aware builds of the 64-lane and the 8-lane kernel */ };

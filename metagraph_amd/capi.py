@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 MGX_OK = 0
-MGX_ABI_VERSION = 3
+MGX_ABI_VERSION = 4
 MGX_ERR_INVALID, MGX_ERR_NO_DEVICE, MGX_ERR_UNSUPPORTED, MGX_ERR_CONFIG, MGX_ERR_CAPACITY, MGX_ERR_OOM = -1, -2, -3, -4, -5, -6
 OP_CHARS = "SX=DIG"
 
@@ -79,7 +79,7 @@ class Stats(C.Structure):
                 ("seeding_ms", C.c_double), ("sort_ms", C.c_double), ("extend_ms", C.c_double), ("n_seed_lines", C.c_uint64),
                 ("n_fast_columns", C.c_uint64), ("extend_kernels", C.c_uint64), ("n_lane_reads", C.c_uint64),
                 ("lane_ms", C.c_double), ("n_lane_lines", C.c_uint64), ("n_lane_columns", C.c_uint64),
-                ("lane_bail_reads", C.c_uint64 * 32)]
+                ("lane_bail_reads", C.c_uint64 * 32), ("n_capacity_retried", C.c_uint64)]
 
 
 KERNEL_GRP8, KERNEL_GRP8_PRIM, KERNEL_GRP8_ALT, KERNEL_EXT64, KERNEL_LANE, KERNEL_LAB64, KERNEL_GRP8_LAB = 1, 2, 4, 8, 16, 32, 64

@@ -213,6 +213,23 @@ struct HostResults {
         return true;
     }
 
+    // append query q of `src` (its status and alignments) as the next query of *this
+    void append_query(const mgx_results &src, uint64_t q) {
+        if (aln_begin.empty()) aln_begin.push_back(0);
+        status.push_back(src.status ? src.status[q] : 0);
+        for (uint64_t ai = src.aln_begin[q]; ai < src.aln_begin[q + 1]; ++ai) {
+            mgx_alignment m = src.alignments[ai];
+            const uint64_t nb = nodes.size(), cb = cigar.size(), sb = seqs.size(), lb = labels.size();
+            nodes.insert(nodes.end(), src.nodes + m.nodes_begin, src.nodes + m.nodes_begin + m.n_nodes);
+            cigar.insert(cigar.end(), src.cigar + m.cigar_begin, src.cigar + m.cigar_begin + m.n_cigar);
+            seqs.insert(seqs.end(), src.seqs + m.seq_begin, src.seqs + m.seq_begin + m.seq_len);
+            if (src.labels && m.n_labels) labels.insert(labels.end(), src.labels + m.labels_begin, src.labels + m.labels_begin + m.n_labels);
+            m.nodes_begin = nb; m.cigar_begin = cb; m.seq_begin = sb; m.labels_begin = lb;
+            alns.push_back(m);
+        }
+        aln_begin.push_back(alns.size());
+    }
+
     void view(mgx_results *out) const {
         out->n_queries = status.size();
         out->aln_begin = aln_begin.data();

@@ -446,6 +446,8 @@ struct mgx_aligner {
     std::vector<uint32_t> h_stream;
     HostResults host;
     HostResults host_chained;          // post_chain_alignments: `host` after chain_host.hpp
+    HostResults host_retried;          // mgx_align_batch: the results with the re-aligned capacity queries in place
+    bool retry_capacity = true;        // (mgx_aligner_set_pipeline "retry_capacity=0": statuses are handed to the caller)
     const char *last_d_seqs = nullptr;           // the batch mgx_align_batch_device ran last (device pointers)
     const uint64_t *last_d_offsets = nullptr;
     std::vector<uint64_t> m_node_begin, m_fwd, m_rc;
@@ -1413,6 +1415,7 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
         else if (key == "primary_alt_build") o.primary_alt_build = v;
         else if (key == "lane") o.lane = v;
         else if (key == "map_pipe") o.map_pipe = v;
+        else if (key == "retry_capacity") A->retry_capacity = v != 0;
         else return fail(MGX_ERR_INVALID, "unknown option '%s'", name);
         return MGX_OK;
     }
@@ -1542,10 +1545,83 @@ int mgx_chain_alignments(const mgx_config *config, uint32_t k, const mgx_results
     return MGX_OK;
 }
 
+// Queries whose per-read arenas overflowed (status MGX_ERR_CAPACITY: the reference has no such limit, its tables grow on the
+// heap) are aligned again by a temporary aligner with doubled limits, up to six doublings, and take their place in the
+// results — what the C++ adapter (host/hip_dbg_aligner.hpp) did for its callers since round 2, now for every caller of
+// mgx_align_batch (the Python binding among them).  What doubling cannot cure stays a capacity status: a query with more
+// alignments than the post_chain_alignments queue holds, a label-aware query beyond the fixed label arenas.
+static int retry_capacity_queries(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_results *out) {
+    std::vector<uint64_t> todo;
+    for (uint64_t q = 0; q < n; ++q) if (out->status[q] == MGX_ERR_CAPACITY) todo.push_back(q);
+    if (todo.empty() || !A->retry_capacity) return MGX_OK;
+    std::vector<uint64_t> h_off;
+    std::vector<char> h_seq;
+    if (on_device) {
+        h_off.resize(n + 1);
+        HIP_TRY(hipMemcpy(h_off.data(), offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
+        h_seq.resize(h_off[n] + 1);
+        if (h_off[n]) HIP_TRY(hipMemcpy(h_seq.data(), seqs, h_off[n], hipMemcpyDeviceToHost));
+        seqs = h_seq.data(); offsets = h_off.data();
+    }
+    // results so far, query by query (replaced below)
+    std::vector<HostResults> fixed(todo.size());
+    std::vector<uint8_t> have(todo.size(), 0);
+    mgx_limits lim;
+    mgx_aligner_get_limits(A, &lim);
+    mgx_aligner *tmp = nullptr;
+    struct Guard { mgx_aligner *&p; ~Guard() { if (p) mgx_aligner_destroy(p); } } guard{ tmp };
+    std::vector<uint64_t> pending(todo.size());
+    for (size_t t = 0; t < todo.size(); ++t) pending[t] = t;
+    for (int attempt = 0; attempt < 6 && !pending.empty(); ++attempt) {
+        lim.max_query_length = 0;                       // the (smaller) batch sets its own
+        lim.max_columns = lim.max_columns * 2;
+        lim.max_seeds = std::min<uint32_t>(65535u, lim.max_seeds * 2);
+        lim.cell_arena_bytes = lim.cell_arena_bytes * 2;
+        if (tmp) { mgx_aligner_destroy(tmp); tmp = nullptr; }
+        if (int rc = aligner_create(A->graph, &A->cfg, &lim, A->anno, &tmp)) return rc;
+        tmp->opt = A->opt; tmp->mode = A->mode; tmp->no_fast = A->no_fast;
+        tmp->retry_capacity = false;
+        std::string blob;
+        std::vector<uint64_t> offs(pending.size() + 1, 0);
+        for (size_t t = 0; t < pending.size(); ++t) {
+            const uint64_t q = todo[pending[t]];
+            blob.append(seqs + offsets[q], offsets[q + 1] - offsets[q]);
+            offs[t + 1] = blob.size();
+        }
+        mgx_results sub{};
+        if (int rc = mgx_align_batch(tmp, blob.data(), offs.data(), pending.size(), 0, &sub)) return rc;
+        std::vector<uint64_t> again;
+        for (size_t t = 0; t < pending.size(); ++t) {
+            if (sub.status[t] == MGX_ERR_CAPACITY) { again.push_back(pending[t]); continue; }
+            fixed[pending[t]].append_query(sub, t);
+            have[pending[t]] = 1;
+        }
+        pending.swap(again);
+        mgx_aligner_get_limits(tmp, &lim);
+    }
+    bool any = false;
+    for (uint8_t h : have) any |= h != 0;
+    if (!any) return MGX_OK;
+    HostResults merged;
+    size_t t = 0;
+    for (uint64_t q = 0; q < n; ++q) {
+        if (t < todo.size() && todo[t] == q) {
+            if (have[t]) { mgx_results v; fixed[t].view(&v); merged.append_query(v, 0); }
+            else merged.append_query(*out, q);
+            ++t;
+        } else merged.append_query(*out, q);
+    }
+    A->host_retried = std::move(merged);
+    A->host_retried.view(out);
+    A->hstats.n_capacity_retried = (uint64_t)std::count(have.begin(), have.end(), (uint8_t)1);
+    return MGX_OK;
+}
+
 int mgx_align_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_results *out) {
     if (!out) return fail(MGX_ERR_INVALID, "null argument");
     if (int rc = mgx_align_batch_device(A, seqs, offsets, n, on_device)) return rc;
-    return mgx_fetch_results(A, out);
+    if (int rc = mgx_fetch_results(A, out)) return rc;
+    return retry_capacity_queries(A, seqs, offsets, n, on_device, out);
 }
 
 // test hook: keep the per-read seed lists of the next batches (device -> mgx_fetch_seeds)

@@ -309,7 +309,9 @@ def test_small_cell_budget_gives_capacity_statuses_not_wrong_answers():
     G = gpu_graph(g)
     lim = capi.Limits()
     lim.cell_arena_bytes = 1600
-    got, status = aligner.Aligner(G, cfg, lim).align_batch(reads)
+    A = aligner.Aligner(G, cfg, lim)
+    A.set_pipeline("retry_capacity=0")                      # (statuses as the kernels report them)
+    got, status = A.align_batch(reads)
     assert any(s == capi.MGX_ERR_CAPACITY for s in status)
     for q, s in enumerate(status):
         assert s in (0, capi.MGX_ERR_CAPACITY)
@@ -317,6 +319,11 @@ def test_small_cell_budget_gives_capacity_statuses_not_wrong_answers():
             assert got[q] == want[q]
     got, status = aligner.Aligner(G, cfg).align_batch(reads)
     assert all(s == 0 for s in status) and got == want
+    # ... and mgx_align_batch re-aligns them itself with doubled limits (round 5: for every caller, not only the C++ adapter)
+    B = aligner.Aligner(G, cfg, lim)
+    got, status = B.align_batch(reads)
+    assert all(s == 0 for s in status) and got == want
+    assert B.stats()["n_capacity_retried"] > 0
 
 
 @pytest.mark.parametrize("per_wave", [0, 1, 3, 8])
