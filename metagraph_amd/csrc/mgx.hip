@@ -472,7 +472,8 @@ struct mgx_aligner {
         int no_compact = 0, no_alias = 0, no_bt_runs = 0, no_flat = 0;
         int primary_alt_build = 0;
         int lane = -1;            // the lane-per-read kernel in front of the extension kernel: -1 auto, 0 off, 1 forced
-        int map_pipe = 1;         // k_map as the request / response machine (map_pipe.hpp); 0 = one chain step per lane (rounds 1-4)
+        int map_pipe = 1;         // k_map as the request / response machine (map_pipe.hpp): 1 = for batches of >= 65536 chains, 2 = always,
+                                  // 0 = never (one chain step per lane and iteration: rounds 1-4)
     } opt;
 };
 
@@ -917,7 +918,9 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
                                                                     A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             A->packed_valid = true;
-            if (A->opt.map_pipe) {
+            // (a batch of few chains — config 0: 1000 long queries — leaves most lanes of either kernel idle; there the one-step-
+            // per-lane machine's single iteration per k-mer beats the pipe's 2.4: 30 vs 46 ms, profiles/r05_config0_*.json)
+            if (A->opt.map_pipe == 1 ? chains >= 65536 : A->opt.map_pipe > 1) {
                 MapArgs ma;
                 ma.offsets = d_offsets; ma.node_begin = A->node_begin.as<uint64_t>();
                 ma.pk_fwd = A->pk_fwd.as<uint64_t>(); ma.pk_rc = A->pk_rc.as<uint64_t>();
