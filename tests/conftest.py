@@ -44,9 +44,11 @@ def pytest_collection_modifyitems(config, items):
 KERNEL_VARIANTS = {
     # name: (options, counters that must have moved, counters that must not have moved)
     "auto": ((), (), ()),
-    "grp8": (("ext64=0", "lane=0"), ("grp8_any",), ("ext64", "lane")),              # 8-lane groups, reads spread over wavefronts
-    "grp8x8": (("ext64=0", "lane=0", "groups_per_wave=0"), ("grp8_any",), ("ext64", "lane")),   # ... 8 reads per wavefront
-    "lane": (("ext64=0", "lane=1", "groups_per_wave=0"), (), ("ext64",)),           # the lane-per-read kernel first (where the
+    # (map_pipe=2: k_map as the request / response machine also for these small batches — the automatic choice takes it from
+    # 65536 chains on; "auto" keeps the one-step-per-lane machine, so both mapping kernels feed every parity test)
+    "grp8": (("ext64=0", "lane=0", "map_pipe=2"), ("grp8_any",), ("ext64", "lane")),              # 8-lane groups, reads spread over wavefronts
+    "grp8x8": (("ext64=0", "lane=0", "groups_per_wave=0", "map_pipe=2"), ("grp8_any",), ("ext64", "lane")),   # ... 8 reads per wavefront
+    "lane": (("ext64=0", "lane=1", "groups_per_wave=0", "map_pipe=2"), (), ("ext64",)),           # the lane-per-read kernel first (where the
                                                                                     # configuration qualifies), 8-lane groups behind it
 }
 

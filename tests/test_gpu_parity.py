@@ -44,13 +44,17 @@ def test_library_sees_gpu():
     assert capi.lib().mgx_device_count() >= 1
 
 
-@pytest.mark.parametrize("k,mask", [(11, False), (11, True), (31, False), (5, False)])
-def test_mapping(k, mask):
-    g, reads = make_world(10 + k, k, mask=mask)
+@pytest.mark.parametrize("machine", ["map_pipe=0", "map_pipe=2"])       # one chain step per lane and iteration / request-response
+@pytest.mark.parametrize("k,mask", [(11, False), (11, True), (31, False), (5, False), (32, False), (3, False)])
+def test_mapping(k, mask, machine):
+    g, reads = make_world(10 + k, k, mask=mask, n_reads=300, read_len=150, genome_len=8000)
+    reads += ["", "A", reads[0][:k], reads[1][:32], reads[2][:33], reads[3][:64], reads[4][:65], reads[5][:20] + "N" * 40 + reads[5][60:], "N" * 70]
     G = gpu_graph(g)
     cfg = capi.config_cli(k)
     want = orc.AlignRun(g, cfg, reads).mapping()
-    got = aligner.Aligner(G, cfg).map_batch(reads)
+    A = aligner.Aligner(G, cfg)
+    A.set_pipeline(machine)
+    got = A.map_batch(reads)
     assert got == want
 
 
