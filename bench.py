@@ -331,7 +331,7 @@ def main():
     try:
         here = os.path.dirname(os.path.abspath(__file__))
         # (label-aware runs have PMC passes of their own: other kernels, other seeds per read)
-        pmc_names = ("r04_labels_pmc_summary.json",) if args.labels else ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
+        pmc_names = ("r05_labels_pmc_summary.json", "r04_labels_pmc_summary.json") if args.labels else ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")
         pmc_name = next(n for n in pmc_names if os.path.exists(os.path.join(here, "profiles", n)))
         pmc = json.load(open(os.path.join(here, "profiles", pmc_name)))
         per_read = pmc["kernels"].get(dom, {}).get("traffic_bytes_per_read")
