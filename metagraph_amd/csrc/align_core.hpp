@@ -1469,79 +1469,124 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
     const bool pre_fits = (uint64_t)5 * (uint64_t)nslots <= MGX_PARAMS_OF(w).lim.cell_words;
     const bool tail_known = w.n_kmers > 0 && w.nodes[s][w.n_kmers - 1] != 0 && !w.inv_any[s]
                             && !(kWithPrimary && cfg.canonical >= 2 && w.nodes[s][w.n_kmers - 1] > g.n);
-    // lane-parallel longest-prefix lookups for every position that can report a seed
+    // lane-parallel longest-prefix lookups for every position that can report a seed: the lookup of position i
+    auto lookup_position = [&](const int32_t i, LineCtr &lc) -> bool {
+        int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
+        uint16_t mlen = 0;
+        uint32_t rf = 0, rl_ = 0;
+        bool need = max_len >= (int32_t)w.msl[i];
+        int32_t known = -1;                              // match length with a stored range, if any
+        int32_t known_at = i;                            // the slot of rng[] that holds it
+        if (need && w.mlen[s] && i < w.n_kmers && max_len == k - 1) {
+            // k_map's index() walked this very chain (BOSS::index_range == index() up to the failing
+            // character): skip lookups that cannot reach min_seed_length, reuse the range of those that do
+            const uint32_t ml = w.mlen[s][i];
+            if (ml == MLEN_LT_PREFIX) need = msl0 <= (int32_t)g.prefix_len;
+            else if (ml < MLEN_TAIL) {
+                need = (int32_t)ml >= msl0;
+                if (need && w.rng[s]) known = (int32_t)ml;
+            }
+        }
+        // (MANY: not deferred.  With a full seed at every matched k-mer the last-full-seed rule below (:240-244) drops the
+        // tail positions' seeds one after the other without raising msl[] behind them, so ALL of them report and each
+        // deferred range was a walk of ~25 dependent steps by the whole wavefront — 40 % of the label-aware seeding kernel,
+        // profiles/r04_ab7_seed_sections.txt; here the tail positions walk side by side, one per lane.)
+        // (Few seeds: only the first tail position reports, and raises msl[] for those behind it; looking it up here instead
+        // moves 12 ms per 2 M reads from the bookkeeping to this loop and saves 1 — same file.)
+        // the tail position two behind the last k-mer — the one that reports when that k-mer is covered by a MEM — has its
+        // range from k_map (MLEN_TAIL, map_pipe.hpp): there the walk is one of 64 per wavefront
+        if (need && tail_known && i == w.n_kmers + 1 && max_len == L - i && max_len == k - 2 && max_len >= msl0 && w.mlen[s]
+                && w.rng[s] && w.mlen[s][w.n_kmers - 1] == MLEN_TAIL) {
+            known = max_len; known_at = w.n_kmers - 1;
+        }
+        if (!MANY && known < 0 && need && tail_known && i >= w.n_kmers && max_len == L - i && max_len >= msl0) {
+            mlen = (uint16_t)max_len;
+            rf = DEFERRED_RANGE;
+            need = false;
+        }
+        if (need) {
+            uint64_t first, last;
+            int32_t m;
+            if (known >= 0) {
+                const uint2 r = w.rng[s][known_at];
+                ++lc.bit_lines;
+                first = succ_last(g, r.x, lc);           // index_range's return (boss.hpp:756-763)
+                last = r.y;
+                m = known;
+            } else {
+                m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
+            }
+            if (m >= msl0 && first && first <= g.n) {
+                mlen = (uint16_t)m;
+                if (first == last) {
+                    rf = SINGLE_NODE; rl_ = (uint32_t)first;
+                    // the parents of that node (what the position contributes if it reports, below), fetched here,
+                    // one position per lane, instead of one reporting position after the other: most of these never
+                    // report — a longer match to their left covers them — but a dependent chain of three or four lines
+                    // per reporting position was 30 % of this kernel
+                    if (pre_fits) {
+                        const int np = incoming_nodes32(g, first, pre + 5 * i + 1, 4, lc);
+                        gst(pre + 5 * i, (uint32_t)np);
+                    }
+                }
+                else { rf = rank_last(g, first, lc); rl_ = rank_last(g, last, lc); }
+            }
+        }
+        w.ml[i] = mlen; w.rfirst[i] = rf; w.rlast[i] = rl_;
+        return mlen != 0;
+    };
+    if (WAVE == 64 && nslots <= 3 * WAVE) {
+        // Short reads (round 5): only the positions whose lookup can matter — msl[i] within reach, i.e. not covered by a MEM:
+        // a dozen read-tail positions, plus ~30 per error — are looked up, COMPACTED into as few 64-lane passes as they need
+        // (one, typically): a pass is a chain of six or seven dependent loads (match length, range, succ_last, bwd's rank and
+        // select, the parents' scan) whatever the number of lanes that take part, and three passes per strand over mostly idle
+        // lanes were a seventh of this kernel's time.  Which lane takes which position: the R-th set bit of the ballots.
+        uint64_t nm[3] = { 0, 0, 0 };
+        for (int c = 0; c < 3; ++c) {
+            LV<bool> nd;
+            FOR_LANES(l) {
+                const int32_t i = c * WAVE + l;
+                nd[l] = false;
+                if (i < nslots) {
+                    const int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
+                    nd[l] = max_len >= (int32_t)w.msl[i];
+                    w.ml[i] = 0; w.rfirst[i] = 0; w.rlast[i] = 0;
+                }
+            }
+            nm[c] = wave_ballot(nd);
+        }
+        wave_sync();
+        const int32_t c0 = popc64(nm[0]), c1 = popc64(nm[1]), total = c0 + c1 + popc64(nm[2]);
+        for (int32_t base = 0; base < total; base += WAVE) {
+            LV<int32_t> nr, ns;
+            FOR_LANES(l) {
+                LineCtr lc = { 0, 0, 0 };
+                const int32_t R = base + l;
+                if (R < total) {
+                    const int32_t i = R < c0 ? select64(nm[0], R + 1) : R < c0 + c1 ? WAVE + select64(nm[1], R - c0 + 1)
+                                                                                     : 2 * WAVE + select64(nm[2], R - c0 - c1 + 1);
+                    (void)lookup_position(i, lc);
+                }
+                nr[l] = (int32_t)(lc.rank_lines + lc.bit_lines); ns[l] = (int32_t)lc.select_lines;
+            }
+            w.ctr.rank_lines += (uint32_t)wave_sum(nr);
+            w.ctr.select_lines += (uint32_t)wave_sum(ns);
+        }
+        wave_sync();
+        for (int c = 0; c * WAVE < nslots; ++c) {
+            LV<bool> hit;
+            FOR_LANES(l) { const int32_t i = c * WAVE + l; hit[l] = i < nslots && w.ml[i] != 0; }
+            const uint64_t hb = wave_ballot(hit);
+            FOR_LANES(l) { if (l == 0) { w.bm[2][c] |= hb; w.bm[3][c] |= hb; } }
+        }
+    } else
     for (int32_t base = 0; base < nslots; base += WAVE) {
         LV<int32_t> nr, ns;
         LV<bool> hit;
         FOR_LANES(l) {
             LineCtr lc = { 0, 0, 0 };
             int32_t i = base + l;
-            hit[l] = false;
-            if (i < nslots) {
-                int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
-                uint16_t mlen = 0;
-                uint32_t rf = 0, rl_ = 0;
-                bool need = max_len >= (int32_t)w.msl[i];
-                int32_t known = -1;                              // match length with a stored range, if any
-                int32_t known_at = i;                            // the slot of rng[] that holds it
-                if (need && w.mlen[s] && i < w.n_kmers && max_len == k - 1) {
-                    // k_map's index() walked this very chain (BOSS::index_range == index() up to the failing
-                    // character): skip lookups that cannot reach min_seed_length, reuse the range of those that do
-                    const uint32_t ml = w.mlen[s][i];
-                    if (ml == MLEN_LT_PREFIX) need = msl0 <= (int32_t)g.prefix_len;
-                    else if (ml < MLEN_TAIL) {
-                        need = (int32_t)ml >= msl0;
-                        if (need && w.rng[s]) known = (int32_t)ml;
-                    }
-                }
-                // (MANY: not deferred.  With a full seed at every matched k-mer the last-full-seed rule below (:240-244) drops the
-                // tail positions' seeds one after the other without raising msl[] behind them, so ALL of them report and each
-                // deferred range was a walk of ~25 dependent steps by the whole wavefront — 40 % of the label-aware seeding kernel,
-                // profiles/r04_ab7_seed_sections.txt; here the tail positions walk side by side, one per lane.)
-                // (Few seeds: only the first tail position reports, and raises msl[] for those behind it; looking it up here instead
-                // moves 12 ms per 2 M reads from the bookkeeping to this loop and saves 1 — same file.)
-                // the tail position two behind the last k-mer — the one that reports when that k-mer is covered by a MEM — has its
-                // range from k_map (MLEN_TAIL, map_pipe.hpp): there the walk is one of 64 per wavefront
-                if (need && tail_known && i == w.n_kmers + 1 && max_len == L - i && max_len == k - 2 && max_len >= msl0 && w.mlen[s]
-                        && w.rng[s] && w.mlen[s][w.n_kmers - 1] == MLEN_TAIL) {
-                    known = max_len; known_at = w.n_kmers - 1;
-                }
-                if (!MANY && known < 0 && need && tail_known && i >= w.n_kmers && max_len == L - i && max_len >= msl0) {
-                    mlen = (uint16_t)max_len;
-                    rf = DEFERRED_RANGE;
-                    need = false;
-                }
-                if (need) {
-                    uint64_t first, last;
-                    int32_t m;
-                    if (known >= 0) {
-                        const uint2 r = w.rng[s][known_at];
-                        ++lc.bit_lines;
-                        first = succ_last(g, r.x, lc);           // index_range's return (boss.hpp:756-763)
-                        last = r.y;
-                        m = known;
-                    } else {
-                        m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
-                    }
-                    if (m >= msl0 && first && first <= g.n) {
-                        mlen = (uint16_t)m;
-                        if (first == last) {
-                            rf = SINGLE_NODE; rl_ = (uint32_t)first;
-                            // the parents of that node (what the position contributes if it reports, below), fetched here,
-                            // one position per lane, instead of one reporting position after the other: most of these never
-                            // report — a longer match to their left covers them — but a dependent chain of three or four lines
-                            // per reporting position was 30 % of this kernel
-                            if (pre_fits) {
-                                const int np = incoming_nodes32(g, first, pre + 5 * i + 1, 4, lc);
-                                gst(pre + 5 * i, (uint32_t)np);
-                            }
-                        }
-                        else { rf = rank_last(g, first, lc); rl_ = rank_last(g, last, lc); }
-                    }
-                }
-                w.ml[i] = mlen; w.rfirst[i] = rf; w.rlast[i] = rl_;
-                hit[l] = mlen != 0;
-            }
+            hit[l] = i < nslots && lookup_position(i, lc);
             nr[l] = (int32_t)(lc.rank_lines + lc.bit_lines); ns[l] = (int32_t)lc.select_lines;
         }
         w.ctr.rank_lines += (uint32_t)wave_sum(nr);
