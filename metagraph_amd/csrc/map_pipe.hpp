@@ -65,9 +65,14 @@ struct MapPipe {
     int32_t state, purpose;
     // what the last settled k-mer leaves behind, written at the top of the NEXT iteration with that iteration's requests (gfx9
     // counts loads and stores with one counter: a store issued after the wait would be waited for before the next requests)
-    uint32_t st_flags;            // 1: node, 2: match length, 4: range
-    uint32_t st_node, st_len;
-    uint64_t st_idx, st_rng;      // index into nodes_* / mlen_* / rng_* of strand (st_flags >> 8)
+    uint32_t st_flags;            // 1: the node quad, 2: match length, 4: range
+    uint32_t st_len;
+    uint64_t st_idx, st_rng;      // index into mlen_* / rng_* of strand (st_flags >> 8)
+    // node ids leave in quads: four consecutive k-mer positions as ONE 16-byte store where the chain covers the quad (its
+    // first and last positions may share a quad with the neighbouring reads: those go as single words).  240 scattered 4-byte
+    // stores per read were 18 KB of write traffic per read at the fabric — 40 % of this kernel's traffic (round 5 PMC).
+    uint32_t ob[4], ob_mask, ob_strand;
+    uint64_t ob_q;                // the quad: positions 4 ob_q .. 4 ob_q + 3 of nodes_* (ob_strand)
     // the next chain
     int32_t bg, bg_strand, bg_L;
     uint64_t bg_read, bg_w, bg_nb, bg_cur, bg_nxt;
@@ -79,7 +84,8 @@ MGX_DEV void map_pipe_init(MapPipe &m) {
     m.tail = 2; m.last_node = 0;
     m.cur = m.nxt = 0; m.icur = m.inxt = 0; m.rl = m.ru = 0; m.r_hi = m.r_lo = m.rk_ru = 0; m.req = 0;
     m.wbase = m.nbase = 0; m.strand = 0; m.n_words = 0;
-    m.st_flags = 0; m.st_node = m.st_len = 0; m.st_idx = m.st_rng = 0;
+    m.st_flags = 0; m.st_len = 0; m.st_idx = m.st_rng = 0;
+    m.ob[0] = m.ob[1] = m.ob[2] = m.ob[3] = 0; m.ob_mask = 0; m.ob_strand = 0; m.ob_q = 0;
     m.blk = Block{};
 }
 
@@ -140,7 +146,16 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
     const uint64_t cid = claim.get(m.bg == BG_WANT);
     if (m.st_flags) {
         const bool rcs = (m.st_flags >> 8) != 0;
-        if (m.st_flags & 1) gst_stream((rcs ? a.nodes_rc : a.nodes_fwd) + m.st_idx, m.st_node);
+        if (m.st_flags & 1) {
+            uint32_t *q = (m.ob_strand ? a.nodes_rc : a.nodes_fwd) + (m.ob_q << 2);
+            if (m.ob_mask == 0xFu) gst4((int32_t *)q, (int32_t)m.ob[0], (int32_t)m.ob[1], (int32_t)m.ob[2], (int32_t)m.ob[3]);
+            else {
+                if (m.ob_mask & 1u) gst_stream(q, m.ob[0]);
+                if (m.ob_mask & 2u) gst_stream(q + 1, m.ob[1]);
+                if (m.ob_mask & 4u) gst_stream(q + 2, m.ob[2]);
+                if (m.ob_mask & 8u) gst_stream(q + 3, m.ob[3]);
+            }
+        }
         if (m.st_flags & 2) gst_stream((rcs ? a.mlen_rc : a.mlen_fwd) + m.st_idx, (uint8_t)m.st_len);
         if (m.st_flags & 4) gst((uint64_t *)((rcs ? a.rng_rc : a.rng_fwd) + m.st_idx), m.st_rng);
     }
@@ -188,11 +203,19 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
         m.bg_nb = nb;
         m.bg = m.bg_L >= k ? BG_DESC : BG_WANT;          // a read without a k-mer has no chain: ask for the next id
     }
+    if (m.st_flags & 1) m.ob_mask = 0;
     m.st_flags = 0;
     if (st == MP_DONE) return false;
 
     // outputs of the settled k-mer: pending stores (one settled k-mer per iteration, MP_SETTLE otherwise)
-    auto out_node = [&](uint32_t v) { m.st_flags |= 1u | ((uint32_t)m.strand << 8); m.st_idx = m.nbase + (uint64_t)m.i; m.st_node = v; };
+    auto out_node = [&](uint32_t v) {
+        const uint64_t gi = m.nbase + (uint64_t)m.i;
+        const uint32_t slot = (uint32_t)gi & 3u;
+        m.ob_q = gi >> 2; m.ob_strand = (uint32_t)m.strand;
+        if (slot == 0) m.ob[0] = v; else if (slot == 1) m.ob[1] = v; else if (slot == 2) m.ob[2] = v; else m.ob[3] = v;
+        m.ob_mask |= 1u << slot;
+        if (slot == 3 || m.i + 1 >= m.n_kmers) m.st_flags |= 1u;           // the quad, or the chain, is complete: out with it
+    };
     auto out_len = [&](uint8_t v) { m.st_flags |= 2u | ((uint32_t)m.strand << 8); m.st_idx = m.nbase + (uint64_t)m.i; m.st_len = v; };
     auto out_rng = [&]() { m.st_flags |= 4u; m.st_rng = ((uint64_t)m.ru << 32) | m.rl; };
     const bool lens = a.mlen_fwd && k - 1 < (int32_t)MLEN_LT_PREFIX;
@@ -305,7 +328,7 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
                 if ((m.blk.last_bits >> (m.edge & 63)) & 1) { m.edge = 0; act = ACT_ADVANCE; break; }
             }
         }
-        if (act == ACT_ADVANCE && (m.st_flags & 1)) { m.state = MP_SETTLE; act = ACT_NONE; }      // second k-mer settled in this iteration
+        if (act == ACT_ADVANCE && (m.st_flags & 1)) { m.state = MP_SETTLE; act = ACT_NONE; }      // the quad of the earlier k-mers is still on its way out
         if (act == ACT_ADVANCE) {
             // the k-mer at position i is settled: m.edge (0 = not found)
             m.last_node = in_graph(g, m.edge) ? m.edge : 0u;

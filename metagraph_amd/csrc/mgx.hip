@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(256, MGX_MAP_PACKED_WAVES) k_map_packed(DevGra
 
 // k_map as a request / response machine (map_pipe.hpp): one memory round trip per iteration for all lanes of a wavefront
 #ifndef MGX_MAP_PIPE_WAVES
-#define MGX_MAP_PIPE_WAVES 4
+#define MGX_MAP_PIPE_WAVES 3
 #endif
 #ifndef MGX_SEL_ANCHOR_MAX
 #define MGX_SEL_ANCHOR_MAX 8192      // entries of the select-anchor table (32 KB of LDS per workgroup of k_map_pipe)
@@ -472,6 +472,7 @@ struct mgx_aligner {
         int no_compact = 0, no_alias = 0, no_bt_runs = 0, no_flat = 0;
         int primary_alt_build = 0;
         int lane = -1;            // the lane-per-read kernel in front of the extension kernel: -1 auto, 0 off, 1 forced
+        int seed_wps = 8;         // wavefronts per SIMD of the short-read seeding kernel: 8 (64 VGPRs, spills) or 4 (102 VGPRs, tables in LDS)
         int map_pipe = 1;         // k_map as the request / response machine (map_pipe.hpp): 1 = for batches of >= 65536 chains, 2 = always,
                                   // 0 = never (one chain step per lane and iteration: rounds 1-4)
     } opt;
@@ -1190,7 +1191,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     if (split) {
         if (probe_env_set("MGX_SEED_GROUPS")) {                 // A/B probe (needs a -DMGX_GRP_SEED_PROBE build of mgx_grp.hip)
             if (int rc = launch_groups(PH_SEED)) return fail(MGX_ERR_NO_DEVICE, "group seeding kernel: %d", rc);
-        } else if (l.Lmax <= 192 && slots >= (uint64_t)prop.multiProcessorCount * 4 * 8) {
+        } else if (A->opt.seed_wps == 8 && l.Lmax <= 192 && slots >= (uint64_t)prop.multiProcessorCount * 4 * 8) {
             // (measured on 150-bp reads: the kernel is 10 % faster with 4944 B of LDS per wavefront than with 5056 B, although
             // both leave room for 32 wavefronts per CU; hence the wider margin)
             const uint32_t budget8 = (160u * 1024u) / (4 * MGX_SEED_WPS) - static_lds - 192u;
@@ -1418,6 +1419,7 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
         else if (key == "primary_alt_build") o.primary_alt_build = v;
         else if (key == "lane") o.lane = v;
         else if (key == "map_pipe") o.map_pipe = v;
+        else if (key == "seed_wps") o.seed_wps = v;
         else if (key == "retry_capacity") A->retry_capacity = v != 0;
         else return fail(MGX_ERR_INVALID, "unknown option '%s'", name);
         return MGX_OK;
