@@ -42,13 +42,22 @@ struct LaneChip {
 enum { CD_B_SCORE, CD_B_NOD, CD_B_I, CD_B_POS, CD_T_SCORE, CD_T_NOD, CD_T_POS,
        CD_FA_ALIVE, CD_FA_CONV, CD_FA_MAX,
        CD_D_SCORE0, CD_D_SCORE1, CD_D_SCORE2, CD_D_MAX0, CD_D_MAX1, CD_D_MAX2,
-       CD_KID_N0, CD_KID_C0, CD_KID_N1, CD_KID_C1,
+       CD_KID_N0, CD_KID_C0, CD_KID_N1, CD_KID_C1, CD_KID_R0, CD_KID_R1,
        CD_TABLE_CAP, CD_TSB_LO, CD_TSB_HI, CD_CELL_TOP, CD_NCOLS, CD_F_NODE, CD_F_IDX, CD_F_MAX,
-       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_ROOT_PUSHES, CD_CTR_RANK, CD_CTR_SEL, CD_FWD_N_NODES, CD_FWD_N_SEQ, CD_STRAND, CD_HAVE_ALN, CD_MODE, CD_CLIP, CD_L, CD_NSEEDS, CD_REPLAY_TOP, CD_REPLAY_MATCHING,
+       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_ROOT_PUSHES, CD_CTR_RANK, CD_CTR_SEL, CD_FWD_N_NODES, CD_FWD_N_SEQ, CD_HMS, CD_CLIP, CD_L, CD_NSEEDS, CD_REPLAY_TOP, CD_S8_FILTER,
        LANE_COLD_WORDS };
 static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 #define LANE_CI(f) (*(int32_t *)(chip.cold + (f) * chip.cstride))
 #define LANE_CU(f) (*(chip.cold + (f) * chip.cstride))
+// CD_HMS: bit 0 = an alignment so far, bits 1-2 = where lane_emit() finds it (LANE_EMIT_*), bit 3 = the strand of pass 0,
+// bit 4 = the replayed characters have all matched the query's so far (backward pass)
+#define LANE_REPLAY_MATCHING() ((LANE_CI(CD_HMS) >> 4) & 1)
+#define LANE_SET_REPLAY_MATCHING(v) (LANE_CI(CD_HMS) = (LANE_CI(CD_HMS) & ~16) | ((v) ? 16 : 0))
+#define LANE_HAVE_ALN() (LANE_CI(CD_HMS) & 1)
+#define LANE_MODE() ((LANE_CI(CD_HMS) >> 1) & 3)
+#define LANE_STRAND() ((LANE_CI(CD_HMS) >> 3) & 1)
+#define LANE_SET_HAVE_ALN(v) (LANE_CI(CD_HMS) = (LANE_CI(CD_HMS) & ~1) | ((v) ? 1 : 0))
+#define LANE_SET_MODE(v) (LANE_CI(CD_HMS) = (LANE_CI(CD_HMS) & ~6) | ((int32_t)(v) << 1))
 // hides where a value came from: what is computed from it afterwards is computed again, not kept in registers across the column loop
 #if defined(__HIP_DEVICE_COMPILE__)
 #define LANE_OPAQUE(x) asm volatile("" : "+v"(x))
@@ -158,16 +167,25 @@ MGX_HD uint32_t lane_hash(uint32_t key, uint32_t mask) {
 // the children of `v` on the forward graph (DBGSuccinct::call_outgoing_kmers, dbg_succinct.cpp:110-139, minus the sentinel-
 // labelled children the extender drops, aligner_extender_methods.cpp:381-384; dev_graph.hpp outgoing() without its arrays):
 // returns their number — 3 stands for "more than two" — and the first two (node, label code) in edge order
-MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t &n0, uint32_t &c0, uint32_t &n1, uint32_t &c1, const LaneChip &chip) {
+MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t sel_r, uint32_t &n0, uint32_t &c0, uint32_t &r0,
+                          uint32_t &n1, uint32_t &c1, uint32_t &r1, const LaneChip &chip) {
+    // sel_r: NF[c] + rank_W(v, c) of v's own label c if the caller knows it (r0 / r1 of the call that enumerated v: a child's
+    // edge lies in a block that call held, so the rank half of the child's fwd() costs it a few instructions and saves this call
+    // the line of v's block), else 0.  r0 / r1: the same for the children returned here.
     LineCtr lc = { 0, 0, 0 };
     const uint64_t v = vv;
-    ++lc.rank_lines;
-    const Block cur = load_block(g, (uint32_t)(v >> 6));
-    const uint32_t w = block_W(cur, (int)(v & 63));
     int n = 0;
-    if (!(v > 1 && w == 0)) {
-        Block tgt;
-        const uint64_t lst = fwd_from(g, v, cur, w % SIGMA, tgt, lc);
+    Block tgt;
+    uint64_t lst = 0;
+    if (sel_r) {
+        lst = select_last_blk(g, sel_r, tgt, lc);
+    } else {
+        ++lc.rank_lines;
+        const Block cur = load_block(g, (uint32_t)(v >> 6));
+        const uint32_t w = block_W(cur, (int)(v & 63));
+        if (!(v > 1 && w == 0)) lst = fwd_from(g, v, cur, w % SIGMA, tgt, lc);
+    }
+    if (lst) {
         uint64_t first = pred_last_from(g, lst - 1, ((lst - 1) >> 6) == (lst >> 6) ? tgt : load_block(g, (uint32_t)((lst - 1) >> 6)), lc) + 1;
         if (first < 2) first = 2;
         Block b = tgt;
@@ -176,7 +194,8 @@ MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t &n0, uint32_t
             if ((uint32_t)(i >> 6) != bi) { bi = (uint32_t)(i >> 6); ++lc.rank_lines; b = load_block(g, bi); }
             const uint32_t c = block_W(b, (int)(i & 63)) % SIGMA;
             if (c != 0 && in_graph(g, i)) {
-                if (n == 0) { n0 = (uint32_t)i; c0 = c; } else if (n == 1) { n1 = (uint32_t)i; c1 = c; }
+                const uint32_t r = nf_of(g, c) + block_rank_W(b, (int)(i & 63), c, bi == 0);
+                if (n == 0) { n0 = (uint32_t)i; c0 = c; r0 = r; } else if (n == 1) { n1 = (uint32_t)i; c1 = c; r1 = r; }
                 ++n;
             }
         }
@@ -267,6 +286,8 @@ struct LaneResult {
 #define kid_code0 LANE_CU(CD_KID_C0)
 #define kid_node1 LANE_CU(CD_KID_N1)
 #define kid_code1 LANE_CU(CD_KID_C1)
+#define kid_rank0 LANE_CU(CD_KID_R0)
+#define kid_rank1 LANE_CU(CD_KID_R1)
 #define table_cap LANE_CU(CD_TABLE_CAP)
 #define tsb_lo LANE_CU(CD_TSB_LO)
 #define tsb_hi LANE_CU(CD_TSB_HI)
@@ -324,7 +345,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         }
         n = s ? ns1 : ns0;
         // the result: which alignment (LaneResult::mode) and its scalars
-        LANE_CI(CD_HAVE_ALN) = 0; LANE_CI(CD_MODE) = 0; LANE_CI(CD_STRAND) = s; LANE_CI(CD_L) = L; LANE_CI(CD_NSEEDS) = n;
+        LANE_CI(CD_HMS) = s << 3; LANE_CI(CD_L) = L; LANE_CI(CD_NSEEDS) = n;
         cols_done = 0;
         LANE_CU(CD_CTR_RANK) = 0; LANE_CU(CD_CTR_SEL) = 0;
     } else {
@@ -349,7 +370,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         };
         int32_t clipping;
         if (!pass) {
-            const int s = LANE_CI(CD_STRAND);
+            const int s = LANE_STRAND();
             if (!load_strand(s)) LANE_BAIL(5);
             // ---- seed 0 (seedref_from_seed) ----
             const SeedHdr *hp = P.seed_hdr + read;
@@ -360,6 +381,18 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             const uint32_t node0 = seed_off == 0 ? gld(rnodes + clipping) : gld(&s0->node);
             if (node0 == 0) LANE_BAIL(6);
             LANE_CI(CD_SEED_LEN) = seed_len; LANE_CI(CD_SEED_OFF) = seed_off; LANE_CU(CD_NODE0) = node0;
+            // Which columns will be asked for their S row: those of the later seeds' last nodes (check_seed below), as a 32-bit
+            // filter over the node ids — a column whose node misses the filter keeps its slot only (one line written per column
+            // instead of two; the trace needs flags and links, not scores).
+            uint32_t flt = 0;
+            if (n - 1 > LANE_S8_FILTER_SEEDS) flt = ~0u;
+            else for (int32_t t = 1; t < n; ++t) {
+                const DevSeed *sj = s0 + t;
+                const int32_t cl = (int32_t)gld(&sj->clipping), so = (int32_t)gld(&sj->offset), nn = (int32_t)gld(&sj->n_nodes);
+                const uint32_t ln = so == 0 ? gld(rnodes + cl + nn - 1) : gld(&sj->node);
+                flt |= 1u << (lane_hash(ln, 31u));
+            }
+            LANE_CU(CD_S8_FILTER) = flt;
         } else {
             clipping = LANE_CI(CD_CLIP);            // (the seed of the backward pass and its strand: set up when pass 0 ended)
         }
@@ -442,7 +475,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 #pragma unroll
         for (int t = 0; t < LANE_MAX_DEFER; ++t) { d_score(t) = INT32_MIN; d_max(t) = NINF; }
         // the children of the head that are being computed (call_outgoing :330-387): one, or the two of a fork
-        kid_node0 = 0; kid_code0 = 0; kid_node1 = 0; kid_code1 = 0;
+        kid_node0 = 0; kid_code0 = 0; kid_node1 = 0; kid_code1 = 0; kid_rank0 = 0; kid_rank1 = 0;
         int n_kids = 0, kid = 0;
         // the first child of a fork, parked while the second is computed (its window in the lane's scratch)
         fa_alive = 0; fa_conv = 0; fa_max_val = 0;
@@ -462,8 +495,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         // kept copies of it and spilled hundreds of registers.
         int32_t hd_begin = 0, hd_prev_end = 0;
 #define replay_top LANE_CI(CD_REPLAY_TOP)
-#define replay_matching LANE_CI(CD_REPLAY_MATCHING)
-        replay_top = -1; replay_matching = 1;
+        replay_top = -1; LANE_SET_REPLAY_MATCHING(1);
         bool reload = false, ext_over = false;
         int reload_slot = -1;                               // -1: the parent of a fork again; else the frontier slot whose column is the head now
         while (!ext_over) {
@@ -488,21 +520,23 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         const int32_t no = f_offset + 1, sp = no - c_seed_off;
                         if (sp >= 0 && sp < c_seed_len && (no < k || pass)) {
                             if (!pass) {
-                                kid_node0 = c_node0; kid_code0 = qcode(clipping + sp) + 1;   // the seed's first node, its spelling
+                                kid_node0 = c_node0; kid_rank0 = 0; kid_code0 = qcode(clipping + sp) + 1;   // the seed's first node, its spelling
                             } else {
                                 // force_fixed_seed (:344-372): the reversed forward alignment, node by node — its spelling is
                                 // the complement of the path's, read backwards (A <-> T, C <-> G: code 5 - c)
                                 const int32_t fn = c_fwd_n_nodes, fq = c_fwd_n_seq;
                                 kid_code0 = 5u - gld(pa_code() + (fq - 1 - sp));
-                                kid_node0 = gld(pa_node() + (fn - 1 - imax(0, no - k + 1)));
+                                kid_node0 = gld(pa_node() + (fn - 1 - imax(0, no - k + 1))); kid_rank0 = 0;
                             }
                             n_kids = 1;
                         } else {
-                            uint32_t kn0 = 0, kc0 = 0, kn1 = 0, kc1 = 0;
+                            uint32_t kn0 = 0, kc0 = 0, kn1 = 0, kc1 = 0, kr0 = 0, kr1 = 0;
+                            // (the head is a child of the previous enumeration, or that one's rank says nothing about it)
+                            const uint32_t hr = f_node == kid_node0 ? kid_rank0 : (f_node == kid_node1 ? kid_rank1 : 0u);
                             const int nc = pass ? lane_parents(P.g, f_node, kn0, kc0, kn1, kc1, chip)
-                                                : lane_children(P.g, f_node, kn0, kc0, kn1, kc1, chip);
+                                                : lane_children(P.g, f_node, hr, kn0, kc0, kr0, kn1, kc1, kr1, chip);
                             if (nc > 2) LANE_BAIL(10);                                 // more than two children
-                            kid_node0 = kn0; kid_code0 = kc0; kid_node1 = kn1; kid_code1 = kc1;
+                            kid_node0 = kn0; kid_code0 = kc0; kid_node1 = kn1; kid_code1 = kc1; kid_rank0 = kr0; kid_rank1 = kr1;
                             if (nc == 0) {                                             // a tip: its start cell counts after all
                                 if (t_score != INT32_MIN) cand(t_score, t_nod, f_idx, t_pos);
                                 head_dead = true;
@@ -584,31 +618,36 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     // commit: the slot (flags, node, base, geometry, parent) and the S row
                     const int32_t base = max_val == NINF ? 0 : max_val;
                     {
-                        uint32_t sw[8];
-                        bool wide = false;
-#pragma unroll
-                        for (int b = 0; b < LFW / 4; ++b) {
-                            uint32_t v = 0;
-#pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4) {
-                                const int32_t sv = S[4 * b + q4];
-                                const int32_t d = (int32_t)((uint32_t)sv - (uint32_t)base);      // (sv may be ninf: its d is not used, but must not overflow)
-                                wide |= sv != NINF && d < -127;
-                                v |= (sv == NINF ? 0x80u : ((uint32_t)d & 0xFFu)) << (8 * q4);
-                            }
-                            sw[b] = v;
-                        }
-                        if (wide) LANE_BAIL(17);
+                        // (the S row: where something may read it — a replay column of the backward pass (merged below), a later
+                        // seed's last node — and else not at all; the trace's last cell, if it is in such a column, bails)
+                        const bool keep_row = (pass && replay) || ((LANE_CU(CD_S8_FILTER) >> lane_hash(next, 31u)) & 1u);
                         uint32_t *sl = (uint32_t *)(slots + (uint64_t)my_idx * LANE_SLOT_BYTES);
-                        uint32_t *sr = (uint32_t *)(s8rows() + (uint64_t)my_idx * LANE_S8_BYTES);
 #pragma unroll
                         for (int b = 0; b < 8; ++b) gst(sl + b, out.fw[b]);
                         gst(sl + 8, next);
                         gst(sl + 9, (uint32_t)base);
-                        gst(sl + 10, (uint32_t)begin | ((uint32_t)size << 16) | (ccode << 24));
+                        gst(sl + 10, (uint32_t)begin | ((uint32_t)size << 16) | (ccode << 24) | (keep_row ? LANE_GEOM_ROW : 0u));
                         gst(sl + 11, (uint32_t)f_idx | ((uint32_t)next_offset << 16));
+                        if (keep_row) {
+                            uint32_t sw[8];
+                            bool wide = false;
 #pragma unroll
-                        for (int b = 0; b < 8; ++b) gst(sr + b, sw[b]);
+                            for (int b = 0; b < LFW / 4; ++b) {
+                                uint32_t v = 0;
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) {
+                                    const int32_t sv = S[4 * b + q4];
+                                    const int32_t d = (int32_t)((uint32_t)sv - (uint32_t)base);      // (sv may be ninf: its d is not used, but must not overflow)
+                                    wide |= sv != NINF && d < -127;
+                                    v |= (sv == NINF ? 0x80u : ((uint32_t)d & 0xFFu)) << (8 * q4);
+                                }
+                                sw[b] = v;
+                            }
+                            if (wide) LANE_BAIL(17);
+                            uint32_t *sr = (uint32_t *)(s8rows() + (uint64_t)my_idx * LANE_S8_BYTES);
+#pragma unroll
+                            for (int b = 0; b < 8; ++b) gst(sr + b, sw[b]);
+                        }
                     }
                     tsize = my_idx + 1;
                     if (pass && replay) {
@@ -624,10 +663,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         if (!(top >= begin && top < begin + size)) top = -1;
                         const int32_t ap = clipping + seed_pos + 1;                     // the query character under the diagonal cell
                         const bool same = ap >= 1 && ap <= L && qcode(ap - 1) + 1 == ccode;
-                        if (probe) { replay_matching = 1; gst(arec() + 12, 0u); }
-                        if (!same) replay_matching = 0;
+                        if (probe) { LANE_SET_REPLAY_MATCHING(1); gst(arec() + 12, 0u); }
+                        if (!same) LANE_SET_REPLAY_MATCHING(0);
                         const bool exact_on = gld(arec() + 12) != 0;
-                        if (exact_on || (!probe && !replay_matching && !(top > replay_top))) {
+                        if (exact_on || (!probe && !LANE_REPLAY_MATCHING() && !(top > replay_top))) {
                             int32_t *cv = (int32_t *)(arec() + 32);
                             int32_t c0 = my_idx;
                             if (!exact_on) { c0 = 1; gst(arec() + 12, 1u); gst(arec() + 14, 0u); }       // (no vector yet:) the columns so far, then this one
@@ -815,7 +854,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         // there are more extensions to run.  A node's entry is its first (and only) column here: the node table gives the column,
         // the column's S row the score at the seed's last query position.  (Before the backward pass reuses the tables, as
         // aln_both does.)
-        const int s = LANE_CI(CD_STRAND);
+        const int s = LANE_STRAND();
         const SeedHdr *hp2 = P.seed_hdr + read;
         const DevSeed *seeds = P.seed_stream + gld(&hp2->off) + (s ? (int32_t)gld(&hp2->n_seeds[0]) : 0);
         const uint32_t *rnodes = (s ? P.nodes_rc : P.nodes_fwd) + gld(P.node_begin + read);
@@ -843,6 +882,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             const int32_t skip = cbegin ? 0 : 1;
             const int32_t qs = start + cbegin - (cbegin ? 1 : 0), qn = csize - skip;
             if (lpos < qs || lpos - qs >= qn) LANE_BAIL(19);                         // outside the entry's range: the seed lives
+            if (!(geom & LANE_GEOM_ROW)) LANE_BAIL(19);                              // (cannot be: the filter holds ln)
             const int32_t a = lpos - start + 1, x = a - (cbegin & ~3);
             int32_t v = NINF;
             if (a - cbegin >= 0 && a - cbegin < csize + 5 && x < LFW) {
@@ -891,7 +931,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             if (!j) break;
             const uint32_t geom = slot_geom(j);
             const uint32_t link = slot_link(j);
-            const uint32_t ccode = geom >> 24;
+            const uint32_t ccode = (geom >> 24) & 7u;
             const int32_t col_offset = (int32_t)(link >> 16);
             align_offset = imin(col_offset, k_minus_1);
             const uint32_t fl = slot_flags(j, geom, pos);
@@ -951,6 +991,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 const int32_t jx = pos - begin, x = pos - (begin & ~3);
                 cur_cell_score = NINF;
                 if (jx >= 0 && jx < size + 5 && x < LFW) {
+                    if (!(geom & LANE_GEOM_ROW)) LANE_BAIL(29);                      // a trace that ends inside a column without its S row
                     const int32_t v = (int32_t)(int8_t)gld(s8rows() + (uint64_t)j * LANE_S8_BYTES + x);
                     const int32_t cb = (int32_t)gld((const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES) + 9);
                     if (v != -128) cur_cell_score = cb + v;
@@ -979,9 +1020,9 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             gst(arec() + 0, (uint32_t)x_score); gst(arec() + 1, (uint32_t)x_offset); gst(arec() + 2, (uint32_t)x_clip);
             gst(arec() + 3, (uint32_t)x_end_clip); gst(arec() + 4, (uint32_t)x_n_runs); gst(arec() + 5, (uint32_t)x_j_hi);
             gst(arec() + 6, (uint32_t)x_n_nodes); gst(arec() + 7, (uint32_t)x_n_seq);
-            LANE_CI(CD_HAVE_ALN) = 1; LANE_CI(CD_MODE) = LANE_EMIT_SLOTS;
+            LANE_SET_HAVE_ALN(1); LANE_SET_MODE(LANE_EMIT_SLOTS);
             if (!have_rc) break;
-            if (!(x_score >= cfg.min_path_score)) LANE_CI(CD_HAVE_ALN) = 0;         // get_min_path_score with an empty aggregator
+            if (!(x_score >= cfg.min_path_score)) LANE_SET_HAVE_ALN(0);         // get_min_path_score with an empty aggregator
             if (!(x_clip && !x_offset)) break;                        // nothing to extend backwards
             // The backward pass: the forward alignment, reversed (Alignment::reverse_complement :563-565 on the RCDBG view: nodes
             // and CIGAR reversed, spelling complemented), is the seed.  Its nodes, characters and CIGAR runs move to the lane's
@@ -992,20 +1033,21 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 for (int32_t xx = x_n_seq - 1; xx >= 0; --xx) {
                     const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)jj * LANE_SLOT_BYTES);
                     const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
-                    gst(pa_code() + xx, geom >> 24);
+                    gst(pa_code() + xx, (geom >> 24) & 7u);
                     if ((int32_t)(link >> 16) >= k - 1) { if (ni >= 0) gst(pa_node() + ni, node); --ni; }
                     jj = (int32_t)(link & 0xFFFFu);
                 }
                 for (int32_t xx = 0; xx < x_n_runs; ++xx) gst(runs_fwd() + xx, chip.runs[xx * chip.rstride]);
             }
-            gst(arec() + 8, (uint32_t)LANE_CI(CD_HAVE_ALN)); gst(arec() + 9, (uint32_t)x_score); gst(arec() + 10, (uint32_t)x_clip);
+            gst(arec() + 8, (uint32_t)LANE_HAVE_ALN()); gst(arec() + 9, (uint32_t)x_score); gst(arec() + 10, (uint32_t)x_clip);
             gst(arec() + 11, (uint32_t)x_end_clip);
             c_fwd_n_nodes = x_n_nodes; c_fwd_n_seq = x_n_seq;
-            LANE_CI(CD_MODE) = LANE_EMIT_ARRAYS;
+            LANE_SET_MODE(LANE_EMIT_ARRAYS);
             // seedref_from_aln of the reversal: clipping = the alignment's end clipping, the whole spelling is the seed
             LANE_CI(CD_CLIP) = x_end_clip;
             c_seed_len = x_n_seq; c_seed_off = 0; c_node0 = gld(pa_node() + (x_n_nodes - 1));
-            if (!load_strand(1 - LANE_CI(CD_STRAND))) LANE_BAIL(5);
+            if (!load_strand(1 - LANE_STRAND())) LANE_BAIL(5);
+            LANE_CU(CD_S8_FILTER) = 0;                  // (the backward pass: the replay columns' rows only)
             return LR_AGAIN;
         }
         // ---- pass 1 is over (:700-722): the backward alignment, reversed again, joins the aggregator ----
@@ -1027,7 +1069,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 if (x_score < gcut || less) take = false;
             }
             if (take) {
-                LANE_CI(CD_HAVE_ALN) = 1; LANE_CI(CD_MODE) = LANE_EMIT_SLOTS_REVERSED;
+                LANE_SET_HAVE_ALN(1); LANE_SET_MODE(LANE_EMIT_SLOTS_REVERSED);
                 gst(arec() + 0, (uint32_t)x_score); gst(arec() + 1, 0u); gst(arec() + 2, (uint32_t)x_end_clip);
                 gst(arec() + 3, (uint32_t)x_clip); gst(arec() + 4, (uint32_t)x_n_runs); gst(arec() + 5, (uint32_t)x_j_hi);
                 gst(arec() + 6, (uint32_t)x_n_nodes); gst(arec() + 7, (uint32_t)x_n_seq);
@@ -1049,11 +1091,11 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
     gst(arec() + 27, gld(arec() + 27) + LANE_CU(CD_CTR_RANK));
     gst(arec() + 28, gld(arec() + 28) + LANE_CU(CD_CTR_SEL));
     {
-        const int32_t have_aln = n > 0 ? LANE_CI(CD_HAVE_ALN) : 0;
+        const int32_t have_aln = n > 0 ? LANE_HAVE_ALN() : 0;
         const int32_t a_n_nodes = have_aln ? (int32_t)gld(arec() + 6) : 0;
         R.have_aln = (have_aln && a_n_nodes) ? 1 : 0;
-        R.mode = LANE_CI(CD_MODE);
-        R.strand = LANE_CI(CD_STRAND);
+        R.mode = LANE_MODE();
+        R.strand = LANE_STRAND();
         R.words = 0; R.trim = 0;
         if (R.have_aln) {
             R.score = (int32_t)gld(arec() + 0); R.offset = (int32_t)gld(arec() + 1); R.clip = (int32_t)gld(arec() + 2);
@@ -1066,7 +1108,6 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 }
 
 #undef replay_top
-#undef replay_matching
 #undef c_fwd_n_nodes
 #undef c_fwd_n_seq
 #undef c_seed_len
@@ -1088,6 +1129,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 #undef kid_code0
 #undef kid_node1
 #undef kid_code1
+#undef kid_rank0
+#undef kid_rank1
 #undef table_cap
 #undef tsb_lo
 #undef tsb_hi
@@ -1123,7 +1166,7 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
                 for (int32_t x = R.n_seq - 1; x >= 0; --x) {
                     const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES);
                     const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
-                    gst(dseq + x, decode_code(geom >> 24));
+                    gst(dseq + x, decode_code((geom >> 24) & 7u));
                     if ((int32_t)(link >> 16) >= k_minus_1) { if (ni >= 0) gst(dst + ni, node); --ni; }
                     j = (int32_t)(link & 0xFFFFu);
                 }
@@ -1142,7 +1185,7 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
                 for (int32_t x = 0; x < R.n_seq; ++x) {
                     const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES);
                     const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
-                    gst(dseq + x, decode_code(5u - (geom >> 24)));
+                    gst(dseq + x, decode_code(5u - ((geom >> 24) & 7u)));
                     if ((int32_t)(link >> 16) >= k_minus_1) { if (ni < R.n_nodes) gst(dst + ni, node); ++ni; }
                     j = (int32_t)(link & 0xFFFFu);
                 }

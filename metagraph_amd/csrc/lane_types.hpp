@@ -17,6 +17,8 @@ constexpr int LANE_MAX_SEEDS = 512;        // seeds of the strand (the later one
 constexpr int LANE_SLOT_BYTES = 64;        // per column: 32 flag bytes + node + base + geometry (+ 4 unused words)
 constexpr int LANE_MAX_DEFER = 3;          // columns that may stay behind in the frontier (the other children of forks)
 constexpr int LANE_DSLOT_WORDS = 80;       // a column that stays behind: its window (64 words) + nine words of column state
+constexpr uint32_t LANE_GEOM_ROW = 1u << 31;   // in a slot's geometry word: the column's S row was written
+constexpr int LANE_S8_FILTER_SEEDS = 16;   // later seeds whose last nodes select the columns that keep their S row (more: every column does)
 constexpr int LANE_S8_BYTES = 32;          // per column: S of the window as 8-bit offsets from `base` (read at the trace's end only)
 
 // what one launch of the lane kernel needs on top of AlignParams
