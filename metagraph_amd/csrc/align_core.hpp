@@ -1449,11 +1449,14 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
         wave_sync();
     } else {
         for (int32_t b = 0; b < n_base; ++b) {
-            DevSeed sd = w.seeds[s][b];
-            int32_t i = sd.clipping;
+            const DevSeed sd = w.seeds[s][b];
+            const int32_t i = sd.clipping, nn = sd.n_nodes;
             w.bm[3][i >> 6] |= 1ull << (i & 63);
-            for (int32_t j = 0; j < sd.n_nodes; ++j) w.msl[i + j] = (uint16_t)k;
-            if (i + sd.n_nodes < nslots) w.msl[i + sd.n_nodes] = (uint16_t)k;
+            // (a MEM of a short read covers ~100 positions: one per lane, not one after the other)
+            const int32_t cover = nn + (i + nn < nslots ? 1 : 0);
+            for (int32_t jb = 0; jb < cover; jb += WAVE) {
+                FOR_LANES(l) { const int32_t j = jb + l; if (j < cover) w.msl[i + j] = (uint16_t)k; }
+            }
             w.pos_full[i] = 1;            // suffix_seeds[i] holds exactly this full seed
             w.pos_cnt[i] = 1;
             w.pos_start[i] = (uint32_t)b; // index of the full seed among the base seeds
@@ -1677,10 +1680,22 @@ MGX_NI_G2 void make_seeder(Wave &w, int s) {
             w.msl[ii] = (uint16_t)sl;
             if (w.pos_cnt[ii] == 0) { w.pos_start[ii] = first_alt + a; w.pos_full[ii] = 0; }
             ++w.pos_cnt[ii];
-            for (++ii; ii < nslots && sl > (int32_t)w.msl[ii]; ++ii) {
-                w.msl[ii] = (uint16_t)sl--;
-                w.pos_cnt[ii] = 0;
-                w.pos_full[ii] = 0;
+            // the positions behind i take the remainder of the match while it is longer than what they hold: position
+            // i + 1 + t gets sl - t.  Every test reads the value from before this loop (a position is written after its own
+            // test only), so the tests of a stretch run side by side and the first failure ends the run.
+            ++ii;
+            for (bool go_on = true; go_on && ii < nslots && sl > 0; ) {
+                LV<bool> fail;
+                FOR_LANES(l) { const int32_t p = ii + l; fail[l] = !(p < nslots && sl - l > (int32_t)w.msl[p]); }
+                const uint64_t fb = wave_ballot(fail);
+                const int32_t run = fb ? ctz64(fb) : WAVE;
+                wave_sync();
+                FOR_LANES(l) {
+                    if (l < run) { const int32_t p = ii + l; w.msl[p] = (uint16_t)(sl - l); w.pos_cnt[p] = 0; w.pos_full[p] = 0; }
+                }
+                wave_sync();
+                ii += run; sl -= run;
+                go_on = run == WAVE;
             }
         }
     }
