@@ -226,6 +226,7 @@ struct BtIndex { int32_t score, neg_off_diag, neg_i, pos; };
 constexpr int MAX_ALT = MGX_MAX_ALT;
 // label-aware alignment: a backtracking reports up to LAB_EXT alignments (one per label subset of the seed), the per-label
 // aggregator holds up to LAB_POOL_PER_ALT x num_alternative_paths alignments (DevLimits::lab_ext / lab_pool, host_common.hpp)
+// — the sizes of a first run; mgx_align_batch re-runs a read that outgrows them with larger ones
 constexpr int LAB_EXT = 8, LAB_POOL_PER_ALT = 32;
 constexpr int N_ALN = kWithLabels ? 3 * LAB_EXT + LAB_POOL_PER_ALT * MAX_ALT : 4 * MAX_ALT;   // alignment buffers: extension results, their reversals, backward results, the best
 
@@ -496,8 +497,8 @@ MGX_DEV bool aln_less(const DevAln &a, const DevAln &b) {
 MGX_HD uint64_t align8(uint64_t x) { return (x + 7) & ~7ull; }
 
 // words of the per-label aggregator's state (label_driver.hpp): header, one record per label queue, reference counts
-constexpr uint32_t LAB_MAX_QUEUES = 64;
-MGX_HD uint64_t lab_agg_words(const DevLimits &lim) { return 16 + (uint64_t)LAB_MAX_QUEUES * 8 + lim.lab_pool + 8 + (LAB_MAX_QUEUES * 4 + 16) + lim.lab_pool + 8; }
+// (DevLimits::lab_queues label queues of 8 words each, lab_pool reference counts, the output order's scratch)
+MGX_HD uint64_t lab_agg_words(const DevLimits &lim) { return 16 + (uint64_t)lim.lab_queues * 8 + lim.lab_pool + 8 + ((uint64_t)lim.lab_queues * 4 + 16) + lim.lab_pool + 8; }
 
 // Test builds only (tools/fuzz_asan.sh: the host model under -fsanitize=address with -DMGX_ARENA_REDZONE=64): a poisoned gap behind
 // each of the arena's larger arrays, so that an index past the end of one is reported instead of landing in its neighbour — the
@@ -652,7 +653,7 @@ MGX_DEV void carve(Wave &w, const AlignParams &P, uint8_t *base, uint8_t *lds, u
     w.aln = (DevAln *)aln_end;
     aln_end += align8((uint64_t)lim.n_aln * sizeof(DevAln));
 #endif
-    for (int a = 0; a < N_ALN && a < (int)lim.n_aln; ++a) {
+    for (int a = 0; (kWithLabels || a < N_ALN) && a < (int)lim.n_aln; ++a) {        // (label builds: the records live in the arena, n_aln of them)
         w.aln[a].nodes = (uint32_t *)take((uint64_t)lim.max_path * 4);
         w.aln[a].cigar = (uint32_t *)take((uint64_t)lim.max_path * 4);
         w.aln[a].seq = take(lim.max_path);
@@ -5044,7 +5045,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     if (P.labeled && w.status == ST_OK && (PHASE & PH_EXTEND)) {
         // the labeled aggregator's alignments; stream layout as below, with every alignment followed by its label count and
         // its labels (ascending)
-        uint32_t *order = w.agg + ag_list0(P.lim) + (LAB_MAX_QUEUES * 4 + 16);
+        uint32_t *order = w.agg + ag_list0(P.lim) + (P.lim.lab_queues * 4 + 16);
         const int n_out = lab_get_alignments(w, order);
         uint32_t words = 0;
         for (int t = 0; t < n_out; ++t) {

@@ -41,6 +41,7 @@ struct DevLimits {
     uint32_t lab_words;          // uint32 words of the per-read label-set arena
     uint32_t lab_ext;            // alignments one backtracking may report (one per label subset of its seed)
     uint32_t lab_pool;           // alignments the per-label aggregator may hold at a time
+    uint32_t lab_queues;         // labels with alignments the aggregator may hold queues for (and labels on a read's seeds)
 };
 
 // per-read result header; variable-length parts live in the output stream

@@ -74,7 +74,9 @@ inline int prepare_config(const mgx_config &in, uint64_t k, mgx_config *out, Dev
 
 inline uint32_t next_pow2(uint64_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
 
-inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lmax, DevLimits *lim, std::string *err, bool labeled = false) {
+// label_scale: multiplies the label-aware aligner's own arenas (the capacity retry of mgx_align_batch doubles it per attempt)
+inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lmax, DevLimits *lim, std::string *err, bool labeled = false,
+                         uint32_t label_scale = 1) {
     DevLimits &l = *lim;
     if (u && u->max_query_length && Lmax > u->max_query_length) {
         *err = "a query of length " + std::to_string(Lmax) + " exceeds mgx_limits.max_query_length = " + std::to_string(u->max_query_length);
@@ -117,17 +119,20 @@ inline int derive_limits(const mgx_config &cfg, const mgx_limits *u, uint32_t Lm
     // cell words per extender never binds on the test and bench workloads; a read that runs out gets MGX_ERR_CAPACITY
     // and the adapter's retry (doubled cell_arena_bytes) doubles the pool with it.
     l.conv_pool_words = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, (uint64_t)l.cell_words / 2 + 16ull * l.Lmax + 1024);
-    l.lab_words = l.lab_ext = l.lab_pool = 0;
+    l.lab_words = l.lab_ext = l.lab_pool = l.lab_queues = 0;
     if (labeled) {
         // Label-aware alignment: a backtracking reports one alignment per label subset of its seed and the aggregator keeps a
         // queue per label, so the alignment buffers are [0, E) extension results, [E, 2E) their reversals, [2E, 3E) backward
         // results, [3E, 3E + pool) the aggregator's alignments.  A read that outgrows any of them gets MGX_ERR_CAPACITY.
-        l.lab_ext = 8;
-        l.lab_pool = 32 * (uint32_t)std::max<uint64_t>(1, cfg.num_alternative_paths);
+        // The reference bounds none of this; here a read beyond a bound is re-run with all of them doubled (mgx_align_batch).
+        const uint32_t ls = std::min<uint32_t>(std::max<uint32_t>(1, label_scale), 8);      // (lab_ext <= 64: a bit per reversal)
+        l.lab_ext = 8 * ls;
+        l.lab_pool = 32 * ls * (uint32_t)std::max<uint64_t>(1, cfg.num_alternative_paths);
+        l.lab_queues = 64 * ls;                    // labels with alignments per read == labels on a read's seeds (filter_seeds)
         l.n_aln = 3 * l.lab_ext + l.lab_pool;
         // label sets: per-extension sets (one per fork and per flushed column that lost labels), per-read sets (seeds,
         // alignments), the seed filter's position bitmaps (one per label seen on the read's seeds)
-        l.lab_words = (uint32_t)std::min<uint64_t>(1u << 24, 16384 + 8ull * l.max_columns + 64ull * ((l.Lmax + 31) / 32 + 2));
+        l.lab_words = (uint32_t)std::min<uint64_t>(1u << 24, (uint64_t)ls * 16384 + 8ull * l.max_columns + (uint64_t)l.lab_queues * ((l.Lmax + 31) / 32 + 2));
         // every column goes through the general path (pool entries, no aliases) and every backward alignment writes its
         // filter_nodes marks (a vector of the aligned query range per path node): room for a few of them on short reads
         l.conv_pool_words = (uint32_t)std::min<uint64_t>(0xFFFFFF00ull, (uint64_t)l.conv_pool_words

@@ -9,15 +9,15 @@
 // queues hold shared_ptrs; here a queue holds pool indices and Wave::agg counts the references.
 
 enum { AG_NQ = 0, AG_UNL_N = 1, AG_UNL = 2, AG_Q0 = 16, AG_QW = 8 };
-MGX_DEV uint32_t ag_ref0() { return AG_Q0 + LAB_MAX_QUEUES * AG_QW; }
-MGX_DEV uint32_t ag_list0(const DevLimits &lim) { return ag_ref0() + lim.lab_pool + 8; }
+MGX_DEV uint32_t ag_ref0(const DevLimits &lim) { return AG_Q0 + lim.lab_queues * AG_QW; }
+MGX_DEV uint32_t ag_list0(const DevLimits &lim) { return ag_ref0(lim) + lim.lab_pool + 8; }
 MGX_DEV int lab_e(const Wave &w) { return (int)MGX_PARAMS_OF(w).lim.lab_ext; }
 MGX_DEV DevAln &lab_pool_aln(Wave &w, uint32_t p) { return w.aln[3 * lab_e(w) + (int)p]; }
 
 MGX_DEV void lab_agg_reset(Wave &w) {
     const DevLimits &lim = MGX_PARAMS_OF(w).lim;
     w.agg[AG_NQ] = 0; w.agg[AG_UNL_N] = 0;
-    for (uint32_t p = 0; p < lim.lab_pool; ++p) w.agg[ag_ref0() + p] = 0;
+    for (uint32_t p = 0; p < lim.lab_pool; ++p) w.agg[ag_ref0(MGX_PARAMS_OF(w).lim) + p] = 0;
 }
 
 // ---- LabeledAligner::filter_seeds (aligner_labeled.cpp:612-721, no coordinates) for the seeds of strand s ----
@@ -45,12 +45,13 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
     uint32_t *scr = (uint32_t *)w.indices;
     const uint64_t cap_words = (uint64_t)P.lim.max_columns * 2 * (sizeof(BtIndex) / 4);
     const uint32_t nrw = 2 * (((uint32_t)n + 63) / 64);
-    const uint64_t fixed_words = 64 + 2ull * n + n + (n & 1) + nrw + n + n;
+    const uint32_t ML = (P.lim.lab_queues + 1u) & ~1u;       // labels the read's seeds may carry (as many as the aggregator has queues)
+    const uint64_t fixed_words = ML + 2ull * n + n + (n & 1) + nrw + n + n;
     if (cap_words < fixed_words + (uint64_t)W) { w.status = ST_CAPACITY; return; }
-    const uint32_t max_l = (uint32_t)imin<uint64_t>(64, (cap_words - fixed_words) / W);
+    const uint32_t max_l = (uint32_t)imin<uint64_t>(ML, (cap_words - fixed_words) / W);
     uint32_t *mlab = scr;                                    // labels seen on the seeds' first nodes (VectorMap order)
-    uint64_t *heads = (uint64_t *)(scr + 64);                // per seed: the head word of its first node's row (0: no labels)
-    uint32_t *span = scr + 64 + 2 * n;                       // per seed: first k-mer's query range, lo | hi << 16
+    uint64_t *heads = (uint64_t *)(scr + ML);                // per seed: the head word of its first node's row (0: no labels)
+    uint32_t *span = scr + ML + 2 * n;                       // per seed: first k-mer's query range, lo | hi << 16
     uint64_t *rs = (uint64_t *)(span + n + (n & 1));         // bit i: seed i starts a run (below)
     uint32_t *sh = (uint32_t *)rs + nrw;                     // per run start: the run's label set
     uint32_t *ends = sh + n;                                 // per kept seed: its query end (num_matching)
@@ -233,7 +234,7 @@ MGX_NI_G4 void lab_filter_seeds(Wave &w, int s) {
 // ---- AlignmentAggregator with labels (aligner_aggregator.hpp:24-206) ----
 MGX_DEV int lab_pool_alloc(Wave &w) {
     const DevLimits &lim = MGX_PARAMS_OF(w).lim;
-    for (uint32_t p = 0; p < lim.lab_pool; ++p) if (!w.agg[ag_ref0() + p]) return (int)p;
+    for (uint32_t p = 0; p < lim.lab_pool; ++p) if (!w.agg[ag_ref0(MGX_PARAMS_OF(w).lim) + p]) return (int)p;
     w.status = ST_CAPACITY;
     return -1;
 }
@@ -294,7 +295,7 @@ MGX_NI_G4 bool lab_add_alignment(Wave &w, const DevAln &a) {
     auto queue_of = [&](uint32_t label) -> int {
         int q = lab_find_queue(w, label);
         if (q >= 0) return q;
-        if (g[AG_NQ] >= LAB_MAX_QUEUES) { w.status = ST_CAPACITY; return -1; }
+        if (g[AG_NQ] >= MGX_PARAMS_OF(w).lim.lab_queues) { w.status = ST_CAPACITY; return -1; }
         q = (int)g[AG_NQ]++;
         g[AG_Q0 + (uint32_t)q * AG_QW] = label; g[AG_Q0 + (uint32_t)q * AG_QW + 1] = 0;
         return q;
@@ -302,12 +303,12 @@ MGX_NI_G4 bool lab_add_alignment(Wave &w, const DevAln &a) {
     const uint32_t nl = a.lab ? lab_size(w, a.lab) : 0;
     if (!g[AG_UNL_N]) {
         if (own() < 0) return false;
-        g[AG_UNL] = (uint32_t)pa; g[AG_UNL_N] = 1; ++g[ag_ref0() + (uint32_t)pa];
+        g[AG_UNL] = (uint32_t)pa; g[AG_UNL_N] = 1; ++g[ag_ref0(MGX_PARAMS_OF(w).lim) + (uint32_t)pa];
         for (uint32_t x = 0; x < nl; ++x) {
             const int q = queue_of(lab_at(w, a.lab, x));
             if (q < 0) return false;
             uint32_t *rec = g + AG_Q0 + (uint32_t)q * AG_QW;
-            rec[2 + rec[1]++] = (uint32_t)pa; ++g[ag_ref0() + (uint32_t)pa];
+            rec[2 + rec[1]++] = (uint32_t)pa; ++g[ag_ref0(MGX_PARAMS_OF(w).lim) + (uint32_t)pa];
         }
         return true;
     }
@@ -316,14 +317,14 @@ MGX_NI_G4 bool lab_add_alignment(Wave &w, const DevAln &a) {
         for (uint32_t t = 0; t < *size; ++t) if (aln_equal(w, a, lab_pool_aln(w, items[t]))) return false;
         if (*size < n_alt) {
             if (own() < 0) return false;
-            items[(*size)++] = (uint32_t)pa; ++g[ag_ref0() + (uint32_t)pa];
+            items[(*size)++] = (uint32_t)pa; ++g[ag_ref0(MGX_PARAMS_OF(w).lim) + (uint32_t)pa];
             return true;
         }
         const int mn = lab_q_min(w, items, *size);
         if (aln_less(a, lab_pool_aln(w, items[mn]))) return false;
         if (own() < 0) return false;
-        ++g[ag_ref0() + (uint32_t)pa];                       // (before the release: the slot `a` was copied to stays taken)
-        --g[ag_ref0() + items[mn]];
+        ++g[ag_ref0(MGX_PARAMS_OF(w).lim) + (uint32_t)pa];                       // (before the release: the slot `a` was copied to stays taken)
+        --g[ag_ref0(MGX_PARAMS_OF(w).lim) + items[mn]];
         items[mn] = (uint32_t)pa;                            // queue.update(minimum, a)
         return true;
     };
@@ -331,7 +332,7 @@ MGX_NI_G4 bool lab_add_alignment(Wave &w, const DevAln &a) {
     if (!g[AG_NQ] && g[AG_UNL_N] > 1) {
         // the first labeled alignment: the global queue only serves the global cut-off from now on (:110-117)
         const uint32_t keep = g[AG_UNL + lab_q_max(w, g + AG_UNL, g[AG_UNL_N])];
-        for (uint32_t t = 0; t < g[AG_UNL_N]; ++t) if (g[AG_UNL + t] != keep) --g[ag_ref0() + g[AG_UNL + t]];
+        for (uint32_t t = 0; t < g[AG_UNL_N]; ++t) if (g[AG_UNL + t] != keep) --g[ag_ref0(MGX_PARAMS_OF(w).lim) + g[AG_UNL + t]];
         g[AG_UNL] = keep; g[AG_UNL_N] = 1;
     }
     bool added = false;
@@ -345,8 +346,8 @@ MGX_NI_G4 bool lab_add_alignment(Wave &w, const DevAln &a) {
     if (!added) return false;
     if (!aln_less(a, lab_pool_aln(w, g[AG_UNL + lab_q_max(w, g + AG_UNL, g[AG_UNL_N])]))) {
         const int mn = lab_q_min(w, g + AG_UNL, g[AG_UNL_N]);
-        ++g[ag_ref0() + (uint32_t)pa];
-        --g[ag_ref0() + g[AG_UNL + mn]];
+        ++g[ag_ref0(MGX_PARAMS_OF(w).lim) + (uint32_t)pa];
+        --g[ag_ref0(MGX_PARAMS_OF(w).lim) + g[AG_UNL + mn]];
         g[AG_UNL + mn] = (uint32_t)pa;
     }
     return true;
@@ -423,7 +424,7 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
         w.cyc[3] += cycle_clock() - t1;
         if (w.status != ST_OK) return;
         int n_rev = 0;
-        bool rev_alive[LAB_EXT];
+        uint64_t rev_alive = 0;           // bit r: reversal r is still to be extended (lab_ext <= 64: derive_limits)
         for (int e = 0; e < n_fwd; ++e) {
             DevAln &path = w.aln[e];
             DevAln &rev = w.aln[E + n_rev];
@@ -440,18 +441,18 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
                     if (w.status != ST_OK) return;
                 }
                 if (!to_left || !have_rev) continue;
-                rev_alive[n_rev++] = true;
+                rev_alive |= 1ull << n_rev++;
                 continue;
             }
             if (path.score >= lab_min_path_score(w, path.lab)) { lab_add_alignment(w, path); if (w.status != ST_OK) return; }
             if (!aln_clipping(path) || path.offset) continue;
             copy_aln(rev, path);
             if (!reverse_complement_aln(w, rev)) continue;
-            rev_alive[n_rev++] = true;
+            rev_alive |= 1ull << n_rev++;
         }
         // align_core (:360-384) on the backward extender over the reversed extensions
         for (int r = 0; r < n_rev; ++r) {
-            if (!rev_alive[r]) continue;
+            if (!((rev_alive >> r) & 1)) continue;
             DevAln &rev = w.aln[E + r];
             SeedRef rseed = seedref_from_aln(rev);
             const int32_t mps2 = imax(0, lab_min_path_score(w, rev.lab));
@@ -480,12 +481,12 @@ MGX_NI_G4 void lab_aln_both(Wave &w, int s) {
                 if (w.status != ST_OK) return;
             }
             for (int r2 = r + 1; r2 < n_rev; ++r2) {
-                if (!rev_alive[r2]) continue;
+                if (!((rev_alive >> r2) & 1)) continue;
                 DevAln &o = w.aln[E + r2];
                 if (!check_seed(w, B, o.nodes[o.n_nodes - 1], o.qlen, aln_clipping(o), o.score)) {
                     o.lab = lab_filter_seed(w, rev.lab, o.lab);
                     if (w.status != ST_OK) return;
-                    if (!o.lab) rev_alive[r2] = false;
+                    if (!o.lab) rev_alive &= ~(1ull << r2);
                 }
             }
         }

@@ -448,6 +448,7 @@ struct mgx_aligner {
     HostResults host_chained;          // post_chain_alignments: `host` after chain_host.hpp
     HostResults host_retried;          // mgx_align_batch: the results with the re-aligned capacity queries in place
     bool retry_capacity = true;        // (mgx_aligner_set_pipeline "retry_capacity=0": statuses are handed to the caller)
+    uint32_t label_scale = 1;          // the label arenas' multiplier (derive_limits; doubled per attempt of the capacity retry)
     const char *last_d_seqs = nullptr;           // the batch mgx_align_batch_device ran last (device pointers)
     const uint64_t *last_d_offsets = nullptr;
     std::vector<uint64_t> m_node_begin, m_fwd, m_rc;
@@ -970,7 +971,7 @@ static int work_key_bits(uint64_t n) {
 static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, uint32_t Lmax) {
     {
         std::string err;
-        int rc = derive_limits(A->cfg, A->have_user_lim ? &A->user_lim : nullptr, Lmax, &A->lim, &err, A->anno != nullptr);
+        int rc = derive_limits(A->cfg, A->have_user_lim ? &A->user_lim : nullptr, Lmax, &A->lim, &err, A->anno != nullptr, A->label_scale);
         if (rc) return fail(rc, "%s", err.c_str());
     }
     const bool labeled = A->anno != nullptr;
@@ -1554,7 +1555,8 @@ int mgx_chain_alignments(const mgx_config *config, uint32_t k, const mgx_results
 // heap) are aligned again by a temporary aligner with doubled limits, up to six doublings, and take their place in the
 // results — what the C++ adapter (host/hip_dbg_aligner.hpp) did for its callers since round 2, now for every caller of
 // mgx_align_batch (the Python binding among them).  What doubling cannot cure stays a capacity status: a query with more
-// alignments than the post_chain_alignments queue holds, a label-aware query beyond the fixed label arenas.
+// alignments than the post_chain_alignments queue holds.  (Label-aware alignment: the retry also doubles the label arenas —
+// alignments per backtracking, aggregator pool, label queues, label sets; derive_limits' label_scale.)
 static int retry_capacity_queries(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_results *out) {
     std::vector<uint64_t> todo;
     for (uint64_t q = 0; q < n; ++q) if (out->status[q] == MGX_ERR_CAPACITY) todo.push_back(q);
@@ -1586,6 +1588,7 @@ static int retry_capacity_queries(mgx_aligner *A, const char *seqs, const uint64
         if (int rc = aligner_create(A->graph, &A->cfg, &lim, A->anno, &tmp)) return rc;
         tmp->opt = A->opt; tmp->mode = A->mode; tmp->no_fast = A->no_fast;
         tmp->retry_capacity = false;
+        tmp->label_scale = 2u << attempt;
         std::string blob;
         std::vector<uint64_t> offs(pending.size() + 1, 0);
         for (size_t t = 0; t < pending.size(); ++t) {

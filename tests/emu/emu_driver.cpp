@@ -373,7 +373,9 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     R->m_rc.assign(nr.begin(), nr.end());
     R->m_len[0] = lf; R->m_len[1] = lr; R->m_rng[0] = gf; R->m_rng[1] = gr;
     if (map_only) return R;
-    rc = derive_limits(cfg, limits, Lmax, &R->lim, &R->error, AN != nullptr);
+    // (MGX_EMU_LABEL_SCALE: the label arenas' multiplier, what mgx_align_batch's capacity retry doubles per attempt)
+    const char *ls_env = getenv("MGX_EMU_LABEL_SCALE");
+    rc = derive_limits(cfg, limits, Lmax, &R->lim, &R->error, AN != nullptr, ls_env ? (uint32_t)atoi(ls_env) : 1u);
     if (rc) return R;
     const uint64_t stride = arena_bytes(R->lim);
     std::vector<uint8_t> arena(stride, 0);

@@ -209,3 +209,16 @@ def test_mgx_align_driver_with_an_annotation(tmp_path):
         want += "\t*\t*\t%d\t*\t*\t*" % cli_cfg.min_path_score
     assert r.stdout == want + "\n"
     assert o.results()[0], "the case should align"
+
+
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+def test_reads_with_more_labels_than_the_first_arenas_hold(kernel):
+    """100 labels on one genome: the first run's label arenas (64 label queues / labels on a read's seeds) report a capacity
+    status, mgx_align_batch re-runs those reads with doubled arenas (derive_limits' label_scale) — the caller sees exact results
+    and mgx_stats.n_capacity_retried."""
+    from test_labeled_emu import many_labels_world
+    g, anno, reads = many_labels_world()
+    cfg = capi.config_cli(11)
+    A, want = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=False, kernel=kernel)
+    assert max(len(x["labels"]) for a in want for x in a) > 64
+    assert A.stats()["n_capacity_retried"] > 0

@@ -125,3 +125,31 @@ def test_labeled_alignment_on_canonical_mode_graphs(seed, k):
         cfg.min_seed_length = 11
     want = compare_emu_labeled(g, anno, cfg, reads, mode=1)
     assert sum(1 for a in want if a) >= 8
+
+
+def many_labels_world(n_labels=100, k=11, seed=77):
+    """one genome carrying n_labels labels — more than the label arenas of a first run hold (64 queues / labels per read)"""
+    import random
+    from test_emu_vs_oracle import rand_seq, mutate
+    rng = random.Random(seed)
+    genome = rand_seq(rng, 500)
+    g = orc.Graph.build(k, [genome], 0, False)
+    anno = orc.Annotation(g, n_labels)
+    for j in range(n_labels):
+        anno.annotate(genome if j % 3 else genome[50:450], j)        # (two kinds of rows)
+    reads = [mutate(rng, genome[a:a + 80], 0.02) for a in (10, 120, 300, 400)]
+    return g, anno, reads
+
+
+def test_label_arenas_grow_with_the_capacity_retry(monkeypatch):
+    """A read with more labels than the first run's arenas hold reports a capacity status there — never a wrong result — and is
+    exact with the arenas the retry of mgx_align_batch derives (derive_limits' label_scale)."""
+    g, anno, reads = many_labels_world()
+    cfg = capi.config_cli(11)
+    e = emu_drv.EmuRun(emu_drv.EmuGraph(g), cfg, reads, annotation=emu_drv.EmuAnnotation(anno))
+    assert e.error == "", e.error
+    _, status = e.results()
+    assert any(s == capi.MGX_ERR_CAPACITY for s in status) and all(s in (0, capi.MGX_ERR_CAPACITY) for s in status), status
+    monkeypatch.setenv("MGX_EMU_LABEL_SCALE", "2")
+    want = compare_emu_labeled(g, anno, cfg, reads)
+    assert max(len(x["labels"]) for a in want for x in a) > 64
