@@ -368,7 +368,7 @@ int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n,
  * the graph's device, with at least as many rows as the graph has nodes (row = node - 1).
  * This round: BASIC-, PRIMARY- and CANONICAL-mode graphs (PRIMARY: through the CanonicalDBG wrapper, labels looked up by base
  * node; CANONICAL: by the k-mer's representative, the smaller BOSS index of the k-mer and its reverse complement — as
- * annotation_buffer.cpp:41-63 does), annotations without coordinates (ColumnCompressed), num_alternative_paths <= 2;
+ * annotation_buffer.cpp:41-63 does), annotations without coordinates (ColumnCompressed), num_alternative_paths <= MGX_MAX_ALTERNATIVE_PATHS;
  * anything else: MGX_ERR_UNSUPPORTED.  A read whose label bookkeeping outgrows the arenas of a first run (64 labels with
  * alignments, 8 alignments per backtracking, ...) gets MGX_ERR_CAPACITY from mgx_align_batch_device; mgx_align_batch re-runs it
  * with the arenas doubled (up to 8 x) like any other capacity status (mgx_stats.n_capacity_retried).

@@ -13,7 +13,7 @@
 // A third build (-DMGX_PRIM_BUILD -DMGX_WITH_PRIMARY=1) is the product kernel with the CanonicalDBG branches compiled in: PRIMARY
 // graphs with one alignment per query run the rounds at 3 waves per SIMD like every other graph, instead of sharing the
 // 2-wave build of the alternative paths.
-// A fourth build (-DMGX_LAB_BUILD -DMGX_ALT_BUILD -DMGX_WITH_LABELS=1 -DMGX_MAX_ALT=2) carries the label-aware extender
+// A fourth build (-DMGX_LAB_BUILD -DMGX_ALT_BUILD -DMGX_WITH_LABELS=1 -DMGX_MAX_ALT=4) carries the label-aware extender
 // (label_sets.hpp / label_driver.hpp): the batches of a mgx_labeled_aligner_create aligner, through the per-read program.
 #if defined(MGX_LAB_BUILD)
 #define MGX_SUFFIX(x) MGX_CAT(x, _lab)

@@ -8,7 +8,7 @@
 #define MGX_WITH_LABELS 1
 #define MGX_WITH_PRIMARY 1
 #ifndef MGX_MAX_ALT
-#define MGX_MAX_ALT 2
+#define MGX_MAX_ALT 4
 #endif
 #define MGX_ALIGN_WAVES_PER_SIMD 2
 #include "wave.hpp"

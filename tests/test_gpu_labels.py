@@ -163,7 +163,7 @@ def test_labeled_alignment_on_canonical_mode_graphs_on_gpu(seed, k, kernel):
 
 def test_labeled_aligner_refuses_what_it_cannot_do():
     cfg = capi.config_cli(5)
-    cfg.num_alternative_paths = 3
+    cfg.num_alternative_paths = 5                          # (more than MGX_MAX_ALTERNATIVE_PATHS: as for any aligner)
     g0 = orc.Graph.build(5, ["GTCGAAATTAGTCGAAA"], 0, False)
     with pytest.raises(aligner.MgxError) as e:
         aligner.Aligner(gpu_graph(g0), cfg, annotation=gpu_annotation(orc.Annotation(g0, 1)))
@@ -222,3 +222,15 @@ def test_reads_with_more_labels_than_the_first_arenas_hold(kernel):
     A, want = compare_gpu_labeled(g, anno, cfg, reads, check_seeds=False, kernel=kernel)
     assert max(len(x["labels"]) for a in want for x in a) > 64
     assert A.stats()["n_capacity_retried"] > 0
+
+
+@pytest.mark.parametrize("kernel", sorted(KERNELS))
+@pytest.mark.parametrize("seed,k,n_alt", [(7, 15, 4), (8, 11, 3), (9, 12, 4)])
+def test_labeled_worlds_with_up_to_four_alignments_per_label_on_gpu(seed, k, n_alt, kernel):
+    from test_labeled_emu import paralog_world
+    g, anno, reads = paralog_world(seed, k)
+    cfg = capi.config_cli(k)
+    cfg.num_alternative_paths = n_alt
+    cfg.rel_score_cutoff = 0.0                         # (keep the weaker copies' alignments)
+    _, want = compare_gpu_labeled(g, anno, cfg, reads, kernel=kernel)
+    assert any(len(a) > 2 for a in want)

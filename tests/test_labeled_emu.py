@@ -61,6 +61,40 @@ def test_random_labeled_worlds(seed, k, n_strains, divergence, monkeypatch):
         assert SEEN["multi_aln"] >= 5 and SEEN["multi_label"] >= 5, SEEN
 
 
+def paralog_world(seed, k, copies=4):
+    """one labelled genome holding several diverged copies of a segment: a read from one copy aligns to all of them, under the
+    same label — what num_alternative_paths > 1 is for"""
+    import random
+    from test_emu_vs_oracle import rand_seq, mutate, rc
+    rng = random.Random(seed)
+    seg = rand_seq(rng, 160)
+    parts = []
+    for c in range(copies):
+        parts.append(rand_seq(rng, 60))
+        parts.append(seg if c == 0 else mutate(rng, seg, 0.04))
+    genome = "".join(parts) + rand_seq(rng, 60)
+    g = orc.Graph.build(k, [genome], 0, False)
+    anno = orc.Annotation(g, 2)
+    anno.annotate(genome, 0)
+    anno.annotate(genome[:len(genome) // 2], 1)
+    reads = []
+    for i in range(12):
+        a = rng.randrange(0, 160 - 90)
+        r = mutate(rng, seg[a:a + 90], rng.choice([0.0, 0.02]))
+        reads.append(rc(r) if i % 3 == 0 else r)
+    return g, anno, reads
+
+
+@pytest.mark.parametrize("seed,k,n_alt", [(7, 15, 4), (8, 11, 3), (9, 12, 4)])
+def test_labeled_worlds_with_up_to_four_alignments_per_label(seed, k, n_alt):
+    g, anno, reads = paralog_world(seed, k)
+    cfg = capi.config_cli(k)
+    cfg.num_alternative_paths = n_alt
+    cfg.rel_score_cutoff = 0.0                         # (keep the weaker copies' alignments)
+    want = compare_emu_labeled(g, anno, cfg, reads)
+    assert any(len(a) > 2 for a in want), [len(a) for a in want]
+
+
 def primary_labeled_world(seed, k):
     """a PRIMARY graph (seen through the CanonicalDBG wrapper) over two strains, labels per strain and per segment"""
     import random
