@@ -222,8 +222,9 @@ typedef struct mgx_stats {
     uint64_t lane_bail_reads[32]; /* reads the lane-per-read kernel passed on to the group kernel, by reason (the LANE_BAIL codes of
                                    csrc/lane_read.hpp: 3 second strand, 4 many seeds, 5 invalid characters, 10 fork, 14 / 16 wide band,
                                    15 node seen before, 19 a later seed survives, 26 backward extension, ...) */
-    uint64_t n_capacity_retried; /* queries the last mgx_align_batch re-aligned with doubled limits after an MGX_ERR_CAPACITY status
-                                   (they are in its results like any other query; n_capacity_errors counts them too) */
+    uint64_t n_capacity_retried; /* queries the last mgx_fetch_results / mgx_align_batch re-aligned with doubled limits after an
+                                   MGX_ERR_CAPACITY status (they are in its results like any other query; n_capacity_errors counts
+                                   them too) */
 } mgx_stats;
 enum { MGX_KERNEL_GRP8 = 1, MGX_KERNEL_GRP8_PRIM = 2, MGX_KERNEL_GRP8_ALT = 4, MGX_KERNEL_EXT64 = 8, MGX_KERNEL_LANE = 16,
        MGX_KERNEL_LAB64 = 32, MGX_KERNEL_GRP8_LAB = 64 /* the label-aware builds of the 64-lane and the 8-lane kernel */ };
@@ -258,7 +259,11 @@ int mgx_align_batch(mgx_aligner *a, const char *seqs, const uint64_t *offsets, u
                     int seqs_on_device, mgx_results *out);
 
 /* The two halves of mgx_align_batch: run the kernels and leave the results in HBM / copy them out.
- * mgx_align_batch(a, ...) == mgx_align_batch_device(a, ...) followed by mgx_fetch_results(a, out). */
+ * mgx_align_batch(a, ...) == mgx_align_batch_device(a, ...) followed by mgx_fetch_results(a, out).
+ * mgx_fetch_results re-aligns the queries whose per-read arenas overflowed (MGX_ERR_CAPACITY: the reference's tables grow on
+ * the heap, it has no such status) with doubled limits, up to six times, and reads them from the batch's device buffers:
+ * with seqs_on_device != 0 the caller's `seqs` / `offsets` must stay valid until it returns.  The raw device results
+ * (mgx_device_results, the RCCL gather path) are what the kernels wrote: statuses included. */
 int mgx_align_batch_device(mgx_aligner *a, const char *seqs, const uint64_t *offsets, uint64_t n_queries,
                            int seqs_on_device);
 int mgx_fetch_results(mgx_aligner *a, mgx_results *out);

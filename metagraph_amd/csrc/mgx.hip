@@ -1475,6 +1475,8 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
     return MGX_OK;
 }
 
+static int retry_capacity_queries(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, mgx_results *out);
+
 int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
     HostStageTimer t_fetch("fetch_results");
     const uint64_t n = A->n_reads;
@@ -1500,7 +1502,8 @@ int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
         chain_results(plain, reads.data(), offs.data(), A->cfg, A->graph->g.k, &A->host_chained);
         A->host_chained.view(out);
     }
-    return MGX_OK;
+    // reads the batch's limits were too small for: once more, with larger ones (below)
+    return retry_capacity_queries(A, A->last_d_seqs, A->last_d_offsets, n, out);
 }
 
 int mgx_device_results(mgx_aligner *A, const void **headers, uint64_t *header_bytes, uint64_t *n_queries,
@@ -1554,20 +1557,40 @@ int mgx_chain_alignments(const mgx_config *config, uint32_t k, const mgx_results
 // Queries whose per-read arenas overflowed (status MGX_ERR_CAPACITY: the reference has no such limit, its tables grow on the
 // heap) are aligned again by a temporary aligner with doubled limits, up to six doublings, and take their place in the
 // results — what the C++ adapter (host/hip_dbg_aligner.hpp) did for its callers since round 2, now for every caller of
-// mgx_align_batch (the Python binding among them).  What doubling cannot cure stays a capacity status: a query with more
+// mgx_fetch_results / mgx_align_batch (the Python binding and the device-resident batches among them).  What doubling cannot cure stays a capacity status: a query with more
 // alignments than the post_chain_alignments queue holds.  (Label-aware alignment: the retry also doubles the label arenas —
 // alignments per backtracking, aggregator pool, label queues, label sets; derive_limits' label_scale.)
-static int retry_capacity_queries(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_results *out) {
+static int retry_capacity_queries(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, mgx_results *out) {
     std::vector<uint64_t> todo;
     for (uint64_t q = 0; q < n; ++q) if (out->status[q] == MGX_ERR_CAPACITY) todo.push_back(q);
-    if (todo.empty() || !A->retry_capacity) return MGX_OK;
-    std::vector<uint64_t> h_off;
+    if (todo.empty() || !A->retry_capacity || !d_seqs || !d_offsets) return MGX_OK;
+    // the reads in question, from the batch as the device holds it (the caller's buffers, or the upload of a host batch): a few
+    // of them one by one, a large share of the batch in one copy
+    std::vector<uint64_t> h_off(n + 1);
+    HIP_TRY(hipMemcpy(h_off.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
     std::vector<char> h_seq;
-    if (on_device) {
-        h_off.resize(n + 1);
-        HIP_TRY(hipMemcpy(h_off.data(), offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> offsets_v(n + 1, 0);
+    const char *seqs;
+    const uint64_t *offsets;
+    if (todo.size() * 64 < n) {
+        uint64_t total = 0;
+        for (uint64_t q : todo) total += h_off[q + 1] - h_off[q];
+        h_seq.resize(total + 1);
+        uint64_t at = 0;
+        for (uint64_t q = 0, t = 0; q < n; ++q) {                 // offsets over the compacted bytes: empty except for the reads to redo
+            offsets_v[q] = at;
+            if (t < todo.size() && todo[t] == q) {
+                const uint64_t len = h_off[q + 1] - h_off[q];
+                if (len) HIP_TRY(hipMemcpy(h_seq.data() + at, d_seqs + h_off[q], len, hipMemcpyDeviceToHost));
+                at += len;
+                ++t;
+            }
+        }
+        offsets_v[n] = at;
+        seqs = h_seq.data(); offsets = offsets_v.data();
+    } else {
         h_seq.resize(h_off[n] + 1);
-        if (h_off[n]) HIP_TRY(hipMemcpy(h_seq.data(), seqs, h_off[n], hipMemcpyDeviceToHost));
+        if (h_off[n]) HIP_TRY(hipMemcpy(h_seq.data(), d_seqs, h_off[n], hipMemcpyDeviceToHost));
         seqs = h_seq.data(); offsets = h_off.data();
     }
     // results so far, query by query (replaced below)
@@ -1628,8 +1651,7 @@ static int retry_capacity_queries(mgx_aligner *A, const char *seqs, const uint64
 int mgx_align_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device, mgx_results *out) {
     if (!out) return fail(MGX_ERR_INVALID, "null argument");
     if (int rc = mgx_align_batch_device(A, seqs, offsets, n, on_device)) return rc;
-    if (int rc = mgx_fetch_results(A, out)) return rc;
-    return retry_capacity_queries(A, seqs, offsets, n, on_device, out);
+    return mgx_fetch_results(A, out);          // (with the capacity retry)
 }
 
 // test hook: keep the per-read seed lists of the next batches (device -> mgx_fetch_seeds)

@@ -328,6 +328,17 @@ def test_small_cell_budget_gives_capacity_statuses_not_wrong_answers():
     got, status = B.align_batch(reads)
     assert all(s == 0 for s in status) and got == want
     assert B.stats()["n_capacity_retried"] > 0
+    # ... also for reads that were in HBM already (mgx_align_batch_device + mgx_fetch_results: the retry reads them back)
+    import numpy as np
+    import torch
+    blob, offs = aligner.pack_queries(reads)
+    d_seqs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    d_offs = torch.from_numpy(np.asarray(offs, dtype=np.int64)).cuda()
+    D = aligner.Aligner(G, cfg, lim)
+    D.align_device(d_seqs.data_ptr(), d_offs.data_ptr(), len(reads))
+    res = D.fetch()
+    assert all(res.status[i] == 0 for i in range(len(reads))) and capi.results_to_py(res) == want
+    assert D.stats()["n_capacity_retried"] > 0
 
 
 @pytest.mark.parametrize("per_wave", [0, 1, 3, 8])
