@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--world-seconds", type=int, default=60)
     args = ap.parse_args()
     import orc
+    import emu_drv  # noqa: F401  (builds the host model if it is stale: here, not inside a world's time limit)
     from metagraph_amd import capi
     import multiprocessing as mp
     ctx = mp.get_context("fork")
