@@ -178,6 +178,9 @@ MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t sel_r, uint32
     Block tgt;
     uint64_t lst = 0;
     if (sel_r) {
+        // (the rank_W primitive of this fwd() ran on the block the caller held: counted as the line the algorithm requires —
+        // SURVEY 8(d) counts primitives — although no request leaves for it; the PMC traffic shows the saving)
+        ++lc.rank_lines;
         lst = select_last_blk(g, sel_r, tgt, lc);
     } else {
         ++lc.rank_lines;

@@ -73,6 +73,12 @@ struct MapPipe {
     // stores per read were 18 KB of write traffic per read at the fabric — 40 % of this kernel's traffic (round 5 PMC).
     uint32_t ob[4], ob_mask, ob_strand;
     uint64_t ob_q;                // the quad: positions 4 ob_q .. 4 ob_q + 3 of nodes_* (ob_strand)
+    // ... and so do the match lengths of the positions index() failed at (mlen_*, same positions): one 4-byte store where all
+    // four positions of a quad failed — every quad of a strand that is not in the graph — else single bytes.  pl: the length
+    // of the position at hand, known when its walk fails, entered into the quad when the position settles (a quad on its way
+    // out holds the positions before it).
+    uint32_t lb, lb_mask;
+    int32_t pl;
     // the next chain
     int32_t bg, bg_strand, bg_L;
     uint64_t bg_read, bg_w, bg_nb, bg_cur, bg_nxt;
@@ -86,6 +92,7 @@ MGX_DEV void map_pipe_init(MapPipe &m) {
     m.wbase = m.nbase = 0; m.strand = 0; m.n_words = 0;
     m.st_flags = 0; m.st_len = 0; m.st_idx = m.st_rng = 0;
     m.ob[0] = m.ob[1] = m.ob[2] = m.ob[3] = 0; m.ob_mask = 0; m.ob_strand = 0; m.ob_q = 0;
+    m.lb = 0; m.lb_mask = 0; m.pl = -1;
     m.blk = Block{};
 }
 
@@ -155,6 +162,16 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
                 if (m.ob_mask & 4u) gst_stream(q + 2, m.ob[2]);
                 if (m.ob_mask & 8u) gst_stream(q + 3, m.ob[3]);
             }
+            if (m.lb_mask) {
+                uint8_t *ql = (m.ob_strand ? a.mlen_rc : a.mlen_fwd) + (m.ob_q << 2);
+                if (m.lb_mask == 0xFu) gst_stream((uint32_t *)ql, m.lb);
+                else {
+                    if (m.lb_mask & 1u) gst_stream(ql, (uint8_t)m.lb);
+                    if (m.lb_mask & 2u) gst_stream(ql + 1, (uint8_t)(m.lb >> 8));
+                    if (m.lb_mask & 4u) gst_stream(ql + 2, (uint8_t)(m.lb >> 16));
+                    if (m.lb_mask & 8u) gst_stream(ql + 3, (uint8_t)(m.lb >> 24));
+                }
+            }
         }
         if (m.st_flags & 2) gst_stream((rcs ? a.mlen_rc : a.mlen_fwd) + m.st_idx, (uint8_t)m.st_len);
         if (m.st_flags & 4) gst((uint64_t *)((rcs ? a.rng_rc : a.rng_fwd) + m.st_idx), m.st_rng);
@@ -203,7 +220,7 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
         m.bg_nb = nb;
         m.bg = m.bg_L >= k ? BG_DESC : BG_WANT;          // a read without a k-mer has no chain: ask for the next id
     }
-    if (m.st_flags & 1) m.ob_mask = 0;
+    if (m.st_flags & 1) { m.ob_mask = 0; m.lb_mask = 0; m.lb = 0; }
     m.st_flags = 0;
     if (st == MP_DONE) return false;
 
@@ -216,8 +233,8 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
         m.ob_mask |= 1u << slot;
         if (slot == 3 || m.i + 1 >= m.n_kmers) m.st_flags |= 1u;           // the quad, or the chain, is complete: out with it
     };
-    auto out_len = [&](uint8_t v) { m.st_flags |= 2u | ((uint32_t)m.strand << 8); m.st_idx = m.nbase + (uint64_t)m.i; m.st_len = v; };
-    auto out_rng = [&]() { m.st_flags |= 4u; m.st_rng = ((uint64_t)m.ru << 32) | m.rl; };
+    auto out_len = [&](uint8_t v) { m.pl = (int32_t)v; };                        // (into the quad when the position settles)
+    auto out_rng = [&]() { m.st_flags |= 4u | ((uint32_t)m.strand << 8); m.st_idx = m.nbase + (uint64_t)m.i; m.st_rng = ((uint64_t)m.ru << 32) | m.rl; };
     const bool lens = a.mlen_fwd && k - 1 < (int32_t)MLEN_LT_PREFIX;
     const bool rngs = a.rng_fwd != nullptr;
 
@@ -332,11 +349,17 @@ MGX_DEV bool map_pipe_step(const DevGraph &g, const MapArgs &a, MapPipe &m, Line
         if (act == ACT_ADVANCE) {
             // the k-mer at position i is settled: m.edge (0 = not found)
             m.last_node = in_graph(g, m.edge) ? m.edge : 0u;
-            out_node(m.last_node);
             if (m.t == k - 1 && !m.edge && lens) {
                 out_len((uint8_t)(k - 1));
                 if (rngs && k - 1 >= a.min_rng_len) out_rng();
             }
+            if (m.pl >= 0) {
+                const uint32_t slot = (uint32_t)(m.nbase + (uint64_t)m.i) & 3u;
+                m.lb |= (uint32_t)m.pl << (8 * slot);
+                m.lb_mask |= 1u << slot;
+                m.pl = -1;
+            }
+            out_node(m.last_node);
             m.t = -1;
             m.cur = (m.cur >> 2) | ((m.nxt & 3) << 62);
             m.icur = (m.icur >> 1) | ((m.inxt & 1) << 31);
