@@ -1366,6 +1366,65 @@ MGX_DEV void primary_rc_suffix_seeds(Wave &w, int s, uint32_t alt_n) {
     }
 }
 
+// A strand the seeder has nothing to say about — the usual fate of one of a read's two strands: no k-mer of it is in the graph
+// (no MEM, num_matching 0) and no position can report a sub-k seed: k_map's index() matched fewer than min_seed_length characters
+// at every k-mer position (its match lengths), and the walks of the read-tail positions, made here side by side, end below it
+// too.  make_seeder() would set up its tables, look the same things up and report no seed; this answers in one pass.  `false`
+// whenever anything is not known for certain (a match length k_map did not record, a position that does reach min_seed_length,
+// PRIMARY graphs, whose wrapper also seeds from the other strand): the full seeder runs.
+MGX_NI_G2 bool strand_without_seeds(Wave &w, int s) {
+    MGX_ASSUME_LDS(&w);
+    const AlignParams &P = MGX_PARAMS_OF(w);
+    const DevConfig &cfg = P.cfg;
+    const DevGraph &g = P.g;
+    const int32_t k = (int32_t)g.k, L = w.L;
+    if (cfg.canonical != 0 || !w.mlen[s] || w.n_kmers <= 0) return false;
+    {
+        // no matched k-mer (kmer_masks' first mask, without its terminus look-ups)
+        const uint32_t *nodes = w.nodes[s];
+        bool any = false;
+        for (int32_t base = 0; base < w.n_kmers; base += WAVE) {
+            LV<bool> mt;
+            FOR_LANES(l) { const int32_t i = base + l; mt[l] = i < w.n_kmers && nodes[i] != 0; }
+            any |= wave_ballot(mt) != 0;
+        }
+        if (any) return false;
+    }
+    const int32_t msl0 = (int32_t)cfg.min_seed_length;
+    if ((uint32_t)L < cfg.min_seed_length || msl0 >= k) return true;            // (no sub-k seeding: base seeds only, and there are none)
+    const int32_t nslots = L - msl0 + 1;
+    bool maybe = false;
+    for (int32_t base = 0; base < nslots; base += WAVE) {
+        LV<bool> nd;
+        LV<int32_t> nr, ns;
+        FOR_LANES(l) {
+            LineCtr lc = { 0, 0, 0 };
+            const int32_t i = base + l;
+            nd[l] = false;
+            if (i < nslots) {
+                const int32_t max_len = (int32_t)imin<uint32_t>(imin<uint32_t>(cfg.max_seed_length, (uint32_t)(k - 1)), (uint32_t)(L - i));
+                if (max_len >= msl0) {
+                    if (i < w.n_kmers && max_len == k - 1) {
+                        const uint32_t ml = w.mlen[s][i];
+                        if (ml == MLEN_LT_PREFIX) nd[l] = msl0 <= (int32_t)g.prefix_len;
+                        else if (ml < MLEN_TAIL) nd[l] = (int32_t)ml >= msl0;
+                        else nd[l] = true;                                      // not recorded
+                    } else {
+                        uint64_t first, last;
+                        const int32_t m = index_range_lane(w, s, i, max_len, msl0, &first, &last, lc);
+                        nd[l] = m >= msl0 && first && first <= g.n;
+                    }
+                }
+            }
+            nr[l] = (int32_t)(lc.rank_lines + lc.bit_lines); ns[l] = (int32_t)lc.select_lines;
+        }
+        w.ctr.rank_lines += (uint32_t)wave_sum(nr);
+        w.ctr.select_lines += (uint32_t)wave_sum(ns);
+        maybe |= wave_ballot(nd) != 0;
+    }
+    return !maybe;
+}
+
 // SuffixSeeder<UniMEMSeeder> ctor + generate_seeds (A/aligner_seeder_methods.cpp:153-358; the CanonicalDBG part above)
 // Two instantiations: MANY = one seed per matched k-mer (max_seed_length <= k: label-aware alignment, ~120 base seeds per strand
 // of a short read), whose bookkeeping runs one seed / one slot per lane; else a handful of MEMs, seed by seed.  (As run-time
@@ -4844,9 +4903,11 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
         const uint64_t tseed = cycle_clock();
         if constexpr (PHASE & PH_SEED) {
             const bool many = (uint32_t)P.g.k >= P.cfg.max_seed_length;
+            if (strand_without_seeds(w, 0)) { w.n_seeds[0] = 0; w.num_matching[0] = 0; } else
             if (many) make_seeder<true>(w, 0); else make_seeder<false>(w, 0);
             if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[0]) { w.n_seeds[0] = 0; w.num_matching[0] = 0; }
             if (have_rc && w.status == ST_OK) {
+                if (strand_without_seeds(w, 1)) { w.n_seeds[1] = 0; w.num_matching[1] = 0; } else
                 if (many) make_seeder<true>(w, 1); else make_seeder<false>(w, 1);
                 if ((double)w.L * P.cfg.min_exact_match > (double)w.num_matching[1]) { w.n_seeds[1] = 0; w.num_matching[1] = 0; }
             } else {
