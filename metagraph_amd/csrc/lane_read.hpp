@@ -861,6 +861,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         const SeedHdr *hp2 = P.seed_hdr + read;
         const DevSeed *seeds = P.seed_stream + gld(&hp2->off) + (s ? (int32_t)gld(&hp2->n_seeds[0]) : 0);
         const uint32_t *rnodes = (s ? P.nodes_rc : P.nodes_fwd) + gld(P.node_begin + read);
+        bool node0_merged = false;
         for (int32_t t = 1; t < n; ++t) {
             const DevSeed *sj = seeds + t;
             const int32_t cl = (int32_t)gld(&sj->clipping), len = (int32_t)gld(&sj->length), so = (int32_t)gld(&sj->offset);
@@ -868,7 +869,26 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             const uint32_t ln = so == 0 ? gld(rnodes + cl + nn - 1) : gld(&sj->node);
             const int32_t lpos = len + cl - 1;
             const int32_t lscore = len * m + (!cl ? cfg.left_end_bonus : 0) + (!(L - cl - len) ? cfg.right_end_bonus : 0);
-            if (ln == node0) LANE_BAIL(7);                                           // (its entry is the replay columns' merged vector)
+            if (ln == node0) {
+                // The seed's first node: its entry is the merged vector of the replay columns (update_seed_filter :100-156 over
+                // the columns in index order, as the backward pass builds it: lane_merge_column) — the first columns of the
+                // extension, whose S rows were kept because the filter holds this very node.
+                int32_t *cv = (int32_t *)(arec() + 32);
+                if (!node0_merged) {
+                    gst(arec() + 13, 0u); gst(arec() + 14, 0u);
+                    for (int32_t c = 1; c < tsize; ++c) {
+                        const uint32_t *slc = (const uint32_t *)(slots + (uint64_t)c * LANE_SLOT_BYTES);
+                        if (gld(slc + 8) != node0) break;
+                        if (!(gld(slc + 10) & LANE_GEOM_ROW)) LANE_BAIL(7);
+                        (void)lane_merge_column(slots, s8rows(), cv, arec() + 13, c, start, cfg.rel_score_cutoff);
+                    }
+                    node0_merged = true;
+                }
+                const int32_t vstart = (int32_t)gld(arec() + 13), vlen = (int32_t)gld(arec() + 14);
+                if (vlen == 0 || lpos < vstart || lpos - vstart >= vlen) LANE_BAIL(19);      // outside the entry's range: the seed lives
+                if ((int32_t)gld(cv + lpos) < lscore) LANE_BAIL(19);                    // the seed lives
+                continue;
+            }
             uint32_t hs = lane_hash(ln, hmask);
             int32_t idx = -1;
             for (;;) {

@@ -23,6 +23,7 @@ def main():
     import orc
     import emu_drv  # noqa: F401  (builds the host model if it is stale: here, not inside a world's time limit)
     from metagraph_amd import capi
+    capi.lib()                                  # (loaded here once: not by every world's child, while a rebuild may be replacing it)
     import multiprocessing as mp
     ctx = mp.get_context("fork")
     t_end = time.time() + 60 * args.minutes
