@@ -53,6 +53,10 @@ static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 // bit 4 = the replayed characters have all matched the query's so far (backward pass)
 #define LANE_REPLAY_MATCHING() ((LANE_CI(CD_HMS) >> 4) & 1)
 #define LANE_SET_REPLAY_MATCHING(v) (LANE_CI(CD_HMS) = (LANE_CI(CD_HMS) & ~16) | ((v) ? 16 : 0))
+// bit 5 = a tie between columns beyond the query's end was resolved in the lane's own order (see the frontier): from then on the
+// pass must not see anything the order of equal-score columns could change
+#define LANE_TIE_MODE() ((LANE_CI(CD_HMS) >> 5) & 1)
+#define LANE_SET_TIE_MODE(v) (LANE_CI(CD_HMS) = (LANE_CI(CD_HMS) & ~32) | ((v) ? 32 : 0))
 #define LANE_HAVE_ALN() (LANE_CI(CD_HMS) & 1)
 #define LANE_MODE() ((LANE_CI(CD_HMS) >> 1) & 3)
 #define LANE_STRAND() ((LANE_CI(CD_HMS) >> 3) & 1)
@@ -463,8 +467,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         // backtrack start cells, collected while the columns are in registers (bt_begin :815-867)
         b_score = INT32_MIN; b_nod = INT32_MIN; b_i = 0; b_pos = 0;                 // the best (score, -off_diag, -i, pos)
         t_score = INT32_MIN; t_nod = 0; t_pos = 0;                                  // the head column's start cell if it were a tip
+        bool tie_bad = false;                               // tie mode: a start cell that could compete with the best one
         auto cand = [&](int32_t sc, int32_t nod, int32_t i, int32_t pos) {
             const int32_t bs = b_score, bn = b_nod, bi = b_i, bp = b_pos;
+            if (LANE_TIE_MODE() && (bs == INT32_MIN || sc >= bs)) tie_bad = true;
             const bool better = sc != bs ? sc > bs : (nod != bn ? nod > bn : (-i != -bi ? -i > -bi : pos > bp));
             if (bs == INT32_MIN || better) { b_score = sc; b_nod = nod; b_i = i; b_pos = pos; }
         };
@@ -498,7 +504,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         // kept copies of it and spilled hundreds of registers.
         int32_t hd_begin = 0, hd_prev_end = 0;
 #define replay_top LANE_CI(CD_REPLAY_TOP)
-        replay_top = -1; LANE_SET_REPLAY_MATCHING(1);
+        replay_top = -1; LANE_SET_REPLAY_MATCHING(1); LANE_SET_TIE_MODE(0);
         bool reload = false, ext_over = false;
         int reload_slot = -1;                               // -1: the parent of a fork again; else the frontier slot whose column is the head now
         while (!ext_over) {
@@ -511,6 +517,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     if ((double)tsize / (double)window_size >= cfg.max_nodes_per_seq_char) stop_all = true;
                     else if ((double)table_size_bytes() / 1000000.0 > cfg.max_ram_per_alignment) stop_all = true;
                 }
+                if (stop_all && LANE_TIE_MODE()) LANE_BAIL(27);                        // (which columns exist by now depends on the order)
                 if (stop_all) {
                     ext_over = true;                                                   // (the frontier is dropped with it)
                 } else {
@@ -542,6 +549,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                             kid_node0 = kn0; kid_code0 = kc0; kid_node1 = kn1; kid_code1 = kc1; kid_rank0 = kr0; kid_rank1 = kr1;
                             if (nc == 0) {                                             // a tip: its start cell counts after all
                                 if (t_score != INT32_MIN) cand(t_score, t_nod, f_idx, t_pos);
+                                if (tie_bad) LANE_BAIL(27);
                                 head_dead = true;
                             }
                             n_kids = nc;
@@ -604,6 +612,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     }
                     const int32_t max_val = out.max_val;
                     if ((int32_t)((uint32_t)max_val - (uint32_t)xdrop_cutoff) > xdrop) xdrop_cutoff = max_val - xdrop;
+                    if (LANE_TIE_MODE() && max_val >= best_score) LANE_BAIL(27);        // (tie mode: the best score stands)
                     best_score = imax(best_score, max_val);
                     const int32_t my_idx = tsize;
                     if (probe) {
@@ -705,6 +714,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                             }
                         }
                     }
+                    if (tie_bad) LANE_BAIL(27);
                     if (converged != NINF) {
                         c_alive = 1; c_conv = converged; c_org = org; c_trim = begin; c_size = size; c_max_val = max_val; c_idx = my_idx;
                         c_node = next;
@@ -786,8 +796,26 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                             if (top == INT32_MIN) {
                                 frontier_done = true;                                  // the frontier is empty
                             } else if (a_top || c_top) {
-                                if (n_top > 1) LANE_BAIL(27);                          // an equal-score batch (:491-500): the general path
-                                if (a_top) {
+                                bool take_c = false;
+                                if (n_top > 1) {
+                                    // An equal-score batch (:491-500): the reference pops all of it and processes it from the back —
+                                    // the general path's business, except where the ORDER inside the batch cannot matter: every
+                                    // column of the batch lies beyond the query's end (nothing but gap cells left to gain: the
+                                    // children of a fork there tie by construction, and keep tying level by level until the x-drop
+                                    // ends both branches), so each is extended on its own, the best score and the cut-off stand, and
+                                    // only the column indices come out in another order.  The lane takes the child in its registers
+                                    // and guards the rest of the pass (LANE_TIE_MODE: no new best score, no start cell that competes,
+                                    // no early cut-off; the size caps are checked once more when the extension ends).
+                                    const int32_t end_diag = window_size + (c_seed_off - 1);          // next_offset of the last column on the query
+                                    bool post_end = c_top && next_offset > end_diag;
+#pragma unroll
+                                    for (int t = 0; t < LANE_MAX_DEFER; ++t)
+                                        if (d_score(t) == top && !((int32_t)gld(dsave(t) + 67) > end_diag)) post_end = false;
+                                    if (!post_end) LANE_BAIL(27);
+                                    LANE_SET_TIE_MODE(1);
+                                    take_c = true;
+                                }
+                                if (a_top && !take_c) {
                                     if (c_alive && !stay_behind_c(fa_alive - 1)) LANE_BAIL(28);
                                     f_max_val = fa_max_val;
                                     head_from_slot(fa_alive - 1);
@@ -821,6 +849,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 }
 #pragma unroll
                                 for (int t = 0; t < LANE_MAX_DEFER; ++t) { if (t == slot) d_score(t) = INT32_MIN; }
+                                if (stop_all && LANE_TIE_MODE()) LANE_BAIL(27);
                                 if (stop_all) {
                                     frontier_done = true;                              // (extend() drops the whole frontier)
                                 } else if (dm >= xdrop_cutoff) {
@@ -841,6 +870,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 }
             }
         }
+        // (tie mode: the modelled size caps were never reached in any order of the tied columns — they are monotone in the table's
+        // size, and this is its final one)
+        if (LANE_TIE_MODE() && ((double)tsize / (double)window_size >= cfg.max_nodes_per_seq_char
+                                || (double)table_size_bytes() / 1000000.0 > cfg.max_ram_per_alignment)) LANE_BAIL(27);
         // ---- after the extension: everything below is derived afresh from the read's index and the lane's cold state ----
         LANE_OPAQUE(read);
         const int32_t seed_off = c_seed_off, seed_len = c_seed_len;
