@@ -35,6 +35,23 @@ def test_lane_kernel_on_bench_like_reads():
     assert got3 == want and A.stats()["n_lane_reads"] == 0 and not (A.stats()["extend_kernels"] & capi.KERNEL_LANE)
 
 
+@pytest.mark.parametrize("snp_every", [490, 120])
+def test_lane_kernel_on_reads_over_snp_bubbles(snp_every):
+    """the benchmark's graph shape: bubbles the extensions fork at — behind the query's end the children of a fork tie level
+    by level (LANE_TIE_MODE), a later seed may end in the first seed's first node (the merged vector of the replay columns)"""
+    g, reads = bench_like_world(20 + snp_every, 20000, genome_len=120000, snp_every=snp_every)
+    cfg = capi.config_cli(31)
+    A = aligner.Aligner(gpu_graph(g), cfg)
+    A.set_pipeline("lane=1")
+    got, status = A.align_batch(reads)
+    assert all(s == 0 for s in status)
+    st = A.stats()
+    assert st["extend_kernels"] & capi.KERNEL_LANE and st["n_lane_reads"] > (0.9 if snp_every == 490 else 0.7) * len(reads), st
+    want = orc.AlignRun(g, cfg, reads, threads=os.cpu_count() or 8, validate=False).results()
+    for q in range(len(reads)):
+        assert got[q] == want[q], (q, reads[q], got[q], want[q])
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_lane_kernel_on_random_worlds(seed):
     rng = random.Random(2000 + seed)
