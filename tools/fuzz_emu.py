@@ -146,7 +146,7 @@ def main():
                 r = r[:q] + rng.choice(["N", "n", "a", "x"]) + r[q + 1:]
             if r:
                 reads.append(r)
-        for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST", "MGX_EMU_LDS", "MGX_EMU_RESUME_CAP"):
+        for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST", "MGX_EMU_LDS", "MGX_EMU_RESUME_CAP", "MGX_EMU_LABEL_SCALE"):
             os.environ.pop(v, None)
         if rng.random() < 0.5:                                   # modelled LDS size: which per-read arrays live in LDS / in the arena
             os.environ["MGX_EMU_LDS"] = str(rng.choice([0, 256, 700, 1500, 4000, 20000]))
@@ -166,13 +166,16 @@ def main():
             os.environ["MGX_EMU_LANE"] = "1"
         if args.labels:
             os.environ.pop("MGX_EMU_MULTIPASS", None)
-            cfg.num_alternative_paths = rng.choice([1, 1, 1, 2])
+            cfg.num_alternative_paths = rng.choice([1, 1, 1, 2, 3, 4])
+            if rng.random() < 0.25:                                # the label arenas as the capacity retry of mgx_align_batch sizes them
+                os.environ["MGX_EMU_LABEL_SCALE"] = str(rng.choice([2, 4]))
             if rng.random() < 0.3:
                 cfg.left_end_bonus, cfg.right_end_bonus = rng.choice([0, 2, 5]), rng.choice([0, 3, 5])
         desc = dict(seed=seed, mode=mode, k=k, mask=mask, glen=len(genome), n_seqs=len(seqs), msl=cfg.min_seed_length,
                     maxsl=cfg.max_seed_length, per_locus=cfg.max_num_seeds_per_locus, xdrop=cfg.xdrop, n_alt=cfg.num_alternative_paths,
                     fwd_rc=cfg.forward_and_reverse_complement, mem=cfg.min_exact_match,
-                    env={v: os.environ.get(v) for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST", "MGX_EMU_LDS", "MGX_EMU_RESUME_CAP")})
+                    env={v: os.environ.get(v) for v in ("MGX_EMU_SPLIT", "MGX_EMU_MULTIPASS", "MGX_NO_FAST", "MGX_EMU_LDS", "MGX_EMU_RESUME_CAP",
+                                                         "MGX_EMU_LABEL_SCALE")})
         if args.verbose:
             print(desc, [len(r) for r in reads], flush=True)
         try:
