@@ -1,6 +1,7 @@
 // mgx.hip — libmgx.so: gfx950 kernels and the C-ABI of include/mgx.h.
 // Host side is plain C++ around the HIP runtime; there is no CPU execution path for the aligner.
 #include <hip/hip_runtime.h>
+#include "pack_swar.hpp"
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -138,12 +139,15 @@ __global__ void k_canon_merge(DevGraph g, const char *seqs, const uint64_t *offs
 
 __global__ void k_kmer_counts(const uint64_t *offsets, uint64_t n_reads, uint32_t k, uint64_t *counts, unsigned long long *lmax) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long L = 0;
     if (i < n_reads) {
-        uint64_t L = offsets[i + 1] - offsets[i];
+        L = offsets[i + 1] - offsets[i];
         counts[i] = L >= k ? L - k + 1 : 0;
-        atomicMax(lmax, (unsigned long long)L);
     }
     if (i == n_reads) counts[i] = 0;
+    // the batch's longest read: one atomic per wavefront (10 M atomics on one address were most of this kernel's 1.6 ms)
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(L, d); L = o > L ? o : L; }
+    if ((threadIdx.x & 63) == 0 && L) atomicMax(lmax, L);
 }
 
 #ifndef MGX_MAP_BLOCKS_PER_CU
@@ -199,9 +203,29 @@ __global__ void k_pack_reads(const char *seqs, const uint64_t *offsets, uint64_t
     if (32 * j >= L) return;
     const uint64_t w = packed_word_begin(off, read) + (uint64_t)j;
     uint64_t c; uint32_t v;
-    pack_read_word(seqs + off, L, 0, j, &c, &v);
+    // 32 characters at a time (pack_swar.hpp) where the word's 32 bytes lie inside the batch; the byte loop at its two ends
+    const uint64_t total = offsets[n_reads];
+    auto load32 = [&](uint64_t at, uint64_t *b) {
+        const char *p = seqs + at;
+        for (int x = 0; x < 4; ++x) { uint64_t q; __builtin_memcpy(&q, p + 8 * x, 8); b[x] = q; }
+    };
+    const int32_t p0 = 32 * j, nf = L - p0 < 32 ? L - p0 : 32;
+    if (off + (uint64_t)p0 + 32 <= total) {
+        uint64_t b[4];
+        load32(off + (uint64_t)p0, b);
+        mgx_pack::pack32(b, nf, 0, &c, &v);
+    } else pack_read_word(seqs + off, L, 0, j, &c, &v);
     pk_fwd[w] = c; iv_fwd[w] = v;
-    if (do_rc) { pack_read_word(seqs + off, L, 1, j, &c, &v); pk_rc[w] = c; iv_rc[w] = v; }
+    if (do_rc) {
+        // strand position 32 j + t of the reverse complement is read position L - 1 - 32 j - t: the 32 bytes from lo on, backwards
+        const int64_t lo = (int64_t)L - 32 * (int64_t)j - 32;
+        if ((int64_t)off + lo >= 0) {
+            uint64_t b[4];
+            load32((uint64_t)((int64_t)off + lo), b);
+            mgx_pack::pack32(b, nf, 1, &c, &v);
+        } else pack_read_word(seqs + off, L, 1, j, &c, &v);
+        pk_rc[w] = c; iv_rc[w] = v;
+    }
 }
 
 // k_map over the packed reads (k <= 32): same chains, same primitives, same outputs (map_lane_step_packed)
