@@ -956,7 +956,10 @@ MGX_DEV void detect_linear_psum(Wave &w) {
     }
 }
 
-MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding, bool for_extension) {
+// word j of read r's 2-bit packed strands (k_pack_reads, graph_build.hpp): 32 codes per word, every read starts a word
+MGX_HD uint64_t packed_word_begin(uint64_t byte_offset, uint64_t read) { return (byte_offset >> 5) + read; }
+
+MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding, bool for_extension, uint64_t read = 0) {
     MGX_ASSUME_LDS(&w);
     const AlignParams &P = MGX_PARAMS_OF(w);
     const int32_t L = w.L;
@@ -995,9 +998,36 @@ MGX_NI_G1 void prepare_query(Wave &w, const char *raw, bool for_seeding, bool fo
         }
         FOR_LANES(l) { if (l == 0) w.psum[s][L] = 0; }
     }
-    // 2-bit packed strands for the suffix-range table keys (the seeder's lookups only)
+    // 2-bit packed strands for the suffix-range table keys (the seeder's lookups only): as k_pack_reads left them where the
+    // batch was packed for the mapping kernel (same codes, same order: a 64-bit word of 32 codes is two of these words; an
+    // invalid or missing position holds 0 there as here), else encoded here
     for (int s = 0; for_seeding && s < 2; ++s) {
         const int32_t nw = (L + 15) / 16 + 1;
+        if (P.pkw[s] && P.ivw[s]) {
+            const uint64_t wb = packed_word_begin((uint64_t)(raw - P.seqs), read);
+            const int32_t n64 = (L + 31) >> 5;
+            uint64_t bad_any = 0;
+            for (int32_t base = 0; base < nw; base += WAVE) {
+                LV<bool> bad;
+                FOR_LANES(l) {
+                    const int32_t wi = base + l;
+                    bad[l] = false;
+                    if (wi < nw) {
+                        const int32_t j = wi >> 1;
+                        uint32_t v = 0;
+                        if (j < n64) {
+                            const uint64_t q = gld(P.pkw[s] + wb + (uint64_t)j);
+                            v = (wi & 1) ? (uint32_t)(q >> 32) : (uint32_t)q;
+                            if (!(wi & 1)) bad[l] = gld(P.ivw[s] + wb + (uint64_t)j) != 0;
+                        }
+                        w.pk[s][wi] = v;
+                    }
+                }
+                bad_any |= wave_ballot(bad);
+            }
+            w.inv_any[s] = bad_any ? 1 : 0;
+            continue;
+        }
         uint64_t bad_any = 0;
         for (int32_t base = 0; base < nw; base += WAVE) {
             LV<bool> bad;
@@ -4882,7 +4912,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     if (w.L > (int32_t)P.lim.Lmax) {
         w.status = ST_CAPACITY;
     } else {
-        prepare_query(w, P.seqs + off, (PHASE & PH_SEED) != 0, (PHASE & PH_EXTEND) != 0);
+        prepare_query(w, P.seqs + off, (PHASE & PH_SEED) != 0, (PHASE & PH_EXTEND) != 0, read);
         w.lc_any[0] = w.lc_any[1] = -1;
         w.lc_maybe = -1;
         w.cyc[0] = cycle_clock() - tstart;

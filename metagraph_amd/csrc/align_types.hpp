@@ -154,6 +154,10 @@ struct AlignParams {
     const uint32_t *anno_base;           // CANONICAL-mode graphs: node -> the representative whose row holds its labels (canon_repr_node), else null
     uint32_t ablate;                     // timing probes only (results become WRONG): bit 0 = no convergence table in the chain
                                          // step, bit 1 = no cell records / column metadata stores, bit 2 = no backtrack
+    // the strands as k_pack_reads left them (k <= 32: 32 codes per 64-bit word + one invalid flag per base, word j of read r at
+    // packed_word_begin(offsets[r], r) + j), or null: the seeding phase takes its 2-bit strands from here instead of encoding again
+    const uint64_t *pkw[2];
+    const uint32_t *ivw[2];
 };
 
 } // namespace mgx

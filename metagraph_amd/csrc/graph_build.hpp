@@ -144,7 +144,7 @@ MGX_DEV bool build_terminus(const DevGraph &g, uint64_t v) {
 // index(), tighten_range, fwd and pick_edge look at (positions i .. i + k - 1) is a shift away, where the byte path
 // issues a global load, an alphabet switch and a complement per character.
 // ------------------------------------------------------------------------------------------------
-MGX_HD uint64_t packed_word_begin(uint64_t byte_offset, uint64_t read) { return (byte_offset >> 5) + read; }
+// (packed_word_begin: align_core.hpp, next to prepare_query, which reads these words too)
 
 MGX_DEV void pack_read_word(const char *seq, int32_t L, int strand, int32_t j, uint64_t *codes, uint32_t *inv) {
     uint64_t c = 0;

@@ -1100,6 +1100,10 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     P.stats = A->d_stats.as<KernelStats>();
     P.dbg_seeds = A->keep_seeds ? A->dbg_seeds.as<DevSeed>() : nullptr;
     P.no_fast = A->no_fast;
+    if (A->packed_valid) {
+        P.pkw[0] = A->pk_fwd.as<uint64_t>(); P.ivw[0] = A->iv_fwd.as<uint32_t>();
+        P.pkw[1] = A->dcfg.fwd_and_rc ? A->pk_rc.as<uint64_t>() : nullptr; P.ivw[1] = A->dcfg.fwd_and_rc ? A->iv_rc.as<uint32_t>() : nullptr;
+    }
     P.no_compact = A->opt.no_compact != 0;
     P.no_alias = A->opt.no_alias != 0;
     P.no_bt_runs = A->opt.no_bt_runs != 0;

@@ -398,6 +398,10 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
     P.results = R->results.data(); P.out_stream = R->stream.data(); P.out_capacity = out_words;
     P.out_cursor = &cursors[0]; P.read_cursor = &cursors[1]; P.stats = &R->stats; P.dbg_seeds = R->seeds.data();
     P.no_fast = getenv("MGX_NO_FAST") && atoi(getenv("MGX_NO_FAST")) == 1;     // every column through the general path
+    if (have_packed && !getenv("MGX_EMU_NO_PKW")) {              // (as mgx.hip: the strands of k_pack_reads for the seeding phase)
+        P.pkw[0] = pkf.data(); P.ivw[0] = ivf.data();
+        if (dcfg.fwd_and_rc) { P.pkw[1] = pkr.data(); P.ivw[1] = ivr.data(); }
+    }
     if (AN) {
         P.labeled = 1; P.no_alias = 1;        // as mgx.hip
         if (G->mode == MGX_MODE_CANONICAL) {   // k_canon_repr
