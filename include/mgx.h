@@ -221,7 +221,8 @@ typedef struct mgx_stats {
     uint64_t n_lane_columns;    /* part of n_columns computed by it (for the reads it passes on too) */
     uint64_t lane_bail_reads[32]; /* reads the lane-per-read kernel passed on to the group kernel, by reason (the LANE_BAIL codes of
                                    csrc/lane_read.hpp: 3 second strand, 4 many seeds, 5 invalid characters, 10 fork, 14 / 16 wide band,
-                                   15 node seen before, 19 a later seed survives, 26 backward extension, ...) */
+                                   15 node seen before, 19 a later seed survives, 26 backward extension, 27 an equal-score batch of columns on the query,
+                                   28 more parked columns than frontier slots, ...) */
     uint64_t n_capacity_retried; /* queries the last mgx_fetch_results / mgx_align_batch re-aligned with doubled limits after an
                                    MGX_ERR_CAPACITY status (they are in its results like any other query; n_capacity_errors counts
                                    them too) */
