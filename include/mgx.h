@@ -312,9 +312,21 @@ void mgx_kernel_launch_counts(uint64_t *out5);
  *   groups_per_wave=n    8-lane kernel: n = 1 .. 8 groups of a wavefront take reads, 0 = all (default: from the batch size)
  *   multi_pass=0|1       one extension per read and launch (default: automatic from the seeds per read); two_pass=1
  *   lane=0|1             the lane-per-read kernel in front of the group kernel (default: automatic)
+ *   device_share=n       n handles are at work on this device at the same time (worker threads): this handle sizes its per-slot
+ *                        arenas for 1 / n of the machine (default 1: all of it)
  *   no_compact / no_alias / no_bt_runs / no_flat / primary_alt_build = 1   A/B forms of the column records and loops
  * Unknown name: MGX_ERR_INVALID.  (Measurement probes that change results or occupancy exist only in -DMGX_PROBES builds.) */
 int mgx_aligner_set_pipeline(mgx_aligner *a, const char *name);
+/* The HIP stream (a hipStream_t, passed as void * so that this header needs no HIP header) every kernel launch, asynchronous
+ * copy and device-library call of this aligner goes to; its blocking copies synchronise that stream only.  NULL (the state
+ * after creation) = the legacy default stream.  With a stream of its own per handle, the aligners of several worker threads on
+ * one device — the reference builds one aligner per thread-pool task, cli/align.cpp:440-475 — run side by side instead of
+ * serialising on the default stream.  The stream stays the caller's (not destroyed with the aligner); device buffers handed to
+ * mgx_align_batch_device / mgx_map_batch must be ready on it.  mgx_aligner_create_stream gives the aligner a non-blocking
+ * stream that it owns (destroyed with it) — what host/mgx_align -p N does per worker. */
+int mgx_aligner_set_stream(mgx_aligner *a, void *hip_stream);
+int mgx_aligner_create_stream(mgx_aligner *a);
+void *mgx_aligner_get_stream(const mgx_aligner *a);
 
 /* Format one query's results exactly like format_alignment() (cli/align.cpp:254-285):
  * "header\tquery\t(+|-)\tpath\tscore\tnum_matches\tcigar\toffset\n", or the "*" line.

@@ -4548,7 +4548,9 @@ MGX_NI_G4 void add_alignment(Wave &w, const DevAln &a) {
     if (w.have_best < n_alt) { copy_aln(w.aln[Q0 + w.have_best], a); ++w.have_best; return; }
     // post_chain_alignments: "never skip any alignments" (:92-96) — the host chains them (chain_host.hpp); a query with more
     // than the queue holds is a capacity status, not a silently shortened list
-    if (dc.post_chain) { w.status = ST_CAPACITY; return; }
+    // (have_best = -1 marks the cause: the result writer flags the record — ReadResult::orientation = RR_CAUSE_QUEUE — so that the
+    // host's capacity retry does not try to cure with larger arenas what larger arenas cannot cure)
+    if (dc.post_chain) { w.status = ST_CAPACITY; w.have_best = -1; return; }
     int mn = 0;                                             // std::min_element: the first of equal minima
     for (int t = 1; t < w.have_best; ++t) if (aln_less(w.aln[Q0 + t], w.aln[Q0 + mn])) mn = t;
     if (aln_less(a, w.aln[Q0 + mn])) return;
@@ -5131,6 +5133,7 @@ MGX_DEV void align_read(Wave &w, const AlignParams &P, uint64_t read, uint32_t s
     const uint64_t tout = cycle_clock();
 
     rr.status = w.status;
+    if (w.status == ST_CAPACITY && w.have_best < 0) rr.orientation = RR_CAUSE_QUEUE;
     rr.n_extensions = w.n_extensions; rr.n_columns = w.n_columns;
 #if MGX_WITH_LABELS && !defined(MGX_NO_EXTEND)
     if (P.labeled && w.status == ST_OK && (PHASE & PH_EXTEND)) {
@@ -5604,7 +5607,7 @@ MGX_DEV bool flat_read_end(Wave &w, const AlignParams &P, uint64_t read, KernelS
     const uint64_t tout = cycle_clock();
     ReadResult rr;
     rr.status = w.status; rr.n_alignments = 0; rr.score = 0; rr.offset = 0; rr.n_nodes = rr.n_cigar = rr.seq_len = 0;
-    rr.orientation = 0; rr.stream_off = 0;
+    rr.orientation = (w.status == ST_CAPACITY && w.have_best < 0) ? RR_CAUSE_QUEUE : 0; rr.stream_off = 0;
     rr.num_matches_fwd = w.num_matching[0]; rr.num_matches_rc = w.num_matching[1];
     rr.n_seeds_fwd = (uint32_t)w.n_seeds[0]; rr.n_seeds_rc = (uint32_t)w.n_seeds[1];
     rr.n_extensions = w.n_extensions; rr.n_columns = w.n_columns;

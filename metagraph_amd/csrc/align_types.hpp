@@ -10,6 +10,9 @@ constexpr uint32_t INF_LEN = 0xFFFFFFFFu;            // "unbounded" size_t confi
 enum { OP_CLIPPED = 0, OP_MISMATCH = 1, OP_MATCH = 2, OP_DELETION = 3, OP_INSERTION = 4, OP_NODE_INSERTION = 5 };
 
 enum { ST_OK = 0, ST_CAPACITY = -5, ST_RETRY = -100 };      // ST_RETRY is internal to the two-pass extension (never reported)
+// ReadResult::orientation of a record with status ST_CAPACITY: why.  0 = a per-read arena (larger limits cure it: the host's
+// capacity retry), RR_CAUSE_QUEUE = more alignments than the post_chain_alignments queue holds (no limit cures it).
+enum { RR_CAUSE_QUEUE = 2 };
 
 // DBGAlignerConfig after the DBGAligner ctor clamps (dbg_aligner.cpp:33-61), narrowed for the device
 struct DevConfig {

@@ -274,8 +274,10 @@ inline void chain_strands(const char *raw, size_t len, std::string *fwd, std::st
 }
 
 // Post-chain every query of `in` (whose reads are seqs[offsets[q] .. offsets[q + 1])) into `out`.
+// seq_origin: the batch offset of seqs[0] (the caller may hold only the span of the batch whose queries have two or more
+// alignments: the reads of the others are never looked at, their lengths come from `offsets`)
 inline void chain_results(const mgx_results &in, const char *seqs, const uint64_t *offsets, const mgx_config &cfg, uint32_t k,
-                          HostResults *out) {
+                          HostResults *out, uint64_t seq_origin = 0) {
     out->aln_begin.assign(1, 0);
     out->alns.clear(); out->nodes.clear(); out->cigar.clear(); out->seqs.clear(); out->status.clear(); out->labels.clear();
     std::string fwd, rc;
@@ -296,7 +298,7 @@ inline void chain_results(const mgx_results &in, const char *seqs, const uint64_
             items.push_back(std::move(c));
         }
         if (items.size() >= 2) {
-            chain_strands(seqs + offsets[q], L, &fwd, &rc);
+            chain_strands(seqs + (offsets[q] - seq_origin), L, &fwd, &rc);
             items = chain_query(std::move(items), fwd, rc, cfg, k - 1);
         }
         for (const ChainItem &c : items) {

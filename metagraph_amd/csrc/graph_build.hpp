@@ -73,8 +73,9 @@ MGX_DEV void build_sel_anchor(const DevGraph &g, uint32_t j, uint32_t shift, uin
     const uint64_t r0 = (uint64_t)(j - 1) << shift;
     if (j + 1 < n_entries || r0 > total_last) { out[j] = (uint32_t)g.n; return; }
     const uint64_t p0 = r0 ? select_last(g, (uint32_t)r0, ctr) : 0, p1 = select_last(g, total_last, ctr);
-    const uint64_t span = total_last - r0;                     // ranks of the last segment (>= 1 here)
-    const uint64_t ext = p0 + (((p1 - p0) << shift) + span - 1) / (span ? span : 1);
+    const uint64_t span = total_last - r0;                     // ranks of the last segment
+    if (span == 0) { out[j] = (uint32_t)g.n; return; }         // (total_last a multiple of 2^shift: no rank lies in this segment)
+    const uint64_t ext = p0 + (((p1 - p0) << shift) + span - 1) / span;
     out[j] = (uint32_t)(ext > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : ext);
 }
 

@@ -30,6 +30,7 @@ namespace mgx {
 
 // per-lane views of the small on-chip arrays (LDS on the device, plain arrays in the host model)
 struct LaneChip {
+    int32_t lane;                        // the lane's index in its wavefront (its private scratch slice: lane_rest())
     uint64_t *qw; int32_t qstride;       // packed strand of the read: word i at qw[i * qstride]
     uint32_t *runs; int32_t rstride;     // CIGAR runs of the trace, last first: run i at runs[i * rstride]
     uint32_t *cold; int32_t cstride;     // the lane's cold state (below): word i at cold[i * cstride]
@@ -90,9 +91,29 @@ struct LaneProfPacked {
     }
 };
 
+// timing probes (never in a product build): MGX_LANE_PROBE bit 0 = no node-table probe / insert, bit 1 = no slot stores,
+// bit 2 = the select of lane_children predicted from DevGraph::sel_anchor (global memory) instead of the last_hint fetch
+#ifndef MGX_LANE_PROBE
+#define MGX_LANE_PROBE 0
+#endif
 enum { LR_DONE = 0, LR_BAIL = 1, LR_AGAIN = 2 };      // LR_AGAIN: call again for the same read with pass = 1 (the backward pass)
 
-struct LaneCounters { uint32_t reason; };     // reason: which test sent the read to the group kernel
+// -DMGX_LANE_TIMERS (measurement builds): wave cycles by section of lane_read() — 0 read set-up, 1 the head's children (graph),
+// 2 the column pass, 3 node table + commit + start cells, 4 frontier, 5 later seeds + trace, 6 result
+#ifndef MGX_LANE_TIMERS
+#define MGX_LANE_TIMERS 0
+#endif
+struct LaneCounters {
+    uint32_t reason;                             // which test sent the read to the group kernel
+#if MGX_LANE_TIMERS
+    uint64_t t[8], t0;
+#endif
+};
+#if MGX_LANE_TIMERS
+#define LANE_T(i) do { const uint64_t t_ = cycle_clock(); ctr.t[i] += t_ - ctr.t0; ctr.t0 = t_; } while (0)
+#else
+#define LANE_T(i) ((void)0)
+#endif
 #define LANE_BAIL(code) do { ctr.reason = (code); return LR_BAIL; } while (0)
 
 // the children of `v` on the reverse-complement view of the graph (RCDBG::call_outgoing_kmers, rc_dbg.hpp:88-99): the parents of
@@ -185,7 +206,11 @@ MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t sel_r, uint32
         // (the rank_W primitive of this fwd() ran on the block the caller held: counted as the line the algorithm requires —
         // SURVEY 8(d) counts primitives — although no request leaves for it; the PMC traffic shows the saving)
         ++lc.rank_lines;
+#if MGX_LANE_PROBE & 4
+        lst = select_last_scan(g, sel_r, sel_predict(g.sel_anchor, g.sel_shift, sel_r), tgt, lc);
+#else
         lst = select_last_blk(g, sel_r, tgt, lc);
+#endif
     } else {
         ++lc.rank_lines;
         const Block cur = load_block(g, (uint32_t)(v >> 6));
@@ -216,19 +241,37 @@ MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t sel_r, uint32
 // reversal (Alignment::reverse_complement) is what a walk down the parent links yields anyway
 enum { LANE_EMIT_SLOTS = 0, LANE_EMIT_ARRAYS = 1, LANE_EMIT_SLOTS_REVERSED = 2 };
 
+// ---- the wavefront's scratch as one lane sees it (layout: LaneParams, lane_types.hpp) ----
+// `il`: the interleaved part from this lane's word on (wave base + 4 * lane): word w of column c's slot, of its S row
+MGX_HD uint32_t *lane_slot_word(const uint8_t *il, int32_t c, int w) {
+    return (uint32_t *)il + ((uint32_t)c * LANE_SLOT_WORDS + (uint32_t)w) * LANE_WAVE;
+}
+MGX_HD uint8_t *lane_slot_flag(const uint8_t *il, int32_t c, int32_t x) {          // flag byte of window cell x
+    return (uint8_t *)lane_slot_word(il, c, x >> 2) + (x & 3);
+}
+MGX_HD uint32_t *lane_s8_word(const uint8_t *il, uint32_t max_cols, int32_t c, int w) {
+    return (uint32_t *)il + (max_cols * LANE_SLOT_WORDS + (uint32_t)c * LANE_S8_WORDS + (uint32_t)w) * LANE_WAVE;
+}
+MGX_HD uint8_t *lane_s8_byte(const uint8_t *il, uint32_t max_cols, int32_t c, int32_t x) {
+    return (uint8_t *)lane_s8_word(il, max_cols, c, x >> 2) + (x & 3);
+}
+// the lane's private slice behind the interleaved part
+MGX_HD uint8_t *lane_rest(const LaneParams &LP, const uint8_t *il, int32_t lane) {
+    return (uint8_t *)il + (LP.wave_stride - (uint64_t)LANE_WAVE * LP.rest_stride) + (uint64_t)lane * (LP.rest_stride - 4);
+}
+
 // update_seed_filter (:100-156) for column c of a node whose columns all belong to one replay (the first node of a seed): merges
 // the column's S row into the node's vector cv[query position] (range state in vr[0] = start, vr[1] = length; length 0 = none yet)
 // exactly as chain_step does — a disjoint range is taken as it is (the gap reads ninf), an overlapping one cell by cell: a cell
 // counts as improved when S > old * rel_score_cutoff — and returns the converged score (ninf: nothing improved).
-MGX_DEV int32_t lane_merge_column(const uint8_t *slots, const uint8_t *s8rows, int32_t *cv, uint32_t *vr, int32_t c, int32_t start, double rel) {
-    const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)c * LANE_SLOT_BYTES);
-    const int32_t base = (int32_t)gld(sl + 9);
-    const uint32_t geom = gld(sl + 10);
+MGX_DEV int32_t lane_merge_column(const uint8_t *il, uint32_t max_cols, int32_t *cv, uint32_t *vr, int32_t c, int32_t start, double rel) {
+    const int32_t base = (int32_t)gld(lane_slot_word(il, c, 9));
+    const uint32_t geom = gld(lane_slot_word(il, c, 10));
     const int32_t begin = (int32_t)(geom & 0xFFFF), size = (int32_t)((geom >> 16) & 0xFF), org = begin & ~3;
     const int32_t skip = begin ? 0 : 1;
     const int32_t cn = size - skip, query_start = start + begin - (begin ? 1 : 0);
     auto cell_S = [&](int32_t j) -> int32_t {                       // cell j of the column (window position begin + j)
-        const int32_t d = (int32_t)(int8_t)gld(s8rows + (uint64_t)c * LANE_S8_BYTES + (begin + j - org));
+        const int32_t d = (int32_t)(int8_t)gld(lane_s8_byte(il, max_cols, c, begin + j - org));
         return d == -128 ? NINF : base + d;
     };
     const int32_t vstart = (int32_t)gld(vr), vlen = (int32_t)gld(vr + 1);
@@ -262,9 +305,8 @@ MGX_DEV int32_t lane_merge_column(const uint8_t *slots, const uint8_t *s8rows, i
 
 // the lane's record in its scratch slice (lane_read's arec): words 26 .. 31 are counters that outlive a read — columns, rank-type
 // lines, select-type lines, reads finished, extensions, capacity statuses
-MGX_DEV uint32_t *lane_record(const LaneParams &LP, uint8_t *scratch) {
-    return (uint32_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8) + 4 * LFW
-           + 2 * LP.max_cols + LANE_MAX_RUNS;
+MGX_DEV uint32_t *lane_record(const LaneParams &LP, uint8_t *scratch, int32_t lane) {
+    return (uint32_t *)(lane_rest(LP, scratch, lane) + (uint64_t)LP.hash_slots * 8) + 4 * LFW + 2 * LP.max_cols + LANE_MAX_RUNS;
 }
 
 // what lane_read() leaves for lane_emit(): the result record and where the alignment's pieces are
@@ -275,7 +317,8 @@ struct LaneResult {
     uint32_t words;                      // words of the output stream the alignment takes
 };
 
-// One read.  `item`: its position in the launch (tags the node table).  scratch: this lane's LaneParams::scratch slice.
+// One read.  `item`: its position in the launch (tags the node table).  scratch: the wavefront's LaneParams::scratch from this
+// lane's word on (wave base + 4 * chip.lane).
 // Returns LR_DONE (R filled: lane_emit() writes results[read] and the output stream) or LR_BAIL (nothing to write).
 #define b_score LANE_CI(CD_B_SCORE)
 #define b_nod LANE_CI(CD_B_NOD)
@@ -313,14 +356,17 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
     const int32_t k = (int32_t)P.g.k;
     const int32_t go = cfg.gap_open, ge = cfg.gap_ext;
     const int32_t m = LP.self_score;
+#if MGX_LANE_TIMERS
+    ctr.t0 = cycle_clock();
+#endif
     const bool have_rc = cfg.fwd_and_rc != 0;
-    uint8_t *slots = scratch;
-    // The other arrays of the scratch slice are addressed from its base WHERE THEY ARE USED: left to itself the compiler hoists
-    // every one of these address computations out of the column loop and keeps a dozen 64-bit pointers in registers across it.
+    // The arrays of the scratch are addressed from its base WHERE THEY ARE USED: left to itself the compiler hoists every one of
+    // these address computations out of the column loop and keeps a dozen 64-bit pointers in registers across it.
     auto sbase = [&]() -> uint8_t * { uint8_t *b = scratch; LANE_OPAQUE_PTR(b); return b; };
-    auto s8rows = [&]() -> uint8_t * { return sbase() + (uint64_t)LP.max_cols * LANE_SLOT_BYTES; };
-    auto htab = [&]() -> uint64_t * { return (uint64_t *)(sbase() + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES)); };
-    auto save_p = [&]() -> uint32_t * { return (uint32_t *)(sbase() + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8); };
+    auto slots = [&]() -> uint8_t * { return sbase(); };                             // (lane_slot_word / lane_s8_word)
+    auto rest = [&]() -> uint8_t * { return lane_rest(LP, sbase(), chip.lane); };
+    auto htab = [&]() -> uint64_t * { return (uint64_t *)rest(); };
+    auto save_p = [&]() -> uint32_t * { return (uint32_t *)(rest() + (uint64_t)LP.hash_slots * 8); };
     auto save_a = [&]() -> uint32_t * { return save_p() + 2 * LFW; };      // (unused since the parked child lives in a frontier slot)
     auto pa_node = [&]() -> uint32_t * { return save_p() + 4 * LFW; };            // the forward alignment's nodes and character codes,
     auto pa_code = [&]() -> uint32_t * { return pa_node() + LP.max_cols; };       // in path order (the seed of the backward pass)
@@ -507,7 +553,9 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         replay_top = -1; LANE_SET_REPLAY_MATCHING(1); LANE_SET_TIE_MODE(0);
         bool reload = false, ext_over = false;
         int reload_slot = -1;                               // -1: the parent of a fork again; else the frontier slot whose column is the head now
+        LANE_T(0);
         while (!ext_over) {
+            LANE_T(4);
             if (reload) { win_load(reload_slot < 0 ? save_p() : dsave(reload_slot)); reload = false; }
             bool head_dead = false;
             if (n_kids == 0) {
@@ -559,6 +607,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     }
                 }
             }
+            LANE_T(1);
             // the child computed in this iteration (if any)
             int32_t c_alive = 0, c_conv = NINF, c_org = 0, c_trim = 0, c_size = 0, c_max_val = 0, c_idx = 0;
             int32_t c_t_score = INT32_MIN, c_t_nod = 0, c_t_pos = 0;
@@ -590,7 +639,11 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 // m > 0 >= gaps, mismatches <= m, sroot >= 0, 0 <= rel_score_cutoff <= 1: checked before the kernel is launched.)
                 // The vector itself is never needed: a later seed ending in that node, or the graph leading back to it, bails.
                 const bool replay = in_seed && next_offset < k;      // (columns of the seed's first node)
+#if MGX_LANE_PROBE & 1
+                const bool probe = false;
+#else
                 const bool probe = !replay || f_offset == seed_off - 1;
+#endif
                 uint32_t hs = lane_hash(next, hmask);
                 uint64_t he = probe ? gld(htab() + hs) : 0;
                 in.next_offset = next_offset; in.score = 0; in.in_seed = in_seed;
@@ -598,7 +651,9 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 in.partial_sum_offset = 0; in.psum_lin = m; in.psum = nullptr; in.seed_off = seed_off; in.q = nullptr; in.row = nullptr;
                 prof.rowp = ccode == 1 ? LP.t4[0] : ccode == 2 ? LP.t4[1] : ccode == 3 ? LP.t4[2] : LP.t4[3];
                 LaneColumnOut out;
+                LANE_T(3);
                 const int rc = lane_column(in, S, F, out, prof);
+                LANE_T(2);
                 if (rc == LC_FALLBACK) LANE_BAIL(14);
                 const uint32_t table_cap_before = table_cap;
                 if ((uint32_t)tsize == table_cap) table_cap = imax<uint32_t>(1u, 2 * table_cap);
@@ -633,13 +688,18 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         // (the S row: where something may read it — a replay column of the backward pass (merged below), a later
                         // seed's last node — and else not at all; the trace's last cell, if it is in such a column, bails)
                         const bool keep_row = (pass && replay) || ((LANE_CU(CD_S8_FILTER) >> lane_hash(next, 31u)) & 1u);
-                        uint32_t *sl = (uint32_t *)(slots + (uint64_t)my_idx * LANE_SLOT_BYTES);
+                        uint32_t *sl = lane_slot_word(slots(), my_idx, 0);               // (word w: sl + w * LANE_WAVE)
+#if MGX_LANE_PROBE & 2
+                        if (my_idx > 100000)
+#endif
+                        {
 #pragma unroll
-                        for (int b = 0; b < 8; ++b) gst(sl + b, out.fw[b]);
-                        gst(sl + 8, next);
-                        gst(sl + 9, (uint32_t)base);
-                        gst(sl + 10, (uint32_t)begin | ((uint32_t)size << 16) | (ccode << 24) | (keep_row ? LANE_GEOM_ROW : 0u));
-                        gst(sl + 11, (uint32_t)f_idx | ((uint32_t)next_offset << 16));
+                            for (int b = 0; b < 8; ++b) gst(sl + b * LANE_WAVE, out.fw[b]);
+                            gst(sl + 8 * LANE_WAVE, next);
+                            gst(sl + 9 * LANE_WAVE, (uint32_t)base);
+                            gst(sl + 10 * LANE_WAVE, (uint32_t)begin | ((uint32_t)size << 16) | (ccode << 24) | (keep_row ? LANE_GEOM_ROW : 0u));
+                            gst(sl + 11 * LANE_WAVE, (uint32_t)f_idx | ((uint32_t)next_offset << 16));
+                        }
                         if (keep_row) {
                             uint32_t sw[8];
                             bool wide = false;
@@ -656,9 +716,9 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 sw[b] = v;
                             }
                             if (wide) LANE_BAIL(17);
-                            uint32_t *sr = (uint32_t *)(s8rows() + (uint64_t)my_idx * LANE_S8_BYTES);
+                            uint32_t *sr = lane_s8_word(slots(), LP.max_cols, my_idx, 0);
 #pragma unroll
-                            for (int b = 0; b < 8; ++b) gst(sr + b, sw[b]);
+                            for (int b = 0; b < 8; ++b) gst(sr + b * LANE_WAVE, sw[b]);
                         }
                     }
                     tsize = my_idx + 1;
@@ -683,7 +743,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                             int32_t c0 = my_idx;
                             if (!exact_on) { c0 = 1; gst(arec() + 12, 1u); gst(arec() + 14, 0u); }       // (no vector yet:) the columns so far, then this one
                             for (int32_t c = c0; c <= my_idx; ++c)
-                                converged = lane_merge_column(slots, s8rows(), cv, arec() + 13, c, start, cfg.rel_score_cutoff);
+                                converged = lane_merge_column(slots(), LP.max_cols, cv, arec() + 13, c, start, cfg.rel_score_cutoff);
                         }
                         replay_top = probe ? top : imax(replay_top, top);
                     }
@@ -721,6 +781,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     }
                 }
             }
+            LANE_T(3);
             if (!ext_over) {
                 if (compute && forked && kid == 0) {
                     // the first child of a fork waits (window in scratch) while the second is computed from the same parent
@@ -870,6 +931,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 }
             }
         }
+        LANE_T(4);
         // (tie mode: the modelled size caps were never reached in any order of the tied columns — they are monotone in the table's
         // size, and this is its final one)
         if (LANE_TIE_MODE() && ((double)tsize / (double)window_size >= cfg.max_nodes_per_seq_char
@@ -910,10 +972,9 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 if (!node0_merged) {
                     gst(arec() + 13, 0u); gst(arec() + 14, 0u);
                     for (int32_t c = 1; c < tsize; ++c) {
-                        const uint32_t *slc = (const uint32_t *)(slots + (uint64_t)c * LANE_SLOT_BYTES);
-                        if (gld(slc + 8) != node0) break;
-                        if (!(gld(slc + 10) & LANE_GEOM_ROW)) LANE_BAIL(7);
-                        (void)lane_merge_column(slots, s8rows(), cv, arec() + 13, c, start, cfg.rel_score_cutoff);
+                        if (gld(lane_slot_word(slots(), c, 8)) != node0) break;
+                        if (!(gld(lane_slot_word(slots(), c, 10)) & LANE_GEOM_ROW)) LANE_BAIL(7);
+                        (void)lane_merge_column(slots(), LP.max_cols, cv, arec() + 13, c, start, cfg.rel_score_cutoff);
                     }
                     node0_merged = true;
                 }
@@ -931,9 +992,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 hs = (hs + 1) & hmask;
             }
             if (idx < 0) LANE_BAIL(19);                                              // not in the table: the seed lives
-            const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)idx * LANE_SLOT_BYTES);
-            if (gld(sl + 8) != ln) LANE_BAIL(19);                                    // (an entry another launch left behind)
-            const uint32_t geom = gld(sl + 10);
+            if (gld(lane_slot_word(slots(), idx, 8)) != ln) LANE_BAIL(19);           // (an entry another launch left behind)
+            const uint32_t geom = gld(lane_slot_word(slots(), idx, 10));
             const int32_t cbegin = (int32_t)(geom & 0xFFFF), csize = (int32_t)((geom >> 16) & 0xFF);
             const int32_t skip = cbegin ? 0 : 1;
             const int32_t qs = start + cbegin - (cbegin ? 1 : 0), qn = csize - skip;
@@ -942,8 +1002,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             const int32_t a = lpos - start + 1, x = a - (cbegin & ~3);
             int32_t v = NINF;
             if (a - cbegin >= 0 && a - cbegin < csize + 5 && x < LFW) {
-                const int32_t d = (int32_t)(int8_t)gld(s8rows() + (uint64_t)idx * LANE_S8_BYTES + x);
-                if (d != -128) v = (int32_t)gld(sl + 9) + d;
+                const int32_t d = (int32_t)(int8_t)gld(lane_s8_byte(slots(), LP.max_cols, idx, x));
+                if (d != -128) v = (int32_t)gld(lane_slot_word(slots(), idx, 9)) + d;
             }
             if (v < lscore) LANE_BAIL(19);                                           // the seed lives
         }
@@ -975,13 +1035,13 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 chip.runs[(n_runs - 1) * chip.rstride] = cur_run;
             }
         };
-        auto slot_geom = [&](int32_t jj) -> uint32_t { return gld((const uint32_t *)(slots + (uint64_t)jj * LANE_SLOT_BYTES) + 10); };
-        auto slot_link = [&](int32_t jj) -> uint32_t { return gld((const uint32_t *)(slots + (uint64_t)jj * LANE_SLOT_BYTES) + 11); };     // parent | offset << 16
+        auto slot_geom = [&](int32_t jj) -> uint32_t { return gld(lane_slot_word(slots(), jj, 10)); };
+        auto slot_link = [&](int32_t jj) -> uint32_t { return gld(lane_slot_word(slots(), jj, 11)); };     // parent | offset << 16
         auto slot_flags = [&](int32_t jj, uint32_t geom, int32_t p) -> uint32_t {
             const int32_t begin = (int32_t)(geom & 0xFFFF), size = (int32_t)((geom >> 16) & 0xFF);
             const int32_t jx = p - begin, x = p - (begin & ~3);
             if (!(jx >= 0 && jx < size + 5 && x < LFW)) return 0;
-            return gld(slots + (uint64_t)jj * LANE_SLOT_BYTES + x);
+            return gld(lane_slot_flag(slots(), jj, x));
         };
         for (;;) {
             if (!j) break;
@@ -1048,8 +1108,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 cur_cell_score = NINF;
                 if (jx >= 0 && jx < size + 5 && x < LFW) {
                     if (!(geom & LANE_GEOM_ROW)) LANE_BAIL(29);                      // a trace that ends inside a column without its S row
-                    const int32_t v = (int32_t)(int8_t)gld(s8rows() + (uint64_t)j * LANE_S8_BYTES + x);
-                    const int32_t cb = (int32_t)gld((const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES) + 9);
+                    const int32_t v = (int32_t)(int8_t)gld(lane_s8_byte(slots(), LP.max_cols, j, x));
+                    const int32_t cb = (int32_t)gld(lane_slot_word(slots(), j, 9));
                     if (v != -128) cur_cell_score = cb + v;
                 }
             }
@@ -1087,8 +1147,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             {
                 int32_t jj = x_j_hi, ni = x_n_nodes - 1;
                 for (int32_t xx = x_n_seq - 1; xx >= 0; --xx) {
-                    const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)jj * LANE_SLOT_BYTES);
-                    const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
+                    const uint32_t node = gld(lane_slot_word(slots(), jj, 8)), geom = gld(lane_slot_word(slots(), jj, 10)), link = gld(lane_slot_word(slots(), jj, 11));
                     gst(pa_code() + xx, (geom >> 24) & 7u);
                     if ((int32_t)(link >> 16) >= k - 1) { if (ni >= 0) gst(pa_node() + ni, node); --ni; }
                     jj = (int32_t)(link & 0xFFFFu);
@@ -1133,6 +1192,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         }
         } while (0);
     }
+    LANE_T(5);
     {
         ReadResult &rr = R.rr;
         rr.status = ST_OK; rr.n_alignments = 0; rr.score = 0; rr.offset = 0; rr.n_nodes = rr.n_cigar = rr.seq_len = 0;
@@ -1160,6 +1220,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             R.words = (uint32_t)R.n_nodes + (uint32_t)((R.clip ? 1 : 0) + R.n_runs + (R.end_clip ? 1 : 0)) + ((uint32_t)R.n_seq + 3) / 4;
         }
     }
+    LANE_T(6);
     return LR_DONE;
 }
 
@@ -1202,7 +1263,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t *scratch, const LaneChip &chip, LaneResult &R,
                        const uint64_t so) {
     const AlignParams &P = LP.P;
-    const uint8_t *slots = scratch;
+    const uint8_t *slots = scratch;                      // (lane_slot_word)
     ReadResult &rr = R.rr;
     if (R.have_aln) {
         if (so + R.words > P.out_capacity) {
@@ -1220,15 +1281,14 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
                 // reaches k - 1 (minus the leading ones trim_offset dropped)
                 int32_t j = R.j_hi, ni = R.n_nodes - 1;
                 for (int32_t x = R.n_seq - 1; x >= 0; --x) {
-                    const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES);
-                    const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
+                    const uint32_t node = gld(lane_slot_word(slots, j, 8)), geom = gld(lane_slot_word(slots, j, 10)), link = gld(lane_slot_word(slots, j, 11));
                     gst(dseq + x, decode_code((geom >> 24) & 7u));
                     if ((int32_t)(link >> 16) >= k_minus_1) { if (ni >= 0) gst(dst + ni, node); --ni; }
                     j = (int32_t)(link & 0xFFFFu);
                 }
             } else if (R.mode == LANE_EMIT_ARRAYS) {
                 // the forward alignment as the backward pass kept it: path order, runs last first
-                const uint32_t *pn = (const uint32_t *)(scratch + (uint64_t)LP.max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)LP.hash_slots * 8) + 4 * LFW;
+                const uint32_t *pn = (const uint32_t *)(lane_rest(LP, scratch, chip.lane) + (uint64_t)LP.hash_slots * 8) + 4 * LFW;
                 const uint32_t *pc = pn + LP.max_cols, *pr = pc + LP.max_cols;
                 for (int32_t x = R.n_runs - 1; x >= 0; --x) gst(dst + R.n_nodes + nc++, gld(pr + x));
                 for (int32_t x = 0; x < R.n_nodes; ++x) gst(dst + x, gld(pn + x));
@@ -1239,8 +1299,7 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
                 for (int32_t x = 0; x < R.n_runs; ++x) gst(dst + R.n_nodes + nc++, chip.runs[x * chip.rstride]);
                 int32_t j = R.j_hi, ni = 0;
                 for (int32_t x = 0; x < R.n_seq; ++x) {
-                    const uint32_t *sl = (const uint32_t *)(slots + (uint64_t)j * LANE_SLOT_BYTES);
-                    const uint32_t node = gld(sl + 8), geom = gld(sl + 10), link = gld(sl + 11);
+                    const uint32_t node = gld(lane_slot_word(slots, j, 8)), geom = gld(lane_slot_word(slots, j, 10)), link = gld(lane_slot_word(slots, j, 11));
                     gst(dseq + x, decode_code(5u - ((geom >> 24) & 7u)));
                     if ((int32_t)(link >> 16) >= k_minus_1) { if (ni < R.n_nodes) gst(dst + ni, node); ++ni; }
                     j = (int32_t)(link & 0xFFFFu);

@@ -14,20 +14,29 @@ constexpr int LANE_MAX_L = 256;            // longest read a lane takes (packed 
 constexpr int LANE_QWORDS = LANE_MAX_L / 32 + 2;
 constexpr int LANE_MAX_RUNS = 16;          // CIGAR runs of a trace kept in LDS
 constexpr int LANE_MAX_SEEDS = 512;        // seeds of the strand (the later ones are checked against the extension one by one)
-constexpr int LANE_SLOT_BYTES = 64;        // per column: 32 flag bytes + node + base + geometry (+ 4 unused words)
+constexpr int LANE_SLOT_WORDS = 12;        // per column: 8 flag words (32 cells, a byte each) + node + base + geometry + link
+constexpr int LANE_WAVE = 64;              // lanes whose column slots and S rows are interleaved word by word (below)
 constexpr int LANE_MAX_DEFER = 3;          // columns that may stay behind in the frontier (the other children of forks)
 constexpr int LANE_DSLOT_WORDS = 80;       // a column that stays behind: its window (64 words) + nine words of column state
 constexpr uint32_t LANE_GEOM_ROW = 1u << 31;   // in a slot's geometry word: the column's S row was written
 constexpr int LANE_S8_FILTER_SEEDS = 16;   // later seeds whose last nodes select the columns that keep their S row (more: every column does)
-constexpr int LANE_S8_BYTES = 32;          // per column: S of the window as 8-bit offsets from `base` (read at the trace's end only)
+constexpr int LANE_S8_WORDS = 8;           // per column: S of the window as 8-bit offsets from `base` (read at the trace's end only)
 
 // what one launch of the lane kernel needs on top of AlignParams
 struct LaneParams {
     AlignParams P;
     const uint64_t *pk[2];               // 2-bit packed strands (k_pack_reads): word j of read r at packed_word_begin(offsets[r], r) + j
     const uint32_t *iv[2];               // invalid-character flags, same indexing
-    uint8_t *scratch;                    // per resident lane: column slots | S8 rows | node table
-    uint64_t scratch_stride;
+    // Scratch of a resident wavefront (round 6: wave-interleaved).  The 64 lanes of a wavefront step their columns in lock-step —
+    // lane_read() starts every lane at column 1 and each loop iteration commits one — so the column slots and S rows are laid
+    // out [column][word][lane]: the store of "word w of column c" by the 64 lanes is 256 contiguous bytes (four full lines)
+    // where lane-private slices made it 64 partial-line writes 18 KB apart, and the trace's reads of a column's words find
+    // the lanes' words in the same lines.  What is addressed by a lane's own data (the node table) or touched rarely (parked
+    // windows, the forward alignment during a backward pass, counters) stays in a private slice per lane behind them:
+    //   wave w:  [ slots: max_cols x LANE_SLOT_WORDS x 64 words | S rows: max_cols x LANE_S8_WORDS x 64 words | 64 x rest_stride bytes ]
+    uint8_t *scratch;
+    uint64_t wave_stride;                // bytes per wavefront (lane_wave_scratch_bytes)
+    uint64_t rest_stride;                // bytes of a lane's private slice (lane_rest_bytes, rounded to 64)
     uint32_t max_cols;                   // columns a lane's scratch holds (lane_max_cols)
     uint32_t hash_slots;                 // power of two >= 2 * max_cols
     uint32_t tag_seed;                   // changes per launch (node-table entries of earlier launches read as empty)
@@ -45,10 +54,18 @@ inline uint32_t lane_max_cols(uint32_t Lmax, int32_t xdrop) {
     return Lmax + (uint32_t)std::min<int64_t>(Lmax, std::max<int64_t>(xdrop, 0)) + 8;
 }
 
-inline uint64_t lane_scratch_bytes(uint32_t max_cols, uint32_t hash_slots) {
-    return (uint64_t)max_cols * (LANE_SLOT_BYTES + LANE_S8_BYTES) + (uint64_t)hash_slots * 8 + 2 * 2 * 32 * 4      // + two parked windows (S, F of 32 cells)
-           + (uint64_t)max_cols * 8 + LANE_MAX_RUNS * 4 + 32 * 4 + (uint64_t)(LANE_MAX_L + 8) * 4       // ... and the merged vector of a replayed node
-           + (uint64_t)LANE_MAX_DEFER * LANE_DSLOT_WORDS * 4;      // + the columns that stayed behind in the frontier      // + the forward alignment while the backward pass runs (nodes, characters, CIGAR runs), the result's scalars
+// a lane's private slice: node table | two parked windows (S, F of 32 cells each; one unused) | the forward alignment while the
+// backward pass runs (nodes, character codes, CIGAR runs) | the result's scalars and counters | the merged vector of a replayed
+// node | the columns that stayed behind in the frontier
+inline uint64_t lane_rest_bytes(uint32_t max_cols, uint32_t hash_slots) {
+    return (uint64_t)hash_slots * 8 + 2 * 2 * 32 * 4
+           + (uint64_t)max_cols * 8 + LANE_MAX_RUNS * 4 + 32 * 4 + (uint64_t)(LANE_MAX_L + 8) * 4
+           + (uint64_t)LANE_MAX_DEFER * LANE_DSLOT_WORDS * 4;
+}
+inline uint64_t lane_slots_bytes(uint32_t max_cols) { return (uint64_t)max_cols * LANE_SLOT_WORDS * LANE_WAVE * 4; }
+inline uint64_t lane_s8_bytes(uint32_t max_cols) { return (uint64_t)max_cols * LANE_S8_WORDS * LANE_WAVE * 4; }
+inline uint64_t lane_wave_scratch_bytes(uint32_t max_cols, uint64_t rest_stride) {
+    return lane_slots_bytes(max_cols) + lane_s8_bytes(max_cols) + (uint64_t)LANE_WAVE * rest_stride;
 }
 
 

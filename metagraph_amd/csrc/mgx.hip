@@ -381,7 +381,7 @@ struct mgx_graph {
     mutable std::mutex label_mu;
     mutable DevBuf canon_repr;        // CANONICAL-mode graphs: node -> the representative of its k-mer (k_canon_repr, 4 B per node)
     mutable bool canon_repr_ready = false;
-    mutable std::map<std::tuple<const void *, const void *, uint64_t>, bool> dummy_clean;   // per annotation (handle, matrix, rows)
+    mutable std::map<uint64_t, bool> dummy_clean;   // per annotation, by its process-unique id (mgx_annotation_uid: never reused, unlike the handle's address)
 };
 
 extern "C" int mgx_launch_align_grp8(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);    // mgx_grp.hip, MGX_GROUP=8
@@ -407,6 +407,7 @@ extern "C" int mgx_lab64_waves_per_simd(void);
 extern "C" int mgx_lab64_max_alt(void);
 extern "C" void mgx_annotation_device_view(const mgx_annotation *a, int *device, uint64_t *n_rows, const uint64_t **head,
                                            const uint32_t **count, const uint32_t **more);                    // mgx_annot.hip
+extern "C" uint64_t mgx_annotation_uid(const mgx_annotation *a);                                            // mgx_annot.hip
 extern "C" int mgx_lane_waves_per_simd(void);
 extern "C" unsigned mgx_ext64_static_lds(void);
 extern "C" int mgx_ext64_waves_per_simd(void);
@@ -475,6 +476,16 @@ struct mgx_aligner {
     uint32_t label_scale = 1;          // the label arenas' multiplier (derive_limits; doubled per attempt of the capacity retry)
     const char *last_d_seqs = nullptr;           // the batch mgx_align_batch_device ran last (device pointers)
     const uint64_t *last_d_offsets = nullptr;
+    // Every launch, asynchronous copy and hipcub call of this aligner goes to this stream, and its blocking copies synchronise
+    // this stream only (copy_sync).  0 = the legacy default stream (what rounds 1-5 used throughout): ordered with everything
+    // else the process does on blocking streams.  mgx_aligner_set_stream() gives a handle its own stream, so that the handles
+    // of several worker threads on one device (cli/align.cpp:440-475: one aligner per thread-pool task) overlap instead of
+    // serialising on the default stream.
+    hipStream_t hstream = nullptr;
+    bool own_stream = false;           // mgx_aligner_create_stream: destroyed with the aligner
+    uint64_t stage_generation = 0;               // counts stage_batch calls (mgx_map_batch re-stages the same buffers) ...
+    uint64_t aligned_generation = 0;             // ... and which of them mgx_align_batch_device aligned: post-chaining and the
+                                                 // capacity retry read the batch back only while it is still the staged one
     std::vector<uint64_t> m_node_begin, m_fwd, m_rc;
     mgx_stats hstats;
     hipEvent_t ev[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -498,6 +509,8 @@ struct mgx_aligner {
         int primary_alt_build = 0;
         int lane = -1;            // the lane-per-read kernel in front of the extension kernel: -1 auto, 0 off, 1 forced
         int seed_wps = 8;         // wavefronts per SIMD of the short-read seeding kernel: 8 (64 VGPRs, spills) or 4 (102 VGPRs, tables in LDS)
+        int device_share = 1;     // handles expected to run on this device at the same time (worker threads, -p N): the per-slot
+                                  // arenas of this handle are sized for 1 / device_share of the machine instead of all of it
         int map_pipe = 1;         // k_map as the request / response machine (map_pipe.hpp): 1 = for batches of >= 65536 chains, 2 = always,
                                   // 0 = never (one chain step per lane and iteration: rounds 1-4)
     } opt;
@@ -797,7 +810,7 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
         int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;
         mgx_annotation_device_view(anno, &adev, &arows, &h, &c, &m);
         std::lock_guard<std::mutex> lock(g->label_mu);
-        const auto key = std::make_tuple((const void *)anno, (const void *)h, arows);
+        const uint64_t key = mgx_annotation_uid(anno);
         auto it = g->dummy_clean.find(key);
         if (it == g->dummy_clean.end()) {
             uint32_t *d_flag = nullptr, flag = 1;
@@ -839,7 +852,10 @@ int mgx_labeled_aligner_create(const mgx_graph *g, const mgx_config *config, con
 
 void mgx_aligner_destroy(mgx_aligner *a) {
     if (!a) return;
+    (void)hipSetDevice(a->graph->device);
+    (void)hipStreamSynchronize(a->hstream);
     for (auto &e : a->ev) if (e) (void)hipEventDestroy(e);
+    if (a->own_stream) (void)hipStreamDestroy(a->hstream);
     delete a;
 }
 
@@ -855,10 +871,17 @@ int mgx_aligner_get_limits(const mgx_aligner *a, mgx_limits *out) {
     return MGX_OK;
 }
 
+// a blocking copy that synchronises the aligner's stream only (hipMemcpy would synchronise the whole device's default stream)
+static hipError_t copy_sync(mgx_aligner *A, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    if (hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, A->hstream)) return e;
+    return hipStreamSynchronize(A->hstream);
+}
+
 // stage inputs, compute k-mer slot offsets and Lmax on the device
 static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uint64_t n, int on_device,
                        const char **d_seqs, const uint64_t **d_offsets, uint32_t *Lmax_out) {
     const uint32_t k = A->graph->g.k;
+    ++A->stage_generation;
     if (on_device) {
         *d_seqs = seqs;
         *d_offsets = offsets;
@@ -866,25 +889,25 @@ static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets
         uint64_t total = offsets[n];
         if (int rc = A->seqs.ensure(total + 16)) return rc;
         if (int rc = A->offsets.ensure((n + 1) * 8)) return rc;
-        HIP_TRY(hipMemcpyAsync(A->seqs.p, seqs, total, hipMemcpyHostToDevice, 0));
-        HIP_TRY(hipMemcpyAsync(A->offsets.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, 0));
+        HIP_TRY(hipMemcpyAsync(A->seqs.p, seqs, total, hipMemcpyHostToDevice, A->hstream));
+        HIP_TRY(hipMemcpyAsync(A->offsets.p, offsets, (n + 1) * 8, hipMemcpyHostToDevice, A->hstream));
         *d_seqs = A->seqs.as<char>();
         *d_offsets = A->offsets.as<uint64_t>();
     }
     if (int rc = A->counts.ensure((n + 2) * 8)) return rc;
     if (int rc = A->node_begin.ensure((n + 2) * 8)) return rc;
     unsigned long long *cur = A->cursors.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(cur, 0, 64, 0));
-    k_kmer_counts<<<(uint32_t)((n + 1 + 255) / 256), 256>>>(*d_offsets, n, k, A->counts.as<uint64_t>(), cur + 2);
+    HIP_TRY(hipMemsetAsync(cur, 0, 64, A->hstream));
+    k_kmer_counts<<<(uint32_t)((n + 1 + 255) / 256), 256, 0, A->hstream>>>(*d_offsets, n, k, A->counts.as<uint64_t>(), cur + 2);
     HIP_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, A->counts.as<uint64_t>(), A->node_begin.as<uint64_t>(), (int)(n + 1)));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, A->counts.as<uint64_t>(), A->node_begin.as<uint64_t>(), (int)(n + 1), A->hstream));
     if (int rc = A->scan_tmp.ensure(tmp_bytes + 16)) return rc;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(A->scan_tmp.p, tmp_bytes, A->counts.as<uint64_t>(), A->node_begin.as<uint64_t>(), (int)(n + 1)));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(A->scan_tmp.p, tmp_bytes, A->counts.as<uint64_t>(), A->node_begin.as<uint64_t>(), (int)(n + 1), A->hstream));
     uint64_t total_kmers = 0;
     unsigned long long lmax = 0;
-    HIP_TRY(hipMemcpy(&total_kmers, A->node_begin.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&lmax, cur + 2, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(A, &total_kmers, A->node_begin.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(A, &lmax, cur + 2, 8, hipMemcpyDeviceToHost));
     A->total_kmers = total_kmers;
     A->n_reads = n;
     *Lmax_out = (uint32_t)lmax;
@@ -908,22 +931,22 @@ static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets
 
 static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, bool do_rc, bool mapped, uint32_t Lmax) {
     // k_map's counters live in their own block: a re-run of the alignment stage (stream overflow) resets only its own
-    HIP_TRY(hipMemsetAsync(A->d_stats_map.p, 0, sizeof(KernelStats), 0));
-    HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), 0));
+    HIP_TRY(hipMemsetAsync(A->d_stats_map.p, 0, sizeof(KernelStats), A->hstream));
+    HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), A->hstream));
     A->packed_valid = false;
     if (!mapped) {
         // max_seed_length < k: nodes are not mapped (dbg_aligner.cpp:209-213)
-        HIP_TRY(hipMemsetAsync(A->nodes_fwd.p, 0, (A->total_kmers + 1) * 4, 0));
-        HIP_TRY(hipMemsetAsync(A->nodes_rc.p, 0, (A->total_kmers + 1) * 4, 0));
-        HIP_TRY(hipMemsetAsync(A->mlen_fwd.p, 0xFF, A->total_kmers + 1, 0));
-        HIP_TRY(hipMemsetAsync(A->mlen_rc.p, 0xFF, A->total_kmers + 1, 0));
+        HIP_TRY(hipMemsetAsync(A->nodes_fwd.p, 0, (A->total_kmers + 1) * 4, A->hstream));
+        HIP_TRY(hipMemsetAsync(A->nodes_rc.p, 0, (A->total_kmers + 1) * 4, A->hstream));
+        HIP_TRY(hipMemsetAsync(A->mlen_fwd.p, 0xFF, A->total_kmers + 1, A->hstream));
+        HIP_TRY(hipMemsetAsync(A->mlen_rc.p, 0xFF, A->total_kmers + 1, A->hstream));
         return MGX_OK;
     }
     unsigned long long *map_cursor = A->cursors.as<unsigned long long>() + 4;
-    HIP_TRY(hipMemsetAsync(map_cursor, 0, 8, 0));
-    HIP_TRY(hipMemsetAsync(A->mlen_fwd.p, 0xFF, A->total_kmers + 1, 0));       // MLEN_UNKNOWN
-    if (do_rc) HIP_TRY(hipMemsetAsync(A->mlen_rc.p, 0xFF, A->total_kmers + 1, 0));
-    HIP_TRY(hipEventRecord(A->ev[0], 0));
+    HIP_TRY(hipMemsetAsync(map_cursor, 0, 8, A->hstream));
+    HIP_TRY(hipMemsetAsync(A->mlen_fwd.p, 0xFF, A->total_kmers + 1, A->hstream));       // MLEN_UNKNOWN
+    if (do_rc) HIP_TRY(hipMemsetAsync(A->mlen_rc.p, 0xFF, A->total_kmers + 1, A->hstream));
+    HIP_TRY(hipEventRecord(A->ev[0], A->hstream));
     {
         // persistent lanes: enough wavefronts to fill the device, never more lanes than chains
         hipDeviceProp_t prop;
@@ -940,7 +963,7 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
             if (do_rc) { if (int rc = A->pk_rc.ensure(words * 8)) return rc; if (int rc = A->iv_rc.ensure(words * 4)) return rc; }
             const uint32_t wpr = (Lmax + 31) / 32;
             const uint64_t threads = n * wpr;
-            k_pack_reads<<<(uint32_t)((threads + 255) / 256), 256>>>(d_seqs, d_offsets, n, wpr, do_rc ? 1 : 0, A->pk_fwd.as<uint64_t>(),
+            k_pack_reads<<<(uint32_t)((threads + 255) / 256), 256, 0, A->hstream>>>(d_seqs, d_offsets, n, wpr, do_rc ? 1 : 0, A->pk_fwd.as<uint64_t>(),
                                                                     A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>());
             HIP_TRY(hipGetLastError());
             A->packed_valid = true;
@@ -957,9 +980,9 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
                 ma.min_rng_len = (int32_t)std::min<uint64_t>(A->cfg.min_seed_length, 1u << 20);
                 ma.n_reads = n; ma.do_rc = do_rc ? 1 : 0; ma.cursor = map_cursor;
                 const uint64_t pblocks = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)prop.multiProcessorCount * MGX_MAP_PIPE_WAVES, (chains + 255) / 256));
-                k_map_pipe<<<(uint32_t)pblocks, 256>>>(A->graph->g, ma, A->d_stats_map.as<KernelStats>());
+                k_map_pipe<<<(uint32_t)pblocks, 256, 0, A->hstream>>>(A->graph->g, ma, A->d_stats_map.as<KernelStats>());
             } else
-            k_map_packed<<<(uint32_t)blocks, 256>>>(A->graph->g, d_offsets, A->node_begin.as<uint64_t>(),
+            k_map_packed<<<(uint32_t)blocks, 256, 0, A->hstream>>>(A->graph->g, d_offsets, A->node_begin.as<uint64_t>(),
                                          A->pk_fwd.as<uint64_t>(), A->pk_rc.as<uint64_t>(), A->iv_fwd.as<uint32_t>(), A->iv_rc.as<uint32_t>(),
                                          A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(),
                                          A->mlen_fwd.as<uint8_t>(), A->mlen_rc.as<uint8_t>(),
@@ -967,7 +990,7 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
                                          (int)std::min<uint64_t>(A->cfg.min_seed_length, 1u << 20), n, do_rc ? 1 : 0,
                                          map_cursor, A->d_stats_map.as<KernelStats>());
         } else {
-            k_map<<<(uint32_t)blocks, 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
+            k_map<<<(uint32_t)blocks, 256, 0, A->hstream>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
                                          A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(),
                                          A->mlen_fwd.as<uint8_t>(), A->mlen_rc.as<uint8_t>(),
                                          A->have_rng ? A->rng_fwd.as<uint2>() : nullptr, A->have_rng ? A->rng_rc.as<uint2>() : nullptr,
@@ -977,11 +1000,11 @@ static int run_map(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets
     }
     HIP_TRY(hipGetLastError());
     if (A->graph->mode == MGX_MODE_PRIMARY && do_rc && n) {
-        k_canon_merge<<<(uint32_t)std::min<uint64_t>((n + 3) / 4, 65536), 256>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
+        k_canon_merge<<<(uint32_t)std::min<uint64_t>((n + 3) / 4, 65536), 256, 0, A->hstream>>>(A->graph->g, d_seqs, d_offsets, A->node_begin.as<uint64_t>(),
                                                                              A->nodes_fwd.as<uint32_t>(), A->nodes_rc.as<uint32_t>(), n);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipEventRecord(A->ev[1], 0));
+    HIP_TRY(hipEventRecord(A->ev[1], A->hstream));
     return MGX_OK;
 }
 
@@ -1015,10 +1038,12 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     if (lane_ok) {
         LP.max_cols = lane_max_cols(l.Lmax, A->dcfg.xdrop);
         LP.hash_slots = next_pow2(2ull * LP.max_cols);
-        LP.scratch_stride = (lane_scratch_bytes(LP.max_cols, LP.hash_slots) + 63) & ~63ull;
+        if (const char *hm = getenv("MGX_LANE_HASH_MULT")) LP.hash_slots *= (uint32_t)std::max(1, atoi(hm));      // (measurement only)
+        LP.rest_stride = (lane_rest_bytes(LP.max_cols, LP.hash_slots) + 63) & ~63ull;
+        LP.wave_stride = lane_wave_scratch_bytes(LP.max_cols, LP.rest_stride);
         const size_t before = A->lane_scratch.bytes;
-        if (A->lane_scratch.ensure((size_t)lane_blocks * 64 * LP.scratch_stride, true) != MGX_OK) lane_ok = false;      // (no room: the group kernel alone)
-        else if (A->lane_scratch.bytes != before) HIP_TRY(hipMemsetAsync(A->lane_scratch.p, 0, A->lane_scratch.bytes, 0));    // node tables start empty
+        if (A->lane_scratch.ensure((size_t)lane_blocks * LP.wave_stride, true) != MGX_OK) lane_ok = false;      // (no room: the group kernel alone)
+        else if (A->lane_scratch.bytes != before) HIP_TRY(hipMemsetAsync(A->lane_scratch.p, 0, A->lane_scratch.bytes, A->hstream));    // node tables start empty
     }
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1045,7 +1070,11 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     const uint64_t need_later = later > held ? later - held : 0;
     const uint64_t avail = (uint64_t)free_b + A->arena.bytes;             // a growing arena frees its old block first
     uint64_t budget = avail > need_later ? (avail - need_later) / 10 * 9 : avail / 2;
-    uint64_t slots = std::min<uint64_t>(std::min<uint64_t>(want_slots, std::max<uint64_t>(n, 1)), std::max<uint64_t>(1, budget / stride));
+    // (device_share: this handle is one of several at work on the device — each gets its share of the slots the machine can keep
+    // resident and of the memory, instead of the first handles taking all of it and the later ones what is left)
+    const uint64_t share = (uint64_t)std::max(1, A->opt.device_share);
+    budget /= share;
+    uint64_t slots = std::min<uint64_t>(std::min<uint64_t>((want_slots + share - 1) / share, std::max<uint64_t>(n, 1)), std::max<uint64_t>(1, budget / stride));
     if (slots == 0) slots = 1;
     {
         // The hash tables of the convergence checker are cleared by generation tags that persist in each slice,
@@ -1053,7 +1082,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         const size_t before = A->arena.bytes;
         if (int rc = A->arena.ensure(slots * stride, true)) return rc;
         if (A->arena.bytes != before || A->arena_stride != stride) {
-            HIP_TRY(hipMemsetAsync(A->arena.p, 0, A->arena.bytes, 0));
+            HIP_TRY(hipMemsetAsync(A->arena.p, 0, A->arena.bytes, A->hstream));
             A->arena_stride = stride;
         }
     }
@@ -1069,11 +1098,11 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     A->out_words = out_words;
     if (A->keep_seeds) {
         if (int rc = A->dbg_seeds.ensure(n * 2 * (uint64_t)l.max_seeds * sizeof(DevSeed))) return rc;
-        HIP_TRY(hipMemsetAsync(A->dbg_seeds.p, 0, n * 2 * (uint64_t)l.max_seeds * sizeof(DevSeed), 0));
+        HIP_TRY(hipMemsetAsync(A->dbg_seeds.p, 0, n * 2 * (uint64_t)l.max_seeds * sizeof(DevSeed), A->hstream));
     }
     unsigned long long *cur = A->cursors.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(cur, 0, 32, 0));
-    HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), 0));     // counters of this run of the stage only
+    HIP_TRY(hipMemsetAsync(cur, 0, 32, A->hstream));
+    HIP_TRY(hipMemsetAsync(A->d_stats.p, 0, sizeof(KernelStats), A->hstream));     // counters of this run of the stage only
     AlignParams P;
     memset(&P, 0, sizeof(P));
     P.g = A->graph->g;
@@ -1135,7 +1164,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         if (int rc = A->order.ensure(n * 4)) return rc;
         if (int rc = A->retry_list.ensure(n * 4 + 4)) return rc;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp_bytes, A->work_key.as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
-                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, work_key_bits(n), (hipStream_t)0));
+                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, work_key_bits(n), A->hstream));
         if (int rc = A->sort_tmp.ensure(sort_tmp_bytes)) return rc;
         P.seed_hdr = A->seed_hdr.as<SeedHdr>();
         P.seed_stream = A->seed_stream.as<DevSeed>();
@@ -1143,7 +1172,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
         P.seed_cursor = cur + 2;
         P.work_key = A->work_key.as<uint32_t>();
     }
-    HIP_TRY(hipEventRecord(A->ev[2], 0));
+    HIP_TRY(hipEventRecord(A->ev[2], A->hstream));
     // latency-critical scalar arrays go to LDS when they fit next to the other resident waves of the CU
     // per-wavefront share of the CU's 160 KB minus the kernel's static LDS (control block, sdust scratch, score rows);
     // overshooting by a few bytes costs a whole resident wavefront per CU
@@ -1193,7 +1222,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                 const uint32_t lds64 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), (160u * 1024u) / wcu64 - mgx_lab64_static_lds() - 128u) & ~15u;
                 P.groups_per_wave = 1;
                 A->kernels_ran |= MGX_KERNEL_LAB64;
-                return mgx_launch_lab64(&P, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(slots, resident64)), lds64, nullptr);
+                return mgx_launch_lab64(&P, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(slots, resident64)), lds64, A->hstream);
             }
             const uint32_t wcu = 4u * (uint32_t)mgx_grp_waves_per_simd8_lab();
             const uint32_t per_wave_l = (160u * 1024u) / wcu - mgx_grp_static_lds8_lab() - 64u;
@@ -1201,7 +1230,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             const int gpw_opt = A->opt.groups_per_wave;
             P.groups_per_wave = gpw_opt > 0 ? (uint32_t)std::min(8, gpw_opt) : 0u;
             A->kernels_ran |= MGX_KERNEL_GRP8_LAB;
-            return mgx_launch_align_grp8_lab(&P, (uint32_t)slots, per_group_l, phase, nullptr);
+            return mgx_launch_align_grp8_lab(&P, (uint32_t)slots, per_group_l, phase, A->hstream);
         }
         const bool ext64 = A->opt.ext64 != 0;
         if (ext64 && phase == PH_EXTEND && P.groups_per_wave == 1) {
@@ -1209,11 +1238,11 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             const uint32_t lds64 = std::min<uint32_t>(fast_lds_bytes(l.Lmax), (160u * 1024u) / wcu - mgx_ext64_static_lds() - 128u) & ~15u;
             A->kernels_ran |= MGX_KERNEL_EXT64;
             ++g_kernel_launches[3];
-            return mgx_launch_ext64(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), lds64, nullptr);
+            return mgx_launch_ext64(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), lds64, A->hstream);
         }
         A->kernels_ran |= alt ? MGX_KERNEL_GRP8_ALT : prim ? MGX_KERNEL_GRP8_PRIM : MGX_KERNEL_GRP8;
         ++g_kernel_launches[alt ? 2 : prim ? 1 : 0];
-        return (alt ? mgx_launch_align_grp8_alt : prim ? mgx_launch_align_grp8_prim : mgx_launch_align_grp8)(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), per_group, phase, nullptr);      // never more groups than arena slices (a partial wavefront is fine: the kernel returns for slot >= n_groups)
+        return (alt ? mgx_launch_align_grp8_alt : prim ? mgx_launch_align_grp8_prim : mgx_launch_align_grp8)(&P, (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(1, slots * pct / 100)), per_group, phase, A->hstream);      // never more groups than arena slices (a partial wavefront is fine: the kernel returns for slot >= n_groups)
     };
     A->split_ran = split;
     A->kernels_ran = 0;
@@ -1228,27 +1257,27 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             lds8 = std::min<uint32_t>(lds8, probe_env_u32("MGX_SEED_LDS_CAP", lds8)) & ~15u;     // tuning probe
             if (probe_env_set("MGX_SEED_LDS_PRINT")) fprintf(stderr, "k_seed: static_lds %u budget8 %u lds8 %u (fast_lds_bytes %u)\n", static_lds, budget8, lds8, fast_lds_bytes(l.Lmax));
             if (A->dcfg.canonical >= 2) {
-                if (int rc = mgx_launch_seed_primary(&P, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, lds8, 1, nullptr))
+                if (int rc = mgx_launch_seed_primary(&P, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS, lds8, 1, A->hstream))
                     return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
             } else {
                 // tuning probe: MGX_SEED_WAVES_PCT=50 launches half the resident wavefronts (is the kernel bound by what each
                 // wavefront waits for, or by what all of them move?)
                 const uint32_t spct = probe_env_pct("MGX_SEED_WAVES_PCT");
-                k_align<PH_SEED, MGX_SEED_WPS><<<std::max(1u, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS * spct / 100), 64, lds8>>>(P, lds8);
+                k_align<PH_SEED, MGX_SEED_WPS><<<std::max(1u, (uint32_t)prop.multiProcessorCount * 4 * MGX_SEED_WPS * spct / 100), 64, lds8, A->hstream>>>(P, lds8);
             }
         } else if (A->dcfg.canonical >= 2) {
-            if (int rc = mgx_launch_seed_primary(&P, w_slots, lds_bytes, 0, nullptr)) return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
+            if (int rc = mgx_launch_seed_primary(&P, w_slots, lds_bytes, 0, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "seeding kernel (PRIMARY): %d", rc);
         } else {
-            k_align<PH_SEED><<<w_slots, 64, lds_bytes>>>(P, lds_bytes);
+            k_align<PH_SEED><<<w_slots, 64, lds_bytes, A->hstream>>>(P, lds_bytes);
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(A->ev[4], 0));
-        k_iota<<<(uint32_t)((n + 255) / 256), 256>>>(A->order_in.as<uint32_t>(), n);
+        HIP_TRY(hipEventRecord(A->ev[4], A->hstream));
+        k_iota<<<(uint32_t)((n + 255) / 256), 256, 0, A->hstream>>>(A->order_in.as<uint32_t>(), n);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, sort_tmp_bytes, A->work_key.as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
-                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, work_key_bits(n), (hipStream_t)0));
-        HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));                      // rewind the read cursor
+                                                   A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)n, 0, work_key_bits(n), A->hstream));
+        HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));                      // rewind the read cursor
         P.order = A->order.as<uint32_t>();
-        HIP_TRY(hipEventRecord(A->ev[5], 0));
+        HIP_TRY(hipEventRecord(A->ev[5], A->hstream));
         // Passes.  MGX_MULTI_PASS=1 (default when a batch carries many seeds per read, see below): a pass extends at most
         // one seed per read; reads with live seeds left write a resume record and are re-sorted by the work of their next
         // seed for the next pass (AlignParams::resume_*).  Reads of a wavefront then differ by one extension at most,
@@ -1260,21 +1289,21 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             // automatic: worth it when reads run many extensions, i.e. carry many seeds (sub-k seeds of a pan-genome: ~100 per
             // read; a plain read: a handful).  The seeding kernel has finished counting them by now.
             unsigned long long seeds_total = 0;
-            HIP_TRY(hipMemcpy(&seeds_total, cur + 2, 8, hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(A, &seeds_total, cur + 2, 8, hipMemcpyDeviceToHost));
             multi = n > 0 && seeds_total / n >= 24;
         }
         A->n_passes = 1;
         A->lane_done = 0;
         memset(A->lane_hist_h, 0, sizeof(A->lane_hist_h));
-        HIP_TRY(hipEventRecord(A->ev[6], 0));
+        HIP_TRY(hipEventRecord(A->ev[6], A->hstream));
         bool nothing_left = false;
         if (lane_ok && !multi && n) {
             // every read through the lane kernel first, in the sorted order; what it lists goes on to the group kernel below
             if (int rc = A->lane_bail.ensure(n * 4 + 4)) return rc;
             if (int rc = A->lane_params.ensure(sizeof(LaneParams))) return rc;
-            if (int rc = A->lane_hist.ensure(32 * 8)) return rc;
-            HIP_TRY(hipMemsetAsync(A->lane_hist.p, 0, 32 * 8, 0));
-            HIP_TRY(hipMemsetAsync(cur + 5, 0, 16, 0));
+            if (int rc = A->lane_hist.ensure(64 * 8)) return rc;          // ([32 .. 63]: section timers of -DMGX_LANE_TIMERS builds)
+            HIP_TRY(hipMemsetAsync(A->lane_hist.p, 0, 64 * 8, A->hstream));
+            HIP_TRY(hipMemsetAsync(cur + 5, 0, 16, A->hstream));
             LP.P = P;
             LP.P.n_items = n;
             LP.pk[0] = A->pk_fwd.as<uint64_t>(); LP.pk[1] = A->pk_rc.as<uint64_t>();
@@ -1285,17 +1314,26 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             LP.bail_count = cur + 5;
             LP.done_count = cur + 6;
             LP.bail_hist = A->lane_hist.as<unsigned long long>();
-            HIP_TRY(hipMemcpy(A->lane_params.p, &LP, sizeof(LP), hipMemcpyHostToDevice));
-            const uint32_t blocks = (uint32_t)std::min<uint64_t>(lane_blocks, (n + 63) / 64);
-            if (int rc = mgx_launch_lane(A->lane_params.p, blocks, nullptr)) return fail(MGX_ERR_NO_DEVICE, "lane kernel: %d", rc);
+            HIP_TRY(copy_sync(A, A->lane_params.p, &LP, sizeof(LP), hipMemcpyHostToDevice));
+            uint32_t blocks = (uint32_t)std::min<uint64_t>(lane_blocks, (n + 63) / 64);
+            // (measurement only: MGX_LANE_BLOCKS_PCT < 100 launches that share of the resident wavefronts — is the kernel bound by
+            // the latency of its own dependent accesses, or by what the memory system serves per second?)
+            if (const char *pct = getenv("MGX_LANE_BLOCKS_PCT")) blocks = std::max<uint32_t>(1u, (uint32_t)((uint64_t)blocks * (uint64_t)atoi(pct) / 100));
+            if (int rc = mgx_launch_lane(A->lane_params.p, blocks, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane kernel: %d", rc);
             A->kernels_ran |= MGX_KERNEL_LANE;
             ++g_kernel_launches[4];
-            HIP_TRY(hipEventRecord(A->ev[6], 0));
+            HIP_TRY(hipEventRecord(A->ev[6], A->hstream));
             unsigned long long counts[2] = { 0, 0 };
-            HIP_TRY(hipMemcpy(counts, cur + 5, 16, hipMemcpyDeviceToHost));     // (synchronises with the kernel)
+            HIP_TRY(copy_sync(A, counts, cur + 5, 16, hipMemcpyDeviceToHost));     // (synchronises with the kernel)
             A->lane_done = counts[1];
-            HIP_TRY(hipMemcpy(A->lane_hist_h, A->lane_hist.p, 32 * 8, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));                          // rewind the read cursor
+            HIP_TRY(copy_sync(A, A->lane_hist_h, A->lane_hist.p, 32 * 8, hipMemcpyDeviceToHost));
+            if (getenv("MGX_LANE_TIMERS")) {
+                unsigned long long t[16];
+                HIP_TRY(copy_sync(A, t, A->lane_hist.as<unsigned long long>() + 32, sizeof(t), hipMemcpyDeviceToHost));
+                fprintf(stderr, "k_lane timers (cycles of lane 0, summed over %u wavefronts): setup %llu children %llu column %llu commit %llu frontier %llu trace %llu result %llu | emit %llu kernel %llu\n",
+                        blocks, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[8], t[9]);
+            }
+            HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));                          // rewind the read cursor
             P.order = A->lane_bail.as<uint32_t>();
             P.n_items = counts[0];
             nothing_left = counts[0] == 0;
@@ -1331,17 +1369,17 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                     P.seed_limit = pass < 8 ? 1 : pass < 16 ? 4 : pass < 24 ? 16 : 0;
                     HIP_TRY((hipError_t)launch_groups(PH_EXTEND));
                     unsigned long long c = 0;
-                    HIP_TRY(hipMemcpy(&c, cur + 3, 8, hipMemcpyDeviceToHost));     // (synchronises with the pass)
+                    HIP_TRY(copy_sync(A, &c, cur + 3, 8, hipMemcpyDeviceToHost));     // (synchronises with the pass)
                     c = std::min<unsigned long long>(c, cap);
                     A->n_passes = pass + 1;
                     if (c == 0 || P.seed_limit == 0) break;
                     // next pass: the retry positions of this one, sorted by their work key
-                    k_iota<<<(uint32_t)((c + 255) / 256), 256>>>(A->order_in.as<uint32_t>(), c);
+                    k_iota<<<(uint32_t)((c + 255) / 256), 256, 0, A->hstream>>>(A->order_in.as<uint32_t>(), c);
                     size_t tmp_bytes = sort_tmp_bytes;
                     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, tmp_bytes, A->retry_key[out].as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
-                                                               A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)c, 0, 12, (hipStream_t)0));
-                    HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));              // rewind the read cursor
-                    HIP_TRY(hipMemsetAsync(cur + 3, 0, 8, 0));              // and the retry counter
+                                                               A->order_in.as<uint32_t>(), A->order.as<uint32_t>(), (int)c, 0, 12, A->hstream));
+                    HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));              // rewind the read cursor
+                    HIP_TRY(hipMemsetAsync(cur + 3, 0, 8, A->hstream));              // and the retry counter
                     P.order = A->order.as<uint32_t>();
                     P.n_items = c;
                     P.resume_in = A->resume_pool[out].as<uint8_t>();
@@ -1360,7 +1398,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                     P.retry_list = A->retry_list.as<uint32_t>();
                     P.retry_count = cur + 3;
                 } else if (two_pass) {
-                    HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, 0));              // rewind the read cursor
+                    HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));              // rewind the read cursor
                     P.seed_limit = 0;
                     P.order = A->retry_list.as<uint32_t>();
                     P.n_items_ptr = cur + 3;
@@ -1369,15 +1407,15 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             }
         }
     }
-    HIP_TRY(hipEventRecord(A->ev[3], 0));
+    HIP_TRY(hipEventRecord(A->ev[3], A->hstream));
     return MGX_OK;
 }
 
 static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(A->hstream));
     KernelStats ks, km;
-    HIP_TRY(hipMemcpy(&ks, A->d_stats.p, sizeof(ks), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&km, A->d_stats_map.p, sizeof(km), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(A, &ks, A->d_stats.p, sizeof(ks), hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(A, &km, A->d_stats_map.p, sizeof(km), hipMemcpyDeviceToHost));
     ks.rank_lines += km.rank_lines; ks.select_lines += km.select_lines; ks.bit_lines += km.bit_lines; ks.map_lines += km.map_lines;
     mgx_stats &s = A->hstats;
     memset(&s, 0, sizeof(s));
@@ -1412,11 +1450,11 @@ int mgx_map_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uin
     if (int rc = run_map(A, d_seqs, d_offsets, n, true, true, Lmax)) return rc;
     if (int rc = collect_stats(A, true, false)) return rc;
     A->m_node_begin.resize(n + 1);
-    HIP_TRY(hipMemcpy(A->m_node_begin.data(), A->node_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(copy_sync(A, A->m_node_begin.data(), A->node_begin.p, (n + 1) * 8, hipMemcpyDeviceToHost));
     std::vector<uint32_t> f(A->total_kmers), r(A->total_kmers);
     if (A->total_kmers) {
-        HIP_TRY(hipMemcpy(f.data(), A->nodes_fwd.p, A->total_kmers * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(r.data(), A->nodes_rc.p, A->total_kmers * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(A, f.data(), A->nodes_fwd.p, A->total_kmers * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(A, r.data(), A->nodes_rc.p, A->total_kmers * 4, hipMemcpyDeviceToHost));
     }
     A->m_fwd.assign(f.begin(), f.end());
     A->m_rc.assign(r.begin(), r.end());
@@ -1426,6 +1464,25 @@ int mgx_map_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uin
     out->nodes_rc = A->m_rc.data();
     return MGX_OK;
 }
+
+int mgx_aligner_set_stream(mgx_aligner *A, void *hip_stream) {
+    if (!A) return fail(MGX_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(A->graph->device));
+    HIP_TRY(hipStreamSynchronize(A->hstream));              // what the handle has in flight finishes where it was issued
+    if (A->own_stream) { (void)hipStreamDestroy(A->hstream); A->own_stream = false; }
+    A->hstream = (hipStream_t)hip_stream;
+    return MGX_OK;
+}
+int mgx_aligner_create_stream(mgx_aligner *A) {
+    if (!A) return fail(MGX_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(A->graph->device));
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (int rc = mgx_aligner_set_stream(A, st)) { (void)hipStreamDestroy(st); return rc; }
+    A->own_stream = true;
+    return MGX_OK;
+}
+void *mgx_aligner_get_stream(const mgx_aligner *A) { return A ? (void *)A->hstream : nullptr; }
 
 int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
     if (!A) return fail(MGX_ERR_INVALID, "null argument");
@@ -1447,6 +1504,7 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
         else if (key == "no_flat") o.no_flat = v;
         else if (key == "primary_alt_build") o.primary_alt_build = v;
         else if (key == "lane") o.lane = v;
+        else if (key == "device_share") o.device_share = std::max(1, std::min(v, 64));
         else if (key == "map_pipe") o.map_pipe = v;
         else if (key == "seed_wps") o.seed_wps = v;
         else if (key == "retry_capacity") A->retry_capacity = v != 0;
@@ -1478,7 +1536,7 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
     const char *d_seqs; const uint64_t *d_offsets; uint32_t Lmax;
     if (n == 0) { A->n_reads = 0; return MGX_OK; }
     { HostStageTimer t("stage_batch"); if (int rc = stage_batch(A, seqs, offsets, n, on_device, &d_seqs, &d_offsets, &Lmax)) return rc; }
-    A->last_d_seqs = d_seqs; A->last_d_offsets = d_offsets;
+    A->last_d_seqs = d_seqs; A->last_d_offsets = d_offsets; A->aligned_generation = A->stage_generation;
     bool mapped = A->cfg.max_seed_length >= A->graph->g.k;
     { HostStageTimer t("run_map"); if (int rc = run_map(A, d_seqs, d_offsets, n, A->dcfg.fwd_and_rc != 0, mapped, Lmax)) return rc; }
     for (;;) {
@@ -1487,11 +1545,11 @@ int mgx_align_batch_device(mgx_aligner *A, const char *seqs, const uint64_t *off
         // both streams keep counting past their capacity: reads that found no room got a capacity status and the
         // stage is redone with what it asked for
         unsigned long long out_wanted = 0, seeds_wanted = 0;
-        HIP_TRY(hipMemcpy(&out_wanted, A->cursors.as<unsigned long long>(), 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(A, &out_wanted, A->cursors.as<unsigned long long>(), 8, hipMemcpyDeviceToHost));
         bool again = false;
         if (out_wanted > A->out_words) { A->out_min_words = out_wanted + out_wanted / 8 + 1024; again = true; }
         if (A->split_ran) {
-            HIP_TRY(hipMemcpy(&seeds_wanted, A->cursors.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost));
+            HIP_TRY(copy_sync(A, &seeds_wanted, A->cursors.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost));
             if (seeds_wanted > A->seed_cap) {
                 A->seed_scale = seeds_wanted / std::max<uint64_t>(1, A->seed_cap / A->seed_scale) + 2;
                 again = true;
@@ -1512,25 +1570,40 @@ int mgx_fetch_results(mgx_aligner *A, mgx_results *out) {
     A->h_results.resize(n);
     unsigned long long used = 0;
     if (n) {
-        HIP_TRY(hipMemcpy(A->h_results.data(), A->results.p, n * sizeof(ReadResult), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&used, A->cursors.p, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(A, A->h_results.data(), A->results.p, n * sizeof(ReadResult), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(A, &used, A->cursors.p, 8, hipMemcpyDeviceToHost));
         used = std::min<unsigned long long>(used, A->out_words);
     }
     A->h_stream.resize(used);
-    if (used) HIP_TRY(hipMemcpy(A->h_stream.data(), A->stream.p, used * 4, hipMemcpyDeviceToHost));
+    if (used) HIP_TRY(copy_sync(A, A->h_stream.data(), A->stream.p, used * 4, hipMemcpyDeviceToHost));
     A->host.decode(A->h_results.data(), n, A->h_stream.data(), ~0ull, A->anno != nullptr);
     A->host.view(out);
+    // the aligned batch is read back below (post-chaining, the capacity retry): only while the staging buffers still hold it —
+    // mgx_map_batch on this aligner re-stages them; a caller's device buffers are the caller's to keep until the fetch
+    const bool batch_intact = A->aligned_generation == A->stage_generation && A->last_d_seqs && A->last_d_offsets;
     if (A->cfg.post_chain_alignments && n) {
-        // chain_alignments (dbg_aligner.cpp:328-332) on the host: needs the reads once more (a few bytes per alignment kept)
-        std::vector<uint64_t> offs(n + 1);
-        HIP_TRY(hipMemcpy(offs.data(), A->last_d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
-        std::vector<char> reads(offs[n] + 1);
-        if (offs[n]) HIP_TRY(hipMemcpy(reads.data(), A->last_d_seqs, offs[n], hipMemcpyDeviceToHost));
+        // chain_alignments (dbg_aligner.cpp:328-332) on the host: needs the reads of the queries with two or more alignments once
+        // more — one transfer of the span of the batch that holds them (none at all when no query has two)
+        uint64_t q_lo = n, q_hi = 0;
+        for (uint64_t q = 0; q < n; ++q) if (out->aln_begin[q + 1] - out->aln_begin[q] >= 2) { q_lo = std::min(q_lo, q); q_hi = q + 1; }
+        if (!batch_intact)
+            return fail(MGX_ERR_INVALID, "post_chain_alignments: another batch was staged on this aligner between mgx_align_batch_device and mgx_fetch_results");
+        std::vector<uint64_t> offs(n + 1, 0);
+        HIP_TRY(copy_sync(A, offs.data(), A->last_d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
+        std::vector<char> reads(1);
+        uint64_t b0 = 0;
+        if (q_lo < q_hi) {
+            b0 = offs[q_lo];
+            const uint64_t b1 = offs[q_hi];
+            reads.resize(b1 - b0 + 1);
+            if (b1 > b0) HIP_TRY(copy_sync(A, reads.data(), A->last_d_seqs + b0, b1 - b0, hipMemcpyDeviceToHost));
+        }
         mgx_results plain = *out;
-        chain_results(plain, reads.data(), offs.data(), A->cfg, A->graph->g.k, &A->host_chained);
+        chain_results(plain, reads.data(), offs.data(), A->cfg, A->graph->g.k, &A->host_chained, b0);
         A->host_chained.view(out);
     }
     // reads the batch's limits were too small for: once more, with larger ones (below)
+    if (!batch_intact) return MGX_OK;              // (statuses stay: the reads are no longer where they were)
     return retry_capacity_queries(A, A->last_d_seqs, A->last_d_offsets, n, out);
 }
 
@@ -1538,7 +1611,7 @@ int mgx_device_results(mgx_aligner *A, const void **headers, uint64_t *header_by
                        const void **stream, uint64_t *stream_words) {
     if (!A) return fail(MGX_ERR_INVALID, "null argument");
     unsigned long long used = 0;
-    if (A->n_reads) HIP_TRY(hipMemcpy(&used, A->cursors.p, 8, hipMemcpyDeviceToHost));
+    if (A->n_reads) HIP_TRY(copy_sync(A, &used, A->cursors.p, 8, hipMemcpyDeviceToHost));
     used = std::min<unsigned long long>(used, A->out_words);
     *headers = A->results.p; *header_bytes = sizeof(ReadResult); *n_queries = A->n_reads;
     *stream = A->stream.p; *stream_words = used;
@@ -1590,37 +1663,21 @@ int mgx_chain_alignments(const mgx_config *config, uint32_t k, const mgx_results
 // alignments per backtracking, aggregator pool, label queues, label sets; derive_limits' label_scale.)
 static int retry_capacity_queries(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offsets, uint64_t n, mgx_results *out) {
     std::vector<uint64_t> todo;
-    for (uint64_t q = 0; q < n; ++q) if (out->status[q] == MGX_ERR_CAPACITY) todo.push_back(q);
+    // (a query whose post_chain_alignments queue overflowed is flagged by the kernel — RR_CAUSE_QUEUE — and stays a status: no
+    // limit cures it, and six rounds of ever larger arenas would be paid for nothing)
+    for (uint64_t q = 0; q < n; ++q)
+        if (out->status[q] == MGX_ERR_CAPACITY && !(q < A->h_results.size() && A->h_results[q].orientation == RR_CAUSE_QUEUE)) todo.push_back(q);
     if (todo.empty() || !A->retry_capacity || !d_seqs || !d_offsets) return MGX_OK;
-    // the reads in question, from the batch as the device holds it (the caller's buffers, or the upload of a host batch): a few
-    // of them one by one, a large share of the batch in one copy
+    // the reads in question, from the batch as the device holds it (the caller's buffers, or the upload of a host batch): ONE
+    // transfer of the span of the batch between the first and the last of them
     std::vector<uint64_t> h_off(n + 1);
-    HIP_TRY(hipMemcpy(h_off.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
-    std::vector<char> h_seq;
-    std::vector<uint64_t> offsets_v(n + 1, 0);
-    const char *seqs;
-    const uint64_t *offsets;
-    if (todo.size() * 64 < n) {
-        uint64_t total = 0;
-        for (uint64_t q : todo) total += h_off[q + 1] - h_off[q];
-        h_seq.resize(total + 1);
-        uint64_t at = 0;
-        for (uint64_t q = 0, t = 0; q < n; ++q) {                 // offsets over the compacted bytes: empty except for the reads to redo
-            offsets_v[q] = at;
-            if (t < todo.size() && todo[t] == q) {
-                const uint64_t len = h_off[q + 1] - h_off[q];
-                if (len) HIP_TRY(hipMemcpy(h_seq.data() + at, d_seqs + h_off[q], len, hipMemcpyDeviceToHost));
-                at += len;
-                ++t;
-            }
-        }
-        offsets_v[n] = at;
-        seqs = h_seq.data(); offsets = offsets_v.data();
-    } else {
-        h_seq.resize(h_off[n] + 1);
-        if (h_off[n]) HIP_TRY(hipMemcpy(h_seq.data(), d_seqs, h_off[n], hipMemcpyDeviceToHost));
-        seqs = h_seq.data(); offsets = h_off.data();
-    }
+    HIP_TRY(copy_sync(A, h_off.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost));
+    const uint64_t b0 = h_off[todo.front()], b1 = h_off[todo.back() + 1];
+    std::vector<char> h_seq(b1 - b0 + 1);
+    if (b1 > b0) HIP_TRY(copy_sync(A, h_seq.data(), d_seqs + b0, b1 - b0, hipMemcpyDeviceToHost));
+    const char *seqs = h_seq.data();
+    auto seq_of = [&](uint64_t q) { return seqs + (h_off[q] - b0); };
+    const uint64_t *offsets = h_off.data();
     // results so far, query by query (replaced below)
     std::vector<HostResults> fixed(todo.size());
     std::vector<uint8_t> have(todo.size(), 0);
@@ -1636,22 +1693,29 @@ static int retry_capacity_queries(mgx_aligner *A, const char *d_seqs, const uint
         lim.max_seeds = std::min<uint32_t>(65535u, lim.max_seeds * 2);
         lim.cell_arena_bytes = lim.cell_arena_bytes * 2;
         if (tmp) { mgx_aligner_destroy(tmp); tmp = nullptr; }
-        if (int rc = aligner_create(A->graph, &A->cfg, &lim, A->anno, &tmp)) return rc;
+        // (an attempt that fails — out of memory at the inflated limits, say — ends the retry: what the batch and the earlier
+        // attempts produced stays valid and is what the caller gets, statuses included)
+        if (aligner_create(A->graph, &A->cfg, &lim, A->anno, &tmp) != MGX_OK) break;
         tmp->opt = A->opt; tmp->mode = A->mode; tmp->no_fast = A->no_fast;
+        tmp->hstream = A->hstream;                        // (borrowed: the retry runs where the batch ran)
         tmp->retry_capacity = false;
         tmp->label_scale = 2u << attempt;
         std::string blob;
         std::vector<uint64_t> offs(pending.size() + 1, 0);
         for (size_t t = 0; t < pending.size(); ++t) {
             const uint64_t q = todo[pending[t]];
-            blob.append(seqs + offsets[q], offsets[q + 1] - offsets[q]);
+            blob.append(seq_of(q), offsets[q + 1] - offsets[q]);
             offs[t + 1] = blob.size();
         }
         mgx_results sub{};
-        if (int rc = mgx_align_batch(tmp, blob.data(), offs.data(), pending.size(), 0, &sub)) return rc;
+        if (mgx_align_batch(tmp, blob.data(), offs.data(), pending.size(), 0, &sub) != MGX_OK) break;
         std::vector<uint64_t> again;
         for (size_t t = 0; t < pending.size(); ++t) {
-            if (sub.status[t] == MGX_ERR_CAPACITY) { again.push_back(pending[t]); continue; }
+            if (sub.status[t] == MGX_ERR_CAPACITY) {
+                // (its queue overflowed this time: final)
+                if (!(t < tmp->h_results.size() && tmp->h_results[t].orientation == RR_CAUSE_QUEUE)) again.push_back(pending[t]);
+                continue;
+            }
             fixed[pending[t]].append_query(sub, t);
             have[pending[t]] = 1;
         }
@@ -1690,7 +1754,7 @@ int mgx_fetch_seed_info(mgx_aligner *A, uint32_t *info6, uint32_t *seeds /* [n][
     const uint64_t n = A->n_reads;
     if (A->h_results.size() != n || n == 0) {
         A->h_results.resize(n);
-        if (n) HIP_TRY(hipMemcpy(A->h_results.data(), A->results.p, n * sizeof(ReadResult), hipMemcpyDeviceToHost));
+        if (n) HIP_TRY(copy_sync(A, A->h_results.data(), A->results.p, n * sizeof(ReadResult), hipMemcpyDeviceToHost));
     }
     for (uint64_t i = 0; i < n; ++i) {
         const ReadResult &r = A->h_results[i];
@@ -1701,7 +1765,7 @@ int mgx_fetch_seed_info(mgx_aligner *A, uint32_t *info6, uint32_t *seeds /* [n][
     if (max_seeds_out) *max_seeds_out = A->lim.max_seeds;
     if (seeds && A->keep_seeds && n) {
         std::vector<DevSeed> h(n * 2 * (uint64_t)A->lim.max_seeds);
-        HIP_TRY(hipMemcpy(h.data(), A->dbg_seeds.p, h.size() * sizeof(DevSeed), hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(A, h.data(), A->dbg_seeds.p, h.size() * sizeof(DevSeed), hipMemcpyDeviceToHost));
         for (size_t x = 0; x < h.size(); ++x) {
             seeds[4 * x] = h[x].clipping; seeds[4 * x + 1] = h[x].length; seeds[4 * x + 2] = h[x].offset;
             seeds[4 * x + 3] = h[x].offset ? h[x].node : h[x].n_nodes;

@@ -17,6 +17,7 @@
 // get_rows(rows[n]) -> CSR (begin[n + 1], labels[]): count kernel, scan, gather kernel — dependent random accesses only to
 // head[] (8 B per row) and, for multi-label rows, one run of more[].
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hipcub/hipcub.hpp>
 #include <cstdarg>
 #include <cstdio>
@@ -153,7 +154,13 @@ __global__ void k_pairs_fill(const uint64_t *keys, uint64_t n_pairs, uint64_t n_
 }
 } // namespace
 
+// every annotation object gets an id no other one of this process ever had: what is cached about an annotation elsewhere (the
+// per-graph "no dummy node's row holds a label" flag, mgx.hip) is keyed by it — pointers come back from malloc / hipMalloc after
+// a destroy + create and would hand a new annotation the old one's entry
+static std::atomic<uint64_t> g_annotation_uid{0};
+
 struct mgx_annotation {
+    const uint64_t uid = ++g_annotation_uid;
     int device = 0;
     uint64_t n_rows = 0;
     uint32_t n_labels = 0;
@@ -319,6 +326,7 @@ extern "C" void mgx_annotation_device_view(const mgx_annotation *a, int *device,
                                            const uint32_t **count, const uint32_t **more) {
     *device = a->device; *n_rows = a->n_rows; *head = a->head; *count = a->count; *more = a->more;
 }
+extern "C" uint64_t mgx_annotation_uid(const mgx_annotation *a) { return a ? a->uid : 0; }
 
 /* BinaryMatrix::get_rows(rows) (annotation/binary_matrix/base/binary_matrix.hpp; ColumnMajor: column_major.cpp:27-44) for a
  * whole batch of rows — the ONE call of AnnotationBuffer::fetch_queued_annotations (annotation_buffer.cpp:182) — answered

@@ -6,8 +6,9 @@
 // the same number of columns), runs lane_read() on them — the column loop is where the lanes spend their time; a lane whose read
 // ends or bails early idles until its 63 wave-mates are through — hands out the output-stream words of the whole wavefront with
 // ONE atomic, and writes results.  Per-lane state: the DP window (32 S + 32 F cells) and the bookkeeping of one extension in
-// VGPRs; the packed query and the CIGAR runs of the trace in LDS (word-major, conflict free); column slots, S rows and the node
-// table in a private slice of HBM scratch.
+// VGPRs; the packed query and the CIGAR runs of the trace in LDS (word-major, conflict free); column slots and S rows in the
+// wavefront's HBM scratch, interleaved over its lanes (the lanes commit their columns in lock-step: full-line stores); the node
+// table in a private slice per lane.
 #include <hip/hip_runtime.h>
 
 #define mgx mgx_lane_ns
@@ -29,16 +30,22 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
     __shared__ uint32_t s_runs[LANE_MAX_RUNS][64];
     __shared__ uint32_t s_cold[LANE_COLD_WORDS][64];
     const int lane = (int)threadIdx.x;
-    const uint64_t slot = (uint64_t)blockIdx.x * 64 + (uint64_t)lane;
-    uint8_t *scratch = LP.scratch + slot * LP.scratch_stride;
+    // the wavefront's scratch from this lane's word on (layout: LaneParams — column slots and S rows interleaved over the lanes)
+    uint8_t *scratch = LP.scratch + (uint64_t)blockIdx.x * LP.wave_stride + 4u * (uint32_t)lane;
     LaneChip chip;
+    chip.lane = lane;
     chip.qw = &s_qw[0][lane]; chip.qstride = 64;
     chip.runs = &s_runs[0][lane]; chip.rstride = 64;
     chip.cold = &s_cold[0][lane]; chip.cstride = 64;
     const uint64_t n_items = LP.P.n_items ? LP.P.n_items : LP.P.n_reads;
-    LaneCounters ctr = { 0 };
+    LaneCounters ctr;
+    memset(&ctr, 0, sizeof(ctr));
+#if MGX_LANE_TIMERS
+    const uint64_t t_kernel = cycle_clock();
+    uint64_t t_emit = 0;
+#endif
     {
-        uint32_t *rec = lane_record(LP, scratch);
+        uint32_t *rec = lane_record(LP, scratch, lane);
         for (int x = 26; x < 32; ++x) gst(rec + x, 0u);
     }
     // Every lane holds one read at a time: a new one from the sorted order, or — after LR_AGAIN — the same one for its backward
@@ -78,12 +85,18 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
         sv.v = 0;
         if (lane == 0 && total) sv.v = atomicAdd(LP.P.out_cursor, (unsigned long long)total);
         const uint64_t so = wave_bcast(sv, 0) + (uint64_t)pre.v;
+#if MGX_LANE_TIMERS
+        const uint64_t te0 = cycle_clock();
+#endif
         if (done) {
             lane_emit(LP, read, scratch, chip, R, so);
-            uint32_t *rec = lane_record(LP, scratch);
+            uint32_t *rec = lane_record(LP, scratch, lane);
             gst(rec + 29, gld(rec + 29) + 1u); gst(rec + 30, gld(rec + 30) + R.rr.n_extensions);
             gst(rec + 31, gld(rec + 31) + (uint32_t)(R.rr.status != ST_OK));
         }
+#if MGX_LANE_TIMERS
+        t_emit += cycle_clock() - te0;
+#endif
         // the reads for the group kernel, in processing order
         LV<bool> bl;
         bl.v = bail;
@@ -109,7 +122,7 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
         }
     }
     // counters: one atomic per wavefront and counter
-    const uint32_t *rec = lane_record(LP, scratch);
+    const uint32_t *rec = lane_record(LP, scratch, lane);
     LV<int32_t> v;
     v.v = (int32_t)gld(rec + 27); const int32_t rl = wave_sum(v);
     v.v = (int32_t)gld(rec + 28); const int32_t sl = wave_sum(v);
@@ -117,6 +130,14 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
     v.v = (int32_t)gld(rec + 29); const int32_t nd = wave_sum(v);
     v.v = (int32_t)gld(rec + 30); const int32_t ne = wave_sum(v);
     v.v = (int32_t)gld(rec + 31); const int32_t nc = wave_sum(v);
+#if MGX_LANE_TIMERS
+    // (bail_hist[32 .. 39]: the sections of lane_read(), [40] lane_emit, [41] the kernel: cycles of lane 0 of every wavefront)
+    if (lane == 0) {
+        for (int x = 0; x < 8; ++x) atomicAdd(LP.bail_hist + 32 + x, (unsigned long long)ctr.t[x]);
+        atomicAdd(LP.bail_hist + 40, (unsigned long long)t_emit);
+        atomicAdd(LP.bail_hist + 41, (unsigned long long)(cycle_clock() - t_kernel));
+    }
+#endif
     if (lane == 0) {
         atomicAdd(&LP.P.stats->rank_lines, (unsigned long long)rl);
         atomicAdd(&LP.P.stats->select_lines, (unsigned long long)sl);
@@ -130,7 +151,7 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
     }
 }
 
-// blocks = resident wavefronts (each lane owns scratch slice blockIdx * 64 + lane)
+// blocks = resident wavefronts (wavefront b owns LaneParams::scratch + b * wave_stride)
 // d_params: the LaneParams of this launch in device memory
 extern "C" int mgx_launch_lane(const void *d_params, uint32_t blocks, void *stream) {
     k_lane<<<blocks, 64, 0, (hipStream_t)stream>>>(static_cast<const LaneParams *>(d_params));

@@ -196,6 +196,7 @@ class HipDBGAligner : public IDBGAligner {
         if (int rc = mgx_aligner_create(graph.handle(), &config, limits, &a_))
             throw std::runtime_error(std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")");
         mgx_aligner_get_config(a_, &config_);
+        own_stream();
     }
     // LabeledAligner<>(graph, config, annotator): every alignment of the results carries its label_columns
     HipDBGAligner(const HipBOSSGraph &graph, const DBGAlignerConfig &config, const HipAnnotation &annotation,
@@ -204,6 +205,12 @@ class HipDBGAligner : public IDBGAligner {
         if (int rc = mgx_labeled_aligner_create(graph.handle(), &config, limits, annotation.handle(), &a_))
             throw std::runtime_error(std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")");
         mgx_aligner_get_config(a_, &config_);
+        own_stream();
+    }
+    // `workers` aligners are at work on this device at the same time (cli/align.cpp's thread pool): each sizes its arenas for its share
+    void set_device_share(unsigned workers) {
+        const std::string opt = "device_share=" + std::to_string(workers ? workers : 1);
+        mgx_aligner_set_pipeline(a_, opt.c_str());
     }
     ~HipDBGAligner() override { mgx_aligner_destroy(a_); }
     const HipBOSSGraph &get_graph() const override { return graph_; }
@@ -211,69 +218,58 @@ class HipDBGAligner : public IDBGAligner {
     bool has_coordinates() const override { return false; }
 
     void align_batch(const std::vector<Query> &seq_batch, const AlignmentCallback &callback) const override {
-        // results per query; queries whose device arena overflowed (MGX_ERR_CAPACITY status: the reference has no such
-        // limit, it grows on the heap) are re-run by a temporary aligner with doubled limits until they fit
+        // One call: mgx_align_batch itself re-aligns queries whose per-read device arenas overflowed (MGX_ERR_CAPACITY: the
+        // reference has no such limit, its tables grow on the heap) with doubled limits, up to six doublings.  A status that is
+        // left after that is an error of this call, as nothing in the reference's interface could carry it.
         std::vector<AlignmentResults> results;
         results.reserve(seq_batch.size());
         for (const auto &q : seq_batch) results.emplace_back(q.second);
-        std::vector<size_t> todo(seq_batch.size());
-        for (size_t i = 0; i < todo.size(); ++i) todo[i] = i;
-        mgx_aligner *cur = a_;
-        mgx_aligner *tmp = nullptr;
-        struct Guard { mgx_aligner *&p; ~Guard() { if (p) mgx_aligner_destroy(p); } } guard{ tmp };
-        for (int attempt = 0; !todo.empty(); ++attempt) {
-            std::string blob;
-            std::vector<uint64_t> offsets(todo.size() + 1, 0);
-            for (size_t t = 0; t < todo.size(); ++t) {
-                blob += seq_batch[todo[t]].second;
-                offsets[t + 1] = blob.size();
+        std::string blob;
+        std::vector<uint64_t> offsets(seq_batch.size() + 1, 0);
+        for (size_t t = 0; t < seq_batch.size(); ++t) {
+            blob += seq_batch[t].second;
+            offsets[t + 1] = blob.size();
+        }
+        mgx_results res{};
+        if (int rc = mgx_align_batch(a_, blob.data(), offsets.data(), seq_batch.size(), 0, &res))
+            throw std::runtime_error(std::string("mgx_align_batch: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
+        for (size_t t = 0; t < seq_batch.size(); ++t) {
+            if (res.status[t] != MGX_OK)
+                throw std::runtime_error("query " + std::to_string(t) + " (" + seq_batch[t].first + "): status "
+                                         + std::to_string(res.status[t]) + " after the capacity retry of mgx_align_batch");
+            AlignmentResults &paths = results[t];
+            for (uint64_t ai = res.aln_begin[t]; ai < res.aln_begin[t + 1]; ++ai) {
+                const mgx_alignment &m = res.alignments[ai];
+                Alignment a;
+                a.orientation_ = m.orientation;
+                a.offset_ = m.offset;
+                a.score_ = m.score;
+                a.sequence_.assign(res.seqs + m.seq_begin, m.seq_len);
+                a.nodes_.assign(res.nodes + m.nodes_begin, res.nodes + m.nodes_begin + m.n_nodes);
+                for (uint32_t x = 0; x < m.n_cigar; ++x)
+                    a.cigar_.data().emplace_back(res.cigar[m.cigar_begin + x].op, res.cigar[m.cigar_begin + x].len);
+                const std::string &q = paths.get_query(m.orientation);
+                a.query_view_ = std::string_view(q).substr(m.clipping, q.size() - m.clipping - m.end_clipping);
+                if (res.labels && m.n_labels)
+                    a.label_columns_.assign(res.labels + m.labels_begin, res.labels + m.labels_begin + m.n_labels);
+                paths.alignments_.push_back(std::move(a));
             }
-            mgx_results res{};
-            if (int rc = mgx_align_batch(cur, blob.data(), offsets.data(), todo.size(), 0, &res))
-                throw std::runtime_error(std::string("mgx_align_batch: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
-            std::vector<size_t> again;
-            for (size_t t = 0; t < todo.size(); ++t) {
-                if (res.status[t] != MGX_OK) { again.push_back(todo[t]); continue; }
-                AlignmentResults &paths = results[todo[t]];
-                for (uint64_t ai = res.aln_begin[t]; ai < res.aln_begin[t + 1]; ++ai) {
-                    const mgx_alignment &m = res.alignments[ai];
-                    Alignment a;
-                    a.orientation_ = m.orientation;
-                    a.offset_ = m.offset;
-                    a.score_ = m.score;
-                    a.sequence_.assign(res.seqs + m.seq_begin, m.seq_len);
-                    a.nodes_.assign(res.nodes + m.nodes_begin, res.nodes + m.nodes_begin + m.n_nodes);
-                    for (uint32_t x = 0; x < m.n_cigar; ++x)
-                        a.cigar_.data().emplace_back(res.cigar[m.cigar_begin + x].op, res.cigar[m.cigar_begin + x].len);
-                    const std::string &q = paths.get_query(m.orientation);
-                    a.query_view_ = std::string_view(q).substr(m.clipping, q.size() - m.clipping - m.end_clipping);
-                    if (res.labels && m.n_labels)
-                        a.label_columns_.assign(res.labels + m.labels_begin, res.labels + m.labels_begin + m.n_labels);
-                    paths.alignments_.push_back(std::move(a));
-                }
-            }
-            if (again.empty()) break;
-            if (attempt == 6)
-                throw std::runtime_error("query " + std::to_string(again[0]) + ": device arena overflow after 6 doublings of mgx_limits");
-            mgx_limits lim;
-            mgx_aligner_get_limits(cur, &lim);
-            lim.max_query_length = 0;                       // the next (smaller) batch sets its own
-            lim.max_columns = lim.max_columns * 2;
-            lim.max_seeds = std::min<uint32_t>(65535u, lim.max_seeds * 2);
-            lim.cell_arena_bytes = lim.cell_arena_bytes * 2;
-            mgx_aligner *next = nullptr;
-            if (int rc = annotation_ ? mgx_labeled_aligner_create(graph_.handle(), &config_, &lim, annotation_->handle(), &next)
-                                     : mgx_aligner_create(graph_.handle(), &config_, &lim, &next))
-                throw std::runtime_error(std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")");
-            if (tmp) mgx_aligner_destroy(tmp);
-            tmp = next;
-            cur = tmp;
-            todo.swap(again);
         }
         for (size_t i = 0; i < seq_batch.size(); ++i) callback(seq_batch[i].first, std::move(results[i]));
     }
 
   private:
+    // the reference builds one aligner per thread-pool task (cli/align.cpp:440-475): every handle works on a stream of its own, so
+    // that the tasks of one device overlap instead of taking turns on the default stream (batches arrive from host memory: nothing
+    // of the caller's is ordered against it)
+    void own_stream() {
+        if (int rc = mgx_aligner_create_stream(a_)) {
+            const std::string msg = std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")";
+            mgx_aligner_destroy(a_);
+            a_ = nullptr;
+            throw std::runtime_error(msg);
+        }
+    }
     const HipBOSSGraph &graph_;
     const HipAnnotation *annotation_ = nullptr;
     DBGAlignerConfig config_;

@@ -3,6 +3,7 @@
 // SMALL / STAT / FAST state, DNA; the graph's mode is the file's) or a flat BOSS dump (k, n_edges, F[5], W[], last[]).  Usage:
 //   mgx_align GRAPH.{dbg,boss} READS.{fa,fq} [--align-only-forwards] [--align-min-exact-match X] [--align-min-seed-length N]
 //             [-p THREADS] [--query-batch-size BASES] [--canonical | --primary (the dump is a CANONICAL- / PRIMARY-mode graph)]
+//             [--time]        wall time of the align loop on stderr
 //             [--devices D]   in-process multi-GPU: one graph replica per device, whole batches routed round-robin, no collective
 //             [-a ANNOTATION]  label-aware alignment (metagraph align -a: LabeledAligner); every alignment is printed with its
 //                              labels' names (cli/align.cpp:274-281).  ANNOTATION: `.column.annodbg` files written by the
@@ -11,6 +12,7 @@
 //                              count x u64 rows (row = node - 1)
 //                             (the reference's unit of parallelism, cli/align.cpp:440-475: one task per batch)
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -89,6 +91,7 @@ int main(int argc, char **argv) {
     DBGAlignerConfig cfg;
     mgx_config_init_cli(&cfg, k);
     unsigned threads = 1;
+    bool report_time = false;
     uint64_t batch_size = 100000000ull;
     mgx_limits lim;
     bool have_lim = false;
@@ -104,6 +107,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--max-columns") && i + 1 < argc) { lim.max_columns = (uint32_t)atoi(argv[++i]); have_lim = true; }
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, atoi(argv[++i]));
         else if (!strcmp(argv[i], "-a") && i + 1 < argc) anno_paths.push_back(argv[++i]);
+        else if (!strcmp(argv[i], "--time")) report_time = true;            // wall time of the align loop (batches -> results printed) on stderr
         else if (!strcmp(argv[i], "--canonical")) graph_mode = MGX_MODE_CANONICAL;
         else if (!strcmp(argv[i], "--primary")) graph_mode = MGX_MODE_PRIMARY;         // aligned through the CanonicalDBG wrapper
     }
@@ -157,6 +161,7 @@ int main(int argc, char **argv) {
         if (!read_records(argv[2], &all)) { fprintf(stderr, "cannot open %s\n", argv[2]); return 1; }
         // batches by bases read (align.cpp:431-442: a record is added while the running total is <= batch_size)
         std::vector<std::vector<IDBGAligner::Query>> batches;
+        const size_t n_queries = all.size();
         for (size_t i = 0; i < all.size();) {
             std::vector<IDBGAligner::Query> b;
             uint64_t bytes = 0;
@@ -177,6 +182,8 @@ int main(int argc, char **argv) {
                         ? new HipDBGAligner(graph, cfg, *annotation, have_lim ? &lim : nullptr)
                         : new HipDBGAligner(graph, cfg, have_lim ? &lim : nullptr));
                     HipDBGAligner &aligner = *aligner_p;
+                    // (the workers of one device share it: every handle on its own stream, its arenas sized for its share)
+                    aligner.set_device_share((threads + (unsigned)devices - 1) / (unsigned)devices);
                     aligner.align_batch(batches[bi], [&](const std::string &header, AlignmentResults &&paths) {
                         const std::string res = format_alignment(header, paths, cfg.min_path_score, annotation ? &label_names : nullptr);
                         std::lock_guard<std::mutex> lock(print_mutex);
@@ -188,10 +195,16 @@ int main(int argc, char **argv) {
                 if (first_error.empty()) first_error = e.what();
             }
         };
+        const auto t_align0 = std::chrono::steady_clock::now();
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker, t);
         worker(0);
         for (auto &t : pool) t.join();
+        if (report_time) {
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align0).count();
+            fprintf(stderr, "mgx_align: %zu queries in %zu batches, %u worker(s), %.3f s in the align loop (%.0f queries/s)\n",
+                    n_queries, batches.size(), threads, sec, sec > 0 ? (double)n_queries / sec : 0.0);
+        }
         if (!first_error.empty()) { fprintf(stderr, "error: %s\n", first_error.c_str()); return 1; }
     } catch (const std::exception &e) {
         fprintf(stderr, "error: %s\n", e.what());

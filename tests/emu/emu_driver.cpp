@@ -475,27 +475,32 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
                 LP.pk[0] = pkf.data(); LP.pk[1] = pkr.data(); LP.iv[0] = ivf.data(); LP.iv[1] = ivr.data();
                 LP.max_cols = lane_max_cols(R->lim.Lmax, dcfg.xdrop);
                 LP.hash_slots = 4; while (LP.hash_slots < 2 * LP.max_cols) LP.hash_slots *= 2;
-                LP.scratch_stride = lane_scratch_bytes(LP.max_cols, LP.hash_slots);
-                std::vector<uint8_t> scratch(LP.scratch_stride, 0);
-                LP.scratch = scratch.data();
+                // one wavefront's scratch (column slots and S rows interleaved over 64 lanes, as on the device); read i runs as
+                // lane i % 64 of it, so that the interleaved addressing is what the CPU suite exercises
+                LP.rest_stride = (lane_rest_bytes(LP.max_cols, LP.hash_slots) + 63) & ~63ull;
+                LP.wave_stride = lane_wave_scratch_bytes(LP.max_cols, LP.rest_stride);
+                std::vector<uint8_t> scratch_v(LP.wave_stride, 0);
+                LP.scratch = scratch_v.data();
                 LP.tag_seed = 12345;
                 std::vector<uint64_t> qw(LANE_QWORDS);
                 std::vector<uint32_t> runs(LANE_MAX_RUNS);
                 std::vector<uint32_t> cold(LANE_COLD_WORDS);
-                LaneChip chip = { qw.data(), 1, runs.data(), 1, cold.data(), 1 };
+                LaneChip chip = { 0, qw.data(), 1, runs.data(), 1, cold.data(), 1 };
                 R->lane_reason.assign(n, 0);
                 for (uint64_t i = 0; i < n; ++i) {
                     LaneCounters lc = { 0 };
-                    uint32_t *lrec = lane_record(LP, scratch.data());
+                    chip.lane = (int32_t)(i % LANE_WAVE);
+                    uint8_t *scratch = LP.scratch + 4 * chip.lane;
+                    uint32_t *lrec = lane_record(LP, scratch, chip.lane);
                     lrec[27] = 0; lrec[28] = 0;
                     LaneResult LR;
                     memset(&LR, 0, sizeof(LR));
-                    int lrc = lane_read(LP, order[i], (uint32_t)i, 0, scratch.data(), chip, lc, LR);
-                    if (lrc == LR_AGAIN) lrc = lane_read(LP, order[i], (uint32_t)i, 1, scratch.data(), chip, lc, LR);
+                    int lrc = lane_read(LP, order[i], (uint32_t)i, 0, scratch, chip, lc, LR);
+                    if (lrc == LR_AGAIN) lrc = lane_read(LP, order[i], (uint32_t)i, 1, scratch, chip, lc, LR);
                     if (lrc == LR_DONE) {
                         const uint64_t so = cursors[0];
                         cursors[0] += LR.words;
-                        lane_emit(LP, order[i], scratch.data(), chip, LR, so);
+                        lane_emit(LP, order[i], scratch, chip, LR, so);
                         R->stats.columns += LR.rr.n_columns; R->stats.fast_columns += LR.rr.n_columns; R->stats.extensions += LR.rr.n_extensions;
                         R->stats.capacity_errors += LR.rr.status != ST_OK;
                         ++R->lane_done;

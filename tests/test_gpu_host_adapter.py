@@ -107,3 +107,49 @@ def test_mgx_align_driver_on_a_canonical_graph(tmp_path):
             assert lines[i] == want
         if line5:
             assert lines[5] == line5
+
+
+def test_mgx_align_workers_share_one_device(tmp_path):
+    """cli/align.cpp:440-475: one aligner per thread-pool task, `-p N` tasks at a time on ONE device.  Every handle works on a
+    stream of its own (mgx_aligner_create_stream) and sizes its arenas for its share of the device (device_share=N), so four
+    workers neither take turns on the default stream nor starve each other of arena slots: the same lines as one worker, and
+    the align loop is not slower than with one worker (the bound is loose — the measured ratio on a 4 M-read file is in
+    profiles/r06_workers_one_device.txt)."""
+    import random
+    import re
+    from test_emu_vs_oracle import rand_seq, mutate, rc
+    rng = random.Random(4242)
+    k, genome_len, n_reads, read_len = 31, 300_000, 120_000, 150
+    genome = rand_seq(rng, genome_len)
+    g = orc.Graph.build(k, [genome], 0, False)
+    W, last, F, _ = g.export()
+    dump = tmp_path / "g.boss"
+    with open(dump, "wb") as f:
+        f.write(struct.pack("<7Q", g.k, g.n_edges, *[int(x) for x in F]))
+        f.write(W.tobytes())
+        f.write(last.tobytes())
+    fa = tmp_path / "reads.fa"
+    with open(fa, "w") as f:
+        for i in range(n_reads):
+            p = rng.randrange(0, genome_len - read_len)
+            r = mutate(rng, genome[p:p + read_len])
+            if rng.random() < 0.5:
+                r = rc(r)
+            f.write(">r%d\n%s\n" % (i, r))
+    exe = os.path.join(ROOT, "metagraph_amd", "_build", "mgx_align")
+    batch = str(n_reads * read_len // 8)              # eight tasks
+    outs, secs = {}, {}
+    for p in (1, 4, 1, 4):
+        out = tmp_path / ("out_p%d.tsv" % p)
+        with open(out, "w") as fo:
+            r = subprocess.run([exe, str(dump), str(fa), "-p", str(p), "--query-batch-size", batch, "--time"],
+                               stdout=fo, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        m = re.search(r"([0-9.]+) s in the align loop", r.stderr)
+        assert m, r.stderr
+        secs[p] = min(secs.get(p, 1e9), float(m.group(1)))
+        outs[p] = sorted(open(out).read().rstrip("\n").split("\n"))
+    assert len(outs[1]) == n_reads
+    assert outs[4] == outs[1]
+    print("align loop: -p 1 %.3f s, -p 4 %.3f s" % (secs[1], secs[4]))
+    assert secs[4] <= 1.25 * secs[1], secs
