@@ -324,6 +324,10 @@ int mgx_aligner_set_pipeline(mgx_aligner *a, const char *name);
  * serialising on the default stream.  The stream stays the caller's (not destroyed with the aligner); device buffers handed to
  * mgx_align_batch_device / mgx_map_batch must be ready on it.  mgx_aligner_create_stream gives the aligner a non-blocking
  * stream that it owns (destroyed with it) — what host/mgx_align -p N does per worker. */
+/* Device memory of destroyed aligners is kept per device for the next aligner (one aligner per task is the reference's model:
+ * without this every task paid for fresh multi-GB arenas); it is released when an allocation of the library fails and by this
+ * call — for a host that wants the memory back for something else. */
+int mgx_device_trim(int device);
 int mgx_aligner_set_stream(mgx_aligner *a, void *hip_stream);
 int mgx_aligner_create_stream(mgx_aligner *a);
 void *mgx_aligner_get_stream(const mgx_aligner *a);

@@ -352,16 +352,80 @@ static int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                                \
     } while (0)
 
+// Device blocks of destroyed aligners, kept for the next aligner on the same device.  The reference builds one aligner per
+// thread-pool task (cli/align.cpp:440-475); with hipMalloc / hipFree per handle every task paid for fresh multi-GB arenas
+// (first-touch of a new 20 - 40 GB block: seconds, `profiles/r06_workers_one_device.txt`) and every hipFree synchronised the
+// whole device under the other workers.  A block returns here when its aligner is destroyed (its stream has been
+// synchronised by then) and is handed out best-fit; the pool is emptied when an allocation fails and by mgx_device_trim().
+struct DevPool {
+    enum { MAX_DEV = 16 };
+    std::mutex mu;
+    std::multimap<size_t, void *> blocks[MAX_DEV];
+    size_t held[MAX_DEV] = { 0 };
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < MAX_DEV ? d : -1; }
+    void *take(size_t want, size_t *got) {
+        const int d = dev();
+        if (d < 0) return nullptr;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = blocks[d].lower_bound(want);
+        if (it == blocks[d].end() || it->first > want + want / 2 + (1u << 20)) return nullptr;       // (a much larger block stays for who needs it)
+        void *p = it->second;
+        *got = it->first;
+        held[d] -= it->first;
+        blocks[d].erase(it);
+        return p;
+    }
+    void give(void *p, size_t bytes) {
+        const int d = dev();
+        if (d < 0) { (void)hipFree(p); return; }
+        std::lock_guard<std::mutex> lock(mu);
+        blocks[d].emplace(bytes, p);
+        held[d] += bytes;
+    }
+    size_t held_bytes() {
+        const int d = dev();
+        if (d < 0) return 0;
+        std::lock_guard<std::mutex> lock(mu);
+        return held[d];
+    }
+    void flush() {
+        const int d = dev();
+        if (d < 0) return;
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto &e : blocks[d]) (void)hipFree(e.second);
+        blocks[d].clear();
+        held[d] = 0;
+    }
+};
+static DevPool g_pool;
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    // headroom: 1/8 on top for buffers that grow with the batch; none for the arena, which is sized from the free memory
+    bool pooled = false;              // an aligner's buffer: comes from / returns to g_pool (the graph's own tables do not)
+    ~DevBuf() { release(); }
+    void release() {
+        if (!p) return;
+        if (pooled) g_pool.give(p, bytes); else (void)hipFree(p);
+        p = nullptr; bytes = 0;
+    }
+    // headroom: 1/8 on top for buffers that grow with the batch; none for the arena, which is sized from the free memory.
+    // (A block from the pool holds whatever its last owner left: like a fresh hipMalloc block, its contents are undefined —
+    // every owner initialises what it reads, keyed on `bytes` having changed.)
     int ensure(size_t n, bool exact = false) {
         if (n <= bytes) return MGX_OK;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        release();
         size_t want = exact ? n : n + n / 8 + 256;
+        if (pooled) {
+            size_t got = 0;
+            if (void *q = g_pool.take(want, &got)) { p = q; bytes = got; return MGX_OK; }
+        }
         hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess && g_pool.held_bytes()) {      // what the pool holds is free memory: give it back and try again
+            (void)hipGetLastError();
+            g_pool.flush();
+            e = hipMalloc(&p, want);
+        }
         if (e != hipSuccess) { p = nullptr; return fail(MGX_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
         bytes = want;
         return MGX_OK;
@@ -482,6 +546,7 @@ struct mgx_aligner {
     // of several worker threads on one device (cli/align.cpp:440-475: one aligner per thread-pool task) overlap instead of
     // serialising on the default stream.
     hipStream_t hstream = nullptr;
+    int device = 0;                    // the graph's device
     bool own_stream = false;           // mgx_aligner_create_stream: destroyed with the aligner
     uint64_t stage_generation = 0;               // counts stage_batch calls (mgx_map_batch re-stages the same buffers) ...
     uint64_t aligned_generation = 0;             // ... and which of them mgx_align_batch_device aligned: post-chaining and the
@@ -783,6 +848,14 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
     std::unique_ptr<mgx_aligner> guard(A);
     A->graph = g;
     A->anno = anno;
+    A->device = g->device;
+    // every device buffer of an aligner goes through the per-device block pool (DevPool): the next aligner takes them over
+    for (DevBuf *b : { &A->mlen_fwd, &A->mlen_rc, &A->pk_fwd, &A->pk_rc, &A->iv_fwd, &A->iv_rc, &A->rng_fwd, &A->rng_rc, &A->score_matrix,
+                       &A->seqs, &A->offsets, &A->counts, &A->node_begin, &A->nodes_fwd, &A->nodes_rc, &A->arena, &A->results, &A->stream,
+                       &A->cursors, &A->d_stats, &A->d_stats_map, &A->scan_tmp, &A->dbg_seeds, &A->seed_hdr, &A->seed_stream, &A->work_key,
+                       &A->work_key_sorted, &A->order_in, &A->order, &A->sort_tmp, &A->retry_list, &A->resume_pool[0], &A->resume_pool[1],
+                       &A->retry_list2, &A->retry_key[0], &A->retry_key[1], &A->lane_scratch, &A->lane_params, &A->lane_bail, &A->lane_hist })
+        b->pooled = true;
     {
         std::string err;
         int rc = prepare_config(*config, g->g.k, &A->cfg, &A->dcfg, &err, anno != nullptr);
@@ -852,7 +925,7 @@ int mgx_labeled_aligner_create(const mgx_graph *g, const mgx_config *config, con
 
 void mgx_aligner_destroy(mgx_aligner *a) {
     if (!a) return;
-    (void)hipSetDevice(a->graph->device);
+    (void)hipSetDevice(a->device);                          // (its own copy: the graph may be gone by now — a binding's GC order)
     (void)hipStreamSynchronize(a->hstream);
     for (auto &e : a->ev) if (e) (void)hipEventDestroy(e);
     if (a->own_stream) (void)hipStreamDestroy(a->hstream);
@@ -919,6 +992,7 @@ static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets
         // the range arrays are an optimisation: only when they fit comfortably next to everything else
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        free_b += g_pool.held_bytes();
         const size_t need = 2 * (total_kmers + 1) * sizeof(uint2);
         A->have_rng = need <= A->rng_fwd.bytes + A->rng_rc.bytes || need < free_b / 4;
         if (A->have_rng) {
@@ -1068,7 +1142,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                            + (n * 24 + A->total_kmers / 8 + 4096) * A->seed_scale * sizeof(DevSeed) + (1ull << 30);
     const uint64_t held = A->results.bytes + A->stream.bytes + A->seed_stream.bytes + A->seed_hdr.bytes;     // re-used as far as they reach
     const uint64_t need_later = later > held ? later - held : 0;
-    const uint64_t avail = (uint64_t)free_b + A->arena.bytes;             // a growing arena frees its old block first
+    const uint64_t avail = (uint64_t)free_b + A->arena.bytes + g_pool.held_bytes();     // a growing arena frees its old block first; what the
+                                                                                          // block pool holds is handed out or freed on demand
     uint64_t budget = avail > need_later ? (avail - need_later) / 10 * 9 : avail / 2;
     // (device_share: this handle is one of several at work on the device — each gets its share of the slots the machine can keep
     // resident and of the memory, instead of the first handles taking all of it and the later ones what is left)
@@ -1344,6 +1419,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             const uint32_t rb = resume_rec_bytes(l, (uint32_t)std::max<uint64_t>(1, A->cfg.num_alternative_paths));
             size_t fb = 0, tb = 0;
             HIP_TRY(hipMemGetInfo(&fb, &tb));
+            fb += g_pool.held_bytes();
             const uint64_t have = A->resume_pool[0].bytes + A->resume_pool[1].bytes;
             uint64_t cap = std::min<uint64_t>(n, ((uint64_t)fb / 2 + have) / (2ull * rb));      // two pools
             if (cap > 0xFFFFFFF0ull) cap = 0xFFFFFFF0ull;
@@ -1462,6 +1538,16 @@ int mgx_map_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets, uin
     out->node_begin = A->m_node_begin.data();
     out->nodes_fwd = A->m_fwd.data();
     out->nodes_rc = A->m_rc.data();
+    return MGX_OK;
+}
+
+// the device blocks kept from destroyed aligners (DevPool) go back to the driver
+int mgx_device_trim(int device) {
+    int cur = 0;
+    HIP_TRY(hipGetDevice(&cur));
+    HIP_TRY(hipSetDevice(device));
+    g_pool.flush();
+    HIP_TRY(hipSetDevice(cur));
     return MGX_OK;
 }
 

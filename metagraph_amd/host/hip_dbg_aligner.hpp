@@ -14,6 +14,7 @@
 #include <memory>
 #include <algorithm>
 #include <stdexcept>
+#include <cstdlib>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -263,6 +264,7 @@ class HipDBGAligner : public IDBGAligner {
     // that the tasks of one device overlap instead of taking turns on the default stream (batches arrive from host memory: nothing
     // of the caller's is ordered against it)
     void own_stream() {
+        if (getenv("MGX_ADAPTER_DEFAULT_STREAM")) return;          // (A/B switch: every handle on the legacy default stream, as before round 6)
         if (int rc = mgx_aligner_create_stream(a_)) {
             const std::string msg = std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")";
             mgx_aligner_destroy(a_);

@@ -13,6 +13,7 @@
 #include <memory>
 #include <numeric>
 #include <queue>
+#include <set>
 #include <stdexcept>
 #include <tuple>
 #include <unordered_map>
@@ -183,7 +184,7 @@ Alignment::Alignment(const Seed &seed, const mgx_config &config)
         sequence(seed.query_view),
         score(match_score(config, seed.query_view) + (!seed.clipping ? config.left_end_bonus : 0)
                 + (!seed.end_clipping ? config.right_end_bonus : 0)),
-        cigar(MGX_OP_CLIPPED, seed.clipping), label_columns(seed.label_columns) {
+        cigar(MGX_OP_CLIPPED, seed.clipping), label_columns(seed.label_columns), label_coordinates(seed.label_coordinates) {
     cigar.append(MGX_OP_MATCH, query_view.size());
     cigar.append(MGX_OP_CLIPPED, seed.end_clipping);
 }
@@ -198,11 +199,52 @@ void Alignment::extend_query_end(const char *end) {
     if (full_query_end < end) cigar.append(MGX_OP_CLIPPED, end - full_query_end);
 }
 
+// utils::match_indexed_values (common/algorithms.hpp:184-206): callback(index, value1, value2) for every index both sorted
+// index ranges hold
+template <class Callback>
+static void match_indexed_values(const Columns &i1, const CoordinateSet &v1, const Columns &i2, const CoordinateSet &v2, const Callback &callback) {
+    size_t a = 0, b = 0;
+    while (a < i1.size() && b < i2.size()) {
+        if (i1[a] < i2[b]) { ++a; continue; }
+        if (i1[a] == i2[b]) { callback(i1[a], v1[a], v2[b]); ++a; }
+        ++b;
+    }
+}
+// utils::set_intersection with a delta (common/algorithms.hpp:208-225): the elements a of A with a + delta in B
+static void set_intersection_delta(const Tuple &A, const Tuple &B, Tuple *out, int64_t delta) {
+    size_t a = 0, b = 0;
+    while (a < A.size() && b < B.size()) {
+        if (A[a] + delta < B[b]) ++a;
+        else if (A[a] + delta > B[b]) ++b;
+        else { out->push_back(A[a]); ++a; ++b; }
+    }
+}
+
 bool Alignment::append(Alignment &&other) {
-    // alignment.cpp:94-175; label_coordinates are not restated, label_columns are intersected (:148-160)
+    // alignment.cpp:94-175
     bool ret_val = false;
+    if (label_coordinates.size() && other.label_coordinates.empty()) label_coordinates.clear();
     if (label_columns.size() && other.label_columns.empty()) label_columns.clear();
-    if (label_columns.size()) {
+    if (label_coordinates.size()) {
+        // (:107-149) coordinates: the alignments fit together only where a coordinate of `other` continues one of this
+        Columns merged_columns;
+        CoordinateSet merged_coordinates;
+        const int64_t len = (int64_t)sequence.size();
+        match_indexed_values(label_columns, label_coordinates, other.label_columns, other.label_coordinates,
+            [&](Label col, const Tuple &coords, const Tuple &other_coords) {
+                Tuple merged;
+                set_intersection_delta(coords, other_coords, &merged, len);
+                if (merged.size()) { merged_columns.push_back(col); merged_coordinates.push_back(std::move(merged)); }
+            });
+        if (merged_columns.empty()) { *this = Alignment(); return true; }
+        ret_val = merged_columns.size() < label_columns.size();
+        if (!ret_val) {
+            for (size_t i = 0; i < label_columns.size(); ++i)
+                if (merged_coordinates[i].size() < label_coordinates[i].size()) { ret_val = true; break; }
+        }
+        std::swap(label_columns, merged_columns);
+        std::swap(label_coordinates, merged_coordinates);
+    } else if (label_columns.size()) {
         Columns merged;
         std::set_intersection(label_columns.begin(), label_columns.end(), other.label_columns.begin(), other.label_columns.end(),
                               std::back_inserter(merged));
@@ -260,6 +302,10 @@ size_t Alignment::trim_query_prefix(size_t n, size_t node_overlap, const mgx_con
         ++cigar_offset;
         if (cigar_offset == it->second) { ++it; cigar_offset = 0; }
     }
+    {
+        const int64_t seq_trim = s_it - sequence.begin();              // (:261-266)
+        for (Tuple &coords : label_coordinates) for (int64_t &c : coords) c += seq_trim;
+    }
     if (!clipping && it != cigar.ops.begin()) score -= config.left_end_bonus;
     nodes.erase(nodes.begin(), node_it);
     sequence.erase(sequence.begin(), s_it);
@@ -267,6 +313,276 @@ size_t Alignment::trim_query_prefix(size_t n, size_t node_overlap, const mgx_con
     cigar.ops.erase(cigar.ops.begin(), it);
     extend_query_begin(query_begin);
     return cigar_offset;
+}
+
+bool Alignment::splice(Alignment &&other) {
+    // alignment.hpp:196-205
+    if (empty()) { std::swap(*this, other); return label_columns.size(); }
+    trim_end_clipping();
+    other.trim_clipping();
+    return append(std::move(other));
+}
+
+// What the four trimming routines share (alignment.cpp:192-538): CIGAR operators are consumed one at a time from one end, the
+// score gives back what each was worth, reference-consuming operators advance through sequence and nodes.
+size_t Alignment::trim_query_suffix(size_t n, const mgx_config &config, bool trim_excess_deletions) {
+    // alignment.cpp:280-362
+    const size_t end_clipping = get_end_clipping();
+    const char *query_end = query_view.data() + query_view.size() + end_clipping;
+    trim_end_clipping();
+    auto it = cigar.ops.rbegin();
+    size_t cigar_offset = 0;
+    auto s_it = sequence.rbegin();
+    auto node_it = nodes.rbegin();
+    auto consume_ref = [&]() {
+        ++s_it;
+        if (node_it + 1 < nodes.rend()) ++node_it;
+        else *this = Alignment();
+    };
+    while (n || (trim_excess_deletions && it != cigar.ops.rend() && it->first == MGX_OP_DELETION)) {
+        if (it == cigar.ops.rend()) { *this = Alignment(); return 0; }
+        switch (it->first) {
+            case MGX_OP_MATCH:
+            case MGX_OP_MISMATCH:
+                score -= config.score_matrix[(uint8_t)query_view.back() & 127][(uint8_t)*s_it & 127];
+                query_view.remove_suffix(1);
+                --n;
+                consume_ref();
+                if (empty()) return 0;
+                break;
+            case MGX_OP_INSERTION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                query_view.remove_suffix(1);
+                --n;
+                break;
+            case MGX_OP_DELETION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                consume_ref();
+                if (empty()) return 0;
+                break;
+            default:
+                throw std::runtime_error("trimming chains not supported");
+        }
+        ++cigar_offset;
+        if (cigar_offset == it->second) { ++it; cigar_offset = 0; }
+    }
+    if (!end_clipping && (cigar_offset || it.base() != cigar.ops.end())) score -= config.right_end_bonus;
+    nodes.erase(node_it.base(), nodes.end());
+    sequence.erase(s_it.base(), sequence.end());
+    it->second -= cigar_offset;
+    cigar.ops.erase(it.base(), cigar.ops.end());
+    extend_query_end(query_end);
+    return cigar_offset;
+}
+
+size_t Alignment::trim_reference_prefix(size_t n, size_t node_overlap, const mgx_config &config, bool trim_excess_insertions) {
+    // alignment.cpp:364-455
+    const size_t clipping = get_clipping();
+    const char *query_begin = query_view.data() - clipping;
+    auto it = cigar.ops.begin() + static_cast<bool>(clipping);
+    size_t cigar_offset = 0;
+    auto s_it = sequence.begin();
+    auto node_it = nodes.begin();
+    int64_t seq_trim = 0;
+    auto consume_ref = [&]() {
+        if (*s_it != '$') { ++seq_trim; --n; }
+        ++s_it;
+        if (offset < node_overlap) ++offset;
+        else if (node_it + 1 < nodes.end()) ++node_it;
+        else *this = Alignment();
+    };
+    while (n || (trim_excess_insertions && it != cigar.ops.end() && it->first == MGX_OP_INSERTION)) {
+        if (it == cigar.ops.end()) { *this = Alignment(); return 0; }
+        switch (it->first) {
+            case MGX_OP_MATCH:
+            case MGX_OP_MISMATCH:
+                score -= config.score_matrix[(uint8_t)query_view[0] & 127][(uint8_t)*s_it & 127];
+                query_view.remove_prefix(1);
+                consume_ref();
+                if (empty()) return 0;
+                break;
+            case MGX_OP_INSERTION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                query_view.remove_prefix(1);
+                break;
+            case MGX_OP_DELETION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                consume_ref();
+                if (empty()) return 0;
+                break;
+            case MGX_OP_NODE_INSERTION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                break;
+            default:
+                throw std::runtime_error("trim_reference_prefix: a clipping inside the alignment");
+        }
+        ++cigar_offset;
+        if (cigar_offset == it->second) { ++it; cigar_offset = 0; }
+    }
+    for (Tuple &coords : label_coordinates) for (int64_t &c : coords) c += seq_trim;
+    if (!clipping && (cigar_offset || it != cigar.ops.begin())) score -= config.left_end_bonus;
+    nodes.erase(nodes.begin(), node_it);
+    sequence.erase(sequence.begin(), s_it);
+    it->second -= cigar_offset;
+    cigar.ops.erase(cigar.ops.begin(), it);
+    extend_query_begin(query_begin);
+    return cigar_offset;
+}
+
+size_t Alignment::trim_reference_suffix(size_t n, const mgx_config &config, bool trim_excess_insertions) {
+    // alignment.cpp:457-538
+    const size_t end_clipping = get_end_clipping();
+    const char *query_end = query_view.data() + query_view.size() + end_clipping;
+    trim_end_clipping();
+    auto it = cigar.ops.rbegin();
+    size_t cigar_offset = 0;
+    auto s_it = sequence.rbegin();
+    auto node_it = nodes.rbegin();
+    auto consume_ref = [&]() {
+        --n;
+        ++s_it;
+        if (node_it + 1 < nodes.rend()) ++node_it;
+        else *this = Alignment();
+    };
+    while (n || (trim_excess_insertions && it != cigar.ops.rend() && it->first == MGX_OP_INSERTION)) {
+        if (it == cigar.ops.rend()) { *this = Alignment(); return 0; }
+        switch (it->first) {
+            case MGX_OP_MATCH:
+            case MGX_OP_MISMATCH:
+                score -= config.score_matrix[(uint8_t)query_view.back() & 127][(uint8_t)*s_it & 127];
+                query_view.remove_suffix(1);
+                consume_ref();
+                if (empty()) return 0;
+                break;
+            case MGX_OP_INSERTION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                query_view.remove_suffix(1);
+                break;
+            case MGX_OP_DELETION:
+                score -= it->second - cigar_offset == 1 ? config.gap_opening_penalty : config.gap_extension_penalty;
+                consume_ref();
+                if (empty()) return 0;
+                break;
+            default:
+                throw std::runtime_error("trimming chains not supported");
+        }
+        ++cigar_offset;
+        if (cigar_offset == it->second) { ++it; cigar_offset = 0; }
+    }
+    if (!end_clipping && (cigar_offset || it.base() != cigar.ops.end())) score -= config.right_end_bonus;
+    nodes.erase(node_it.base(), nodes.end());
+    sequence.erase(s_it.base(), sequence.end());
+    it->second -= cigar_offset;
+    cigar.ops.erase(it.base(), cigar.ops.end());
+    extend_query_end(query_end);
+    return cigar_offset;
+}
+
+void Alignment::splice_with_unknown(Alignment &&other, size_t num_unknown, size_t node_overlap, const mgx_config &config) {
+    // alignment.cpp:1048-1152: `other` follows this alignment after num_unknown characters the graph does not hold
+    if (other.offset) { *this = Alignment(); return; }                  // "Can't splice in sub-k alignment"
+    ptrdiff_t overlap = (ptrdiff_t)(get_clipping() + query_view.size()) - (ptrdiff_t)other.get_clipping();
+    other.trim_clipping();
+    const score_t go = config.gap_opening_penalty, ge = config.gap_extension_penalty;
+    if (overlap <= 0) {
+        // a gap between the alignments: characters missing from the graph (typically N)
+        trim_end_clipping();
+        size_t query_gap = (size_t)(-overlap);
+        if (query_gap > num_unknown) {
+            cigar.append(MGX_OP_INSERTION, (uint32_t)(query_gap - num_unknown));
+            score += go + (score_t)(query_gap - num_unknown - 1) * ge;
+            query_view = std::string_view(query_view.data(), query_view.size() + query_gap - num_unknown);
+            query_gap = num_unknown;
+        }
+        const char *start = other.query_view.data() - query_gap;
+        if (query_gap) {
+            other.cigar.ops.insert(other.cigar.ops.begin(), Cigar::value_type(MGX_OP_MISMATCH, (uint32_t)query_gap));
+            other.score += score_sequences(config, std::string_view(start, query_gap), std::string(num_unknown, '$'));
+        }
+        if (num_unknown > query_gap) {
+            other.cigar.ops.insert(other.cigar.ops.begin(), Cigar::value_type(MGX_OP_DELETION, (uint32_t)(num_unknown - query_gap)));
+            other.score += go + (score_t)(num_unknown - query_gap - 1) * ge;
+        }
+        other.cigar.ops.insert(other.cigar.ops.begin(),
+                               Cigar::value_type(MGX_OP_NODE_INSERTION, (uint32_t)(node_overlap + num_unknown - other.offset)));
+        other.query_view = std::string_view(start, other.query_view.size() + query_gap);
+        other.score += go + (score_t)(node_overlap + num_unknown - other.offset - 1) * ge;
+    } else {
+        // the read has fewer copies of a repeat than the graph at a gap of the graph: the deletion is rebuilt
+        const std::vector<node_t> nodes_before = nodes;
+        const std::string seq_before = sequence;
+        trim_query_suffix((size_t)overlap, config, false);
+        if (empty()) { *this = Alignment(); return; }                   // "Not enough nodes in this alignment for splicing"
+        overlap = (ptrdiff_t)(seq_before.size() - sequence.size());
+        trim_end_clipping();
+        if (overlap) {
+            cigar.ops.emplace_back(MGX_OP_DELETION, (uint32_t)overlap);
+            nodes.insert(nodes.end(), nodes_before.end() - overlap, nodes_before.end());
+            sequence += seq_before.substr(seq_before.size() - overlap);
+        }
+        other.cigar.ops.insert(other.cigar.ops.begin(), Cigar::value_type(MGX_OP_DELETION, (uint32_t)num_unknown));
+        other.cigar.ops.insert(other.cigar.ops.begin(), Cigar::value_type(MGX_OP_NODE_INSERTION, (uint32_t)(node_overlap + num_unknown)));
+        other.score += go * 2 + (score_t)(node_overlap + num_unknown - 1 + overlap + num_unknown - 1) * ge;
+    }
+    other.sequence = std::string(num_unknown, '$') + other.sequence;
+    other.nodes.insert(other.nodes.begin(), node_overlap + num_unknown - other.offset, NPOS);
+    other.offset = node_overlap;
+    for (Tuple &tuple : other.label_coordinates) for (int64_t &c : tuple) c -= (int64_t)num_unknown;
+    append(std::move(other));
+}
+
+std::string Alignment::format_coords(const std::vector<std::string> &label_names) const {
+    // alignment.cpp:20-37: "<label>:<start>-<end>[:<start>-<end>...][;...]", 1-based inclusive
+    std::string out;
+    for (size_t i = 0; i < label_coordinates.size(); ++i) {
+        if (i) out += ";";
+        out += label_names.at(label_columns[i]);
+        for (int64_t coord : label_coordinates[i])
+            out += ":" + std::to_string(coord + 1) + "-" + std::to_string(coord + (int64_t)sequence.size());
+    }
+    return out;
+}
+
+std::string Alignment::format_coords(const std::vector<std::vector<std::string>> &headers,
+                                     const std::vector<std::vector<uint64_t>> &kmer_counts, size_t k) const {
+    // alignment.cpp:39-92; CoordToHeader::map_single_coord (annotation/coord_to_header.cpp): the sequence of a column a global
+    // k-mer coordinate falls into (prefix sums of the k-mer counts) and the coordinate within it
+    if (label_coordinates.empty()) return "";
+    typedef std::pair<Label, size_t> Key;                              // (column, sequence)
+    std::vector<std::pair<Key, std::vector<std::pair<uint64_t, uint64_t>>>> seq_ranges;     // VectorMap: insertion order
+    auto ranges_of = [&](const Key &key) -> std::vector<std::pair<uint64_t, uint64_t>> & {
+        for (auto &e : seq_ranges) if (e.first == key) return e.second;
+        seq_ranges.emplace_back(key, std::vector<std::pair<uint64_t, uint64_t>>());
+        return seq_ranges.back().second;
+    };
+    const uint64_t L = sequence.size();
+    for (size_t i = 0; i < label_columns.size(); ++i) {
+        const Label col = label_columns[i];
+        const std::vector<uint64_t> &counts = kmer_counts.at(col);
+        const size_t n_seqs = counts.size();
+        for (int64_t coord : label_coordinates[i]) {
+            size_t seq_id = 0;
+            uint64_t local = (uint64_t)coord;
+            while (seq_id < n_seqs && local >= counts[seq_id]) { local -= counts[seq_id]; ++seq_id; }
+            uint64_t remaining = L;
+            while (remaining) {
+                if (seq_id >= n_seqs) break;                            // (past the last indexed sequence: truncated)
+                const uint64_t nt_len = counts[seq_id] + k - 1;
+                const uint64_t span = std::min(remaining, nt_len - local);
+                ranges_of(Key(col, seq_id)).emplace_back(local, local + span - 1);
+                remaining -= span;
+                ++seq_id;
+                local = 0;
+            }
+        }
+    }
+    std::string out;
+    for (size_t e = 0; e < seq_ranges.size(); ++e) {
+        if (e) out += ";";
+        out += headers.at(seq_ranges[e].first.first).at(seq_ranges[e].first.second);
+        for (const auto &r : seq_ranges[e].second) out += ":" + std::to_string(r.first + 1) + "-" + std::to_string(r.second + 1);
+    }
+    return out;
 }
 
 void Alignment::insert_gap_prefix(ptrdiff_t gap_length, size_t node_overlap, const mgx_config &config) {
@@ -972,6 +1288,13 @@ class AnnotationBuffer {
         std::vector<Columns> rows = annotation_.get_rows(queued_rows);
         for (size_t x = 0; x < rows.size(); ++x) {
             std::sort(rows[x].begin(), rows[x].end());
+            if (has_coordinates()) {
+                // (:168-181) labels and coordinates of a row, stored side by side: label_coords_ of a node = one Tuple per label,
+                // in the order of its label set (BASIC graphs only: the constructor drops coordinates for the other modes, :26-33)
+                CoordinateSet cs;
+                for (auto &lt : annotation_.get_row_tuples(queued_rows[x])) cs.push_back(std::move(lt.second));
+                node_coords_[queued_nodes[x]] = std::move(cs);
+            }
             size_t label_i = cache_column_set(std::move(rows[x]));
             node_to_cols_[queued_nodes[x]] = label_i;    // push_node_labels: BASIC and the canonical wrapper both key by the base node
             if (graph_.mode == CANONICAL && !canonical_) {
@@ -980,6 +1303,18 @@ class AnnotationBuffer {
                 if (base_node != queued_nodes[x]) node_to_cols_.try_emplace(base_node, label_i);
             }
         }
+    }
+
+    bool has_coordinates() const { return annotation_.has_coordinates && graph_.mode == BASIC && !canonical_; }
+    // get_labels_and_coords (:195-217): nullptrs for a node that was never fetched; the coordinates of a node without labels
+    // (a dummy node) are an empty set
+    std::pair<const Columns *, const CoordinateSet *> get_labels_and_coords(node_t node) const {
+        std::pair<const Columns *, const CoordinateSet *> ret(get_labels(node), nullptr);
+        if (ret.first && has_coordinates()) {
+            auto it = node_coords_.find(node);
+            ret.second = it == node_coords_.end() ? &empty_coords_ : &it->second;
+        }
+        return ret;
     }
 
     // get_labels_and_coords().first (:195-217)
@@ -1030,6 +1365,8 @@ class AnnotationBuffer {
     std::deque<Columns> column_sets_;                    // (deque: references handed out stay valid while sets are added)
     std::map<Columns, size_t> column_index_;
     std::unordered_map<node_t, size_t> node_to_cols_;
+    std::unordered_map<node_t, CoordinateSet> node_coords_;       // label_coords_ (hpp:84), keyed by node instead of by map position
+    const CoordinateSet empty_coords_;
     std::vector<std::vector<node_t>> queued_paths_;
 };
 
@@ -1059,22 +1396,38 @@ class Extender {
 
     void set_graph(bool rc) { view_.rc = rc; }
     const GraphView &view() const { return view_; }
+    const Graph &graph() const { return *base_; }
+    const mgx_config &config() const { return config_; }
     size_t num_extensions() const { return num_extensions_; }
     size_t num_explored_nodes() const { return explored_nodes_previous_ + conv_checker_.size(); }
 
     // SeedFilteringExtender::get_extensions (extender hpp:38-51)
-    std::vector<Alignment> get_extensions(const Alignment &seed, score_t min_path_score, bool force_fixed_seed) {
+    // target_length / target_node (hpp:34-45): stop once target_length nucleotides have been aligned to and backtrack from
+    // target_node only (align_connect); trim_query_suffix: the window ends that many characters before the query does;
+    // added_xdrop: on top of the configured x-drop (saturating)
+    std::vector<Alignment> get_extensions(const Alignment &seed, score_t min_path_score, bool force_fixed_seed,
+                                          size_t target_length = 0, node_t target_node = NPOS, bool trim_offset_after_extend = true,
+                                          size_t trim_query_suffix = 0, score_t added_xdrop = 0) {
         seed_ = &seed;                                   // set_seed (:90-98)
         explored_nodes_previous_ += conv_checker_.size();
         conv_checker_.clear();
         if (ab_) {
-            // LabeledExtender::set_seed (aligner_labeled.cpp:139-174, no coordinates): the first node of the seed has
-            // already been flushed; the seed's labels are what backtracking still has to account for
+            // LabeledExtender::set_seed (aligner_labeled.cpp:139-174): the first node of the seed has already been flushed; the
+            // seed's labels are what backtracking still has to account for
             last_flushed_table_i_ = 1;
             remaining_labels_i_ = ab_->cache_column_set(Columns(seed.label_columns));
             node_labels_.assign(1, remaining_labels_i_);
+            // base_coords_: the coordinates of the seed's first k-mer — of its last one when the extension runs backwards
+            base_coords_ = seed.label_coordinates;
+            if (base_coords_.size()) {
+                if (view_.rc) {
+                    for (Tuple &coords : base_coords_) for (int64_t &c : coords) c += (int64_t)seed.nodes.size() - 1 - (int64_t)seed.offset;
+                } else if (seed.offset) {
+                    for (Tuple &coords : base_coords_) for (int64_t &c : coords) c -= (int64_t)seed.offset;
+                }
+            }
         }
-        return extend(min_path_score, force_fixed_seed);
+        return extend(min_path_score, force_fixed_seed, target_length, target_node, trim_offset_after_extend, trim_query_suffix, added_xdrop);
     }
 
     bool check_seed(const Alignment &seed) const {
@@ -1136,6 +1489,8 @@ class Extender {
     std::vector<size_t> node_labels_;
     size_t remaining_labels_i_ = 0;
     Columns label_intersection_, label_diff_;
+    CoordinateSet base_coords_;                          // aligner_labeled.hpp:100
+    std::vector<score_t> scores_reached_;                // extender hpp:156 (global_xdrop == false)
     std::vector<score_t> partial_sums_;
     std::vector<score_t> profile_score_[6];
     std::vector<uint8_t> profile_op_[6];
@@ -1216,6 +1571,42 @@ class Extender {
         flush();
         if (!node_labels_[table_i]) return;
         const Columns columns = ab_->get_cached_column_set(node_labels_[table_i]);     // (copy: the set may grow below)
+        if (ab_->get_labels_and_coords(node).second) {
+            // (:245-300) label AND coordinate consistency, with the seed as the basis: a child keeps the labels of `columns` in
+            // which one of its coordinates lies `dist` behind a coordinate of the seed's first k-mer
+            const int64_t dist = (int64_t)next_offset - (int64_t)view_.get_k() + 1;
+            for (const auto &[next, c, score] : outgoing) {
+                const Columns *base_labels = &seed_->label_columns;
+                const CoordinateSet *base_coords = &base_coords_;
+                auto [next_labels, next_coords] = ab_->get_labels_and_coords(next);
+                if (!next_labels || !next_coords) throw std::logic_error("oracle: call_outgoing(): coordinates of a child were not fetched");
+                if (view_.rc) { std::swap(base_labels, next_labels); std::swap(base_coords, next_coords); }   // backwards: the delta is negated
+                Columns intersect_labels;
+                auto col_it = columns.begin();
+                const auto col_end = columns.end();
+                bool stop = false;
+                match_indexed_values(*base_labels, *base_coords, *next_labels, *next_coords,
+                    [&](Label cc, const Tuple &coords, const Tuple &other_coords) {
+                        if (stop) return;                             // (the reference leaves through an exception)
+                        while (col_it != col_end && cc > *col_it) ++col_it;
+                        if (col_it == col_end) { stop = true; return; }
+                        if (cc < *col_it) return;
+                        // overlap_with_diff (:22-44): some a in coords, b in other_coords with a + dist == b
+                        size_t a = 0, b = 0;
+                        bool hit = false;
+                        while (a < coords.size() && b < other_coords.size()) {
+                            if (coords[a] + dist == other_coords[b]) { hit = true; break; }
+                            if (coords[a] + dist < other_coords[b]) ++a; else ++b;
+                        }
+                        if (hit) intersect_labels.push_back(cc);
+                    });
+                if (intersect_labels.size()) {
+                    node_labels_.push_back(ab_->cache_column_set(std::move(intersect_labels)));
+                    callback(next, c, score);
+                }
+            }
+            return;
+        }
         for (const auto &[next, c, score] : outgoing) {
             const Columns *next_labels = ab_->get_labels(next);
             if (!next_labels) throw std::logic_error("oracle: call_outgoing(): labels of a child were not fetched");
@@ -1252,18 +1643,73 @@ class Extender {
         label_diff_.push_back(kNannot);
         return label_intersection_.empty();
     }
-    // call_alignments (hpp:200-214 / aligner_labeled.cpp:328-448 without coordinates)
-    void call_alignments(Alignment &&alignment, std::vector<Alignment> &extensions) {
-        if (ab_) {
-            alignment.label_columns = std::move(label_intersection_);
-            label_intersection_ = Columns{};
-            if (label_diff_.size() && label_diff_.back() == kNannot) {
+    // call_alignments (hpp:200-214 / aligner_labeled.cpp:328-448); clipping: the window position the trace ended at
+    void call_alignments(Alignment &&alignment, size_t clipping, std::vector<Alignment> &extensions) {
+        auto call_alignment = [&]() {
+            if (ab_ && label_diff_.size() && label_diff_.back() == kNannot) {
                 label_diff_.pop_back();
                 remaining_labels_i_ = ab_->cache_column_set(std::move(label_diff_));
                 label_diff_ = Columns{};
             }
+            extensions.emplace_back(std::move(alignment));
+        };
+        if (!ab_) { call_alignment(); return; }
+        if (!ab_->has_coordinates()) {
+            alignment.label_columns = std::move(label_intersection_);
+            label_intersection_ = Columns{};
+            call_alignment();
+            return;
         }
-        extensions.emplace_back(std::move(alignment));
+        // (:361-447) the labels of label_intersection_ whose coordinates at the alignment's first and last node lie as far apart
+        // as the alignment is long; the alignment's coordinates are those of its first nucleotide
+        auto [base_labels, base_coords] = ab_->get_labels_and_coords(alignment.nodes.front());
+        if (!base_labels || !base_coords) throw std::logic_error("oracle: call_alignments(): the first node's coordinates were not fetched");
+        if (!clipping) base_labels = &seed_->label_columns;
+        int64_t dist = (int64_t)alignment.nodes.size() - 1;
+        if (!clipping) {
+            base_coords = &seed_->label_coordinates;
+            dist -= (int64_t)seed_->offset;
+            if (view_.rc) dist = (int64_t)alignment.sequence.size() - (int64_t)seed_->sequence.size();
+        }
+        auto label_it = label_intersection_.begin();
+        const auto label_end_it = label_intersection_.end();
+        if (alignment.nodes.size() == 1) {
+            auto it = base_labels->begin();
+            const auto end = base_labels->end();
+            auto c_it = base_coords->begin();
+            while (label_it != label_end_it && it != end) {
+                if (*label_it < *it) ++label_it;
+                else if (*label_it > *it) { ++it; ++c_it; }
+                else {
+                    alignment.label_columns.emplace_back(*it);
+                    alignment.label_coordinates.emplace_back(*c_it);
+                    ++it; ++c_it; ++label_it;
+                }
+            }
+        } else {
+            auto [cur_labels, cur_coords] = ab_->get_labels_and_coords(alignment.nodes.back());
+            if (!cur_labels || !cur_coords) throw std::logic_error("oracle: call_alignments(): the last node's coordinates were not fetched");
+            if (view_.rc) { std::swap(cur_labels, base_labels); std::swap(cur_coords, base_coords); }
+            bool stop = false;
+            match_indexed_values(*base_labels, *base_coords, *cur_labels, *cur_coords,
+                [&](Label c, const Tuple &coords, const Tuple &other_coords) {
+                    if (stop) return;
+                    while (label_it != label_end_it && c > *label_it) ++label_it;
+                    if (label_it == label_end_it) { stop = true; return; }
+                    if (c < *label_it) return;
+                    Tuple overlap;
+                    set_intersection_delta(coords, other_coords, &overlap, dist);
+                    if (overlap.size()) {
+                        alignment.label_columns.emplace_back(c);
+                        alignment.label_coordinates.emplace_back(std::move(overlap));
+                    }
+                });
+        }
+        if (alignment.label_coordinates.empty()) return;
+        if (view_.rc && alignment.offset) {
+            for (Tuple &coords : alignment.label_coordinates) for (int64_t &c : coords) c += (int64_t)alignment.offset;
+        }
+        call_alignment();
     }
 
     void table_emplace(Column &&col) {
@@ -1341,20 +1787,23 @@ class Extender {
         }
     }
 
-    std::vector<Alignment> extend(score_t min_path_score, bool force_fixed_seed) {
-        // aligner_extender_methods.cpp:412-772 with target_length = 0, target_node = npos,
-        // trim_offset_after_extend = true, trim_query_suffix = 0, added_xdrop = 0
+    std::vector<Alignment> extend(score_t min_path_score, bool force_fixed_seed, size_t target_length, node_t target_node,
+                                  bool trim_offset_after_extend, size_t trim_query_suffix, score_t added_xdrop) {
+        // aligner_extender_methods.cpp:412-772
         ++num_extensions_;
         if (wc_) ++wc_->n_extensions;
         min_path_score = std::max(0, min_path_score);
         table.clear();      // std::vector::clear keeps capacity: table_cap_ carries over between extensions
         prev_starts.clear();
 
-        score_t xdrop = std::min(config_.xdrop, INT32_MAX - 0) + 0;
+        score_t xdrop = std::min(config_.xdrop, INT32_MAX - added_xdrop) + added_xdrop;      // saturating (:429-430)
         xdrop_cutoffs_.assign(1, std::make_pair(size_t(0), std::max(-xdrop, NINF + 1)));
+        const bool global_xdrop = config_.global_xdrop != 0;
+        if (!global_xdrop) scores_reached_.assign(1, 0);
 
         size_t start = seed_->get_clipping();
-        std::string_view window(seed_->query_view.data(), query_.data() + query_.size() - seed_->query_view.data());
+        std::string_view window(seed_->query_view.data(),
+                                query_.data() + query_.size() - seed_->query_view.data() - trim_query_suffix);
         score_t partial_sum_offset = partial_sums_.at(start + window.size());
         ssize_t_ seed_offset = static_cast<ssize_t_>(seed_->offset) - 1;
         const size_t k = view_.get_k();
@@ -1396,11 +1845,13 @@ class Extender {
                 bool in_seed = next_offset - seed_->offset < seed_->sequence.size();
                 {
                     const Column &col = table[i];
-                    double node_counter = table.size();    // global_xdrop
+                    double node_counter = global_xdrop ? (double)table.size() : (double)((ssize_t_)next_offset - seed_offset);   // (:521-523)
                     if (col.S[col.max_pos - col.trim] < best_score) {
                         if (node_counter / window.size() >= config_.max_nodes_per_seq_char) {
-                            queue = std::priority_queue<TableIt>();
-                            next_nodes.clear();
+                            if (global_xdrop) {                    // (per-branch x-drop: only this branch stops, :531-536)
+                                queue = std::priority_queue<TableIt>();
+                                next_nodes.clear();
+                            }
                             continue;
                         }
                         if (static_cast<double>(table_size_bytes_) / 1'000'000 > config_.max_ram_per_alignment) {
@@ -1432,9 +1883,17 @@ class Extender {
                 size_t end = std::min(static_cast<size_t>(prev_end), window.size()) + 1;
 
                 for (const auto &[next, c, score] : outgoing) {
+                    // (:578-586) global_xdrop == false: every child of a fork gets a cut-off of its own, starting from its parent's
+                    const bool forked_xdrop = !global_xdrop && outgoing.size() > 1;
+                    size_t xdrop_cutoffs_sizediff = 0;
+                    if (forked_xdrop) {
+                        const size_t cap_before = xdrop_cutoffs_.capacity();
+                        xdrop_cutoffs_.emplace_back(table.size(), prev_xdrop_cutoff);
+                        xdrop_cutoffs_sizediff = xdrop_cutoffs_.capacity() - cap_before;
+                    }
                     size_t table_sizediff = table_cap_table();
                     table_emplace(create_column(end - begin, next, i, c, static_cast<ssize_t_>(next_offset),
-                                                begin, begin, prev_xdrop_cutoff_i, score));
+                                                begin, begin, forked_xdrop ? xdrop_cutoffs_.size() - 1 : prev_xdrop_cutoff_i, score));
                     if (wc_) ++wc_->n_columns;
                     const Column &prev = table[i];
                     Column &cur = table.back();
@@ -1458,24 +1917,38 @@ class Extender {
                         std::fma(static_cast<double>(best_score), config_.rel_score_cutoff,
                                  static_cast<double>(partial_sum_offset)));
 
+                    size_t scores_reached_sizediff = 0;
+                    bool scores_reached_cutoff = true;
+                    if (!global_xdrop) {                           // (:637-641)
+                        const size_t cap_before = scores_reached_.capacity();
+                        scores_reached_.resize(cur.S.size() + cur.trim + 1, NINF);
+                        scores_reached_sizediff = scores_reached_.capacity() - cap_before;
+                    }
                     for (size_t j = 0; j < cur.S.size(); ++j, ++cur_offset) {
                         if (cur.S[j] != NINF) min_cell_score_ = std::min(min_cell_score_, cur.S[j]);
                         if (std::make_pair(cur.S[j], std::abs(cur.max_pos - diag_i))
                                 > std::make_pair(cur.S[cur.max_pos - begin], std::abs(cur_offset - diag_i))) {
                             cur.max_pos = j + begin;
                         }
-                        if (!has_extension && cur.S[j] + partial_sums[j] >= extension_cutoff) has_extension = true;
+                        if (!global_xdrop) {                       // (:652-655; the flag is overwritten cell by cell, as there)
+                            scores_reached_[cur.trim + j] = std::max(scores_reached_[cur.trim + j], cur.S[j]);
+                            scores_reached_cutoff = (cur.S[j] >= scores_reached_[cur.trim + j] * config_.rel_score_cutoff);
+                        }
+                        if (!has_extension && scores_reached_cutoff && cur.S[j] + partial_sums[j] >= extension_cutoff) has_extension = true;
                     }
 
                     score_t max_val = cur.S[cur.max_pos - cur.trim];
-                    // target_length == 0: offset - seed_offset >= 1 always, so has_extension is left as computed
+                    // (:676-681) a target length: every column up to it goes on, none beyond it
+                    if (static_cast<size_t>(cur.offset - seed_offset) < target_length + 1) has_extension = true;
+                    else if (target_length) has_extension = false;
 
-                    if (!in_seed && max_val < xdrop_cutoff) { pop(table.size() - 1); continue; }
-                    if (!in_seed && !has_extension) { pop(table.size() - 1); continue; }
+                    if (!in_seed && max_val < xdrop_cutoff) { pop(table.size() - 1); if (forked_xdrop) xdrop_cutoffs_.pop_back(); continue; }
+                    if (!in_seed && !has_extension) { pop(table.size() - 1); if (forked_xdrop) xdrop_cutoffs_.pop_back(); continue; }
 
                     table_sizediff = table_cap_table() - table_sizediff;
                     table_size_bytes_ += kSizeofColumn * table_sizediff
-                        + (cur.S.capacity() + cur.E.capacity() + cur.F.capacity()) * sizeof(score_t);
+                        + (cur.S.capacity() + cur.E.capacity() + cur.F.capacity()) * sizeof(score_t)
+                        + sizeof(score_t) * scores_reached_sizediff + sizeof(std::pair<size_t, score_t>) * xdrop_cutoffs_sizediff;
 
                     // signed overflow in the reference when xdrop is INT32_MAX (unit-test default); it wraps
                     if (static_cast<score_t>(static_cast<uint32_t>(max_val) - static_cast<uint32_t>(xdrop_cutoff)) > xdrop)
@@ -1500,16 +1973,16 @@ class Extender {
         }
 
         std::sort(tips.begin(), tips.end());
-        auto extensions = backtrack(min_path_score, window, config_.right_end_bonus, tips, k);
-        for (auto &ext : extensions) ext.trim_offset();
+        auto extensions = backtrack(min_path_score, window, trim_query_suffix ? 0 : config_.right_end_bonus, tips, k, target_node);
+        if (trim_offset_after_extend) for (auto &ext : extensions) ext.trim_offset();
         return extensions;
     }
 
     size_t table_cap_table() const { return table_cap_; }
 
     std::vector<Alignment> backtrack(score_t min_path_score, std::string_view window, score_t right_end_bonus,
-                                     const std::vector<size_t> &tips, size_t k) {
-        // aligner_extender_methods.cpp:800-1034 with target_node = npos
+                                     const std::vector<size_t> &tips, size_t k, node_t target_node) {
+        // aligner_extender_methods.cpp:800-1034
         if (ab_) flush();                               // LabeledExtender::backtrack (aligner_labeled.hpp:32-43)
         std::vector<Alignment> extensions;
         size_t seed_clipping = seed_->get_clipping();
@@ -1517,7 +1990,7 @@ class Extender {
         ssize_t_ k_minus_1 = k - 1;
         ssize_t_ last_pos = window.size();
         ssize_t_ seed_dist = std::max(k, seed_->sequence.size()) - 1;
-        score_t min_start_score = min_path_score;
+        score_t min_start_score = target_node ? NINF : min_path_score;
         size_t min_trace_length = k - seed_->offset;
 
         std::vector<std::tuple<score_t, ssize_t_, ssize_t_, ssize_t_>> indices;
@@ -1533,7 +2006,14 @@ class Extender {
                 if (col.S[pos] == NINF || par.S.at_ub(pos_p) == NINF) return;
                 score_t end_bonus = start_pos == last_pos ? right_end_bonus : 0;
                 uint8_t s = encode_char(col.c);
-                if (col.S[pos] + end_bonus >= min_start_score) {
+                if (target_node) {
+                    // (:840-845) a target node: only its cells reached by a match (or tips) start a trace
+                    if (is_tip || (col.node == target_node
+                            && col.S[pos] == par.S.at_ub(pos_p) + col.score + profile_score_[s][seed_clipping + start_pos])) {
+                        indices.emplace_back(col.S[pos] + end_bonus, -std::abs(start_pos - col.offset + seed_offset),
+                                             -static_cast<ssize_t_>(i), start_pos);
+                    }
+                } else if (col.S[pos] + end_bonus >= min_start_score) {
                     bool is_match = col.S[pos] == par.S.at_ub(pos_p) + col.score + profile_score_[s][seed_clipping + start_pos]
                         && profile_op_[s][seed_clipping + start_pos] == MGX_OP_MATCH;
                     if (is_match || start_pos == last_pos || is_tip) {
@@ -1544,9 +2024,9 @@ class Extender {
             };
             if (table[i].offset < seed_dist) continue;
             bool is_tip = (it != tips.end() && i == *it);
-            check_and_add_pos(table[i].max_pos, is_tip);
+            if (!target_node || is_tip) check_and_add_pos(table[i].max_pos, is_tip);
             if ((ssize_t_)(table[i].S.size() + table[i].trim) == (ssize_t_)window.size() + 1
-                    && table[i].max_pos != last_pos) {
+                    && (target_node || table[i].max_pos != last_pos)) {
                 check_and_add_pos(last_pos, is_tip);
             }
         }
@@ -1645,7 +2125,7 @@ class Extender {
                         && (pos || cur_cell_score == table[0].S[0])
                         && (config_.allow_left_trim || !j)) {
                     call_alignments(construct_alignment(ops, pos, window.substr(pos, end_pos - pos),
-                                                        path, seq, score, align_offset, extra_score), extensions);
+                                                        path, seq, score, align_offset, extra_score), (size_t)pos, extensions);
                 }
             }
         }
@@ -1957,6 +2437,371 @@ void align_core_labeled(std::vector<Alignment> seeds, Extender &extender,
     }
 }
 
+// =============================================================================================
+// Seed chaining (A/aligner_chainer.cpp:21-542) and chain extension (A/dbg_aligner.cpp:63-250,388-529): what LabeledAligner
+// runs when its annotation carries coordinates (aligner_labeled.cpp:457-462).  Round 6; SURVEY 8 row f3.
+// =============================================================================================
+typedef std::vector<std::pair<Alignment, int64_t>> Chain;              // aligner_chainer.hpp: (alignment, coordinate distance to the one before)
+struct early_term {};
+
+// get_num_char_matches_in_seeds (alignment.hpp:100-127) over the alignments of a chain (same quirk as the Seed form below)
+size_t get_num_char_matches_in_chain(const Chain &chain) {
+    size_t num_matching = 0, last_q_end = 0;
+    for (size_t i = 0; i < chain.size(); ++i) {
+        const Alignment &aln = chain[i].first;
+        if (aln.empty()) continue;
+        size_t q_begin = aln.get_clipping(), q_end = q_begin + aln.query_view.size();
+        if (q_end > last_q_end) {
+            num_matching += q_end - q_begin;
+            if (q_begin < last_q_end) num_matching -= last_q_end - q_begin;
+        }
+        if (aln.offset) i = chain.size() - 1;
+        last_q_end = q_end;
+    }
+    return num_matching;
+}
+
+struct TableElem {                                                      // aligner_chainer.cpp:23-36
+    Label label;
+    int64_t coordinate;
+    int32_t seed_clipping, seed_end;
+    score_t chain_score;
+    uint32_t current_seed_index;
+};
+inline bool table_elem_greater(const TableElem &a, const TableElem &b) {          // :38-41
+    return std::tie(a.label, a.coordinate, a.seed_clipping, a.seed_end) > std::tie(b.label, b.coordinate, b.seed_clipping, b.seed_end);
+}
+constexpr uint32_t kNid = std::numeric_limits<uint32_t>::max();
+
+// chain_seeds (:341-542).  The reference's loop over j is AVX2 code, eight anchors at a time with gathers that reach past the
+// table's end (masked); lane by lane it computes what is written here: the anchors of one label in decreasing coordinate order,
+// each tried as the successor-in-the-table (= predecessor on the query) of the 64 anchors behind it.  The gap cost is FLOAT
+// arithmetic — linear + 0.5 * log2 — rounded to the nearest integer (cvtps_epi32: the current rounding mode, nearest-even),
+// not truncated as in the scalar version the source keeps under `#if 0`.
+struct ChainTables { std::vector<TableElem> dp_table; std::vector<uint32_t> backtrace; size_t num_seeds = 0, num_nodes = 0; };
+ChainTables chain_seeds(const mgx_config &config, std::string_view query, std::vector<Seed> &seeds) {
+    ChainTables T;
+    if (seeds.empty()) return T;
+    for (const Seed &a : seeds)
+        if (a.label_coordinates.empty()) throw std::runtime_error("Chaining only supported for seeds with coordinates");
+    const int64_t query_size = (int64_t)query.size();
+    std::reverse(seeds.begin(), seeds.end());
+    std::map<Label, size_t> label_sizes;
+    for (size_t i = 0; i < seeds.size(); ++i) {
+        for (size_t j = 0; j < seeds[i].label_coordinates.size(); ++j) {
+            const Label c = seeds[i].label_columns[j];
+            const Tuple &coords = seeds[i].label_coordinates[j];
+            const size_t take = std::min<size_t>(coords.size(), config.max_num_seeds_per_locus);
+            for (size_t t = 0; t < take; ++t) {                         // from the largest coordinate down
+                const int64_t coord = coords[coords.size() - 1 - t];
+                ++label_sizes[c];
+                T.dp_table.push_back(TableElem{ c, coord, (int32_t)seeds[i].clipping,
+                                                (int32_t)(seeds[i].clipping + seeds[i].query_view.size()),
+                                                (score_t)seeds[i].query_view.size(), (uint32_t)i });
+            }
+        }
+        seeds[i].label_columns = Columns{};
+        seeds[i].label_coordinates = CoordinateSet{};
+    }
+    T.num_seeds = T.dp_table.size();
+    T.backtrace.assign(T.dp_table.size(), kNid);
+    if (T.dp_table.empty()) return T;
+    // "sort seeds by label, then by decreasing reference coordinate"
+    std::sort(T.dp_table.begin(), T.dp_table.end(), table_elem_greater);
+    const size_t bandwidth = 65;
+    // "scoring function derived from minimap2": float sl = static_cast<float>(min_seed_length) * 0.01 (a double product, narrowed)
+    const float sl = (float)((double)(float)config.min_seed_length * 0.01);
+    std::vector<TableElem> &dp = T.dp_table;
+    size_t cur_label_end = 0, i = 0;
+    while (cur_label_end < dp.size()) {
+        cur_label_end += label_sizes[dp[i].label];
+        for ( ; i < cur_label_end; ++i) {
+            const int64_t prev_coord = dp[i].coordinate;
+            const int32_t prev_clipping = dp[i].seed_clipping;
+            const score_t prev_score = dp[i].chain_score;
+            if (!prev_clipping) continue;
+            const size_t it_end = std::min(bandwidth, cur_label_end - i) + i;
+            const int64_t coord_cutoff = prev_coord - query_size;
+            for (size_t j = i + 1; j < it_end; ++j) {
+                TableElem &e = dp[j];
+                if (coord_cutoff > e.coordinate) break;
+                const int32_t dist = prev_clipping - e.seed_clipping;
+                const int32_t coord_dist = (int32_t)(prev_coord - e.coordinate);          // (epi64 -> epi32: the low half)
+                if (dist > 0 && std::max(dist, coord_dist) < (int32_t)query_size) {
+                    const score_t match = std::min(std::min(dist, coord_dist), e.seed_end - e.seed_clipping);
+                    score_t cur_score = prev_score + match;
+                    const int32_t coord_diff = std::abs(coord_dist - dist);
+                    if (coord_diff > 0) {
+                        const float linear_penalty = (float)coord_diff * sl;
+                        const float log_penalty = std::log2((float)(coord_diff + 1)) * 0.5f;
+                        cur_score -= (score_t)std::lrintf(linear_penalty + log_penalty);      // cvtps_epi32
+                    }
+                    if (cur_score >= e.chain_score) {
+                        e.chain_score = cur_score;
+                        T.backtrace[j] = (uint32_t)i;
+                    }
+                }
+            }
+        }
+    }
+    return T;
+}
+
+struct ChainHash {                                                       // :51-62
+    std::size_t operator()(const Chain &chain) const {
+        uint64_t hash = 0;
+        for (const auto &[aln, dist] : chain) {
+            for (node_t node : aln.nodes) hash ^= node + 0x9e3779b9 + (hash << 6) + (hash >> 2);
+            hash ^= (uint64_t)dist + 0x9e3779b9 + (hash << 6) + (hash >> 2);
+        }
+        return hash;
+    }
+};
+
+// call_seed_chains_both_strands (:64-339).  Chains of equal score are collected in a std::unordered_multiset and handed out in ITS
+// iteration order, as in the reference (the same container of the same standard library, filled in the same order).
+std::pair<size_t, size_t> call_seed_chains_both_strands(std::string_view forward, std::string_view reverse, const mgx_config &config,
+                                                        std::vector<Seed> &&fwd_seeds, std::vector<Seed> &&bwd_seeds,
+                                                        const std::function<void(Chain &&, score_t)> &callback,
+                                                        const std::function<bool(Label)> &skip_column) {
+    auto useless = [](const Seed &a) { return a.empty() || a.label_columns.empty(); };
+    fwd_seeds.erase(std::remove_if(fwd_seeds.begin(), fwd_seeds.end(), useless), fwd_seeds.end());
+    bwd_seeds.erase(std::remove_if(bwd_seeds.begin(), bwd_seeds.end(), useless), bwd_seeds.end());
+    if (fwd_seeds.empty() && bwd_seeds.empty()) return { 0, 0 };
+    std::vector<Seed> both_seeds[2] = { std::move(fwd_seeds), std::move(bwd_seeds) };
+    ChainTables tables[2] = { chain_seeds(config, forward, both_seeds[0]), chain_seeds(config, reverse, both_seeds[1]) };
+    const size_t num_seeds = tables[0].num_seeds + tables[1].num_seeds, num_nodes = tables[0].num_nodes + tables[1].num_nodes;
+    // chains by backtracking, best chain score first
+    std::vector<std::tuple<score_t, uint32_t, ptrdiff_t>> starts;
+    std::vector<bool> both_used[2] = { std::vector<bool>(tables[0].dp_table.size(), false), std::vector<bool>(tables[1].dp_table.size(), false) };
+    for (uint32_t s2 = 0; s2 < 2; ++s2)
+        for (size_t x = 0; x < tables[s2].dp_table.size(); ++x) starts.emplace_back(tables[s2].dp_table[x].chain_score, s2, -(ptrdiff_t)x);
+    if (starts.empty()) return { num_seeds, num_nodes };
+    std::sort(starts.begin(), starts.end(), std::greater<std::tuple<score_t, uint32_t, ptrdiff_t>>());
+    score_t last_chain_score = std::numeric_limits<score_t>::min();
+    std::unordered_multiset<Chain, ChainHash> chains;
+    auto flush_chains = [&]() {
+        auto it = chains.begin();
+        Chain last_chain = *it;
+        for (++it; it != chains.end(); ++it) {
+            const Chain &chain = *it;
+            if (chain != last_chain) {
+                callback(std::move(last_chain), last_chain_score);
+                last_chain = *it;
+                continue;
+            }
+            // the same seeds as the chain before: their label / coordinate sets are merged (:137-180)
+            for (size_t x = 0; x < chain.size(); ++x) {
+                Columns columns;
+                Alignment &mine = last_chain[x].first;
+                const Alignment &theirs = chain[x].first;
+                if (theirs.label_coordinates.size()) {
+                    CoordinateSet coord_union;
+                    size_t a = 0, b = 0;
+                    while (a < mine.label_columns.size() || b < theirs.label_columns.size()) {      // match_indexed_values with both diffs
+                        if (a == mine.label_columns.size()) {
+                            columns.push_back(theirs.label_columns[b]); coord_union.push_back(theirs.label_coordinates[b]); ++b;
+                        } else if (b == theirs.label_columns.size() || mine.label_columns[a] < theirs.label_columns[b]) {
+                            columns.push_back(mine.label_columns[a]); coord_union.push_back(mine.label_coordinates[a]); ++a;
+                        } else {
+                            if (mine.label_columns[a] == theirs.label_columns[b]) {
+                                columns.push_back(mine.label_columns[a]);
+                                coord_union.emplace_back();
+                                std::set_union(mine.label_coordinates[a].begin(), mine.label_coordinates[a].end(),
+                                               theirs.label_coordinates[b].begin(), theirs.label_coordinates[b].end(),
+                                               std::back_inserter(coord_union.back()));
+                                ++a;
+                            } else {
+                                columns.push_back(theirs.label_columns[b]); coord_union.push_back(theirs.label_coordinates[b]);
+                            }
+                            ++b;
+                        }
+                    }
+                    std::swap(mine.label_coordinates, coord_union);
+                } else {
+                    std::set_union(mine.label_columns.begin(), mine.label_columns.end(), theirs.label_columns.begin(),
+                                   theirs.label_columns.end(), std::back_inserter(columns));
+                }
+                std::swap(mine.label_columns, columns);
+            }
+        }
+        callback(std::move(last_chain), last_chain_score);
+        chains.clear();
+    };
+    for (const auto &[chain_score, j, neg_i] : starts) {
+        std::vector<bool> &used = both_used[j];
+        uint32_t i = (uint32_t)(-neg_i);
+        if (used[i]) continue;
+        const std::vector<TableElem> &dp_table = tables[j].dp_table;
+        const std::vector<Seed> &seeds = both_seeds[j];
+        const std::vector<uint32_t> &seed_backtrace = tables[j].backtrace;
+        std::vector<std::pair<Seed, int64_t>> chain_seeds_v;
+        while (i != kNid) {
+            const TableElem &e = dp_table[i];
+            if (skip_column(e.label)) break;
+            used[i] = true;
+            chain_seeds_v.emplace_back(seeds[e.current_seed_index], e.coordinate);
+            // (has_labels: the aligner is a LabeledAligner) one label, one coordinate per chain seed
+            chain_seeds_v.back().first.label_columns.assign(1, e.label);
+            chain_seeds_v.back().first.label_coordinates.assign(1, Tuple(1, e.coordinate));
+            i = seed_backtrace[i];
+        }
+        if (chain_seeds_v.empty()) continue;
+        // overlapping seeds whose query and coordinate shifts agree are merged (:214-243)
+        for (size_t x = chain_seeds_v.size() - 1; x > 0; --x) {
+            Seed &cur_seed = chain_seeds_v[x].first;
+            Seed &prev_seed = chain_seeds_v[x - 1].first;
+            const size_t prev_end = prev_seed.clipping + prev_seed.query_view.size();
+            if (prev_end > cur_seed.clipping) {
+                const size_t coord_dist = (size_t)(cur_seed.label_coordinates[0][0] + (int64_t)cur_seed.query_view.size()
+                                                   - prev_seed.label_coordinates[0][0] - (int64_t)prev_seed.query_view.size());
+                const size_t dist = cur_seed.clipping + cur_seed.query_view.size() - prev_end;
+                if (dist == coord_dist && cur_seed.nodes.size() >= dist) {
+                    prev_seed.expand(std::vector<node_t>(cur_seed.nodes.end() - dist, cur_seed.nodes.end()));
+                    cur_seed = Seed();
+                }
+            }
+        }
+        auto drop_empty = [&]() {
+            chain_seeds_v.erase(std::remove_if(chain_seeds_v.begin(), chain_seeds_v.end(),
+                                               [](const std::pair<Seed, int64_t> &a) { return a.first.empty(); }), chain_seeds_v.end());
+        };
+        drop_empty();
+        // "Drop coord-redundant seeds": two consecutive seeds with the same reference coordinate — the longer one stays (:248-274)
+        for (size_t x = chain_seeds_v.size(); x-- > 1;) {
+            Seed &prev_seed = chain_seeds_v[x - 1].first;
+            Seed &cur_seed = chain_seeds_v[x].first;
+            if (prev_seed.empty() || cur_seed.empty()) continue;
+            if (chain_seeds_v[x - 1].second == chain_seeds_v[x].second) {
+                if (prev_seed.query_view.size() <= cur_seed.query_view.size()) prev_seed = Seed(); else cur_seed = Seed();
+            }
+        }
+        drop_empty();
+        for (size_t x = chain_seeds_v.size() - 1; x > 0; --x) chain_seeds_v[x].second -= chain_seeds_v[x - 1].second;
+        chain_seeds_v[0].second = 0;
+        if (chain_seeds_v[0].first.label_columns.empty()) continue;
+        Chain chain;
+        chain.reserve(chain_seeds_v.size());
+        for (const auto &c : chain_seeds_v) chain.emplace_back(Alignment(c.first, config), c.second);
+        if (chains.empty()) { chains.emplace(std::move(chain)); last_chain_score = chain_score; continue; }
+        if (chain_score == last_chain_score) { chains.emplace(std::move(chain)); continue; }
+        flush_chains();
+        chains.emplace(std::move(chain));
+        last_chain_score = chain_score;
+    }
+    flush_chains();
+    return { num_seeds, num_nodes };
+}
+
+// split_seed (dbg_aligner.cpp:63-100): all but the last k characters of the alignment, and its last k-mer
+std::pair<Alignment, Alignment> split_seed(size_t k, const mgx_config &config, const Alignment &alignment) {
+    if (alignment.sequence.size() < k * 2 || std::find(alignment.nodes.begin(), alignment.nodes.end(), NPOS) != alignment.nodes.end())
+        return std::make_pair(Alignment(), alignment);
+    std::pair<Alignment, Alignment> ret(alignment, alignment);
+    ret.first.trim_reference_suffix(k, config, false);
+    size_t trim_nodes = k;                               // "ensure that there's no DELETION at the splice point"
+    if (ret.first.size()) {
+        auto it = ret.first.cigar.ops.rbegin();
+        if (it->first == MGX_OP_CLIPPED) ++it;
+        if (it->first == MGX_OP_DELETION) {
+            const size_t n_del = it->second;
+            trim_nodes += n_del;
+            ret.first.trim_reference_suffix(n_del, config, false);
+        }
+    }
+    ret.second.trim_reference_prefix(alignment.sequence.size() - trim_nodes, k - 1, config, true);
+    return ret;
+}
+
+// align_connect (dbg_aligner.cpp:151-191): `first` is extended until it reaches the end of `second`; false: the connection
+// failed, `first` went to partial_alignments and `second` takes its place
+bool align_connect(size_t k, const mgx_config &config, Alignment &first, Alignment &second, int64_t coord_dist, Extender &extender,
+                   std::vector<Alignment> &partial_alignments) {
+    auto [left, next] = split_seed(k, config, first);
+    coord_dist += (int64_t)second.sequence.size() + (int64_t)next.sequence.size() - (int64_t)first.sequence.size();
+    auto extensions = extender.get_extensions(next, NINF /* min_path_score */, true /* force_fixed_seed */, (size_t)coord_dist /* target_length */,
+                                              second.nodes.back() /* target_node */, false /* trim_offset_after_extend */,
+                                              second.get_end_clipping() /* trim_query_suffix */, first.score - next.score /* added_xdrop */);
+    if (extensions.size() && extensions[0].get_end_clipping() < first.get_end_clipping()) {
+        left.splice(std::move(extensions[0]));
+        std::swap(left, first);
+        if (first.score >= second.score) return true;
+    }
+    partial_alignments.emplace_back(first);
+    std::swap(first, second);
+    return false;
+}
+
+// extend_chain (dbg_aligner.cpp:385-529): a full alignment from a chain — the query between consecutive chain seeds is aligned
+// to the graph (align_connect); pieces that could not be connected are spliced with runs of unknown characters where their
+// coordinates allow (splice_with_unknown); the best piece is extended to both ends of the query
+void extend_chain(std::string_view query, std::string_view query_rc, Extender &extender, Chain &&chain, const CanonicalView *canon,
+                  AnnotationBuffer *annotation_buffer, const std::function<void(Alignment &&)> &callback) {
+    const Graph &graph = extender.graph();
+    const mgx_config &config = extender.config();
+    const size_t k = graph.get_k();
+    LocalAlignmentLess less;
+    Alignment cur = std::move(chain[0].first);
+    Alignment best = cur;
+    std::vector<Alignment> partial_alignments;
+    std::vector<int64_t> coord_offsets{ 0 };
+    int64_t coord_offset = 0;
+    for (size_t i = 1; i < chain.size(); ++i) {
+        coord_offset += chain[i].second;
+        if (!align_connect(k, config, cur, chain[i].first, coord_offset, extender, partial_alignments)) {
+            if (less(best, partial_alignments.back())) best = partial_alignments.back();
+            coord_offsets.push_back(coord_offset);
+            coord_offset = 0;
+        }
+        if (less(best, cur)) best = cur;
+    }
+    if (partial_alignments.size()) {
+        partial_alignments.emplace_back(cur);
+        Alignment *first = &partial_alignments[0];
+        for (size_t i = 1; i < partial_alignments.size(); ++i) {
+            Alignment &next = partial_alignments[i];
+            if (next.sequence.size() < k) { first = &next; continue; }
+            const int64_t num_unknown = coord_offsets[i] - (int64_t)first->sequence.size();
+            if (num_unknown > 0 && (int64_t)next.get_clipping() > num_unknown) {
+                Alignment merged = *first;
+                Alignment next_fixed = next;
+                next_fixed.trim_offset();
+                merged.splice_with_unknown(std::move(next_fixed), (size_t)num_unknown, k - 1, config);
+                if (merged.size()) std::swap(*first, merged);
+                else { first = &next; continue; }
+            } else {
+                first = &next;
+                continue;
+            }
+            if (less(best, *first)) best = *first;
+        }
+        if (less(best, *first)) best = *first;
+    }
+    if (best.get_end_clipping()) {                       // "Extending back"
+        auto extensions = extender.get_extensions(best, NINF, true);
+        if (extensions.size() && extensions[0].get_end_clipping() < best.get_end_clipping() && extensions[0].score > best.score)
+            std::swap(best, extensions[0]);
+    }
+    best.trim_offset();
+    if (best.get_clipping()) {                           // "Extending front": on the reverse-complement view of the graph
+        const bool use_rcdbg = graph.mode != CANONICAL;
+        GraphView rc_view{ &graph, use_rcdbg, canon };
+        Alignment rev = best;
+        rev.reverse_complement(rc_view, query_rc);
+        if (rev.size() && rev.nodes.back()) {
+            Extender extender_rc(graph, config, query_rc, nullptr, canon, annotation_buffer);
+            extender_rc.set_graph(use_rcdbg);
+            auto extensions = extender_rc.get_extensions(rev, NINF, true);
+            if (extensions.size() && extensions[0].get_end_clipping() < rev.get_end_clipping()) {
+                extensions[0].reverse_complement(rc_view, query);
+                if (extensions[0].size()) std::swap(best, extensions[0]);
+            }
+        }
+    }
+    callback(std::move(best));
+    for (Alignment &aln : partial_alignments) if (!aln.empty()) callback(std::move(aln));
+}
+
 // get_num_char_matches_in_seeds (A/alignment.hpp:100-127).  Quirk kept: `aln` refers to the seed that has the offset, so the
 // inner loop's condition does not change and runs to the end — nothing after the first sub-k seed is counted.
 size_t get_num_char_matches_in_seeds(const std::vector<Seed> &seeds) {
@@ -2004,6 +2849,31 @@ void Annotation::annotate_sequence(const Graph &graph, std::string_view sequence
     for (node_t v : nodes) if (v > 0) set(v - 1, column);
 }
 
+void Annotation::annotate_kmer_coords(const Graph &graph, std::string_view sequence, size_t column, uint64_t start) {
+    // annotated_dbg.cpp:192-233: map_to_nodes over the sequence, the coordinate counts every k-mer (found or not)
+    if (sequence.size() < graph.get_k()) return;
+    has_coordinates = true;
+    uint64_t coord = start;
+    for (node_t v : graph.map_to_nodes(sequence)) {
+        if (v > 0) {
+            set(v - 1, column);
+            Tuple &t = coordinates[column][v - 1];
+            t.insert(std::upper_bound(t.begin(), t.end(), (int64_t)coord), (int64_t)coord);
+        }
+        ++coord;
+    }
+}
+
+std::vector<std::pair<Label, Tuple>> Annotation::get_row_tuples(uint64_t row) const {
+    std::vector<std::pair<Label, Tuple>> out;
+    for (size_t j = 0; j < columns.size(); ++j) {
+        if (row >= n_rows || !get(row, j)) continue;
+        auto it = coordinates[j].find(row);
+        out.emplace_back((Label)j, it == coordinates[j].end() ? Tuple{} : it->second);
+    }
+    return out;
+}
+
 // =============================================================================================
 // LabeledAligner (A/aligner_labeled.cpp:450-721 + DBGAligner::align_batch / align_both_directions with labeled seeds)
 // =============================================================================================
@@ -2019,9 +2889,15 @@ LabeledAligner::LabeledAligner(const Graph &graph, const mgx_config &config, con
     config_.max_seed_length = hi;
     if (!check_config_scores(config_))
         throw std::runtime_error("Error: sum of min_cell_score and lowest penalty too low.");
-    if (config_.chain_alignments || config_.post_chain_alignments || !config_.global_xdrop || config_.no_backtrack)
-        throw std::runtime_error("oracle: chaining / per-branch xdrop / no_backtrack are out of scope");
-    // ... then LabeledAligner's (aligner_labeled.cpp:463-465; no coordinates: no chaining)
+    if (config_.chain_alignments || config_.post_chain_alignments || config_.no_backtrack)
+        throw std::runtime_error("oracle: chain_alignments set by the caller / post-chaining of labeled alignments / no_backtrack are out of scope");
+    // (dbg_aligner.cpp:58-60 ran with the caller's chain_alignments == false: allow_left_trim stays as configured)
+    // ... then LabeledAligner's (aligner_labeled.cpp:456-465): "do not use a global xdrop cutoff since we need separate cutoffs
+    // for each label"; coordinates switch seed chaining on (AnnotationBuffer::has_coordinates: BASIC graphs only)
+    if (annotation_.has_coordinates && graph_.mode == BASIC) {
+        config_.global_xdrop = 0;
+        config_.chain_alignments = 1;
+    }
     config_.min_seed_length = std::min<uint64_t>(k, config_.min_seed_length);
     config_.max_seed_length = std::min<uint64_t>(k, config_.max_seed_length);
 }
@@ -2071,9 +2947,21 @@ size_t filter_seeds(std::vector<Seed> &seeds, const AnnotationBuffer &ab, const 
     for (Seed &seed : seeds) {
         if (!seed.has_label_encoder) {
             seed.label_columns.clear();
-            const Columns *fetch_labels = ab.get_labels(seed.nodes[0]);
-            std::set_intersection(fetch_labels->begin(), fetch_labels->end(), labels.begin(), labels.end(),
-                                  std::back_inserter(seed.label_columns));
+            auto [fetch_labels, fetch_coords] = ab.get_labels_and_coords(seed.nodes[0]);
+            if (ab.has_coordinates()) {
+                // matched_intersection (:594-610): the kept labels with the node's coordinates; a sub-k seed's coordinates are
+                // those of its first nucleotide (:693-699)
+                size_t a = 0, b = 0;
+                while (a < fetch_labels->size() && b < labels.size()) {
+                    if ((*fetch_labels)[a] < labels[b]) ++a;
+                    else if ((*fetch_labels)[a] > labels[b]) ++b;
+                    else { seed.label_columns.push_back((*fetch_labels)[a]); seed.label_coordinates.push_back((*fetch_coords)[a]); ++a; ++b; }
+                }
+                if (seed.offset) for (Tuple &tuple : seed.label_coordinates) for (int64_t &coord : tuple) coord += (int64_t)seed.offset;
+            } else {
+                std::set_intersection(fetch_labels->begin(), fetch_labels->end(), labels.begin(), labels.end(),
+                                      std::back_inserter(seed.label_columns));
+            }
             if (seed.label_columns.size()) seed.has_label_encoder = true;
         }
     }
@@ -2145,6 +3033,47 @@ void LabeledAligner::align_batch(const std::vector<std::string> &queries, std::v
         Extender extender(graph_, config_, this_query, nullptr, canon, &annotation_buffer);
         if (qs.has_rc) {
             Extender extender_rc(graph_, config_, reverse, nullptr, canon, &annotation_buffer);
+            if (config_.chain_alignments) {
+                // align_both_directions, the chaining branch (dbg_aligner.cpp:545-644): chains of seeds with consistent coordinates,
+                // best first; each is extended seed to seed (extend_chain); a label is finished once the aggregator turns an
+                // alignment of it away
+                if (!annotation_buffer.has_coordinates()) throw std::runtime_error("Chaining only supported for seeds with coordinates");
+                std::vector<Seed> fwd_chain_seeds = qs.fwd, bwd_chain_seeds = qs.rc;
+                if (!(fwd_chain_seeds.empty() && bwd_chain_seeds.empty())) {
+                    LabeledAggregator chain_aggregator(config_);
+                    std::set<Label> all_columns, finished_columns;
+                    for (const Seed &seed : fwd_chain_seeds) all_columns.insert(seed.label_columns.begin(), seed.label_columns.end());
+                    for (const Seed &seed : bwd_chain_seeds) all_columns.insert(seed.label_columns.begin(), seed.label_columns.end());
+                    try {
+                        call_seed_chains_both_strands(this_query, reverse, config_, std::move(fwd_chain_seeds), std::move(bwd_chain_seeds),
+                            [&](Chain &&chain, score_t) {
+                                if (config_.num_alternative_paths <= 1 && finished_columns.size() == all_columns.size()) throw early_term();
+                                const double exact_match_fraction = static_cast<double>(get_num_char_matches_in_chain(chain)) / this_query.size();
+                                if (exact_match_fraction < config_.min_exact_match) throw early_term();
+                                const bool rev = chain[0].first.orientation;
+                                extend_chain(rev ? reverse : this_query, rev ? this_query : reverse, rev ? extender_rc : extender,
+                                             std::move(chain), canon, &annotation_buffer,
+                                             [&](Alignment &&aln) {
+                                                 const Columns cur_columns = aln.label_columns;
+                                                 if (!chain_aggregator.add_alignment(std::move(aln)))
+                                                     finished_columns.insert(cur_columns.begin(), cur_columns.end());
+                                             });
+                            },
+                            [&](Label column) { return finished_columns.count(column) != 0; });
+                    } catch (const early_term &) {}
+                    for (Alignment &alignment : chain_aggregator.get_alignments()) {
+                        if (alignment.score < get_min_path_score(alignment)) continue;
+                        if (graph_.mode == CANONICAL && alignment.orientation) {
+                            Alignment rev(alignment);
+                            rev.reverse_complement(gview, this_query);
+                            if (rev.size()) std::swap(rev, alignment);
+                        }
+                        add_alignment(std::move(alignment));
+                    }
+                }
+                res.alignments = aggregator.get_alignments();
+                continue;
+            }
             auto fwd_seeds = seeds_to_alignments(qs.fwd, config_);
             auto bwd_seeds = seeds_to_alignments(qs.rc, config_);
             // align_both_directions (dbg_aligner.cpp:531-758), the branch without chaining

@@ -10,6 +10,7 @@
 //   * Priority-Deque / std::sort tie order for num_alternative_paths > 1: parity unpinned.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -43,6 +44,8 @@ struct Cigar {
 
 typedef uint64_t Label;                      // annotation column = label id (annot::matrix::BinaryMatrix::Column)
 typedef std::vector<Label> Columns;          // Alignment::Columns: a sorted label set
+typedef std::vector<int64_t> Tuple;          // Alignment::Tuple (alignment.hpp:137): the coordinates of one label, ascending
+typedef std::vector<Tuple> CoordinateSet;    // Alignment::CoordinateSet: one Tuple per entry of label_columns
 
 // A/alignment.hpp:32-98
 struct Seed {
@@ -52,7 +55,15 @@ struct Seed {
     size_t offset = 0;
     uint32_t clipping = 0, end_clipping = 0;
     Columns label_columns;                   // :84 (filled by LabeledAligner::filter_seeds)
+    CoordinateSet label_coordinates;         // :86-89 coordinates of the seed's first nucleotide, per label
     bool has_label_encoder = false;          // :82 label_encoder != nullptr
+    bool empty() const { return nodes.empty(); }
+    // :74-80: more nodes for the seed; the query has |next| further characters and the path still spells the view
+    void expand(const std::vector<node_t> &next) {
+        query_view = std::string_view(query_view.data(), query_view.size() + next.size());
+        end_clipping -= next.size();
+        nodes.insert(nodes.end(), next.begin(), next.end());
+    }
 };
 
 // A/alignment.hpp:132-331
@@ -65,7 +76,8 @@ struct Alignment {
     score_t score = 0;
     Cigar cigar;
     score_t extra_score = 0;
-    Columns label_columns;                   // alignment.hpp:285 (coordinates: not restated)
+    Columns label_columns;                   // alignment.hpp:285
+    CoordinateSet label_coordinates;         // :287-290 per label: the coordinates of the alignment's first nucleotide
 
     Alignment() {}
     Alignment(std::string_view query, std::vector<node_t> &&nodes_, std::string &&seq, score_t score_,
@@ -81,7 +93,16 @@ struct Alignment {
     size_t trim_offset();                                            // alignment.cpp:177-190
     size_t trim_clipping() { return cigar.trim_clipping(); }         // alignment.hpp:224
     size_t trim_end_clipping() { return cigar.trim_end_clipping(); } // alignment.hpp:225
-    bool append(Alignment &&other);                                  // alignment.cpp:94-175 (no coordinates)
+    bool append(Alignment &&other);                                  // alignment.cpp:94-175
+    bool splice(Alignment &&other);                                  // alignment.hpp:196-205
+    size_t trim_query_suffix(size_t n, const mgx_config &config, bool trim_excess_deletions = true);                          // :280-362
+    size_t trim_reference_prefix(size_t n, size_t node_overlap, const mgx_config &config, bool trim_excess_insertions = true); // :364-455
+    size_t trim_reference_suffix(size_t n, const mgx_config &config, bool trim_excess_insertions = true);                     // :457-538
+    void splice_with_unknown(Alignment &&other, size_t num_unknown, size_t node_overlap, const mgx_config &config);           // :1048-1152
+    std::string format_coords(const std::vector<std::string> &label_names) const;                                             // :20-37
+    // :39-92 with annot::CoordToHeader as (headers, k-mer counts) per column
+    std::string format_coords(const std::vector<std::vector<std::string>> &headers, const std::vector<std::vector<uint64_t>> &kmer_counts,
+                              size_t k) const;
     size_t trim_query_prefix(size_t n, size_t node_overlap, const mgx_config &config, bool trim_excess_deletions = true); // :192-278
     void insert_gap_prefix(ptrdiff_t gap_length, size_t node_overlap, const mgx_config &config);                        // :1154-1234
     void reverse_complement(const GraphView &graph, std::string_view query_rev_comp); // alignment.cpp:540-702
@@ -149,7 +170,19 @@ class Aligner {
 struct Annotation {
     uint64_t n_rows = 0;
     std::vector<std::vector<uint64_t>> columns;
-    void resize(uint64_t rows, size_t n_columns) { n_rows = rows; columns.assign(n_columns, std::vector<uint64_t>((rows + 63) / 64, 0)); }
+    // k-mer coordinates (annot::matrix::MultiIntMatrix behind a ColumnCoordAnnotator): per column, row -> ascending coordinates.
+    // has_coordinates: AnnotationBuffer::has_coordinates() (annotation_buffer.hpp) — the annotator carries a MultiIntMatrix.
+    bool has_coordinates = false;
+    std::vector<std::map<uint64_t, Tuple>> coordinates;
+    void resize(uint64_t rows, size_t n_columns) {
+        n_rows = rows; columns.assign(n_columns, std::vector<uint64_t>((rows + 63) / 64, 0));
+        coordinates.assign(n_columns, {});
+    }
+    // AnnotatedDBG::annotate_kmer_coords (annotated_dbg.cpp:192-233) for one (sequence, { label }, first coordinate): the i-th
+    // k-mer of the sequence has coordinate start + i, recorded for the k-mers found in the graph
+    void annotate_kmer_coords(const Graph &graph, std::string_view sequence, size_t column, uint64_t start);
+    // MultiIntMatrix::get_row_tuples for one row: (column, coordinates) pairs, columns ascending
+    std::vector<std::pair<Label, Tuple>> get_row_tuples(uint64_t row) const;
     void set(uint64_t row, size_t column) { columns[column][row >> 6] |= 1ull << (row & 63); }
     bool get(uint64_t row, size_t column) const { return (columns[column][row >> 6] >> (row & 63)) & 1; }
     std::vector<Columns> get_rows(const std::vector<uint64_t> &rows) const;      // column_major.cpp:27-44 (labels ascending)
@@ -157,8 +190,11 @@ struct Annotation {
     void annotate_sequence(const Graph &graph, std::string_view sequence, size_t column);
 };
 
-// LabeledAligner<SuffixSeeder<ExactSeeder>, LabeledExtender, LocalAlignmentLess> (A/aligner_labeled.{hpp,cpp}), annotation
-// without coordinates: seeds are filtered by label (build_seeders :479-558, filter_seeds :612-721), every column of the DP
+// LabeledAligner<SuffixSeeder<ExactSeeder>, LabeledExtender, LocalAlignmentLess> (A/aligner_labeled.{hpp,cpp}).  Annotation
+// with coordinates (round 6): the constructor switches seed chaining on and the global x-drop off
+// (aligner_labeled.cpp:457-462) — chain_seeds / call_seed_chains_both_strands (aligner_chainer.cpp:64-542), extend_chain /
+// align_connect (dbg_aligner.cpp:155-250,388-529), coordinate-consistent call_outgoing and call_alignments
+// (aligner_labeled.cpp:245-300,361-448).  Annotation without coordinates: seeds are filtered by label (build_seeders :479-558, filter_seeds :612-721), every column of the DP
 // table carries a label set that is intersected along the tree (LabeledExtender::call_outgoing :176-302, flush :81-137),
 // backtracking reports one alignment per not-yet-seen seed label set (skip_backtrack_start :304-326, call_alignments
 // :328-448), the aggregator keeps a queue per label (aligner_aggregator.hpp:68-138).

@@ -36,6 +36,12 @@ struct ResultStore {
     std::string error;
     // label-aware runs: the label set of every alignment (same order as `alignments`)
     std::vector<uint64_t> label_begin, labels;
+    // ... and, for annotations with coordinates, the coordinates of every label entry: entry e of `labels` has
+    // coords[coord_begin[e] .. coord_begin[e + 1]) (Alignment::label_coordinates); kept alignments for format_coords
+    std::vector<uint64_t> coord_begin;
+    std::vector<int64_t> coords;
+    std::vector<AlignmentResults> kept;
+    std::string scratch;
 };
 
 void flatten(const std::vector<AlignmentResults> &res, ResultStore *st, int32_t min_path_score) {
@@ -58,6 +64,11 @@ void flatten(const std::vector<AlignmentResults> &res, ResultStore *st, int32_t 
             if (st->label_begin.empty()) st->label_begin.push_back(0);
             st->labels.insert(st->labels.end(), a.label_columns.begin(), a.label_columns.end());
             st->label_begin.push_back(st->labels.size());
+            if (st->coord_begin.empty()) st->coord_begin.push_back(0);
+            for (size_t e = 0; e < a.label_columns.size(); ++e) {
+                if (e < a.label_coordinates.size()) st->coords.insert(st->coords.end(), a.label_coordinates[e].begin(), a.label_coordinates[e].end());
+                st->coord_begin.push_back(st->coords.size());
+            }
         }
         st->aln_begin.push_back(st->alignments.size());
         st->status.push_back(MGX_OK);
@@ -341,10 +352,45 @@ void *orc_align_batch_labeled(void *h, const mgx_config *config, void *annotatio
                 }
         }
         flatten(res, st, config->min_path_score);
+        st->kept = std::move(res);                       // (the alignments' string_views point into the results' own query strings)
     } catch (const std::exception &e) {
         st->error = e.what();
     }
     return st;
+}
+// AnnotatedDBG::annotate_kmer_coords for one (sequence, { label }, first coordinate)
+int orc_annotation_annotate_coords(void *a, void *graph, const char *seq, uint32_t len, uint32_t label, uint64_t start) {
+    try { static_cast<Annotation *>(a)->annotate_kmer_coords(*static_cast<Graph *>(graph), std::string_view(seq, len), label, start); }
+    catch (const std::exception &) { return 1; }
+    return 0;
+}
+// coordinates of the label entries of a labeled run (see ResultStore)
+void orc_results_coords(void *r, const uint64_t **coord_begin, const int64_t **coords) {
+    auto *st = static_cast<ResultStore *>(r);
+    if (st->coord_begin.empty()) st->coord_begin.push_back(0);
+    *coord_begin = st->coord_begin.data();
+    *coords = st->coords.data();
+}
+// Alignment::format_coords(CoordToHeader(headers, kmer_counts), k) of alignment `ai` of query `q`: one column (label 0 .. ), its
+// sequences' headers as a '\n'-separated string per column ('\t' between columns) and their k-mer counts flattened likewise
+const char *orc_results_format_coords(void *r, uint64_t q, uint64_t ai, const char *headers, const uint64_t *kmer_counts,
+                                      const uint64_t *n_seqs_per_column, uint32_t n_columns, uint32_t k) {
+    auto *st = static_cast<ResultStore *>(r);
+    std::vector<std::vector<std::string>> hs(n_columns);
+    std::vector<std::vector<uint64_t>> kc(n_columns);
+    const char *p = headers;
+    size_t flat = 0;
+    for (uint32_t c = 0; c < n_columns; ++c) {
+        for (uint64_t x = 0; x < n_seqs_per_column[c]; ++x) {
+            const char *e = p;
+            while (*e && *e != '\n' && *e != '\t') ++e;
+            hs[c].emplace_back(p, e);
+            p = *e ? e + 1 : e;
+            kc[c].push_back(kmer_counts[flat++]);
+        }
+    }
+    st->scratch = st->kept.at(q).alignments.at(ai).format_coords(hs, kc, k);
+    return st->scratch.c_str();
 }
 // label sets of the alignments of a run, in the order of mgx_results.alignments
 void orc_results_labels(void *r, const uint64_t **begin, const uint64_t **labels) {

@@ -248,6 +248,14 @@ class Annotation:
         if L().orc_annotation_annotate(self.h, self.graph.h, b, len(b), label, err, 256):
             raise RuntimeError(err.value.decode())
 
+    def annotate_coords(self, seq, label, start=0):
+        """AnnotatedDBG::annotate_kmer_coords([(seq, [label], start)]): the i-th k-mer of seq has coordinate start + i"""
+        lib = L()
+        lib.orc_annotation_annotate_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint64]
+        b = seq.encode()
+        if lib.orc_annotation_annotate_coords(self.h, self.graph.h, b, len(b), label, start):
+            raise RuntimeError("annotate_kmer_coords failed")
+
     def get_rows(self, rows):
         """-> one ascending label list per requested row (row = node - 1)"""
         n = len(rows)
@@ -286,6 +294,36 @@ class LabeledAlignRun(AlignRun):
                                              offs.ctypes.data_as(C.POINTER(C.c_uint64)), len(queries), int(validate))
         self.error = lib.orc_results_error(self.r).decode()
         self.n = len(queries)
+
+    def coordinates(self):
+        """-> per query, per alignment: one coordinate list per label of labels() (Alignment::label_coordinates)"""
+        v = capi.Results()
+        L().orc_results_view(self.r, C.byref(v))
+        begin = C.POINTER(C.c_uint64)()
+        labs = C.POINTER(C.c_uint64)()
+        L().orc_results_labels.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint64))]
+        L().orc_results_labels(self.r, C.byref(begin), C.byref(labs))
+        cb = C.POINTER(C.c_uint64)()
+        co = C.POINTER(C.c_int64)()
+        L().orc_results_coords.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_int64))]
+        L().orc_results_coords(self.r, C.byref(cb), C.byref(co))
+        out = []
+        for q in range(self.n):
+            out.append([[[co[x] for x in range(cb[e], cb[e + 1])] for e in range(begin[a], begin[a + 1])]
+                        for a in range(v.aln_begin[q], v.aln_begin[q + 1])])
+        return out
+
+    def format_coords(self, q, ai, headers, kmer_counts, k):
+        """Alignment::format_coords(CoordToHeader(headers, kmer_counts), k): headers / kmer_counts = one list per column"""
+        lib = L()
+        lib.orc_results_format_coords.restype = C.c_char_p
+        lib.orc_results_format_coords.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64),
+                                                  C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32]
+        flat_h = "\t".join("\n".join(col) for col in headers).encode()
+        flat_c = [c for col in kmer_counts for c in col]
+        n_per = [len(col) for col in headers]
+        return lib.orc_results_format_coords(self.r, q, ai, flat_h, (C.c_uint64 * max(1, len(flat_c)))(*flat_c),
+                                             (C.c_uint64 * max(1, len(n_per)))(*n_per), len(headers), k).decode()
 
     def labels(self):
         """-> per query: the label list of each of its alignments"""
