@@ -380,6 +380,38 @@ uint32_t mgx_annotation_num_labels(const mgx_annotation *a);
 int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n, int rows_on_device,
                             uint64_t *out_begin, uint32_t *out_labels, uint64_t cap, int out_on_device, uint64_t *n_labels_out);
 
+/* k-mer coordinates (annot::ColumnCoordAnnotator: a MultiIntMatrix next to the binary matrix; AnnotationBuffer::has_coordinates,
+ * annotation_buffer.cpp:26-33) for an annotation created from the same n_labels / col_begin / rows with
+ * mgx_annotation_create_sparse: pair x (label j = the column whose range holds x, row rows[x]) has the ascending coordinates
+ * coords[coord_begin[x] .. coord_begin[x + 1]).  Host arrays.  Round 6: the annotation and its batched lookup
+ * (mgx_annotation_get_row_tuples = MultiIntMatrix::get_row_tuples, what AnnotationBuffer::fetch_queued_annotations calls,
+ * annotation_buffer.cpp:166-181) are on the device; LabeledAligner's coordinate mode itself (seed chaining,
+ * aligner_labeled.cpp:457-462) is not — mgx_labeled_aligner_create refuses such an annotation (MGX_ERR_UNSUPPORTED). */
+int mgx_annotation_set_coordinates(mgx_annotation *a, uint32_t n_labels, const uint64_t *col_begin, const uint64_t *rows,
+                                   const uint64_t *coord_begin, const int64_t *coords);
+int mgx_annotation_has_coordinates(const mgx_annotation *a);
+int mgx_annotation_get_row_tuples(mgx_annotation *a, const uint64_t *rows, uint64_t n, uint64_t *out_begin, uint32_t *out_labels,
+                                  uint64_t label_cap, uint64_t *out_coord_begin, int64_t *out_coords, uint64_t coord_cap,
+                                  uint64_t *n_labels_out, uint64_t *n_coords_out);
+
+/* chain_seeds (aligner_chainer.cpp:341-542) — the anchor DP of seed chaining, on the device.  An anchor is one (seed, label,
+ * coordinate) of a (query, strand): the reference's TableElem (aligner_chainer.cpp:23-36, same 32 bytes).  Input: the anchors of
+ * n_lists lists (list l = anchors[list_begin[l] .. list_begin[l + 1])) in any order, chain_score = the seed's length
+ * (seed_end - seed_clipping), query_size[l] = the length of the list's query; config->min_seed_length sets the gap cost.  Output:
+ * every list sorted as the reference sorts it — (label, coordinate, seed_clipping, seed_end) descending — with the final
+ * chain_score of every anchor, and backtrace_out[x] = the anchor (index relative to its list's begin, in the sorted order)
+ * anchor x's best chain continues with, 0xFFFFFFFF for none.  Bit-identical to the reference's AVX2 loop incl. the float gap
+ * cost (tabulated on the host with the host's libm).  At most 6144 anchors per list.  Host arrays. */
+typedef struct mgx_chain_anchor {
+    uint64_t label;
+    int64_t coordinate;
+    int32_t seed_clipping, seed_end;
+    int32_t chain_score;
+    uint32_t seed_index;
+} mgx_chain_anchor;
+int mgx_chain_seeds(const mgx_config *config, int device, const mgx_chain_anchor *anchors, const uint64_t *list_begin,
+                    const uint32_t *query_size, uint64_t n_lists, mgx_chain_anchor *sorted_out, uint32_t *backtrace_out);
+
 /* LabeledAligner<>(graph, config, annotator) (aligner_labeled.hpp:125-127; ctor aligner_labeled.cpp:450-466: DBGAligner's
  * clamps, then min / max_seed_length <= k): an aligner whose batches run label-aware — seeds filtered by label
  * (filter_seeds, aligner_labeled.cpp:612-721), every DP column carries the labels shared along its path

@@ -472,6 +472,7 @@ extern "C" int mgx_lab64_max_alt(void);
 extern "C" void mgx_annotation_device_view(const mgx_annotation *a, int *device, uint64_t *n_rows, const uint64_t **head,
                                            const uint32_t **count, const uint32_t **more);                    // mgx_annot.hip
 extern "C" uint64_t mgx_annotation_uid(const mgx_annotation *a);                                            // mgx_annot.hip
+extern "C" int mgx_annotation_has_coordinates(const mgx_annotation *a);                                     // mgx_annot.hip
 extern "C" int mgx_lane_waves_per_simd(void);
 extern "C" unsigned mgx_ext64_static_lds(void);
 extern "C" int mgx_ext64_waves_per_simd(void);
@@ -871,6 +872,12 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
         int adev = 0; uint64_t arows = 0; const uint64_t *h; const uint32_t *c, *m;
         mgx_annotation_device_view(anno, &adev, &arows, &h, &c, &m);
         if (adev != g->device) return fail(MGX_ERR_INVALID, "the annotation lives on device %d, the graph on device %d", adev, g->device);
+        // An annotation with coordinates makes LabeledAligner chain seeds (aligner_labeled.cpp:457-462: chain_alignments on, global
+        // x-drop off).  Of that mode the device has the annotation (mgx_annotation_get_row_tuples) and the chaining DP
+        // (mgx_chain_seeds); the extension between chain seeds (dbg_aligner.cpp:155-250,388-529) is not built: refused, so that
+        // the caller keeps the reference's aligner — never answered with the plain label-aware mode
+        if (mgx_annotation_has_coordinates(anno) && g->mode == MGX_MODE_BASIC)
+            return fail(MGX_ERR_UNSUPPORTED, "label-aware alignment with coordinates (seed chaining) is not on the device");
         if (arows < g->g.n) return fail(MGX_ERR_INVALID, "the annotation has %llu rows, the graph %llu nodes (row = node - 1)",
                                         (unsigned long long)arows, (unsigned long long)g->g.n);
     }

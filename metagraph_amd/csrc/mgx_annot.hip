@@ -154,6 +154,32 @@ __global__ void k_pairs_fill(const uint64_t *keys, uint64_t n_pairs, uint64_t n_
 }
 } // namespace
 
+// get_row_tuples: per requested row and label, the number of its coordinates, then the coordinates themselves
+__global__ void k_tuple_count(const uint64_t *row_entry, const uint64_t *coord_off, uint64_t n_rows, const uint64_t *rows, uint64_t n,
+                              const uint64_t *out_begin, uint64_t *out_cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = rows[i];
+    const uint64_t nl = out_begin[i + 1] - out_begin[i];
+    for (uint64_t t = 0; t < nl; ++t) {
+        uint64_t c = 0;
+        if (r < n_rows) { const uint64_t e = row_entry[r] + t; c = coord_off[e + 1] - coord_off[e]; }
+        out_cnt[out_begin[i] + t] = c;
+    }
+}
+__global__ void k_tuple_gather(const uint64_t *row_entry, const uint64_t *coord_off, const int64_t *coords, uint64_t n_rows,
+                               const uint64_t *rows, uint64_t n, const uint64_t *out_begin, const uint64_t *out_coord_begin, int64_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = rows[i];
+    if (r >= n_rows) return;
+    const uint64_t nl = out_begin[i + 1] - out_begin[i];
+    for (uint64_t t = 0; t < nl; ++t) {
+        const uint64_t e = row_entry[r] + t, o = out_coord_begin[out_begin[i] + t];
+        for (uint64_t x = coord_off[e]; x < coord_off[e + 1]; ++x) out[o + (x - coord_off[e])] = coords[x];
+    }
+}
+
 // every annotation object gets an id no other one of this process ever had: what is cached about an annotation elsewhere (the
 // per-graph "no dummy node's row holds a label" flag, mgx.hip) is keyed by it — pointers come back from malloc / hipMalloc after
 // a destroy + create and would hand a new annotation the old one's entry
@@ -169,6 +195,12 @@ struct mgx_annotation {
     uint32_t *count = nullptr;    // exact label count per row (rows with >= 0xFFFF labels need it; 4 B per row)
     uint32_t *more = nullptr;
     uint64_t bytes = 0;
+    // k-mer coordinates (annot::matrix::MultiIntMatrix behind a ColumnCoordAnnotator; mgx_annotation_set_coordinates), row-major
+    // like the labels: the labels of row r are entries row_entry[r] .. row_entry[r + 1) in the order of its label list, and
+    // entry e carries the ascending coordinates coords[coord_off[e] .. coord_off[e + 1])
+    uint64_t *row_entry = nullptr, *coord_off = nullptr;
+    int64_t *coords = nullptr;
+    uint64_t n_entries = 0, n_coords = 0;
     // scratch of get_rows, grown on demand; get_rows calls on one handle are serialised (workers of one process share the
     // annotation: mgx_align --devices, cli/align.cpp's thread pool)
     std::mutex rows_mutex;
@@ -316,6 +348,7 @@ void mgx_annotation_destroy(mgx_annotation *a) {
     (void)hipSetDevice(a->device);
     (void)hipFree(a->head); (void)hipFree(a->count); (void)hipFree(a->more);
     (void)hipFree(a->d_rows); (void)hipFree(a->d_begin); (void)hipFree(a->d_labels); (void)hipFree(a->d_tmp);
+    (void)hipFree(a->row_entry); (void)hipFree(a->coord_off); (void)hipFree(a->coords);
     delete a;
 }
 uint64_t mgx_annotation_device_bytes(const mgx_annotation *a) { return a ? a->bytes : 0; }
@@ -376,6 +409,100 @@ int mgx_annotation_get_rows(mgx_annotation *a, const uint64_t *rows, uint64_t n,
     HIP_TRY_A(hipGetLastError());
     if (!out_on_device && total) HIP_TRY_A(hipMemcpy(out_labels, d_labels, total * 4, hipMemcpyDeviceToHost));
     else HIP_TRY_A(hipDeviceSynchronize());
+    return MGX_OK;
+}
+
+
+/* k-mer coordinates of an annotation built from the columns' set rows (mgx_annotation_create_sparse with the same n_labels /
+ * col_begin / rows): the ascending coordinates of pair x — label j = the column whose range holds x, row rows[x] — are
+ * coords[coord_begin[x] .. coord_begin[x + 1]).  What annot::ColumnCoordAnnotator holds next to the binary matrix
+ * (annot::matrix::MultiIntMatrix::get_row_tuples); host arrays.  The row-major form the device keeps is built on the host: like
+ * everything about annotation CONSTRUCTION, outside the aligner's path. */
+int mgx_annotation_set_coordinates(mgx_annotation *a, uint32_t n_labels, const uint64_t *col_begin, const uint64_t *rows,
+                                   const uint64_t *coord_begin, const int64_t *coords) {
+    if (!a || !col_begin || n_labels != a->n_labels) return afail(MGX_ERR_INVALID, "mgx_annotation_set_coordinates: bad arguments");
+    const uint64_t n_pairs = col_begin[n_labels];
+    if (n_pairs && (!rows || !coord_begin)) return afail(MGX_ERR_INVALID, "mgx_annotation_set_coordinates: bad arguments");
+    if (mgx_device_count() <= a->device) return afail(MGX_ERR_NO_DEVICE, "no HIP device");
+    HIP_TRY_A(hipSetDevice(a->device));
+    // (row, label) -> pair index, rows ascending and labels ascending within a row: the order of the device's label lists
+    std::vector<std::pair<std::pair<uint64_t, uint32_t>, uint64_t>> order;
+    order.reserve(n_pairs);
+    for (uint32_t j = 0; j < n_labels; ++j)
+        for (uint64_t x = col_begin[j]; x < col_begin[j + 1]; ++x) {
+            if (rows[x] >= a->n_rows) return afail(MGX_ERR_INVALID, "mgx_annotation_set_coordinates: a row index is outside the matrix");
+            order.push_back({ { rows[x], j }, x });
+        }
+    std::sort(order.begin(), order.end());
+    std::vector<uint64_t> row_entry(a->n_rows + 1, 0), coord_off(n_pairs + 1, 0);
+    std::vector<int64_t> flat;
+    flat.reserve(n_pairs ? coord_begin[n_pairs] : 0);
+    for (uint64_t e = 0; e < n_pairs; ++e) {
+        const uint64_t x = order[e].second;
+        ++row_entry[order[e].first.first + 1];
+        for (uint64_t c = coord_begin[x]; c < coord_begin[x + 1]; ++c) {
+            if (c > coord_begin[x] && coords[c] < coords[c - 1]) return afail(MGX_ERR_INVALID, "mgx_annotation_set_coordinates: coordinates must be ascending");
+            flat.push_back(coords[c]);
+        }
+        coord_off[e + 1] = flat.size();
+    }
+    for (uint64_t r = 0; r < a->n_rows; ++r) row_entry[r + 1] += row_entry[r];
+    (void)hipFree(a->row_entry); (void)hipFree(a->coord_off); (void)hipFree(a->coords);
+    a->row_entry = a->coord_off = nullptr; a->coords = nullptr;
+    HIP_TRY_A(hipMalloc(&a->row_entry, row_entry.size() * 8));
+    HIP_TRY_A(hipMalloc(&a->coord_off, coord_off.size() * 8));
+    HIP_TRY_A(hipMalloc(&a->coords, std::max<size_t>(1, flat.size()) * 8));
+    HIP_TRY_A(hipMemcpy(a->row_entry, row_entry.data(), row_entry.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY_A(hipMemcpy(a->coord_off, coord_off.data(), coord_off.size() * 8, hipMemcpyHostToDevice));
+    if (flat.size()) HIP_TRY_A(hipMemcpy(a->coords, flat.data(), flat.size() * 8, hipMemcpyHostToDevice));
+    a->n_entries = n_pairs; a->n_coords = flat.size();
+    a->bytes += row_entry.size() * 8 + coord_off.size() * 8 + flat.size() * 8;
+    return MGX_OK;
+}
+int mgx_annotation_has_coordinates(const mgx_annotation *a) { return a && a->row_entry != nullptr; }
+
+/* MultiIntMatrix::get_row_tuples(rows) for a whole batch — what AnnotationBuffer::fetch_queued_annotations calls instead of
+ * get_rows when the annotation carries coordinates (annotation_buffer.cpp:166-181): the labels as mgx_annotation_get_rows
+ * returns them, and for label entry e (index into out_labels) the coordinates out_coords[out_coord_begin[e] ..
+ * out_coord_begin[e + 1]).  Host arrays; capacities as in get_rows (MGX_ERR_CAPACITY with the counts reported). */
+int mgx_annotation_get_row_tuples(mgx_annotation *a, const uint64_t *rows, uint64_t n, uint64_t *out_begin, uint32_t *out_labels,
+                                  uint64_t label_cap, uint64_t *out_coord_begin, int64_t *out_coords, uint64_t coord_cap,
+                                  uint64_t *n_labels_out, uint64_t *n_coords_out) {
+    if (!a || !a->row_entry) return afail(MGX_ERR_INVALID, "mgx_annotation_get_row_tuples: the annotation has no coordinates");
+    if (!out_coord_begin || (!out_coords && coord_cap)) return afail(MGX_ERR_INVALID, "mgx_annotation_get_row_tuples: bad arguments");
+    uint64_t total = 0;
+    if (int rc = mgx_annotation_get_rows(a, rows, n, 0, out_begin, out_labels, label_cap, 0, &total)) { if (n_labels_out) *n_labels_out = total; return rc; }
+    if (n_labels_out) *n_labels_out = total;
+    std::lock_guard<std::mutex> lock(a->rows_mutex);
+    HIP_TRY_A(hipSetDevice(a->device));
+    uint64_t *d_rows = nullptr, *d_begin = nullptr, *d_cb = nullptr;
+    int64_t *d_out = nullptr;
+    void *d_tmp = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_rows); (void)hipFree(d_begin); (void)hipFree(d_cb); (void)hipFree(d_out); (void)hipFree(d_tmp); };
+#define HIP_TRY_C(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { cleanup(); return afail(MGX_ERR_NO_DEVICE, "%s: %s", #e, hipGetErrorString(r_)); } } while (0)
+    HIP_TRY_C(hipMalloc(&d_rows, std::max<uint64_t>(1, n) * 8));
+    HIP_TRY_C(hipMalloc(&d_begin, (n + 1) * 8));
+    HIP_TRY_C(hipMalloc(&d_cb, (total + 1) * 8));
+    if (n) HIP_TRY_C(hipMemcpy(d_rows, rows, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemcpy(d_begin, out_begin, (n + 1) * 8, hipMemcpyHostToDevice));
+    HIP_TRY_C(hipMemset(d_cb, 0, (total + 1) * 8));
+    const uint32_t tb = 256, blocks = (uint32_t)((n + tb - 1) / tb);
+    if (n) k_tuple_count<<<blocks, tb>>>(a->row_entry, a->coord_off, a->n_rows, d_rows, n, d_begin, d_cb);
+    size_t tmp_bytes = 0;
+    HIP_TRY_C(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cb, d_cb, total + 1));
+    HIP_TRY_C(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    HIP_TRY_C(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cb, d_cb, total + 1));
+    uint64_t n_coords = 0;
+    HIP_TRY_C(hipMemcpy(&n_coords, d_cb + total, 8, hipMemcpyDeviceToHost));
+    if (n_coords_out) *n_coords_out = n_coords;
+    HIP_TRY_C(hipMemcpy(out_coord_begin, d_cb, (total + 1) * 8, hipMemcpyDeviceToHost));
+    if (n_coords > coord_cap) { cleanup(); return afail(MGX_ERR_CAPACITY, "mgx_annotation_get_row_tuples: %llu coordinates, room for %llu", (unsigned long long)n_coords, (unsigned long long)coord_cap); }
+    HIP_TRY_C(hipMalloc(&d_out, std::max<uint64_t>(1, n_coords) * 8));
+    if (n && n_coords) k_tuple_gather<<<blocks, tb>>>(a->row_entry, a->coord_off, a->coords, a->n_rows, d_rows, n, d_begin, d_cb, d_out);
+    HIP_TRY_C(hipGetLastError());
+    if (n_coords) HIP_TRY_C(hipMemcpy(out_coords, d_out, n_coords * 8, hipMemcpyDeviceToHost));
+#undef HIP_TRY_C
+    cleanup();
     return MGX_OK;
 }
 

@@ -2479,6 +2479,8 @@ constexpr uint32_t kNid = std::numeric_limits<uint32_t>::max();
 // arithmetic — linear + 0.5 * log2 — rounded to the nearest integer (cvtps_epi32: the current rounding mode, nearest-even),
 // not truncated as in the scalar version the source keeps under `#if 0`.
 struct ChainTables { std::vector<TableElem> dp_table; std::vector<uint32_t> backtrace; size_t num_seeds = 0, num_nodes = 0; };
+void chain_dp(const mgx_config &config, int64_t query_size, std::map<Label, size_t> &label_sizes, std::vector<TableElem> *dp_table,
+              std::vector<uint32_t> *backtrace);
 ChainTables chain_seeds(const mgx_config &config, std::string_view query, std::vector<Seed> &seeds) {
     ChainTables T;
     if (seeds.empty()) return T;
@@ -2504,8 +2506,16 @@ ChainTables chain_seeds(const mgx_config &config, std::string_view query, std::v
         seeds[i].label_coordinates = CoordinateSet{};
     }
     T.num_seeds = T.dp_table.size();
+    chain_dp(config, query_size, label_sizes, &T.dp_table, &T.backtrace);
+    return T;
+}
+
+// the sort and the DP of chain_seeds (:383-539) over a filled table
+void chain_dp(const mgx_config &config, int64_t query_size, std::map<Label, size_t> &label_sizes, std::vector<TableElem> *dp_table,
+              std::vector<uint32_t> *backtrace) {
+    struct { std::vector<TableElem> &dp_table; std::vector<uint32_t> &backtrace; } T{ *dp_table, *backtrace };
     T.backtrace.assign(T.dp_table.size(), kNid);
-    if (T.dp_table.empty()) return T;
+    if (T.dp_table.empty()) return;
     // "sort seeds by label, then by decreasing reference coordinate"
     std::sort(T.dp_table.begin(), T.dp_table.end(), table_elem_greater);
     const size_t bandwidth = 65;
@@ -2544,7 +2554,6 @@ ChainTables chain_seeds(const mgx_config &config, std::string_view query, std::v
             }
         }
     }
-    return T;
 }
 
 struct ChainHash {                                                       // :51-62
@@ -3134,6 +3143,24 @@ void LabeledAligner::align_batch(const std::vector<std::string> &queries, std::v
             align_core_labeled(seeds_to_alignments(qs.fwd, config_), extender, add_alignment, get_min_path_score, false);
         }
         res.alignments = aggregator.get_alignments();
+    }
+}
+
+// chain_seeds' sort + DP over caller-filled anchors (the checker of mgx_chain_seeds): anchors = TableElem records of one list
+void chain_anchors(const mgx_config &config, uint32_t query_size, mgx_chain_anchor *anchors, size_t n, uint32_t *backtrace) {
+    std::vector<TableElem> dp(n);
+    std::map<Label, size_t> label_sizes;
+    for (size_t i = 0; i < n; ++i) {
+        dp[i] = TableElem{ anchors[i].label, anchors[i].coordinate, anchors[i].seed_clipping, anchors[i].seed_end, anchors[i].chain_score,
+                           anchors[i].seed_index };
+        ++label_sizes[anchors[i].label];
+    }
+    std::vector<uint32_t> back;
+    chain_dp(config, (int64_t)query_size, label_sizes, &dp, &back);
+    for (size_t i = 0; i < n; ++i) {
+        anchors[i].label = dp[i].label; anchors[i].coordinate = dp[i].coordinate; anchors[i].seed_clipping = dp[i].seed_clipping;
+        anchors[i].seed_end = dp[i].seed_end; anchors[i].chain_score = dp[i].chain_score; anchors[i].seed_index = dp[i].current_seed_index;
+        backtrace[i] = back[i];
     }
 }
 

@@ -211,6 +211,10 @@ class LabeledAligner {
     const Annotation &annotation_;
 };
 
+// chain_seeds (A/aligner_chainer.cpp:383-539: the sort and the banded DP) over one list of anchors, in place: sorted as the
+// reference sorts them, chain_score final, backtrace[i] = index of the anchor i's best chain continues with (0xFFFFFFFF: none)
+void chain_anchors(const mgx_config &config, uint32_t query_size, mgx_chain_anchor *anchors, size_t n, uint32_t *backtrace);
+
 // cli/align.cpp:254-285 + fmt formatter alignment.hpp:426-433
 std::string format_alignment_tsv(const std::string &header, const AlignmentResults &paths, int32_t min_path_score);
 

@@ -392,6 +392,24 @@ const char *orc_results_format_coords(void *r, uint64_t q, uint64_t ai, const ch
     st->scratch = st->kept.at(q).alignments.at(ai).format_coords(hs, kc, k);
     return st->scratch.c_str();
 }
+// MultiIntMatrix::get_row_tuples for one row: labels (ascending) with their coordinates; returns the label count
+uint64_t orc_annotation_row_tuples(void *a, uint64_t row, uint64_t *labels, uint64_t *coord_begin, int64_t *coords, uint64_t coord_cap) {
+    auto t = static_cast<Annotation *>(a)->get_row_tuples(row);
+    uint64_t nc = 0;
+    coord_begin[0] = 0;
+    for (size_t i = 0; i < t.size(); ++i) {
+        labels[i] = t[i].first;
+        for (int64_t c : t[i].second) { if (nc < coord_cap) coords[nc] = c; ++nc; }
+        coord_begin[i + 1] = nc;
+    }
+    return t.size();
+}
+// chain_seeds' sort + DP for n_lists anchor lists (the checker of mgx_chain_seeds), in place
+void orc_chain_seeds(const mgx_config *config, mgx_chain_anchor *anchors, const uint64_t *list_begin, const uint32_t *query_size,
+                     uint64_t n_lists, uint32_t *backtrace) {
+    for (uint64_t l = 0; l < n_lists; ++l)
+        chain_anchors(*config, query_size[l], anchors + list_begin[l], list_begin[l + 1] - list_begin[l], backtrace + list_begin[l]);
+}
 // label sets of the alignments of a run, in the order of mgx_results.alignments
 void orc_results_labels(void *r, const uint64_t **begin, const uint64_t **labels) {
     auto *st = static_cast<ResultStore *>(r);
