@@ -14,6 +14,13 @@
 // from scratch.  Nothing is handed over mid-read, so results cannot depend on which kernel ran a read (tests run every read
 // both ways).
 //
+// Label-aware alignment (LabeledAligner, A/aligner_labeled.cpp; round 6): the pattern is "one label all along".  The seeds of the
+// read's strands carry exactly one label L, the same for all (filter_seeds :612-721 then keeps every seed with { L } or, below
+// min_exact_match, none); every column's node has the row { L } (an only child inherits its parent's set unseen, flush() :81-137
+// confirms it: checked here when the column is committed); at a fork the children without L are no children (:232-263); one
+// backtrack reports the alignment with { L } (:304-359), which ends it (terminate_backtrack_start).  Anything else — a node with
+// no or several labels, seeds of different labels — leaves the lane, as ever without having written anything.
+//
 // Restated (A/ = M/src/graph/alignment/), as far as the pattern reaches:
 //   driver        A/dbg_aligner.cpp:360-384,657-755  (align_core, aln_both, align_both_directions) — flat_drive
 //   extension     A/aligner_extender_methods.cpp:412-772 (extend), :209-328 (update_column, extend_ins_end: lane_column.hpp),
@@ -58,6 +65,8 @@ static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 // pass must not see anything the order of equal-score columns could change
 #define LANE_TIE_MODE() ((LANE_CI(CD_HMS) >> 5) & 1)
 #define LANE_SET_TIE_MODE(v) (LANE_CI(CD_HMS) = (LANE_CI(CD_HMS) & ~32) | ((v) ? 32 : 0))
+// bits 8 .. 31 = the read's label (label-aware alignment: the one label its seeds and every column of its extensions carry)
+#define LANE_LABEL() ((uint32_t)LANE_CI(CD_HMS) >> 8)
 #define LANE_HAVE_ALN() (LANE_CI(CD_HMS) & 1)
 #define LANE_MODE() ((LANE_CI(CD_HMS) >> 1) & 3)
 #define LANE_STRAND() ((LANE_CI(CD_HMS) >> 3) & 1)
@@ -315,6 +324,7 @@ struct LaneResult {
     int32_t have_aln, mode;              // mode: where lane_emit() finds the alignment (LANE_EMIT_*)
     int32_t score, offset, clip, end_clip, n_runs, j_hi, n_nodes, n_seq, trim, strand;      // j_hi: last column of the path; trim: nodes trim_offset dropped
     uint32_t words;                      // words of the output stream the alignment takes
+    uint32_t label;                      // label-aware: the alignment's one label
 };
 
 // One read.  `item`: its position in the launch (tags the node table).  scratch: the wavefront's LaneParams::scratch from this
@@ -386,8 +396,57 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         if (L > (int32_t)lim.Lmax || L > LANE_MAX_L) LANE_BAIL(1);
         const SeedHdr *hp = P.seed_hdr + read;
         if (gld(&hp->status) != ST_OK) LANE_BAIL(2);
-        const uint32_t nm0 = gld(&hp->num_matching[0]), nm1 = gld(&hp->num_matching[1]);
-        const int32_t ns0 = (int32_t)gld(&hp->n_seeds[0]), ns1 = (int32_t)gld(&hp->n_seeds[1]);
+        uint32_t nm0 = gld(&hp->num_matching[0]), nm1 = gld(&hp->num_matching[1]);
+        int32_t ns0 = (int32_t)gld(&hp->n_seeds[0]), ns1 = (int32_t)gld(&hp->n_seeds[1]);
+        uint32_t label = 0;
+        if (P.labeled) {
+            // LabeledAligner::filter_seeds (aligner_labeled.cpp:612-721) for both strands, in the one-label case: every seed's
+            // first node has the row { L }; L stays if the query positions under the seeds' first k-mers reach min_exact_match
+            // (else the strand loses its seeds); num_matching is recounted over the seeds left (get_num_char_matches_in_seeds,
+            // alignment.hpp:100-127 with its quirk: nothing behind the first sub-k seed counts)
+            if (!(P.labeled & 2u)) LANE_BAIL(30);                    // (rows of dummy nodes would need the W test)
+            bool have_label = false;
+            const int32_t ns0_h = ns0;                                // (strand 1's seeds follow strand 0's in the stream)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int32_t n_in = s2 ? ns1 : ns0;
+                if (!n_in) continue;
+                if (s2 && !have_rc) continue;
+                const DevSeed *sd0 = P.seed_stream + gld(&hp->off) + (s2 ? ns0_h : 0);
+                const uint32_t *rn = (s2 ? P.nodes_rc : P.nodes_fwd) + gld(P.node_begin + read);
+                uint64_t cov[4] = { 0, 0, 0, 0 };
+                uint32_t nm = 0;
+                int32_t last_end = 0;
+                bool counting = true;
+                for (int32_t j = 0; j < n_in; ++j) {
+                    const DevSeed *sj = sd0 + j;
+                    const int32_t cl = (int32_t)gld(&sj->clipping), so = (int32_t)gld(&sj->offset), len = (int32_t)gld(&sj->length);
+                    const uint32_t node0 = so == 0 ? gld(rn + cl) : gld(&sj->node);
+                    uint64_t h = 0;
+                    if (node0 && node0 <= P.g.n && (uint64_t)node0 - 1 < P.anno_rows) h = gld(P.anno_head + ((uint64_t)node0 - 1));
+                    if ((h & 0xFFFF) != 1) LANE_BAIL(30);              // no label or several: the group kernel's label sets
+                    const uint32_t lbl = (uint32_t)(h >> 16);
+                    if (!have_label) { label = lbl; have_label = true; } else if (lbl != label) LANE_BAIL(30);
+                    const int32_t lo = cl, hi = imin(cl + k - so, L);
+#pragma unroll
+                    for (int wq = 0; wq < 4; ++wq) {                       // bits [lo, hi) of the 256-position indicator
+                        const int32_t a = imin(imax(lo - 64 * wq, 0), 64), b = imin(imax(hi - 64 * wq, 0), 64);
+                        const uint64_t below_b = b >= 64 ? ~0ull : (1ull << b) - 1ull, below_a = a >= 64 ? ~0ull : (1ull << a) - 1ull;
+                        cov[wq] |= below_b & ~below_a;
+                    }
+                    if (counting) {
+                        const int32_t q_end = cl + len;
+                        if (q_end > last_end) nm += (uint32_t)((q_end - cl) - (cl < last_end ? last_end - cl : 0));
+                        last_end = q_end;
+                        if (so) counting = false;
+                    }
+                }
+                const uint32_t cnt = (uint32_t)(popc64(cov[0]) + popc64(cov[1]) + popc64(cov[2]) + popc64(cov[3]));
+                const bool keep = !((double)cnt < cfg.min_exact_match * (double)L);
+                if (s2) { ns1 = keep ? n_in : 0; nm1 = keep ? nm : 0u; } else { ns0 = keep ? n_in : 0; nm0 = keep ? nm : 0u; }
+            }
+            gst(arec() + 15, (uint32_t)ns0 | ((uint32_t)ns1 << 16));
+            gst(arec() + 25, nm0 | (nm1 << 16));
+        }
         // align_both_directions (:738-755): the strand with more matches; the other one only if it is within rel_score_cutoff
         const int first = nm0 >= nm1 ? 0 : 1;
         const int s = have_rc ? first : 0;
@@ -398,7 +457,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         }
         n = s ? ns1 : ns0;
         // the result: which alignment (LaneResult::mode) and its scalars
-        LANE_CI(CD_HMS) = s << 3; LANE_CI(CD_L) = L; LANE_CI(CD_NSEEDS) = n;
+        LANE_CI(CD_HMS) = (s << 3) | (int32_t)(label << 8); LANE_CI(CD_L) = L; LANE_CI(CD_NSEEDS) = n;
         cols_done = 0;
         LANE_CU(CD_CTR_RANK) = 0; LANE_CU(CD_CTR_SEL) = 0;
     } else {
@@ -472,7 +531,11 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         int32_t min_start_score = have_rc ? imax(0, cfg.min_cell_score) : imax(0, cfg.min_path_score);
         if (pass) {
             const int32_t fw_added = (int32_t)gld(arec() + 8), fw_score = (int32_t)gld(arec() + 9);
-            const int32_t gcut = !fw_added ? NINF : (fw_score > 0 ? (int32_t)((double)fw_score * cfg.rel_score_cutoff) : fw_score);
+            // get_min_path_score (dbg_aligner.cpp:277-282): the aggregator's global cut-off — label-aware its cut-off for the seed's
+            // labels (get_score_cutoff, aligner_aggregator.hpp:152-166): the full queue of L holds the forward alignment, whose score
+            // is the label's cut-off and lies above the global one
+            int32_t gcut = !fw_added ? NINF : (fw_score > 0 ? (int32_t)((double)fw_score * cfg.rel_score_cutoff) : fw_score);
+            if (P.labeled && fw_added) gcut = imax(gcut, fw_score);
             min_start_score = imax(0, imax(cfg.min_path_score, gcut));
         }
         const uint32_t ptag = pass ? (((tag ^ 0x5A5A5u) & 0xFFFFFu) | 1u) : tag;
@@ -594,13 +657,29 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                             const int nc = pass ? lane_parents(P.g, f_node, kn0, kc0, kn1, kc1, chip)
                                                 : lane_children(P.g, f_node, hr, kn0, kc0, kr0, kn1, kc1, kr1, chip);
                             if (nc > 2) LANE_BAIL(10);                                 // more than two children
+                            int nc_l = nc;
+                            if (P.labeled && nc == 2) {
+                                // LabeledExtender::call_outgoing at a fork (aligner_labeled.cpp:232-263): the children that share
+                                // a label with this column — here: whose row is { L } — are the children; a row with several labels
+                                // would make a new set (the group kernel's business)
+                                const uint32_t lbl = LANE_LABEL();
+                                auto row_of = [&](uint32_t node) -> uint64_t {
+                                    return (node && node <= P.g.n && (uint64_t)node - 1 < P.anno_rows) ? gld(P.anno_head + ((uint64_t)node - 1)) : 0ull;
+                                };
+                                const uint64_t h0 = row_of(kn0), h1 = row_of(kn1);
+                                if ((h0 & 0xFFFF) > 1 || (h1 & 0xFFFF) > 1) LANE_BAIL(30);
+                                const bool k0 = (h0 & 0xFFFF) == 1 && (uint32_t)(h0 >> 16) == lbl, k1 = (h1 & 0xFFFF) == 1 && (uint32_t)(h1 >> 16) == lbl;
+                                if (!k0) { kn0 = kn1; kc0 = kc1; kr0 = kr1; }
+                                nc_l = (k0 ? 1 : 0) + (k1 ? 1 : 0);
+                                if (nc_l < 2) { kn1 = 0; kc1 = 0; kr1 = 0; }
+                            }
                             kid_node0 = kn0; kid_code0 = kc0; kid_node1 = kn1; kid_code1 = kc1; kid_rank0 = kr0; kid_rank1 = kr1;
-                            if (nc == 0) {                                             // a tip: its start cell counts after all
+                            if (nc_l == 0) {                                           // a tip: its start cell counts after all
                                 if (t_score != INT32_MIN) cand(t_score, t_nod, f_idx, t_pos);
                                 if (tie_bad) LANE_BAIL(27);
                                 head_dead = true;
                             }
-                            n_kids = nc;
+                            n_kids = nc_l;
                         }
                         kid = 0;
                         fa_alive = 0;
@@ -646,6 +725,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 #endif
                 uint32_t hs = lane_hash(next, hmask);
                 uint64_t he = probe ? gld(htab() + hs) : 0;
+                // label-aware: the row of the column's node (flush() :81-137 intersects it with the parent's set when the table is
+                // flushed — at the next fork, at the latest before backtracking: the set must stay { L })
+                uint64_t hrow = 0;
+                if (P.labeled && (uint64_t)next - 1 < P.anno_rows) hrow = gld(P.anno_head + ((uint64_t)next - 1));
                 in.next_offset = next_offset; in.score = 0; in.in_seed = in_seed;
                 in.best_score = best_score; in.min_cell_score = min_cell_score; in.rel_cutoff = cfg.rel_score_cutoff;
                 in.partial_sum_offset = 0; in.psum_lin = m; in.psum = nullptr; in.seed_off = seed_off; in.q = nullptr; in.row = nullptr;
@@ -655,6 +738,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 const int rc = lane_column(in, S, F, out, prof);
                 LANE_T(2);
                 if (rc == LC_FALLBACK) LANE_BAIL(14);
+                if (P.labeled && rc != LC_POP && !((hrow & 0xFFFF) == 1 && (uint32_t)(hrow >> 16) == LANE_LABEL())) LANE_BAIL(30);
                 const uint32_t table_cap_before = table_cap;
                 if ((uint32_t)tsize == table_cap) table_cap = imax<uint32_t>(1u, 2 * table_cap);
                 ++cols_done;
@@ -1200,6 +1284,10 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         const SeedHdr *hp = P.seed_hdr + read;
         rr.num_matches_fwd = gld(&hp->num_matching[0]); rr.num_matches_rc = gld(&hp->num_matching[1]);
         rr.n_seeds_fwd = (uint32_t)gld(&hp->n_seeds[0]); rr.n_seeds_rc = (uint32_t)gld(&hp->n_seeds[1]);
+        if (P.labeled) {                                     // (what the label filter left)
+            const uint32_t nsw = gld(arec() + 15), nmw = gld(arec() + 25);
+            rr.n_seeds_fwd = nsw & 0xFFFFu; rr.n_seeds_rc = nsw >> 16; rr.num_matches_fwd = nmw & 0xFFFFu; rr.num_matches_rc = nmw >> 16;
+        }
         rr.n_extensions = (uint32_t)n_extensions; rr.n_columns = n > 0 ? (uint32_t)cols_done : 0u;
     }
     // the lane's counters (kept in its scratch, summed when the kernel ends): columns, block lines
@@ -1218,6 +1306,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             R.end_clip = (int32_t)gld(arec() + 3); R.n_runs = (int32_t)gld(arec() + 4); R.j_hi = (int32_t)gld(arec() + 5);
             R.n_nodes = a_n_nodes; R.n_seq = (int32_t)gld(arec() + 7);
             R.words = (uint32_t)R.n_nodes + (uint32_t)((R.clip ? 1 : 0) + R.n_runs + (R.end_clip ? 1 : 0)) + ((uint32_t)R.n_seq + 3) / 4;
+            if (P.labeled) { R.words += 2; R.label = LANE_LABEL(); }                 // (label count + the one label behind the alignment)
         }
     }
     LANE_T(6);
@@ -1307,6 +1396,11 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
             }
             if (R.end_clip) gst(dst + R.n_nodes + nc++, ((uint32_t)R.end_clip << 3) | OP_CLIPPED);
             for (int32_t x = R.n_seq; x & 3; ++x) gst(dseq + x, (uint8_t)0);          // (pad the last word)
+            if (P.labeled) {
+                // the labeled stream layout (align_core.hpp, the labeled result writer): the alignment's label count and labels follow it
+                uint32_t *lab = dst + R.n_nodes + n_cigar + ((uint32_t)R.n_seq + 3) / 4;
+                gst(lab, 1u); gst(lab + 1, R.label);
+            }
             rr.score = R.score; rr.offset = (uint32_t)R.offset;
             rr.n_nodes = (uint32_t)R.n_nodes; rr.n_cigar = (uint32_t)n_cigar; rr.seq_len = (uint32_t)R.n_seq;
             rr.orientation = (uint32_t)R.strand; rr.stream_off = so;
@@ -1327,7 +1421,8 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
         const uint64_t h_off = gld(&hp->off);
         const int32_t ns0 = (int32_t)gld(&hp->n_seeds[0]), ns1 = (int32_t)gld(&hp->n_seeds[1]);
         for (int st = 0; st < 2; ++st) {
-            const int32_t cnt = st ? ns1 : ns0;
+            // (label-aware: a strand whose label fell below min_exact_match has lost its seeds)
+            const int32_t cnt = P.labeled ? (int32_t)(st ? rr.n_seeds_rc : rr.n_seeds_fwd) : (st ? ns1 : ns0);
             const DevSeed *src = P.seed_stream + h_off + (st ? ns0 : 0);
             for (int32_t i = 0; i < cnt; ++i) {
                 DevSeed *d = P.dbg_seeds + ((uint64_t)read * 2 + st) * P.lim.max_seeds + i;

@@ -72,8 +72,12 @@ inline uint64_t lane_wave_scratch_bytes(uint32_t max_cols, uint64_t rest_stride)
 // Whether the lane-per-read kernel may run in front of the group kernel for this configuration (every read it cannot finish
 // goes to the group kernel anyway; this only rules out configurations in which its shortcuts would not be exact or no read
 // could finish), and the scoring constants it runs with.  `why`: the first reason against.
-inline bool lane_enabled(const mgx_config &c, const DevConfig &d, uint32_t k, uint32_t Lmax, bool no_fast, LaneParams *LP, std::string *why) {
+// labeled: label-aware alignment (LabeledAligner); labeled_flags: AlignParams::labeled — bit 1 must be set (no dummy node's row holds
+// a label: the lane reads rows without the W test)
+inline bool lane_enabled(const mgx_config &c, const DevConfig &d, uint32_t k, uint32_t Lmax, bool no_fast, LaneParams *LP, std::string *why,
+                         uint32_t labeled_flags = 0) {
     auto no = [&](const char *w) { if (why) *why = w; return false; };
+    if ((labeled_flags & 1u) && !(labeled_flags & 2u)) return no("label-aware: rows of dummy nodes hold labels");
     if (d.num_alt != 1 || d.post_chain) return no("alternative paths");
     if (d.canonical != 0) return no("CANONICAL / PRIMARY graph");
     if (k > 32 || k < 2) return no("k > 32: reads are not 2-bit packed");

@@ -1113,8 +1113,11 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     memset(&LP, 0, sizeof(LP));
     std::string lane_why;
     const uint32_t lane_blocks = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)mgx_lane_waves_per_simd();
-    bool lane_ok = !labeled && A->opt.lane != 0 && A->packed_valid && A->mode == MODE_SPLIT8 && !A->opt.two_pass && A->opt.multi_pass != 1
-                   && lane_enabled(A->cfg, A->dcfg, A->graph->g.k, l.Lmax, A->no_fast, &LP, &lane_why)
+    // (label-aware batches, round 6: the lane takes the reads whose seeds and columns all carry one and the same single label —
+    // lane_read.hpp; it needs the annotation's "no dummy node's row holds a label" flag, as it reads rows without the W test)
+    bool lane_ok = A->opt.lane != 0 && A->packed_valid && A->mode == MODE_SPLIT8 && !A->opt.two_pass && A->opt.multi_pass != 1
+                   && lane_enabled(A->cfg, A->dcfg, A->graph->g.k, l.Lmax, A->no_fast, &LP, &lane_why,
+                                   labeled ? (1u | (A->anno_dummy_clean ? 2u : 0u)) : 0u)
                    && (A->opt.lane == 1 || n >= (uint64_t)lane_blocks * 16);       // (a small batch: the spread / 64-lane kernels are quicker)
     if (lane_ok) {
         LP.max_cols = lane_max_cols(l.Lmax, A->dcfg.xdrop);

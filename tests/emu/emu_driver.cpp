@@ -466,11 +466,11 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
         const char *lane_env = getenv("MGX_EMU_LANE");
         std::vector<uint32_t> lane_rest;
         uint64_t n_ext = n;                  // reads the wave program's extension phase takes
-        if (lane_env && *lane_env == '1' && have_packed && !AN) {
+        if (lane_env && *lane_env == '1' && have_packed) {
             LaneParams LP;
             memset(&LP, 0, sizeof(LP));
             std::string why;
-            if (lane_enabled(cfg, dcfg, k, R->lim.Lmax, P.no_fast != 0, &LP, &why)) {
+            if (lane_enabled(cfg, dcfg, k, R->lim.Lmax, P.no_fast != 0, &LP, &why, P.labeled)) {
                 LP.P = P;
                 LP.pk[0] = pkf.data(); LP.pk[1] = pkr.data(); LP.iv[0] = ivf.data(); LP.iv[1] = ivr.data();
                 LP.max_cols = lane_max_cols(R->lim.Lmax, dcfg.xdrop);
