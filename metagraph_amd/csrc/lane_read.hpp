@@ -763,6 +763,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         }
                         gst(htab() + hs, (uint64_t)next | ((uint64_t)ptag << 44) | ((uint64_t)(uint32_t)my_idx << 32));
                     }
+                    LANE_T(7);                                                         // (timers: the node table's share of "commit")
                     // (replay columns: see above; the column's own maximum stands in for the merged score, ninf neither way)
                     int32_t converged = out.converged;
                     const int32_t size = out.size, org = out.org;

@@ -1415,8 +1415,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             if (getenv("MGX_LANE_TIMERS")) {
                 unsigned long long t[16];
                 HIP_TRY(copy_sync(A, t, A->lane_hist.as<unsigned long long>() + 32, sizeof(t), hipMemcpyDeviceToHost));
-                fprintf(stderr, "k_lane timers (cycles of lane 0, summed over %u wavefronts): setup %llu children %llu column %llu commit %llu frontier %llu trace %llu result %llu | emit %llu kernel %llu\n",
-                        blocks, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[8], t[9]);
+                fprintf(stderr, "k_lane timers (cycles of lane 0, summed over %u wavefronts): setup %llu children %llu column %llu node-table %llu commit %llu frontier %llu trace %llu result %llu | emit %llu kernel %llu\n",
+                        blocks, t[0], t[1], t[2], t[7], t[3], t[4], t[5], t[6], t[8], t[9]);
             }
             HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));                          // rewind the read cursor
             P.order = A->lane_bail.as<uint32_t>();

@@ -42,3 +42,20 @@ def test_bench_config3_labels_at_reduced_size():
     assert out["parity"]["sample"] == 1500 and out["parity"]["mismatches"] == 0 and out["parity"]["capacity_errors"] == 0
     assert out["parity"]["full_batch_capacity_errors"] == 0
     assert out["roofline"]["kernel_ms"]["k_extend"] > 0 and out["cpu_baseline"]["cores"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_config3_1000_labels_at_a_million_reads():
+    """BASELINE config 3 at its own graph and annotation (104 M-edge graph, 1000 labels) with 1 M reads: the lane-per-read kernel in
+    front of the labeled group kernel (round 6) — most reads must finish in the lane — and every read of a 20 000-read sample
+    equal to the oracle's LabeledAligner, label lists included."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--labels", "1000", "--reads", "1000000", "--steps", "1", "--warmup", "1",
+           "--parity-sample", "20000", "--no-cpu-baseline", "--host-steps", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert "1000-label" in out["config"]["workload"] and out["config"]["graph_edges"] > 100_000_000
+    assert out["parity"]["sample"] == 20000 and out["parity"]["mismatches"] == 0 and out["parity"]["capacity_errors"] == 0
+    assert out["parity"]["full_batch_capacity_errors"] == 0
+    km = out["roofline"]["kernel_ms"]
+    assert km.get("k_lane", 0) > 0 and km["reads_finished_by_k_lane"] >= 0.9 * 1_000_000, km
