@@ -134,7 +134,8 @@ int mgx_chain_seeds(const mgx_config *config, int device, const mgx_chain_anchor
     if (!config || !list_begin || !query_size || (n_lists && (!sorted_out || !backtrace_out))) return cfail(MGX_ERR_INVALID, "mgx_chain_seeds: null argument");
     const uint64_t n = n_lists ? list_begin[n_lists] : 0;
     if (n && !anchors) return cfail(MGX_ERR_INVALID, "mgx_chain_seeds: null argument");
-    if (n >= 0xFFFFFFF0ull) return cfail(MGX_ERR_UNSUPPORTED, "mgx_chain_seeds: %llu anchors in one call", (unsigned long long)n);
+    if (n >= 0x7FFFFFF0ull || n_lists >= 0x7FFFFFF0ull)       // (the segmented sort counts items and segments in int)
+        return cfail(MGX_ERR_UNSUPPORTED, "mgx_chain_seeds: %llu anchors in %llu lists in one call", (unsigned long long)n, (unsigned long long)n_lists);
     uint32_t max_q = 1;
     for (uint64_t l = 0; l < n_lists; ++l) {
         if (list_begin[l] > list_begin[l + 1]) return cfail(MGX_ERR_INVALID, "mgx_chain_seeds: list_begin must be ascending");
