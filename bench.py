@@ -316,6 +316,11 @@ def main():
                                 + (12 * st["n_seeds"] if lane_ms <= 0 else 0))}
         kernel_ms = {"k_map": round(k_map, 3), "k_seed": round(st["seeding_ms"], 3), "work_sort": round(st["sort_ms"], 3),
                      "k_extend": round(st["extend_ms"] - lane_ms, 3)}
+        if st.get("seed_lane_ms", 0) > 0:
+            # (the seeding stage is two launches since round 6: the lane-per-read seeder, then the wave-per-read kernel on what it left)
+            kernel_ms["k_seed_lane_part_of_k_seed"] = round(st["seed_lane_ms"], 3)
+            kernel_ms["reads_seeded_by_k_seed_lane"] = st["n_seed_lane_reads"]
+            kernel_ms["reads_k_seed_lane_left_by_reason"] = st["seed_lane_left_reads"]
         if lane_ms > 0 and (st["extend_kernels"] & capi.KERNEL_LANE):
             kernels["k_lane"] = (lane_ms, 64.0 * lines_lane + args.reads * io_per_read + 12 * st["n_seeds"])
             kernel_ms["k_lane"] = round(lane_ms, 3)

@@ -226,6 +226,11 @@ typedef struct mgx_stats {
     uint64_t n_capacity_retried; /* queries the last mgx_fetch_results / mgx_align_batch re-aligned with doubled limits after an
                                    MGX_ERR_CAPACITY status (they are in its results like any other query; n_capacity_errors counts
                                    them too) */
+    uint64_t n_seed_lane_reads; /* reads the lane-per-read seeder (round 6, csrc/seed_lane.hpp) seeded on its own; the rest went on to the
+                                   wave-per-read seeding kernel */
+    double seed_lane_ms;        /* HIP-event time of the lane-per-read seeder (part of seeding_ms) */
+    uint64_t seed_lane_left_reads[16]; /* reads it left to the seeding kernel, by reason (seed_lane.hpp: 1 read length, 2 k-mer positions,
+                                   3 characters outside ACGT, 4 the DUST scan could mask something, 5 alternative nodes, 6 / 7 seeds) */
 } mgx_stats;
 enum { MGX_KERNEL_GRP8 = 1, MGX_KERNEL_GRP8_PRIM = 2, MGX_KERNEL_GRP8_ALT = 4, MGX_KERNEL_EXT64 = 8, MGX_KERNEL_LANE = 16,
        MGX_KERNEL_LAB64 = 32, MGX_KERNEL_GRP8_LAB = 64 /* the label-aware builds of the 64-lane and the 8-lane kernel */ };

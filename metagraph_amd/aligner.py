@@ -248,6 +248,7 @@ class Aligner:
         d["phase_cycles"] = list(s.phase_cycles)
         d["extend_cycles"] = list(s.extend_cycles)
         d["lane_bail_reads"] = {i: int(v) for i, v in enumerate(s.lane_bail_reads) if v}
+        d["seed_lane_left_reads"] = {i: int(v) for i, v in enumerate(s.seed_lane_left_reads) if v}
         return d
 
     def format_tsv(self, res, qi, header, query):

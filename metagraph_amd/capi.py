@@ -79,7 +79,8 @@ class Stats(C.Structure):
                 ("seeding_ms", C.c_double), ("sort_ms", C.c_double), ("extend_ms", C.c_double), ("n_seed_lines", C.c_uint64),
                 ("n_fast_columns", C.c_uint64), ("extend_kernels", C.c_uint64), ("n_lane_reads", C.c_uint64),
                 ("lane_ms", C.c_double), ("n_lane_lines", C.c_uint64), ("n_lane_columns", C.c_uint64),
-                ("lane_bail_reads", C.c_uint64 * 32), ("n_capacity_retried", C.c_uint64)]
+                ("lane_bail_reads", C.c_uint64 * 32), ("n_capacity_retried", C.c_uint64),
+                ("n_seed_lane_reads", C.c_uint64), ("seed_lane_ms", C.c_double), ("seed_lane_left_reads", C.c_uint64 * 16)]
 
 
 KERNEL_GRP8, KERNEL_GRP8_PRIM, KERNEL_GRP8_ALT, KERNEL_EXT64, KERNEL_LANE, KERNEL_LAB64, KERNEL_GRP8_LAB = 1, 2, 4, 8, 16, 32, 64

@@ -117,6 +117,8 @@ struct AlignParams {
     unsigned long long *seed_cursor;
     uint32_t *work_key;                  // [n_reads], written by the seeding phase
     const uint32_t *order;               // optional: the extension phase processes read order[i] as its i-th item
+    const uint32_t *seed_list;           // optional: the seeding phase processes read seed_list[i] as its i-th item (what the
+                                         // lane-per-read seeder left: seed_lane.hpp; the item count then comes from *n_items_ptr)
     // two-pass extension: pass 1 stops a read that would extend a second seed (seed_limit = 1) and lists it in
     // retry_list; pass 2 re-runs the listed reads from scratch without a limit (order = retry_list, item count read
     // from *n_items_ptr on the device).  Keeps the rare multi-seed reads from stalling the 7 other reads of their

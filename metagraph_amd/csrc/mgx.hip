@@ -24,6 +24,7 @@
 #include "host_common.hpp"
 #include "chain_host.hpp"
 #include "lane_types.hpp"
+#include "seed_lane.hpp"
 
 using namespace mgx;
 
@@ -460,6 +461,8 @@ extern "C" unsigned mgx_grp_static_lds8_alt(void);
 extern "C" int mgx_grp_waves_per_simd8_alt(void);
 extern "C" int mgx_launch_ext64(const void *params, uint32_t blocks, uint32_t lds_bytes, void *stream);      // mgx_ext64.hip
 extern "C" int mgx_launch_lane(const void *d_params, uint32_t blocks, void *stream);                         // mgx_lane.hip
+extern "C" int mgx_launch_seed_lane(const void *d_params, uint32_t blocks, void *stream);                    // mgx_seedlane.hip
+extern "C" int mgx_seed_lane_waves_per_simd(void);
 // the 64-lane extension kernel with the label-aware extender compiled in (mgx_lab64.hip: -DMGX_WITH_LABELS=1)
 extern "C" int mgx_launch_align_grp8_lab(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);   // mgx_grp.hip, the labeled build
 extern "C" unsigned mgx_grp_static_lds8_lab(void);
@@ -526,6 +529,8 @@ struct mgx_aligner {
     uint32_t lane_epoch = 0;
     uint64_t lane_done = 0;
     unsigned long long lane_hist_h[32] = { 0 };
+    DevBuf seedlane_scratch, seedlane_params, seedlane_bail, seedlane_hist;   // lane-per-read seeder: seed buffers, parameter block, the reads it leaves, why
+    uint64_t seedlane_launched = 0;    // the last batch ran it (its counters are read back by collect_stats)
     uint32_t n_passes = 0;
     DevLimits lim;
     uint64_t n_reads = 0, total_kmers = 0;
@@ -554,7 +559,7 @@ struct mgx_aligner {
                                                  // capacity retry read the batch back only while it is still the staged one
     std::vector<uint64_t> m_node_begin, m_fwd, m_rc;
     mgx_stats hstats;
-    hipEvent_t ev[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t ev[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };     // ([7]: the lane-per-read seeder is through)
     bool split_ran = false;
     uint64_t kernels_ran = 0;     // MGX_KERNEL_* bits of the extension kernels the last batch launched
     uint64_t seed_scale = 1, seed_cap = 0;
@@ -574,6 +579,7 @@ struct mgx_aligner {
         int no_compact = 0, no_alias = 0, no_bt_runs = 0, no_flat = 0;
         int primary_alt_build = 0;
         int lane = -1;            // the lane-per-read kernel in front of the extension kernel: -1 auto, 0 off, 1 forced
+        int seed_lane = -1;       // the lane-per-read seeder in front of the seeding kernel (seed_lane.hpp): -1 auto, 0 off, 1 forced
         int seed_wps = 8;         // wavefronts per SIMD of the short-read seeding kernel: 8 (64 VGPRs, spills) or 4 (102 VGPRs, tables in LDS)
         int device_share = 1;     // handles expected to run on this device at the same time (worker threads, -p N): the per-slot
                                   // arenas of this handle are sized for 1 / device_share of the machine instead of all of it
@@ -855,7 +861,8 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
                        &A->seqs, &A->offsets, &A->counts, &A->node_begin, &A->nodes_fwd, &A->nodes_rc, &A->arena, &A->results, &A->stream,
                        &A->cursors, &A->d_stats, &A->d_stats_map, &A->scan_tmp, &A->dbg_seeds, &A->seed_hdr, &A->seed_stream, &A->work_key,
                        &A->work_key_sorted, &A->order_in, &A->order, &A->sort_tmp, &A->retry_list, &A->resume_pool[0], &A->resume_pool[1],
-                       &A->retry_list2, &A->retry_key[0], &A->retry_key[1], &A->lane_scratch, &A->lane_params, &A->lane_bail, &A->lane_hist })
+                       &A->retry_list2, &A->retry_key[0], &A->retry_key[1], &A->lane_scratch, &A->lane_params, &A->lane_bail, &A->lane_hist, &A->seedlane_scratch, &A->seedlane_params,
+                       &A->seedlane_bail, &A->seedlane_hist })
         b->pooled = true;
     {
         std::string err;
@@ -912,7 +919,7 @@ static int aligner_create(const mgx_graph *g, const mgx_config *config, const mg
     }
     if (int rc = A->score_matrix.ensure(128 * 128)) return rc;
     HIP_TRY(hipMemcpy(A->score_matrix.p, c.score_matrix, 128 * 128, hipMemcpyHostToDevice));
-    if (int rc = A->cursors.ensure(64)) return rc;
+    if (int rc = A->cursors.ensure(128)) return rc;
     if (int rc = A->d_stats.ensure(sizeof(KernelStats))) return rc;
     if (int rc = A->d_stats_map.ensure(sizeof(KernelStats))) return rc;
     for (auto &e : A->ev) HIP_TRY(hipEventCreate(&e));
@@ -977,7 +984,7 @@ static int stage_batch(mgx_aligner *A, const char *seqs, const uint64_t *offsets
     if (int rc = A->counts.ensure((n + 2) * 8)) return rc;
     if (int rc = A->node_begin.ensure((n + 2) * 8)) return rc;
     unsigned long long *cur = A->cursors.as<unsigned long long>();
-    HIP_TRY(hipMemsetAsync(cur, 0, 64, A->hstream));
+    HIP_TRY(hipMemsetAsync(cur, 0, 128, A->hstream));
     k_kmer_counts<<<(uint32_t)((n + 1 + 255) / 256), 256, 0, A->hstream>>>(*d_offsets, n, k, A->counts.as<uint64_t>(), cur + 2);
     HIP_TRY(hipGetLastError());
     size_t tmp_bytes = 0;
@@ -1331,7 +1338,41 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     };
     A->split_ran = split;
     A->kernels_ran = 0;
+    A->seedlane_launched = 0;
     if (split) {
+        // The lane-per-read seeder (seed_lane.hpp, mgx_seedlane.hip) first: every lane seeds its own read and either publishes
+        // header, seeds and work key as the seeding kernel would, or lists the read for that kernel, which then seeds the
+        // list from scratch (no host round trip in between: the list's length stays on the device).
+        const bool seed_lane = A->opt.seed_lane != 0 && !probe_env_set("MGX_SEED_GROUPS") && A->packed_valid && P.pkw[0] && P.ivw[0]
+                               && (!A->dcfg.fwd_and_rc || (P.pkw[1] && P.ivw[1])) && P.mlen_fwd && P.rng_fwd
+                               && (!A->dcfg.fwd_and_rc || (P.mlen_rc && P.rng_rc))
+                               && seed_lane_enabled(A->dcfg, (uint32_t)A->graph->g.k, l.Lmax, true, true)
+                               && (A->opt.seed_lane == 1 || n >= 4096);
+        if (seed_lane && n) {
+            const uint32_t sl_blocks = (uint32_t)std::min<uint64_t>((uint64_t)prop.multiProcessorCount * 4 * (uint64_t)mgx_seed_lane_waves_per_simd(), (n + 63) / 64);
+            if (int rc = A->seedlane_scratch.ensure((size_t)sl_blocks * SL_WAVE_SCRATCH_WORDS * 4)) return rc;
+            if (int rc = A->seedlane_params.ensure(sizeof(SeedLaneParams))) return rc;
+            if (int rc = A->seedlane_bail.ensure(n * 4 + 4)) return rc;
+            if (int rc = A->seedlane_hist.ensure(32 * 8)) return rc;          // ([16 .. 24): section timers of -DMGX_SL_TIMERS builds)
+            HIP_TRY(hipMemsetAsync(A->seedlane_hist.p, 0, 32 * 8, A->hstream));
+            HIP_TRY(hipMemsetAsync(cur + 8, 0, 16, A->hstream));
+            SeedLaneParams SP;
+            memset(&SP, 0, sizeof(SP));
+            SP.P = P;
+            SP.P.n_items = n;
+            SP.scratch = A->seedlane_scratch.as<uint32_t>();
+            SP.bail_list = A->seedlane_bail.as<uint32_t>();
+            SP.bail_count = cur + 8;
+            SP.done_count = cur + 9;
+            SP.bail_hist = A->seedlane_hist.as<unsigned long long>();
+            HIP_TRY(copy_sync(A, A->seedlane_params.p, &SP, sizeof(SP), hipMemcpyHostToDevice));
+            if (int rc = mgx_launch_seed_lane(A->seedlane_params.p, sl_blocks, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane-per-read seeder: %d", rc);
+            HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));                      // rewind the read cursor
+            P.seed_list = A->seedlane_bail.as<uint32_t>();
+            P.n_items_ptr = cur + 8;
+            A->seedlane_launched = 1;
+        }
+        HIP_TRY(hipEventRecord(A->ev[7], A->hstream));
         if (probe_env_set("MGX_SEED_GROUPS")) {                 // A/B probe (needs a -DMGX_GRP_SEED_PROBE build of mgx_grp.hip)
             if (int rc = launch_groups(PH_SEED)) return fail(MGX_ERR_NO_DEVICE, "group seeding kernel: %d", rc);
         } else if (A->opt.seed_wps == 8 && l.Lmax <= 192 && slots >= (uint64_t)prop.multiProcessorCount * 4 * 8) {
@@ -1356,6 +1397,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             k_align<PH_SEED><<<w_slots, 64, lds_bytes, A->hstream>>>(P, lds_bytes);
         }
         HIP_TRY(hipGetLastError());
+        P.seed_list = nullptr; P.n_items_ptr = nullptr;
         HIP_TRY(hipEventRecord(A->ev[4], A->hstream));
         k_iota<<<(uint32_t)((n + 255) / 256), 256, 0, A->hstream>>>(A->order_in.as<uint32_t>(), n);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(A->sort_tmp.p, sort_tmp_bytes, A->work_key.as<uint32_t>(), A->work_key_sorted.as<uint32_t>(),
@@ -1514,6 +1556,19 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
     s.n_lane_reads = A->lane_done;
     s.n_lane_lines = ks.lane_lines; s.n_lane_columns = ks.lane_columns;
     for (int x = 0; x < 32; ++x) s.lane_bail_reads[x] = A->lane_hist_h[x];
+    if (aligned && A->seedlane_launched && getenv("MGX_SL_TIMERS")) {
+        unsigned long long t[8];
+        HIP_TRY(copy_sync(A, t, A->seedlane_hist.as<unsigned long long>() + 16, sizeof(t), hipMemcpyDeviceToHost));
+        fprintf(stderr, "k_seed_lane timers (cycles of lane 0, summed over the wavefronts): strands %llu masks %llu scan %llu walks %llu dust %llu ranges+enumerate %llu publish %llu wave-mates %llu\n",
+                t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+    }
+    if (aligned && A->seedlane_launched) {
+        unsigned long long done = 0, why[16];
+        HIP_TRY(copy_sync(A, &done, A->cursors.as<unsigned long long>() + 9, 8, hipMemcpyDeviceToHost));
+        HIP_TRY(copy_sync(A, why, A->seedlane_hist.p, sizeof(why), hipMemcpyDeviceToHost));
+        s.n_seed_lane_reads = done;
+        for (int x = 0; x < 16; ++x) s.seed_lane_left_reads[x] = why[x];
+    }
     for (int x = 0; x < 8; ++x) { s.phase_cycles[x] = ks.cyc[x]; s.extend_cycles[x] = ks.xcyc[x]; }
     float ms = 0;
     if (mapped) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[0], A->ev[1])); s.seed_kernel_ms = ms; }
@@ -1523,6 +1578,7 @@ static int collect_stats(mgx_aligner *A, bool mapped, bool aligned) {
         HIP_TRY(hipEventElapsedTime(&ms, A->ev[4], A->ev[5])); s.sort_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, A->ev[5], A->ev[3])); s.extend_ms = ms;
         HIP_TRY(hipEventElapsedTime(&ms, A->ev[5], A->ev[6])); s.lane_ms = ms;
+        if (A->seedlane_launched) { HIP_TRY(hipEventElapsedTime(&ms, A->ev[2], A->ev[7])); s.seed_lane_ms = ms; }
     }
     return MGX_OK;
 }
@@ -1603,6 +1659,7 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
         else if (key == "device_share") o.device_share = std::max(1, std::min(v, 64));
         else if (key == "map_pipe") o.map_pipe = v;
         else if (key == "seed_wps") o.seed_wps = v;
+        else if (key == "seed_lane") o.seed_lane = v;
         else if (key == "retry_capacity") A->retry_capacity = v != 0;
         else return fail(MGX_ERR_INVALID, "unknown option '%s'", name);
         return MGX_OK;

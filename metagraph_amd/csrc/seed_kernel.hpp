@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(64, WPS) k_align(mgx::AlignParams P, uint32_t 
         if (lane_id() == 0) rv.v = atomicAdd(P.read_cursor, 1ull);
         uint64_t item = wave_bcast(rv, 0);
         if (item >= n_items) break;
-        uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : item;
+        uint64_t read = (PHASE == PH_EXTEND && P.order) ? P.order[item] : (PHASE == PH_SEED && P.seed_list) ? (uint64_t)P.seed_list[item] : item;
         const uint8_t *rec = nullptr;
         if (PHASE == PH_EXTEND && P.resume_in) {         // a later pass of the multi-pass extension: `read` is a retry position
             rec = P.resume_in + read * P.resume_rec_bytes;

@@ -213,6 +213,11 @@ class HipDBGAligner : public IDBGAligner {
         const std::string opt = "device_share=" + std::to_string(workers ? workers : 1);
         mgx_aligner_set_pipeline(a_, opt.c_str());
     }
+    // a result-preserving kernel-selection switch of the library ("key=value", mgx_aligner_set_pipeline): A/B runs
+    void set_kernel_option(const std::string &opt) {
+        if (int rc = mgx_aligner_set_pipeline(a_, opt.c_str()))
+            throw std::runtime_error(std::string(mgx_last_error()) + " (" + std::to_string(rc) + ")");
+    }
     ~HipDBGAligner() override { mgx_aligner_destroy(a_); }
     const HipBOSSGraph &get_graph() const override { return graph_; }
     const DBGAlignerConfig &get_config() const override { return config_; }

@@ -97,6 +97,7 @@ int main(int argc, char **argv) {
     bool have_lim = false;
     int devices = 1;
     std::vector<const char *> anno_paths;
+    std::vector<std::string> kernel_options;            // --kernel-option key=value: result-preserving kernel selection (A/B runs)
     mgx_limits_init_default(&lim, 0);
     for (int i = 3; i < argc; ++i) {
         if (!strcmp(argv[i], "--align-only-forwards")) cfg.forward_and_reverse_complement = 0;
@@ -107,6 +108,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--max-columns") && i + 1 < argc) { lim.max_columns = (uint32_t)atoi(argv[++i]); have_lim = true; }
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, atoi(argv[++i]));
         else if (!strcmp(argv[i], "-a") && i + 1 < argc) anno_paths.push_back(argv[++i]);
+        else if (!strcmp(argv[i], "--kernel-option") && i + 1 < argc) kernel_options.push_back(argv[++i]);
         else if (!strcmp(argv[i], "--time")) report_time = true;            // wall time of the align loop (batches -> results printed) on stderr
         else if (!strcmp(argv[i], "--canonical")) graph_mode = MGX_MODE_CANONICAL;
         else if (!strcmp(argv[i], "--primary")) graph_mode = MGX_MODE_PRIMARY;         // aligned through the CanonicalDBG wrapper
@@ -184,6 +186,7 @@ int main(int argc, char **argv) {
                     HipDBGAligner &aligner = *aligner_p;
                     // (the workers of one device share it: every handle on its own stream, its arenas sized for its share)
                     aligner.set_device_share((threads + (unsigned)devices - 1) / (unsigned)devices);
+                    for (const std::string &opt : kernel_options) aligner.set_kernel_option(opt);
                     aligner.align_batch(batches[bi], [&](const std::string &header, AlignmentResults &&paths) {
                         const std::string res = format_alignment(header, paths, cfg.min_path_score, annotation ? &label_names : nullptr);
                         std::lock_guard<std::mutex> lock(print_mutex);

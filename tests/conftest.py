@@ -48,8 +48,8 @@ KERNEL_VARIANTS = {
     # 65536 chains on; "auto" keeps the one-step-per-lane machine, so both mapping kernels feed every parity test)
     "grp8": (("ext64=0", "lane=0", "map_pipe=2"), ("grp8_any",), ("ext64", "lane")),              # 8-lane groups, reads spread over wavefronts
     "grp8x8": (("ext64=0", "lane=0", "groups_per_wave=0", "map_pipe=2"), ("grp8_any",), ("ext64", "lane")),   # ... 8 reads per wavefront
-    "lane": (("ext64=0", "lane=1", "groups_per_wave=0", "map_pipe=2"), (), ("ext64",)),           # the lane-per-read kernel first (where the
-                                                                                    # configuration qualifies), 8-lane groups behind it
+    "lane": (("ext64=0", "lane=1", "groups_per_wave=0", "map_pipe=2", "seed_lane=1"), (), ("ext64",)),           # the lane-per-read kernels first (seeding and
+                                                                                    # extension, where the configuration qualifies), the wave programs behind them
 }
 
 

@@ -15,6 +15,7 @@
 #include "map_pipe.hpp"
 #include "host_common.hpp"
 #include "lane_read.hpp"
+#include "seed_lane.hpp"
 
 using namespace mgx;
 
@@ -44,6 +45,8 @@ struct EmuRun {
     uint64_t out_used = 0;        // words of `stream` in use
     uint64_t lane_done = 0, lane_ran = 0;     // MGX_EMU_LANE: reads the lane-per-read path finished; whether it ran at all
     uint64_t lane_bail[32] = { 0 };            // ... and why it sent the others on (LANE_BAIL codes)
+    uint64_t seedlane_done = 0, seedlane_ran = 0;       // MGX_EMU_SEEDLANE: reads the lane-per-read seeder finished; whether it ran
+    uint64_t seedlane_bail[16] = { 0 };
     std::vector<uint8_t> lane_reason;          // per read: 0 = finished by the lane path, else the code
 };
 // the label matrix in the device's row-major form (mgx_annot.hip: head word = count:16 | single label or offset into more[])
@@ -454,8 +457,37 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
         unsigned long long seed_cursor = 0;
         P.seed_hdr = hdr.data(); P.seed_stream = sstream.data(); P.seed_capacity = sstream.size();
         P.seed_cursor = &seed_cursor; P.work_key = key.data();
+        // MGX_EMU_SEEDLANE=1: the lane-per-read seeder in front of the wave program's, as mgx.hip launches it (seed_lane_enabled()
+        // decides whether the batch qualifies): read i runs as lane i % 64 of one wavefront's interleaved seed buffer; what it
+        // leaves is seeded by the wave program from scratch
+        std::vector<uint8_t> seeded(n, 0);
+        {
+            const char *sl_env = getenv("MGX_EMU_SEEDLANE");
+            if (sl_env && *sl_env == '1' && P.pkw[0] && (!dcfg.fwd_and_rc || P.pkw[1])
+                    && seed_lane_enabled(dcfg, k, R->lim.Lmax, true, true)) {
+                std::vector<uint64_t> sq(2 * SL_QWORDS);
+                std::vector<uint32_t> sbuf(SL_WAVE_SCRATCH_WORDS, 0);
+                R->seedlane_ran = 1;
+                for (uint64_t i = 0; i < n; ++i) {
+                    SeedLaneChip chip = { sq.data(), 1, sbuf.data() + (i % 64), 64 };
+                    SeedLaneOut so;
+                    so.reason = 0;
+                    if (seed_lane_read(P, i, chip, so) == SL_DONE) {
+                        const uint64_t at = seed_cursor;
+                        seed_cursor += (uint64_t)(so.n_seeds[0] + so.n_seeds[1]);
+                        seed_lane_publish(P, i, chip, so, at);
+                        R->stats.seeds += (uint64_t)(so.n_seeds[0] + so.n_seeds[1]);
+                        seeded[i] = 1;
+                        ++R->seedlane_done;
+                    } else {
+                        ++R->seedlane_bail[so.reason & 15u];
+                    }
+                    R->stats.rank_lines += so.ctr.rank_lines; R->stats.select_lines += so.ctr.select_lines; R->stats.bit_lines += so.ctr.bit_lines;
+                }
+            }
+        }
         for (uint64_t i = 0; i < n; ++i)
-            align_read<PH_SEED>(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
+            if (!seeded[i]) align_read<PH_SEED>(*w, P, i, 0, &R->stats, &sd, rows.data(), lds.data(), (uint32_t)(lds_env ? atoi(lds_env) : 2048));
         for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
         P.order = order.data();
@@ -639,6 +671,12 @@ uint32_t emu_seed_info(void *r, uint32_t *info6, uint32_t *seeds) {
 }
 void emu_lane_stats(void *r, uint64_t *out2) { out2[0] = static_cast<EmuRun *>(r)->lane_ran; out2[1] = static_cast<EmuRun *>(r)->lane_done; }
 void emu_lane_reasons(void *r, uint8_t *out, uint64_t n) { auto &v = static_cast<EmuRun *>(r)->lane_reason; for (uint64_t i = 0; i < n && i < v.size(); ++i) out[i] = v[i]; }
+// [0] whether the lane-per-read seeder ran, [1] reads it finished, [2 .. 18) reads it left, by reason
+void emu_seedlane_stats(void *r, uint64_t *out18) {
+    const EmuRun *R = static_cast<EmuRun *>(r);
+    out18[0] = R->seedlane_ran; out18[1] = R->seedlane_done;
+    for (int x = 0; x < 16; ++x) out18[2 + x] = R->seedlane_bail[x];
+}
 void emu_lane_bails(void *r, uint64_t *out32) { for (int x = 0; x < 32; ++x) out32[x] = static_cast<EmuRun *>(r)->lane_bail[x]; }
 void emu_stats(void *r, uint64_t *out8) {
     auto &s = static_cast<EmuRun *>(r)->stats;

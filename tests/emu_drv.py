@@ -200,6 +200,13 @@ class EmuRun:
         L().emu_lane_reasons(self.r, a, self.n)
         return list(a)[:self.n]
 
+    def seedlane_stats(self):
+        """MGX_EMU_SEEDLANE=1 runs: (whether the lane-per-read seeder ran, reads it finished, {reason: reads it left})"""
+        a = (C.c_uint64 * 18)()
+        L().emu_seedlane_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L().emu_seedlane_stats(self.r, a)
+        return bool(a[0]), int(a[1]), {i: int(a[2 + i]) for i in range(16) if a[2 + i]}
+
     def lane_bails(self):
         """reads the lane-per-read path sent on to the wave program, by LANE_BAIL code (lane_read.hpp)"""
         a = (C.c_uint64 * 32)()

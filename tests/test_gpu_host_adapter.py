@@ -139,7 +139,7 @@ def test_mgx_align_workers_share_one_device(tmp_path):
     exe = os.path.join(ROOT, "metagraph_amd", "_build", "mgx_align")
     batch = str(n_reads * read_len // 8)              # eight tasks
     outs, secs = {}, {}
-    for p in (1, 4, 1, 4):
+    for p in (1, 4, 1, 4, 1, 4):          # (best of three: a run now and then pays ~1 s for fresh device blocks, with any number of workers)
         out = tmp_path / ("out_p%d.tsv" % p)
         with open(out, "w") as fo:
             r = subprocess.run([exe, str(dump), str(fa), "-p", str(p), "--query-batch-size", batch, "--time"],

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--modes", default="0,0,1,2,2", help="graph modes to draw from (0 BASIC, 1 CANONICAL, 2 PRIMARY)")
     ap.add_argument("--lane", action="store_true", help="campaign of the lane-per-read path: BASIC graphs, k <= 32, one alignment per "
                     "query, the split pipeline with MGX_EMU_LANE=1, short reads, more reads per world, scoring variants")
+    ap.add_argument("--seedlane", action="store_true", help="campaign of the lane-per-read seeder: BASIC / CANONICAL graphs, k <= 32, the split "
+                    "pipeline with MGX_EMU_SEEDLANE=1, reads of up to 160 characters mostly, seed lists compared")
     ap.add_argument("--labels", action="store_true", help="campaign of label-aware alignment (LabeledAligner): BASIC graphs built from "
                     "several diverged strains, a label per strain and per genome segment, compared with the oracle's LabeledAligner "
                     "(alignment lists and their label sets)")
@@ -41,6 +43,7 @@ def main():
     it = args.start
     n_reads_total = 0
     n_lane_total = 0
+    sl_why = {}
     lab_hist = [0] * 12                  # --labels: reads by their number of alignments (0..5+), alignments by their number of labels
     while time.time() < t_end and not (args.worlds and it >= args.start + args.worlds):
         seed = args.seed * 1000003 + it
@@ -54,6 +57,9 @@ def main():
         if args.labels:
             mode = rng.choice([0, 0, 1, 2])
             k = rng.choice([5, 7, 8, 11, 12, 15, 19, 20, 31, 33])
+        if args.seedlane:
+            mode = rng.choice([0, 0, 0, 1])
+            k = rng.choice([5, 7, 8, 11, 12, 15, 19, 20, 27, 31, 32])
         mask = rng.random() < 0.4
         glen = rng.choice([300, 1000, 3000, 6000])
         genome = rand_seq(rng, glen)
@@ -131,6 +137,8 @@ def main():
             L = rng.choice([k - 1, k, k + 3, 40, 100, 150, 150, 400, 1200])      # long reads: wide bands, many seeds, long chains
             if args.lane:
                 L = rng.choice([k, k + 3, 40, 75, 100, 150, 150, 150, 250, 256, 257])
+            if args.seedlane:
+                L = rng.choice([k - 1, k, k + 1, k + 3, 40, 75, 100, 150, 150, 150, 159, 160, 161, 250])
             if k < 11 and L > 150:
                 L = 150                                          # (tiny k x long reads: thousands of extensions per read, minutes per world)
             L = max(1, min(L, len(genome) - 1))
@@ -164,6 +172,10 @@ def main():
             os.environ.pop("MGX_EMU_MULTIPASS", None)
             os.environ["MGX_EMU_SPLIT"] = "1"
             os.environ["MGX_EMU_LANE"] = "1"
+        os.environ.pop("MGX_EMU_SEEDLANE", None)
+        if args.seedlane:
+            os.environ["MGX_EMU_SPLIT"] = "1"
+            os.environ["MGX_EMU_SEEDLANE"] = "1"
         if args.labels:
             os.environ.pop("MGX_EMU_MULTIPASS", None)
             cfg.num_alternative_paths = rng.choice([1, 1, 1, 2, 3, 4])
@@ -215,15 +227,21 @@ def main():
                 for strand in (0, 1):
                     for q, (ss, nm) in enumerate(o.seeds(strand)):
                         assert info[q]["num_matches"][strand] == nm, ("num_matches", q, strand, reads[q])
-                        assert info[q]["seeds"][strand] == emu_drv.oracle_seeds_as_tuples(ss), ("seeds", q, strand, reads[q])
+                        assert info[q]["seeds"][strand] == emu_drv.oracle_seeds_as_tuples(ss), ("seeds", q, strand, reads[q], info[q]["seeds"][strand], emu_drv.oracle_seeds_as_tuples(ss))
             n_reads_total += len(reads)
             if args.lane:
                 n_lane_total += e.lane_stats()[1]
+            if args.seedlane:
+                ran, done, why = e.seedlane_stats()
+                n_lane_total += done
+                for c, v in why.items():
+                    sl_why[c] = sl_why.get(c, 0) + v
         except AssertionError as ex:
             print("MISMATCH", desc)
             print(str(ex)[:3000])
             sys.exit(1)
     print("ok: %d worlds, %d reads, no difference" % (it, n_reads_total) + (" (%d reads finished by the lane path)" % n_lane_total if args.lane else "")
+          + (" (%d reads seeded by the lane-per-read seeder; left by reason: %s)" % (n_lane_total, dict(sorted(sl_why.items()))) if args.seedlane else "")
           + (" (reads with 0..5+ alignments: %s; alignments with 0..5+ labels: %s)" % (lab_hist[:6], lab_hist[6:]) if args.labels else ""))
 
 
