@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 4      /* 4 (round 5): mgx_stats::n_capacity_retried, mgx_chain_alignments, post_chain_alignments accepted;
+#define MGX_ABI_VERSION 5      /* 5 (round 6): mgx_stats::n_seed_lane_reads / seed_lane_ms / seed_lane_left_reads, streams, coordinates,
+                                * mgx_chain_seeds; 4 (round 5): mgx_stats::n_capacity_retried, mgx_chain_alignments, post_chain_alignments accepted;
                                 * 3 (round 4): mgx_alignment::n_labels / labels_begin, mgx_results::labels (label-aware alignment),
                                 * mgx_stats::extend_kernels / n_lane_reads / lane_ms, "key=value" options of mgx_aligner_set_pipeline;
                                 * 2 (round 3): mgx_annotation_*; mgx_stats / mgx_config grew in round 2 without a bump (callers built

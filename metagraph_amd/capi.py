@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 MGX_OK = 0
-MGX_ABI_VERSION = 4
+MGX_ABI_VERSION = 5
 MGX_ERR_INVALID, MGX_ERR_NO_DEVICE, MGX_ERR_UNSUPPORTED, MGX_ERR_CONFIG, MGX_ERR_CAPACITY, MGX_ERR_OOM = -1, -2, -3, -4, -5, -6
 OP_CHARS = "SX=DIG"
 

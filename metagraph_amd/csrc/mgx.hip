@@ -1349,27 +1349,45 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                                && seed_lane_enabled(A->dcfg, (uint32_t)A->graph->g.k, l.Lmax, true, true)
                                && (A->opt.seed_lane == 1 || n >= 4096);
         if (seed_lane && n) {
-            const uint32_t sl_blocks = (uint32_t)std::min<uint64_t>((uint64_t)prop.multiProcessorCount * 4 * (uint64_t)mgx_seed_lane_waves_per_simd(), (n + 63) / 64);
-            if (int rc = A->seedlane_scratch.ensure((size_t)sl_blocks * SL_WAVE_SCRATCH_WORDS * 4)) return rc;
-            if (int rc = A->seedlane_params.ensure(sizeof(SeedLaneParams))) return rc;
-            if (int rc = A->seedlane_bail.ensure(n * 4 + 4)) return rc;
+            const uint32_t resident = (uint32_t)prop.multiProcessorCount * 4 * (uint32_t)mgx_seed_lane_waves_per_simd();
+            const uint32_t blocks1 = (uint32_t)std::min<uint64_t>(resident, (n + 63) / 64);
+            // (the second pass: what the first left — a sixth of a typical batch — with the big buffers)
+            const uint32_t blocks2 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(resident, (n / 4 + 63) / 64));
+            const uint64_t words1 = seed_lane_wave_scratch_words(SL_SEEDS_1, SL_PENDING_1), words2 = seed_lane_wave_scratch_words(SL_SEEDS_2, SL_PENDING_2);
+            if (int rc = A->seedlane_scratch.ensure((size_t)std::max<uint64_t>(blocks1 * words1, blocks2 * words2) * 4)) return rc;
+            if (int rc = A->seedlane_params.ensure(2 * sizeof(SeedLaneParams))) return rc;
+            if (int rc = A->seedlane_bail.ensure(2 * (n * 4 + 4))) return rc;
             if (int rc = A->seedlane_hist.ensure(32 * 8)) return rc;          // ([16 .. 24): section timers of -DMGX_SL_TIMERS builds)
             HIP_TRY(hipMemsetAsync(A->seedlane_hist.p, 0, 32 * 8, A->hstream));
-            HIP_TRY(hipMemsetAsync(cur + 8, 0, 16, A->hstream));
-            SeedLaneParams SP;
-            memset(&SP, 0, sizeof(SP));
-            SP.P = P;
-            SP.P.n_items = n;
-            SP.scratch = A->seedlane_scratch.as<uint32_t>();
-            SP.bail_list = A->seedlane_bail.as<uint32_t>();
-            SP.bail_count = cur + 8;
-            SP.done_count = cur + 9;
-            SP.bail_hist = A->seedlane_hist.as<unsigned long long>();
-            HIP_TRY(copy_sync(A, A->seedlane_params.p, &SP, sizeof(SP), hipMemcpyHostToDevice));
-            if (int rc = mgx_launch_seed_lane(A->seedlane_params.p, sl_blocks, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane-per-read seeder: %d", rc);
+            HIP_TRY(hipMemsetAsync(cur + 8, 0, 32, A->hstream));
+            const bool two = A->opt.seed_lane != 2;                          // (seed_lane=2: A/B switch, the first pass only)
+            SeedLaneParams SP[2];
+            memset(SP, 0, sizeof(SP));
+            uint32_t *list1 = A->seedlane_bail.as<uint32_t>(), *list2 = list1 + n + 1;
+            for (int ps = 0; ps < 2; ++ps) {
+                SP[ps].P = P;
+                SP[ps].P.n_items = n;
+                SP[ps].scratch = A->seedlane_scratch.as<uint32_t>();
+                SP[ps].max_entries = ps ? SL_SEEDS_2 : SL_SEEDS_1; SP[ps].max_pending = ps ? SL_PENDING_2 : SL_PENDING_1;
+                SP[ps].second_pass = (uint32_t)ps;
+                SP[ps].in_list = ps ? list1 : nullptr; SP[ps].in_count = ps ? cur + 8 : nullptr; SP[ps].in_count_back = ps ? cur + 11 : nullptr;
+                SP[ps].list_len = n;
+                SP[ps].bail_list = ps ? list2 : list1;
+                SP[ps].bail_count = ps ? cur + 10 : cur + 8;
+                SP[ps].bail_count_back = (!ps && two) ? cur + 11 : nullptr;
+                SP[ps].done_count = cur + 9;
+                // (why a read left: counted where it leaves for the wave program)
+                SP[ps].bail_hist = (ps || !two) ? A->seedlane_hist.as<unsigned long long>() : nullptr;
+            }
+            HIP_TRY(copy_sync(A, A->seedlane_params.p, SP, sizeof(SP), hipMemcpyHostToDevice));
+            if (int rc = mgx_launch_seed_lane(A->seedlane_params.p, blocks1, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane-per-read seeder: %d", rc);
             HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));                      // rewind the read cursor
-            P.seed_list = A->seedlane_bail.as<uint32_t>();
-            P.n_items_ptr = cur + 8;
+            if (two) {
+                if (int rc = mgx_launch_seed_lane(A->seedlane_params.as<SeedLaneParams>() + 1, blocks2, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane-per-read seeder, second pass: %d", rc);
+                HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));
+            }
+            P.seed_list = two ? list2 : list1;
+            P.n_items_ptr = two ? cur + 10 : cur + 8;
             A->seedlane_launched = 1;
         }
         HIP_TRY(hipEventRecord(A->ev[7], A->hstream));

@@ -24,11 +24,15 @@ __global__ void __launch_bounds__(64, MGX_SEEDLANE_WAVES_PER_SIMD) k_seed_lane(c
     const SeedLaneParams &SP = *SPp;
     const AlignParams &P = SP.P;
     __shared__ uint64_t s_qw[2 * SL_QWORDS][64];
+    __shared__ uint32_t s_cnt[16][64];
     const int lane = (int)threadIdx.x;
     SeedLaneChip chip;
     chip.qw = &s_qw[0][lane]; chip.qstride = 64;
-    chip.sbuf = SP.scratch + (uint64_t)blockIdx.x * SL_WAVE_SCRATCH_WORDS + (uint32_t)lane; chip.sstride = 64;
-    const uint64_t n_items = P.n_items ? P.n_items : P.n_reads;
+    chip.sbuf = SP.scratch + (uint64_t)blockIdx.x * seed_lane_wave_scratch_words(SP.max_entries, SP.max_pending) + (uint32_t)lane; chip.sstride = 64;
+    chip.cnt = &s_cnt[0][lane]; chip.cntstride = 64;
+    chip.max_entries = (int32_t)SP.max_entries; chip.max_pending = (int32_t)SP.max_pending; chip.second_pass = (int32_t)SP.second_pass;
+    const uint64_t n_front = SP.second_pass ? (uint64_t)gld(SP.in_count) : 0, n_back = SP.second_pass && SP.in_count_back ? (uint64_t)gld(SP.in_count_back) : 0;
+    const uint64_t n_items = SP.second_pass ? n_front + n_back : (P.n_items ? P.n_items : P.n_reads);
     uint32_t c_rank = 0, c_sel = 0, c_bit = 0, c_seeds = 0, c_done = 0;
     for (;;) {
         // one read per lane and round
@@ -37,8 +41,11 @@ __global__ void __launch_bounds__(64, MGX_SEEDLANE_WAVES_PER_SIMD) k_seed_lane(c
         if (lane == 0) bv.v = atomicAdd(P.read_cursor, 64ull);
         const uint64_t base = wave_bcast(bv, 0);
         if (base >= n_items) break;
-        const uint64_t read = base + (uint64_t)lane;
-        const bool active = read < n_items;
+        const uint64_t item = base + (uint64_t)lane;
+        const bool active = item < n_items;
+        const uint64_t read = !active ? 0 : !SP.second_pass ? item
+                              : (uint64_t)gld(SP.in_list + (item < n_front ? item : SP.list_len - 1 - (item - n_front)));
+        chip.second_pass = !SP.second_pass ? 0 : item < n_front ? 1 : 2;
         SeedLaneOut out;
 #if MGX_SL_TIMERS
         out.t0 = cycle_clock();
@@ -68,21 +75,22 @@ __global__ void __launch_bounds__(64, MGX_SEEDLANE_WAVES_PER_SIMD) k_seed_lane(c
         }
 #if MGX_SL_TIMERS
         SL_T(6);
-        if (lane == 0) for (int x = 0; x < 8; ++x) atomicAdd(SP.bail_hist + 16 + x, (unsigned long long)out.t[x]);
+        if (lane == 0 && SP.bail_hist) for (int x = 0; x < 8; ++x) atomicAdd(SP.bail_hist + 16 + x, (unsigned long long)out.t[x]);
 #endif
         if (active) { c_rank += out.ctr.rank_lines; c_sel += out.ctr.select_lines; c_bit += out.ctr.bit_lines; }
         // the reads for the wave program
-        LV<bool> bl;
-        bl.v = bail;
-        const uint64_t bm = wave_ballot(bl);
-        if (bm) {
+        for (int side = 0; side < 2; ++side) {
+            LV<bool> bl;
+            bl.v = bail && (side == 1) == (SP.bail_count_back != nullptr && out.reason != 4u);
+            const uint64_t bm = wave_ballot(bl);
+            if (!bm) continue;
             LV<uint64_t> pv;
             pv.v = 0;
-            if (lane == 0) pv.v = atomicAdd(SP.bail_count, (unsigned long long)popc64(bm));
-            const uint64_t p0 = wave_bcast(pv, 0);
-            if (bail) {
-                gst(SP.bail_list + p0 + (uint64_t)popc64(bm & ((1ull << lane) - 1)), (uint32_t)read);
-                atomicAdd(SP.bail_hist + (out.reason & 15u), 1ull);
+            if (lane == 0) pv.v = atomicAdd(side ? SP.bail_count_back : SP.bail_count, (unsigned long long)popc64(bm));
+            const uint64_t at = wave_bcast(pv, 0) + (uint64_t)popc64(bm & ((1ull << lane) - 1));
+            if (bl.v) {
+                gst(SP.bail_list + (side ? SP.list_len - 1 - at : at), (uint32_t)read);
+                if (SP.bail_hist) atomicAdd(SP.bail_hist + (out.reason & 15u), 1ull);
             }
         }
     }
@@ -102,7 +110,7 @@ __global__ void __launch_bounds__(64, MGX_SEEDLANE_WAVES_PER_SIMD) k_seed_lane(c
     }
 }
 
-// blocks = resident wavefronts (wavefront b owns SeedLaneParams::scratch + b * seed_lane_wave_scratch_words())
+// blocks = resident wavefronts (wavefront b owns SeedLaneParams::scratch + b * seed_lane_wave_scratch_words(...))
 extern "C" int mgx_launch_seed_lane(const void *d_params, uint32_t blocks, void *stream) {
     k_seed_lane<<<blocks, 64, 0, (hipStream_t)stream>>>(static_cast<const SeedLaneParams *>(d_params));
     return (int)hipGetLastError();

@@ -37,24 +37,39 @@ namespace mgx {
 constexpr int SL_MAX_KMERS = 128;          // k-mer positions of a strand (two 64-bit masks)
 constexpr int SL_MAX_L = 160;              // longest read a lane takes
 constexpr int SL_QWORDS = 6;               // packed strand: 32 codes per word, one zero word behind the last
-constexpr int SL_MAX_SEEDS = 32;           // seeds of a read (both strands) the lane's buffer holds
 constexpr int SL_SEED_WORDS = 3;           // a DevSeed as three words
-constexpr int SL_MAX_PENDING = 8;          // reporting sub-k positions of a read whose look-ups are made side by side
-constexpr int SL_PEND_WORDS = 6;
+constexpr int SL_PEND_WORDS = 6;           // a pending record (below)
+// Two passes (mgx.hip): the first takes every read with a small buffer — at most SL_SEEDS_1 buffer entries, SL_PENDING_1 of
+// them reporting sub-k positions, whose look-ups the lanes of a wavefront make side by side — and leaves, among others, the
+// reads that need more and the reads its quick DUST scan cannot clear; the second takes what the first left with room for
+// every seed a read of SL_MAX_L characters can have, the exact interval test, and the strands below min_exact_match (a
+// look-up per matched k-mer).  Reads of a kind side by side again: in one launch the few heavy reads would hold up their
+// 63 wave-mates for dozens of look-ups each.
+constexpr int SL_SEEDS_1 = 32, SL_PENDING_1 = 8;
+constexpr int SL_SEEDS_2 = 160, SL_PENDING_2 = 144;
 
 // what one launch of the kernel needs on top of AlignParams
 struct SeedLaneParams {
     AlignParams P;
-    uint32_t *scratch;                     // per resident wavefront SL_WAVE_SCRATCH_WORDS words: word w of seed t of lane l at
+    uint32_t *scratch;                     // per resident wavefront seed_lane_wave_scratch_words() words: word w of seed t of lane l at
                                            // ((t * SL_SEED_WORDS + w) * 64 + l); the pending records behind the seeds
-    uint32_t *bail_list;                   // reads for the wave-per-read seeder
-    unsigned long long *bail_count;
+    uint32_t max_entries, max_pending;     // buffer entries / pending records a lane's share of the scratch holds
+    uint32_t second_pass;                  // 0: every read of the batch; 1: the reads of in_list (what the first pass left)
+    // The first pass lists what it leaves from both ends of one array of list_len entries: the reads its quick DUST scan could not
+    // clear from the front, the others (strands below min_exact_match: dozens of look-ups each) from the back — so that the
+    // second pass, which takes 64 consecutive entries per wavefront, has reads of a kind side by side.
+    const uint32_t *in_list;
+    const unsigned long long *in_count, *in_count_back;
+    uint64_t list_len;
+    uint32_t *bail_list;                   // reads for the next pass / the wave-per-read seeder
+    unsigned long long *bail_count, *bail_count_back;      // (bail_count_back: null = one list, from the front)
     unsigned long long *done_count;
     unsigned long long *bail_hist;         // [16] reads passed on, by reason
 };
 
-constexpr uint64_t SL_WAVE_SCRATCH_WORDS = ((uint64_t)SL_MAX_SEEDS * SL_SEED_WORDS + (uint64_t)SL_MAX_PENDING * SL_PEND_WORDS) * 64;
-inline uint64_t seed_lane_wave_scratch_words() { return SL_WAVE_SCRATCH_WORDS; }
+MGX_HD uint64_t seed_lane_wave_scratch_words(uint32_t max_entries, uint32_t max_pending) {
+    return ((uint64_t)max_entries * SL_SEED_WORDS + (uint64_t)max_pending * SL_PEND_WORDS) * 64;
+}
 
 // does the batch's configuration suit the kernel at all (mgx.hip; the host model asks the same)
 inline bool seed_lane_enabled(const DevConfig &d, uint32_t k, uint32_t Lmax, bool have_match_lengths, bool have_packed) {
@@ -71,6 +86,9 @@ inline bool seed_lane_enabled(const DevConfig &d, uint32_t k, uint32_t Lmax, boo
 struct SeedLaneChip {
     uint64_t *qw; int32_t qstride;         // packed strand s, word j: qw[(s * SL_QWORDS + j) * qstride]
     uint32_t *sbuf; int32_t sstride;       // the lane's seed buffer: word w of seed t at sbuf[(t * SL_SEED_WORDS + w) * sstride]
+    int32_t max_entries, max_pending;      // its capacities (SeedLaneParams)
+    int32_t second_pass;                   // 0 first pass; second pass: 1 = a read the quick DUST scan could not clear, 2 = another
+    uint32_t *cnt; int32_t cntstride;      // 64 byte counters (the DUST scans' triplet counts): byte t in word cnt[(t >> 2) * cntstride]
 };
 
 struct SeedLaneOut {
@@ -168,6 +186,32 @@ MGX_DEV bool sl_dust_could_mask(const uint64_t *qw, int32_t qstride, int32_t L) 
     return false;
 }
 
+// maybe_low_complexity (align_core.hpp) for one lane, second pass: is there an interval of at most 62 consecutive triplets whose
+// DUST score exceeds T — pairs of equal triplets times 10 above T times (triplets - 1), the test find_perfect applies?  Every
+// interval sdust can mask, on the strand or on any window of it, is one: `false` proves that no window is low-complexity.  Per
+// end position the start walks back and r grows by the number of later positions with the start's triplet (byte counts in
+// the lane's 64-byte table).  Mirror-symmetric, so one strand's answer serves both.
+MGX_DEV_NOINLINE bool sl_dust_interval_exists(const uint64_t *qw, int32_t qstride, int32_t L, uint32_t *cnt, int32_t cntstride) {
+    constexpr int32_t T = 20, SPAN = 61;
+    auto at = [&](uint32_t t) -> uint8_t * { return (uint8_t *)(cnt + (t >> 2) * cntstride) + (t & 3u); };
+    for (int32_t e = 2; e < L; ++e) {
+#pragma unroll
+        for (int x = 0; x < 16; ++x) cnt[x * cntstride] = 0;
+        uint32_t t = (sl_code(qw, qstride, e - 2) << 4) | (sl_code(qw, qstride, e - 1) << 2) | sl_code(qw, qstride, e);
+        *at(t) = 1;
+        int32_t r = 0;
+        for (int32_t d = 1; d <= SPAN && e - d >= 2; ++d) {
+            t = (t >> 2) | (sl_code(qw, qstride, e - d - 2) << 4);           // the triplet that ends at e - d
+            uint8_t *c = at(t);
+            const uint32_t v = *c;
+            r += (int32_t)v;
+            *c = (uint8_t)(v + 1);
+            if (r * 10 > T * d) return true;
+        }
+    }
+    return false;
+}
+
 // BOSS::index_range (boss.hpp:720-764) on a packed strand without invalid characters: codes [i, i + len); as index_range_lane
 MGX_DEV int32_t sl_index_range(const DevGraph &g, const uint64_t *qw, int32_t qstride, int32_t i, int32_t len, int32_t min_len,
                                uint64_t *first, uint64_t *last, LineCtr &ctr) {
@@ -204,11 +248,12 @@ MGX_DEV void sl_store_seed(const SeedLaneChip &chip, int32_t t, int32_t clip, in
     gst(d + 2 * chip.sstride, node);
 }
 // A reporting sub-k position whose nodes are not known yet (a "pending" seed): a seed with n_nodes == 0 in the buffer, its
-// node word = which pending record (SL_MAX_PENDING of SL_PEND_WORDS words behind the seeds) holds what the look-up needs
+// node word = which pending record (SL_PEND_WORDS words each, behind the seeds) holds what the look-up needs
 // and, afterwards, what it found: [0] kind (1 = k_map's range at slot [1], 2 = the range first [1] .. last [2] of the walk that
-// was made, 3 = the walk is still to make) -> number of nodes; [1 .. 4] -> the nodes; [5] strand | tail position flag
+// was made, 3 = the walk is still to make, 4 = the matched k-mer at position [1]: the range is its node's) -> number of nodes;
+// [1 .. 4] -> the nodes; [5] strand | tail position << 1 | a MEM starts at the last k-mer << 2 | its buffer entry << 8
 MGX_DEV uint32_t *sl_pending(const SeedLaneChip &chip, int32_t j) {
-    return chip.sbuf + (SL_MAX_SEEDS * SL_SEED_WORDS + j * SL_PEND_WORDS) * chip.sstride;
+    return chip.sbuf + (chip.max_entries * SL_SEED_WORDS + j * SL_PEND_WORDS) * chip.sstride;
 }
 
 // One strand: make_seeder<false> (+ strand_without_seeds, which only answers the same question sooner) up to the look-ups
@@ -295,7 +340,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
             const int32_t mem_length = (next - it) + k - 1;
             if ((uint32_t)mem_length >= cfg.min_seed_length) {
                 if (ns >= max_seeds) SL_LEAVE(6);
-                if (t0 + ns >= SL_MAX_SEEDS) SL_LEAVE(7);
+                if (t0 + ns >= chip.max_entries) SL_LEAVE(7);
                 sl_store_seed(chip, t0 + ns, it, mem_length, 0, next - it, 0u);
                 ++ns;
             }
@@ -306,7 +351,9 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
     }
     // Matched k-mers that base_seeds does not report (num_matching below min_exact_match): every one of them becomes a
     // sub-k position with a look-up of its own (k - 1 characters) — dozens of walks per strand: the wave program's
-    if (!base_ok && (mt0 | mt1)) SL_LEAVE(8);
+    // (the second pass takes them: the look-up of a matched k-mer's position needs no walk — its k - 1 characters are the
+    // label of the BOSS node the k-mer's edge leaves, so the range is that node's edges: kind 4)
+    if (!base_ok && (mt0 | mt1) && !chip.second_pass) SL_LEAVE(8);
     const int32_t msl0 = (int32_t)cfg.min_seed_length;
     const int32_t nslots = L - msl0 + 1;
     const bool tail_known = test2(mt0, mt1, n - 1);                // (no invalid character; plain graph)
@@ -329,7 +376,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
             if (next < n && test2(mt0, mt1, next)) ++next;
             const int32_t nn = next - i, mem_length = nn + k - 1;
             if (ns >= max_seeds) SL_LEAVE(6);
-            if (t0 + ns >= SL_MAX_SEEDS) SL_LEAVE(7);
+            if (t0 + ns >= chip.max_entries) SL_LEAVE(7);
             sl_store_seed(chip, t0 + ns, i, mem_length, 0, nn, 0u);
             ++ns;
             count_matches(i, i + mem_length);
@@ -346,7 +393,9 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
         if (max_len >= eff) {
             // the position's longest-prefix lookup, as far as needed (lookup_position of make_seeder)
             int32_t ml = 0, src = 2, known_at = i;                 // src: 1 = k_map's range, 2 = walk, 3 = walk only if it reports
-            if (i < n) {                                           // (max_len == k - 1 here)
+            if (i < n && test2(mt0, mt1, i)) {                     // (a matched k-mer no MEM reports: see above)
+                ml = max_len; src = 4;
+            } else if (i < n) {                                    // (max_len == k - 1 here)
                 const uint32_t c = gld(mlen + i);
                 if (c == MLEN_LT_PREFIX) src = msl0 <= (int32_t)g.prefix_len ? 2 : 0;
                 else if (c < MLEN_TAIL) { if ((int32_t)c >= msl0) { ml = (int32_t)c; src = 1; } else src = 0; }
@@ -373,16 +422,16 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
             if (reports) {
                 // listed; taken to report (see above)
                 const int32_t j = *n_pending;
-                if (j >= SL_MAX_PENDING) SL_LEAVE(7);
+                if (j >= chip.max_pending) SL_LEAVE(7);
                 if (ns >= max_seeds) SL_LEAVE(6);
-                if (t0 + ns >= SL_MAX_SEEDS) SL_LEAVE(7);
+                if (t0 + ns >= chip.max_entries) SL_LEAVE(7);
                 sl_store_seed(chip, t0 + ns, i, ml, k - ml, 0, (uint32_t)j);
                 ++ns;
                 uint32_t *pd = sl_pending(chip, j);
                 gst(pd, (uint32_t)src);
-                gst(pd + chip.sstride, src == 1 ? (uint32_t)known_at : (uint32_t)first);
+                gst(pd + chip.sstride, src == 1 ? (uint32_t)known_at : src == 4 ? (uint32_t)i : (uint32_t)first);
                 gst(pd + 2 * chip.sstride, (uint32_t)last);
-                gst(pd + 5 * chip.sstride, (uint32_t)s | (i >= n ? 2u : 0u) | (mem_at_last ? 4u : 0u));
+                gst(pd + 5 * chip.sstride, (uint32_t)s | (i >= n ? 2u : 0u) | (mem_at_last ? 4u : 0u) | ((uint32_t)(t0 + ns - 1) << 8));
                 *n_pending = j + 1;
                 count_matches(i, i + ml);
                 run = ml + 1;                                      // append_suffix_seed: the positions behind take ml, ml - 1, ... (one off below)
@@ -440,7 +489,7 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
         pend_of[s] = n_pending - p0;
     }
     // the DUST filter of the strands that report sub-k seeds (the scans of a wavefront's lanes run side by side here)
-    if (cfg.seed_complexity_filter) {
+    if (cfg.seed_complexity_filter && !chip.second_pass) {
         for (int s = 0; s < 2; ++s) {
             bool masked = false;
 #if !(MGX_SL_PROBE & 2)
@@ -448,6 +497,13 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
 #endif
             if (masked) SL_LEAVE(4);
         }
+    } else if (cfg.seed_complexity_filter && chip.second_pass == 1) {
+        // (second pass, the reads the quick scan could not clear — side by side: the exact interval test, once per read)
+        if ((pend_of[0] || pend_of[1]) && sl_dust_interval_exists(chip.qw, chip.qstride, L, chip.cnt, chip.cntstride)) SL_LEAVE(11);
+    } else if (cfg.seed_complexity_filter) {
+        // (second pass, the others: the quick scan; the few it cannot clear would hold up their wave-mates for the exact test)
+        for (int s = 0; s < 2; ++s)
+            if (pend_of[s] && sl_dust_could_mask(chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, L)) SL_LEAVE(4);
     }
     SL_T(4);
     // the look-ups of the listed positions, the j-th of every lane side by side: range, nodes (dbg_succinct.cpp:349-392: the
@@ -459,17 +515,7 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
         uint32_t *pd = sl_pending(chip, j);
         const uint32_t kind = gld(pd), a1 = gld(pd + chip.sstride), a2 = gld(pd + 2 * chip.sstride), fl = gld(pd + 5 * chip.sstride);
         const int s = (int)(fl & 1u);
-        // (which buffer entry: the j-th pending one, in order)
-        int32_t t = 0;
-        {
-            int32_t seen = -1;
-            const int32_t total = out.n_entries[0] + out.n_entries[1];
-            for (; t < total; ++t) {
-                const uint32_t w1 = gld(chip.sbuf + (t * SL_SEED_WORDS + 1) * chip.sstride);
-                if ((w1 >> 16) == 0 && ++seen == j) break;
-            }
-            if (t >= total) SL_LEAVE(10);
-        }
+        const int32_t t = (int32_t)(fl >> 8);                          // its buffer entry
         const uint32_t w0 = gld(chip.sbuf + (t * SL_SEED_WORDS) * chip.sstride);
         const int32_t i = (int32_t)(w0 & 0xFFFFu), ml = (int32_t)(w0 >> 16);
         uint64_t first = 0, last = 0;
@@ -482,6 +528,9 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
             hit = first && first <= g.n;
         } else if (kind == 2) {
             first = a1; last = a2;
+        } else if (kind == 4) {
+            first = last = succ_last(g, (uint64_t)gld((s ? P.nodes_rc : P.nodes_fwd) + nb + a1), out.ctr);
+            hit = first && first <= g.n;
         } else {
             const int32_t m = sl_index_range(g, chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, i, ml, msl0, &first, &last, out.ctr);
             hit = m >= msl0 && first && first <= g.n;

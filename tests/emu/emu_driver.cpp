@@ -466,23 +466,37 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
             if (sl_env && *sl_env == '1' && P.pkw[0] && (!dcfg.fwd_and_rc || P.pkw[1])
                     && seed_lane_enabled(dcfg, k, R->lim.Lmax, true, true)) {
                 std::vector<uint64_t> sq(2 * SL_QWORDS);
-                std::vector<uint32_t> sbuf(SL_WAVE_SCRATCH_WORDS, 0);
+                std::vector<uint32_t> scnt(16);
                 R->seedlane_ran = 1;
-                for (uint64_t i = 0; i < n; ++i) {
-                    SeedLaneChip chip = { sq.data(), 1, sbuf.data() + (i % 64), 64 };
-                    SeedLaneOut so;
-                    so.reason = 0;
-                    if (seed_lane_read(P, i, chip, so) == SL_DONE) {
-                        const uint64_t at = seed_cursor;
-                        seed_cursor += (uint64_t)(so.n_seeds[0] + so.n_seeds[1]);
-                        seed_lane_publish(P, i, chip, so, at);
-                        R->stats.seeds += (uint64_t)(so.n_seeds[0] + so.n_seeds[1]);
-                        seeded[i] = 1;
-                        ++R->seedlane_done;
-                    } else {
-                        ++R->seedlane_bail[so.reason & 15u];
+                // (MGX_EMU_SEEDLANE_ONE=1: the first pass only)
+                const bool two = !(getenv("MGX_EMU_SEEDLANE_ONE") && atoi(getenv("MGX_EMU_SEEDLANE_ONE")) == 1);
+                std::vector<uint64_t> todo(n), left;
+                std::vector<uint8_t> why1(n, 0);             // why the first pass left the read (the second pass treats the DUST ones apart)
+                for (uint64_t i = 0; i < n; ++i) todo[i] = i;
+                for (int ps = 0; ps < (two ? 2 : 1); ++ps) {
+                    const int32_t me = ps ? SL_SEEDS_2 : SL_SEEDS_1, mp = ps ? SL_PENDING_2 : SL_PENDING_1;
+                    std::vector<uint32_t> sbuf(seed_lane_wave_scratch_words((uint32_t)me, (uint32_t)mp), 0);
+                    left.clear();
+                    for (size_t x = 0; x < todo.size(); ++x) {
+                        const uint64_t i = todo[x];
+                        SeedLaneChip chip = { sq.data(), 1, sbuf.data() + (x % 64), 64, me, mp, !ps ? 0 : why1[i] == 4 ? 1 : 2, scnt.data(), 1 };
+                        SeedLaneOut so;
+                        so.reason = 0;
+                        if (seed_lane_read(P, i, chip, so) == SL_DONE) {
+                            const uint64_t at = seed_cursor;
+                            seed_cursor += (uint64_t)(so.n_seeds[0] + so.n_seeds[1]);
+                            seed_lane_publish(P, i, chip, so, at);
+                            R->stats.seeds += (uint64_t)(so.n_seeds[0] + so.n_seeds[1]);
+                            seeded[i] = 1;
+                            ++R->seedlane_done;
+                        } else {
+                            left.push_back(i);
+                            why1[i] = (uint8_t)so.reason;
+                            if (ps || !two) ++R->seedlane_bail[so.reason & 15u];
+                        }
+                        R->stats.rank_lines += so.ctr.rank_lines; R->stats.select_lines += so.ctr.select_lines; R->stats.bit_lines += so.ctr.bit_lines;
                     }
-                    R->stats.rank_lines += so.ctr.rank_lines; R->stats.select_lines += so.ctr.select_lines; R->stats.bit_lines += so.ctr.bit_lines;
+                    todo = left;
                 }
             }
         }
