@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 out_name = sys.argv[2] if len(sys.argv) > 2 else "r02_pmc_summary.json"
-KERNELS = {"k_map": "k_map_pipe", "k_map_lanes": "k_map_packed", "k_pack_reads": "k_pack_reads", "k_map_bytes": "k_map(", "k_seed": "k_align<1", "k_extend": "k_align_grp8", "k_lane": "k_lane"}      # (k_align_grp8<2> or, for PRIMARY graphs / alternative paths, k_align_grp8_alt<2>)
+KERNELS = {"k_map": "k_map_pipe", "k_map_lanes": "k_map_packed", "k_pack_reads": "k_pack_reads", "k_map_bytes": "k_map(", "k_seed": "k_align<1", "k_seed_lane": "k_seed_lane", "k_extend": "k_align_grp8", "k_lane": "k_lane"}      # (k_align_grp8<2> or, for PRIMARY graphs / alternative paths, k_align_grp8_alt<2>)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
 for path in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_*", "**", "*counter_collection.csv"), recursive=True):
@@ -23,7 +23,7 @@ for path in glob.glob(os.path.join(ROOT, "gpurun_out", "pmc_*", "**", "*counter_
 # bytes): dependent random 64-B line gathers are tallied 1.00 : 1 (0.9996 over a 9 GB set, 0.975 over a 104 MB set, i.e.
 # Infinity-Cache hits included), streaming 16-B loads 0.50 : 1 (the x2 of MI355X_MICROARCH.md), stores 1.00 : 1.  The
 # aligner's kernels gather 64-B lines, so their fetch bytes are FETCH_SIZE x 1024 x 1.0; the x2 figure is kept beside it.
-GATHER_KERNELS = ("k_map", "k_map_lanes", "k_map_bytes", "k_seed", "k_extend", "k_lane")
+GATHER_KERNELS = ("k_map", "k_map_lanes", "k_map_bytes", "k_seed", "k_seed_lane", "k_extend", "k_lane")
 summary = {"reads_per_launch": reads, "note": "bench.py --reads %d --steps 1 --warmup 0: one launch of each kernel; "
            "FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  fetch_bytes_calibrated = FETCH_SIZE x 1024 x f with f = 1.0 "
            "for the gather kernels (64-B line gathers are tallied 1:1, profiles/r03_pmc_calibration.json) and 2.0 for "
