@@ -1353,7 +1353,9 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             const uint32_t blocks1 = (uint32_t)std::min<uint64_t>(resident, (n + 63) / 64);
             // (the second pass: what the first left — a sixth of a typical batch — with the big buffers)
             const uint32_t blocks2 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(resident, (n / 4 + 63) / 64));
-            const uint64_t words1 = seed_lane_wave_scratch_words(SL_SEEDS_1, SL_PENDING_1), words2 = seed_lane_wave_scratch_words(SL_SEEDS_2, SL_PENDING_2);
+            const bool many = (uint64_t)A->graph->g.k >= A->dcfg.max_seed_length;
+            const uint32_t me1 = many ? SL_SEEDS_1_MANY : SL_SEEDS_1, mp1 = many ? SL_PENDING_1_MANY : SL_PENDING_1;
+            const uint64_t words1 = seed_lane_wave_scratch_words(me1, mp1), words2 = seed_lane_wave_scratch_words(SL_SEEDS_2, SL_PENDING_2);
             if (int rc = A->seedlane_scratch.ensure((size_t)std::max<uint64_t>(blocks1 * words1, blocks2 * words2) * 4)) return rc;
             if (int rc = A->seedlane_params.ensure(2 * sizeof(SeedLaneParams))) return rc;
             if (int rc = A->seedlane_bail.ensure(2 * (n * 4 + 4))) return rc;
@@ -1368,7 +1370,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                 SP[ps].P = P;
                 SP[ps].P.n_items = n;
                 SP[ps].scratch = A->seedlane_scratch.as<uint32_t>();
-                SP[ps].max_entries = ps ? SL_SEEDS_2 : SL_SEEDS_1; SP[ps].max_pending = ps ? SL_PENDING_2 : SL_PENDING_1;
+                SP[ps].max_entries = ps ? SL_SEEDS_2 : me1; SP[ps].max_pending = ps ? SL_PENDING_2 : mp1;
                 SP[ps].second_pass = (uint32_t)ps;
                 SP[ps].in_list = ps ? list1 : nullptr; SP[ps].in_count = ps ? cur + 8 : nullptr; SP[ps].in_count_back = ps ? cur + 11 : nullptr;
                 SP[ps].list_len = n;

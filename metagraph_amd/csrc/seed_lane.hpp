@@ -9,8 +9,9 @@
 // Contract: "complete or redo", as the extension's lane kernel (lane_read.hpp).  seed_lane_read() either finishes a read — its
 // seeds in the lane's buffer, ready for seed_lane_publish() to write header, seed stream and work key exactly as
 // align_read<PH_SEED> does — or returns SL_BAIL having written nothing, and the read goes to the wave program in its own
-// launch.  What a lane takes: UniMEM seeding with or without sub-k seeds (max_seed_length > k; SuffixSeeder<UniMEMSeeder>,
-// A/aligner_seeder_methods.cpp:153-358 over :116-135 of the header), k <= 32, reads of k .. SL_MAX_L characters in ACGT only,
+// launch.  What a lane takes: UniMEM seeding (max_seed_length > k; SuffixSeeder<UniMEMSeeder>, A/aligner_seeder_methods.cpp:153-358
+// over :116-135 of the header) or one seed per k-mer (max_seed_length == k: ExactSeeder :67-93, every label-aware batch), with or
+// without sub-k seeds, k <= 32, reads of k .. SL_MAX_L characters in ACGT only,
 // plain (BASIC / CANONICAL-mode) graphs, k_map's match lengths and ranges present.  It leaves: reads whose DUST scan could
 // mask anything (the exact filter runs in the wave program), more seeds or alternative nodes than its buffer or the limits
 // hold, anything else unusual.
@@ -46,6 +47,8 @@ constexpr int SL_PEND_WORDS = 6;           // a pending record (below)
 // look-up per matched k-mer).  Reads of a kind side by side again: in one launch the few heavy reads would hold up their
 // 63 wave-mates for dozens of look-ups each.
 constexpr int SL_SEEDS_1 = 32, SL_PENDING_1 = 8;
+// (one seed per matched k-mer — max_seed_length == k, every label-aware batch: ~120 seeds per strand, a look-up per tail position)
+constexpr int SL_SEEDS_1_MANY = 160, SL_PENDING_1_MANY = 32;
 constexpr int SL_SEEDS_2 = 160, SL_PENDING_2 = 144;
 
 // what one launch of the kernel needs on top of AlignParams
@@ -76,7 +79,7 @@ inline bool seed_lane_enabled(const DevConfig &d, uint32_t k, uint32_t Lmax, boo
     if (!have_match_lengths || !have_packed) return false;
     if (d.canonical >= 2) return false;                                  // PRIMARY: the wrapper seeds from both strands
     if (k > 32 || k < 3) return false;
-    if (!(d.max_seed_length > k)) return false;                          // one seed per k-mer (label-aware): the wave program's MANY path
+    if (d.max_seed_length < k) return false;                             // (k-mers are not even mapped then)
     if (d.min_seed_length < 1) return false;
     if (Lmax < k) return false;
     return true;
@@ -262,7 +265,7 @@ MGX_DEV uint32_t *sl_pending(const SeedLaneChip &chip, int32_t j) {
 // does not drop —, which is what decides the positions behind it; the look-up confirms it or the read leaves the kernel.
 // Seeds go to the lane's buffer from index t0 on; *n_out = buffer entries; *nm_out as w.num_matching[s] after make_seeder.
 MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s, const int32_t L, const int32_t n, const int32_t t0,
-                      const SeedLaneChip &chip, SeedLaneOut &out, int32_t *n_out, uint32_t *nm_out, int32_t *n_pending, bool *mem_at_last_out) {
+                      const SeedLaneChip &chip, SeedLaneOut &out, int32_t *n_out, uint32_t *nm_out, int32_t *n_pending, bool *filtered_seeds) {
     const DevConfig &cfg = P.cfg;
     const DevGraph &g = P.g;
     const int32_t k = (int32_t)g.k;
@@ -323,7 +326,9 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
             }
         }
     }
-    *n_out = 0; *nm_out = nm0; *mem_at_last_out = false;
+    *n_out = 0; *nm_out = nm0; *filtered_seeds = false;
+    // one seed per matched k-mer (ExactSeeder, :67-93: max_seed_length <= k) instead of one per MEM; each goes through the DUST filter
+    const bool many = (uint32_t)k >= cfg.max_seed_length;
 #if MGX_SL_PROBE & 8
     return SL_DONE;
 #endif
@@ -332,8 +337,16 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
     const int32_t max_seeds = (int32_t)P.lim.max_seeds;
     int32_t ns = 0;                                                              // buffer entries of this strand
     if (cfg.min_seed_length >= (uint32_t)k) {
-        // base seeds only (UniMEMSeeder, seeder hpp:116-135)
+        // base seeds only (UniMEMSeeder, seeder hpp:116-135; ExactSeeder)
         int32_t it = base_ok ? next2(mt0, mt1, 0, true) : n;
+        while (many && it < n) {
+            if (ns >= max_seeds) SL_LEAVE(6);
+            if (t0 + ns >= chip.max_entries) SL_LEAVE(7);
+            sl_store_seed(chip, t0 + ns, it, k, 0, 1, gld(nodes + it));
+            ++ns;
+            *filtered_seeds = true;
+            it = next2(mt0, mt1, it + 1, true);
+        }
         while (it < n) {
             int32_t next = next2(sp0, sp1, it, true);
             if (next < n && test2(mt0, mt1, next)) ++next;
@@ -359,7 +372,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
     const bool tail_known = test2(mt0, mt1, n - 1);                // (no invalid character; plain graph)
     constexpr int32_t NO_MEM = 0x7FFFFFFF;
     auto next_mem = [&](int32_t from) -> int32_t { const int32_t p = next2(mt0, mt1, from, true); return p < n ? p : NO_MEM; };
-    int32_t mem_it = base_ok ? next_mem(0) : NO_MEM;               // the next MEM's first position
+    int32_t mem_it = base_ok && !many ? next_mem(0) : NO_MEM;      // the next MEM's first position
     int32_t cover_until = -1;                                      // positions <= this one hold k (a MEM's cover)
     int32_t run = 0;                                               // the value the running raise holds at position i (0: none)
     bool mem_at_last = false;                                      // a MEM starts at the last k-mer (:240-244)
@@ -371,18 +384,22 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
         last_end = end;
     };
     for (int32_t i = 0; i < nslots; ++i) {
-        if (i == mem_it) {
-            int32_t next = next2(sp0, sp1, i, true);
-            if (next < n && test2(mt0, mt1, next)) ++next;
+        if (many ? (base_ok && i < n && test2(mt0, mt1, i)) : i == mem_it) {
+            int32_t next = i + 1;
+            if (!many) {
+                next = next2(sp0, sp1, i, true);
+                if (next < n && test2(mt0, mt1, next)) ++next;
+            }
             const int32_t nn = next - i, mem_length = nn + k - 1;
             if (ns >= max_seeds) SL_LEAVE(6);
             if (t0 + ns >= chip.max_entries) SL_LEAVE(7);
-            sl_store_seed(chip, t0 + ns, i, mem_length, 0, nn, 0u);
+            sl_store_seed(chip, t0 + ns, i, mem_length, 0, nn, many ? gld(nodes + i) : 0u);
+            if (many) *filtered_seeds = true;
             ++ns;
             count_matches(i, i + mem_length);
             if (i == n - 1) mem_at_last = true;
             cover_until = i + nn;
-            mem_it = next_mem(next);
+            if (!many) mem_it = next_mem(next);
             run = 0;                                               // (a run holds at most k - 1 < k: it ends here)
             continue;
         }
@@ -431,10 +448,15 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
                 gst(pd, (uint32_t)src);
                 gst(pd + chip.sstride, src == 1 ? (uint32_t)known_at : src == 4 ? (uint32_t)i : (uint32_t)first);
                 gst(pd + 2 * chip.sstride, (uint32_t)last);
-                gst(pd + 5 * chip.sstride, (uint32_t)s | (i >= n ? 2u : 0u) | (mem_at_last ? 4u : 0u) | ((uint32_t)(t0 + ns - 1) << 8));
+                // ":240-244": a tail position whose one node is the last k-mer's, which a seed of its own reports, adds nothing — what
+                // the scan expects of every tail position behind such a seed (with one seed per k-mer: of all of them)
+                const bool expect_dup = i >= n && mem_at_last;
+                gst(pd + 5 * chip.sstride, (uint32_t)s | (i >= n ? 2u : 0u) | (mem_at_last ? 4u : 0u) | (expect_dup ? 8u : 0u) | ((uint32_t)(t0 + ns - 1) << 8));
                 *n_pending = j + 1;
-                count_matches(i, i + ml);
-                run = ml + 1;                                      // append_suffix_seed: the positions behind take ml, ml - 1, ... (one off below)
+                if (!expect_dup) {
+                    count_matches(i, i + ml);
+                    run = ml + 1;                                  // append_suffix_seed: the positions behind take ml, ml - 1, ... (one off below)
+                }
             }
         }
         if (run > 0) --run;
@@ -442,7 +464,6 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
     SL_T(2);
     *n_out = ns;
     *nm_out = num;
-    *mem_at_last_out = mem_at_last;
     return SL_DONE;
 }
 
@@ -478,13 +499,15 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
     SL_T(0);
     int32_t n_pending = 0;
     int32_t pend_of[2] = { 0, 0 };                                 // pending seeds per strand
+    bool filtered[2] = { false, false };                           // the strand has seeds the DUST filter looked at (one per k-mer)
     for (int s = 0; s < (have_rc ? 2 : 1); ++s) {
         int32_t ne = 0;
         uint32_t nm = 0;
-        bool mal = false;
+        bool fs = false;
         const int32_t p0 = n_pending;
-        if (sl_strand(P, nb, s, L, n, out.n_entries[0], chip, out, &ne, &nm, &n_pending, &mal) != SL_DONE) return SL_BAIL;
+        if (sl_strand(P, nb, s, L, n, out.n_entries[0], chip, out, &ne, &nm, &n_pending, &fs) != SL_DONE) return SL_BAIL;
         if ((double)L * cfg.min_exact_match > (double)nm) { ne = 0; nm = 0; n_pending = p0; }      // (its look-ups: not needed)
+        filtered[s] = fs;
         out.n_entries[s] = ne; out.num_matching[s] = nm;
         pend_of[s] = n_pending - p0;
     }
@@ -493,29 +516,35 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
         for (int s = 0; s < 2; ++s) {
             bool masked = false;
 #if !(MGX_SL_PROBE & 2)
-            if (pend_of[s]) masked = sl_dust_could_mask(chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, L);
+            if (pend_of[s] || filtered[s]) masked = sl_dust_could_mask(chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, L);
 #endif
             if (masked) SL_LEAVE(4);
         }
     } else if (cfg.seed_complexity_filter && chip.second_pass == 1) {
         // (second pass, the reads the quick scan could not clear — side by side: the exact interval test, once per read)
-        if ((pend_of[0] || pend_of[1]) && sl_dust_interval_exists(chip.qw, chip.qstride, L, chip.cnt, chip.cntstride)) SL_LEAVE(11);
+        if ((pend_of[0] || pend_of[1] || filtered[0] || filtered[1]) && sl_dust_interval_exists(chip.qw, chip.qstride, L, chip.cnt, chip.cntstride)) SL_LEAVE(11);
     } else if (cfg.seed_complexity_filter) {
         // (second pass, the others: the quick scan; the few it cannot clear would hold up their wave-mates for the exact test)
         for (int s = 0; s < 2; ++s)
-            if (pend_of[s] && sl_dust_could_mask(chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, L)) SL_LEAVE(4);
+            if ((pend_of[s] || filtered[s]) && sl_dust_could_mask(chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, L)) SL_LEAVE(4);
     }
     SL_T(4);
     // the look-ups of the listed positions, the j-th of every lane side by side: range, nodes (dbg_succinct.cpp:349-392: the
     // parents of every node of the range)
     const int32_t msl0 = (int32_t)cfg.min_seed_length;
     uint32_t alt_total[2] = { 0, 0 };
+    bool tail_reported[2] = { false, false };
     int32_t extra[2] = { 0, 0 };                                   // seeds a strand's pending entries expand to, minus one each
     for (int32_t j = 0; j < n_pending; ++j) {
         uint32_t *pd = sl_pending(chip, j);
         const uint32_t kind = gld(pd), a1 = gld(pd + chip.sstride), a2 = gld(pd + 2 * chip.sstride), fl = gld(pd + 5 * chip.sstride);
         const int s = (int)(fl & 1u);
         const int32_t t = (int32_t)(fl >> 8);                          // its buffer entry
+        if (tail_reported[s]) {                                        // (behind a tail position that reports nothing can: below)
+            gst(pd, 0u);
+            extra[s] -= 1;
+            continue;
+        }
         const uint32_t w0 = gld(chip.sbuf + (t * SL_SEED_WORDS) * chip.sstride);
         const int32_t i = (int32_t)(w0 & 0xFFFFu), ml = (int32_t)(w0 >> 16);
         uint64_t first = 0, last = 0;
@@ -545,14 +574,23 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
             uint32_t fc[5];
             const int ni = incoming<false, false>(g, e, inc, fc, out.ctr);
             for (int x = 0; x < ni; ++x) {
-                if (cnt >= 4) SL_LEAVE(9);
+                if (cnt >= 4) SL_LEAVE(13);
                 gst(pd + (1 + cnt) * chip.sstride, (uint32_t)inc[x]);
                 ++cnt;
             }
         }
-        if (cnt == 0 || (uint32_t)cnt > cfg.max_num_seeds_per_locus) SL_LEAVE(9);
-        // ":240-244": the one node of a tail position is the last k-mer's node, which a MEM of its own reports — no seed then
-        if ((fl & 2u) && cnt == 1 && (fl & 4u) && gld(pd + chip.sstride) == gld((s ? P.nodes_rc : P.nodes_fwd) + nb + n - 1)) SL_LEAVE(9);
+        if (cnt == 0) SL_LEAVE(12);
+        if ((uint32_t)cnt > cfg.max_num_seeds_per_locus) SL_LEAVE(13);
+        // ":240-244": the one node of a tail position is the last k-mer's node, which a seed of its own reports — no seed then,
+        // as the scan expected or not
+        const bool dup = (fl & 2u) && cnt == 1 && (fl & 4u) && gld(pd + chip.sstride) == gld((s ? P.nodes_rc : P.nodes_fwd) + nb + n - 1);
+        if (dup && !(fl & 8u)) SL_LEAVE(14);
+        // A tail position the scan expected to add nothing, and it does report (several nodes end with these characters, or
+        // another one): its seeds stay, and the positions behind it — all listed, as expected non-reporters — are raised above
+        // what they could match (position i + 1 takes L - i, and has L - i - 1 characters), so none of them reports.  Its
+        // matches add nothing to num_matching: the seed at the last k-mer already ends at L.
+        if (!dup && (fl & 8u)) tail_reported[s] = true;
+        if (dup) cnt = 0;
         alt_total[s] += (uint32_t)cnt;
         if (alt_total[s] > P.lim.max_alt) SL_LEAVE(5);
         gst(pd, (uint32_t)cnt);
@@ -569,11 +607,16 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
 // seed x (expanded numbering: a pending entry counts for its nodes) of the lane's buffer, as three words
 struct SlCursor { int32_t t, sub; };
 MGX_DEV void sl_next_seed(const SeedLaneChip &chip, SlCursor &c, uint32_t *w) {
-    const uint32_t *e = chip.sbuf + (c.t * SL_SEED_WORDS) * chip.sstride;
-    w[0] = gld(e); w[1] = gld(e + chip.sstride); w[2] = gld(e + 2 * chip.sstride);
-    if ((w[1] >> 16) != 0) { ++c.t; return; }
-    const uint32_t *pd = sl_pending(chip, (int32_t)w[2]);
-    const int32_t cnt = (int32_t)gld(pd);
+    const uint32_t *pd;
+    int32_t cnt;
+    for (;; ++c.t) {                                               // (a pending entry without nodes stands for no seed)
+        const uint32_t *e = chip.sbuf + (c.t * SL_SEED_WORDS) * chip.sstride;
+        w[0] = gld(e); w[1] = gld(e + chip.sstride); w[2] = gld(e + 2 * chip.sstride);
+        if ((w[1] >> 16) != 0) { ++c.t; return; }
+        pd = sl_pending(chip, (int32_t)w[2]);
+        cnt = (int32_t)gld(pd);
+        if (cnt > 0) break;
+    }
     w[1] |= 1u << 16;
     w[2] = gld(pd + (1 + c.sub) * chip.sstride);
     if (++c.sub >= cnt) { c.sub = 0; ++c.t; }

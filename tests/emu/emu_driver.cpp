@@ -474,7 +474,8 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
                 std::vector<uint8_t> why1(n, 0);             // why the first pass left the read (the second pass treats the DUST ones apart)
                 for (uint64_t i = 0; i < n; ++i) todo[i] = i;
                 for (int ps = 0; ps < (two ? 2 : 1); ++ps) {
-                    const int32_t me = ps ? SL_SEEDS_2 : SL_SEEDS_1, mp = ps ? SL_PENDING_2 : SL_PENDING_1;
+                    const bool many = (uint64_t)k >= dcfg.max_seed_length;
+                    const int32_t me = ps ? SL_SEEDS_2 : many ? SL_SEEDS_1_MANY : SL_SEEDS_1, mp = ps ? SL_PENDING_2 : many ? SL_PENDING_1_MANY : SL_PENDING_1;
                     std::vector<uint32_t> sbuf(seed_lane_wave_scratch_words((uint32_t)me, (uint32_t)mp), 0);
                     left.clear();
                     for (size_t x = 0; x < todo.size(); ++x) {

@@ -71,9 +71,19 @@ def test_random_worlds(seedlane_env, seed):
     assert ran and done > 0, why
 
 
+def test_one_seed_per_kmer(seedlane_env):
+    """max_seed_length == k (what label-aware alignment sets): ExactSeeder's seed per matched k-mer, every tail position looked up"""
+    g, reads = bench_like_world(47, 600, genome_len=40000, snp_every=150)
+    cfg = capi.config_cli(31)
+    cfg.max_seed_length = 31
+    ran, done, why = run(g, cfg, reads)
+    assert ran and done > 0.9 * len(reads), (done, why)
+
+
 def test_configurations_the_kernel_does_not_take(seedlane_env):
     g, reads = make_world(77, 15, genome_len=3000, n_reads=40, read_len=80)
     cfg = capi.config_cli(15)
-    cfg.max_seed_length = 15                                   # one seed per k-mer: the wave program's MANY path
+    cfg.max_seed_length = 10                                   # below k: the k-mers are not even mapped
+    cfg.min_seed_length = 8
     ran, done, why = run(g, cfg, reads)
     assert not ran and done == 0

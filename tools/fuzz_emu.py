@@ -114,6 +114,10 @@ def main():
             cfg.max_seed_length = rng.choice([k, k + 20, 2 ** 32])
             if cfg.max_seed_length < cfg.min_seed_length:
                 cfg.max_seed_length = cfg.min_seed_length
+        if args.seedlane and rng.random() < 0.35:
+            cfg.max_seed_length = k                              # one seed per matched k-mer (what label-aware alignment sets)
+            if cfg.min_seed_length > k:
+                cfg.min_seed_length = k
         cfg.max_num_seeds_per_locus = rng.choice([1, 2, 1000])
         cfg.xdrop = rng.choice([10, 27, 27, 50])
         cfg.num_alternative_paths = rng.choice([1, 1, 1, 2, 3])

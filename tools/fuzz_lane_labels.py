@@ -8,11 +8,12 @@ import os, sys, random
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["MGX_EMU_SPLIT"] = "1"; os.environ["MGX_EMU_LANE"] = "1"
+os.environ.setdefault("MGX_EMU_SEEDLANE", "1")          # (round 6: the lane-per-read seeder in front, one seed per k-mer)
 import emu_drv, orc
 from metagraph_amd import capi
 from labeled_worlds import with_labels
 from test_lane_labels import segment_world
-tot = done_t = bad_t = 0
+tot = done_t = bad_t = sl_t = 0
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 for seed in range(first, first + int(sys.argv[1])):
     rng = random.Random(seed)
@@ -34,6 +35,7 @@ for seed in range(first, first + int(sys.argv[1])):
         for q, (ss, nm) in enumerate(o.seeds(strand)):
             if info[q]["num_matches"][strand] != nm or info[q]["seeds"][strand] != emu_drv.oracle_seeds_as_tuples(ss): bad.append(q)
     ran, nd = e.lane_stats()
+    sl_t += e.seedlane_stats()[1]
     tot += len(reads); done_t += nd; bad_t += len(bad)
     if bad: print("seed", seed, "k", k, "BAD", bad[:5])
-print("worlds done: reads", tot, "lane finished", done_t, "mismatches", bad_t)
+print("worlds done: reads", tot, "seeded by the lane-per-read seeder", sl_t, "lane finished", done_t, "mismatches", bad_t)
