@@ -71,7 +71,7 @@ struct SeedLaneParams {
 };
 
 MGX_HD uint64_t seed_lane_wave_scratch_words(uint32_t max_entries, uint32_t max_pending) {
-    return ((uint64_t)max_entries * SL_SEED_WORDS + (uint64_t)max_pending * SL_PEND_WORDS) * 64;
+    return ((uint64_t)max_entries * SL_SEED_WORDS + (uint64_t)max_pending * SL_PEND_WORDS + (uint64_t)(SL_MAX_L / 4)) * 64;
 }
 
 // does the batch's configuration suit the kernel at all (mgx.hip; the host model asks the same)
@@ -93,6 +93,7 @@ struct SeedLaneChip {
     int32_t second_pass;                   // 0 first pass; second pass: 1 = a read the quick DUST scan could not clear, 2 = another
     uint32_t *cnt; int32_t cntstride;      // 64 byte counters (the DUST scans' triplet counts): byte t in word cnt[(t >> 2) * cntstride]
 };
+constexpr int SL_DUST_WORDS = SL_MAX_L / 4;    // the lane's DUST map (sl_dust_map): a byte per character, behind the pending records
 
 struct SeedLaneOut {
     int32_t L;
@@ -189,14 +190,20 @@ MGX_DEV bool sl_dust_could_mask(const uint64_t *qw, int32_t qstride, int32_t L) 
     return false;
 }
 
-// maybe_low_complexity (align_core.hpp) for one lane, second pass: is there an interval of at most 62 consecutive triplets whose
-// DUST score exceeds T — pairs of equal triplets times 10 above T times (triplets - 1), the test find_perfect applies?  Every
-// interval sdust can mask, on the strand or on any window of it, is one: `false` proves that no window is low-complexity.  Per
-// end position the start walks back and r grows by the number of later positions with the start's triplet (byte counts in
-// the lane's 64-byte table).  Mirror-symmetric, so one strand's answer serves both.
-MGX_DEV_NOINLINE bool sl_dust_interval_exists(const uint64_t *qw, int32_t qstride, int32_t L, uint32_t *cnt, int32_t cntstride) {
+// The DUST filter for one lane, exactly (second pass, the reads the quick scan could not clear).  sdust masks something in a
+// string if and only if some interval of at most 62 consecutive triplets has more than T / 10 times (triplets - 1) pairs of
+// equal triplets — the definition `orc_sdust_bruteforce` restates and tests/test_sdust_definition.py pins the oracle's and the
+// kernels' sdust to.  So is_low_complexity(window) == "such an interval lies inside the window", and one pass over the strand
+// answers every window: per end position e the start walks back (byte counters of the triplets seen, r grows by the count
+// of the start's triplet) until the first — nearest — start whose interval qualifies; map[a] = the least end of a qualifying
+// interval that starts at character a or later (255: none).  A window [x, x + len) is low-complexity iff map[x] <= x + len - 1.
+// Intervals of the reverse complement are the mirror images (same pairs of equal triplets), so the forward strand's map
+// serves both strands.
+MGX_DEV uint8_t *sl_dust_byte(uint32_t *map, int32_t stride, int32_t a) { return (uint8_t *)(map + (a >> 2) * stride) + (a & 3); }
+MGX_DEV_NOINLINE void sl_dust_map(const uint64_t *qw, int32_t qstride, int32_t L, uint32_t *cnt, int32_t cntstride, uint32_t *map, int32_t mstride) {
     constexpr int32_t T = 20, SPAN = 61;
     auto at = [&](uint32_t t) -> uint8_t * { return (uint8_t *)(cnt + (t >> 2) * cntstride) + (t & 3u); };
+    for (int32_t x = 0; x < (L + 3) / 4; ++x) gst(map + x * mstride, 0xFFFFFFFFu);
     for (int32_t e = 2; e < L; ++e) {
 #pragma unroll
         for (int x = 0; x < 16; ++x) cnt[x * cntstride] = 0;
@@ -209,10 +216,25 @@ MGX_DEV_NOINLINE bool sl_dust_interval_exists(const uint64_t *qw, int32_t qstrid
             const uint32_t v = *c;
             r += (int32_t)v;
             *c = (uint8_t)(v + 1);
-            if (r * 10 > T * d) return true;
+            if (r * 10 > T * d) {
+                uint8_t *m = sl_dust_byte(map, mstride, e - d - 2);
+                if (gld(m) == 255) gst(m, (uint8_t)e);                       // (ends come in increasing order: the first is the least)
+                break;
+            }
         }
     }
-    return false;
+    uint32_t least = 255;
+    for (int32_t a = L - 1; a >= 0; --a) {
+        uint8_t *m = sl_dust_byte(map, mstride, a);
+        least = imin<uint32_t>(least, (uint32_t)gld(m));
+        gst(m, (uint8_t)least);
+    }
+}
+// is_low_complexity(strand s, characters [x, x + len)) from the forward strand's map
+MGX_DEV bool sl_dust_window(const uint32_t *map, int32_t mstride, int32_t L, int s, int32_t x, int32_t len) {
+    if (s) x = L - x - len;
+    if (x < 0 || len < 3) return false;
+    return (int32_t)gld(sl_dust_byte(const_cast<uint32_t *>(map), mstride, x)) <= x + len - 1;
 }
 
 // BOSS::index_range (boss.hpp:720-764) on a packed strand without invalid characters: codes [i, i + len); as index_range_lane
@@ -265,7 +287,8 @@ MGX_DEV uint32_t *sl_pending(const SeedLaneChip &chip, int32_t j) {
 // does not drop —, which is what decides the positions behind it; the look-up confirms it or the read leaves the kernel.
 // Seeds go to the lane's buffer from index t0 on; *n_out = buffer entries; *nm_out as w.num_matching[s] after make_seeder.
 MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s, const int32_t L, const int32_t n, const int32_t t0,
-                      const SeedLaneChip &chip, SeedLaneOut &out, int32_t *n_out, uint32_t *nm_out, int32_t *n_pending, bool *filtered_seeds) {
+                      const SeedLaneChip &chip, SeedLaneOut &out, int32_t *n_out, uint32_t *nm_out, int32_t *n_pending, bool *filtered_seeds,
+                      const uint32_t *dust) {
     const DevConfig &cfg = P.cfg;
     const DevGraph &g = P.g;
     const int32_t k = (int32_t)g.k;
@@ -340,6 +363,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
         // base seeds only (UniMEMSeeder, seeder hpp:116-135; ExactSeeder)
         int32_t it = base_ok ? next2(mt0, mt1, 0, true) : n;
         while (many && it < n) {
+            if (dust && sl_dust_window(dust, chip.sstride, L, s, it, k)) { it = next2(mt0, mt1, it + 1, true); continue; }
             if (ns >= max_seeds) SL_LEAVE(6);
             if (t0 + ns >= chip.max_entries) SL_LEAVE(7);
             sl_store_seed(chip, t0 + ns, it, k, 0, 1, gld(nodes + it));
@@ -384,7 +408,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
         last_end = end;
     };
     for (int32_t i = 0; i < nslots; ++i) {
-        if (many ? (base_ok && i < n && test2(mt0, mt1, i)) : i == mem_it) {
+        if (many ? (base_ok && i < n && test2(mt0, mt1, i) && !(dust && sl_dust_window(dust, chip.sstride, L, s, i, k))) : i == mem_it) {
             int32_t next = i + 1;
             if (!many) {
                 next = next2(sp0, sp1, i, true);
@@ -410,7 +434,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
         if (max_len >= eff) {
             // the position's longest-prefix lookup, as far as needed (lookup_position of make_seeder)
             int32_t ml = 0, src = 2, known_at = i;                 // src: 1 = k_map's range, 2 = walk, 3 = walk only if it reports
-            if (i < n && test2(mt0, mt1, i)) {                     // (a matched k-mer no MEM reports: see above)
+            if (i < n && test2(mt0, mt1, i)) {                     // (a matched k-mer no seed reports: see above; or its seed was masked)
                 ml = max_len; src = 4;
             } else if (i < n) {                                    // (max_len == k - 1 here)
                 const uint32_t c = gld(mlen + i);
@@ -434,7 +458,8 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
 #if MGX_SL_PROBE & 16
             const bool reports = false;
 #else
-            const bool reports = src && ml && ml >= eff;
+            // (the complexity filter looks at the eff characters the position must match, :226-229: a masked window reports nothing)
+            const bool reports = src && ml && ml >= eff && !(dust && sl_dust_window(dust, chip.sstride, L, s, i, eff));
 #endif
             if (reports) {
                 // listed; taken to report (see above)
@@ -497,6 +522,14 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
         if (inv) SL_LEAVE(3);
     }
     SL_T(0);
+    // second pass (the reads the first pass's quick DUST scan could not clear are among these): the exact filter, as a map of the
+    // read that answers every window the scan asks about
+    uint32_t *dust = nullptr;
+    if (cfg.seed_complexity_filter && chip.second_pass) {
+        dust = chip.sbuf + (chip.max_entries * SL_SEED_WORDS + chip.max_pending * SL_PEND_WORDS) * chip.sstride;
+        sl_dust_map(chip.qw, chip.qstride, L, chip.cnt, chip.cntstride, dust, chip.sstride);
+    }
+    SL_T(4);
     int32_t n_pending = 0;
     int32_t pend_of[2] = { 0, 0 };                                 // pending seeds per strand
     bool filtered[2] = { false, false };                           // the strand has seeds the DUST filter looked at (one per k-mer)
@@ -505,7 +538,7 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
         uint32_t nm = 0;
         bool fs = false;
         const int32_t p0 = n_pending;
-        if (sl_strand(P, nb, s, L, n, out.n_entries[0], chip, out, &ne, &nm, &n_pending, &fs) != SL_DONE) return SL_BAIL;
+        if (sl_strand(P, nb, s, L, n, out.n_entries[0], chip, out, &ne, &nm, &n_pending, &fs, dust) != SL_DONE) return SL_BAIL;
         if ((double)L * cfg.min_exact_match > (double)nm) { ne = 0; nm = 0; n_pending = p0; }      // (its look-ups: not needed)
         filtered[s] = fs;
         out.n_entries[s] = ne; out.num_matching[s] = nm;
@@ -520,14 +553,8 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
 #endif
             if (masked) SL_LEAVE(4);
         }
-    } else if (cfg.seed_complexity_filter && chip.second_pass == 1) {
-        // (second pass, the reads the quick scan could not clear — side by side: the exact interval test, once per read)
-        if ((pend_of[0] || pend_of[1] || filtered[0] || filtered[1]) && sl_dust_interval_exists(chip.qw, chip.qstride, L, chip.cnt, chip.cntstride)) SL_LEAVE(11);
-    } else if (cfg.seed_complexity_filter) {
-        // (second pass, the others: the quick scan; the few it cannot clear would hold up their wave-mates for the exact test)
-        for (int s = 0; s < 2; ++s)
-            if ((pend_of[s] || filtered[s]) && sl_dust_could_mask(chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, L)) SL_LEAVE(4);
     }
+    // (second pass: the scans above asked the exact filter's map)
     SL_T(4);
     // the look-ups of the listed positions, the j-th of every lane side by side: range, nodes (dbg_succinct.cpp:349-392: the
     // parents of every node of the range)

@@ -80,6 +80,34 @@ def test_one_seed_per_kmer(seedlane_env):
     assert ran and done > 0.9 * len(reads), (done, why)
 
 
+@pytest.mark.parametrize("many", [0, 1])
+def test_low_complexity_islands(seedlane_env, many):
+    """reads over homopolymer / short tandem stretches: the second pass answers the DUST filter's windows from its map of the
+    read (seed_lane.hpp sl_dust_map) — masked sub-k positions report nothing, masked k-mer seeds are dropped"""
+    rng = random.Random(91 + many)
+    from test_emu_vs_oracle import rand_seq, rc
+    G = list(rand_seq(rng, 30000))
+    for _ in range(120):
+        a = rng.randrange(0, len(G) - 60)
+        u = rng.choice(["A", "C", "T", "AT", "CG", "AC", "AAT", "CAG", "ACGT"])
+        for x in range(a, a + rng.randint(6, 45)):
+            G[x] = u[(x - a) % len(u)]
+    G = "".join(G)
+    k = 21
+    g = orc.Graph.build(k, [G], 0, False)
+    reads = []
+    for _ in range(700):
+        p = rng.randrange(0, len(G) - 130)
+        r = mutate(rng, G[p:p + 120], sub=0.02, ins=0.002, dele=0.002)
+        reads.append(rc(r) if rng.random() < 0.5 else r)
+    cfg = capi.config_cli(k)
+    cfg.min_seed_length = 12
+    if many:
+        cfg.max_seed_length = k
+    ran, done, why = run(g, cfg, reads)
+    assert ran and done > 0.85 * len(reads), (done, why)
+
+
 def test_configurations_the_kernel_does_not_take(seedlane_env):
     g, reads = make_world(77, 15, genome_len=3000, n_reads=40, read_len=80)
     cfg = capi.config_cli(15)

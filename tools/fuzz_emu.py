@@ -68,6 +68,15 @@ def main():
             unit = rand_seq(rng, rng.choice([15, 40, 90]))
             genome = genome[:glen // 3] + unit + genome[glen // 3:2 * glen // 3] + (rc(unit) if rng.random() < 0.5 else unit) + genome[2 * glen // 3:]
             seqs = [genome]
+        if args.seedlane and rng.random() < 0.6:                 # low-complexity islands: what the DUST filter masks
+            g2 = list(genome)
+            for _ in range(rng.choice([1, 3, 8])):
+                a = rng.randrange(0, max(1, len(g2) - 60))
+                u = rng.choice(["A", "C", "G", "T", "AT", "CG", "AC", "GT", "AAT", "CAG", "ACGT", "AACCT"])
+                for x in range(a, min(len(g2), a + rng.randint(5, 45))):
+                    g2[x] = u[(x - a) % len(u)]
+            genome = "".join(g2)
+            seqs = [genome]
         for _ in range(rng.choice([0, 5, 30])):                  # variants (bubbles)
             p = rng.randrange(k, len(genome) - k)
             alt = rng.choice([c for c in "ACGT" if c != genome[p]])
