@@ -35,7 +35,7 @@
 
 namespace mgx {
 
-constexpr int SL_MAX_KMERS = 128;          // k-mer positions of a strand (two 64-bit masks)
+constexpr int SL_MAX_KMERS = 192;          // k-mer positions of a strand (three 64-bit masks)
 constexpr int SL_MAX_L = 160;              // longest read a lane takes
 constexpr int SL_QWORDS = 6;               // packed strand: 32 codes per word, one zero word behind the last
 constexpr int SL_SEED_WORDS = 3;           // a DevSeed as three words
@@ -48,8 +48,8 @@ constexpr int SL_PEND_WORDS = 6;           // a pending record (below)
 // 63 wave-mates for dozens of look-ups each.
 constexpr int SL_SEEDS_1 = 32, SL_PENDING_1 = 8;
 // (one seed per matched k-mer — max_seed_length == k, every label-aware batch: ~120 seeds per strand, a look-up per tail position)
-constexpr int SL_SEEDS_1_MANY = 160, SL_PENDING_1_MANY = 32;
-constexpr int SL_SEEDS_2 = 160, SL_PENDING_2 = 144;
+constexpr int SL_SEEDS_1_MANY = 192, SL_PENDING_1_MANY = 32;
+constexpr int SL_SEEDS_2 = 192, SL_PENDING_2 = 144;
 
 // what one launch of the kernel needs on top of AlignParams
 struct SeedLaneParams {
@@ -281,6 +281,24 @@ MGX_DEV uint32_t *sl_pending(const SeedLaneChip &chip, int32_t j) {
     return chip.sbuf + (chip.max_entries * SL_SEED_WORDS + j * SL_PEND_WORDS) * chip.sstride;
 }
 
+// a mask over a strand's k-mer positions (three words held as three variables: an indexable array would live in scratch memory)
+struct SlMask {
+    uint64_t w0, w1, w2;
+    MGX_DEV void set(int32_t i) { const uint64_t b = 1ull << (i & 63); if (i < 64) w0 |= b; else if (i < 128) w1 |= b; else w2 |= b; }
+    MGX_DEV bool test(int32_t i) const { return (((i < 64 ? w0 : i < 128 ? w1 : w2) >> (i & 63)) & 1ull) != 0; }
+    MGX_DEV bool any() const { return (w0 | w1 | w2) != 0; }
+    // bits_next over [0, n): the first position >= from whose bit equals val; n if none
+    MGX_DEV int32_t next(int32_t from, bool val, int32_t n) const {
+        const uint64_t flip = val ? 0ull : ~0ull;
+        for (int32_t base = from & ~63; base < n && base < 192; base += 64) {
+            uint64_t x = (base == 0 ? w0 : base == 64 ? w1 : w2) ^ flip;
+            if (base < from) x &= ~0ull << (from - base);
+            if (x) { const int32_t p = base + ctz64(x); return p < n ? p : n; }
+        }
+        return n;
+    }
+};
+
 // One strand: make_seeder<false> (+ strand_without_seeds, which only answers the same question sooner) up to the look-ups
 // of the reporting sub-k positions, which are listed (seed_lane_read makes them for all strands and lanes side by side).
 // Optimistic: a listed position is taken to report — its range exists and holds at least one node that the ":240-244" rule
@@ -298,7 +316,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
     const int32_t qs = chip.qstride;
     LineCtr &ctr = out.ctr;
     // kmer_masks: matched k-mers, MEM stops (the terminus of a matched k-mer, inclusive, or an unmatched k-mer)
-    uint64_t mt0 = 0, mt1 = 0, sp0 = 0, sp1 = 0;
+    SlMask mt = { 0, 0, 0 }, sp = { 0, 0, 0 };
     {
         uint32_t v = gld(nodes);
         for (int32_t i = 0; i < n; ++i) {
@@ -310,39 +328,25 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
                 if (!term) { term = (gld(g.terminus + (v >> 6)) >> (v & 63)) & 1; ++ctr.bit_lines; }
 #endif
                 stop = term;
-                if (i < 64) mt0 |= 1ull << i; else mt1 |= 1ull << (i - 64);
+                mt.set(i);
             }
-            if (stop) { if (i < 64) sp0 |= 1ull << i; else sp1 |= 1ull << (i - 64); }
+            if (stop) sp.set(i);
             v = nxt;
         }
     }
-    // (two-word masks without an indexable array: those end up in scratch memory)
-    auto test2 = [](uint64_t w0, uint64_t w1, int32_t i) -> bool { return ((i < 64 ? w0 >> i : w1 >> (i - 64)) & 1ull) != 0; };
-    auto next2 = [&](uint64_t w0, uint64_t w1, int32_t from, bool val) -> int32_t {      // bits_next over [0, n)
-        if (from >= n) return n;
-        if (!val) { w0 = ~w0; w1 = ~w1; }
-        if (from < 64) {
-            const uint64_t x = w0 >> from;
-            if (x) { const int32_t p = from + ctz64(x); return p < n ? p : n; }
-            from = 64;
-        }
-        const uint64_t y = from - 64 < 64 ? w1 >> (from - 64) : 0ull;
-        if (y) { const int32_t p = from + ctz64(y); return p < n ? p : n; }
-        return n;
-    };
     SL_T(1);
     uint32_t nm0 = 0;
     {   // num_exact_matching (A/aligner_seeder_methods.cpp:49-65), run by run
         uint32_t last_match_count = 0;
         int32_t i = 0;
         while (i < n) {
-            if (test2(mt0, mt1, i)) {
-                const int32_t j = next2(mt0, mt1, i + 1, false);
+            if (mt.test(i)) {
+                const int32_t j = mt.next(i + 1, false, n);
                 nm0 += (uint32_t)k + (uint32_t)(j - i) - 1 - last_match_count;
                 last_match_count = (uint32_t)k;
                 i = j;
             } else {
-                const int32_t j = next2(mt0, mt1, i + 1, true);
+                const int32_t j = mt.next(i + 1, true, n);
                 const uint32_t zeros = (uint32_t)(j - i);
                 last_match_count = last_match_count > zeros ? last_match_count - zeros : 0;
                 i = j;
@@ -361,19 +365,19 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
     int32_t ns = 0;                                                              // buffer entries of this strand
     if (cfg.min_seed_length >= (uint32_t)k) {
         // base seeds only (UniMEMSeeder, seeder hpp:116-135; ExactSeeder)
-        int32_t it = base_ok ? next2(mt0, mt1, 0, true) : n;
+        int32_t it = base_ok ? mt.next(0, true, n) : n;
         while (many && it < n) {
-            if (dust && sl_dust_window(dust, chip.sstride, L, s, it, k)) { it = next2(mt0, mt1, it + 1, true); continue; }
+            if (dust && sl_dust_window(dust, chip.sstride, L, s, it, k)) { it = mt.next(it + 1, true, n); continue; }
             if (ns >= max_seeds) SL_LEAVE(6);
             if (t0 + ns >= chip.max_entries) SL_LEAVE(7);
             sl_store_seed(chip, t0 + ns, it, k, 0, 1, gld(nodes + it));
             ++ns;
             *filtered_seeds = true;
-            it = next2(mt0, mt1, it + 1, true);
+            it = mt.next(it + 1, true, n);
         }
         while (it < n) {
-            int32_t next = next2(sp0, sp1, it, true);
-            if (next < n && test2(mt0, mt1, next)) ++next;
+            int32_t next = sp.next(it, true, n);
+            if (next < n && mt.test(next)) ++next;
             const int32_t mem_length = (next - it) + k - 1;
             if ((uint32_t)mem_length >= cfg.min_seed_length) {
                 if (ns >= max_seeds) SL_LEAVE(6);
@@ -381,7 +385,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
                 sl_store_seed(chip, t0 + ns, it, mem_length, 0, next - it, 0u);
                 ++ns;
             }
-            it = next2(mt0, mt1, next, true);
+            it = mt.next(next, true, n);
         }
         *n_out = ns;
         return SL_DONE;
@@ -390,12 +394,12 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
     // sub-k position with a look-up of its own (k - 1 characters) — dozens of walks per strand: the wave program's
     // (the second pass takes them: the look-up of a matched k-mer's position needs no walk — its k - 1 characters are the
     // label of the BOSS node the k-mer's edge leaves, so the range is that node's edges: kind 4)
-    if (!base_ok && (mt0 | mt1) && !chip.second_pass) SL_LEAVE(8);
+    if (!base_ok && mt.any() && !chip.second_pass) SL_LEAVE(8);
     const int32_t msl0 = (int32_t)cfg.min_seed_length;
     const int32_t nslots = L - msl0 + 1;
-    const bool tail_known = test2(mt0, mt1, n - 1);                // (no invalid character; plain graph)
+    const bool tail_known = mt.test(n - 1);                // (no invalid character; plain graph)
     constexpr int32_t NO_MEM = 0x7FFFFFFF;
-    auto next_mem = [&](int32_t from) -> int32_t { const int32_t p = next2(mt0, mt1, from, true); return p < n ? p : NO_MEM; };
+    auto next_mem = [&](int32_t from) -> int32_t { const int32_t p = mt.next(from, true, n); return p < n ? p : NO_MEM; };
     int32_t mem_it = base_ok && !many ? next_mem(0) : NO_MEM;      // the next MEM's first position
     int32_t cover_until = -1;                                      // positions <= this one hold k (a MEM's cover)
     int32_t run = 0;                                               // the value the running raise holds at position i (0: none)
@@ -408,11 +412,11 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
         last_end = end;
     };
     for (int32_t i = 0; i < nslots; ++i) {
-        if (many ? (base_ok && i < n && test2(mt0, mt1, i) && !(dust && sl_dust_window(dust, chip.sstride, L, s, i, k))) : i == mem_it) {
+        if (many ? (base_ok && i < n && mt.test(i) && !(dust && sl_dust_window(dust, chip.sstride, L, s, i, k))) : i == mem_it) {
             int32_t next = i + 1;
             if (!many) {
-                next = next2(sp0, sp1, i, true);
-                if (next < n && test2(mt0, mt1, next)) ++next;
+                next = sp.next(i, true, n);
+                if (next < n && mt.test(next)) ++next;
             }
             const int32_t nn = next - i, mem_length = nn + k - 1;
             if (ns >= max_seeds) SL_LEAVE(6);
@@ -434,7 +438,7 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
         if (max_len >= eff) {
             // the position's longest-prefix lookup, as far as needed (lookup_position of make_seeder)
             int32_t ml = 0, src = 2, known_at = i;                 // src: 1 = k_map's range, 2 = walk, 3 = walk only if it reports
-            if (i < n && test2(mt0, mt1, i)) {                     // (a matched k-mer no seed reports: see above; or its seed was masked)
+            if (i < n && mt.test(i)) {                     // (a matched k-mer no seed reports: see above; or its seed was masked)
                 ml = max_len; src = 4;
             } else if (i < n) {                                    // (max_len == k - 1 here)
                 const uint32_t c = gld(mlen + i);
