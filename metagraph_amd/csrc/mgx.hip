@@ -461,7 +461,7 @@ extern "C" unsigned mgx_grp_static_lds8_alt(void);
 extern "C" int mgx_grp_waves_per_simd8_alt(void);
 extern "C" int mgx_launch_ext64(const void *params, uint32_t blocks, uint32_t lds_bytes, void *stream);      // mgx_ext64.hip
 extern "C" int mgx_launch_lane(const void *d_params, uint32_t blocks, void *stream);                         // mgx_lane.hip
-extern "C" int mgx_launch_seed_lane(const void *d_params, uint32_t blocks, void *stream);                    // mgx_seedlane.hip
+extern "C" int mgx_launch_seed_lane(const void *d_params, uint32_t blocks, int long_reads, void *stream);                    // mgx_seedlane.hip
 extern "C" int mgx_seed_lane_waves_per_simd(void);
 // the 64-lane extension kernel with the label-aware extender compiled in (mgx_lab64.hip: -DMGX_WITH_LABELS=1)
 extern "C" int mgx_launch_align_grp8_lab(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);   // mgx_grp.hip, the labeled build
@@ -1349,13 +1349,15 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                                && seed_lane_enabled(A->dcfg, (uint32_t)A->graph->g.k, l.Lmax, true, true)
                                && (A->opt.seed_lane == 1 || n >= 4096);
         if (seed_lane && n) {
+            const bool long_reads = l.Lmax > (uint32_t)SL_SHORT_L;            // (the kernel's build with nine packed words per strand)
             const uint32_t resident = (uint32_t)prop.multiProcessorCount * 4 * (uint32_t)mgx_seed_lane_waves_per_simd();
             const uint32_t blocks1 = (uint32_t)std::min<uint64_t>(resident, (n + 63) / 64);
             // (the second pass: what the first left — a sixth of a typical batch — with the big buffers)
-            const uint32_t blocks2 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(resident, (n / 4 + 63) / 64));
+            const uint32_t blocks2 = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(resident / (long_reads ? 2 : 1), (n / 4 + 63) / 64));
             const bool many = (uint64_t)A->graph->g.k >= A->dcfg.max_seed_length;
-            const uint32_t me1 = many ? SL_SEEDS_1_MANY : SL_SEEDS_1, mp1 = many ? SL_PENDING_1_MANY : SL_PENDING_1;
-            const uint64_t words1 = seed_lane_wave_scratch_words(me1, mp1), words2 = seed_lane_wave_scratch_words(SL_SEEDS_2, SL_PENDING_2);
+            const uint32_t me1 = many ? (long_reads ? SL_SEEDS_1_MANY_LONG : SL_SEEDS_1_MANY) : SL_SEEDS_1, mp1 = many ? SL_PENDING_1_MANY : SL_PENDING_1;
+            const uint32_t me2 = long_reads ? SL_SEEDS_2_LONG : SL_SEEDS_2, mp2 = long_reads ? SL_PENDING_2_LONG : SL_PENDING_2;
+            const uint64_t words1 = seed_lane_wave_scratch_words(me1, mp1), words2 = seed_lane_wave_scratch_words(me2, mp2);
             if (int rc = A->seedlane_scratch.ensure((size_t)std::max<uint64_t>(blocks1 * words1, blocks2 * words2) * 4)) return rc;
             if (int rc = A->seedlane_params.ensure(2 * sizeof(SeedLaneParams))) return rc;
             if (int rc = A->seedlane_bail.ensure(2 * (n * 4 + 4))) return rc;
@@ -1370,7 +1372,8 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                 SP[ps].P = P;
                 SP[ps].P.n_items = n;
                 SP[ps].scratch = A->seedlane_scratch.as<uint32_t>();
-                SP[ps].max_entries = ps ? SL_SEEDS_2 : me1; SP[ps].max_pending = ps ? SL_PENDING_2 : mp1;
+                SP[ps].max_entries = ps ? me2 : me1; SP[ps].max_pending = ps ? mp2 : mp1;
+                SP[ps].long_reads = long_reads ? 1u : 0u;
                 SP[ps].second_pass = (uint32_t)ps;
                 SP[ps].in_list = ps ? list1 : nullptr; SP[ps].in_count = ps ? cur + 8 : nullptr; SP[ps].in_count_back = ps ? cur + 11 : nullptr;
                 SP[ps].list_len = n;
@@ -1382,10 +1385,10 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
                 SP[ps].bail_hist = (ps || !two) ? A->seedlane_hist.as<unsigned long long>() : nullptr;
             }
             HIP_TRY(copy_sync(A, A->seedlane_params.p, SP, sizeof(SP), hipMemcpyHostToDevice));
-            if (int rc = mgx_launch_seed_lane(A->seedlane_params.p, blocks1, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane-per-read seeder: %d", rc);
+            if (int rc = mgx_launch_seed_lane(A->seedlane_params.p, blocks1, long_reads, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane-per-read seeder: %d", rc);
             HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));                      // rewind the read cursor
             if (two) {
-                if (int rc = mgx_launch_seed_lane(A->seedlane_params.as<SeedLaneParams>() + 1, blocks2, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane-per-read seeder, second pass: %d", rc);
+                if (int rc = mgx_launch_seed_lane(A->seedlane_params.as<SeedLaneParams>() + 1, blocks2, long_reads, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane-per-read seeder, second pass: %d", rc);
                 HIP_TRY(hipMemsetAsync(cur + 1, 0, 8, A->hstream));
             }
             P.seed_list = two ? list2 : list1;

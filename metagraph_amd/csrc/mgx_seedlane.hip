@@ -20,14 +20,16 @@ using namespace mgx;
 #define MGX_SEEDLANE_WAVES_PER_SIMD 4
 #endif
 
+template <int QW>
 __global__ void __launch_bounds__(64, MGX_SEEDLANE_WAVES_PER_SIMD) k_seed_lane(const SeedLaneParams *__restrict__ SPp) {
     const SeedLaneParams &SP = *SPp;
     const AlignParams &P = SP.P;
-    __shared__ uint64_t s_qw[2 * SL_QWORDS][64];
+    __shared__ uint64_t s_qw[2 * QW][64];
     __shared__ uint32_t s_cnt[16][64];
     const int lane = (int)threadIdx.x;
     SeedLaneChip chip;
     chip.qw = &s_qw[0][lane]; chip.qstride = 64;
+    chip.qwords = QW; chip.max_l = QW == SL_QWORDS_SHORT ? SL_SHORT_L : SL_MAX_L;
     chip.sbuf = SP.scratch + (uint64_t)blockIdx.x * seed_lane_wave_scratch_words(SP.max_entries, SP.max_pending) + (uint32_t)lane; chip.sstride = 64;
     chip.cnt = &s_cnt[0][lane]; chip.cntstride = 64;
     chip.max_entries = (int32_t)SP.max_entries; chip.max_pending = (int32_t)SP.max_pending; chip.second_pass = (int32_t)SP.second_pass;
@@ -111,8 +113,10 @@ __global__ void __launch_bounds__(64, MGX_SEEDLANE_WAVES_PER_SIMD) k_seed_lane(c
 }
 
 // blocks = resident wavefronts (wavefront b owns SeedLaneParams::scratch + b * seed_lane_wave_scratch_words(...))
-extern "C" int mgx_launch_seed_lane(const void *d_params, uint32_t blocks, void *stream) {
-    k_seed_lane<<<blocks, 64, 0, (hipStream_t)stream>>>(static_cast<const SeedLaneParams *>(d_params));
+// long_reads: the build for reads of more than SL_SHORT_L characters (SeedLaneParams::long_reads says the same to the host side)
+extern "C" int mgx_launch_seed_lane(const void *d_params, uint32_t blocks, int long_reads, void *stream) {
+    if (long_reads) k_seed_lane<SL_QWORDS_LONG><<<blocks, 64, 0, (hipStream_t)stream>>>(static_cast<const SeedLaneParams *>(d_params));
+    else k_seed_lane<SL_QWORDS_SHORT><<<blocks, 64, 0, (hipStream_t)stream>>>(static_cast<const SeedLaneParams *>(d_params));
     return (int)hipGetLastError();
 }
 extern "C" int mgx_seed_lane_waves_per_simd(void) { return MGX_SEEDLANE_WAVES_PER_SIMD; }

@@ -9,7 +9,7 @@
 // Contract: "complete or redo", as the extension's lane kernel (lane_read.hpp).  seed_lane_read() either finishes a read — its
 // seeds in the lane's buffer, ready for seed_lane_publish() to write header, seed stream and work key exactly as
 // align_read<PH_SEED> does — or returns SL_BAIL having written nothing, and the read goes to the wave program in its own
-// launch.  What a lane takes: UniMEM seeding (max_seed_length > k; SuffixSeeder<UniMEMSeeder>, A/aligner_seeder_methods.cpp:153-358
+// launch.  What a lane takes (reads of up to SL_MAX_L characters): UniMEM seeding (max_seed_length > k; SuffixSeeder<UniMEMSeeder>, A/aligner_seeder_methods.cpp:153-358
 // over :116-135 of the header) or one seed per k-mer (max_seed_length == k: ExactSeeder :67-93, every label-aware batch), with or
 // without sub-k seeds, k <= 32, reads of k .. SL_MAX_L characters in ACGT only,
 // plain (BASIC / CANONICAL-mode) graphs, k_map's match lengths and ranges present.  It leaves: reads whose DUST scan could
@@ -35,9 +35,11 @@
 
 namespace mgx {
 
-constexpr int SL_MAX_KMERS = 192;          // k-mer positions of a strand (three 64-bit masks)
-constexpr int SL_MAX_L = 160;              // longest read a lane takes
-constexpr int SL_QWORDS = 6;               // packed strand: 32 codes per word, one zero word behind the last
+constexpr int SL_MAX_KMERS = 256;          // k-mer positions of a strand (four 64-bit masks)
+constexpr int SL_MAX_L = 255;              // longest read a lane takes (the DUST map holds positions as bytes, 255 = none)
+// packed strands in LDS, 32 codes per word and one zero word behind the last: two builds of the kernel, for batches of reads of
+// up to SL_SHORT_L characters (6 words per strand: 16 wavefronts per CU) and of up to SL_MAX_L (9 words: 12 per CU)
+constexpr int SL_SHORT_L = 160, SL_QWORDS_SHORT = 6, SL_QWORDS_LONG = 9;
 constexpr int SL_SEED_WORDS = 3;           // a DevSeed as three words
 constexpr int SL_PEND_WORDS = 6;           // a pending record (below)
 // Two passes (mgx.hip): the first takes every read with a small buffer — at most SL_SEEDS_1 buffer entries, SL_PENDING_1 of
@@ -49,6 +51,8 @@ constexpr int SL_PEND_WORDS = 6;           // a pending record (below)
 constexpr int SL_SEEDS_1 = 32, SL_PENDING_1 = 8;
 // (one seed per matched k-mer — max_seed_length == k, every label-aware batch: ~120 seeds per strand, a look-up per tail position)
 constexpr int SL_SEEDS_1_MANY = 192, SL_PENDING_1_MANY = 32;
+// (batches with reads of more than SL_SHORT_L characters: more positions)
+constexpr int SL_SEEDS_1_MANY_LONG = 288, SL_SEEDS_2_LONG = 288, SL_PENDING_2_LONG = 256;
 constexpr int SL_SEEDS_2 = 192, SL_PENDING_2 = 144;
 
 // what one launch of the kernel needs on top of AlignParams
@@ -58,6 +62,7 @@ struct SeedLaneParams {
                                            // ((t * SL_SEED_WORDS + w) * 64 + l); the pending records behind the seeds
     uint32_t max_entries, max_pending;     // buffer entries / pending records a lane's share of the scratch holds
     uint32_t second_pass;                  // 0: every read of the batch; 1: the reads of in_list (what the first pass left)
+    uint32_t long_reads;                   // the SL_QWORDS_LONG build (mgx_launch_seed_lane picks the kernel by it)
     // The first pass lists what it leaves from both ends of one array of list_len entries: the reads its quick DUST scan could not
     // clear from the front, the others (strands below min_exact_match: dozens of look-ups each) from the back — so that the
     // second pass, which takes 64 consecutive entries per wavefront, has reads of a kind side by side.
@@ -71,7 +76,7 @@ struct SeedLaneParams {
 };
 
 MGX_HD uint64_t seed_lane_wave_scratch_words(uint32_t max_entries, uint32_t max_pending) {
-    return ((uint64_t)max_entries * SL_SEED_WORDS + (uint64_t)max_pending * SL_PEND_WORDS + (uint64_t)(SL_MAX_L / 4)) * 64;
+    return ((uint64_t)max_entries * SL_SEED_WORDS + (uint64_t)max_pending * SL_PEND_WORDS + (uint64_t)((SL_MAX_L + 1) / 4)) * 64;
 }
 
 // does the batch's configuration suit the kernel at all (mgx.hip; the host model asks the same)
@@ -87,13 +92,14 @@ inline bool seed_lane_enabled(const DevConfig &d, uint32_t k, uint32_t Lmax, boo
 
 // per-lane views of the on-chip arrays (LDS on the device, plain arrays in the host model)
 struct SeedLaneChip {
-    uint64_t *qw; int32_t qstride;         // packed strand s, word j: qw[(s * SL_QWORDS + j) * qstride]
+    uint64_t *qw; int32_t qstride;         // packed strand s, word j: qw[(s * qwords + j) * qstride]
+    int32_t qwords, max_l;                 // words per strand, longest read (SL_QWORDS_* / SL_SHORT_L or SL_MAX_L)
     uint32_t *sbuf; int32_t sstride;       // the lane's seed buffer: word w of seed t at sbuf[(t * SL_SEED_WORDS + w) * sstride]
     int32_t max_entries, max_pending;      // its capacities (SeedLaneParams)
     int32_t second_pass;                   // 0 first pass; second pass: 1 = a read the quick DUST scan could not clear, 2 = another
     uint32_t *cnt; int32_t cntstride;      // 64 byte counters (the DUST scans' triplet counts): byte t in word cnt[(t >> 2) * cntstride]
 };
-constexpr int SL_DUST_WORDS = SL_MAX_L / 4;    // the lane's DUST map (sl_dust_map): a byte per character, behind the pending records
+constexpr int SL_DUST_WORDS = (SL_MAX_L + 1) / 4;    // the lane's DUST map (sl_dust_map): a byte per character, behind the pending records
 
 struct SeedLaneOut {
     int32_t L;
@@ -281,17 +287,17 @@ MGX_DEV uint32_t *sl_pending(const SeedLaneChip &chip, int32_t j) {
     return chip.sbuf + (chip.max_entries * SL_SEED_WORDS + j * SL_PEND_WORDS) * chip.sstride;
 }
 
-// a mask over a strand's k-mer positions (three words held as three variables: an indexable array would live in scratch memory)
+// a mask over a strand's k-mer positions (four words held as four variables: an indexable array would live in scratch memory)
 struct SlMask {
-    uint64_t w0, w1, w2;
-    MGX_DEV void set(int32_t i) { const uint64_t b = 1ull << (i & 63); if (i < 64) w0 |= b; else if (i < 128) w1 |= b; else w2 |= b; }
-    MGX_DEV bool test(int32_t i) const { return (((i < 64 ? w0 : i < 128 ? w1 : w2) >> (i & 63)) & 1ull) != 0; }
-    MGX_DEV bool any() const { return (w0 | w1 | w2) != 0; }
+    uint64_t w0, w1, w2, w3;
+    MGX_DEV void set(int32_t i) { const uint64_t b = 1ull << (i & 63); if (i < 64) w0 |= b; else if (i < 128) w1 |= b; else if (i < 192) w2 |= b; else w3 |= b; }
+    MGX_DEV bool test(int32_t i) const { return (((i < 64 ? w0 : i < 128 ? w1 : i < 192 ? w2 : w3) >> (i & 63)) & 1ull) != 0; }
+    MGX_DEV bool any() const { return (w0 | w1 | w2 | w3) != 0; }
     // bits_next over [0, n): the first position >= from whose bit equals val; n if none
     MGX_DEV int32_t next(int32_t from, bool val, int32_t n) const {
         const uint64_t flip = val ? 0ull : ~0ull;
-        for (int32_t base = from & ~63; base < n && base < 192; base += 64) {
-            uint64_t x = (base == 0 ? w0 : base == 64 ? w1 : w2) ^ flip;
+        for (int32_t base = from & ~63; base < n && base < 256; base += 64) {
+            uint64_t x = (base == 0 ? w0 : base == 64 ? w1 : base == 128 ? w2 : w3) ^ flip;
             if (base < from) x &= ~0ull << (from - base);
             if (x) { const int32_t p = base + ctz64(x); return p < n ? p : n; }
         }
@@ -312,11 +318,11 @@ MGX_DEV int sl_strand(const AlignParams &P, const uint64_t read_nb, const int s,
     const int32_t k = (int32_t)g.k;
     const uint32_t *nodes = (s ? P.nodes_rc : P.nodes_fwd) + read_nb;
     const uint8_t *mlen = (s ? P.mlen_rc : P.mlen_fwd) + read_nb;
-    const uint64_t *qw = chip.qw + (s * SL_QWORDS) * chip.qstride;
+    const uint64_t *qw = chip.qw + (s * chip.qwords) * chip.qstride;
     const int32_t qs = chip.qstride;
     LineCtr &ctr = out.ctr;
     // kmer_masks: matched k-mers, MEM stops (the terminus of a matched k-mer, inclusive, or an unmatched k-mer)
-    SlMask mt = { 0, 0, 0 }, sp = { 0, 0, 0 };
+    SlMask mt = { 0, 0, 0, 0 }, sp = { 0, 0, 0, 0 };
     {
         uint32_t v = gld(nodes);
         for (int32_t i = 0; i < n; ++i) {
@@ -508,7 +514,7 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
     const uint64_t off = gld(P.offsets + read);
     const int32_t L = (int32_t)(gld(P.offsets + read + 1) - off);
     out.L = L;
-    if (L > (int32_t)P.lim.Lmax || L > SL_MAX_L || L < k) SL_LEAVE(1);
+    if (L > (int32_t)P.lim.Lmax || L > chip.max_l || L < k) SL_LEAVE(1);
     const uint64_t nb = gld(P.node_begin + read);
     const int32_t n = (int32_t)(gld(P.node_begin + read + 1) - nb);
     if (n != L - k + 1 || n > SL_MAX_KMERS) SL_LEAVE(2);
@@ -518,10 +524,10 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
         const int32_t nw = (L + 31) >> 5;
         uint32_t inv = 0;
         for (int s = 0; s < (have_rc ? 2 : 1); ++s)
-            for (int32_t j = 0; j < SL_QWORDS; ++j) {
+            for (int32_t j = 0; j < chip.qwords; ++j) {
                 uint64_t v = 0;
                 if (j < nw) { v = gld(P.pkw[s] + wb + j); inv |= gld(P.ivw[s] + wb + j); }
-                chip.qw[(s * SL_QWORDS + j) * chip.qstride] = v;
+                chip.qw[(s * chip.qwords + j) * chip.qstride] = v;
             }
         if (inv) SL_LEAVE(3);
     }
@@ -553,7 +559,7 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
         for (int s = 0; s < 2; ++s) {
             bool masked = false;
 #if !(MGX_SL_PROBE & 2)
-            if (pend_of[s] || filtered[s]) masked = sl_dust_could_mask(chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, L);
+            if (pend_of[s] || filtered[s]) masked = sl_dust_could_mask(chip.qw + (s * chip.qwords) * chip.qstride, chip.qstride, L);
 #endif
             if (masked) SL_LEAVE(4);
         }
@@ -592,7 +598,7 @@ MGX_DEV int seed_lane_read(const AlignParams &P, const uint64_t read, const Seed
             first = last = succ_last(g, (uint64_t)gld((s ? P.nodes_rc : P.nodes_fwd) + nb + a1), out.ctr);
             hit = first && first <= g.n;
         } else {
-            const int32_t m = sl_index_range(g, chip.qw + (s * SL_QWORDS) * chip.qstride, chip.qstride, i, ml, msl0, &first, &last, out.ctr);
+            const int32_t m = sl_index_range(g, chip.qw + (s * chip.qwords) * chip.qstride, chip.qstride, i, ml, msl0, &first, &last, out.ctr);
             hit = m >= msl0 && first && first <= g.n;
         }
         if (!hit) SL_LEAVE(9);

@@ -465,7 +465,9 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
             const char *sl_env = getenv("MGX_EMU_SEEDLANE");
             if (sl_env && *sl_env == '1' && P.pkw[0] && (!dcfg.fwd_and_rc || P.pkw[1])
                     && seed_lane_enabled(dcfg, k, R->lim.Lmax, true, true)) {
-                std::vector<uint64_t> sq(2 * SL_QWORDS);
+                const bool long_reads = R->lim.Lmax > (uint32_t)SL_SHORT_L;       // (as mgx.hip picks the kernel build)
+                const int32_t qwords = long_reads ? SL_QWORDS_LONG : SL_QWORDS_SHORT, max_l = long_reads ? SL_MAX_L : SL_SHORT_L;
+                std::vector<uint64_t> sq(2 * qwords);
                 std::vector<uint32_t> scnt(16);
                 R->seedlane_ran = 1;
                 // (MGX_EMU_SEEDLANE_ONE=1: the first pass only)
@@ -475,12 +477,13 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
                 for (uint64_t i = 0; i < n; ++i) todo[i] = i;
                 for (int ps = 0; ps < (two ? 2 : 1); ++ps) {
                     const bool many = (uint64_t)k >= dcfg.max_seed_length;
-                    const int32_t me = ps ? SL_SEEDS_2 : many ? SL_SEEDS_1_MANY : SL_SEEDS_1, mp = ps ? SL_PENDING_2 : many ? SL_PENDING_1_MANY : SL_PENDING_1;
+                    const int32_t me = ps ? (long_reads ? SL_SEEDS_2_LONG : SL_SEEDS_2) : many ? (long_reads ? SL_SEEDS_1_MANY_LONG : SL_SEEDS_1_MANY) : SL_SEEDS_1;
+                    const int32_t mp = ps ? (long_reads ? SL_PENDING_2_LONG : SL_PENDING_2) : many ? SL_PENDING_1_MANY : SL_PENDING_1;
                     std::vector<uint32_t> sbuf(seed_lane_wave_scratch_words((uint32_t)me, (uint32_t)mp), 0);
                     left.clear();
                     for (size_t x = 0; x < todo.size(); ++x) {
                         const uint64_t i = todo[x];
-                        SeedLaneChip chip = { sq.data(), 1, sbuf.data() + (x % 64), 64, me, mp, !ps ? 0 : why1[i] == 4 ? 1 : 2, scnt.data(), 1 };
+                        SeedLaneChip chip = { sq.data(), 1, qwords, max_l, sbuf.data() + (x % 64), 64, me, mp, !ps ? 0 : why1[i] == 4 ? 1 : 2, scnt.data(), 1 };
                         SeedLaneOut so;
                         so.reason = 0;
                         if (seed_lane_read(P, i, chip, so) == SL_DONE) {

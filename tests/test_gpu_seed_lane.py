@@ -70,6 +70,16 @@ def test_seed_lane_on_random_worlds(seed):
     check(g, cfg, reads, ("seed_lane=1", "lane=1"), None)
 
 
+def test_seed_lane_on_reads_of_250_characters():
+    """the build of the kernel for batches with reads of 161 .. 255 characters (nine packed words per strand)"""
+    g, reads = bench_like_world(250, 6000, genome_len=120000, read_len=250, snp_every=300)
+    reads += [reads[0][:255], reads[1][:160], reads[2][:161], reads[3] + reads[4][:6], "ACGT" * 60]
+    cfg = capi.config_cli(31)
+    check(g, cfg, reads, ("seed_lane=1",), 0.9)
+    cfg.max_seed_length = 31
+    check(g, cfg, reads[:2000], ("seed_lane=1",), 0.8)
+
+
 def test_seed_lane_is_the_automatic_choice_for_large_batches_only():
     g, reads = bench_like_world(77, 6000, genome_len=60000)
     cfg = capi.config_cli(31)

@@ -151,7 +151,7 @@ def main():
             if args.lane:
                 L = rng.choice([k, k + 3, 40, 75, 100, 150, 150, 150, 250, 256, 257])
             if args.seedlane:
-                L = rng.choice([k - 1, k, k + 1, k + 3, 40, 75, 100, 150, 150, 150, 159, 160, 161, 250])
+                L = rng.choice([k - 1, k, k + 1, k + 3, 40, 75, 100, 150, 150, 150, 159, 160, 161, 200, 250, 254, 255, 256, 300])
             if k < 11 and L > 150:
                 L = 150                                          # (tiny k x long reads: thousands of extensions per read, minutes per world)
             L = max(1, min(L, len(genome) - 1))
