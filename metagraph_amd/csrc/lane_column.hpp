@@ -23,6 +23,13 @@ namespace mgx {
 #define LANE_SCHED_FENCE() ((void)0)
 #endif
 
+// hides how a per-lane base was computed: the compiler otherwise folds x ge - bo ge back into (x - bo) ge, one multiplication per cell
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LANE_COL_OPAQUE(v) asm volatile("" : "+v"(v))
+#else
+#define LANE_COL_OPAQUE(v) ((void)0)
+#endif
+
 #ifndef MGX_LFW
 #define MGX_LFW 32
 #endif
@@ -59,10 +66,21 @@ enum { LC_OK = 0, LC_EMPTY_BAND = 1, LC_FALLBACK = 2, LC_POP = 3 };
 // This one reads the byte query and the score-matrix row (the 8-lane groups' data; the cross-check build); the lane-per-read
 // kernel brings its own over the 2-bit packed strand (lane_read.hpp).
 struct LaneProfBytes {
+    static constexpr bool linear_psum_only = false;  // the caller may hand over a table of partial sums (LaneColumnIn::psum)
     const uint8_t *q; const int8_t *row; int32_t qlen;
     MGX_HD void prepare(int32_t) {}
     MGX_HD int32_t at(int, int32_t ap) const { return (ap >= 1 && ap <= qlen) ? (int32_t)row[q[ap - 1] & 127] : 0; }
 };
+
+// a + b, saturating (v_add_i32 ... clamp)
+MGX_HD int32_t lane_add_sat(int32_t a, int32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_elementwise_add_sat(a, b);
+#else
+    const int64_t t = (int64_t)a + (int64_t)b;
+    return t < (int64_t)INT32_MIN ? INT32_MIN : (t > (int64_t)INT32_MAX ? INT32_MAX : (int32_t)t);
+#endif
+}
 
 // band within the x-drop cut-off (:549-560): [begin, prev_end) in window positions; empty when prev_end <= begin
 MGX_HD void lane_band(const LaneColumnIn &in, const int32_t *S, int32_t &begin, int32_t &prev_end) {
@@ -114,9 +132,17 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
     int32_t e_next = NINF;                           // E[j] of the cell at hand as the recurrence gives it
     int32_t ce_prev = NINF;                          // E of the cell before, final
     bool pushing = false;                            // extend_ins_end (:293-328), decided at the column's last cell
-    int32_t ins_score = 0, n_push = 0;
+    int32_t n_push = 0;
     int32_t mx = INT32_MIN, mn = INT32_MAX, key = INT32_MAX, conv = INT32_MIN;
     bool ext = false;
+    // (round 6: everything of a cell that is linear in its index — jj ge, (jj + 1) ge, the insertion run behind the column's end,
+    // the linear partial sum — is a per-lane base plus a multiple of a uniform: one addition with a scalar operand where the pass
+    // spent three quarter-rate multiplications per cell)
+    int32_t boge = bo * ge;                          // jj ge == x ge - boge
+    int32_t go_boge = go + boge;                     // go - jj ge == go_boge - x ge
+    int32_t ps0 = in.psum_lin ? (in.qlen - (in.start + org)) * in.psum_lin : 0;            // the linear partial sum under cell 0
+    int32_t ins_base = 0;                            // ins_score - (bo + size0) ge: the run's cell t scores ins_base + x ge
+    LANE_COL_OPAQUE(boge); LANE_COL_OPAQUE(go_boge); LANE_COL_OPAQUE(ps0);
     // cells from `hi` on hold nothing (beyond the overshoot of update_column and beyond the column's end): whole blocks of four
     // are skipped; the insertion run may move the end once, when the pass reaches the column's last cell
     int32_t hi = bo + imax(n_loop, size0);
@@ -138,14 +164,15 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
                 const int32_t match = jj >= 1 ? mraw : NINF;
                 const int32_t m = imax(match, del);
                 int32_t fv = inl ? del : NINF;
-                run = inl ? imax(run, m + go - jj * ge) : run;
-                int32_t ce = (jj >= 0 && jj <= n_loop) ? e_next : NINF;
+                run = inl ? imax(run, m + (go_boge - x * ge)) : run;
+                // (E of the cell at hand: e_next is ninf wherever the cell before was not in the loop, i.e. outside 0 < jj <= n_loop,
+                // and the recurrence's value — ninf extended — at jj == 0)
+                int32_t ce = e_next;
                 int32_t sv = imax(m, e_next);
                 sv = (inl && sv > cutoff - 1) ? sv : NINF;
                 // E[j + 1] = max(E[j] + ge, m[j] + go) in closed form over the column (E[0] = ninf extended j + 1 times, saturating)
-                const int32_t dec = (jj + 1) * ge;
-                const int32_t from_e0 = dec < -100 ? INT32_MIN : NINF + dec;
-                e_next = inl ? imax(run + jj * ge, from_e0) : NINF;
+                const int32_t from_e0 = lane_add_sat(NINF, (x + 1) * ge - boge);          // (dec < -100 ? INT32_MIN : ninf + dec, dec = (jj + 1) ge)
+                e_next = inl ? imax(run + (x * ge - boge), from_e0) : NINF;
                 if (jj == size0 - 1) {
                     if (tail) { const int32_t mt = imax(mraw, ce); if (mt >= cutoff) sv = mt; }
                     if (size0 < max_size) {
@@ -159,7 +186,8 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
                             fallback = bo + size0 + n_push > LFW;
                             n_push = fallback ? 0 : n_push;
                             pushing = !fallback;
-                            ins_score = ins;
+                            ins_base = ins - (bo + size0) * ge;
+                            LANE_COL_OPAQUE(ins_base);
                             hi = imax(hi, bo + size0 + n_push);
                         }
                     }
@@ -169,7 +197,7 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
                     const int32_t t = jj - size0;
                     const bool beyond = pushing && t >= 0;
                     const bool pc = beyond && t < n_push;
-                    const int32_t v = ins_score + t * ge;
+                    const int32_t v = ins_base + x * ge;                               // ins_score + t ge
                     sv = beyond ? (pc ? v : NINF) : sv;
                     ce = beyond ? (pc ? v : NINF) : ce;
                     fv = beyond ? NINF : fv;
@@ -181,13 +209,14 @@ MGX_HD int lane_column(const LaneColumnIn &in, int32_t *S, int32_t *F, LaneColum
                     key = svc > mx ? kk : ((svc == mx && in_col) ? imin(key, kk) : key);
                     mx = imax(mx, svc);
                     mn = (in_col && sv != NINF) ? imin(mn, sv) : mn;
-                    const int32_t ps_here = in.psum_lin ? (in.qlen - (in.start + a)) * in.psum_lin : (in_col ? in.psum[in.start + a] : 0);
+                    int32_t ps_here = ps0 - x * in.psum_lin;                          // (qlen - (start + a)) psum_lin
+                    if (!Prof::linear_psum_only) { if (!in.psum_lin) ps_here = in_col ? in.psum[in.start + a] : 0; }
                     ext |= in_col && sv + ps_here >= extension_cutoff;
                     conv = (in_col && jj >= skip) ? imax(conv, sv) : conv;
                 }
                 // the flag byte (what backtrack compares, evaluated once: ColSlot)
                 {
-                    const int32_t ep = (jj <= 0 || x == 0) ? NINF : ce_prev;
+                    const int32_t ep = ce_prev;                  // (ninf at jj <= 0: no cell before it was in the loop)
                     const bool pin = a - 1 >= in.p_trim;
                     uint32_t fl = 0;
                     fl |= sv != NINF ? CF_REAL : 0;

@@ -39,20 +39,21 @@ namespace mgx {
 struct LaneChip {
     int32_t lane;                        // the lane's index in its wavefront (its private scratch slice: lane_rest())
     uint64_t *qw; int32_t qstride;       // packed strand of the read: word i at qw[i * qstride]
-    uint32_t *runs; int32_t rstride;     // CIGAR runs of the trace, last first: run i at runs[i * rstride]
     uint32_t *cold; int32_t cstride;     // the lane's cold state (below): word i at cold[i * cstride]
 };
 
 // Per-read state that is touched once per column or less — the best backtrack start, the parked child of a fork, the columns that
 // stayed behind, the modelled capacities ... — lives in LDS, not in VGPRs: the DP window (64 registers) and the column pass need
 // the register file (the kernel was at 250+ VGPRs and spilling with all of it in registers).  Accessed as plain variables through
-// the macros below.
+// the macros below.  (Round 6: 44 -> 38 words, part of the LDS a third wavefront per SIMD needs — what is touched once or twice
+// per pass — the read's length and seed count, the backward pass's clipping, the root's insertion run — moved to the lane's
+// record in its scratch slice, arec() words 16 .. 19; the two line counters share a word, as do the two children's characters.)
 enum { CD_B_SCORE, CD_B_NOD, CD_B_I, CD_B_POS, CD_T_SCORE, CD_T_NOD, CD_T_POS,
        CD_FA_ALIVE, CD_FA_CONV, CD_FA_MAX,
        CD_D_SCORE0, CD_D_SCORE1, CD_D_SCORE2, CD_D_MAX0, CD_D_MAX1, CD_D_MAX2,
-       CD_KID_N0, CD_KID_C0, CD_KID_N1, CD_KID_C1, CD_KID_R0, CD_KID_R1,
+       CD_KID_N0, CD_KID_C, CD_KID_N1, CD_KID_R0, CD_KID_R1,
        CD_TABLE_CAP, CD_TSB_LO, CD_TSB_HI, CD_CELL_TOP, CD_NCOLS, CD_F_NODE, CD_F_IDX, CD_F_MAX,
-       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_ROOT_PUSHES, CD_CTR_RANK, CD_CTR_SEL, CD_FWD_N_NODES, CD_FWD_N_SEQ, CD_HMS, CD_CLIP, CD_L, CD_NSEEDS, CD_REPLAY_TOP, CD_S8_FILTER,
+       CD_SEED_LEN, CD_SEED_OFF, CD_NODE0, CD_CTR, CD_FWD_N_NODES, CD_FWD_N_SEQ, CD_HMS, CD_REPLAY_TOP, CD_S8_FILTER,
        LANE_COLD_WORDS };
 static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 #define LANE_CI(f) (*(int32_t *)(chip.cold + (f) * chip.cstride))
@@ -83,6 +84,7 @@ static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 
 // profile scores over the packed strand (see LaneProfBytes)
 struct LaneProfPacked {
+    static constexpr bool linear_psum_only = true;   // the lane kernel takes reads without invalid characters only: psum_lin != 0
     const uint64_t *qw; int32_t qstride, qlen;
     uint32_t rowp;                       // the column character's row of LaneParams::t4
     uint64_t w;                          // codes of the query characters under cells 0 .. 31 (cell x: bits 2x, 2x + 1)
@@ -164,7 +166,7 @@ MGX_DEV int lane_parents(const DevGraph &g, uint32_t vv, uint32_t &n0, uint32_t 
         ++bi;
         pos = (uint64_t)bi << 6;
     }
-    LANE_CU(CD_CTR_RANK) += lc.rank_lines + lc.bit_lines; LANE_CU(CD_CTR_SEL) += lc.select_lines;
+    LANE_CU(CD_CTR) += (lc.rank_lines + lc.bit_lines) | (lc.select_lines << 16);
     return n > 2 ? 3 : n;
 }
 
@@ -241,7 +243,7 @@ MGX_DEV int lane_children(const DevGraph &g, uint32_t vv, uint32_t sel_r, uint32
             }
         }
     }
-    LANE_CU(CD_CTR_RANK) += lc.rank_lines; LANE_CU(CD_CTR_SEL) += lc.select_lines;
+    LANE_CU(CD_CTR) += lc.rank_lines | (lc.select_lines << 16);
     return n > 2 ? 3 : n;
 }
 
@@ -263,6 +265,11 @@ MGX_HD uint32_t *lane_s8_word(const uint8_t *il, uint32_t max_cols, int32_t c, i
 }
 MGX_HD uint8_t *lane_s8_byte(const uint8_t *il, uint32_t max_cols, int32_t c, int32_t x) {
     return (uint8_t *)lane_s8_word(il, max_cols, c, x >> 2) + (x & 3);
+}
+// CIGAR run i of the trace (last first), behind the S rows: written when a run ends, read when the alignment is written out — the
+// 4 KB per wavefront they took in LDS until round 6 are part of what a third wavefront per SIMD needs
+MGX_HD uint32_t *lane_run_word(const uint8_t *il, uint32_t max_cols, int32_t i) {
+    return (uint32_t *)il + (max_cols * (LANE_SLOT_WORDS + LANE_S8_WORDS) + (uint32_t)i) * LANE_WAVE;
 }
 // the lane's private slice behind the interleaved part
 MGX_HD uint8_t *lane_rest(const LaneParams &LP, const uint8_t *il, int32_t lane) {
@@ -343,9 +350,8 @@ struct LaneResult {
 #define d_score(t) LANE_CI(CD_D_SCORE0 + (t))
 #define d_max(t) LANE_CI(CD_D_MAX0 + (t))
 #define kid_node0 LANE_CU(CD_KID_N0)
-#define kid_code0 LANE_CU(CD_KID_C0)
+#define kid_codes LANE_CU(CD_KID_C)                  /* child 0's character in the low byte, child 1's above it */
 #define kid_node1 LANE_CU(CD_KID_N1)
-#define kid_code1 LANE_CU(CD_KID_C1)
 #define kid_rank0 LANE_CU(CD_KID_R0)
 #define kid_rank1 LANE_CU(CD_KID_R1)
 #define table_cap LANE_CU(CD_TABLE_CAP)
@@ -383,7 +389,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
     auto runs_fwd = [&]() -> uint32_t * { return pa_code() + LP.max_cols; };      // ... and its CIGAR runs
     // the alignment found so far, as the output needs it (written once per pass, read at the end: memory, not registers):
     // [0 .. 8) score, offset, clip, end clip, runs, last column, nodes, characters; [8 .. 12) the forward alignment while the
-    // backward pass runs: in the aggregator?, score, clip, end clip; [16 .. 25) the parked child of a fork; [26 .. 32) counters
+    // backward pass runs: in the aggregator?, score, clip, end clip; [16 .. 20) the read's length, its seed count, the clipping of the backward pass's seed, the root's insertion run; [26 .. 32) counters
     auto arec = [&]() -> uint32_t * { return runs_fwd() + LANE_MAX_RUNS; };
     // a column that stays behind in the frontier: its window (S, F) and what makes it the head again — slot t of LANE_MAX_DEFER
     auto dsave = [&](int t) -> uint32_t * { return arec() + 32 + (LANE_MAX_L + 8) + t * LANE_DSLOT_WORDS; };
@@ -457,11 +463,11 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         }
         n = s ? ns1 : ns0;
         // the result: which alignment (LaneResult::mode) and its scalars
-        LANE_CI(CD_HMS) = (s << 3) | (int32_t)(label << 8); LANE_CI(CD_L) = L; LANE_CI(CD_NSEEDS) = n;
+        LANE_CI(CD_HMS) = (s << 3) | (int32_t)(label << 8); gst(arec() + 16, (uint32_t)L); gst(arec() + 17, (uint32_t)n);
         cols_done = 0;
-        LANE_CU(CD_CTR_RANK) = 0; LANE_CU(CD_CTR_SEL) = 0;
+        LANE_CU(CD_CTR) = 0;
     } else {
-        L = LANE_CI(CD_L); n = LANE_CI(CD_NSEEDS);
+        L = (int32_t)gld(arec() + 16); n = (int32_t)gld(arec() + 17);
     }
     const int32_t n_extensions = n > 0 ? pass + 1 : 0;
     if (n > 0) {
@@ -506,7 +512,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             }
             LANE_CU(CD_S8_FILTER) = flt;
         } else {
-            clipping = LANE_CI(CD_CLIP);            // (the seed of the backward pass and its strand: set up when pass 0 ended)
+            clipping = (int32_t)gld(arec() + 18);            // (the seed of the backward pass and its strand: set up when pass 0 ended)
         }
 #define c_seed_len LANE_CI(CD_SEED_LEN)
 #define c_seed_off LANE_CI(CD_SEED_OFF)
@@ -555,7 +561,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                 root_pushes = n_push;
             }
             const int32_t root_size = 1 + root_pushes;
-            LANE_CI(CD_ROOT_PUSHES) = root_pushes;
+            gst(arec() + 19, (uint32_t)root_pushes);
             if ((uint64_t)rec_words((uint32_t)root_size + 8) > lim.cell_words) LANE_BAIL(8);
             // (the table of a strand's extender keeps its capacity between extensions; a read's two passes use two extenders)
             table_cap = 1;
@@ -593,7 +599,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 #pragma unroll
         for (int t = 0; t < LANE_MAX_DEFER; ++t) { d_score(t) = INT32_MIN; d_max(t) = NINF; }
         // the children of the head that are being computed (call_outgoing :330-387): one, or the two of a fork
-        kid_node0 = 0; kid_code0 = 0; kid_node1 = 0; kid_code1 = 0; kid_rank0 = 0; kid_rank1 = 0;
+        kid_node0 = 0; kid_codes = 0; kid_node1 = 0; kid_rank0 = 0; kid_rank1 = 0;
         int n_kids = 0, kid = 0;
         // the first child of a fork, parked while the second is computed (its window in the lane's scratch)
         fa_alive = 0; fa_conv = 0; fa_max_val = 0;
@@ -641,12 +647,12 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         const int32_t no = f_offset + 1, sp = no - c_seed_off;
                         if (sp >= 0 && sp < c_seed_len && (no < k || pass)) {
                             if (!pass) {
-                                kid_node0 = c_node0; kid_rank0 = 0; kid_code0 = qcode(clipping + sp) + 1;   // the seed's first node, its spelling
+                                kid_node0 = c_node0; kid_rank0 = 0; kid_codes = (kid_codes & ~0xFFu) | (qcode(clipping + sp) + 1);   // the seed's first node, its spelling
                             } else {
                                 // force_fixed_seed (:344-372): the reversed forward alignment, node by node — its spelling is
                                 // the complement of the path's, read backwards (A <-> T, C <-> G: code 5 - c)
                                 const int32_t fn = c_fwd_n_nodes, fq = c_fwd_n_seq;
-                                kid_code0 = 5u - gld(pa_code() + (fq - 1 - sp));
+                                kid_codes = (kid_codes & ~0xFFu) | ((5u - gld(pa_code() + (fq - 1 - sp))) & 0xFFu);
                                 kid_node0 = gld(pa_node() + (fn - 1 - imax(0, no - k + 1))); kid_rank0 = 0;
                             }
                             n_kids = 1;
@@ -673,7 +679,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 nc_l = (k0 ? 1 : 0) + (k1 ? 1 : 0);
                                 if (nc_l < 2) { kn1 = 0; kc1 = 0; kr1 = 0; }
                             }
-                            kid_node0 = kn0; kid_code0 = kc0; kid_node1 = kn1; kid_code1 = kc1; kid_rank0 = kr0; kid_rank1 = kr1;
+                            kid_node0 = kn0; kid_codes = (kc0 & 0xFFu) | (kc1 << 8); kid_node1 = kn1; kid_rank0 = kr0; kid_rank1 = kr1;
                             if (nc_l == 0) {                                           // a tip: its start cell counts after all
                                 if (t_score != INT32_MIN) cand(t_score, t_nod, f_idx, t_pos);
                                 if (tie_bad) LANE_BAIL(27);
@@ -696,7 +702,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             const bool forked = n_kids == 2;
             if (compute) {
                 if (forked && kid == 0) win_save(save_p());                            // the parent is needed twice
-                const uint32_t next = kid == 0 ? kid_node0 : kid_node1, ccode = kid == 0 ? kid_code0 : kid_code1;
+                const uint32_t next = kid == 0 ? kid_node0 : kid_node1, ccode = kid == 0 ? (kid_codes & 0xFFu) : (kid_codes >> 8);
                 const int32_t seed_off = c_seed_off;
                 const int32_t seed_pos = next_offset - seed_off;
                 const bool in_seed = seed_pos >= 0 && seed_pos < c_seed_len;
@@ -1026,7 +1032,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         const int32_t seed_off = c_seed_off, seed_len = c_seed_len;
         const uint32_t node0 = c_node0;
         const int32_t sroot = (cfg.left_end_bonus && !clipping) ? cfg.left_end_bonus : 0;
-        const int32_t root_pushes = LANE_CI(CD_ROOT_PUSHES), root_size = 1 + root_pushes;
+        const int32_t root_pushes = (int32_t)gld(arec() + 19), root_size = 1 + root_pushes;
         const int32_t root_ins = imax(sroot + go, NINF + ge);
         auto root_S = [&](int32_t pos) -> int32_t {
             return pos == 0 ? sroot : (pos >= 1 && pos <= root_pushes ? root_ins + (pos - 1) * ge : NINF);
@@ -1110,14 +1116,15 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
         int32_t align_offset = seed_off;
         int32_t j_stop = j;                                  // columns (j_stop, j_start] are on the path
         bool bad = false;
+        // (the run at hand grows in a register; it is stored when the next one begins and when the trace ends)
         auto push_op = [&](uint32_t op, uint32_t num) {
             if (n_runs == 0 || (cur_run & 7) != op) {
                 if (n_runs >= LANE_MAX_RUNS) { bad = true; return; }
+                if (n_runs) gst(lane_run_word(slots(), LP.max_cols, n_runs - 1), cur_run);
                 cur_run = (num << 3) | op;
-                chip.runs[n_runs++ * chip.rstride] = cur_run;
+                ++n_runs;
             } else {
                 cur_run += num << 3;
-                chip.runs[(n_runs - 1) * chip.rstride] = cur_run;
             }
         };
         auto slot_geom = [&](int32_t jj) -> uint32_t { return gld(lane_slot_word(slots(), jj, 10)); };
@@ -1179,6 +1186,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
             if (bad || n_seq > cap || n_path > cap) LANE_BAIL(20);
         }
         if (bad) LANE_BAIL(21);
+        if (n_runs) gst(lane_run_word(slots(), LP.max_cols, n_runs - 1), cur_run);
         if (!(n_trace >= min_trace_length && n_path)) LANE_BAIL(22);             // (the next start cell would be tried)
         {
             // the cell the trace ended in (the root's cells are known in closed form)
@@ -1237,14 +1245,14 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     if ((int32_t)(link >> 16) >= k - 1) { if (ni >= 0) gst(pa_node() + ni, node); --ni; }
                     jj = (int32_t)(link & 0xFFFFu);
                 }
-                for (int32_t xx = 0; xx < x_n_runs; ++xx) gst(runs_fwd() + xx, chip.runs[xx * chip.rstride]);
+                for (int32_t xx = 0; xx < x_n_runs; ++xx) gst(runs_fwd() + xx, gld(lane_run_word(slots(), LP.max_cols, xx)));
             }
             gst(arec() + 8, (uint32_t)LANE_HAVE_ALN()); gst(arec() + 9, (uint32_t)x_score); gst(arec() + 10, (uint32_t)x_clip);
             gst(arec() + 11, (uint32_t)x_end_clip);
             c_fwd_n_nodes = x_n_nodes; c_fwd_n_seq = x_n_seq;
             LANE_SET_MODE(LANE_EMIT_ARRAYS);
             // seedref_from_aln of the reversal: clipping = the alignment's end clipping, the whole spelling is the seed
-            LANE_CI(CD_CLIP) = x_end_clip;
+            gst(arec() + 18, (uint32_t)x_end_clip);
             c_seed_len = x_n_seq; c_seed_off = 0; c_node0 = gld(pa_node() + (x_n_nodes - 1));
             if (!load_strand(1 - LANE_STRAND())) LANE_BAIL(5);
             LANE_CU(CD_S8_FILTER) = 0;                  // (the backward pass: the replay columns' rows only)
@@ -1293,8 +1301,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
     }
     // the lane's counters (kept in its scratch, summed when the kernel ends): columns, block lines
     gst(arec() + 26, gld(arec() + 26) + (n > 0 ? (uint32_t)cols_done : 0u));
-    gst(arec() + 27, gld(arec() + 27) + LANE_CU(CD_CTR_RANK));
-    gst(arec() + 28, gld(arec() + 28) + LANE_CU(CD_CTR_SEL));
+    gst(arec() + 27, gld(arec() + 27) + (LANE_CU(CD_CTR) & 0xFFFFu));
+    gst(arec() + 28, gld(arec() + 28) + (LANE_CU(CD_CTR) >> 16));
     {
         const int32_t have_aln = n > 0 ? LANE_HAVE_ALN() : 0;
         const int32_t a_n_nodes = have_aln ? (int32_t)gld(arec() + 6) : 0;
@@ -1333,9 +1341,8 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
 #undef d_score
 #undef d_max
 #undef kid_node0
-#undef kid_code0
+#undef kid_codes
 #undef kid_node1
-#undef kid_code1
 #undef kid_rank0
 #undef kid_rank1
 #undef table_cap
@@ -1366,7 +1373,7 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
             int32_t nc = 0;
             if (R.clip) gst(dst + R.n_nodes + nc++, ((uint32_t)R.clip << 3) | OP_CLIPPED);
             if (R.mode == LANE_EMIT_SLOTS) {
-                for (int32_t x = R.n_runs - 1; x >= 0; --x) gst(dst + R.n_nodes + nc++, chip.runs[x * chip.rstride]);
+                for (int32_t x = R.n_runs - 1; x >= 0; --x) gst(dst + R.n_nodes + nc++, gld(lane_run_word(slots, LP.max_cols, x)));
                 // the path, last column first, down the parent links: characters of all its columns, nodes of those whose offset
                 // reaches k - 1 (minus the leading ones trim_offset dropped)
                 int32_t j = R.j_hi, ni = R.n_nodes - 1;
@@ -1386,7 +1393,7 @@ MGX_DEV void lane_emit(const LaneParams &LP, const uint64_t read, const uint8_t 
             } else {
                 // the backward alignment reversed (Alignment::reverse_complement): its runs in the order the trace recorded them,
                 // its columns in the order the parent links give them, characters complemented
-                for (int32_t x = 0; x < R.n_runs; ++x) gst(dst + R.n_nodes + nc++, chip.runs[x * chip.rstride]);
+                for (int32_t x = 0; x < R.n_runs; ++x) gst(dst + R.n_nodes + nc++, gld(lane_run_word(slots, LP.max_cols, x)));
                 int32_t j = R.j_hi, ni = 0;
                 for (int32_t x = 0; x < R.n_seq; ++x) {
                     const uint32_t node = gld(lane_slot_word(slots, j, 8)), geom = gld(lane_slot_word(slots, j, 10)), link = gld(lane_slot_word(slots, j, 11));

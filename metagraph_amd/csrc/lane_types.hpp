@@ -10,7 +10,14 @@
 
 namespace mgx {
 
-constexpr int LANE_MAX_L = 256;            // longest read a lane takes (packed strand in LDS: LANE_QWORDS words per lane)
+// longest read a lane takes (packed strand in LDS: LANE_QWORDS words per lane).  The host lays the scratch out for 256; the kernel
+// is built twice (mgx_lane.hip): for reads of up to 256 characters, and — MGX_LANE_MAX_L=160 — for batches whose longest read has
+// at most 160, where the smaller packed strand is what lets a third wavefront per SIMD fit the LDS.
+#ifndef MGX_LANE_MAX_L
+#define MGX_LANE_MAX_L 256
+#endif
+constexpr int LANE_MAX_L = MGX_LANE_MAX_L;
+constexpr int LANE_MAX_L_HOST = 256;       // what the scratch layout is sized for, whichever build runs
 constexpr int LANE_QWORDS = LANE_MAX_L / 32 + 2;
 constexpr int LANE_MAX_RUNS = 16;          // CIGAR runs of a trace kept in LDS
 constexpr int LANE_MAX_SEEDS = 512;        // seeds of the strand (the later ones are checked against the extension one by one)
@@ -33,7 +40,8 @@ struct LaneParams {
     // where lane-private slices made it 64 partial-line writes 18 KB apart, and the trace's reads of a column's words find
     // the lanes' words in the same lines.  What is addressed by a lane's own data (the node table) or touched rarely (parked
     // windows, the forward alignment during a backward pass, counters) stays in a private slice per lane behind them:
-    //   wave w:  [ slots: max_cols x LANE_SLOT_WORDS x 64 words | S rows: max_cols x LANE_S8_WORDS x 64 words | 64 x rest_stride bytes ]
+    //   wave w:  [ slots: max_cols x LANE_SLOT_WORDS x 64 words | S rows: max_cols x LANE_S8_WORDS x 64 words
+    //              | CIGAR runs of the trace: LANE_MAX_RUNS x 64 words | 64 x rest_stride bytes ]
     uint8_t *scratch;
     uint64_t wave_stride;                // bytes per wavefront (lane_wave_scratch_bytes)
     uint64_t rest_stride;                // bytes of a lane's private slice (lane_rest_bytes, rounded to 64)
@@ -59,13 +67,14 @@ inline uint32_t lane_max_cols(uint32_t Lmax, int32_t xdrop) {
 // node | the columns that stayed behind in the frontier
 inline uint64_t lane_rest_bytes(uint32_t max_cols, uint32_t hash_slots) {
     return (uint64_t)hash_slots * 8 + 2 * 2 * 32 * 4
-           + (uint64_t)max_cols * 8 + LANE_MAX_RUNS * 4 + 32 * 4 + (uint64_t)(LANE_MAX_L + 8) * 4
+           + (uint64_t)max_cols * 8 + LANE_MAX_RUNS * 4 + 32 * 4 + (uint64_t)(LANE_MAX_L_HOST + 8) * 4
            + (uint64_t)LANE_MAX_DEFER * LANE_DSLOT_WORDS * 4;
 }
 inline uint64_t lane_slots_bytes(uint32_t max_cols) { return (uint64_t)max_cols * LANE_SLOT_WORDS * LANE_WAVE * 4; }
 inline uint64_t lane_s8_bytes(uint32_t max_cols) { return (uint64_t)max_cols * LANE_S8_WORDS * LANE_WAVE * 4; }
+inline uint64_t lane_runs_bytes() { return (uint64_t)LANE_MAX_RUNS * LANE_WAVE * 4; }
 inline uint64_t lane_wave_scratch_bytes(uint32_t max_cols, uint64_t rest_stride) {
-    return lane_slots_bytes(max_cols) + lane_s8_bytes(max_cols) + (uint64_t)LANE_WAVE * rest_stride;
+    return lane_slots_bytes(max_cols) + lane_s8_bytes(max_cols) + lane_runs_bytes() + (uint64_t)LANE_WAVE * rest_stride;
 }
 
 
@@ -81,7 +90,7 @@ inline bool lane_enabled(const mgx_config &c, const DevConfig &d, uint32_t k, ui
     if (d.num_alt != 1 || d.post_chain) return no("alternative paths");
     if (d.canonical != 0) return no("CANONICAL / PRIMARY graph");
     if (k > 32 || k < 2) return no("k > 32: reads are not 2-bit packed");
-    if (Lmax < 1 || Lmax > (uint32_t)LANE_MAX_L) return no("reads longer than a lane takes");
+    if (Lmax < 1 || Lmax > (uint32_t)LANE_MAX_L_HOST) return no("reads longer than a lane takes");
     if (no_fast || c.xdrop > 30000) return no("chain path off");
     const char acgt[4] = { 'A', 'C', 'G', 'T' };
     const int m = c.score_matrix[(int)'A'][(int)'A'];

@@ -477,6 +477,15 @@ extern "C" void mgx_annotation_device_view(const mgx_annotation *a, int *device,
 extern "C" uint64_t mgx_annotation_uid(const mgx_annotation *a);                                            // mgx_annot.hip
 extern "C" int mgx_annotation_has_coordinates(const mgx_annotation *a);                                     // mgx_annot.hip
 extern "C" int mgx_lane_waves_per_simd(void);
+// (measurement builds only, tools/build_lane_short_variant.sh: the kernel's -DMGX_LANE_SHORT build — reads of up to 160 characters,
+// three wavefronts per SIMD; profiles/r06_ab10_lane_three_waves.txt is why the product does not carry it)
+#ifdef MGX_WITH_LANE_SHORT
+extern "C" int mgx_launch_lane_short(const void *d_params, uint32_t blocks, void *stream);                   // mgx_lane.hip, -DMGX_LANE_SHORT
+extern "C" int mgx_lane_short_waves_per_simd(void);
+#else
+static int mgx_launch_lane_short(const void *, uint32_t, void *) { return (int)hipErrorNotSupported; }
+static int mgx_lane_short_waves_per_simd(void) { return 0; }
+#endif
 extern "C" unsigned mgx_ext64_static_lds(void);
 extern "C" int mgx_ext64_waves_per_simd(void);
 extern "C" int mgx_launch_align_grp8_prim(const void *params, uint32_t n_groups, uint32_t lds_bytes, int phase, void *stream);
@@ -579,6 +588,7 @@ struct mgx_aligner {
         int no_compact = 0, no_alias = 0, no_bt_runs = 0, no_flat = 0;
         int primary_alt_build = 0;
         int lane = -1;            // the lane-per-read kernel in front of the extension kernel: -1 auto, 0 off, 1 forced
+        int lane_short = 0;       // (measurement builds with MGX_WITH_LANE_SHORT) 1: batches whose longest read has <= 160 characters run the lane kernel's three-wavefront build
         int seed_lane = -1;       // the lane-per-read seeder in front of the seeding kernel (seed_lane.hpp): -1 auto, 0 off, 1 forced
         int seed_wps = 8;         // wavefronts per SIMD of the short-read seeding kernel: 8 (64 VGPRs, spills) or 4 (102 VGPRs, tables in LDS)
         int device_share = 1;     // handles expected to run on this device at the same time (worker threads, -p N): the per-slot
@@ -1119,7 +1129,9 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
     LaneParams LP;
     memset(&LP, 0, sizeof(LP));
     std::string lane_why;
-    const uint32_t lane_blocks = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)mgx_lane_waves_per_simd();
+    // (two builds of the kernel: reads of up to 160 characters at three wavefronts per SIMD, up to 256 at two)
+    const bool lane_short = A->opt.lane_short != 0 && l.Lmax <= 160 && mgx_lane_short_waves_per_simd() > 0;
+    const uint32_t lane_blocks = (uint32_t)prop.multiProcessorCount * 4u * (uint32_t)(lane_short ? mgx_lane_short_waves_per_simd() : mgx_lane_waves_per_simd());
     // (label-aware batches, round 6: the lane takes the reads whose seeds and columns all carry one and the same single label —
     // lane_read.hpp; it needs the annotation's "no dummy node's row holds a label" flag, as it reads rows without the W test)
     bool lane_ok = A->opt.lane != 0 && A->packed_valid && A->mode == MODE_SPLIT8 && !A->opt.two_pass && A->opt.multi_pass != 1
@@ -1469,7 +1481,7 @@ static int run_align(mgx_aligner *A, const char *d_seqs, const uint64_t *d_offse
             // (measurement only: MGX_LANE_BLOCKS_PCT < 100 launches that share of the resident wavefronts — is the kernel bound by
             // the latency of its own dependent accesses, or by what the memory system serves per second?)
             if (const char *pct = getenv("MGX_LANE_BLOCKS_PCT")) blocks = std::max<uint32_t>(1u, (uint32_t)((uint64_t)blocks * (uint64_t)atoi(pct) / 100));
-            if (int rc = mgx_launch_lane(A->lane_params.p, blocks, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane kernel: %d", rc);
+            if (int rc = lane_short ? mgx_launch_lane_short(A->lane_params.p, blocks, A->hstream) : mgx_launch_lane(A->lane_params.p, blocks, A->hstream)) return fail(MGX_ERR_NO_DEVICE, "lane kernel: %d", rc);
             A->kernels_ran |= MGX_KERNEL_LANE;
             ++g_kernel_launches[4];
             HIP_TRY(hipEventRecord(A->ev[6], A->hstream));
@@ -1679,6 +1691,7 @@ int mgx_aligner_set_pipeline(mgx_aligner *A, const char *name) {
         else if (key == "no_flat") o.no_flat = v;
         else if (key == "primary_alt_build") o.primary_alt_build = v;
         else if (key == "lane") o.lane = v;
+        else if (key == "lane_short") o.lane_short = v;
         else if (key == "device_share") o.device_share = std::max(1, std::min(v, 64));
         else if (key == "map_pipe") o.map_pipe = v;
         else if (key == "seed_wps") o.seed_wps = v;

@@ -6,12 +6,27 @@
 // the same number of columns), runs lane_read() on them — the column loop is where the lanes spend their time; a lane whose read
 // ends or bails early idles until its 63 wave-mates are through — hands out the output-stream words of the whole wavefront with
 // ONE atomic, and writes results.  Per-lane state: the DP window (32 S + 32 F cells) and the bookkeeping of one extension in
-// VGPRs; the packed query and the CIGAR runs of the trace in LDS (word-major, conflict free); column slots and S rows in the
-// wavefront's HBM scratch, interleaved over its lanes (the lanes commit their columns in lock-step: full-line stores); the node
-// table in a private slice per lane.
+// VGPRs; the packed query and the cold per-read state in LDS (word-major, conflict free); column slots, S rows and the CIGAR
+// runs of the trace in the wavefront's HBM scratch, interleaved over its lanes (the lanes commit their columns in lock-step:
+// full-line stores); the node table in a private slice per lane.
 #include <hip/hip_runtime.h>
 
+// Built twice: as is — reads of up to 256 characters, two wavefronts per SIMD — and with -DMGX_LANE_SHORT for batches whose
+// longest read has at most 160 characters (the benchmark's 150-bp reads): seven packed words per strand instead of ten, which
+// together with the CIGAR runs and six cold words that left the LDS in round 6 fits THREE wavefronts per SIMD into the LDS
+// (52 rows x 256 B = 13 312 B per wavefront); the register budget of three (168) is the compiler's to meet.
+#ifdef MGX_LANE_SHORT
+#define mgx mgx_lane_short_ns
+#define MGX_LANE_MAX_L 160
+#ifndef MGX_LANE_WAVES_PER_SIMD
+#define MGX_LANE_WAVES_PER_SIMD 3
+#endif
+#define k_lane k_lane_short
+#define mgx_launch_lane mgx_launch_lane_short
+#define mgx_lane_waves_per_simd mgx_lane_short_waves_per_simd
+#else
 #define mgx mgx_lane_ns
+#endif
 #include "wave.hpp"
 #include "graph_build.hpp"
 #include "lane_read.hpp"
@@ -27,7 +42,6 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
     // occupying — and spilling — scalar registers across the column loop)
     const LaneParams &LP = *LPp;
     __shared__ uint64_t s_qw[LANE_QWORDS][64];
-    __shared__ uint32_t s_runs[LANE_MAX_RUNS][64];
     __shared__ uint32_t s_cold[LANE_COLD_WORDS][64];
     const int lane = (int)threadIdx.x;
     // the wavefront's scratch from this lane's word on (layout: LaneParams — column slots and S rows interleaved over the lanes)
@@ -35,7 +49,6 @@ __global__ void __launch_bounds__(64, MGX_LANE_WAVES_PER_SIMD) k_lane(const Lane
     LaneChip chip;
     chip.lane = lane;
     chip.qw = &s_qw[0][lane]; chip.qstride = 64;
-    chip.runs = &s_runs[0][lane]; chip.rstride = 64;
     chip.cold = &s_cold[0][lane]; chip.cstride = 64;
     const uint64_t n_items = LP.P.n_items ? LP.P.n_items : LP.P.n_reads;
     LaneCounters ctr;

@@ -533,9 +533,8 @@ void *emu_align_anno(void *gh, void *anno, const mgx_config *config, const mgx_l
                 LP.scratch = scratch_v.data();
                 LP.tag_seed = 12345;
                 std::vector<uint64_t> qw(LANE_QWORDS);
-                std::vector<uint32_t> runs(LANE_MAX_RUNS);
                 std::vector<uint32_t> cold(LANE_COLD_WORDS);
-                LaneChip chip = { 0, qw.data(), 1, runs.data(), 1, cold.data(), 1 };
+                LaneChip chip = { 0, qw.data(), 1, cold.data(), 1 };
                 R->lane_reason.assign(n, 0);
                 for (uint64_t i = 0; i < n; ++i) {
                     LaneCounters lc = { 0 };
