@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MGX_ABI_VERSION 5      /* 5 (round 6): mgx_stats::n_seed_lane_reads / seed_lane_ms / seed_lane_left_reads, streams, coordinates,
+#define MGX_ABI_VERSION 6      /* 6 (round 6, late): mgx_gather_* (RCCL gather of the device results); 5 (round 6): mgx_stats::n_seed_lane_reads / seed_lane_ms / seed_lane_left_reads, streams, coordinates,
                                 * mgx_chain_seeds; 4 (round 5): mgx_stats::n_capacity_retried, mgx_chain_alignments, post_chain_alignments accepted;
                                 * 3 (round 4): mgx_alignment::n_labels / labels_begin, mgx_results::labels (label-aware alignment),
                                 * mgx_stats::extend_kernels / n_lane_reads / lane_ms, "key=value" options of mgx_aligner_set_pipeline;
@@ -337,6 +337,36 @@ int mgx_device_trim(int device);
 int mgx_aligner_set_stream(mgx_aligner *a, void *hip_stream);
 int mgx_aligner_create_stream(mgx_aligner *a);
 void *mgx_aligner_get_stream(const mgx_aligner *a);
+
+/*
+ * The gather of complete alignments over RCCL (north_star: "RCCL-over-xGMI used only to gather alignment results").
+ * Replaces, for one aligner per device, the reference's output loop (cli/align.cpp:469-473: every task prints its queries under a
+ * mutex): every rank's device results of a batch (mgx_device_results: n_queries records + the used words of its stream) travel to
+ * `root`, which decodes them with mgx_results_from_raw[_labeled] and prints.  Two phases: an all-gather of (n_queries, used words),
+ * then one group of send / receive pairs (xGMI is point-to-point).  librccl.so is opened at the first call (dlopen: libmgx does not
+ * link it); without it every mgx_gather_create* returns MGX_ERR_UNSUPPORTED.  No other call of this library communicates.
+ *   one process per device:  rank 0 calls mgx_gather_unique_id and hands the bytes to the other ranks (a file, MPI, a socket: the
+ *                            host's business), every rank calls mgx_gather_create_rank; or mgx_gather_create_comm over an ncclComm_t
+ *                            the host has already (not destroyed with the handle);
+ *   one process, D devices:  mgx_gather_create_local (ncclCommInitAll) fills out[0 .. D); worker thread r uses out[r] — the calls
+ *                            below are collective and block, so every device needs its own thread (host/mgx_align --rccl-gather).
+ */
+typedef struct mgx_gather mgx_gather;
+uint64_t mgx_gather_unique_id_bytes(void);
+int mgx_gather_unique_id(void *id_out, uint64_t id_bytes);
+int mgx_gather_create_rank(const void *unique_id, uint64_t id_bytes, int rank, int world, int root, int device, mgx_gather **out);
+int mgx_gather_create_comm(void *nccl_comm, int rank, int world, int root, int device, mgx_gather **out);
+int mgx_gather_create_local(const int *devices, int n_devices, int root, mgx_gather **out /* [n_devices] */);
+void mgx_gather_destroy(mgx_gather *g);
+int mgx_gather_world(const mgx_gather *g);
+int mgx_gather_rank(const mgx_gather *g);
+/* Collective: every rank, after mgx_align_batch_device on ITS aligner (same device as the handle).  Returns when this rank's
+ * transfers are enqueued on the handle's own stream; the aligner's device results must stay untouched until mgx_gather_finish. */
+int mgx_gather_start(mgx_gather *g, mgx_aligner *a);
+/* Waits for this rank's transfers.  On the root the caller's arrays of `world` entries receive, per rank r, the number of
+ * queries, host pointers to its records and stream (valid until the next mgx_gather_start / mgx_gather_destroy) and the
+ * stream's words — the arguments of mgx_results_from_raw.  On the other ranks the arrays are ignored (may be NULL). */
+int mgx_gather_finish(mgx_gather *g, uint64_t *n_queries, const void **headers, const uint32_t **streams, uint64_t *stream_words);
 
 /* Format one query's results exactly like format_alignment() (cli/align.cpp:254-285):
  * "header\tquery\t(+|-)\tpath\tscore\tnum_matches\tcigar\toffset\n", or the "*" line.

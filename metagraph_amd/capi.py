@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 MGX_OK = 0
-MGX_ABI_VERSION = 5
+MGX_ABI_VERSION = 6
 MGX_ERR_INVALID, MGX_ERR_NO_DEVICE, MGX_ERR_UNSUPPORTED, MGX_ERR_CONFIG, MGX_ERR_CAPACITY, MGX_ERR_OOM = -1, -2, -3, -4, -5, -6
 OP_CHARS = "SX=DIG"
 
@@ -246,6 +246,18 @@ def lib():
     L.mgx_chain_alignments.restype = C.c_int
     L.mgx_results_from_raw_labeled.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(Results)]
     L.mgx_raw_store_free.argtypes = [C.c_void_p]
+    # the RCCL gather of the device results (include/mgx.h, csrc/mgx_gather.hip)
+    L.mgx_gather_unique_id_bytes.restype = C.c_uint64
+    L.mgx_gather_unique_id.argtypes = [C.c_void_p, C.c_uint64]
+    L.mgx_gather_create_rank.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.mgx_gather_create_comm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.mgx_gather_create_local.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.mgx_gather_destroy.argtypes = [C.c_void_p]
+    L.mgx_gather_destroy.restype = None
+    L.mgx_gather_world.argtypes = [C.c_void_p]
+    L.mgx_gather_rank.argtypes = [C.c_void_p]
+    L.mgx_gather_start.argtypes = [C.c_void_p, C.c_void_p]
+    L.mgx_gather_finish.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.mgx_map_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.POINTER(Mapping)]
     L.mgx_aligner_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.mgx_config_init_default.argtypes = [C.POINTER(Config)]

@@ -227,9 +227,6 @@ class HipDBGAligner : public IDBGAligner {
         // One call: mgx_align_batch itself re-aligns queries whose per-read device arenas overflowed (MGX_ERR_CAPACITY: the
         // reference has no such limit, its tables grow on the heap) with doubled limits, up to six doublings.  A status that is
         // left after that is an error of this call, as nothing in the reference's interface could carry it.
-        std::vector<AlignmentResults> results;
-        results.reserve(seq_batch.size());
-        for (const auto &q : seq_batch) results.emplace_back(q.second);
         std::string blob;
         std::vector<uint64_t> offsets(seq_batch.size() + 1, 0);
         for (size_t t = 0; t < seq_batch.size(); ++t) {
@@ -239,10 +236,32 @@ class HipDBGAligner : public IDBGAligner {
         mgx_results res{};
         if (int rc = mgx_align_batch(a_, blob.data(), offsets.data(), seq_batch.size(), 0, &res))
             throw std::runtime_error(std::string("mgx_align_batch: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
+        deliver(res, seq_batch, callback);
+    }
+
+    // The two halves for a host that gathers the results of several devices over RCCL (mgx_gather_*, mgx_align --rccl-gather):
+    // the kernels of a batch with the results left in HBM — mgx_gather_start(g, handle()) takes them from there — and, on the
+    // root, the decoded records of any rank (mgx_results_from_raw) handed to the callback like align_batch does.
+    void align_batch_device(const std::vector<Query> &seq_batch) const {
+        std::string blob;
+        std::vector<uint64_t> offsets(seq_batch.size() + 1, 0);
+        for (size_t t = 0; t < seq_batch.size(); ++t) {
+            blob += seq_batch[t].second;
+            offsets[t + 1] = blob.size();
+        }
+        if (blob.empty()) blob.push_back('\0');                      // (an empty batch still needs a pointer)
+        if (int rc = mgx_align_batch_device(a_, blob.data(), offsets.data(), seq_batch.size(), 0))
+            throw std::runtime_error(std::string("mgx_align_batch_device: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
+    }
+    mgx_aligner *handle() const { return a_; }
+    static void deliver(const mgx_results &res, const std::vector<Query> &seq_batch, const AlignmentCallback &callback) {
+        std::vector<AlignmentResults> results;
+        results.reserve(seq_batch.size());
+        for (const auto &q : seq_batch) results.emplace_back(q.second);
         for (size_t t = 0; t < seq_batch.size(); ++t) {
             if (res.status[t] != MGX_OK)
                 throw std::runtime_error("query " + std::to_string(t) + " (" + seq_batch[t].first + "): status "
-                                         + std::to_string(res.status[t]) + " after the capacity retry of mgx_align_batch");
+                                         + std::to_string(res.status[t]) + " (after the capacity retry, where the call has one)");
             AlignmentResults &paths = results[t];
             for (uint64_t ai = res.aln_begin[t]; ai < res.aln_begin[t + 1]; ++ai) {
                 const mgx_alignment &m = res.alignments[ai];

@@ -5,6 +5,9 @@
 //             [-p THREADS] [--query-batch-size BASES] [--canonical | --primary (the dump is a CANONICAL- / PRIMARY-mode graph)]
 //             [--time]        wall time of the align loop on stderr
 //             [--devices D]   in-process multi-GPU: one graph replica per device, whole batches routed round-robin, no collective
+//             [--rccl-gather] with --devices D: one worker per device, batches in rounds of D; every round's device results are
+//                             gathered to device 0 over RCCL (mgx_gather_*: the C-ABI of north_star's "RCCL-over-xGMI only to
+//                             gather alignment results"), decoded there (mgx_results_from_raw) and printed by that worker alone
 //             [-a ANNOTATION]  label-aware alignment (metagraph align -a: LabeledAligner); every alignment is printed with its
 //                              labels' names (cli/align.cpp:274-281).  ANNOTATION: `.column.annodbg` files written by the
 //                              reference (-a may be repeated: their columns side by side, mgx_column_file_read), or a dump of
@@ -96,6 +99,7 @@ int main(int argc, char **argv) {
     mgx_limits lim;
     bool have_lim = false;
     int devices = 1;
+    bool rccl_gather = false;
     std::vector<const char *> anno_paths;
     std::vector<std::string> kernel_options;            // --kernel-option key=value: result-preserving kernel selection (A/B runs)
     mgx_limits_init_default(&lim, 0);
@@ -109,6 +113,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, atoi(argv[++i]));
         else if (!strcmp(argv[i], "-a") && i + 1 < argc) anno_paths.push_back(argv[++i]);
         else if (!strcmp(argv[i], "--kernel-option") && i + 1 < argc) kernel_options.push_back(argv[++i]);
+        else if (!strcmp(argv[i], "--rccl-gather")) rccl_gather = true;
         else if (!strcmp(argv[i], "--time")) report_time = true;            // wall time of the align loop (batches -> results printed) on stderr
         else if (!strcmp(argv[i], "--canonical")) graph_mode = MGX_MODE_CANONICAL;
         else if (!strcmp(argv[i], "--primary")) graph_mode = MGX_MODE_PRIMARY;         // aligned through the CanonicalDBG wrapper
@@ -198,11 +203,83 @@ int main(int argc, char **argv) {
                 if (first_error.empty()) first_error = e.what();
             }
         };
+        // --rccl-gather: worker w = rank w = device w; round r takes batches r D .. r D + D - 1 (a rank without one aligns an empty
+        // batch: the gather is collective); rank 0 receives every rank's records and stream and prints the round
+        std::vector<mgx_gather *> gathers((size_t)devices, nullptr);
+        auto gather_worker = [&](unsigned w) {
+            const size_t D = (size_t)devices, rounds = (batches.size() + D - 1) / D;
+            const HipBOSSGraph &graph = graphs.for_worker(w);
+            static const std::vector<IDBGAligner::Query> no_queries;
+            for (size_t r = 0; r < rounds; ++r) {
+                const size_t bi = r * D + w;
+                const std::vector<IDBGAligner::Query> &mine = bi < batches.size() ? batches[bi] : no_queries;
+                std::unique_ptr<HipDBGAligner> aligner_p;
+                bool ok = true;
+                try {
+                    aligner_p.reset(annotation ? new HipDBGAligner(graph, cfg, *annotation, have_lim ? &lim : nullptr)
+                                               : new HipDBGAligner(graph, cfg, have_lim ? &lim : nullptr));
+                    for (const std::string &opt : kernel_options) aligner_p->set_kernel_option(opt);
+                    aligner_p->align_batch_device(mine);
+                } catch (const std::exception &e) {
+                    std::lock_guard<std::mutex> lock(err_mutex);
+                    if (first_error.empty()) first_error = e.what();
+                    ok = false;
+                }
+                if (!ok) {                            // (stay in the collective: the other ranks are waiting in it)
+                    try { aligner_p.reset(new HipDBGAligner(graph, cfg, have_lim ? &lim : nullptr)); aligner_p->align_batch_device(no_queries); }
+                    catch (const std::exception &) { fprintf(stderr, "error: rank %u cannot take part in the gather\n", w); std::abort(); }
+                }
+                std::vector<uint64_t> nq(D), words(D);
+                std::vector<const void *> hdrs(D);
+                std::vector<const uint32_t *> streams(D);
+                if (mgx_gather_start(gathers[w], aligner_p->handle()) != MGX_OK
+                    || mgx_gather_finish(gathers[w], nq.data(), hdrs.data(), streams.data(), words.data()) != MGX_OK) {
+                    fprintf(stderr, "error: rank %u: %s\n", w, mgx_last_error());
+                    std::abort();                    // (a broken collective cannot be left politely)
+                }
+                if (w != 0) continue;
+                for (size_t q = 0; q < D; ++q) {
+                    const size_t bq = r * D + q;
+                    if (bq >= batches.size()) continue;
+                    try {
+                        if (nq[q] != batches[bq].size()) throw std::runtime_error("rank " + std::to_string(q) + " sent " + std::to_string(nq[q]) + " records for a batch of " + std::to_string(batches[bq].size()));
+                        mgx_raw_store *store = nullptr;
+                        mgx_results res{};
+                        if (int rc = mgx_results_from_raw_labeled(hdrs[q], nq[q], streams[q], words[q], annotation ? 1 : 0, &store, &res))
+                            throw std::runtime_error(std::string("mgx_results_from_raw: ") + mgx_last_error() + " (" + std::to_string(rc) + ")");
+                        try {
+                            HipDBGAligner::deliver(res, batches[bq], [&](const std::string &header, AlignmentResults &&paths) {
+                                std::cout << format_alignment(header, paths, cfg.min_path_score, annotation ? &label_names : nullptr);
+                            });
+                        } catch (...) { mgx_raw_store_free(store); throw; }
+                        mgx_raw_store_free(store);
+                    } catch (const std::exception &e) {
+                        std::lock_guard<std::mutex> lock(err_mutex);
+                        if (first_error.empty()) first_error = e.what();
+                    }
+                }
+            }
+        };
+        if (rccl_gather) {
+            std::vector<int> devs((size_t)devices);
+            for (int d = 0; d < devices; ++d) devs[(size_t)d] = d;
+            if (int rc = mgx_gather_create_local(devs.data(), devices, 0, gathers.data())) {
+                fprintf(stderr, "error: %s (%d)\n", mgx_last_error(), rc);
+                return 1;
+            }
+            threads = (unsigned)devices;
+        }
         const auto t_align0 = std::chrono::steady_clock::now();
         std::vector<std::thread> pool;
-        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker, t);
-        worker(0);
+        if (rccl_gather) {
+            for (unsigned t = 1; t < threads; ++t) pool.emplace_back(gather_worker, t);
+            gather_worker(0);
+        } else {
+            for (unsigned t = 1; t < threads; ++t) pool.emplace_back(worker, t);
+            worker(0);
+        }
         for (auto &t : pool) t.join();
+        for (mgx_gather *g : gathers) mgx_gather_destroy(g);
         if (report_time) {
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_align0).count();
             fprintf(stderr, "mgx_align: %zu queries in %zu batches, %u worker(s), %.3f s in the align loop (%.0f queries/s)\n",

@@ -21,7 +21,7 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 20
     for n in names:
         assert hasattr(L, n), "libmgx.so does not export %s" % n
-    assert L.mgx_abi_version() == capi.MGX_ABI_VERSION == 5
+    assert L.mgx_abi_version() == capi.MGX_ABI_VERSION == 6
 
 
 def test_struct_layouts_match_header():

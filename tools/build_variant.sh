@@ -16,5 +16,5 @@ if [ -n "$VARIANT_ALL_UNITS" ]; then      # the flags also go to the seeding uni
     /opt/rocm/bin/hipcc $FLAGS "$@" -c -o $B/mgx_$tag.o metagraph_amd/csrc/mgx.hip
     MGX_O=$B/mgx_$tag.o
 fi
-/opt/rocm/bin/hipcc $FLAGS -shared -o $B/libmgx_$tag.so $MGX_O $B/mgx_primary.o $B/mgx_annot.o $B/mgx_files.o $B/mgx_chain.o $B/mgx_seedlane.o $B/mgx_ext64.o $B/mgx_lane.o $B/mgx_lab64.o $B/mgx_grp8_lab.o $B/mgx_grp8_$tag.o $B/mgx_grp8_prim.o $B/mgx_grp8_alt.o
+/opt/rocm/bin/hipcc $FLAGS -shared -o $B/libmgx_$tag.so $MGX_O $B/mgx_primary.o $B/mgx_annot.o $B/mgx_files.o $B/mgx_chain.o $B/mgx_gather.o $B/mgx_seedlane.o $B/mgx_ext64.o $B/mgx_lane.o $B/mgx_lab64.o $B/mgx_grp8_lab.o $B/mgx_grp8_$tag.o $B/mgx_grp8_prim.o $B/mgx_grp8_alt.o
 echo built $B/libmgx_$tag.so
