@@ -66,6 +66,8 @@ def test_mgx_align_rccl_gather_prints_the_same_lines(tmp_path):
     for extra in (["--devices", "1", "--rccl-gather"], ["--devices", "1", "--rccl-gather", "--query-batch-size", "300"]):
         r = subprocess.run(base + extra, capture_output=True, text=True, timeout=180)
         assert r.returncode == 0, r.stderr
-        assert r.stdout == ref.stdout              # (one rank, rounds in input order)
+        # (RCCL announces its version on stdout when a communicator is made: result lines are the ones with tabs)
+        got = [ln for ln in r.stdout.split("\n") if "\t" in ln]
+        assert got == [ln for ln in ref.stdout.split("\n") if "\t" in ln]          # one rank, rounds in input order
     r = subprocess.run(base + ["--devices", "2", "--rccl-gather"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "device" in r.stderr
