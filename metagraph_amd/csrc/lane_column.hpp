@@ -82,14 +82,23 @@ MGX_HD int32_t lane_add_sat(int32_t a, int32_t b) {
 #endif
 }
 
-// band within the x-drop cut-off (:549-560): [begin, prev_end) in window positions; empty when prev_end <= begin
+// band within the x-drop cut-off (:549-560): [begin, prev_end) in window positions; empty when prev_end <= begin.
+// (Round 6: the cells at or above the cut-off are collected as one bit each, shifted in from the top cell down, and the two ends
+// are the lowest and highest bit inside the column's range — three instructions per cell where the per-cell range test with its
+// two selects and a min / max took ten; the or-of-selected-bits form of the same idea costs the allocator three spilled registers
+// in the lane kernel: profiles/r06_ab12_lane_same_box.txt, r06_ab14_lane_band2.txt.)
 MGX_HD void lane_band(const LaneColumnIn &in, const int32_t *S, int32_t &begin, int32_t &prev_end) {
-    begin = INT32_MAX; prev_end = INT32_MIN;
+    static_assert(LFW <= 32, "one bit per window cell");
+    uint32_t m = 0;
 #pragma unroll
-    for (int x = 0; x < LFW; ++x) {
-        const int32_t a = in.p_org + x, j = a - in.p_trim;
-        if (j >= 0 && j < in.p_size && S[x] >= in.xdrop_cutoff) { begin = imin(begin, a); prev_end = imax(prev_end, a + 1); }
-    }
+    for (int x = LFW - 1; x >= 0; --x) m = (m << 1) | (S[x] >= in.xdrop_cutoff ? 1u : 0u);
+    // the column's cells: j = x + p_org - p_trim in [0, p_size)
+    const int32_t d = in.p_trim - in.p_org;
+    const int32_t lo = imax(d, 0), hi = imin(d + in.p_size, LFW);
+    const uint32_t range = hi > lo ? ((hi - lo >= 32 ? ~0u : (1u << (hi - lo)) - 1u) << lo) : 0u;
+    m &= range;
+    begin = INT32_MAX; prev_end = INT32_MIN;
+    if (m) { begin = in.p_org + ctz64((uint64_t)m); prev_end = in.p_org + (64 - clz64((uint64_t)m)); }
 }
 
 // S, F: in = the parent's window (cell x is window position in.p_org + x), out = the child's (cell x is position out.org + x).
