@@ -793,6 +793,27 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         }
                         if (keep_row) {
                             uint32_t sw[8];
+                            // Every real cell of a column lies at or above the cut-off its pass ran with (update_column keeps
+                            // S > cutoff - 1, the scalar tail and the insertion run test >= cutoff), the cut-off is the best score
+                            // so far minus xdrop, and a column's maximum exceeds its parent's — hence the best score so far — by at
+                            // most one match: d >= -(m + xdrop).  Where that is within a byte (the CLI's scores: 2 + 27) no cell
+                            // can be too wide, ninf is what clamps to -128, and a cell costs a max and a subtraction; else cell by cell.
+                            if (xdrop >= 0 && m + xdrop <= 127) {
+                                const int32_t floor_d = base - 128;
+#pragma unroll
+                                for (int b = 0; b < LFW / 4; ++b) {
+                                    uint32_t v = 0;
+#pragma unroll
+                                    for (int q4 = 0; q4 < 4; ++q4) {
+                                        const int32_t sv = S[4 * b + q4];
+#if !defined(__HIPCC__)                 /* the host model checks the argument above on every cell it packs */
+                                        if (sv != NINF && (int64_t)sv - (int64_t)base < -127) { fprintf(stderr, "lane_read: an S row's cell below its byte\n"); abort(); }
+#endif
+                                        v |= ((uint32_t)(imax(sv, floor_d) - base) & 0xFFu) << (8 * q4);
+                                    }
+                                    sw[b] = v;
+                                }
+                            } else {
                             bool wide = false;
 #pragma unroll
                             for (int b = 0; b < LFW / 4; ++b) {
@@ -807,6 +828,7 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 sw[b] = v;
                             }
                             if (wide) LANE_BAIL(17);
+                            }
                             uint32_t *sr = lane_s8_word(slots(), LP.max_cols, my_idx, 0);
 #pragma unroll
                             for (int b = 0; b < 8; ++b) gst(sr + b * LANE_WAVE, sw[b]);
