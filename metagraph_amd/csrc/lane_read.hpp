@@ -66,6 +66,10 @@ static_assert(LANE_MAX_DEFER == 3, "CD_D_* above");
 // pass must not see anything the order of equal-score columns could change
 #define LANE_TIE_MODE() ((LANE_CI(CD_HMS) >> 5) & 1)
 #define LANE_SET_TIE_MODE(v) (LANE_CI(CD_HMS) = (LANE_CI(CD_HMS) & ~32) | ((v) ? 32 : 0))
+// bit 6 = the replayed node's vector is kept exactly from here on (backward pass; a word of the lane's record in HBM until round 6:
+// a store and a dependent load per replay column in the column loop's chain)
+#define LANE_REPLAY_EXACT() ((LANE_CI(CD_HMS) >> 6) & 1)
+#define LANE_SET_REPLAY_EXACT(v) (LANE_CI(CD_HMS) = (LANE_CI(CD_HMS) & ~64) | ((v) ? 64 : 0))
 // bits 8 .. 31 = the read's label (label-aware alignment: the one label its seeds and every column of its extensions carry)
 #define LANE_LABEL() ((uint32_t)LANE_CI(CD_HMS) >> 8)
 #define LANE_HAVE_ALN() (LANE_CI(CD_HMS) & 1)
@@ -645,18 +649,19 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                     head_dead = hd_prev_end <= hd_begin;
                     if (!head_dead) {
                         const int32_t no = f_offset + 1, sp = no - c_seed_off;
-                        if (sp >= 0 && sp < c_seed_len && (no < k || pass)) {
-                            if (!pass) {
-                                kid_node0 = c_node0; kid_rank0 = 0; kid_codes = (kid_codes & ~0xFFu) | (qcode(clipping + sp) + 1);   // the seed's first node, its spelling
-                            } else {
-                                // force_fixed_seed (:344-372): the reversed forward alignment, node by node — its spelling is
-                                // the complement of the path's, read backwards (A <-> T, C <-> G: code 5 - c)
-                                const int32_t fn = c_fwd_n_nodes, fq = c_fwd_n_seq;
-                                kid_codes = (kid_codes & ~0xFFu) | ((5u - gld(pa_code() + (fq - 1 - sp))) & 0xFFu);
-                                kid_node0 = gld(pa_node() + (fn - 1 - imax(0, no - k + 1))); kid_rank0 = 0;
-                            }
-                            n_kids = 1;
-                        } else {
+                        const bool use_seed = sp >= 0 && sp < c_seed_len && (no < k || pass);
+                        // (the replayed column's character and node are REQUESTED here and taken below, behind the enumeration of
+                        // the wave-mates' heads: the branches of a wavefront run one after the other, and a load that is consumed
+                        // inside its branch keeps the others waiting for its round trip)
+                        uint32_t rp_code = 0, rp_node = 0;
+                        if (use_seed && pass) {
+                            // force_fixed_seed (:344-372): the reversed forward alignment, node by node — its spelling is
+                            // the complement of the path's, read backwards (A <-> T, C <-> G: code 5 - c)
+                            const int32_t fn = c_fwd_n_nodes, fq = c_fwd_n_seq;
+                            rp_code = gld(pa_code() + (fq - 1 - sp));
+                            rp_node = gld(pa_node() + (fn - 1 - imax(0, no - k + 1)));
+                        }
+                        if (!use_seed) {
                             uint32_t kn0 = 0, kc0 = 0, kn1 = 0, kc1 = 0, kr0 = 0, kr1 = 0;
                             // (the head is a child of the previous enumeration, or that one's rank says nothing about it)
                             const uint32_t hr = f_node == kid_node0 ? kid_rank0 : (f_node == kid_node1 ? kid_rank1 : 0u);
@@ -686,6 +691,14 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                                 head_dead = true;
                             }
                             n_kids = nc_l;
+                        } else {
+                            if (!pass) {
+                                kid_node0 = c_node0; kid_rank0 = 0; kid_codes = (kid_codes & ~0xFFu) | (qcode(clipping + sp) + 1);   // the seed's first node, its spelling
+                            } else {
+                                kid_codes = (kid_codes & ~0xFFu) | ((5u - rp_code) & 0xFFu);
+                                kid_node0 = rp_node; kid_rank0 = 0;
+                            }
+                            n_kids = 1;
                         }
                         kid = 0;
                         fa_alive = 0;
@@ -848,13 +861,13 @@ MGX_DEV int lane_read(const LaneParams &LP, uint64_t read, const uint32_t item, 
                         if (!(top >= begin && top < begin + size)) top = -1;
                         const int32_t ap = clipping + seed_pos + 1;                     // the query character under the diagonal cell
                         const bool same = ap >= 1 && ap <= L && qcode(ap - 1) + 1 == ccode;
-                        if (probe) { LANE_SET_REPLAY_MATCHING(1); gst(arec() + 12, 0u); }
+                        if (probe) { LANE_SET_REPLAY_MATCHING(1); LANE_SET_REPLAY_EXACT(0); }
                         if (!same) LANE_SET_REPLAY_MATCHING(0);
-                        const bool exact_on = gld(arec() + 12) != 0;
+                        const bool exact_on = LANE_REPLAY_EXACT() != 0;
                         if (exact_on || (!probe && !LANE_REPLAY_MATCHING() && !(top > replay_top))) {
                             int32_t *cv = (int32_t *)(arec() + 32);
                             int32_t c0 = my_idx;
-                            if (!exact_on) { c0 = 1; gst(arec() + 12, 1u); gst(arec() + 14, 0u); }       // (no vector yet:) the columns so far, then this one
+                            if (!exact_on) { c0 = 1; LANE_SET_REPLAY_EXACT(1); gst(arec() + 14, 0u); }       // (no vector yet:) the columns so far, then this one
                             for (int32_t c = c0; c <= my_idx; ++c)
                                 converged = lane_merge_column(slots(), LP.max_cols, cv, arec() + 13, c, start, cfg.rel_score_cutoff);
                         }
