@@ -58,6 +58,9 @@ def main():
                     "annotation of this many labels, label j = the j-th segment of the genome (+ 15 positions into its neighbours)")
     ap.add_argument("--options", default="", help="kernel-selection options for A/B runs, '+'-separated (mgx_aligner_set_pipeline, "
                     "e.g. lane=0: without the lane-per-read kernel); results never depend on them")
+    ap.add_argument("--handles", type=int, default=int(os.environ.get("MGX_BENCH_HANDLES", 1)), help="(measurement) a further leg with this many "
+                    "aligner handles on streams of their own, one host thread each, the --steps batches dealt round robin — what "
+                    "`metagraph align -p N` does on one device (cli/align.cpp:440-475): the kernels of neighbouring batches overlap")
     args = ap.parse_args()
     if args.host_steps < 0:
         args.host_steps = args.steps
@@ -213,6 +216,48 @@ def main():
     ms_per_step = 1000.0 * elapsed / max(1, args.steps)
     total_reads = args.reads * world
     value = total_reads / (elapsed / max(1, args.steps))
+
+    # ---------------- (measurement) several handles at work on the device at once ----------------
+    handles_ms = None
+    if args.handles > 1 and not dist:
+        import ctypes as C
+        import threading
+        L = capi.lib()
+        L.mgx_aligner_create_stream.argtypes = [C.c_void_p]
+        As = [aligner.Aligner(G, cfg, lim, annotation=AN) for _ in range(args.handles)]
+        for a in As:
+            for opt in [o for o in args.options.split("+") if o]:
+                a.set_pipeline(opt)
+            assert L.mgx_aligner_create_stream(a.h) == 0
+        share = [args.steps // args.handles + (1 if h < args.steps % args.handles else 0) for h in range(args.handles)]
+
+        failed = []
+
+        def work(a, n):
+            try:
+                for _ in range(n):
+                    a.align_device(reads.data_ptr(), offsets.data_ptr(), args.reads)
+            except Exception as e:                     # (a thread's exception would otherwise end the thread and nothing else)
+                failed.append(e)
+
+        def run(counts):
+            ts = [threading.Thread(target=work, args=(a, n)) for a, n in zip(As, counts)]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            torch.cuda.synchronize()
+            if failed:
+                raise failed[0]
+
+        run([1] * args.handles)
+        th = time.time()
+        run(share)
+        handles_ms = 1000.0 * (time.time() - th) / args.steps
+        log("handles=%d: %.1f ms per step (one handle: %.1f)" % (args.handles, handles_ms, ms_per_step))
+        for a in As:
+            a.close()
+        del As
 
     # ---------------- read H2D and result D2H inside the timed region, overlapped with the kernels ----------------
     # Two device read buffers and two pinned result buffers; copies run on a side stream (libmgx's kernels run on the default
@@ -510,6 +555,9 @@ def main():
                        + ("; label-aware (LabeledAligner) with a %d-label annotation, one label per genome segment" % args.labels if args.labels else "")),
                       "reads_per_gpu": args.reads, "graph_edges": n_edges, "k": args.k, "graph_mode": args.graph_mode, "parallelism": "reads sharded x%d, graph replicated" % world},
            "roofline": roofline, "cpu_baseline": cpu, "parity": parity}
+    if handles_ms is not None:
+        out["handles_leg"] = {"handles": args.handles, "ms_per_step": round(handles_ms, 3), "value": round(args.reads / (handles_ms * 1e-3), 1),
+                              "note": "device-resident reads, --steps batches dealt to the handles' host threads; measurement only"}
     # the whole step against the same peak (north_star's 40 % is a statement about the path, not about one kernel): the
     # algorithmic bytes of every kernel of a step over the step's wall time (the figure `value` is computed from)
     step_ms = out["ms_per_step"]
