@@ -220,10 +220,10 @@ def main():
     # ---------------- (measurement) several handles at work on the device at once ----------------
     handles_ms = None
     if args.handles > 1 and not dist:
-        import ctypes as C
+        import ctypes as _ct
         import threading
         L = capi.lib()
-        L.mgx_aligner_create_stream.argtypes = [C.c_void_p]
+        L.mgx_aligner_create_stream.argtypes = [_ct.c_void_p]
         As = [aligner.Aligner(G, cfg, lim, annotation=AN) for _ in range(args.handles)]
         for a in As:
             for opt in [o for o in args.options.split("+") if o]:
