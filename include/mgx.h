@@ -96,7 +96,12 @@ typedef struct mgx_config {
     int8_t left_end_bonus;             /* :45 */
     int8_t right_end_bonus;            /* :46 */
     uint8_t forward_and_reverse_complement; /* :48 */
-    uint8_t chain_alignments;          /* :49 (must be 0: seed chaining, aligner_chainer.cpp:47-339, is not built) */
+    uint8_t chain_alignments;          /* :49 (must be 0.  The reference never lets a caller set it either: it exits without coordinates,
+                                        * dbg_aligner.cpp:546-550, and LabeledAligner switches it on itself for an annotation with
+                                        * coordinates, aligner_labeled.cpp:457-462 — such annotations are refused at
+                                        * mgx_labeled_aligner_create.  Of seed chaining, aligner_chainer.cpp:47-542, the device has the
+                                        * chainer's DP, mgx_chain_seeds, and k-mer coordinates, mgx_annotation_set_coordinates; the
+                                        * extension between chained seeds is not built: DESIGN 3.9) */
     uint8_t post_chain_alignments;     /* :50: chain_alignments (aligner_chainer.cpp:555-720) over every query's alignments.  The
                                         * device then keeps EVERY alignment of a query (aligner_aggregator.hpp:88-96; at most
                                         * 4 x MGX_MAX_ALTERNATIVE_PATHS - 3 x num_alternative_paths = 13 with the default of
