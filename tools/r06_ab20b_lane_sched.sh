@@ -1,0 +1,7 @@
+# round 6 A/B 20, second call (one box): iterative-ilp again (`_iilp`), and without the scheduling fences between the blocks of the column pass (`_iilpnf`)
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+run() { MGX_LIB_PATH=metagraph_amd/_build/libmgx$1.so timeout 600 python bench.py --reads 4000000 --steps 3 --no-cpu-baseline --host-steps 0 --cpu-sample 20000 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); km=d['roofline']['kernel_ms']; print('$1', d['ms_per_step'], {k: km[k] for k in ('k_lane','k_extend','reads_finished_by_k_lane') if k in km}, d.get('parity'))"; }
+{ for r in 1 2 3; do for t in _head _iilp _iilpnf; do run $t; done; done; } > gpurun_out/r06_ab20b_lane_sched.txt 2>&1
+cat gpurun_out/r06_ab20b_lane_sched.txt
