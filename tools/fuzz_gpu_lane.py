@@ -2,7 +2,9 @@
 """Differential fuzzing of the lane-per-read kernels ON THE GPU (libmgx.so as built: k_seed_lane, k_lane — the unit compiled with
 the iterative-ilp scheduling strategy — in front of the group kernel) against the oracle: random worlds of the parity suite's and of
 the benchmark's shape, random scoring / seeding configurations, every read of every world.
-    python tools/fuzz_gpu_lane.py MINUTES [FIRST_SEED]
+    python tools/fuzz_gpu_lane.py MINUTES [FIRST_SEED] [--labels]
+--labels: label-aware alignment (LabeledAligner) on segment-labelled worlds (tests/test_lane_labels.py::segment_world), alignments and
+label lists against the oracle's LabeledAligner.
 Needs a GPU (run through gpurun).  Test infrastructure: the oracle is the checker."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,12 +15,41 @@ from test_emu_vs_oracle import make_world, mutate
 from test_gpu_parity import gpu_graph
 from test_lane_read import bench_like_world
 
-minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 9000
+labels = "--labels" in sys.argv
+argv = [a for a in sys.argv if a != "--labels"]
+minutes = float(argv[1]) if len(argv) > 1 else 5.0
+seed = first = int(argv[2]) if len(argv) > 2 else 9000
+if labels:
+    from labeled_worlds import with_labels
+    from test_lane_labels import segment_world
+    from test_gpu_labels import gpu_annotation
 t0 = time.time()
 worlds = reads_total = lane_total = seeded_total = 0
 while time.time() - t0 < 60 * minutes:
     rng = random.Random(seed)
+    if labels:
+        k = rng.choice([11, 15, 21, 27, 31])
+        g, anno, reads = segment_world(seed, k=k, genome_len=rng.choice([3000, 8000, 20000]), n_labels=rng.choice([1, 3, 8, 20]), n_reads=1200,
+                                       read_len=rng.choice([60, 100, 150]), snp_every=rng.choice([0, 90, 200]) or 10**9, label_alt=bool(seed % 2))
+        cfg = capi.config_cli(k)
+        if seed % 5 == 0: cfg.min_seed_length = max(5, k - 6)
+        if seed % 7 == 0: cfg.min_exact_match = 0.9
+        if seed % 11 == 0: cfg.xdrop = 10
+        o = orc.LabeledAlignRun(g, cfg, anno, reads)
+        assert o.error == "", o.error
+        want = with_labels(o)
+        A = aligner.Aligner(gpu_graph(g), cfg, annotation=gpu_annotation(anno))
+        for opt in ("lane=1", "seed_lane=1", "ext64=0"):
+            A.set_pipeline(opt)
+        got, status = A.align_batch(reads)
+        assert all(s == 0 for s in status), (seed, [s for s in status if s][:5])
+        for q in range(len(reads)):
+            assert got[q] == want[q], ("MISMATCH", seed, q, reads[q], got[q], want[q])
+        st = A.stats()
+        worlds += 1; reads_total += len(reads); lane_total += st["n_lane_reads"]
+        A.close()
+        seed += 1
+        continue
     if seed % 3 == 0:
         k = 31
         g, reads = bench_like_world(seed, 6000, genome_len=rng.choice([60000, 150000]), read_len=rng.choice([100, 150, 150, 250]),
@@ -49,4 +80,4 @@ while time.time() - t0 < 60 * minutes:
     worlds += 1; reads_total += len(reads); lane_total += st["n_lane_reads"]
     A.close()
     seed += 1
-print("ok: %d worlds (seeds from %s), %d reads, %d finished by k_lane, no difference" % (worlds, sys.argv[2] if len(sys.argv) > 2 else 9000, reads_total, lane_total))
+print("ok%s: %d worlds (seeds from %d), %d reads, %d finished by k_lane, no difference" % (" (label-aware)" if labels else "", worlds, first, reads_total, lane_total))
