@@ -23,3 +23,17 @@ def test_deferred_chain_record_stays_inside_the_cell_arena():
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "no difference" in r.stdout
+
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--labels"]], ids=["plain", "labels"])
+def test_gpu_fuzzer_runs_clean_for_twenty_seconds(extra):
+    """tools/fuzz_gpu_lane.py: the built library's lane kernels (forced) on random worlds against the oracle — a short seeded run, so
+    that the tool stays runnable and every GPU suite run sees worlds no other test holds"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu_lane.py"), "0.3", "77000"] + extra,
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "no difference" in r.stdout
